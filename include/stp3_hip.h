@@ -1,0 +1,130 @@
+/*
+ * stp3_hip.h -- C ABI of libstp3hip.so: the MI355X (gfx950) implementation of ST-P3's
+ * LSS camera->BEV lifting hot path.
+ *
+ * Boundary.  The reference is pure Python; the operator boundary this library replaces is
+ *   - stp3/utils/geometry.py:299-330   VoxelsSumming.apply(x, geometry, ranks)
+ * and, one level up, the code that feeds it:
+ *   - stp3/models/stp3.py:186-201      STP3.get_geometry
+ *   - stp3/models/stp3.py:215-221      softmax(depth) (x) feature outer product
+ *   - stp3/models/stp3.py:226-301      STP3.projection_to_birds_eye_view (ego alignment,
+ *                                      voxel index, sort, per-voxel sum, discounted accumulate)
+ * The Python host (st-p3_amd/stp3_amd/ops.py) binds these entry points with ctypes and wraps
+ * them in torch.autograd.Functions; INTEGRATION.md shows the stub a maintainer of the reference
+ * would add.
+ *
+ * Conventions
+ *   - every pointer except `dims` is a DEVICE pointer into caller-owned memory that must stay
+ *     valid until the work enqueued on `stream` has completed; the library allocates nothing;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls only enqueue,
+ *     they never synchronise, so they can be captured into a hipGraph;
+ *   - return value: 0 on success, a negative hipError_t on a launch failure, or one of the
+ *     STP3_E* codes for rejected arguments.  Nothing throws, nothing exits;
+ *   - re-entrant: no global mutable state.
+ *
+ * Layouts ("pixel-major" = channels-last memory of the corresponding NCHW tensor)
+ *   pix   = (n*fH + h)*fW + w                      camera pixel index inside one (b,t) frame
+ *   feat  [B*T][N*fH*fW][C]     float32            encoder features   (stp3.py:208, x)
+ *   depth [B*T][N*fH*fW][D]     float32            depth logits / probabilities
+ *   vox   int32 voxel id = ix*(Y*Z) + iy*Z + iz, or -1 if the point falls outside the grid
+ *   bev   [B][T][C][X][Y]       float32            reference layout (stp3.py:230-232)
+ */
+#ifndef STP3_HIP_H
+#define STP3_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STP3_OK          0
+#define STP3_EINVAL   (-10001)  /* bad dimension / null pointer */
+#define STP3_EUNSUP   (-10002)  /* valid request this build does not support (e.g. Z != 1 for pooling) */
+#define STP3_ENOSPACE (-10003)  /* workspace too small */
+
+/* Problem shape.  P = N*D*fH*fW frustum points per (b,t); V = X*Y*Z voxels. */
+typedef struct stp3_lift_dims {
+    int32_t B, T, N;      /* batch, frames (time receptive field), cameras           */
+    int32_t D, fH, fW;    /* depth bins, feature-map height/width                     */
+    int32_t C;            /* feature channels (cfg.MODEL.ENCODER.OUT_CHANNELS)        */
+    int32_t X, Y, Z;      /* BEV grid (geometry.py:56-57)                             */
+} stp3_lift_dims;
+
+/* order of the voxel-id array written by stp3_voxel_index */
+#define STP3_VOX_REFERENCE  0   /* [B*T][N][D][fH][fW] -- the reference's flatten order (stp3.py:284) */
+#define STP3_VOX_PIXELMAJOR 1   /* [B*T][N*fH*fW][D]   -- what the pooling kernels consume           */
+
+/* library / build identification: returns a static string such as "stp3hip 0.1 gfx950" */
+const char* stp3_version(void);
+
+/*
+ * stp3_voxel_index -- frustum point -> voxel id, bit-exact with the reference's CPU arithmetic.
+ * Replaces stp3.py:192-198 (get_geometry), :270-277 (ego alignment), :287-289 (index),
+ * :239-255 (range mask + rank).  Float32, one rounding per operation, left-to-right
+ * ((m0*x + m1*y) + m2*z) + t, true division, truncation toward zero.
+ *
+ *   cam_m  [B*T*N][9]  R . K^-1 per camera (row-major 3x3), built by the host with torch CPU ops
+ *   cam_t  [B*T*N][3]  camera translation in the ego frame
+ *   ego_r  [B*T][9], ego_t [B*T][3]   pose_vec2mat(future_egomotion) (geometry.py:158-172);
+ *          frame k of sample b is mapped by ego[b][k], ego[b][k+1], ..., ego[b][T-2] in turn
+ *   xs [fW], ys [fH], ds [D]          the separable frustum (stp3.py:111-130)
+ *   bev_offset [3] = bev_start - bev_res/2 (float32), bev_res [3]
+ *   vox  [B*T*P] int32 out, in `order`
+ *   counts [B*T*V] int32 or NULL: if non-NULL it must be zero-filled by the caller; the kernel
+ *          adds the number of points per voxel (the histogram stp3_lift_plan_build consumes).
+ */
+int stp3_voxel_index(const stp3_lift_dims* dims,
+                     const float* cam_m, const float* cam_t,
+                     const float* ego_r, const float* ego_t,
+                     const float* xs, const float* ys, const float* ds,
+                     const float* bev_offset, const float* bev_res,
+                     int order, int32_t* vox, int32_t* counts, void* stream);
+
+/*
+ * Pooling plan: the geometry-only structure (per-voxel lists of contributing points) that the
+ * forward kernel consumes.  It replaces the reference's boolean mask + argsort (stp3.py:247-257)
+ * and depends only on the voxel ids, so it can be built on a side stream while the image
+ * encoder is running.
+ *
+ *   stp3_lift_plan_bytes : size of the plan buffer for `dims`
+ *   stp3_lift_plan_build : vox_pm = ids in STP3_VOX_PIXELMAJOR order, counts = the histogram
+ *                          written by stp3_voxel_index (consumed: left as per-voxel counts).
+ *                          `deterministic` != 0 additionally orders every voxel's list
+ *                          canonically, which makes the forward sums bit-reproducible run to
+ *                          run (lists longer than 4096 points keep their arrival order).
+ */
+int stp3_lift_plan_bytes(const stp3_lift_dims* dims, size_t* bytes);
+int stp3_lift_plan_build(const stp3_lift_dims* dims, const int32_t* vox_pm, int32_t* counts,
+                         void* plan, size_t plan_bytes, int deterministic, void* stream);
+
+/* stp3_depth_softmax -- softmax over the D depth bins of every pixel (stp3.py:215).
+ * logits, prob: [B*T][N*fH*fW][D] float32 (may alias). */
+int stp3_depth_softmax(const stp3_lift_dims* dims, const float* logits, float* prob, void* stream);
+
+/*
+ * stp3_lift_splat_fwd -- out[b][t] = sum_{k<=t} discount^(t-k) Pool_k,
+ *   Pool_k[c][v] = sum over points p of frame k with vox(p) == v of prob[p] * feat[pix(p)][c].
+ * Replaces stp3.py:216-221 (outer product, never materialised), geometry.py:302-318
+ * (VoxelsSumming.forward) and stp3.py:279-299 (scatter, discount, permute).  Requires Z == 1.
+ *   bev [B][T][C][X][Y] float32, fully overwritten (empty voxels get 0).
+ */
+int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const float* prob,
+                        const void* plan, float discount, float* bev, void* stream);
+
+/*
+ * stp3_lift_splat_bwd -- gradients of stp3_lift_splat_fwd composed with stp3_depth_softmax.
+ * Replaces autograd through stp3.py:215-301 and VoxelsSumming.backward (geometry.py:320-330).
+ *   grad_bev   [B][T][C][X][Y]      dL/d(out)
+ *   gacc       [B*T][V][C] float32  scratch (the discounted reverse accumulation of grad_bev)
+ *   grad_feat  [B*T][N*fH*fW][C], grad_logits [B*T][N*fH*fW][D]   outputs, fully overwritten
+ */
+int stp3_lift_splat_bwd(const stp3_lift_dims* dims, const float* grad_bev, const float* feat,
+                        const float* prob, const int32_t* vox_pm, float discount, float* gacc,
+                        float* grad_feat, float* grad_logits, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STP3_HIP_H */

@@ -1,0 +1,113 @@
+"""TEST INFRASTRUCTURE (container only) -- make the reference importable.
+
+/root/reference is pure Python but depends on packages that are not installed
+here (pyquaternion, nuscenes, timm, efficientnet_pytorch, torchvision, skimage,
+fvcore, pytorch_lightning).  ``install()`` registers minimal stand-ins in
+``sys.modules`` so that the reference's *own* first-party
+arithmetic can be executed unmodified and used to pin the restatement in
+``oracle/lift_oracle.py`` and to generate ``tests/golden`` fixtures
+(``oracle/make_golden.py``).
+
+Nothing under ``st-p3_amd/`` imports this file, and nothing that runs on the
+GPU box may: /root/reference does not exist there.
+"""
+import os
+import sys
+import types
+
+REFERENCE_ROOT = '/root/reference'
+
+
+def reference_available():
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, 'stp3'))
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def install(efficientnet_cls=None, resnet18_fn=None):
+    """Register stubs and put the reference on sys.path.  Idempotent."""
+    import numpy as np
+    import torch.nn as nn
+
+    if not reference_available():
+        raise RuntimeError('reference tree not present (expected only in the build container)')
+    if not hasattr(np, 'int'):
+        np.int = int  # encoder.py:28,84 uses the removed alias
+
+    class _Dummy:  # placeholder for names that are imported (and sometimes constructed at import
+        # time, tools.py:161-172) but never *used* on this path
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            raise RuntimeError('stubbed third-party symbol was called')
+
+    _mod('pyquaternion', Quaternion=_Dummy)
+    _mod('nuscenes')
+    _mod('nuscenes.utils')
+    _mod('nuscenes.utils.geometry_utils', transform_matrix=_Dummy)
+    _mod('nuscenes.utils.data_classes', LidarPointCloud=_Dummy, Box=_Dummy)
+    _mod('nuscenes.map_expansion')
+    _mod('nuscenes.map_expansion.map_api', NuScenesMap=_Dummy)
+    _mod('timm')
+    _mod('timm.models')
+    _mod('timm.models.layers', DropPath=nn.Identity)
+    _mod('skimage')
+    _mod('skimage.draw', polygon=_Dummy)
+
+    class _Normalize:  # network.py:33 subclasses it
+        def __init__(self, mean=None, std=None):
+            self.mean, self.std = mean, std
+
+    tv = _mod('torchvision')
+    tv.transforms = _mod('torchvision.transforms', Normalize=_Normalize, Compose=_Dummy, ToTensor=_Dummy,
+                         ToPILImage=_Dummy)
+    tv.models = _mod('torchvision.models')
+    tv.models.resnet = _mod('torchvision.models.resnet', resnet18=resnet18_fn or _Dummy)
+    _mod('efficientnet_pytorch', EfficientNet=efficientnet_cls or _Dummy)
+
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+
+
+def make_reference_lifter(final_dim=(224, 480), x_bound=(-50.0, 50.0, 0.5), y_bound=(-50.0, 50.0, 0.5),
+                          z_bound=(-10.0, 10.0, 20.0), d_bound=(2.0, 50.0, 1.0), downsample=8, out_channels=64,
+                          discount=0.5):
+    """An ``STP3`` instance with only the lifting attributes populated (no encoder).
+
+    Follows SURVEY.md Appendix C: built with ``__new__`` so that ``create_frustum``,
+    ``get_geometry`` and ``projection_to_birds_eye_view`` (reference
+    stp3/models/stp3.py:111-130, 186-201, 226-301) can be executed directly.
+    """
+    install()
+    import torch.nn as nn
+    from types import SimpleNamespace as NS
+    from stp3.models.stp3 import STP3
+    from stp3.utils.geometry import calculate_birds_eye_view_parameters
+
+    m = STP3.__new__(STP3)
+    nn.Module.__init__(m)
+    m.cfg = NS(
+        IMAGE=NS(FINAL_DIM=tuple(final_dim)),
+        LIFT=NS(X_BOUND=list(x_bound), Y_BOUND=list(y_bound), Z_BOUND=list(z_bound), D_BOUND=list(d_bound),
+                DISCOUNT=discount),
+        MODEL=NS(ENCODER=NS(DOWNSAMPLE=downsample, OUT_CHANNELS=out_channels, USE_DEPTH_DISTRIBUTION=True),
+                 TEMPORAL_MODEL=NS(INPUT_EGOPOSE=True)),
+        PLANNING=NS(ENABLED=False),
+    )
+    res, start, dim = calculate_birds_eye_view_parameters(m.cfg.LIFT.X_BOUND, m.cfg.LIFT.Y_BOUND, m.cfg.LIFT.Z_BOUND)
+    m.bev_resolution = nn.Parameter(res, requires_grad=False)
+    m.bev_start_position = nn.Parameter(start, requires_grad=False)
+    m.bev_dimension = nn.Parameter(dim, requires_grad=False)
+    m.encoder_downsample = downsample
+    m.encoder_out_channels = out_channels
+    m.frustum = m.create_frustum()
+    m.depth_channels = m.frustum.shape[0]
+    m.discount = discount
+    return m

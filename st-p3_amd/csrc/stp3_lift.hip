@@ -1,0 +1,573 @@
+// stp3_lift.hip -- gfx950 (MI355X / CDNA4) kernels + C ABI for ST-P3's LSS lift / voxel-pool path.
+//
+// Replaces (reference file:line) stp3/models/stp3.py:186-201 get_geometry, :215-221 depth
+// softmax (x) feature outer product, :226-301 projection_to_birds_eye_view and
+// stp3/utils/geometry.py:299-330 VoxelsSumming (forward and backward).  See include/stp3_hip.h
+// for the contract of every entry point and DESIGN.md for layouts / rooflines.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC
+// (-ffp-contract=off matters: the voxel-id arithmetic must round after every operation to be
+// bit-identical with the reference's torch-CPU evaluation; the pooling kernels ask for FMAs
+// explicitly with fmaf()).
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <stdint.h>
+
+#include "stp3_hip.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kSortCap = 4096;  // longest per-voxel list that is canonically ordered
+
+struct Dims {
+    int B, T, N, D, fH, fW, C, X, Y, Z;
+    int BT, NPIX, P, V;
+    int dbits;  // bits needed for a depth-bin index
+};
+
+inline int check_dims(const stp3_lift_dims* d, Dims* o) {
+    if (!d) return STP3_EINVAL;
+    if (d->B <= 0 || d->T <= 0 || d->N <= 0 || d->D <= 0 || d->fH <= 0 || d->fW <= 0 || d->C <= 0 || d->X <= 0 ||
+        d->Y <= 0 || d->Z <= 0)
+        return STP3_EINVAL;
+    o->B = d->B; o->T = d->T; o->N = d->N; o->D = d->D; o->fH = d->fH; o->fW = d->fW;
+    o->C = d->C; o->X = d->X; o->Y = d->Y; o->Z = d->Z;
+    o->BT = d->B * d->T;
+    int64_t npix = (int64_t)d->N * d->fH * d->fW;
+    int64_t p = npix * d->D;
+    int64_t v = (int64_t)d->X * d->Y * d->Z;
+    int db = 0;
+    while ((1 << db) < d->D) ++db;
+    if (p >= (1LL << 31) || v >= (1LL << 31) || (npix << db) >= (1LL << 31)) return STP3_EUNSUP;
+    if (npix * d->C >= (1LL << 31)) return STP3_EUNSUP;
+    o->NPIX = (int)npix; o->P = (int)p; o->V = (int)v; o->dbits = db;
+    return STP3_OK;
+}
+
+inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? STP3_OK : -(int)e;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1/K3: frustum point -> voxel id (bit-exact), optional per-voxel histogram
+// ------------------------------------------------------------------------------------------
+// q_i = ((m_i0*x + m_i1*y) + m_i2*z) + t_i, float32, one rounding per operation (no FMA): this
+// is what the reference's torch-CPU small-matrix bmm + in-place add evaluate to (stp3.py:197-198,
+// :275-276).  The pragma (and -ffp-contract=off on the command line) forbid contraction.
+__device__ __forceinline__ void affine3(const float* __restrict__ m, const float* __restrict__ t, float& x, float& y,
+                                        float& z) {
+#pragma clang fp contract(off)
+    float q0 = m[0] * x;
+    q0 = q0 + m[1] * y;
+    q0 = q0 + m[2] * z;
+    q0 = q0 + t[0];
+    float q1 = m[3] * x;
+    q1 = q1 + m[4] * y;
+    q1 = q1 + m[5] * z;
+    q1 = q1 + t[1];
+    float q2 = m[6] * x;
+    q2 = q2 + m[7] * y;
+    q2 = q2 + m[8] * z;
+    q2 = q2 + t[2];
+    x = q0; y = q1; z = q2;
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(256) void voxel_index_kernel(Dims dm, const float* __restrict__ cam_m,
+                                                          const float* __restrict__ cam_t,
+                                                          const float* __restrict__ ego_r,
+                                                          const float* __restrict__ ego_t, const float* __restrict__ xs,
+                                                          const float* __restrict__ ys, const float* __restrict__ ds,
+                                                          const float* __restrict__ bev_off,
+                                                          const float* __restrict__ bev_res, int32_t* __restrict__ vox,
+                                                          int32_t* __restrict__ counts) {
+#pragma clang fp contract(off)
+    const int bt = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= dm.P) return;
+    const int b = bt / dm.T, t = bt - b * dm.T;
+    int n, d, h, w;
+    if (ORDER == STP3_VOX_REFERENCE) {
+        w = idx % dm.fW;
+        int r = idx / dm.fW;
+        h = r % dm.fH;
+        r /= dm.fH;
+        d = r % dm.D;
+        n = r / dm.D;
+    } else {
+        d = idx % dm.D;
+        int pix = idx / dm.D;
+        w = pix % dm.fW;
+        int r = pix / dm.fW;
+        h = r % dm.fH;
+        n = r / dm.fH;
+    }
+    const float dep = ds[d];
+    float x = xs[w] * dep;  // stp3.py:195
+    float y = ys[h] * dep;
+    float z = dep;
+    const int cam = bt * dm.N + n;
+    affine3(cam_m + cam * 9, cam_t + cam * 3, x, y, z);  // stp3.py:197-198
+    for (int k = t; k < dm.T - 1; ++k) {                   // stp3.py:270-277
+        const int e = b * dm.T + k;
+        affine3(ego_r + e * 9, ego_t + e * 3, x, y, z);
+    }
+    // stp3.py:287-289: ((p - (start - res/2)) / res).long() -- true division, truncation
+    const float gx = (x - bev_off[0]) / bev_res[0];
+    const float gy = (y - bev_off[1]) / bev_res[1];
+    const float gz = (z - bev_off[2]) / bev_res[2];
+    // trunc(g) in [0, dim)  <=>  -1 < g < dim ; NaN fails both (stp3.py:239-246)
+    const bool keep = (gx > -1.0f) && (gx < (float)dm.X) && (gy > -1.0f) && (gy < (float)dm.Y) && (gz > -1.0f) &&
+                      (gz < (float)dm.Z);
+    int rank = -1;
+    if (keep) {
+        rank = (int)gx * (dm.Y * dm.Z) + (int)gy * dm.Z + (int)gz;  // stp3.py:251-255
+        if (counts) atomicAdd(counts + (size_t)bt * dm.V + rank, 1);
+    }
+    vox[(size_t)bt * dm.P + idx] = rank;
+}
+
+// ------------------------------------------------------------------------------------------
+// Pooling plan: offsets (exclusive scan of the histogram), fill, canonical ordering
+// ------------------------------------------------------------------------------------------
+struct PlanView {
+    int32_t* offsets;  // [BT][V+1]
+    int32_t* list;     // [BT][P]   entries (pix << dbits) | d, grouped by voxel
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+inline size_t plan_bytes(const Dims& dm) {
+    return align256((size_t)dm.BT * (dm.V + 1) * 4) + align256((size_t)dm.BT * dm.P * 4);
+}
+
+inline PlanView plan_view(const Dims& dm, void* base) {
+    PlanView pv;
+    char* p = (char*)base;
+    pv.offsets = (int32_t*)p;
+    p += align256((size_t)dm.BT * (dm.V + 1) * 4);
+    pv.list = (int32_t*)p;
+    return pv;
+}
+
+__global__ __launch_bounds__(1024) void plan_scan_kernel(int V, int32_t* __restrict__ counts,
+                                                         int32_t* __restrict__ offsets) {
+    __shared__ int wave_tot[16];
+    const int bt = blockIdx.x, tid = threadIdx.x;
+    int32_t* cnt = counts + (size_t)bt * V;
+    int32_t* off = offsets + (size_t)bt * (V + 1);
+    const int per = (V + 1023) / 1024;
+    const int lo = min(tid * per, V), hi = min(lo + per, V);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += cnt[i];
+    // inclusive scan inside the wave
+    int incl = sum;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int s = 1; s < 64; s <<= 1) {
+        int o = __shfl_up(incl, s);
+        if (lane >= s) incl += o;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < wv; ++i) base += wave_tot[i];
+    int run = base + incl - sum;
+    for (int i = lo; i < hi; ++i) {
+        const int c = cnt[i];
+        off[i] = run;
+        run += c;
+        cnt[i] = 0;  // becomes the fill cursor
+    }
+    if (tid == 1023) off[V] = run;
+}
+
+__global__ __launch_bounds__(256) void plan_fill_kernel(Dims dm, const int32_t* __restrict__ vox_pm,
+                                                        int32_t* __restrict__ cursor,
+                                                        const int32_t* __restrict__ offsets,
+                                                        int32_t* __restrict__ list) {
+    const int bt = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= dm.P) return;
+    const int v = vox_pm[(size_t)bt * dm.P + idx];
+    if (v < 0) return;
+    const int d = idx % dm.D, pix = idx / dm.D;
+    const int slot = offsets[(size_t)bt * (dm.V + 1) + v] + atomicAdd(cursor + (size_t)bt * dm.V + v, 1);
+    list[(size_t)bt * dm.P + slot] = (pix << dm.dbits) | d;
+}
+
+// One wave per voxel list: order the entries ascending so that the forward kernel adds every
+// voxel's contributions in one fixed order (n, h, w, d) regardless of how the atomics in
+// plan_fill_kernel interleaved.
+__global__ __launch_bounds__(128) void plan_sort_kernel(Dims dm, const int32_t* __restrict__ offsets,
+                                                        int32_t* __restrict__ list) {
+    __shared__ int32_t sbuf[2][kSortCap];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t total = (int64_t)dm.BT * dm.V;
+    const int64_t nwaves = (int64_t)gridDim.x * 2;
+    int32_t* s = sbuf[wv];
+    for (int64_t item = (int64_t)blockIdx.x * 2 + wv; item < total; item += nwaves) {
+        const int bt = (int)(item / dm.V), v = (int)(item - (int64_t)bt * dm.V);
+        const int32_t* off = offsets + (size_t)bt * (dm.V + 1) + v;
+        const int start = __builtin_amdgcn_readfirstlane(off[0]);
+        const int n = __builtin_amdgcn_readfirstlane(off[1]) - start;
+        if (n < 2 || n > kSortCap) continue;
+        int32_t* seg = list + (size_t)bt * dm.P + start;
+        if (n <= kWave) {
+            const int e = lane < n ? seg[lane] : INT_MAX;
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += (__builtin_amdgcn_readlane(e, j) < e) ? 1 : 0;
+            if (lane < n) seg[rank] = e;  // entries are distinct, so ranks are a permutation
+        } else {
+            int m = 128;
+            while (m < n) m <<= 1;
+            for (int i = lane; i < m; i += kWave) s[i] = i < n ? seg[i] : INT_MAX;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int k = 2; k <= m; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = lane; i < m; i += kWave) {
+                        const int p = i ^ j;
+                        if (p > i) {
+                            const int a = s[i], bb = s[p];
+                            const bool up = (i & k) == 0;
+                            if ((a > bb) == up) { s[i] = bb; s[p] = a; }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            for (int i = lane; i < n; i += kWave) seg[i] = s[i];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2a: softmax over depth bins, pixel-major rows of D floats (stp3.py:215)
+// ------------------------------------------------------------------------------------------
+template <int LPP>  // lanes per pixel, each lane owns 4 consecutive bins
+__global__ __launch_bounds__(256) void depth_softmax_kernel(int64_t npix_total, int D,
+                                                            const float* __restrict__ logits,
+                                                            float* __restrict__ prob) {
+    constexpr int PPB = 256 / LPP;
+    const int sub = threadIdx.x % LPP;
+    const int64_t pix = (int64_t)blockIdx.x * PPB + threadIdx.x / LPP;
+    const bool live = pix < npix_total;
+    const int e0 = sub * 4;
+    float v[4];
+    const float* row = logits + pix * D;
+    if (live && (D & 3) == 0 && e0 < D) {
+        const float4 q = *reinterpret_cast<const float4*>(row + e0);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (live && e0 + k < D) ? row[e0 + k] : -INFINITY;
+    }
+    float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+#pragma unroll
+    for (int s = LPP / 2; s > 0; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
+    float ex[4], sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ex[k] = (e0 + k < D) ? __expf(v[k] - mx) : 0.f;
+        sum += ex[k];
+    }
+#pragma unroll
+    for (int s = LPP / 2; s > 0; s >>= 1) sum += __shfl_xor(sum, s);
+    const float inv = 1.0f / sum;
+    float* orow = prob + pix * D;
+    if (live && (D & 3) == 0 && e0 < D) {
+        *reinterpret_cast<float4*>(orow + e0) = make_float4(ex[0] * inv, ex[1] * inv, ex[2] * inv, ex[3] * inv);
+    } else if (live) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (e0 + k < D) orow[e0 + k] = ex[k] * inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2+K4+K5: pull-style voxel pooling, lane = channel, fused discount accumulation over t
+// ------------------------------------------------------------------------------------------
+// A workgroup owns 64 consecutive voxels of one sample; wave w owns voxels [16w, 16w+16).
+// For every frame t each wave walks its voxels' point lists (canonical order), accumulating
+// prob[p] * feat[pix(p)][lane] with one coalesced 256-B row load per point; the running
+// bev*discount + pool_t lives in an LDS tile [voxel][channel] that is written out transposed,
+// i.e. as 256-B coalesced rows of the reference's [C][X*Y] planes.
+constexpr int kTileV = 64;
+constexpr int kTilePad = 65;
+
+__global__ __launch_bounds__(256) void lift_splat_fwd_kernel(Dims dm, const float* __restrict__ feat,
+                                                             const float* __restrict__ prob,
+                                                             const int32_t* __restrict__ offsets,
+                                                             const int32_t* __restrict__ list, float discount,
+                                                             float* __restrict__ bev) {
+    __shared__ float tile[kTileV * kTilePad];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int v0 = blockIdx.x * kTileV;
+    const bool chan = lane < dm.C;
+    const int dmask = (1 << dm.dbits) - 1;
+
+    for (int i = threadIdx.x; i < kTileV * kTilePad; i += 256) tile[i] = 0.f;
+    __syncthreads();
+
+    for (int t = 0; t < dm.T; ++t) {
+        const int bt = b * dm.T + t;
+        const float* fbt = feat + (size_t)bt * dm.NPIX * dm.C;
+        const float* pbt = prob + (size_t)bt * dm.NPIX * dm.D;
+        const int32_t* obt = offsets + (size_t)bt * (dm.V + 1);
+        const int32_t* lbt = list + (size_t)bt * dm.P;
+        for (int vi = 0; vi < 16; ++vi) {
+            const int vl = wv * 16 + vi;
+            const int v = v0 + vl;
+            float acc = 0.f;
+            if (v < dm.V) {
+                const int start = __builtin_amdgcn_readfirstlane(obt[v]);
+                const int end = __builtin_amdgcn_readfirstlane(obt[v + 1]);
+                for (int base = start; base < end; base += kWave) {
+                    const int cnt = min(kWave, end - base);
+                    int roff = 0;
+                    float pr = 0.f;
+                    if (lane < cnt) {
+                        const int e = lbt[base + lane];
+                        const int pix = e >> dm.dbits;
+                        pr = pbt[pix * dm.D + (e & dmask)];
+                        roff = pix * dm.C;
+                    }
+                    int j = 0;
+                    for (; j + 8 <= cnt; j += 8) {
+                        float f[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int r = __builtin_amdgcn_readlane(roff, j + u);
+                            f[u] = chan ? fbt[r + lane] : 0.f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            acc = fmaf(__builtin_amdgcn_readlane(pr, j + u), f[u], acc);
+                    }
+                    for (; j < cnt; ++j) {
+                        const int r = __builtin_amdgcn_readlane(roff, j);
+                        const float f = chan ? fbt[r + lane] : 0.f;
+                        acc = fmaf(__builtin_amdgcn_readlane(pr, j), f, acc);
+                    }
+                }
+            }
+            // stp3.py:296  bev_feature = bev_feature * discount + tmp_bev_feature
+            float* cell = tile + vl * kTilePad + lane;
+            *cell = *cell * discount + acc;
+        }
+        __syncthreads();
+        // transposed store: lane = voxel, 16 channel planes per wave, 256-B rows
+        const int v = v0 + lane;
+        if (v < dm.V) {
+            for (int ci = 0; ci < 16; ++ci) {
+                const int c = wv * 16 + ci;
+                if (c < dm.C) bev[((size_t)bt * dm.C + c) * dm.V + v] = tile[lane * kTilePad + c];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K6: backward
+// ------------------------------------------------------------------------------------------
+// (a) G_t = sum_{t'>=t} discount^(t'-t) dL/dout[b][t'], transposed to voxel-major [V][C] so that
+//     the gather in (b) reads one 256-B row per point.
+__global__ __launch_bounds__(256) void bev_grad_accumulate_kernel(Dims dm, const float* __restrict__ grad_bev,
+                                                                  float discount, float* __restrict__ gacc) {
+    __shared__ float stage[64 * kTilePad];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int v0 = blockIdx.x * kTileV;
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int t = dm.T - 1; t >= 0; --t) {
+        const int bt = b * dm.T + t;
+        const int v = v0 + lane;
+        for (int ci = 0; ci < 16; ++ci) {
+            const int c = wv * 16 + ci;
+            float g = 0.f;
+            if (c < dm.C && v < dm.V) g = grad_bev[((size_t)bt * dm.C + c) * dm.V + v];
+            stage[c * kTilePad + lane] = g;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int vl = wv * 16 + i;
+            acc[i] = acc[i] * discount + stage[lane * kTilePad + vl];
+            if (v0 + vl < dm.V && lane < dm.C) gacc[((size_t)bt * dm.V + v0 + vl) * dm.C + lane] = acc[i];
+        }
+        __syncthreads();
+    }
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+
+// sum over the 64 lanes of a wave; the total is returned in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_f<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x141, 0xF>(v);  // row_half_mirror
+    v += dpp_f<0x140, 0xF>(v);  // row_mirror
+    v += dpp_f<0x142, 0xA>(v);  // row_bcast15 -> rows 1,3
+    v += dpp_f<0x143, 0xC>(v);  // row_bcast31 -> rows 2,3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// (b) one wave per camera pixel, lane = channel for feat / dfeat and lane = depth bin for
+//     prob / vox / dprob.  dprob[d] = <feat, G[v_d]>, dfeat += prob[d] * G[v_d], then the softmax
+//     backward dlogit = prob * (dprob - sum_d prob*dprob) fused in the epilogue.
+__global__ __launch_bounds__(256) void lift_splat_bwd_kernel(Dims dm, const float* __restrict__ gacc,
+                                                             const float* __restrict__ feat,
+                                                             const float* __restrict__ prob,
+                                                             const int32_t* __restrict__ vox_pm,
+                                                             float* __restrict__ grad_feat,
+                                                             float* __restrict__ grad_logits) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t gp = (int64_t)blockIdx.x * 4 + wv;  // global pixel = bt * NPIX + pix
+    if (gp >= (int64_t)dm.BT * dm.NPIX) return;
+    const int bt = (int)(gp / dm.NPIX);
+    const float* g_bt = gacc + (size_t)bt * dm.V * dm.C;
+    const bool chan = lane < dm.C;
+    const bool bin = lane < dm.D;
+    const float f = chan ? feat[gp * dm.C + lane] : 0.f;
+    const float pr = bin ? prob[gp * dm.D + lane] : 0.f;
+    const int vx = bin ? vox_pm[gp * dm.D + lane] : -1;
+    float dfeat = 0.f, dprob = 0.f;
+#pragma unroll 4
+    for (int d = 0; d < dm.D; ++d) {
+        const int v = __builtin_amdgcn_readlane(vx, d);
+        const float p = __builtin_amdgcn_readlane(pr, d);
+        const int row = v < 0 ? 0 : v;
+        float g = chan ? g_bt[(size_t)row * dm.C + lane] : 0.f;
+        g = v < 0 ? 0.f : g;
+        dfeat = fmaf(p, g, dfeat);
+        const float s = wave_sum(f * g);
+        dprob = (lane == d) ? s : dprob;
+    }
+    const float sdot = wave_sum(pr * dprob);
+    if (chan) grad_feat[gp * dm.C + lane] = dfeat;
+    if (bin) grad_logits[gp * dm.D + lane] = pr * (dprob - sdot);
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+const char* stp3_version(void) { return "stp3hip 0.1 gfx950"; }
+
+int stp3_voxel_index(const stp3_lift_dims* dims, const float* cam_m, const float* cam_t, const float* ego_r,
+                     const float* ego_t, const float* xs, const float* ys, const float* ds, const float* bev_offset,
+                     const float* bev_res, int order, int32_t* vox, int32_t* counts, void* stream) {
+    Dims dm;
+    int rc = check_dims(dims, &dm);
+    if (rc) return rc;
+    if (!cam_m || !cam_t || !ego_r || !ego_t || !xs || !ys || !ds || !bev_offset || !bev_res || !vox)
+        return STP3_EINVAL;
+    if (order != STP3_VOX_REFERENCE && order != STP3_VOX_PIXELMAJOR) return STP3_EINVAL;
+    dim3 grid((dm.P + 255) / 256, dm.BT);
+    hipStream_t s = (hipStream_t)stream;
+    if (order == STP3_VOX_REFERENCE)
+        hipLaunchKernelGGL(voxel_index_kernel<STP3_VOX_REFERENCE>, grid, dim3(256), 0, s, dm, cam_m, cam_t, ego_r,
+                           ego_t, xs, ys, ds, bev_offset, bev_res, vox, counts);
+    else
+        hipLaunchKernelGGL(voxel_index_kernel<STP3_VOX_PIXELMAJOR>, grid, dim3(256), 0, s, dm, cam_m, cam_t, ego_r,
+                           ego_t, xs, ys, ds, bev_offset, bev_res, vox, counts);
+    return launch_status();
+}
+
+int stp3_lift_plan_bytes(const stp3_lift_dims* dims, size_t* bytes) {
+    Dims dm;
+    int rc = check_dims(dims, &dm);
+    if (rc) return rc;
+    if (!bytes) return STP3_EINVAL;
+    *bytes = plan_bytes(dm);
+    return STP3_OK;
+}
+
+int stp3_lift_plan_build(const stp3_lift_dims* dims, const int32_t* vox_pm, int32_t* counts, void* plan,
+                         size_t plan_size, int deterministic, void* stream) {
+    Dims dm;
+    int rc = check_dims(dims, &dm);
+    if (rc) return rc;
+    if (!vox_pm || !counts || !plan) return STP3_EINVAL;
+    if (plan_size < plan_bytes(dm)) return STP3_ENOSPACE;
+    PlanView pv = plan_view(dm, plan);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(dm.BT), dim3(1024), 0, s, dm.V, counts, pv.offsets);
+    hipLaunchKernelGGL(plan_fill_kernel, dim3((dm.P + 255) / 256, dm.BT), dim3(256), 0, s, dm, vox_pm, counts,
+                       pv.offsets, pv.list);
+    if (deterministic) {
+        int64_t items = (int64_t)dm.BT * dm.V;
+        int blocks = (int)((items + 1) / 2 < 4096 ? (items + 1) / 2 : 4096);
+        hipLaunchKernelGGL(plan_sort_kernel, dim3(blocks), dim3(128), 0, s, dm, pv.offsets, pv.list);
+    }
+    return launch_status();
+}
+
+int stp3_depth_softmax(const stp3_lift_dims* dims, const float* logits, float* prob, void* stream) {
+    Dims dm;
+    int rc = check_dims(dims, &dm);
+    if (rc) return rc;
+    if (!logits || !prob) return STP3_EINVAL;
+    if (dm.D > 128) return STP3_EUNSUP;
+    const int64_t npix = (int64_t)dm.BT * dm.NPIX;
+    hipStream_t s = (hipStream_t)stream;
+    if (dm.D <= 32) {
+        hipLaunchKernelGGL(depth_softmax_kernel<8>, dim3((unsigned)((npix + 31) / 32)), dim3(256), 0, s, npix, dm.D,
+                           logits, prob);
+    } else if (dm.D <= 64) {
+        hipLaunchKernelGGL(depth_softmax_kernel<16>, dim3((unsigned)((npix + 15) / 16)), dim3(256), 0, s, npix, dm.D,
+                           logits, prob);
+    } else {
+        hipLaunchKernelGGL(depth_softmax_kernel<32>, dim3((unsigned)((npix + 7) / 8)), dim3(256), 0, s, npix, dm.D,
+                           logits, prob);
+    }
+    return launch_status();
+}
+
+int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const float* prob, const void* plan,
+                        float discount, float* bev, void* stream) {
+    Dims dm;
+    int rc = check_dims(dims, &dm);
+    if (rc) return rc;
+    if (!feat || !prob || !plan || !bev) return STP3_EINVAL;
+    if (dm.Z != 1 || dm.C > 64) return STP3_EUNSUP;  // stp3.py:297-299 squeezes Z; lane = channel
+    PlanView pv = plan_view(dm, const_cast<void*>(plan));
+    dim3 grid((dm.V + kTileV - 1) / kTileV, dm.B);
+    hipLaunchKernelGGL(lift_splat_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dm, feat, prob, pv.offsets,
+                       pv.list, discount, bev);
+    return launch_status();
+}
+
+int stp3_lift_splat_bwd(const stp3_lift_dims* dims, const float* grad_bev, const float* feat, const float* prob,
+                        const int32_t* vox_pm, float discount, float* gacc, float* grad_feat, float* grad_logits,
+                        void* stream) {
+    Dims dm;
+    int rc = check_dims(dims, &dm);
+    if (rc) return rc;
+    if (!grad_bev || !feat || !prob || !vox_pm || !gacc || !grad_feat || !grad_logits) return STP3_EINVAL;
+    if (dm.Z != 1 || dm.C > 64 || dm.D > 64) return STP3_EUNSUP;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bev_grad_accumulate_kernel, dim3((dm.V + kTileV - 1) / kTileV, dm.B), dim3(256), 0, s, dm,
+                       grad_bev, discount, gacc);
+    const int64_t npix = (int64_t)dm.BT * dm.NPIX;
+    hipLaunchKernelGGL(lift_splat_bwd_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, dm, gacc, feat, prob,
+                       vox_pm, grad_feat, grad_logits);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+"""ctypes binding of libstp3hip.so (the C ABI declared in include/stp3_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback for the operators it
+exports.  ``lib()`` raises if the shared object is missing or lacks a symbol, and every
+operator in ``stp3_amd.ops`` raises if it is handed non-GPU tensors.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libstp3hip.so')
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_size_t = ctypes.c_size_t
+
+
+class LiftDims(ctypes.Structure):
+    """struct stp3_lift_dims (include/stp3_hip.h)."""
+    _fields_ = [(k, ctypes.c_int32) for k in ('B', 'T', 'N', 'D', 'fH', 'fW', 'C', 'X', 'Y', 'Z')]
+
+    @property
+    def BT(self):
+        return self.B * self.T
+
+    @property
+    def NPIX(self):
+        return self.N * self.fH * self.fW
+
+    @property
+    def P(self):
+        return self.NPIX * self.D
+
+    @property
+    def V(self):
+        return self.X * self.Y * self.Z
+
+
+VOX_REFERENCE = 0
+VOX_PIXELMAJOR = 1
+
+_DIMS_P = ctypes.POINTER(LiftDims)
+
+# name -> (restype, argtypes); mirrors include/stp3_hip.h one to one
+SIGNATURES = {
+    'stp3_version': (ctypes.c_char_p, []),
+    'stp3_voxel_index': (c_int, [_DIMS_P] + [c_void_p] * 9 + [c_int, c_void_p, c_void_p, c_void_p]),
+    'stp3_lift_plan_bytes': (c_int, [_DIMS_P, ctypes.POINTER(c_size_t)]),
+    'stp3_lift_plan_build': (c_int, [_DIMS_P, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    'stp3_depth_softmax': (c_int, [_DIMS_P, c_void_p, c_void_p, c_void_p]),
+    'stp3_lift_splat_fwd': (c_int, [_DIMS_P, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    'stp3_lift_splat_bwd': (c_int, [_DIMS_P] + [c_void_p] * 4 + [c_float] + [c_void_p] * 4),
+}
+
+_lib = None
+
+
+class Stp3HipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libstp3hip.so once; fail loudly if it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Stp3HipError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'(or `make -C st-p3_amd/csrc`).  There is no fallback path.')
+    handle = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise Stp3HipError(f'libstp3hip.so does not export {name}') from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return _lib
+
+
+_ERRORS = {-10001: 'STP3_EINVAL (bad dimension / null pointer)',
+           -10002: 'STP3_EUNSUP (unsupported configuration)',
+           -10003: 'STP3_ENOSPACE (workspace too small)'}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise Stp3HipError(f'{what} failed: {_ERRORS.get(rc, f"hipError {-rc}")}')

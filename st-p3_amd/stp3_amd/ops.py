@@ -1,0 +1,210 @@
+"""Host-side operators of the lift / voxel-pool path: thin wrappers that hand raw device pointers
+to libstp3hip.so (include/stp3_hip.h) on the caller's current HIP stream.
+
+Mirrors the reference's operator surface for this path:
+  * ``lift_matrices``      -- the tiny host-side part of ``STP3.get_geometry`` (stp3/models/stp3.py:189,196)
+                              and ``pose_vec2mat`` (stp3/utils/geometry.py:124-172)
+  * ``LiftPlan.build``     -- ``get_geometry`` + ego alignment + index + mask + sort
+                              (stp3.py:192-198, 270-277, 287-289, 239-257), geometry only
+  * ``lift_splat``         -- softmax(depth) (x) feat, ``VoxelsSumming`` and the discounted
+                              accumulation (stp3.py:215-221, geometry.py:299-330, stp3.py:279-299),
+                              differentiable (``torch.autograd.Function``)
+PyTorch is used for device memory, streams and autograd plumbing only.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import LiftDims, VOX_PIXELMAJOR, VOX_REFERENCE, check
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise _lib.Stp3HipError('stp3_amd operators run on the GPU only (got a CPU tensor); there is no fallback')
+
+
+def make_dims(B, T, N, D, fH, fW, C, X, Y, Z):
+    return LiftDims(int(B), int(T), int(N), int(D), int(fH), int(fW), int(C), int(X), int(Y), int(Z))
+
+
+# ----------------------------------------------------------------------------------------------
+# host-side constants
+# ----------------------------------------------------------------------------------------------
+def lift_matrices(intrinsics, extrinsics, future_egomotion):
+    """Camera and ego matrices, built on the HOST with the same torch CPU ops the reference uses,
+    so that libm / LAPACK differences of a device implementation can never move a point across a
+    voxel border (hard part 2).
+
+    intrinsics (B,S,N,3,3), extrinsics (B,S,N,4,4), future_egomotion (B,S,6): CPU or GPU tensors
+    (GPU tensors are copied back; these are a few hundred floats).
+    Returns float32 CPU tensors cam_m (B*S*N,9), cam_t (B*S*N,3), ego_r (B*S,9), ego_t (B*S,3).
+    """
+    intr = intrinsics.detach().float().cpu()
+    extr = extrinsics.detach().float().cpu()
+    ego = future_egomotion.detach().float().cpu()
+    # stp3.py:189,196  combined_transformation = rotation.matmul(torch.inverse(intrinsics))
+    cam_m = extr[..., :3, :3].matmul(torch.inverse(intr)).reshape(-1, 9).contiguous()
+    cam_t = extr[..., :3, 3].reshape(-1, 3).contiguous()
+    # geometry.py:124-155  R = X(rx) . Y(ry) . Z(rz)
+    ang = ego[..., 3:].reshape(-1, 3)
+    rx, ry, rz = ang[:, 0], ang[:, 1], ang[:, 2]
+    zero, one = torch.zeros_like(rz), torch.ones_like(rz)
+    cz, sz = torch.cos(rz), torch.sin(rz)
+    zmat = torch.stack([cz, -sz, zero, sz, cz, zero, zero, zero, one], dim=1).view(-1, 3, 3)
+    cy, sy = torch.cos(ry), torch.sin(ry)
+    ymat = torch.stack([cy, zero, sy, zero, one, zero, -sy, zero, cy], dim=1).view(-1, 3, 3)
+    cx, sx = torch.cos(rx), torch.sin(rx)
+    xmat = torch.stack([one, zero, zero, zero, cx, -sx, zero, sx, cx], dim=1).view(-1, 3, 3)
+    ego_r = xmat.bmm(ymat).bmm(zmat).reshape(-1, 9).contiguous()
+    ego_t = ego[..., :3].reshape(-1, 3).contiguous()
+    return cam_m, cam_t, ego_r, ego_t
+
+
+def separable_frustum(frustum):
+    """(D,fH,fW,3) frustum parameter (stp3.py:111-130) -> xs (fW), ys (fH), ds (D).
+    ``create_frustum`` only ever builds separable grids; anything else is rejected."""
+    fr = frustum.detach().float().cpu()
+    xs, ys, ds = fr[0, 0, :, 0].clone(), fr[0, :, 0, 1].clone(), fr[:, 0, 0, 2].clone()
+    d_, fh, fw, _ = fr.shape
+    ok = (torch.equal(fr[..., 0], xs.view(1, 1, fw).expand(d_, fh, fw))
+          and torch.equal(fr[..., 1], ys.view(1, fh, 1).expand(d_, fh, fw))
+          and torch.equal(fr[..., 2], ds.view(d_, 1, 1).expand(d_, fh, fw)))
+    if not ok:
+        raise _lib.Stp3HipError('frustum is not separable into (x[w], y[h], depth[d]); unsupported')
+    return xs, ys, ds
+
+
+class LiftGrid:
+    """Device-resident constants of one model: frustum axes and BEV grid (uploaded once)."""
+
+    def __init__(self, frustum, bev_resolution, bev_start_position, bev_dimension, device):
+        xs, ys, ds = separable_frustum(frustum)
+        self.D, self.fH, self.fW = ds.numel(), ys.numel(), xs.numel()
+        res = bev_resolution.detach().float().cpu()
+        start = bev_start_position.detach().float().cpu()
+        # stp3.py:288  (bev_start_position - bev_resolution / 2.0), in float32
+        off = start - res / 2.0
+        self.X, self.Y, self.Z = (int(v) for v in bev_dimension.detach().cpu().tolist())
+        self.device = torch.device(device)
+        self.consts = torch.cat([xs, ys, ds, off, res]).to(self.device)
+        o = 0
+        self.xs = self.consts[o:o + self.fW]; o += self.fW
+        self.ys = self.consts[o:o + self.fH]; o += self.fH
+        self.ds = self.consts[o:o + self.D]; o += self.D
+        self.off = self.consts[o:o + 3]; o += 3
+        self.res = self.consts[o:o + 3]
+
+
+def voxel_index(grid, dims, cam_m, cam_t, ego_r, ego_t, order=VOX_REFERENCE, counts=None):
+    """Raw ``stp3_voxel_index``: int32 voxel ids [B*T, P] in ``order``; cam/ego matrices are
+    device float32 tensors laid out as ``lift_matrices`` returns them."""
+    _need_gpu(cam_m, cam_t, ego_r, ego_t)
+    vox = torch.empty(dims.BT, dims.P, dtype=torch.int32, device=cam_m.device)
+    rc = _lib.lib().stp3_voxel_index(ctypes.byref(dims), _ptr(cam_m), _ptr(cam_t), _ptr(ego_r), _ptr(ego_t),
+                                     _ptr(grid.xs), _ptr(grid.ys), _ptr(grid.ds), _ptr(grid.off), _ptr(grid.res),
+                                     int(order), _ptr(vox), _ptr(counts) if counts is not None else None, _stream())
+    check(rc, 'stp3_voxel_index')
+    return vox
+
+
+class LiftPlan:
+    """Geometry-only pooling plan for one batch: voxel ids (pixel-major) + per-voxel point lists.
+
+    Built from camera/ego poses alone, i.e. independent of the image encoder -- ``build`` can be
+    issued on a side stream while the encoder runs (see ``STP3.forward``).
+    """
+
+    def __init__(self, dims, vox_pm, plan, counts):
+        self.dims, self.vox_pm, self.plan, self.counts = dims, vox_pm, plan, counts
+
+    @staticmethod
+    def build(grid, intrinsics, extrinsics, future_egomotion, channels, deterministic=True):
+        b, s, n = intrinsics.shape[:3]
+        dims = make_dims(b, s, n, grid.D, grid.fH, grid.fW, channels, grid.X, grid.Y, grid.Z)
+        mats = torch.cat([m.reshape(-1) for m in lift_matrices(intrinsics, extrinsics, future_egomotion)])
+        mats = mats.to(grid.device, non_blocking=True)
+        n_cam = b * s * n
+        cam_m = mats[:n_cam * 9]
+        cam_t = mats[n_cam * 9:n_cam * 12]
+        ego_r = mats[n_cam * 12:n_cam * 12 + b * s * 9]
+        ego_t = mats[n_cam * 12 + b * s * 9:]
+        counts = torch.zeros(dims.BT, dims.V, dtype=torch.int32, device=grid.device)
+        vox_pm = voxel_index(grid, dims, cam_m, cam_t, ego_r, ego_t, VOX_PIXELMAJOR, counts)
+        nbytes = ctypes.c_size_t()
+        check(_lib.lib().stp3_lift_plan_bytes(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_lift_plan_bytes')
+        plan = torch.empty(nbytes.value, dtype=torch.uint8, device=grid.device)
+        rc = _lib.lib().stp3_lift_plan_build(ctypes.byref(dims), _ptr(vox_pm), _ptr(counts), _ptr(plan),
+                                             ctypes.c_size_t(nbytes.value), int(bool(deterministic)), _stream())
+        check(rc, 'stp3_lift_plan_build')
+        return LiftPlan(dims, vox_pm, plan, counts)
+
+    def offsets(self):
+        """[BT, V+1] int32 view of the plan's offsets (for tests)."""
+        d = self.dims
+        return self.plan[:d.BT * (d.V + 1) * 4].view(torch.int32).view(d.BT, d.V + 1)
+
+
+def depth_softmax(dims, logits_pm):
+    _need_gpu(logits_pm)
+    prob = torch.empty_like(logits_pm)
+    check(_lib.lib().stp3_depth_softmax(ctypes.byref(dims), _ptr(logits_pm), _ptr(prob), _stream()),
+          'stp3_depth_softmax')
+    return prob
+
+
+class _LiftSplat(torch.autograd.Function):
+    """feat_pm [BT,NPIX,C], logits_pm [BT,NPIX,D] (float32, contiguous) -> bev [B,T,C,X,Y]."""
+
+    @staticmethod
+    def forward(ctx, feat_pm, logits_pm, lift_plan, discount):
+        _need_gpu(feat_pm, logits_pm)
+        d = lift_plan.dims
+        feat_pm = feat_pm.contiguous()
+        logits_pm = logits_pm.contiguous()
+        assert feat_pm.dtype == torch.float32 and logits_pm.dtype == torch.float32
+        assert feat_pm.shape == (d.BT, d.NPIX, d.C) and logits_pm.shape == (d.BT, d.NPIX, d.D)
+        prob = depth_softmax(d, logits_pm)
+        bev = torch.empty(d.B, d.T, d.C, d.X, d.Y, dtype=torch.float32, device=feat_pm.device)
+        rc = _lib.lib().stp3_lift_splat_fwd(ctypes.byref(d), _ptr(feat_pm), _ptr(prob), _ptr(lift_plan.plan),
+                                            ctypes.c_float(discount), _ptr(bev), _stream())
+        check(rc, 'stp3_lift_splat_fwd')
+        ctx.save_for_backward(feat_pm, prob)
+        ctx.lift_plan = lift_plan
+        ctx.discount = discount
+        return bev
+
+    @staticmethod
+    def backward(ctx, grad_bev):
+        feat_pm, prob = ctx.saved_tensors
+        d = ctx.lift_plan.dims
+        grad_bev = grad_bev.contiguous().float()
+        gacc = torch.empty(d.BT, d.V, d.C, dtype=torch.float32, device=grad_bev.device)
+        grad_feat = torch.empty_like(feat_pm)
+        grad_logits = torch.empty_like(prob)
+        rc = _lib.lib().stp3_lift_splat_bwd(ctypes.byref(d), _ptr(grad_bev), _ptr(feat_pm), _ptr(prob),
+                                            _ptr(ctx.lift_plan.vox_pm), ctypes.c_float(ctx.discount), _ptr(gacc),
+                                            _ptr(grad_feat), _ptr(grad_logits), _stream())
+        check(rc, 'stp3_lift_splat_bwd')
+        return grad_feat, grad_logits, None, None
+
+
+def lift_splat(feat, depth_logits, lift_plan, discount):
+    """Differentiable lift + voxel pool.
+
+    feat (B,T,N,C,fH,fW) and depth_logits (B,T,N,D,fH,fW) in any memory format (channels-last
+    memory makes the re-layout free); returns the BEV features (B,T,C,X,Y) float32 in the
+    reference's layout (stp3.py:230-232, always float32 even under autocast)."""
+    d = lift_plan.dims
+    feat_pm = feat.float().permute(0, 1, 2, 4, 5, 3).reshape(d.BT, d.NPIX, d.C)
+    logits_pm = depth_logits.float().permute(0, 1, 2, 4, 5, 3).reshape(d.BT, d.NPIX, d.D)
+    return _LiftSplat.apply(feat_pm, logits_pm, lift_plan, float(discount))

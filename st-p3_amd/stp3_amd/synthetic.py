@@ -1,0 +1,140 @@
+"""Synthetic nuScenes-shaped inputs for the LSS camera->BEV path.
+
+There is no dataset in this environment, so tests, ``bench.py`` and the golden
+generator all draw their inputs from here.  The batch *schema* follows what the
+reference's ``TrainingModule.shared_step`` consumes (reference
+``stp3/trainer.py:102-108, 257-347``; produced by
+``stp3/datas/NuscenesData.py:569-646``):
+
+    image            (B, S, N, 3, H, W) float32   ImageNet-normalised pixels
+    intrinsics       (B, S, N, 3, 3)    float32   upper-triangular K
+    extrinsics       (B, S, N, 4, 4)    float32   camera -> ego
+    future_egomotion (B, S, 6)          float32   (tx,ty,tz,rx,ry,rz) frame t -> t+1
+    segmentation / pedestrian (B, S, 1, X, Y) int64, hdmap (B, S, 2, X, Y) int64
+    gt_trajectory, command, sample_trajectory, target_point (unused on this path)
+
+The rig is a nuScenes-like 6-camera ring: yaw
+{55, 0, -55, 110, 180, -110} deg, cameras 1.5 m from the origin at z = 1.5 m,
+intrinsics scaled by the reference's resize 0.3 / top-crop 46
+(``stp3/config.py:63-64``), with small random roll/pitch/yaw so that points do
+not sit exactly on voxel borders (generic case).  ``axis_aligned=True`` removes
+the jitter: the border-degenerate stress case (CARLA's rig is axis aligned,
+``stp3/datas/CarlaData.py:310-313``).
+
+Everything is generated on the CPU with an explicit ``torch.Generator`` so the
+same seed gives the same bits on every box.
+"""
+import math
+
+import torch
+
+CAM_YAWS_DEG = (55.0, 0.0, -55.0, 110.0, 180.0, -110.0)
+
+
+def _rot_z(a):
+    c, s = math.cos(a), math.sin(a)
+    return torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float64)
+
+
+def _rot_y(a):
+    c, s = math.cos(a), math.sin(a)
+    return torch.tensor([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]], dtype=torch.float64)
+
+
+def _rot_x(a):
+    c, s = math.cos(a), math.sin(a)
+    return torch.tensor([[1.0, 0.0, 0.0], [0.0, c, -s], [0.0, s, c]], dtype=torch.float64)
+
+
+# camera frame (z forward, x right, y down) -> ego frame (x forward, y left, z up)
+_CAM_TO_EGO = torch.tensor([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]], dtype=torch.float64)
+
+
+def make_rig(batch, seq, n_cams=6, final_dim=(224, 480), seed=0, axis_aligned=False,
+             resize_scale=0.3, top_crop=46.0):
+    """Return (intrinsics (B,S,N,3,3), extrinsics (B,S,N,4,4), future_egomotion (B,S,6))."""
+    g = torch.Generator().manual_seed(seed)
+    h, w = final_dim
+    # 224x480 corresponds to the reference's scale 0.3 / crop 46 of 900x1600; other
+    # resolutions keep the same field of view by scaling with the width.
+    scale = resize_scale * (w / 480.0)
+    fx = 1266.0 * scale
+    cx = 816.0 * scale
+    cy = 491.0 * scale - top_crop * (h / 224.0)
+
+    intr = torch.zeros(batch, seq, n_cams, 3, 3, dtype=torch.float64)
+    extr = torch.zeros(batch, seq, n_cams, 4, 4, dtype=torch.float64)
+    for b in range(batch):
+        for s in range(seq):
+            for n in range(n_cams):
+                jit = torch.zeros(3) if axis_aligned else torch.randn(3, generator=g) * 3.0
+                k = torch.tensor([[fx + jit[0].item(), 0.0, cx + jit[1].item()],
+                                  [0.0, fx + jit[0].item(), cy + jit[2].item()],
+                                  [0.0, 0.0, 1.0]], dtype=torch.float64)
+                intr[b, s, n] = k
+                yaw = math.radians(CAM_YAWS_DEG[n % len(CAM_YAWS_DEG)])
+                if axis_aligned:
+                    # snap the ring to the axes: 0 / +-90 / 180 deg
+                    yaw = round(yaw / (math.pi / 2)) * (math.pi / 2)
+                    rpy = torch.zeros(3)
+                    dt = torch.zeros(3)
+                else:
+                    rpy = torch.randn(3, generator=g) * 0.03
+                    dt = torch.randn(3, generator=g) * 0.05
+                rot = _rot_z(yaw + rpy[2].item()) @ _rot_y(rpy[1].item()) @ _rot_x(rpy[0].item()) @ _CAM_TO_EGO
+                pos = torch.tensor([1.5 * math.cos(yaw), 1.5 * math.sin(yaw), 1.5], dtype=torch.float64)
+                extr[b, s, n, :3, :3] = rot
+                extr[b, s, n, :3, 3] = pos + dt.double()
+                extr[b, s, n, 3, 3] = 1.0
+
+    ego = torch.zeros(batch, seq, 6, dtype=torch.float64)
+    ego[..., 0] = 2.0      # 4 m/s * 0.5 s between keyframes
+    ego[..., 5] = 0.02     # gentle left turn
+    if not axis_aligned:
+        ego += torch.randn(batch, seq, 6, generator=g).double() * 0.01
+    else:
+        ego[..., 5] = 0.0
+    return intr.float(), extr.float(), ego.float()
+
+
+def make_labels(batch, seq, bev=(200, 200), seed=0, n_hdmap=2):
+    """Bernoulli-blob occupancy labels with the reference's dtypes/shapes."""
+    g = torch.Generator().manual_seed(seed + 7919)
+    x, y = bev
+
+    def blobs(p):
+        coarse = (torch.rand(batch, seq, 1, (x + 3) // 4, (y + 3) // 4, generator=g) < p).float()
+        up = torch.nn.functional.interpolate(coarse.view(batch * seq, 1, *coarse.shape[-2:]), scale_factor=4,
+                                             mode='nearest')[..., :x, :y]
+        return up.view(batch, seq, 1, x, y).long()
+
+    seg = blobs(0.03)
+    ped = blobs(0.01)
+    hd = torch.cat([blobs(0.05) for _ in range(n_hdmap)], dim=2)
+    return seg, ped, hd
+
+
+def make_batch(batch=1, seq=3, n_cams=6, final_dim=(224, 480), bev=(200, 200), seed=0,
+               axis_aligned=False, with_images=True, with_labels=True, gt_depth=False):
+    """Full batch dict with the reference's keys (trainer.py:102-108)."""
+    g = torch.Generator().manual_seed(seed + 104729)
+    intr, extr, ego = make_rig(batch, seq, n_cams, final_dim, seed, axis_aligned)
+    out = {
+        'intrinsics': intr,
+        'extrinsics': extr,
+        'future_egomotion': ego,
+        'command': ['FORWARD'] * batch,
+        'sample_trajectory': torch.zeros(batch, 1, 1, 3),
+        'target_point': torch.zeros(batch, 2),
+        'gt_trajectory': torch.zeros(batch, 1, 3),
+    }
+    if with_images:
+        out['image'] = torch.randn(batch, seq, n_cams, 3, *final_dim, generator=g)
+    if with_labels:
+        seg, ped, hd = make_labels(batch, seq, bev, seed)
+        out['segmentation'] = seg
+        out['pedestrian'] = ped
+        out['hdmap'] = hd
+    if gt_depth:
+        out['depths'] = torch.randint(0, 61, (batch, seq, n_cams, *final_dim), generator=g).float()
+    return out

@@ -1,0 +1,65 @@
+"""CPU: the oracle restatement reproduces the fixtures generated from the reference itself
+(oracle/make_golden.py).  This is what pins oracle/lift_oracle.py when /root/reference is absent."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import lift_oracle as lo
+from tests import helpers as H
+
+
+def _sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def test_manifest_records_reference_agreement():
+    with open(os.path.join(H.GOLDEN, 'MANIFEST.json')) as f:
+        man = json.load(f)
+    for case in man['cases'].values():
+        assert case['oracle_vox_equal_reference'] is True
+        assert case['oracle_literal_pool_bitwise_equal_reference'] is True
+
+
+def test_small_case_ids_pool_and_grads():
+    g = H.load('lift_small.npz')
+    intr, extr, ego = (torch.from_numpy(g[k]) for k in ('intrinsics', 'extrinsics', 'future_egomotion'))
+    feat, logits = torch.from_numpy(g['feat']), torch.from_numpy(g['depth_logits'])
+    # the seeded generator reproduces the stored inputs bit for bit
+    i2, e2, m2, f2, l2 = H.lift_inputs(H.SMALL, 2, 3, 2, seed=11)
+    assert torch.equal(i2, intr) and torch.equal(e2, extr) and torch.equal(m2, ego)
+    assert torch.equal(f2, feat) and torch.equal(l2, logits)
+    vox = H.oracle_vox(H.SMALL, intr, extr, ego)
+    assert np.array_equal(vox, g['ref_vox'])                      # integer part: exact
+    bev = lo.pool_reference_style(feat, logits, vox, (32, 32), 0.5)
+    assert torch.equal(bev, torch.from_numpy(g['ref_bev']))       # literal restatement: bitwise
+    exact = lo.pool_exact(feat, logits, vox, (32, 32), 0.5)
+    assert (exact - torch.from_numpy(g['ref_bev']).double()).abs().max() < 1e-5
+    gf, gl = lo.pool_backward_exact(torch.from_numpy(g['grad_out']), feat, logits, vox, 0.5)
+    assert (gf - torch.from_numpy(g['ref_grad_feat']).double()).abs().max() < 1e-5
+    assert (gl - torch.from_numpy(g['ref_grad_logits']).double()).abs().max() < 1e-5
+
+
+def test_full_size_ids_digest_generic_and_axis_aligned():
+    g = H.load('lift_full.npz')
+    for name, axis in (('generic', False), ('axis_aligned', True)):
+        intr, extr, ego, feat, logits = H.lift_inputs(H.FULL, 1, 3, 6, seed=5, axis_aligned=axis)
+        vox = H.oracle_vox(H.FULL, intr, extr, ego)
+        assert np.array_equal(_sha(vox), g[f'{name}_vox_sha256'])
+        assert np.array_equal(vox.reshape(-1)[::97], g[f'{name}_vox_sample'])
+
+
+def test_truncation_not_floor():
+    """`.long()` truncates toward zero (stp3.py:289): coordinates in (-1, 0) land in cell 0 and are kept."""
+    pts = np.array([[[-50.2, 0.0, -15.0]], [[-50.6, 0.0, 0.0]], [[49.99, 49.99, 9.0]], [[50.0, 0.0, 0.0]]],
+                   dtype=np.float32)
+    res, start, dim = lo.bev_parameters([-50.0, 50.0, 0.5], [-50.0, 50.0, 0.5], [-10.0, 10.0, 20.0])
+    v = lo.voxel_index(pts, lo.bev_offset(start, res), res.numpy(), dim.tolist()).reshape(-1)
+    assert v[0] == 0 * 200 + 100        # x: (-50.2+50)/0.5 = -0.4 -> 0 ; z: (-15+10)/20 = -0.25 -> 0
+    assert v[1] == -1                   # (-50.6+50)/0.5 = -1.2 -> -1 -> dropped
+    assert v[2] == 199 * 200 + 199
+    assert v[3] == -1
+    nan = np.array([[[np.nan, 0.0, 0.0]], [[np.inf, 0.0, 0.0]]], dtype=np.float32)
+    assert (lo.voxel_index(nan, lo.bev_offset(start, res), res.numpy(), dim.tolist()) == -1).all()
