@@ -1,0 +1,50 @@
+"""Quick HIP-event timing of the lift kernels at BASELINE configs[1] shape (B=4,T=3)."""
+import sys, os, ctypes, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'st-p3_amd'))
+import torch
+from stp3_amd import ops, _lib
+from tests import helpers as H
+
+def ev_time(fn, iters=20, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3  # us
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+cfg = H.FULL
+intr, extr, ego, feat, logits = H.lift_inputs(cfg, B, 3, 6, seed=31)
+frustum, res, start, dim = H.grid_params(cfg)
+grid = ops.LiftGrid(frustum, res, start, dim, 'cuda')
+t0 = time.time(); plan = ops.LiftPlan.build(grid, intr, extr, ego, 64); torch.cuda.synchronize(); print('first plan build (host+dev) s', time.time() - t0)
+d = plan.dims
+mats = [m.cuda() for m in ops.lift_matrices(intr, extr, ego)]
+lib = _lib.lib()
+counts = torch.zeros(d.BT, d.V, dtype=torch.int32, device='cuda')
+print('voxel_index us', ev_time(lambda: ops.voxel_index(grid, d, *mats, order=1, counts=counts)))
+nb = ctypes.c_size_t(); lib.stp3_lift_plan_bytes(ctypes.byref(d), ctypes.byref(nb))
+pl = torch.empty(nb.value, dtype=torch.uint8, device='cuda')
+def build(det):
+    counts.zero_()
+    vox = ops.voxel_index(grid, d, *mats, order=1, counts=counts)
+    lib.stp3_lift_plan_build(ctypes.byref(d), ops._ptr(vox), ops._ptr(counts), ops._ptr(pl), nb, det, ops._stream())
+print('index+plan build (det) us', ev_time(lambda: build(1)))
+print('index+plan build (nondet) us', ev_time(lambda: build(0)))
+f = feat.cuda().permute(0,1,2,4,5,3).reshape(d.BT, d.NPIX, d.C).contiguous()
+l = logits.cuda().permute(0,1,2,4,5,3).reshape(d.BT, d.NPIX, d.D).contiguous()
+prob = ops.depth_softmax(d, l)
+print('softmax us', ev_time(lambda: ops.depth_softmax(d, l)))
+bev = torch.empty(d.B, d.T, d.C, d.X, d.Y, device='cuda')
+fwd = lambda: lib.stp3_lift_splat_fwd(ctypes.byref(d), ops._ptr(f), ops._ptr(prob), ops._ptr(plan.plan), ctypes.c_float(0.5), ops._ptr(bev), ops._stream())
+us = ev_time(fwd)
+alg = d.BT * (d.NPIX * d.C * 4 + d.NPIX * d.D * 4 + d.C * d.V * 4)
+print(f'lift_splat_fwd us {us:.1f}  algorithmic {alg/1e6:.1f} MB -> {alg/us/1e6:.3f} TB/s ({alg/us/1e6/8*100:.1f}% of 8 TB/s)')
+gacc = torch.empty(d.BT, d.V, d.C, device='cuda'); gb = torch.randn_like(bev); gf = torch.empty_like(f); gl = torch.empty_like(l)
+bwd = lambda: lib.stp3_lift_splat_bwd(ctypes.byref(d), ops._ptr(gb), ops._ptr(f), ops._ptr(prob), ops._ptr(plan.vox_pm), ctypes.c_float(0.5), ops._ptr(gacc), ops._ptr(gf), ops._ptr(gl), ops._stream())
+us = ev_time(bwd)
+algb = d.BT * (d.C * d.V * 4 + 2 * d.NPIX * d.C * 4 + 2 * d.NPIX * d.D * 4)
+print(f'lift_splat_bwd us {us:.1f}  algorithmic {algb/1e6:.1f} MB -> {algb/us/1e6:.3f} TB/s')
