@@ -300,6 +300,11 @@ __global__ __launch_bounds__(256) void depth_softmax_kernel(int64_t npix_total, 
 constexpr int kTileV = 64;
 constexpr int kTilePad = 65;
 
+// v_readlane_b32 on a float (the builtin is typed int: pass the bits, not the value)
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
 __global__ __launch_bounds__(256) void lift_splat_fwd_kernel(Dims dm, const float* __restrict__ feat,
                                                              const float* __restrict__ prob,
                                                              const int32_t* __restrict__ offsets,
@@ -348,12 +353,12 @@ __global__ __launch_bounds__(256) void lift_splat_fwd_kernel(Dims dm, const floa
                         }
 #pragma unroll
                         for (int u = 0; u < 8; ++u)
-                            acc = fmaf(__builtin_amdgcn_readlane(pr, j + u), f[u], acc);
+                            acc = fmaf(readlane_f(pr, j + u), f[u], acc);
                     }
                     for (; j < cnt; ++j) {
                         const int r = __builtin_amdgcn_readlane(roff, j);
                         const float f = chan ? fbt[r + lane] : 0.f;
-                        acc = fmaf(__builtin_amdgcn_readlane(pr, j), f, acc);
+                        acc = fmaf(readlane_f(pr, j), f, acc);
                     }
                 }
             }
@@ -421,7 +426,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_f<0x140, 0xF>(v);  // row_mirror
     v += dpp_f<0x142, 0xA>(v);  // row_bcast15 -> rows 1,3
     v += dpp_f<0x143, 0xC>(v);  // row_bcast31 -> rows 2,3
-    return __builtin_amdgcn_readlane(v, 63);
+    return readlane_f(v, 63);
 }
 
 // (b) one wave per camera pixel, lane = channel for feat / dfeat and lane = depth bin for
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(256) void lift_splat_bwd_kernel(Dims dm, const floa
 #pragma unroll 4
     for (int d = 0; d < dm.D; ++d) {
         const int v = __builtin_amdgcn_readlane(vx, d);
-        const float p = __builtin_amdgcn_readlane(pr, d);
+        const float p = readlane_f(pr, d);
         const int row = v < 0 ? 0 : v;
         float g = chan ? g_bt[(size_t)row * dm.C + lane] : 0.f;
         g = v < 0 ? 0.f : g;
