@@ -1,0 +1,113 @@
+"""2-D building blocks on the LSS path, parameter-name compatible with the reference's
+``stp3/layers/convolutions.py`` (UpsamplingConcat :183-201, UpsamplingAdd :204-215, ASPP
+:217-270, DeepLabHead :272-280).  The off-path blocks of that file (ConvBlock, Bottleneck,
+ConvNeXt Block, ...) are out of scope.
+
+Exact work reductions relative to a literal translation (no approximation):
+  * a dilated 3x3 whose dilation is >= the feature map's height/width only ever reads its
+    centre row/column/tap (all other taps fall in the zero padding); ``ASPPConv`` then slices the
+    weight and runs the smaller convolution;
+  * the ASPP image-pooling branch is spatially constant; it is applied as a per-sample bias of
+    the 1x1 projection instead of being materialised, interpolated and concatenated.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _conv_bn_relu(in_ch, out_ch, k, padding=0, dilation=1):
+    return [nn.Conv2d(in_ch, out_ch, k, padding=padding, dilation=dilation, bias=False), nn.BatchNorm2d(out_ch),
+            nn.ReLU(inplace=True)]
+
+
+class UpsamplingConcat(nn.Module):
+    """x2 bilinear upsample, concat [skip, upsampled], 2 x (3x3 conv + BN + ReLU)."""
+
+    def __init__(self, in_channels, out_channels, scale_factor=2):
+        super().__init__()
+        self.upsample = nn.Upsample(scale_factor=scale_factor, mode='bilinear', align_corners=False)
+        self.conv = nn.Sequential(*_conv_bn_relu(in_channels, out_channels, 3, padding=1),
+                                  *_conv_bn_relu(out_channels, out_channels, 3, padding=1))
+
+    def forward(self, x_to_upsample, x):
+        return self.conv(torch.cat([x, self.upsample(x_to_upsample)], dim=1))
+
+
+class UpsamplingAdd(nn.Module):
+    """x2 bilinear upsample, 1x1 conv + BN, add the skip."""
+
+    def __init__(self, in_channels, out_channels, scale_factor=2):
+        super().__init__()
+        self.upsample_layer = nn.Sequential(
+            nn.Upsample(scale_factor=scale_factor, mode='bilinear', align_corners=False),
+            nn.Conv2d(in_channels, out_channels, 1, bias=False), nn.BatchNorm2d(out_channels))
+
+    def forward(self, x, x_skip):
+        return self.upsample_layer(x) + x_skip
+
+
+class ASPPConv(nn.Sequential):
+    """3x3 dilated conv + BN + ReLU (modules 0,1,2 like the reference's Sequential)."""
+
+    def __init__(self, in_channels, out_channels, dilation):
+        super().__init__(nn.Conv2d(in_channels, out_channels, 3, padding=dilation, dilation=dilation, bias=False),
+                         nn.BatchNorm2d(out_channels), nn.ReLU())
+        self.dilation = dilation
+
+    def forward(self, x):
+        conv, bn, act = self[0], self[1], self[2]
+        h, w = x.shape[-2:]
+        d = self.dilation
+        wgt = conv.weight
+        if d >= h and d >= w:                       # only the centre tap can ever be in range
+            y = F.conv2d(x, wgt[:, :, 1:2, 1:2])
+        elif d >= h:                                # centre row only: 1x3
+            y = F.conv2d(x, wgt[:, :, 1:2, :], padding=(0, d), dilation=(1, d))
+        elif d >= w:                                # centre column only: 3x1
+            y = F.conv2d(x, wgt[:, :, :, 1:2], padding=(d, 0), dilation=(d, 1))
+        else:
+            y = conv(x)
+        return act(bn(y))
+
+
+class ASPPPooling(nn.Sequential):
+    """Global average pool -> 1x1 conv + BN + ReLU (modules 0..3 like the reference)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__(nn.AdaptiveAvgPool2d(1), nn.Conv2d(in_channels, out_channels, 1, bias=False),
+                         nn.BatchNorm2d(out_channels), nn.ReLU())
+
+    def forward(self, x):
+        """Returns the (N, C, 1, 1) pooled descriptor; bilinear upsampling of a 1x1 map is a
+        broadcast, which ``ASPP`` folds into its projection."""
+        for mod in self:
+            x = mod(x)
+        return x
+
+
+class ASPP(nn.Module):
+    def __init__(self, in_channels, atrous_rates, out_channels=256):
+        super().__init__()
+        mods = [nn.Sequential(nn.Conv2d(in_channels, out_channels, 1, bias=False), nn.BatchNorm2d(out_channels),
+                              nn.ReLU())]
+        mods += [ASPPConv(in_channels, out_channels, r) for r in tuple(atrous_rates)]
+        mods.append(ASPPPooling(in_channels, out_channels))
+        self.convs = nn.ModuleList(mods)
+        self.project = nn.Sequential(nn.Conv2d(len(self.convs) * out_channels, out_channels, 1, bias=False),
+                                     nn.BatchNorm2d(out_channels), nn.ReLU(), nn.Dropout(0.5))
+
+    def forward(self, x):
+        spatial = torch.cat([conv(x) for conv in self.convs[:-1]], dim=1)
+        pooled = self.convs[-1](x)                                   # (N, C, 1, 1)
+        proj, bn, act, drop = self.project
+        n_sp = spatial.shape[1]
+        y = F.conv2d(spatial, proj.weight[:, :n_sp])
+        y = y + F.conv2d(pooled.to(y.dtype), proj.weight[:, n_sp:])  # constant plane == per-sample bias
+        return drop(act(bn(y)))
+
+
+class DeepLabHead(nn.Sequential):
+    def __init__(self, in_channels, num_classes, hidden_channel=256):
+        super().__init__(ASPP(in_channels, [12, 24, 36], hidden_channel),
+                         nn.Conv2d(hidden_channel, hidden_channel, 3, padding=1, bias=False),
+                         nn.BatchNorm2d(hidden_channel), nn.ReLU(), nn.Conv2d(hidden_channel, num_classes, 1))

@@ -1,0 +1,90 @@
+"""Training losses of the perception path, following ``stp3/losses.py``: SpatialRegressionLoss
+(:6-40), SegmentationLoss (:43-83), HDmapLoss (:85-114), DepthLoss (:116-134).
+
+The reference ranks the per-pixel losses with a full descending sort and keeps the first k
+(:76-81, :108-111); only the *mean of the k largest* is used, so ``torch.topk`` computes the same
+quantity without ordering all 40 000 pixels."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _future_discounts(future_discount, seq_len, n_present, like):
+    fut = future_discount ** torch.arange(1, seq_len - n_present + 1, device=like.device, dtype=like.dtype)
+    return torch.cat([torch.ones(n_present, device=like.device, dtype=like.dtype), fut], dim=0)
+
+
+class SpatialRegressionLoss(nn.Module):
+    def __init__(self, norm, ignore_index=255, future_discount=1.0):
+        super().__init__()
+        if norm not in (1, 2):
+            raise ValueError(f'Expected norm 1 or 2, but got norm={norm}')
+        self.norm, self.ignore_index, self.future_discount = norm, ignore_index, future_discount
+        self.loss_fn = F.l1_loss if norm == 1 else F.mse_loss
+
+    def forward(self, prediction, target, n_present=3):
+        assert prediction.dim() == 5, 'Must be a 5D tensor'
+        mask = target[:, :, :1] != self.ignore_index
+        if mask.sum() == 0:
+            return prediction.new_zeros(1)[0].float()
+        loss = self.loss_fn(prediction, target, reduction='none').sum(dim=-3, keepdim=True)
+        seq_len = loss.shape[1]
+        assert seq_len >= n_present
+        loss = loss * _future_discounts(self.future_discount, seq_len, n_present, loss).view(1, seq_len, 1, 1, 1)
+        return loss[mask].mean()
+
+
+class SegmentationLoss(nn.Module):
+    def __init__(self, class_weights, ignore_index=255, use_top_k=False, top_k_ratio=1.0, future_discount=1.0):
+        super().__init__()
+        self.class_weights = class_weights
+        self.ignore_index, self.use_top_k, self.top_k_ratio = ignore_index, use_top_k, top_k_ratio
+        self.future_discount = future_discount
+
+    def forward(self, prediction, target, n_present=3):
+        if target.shape[-3] != 1:
+            raise ValueError('segmentation label must be an index-label with channel dimension = 1.')
+        b, s, c, h, w = prediction.shape
+        loss = F.cross_entropy(prediction.reshape(b * s, c, h, w).float(), target.reshape(b * s, h, w),
+                               ignore_index=self.ignore_index, reduction='none',
+                               weight=self.class_weights.to(prediction.device))
+        loss = loss.view(b, s, h, w)
+        assert s >= n_present
+        loss = loss * _future_discounts(self.future_discount, s, n_present, loss).view(1, s, 1, 1)
+        loss = loss.view(b, s, -1)
+        if self.use_top_k:
+            k = int(self.top_k_ratio * loss.shape[2])
+            loss = loss.topk(k, dim=2, sorted=False).values
+        return loss.mean()
+
+
+class HDmapLoss(nn.Module):
+    def __init__(self, class_weights, training_weights, use_top_k, top_k_ratio, ignore_index=255):
+        super().__init__()
+        self.class_weights, self.training_weights = class_weights, training_weights
+        self.ignore_index, self.use_top_k, self.top_k_ratio = ignore_index, use_top_k, top_k_ratio
+
+    def forward(self, prediction, target):
+        total = 0
+        for i in range(target.shape[-3]):
+            cur = target[:, i]
+            b = cur.shape[0]
+            loss = F.cross_entropy(prediction[:, 2 * i:2 * (i + 1)].float(), cur, ignore_index=self.ignore_index,
+                                   reduction='none', weight=self.class_weights[i].to(target.device)).view(b, -1)
+            if self.use_top_k[i]:
+                k = int(self.top_k_ratio[i] * loss.shape[1])
+                loss = loss.topk(k, dim=1, sorted=False).values
+            total = total + loss.mean() * self.training_weights[i]
+        return total
+
+
+class DepthLoss(nn.Module):
+    def __init__(self, class_weights=None, ignore_index=255):
+        super().__init__()
+        self.class_weights, self.ignore_index = class_weights, ignore_index
+
+    def forward(self, prediction, target):
+        b, s, n, d, h, w = prediction.shape
+        loss = F.cross_entropy(prediction.reshape(b * s * n, d, h, w).float(), target.reshape(b * s * n, h, w),
+                               ignore_index=self.ignore_index, reduction='none', weight=self.class_weights)
+        return loss.mean()

@@ -1,0 +1,79 @@
+"""BEV decoder: 7x7/2 stem + ResNet-18 stages 1-3, three upsample-add skips, per-task heads.
+Mirrors ``stp3/models/decoder.py`` (Decoder :8-140): same constructor, parameter names and output
+dictionary (``None`` for disabled heads)."""
+import torch.nn as nn
+
+from ..layers.convolutions import UpsamplingAdd
+from .resnet import resnet18
+
+
+def _head(channels, out_channels, sigmoid=False):
+    mods = [nn.Conv2d(channels, channels, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(channels),
+            nn.ReLU(inplace=True), nn.Conv2d(channels, out_channels, kernel_size=1, padding=0)]
+    if sigmoid:
+        mods.append(nn.Sigmoid())
+    return nn.Sequential(*mods)
+
+
+class Decoder(nn.Module):
+    def __init__(self, in_channels, n_classes, n_present, n_hdmap, predict_gate):
+        super().__init__()
+        self.perceive_hdmap = predict_gate['perceive_hdmap']
+        self.predict_pedestrian = predict_gate['predict_pedestrian']
+        self.predict_instance = predict_gate['predict_instance']
+        self.predict_future_flow = predict_gate['predict_future_flow']
+        self.planning = predict_gate['planning']
+        self.n_classes = n_classes
+        self.n_present = n_present
+        if self.predict_instance is False and self.predict_future_flow is True:
+            raise ValueError('flow cannot be True when not predicting instance')
+
+        backbone = resnet18(pretrained=False, zero_init_residual=True)
+        self.first_conv = nn.Conv2d(in_channels, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1, self.relu = backbone.bn1, backbone.relu
+        self.layer1, self.layer2, self.layer3 = backbone.layer1, backbone.layer2, backbone.layer3
+
+        shared = in_channels
+        self.up3_skip = UpsamplingAdd(256, 128, scale_factor=2)
+        self.up2_skip = UpsamplingAdd(128, 64, scale_factor=2)
+        self.up1_skip = UpsamplingAdd(64, shared, scale_factor=2)
+
+        self.segmentation_head = _head(shared, n_classes)
+        if self.predict_pedestrian:
+            self.pedestrian_head = _head(shared, n_classes)
+        if self.perceive_hdmap:
+            self.hdmap_head = _head(shared, 2 * n_hdmap)
+        if self.predict_instance:
+            self.instance_offset_head = _head(shared, 2)
+            self.instance_center_head = _head(shared, 1, sigmoid=True)
+        if self.predict_future_flow:
+            self.instance_future_head = _head(shared, 2)
+        if self.planning:
+            self.costvolume_head = _head(shared, 1)
+
+    def forward(self, x):
+        b, s, c, h, w = x.shape
+        x = x.reshape(b * s, c, h, w)
+        skip1 = x
+        x = self.layer1(self.relu(self.bn1(self.first_conv(x))))      # 1/2
+        skip2 = x
+        x = self.layer2(x)                                            # 1/4
+        skip3 = x
+        x = self.layer3(x)                                            # 1/8
+        x = self.up3_skip(x, skip3)
+        x = self.up2_skip(x, skip2)
+        x = self.up1_skip(x, skip1)
+
+        def per_frame(t):
+            return None if t is None else t.view(b, s, *t.shape[1:])
+
+        present = x.view(b, s, *x.shape[1:])[:, self.n_present - 1]    # decoder.py:122
+        return {
+            'segmentation': per_frame(self.segmentation_head(x)),
+            'pedestrian': per_frame(self.pedestrian_head(x) if self.predict_pedestrian else None),
+            'hdmap': self.hdmap_head(present) if self.perceive_hdmap else None,
+            'instance_center': per_frame(self.instance_center_head(x) if self.predict_instance else None),
+            'instance_offset': per_frame(self.instance_offset_head(x) if self.predict_instance else None),
+            'instance_flow': per_frame(self.instance_future_head(x) if self.predict_future_flow else None),
+            'costvolume': per_frame(self.costvolume_head(x).squeeze(1) if self.planning else None),
+        }

@@ -1,0 +1,140 @@
+"""EfficientNet trunk (B0 / B4) as the reference's ``Encoder`` uses it.
+
+The reference imports ``efficientnet_pytorch==0.7.0`` (environment.yml:18), which is not vendored
+under /root/reference and not installed here; this file restates the published architecture
+(Tan & Le 2019) behind the attribute names the reference touches
+(stp3/models/encoder.py:18, 41-55, 62-70): ``_conv_stem, _bn0, _swish, _blocks[i](x,
+drop_connect_rate=...), _global_params.drop_connect_rate`` and the parameter names of that
+package, so its checkpoints load (``_blocks.N._expand_conv / _bn0 / _depthwise_conv / _bn1 /
+_se_reduce / _se_expand / _project_conv / _bn2``).  PARITY UNPINNED against the real package
+(its source is absent); parity is pinned only in the sense that the oracle plugs this very trunk
+into the reference's own ``Encoder`` class.
+
+"Static same" padding: the package fixes each conv's padding for the canonical resolution of
+the variant (380 px for B4, 224 px for B0), asymmetric (extra pixel right/bottom) on stride-2
+convs, and applies it unchanged to the 224x480 inputs used here.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# (repeats, kernel, stride, expand, in, out) of the 7 base stages, SE ratio 0.25 everywhere
+_BASE_STAGES = ((1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
+                (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320))
+# name -> (width multiplier, depth multiplier, canonical resolution, dropout)
+_VARIANTS = {'efficientnet-b0': (1.0, 1.0, 224, 0.2), 'efficientnet-b4': (1.4, 1.8, 380, 0.4)}
+
+
+def _round_filters(filters, width, divisor=8):
+    filters *= width
+    new = max(divisor, int(filters + divisor / 2) // divisor * divisor)
+    if new < 0.9 * filters:
+        new += divisor
+    return int(new)
+
+
+def _round_repeats(repeats, depth):
+    return int(math.ceil(depth * repeats))
+
+
+class StaticSamePadConv2d(nn.Conv2d):
+    """Conv2d whose TF-"same" padding is frozen for a given input size (square ``image_size``)."""
+
+    def __init__(self, in_ch, out_ch, kernel_size, image_size, stride=1, groups=1, bias=False):
+        super().__init__(in_ch, out_ch, kernel_size, stride=stride, groups=groups, bias=bias)
+        k, s = self.kernel_size[0], self.stride[0]
+        out = math.ceil(image_size / s)
+        pad = max((out - 1) * s + (k - 1) + 1 - image_size, 0)
+        self._pad = (pad // 2, pad - pad // 2, pad // 2, pad - pad // 2)   # left, right, top, bottom
+
+    def forward(self, x):
+        if any(self._pad):
+            x = F.pad(x, self._pad)
+        return F.conv2d(x, self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
+
+
+class Swish(nn.Module):
+    def forward(self, x):
+        return F.silu(x)
+
+
+class MBConvBlock(nn.Module):
+    def __init__(self, in_ch, out_ch, kernel, stride, expand, image_size, se_ratio=0.25, bn_mom=0.01, bn_eps=1e-3):
+        super().__init__()
+        self.in_ch, self.out_ch, self.stride, self.expand = in_ch, out_ch, stride, expand
+        mid = in_ch * expand
+        if expand != 1:
+            self._expand_conv = StaticSamePadConv2d(in_ch, mid, 1, image_size)
+            self._bn0 = nn.BatchNorm2d(mid, momentum=bn_mom, eps=bn_eps)
+        self._depthwise_conv = StaticSamePadConv2d(mid, mid, kernel, image_size, stride=stride, groups=mid)
+        self._bn1 = nn.BatchNorm2d(mid, momentum=bn_mom, eps=bn_eps)
+        out_size = math.ceil(image_size / stride)
+        squeezed = max(1, int(in_ch * se_ratio))
+        self._se_reduce = StaticSamePadConv2d(mid, squeezed, 1, 1, bias=True)
+        self._se_expand = StaticSamePadConv2d(squeezed, mid, 1, 1, bias=True)
+        self._project_conv = StaticSamePadConv2d(mid, out_ch, 1, out_size)
+        self._bn2 = nn.BatchNorm2d(out_ch, momentum=bn_mom, eps=bn_eps)
+        self._swish = Swish()
+        self.out_size = out_size
+
+    def forward(self, inputs, drop_connect_rate=None):
+        x = inputs
+        if self.expand != 1:
+            x = self._swish(self._bn0(self._expand_conv(x)))
+        x = self._swish(self._bn1(self._depthwise_conv(x)))
+        # squeeze and excitation
+        s = x.mean((2, 3), keepdim=True)
+        s = self._se_expand(self._swish(self._se_reduce(s)))
+        x = torch.sigmoid(s) * x
+        x = self._bn2(self._project_conv(x))
+        if self.stride == 1 and self.in_ch == self.out_ch:
+            if drop_connect_rate and self.training:
+                keep = 1.0 - drop_connect_rate
+                mask = torch.floor(keep + torch.rand(x.shape[0], 1, 1, 1, dtype=x.dtype, device=x.device))
+                x = x / keep * mask
+            x = x + inputs
+        return x
+
+
+class EfficientNet(nn.Module):
+    """Trunk + (unused here) head placeholders so that the reference's ``delete_unused_layers``
+    (encoder.py:39-55) finds the attributes it deletes."""
+
+    def __init__(self, name='efficientnet-b4', drop_connect_rate=0.2):
+        super().__init__()
+        width, depth, res, dropout = _VARIANTS[name]
+        self._global_params = SimpleNamespace(drop_connect_rate=drop_connect_rate, image_size=res,
+                                              width_coefficient=width, depth_coefficient=depth)
+        stem = _round_filters(32, width)
+        self._conv_stem = StaticSamePadConv2d(3, stem, 3, res, stride=2)
+        self._bn0 = nn.BatchNorm2d(stem, momentum=0.01, eps=1e-3)
+        size = math.ceil(res / 2)
+        blocks = []
+        for repeats, k, s, e, i, o in _BASE_STAGES:
+            i, o = _round_filters(i, width), _round_filters(o, width)
+            for r in range(_round_repeats(repeats, depth)):
+                blk = MBConvBlock(i if r == 0 else o, o, k, s if r == 0 else 1, e, size)
+                size = blk.out_size
+                blocks.append(blk)
+        self._blocks = nn.ModuleList(blocks)
+        head = _round_filters(1280, width)
+        self._conv_head = StaticSamePadConv2d(blocks[-1].out_ch, head, 1, size)
+        self._bn1 = nn.BatchNorm2d(head, momentum=0.01, eps=1e-3)
+        self._avg_pooling = nn.AdaptiveAvgPool2d(1)
+        self._dropout = nn.Dropout(dropout)
+        self._fc = nn.Linear(head, 1000)
+        self._swish = Swish()
+
+    @classmethod
+    def from_name(cls, name):
+        return cls(name)
+
+    @classmethod
+    def from_pretrained(cls, name):
+        """The package would download ImageNet weights here; there is no network, so this is a
+        seeded random initialisation of the same architecture (load real weights with
+        ``load_state_dict`` -- the parameter names match)."""
+        return cls(name)

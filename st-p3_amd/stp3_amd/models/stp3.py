@@ -1,0 +1,164 @@
+"""``STP3`` -- drop-in for the reference's ``stp3.models.stp3.STP3`` on the perception path.
+
+Same constructor (``STP3(cfg)``), attributes (``receptive_field, n_future, encoder_downsample,
+bev_dimension, encoder, temporal_model, decoder`` and the non-trainable parameters
+``bev_resolution / bev_start_position / bev_dimension / frustum``, stp3/models/stp3.py:15-109) and
+``forward(image, intrinsics, extrinsics, future_egomotion) -> dict`` (:132-184).  What differs is
+how the middle is computed: ``get_geometry`` + ``encoder_forward``'s outer product +
+``projection_to_birds_eye_view`` (:186-301) are replaced by the HIP operators in ``stp3_amd.ops``
+(one index/plan pass on a side stream that overlaps the image encoder, then a fused softmax /
+voxel-pool / discounted-accumulate kernel), so the 1.5 GB lifted tensor and the per-(b,t) host
+syncs of the reference never exist.
+
+Out of scope: the prediction / planning stages (``N_FUTURE_FRAMES > 0``,
+``PLANNING.ENABLED``) raise ``NotImplementedError``.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .decoder import Decoder
+from .encoder import Encoder
+from .temporal_model import TemporalModel, TemporalModelIdentity
+
+
+def bev_parameters(x_bounds, y_bounds, z_bounds):
+    """Resolution, first-cell centre and size of the BEV grid (stp3/utils/geometry.py:40-59)."""
+    rows = (x_bounds, y_bounds, z_bounds)
+    resolution = torch.tensor([r[2] for r in rows])
+    start = torch.tensor([r[0] + r[2] / 2.0 for r in rows])
+    dimension = torch.tensor([(r[1] - r[0]) / r[2] for r in rows], dtype=torch.long)
+    return resolution, start, dimension
+
+
+def set_bn_momentum(model, momentum=0.1):
+    """stp3/utils/network.py:27-30 -- applied to every BatchNorm, backbone included."""
+    for m in model.modules():
+        if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
+            m.momentum = momentum
+
+
+class STP3(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        res, start, dim = bev_parameters(cfg.LIFT.X_BOUND, cfg.LIFT.Y_BOUND, cfg.LIFT.Z_BOUND)
+        self.bev_resolution = nn.Parameter(res, requires_grad=False)
+        self.bev_start_position = nn.Parameter(start, requires_grad=False)
+        self.bev_dimension = nn.Parameter(dim, requires_grad=False)
+
+        self.encoder_downsample = cfg.MODEL.ENCODER.DOWNSAMPLE
+        self.encoder_out_channels = cfg.MODEL.ENCODER.OUT_CHANNELS
+        self.frustum = self.create_frustum()
+        self.depth_channels = self.frustum.shape[0]
+        self.discount = cfg.LIFT.DISCOUNT
+
+        if cfg.TIME_RECEPTIVE_FIELD == 1:
+            assert cfg.MODEL.TEMPORAL_MODEL.NAME == 'identity'
+        self.receptive_field = cfg.TIME_RECEPTIVE_FIELD
+        self.n_future = cfg.N_FUTURE_FRAMES
+        self.latent_dim = cfg.MODEL.DISTRIBUTION.LATENT_DIM
+        self.spatial_extent = (cfg.LIFT.X_BOUND[1], cfg.LIFT.Y_BOUND[1])
+        self.bev_size = (int(dim[0]), int(dim[1]))
+        if self.n_future > 0 or cfg.PLANNING.ENABLED:
+            raise NotImplementedError('prediction / planning stages are outside the accelerated perception path '
+                                      '(set N_FUTURE_FRAMES=0, PLANNING.ENABLED=False)')
+        if not cfg.MODEL.ENCODER.USE_DEPTH_DISTRIBUTION:
+            raise NotImplementedError('USE_DEPTH_DISTRIBUTION=False is not on the benchmarked path')
+
+        self.encoder = Encoder(cfg=cfg.MODEL.ENCODER, D=self.depth_channels)
+
+        temporal_in = self.encoder_out_channels + (6 if cfg.MODEL.TEMPORAL_MODEL.INPUT_EGOPOSE else 0)
+        name = cfg.MODEL.TEMPORAL_MODEL.NAME
+        if name == 'identity':
+            self.temporal_model = TemporalModelIdentity(temporal_in, self.receptive_field)
+        elif name == 'temporal_block':
+            tm = cfg.MODEL.TEMPORAL_MODEL
+            self.temporal_model = TemporalModel(
+                temporal_in, self.receptive_field, input_shape=self.bev_size,
+                start_out_channels=tm.START_OUT_CHANNELS, extra_in_channels=tm.EXTRA_IN_CHANNELS,
+                n_spatial_layers_between_temporal_layers=tm.INBETWEEN_LAYERS,
+                use_pyramid_pooling=tm.PYRAMID_POOLING)
+        else:
+            raise NotImplementedError(f'Temporal module {name}.')
+        self.future_pred_in_channels = self.temporal_model.out_channels
+
+        self.decoder = Decoder(
+            in_channels=self.future_pred_in_channels,
+            n_classes=len(cfg.SEMANTIC_SEG.VEHICLE.WEIGHTS),
+            n_present=self.receptive_field,
+            n_hdmap=len(cfg.SEMANTIC_SEG.HDMAP.ELEMENTS),
+            predict_gate={'perceive_hdmap': cfg.SEMANTIC_SEG.HDMAP.ENABLED,
+                          'predict_pedestrian': cfg.SEMANTIC_SEG.PEDESTRIAN.ENABLED,
+                          'predict_instance': cfg.INSTANCE_SEG.ENABLED,
+                          'predict_future_flow': cfg.INSTANCE_FLOW.ENABLED,
+                          'planning': cfg.PLANNING.ENABLED})
+        set_bn_momentum(self, cfg.MODEL.BN_MOMENTUM)
+
+        self.deterministic_pool = True      # canonical per-voxel summation order (bit-reproducible)
+        self._grid = None
+        self._side_stream = None
+
+    # ------------------------------------------------------------------------------------------
+    def create_frustum(self):
+        """(D, fH, fW, 3) image-plane sample grid (x_px, y_px, depth), stp3.py:111-130."""
+        h, w = self.cfg.IMAGE.FINAL_DIM
+        fh, fw = h // self.encoder_downsample, w // self.encoder_downsample
+        depth = torch.arange(*self.cfg.LIFT.D_BOUND, dtype=torch.float)
+        n_d = depth.shape[0]
+        grid = torch.stack((torch.linspace(0, w - 1, fw, dtype=torch.float).view(1, 1, fw).expand(n_d, fh, fw),
+                            torch.linspace(0, h - 1, fh, dtype=torch.float).view(1, fh, 1).expand(n_d, fh, fw),
+                            depth.view(n_d, 1, 1).expand(n_d, fh, fw)), -1)
+        return nn.Parameter(grid, requires_grad=False)
+
+    def lift_grid(self, device):
+        """Device constants of the lift (frustum axes, BEV grid); rebuilt if the parameters moved."""
+        if self._grid is None or self._grid.device != torch.device(device):
+            self._grid = ops.LiftGrid(self.frustum, self.bev_resolution, self.bev_start_position,
+                                      self.bev_dimension, device)
+        return self._grid
+
+    def calculate_birds_eye_view_features(self, image, intrinsics, extrinsics, future_egomotion):
+        """(B,S,N,3,H,W) images -> BEV features (B,S,C,X,Y) float32 + depth logits (B,S,N,D,fH,fW).
+        Replaces stp3.py:303-318 (and everything it calls)."""
+        b, s, n, c, h, w = image.shape
+        dev = image.device
+        grid = self.lift_grid(dev)
+        # geometry-only work goes to a side stream: it overlaps the image encoder below
+        cur = torch.cuda.current_stream(dev)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=dev)
+        side = self._side_stream
+        if intrinsics.is_cuda or extrinsics.is_cuda or future_egomotion.is_cuda:
+            side.wait_stream(cur)           # pose tensors may still be in flight on the main stream
+        with torch.cuda.stream(side):
+            plan = ops.LiftPlan.build(grid, intrinsics, extrinsics, future_egomotion, self.encoder_out_channels,
+                                      deterministic=self.deterministic_pool)
+        feat, depth = self.encoder(image.reshape(b * s * n, c, h, w))
+        cur.wait_stream(side)
+        feat = feat.view(b, s, n, *feat.shape[1:])
+        depth = depth.view(b, s, n, *depth.shape[1:])
+        bev = ops.lift_splat(feat, depth, plan, self.discount)
+        return bev, depth, None
+
+    def forward(self, image, intrinsics, extrinsics, future_egomotion):
+        rf = self.receptive_field
+        image = image[:, :rf].contiguous()
+        intrinsics = intrinsics[:, :rf].contiguous()
+        extrinsics = extrinsics[:, :rf].contiguous()
+        future_egomotion = future_egomotion[:, :rf].contiguous()
+
+        x, depth, cam_front = self.calculate_birds_eye_view_features(image, intrinsics, extrinsics, future_egomotion)
+        output = {'depth_prediction': depth, 'cam_front': cam_front}
+
+        if self.cfg.MODEL.TEMPORAL_MODEL.INPUT_EGOPOSE:
+            # stp3.py:145-152: six broadcast ego-motion planes; frame 0 gets zeros, frame t gets ego[t-1]
+            b, s, c = future_egomotion.shape
+            hh, ww = x.shape[-2:]
+            ego = future_egomotion.to(x.device, non_blocking=True).to(x.dtype)
+            ego = torch.cat([torch.zeros_like(ego[:, :1]), ego[:, :rf - 1]], dim=1)
+            x = torch.cat([x, ego.view(b, s, c, 1, 1).expand(b, s, c, hh, ww)], dim=2)
+
+        states = self.temporal_model(x)
+        output.update(self.decoder(states))
+        return output

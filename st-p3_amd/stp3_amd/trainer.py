@@ -1,0 +1,162 @@
+"""``TrainingModule`` -- the reference's PyTorch-Lightning module surface without the Lightning
+dependency (``stp3/trainer.py:14-462``): ``TrainingModule(hparams_dict)``, ``.model``, ``.cfg``,
+``shared_step(batch, is_train) -> (output, labels, loss_dict)``, ``training_step``,
+``validation_step``, ``configure_optimizers``, ``prepare_future_labels``.  Parameter names match
+the reference's checkpoints (``model.*`` incl. the learned uncertainty scalars
+``model.<task>_weight``, trainer.py:42-97), so ``load_state_dict(ckpt['state_dict'])`` works.
+
+Perception path only: instance / flow / planning heads follow the config gates exactly as the
+reference does, but the prediction and planning stages are rejected by ``STP3``.
+"""
+import torch
+import torch.nn as nn
+
+from .config import get_cfg
+from .geometry import cumulative_warp_features, cumulative_warp_features_reverse
+from .losses import DepthLoss, HDmapLoss, SegmentationLoss, SpatialRegressionLoss
+from .metrics import IntersectionOverUnion
+from .models.stp3 import STP3
+
+
+def _scalar():
+    return nn.Parameter(torch.tensor(0.0), requires_grad=True)
+
+
+class TrainingModule(nn.Module):
+    def __init__(self, hparams):
+        super().__init__()
+        self.hparams = hparams
+        cfg = get_cfg(cfg_dict=hparams)
+        self.cfg = cfg
+        self.n_classes = len(cfg.SEMANTIC_SEG.VEHICLE.WEIGHTS)
+        self.hdmap_class = cfg.SEMANTIC_SEG.HDMAP.ELEMENTS
+        assert cfg.LIFT.X_BOUND[1] > 0 and cfg.LIFT.Y_BOUND[1] > 0
+        self.spatial_extent = (cfg.LIFT.X_BOUND[1], cfg.LIFT.Y_BOUND[1])
+
+        self.model = STP3(cfg)
+        self.losses_fn = nn.ModuleDict()
+
+        seg = cfg.SEMANTIC_SEG
+        self.losses_fn['segmentation'] = SegmentationLoss(
+            class_weights=torch.Tensor(seg.VEHICLE.WEIGHTS), use_top_k=seg.VEHICLE.USE_TOP_K,
+            top_k_ratio=seg.VEHICLE.TOP_K_RATIO, future_discount=cfg.FUTURE_DISCOUNT)
+        self.model.segmentation_weight = _scalar()
+        self.metric_vehicle_val = IntersectionOverUnion(self.n_classes)
+        if seg.PEDESTRIAN.ENABLED:
+            self.losses_fn['pedestrian'] = SegmentationLoss(
+                class_weights=torch.Tensor(seg.PEDESTRIAN.WEIGHTS), use_top_k=seg.PEDESTRIAN.USE_TOP_K,
+                top_k_ratio=seg.PEDESTRIAN.TOP_K_RATIO, future_discount=cfg.FUTURE_DISCOUNT)
+            self.model.pedestrian_weight = _scalar()
+            self.metric_pedestrian_val = IntersectionOverUnion(self.n_classes)
+        if seg.HDMAP.ENABLED:
+            self.losses_fn['hdmap'] = HDmapLoss(
+                class_weights=torch.Tensor(seg.HDMAP.WEIGHTS), training_weights=seg.HDMAP.TRAIN_WEIGHT,
+                use_top_k=seg.HDMAP.USE_TOP_K, top_k_ratio=seg.HDMAP.TOP_K_RATIO)
+            self.metric_hdmap_val = nn.ModuleList([IntersectionOverUnion(2, absent_score=1)
+                                                   for _ in self.hdmap_class])
+            self.model.hdmap_weight = _scalar()
+        if cfg.LIFT.GT_DEPTH:
+            self.losses_fn['depths'] = DepthLoss()
+            self.model.depths_weight = _scalar()
+        if cfg.INSTANCE_SEG.ENABLED:
+            self.losses_fn['instance_center'] = SpatialRegressionLoss(norm=2, future_discount=cfg.FUTURE_DISCOUNT)
+            self.losses_fn['instance_offset'] = SpatialRegressionLoss(
+                norm=1, future_discount=cfg.FUTURE_DISCOUNT, ignore_index=cfg.DATASET.IGNORE_INDEX)
+            self.model.centerness_weight = _scalar()
+            self.model.offset_weight = _scalar()
+        if cfg.INSTANCE_FLOW.ENABLED:
+            self.losses_fn['instance_flow'] = SpatialRegressionLoss(
+                norm=1, future_discount=cfg.FUTURE_DISCOUNT, ignore_index=cfg.DATASET.IGNORE_INDEX)
+            self.model.flow_weight = _scalar()
+        self.training_step_count = 0
+
+    # ------------------------------------------------------------------------------------------
+    def _weighted(self, loss, name, key, value):
+        """Learned-uncertainty weighting 1/(2 exp(w)) * L + w/2 (trainer.py:125-172)."""
+        w = getattr(self.model, f'{name}_weight')
+        loss[key] = value / (2 * torch.exp(w))
+        loss[f'{name}_uncertainty'] = 0.5 * w
+
+    def shared_step(self, batch, is_train):
+        labels = self.prepare_future_labels(batch)
+        output = self.model(batch['image'], batch['intrinsics'], batch['extrinsics'], batch['future_egomotion'])
+        rf = self.model.receptive_field
+        cfg = self.cfg
+        loss = {}
+        if is_train:
+            self._weighted(loss, 'segmentation', 'segmentation',
+                           self.losses_fn['segmentation'](output['segmentation'], labels['segmentation'], rf))
+            if cfg.SEMANTIC_SEG.PEDESTRIAN.ENABLED:
+                self._weighted(loss, 'pedestrian', 'pedestrian',
+                               self.losses_fn['pedestrian'](output['pedestrian'], labels['pedestrian'], rf))
+            if cfg.SEMANTIC_SEG.HDMAP.ENABLED:
+                self._weighted(loss, 'hdmap', 'hdmap', self.losses_fn['hdmap'](output['hdmap'], labels['hdmap']))
+            if cfg.INSTANCE_SEG.ENABLED:
+                self._weighted(loss, 'centerness', 'instance_center', self.losses_fn['instance_center'](
+                    output['instance_center'], labels['centerness'], rf))
+                self._weighted(loss, 'offset', 'instance_offset', self.losses_fn['instance_offset'](
+                    output['instance_offset'], labels['offset'], rf))
+            if cfg.LIFT.GT_DEPTH:
+                self._weighted(loss, 'depths', 'depths',
+                               self.losses_fn['depths'](output['depth_prediction'], labels['depths']))
+            if cfg.INSTANCE_FLOW.ENABLED:
+                self._weighted(loss, 'flow', 'instance_flow', self.losses_fn['instance_flow'](
+                    output['instance_flow'], labels['flow'], rf))
+            output = {**output, 'selected_traj': labels['gt_trajectory']}
+        else:
+            # evaluate.py:95-98 / trainer.py:216-236: argmax over classes, present frame onwards
+            seg_pred = torch.argmax(output['segmentation'].detach(), dim=2, keepdim=True)
+            self.metric_vehicle_val(seg_pred[:, rf - 1:], labels['segmentation'][:, rf - 1:])
+            if cfg.SEMANTIC_SEG.PEDESTRIAN.ENABLED:
+                ped_pred = torch.argmax(output['pedestrian'].detach(), dim=2, keepdim=True)
+                self.metric_pedestrian_val(ped_pred[:, rf - 1:], labels['pedestrian'][:, rf - 1:])
+            if cfg.SEMANTIC_SEG.HDMAP.ENABLED:
+                for i in range(len(self.hdmap_class)):
+                    hd_pred = torch.argmax(output['hdmap'][:, 2 * i:2 * (i + 1)].detach(), dim=1, keepdim=True)
+                    self.metric_hdmap_val[i](hd_pred, labels['hdmap'][:, i:i + 1])
+            output = {**output, 'selected_traj': labels['gt_trajectory']}
+        return output, labels, loss
+
+    def _warp_pair(self, x, ego, rf, to_long):
+        """Past frames warped into the present frame, future frames warped back (trainer.py:279-290)."""
+        past = cumulative_warp_features(x[:, :rf].float(), ego[:, :rf], mode='nearest',
+                                        spatial_extent=self.spatial_extent)
+        fut = cumulative_warp_features_reverse(x[:, rf - 1:].float(), ego[:, rf - 1:], mode='nearest',
+                                               spatial_extent=self.spatial_extent)
+        if to_long:
+            past, fut = past.long(), fut.long()
+        return torch.cat([past.contiguous()[:, :-1], fut.contiguous()], dim=1)
+
+    def prepare_future_labels(self, batch):
+        cfg, rf = self.cfg, self.model.receptive_field
+        dev = batch['segmentation'].device
+        ego = batch['future_egomotion'].to(dev)
+        labels = {'hdmap': batch['hdmap'][:, rf - 1].long().contiguous(), 'gt_trajectory': batch['gt_trajectory']}
+        if cfg.LIFT.GT_DEPTH:
+            ds = self.model.encoder_downsample
+            depth = batch['depths'][:, :rf, :, ::ds, ::ds]
+            depth = torch.clamp(depth, cfg.LIFT.D_BOUND[0], cfg.LIFT.D_BOUND[1] - 1) - cfg.LIFT.D_BOUND[0]
+            labels['depths'] = depth.long().contiguous()
+        labels['segmentation'] = self._warp_pair(batch['segmentation'], ego, rf, True)
+        if cfg.SEMANTIC_SEG.PEDESTRIAN.ENABLED:
+            labels['pedestrian'] = self._warp_pair(batch['pedestrian'], ego, rf, True)
+        if cfg.INSTANCE_SEG.ENABLED:
+            labels['instance'] = self._warp_pair(batch['instance'].unsqueeze(2), ego, rf, True)[:, :, 0]
+            labels['centerness'] = self._warp_pair(batch['centerness'], ego, rf, False)
+            labels['offset'] = self._warp_pair(batch['offset'], ego, rf, False)
+        if cfg.INSTANCE_FLOW.ENABLED:
+            labels['flow'] = self._warp_pair(batch['flow'], ego, rf, False)
+        return labels
+
+    def training_step(self, batch, batch_idx=0):
+        _, _, loss = self.shared_step(batch, True)
+        self.training_step_count += 1
+        return sum(loss.values())
+
+    def validation_step(self, batch, batch_idx=0):
+        output, labels, _ = self.shared_step(batch, False)
+        return {'step_val_seg_iou_dynamic': self.metric_vehicle_val.compute()[1]}
+
+    def configure_optimizers(self):
+        return torch.optim.Adam(self.model.parameters(), lr=self.cfg.OPTIMIZER.LR,
+                                weight_decay=self.cfg.OPTIMIZER.WEIGHT_DECAY)

@@ -42,3 +42,55 @@ def oracle_vox(cfg, intr, extr, ego):
 
 def load(name):
     return np.load(os.path.join(GOLDEN, name))
+
+
+# ----------------------------------------------------------------------------------------------
+# deterministic weights: identical on every box, independent of construction order / RNG
+# ----------------------------------------------------------------------------------------------
+def fill_deterministic(module, seed=0):
+    """Overwrite every floating tensor of ``module.state_dict()`` with values derived from the
+    tensor's *name* by exact integer arithmetic (an LCG), so the reference modules (in the build
+    container) and the modules under test (on the GPU box) get bit-identical weights."""
+    import math
+    import zlib
+    sd = module.state_dict()
+    with torch.no_grad():
+        for name, t in sd.items():
+            if not t.is_floating_point():
+                continue
+            n = t.numel()
+            h = (zlib.crc32(name.encode()) + 7919 * seed) % 2147483647
+            idx = torch.arange(n, dtype=torch.int64)
+            u = ((idx * 1103515245 + h * 12345 + 12345) % 2147483648).double() / 2147483648.0   # [0,1)
+            u = ((u * 7.0 + (idx % 13).double() / 13.0) % 1.0)
+            if name.endswith('running_var'):
+                v = 0.5 + u
+            elif name.endswith('running_mean'):
+                v = 0.2 * (u - 0.5)
+            elif t.dim() <= 1 and name.endswith('weight'):
+                v = 0.5 + u                                      # BN gamma
+            elif t.dim() <= 1:
+                v = 0.2 * (u - 0.5)                              # biases, scalar loss weights
+            else:
+                fan_in = t[0].numel()
+                v = (u - 0.5) * 2.0 * math.sqrt(3.0 / fan_in)    # variance 1/fan_in
+            t.copy_(v.view(t.shape).to(t.dtype))
+    return module
+
+
+def det_tensor(shape, seed, scale=1.0):
+    """Deterministic pseudo-random tensor in [-scale, scale) (exact integer arithmetic)."""
+    n = 1
+    for s in shape:
+        n *= s
+    idx = torch.arange(n, dtype=torch.int64)
+    u = ((idx * 69069 + seed * 1234567 + 1) % 2147483648).double() / 2147483648.0
+    u = (u * 5.0 + (idx % 17).double() / 17.0) % 1.0
+    return ((u - 0.5) * 2.0 * scale).float().view(shape)
+
+
+def sample(t, n=4096):
+    """Strided sample of a tensor (what the module fixtures store)."""
+    flat = t.detach().reshape(-1)
+    step = max(1, flat.numel() // n)
+    return flat[::step].contiguous()
