@@ -58,6 +58,8 @@ def fill_deterministic(module, seed=0):
         for name, t in sd.items():
             if not t.is_floating_point():
                 continue
+            if name.split('.')[-1] in ('frustum', 'bev_resolution', 'bev_start_position', 'bev_dimension'):
+                continue                                         # geometry constants, not weights
             n = t.numel()
             h = (zlib.crc32(name.encode()) + 7919 * seed) % 2147483647
             idx = torch.arange(n, dtype=torch.int64)
