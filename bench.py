@@ -1,0 +1,190 @@
+"""bench.py -- BEV samples/s of the ST-P3 perception training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training pass of the hot path over one batch of synthetic input that is
+already resident in HBM: 6 cameras x 224x480 x T=3 frames, B=4 samples per GPU (BASELINE.json
+configs[2]: forward + backward with the Perception.yml losses, gradient clip, Adam step) --
+EfficientNet-B4 encoder -> HIP lift / voxel pool -> temporal model -> BEV decoder.  Multi-GPU is
+weak scaling: every rank gets its own B=4 (global batch 4N), gradients are all-reduced over RCCL
+and BatchNorm statistics are synchronised (the reference's DDP + sync_batchnorm recipe).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      the voxel-pool forward kernel (stp3_lift_splat_fwd): algorithmic bytes per launch /
+                its HIP-event time on the stream it runs on, against the 8 TB/s HBM3E peak
+  cpu_baseline  the CPU port of the same step (oracle/cpu_model.py: reference algorithm for the
+                lift, same torch modules) timed on this box's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'st-p3_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_module(device, sync_bn):
+    from stp3_amd.config import perception_cfg
+    from stp3_amd.trainer import TrainingModule
+    from stp3_amd.utils import to_channels_last
+    torch.manual_seed(1234)
+    cfg = perception_cfg()
+    module = TrainingModule(cfg.convert_to_dict())
+    if sync_bn:
+        from stp3_amd.parallel import convert_sync_batchnorm
+        module = convert_sync_batchnorm(module)
+    module = to_channels_last(module.to(device))
+    module.train()
+    return module, cfg
+
+
+def make_device_batch(batch_size, device, seed):
+    from stp3_amd import synthetic
+    batch = synthetic.make_batch(batch=batch_size, seq=3, seed=seed)
+    out = {}
+    for k, v in batch.items():
+        if not torch.is_tensor(v):
+            out[k] = v
+        elif k in ('intrinsics', 'extrinsics', 'future_egomotion'):
+            out[k] = v                  # pose tensors (a few hundred floats) stay on the host, where the
+            #                             bit-exact geometry constants are built; no device->host sync per step
+        else:
+            out[k] = v.to(device)
+    return out
+
+
+def cpu_baseline(max_seconds=40.0):
+    """CPU port of the same training step (reference lift algorithm), B=1, on all host cores."""
+    from oracle.cpu_model import CpuPortSTP3
+    from stp3_amd import synthetic
+    from stp3_amd.config import perception_cfg
+    from stp3_amd.trainer import TrainingModule
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    cfg = perception_cfg()
+    module = TrainingModule(cfg.convert_to_dict())
+    port = CpuPortSTP3(cfg)
+    port.load_state_dict(module.model.state_dict(), strict=False)
+    for name in ('segmentation_weight', 'pedestrian_weight', 'hdmap_weight'):
+        setattr(port, name, getattr(module.model, name))
+    module.model = port
+    module.train()
+    batch = synthetic.make_batch(batch=1, seq=3, seed=0)
+    opt = module.configure_optimizers()
+    times = []
+    t_all = time.time()
+    for i in range(3):
+        t0 = time.time()
+        opt.zero_grad()
+        loss = module.training_step(batch)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(module.model.parameters(), cfg.GRAD_NORM_CLIP)
+        opt.step()
+        times.append(time.time() - t0)
+        if time.time() - t_all > max_seconds:
+            break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {'value': 1.0 / best, 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+            'sample': f'B=1 (1 sample = 6 cams x 3 frames) full fwd+bwd+Adam step, fp32, {len(times)} runs, '
+                      f'best of the non-first {best:.2f} s; lift = reference algorithm (outer product, argsort, '
+                      f'cumsum VoxelsSumming)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=4, help='samples per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from stp3_amd import ops
+    from stp3_amd.parallel import GradientBuckets, init_distributed
+    rank, world, local = init_distributed()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+
+    module, cfg = build_module(device, sync_bn=world > 1)
+    buckets = GradientBuckets(module.model)
+    opt = module.configure_optimizers()
+    batch = make_device_batch(args.batch, device, seed=100 + rank)
+
+    def step():
+        buckets.zero_grad()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            loss = module.training_step(batch)
+        loss.backward()
+        buckets.finish()
+        buckets.clip_grad_norm_(cfg.GRAD_NORM_CLIP)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    ops.PROFILE.clear()
+    ops.PROFILE_ENABLED = True
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.PROFILE_ENABLED = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    assert torch.isfinite(loss).item(), 'loss is not finite'
+
+    if rank == 0:
+        prof = ops.profile_summary()
+        d = ops.make_dims(args.batch, 3, 6, 48, 28, 60, 64, 200, 200, 1)
+        alg_fwd = d.BT * (d.NPIX * d.C * 4 + d.NPIX * d.D * 4 + d.C * d.V * 4)   # feat + depth + BEV planes
+        fwd_ms = prof.get('lift_splat_fwd', {}).get('avg_ms')
+        roof = None
+        if fwd_ms:
+            ach = alg_fwd / (fwd_ms * 1e-3) / 1e9
+            roof = {'kernel': 'stp3_lift_splat_fwd', 'bound': 'hbm', 'achieved': round(ach, 1),
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'algorithmic_bytes_per_launch': alg_fwd, 'avg_launch_ms': round(fwd_ms, 4),
+                    'launches': prof['lift_splat_fwd']['n']}
+        line = {
+            'metric': 'BEV samples/sec (6-cam x 3-frame fwd+bwd)', 'value': round(args.batch * world * args.steps / elapsed, 3),
+            'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16 convs / f32 voxel pool', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[2]: batch=4/GPU, 6-cam 224x480, T=3, full STP3 fwd+bwd '
+                                   '(seg+ped+hdmap losses), grad-clip 5, Adam; EfficientNet-B4, D=48, C=64, BEV 200x200',
+                       'global_batch': args.batch * world, 'parallelism': f'dp{world}'},
+            'roofline': roof,
+            'kernel_ms': {k: round(v['avg_ms'], 4) for k, v in prof.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line['cpu_baseline'] = cpu_baseline()
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                line['cpu_baseline'] = {'error': repr(e)}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -27,6 +27,41 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional live timing of the HIP operators with events recorded on the stream they are launched on
+# (bench.py's roofline numbers).  Off by default: zero overhead in normal use.
+PROFILE_ENABLED = False
+PROFILE = []          # (name, start_event, end_event)
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if PROFILE_ENABLED:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.end = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE_ENABLED:
+            self.end.record()
+            PROFILE.append((self.name, self.start, self.end))
+        return False
+
+
+def profile_summary():
+    """name -> {'n', 'avg_ms'} over everything recorded since PROFILE was cleared (synchronises)."""
+    torch.cuda.synchronize()
+    acc = {}
+    for name, s, e in PROFILE:
+        a = acc.setdefault(name, [0, 0.0])
+        a[0] += 1
+        a[1] += s.elapsed_time(e)
+    return {k: {'n': n, 'avg_ms': t / n} for k, (n, t) in acc.items()}
+
+
 def _need_gpu(*tensors):
     for t in tensors:
         if not t.is_cuda:
@@ -139,7 +174,13 @@ class LiftPlan:
         ego_r = mats[n_cam * 12:n_cam * 12 + b * s * 9]
         ego_t = mats[n_cam * 12 + b * s * 9:]
         counts = torch.zeros(dims.BT, dims.V, dtype=torch.int32, device=grid.device)
-        vox_pm = voxel_index(grid, dims, cam_m, cam_t, ego_r, ego_t, VOX_PIXELMAJOR, counts)
+        with _timed('plan_build'):
+            vox_pm = voxel_index(grid, dims, cam_m, cam_t, ego_r, ego_t, VOX_PIXELMAJOR, counts)
+            plan = LiftPlan._finish(grid, dims, vox_pm, counts, deterministic)
+        return plan
+
+    @staticmethod
+    def _finish(grid, dims, vox_pm, counts, deterministic):
         nbytes = ctypes.c_size_t()
         check(_lib.lib().stp3_lift_plan_bytes(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_lift_plan_bytes')
         plan = torch.empty(nbytes.value, dtype=torch.uint8, device=grid.device)
@@ -173,10 +214,12 @@ class _LiftSplat(torch.autograd.Function):
         logits_pm = logits_pm.contiguous()
         assert feat_pm.dtype == torch.float32 and logits_pm.dtype == torch.float32
         assert feat_pm.shape == (d.BT, d.NPIX, d.C) and logits_pm.shape == (d.BT, d.NPIX, d.D)
-        prob = depth_softmax(d, logits_pm)
+        with _timed('depth_softmax'):
+            prob = depth_softmax(d, logits_pm)
         bev = torch.empty(d.B, d.T, d.C, d.X, d.Y, dtype=torch.float32, device=feat_pm.device)
-        rc = _lib.lib().stp3_lift_splat_fwd(ctypes.byref(d), _ptr(feat_pm), _ptr(prob), _ptr(lift_plan.plan),
-                                            ctypes.c_float(discount), _ptr(bev), _stream())
+        with _timed('lift_splat_fwd'):
+            rc = _lib.lib().stp3_lift_splat_fwd(ctypes.byref(d), _ptr(feat_pm), _ptr(prob), _ptr(lift_plan.plan),
+                                                ctypes.c_float(discount), _ptr(bev), _stream())
         check(rc, 'stp3_lift_splat_fwd')
         ctx.save_for_backward(feat_pm, prob)
         ctx.lift_plan = lift_plan
@@ -191,9 +234,10 @@ class _LiftSplat(torch.autograd.Function):
         gacc = torch.empty(d.BT, d.V, d.C, dtype=torch.float32, device=grad_bev.device)
         grad_feat = torch.empty_like(feat_pm)
         grad_logits = torch.empty_like(prob)
-        rc = _lib.lib().stp3_lift_splat_bwd(ctypes.byref(d), _ptr(grad_bev), _ptr(feat_pm), _ptr(prob),
-                                            _ptr(ctx.lift_plan.vox_pm), ctypes.c_float(ctx.discount), _ptr(gacc),
-                                            _ptr(grad_feat), _ptr(grad_logits), _stream())
+        with _timed('lift_splat_bwd'):
+            rc = _lib.lib().stp3_lift_splat_bwd(ctypes.byref(d), _ptr(grad_bev), _ptr(feat_pm), _ptr(prob),
+                                                _ptr(ctx.lift_plan.vox_pm), ctypes.c_float(ctx.discount),
+                                                _ptr(gacc), _ptr(grad_feat), _ptr(grad_logits), _stream())
         check(rc, 'stp3_lift_splat_bwd')
         return grad_feat, grad_logits, None, None
 

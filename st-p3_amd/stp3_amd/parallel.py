@@ -1,0 +1,121 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, RCCL over xGMI.
+
+The reference trains through PyTorch-Lightning's ``accelerator='ddp'`` with
+``sync_batchnorm=True`` and ``gradient_clip_val`` (train.py:43-56); the samples of a batch are
+independent (the voxel pool loops ``for b in range(batch)``, stp3.py:265), so the path shards by
+batch with no data-path collective -- only the gradient all-reduce and the BatchNorm statistics.
+
+``GradientBuckets`` is a small purpose-built reducer rather than a generic DDP wrapper:
+  * parameters are bucketed in *reverse registration order* (decoder -> temporal model -> encoder
+    heads -> trunk), which is the order backward produces their gradients;
+  * every ``.grad`` is a view into its bucket's flat buffer, so there is no gather/scatter copy;
+  * a bucket's all-reduce (RCCL ``ncclAllReduce`` on the communication stream) is launched from the
+    post-accumulate hook of the last gradient that lands in it, i.e. it overlaps the rest of the
+    backward pass;
+  * bucket size defaults to 8 MiB: xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring
+    all-reduce of 33 MB of fp32 gradients is per-link bound at ~0.4 ms, so a handful of large
+    buckets keeps the link busy without serialising the tail behind one big transfer.
+Works with the ``gloo`` backend on CPU tensors too (that is how tests/ cover world_size 2).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def init_distributed(backend=None):
+    """Initialise ``torch.distributed`` from the torchrun environment.  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'   # "nccl" is RCCL on ROCm
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def convert_sync_batchnorm(module, process_group=None):
+    """BatchNorm -> cross-replica BatchNorm (train.py:47 ``sync_batchnorm=True``): the batch statistics
+    are those of the global batch, so N GPUs x B/N samples equal 1 GPU x B samples."""
+    return nn.SyncBatchNorm.convert_sync_batchnorm(module, process_group)
+
+
+class GradientBuckets:
+    def __init__(self, module, bucket_bytes=8 << 20, process_group=None, average=True):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.average = average
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.params = params[::-1]                       # backward order
+        self.buckets = []                                # (flat, [params])
+        self._bucket_of = {}
+        cur, cur_bytes = [], 0
+        for p in self.params:
+            nbytes = p.numel() * p.element_size()
+            if cur and (cur_bytes + nbytes > bucket_bytes or cur[0].dtype != p.dtype or cur[0].device != p.device):
+                self._close(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self._close(cur)
+        self._pending = [0] * len(self.buckets)
+        self._works = []
+        self._hooks = []
+        if self.world > 1:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self.broadcast_parameters(module)
+
+    def _close(self, params):
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=params[0].device)
+        off = 0
+        for p in params:
+            p.grad = flat[off:off + p.numel()].view_as(p)     # gradients accumulate straight into the bucket
+            off += p.numel()
+            self._bucket_of[p] = len(self.buckets)
+        self.buckets.append((flat, list(params)))
+
+    def broadcast_parameters(self, module):
+        if self.world > 1:
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src=0, group=self.group)
+
+    def zero_grad(self):
+        for flat, _ in self.buckets:
+            flat.zero_()
+        self._pending = [len(ps) for _, ps in self.buckets]
+        self._works = []
+
+    def _on_grad(self, p):
+        i = self._bucket_of[p]
+        self._pending[i] -= 1
+        if self._pending[i] == 0:
+            flat = self.buckets[i][0]
+            self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Wait for the in-flight all-reduces (call after ``backward``); averages over ranks."""
+        if self.world == 1:
+            return
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self.average:
+            for flat, _ in self.buckets:
+                flat.div_(self.world)
+
+    def clip_grad_norm_(self, max_norm):
+        """Global-norm clipping on the flat buckets (train.py:48 ``gradient_clip_val``)."""
+        total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(f.float()) for f, _ in self.buckets]))
+        scale = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        for flat, _ in self.buckets:
+            flat.mul_(scale.to(flat.dtype))
+        return total

@@ -99,12 +99,12 @@ def test_full_forward_fp32_and_bf16_iou():
     assert abs(metric.compute()[1].item() - _iou(_iou_counts(o['segmentation'], batch))) < 1e-6
     # pose tensors may also arrive on the GPU (reference behaviour): same result
     o2 = model(img, batch['intrinsics'].cuda(), batch['extrinsics'].cuda(), batch['future_egomotion'].cuda())
-    assert torch.equal(o2['segmentation'], o['segmentation'])
+    torch.testing.assert_close(o2['segmentation'], o['segmentation'], rtol=1e-4, atol=1e-5)   # MIOpen convs are not bit-reproducible
     # bf16 convolutions (the benchmarked precision), channels-last
-    model = model.to(memory_format=torch.channels_last)
+    from stp3_amd.utils import to_channels_last
+    model = to_channels_last(model)
     with torch.autocast('cuda', dtype=torch.bfloat16):
-        ob = model(img.contiguous(memory_format=torch.channels_last_3d) if False else img, batch['intrinsics'],
-                   batch['extrinsics'], batch['future_egomotion'])
+        ob = model(img, batch['intrinsics'], batch['extrinsics'], batch['future_egomotion'])
     close(ob['segmentation'], 'stp3_segmentation', rtol=5e-2, atol=3e-2)
     assert abs(_iou(_iou_counts(ob['segmentation'].float(), batch)) - _iou(ref_counts)) <= 1e-3
 
