@@ -124,6 +124,34 @@ int stp3_lift_splat_bwd(const stp3_lift_dims* dims, const float* grad_bev, const
                         const float* prob, const int32_t* vox_pm, float discount, float* gacc,
                         float* grad_feat, float* grad_logits, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Depthwise 2-D convolution of the EfficientNet trunk (MBConv blocks), channels-last.
+ * Replaces the groups == channels Conv2dStaticSamePadding calls that the reference's Encoder drives
+ * (stp3/models/encoder.py:62-70 -> efficientnet_pytorch MBConvBlock._depthwise_conv; forward and the
+ * two gradients autograd derives from it).
+ *   x  [N][H][W][C], y / dy [N][Ho][Wo][C]   dtype = STP3_DTYPE_F32 or STP3_DTYPE_BF16 (C % 4 / C % 8 == 0)
+ *   w  [K*K][C] float32 (tap-major), dw same layout, float32
+ *   K in {3,5}, stride in {1,2}; pad_top / pad_left = leading zero padding (the trailing padding is
+ *   implied by Ho, Wo: "static same" padding is asymmetric on stride-2 layers)
+ * bwd_weight is deterministic (two-stage reduction through `workspace`, no atomics).
+ */
+#define STP3_DTYPE_F32  0
+#define STP3_DTYPE_BF16 1
+
+typedef struct stp3_dwconv_dims {
+    int32_t N, H, W, C;          /* input  (channels-last)            */
+    int32_t Ho, Wo;              /* output spatial size               */
+    int32_t K, stride;           /* square kernel, stride             */
+    int32_t pad_top, pad_left;   /* leading zero padding              */
+    int32_t dtype;               /* STP3_DTYPE_*  of x / y / dy / dx  */
+} stp3_dwconv_dims;
+
+int stp3_dwconv2d_fwd(const stp3_dwconv_dims* dims, const void* x, const float* w, void* y, void* stream);
+int stp3_dwconv2d_bwd_data(const stp3_dwconv_dims* dims, const void* dy, const float* w, void* dx, void* stream);
+int stp3_dwconv2d_bwd_weight_workspace(const stp3_dwconv_dims* dims, size_t* bytes);
+int stp3_dwconv2d_bwd_weight(const stp3_dwconv_dims* dims, const void* x, const void* dy, float* dw,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,349 @@
+// stp3_dwconv.hip -- depthwise 2-D convolution (forward, data gradient, weight gradient) for the
+// EfficientNet trunk of ST-P3's image encoder on gfx950.
+//
+// Reference: the trunk's MBConv blocks call efficientnet_pytorch's Conv2dStaticSamePadding with
+// groups == channels (reference stp3/models/encoder.py:62-70 drives them; the package itself is
+// not vendored).  These layers are HBM-bound (k*k MACs per element): the kernels below are
+// channels-last (NHWC), vectorised 16 B per lane along C, fp32 accumulation, bf16 or f32 I/O.
+// MIOpen's grouped-conv path for this shape costs ~48 ms per weight-gradient call on MI355X
+// (profiles/r01_bench_steady_miopen.txt); these kernels replace it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "stp3_hip.h"
+
+namespace {
+
+struct DwDims {
+    int N, H, W, C, Ho, Wo;
+    int pad_t, pad_l;
+};
+
+// ---- 16-byte vectors of 8 bf16 / 4 f32 -------------------------------------------------------
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    float4 v;
+    __device__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+    __device__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+    __device__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ void to_float(float* f) const { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+    __device__ void from_float(const float* f) { v = make_float4(f[0], f[1], f[2], f[3]); }
+};
+struct bf16x8 { uint4 v; };
+template <> struct Vec<uint16_t> {
+    static constexpr int N = 8;
+    uint4 v;
+    __device__ void load(const uint16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ void store(uint16_t* p) const { *reinterpret_cast<uint4*>(p) = v; }
+    __device__ void zero() { v = make_uint4(0, 0, 0, 0); }
+    __device__ void to_float(float* f) const {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ static uint32_t rne(float a) {  // fp32 -> bf16 bits, round to nearest even
+        uint32_t u = __float_as_uint(a);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;  // NaN
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    }
+    __device__ void from_float(const float* f) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = rne(f[2 * i]) | (rne(f[2 * i + 1]) << 16);
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+// ---- forward: y[n,ho,wo,c] = sum_{kh,kw} x[n, ho*S+kh-pt, wo*S+kw-pl, c] * w[kh,kw,c] ----------
+// One thread = one channel vector x TW consecutive output columns: the input row segment and the
+// K weight vectors of a kernel row are loaded once and reused across the TW outputs.
+template <typename T, int K, int S, int TW>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwDims d, const T* __restrict__ x,
+                                                         const float* __restrict__ w, T* __restrict__ y) {
+    constexpr int VN = Vec<T>::N;
+    const int CV = d.C / VN;
+    const int wgroups = (d.Wo + TW - 1) / TW;
+    const int64_t total = (int64_t)d.N * d.Ho * wgroups * CV;
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= total) return;
+    const int cv = (int)(tid % CV);
+    int64_t r = tid / CV;
+    const int wg = (int)(r % wgroups);
+    r /= wgroups;
+    const int ho = (int)(r % d.Ho);
+    const int n = (int)(r / d.Ho);
+    const int c0 = cv * VN;
+    const int wo0 = wg * TW;
+    float acc[TW][VN];
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int j = 0; j < VN; ++j) acc[i][j] = 0.f;
+    constexpr int SPAN = (TW - 1) * S + K;
+    const int wi0 = wo0 * S - d.pad_l;
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
+        const int hi = ho * S + kh - d.pad_t;
+        if (hi < 0 || hi >= d.H) continue;
+        float wk[K][VN];
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+            for (int j = 0; j < VN; ++j) wk[kw][j] = w[(kh * K + kw) * d.C + c0 + j];
+        const T* xrow = x + ((int64_t)(n * d.H + hi) * d.W) * d.C + c0;
+        float xin[SPAN][VN];
+#pragma unroll
+        for (int i = 0; i < SPAN; ++i) {
+            const int wi = wi0 + i;
+            Vec<T> v;
+            if (wi >= 0 && wi < d.W) v.load(xrow + (int64_t)wi * d.C); else v.zero();
+            v.to_float(xin[i]);
+        }
+#pragma unroll
+        for (int o = 0; o < TW; ++o)
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                for (int j = 0; j < VN; ++j) acc[o][j] = fmaf(xin[o * S + kw][j], wk[kw][j], acc[o][j]);
+    }
+    T* yrow = y + ((int64_t)(n * d.Ho + ho) * d.Wo) * d.C + c0;
+#pragma unroll
+    for (int o = 0; o < TW; ++o) {
+        if (wo0 + o < d.Wo) {
+            Vec<T> v;
+            v.from_float(acc[o]);
+            v.store(yrow + (int64_t)(wo0 + o) * d.C);
+        }
+    }
+}
+
+// ---- data gradient: dx[n,hi,wi,c] = sum_{kh,kw : (hi+pt-kh) = ho*S, (wi+pl-kw) = wo*S} dy[n,ho,wo,c] w[kh,kw,c]
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(DwDims d, const T* __restrict__ dy,
+                                                              const float* __restrict__ w, T* __restrict__ dx) {
+    constexpr int VN = Vec<T>::N;
+    const int CV = d.C / VN;
+    const int64_t total = (int64_t)d.N * d.H * d.W * CV;
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= total) return;
+    const int cv = (int)(tid % CV);
+    int64_t r = tid / CV;
+    const int wi = (int)(r % d.W);
+    r /= d.W;
+    const int hi = (int)(r % d.H);
+    const int n = (int)(r / d.H);
+    const int c0 = cv * VN;
+    float acc[VN];
+#pragma unroll
+    for (int j = 0; j < VN; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
+        const int th = hi + d.pad_t - kh;
+        if (th < 0 || (S > 1 && (th % S) != 0)) continue;
+        const int ho = th / S;
+        if (ho >= d.Ho) continue;
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+            const int tw = wi + d.pad_l - kw;
+            if (tw < 0 || (S > 1 && (tw % S) != 0)) continue;
+            const int wo = tw / S;
+            if (wo >= d.Wo) continue;
+            Vec<T> v;
+            v.load(dy + ((int64_t)(n * d.Ho + ho) * d.Wo + wo) * d.C + c0);
+            float g[VN];
+            v.to_float(g);
+#pragma unroll
+            for (int j = 0; j < VN; ++j) acc[j] = fmaf(g[j], w[(kh * K + kw) * d.C + c0 + j], acc[j]);
+        }
+    }
+    Vec<T> o;
+    o.from_float(acc);
+    o.store(dx + ((int64_t)(n * d.H + hi) * d.W + wi) * d.C + c0);
+}
+
+// ---- weight gradient: dw[kh,kw,c] = sum_{n,ho,wo} dy[n,ho,wo,c] * x[n,ho*S+kh-pt,wo*S+kw-pl,c] ---
+// Stage 1: block (bx, by, kh) reduces its strided share of the output pixels for one kernel ROW kh
+// into partial[bx][kh*K + kw][C] (threads = channel vectors x pixel lanes, coalesced along C; the
+// pixel lanes are summed through LDS in a fixed order).  Stage 2 sums the partials over bx.
+// No atomics: deterministic.
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwDims d, const T* __restrict__ x,
+                                                                const T* __restrict__ dy,
+                                                                float* __restrict__ partial) {
+    constexpr int VN = Vec<T>::N;
+    constexpr int KK = K * K;
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [PL][K][CVB*VN]
+    const int CV = d.C / VN;
+    const int CVB = min(CV, 256);                    // channel vectors handled by this block column
+    const int PL = 256 / CVB;                        // pixel lanes
+    const int cvb = threadIdx.x % CVB, pl = threadIdx.x / CVB;
+    const int cv = blockIdx.y * CVB + cvb;
+    const int kh = blockIdx.z;
+    const bool live = pl < PL && cv < CV;
+    const int c0 = cv * VN;
+    float acc[K][VN];
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+        for (int j = 0; j < VN; ++j) acc[t][j] = 0.f;
+    const int64_t npix = (int64_t)d.N * d.Ho * d.Wo;
+    if (live) {
+        for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < npix; p += (int64_t)gridDim.x * PL) {
+            const int wo = (int)(p % d.Wo);
+            const int64_t r = p / d.Wo;
+            const int ho = (int)(r % d.Ho);
+            const int n = (int)(r / d.Ho);
+            const int hi = ho * S + kh - d.pad_t;
+            if (hi < 0 || hi >= d.H) continue;
+            Vec<T> gv;
+            gv.load(dy + p * d.C + c0);
+            float g[VN];
+            gv.to_float(g);
+            const T* xrow = x + ((int64_t)(n * d.H + hi) * d.W) * d.C + c0;
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const int wi = wo * S + kw - d.pad_l;
+                if (wi < 0 || wi >= d.W) continue;
+                Vec<T> xv;
+                xv.load(xrow + (int64_t)wi * d.C);
+                float xf[VN];
+                xv.to_float(xf);
+#pragma unroll
+                for (int j = 0; j < VN; ++j) acc[kw][j] = fmaf(g[j], xf[j], acc[kw][j]);
+            }
+        }
+    }
+    const int rowlen = CVB * VN;
+    if (pl < PL) {
+#pragma unroll
+        for (int t = 0; t < K; ++t)
+#pragma unroll
+            for (int j = 0; j < VN; ++j) red[(pl * K + t) * rowlen + cvb * VN + j] = acc[t][j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * rowlen; i += 256) {
+        const int t = i / rowlen, cc = i % rowlen;
+        const int c = blockIdx.y * rowlen + cc;
+        if (c >= d.C) continue;
+        float s = 0.f;
+        for (int q = 0; q < PL; ++q) s += red[(q * K + t) * rowlen + cc];
+        partial[((int64_t)blockIdx.x * KK + kh * K + t) * d.C + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void dwconv_reduce_partials_kernel(int nblocks, int n, const float* __restrict__ partial,
+                                                                     float* __restrict__ dw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * n + i];
+    dw[i] = s;
+}
+
+constexpr int kWgradBlocks = 512;
+
+inline int status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? STP3_OK : -(int)e;
+}
+
+inline int check(const stp3_dwconv_dims* p, DwDims* d, int* vec) {
+    if (!p) return STP3_EINVAL;
+    if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->C <= 0 || p->Ho <= 0 || p->Wo <= 0) return STP3_EINVAL;
+    if (!((p->K == 3 || p->K == 5) && (p->stride == 1 || p->stride == 2))) return STP3_EUNSUP;
+    if (p->dtype != STP3_DTYPE_F32 && p->dtype != STP3_DTYPE_BF16) return STP3_EUNSUP;
+    *vec = p->dtype == STP3_DTYPE_BF16 ? 8 : 4;
+    if (p->C % *vec) return STP3_EUNSUP;
+    if ((int64_t)p->N * p->H * p->W * p->C >= (1LL << 40)) return STP3_EUNSUP;
+    d->N = p->N; d->H = p->H; d->W = p->W; d->C = p->C; d->Ho = p->Ho; d->Wo = p->Wo;
+    d->pad_t = p->pad_top; d->pad_l = p->pad_left;
+    return STP3_OK;
+}
+
+template <typename T, int K, int S>
+int launch_fwd(const DwDims& d, const void* x, const float* w, void* y, hipStream_t s) {
+    constexpr int TW = 4;
+    const int CV = d.C / Vec<T>::N;
+    const int64_t total = (int64_t)d.N * d.Ho * ((d.Wo + TW - 1) / TW) * CV;
+    hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, S, TW>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d,
+                       (const T*)x, w, (T*)y);
+    return status();
+}
+template <typename T, int K, int S>
+int launch_bwd_data(const DwDims& d, const void* dy, const float* w, void* dx, hipStream_t s) {
+    const int64_t total = (int64_t)d.N * d.H * d.W * (d.C / Vec<T>::N);
+    hipLaunchKernelGGL((dwconv_bwd_data_kernel<T, K, S>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d,
+                       (const T*)dy, w, (T*)dx);
+    return status();
+}
+template <typename T, int K, int S>
+int launch_bwd_weight(const DwDims& d, const void* x, const void* dy, float* dw, float* ws, hipStream_t s) {
+    constexpr int VN = Vec<T>::N;
+    const int CV = d.C / VN;
+    const int CVB = CV < 256 ? CV : 256;
+    const int PL = 256 / CVB;
+    const int64_t npix = (int64_t)d.N * d.Ho * d.Wo;
+    int64_t want = (npix + PL - 1) / PL;
+    const int bx = (int)(want < kWgradBlocks ? want : kWgradBlocks);
+    const int by = (CV + CVB - 1) / CVB;
+    const size_t lds = (size_t)PL * K * CVB * VN * sizeof(float);
+    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, S>), dim3(bx, by, K), dim3(256), lds, s, d, (const T*)x,
+                       (const T*)dy, ws);
+    const int n = K * K * d.C;
+    hipLaunchKernelGGL(dwconv_reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, bx, n, ws, dw);
+    return status();
+}
+
+#define DISPATCH(FN, ...)                                                                               \
+    do {                                                                                                \
+        const bool bf = p->dtype == STP3_DTYPE_BF16;                                                    \
+        if (p->K == 3 && p->stride == 1) return bf ? FN<uint16_t, 3, 1>(__VA_ARGS__) : FN<float, 3, 1>(__VA_ARGS__); \
+        if (p->K == 3 && p->stride == 2) return bf ? FN<uint16_t, 3, 2>(__VA_ARGS__) : FN<float, 3, 2>(__VA_ARGS__); \
+        if (p->K == 5 && p->stride == 1) return bf ? FN<uint16_t, 5, 1>(__VA_ARGS__) : FN<float, 5, 1>(__VA_ARGS__); \
+        return bf ? FN<uint16_t, 5, 2>(__VA_ARGS__) : FN<float, 5, 2>(__VA_ARGS__);                       \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int stp3_dwconv2d_fwd(const stp3_dwconv_dims* p, const void* x, const float* w, void* y, void* stream) {
+    DwDims d; int vec;
+    int rc = check(p, &d, &vec);
+    if (rc) return rc;
+    if (!x || !w || !y) return STP3_EINVAL;
+    DISPATCH(launch_fwd, d, x, w, y, (hipStream_t)stream);
+}
+
+int stp3_dwconv2d_bwd_data(const stp3_dwconv_dims* p, const void* dy, const float* w, void* dx, void* stream) {
+    DwDims d; int vec;
+    int rc = check(p, &d, &vec);
+    if (rc) return rc;
+    if (!dy || !w || !dx) return STP3_EINVAL;
+    DISPATCH(launch_bwd_data, d, dy, w, dx, (hipStream_t)stream);
+}
+
+int stp3_dwconv2d_bwd_weight_workspace(const stp3_dwconv_dims* p, size_t* bytes) {
+    DwDims d; int vec;
+    int rc = check(p, &d, &vec);
+    if (rc) return rc;
+    if (!bytes) return STP3_EINVAL;
+    *bytes = (size_t)kWgradBlocks * p->K * p->K * p->C * sizeof(float);
+    return STP3_OK;
+}
+
+int stp3_dwconv2d_bwd_weight(const stp3_dwconv_dims* p, const void* x, const void* dy, float* dw, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    DwDims d; int vec;
+    int rc = check(p, &d, &vec);
+    if (rc) return rc;
+    if (!x || !dy || !dw || !workspace) return STP3_EINVAL;
+    if (workspace_bytes < (size_t)kWgradBlocks * p->K * p->K * p->C * sizeof(float)) return STP3_ENOSPACE;
+    DISPATCH(launch_bwd_weight, d, x, dy, dw, (float*)workspace, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -37,10 +37,20 @@ class LiftDims(ctypes.Structure):
         return self.X * self.Y * self.Z
 
 
+class DwConvDims(ctypes.Structure):
+    """struct stp3_dwconv_dims (include/stp3_hip.h)."""
+    _fields_ = [(k, ctypes.c_int32) for k in ('N', 'H', 'W', 'C', 'Ho', 'Wo', 'K', 'stride', 'pad_top', 'pad_left',
+                                              'dtype')]
+
+
+DTYPE_F32 = 0
+DTYPE_BF16 = 1
+
 VOX_REFERENCE = 0
 VOX_PIXELMAJOR = 1
 
 _DIMS_P = ctypes.POINTER(LiftDims)
+_DW_P = ctypes.POINTER(DwConvDims)
 
 # name -> (restype, argtypes); mirrors include/stp3_hip.h one to one
 SIGNATURES = {
@@ -51,6 +61,10 @@ SIGNATURES = {
     'stp3_depth_softmax': (c_int, [_DIMS_P, c_void_p, c_void_p, c_void_p]),
     'stp3_lift_splat_fwd': (c_int, [_DIMS_P, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     'stp3_lift_splat_bwd': (c_int, [_DIMS_P] + [c_void_p] * 4 + [c_float] + [c_void_p] * 4),
+    'stp3_dwconv2d_fwd': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'stp3_dwconv2d_bwd_data': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'stp3_dwconv2d_bwd_weight_workspace': (c_int, [_DW_P, ctypes.POINTER(c_size_t)]),
+    'stp3_dwconv2d_bwd_weight': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

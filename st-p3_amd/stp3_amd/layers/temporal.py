@@ -64,8 +64,21 @@ class PyramidSpatioTemporalPooling(nn.Module):
         self.features = nn.ModuleList(feats)
 
     def forward(self, x):
-        # the reference drops the last (right-padded) time step: [:, :, :-1] (temporal.py:413)
-        return [f(x)[:, :, :-1] for f in self.features]
+        out = []
+        for f, pool in zip(self.features, self.pool_sizes):
+            _, ph, pw = pool
+            b, c, t, h, w = x.shape
+            if h % ph == 0 and w % pw == 0:
+                # spatial mean over each pool window, then the causal 2-frame mean with
+                # count_include_pad=False (frame 0 averages only itself): identical to the padded
+                # AvgPool3d + [:, :, :-1] of the reference (temporal.py:396-413), as plain reductions
+                sp = x.float().view(b, c, t, h // ph, ph, w // pw, pw).mean(dim=(4, 6))
+                prev = torch.cat([sp[:, :, :1], sp[:, :, :-1]], dim=2)
+                pooled = torch.cat([sp[:, :, :1], 0.5 * (sp[:, :, 1:] + prev[:, :, 1:])], dim=2).to(x.dtype)
+                out.append(f.conv_bn_relu(pooled))
+            else:
+                out.append(f(x)[:, :, :-1])
+        return out
 
 
 class TemporalBlock(nn.Module):

@@ -21,6 +21,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
+
 # (repeats, kernel, stride, expand, in, out) of the 7 base stages, SE ratio 0.25 everywhere
 _BASE_STAGES = ((1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
                 (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320))
@@ -51,6 +53,13 @@ class StaticSamePadConv2d(nn.Conv2d):
         self._pad = (pad // 2, pad - pad // 2, pad // 2, pad - pad // 2)   # left, right, top, bottom
 
     def forward(self, x):
+        if self.groups == self.in_channels == self.out_channels and self.groups > 1 and x.is_cuda:
+            # depthwise: hand-written HIP kernels (padding handled in-kernel, no F.pad copy)
+            return ops.depthwise_conv2d(x, self.weight, self.stride[0], self._pad)
+        if self.kernel_size == (1, 1) and x.shape[-2:] == (1, 1) and self.stride == (1, 1):
+            # squeeze-excite 1x1 convs on a pooled 1x1 map are plain GEMMs
+            y = F.linear(x.flatten(1), self.weight.flatten(1), self.bias)
+            return y.view(*y.shape, 1, 1)
         if any(self._pad):
             x = F.pad(x, self._pad)
         return F.conv2d(x, self.weight, self.bias, self.stride, 0, self.dilation, self.groups)

@@ -252,3 +252,74 @@ def lift_splat(feat, depth_logits, lift_plan, discount):
     feat_pm = feat.float().permute(0, 1, 2, 4, 5, 3).reshape(d.BT, d.NPIX, d.C)
     logits_pm = depth_logits.float().permute(0, 1, 2, 4, 5, 3).reshape(d.BT, d.NPIX, d.D)
     return _LiftSplat.apply(feat_pm, logits_pm, lift_plan, float(discount))
+
+
+# ----------------------------------------------------------------------------------------------
+# depthwise convolution (EfficientNet MBConv blocks)
+# ----------------------------------------------------------------------------------------------
+def _dw_dims(x, k, stride, pad_top, pad_left, ho, wo):
+    n, c, h, w = x.shape
+    if x.dtype == torch.bfloat16:
+        dt = _lib.DTYPE_BF16
+    elif x.dtype == torch.float32:
+        dt = _lib.DTYPE_F32
+    else:
+        raise _lib.Stp3HipError(f'depthwise conv supports float32 / bfloat16, got {x.dtype}')
+    return _lib.DwConvDims(n, h, w, c, ho, wo, k, stride, pad_top, pad_left, dt)
+
+
+class _DepthwiseConv2d(torch.autograd.Function):
+    """x (N,C,H,W) channels-last memory, weight (C,1,K,K) -> y (N,C,Ho,Wo) channels-last memory.
+    pad = (left, right, top, bottom) explicit zero padding ("static same": may be asymmetric)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        _need_gpu(x, weight)
+        c, _, k, _ = weight.shape
+        left, right, top, bottom = pad
+        n, _, h, w = x.shape
+        ho = (h + top + bottom - k) // stride + 1
+        wo = (w + left + right - k) // stride + 1
+        x = x.contiguous(memory_format=torch.channels_last)
+        wt = weight.detach().float().reshape(c, k * k).t().contiguous()        # [K*K][C] float32
+        y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        dims = _dw_dims(x, k, stride, top, left, ho, wo)
+        check(_lib.lib().stp3_dwconv2d_fwd(ctypes.byref(dims), _ptr(x), _ptr(wt), _ptr(y), _stream()),
+              'stp3_dwconv2d_fwd')
+        ctx.save_for_backward(x, wt)
+        ctx.dims = dims
+        ctx.wshape = weight.shape
+        ctx.wdtype = weight.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wt = ctx.saved_tensors
+        dims = ctx.dims
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dx = dw = None
+        lib = _lib.lib()
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x, memory_format=torch.channels_last)
+            check(lib.stp3_dwconv2d_bwd_data(ctypes.byref(dims), _ptr(dy), _ptr(wt), _ptr(dx), _stream()),
+                  'stp3_dwconv2d_bwd_data')
+        if ctx.needs_input_grad[1]:
+            nbytes = ctypes.c_size_t()
+            check(lib.stp3_dwconv2d_bwd_weight_workspace(ctypes.byref(dims), ctypes.byref(nbytes)),
+                  'stp3_dwconv2d_bwd_weight_workspace')
+            ws = torch.empty(nbytes.value, dtype=torch.uint8, device=x.device)
+            dwt = torch.empty_like(wt)
+            check(lib.stp3_dwconv2d_bwd_weight(ctypes.byref(dims), _ptr(x), _ptr(dy), _ptr(dwt), _ptr(ws),
+                                               ctypes.c_size_t(nbytes.value), _stream()), 'stp3_dwconv2d_bwd_weight')
+            dw = dwt.t().reshape(ctx.wshape).to(ctx.wdtype)
+        return dx, dw, None, None
+
+
+def depthwise_conv2d(x, weight, stride=1, pad=(0, 0, 0, 0)):
+    """Depthwise conv (groups == channels) through the HIP kernels.  Under autocast the activations
+    run in the autocast dtype (bf16); the weights are consumed in float32 either way."""
+    if torch.is_autocast_enabled():
+        x = x.to(torch.get_autocast_gpu_dtype())
+    return _DepthwiseConv2d.apply(x, weight, int(stride), tuple(int(p) for p in pad))
