@@ -111,7 +111,7 @@ def main():
     args = ap.parse_args()
 
     from stp3_amd import ops
-    from stp3_amd.parallel import GradientBuckets, init_distributed
+    from stp3_amd.parallel import FlatAdam, GradientBuckets, init_distributed
     rank, world, local = init_distributed()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     device = torch.device('cuda', local)
@@ -119,7 +119,7 @@ def main():
 
     module, cfg = build_module(device, sync_bn=world > 1)
     buckets = GradientBuckets(module.model)
-    opt = module.configure_optimizers()
+    opt = FlatAdam(buckets, lr=cfg.OPTIMIZER.LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY)   # trainer.py:456-462
     batch = make_device_batch(args.batch, device, seed=100 + rank)
 
     def step():

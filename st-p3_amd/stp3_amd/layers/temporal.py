@@ -15,6 +15,36 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+def _pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def _conv2d_padded_channels(x, weight, padding=0):
+    """conv2d with input/output channels zero-padded to multiples of 8 (exact: the extra channels carry
+    zeros).  The tuned bf16 channels-last convolution kernels on MI355X need 16-byte channel vectors; the
+    TemporalBlock's 35 / 70 / 23 / 117-channel layers otherwise fall onto generic kernels that are
+    ~100x slower (profiles/r01_*)."""
+    co, ci = weight.shape[:2]
+    cop, cip = _pad8(co), _pad8(ci)
+    if cip != ci:
+        x = F.pad(x, (0, 0, 0, 0, 0, cip - ci))
+        weight = F.pad(weight, (0, 0, 0, 0, 0, cip - ci))
+    if cop != co:
+        weight = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, cop - co))
+    y = F.conv2d(x, weight, None, 1, padding)
+    return y[:, :co] if cop != co else y
+
+
+def _bn_act_2d(norm, x, relu=True):
+    """BatchNorm3d over (B,C,T,H,W) == batch norm over (B*T,C,H,W): apply the 3-D module's statistics
+    and affine parameters to the frame-folded 4-D tensor."""
+    if norm.training and norm.track_running_stats and norm.num_batches_tracked is not None:
+        norm.num_batches_tracked.add_(1)
+    y = F.batch_norm(x, norm.running_mean, norm.running_var, norm.weight, norm.bias,
+                     norm.training or not norm.track_running_stats, norm.momentum, norm.eps)
+    return F.relu(y, inplace=True) if relu else y
+
+
 class CausalConv3d(nn.Module):
     """Conv3d that pads time on the left only (kernel_time - 1 frames), + BN3d + ReLU."""
 
@@ -36,6 +66,24 @@ class CausalConv3d(nn.Module):
             x = F.pad(x, (0, 0, 0, 0, self._tpad, 0))
         x = F.conv3d(x, self.conv.weight, self.conv.bias, 1, self._hw_pad, self.conv.dilation)
         return self.activation(self.norm(x))
+
+    def forward_folded(self, x2, batch, frames):
+        """Same layer on the frame-folded tensor x2 (B*T, C, H, W).  A causal (2,3,3) convolution is
+        y[t] = W[:, :, 0] * x[t-1] + W[:, :, 1] * x[t] with x[-1] = 0, i.e. ONE 2-D 3x3 convolution over
+        the channel concatenation [x[t-1], x[t]]; a (1,3,3) convolution is a per-frame 2-D 3x3."""
+        w = self.conv.weight
+        kt = w.shape[2]
+        assert self.conv.bias is None and self.conv.dilation == (1, 1, 1) and kt in (1, 2)
+        if kt == 2:
+            c, h, ww = x2.shape[1:]
+            x5 = x2.view(batch, frames, c, h, ww)
+            prev = torch.cat([torch.zeros_like(x5[:, :1]), x5[:, :-1]], dim=1).view(batch * frames, c, h, ww)
+            x2 = torch.cat([prev, x2], dim=1)
+            w2 = torch.cat([w[:, :, 0], w[:, :, 1]], dim=1)
+        else:
+            w2 = w[:, :, 0]
+        y = _conv2d_padded_channels(x2, w2, padding=self._hw_pad[1:])
+        return _bn_act_2d(self.norm, y)
 
 
 def conv_1x1x1_norm_activated(in_channels, out_channels):
@@ -73,9 +121,11 @@ class PyramidSpatioTemporalPooling(nn.Module):
                 # count_include_pad=False (frame 0 averages only itself): identical to the padded
                 # AvgPool3d + [:, :, :-1] of the reference (temporal.py:396-413), as plain reductions
                 sp = x.float().view(b, c, t, h // ph, ph, w // pw, pw).mean(dim=(4, 6))
-                prev = torch.cat([sp[:, :, :1], sp[:, :, :-1]], dim=2)
-                pooled = torch.cat([sp[:, :, :1], 0.5 * (sp[:, :, 1:] + prev[:, :, 1:])], dim=2).to(x.dtype)
-                out.append(f.conv_bn_relu(pooled))
+                # T+1 causal windows: {0}, {0,1}, ..., {T-2,T-1}, {T-1}.  The reference runs conv+BN+ReLU on
+                # all T+1 (so the BatchNorm batch statistics include the last, right-padded window) and
+                # only then drops it.
+                pooled = torch.cat([sp[:, :, :1], 0.5 * (sp[:, :, 1:] + sp[:, :, :-1]), sp[:, :, -1:]], dim=2)
+                out.append(f.conv_bn_relu(pooled.to(x.dtype))[:, :, :-1])
             else:
                 out.append(f(x)[:, :, :-1])
         return out
@@ -111,28 +161,41 @@ class TemporalBlock(nn.Module):
         else:
             self.projection = None
 
+    @staticmethod
+    def _pointwise(seq, x2, relu=True):
+        """conv_1x1x1_norm_activated (or projection) on the frame-folded tensor: a 1x1 2-D convolution."""
+        conv, norm = seq[0], seq[1]
+        y = _conv2d_padded_channels(x2, conv.weight[:, :, 0])
+        return _bn_act_2d(norm, y, relu)
+
     def forward(self, x):
-        b, _, t, h, w = x.shape
-        paths = torch.cat([p(x) for p in self.convolution_paths], dim=1)
+        """x (B, C, T, H, W) -> (B, C', T, H, W).  Everything runs frame-folded as 2-D ops on
+        (B*T, C, H, W): the block only couples frames through the causal 2-tap convolution and the
+        causal pyramid pooling, both of which are expressed explicitly."""
+        b, c, t, h, w = x.shape
+        x2 = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
+        if x2.is_cuda:
+            x2 = x2.contiguous(memory_format=torch.channels_last)
+        outs = []
+        for path in self.convolution_paths[:-1]:
+            y = self._pointwise(path[0], x2)
+            outs.append(path[1].forward_folded(y, b, t))
+        outs.append(self._pointwise(self.convolution_paths[-1], x2))
+        paths = torch.cat(outs, dim=1)
         agg = self.aggregation[0]
-        if not self.use_pyramid_pooling:
-            y = agg.conv(paths)
-        else:
-            wgt = agg.conv.weight
-            y = F.conv3d(paths, wgt[:, :self._paths_channels])
+        wgt = agg.conv.weight[:, :, 0]                                   # (Cout, Cin_total, 1, 1)
+        y = _conv2d_padded_channels(paths, wgt[:, :self._paths_channels])
+        if self.use_pyramid_pooling:
             off = self._paths_channels
-            for pooled in self.pyramid_pooling(x):
-                c = pooled.shape[1]
-                contrib = F.conv3d(pooled.to(y.dtype), wgt[:, off:off + c])
-                if contrib.shape[-2:] != (h, w):
-                    if contrib.shape[-2:] == (1, 1):
-                        pass                                         # broadcast == bilinear upsample of 1x1
-                    else:
-                        contrib = F.interpolate(contrib.permute(0, 2, 1, 3, 4).reshape(b * t, -1, *contrib.shape[-2:]),
-                                                (h, w), mode='bilinear', align_corners=False)
-                        contrib = contrib.view(b, t, -1, h, w).permute(0, 2, 1, 3, 4)
-                y = y + contrib
-                off += c
-        y = agg.activation(agg.norm(y))
-        skip = x if self.projection is None else self.projection(x)
-        return skip + y
+            for pooled in self.pyramid_pooling(x):                       # (B, C', T, h', w')
+                cp = pooled.shape[1]
+                p2 = pooled.permute(0, 2, 1, 3, 4).reshape(b * t, cp, *pooled.shape[-2:])
+                contrib = F.conv2d(p2.to(y.dtype), wgt[:, off:off + cp].to(y.dtype))
+                if contrib.shape[-2:] != (1, 1) and contrib.shape[-2:] != (h, w):
+                    contrib = F.interpolate(contrib, (h, w), mode='bilinear', align_corners=False)
+                y = y + contrib                                          # 1x1 map: broadcast == bilinear upsample
+                off += cp
+        y = _bn_act_2d(agg.norm, y)
+        skip = x2 if self.projection is None else self._pointwise(self.projection, x2, relu=False)
+        out = skip + y
+        return out.view(b, t, -1, h, w).permute(0, 2, 1, 3, 4)

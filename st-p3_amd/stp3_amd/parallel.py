@@ -54,7 +54,8 @@ class GradientBuckets:
         self.average = average
         params = [p for p in module.parameters() if p.requires_grad]
         self.params = params[::-1]                       # backward order
-        self.buckets = []                                # (flat, [params])
+        self.buckets = []                                # (flat gradient, [params])
+        self.flat_params = []                            # flat parameter buffer per bucket
         self._bucket_of = {}
         cur, cur_bytes = [], 0
         for p in self.params:
@@ -75,13 +76,24 @@ class GradientBuckets:
         self.broadcast_parameters(module)
 
     def _close(self, params):
-        flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=params[0].device)
+        n = sum(p.numel() for p in params)
+        flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
+        flat_param = torch.empty(n, dtype=params[0].dtype, device=params[0].device)
         off = 0
-        for p in params:
-            p.grad = flat[off:off + p.numel()].view_as(p)     # gradients accumulate straight into the bucket
-            off += p.numel()
-            self._bucket_of[p] = len(self.buckets)
+        with torch.no_grad():
+            for p in params:
+                # Parameters AND gradients become views into the bucket's flat buffers, with the parameter's
+                # own strides (channels-last weights keep their physical layout), so gradients accumulate
+                # straight into the bucket and the optimizer runs on a handful of flat tensors.
+                size, stride = tuple(p.size()), tuple(p.stride())
+                view = torch.as_strided(flat_param, size, stride, off)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = torch.as_strided(flat, size, stride, off)
+                off += p.numel()
+                self._bucket_of[p] = len(self.buckets)
         self.buckets.append((flat, list(params)))
+        self.flat_params.append(flat_param)
 
     def broadcast_parameters(self, module):
         if self.world > 1:
@@ -119,3 +131,34 @@ class GradientBuckets:
         for flat, _ in self.buckets:
             flat.mul_(scale.to(flat.dtype))
         return total
+
+
+class FlatAdam:
+    """Adam (torch.optim.Adam semantics: L2 weight decay folded into the gradient, bias correction, no
+    amsgrad; the reference's optimizer, trainer.py:456-462) applied to the flat parameter / gradient
+    buffers of ``GradientBuckets``: a few elementwise kernels per bucket instead of several per parameter
+    (the model has ~440 parameter tensors)."""
+
+    def __init__(self, buckets, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.buckets = buckets
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.step_count = 0
+        self.exp_avg = [torch.zeros_like(p) for p in buckets.flat_params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in buckets.flat_params]
+
+    @torch.no_grad()
+    def step(self):
+        self.step_count += 1
+        b1, b2 = self.betas
+        bc1 = 1.0 - b1 ** self.step_count
+        bc2_sqrt = (1.0 - b2 ** self.step_count) ** 0.5
+        for (grad, _), param, m, v in zip(self.buckets.buckets, self.buckets.flat_params, self.exp_avg,
+                                          self.exp_avg_sq):
+            g = grad.add(param, alpha=self.weight_decay) if self.weight_decay else grad
+            m.lerp_(g, 1.0 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+            denom = (v.sqrt() / bc2_sqrt).add_(self.eps)
+            param.addcdiv_(m, denom, value=-self.lr / bc1)
+
+    def state_dict(self):
+        return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq}
