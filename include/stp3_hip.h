@@ -73,7 +73,7 @@ const char* stp3_version(void);
  *   bev_offset [3] = bev_start - bev_res/2 (float32), bev_res [3]
  *   vox  [B*T*P] int32 out, in `order`
  *   counts [B*T*V] int32 or NULL: if non-NULL it must be zero-filled by the caller; the kernel
- *          adds the number of points per voxel (the histogram stp3_lift_plan_build consumes).
+ *          adds the number of points per voxel (a diagnostic histogram; the plan does not need it).
  */
 int stp3_voxel_index(const stp3_lift_dims* dims,
                      const float* cam_m, const float* cam_t,
@@ -83,17 +83,24 @@ int stp3_voxel_index(const stp3_lift_dims* dims,
                      int order, int32_t* vox, int32_t* counts, void* stream);
 
 /*
- * Pooling plan: the geometry-only structure (per-voxel lists of contributing points) that the
- * forward kernel consumes.  It replaces the reference's boolean mask + argsort (stp3.py:247-257)
- * and depends only on the voxel ids, so it can be built on a side stream while the image
- * encoder is running.
+ * Pooling plan: the geometry-only structure that the forward kernels consume.  It replaces the
+ * reference's boolean mask + argsort (stp3.py:247-257) and depends only on the voxel ids, so it
+ * can be built on a side stream while the image encoder is running.
+ *
+ * Along an image column (camera n, feature column w, depth bin d) consecutive rows h fall into
+ * the same BEV cell most of the time; a RUN is a maximal set of consecutive h with one voxel
+ * id >= 0.  The plan numbers the runs canonically (by n, w, d, first row), counts them per voxel
+ * and assigns every run a row of the forward workspace such that each voxel's runs are
+ * contiguous and ordered by run number.
  *
  *   stp3_lift_plan_bytes : size of the plan buffer for `dims`
- *   stp3_lift_plan_build : vox_pm = ids in STP3_VOX_PIXELMAJOR order, counts = the histogram
- *                          written by stp3_voxel_index (consumed: left as per-voxel counts).
- *                          `deterministic` != 0 additionally orders every voxel's list
- *                          canonically, which makes the forward sums bit-reproducible run to
- *                          run (lists longer than 4096 points keep their arrival order).
+ *   stp3_lift_plan_build : vox_pm = ids in STP3_VOX_PIXELMAJOR order; counts = int32 [B*T][V]
+ *                          scratch that the CALLER zero-fills (left holding runs per voxel).
+ *                          `deterministic` != 0 orders every voxel's rows canonically, which
+ *                          makes the forward sums bit-reproducible run to run (voxels with more
+ *                          than 4096 runs keep their arrival order).
+ *   plan layout (int32): run_base [B*T][N*fW*D + 1] | vox_off [B*T][V + 1] | dest [B*T][P] |
+ *                        list [B*T][P]; each section starts 256-byte aligned.
  */
 int stp3_lift_plan_bytes(const stp3_lift_dims* dims, size_t* bytes);
 int stp3_lift_plan_build(const stp3_lift_dims* dims, const int32_t* vox_pm, int32_t* counts,
@@ -107,15 +114,24 @@ int stp3_depth_softmax(const stp3_lift_dims* dims, const float* logits, float* p
  * stp3_lift_splat_fwd -- out[b][t] = sum_{k<=t} discount^(t-k) Pool_k,
  *   Pool_k[c][v] = sum over points p of frame k with vox(p) == v of prob[p] * feat[pix(p)][c].
  * Replaces stp3.py:216-221 (outer product, never materialised), geometry.py:302-318
- * (VoxelsSumming.forward) and stp3.py:279-299 (scatter, discount, permute).  Requires Z == 1.
+ * (VoxelsSumming.forward) and stp3.py:279-299 (scatter, discount, permute).  Requires Z == 1,
+ * C <= 64, D <= 128.  Two launches: (1) per image column, depth (x) feature products summed
+ * along each run -> one C-vector per run in `workspace`; (2) per voxel, sum of its runs,
+ * discounted accumulation over t, transposed store.
+ *   workspace: stp3_lift_workspace_bytes(dims) bytes of scratch (worst case one run per point);
+ *              only the rows of actual runs are touched (typically 5-10 % of it)
  *   bev [B][T][C][X][Y] float32, fully overwritten (empty voxels get 0).
  */
+int stp3_lift_workspace_bytes(const stp3_lift_dims* dims, size_t* bytes);
 int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const float* prob,
-                        const void* plan, float discount, float* bev, void* stream);
+                        const int32_t* vox_pm, const void* plan, float discount,
+                        void* workspace, size_t workspace_bytes, float* bev, void* stream);
 
 /*
  * stp3_lift_splat_bwd -- gradients of stp3_lift_splat_fwd composed with stp3_depth_softmax.
  * Replaces autograd through stp3.py:215-301 and VoxelsSumming.backward (geometry.py:320-330).
+ * Gather form (no atomics): one wave per image column re-fetches a voxel's gradient row only
+ * when the voxel id changes along the column.  Requires Z == 1, C <= 64, D <= 64.
  *   grad_bev   [B][T][C][X][Y]      dL/d(out)
  *   gacc       [B*T][V][C] float32  scratch (the discounted reverse accumulation of grad_bev)
  *   grad_feat  [B*T][N*fH*fW][C], grad_logits [B*T][N*fH*fW][D]   outputs, fully overwritten

@@ -25,12 +25,12 @@ d = plan.dims
 mats = [m.cuda() for m in ops.lift_matrices(intr, extr, ego)]
 lib = _lib.lib()
 counts = torch.zeros(d.BT, d.V, dtype=torch.int32, device='cuda')
-print('voxel_index us', ev_time(lambda: ops.voxel_index(grid, d, *mats, order=1, counts=counts)))
+print('voxel_index us', ev_time(lambda: ops.voxel_index(grid, d, *mats, order=1)))
 nb = ctypes.c_size_t(); lib.stp3_lift_plan_bytes(ctypes.byref(d), ctypes.byref(nb))
 pl = torch.empty(nb.value, dtype=torch.uint8, device='cuda')
 def build(det):
     counts.zero_()
-    vox = ops.voxel_index(grid, d, *mats, order=1, counts=counts)
+    vox = ops.voxel_index(grid, d, *mats, order=1)
     lib.stp3_lift_plan_build(ctypes.byref(d), ops._ptr(vox), ops._ptr(counts), ops._ptr(pl), nb, det, ops._stream())
 print('index+plan build (det) us', ev_time(lambda: build(1)))
 print('index+plan build (nondet) us', ev_time(lambda: build(0)))
@@ -39,7 +39,9 @@ l = logits.cuda().permute(0,1,2,4,5,3).reshape(d.BT, d.NPIX, d.D).contiguous()
 prob = ops.depth_softmax(d, l)
 print('softmax us', ev_time(lambda: ops.depth_softmax(d, l)))
 bev = torch.empty(d.B, d.T, d.C, d.X, d.Y, device='cuda')
-fwd = lambda: lib.stp3_lift_splat_fwd(ctypes.byref(d), ops._ptr(f), ops._ptr(prob), ops._ptr(plan.plan), ctypes.c_float(0.5), ops._ptr(bev), ops._stream())
+ws, wsb = ops.lift_workspace(d, 'cuda')
+fwd = lambda: lib.stp3_lift_splat_fwd(ctypes.byref(d), ops._ptr(f), ops._ptr(prob), ops._ptr(plan.vox_pm), ops._ptr(plan.plan), ctypes.c_float(0.5), ops._ptr(ws), ctypes.c_size_t(wsb), ops._ptr(bev), ops._stream())
+print('runs per (b,t):', plan.offsets()[:, -1].tolist(), ' points per (b,t):', d.P)
 us = ev_time(fwd)
 alg = d.BT * (d.NPIX * d.C * 4 + d.NPIX * d.D * 4 + d.C * d.V * 4)
 print(f'lift_splat_fwd us {us:.1f}  algorithmic {alg/1e6:.1f} MB -> {alg/us/1e6:.3f} TB/s ({alg/us/1e6/8*100:.1f}% of 8 TB/s)')

@@ -175,7 +175,7 @@ class LiftPlan:
         ego_t = mats[n_cam * 12 + b * s * 9:]
         counts = torch.zeros(dims.BT, dims.V, dtype=torch.int32, device=grid.device)
         with _timed('plan_build'):
-            vox_pm = voxel_index(grid, dims, cam_m, cam_t, ego_r, ego_t, VOX_PIXELMAJOR, counts)
+            vox_pm = voxel_index(grid, dims, cam_m, cam_t, ego_r, ego_t, VOX_PIXELMAJOR)
             plan = LiftPlan._finish(grid, dims, vox_pm, counts, deterministic)
         return plan
 
@@ -189,10 +189,21 @@ class LiftPlan:
         check(rc, 'stp3_lift_plan_build')
         return LiftPlan(dims, vox_pm, plan, counts)
 
-    def offsets(self):
-        """[BT, V+1] int32 view of the plan's offsets (for tests)."""
+    @staticmethod
+    def _align256(n):
+        return (n + 255) & ~255
+
+    def run_base(self):
+        """[BT, N*fW*D + 1] int32 view: exclusive scan of the runs per (camera, column, depth bin)."""
         d = self.dims
-        return self.plan[:d.BT * (d.V + 1) * 4].view(torch.int32).view(d.BT, d.V + 1)
+        nq = d.N * d.fW * d.D
+        return self.plan[:d.BT * (nq + 1) * 4].view(torch.int32).view(d.BT, nq + 1)
+
+    def offsets(self):
+        """[BT, V+1] int32 view: exclusive scan of the runs per voxel (= row ranges of the forward workspace)."""
+        d = self.dims
+        o = self._align256(d.BT * (d.N * d.fW * d.D + 1) * 4)
+        return self.plan[o:o + d.BT * (d.V + 1) * 4].view(torch.int32).view(d.BT, d.V + 1)
 
 
 def depth_softmax(dims, logits_pm):
@@ -201,6 +212,22 @@ def depth_softmax(dims, logits_pm):
     check(_lib.lib().stp3_depth_softmax(ctypes.byref(dims), _ptr(logits_pm), _ptr(prob), _stream()),
           'stp3_depth_softmax')
     return prob
+
+
+_WORKSPACE = {}
+
+
+def lift_workspace(dims, device):
+    """Scratch for the run vectors of ``stp3_lift_splat_fwd`` (one buffer per device, grown on demand and
+    reused by every call: it is dead as soon as the forward kernels have run)."""
+    nbytes = ctypes.c_size_t()
+    check(_lib.lib().stp3_lift_workspace_bytes(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_lift_workspace_bytes')
+    key = torch.device(device)
+    ws = _WORKSPACE.get(key)
+    if ws is None or ws.numel() < nbytes.value:
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=key)
+        _WORKSPACE[key] = ws
+    return ws, nbytes.value
 
 
 class _LiftSplat(torch.autograd.Function):
@@ -217,9 +244,11 @@ class _LiftSplat(torch.autograd.Function):
         with _timed('depth_softmax'):
             prob = depth_softmax(d, logits_pm)
         bev = torch.empty(d.B, d.T, d.C, d.X, d.Y, dtype=torch.float32, device=feat_pm.device)
+        ws, ws_bytes = lift_workspace(d, feat_pm.device)
         with _timed('lift_splat_fwd'):
-            rc = _lib.lib().stp3_lift_splat_fwd(ctypes.byref(d), _ptr(feat_pm), _ptr(prob), _ptr(lift_plan.plan),
-                                                ctypes.c_float(discount), _ptr(bev), _stream())
+            rc = _lib.lib().stp3_lift_splat_fwd(ctypes.byref(d), _ptr(feat_pm), _ptr(prob), _ptr(lift_plan.vox_pm),
+                                                _ptr(lift_plan.plan), ctypes.c_float(discount), _ptr(ws),
+                                                ctypes.c_size_t(ws_bytes), _ptr(bev), _stream())
         check(rc, 'stp3_lift_splat_fwd')
         ctx.save_for_backward(feat_pm, prob)
         ctx.lift_plan = lift_plan

@@ -25,6 +25,13 @@ def _sha(a):
     return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
 
 
+def _column_runs(vox):
+    """vox (BT, N, D, fH, fW) -> (run-start mask, ids): a run starts where the id differs from the
+    row above (same camera, depth bin and column) and is >= 0."""
+    prev = np.concatenate([np.full_like(vox[:, :, :, :1], -1), vox[:, :, :, :-1]], axis=3)
+    return (vox != prev) & (vox >= 0), vox
+
+
 def _grid(cfg, dev='cuda'):
     from stp3_amd import ops
     frustum, res, start, dim = H.grid_params(cfg)
@@ -65,12 +72,17 @@ def test_small_case_against_reference_golden():
     # pixel-major ids are the same ids, permuted
     pm = plan.vox_pm.view(2, 3, 2, grid.fH, grid.fW, grid.D).permute(0, 1, 2, 5, 3, 4).cpu().numpy()
     assert np.array_equal(pm, g['ref_vox'])
-    # plan offsets = exclusive scan of the per-voxel histogram
+    # plan structure: runs (maximal stretches of equal voxel id along an image column) counted per
+    # (camera, column, depth bin) and per voxel, both as exclusive scans
+    starts, ids = _column_runs(g['ref_vox'].reshape(6, 2, grid.D, grid.fH, grid.fW))
     off = plan.offsets().cpu().numpy()
+    base = plan.run_base().cpu().numpy()
     for bt in range(6):
-        ids = g['ref_vox'].reshape(6, -1)[bt]
-        hist = np.bincount(ids[ids >= 0], minlength=dims.V)
+        hist = np.bincount(ids[bt][starts[bt]], minlength=dims.V)
         assert np.array_equal(np.diff(off[bt]), hist)
+        per_q = starts[bt].sum(axis=2).transpose(0, 2, 1).reshape(-1)        # (n, d, w) -> (n, w, d)
+        assert np.array_equal(np.diff(base[bt]), per_q)
+        assert off[bt][-1] == base[bt][-1] == starts[bt].sum()
     exact = lo.pool_exact(feat, logits, g['ref_vox'], (32, 32), 0.5)
     torch.testing.assert_close(bev.double(), exact, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(bev, torch.from_numpy(g['ref_bev']), rtol=0, atol=1e-3)
