@@ -168,6 +168,68 @@ int stp3_dwconv2d_bwd_weight_workspace(const stp3_dwconv_dims* dims, size_t* byt
 int stp3_dwconv2d_bwd_weight(const stp3_dwconv_dims* dims, const void* x, const void* dy, float* dw,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused BatchNorm (+ per-sample bias) + activation (+ residual), channels-last, forward / backward.
+ * Replaces the nn.BatchNorm2d/3d -> ReLU / swish (-> "+ skip") chains of
+ * stp3/layers/convolutions.py:183-280, stp3/layers/temporal.py:252-273,315-325,426-489,
+ * stp3/models/decoder.py:22-140 and of the EfficientNet MBConv blocks driven by
+ * stp3/models/encoder.py:57-97; the statistics are handed back between the two passes so the host
+ * can all-reduce them over RCCL (train.py:47 sync_batchnorm=True).
+ *
+ *   x, y, res, dy, dx, dres : [N][rows][C] with row strides ldx (x, dx), ldy (y, dy), ldr (res, dres)
+ *                             elements, dtype STP3_DTYPE_F32 / _BF16 (16-byte vector path when C, the
+ *                             strides and the pointers allow it, scalar path otherwise)
+ *   sbias  [N][C] float32    optional per-sample bias added to x before the normalisation (the ASPP
+ *                             image-pooling branch and the pyramid-pooling branch are spatially
+ *                             constant: convolutions.py:242-270, temporal.py:375-423)
+ *   oscale [N]    float32    optional per-sample scale of the activated output (drop-connect)
+ *   forward : y = act(BN(x + sbias) [+ res if BEFORE_ACT]) * oscale [+ res if AFTER_ACT]
+ *   sums   [2][C] float32    sum and sum of squares of (x + sbias) over the `count` elements per
+ *                             channel they cover (N*rows locally; the host may add other ranks' sums)
+ *   stp3_bn_apply_fwd : sums != NULL -> training mode (batch statistics; writes save_mean /
+ *                       save_invstd [C]; updates running_mean / running_var with `momentum` and the
+ *                       unbiased variance when they are non-NULL); sums == NULL -> inference mode
+ *                       (running statistics).
+ *   stp3_bn_bwd_reduce: sample_sums [N][2][C] and sums [2][C] = sum of g and of g * xhat, where
+ *                       g = dy * oscale * act'(.) is the gradient at the BatchNorm output
+ *                       (dbeta = sums[0], dgamma = sums[1]; per-sample sums give the sbias gradient)
+ *   stp3_bn_apply_bwd : dx = gamma * invstd * (g - sums[0]/count - xhat * sums[1]/count)
+ *                       (sums == NULL: inference-mode BatchNorm, dx = gamma * invstd * g);
+ *                       dres (BEFORE_ACT only, may be NULL) = g.  For AFTER_ACT dres is dy itself.
+ *   workspace: stp3_bn_workspace_bytes(dims) bytes.  Deterministic (no atomics).
+ */
+#define STP3_ACT_NONE  0
+#define STP3_ACT_RELU  1
+#define STP3_ACT_SWISH 2
+#define STP3_RES_NONE       0
+#define STP3_RES_BEFORE_ACT 1
+#define STP3_RES_AFTER_ACT  2
+#define STP3_BN_MAX_ROW_BLOCKS 128
+
+typedef struct stp3_bn_dims {
+    int32_t N, rows, C;        /* samples, rows (H*W) per sample, channels          */
+    int32_t ldx, ldy, ldr;     /* row strides in elements                            */
+    int32_t dtype;             /* STP3_DTYPE_*                                       */
+    int32_t act, res_mode;     /* STP3_ACT_*, STP3_RES_*                             */
+    int32_t has_sbias, has_oscale;
+} stp3_bn_dims;
+
+int stp3_bn_workspace_bytes(const stp3_bn_dims* dims, size_t* bytes);
+int stp3_bn_stats(const stp3_bn_dims* dims, const void* x, const float* sbias, void* workspace,
+                  size_t workspace_bytes, float* sums, void* stream);
+int stp3_bn_apply_fwd(const stp3_bn_dims* dims, const void* x, const float* sbias, const void* res,
+                      const float* oscale, const float* sums, double count, const float* gamma,
+                      const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, float* save_mean, float* save_invstd, void* y, void* stream);
+int stp3_bn_bwd_reduce(const stp3_bn_dims* dims, const void* dy, const void* x, const float* sbias,
+                       const void* res, const float* oscale, const float* mean, const float* invstd,
+                       const float* gamma, const float* beta, void* workspace, size_t workspace_bytes,
+                       float* sample_sums, float* sums, void* stream);
+int stp3_bn_apply_bwd(const stp3_bn_dims* dims, const void* dy, const void* x, const float* sbias,
+                      const void* res, const float* oscale, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, const float* sums, double count, void* dx,
+                      void* dres, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

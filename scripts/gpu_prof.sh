@@ -5,10 +5,12 @@ TAG=${1:-run}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline "$@" > $OUT/prof.log 2>&1
+STEPS=4
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python bench.py --steps $STEPS --warmup 3 --no-cpu-baseline "$@" > $OUT/prof.log 2>&1
 grep '^{' $OUT/prof.log | tail -1 > $OUT/bench_profiled.json
 KT=$(find /tmp/prof_$TAG -name '*kernel_trace.csv' | head -1)
-[ -n "$KT" ] && python scripts/agg_trace.py $KT 0.55 90 > $OUT/steady_kernels.txt 2>&1
+MS=$(python -c "import json;print(json.load(open('$OUT/bench_profiled.json'))['ms_per_step']*($STEPS-1))" 2>/dev/null || echo 300)
+[ -n "$KT" ] && python scripts/agg_trace.py $KT $MS 80 > $OUT/steady_kernels.txt 2>&1
 find /tmp/prof_$TAG -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
 rm -rf /tmp/prof_$TAG
-cat $OUT/bench_profiled.json; head -50 $OUT/steady_kernels.txt; du -sh gpurun_out
+cat $OUT/bench_profiled.json; head -45 $OUT/steady_kernels.txt | cut -c1-200; du -sh gpurun_out

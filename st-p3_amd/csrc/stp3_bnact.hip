@@ -1,0 +1,565 @@
+// stp3_bnact.hip -- fused BatchNorm (+ per-sample bias) + activation (+ residual) for gfx950,
+// channels-last, forward and backward, with the batch statistics exposed between the two passes
+// so that the host can all-reduce them across ranks (cross-replica BatchNorm).
+//
+// Replaces the nn.BatchNorm2d/3d -> ReLU / swish (-> "+ skip") chains of the reference's hot path:
+//   stp3/layers/convolutions.py:183-280 (UpsamplingConcat, UpsamplingAdd, ASPP, DeepLabHead),
+//   stp3/layers/temporal.py:252-273, 315-325, 426-489 (CausalConv3d, conv_1x1x1_norm_activated,
+//   TemporalBlock), stp3/models/decoder.py:22-140 (ResNet-18 blocks, heads) and the MBConv blocks
+//   of the EfficientNet trunk that stp3/models/encoder.py:57-97 drives; sync_batchnorm=True of
+//   train.py:47 is served by the split statistics / apply interface.
+//
+// All of this is HBM-bound elementwise / reduction work: the kernels stream 16-byte channel
+// vectors (8 bf16 / 4 f32) of the [rows][C] matrix, accumulate in fp32, reduce deterministically
+// (two-stage partials, no atomics) and touch every tensor the minimum number of times:
+//   forward : stats pass reads x once; apply pass reads x (+res) once and writes y once
+//   backward: reduce pass reads dy, x (+res); apply pass reads dy, x (+res), writes dx (+dres)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <initializer_list>
+
+#include "stp3_hip.h"
+
+namespace {
+
+struct BnDims {
+    int N, rows, C, ldx, ldy, ldr;
+    int act, res_mode, has_sbias, has_oscale;
+};
+
+constexpr int kThreads = 256;
+
+// ---- element access ---------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+__device__ __forceinline__ uint16_t f2bf(float a) {   // round to nearest even
+    uint32_t u = __float_as_uint(a);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <typename T, int VEC> struct Io;
+template <> struct Io<float, 4> {
+    static __device__ void load(const float* p, float* f) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    }
+    static __device__ void store(float* p, const float* f) {
+        *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+    }
+};
+template <> struct Io<float, 1> {
+    static __device__ void load(const float* p, float* f) { f[0] = p[0]; }
+    static __device__ void store(float* p, const float* f) { p[0] = f[0]; }
+};
+template <> struct Io<uint16_t, 8> {
+    static __device__ void load(const uint16_t* p, float* f) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    static __device__ void store(uint16_t* p, const float* f) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(f[2 * i]) | ((uint32_t)f2bf(f[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+template <> struct Io<uint16_t, 1> {
+    static __device__ void load(const uint16_t* p, float* f) { f[0] = bf2f(p[0]); }
+    static __device__ void store(uint16_t* p, const float* f) { p[0] = f2bf(f[0]); }
+};
+
+// ---- thread -> (row lane, channel vector) mapping shared by all streaming kernels ---------------
+// grid = (row blocks, N samples, channel tiles); a block covers CVB channel vectors x RL row lanes,
+// RL a power of two so that the in-block reduction is a tree.
+struct Map {
+    int CV, CVB, RL, cv, rl;
+    bool live;
+};
+template <int VEC>
+__device__ __forceinline__ Map make_map(const BnDims& d) {
+    Map m;
+    m.CV = (d.C + VEC - 1) / VEC;
+    m.CVB = min(m.CV, kThreads);
+    int rl = 1;
+    while (rl * 2 * m.CVB <= kThreads) rl *= 2;
+    m.RL = rl;
+    const int cvb = threadIdx.x % m.CVB;
+    m.rl = threadIdx.x / m.CVB;
+    m.cv = blockIdx.z * m.CVB + cvb;
+    m.live = m.rl < m.RL && m.cv < m.CV;
+    return m;
+}
+
+__device__ __forceinline__ float act_fwd(int act, float v) {
+    if (act == STP3_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == STP3_ACT_SWISH) return v / (1.f + __expf(-v));
+    return v;
+}
+__device__ __forceinline__ float act_grad(int act, float pre) {
+    if (act == STP3_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
+    if (act == STP3_ACT_SWISH) {
+        const float s = 1.f / (1.f + __expf(-pre));
+        return s * (1.f + pre * (1.f - s));
+    }
+    return 1.f;
+}
+
+// In-block tree reduction over the row lanes of K values per thread, then one partial row per block:
+// partial[((n * gridDim.x + bx) * K + k) * C + c]
+template <int VEC, int K>
+__device__ __forceinline__ void block_reduce_store(const BnDims& d, const Map& m, float (*acc)[VEC], float* red,
+                                                   float* __restrict__ partial) {
+    const int cvb = threadIdx.x % m.CVB;
+    const int width = m.CVB * VEC;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        __syncthreads();
+        if (m.rl < m.RL) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) red[m.rl * width + cvb * VEC + j] = m.live ? acc[k][j] : 0.f;
+        }
+        __syncthreads();
+        for (int s = m.RL >> 1; s > 0; s >>= 1) {
+            if (m.rl < s) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) red[m.rl * width + cvb * VEC + j] += red[(m.rl + s) * width + cvb * VEC + j];
+            }
+            __syncthreads();
+        }
+        if (m.rl == 0 && m.cv < m.CV) {
+            float* out = partial + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * K + k) * d.C + m.cv * VEC;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                if (m.cv * VEC + j < d.C) out[j] = red[cvb * VEC + j];
+        }
+    }
+}
+
+// ---- forward statistics: per-channel sum and sum of squares of (x + sbias) ------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void bn_stats_kernel(BnDims d, const T* __restrict__ x,
+                                                            const float* __restrict__ sbias,
+                                                            float* __restrict__ partial) {
+    __shared__ float red[kThreads * VEC];
+    const Map m = make_map<VEC>(d);
+    const int n = blockIdx.y;
+    float acc[2][VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = 0.f;
+    if (m.live) {
+        const int c0 = m.cv * VEC;
+        float sb[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) sb[j] = (d.has_sbias && c0 + j < d.C) ? sbias[(size_t)n * d.C + c0 + j] : 0.f;
+        const T* xs = x + (size_t)n * d.rows * d.ldx + c0;
+        for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += gridDim.x * m.RL) {
+            float v[VEC];
+            Io<T, VEC>::load(xs + (size_t)r * d.ldx, v);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float t = v[j] + sb[j];
+                acc[0][j] += t;
+                acc[1][j] = fmaf(t, t, acc[1][j]);
+            }
+        }
+    }
+    block_reduce_store<VEC, 2>(d, m, acc, red, partial);
+}
+
+// ---- sums over partial rows: out[g][i] = sum_p partial[(g * parts + p) * width + i], in double ------
+__global__ __launch_bounds__(kThreads) void bn_reduce_partials_kernel(int parts, int width,
+                                                                      const float* __restrict__ partial,
+                                                                      float* __restrict__ out) {
+    __shared__ double red[kThreads];
+    const int il = threadIdx.x % 16, pl = threadIdx.x / 16;          // 16 columns x 16 part lanes
+    const int i = blockIdx.x * 16 + il;
+    const int g = blockIdx.y;
+    double s = 0.0;
+    if (i < width)
+        for (int p = pl; p < parts; p += 16) s += (double)partial[((size_t)g * parts + p) * width + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 8; st > 0; st >>= 1) {
+        if (pl < st) red[threadIdx.x] += red[threadIdx.x + st * 16];
+        __syncthreads();
+    }
+    if (pl == 0 && i < width) out[(size_t)g * width + i] = (float)red[il];
+}
+
+// per-channel scale / shift from the (global) sums; block (0,0,*) row lane 0 also records mean / invstd
+// and updates the running statistics (momentum, unbiased variance) exactly like nn.BatchNorm does
+template <int VEC>
+__device__ __forceinline__ void channel_affine(const BnDims& d, const Map& m, const float* __restrict__ sums,
+                                               float inv_count, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, float eps, float* mean, float* invstd,
+                                               float* scale, float* shift) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int c = m.cv * VEC + j;
+        if (c < d.C) {
+            mean[j] = sums[c] * inv_count;
+            const float var = fmaxf(sums[d.C + c] * inv_count - mean[j] * mean[j], 0.f);
+            invstd[j] = 1.0f / sqrtf(var + eps);
+            const float g = gamma ? gamma[c] : 1.f;
+            scale[j] = g * invstd[j];
+            shift[j] = (beta ? beta[c] : 0.f) - mean[j] * scale[j];
+        } else {
+            mean[j] = 0.f; invstd[j] = 0.f; scale[j] = 0.f; shift[j] = 0.f;
+        }
+    }
+}
+
+// ---- forward apply -------------------------------------------------------------------------------
+// y = act(((x + sbias) - mean) * invstd * gamma + beta [+ res]) [* oscale[n]] [+ res]
+// TRAIN: mean / invstd from `sums` (of `count` elements); else from the running statistics.
+template <typename T, int VEC, bool TRAIN>
+__global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
+    BnDims d, const T* __restrict__ x, const float* __restrict__ sbias, const T* __restrict__ res,
+    const float* __restrict__ oscale, const float* __restrict__ sums, float inv_count, float unbias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ save_mean,
+    float* __restrict__ save_invstd, T* __restrict__ y) {
+    const Map m = make_map<VEC>(d);
+    if (!m.live) return;
+    const int n = blockIdx.y;
+    const int c0 = m.cv * VEC;
+    float mean[VEC], invstd[VEC], scale[VEC], shift[VEC];
+    if (TRAIN) {
+        channel_affine<VEC>(d, m, sums, inv_count, gamma, beta, eps, mean, invstd, scale, shift);
+        if (blockIdx.x == 0 && n == 0 && m.rl == 0) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int c = c0 + j;
+                if (c < d.C) {
+                    save_mean[c] = mean[j];
+                    save_invstd[c] = invstd[j];
+                    if (running_mean) {
+                        const float var = fmaxf(sums[d.C + c] * inv_count - mean[j] * mean[j], 0.f);
+                        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[j];
+                        running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * unbias;
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = c0 + j;
+            if (c < d.C) {
+                const float is = 1.0f / sqrtf(running_var[c] + eps);
+                scale[j] = (gamma ? gamma[c] : 1.f) * is;
+                shift[j] = (beta ? beta[c] : 0.f) - running_mean[c] * scale[j];
+            } else {
+                scale[j] = shift[j] = 0.f;
+            }
+        }
+    }
+    if (d.has_sbias) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            if (c0 + j < d.C) shift[j] = fmaf(sbias[(size_t)n * d.C + c0 + j], scale[j], shift[j]);
+    }
+    const float os = d.has_oscale ? oscale[n] : 1.f;
+    const T* xs = x + (size_t)n * d.rows * d.ldx + c0;
+    const T* rs = d.res_mode ? res + (size_t)n * d.rows * d.ldr + c0 : nullptr;
+    T* ys = y + (size_t)n * d.rows * d.ldy + c0;
+    for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += gridDim.x * m.RL) {
+        float v[VEC], rv[VEC];
+        Io<T, VEC>::load(xs + (size_t)r * d.ldx, v);
+        if (d.res_mode) Io<T, VEC>::load(rs + (size_t)r * d.ldr, rv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float t = fmaf(v[j], scale[j], shift[j]);
+            if (d.res_mode == STP3_RES_BEFORE_ACT) t += rv[j];
+            t = act_fwd(d.act, t) * os;
+            if (d.res_mode == STP3_RES_AFTER_ACT) t += rv[j];
+            v[j] = t;
+        }
+        Io<T, VEC>::store(ys + (size_t)r * d.ldy, v);
+    }
+}
+
+// ---- backward reduce: per (sample, channel) sum of g and of g * xhat ----------------------------
+// g = dy * oscale[n] * act'(pre), pre = xhat * gamma + beta [+ res]
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
+    BnDims d, const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ sbias,
+    const T* __restrict__ res, const float* __restrict__ oscale, const float* __restrict__ mean_,
+    const float* __restrict__ invstd_, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ partial) {
+    __shared__ float red[kThreads * VEC];
+    const Map m = make_map<VEC>(d);
+    const int n = blockIdx.y;
+    float acc[2][VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = 0.f;
+    if (m.live) {
+        const int c0 = m.cv * VEC;
+        float mu[VEC], is[VEC], ga[VEC], be[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = c0 + j;
+            const bool ok = c < d.C;
+            const float sb = (ok && d.has_sbias) ? sbias[(size_t)n * d.C + c] : 0.f;
+            mu[j] = ok ? mean_[c] - sb : 0.f;         // xhat = ((x + sb) - mean) * invstd
+            is[j] = ok ? invstd_[c] : 0.f;
+            ga[j] = ok ? (gamma ? gamma[c] : 1.f) : 0.f;
+            be[j] = ok ? (beta ? beta[c] : 0.f) : 0.f;
+        }
+        const float os = d.has_oscale ? oscale[n] : 1.f;
+        const T* xs = x + (size_t)n * d.rows * d.ldx + c0;
+        const T* gs = dy + (size_t)n * d.rows * d.ldy + c0;
+        const T* rs = d.res_mode == STP3_RES_BEFORE_ACT ? res + (size_t)n * d.rows * d.ldr + c0 : nullptr;
+        for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += gridDim.x * m.RL) {
+            float v[VEC], g[VEC], rv[VEC];
+            Io<T, VEC>::load(xs + (size_t)r * d.ldx, v);
+            Io<T, VEC>::load(gs + (size_t)r * d.ldy, g);
+            if (rs) Io<T, VEC>::load(rs + (size_t)r * d.ldr, rv);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float xh = (v[j] - mu[j]) * is[j];
+                float gg = g[j] * os;
+                if (d.act != STP3_ACT_NONE) {
+                    float pre = fmaf(xh, ga[j], be[j]);
+                    if (rs) pre += rv[j];
+                    gg *= act_grad(d.act, pre);
+                }
+                acc[0][j] += gg;
+                acc[1][j] = fmaf(gg, xh, acc[1][j]);
+            }
+        }
+    }
+    block_reduce_store<VEC, 2>(d, m, acc, red, partial);
+}
+
+// ---- backward apply: dx = gamma * invstd * (g - sum(g)/M - xhat * sum(g*xhat)/M), dres ----------
+// TRAIN == false (running statistics are constants): dx = gamma * invstd * g
+template <typename T, int VEC, bool TRAIN>
+__global__ __launch_bounds__(kThreads) void bn_apply_bwd_kernel(
+    BnDims d, const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ sbias,
+    const T* __restrict__ res, const float* __restrict__ oscale, const float* __restrict__ mean_,
+    const float* __restrict__ invstd_, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ gsums, float inv_count, T* __restrict__ dx, T* __restrict__ dres) {
+    const Map m = make_map<VEC>(d);
+    if (!m.live) return;
+    const int n = blockIdx.y;
+    const int c0 = m.cv * VEC;
+    float mu[VEC], is[VEC], ga[VEC], be[VEC], k0[VEC], k1[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int c = c0 + j;
+        const bool ok = c < d.C;
+        const float sb = (ok && d.has_sbias) ? sbias[(size_t)n * d.C + c] : 0.f;
+        mu[j] = ok ? mean_[c] - sb : 0.f;
+        is[j] = ok ? invstd_[c] : 0.f;
+        ga[j] = ok ? (gamma ? gamma[c] : 1.f) : 0.f;
+        be[j] = ok ? (beta ? beta[c] : 0.f) : 0.f;
+        k0[j] = (TRAIN && ok) ? gsums[c] * inv_count : 0.f;
+        k1[j] = (TRAIN && ok) ? gsums[d.C + c] * inv_count : 0.f;
+    }
+    const float os = d.has_oscale ? oscale[n] : 1.f;
+    const T* xs = x + (size_t)n * d.rows * d.ldx + c0;
+    const T* gs = dy + (size_t)n * d.rows * d.ldy + c0;
+    const bool pre_res = d.res_mode == STP3_RES_BEFORE_ACT;
+    const T* rs = pre_res ? res + (size_t)n * d.rows * d.ldr + c0 : nullptr;
+    T* dxs = dx + (size_t)n * d.rows * d.ldx + c0;
+    T* drs = (pre_res && dres) ? dres + (size_t)n * d.rows * d.ldr + c0 : nullptr;
+    for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += gridDim.x * m.RL) {
+        float v[VEC], g[VEC], rv[VEC];
+        Io<T, VEC>::load(xs + (size_t)r * d.ldx, v);
+        Io<T, VEC>::load(gs + (size_t)r * d.ldy, g);
+        if (rs) Io<T, VEC>::load(rs + (size_t)r * d.ldr, rv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float xh = (v[j] - mu[j]) * is[j];
+            float gg = g[j] * os;
+            if (d.act != STP3_ACT_NONE) {
+                float pre = fmaf(xh, ga[j], be[j]);
+                if (rs) pre += rv[j];
+                gg *= act_grad(d.act, pre);
+            }
+            g[j] = gg;                                             // gradient w.r.t. the pre-activation
+            v[j] = ga[j] * is[j] * (gg - k0[j] - xh * k1[j]);
+        }
+        Io<T, VEC>::store(dxs + (size_t)r * d.ldx, v);
+        if (drs) Io<T, VEC>::store(drs + (size_t)r * d.ldr, g);
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------
+inline int status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? STP3_OK : -(int)e;
+}
+
+struct Launch {
+    BnDims d;
+    int vec;       // 8 / 4 (vector path) or 1
+    bool bf16;
+    dim3 grid;
+    int parts;     // partial rows = N * grid.x
+};
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+inline int plan(const stp3_bn_dims* p, Launch* L, std::initializer_list<const void*> vec_ptrs) {
+    if (!p) return STP3_EINVAL;
+    if (p->N <= 0 || p->rows <= 0 || p->C <= 0 || p->ldx < p->C || p->ldy < p->C) return STP3_EINVAL;
+    if (p->dtype != STP3_DTYPE_F32 && p->dtype != STP3_DTYPE_BF16) return STP3_EUNSUP;
+    if (p->act < STP3_ACT_NONE || p->act > STP3_ACT_SWISH) return STP3_EINVAL;
+    if (p->res_mode < STP3_RES_NONE || p->res_mode > STP3_RES_AFTER_ACT) return STP3_EINVAL;
+    if (p->res_mode != STP3_RES_NONE && p->ldr < p->C) return STP3_EINVAL;
+    if ((int64_t)p->N * p->rows >= (1LL << 31)) return STP3_EUNSUP;
+    L->bf16 = p->dtype == STP3_DTYPE_BF16;
+    const int wide = L->bf16 ? 8 : 4;
+    bool vec_ok = p->C % wide == 0 && p->ldx % wide == 0 && p->ldy % wide == 0 &&
+                  (p->res_mode == STP3_RES_NONE || p->ldr % wide == 0);
+    for (const void* q : vec_ptrs) vec_ok = vec_ok && (q == nullptr || aligned16(q));
+    L->vec = vec_ok ? wide : 1;
+    BnDims& d = L->d;
+    d.N = p->N; d.rows = p->rows; d.C = p->C; d.ldx = p->ldx; d.ldy = p->ldy; d.ldr = p->ldr;
+    d.act = p->act; d.res_mode = p->res_mode; d.has_sbias = p->has_sbias; d.has_oscale = p->has_oscale;
+    const int CV = (p->C + L->vec - 1) / L->vec;
+    const int CVB = CV < kThreads ? CV : kThreads;
+    int RL = 1;
+    while (RL * 2 * CVB <= kThreads) RL *= 2;
+    const int ctiles = (CV + CVB - 1) / CVB;
+    // ~1024 blocks in total, at least 8 rows per row lane
+    int bx = (1024 + p->N * ctiles - 1) / (p->N * ctiles);
+    const int max_bx = (p->rows + RL * 8 - 1) / (RL * 8);
+    if (bx > max_bx) bx = max_bx;
+    if (bx < 1) bx = 1;
+    if (bx > STP3_BN_MAX_ROW_BLOCKS) bx = STP3_BN_MAX_ROW_BLOCKS;
+    L->grid = dim3(bx, p->N, ctiles);
+    L->parts = p->N * bx;
+    return STP3_OK;
+}
+
+// run CALL with `T` / `VEC` bound to the launch's element type and vector width
+#define BN_SWITCH(L, ...)                                                       \
+    do {                                                                        \
+        if ((L).bf16) {                                                         \
+            if ((L).vec == 8) { using T = uint16_t; constexpr int VEC = 8; __VA_ARGS__; } \
+            else              { using T = uint16_t; constexpr int VEC = 1; __VA_ARGS__; } \
+        } else {                                                                \
+            if ((L).vec == 4) { using T = float; constexpr int VEC = 4; __VA_ARGS__; }    \
+            else              { using T = float; constexpr int VEC = 1; __VA_ARGS__; }    \
+        }                                                                       \
+    } while (0)
+
+inline size_t ws_bytes(const stp3_bn_dims* p) {
+    return (size_t)p->N * STP3_BN_MAX_ROW_BLOCKS * 2 * p->C * sizeof(float);
+}
+
+// partial [groups][parts][width] -> out [groups][width]
+inline void reduce_partials(int groups, int parts, int width, const float* partial, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3((width + 15) / 16, groups), dim3(kThreads), 0, s, parts, width,
+                       partial, out);
+}
+
+}  // namespace
+
+extern "C" {
+
+int stp3_bn_workspace_bytes(const stp3_bn_dims* p, size_t* bytes) {
+    if (!p || !bytes || p->N <= 0 || p->C <= 0) return STP3_EINVAL;
+    *bytes = ws_bytes(p);
+    return STP3_OK;
+}
+
+int stp3_bn_stats(const stp3_bn_dims* p, const void* x, const float* sbias, void* workspace, size_t workspace_bytes,
+                  float* sums, void* stream) {
+    Launch L;
+    int rc = plan(p, &L, {x});
+    if (rc) return rc;
+    if (!x || !workspace || !sums || (p->has_sbias && !sbias)) return STP3_EINVAL;
+    if (workspace_bytes < ws_bytes(p)) return STP3_ENOSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    BN_SWITCH(L, hipLaunchKernelGGL((bn_stats_kernel<T, VEC>), L.grid, dim3(kThreads), 0, s, L.d, (const T*)x, sbias,
+                                     partial));
+    reduce_partials(1, L.parts, 2 * p->C, partial, sums, s);
+    return status();
+}
+
+int stp3_bn_apply_fwd(const stp3_bn_dims* p, const void* x, const float* sbias, const void* res, const float* oscale,
+                      const float* sums, double count, const float* gamma, const float* beta, float eps,
+                      float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                      void* y, void* stream) {
+    Launch L;
+    int rc = plan(p, &L, {x, res, y});
+    if (rc) return rc;
+    if (!x || !y || (p->has_sbias && !sbias) || (p->res_mode != STP3_RES_NONE && !res) ||
+        (p->has_oscale && !oscale))
+        return STP3_EINVAL;
+    const bool train = sums != nullptr;
+    if (train && (!save_mean || !save_invstd || !(count >= 1.0))) return STP3_EINVAL;
+    if (train && ((running_mean == nullptr) != (running_var == nullptr))) return STP3_EINVAL;
+    if (!train && (!running_mean || !running_var)) return STP3_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const float inv_count = train ? (float)(1.0 / count) : 0.f;
+    const float unbias = (train && count > 1.0) ? (float)(count / (count - 1.0)) : 1.f;
+    if (train)
+        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_fwd_kernel<T, VEC, true>), L.grid, dim3(kThreads), 0, s, L.d,
+                                         (const T*)x, sbias, (const T*)res, oscale, sums, inv_count, unbias, gamma,
+                                         beta, eps, momentum, running_mean, running_var, save_mean, save_invstd,
+                                         (T*)y));
+    else
+        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_fwd_kernel<T, VEC, false>), L.grid, dim3(kThreads), 0, s, L.d,
+                                         (const T*)x, sbias, (const T*)res, oscale, sums, inv_count, unbias, gamma,
+                                         beta, eps, momentum, running_mean, running_var, save_mean, save_invstd,
+                                         (T*)y));
+    return status();
+}
+
+int stp3_bn_bwd_reduce(const stp3_bn_dims* p, const void* dy, const void* x, const float* sbias, const void* res,
+                       const float* oscale, const float* mean, const float* invstd, const float* gamma,
+                       const float* beta, void* workspace, size_t workspace_bytes, float* sample_sums,
+                       float* sums, void* stream) {
+    Launch L;
+    int rc = plan(p, &L, {dy, x, res});
+    if (rc) return rc;
+    if (!dy || !x || !mean || !invstd || !workspace || !sample_sums || !sums || (p->has_sbias && !sbias) ||
+        (p->res_mode == STP3_RES_BEFORE_ACT && !res) || (p->has_oscale && !oscale))
+        return STP3_EINVAL;
+    if (workspace_bytes < ws_bytes(p)) return STP3_ENOSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    BN_SWITCH(L, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC>), L.grid, dim3(kThreads), 0, s, L.d, (const T*)dy,
+                                     (const T*)x, sbias, (const T*)res, oscale, mean, invstd, gamma, beta, partial));
+    reduce_partials(p->N, (int)L.grid.x, 2 * p->C, partial, sample_sums, s);     // [N][2][C]
+    reduce_partials(1, p->N, 2 * p->C, sample_sums, sums, s);                     // [2][C]
+    return status();
+}
+
+int stp3_bn_apply_bwd(const stp3_bn_dims* p, const void* dy, const void* x, const float* sbias, const void* res,
+                      const float* oscale, const float* mean, const float* invstd, const float* gamma,
+                      const float* beta, const float* sums, double count, void* dx, void* dres, void* stream) {
+    Launch L;
+    int rc = plan(p, &L, {dy, x, res, dx, dres});
+    if (rc) return rc;
+    if (!dy || !x || !mean || !invstd || !dx || (p->has_sbias && !sbias) ||
+        (p->res_mode == STP3_RES_BEFORE_ACT && !res) || (p->has_oscale && !oscale))
+        return STP3_EINVAL;
+    const bool train = sums != nullptr;
+    if (train && !(count >= 1.0)) return STP3_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const float inv_count = train ? (float)(1.0 / count) : 0.f;
+    if (train)
+        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, VEC, true>), L.grid, dim3(kThreads), 0, s, L.d,
+                                         (const T*)dy, (const T*)x, sbias, (const T*)res, oscale, mean, invstd, gamma,
+                                         beta, sums, inv_count, (T*)dx, (T*)dres));
+    else
+        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, VEC, false>), L.grid, dim3(kThreads), 0, s, L.d,
+                                         (const T*)dy, (const T*)x, sbias, (const T*)res, oscale, mean, invstd, gamma,
+                                         beta, sums, inv_count, (T*)dx, (T*)dres));
+    return status();
+}
+
+}  // extern "C"

@@ -43,13 +43,24 @@ class DwConvDims(ctypes.Structure):
                                               'dtype')]
 
 
+class BnDims(ctypes.Structure):
+    """struct stp3_bn_dims (include/stp3_hip.h)."""
+    _fields_ = [(k, ctypes.c_int32) for k in ('N', 'rows', 'C', 'ldx', 'ldy', 'ldr', 'dtype', 'act', 'res_mode',
+                                              'has_sbias', 'has_oscale')]
+
+
 DTYPE_F32 = 0
 DTYPE_BF16 = 1
 
 VOX_REFERENCE = 0
 VOX_PIXELMAJOR = 1
 
+ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
+RES_NONE, RES_BEFORE_ACT, RES_AFTER_ACT = 0, 1, 2
+
 _DIMS_P = ctypes.POINTER(LiftDims)
+_BN_P = ctypes.POINTER(BnDims)
+c_double = ctypes.c_double
 _DW_P = ctypes.POINTER(DwConvDims)
 
 # name -> (restype, argtypes); mirrors include/stp3_hip.h one to one
@@ -67,6 +78,12 @@ SIGNATURES = {
     'stp3_dwconv2d_bwd_data': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_dwconv2d_bwd_weight_workspace': (c_int, [_DW_P, ctypes.POINTER(c_size_t)]),
     'stp3_dwconv2d_bwd_weight': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'stp3_bn_workspace_bytes': (c_int, [_BN_P, ctypes.POINTER(c_size_t)]),
+    'stp3_bn_stats': (c_int, [_BN_P, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    'stp3_bn_apply_fwd': (c_int, [_BN_P] + [c_void_p] * 5 + [c_double, c_void_p, c_void_p, c_float, c_float]
+                          + [c_void_p] * 6),
+    'stp3_bn_bwd_reduce': (c_int, [_BN_P] + [c_void_p] * 10 + [c_size_t, c_void_p, c_void_p, c_void_p]),
+    'stp3_bn_apply_bwd': (c_int, [_BN_P] + [c_void_p] * 10 + [c_double, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -14,6 +14,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, run_fused
+
 
 def _conv_bn_relu(in_ch, out_ch, k, padding=0, dilation=1):
     return [nn.Conv2d(in_ch, out_ch, k, padding=padding, dilation=dilation, bias=False), nn.BatchNorm2d(out_ch),
@@ -30,7 +32,7 @@ class UpsamplingConcat(nn.Module):
                                   *_conv_bn_relu(out_channels, out_channels, 3, padding=1))
 
     def forward(self, x_to_upsample, x):
-        return self.conv(torch.cat([x, self.upsample(x_to_upsample)], dim=1))
+        return run_fused(self.conv, torch.cat([x, self.upsample(x_to_upsample)], dim=1))
 
 
 class UpsamplingAdd(nn.Module):
@@ -43,7 +45,8 @@ class UpsamplingAdd(nn.Module):
             nn.Conv2d(in_channels, out_channels, 1, bias=False), nn.BatchNorm2d(out_channels))
 
     def forward(self, x, x_skip):
-        return self.upsample_layer(x) + x_skip
+        up, conv, bn = self.upsample_layer
+        return bn_act(bn, conv(up(x)), ACT_NONE, res=x_skip, res_mode=RES_AFTER_ACT)
 
 
 class ASPPConv(nn.Sequential):
@@ -67,7 +70,7 @@ class ASPPConv(nn.Sequential):
             y = F.conv2d(x, wgt[:, :, :, 1:2], padding=(d, 0), dilation=(d, 1))
         else:
             y = conv(x)
-        return act(bn(y))
+        return bn_act(bn, y, ACT_RELU)
 
 
 class ASPPPooling(nn.Sequential):
@@ -97,13 +100,16 @@ class ASPP(nn.Module):
                                      nn.BatchNorm2d(out_channels), nn.ReLU(), nn.Dropout(0.5))
 
     def forward(self, x):
-        spatial = torch.cat([conv(x) for conv in self.convs[:-1]], dim=1)
+        branches = [run_fused(self.convs[0], x)] + [conv(x) for conv in self.convs[1:-1]]
+        spatial = torch.cat(branches, dim=1)
         pooled = self.convs[-1](x)                                   # (N, C, 1, 1)
         proj, bn, act, drop = self.project
         n_sp = spatial.shape[1]
         y = F.conv2d(spatial, proj.weight[:, :n_sp])
-        y = y + F.conv2d(pooled.to(y.dtype), proj.weight[:, n_sp:])  # constant plane == per-sample bias
-        return drop(act(bn(y)))
+        # the pooled branch is a constant plane per sample: its projection is a per-sample bias, folded
+        # into the fused BatchNorm instead of a broadcast add over the whole map
+        sbias = F.conv2d(pooled.to(y.dtype), proj.weight[:, n_sp:]).flatten(1).float()
+        return drop(bn_act(bn, y, ACT_RELU, sbias=sbias))
 
 
 class DeepLabHead(nn.Sequential):
@@ -111,3 +117,6 @@ class DeepLabHead(nn.Sequential):
         super().__init__(ASPP(in_channels, [12, 24, 36], hidden_channel),
                          nn.Conv2d(hidden_channel, hidden_channel, 3, padding=1, bias=False),
                          nn.BatchNorm2d(hidden_channel), nn.ReLU(), nn.Conv2d(hidden_channel, num_classes, 1))
+
+    def forward(self, x):
+        return run_fused(self, x)

@@ -1,0 +1,123 @@
+"""BatchNorm + activation (+ residual) as ONE operator.
+
+The reference chains ``nn.BatchNorm2d/3d -> nn.ReLU`` (or swish in the EfficientNet trunk) and adds
+skips as separate elementwise passes (stp3/layers/convolutions.py:183-280, stp3/layers/temporal.py:
+252-273, 315-325, 426-489, stp3/models/decoder.py:22-140).  ``bn_act`` takes the BatchNorm *module*
+(so parameter / buffer names, momentum, eps and train/eval state stay exactly the reference's) and
+runs the whole chain through the HIP kernels of ``stp3_bnact.hip`` on GPU tensors; with more than one
+rank the batch statistics are all-reduced (the reference trains with ``sync_batchnorm=True``,
+train.py:47).
+
+CPU tensors (the gloo data-parallel tests, the CPU port timed by ``bench.py``) and degenerate 1x1 maps
+take ``bn_act_reference``: the same arithmetic written with torch ops.  GPU tensors never fall back: a
+missing ``libstp3hip.so`` raises.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+ACT_NONE, ACT_RELU, ACT_SWISH = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_SWISH
+RES_NONE, RES_BEFORE_ACT, RES_AFTER_ACT = ops.RES_NONE, ops.RES_BEFORE_ACT, ops.RES_AFTER_ACT
+
+
+def _sync_world(bn):
+    if not (bn.training and dist.is_available() and dist.is_initialized()):
+        return 1
+    if getattr(bn, 'stp3_local_stats', False):
+        return 1
+    return dist.get_world_size()
+
+
+def _act(act, y):
+    if act == ACT_RELU:
+        return F.relu(y)
+    if act == ACT_SWISH:
+        return F.silu(y)
+    return y
+
+
+def bn_act_reference(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=None):
+    """Plain-torch statement of ``bn_act`` (any device, any rank count; differentiable)."""
+    shape = [1, -1] + [1] * (x.dim() - 2)
+    lead = [x.shape[0], -1] + [1] * (x.dim() - 2)
+    if sbias is not None:
+        x = x + sbias.to(x.dtype).view(lead)
+    use_batch = bn.training or not bn.track_running_stats
+    if use_batch:
+        dims = [0] + list(range(2, x.dim()))
+        xf = x.float()
+        count = float(xf.numel() // xf.shape[1])
+        s, q = xf.sum(dims), (xf * xf).sum(dims)
+        if _sync_world(bn) > 1:
+            import torch.distributed.nn.functional as dfn
+            packed = dfn.all_reduce(torch.cat([s, q]))
+            s, q = packed[:s.numel()], packed[s.numel():]
+            count *= dist.get_world_size()
+        mean = s / count
+        var = (q / count - mean * mean).clamp_min(0.0)
+        if bn.training and bn.track_running_stats:
+            with torch.no_grad():
+                mom = bn.momentum if bn.momentum is not None else 0.1
+                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(var * (count / max(count - 1.0, 1.0)), alpha=mom)
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked.add_(1)
+    else:
+        mean, var = bn.running_mean.float(), bn.running_var.float()
+    scale = torch.rsqrt(var + bn.eps)
+    shift = -mean * scale
+    if bn.weight is not None:
+        scale = scale * bn.weight.float()
+        shift = shift * bn.weight.float() + bn.bias.float()
+    y = (x.float() * scale.view(shape) + shift.view(shape)).to(x.dtype)
+    if res is not None and res_mode == RES_BEFORE_ACT:
+        y = y + res.to(y.dtype)
+    y = _act(act, y)
+    if oscale is not None:
+        y = y * oscale.to(y.dtype).view([-1] + [1] * (y.dim() - 1))
+    if res is not None and res_mode == RES_AFTER_ACT:
+        y = y + res.to(y.dtype)
+    return y
+
+
+def bn_act(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=None):
+    """y = act(bn(x + sbias) [+ res if BEFORE_ACT]) * oscale [+ res if AFTER_ACT].
+
+    ``bn``: the nn.BatchNorm2d / nn.BatchNorm3d / nn.SyncBatchNorm module (its forward is not called);
+    x (N, C, H, W); sbias (N, C) per-sample bias; oscale (N,) per-sample scale; res like x."""
+    if res is None:
+        res_mode = RES_NONE
+    if not (x.is_cuda and x.dim() == 4 and x.shape[2] * x.shape[3] > 1):
+        return bn_act_reference(bn, x, act, res, res_mode, sbias, oscale)
+    if torch.is_autocast_enabled() and x.dtype == torch.float32:
+        x = x.to(torch.get_autocast_gpu_dtype())
+    training = bn.training or not bn.track_running_stats
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    group = None if _sync_world(bn) > 1 else False
+    return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                      bn.running_var if bn.track_running_stats else None, training, bn.momentum, bn.eps,
+                      act=act, res=res, res_mode=res_mode, sbias=sbias, oscale=oscale, group=group)
+
+
+def run_fused(seq, x):
+    """Run an ``nn.Sequential`` with every ``BatchNorm -> ReLU`` pair (or lone BatchNorm) fused."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.modules.batchnorm._BatchNorm):
+            if i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+                x = bn_act(m, x, ACT_RELU)
+                i += 2
+                continue
+            x = bn_act(m, x, ACT_NONE)
+        elif isinstance(m, nn.Sequential):
+            x = run_fused(m, x)
+        else:
+            x = m(x)
+        i += 1
+    return x

@@ -14,6 +14,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act
+
 
 def _pad8(c):
     return (c + 7) // 8 * 8
@@ -35,14 +37,10 @@ def _conv2d_padded_channels(x, weight, padding=0):
     return y[:, :co] if cop != co else y
 
 
-def _bn_act_2d(norm, x, relu=True):
+def _bn_act_2d(norm, x, relu=True, res=None, sbias=None):
     """BatchNorm3d over (B,C,T,H,W) == batch norm over (B*T,C,H,W): apply the 3-D module's statistics
-    and affine parameters to the frame-folded 4-D tensor."""
-    if norm.training and norm.track_running_stats and norm.num_batches_tracked is not None:
-        norm.num_batches_tracked.add_(1)
-    y = F.batch_norm(x, norm.running_mean, norm.running_var, norm.weight, norm.bias,
-                     norm.training or not norm.track_running_stats, norm.momentum, norm.eps)
-    return F.relu(y, inplace=True) if relu else y
+    and affine parameters to the frame-folded 4-D tensor (fused with the ReLU / skip add)."""
+    return bn_act(norm, x, ACT_RELU if relu else ACT_NONE, res=res, res_mode=RES_AFTER_ACT, sbias=sbias)
 
 
 class CausalConv3d(nn.Module):
@@ -185,17 +183,23 @@ class TemporalBlock(nn.Module):
         agg = self.aggregation[0]
         wgt = agg.conv.weight[:, :, 0]                                   # (Cout, Cin_total, 1, 1)
         y = _conv2d_padded_channels(paths, wgt[:, :self._paths_channels])
+        sbias = None
         if self.use_pyramid_pooling:
             off = self._paths_channels
             for pooled in self.pyramid_pooling(x):                       # (B, C', T, h', w')
                 cp = pooled.shape[1]
                 p2 = pooled.permute(0, 2, 1, 3, 4).reshape(b * t, cp, *pooled.shape[-2:])
                 contrib = F.conv2d(p2.to(y.dtype), wgt[:, off:off + cp].to(y.dtype))
-                if contrib.shape[-2:] != (1, 1) and contrib.shape[-2:] != (h, w):
-                    contrib = F.interpolate(contrib, (h, w), mode='bilinear', align_corners=False)
-                y = y + contrib                                          # 1x1 map: broadcast == bilinear upsample
+                if contrib.shape[-2:] == (1, 1):
+                    # whole-plane pooling (the reference's only setting): a constant plane per frame, i.e. a
+                    # per-sample bias of the aggregation -- folded into the fused BatchNorm
+                    contrib = contrib.flatten(1).float()
+                    sbias = contrib if sbias is None else sbias + contrib
+                else:
+                    if contrib.shape[-2:] != (h, w):
+                        contrib = F.interpolate(contrib, (h, w), mode='bilinear', align_corners=False)
+                    y = y + contrib
                 off += cp
-        y = _bn_act_2d(agg.norm, y)
         skip = x2 if self.projection is None else self._pointwise(self.projection, x2, relu=False)
-        out = skip + y
+        out = _bn_act_2d(agg.norm, y, res=skip, sbias=sbias)
         return out.view(b, t, -1, h, w).permute(0, 2, 1, 3, 4)

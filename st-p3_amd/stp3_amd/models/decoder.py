@@ -4,6 +4,7 @@ dictionary (``None`` for disabled heads)."""
 import torch.nn as nn
 
 from ..layers.convolutions import UpsamplingAdd
+from ..layers.fused import ACT_RELU, bn_act, run_fused
 from .resnet import resnet18
 
 
@@ -55,7 +56,7 @@ class Decoder(nn.Module):
         b, s, c, h, w = x.shape
         x = x.reshape(b * s, c, h, w)
         skip1 = x
-        x = self.layer1(self.relu(self.bn1(self.first_conv(x))))      # 1/2
+        x = self.layer1(bn_act(self.bn1, self.first_conv(x), ACT_RELU))  # 1/2
         skip2 = x
         x = self.layer2(x)                                            # 1/4
         skip3 = x
@@ -69,11 +70,11 @@ class Decoder(nn.Module):
 
         present = x.view(b, s, *x.shape[1:])[:, self.n_present - 1]    # decoder.py:122
         return {
-            'segmentation': per_frame(self.segmentation_head(x)),
-            'pedestrian': per_frame(self.pedestrian_head(x) if self.predict_pedestrian else None),
-            'hdmap': self.hdmap_head(present) if self.perceive_hdmap else None,
-            'instance_center': per_frame(self.instance_center_head(x) if self.predict_instance else None),
-            'instance_offset': per_frame(self.instance_offset_head(x) if self.predict_instance else None),
-            'instance_flow': per_frame(self.instance_future_head(x) if self.predict_future_flow else None),
-            'costvolume': per_frame(self.costvolume_head(x).squeeze(1) if self.planning else None),
+            'segmentation': per_frame(run_fused(self.segmentation_head, x)),
+            'pedestrian': per_frame(run_fused(self.pedestrian_head, x) if self.predict_pedestrian else None),
+            'hdmap': run_fused(self.hdmap_head, present) if self.perceive_hdmap else None,
+            'instance_center': per_frame(run_fused(self.instance_center_head, x) if self.predict_instance else None),
+            'instance_offset': per_frame(run_fused(self.instance_offset_head, x) if self.predict_instance else None),
+            'instance_flow': per_frame(run_fused(self.instance_future_head, x) if self.predict_future_flow else None),
+            'costvolume': per_frame(run_fused(self.costvolume_head, x).squeeze(1) if self.planning else None),
         }

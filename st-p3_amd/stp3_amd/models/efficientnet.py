@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..layers.fused import ACT_NONE, ACT_SWISH, RES_AFTER_ACT, bn_act
 
 # (repeats, kernel, stride, expand, in, out) of the 7 base stages, SE ratio 0.25 everywhere
 _BASE_STAGES = ((1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
@@ -92,20 +93,21 @@ class MBConvBlock(nn.Module):
     def forward(self, inputs, drop_connect_rate=None):
         x = inputs
         if self.expand != 1:
-            x = self._swish(self._bn0(self._expand_conv(x)))
-        x = self._swish(self._bn1(self._depthwise_conv(x)))
+            x = bn_act(self._bn0, self._expand_conv(x), ACT_SWISH)
+        x = bn_act(self._bn1, self._depthwise_conv(x), ACT_SWISH)
         # squeeze and excitation
         s = x.mean((2, 3), keepdim=True)
         s = self._se_expand(self._swish(self._se_reduce(s)))
         x = torch.sigmoid(s) * x
-        x = self._bn2(self._project_conv(x))
+        x = self._project_conv(x)
         if self.stride == 1 and self.in_ch == self.out_ch:
+            oscale = None
             if drop_connect_rate and self.training:
+                # drop-connect: the branch of sample n is scaled by mask_n / keep before the skip is added
                 keep = 1.0 - drop_connect_rate
-                mask = torch.floor(keep + torch.rand(x.shape[0], 1, 1, 1, dtype=x.dtype, device=x.device))
-                x = x / keep * mask
-            x = x + inputs
-        return x
+                oscale = torch.floor(keep + torch.rand(x.shape[0], dtype=torch.float32, device=x.device)) / keep
+            return bn_act(self._bn2, x, ACT_NONE, res=inputs, res_mode=RES_AFTER_ACT, oscale=oscale)
+        return bn_act(self._bn2, x, ACT_NONE)
 
 
 class EfficientNet(nn.Module):

@@ -7,6 +7,7 @@ import math
 import torch.nn as nn
 
 from ..layers.convolutions import DeepLabHead, UpsamplingConcat
+from ..layers.fused import ACT_SWISH, bn_act
 from .efficientnet import EfficientNet
 
 _REDUCTION_CHANNELS = {'b4': [0, 24, 32, 56, 160, 448], 'b0': [0, 16, 24, 40, 112, 320]}
@@ -49,7 +50,7 @@ class Encoder(nn.Module):
         plus the final tensor), encoder.py:59-82."""
         bb = self.backbone
         endpoints = []
-        x = bb._swish(bb._bn0(bb._conv_stem(x)))
+        x = bn_act(bb._bn0, bb._conv_stem(x), ACT_SWISH)
         n_blocks = len(bb._blocks)
         base_rate = bb._global_params.drop_connect_rate
         for idx, block in enumerate(bb._blocks):

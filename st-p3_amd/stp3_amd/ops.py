@@ -352,3 +352,178 @@ def depthwise_conv2d(x, weight, stride=1, pad=(0, 0, 0, 0)):
     if torch.is_autocast_enabled():
         x = x.to(torch.get_autocast_gpu_dtype())
     return _DepthwiseConv2d.apply(x, weight, int(stride), tuple(int(p) for p in pad))
+
+
+# ----------------------------------------------------------------------------------------------
+# fused BatchNorm (+ per-sample bias) + activation (+ residual), cross-replica statistics
+# ----------------------------------------------------------------------------------------------
+ACT_NONE, ACT_RELU, ACT_SWISH = _lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_SWISH
+RES_NONE, RES_BEFORE_ACT, RES_AFTER_ACT = _lib.RES_NONE, _lib.RES_BEFORE_ACT, _lib.RES_AFTER_ACT
+
+_BN_WORKSPACE = {}
+
+
+def _bn_workspace(dims, device):
+    nbytes = ctypes.c_size_t()
+    check(_lib.lib().stp3_bn_workspace_bytes(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_bn_workspace_bytes')
+    key = torch.device(device)
+    ws = _BN_WORKSPACE.get(key)
+    if ws is None or ws.numel() < nbytes.value:
+        ws = torch.empty(max(nbytes.value, 1 << 20), dtype=torch.uint8, device=key)
+        _BN_WORKSPACE[key] = ws
+    return ws, nbytes.value
+
+
+def _rows_view(t):
+    """(N, C, H, W) tensor -> (tensor whose memory is [N][H*W][ld] channels-last, ld).  Channels-last tensors
+    and channel-slices of them are used in place; anything else is copied to channels-last once."""
+    n, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    if c > 1 and sc != 1:
+        ok = False
+    else:
+        ld = sw if w > 1 else (sh if h > 1 else (sn if n > 1 else c))
+        ok = ld >= c and (w == 1 or sw == ld) and (h == 1 or sh == w * ld) and (n == 1 or sn == h * w * ld)
+    if not ok:
+        t = t.contiguous(memory_format=torch.channels_last)
+        ld = c
+    return t, ld
+
+
+def _opt_ptr(t):
+    return _ptr(t) if t is not None else None
+
+
+def _f32(t):
+    return None if t is None else t.detach().float().contiguous()
+
+
+class _BnAct(torch.autograd.Function):
+    """y = act(BN(x + sbias) [+ res]) * oscale [+ res] on (N, C, H, W) tensors, channels-last memory."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, sbias, oscale, running_mean, running_var, training, momentum, eps,
+                act, res_mode, group):
+        _need_gpu(x)
+        if x.dtype == torch.bfloat16:
+            dt = _lib.DTYPE_BF16
+        elif x.dtype == torch.float32:
+            dt = _lib.DTYPE_F32
+        else:
+            raise _lib.Stp3HipError(f'bn_act supports float32 / bfloat16, got {x.dtype}')
+        n, c, h, w = x.shape
+        x, ldx = _rows_view(x)
+        ldr = c
+        if res is not None:
+            if res.shape != x.shape:
+                raise _lib.Stp3HipError('bn_act: residual shape mismatch')
+            res, ldr = _rows_view(res.to(x.dtype))
+        else:
+            res_mode = RES_NONE
+        y = torch.empty((n, c, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        dims = _lib.BnDims(n, h * w, c, ldx, c, ldr, dt, int(act), int(res_mode), int(sbias is not None),
+                           int(oscale is not None))
+        lib = _lib.lib()
+        gamma, beta = _f32(weight), _f32(bias)
+        sb, osc = _f32(sbias), _f32(oscale)
+        world = 1
+        if training:
+            ws, ws_bytes = _bn_workspace(dims, x.device)
+            packed = torch.empty(2 * c + 1, dtype=torch.float32, device=x.device)
+            check(lib.stp3_bn_stats(ctypes.byref(dims), _ptr(x), _opt_ptr(sb), _ptr(ws), ctypes.c_size_t(ws_bytes),
+                                    _ptr(packed), _stream()), 'stp3_bn_stats')
+            count = float(n * h * w)
+            if group is not False and torch.distributed.is_available() and torch.distributed.is_initialized():
+                world = torch.distributed.get_world_size(group)
+            if world > 1:
+                # cross-replica statistics (train.py:47 sync_batchnorm): one small all-reduce per layer;
+                # every rank holds the same number of elements (the batch is sharded evenly)
+                torch.distributed.all_reduce(packed[:2 * c], group=group)
+                count *= world
+            mean = torch.empty(c, dtype=torch.float32, device=x.device)
+            invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+            check(lib.stp3_bn_apply_fwd(ctypes.byref(dims), _ptr(x), _opt_ptr(sb), _opt_ptr(res), _opt_ptr(osc),
+                                        _ptr(packed), ctypes.c_double(count), _opt_ptr(gamma), _opt_ptr(beta),
+                                        ctypes.c_float(eps), ctypes.c_float(momentum), _opt_ptr(running_mean),
+                                        _opt_ptr(running_var), _ptr(mean), _ptr(invstd), _ptr(y), _stream()),
+                  'stp3_bn_apply_fwd')
+        else:
+            count = 0.0
+            mean = running_mean.detach().float()
+            invstd = torch.rsqrt(running_var.detach().float() + eps)
+            check(lib.stp3_bn_apply_fwd(ctypes.byref(dims), _ptr(x), _opt_ptr(sb), _opt_ptr(res), _opt_ptr(osc),
+                                        None, ctypes.c_double(0.0), _opt_ptr(gamma), _opt_ptr(beta),
+                                        ctypes.c_float(eps), ctypes.c_float(0.0), _ptr(running_mean),
+                                        _ptr(running_var), None, None, _ptr(y), _stream()), 'stp3_bn_apply_fwd')
+        ctx.save_for_backward(x, res if res_mode == RES_BEFORE_ACT else None, sb, osc, gamma, beta, mean, invstd)
+        ctx.dims, ctx.training, ctx.count, ctx.world, ctx.group = dims, training, count, world, group
+        ctx.res_dtype = None if res is None else res.dtype
+        ctx.has_affine = (weight is not None, bias is not None)
+        ctx.in_dtypes = (None if weight is None else weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, res, sb, osc, gamma, beta, mean, invstd = ctx.saved_tensors
+        dims = ctx.dims
+        n, rows, c = dims.N, dims.rows, dims.C
+        lib = _lib.lib()
+        dy = dy.to(x.dtype)
+        dy, ldy = _rows_view(dy)
+        if ldy != c:
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        ws, ws_bytes = _bn_workspace(dims, x.device)
+        sample_sums = torch.empty(n, 2, c, dtype=torch.float32, device=x.device)
+        sums = torch.empty(2, c, dtype=torch.float32, device=x.device)
+        check(lib.stp3_bn_bwd_reduce(ctypes.byref(dims), _ptr(dy), _ptr(x), _opt_ptr(sb), _opt_ptr(res), _opt_ptr(osc),
+                                     _ptr(mean), _ptr(invstd), _opt_ptr(gamma), _opt_ptr(beta), _ptr(ws),
+                                     ctypes.c_size_t(ws_bytes), _ptr(sample_sums), _ptr(sums), _stream()),
+              'stp3_bn_bwd_reduce')
+        dgamma = sums[1].to(ctx.in_dtypes[0]) if ctx.has_affine[0] and ctx.needs_input_grad[1] else None
+        dbeta = sums[0].to(ctx.in_dtypes[1]) if ctx.has_affine[1] and ctx.needs_input_grad[2] else None
+        gsums = sums
+        if ctx.training and ctx.world > 1:
+            gsums = sums.clone()
+            torch.distributed.all_reduce(gsums, group=ctx.group)
+        dx = torch.empty_like(x)                      # same (possibly channel-sliced) strides as x
+        if dx.stride() != x.stride():
+            dx = torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device)
+        dres = None
+        if dims.res_mode == RES_BEFORE_ACT and ctx.needs_input_grad[3]:
+            dres = torch.empty((n, c) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device,
+                               memory_format=torch.channels_last)
+            bdims = _lib.BnDims(dims.N, dims.rows, dims.C, dims.ldx, dims.ldy, c, dims.dtype, dims.act,
+                                dims.res_mode, dims.has_sbias, dims.has_oscale)
+            # the reduce pass read `res` with its own stride; the apply pass writes dres densely, so it needs
+            # res dense too (one stride for both)
+            if dims.ldr != c:
+                res = res.contiguous(memory_format=torch.channels_last)
+        else:
+            bdims = dims
+        check(lib.stp3_bn_apply_bwd(ctypes.byref(bdims), _ptr(dy), _ptr(x), _opt_ptr(sb), _opt_ptr(res),
+                                    _opt_ptr(osc), _ptr(mean), _ptr(invstd), _opt_ptr(gamma), _opt_ptr(beta),
+                                    _ptr(gsums) if ctx.training else None, ctypes.c_double(max(ctx.count, 1.0)),
+                                    _ptr(dx), _opt_ptr(dres), _stream()), 'stp3_bn_apply_bwd')
+        if dims.res_mode == RES_AFTER_ACT and ctx.needs_input_grad[3]:
+            dres = dy
+        if dres is not None and ctx.res_dtype is not None and dres.dtype != ctx.res_dtype:
+            dres = dres.to(ctx.res_dtype)
+        dsbias = None
+        if sb is not None and ctx.needs_input_grad[4]:
+            g = gamma if gamma is not None else torch.ones_like(invstd)
+            if ctx.training:
+                k = gsums / ctx.count
+                dsbias = g * invstd * (sample_sums[:, 0] - rows * k[0] - sample_sums[:, 1] * k[1])
+            else:
+                dsbias = g * invstd * sample_sums[:, 0]
+        return dx, dgamma, dbeta, dres, dsbias, None, None, None, None, None, None, None, None, None
+
+
+def bn_act(x, weight, bias, running_mean, running_var, training, momentum, eps, act=ACT_NONE, res=None,
+           res_mode=RES_NONE, sbias=None, oscale=None, group=None):
+    """Fused BatchNorm + activation (+ residual) through the HIP kernels (GPU tensors only).
+    ``group=False`` disables the cross-replica statistics even when torch.distributed is initialised."""
+    if res is None:
+        res_mode = RES_NONE
+    return _BnAct.apply(x, weight, bias, res, sbias, oscale, running_mean, running_var, bool(training),
+                        float(momentum if momentum is not None else 0.1), float(eps), int(act), int(res_mode), group)

@@ -98,3 +98,40 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch():
         opt.step()
     ref = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     torch.testing.assert_close(out[0], ref, rtol=1e-5, atol=1e-6)
+
+
+def _bn_worker(rank, world, port, out):
+    from stp3_amd.layers import fused
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(5)
+    bn = nn.BatchNorm2d(6)
+    x = torch.randn(4, 6, 5, 7)
+    gy = torch.randn(4, 6, 5, 7)
+    sl = slice(2 * rank, 2 * rank + 2)
+    xa = x[sl].clone().requires_grad_(True)
+    y = fused.bn_act(bn, xa, fused.ACT_RELU)
+    y.backward(gy[sl])
+    out[rank] = (y.detach(), xa.grad, bn.running_var.clone())
+    dist.destroy_process_group()
+
+
+def test_cross_replica_batchnorm_statistics_on_cpu():
+    """bn_act with 2 ranks x half the batch == 1 process x whole batch (the reference's sync_batchnorm)."""
+    from stp3_amd.layers import fused
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bn_worker, args=(2, port, out), nprocs=2, join=True)
+    torch.manual_seed(5)
+    bn = nn.BatchNorm2d(6)
+    x = torch.randn(4, 6, 5, 7)
+    gy = torch.randn(4, 6, 5, 7)
+    xa = x.clone().requires_grad_(True)
+    y = fused.bn_act(bn, xa, fused.ACT_RELU)
+    y.backward(gy)
+    torch.testing.assert_close(torch.cat([out[0][0], out[1][0]]), y.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(torch.cat([out[0][1], out[1][1]]), xa.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(out[0][2], bn.running_var, rtol=1e-5, atol=1e-6)
