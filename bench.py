@@ -10,9 +10,15 @@ EfficientNet-B4 encoder -> HIP lift / voxel pool -> temporal model -> BEV decode
 weak scaling: every rank gets its own B=4 (global batch 4N), gradients are all-reduced over RCCL
 and BatchNorm statistics are synchronised (the reference's DDP + sync_batchnorm recipe).
 
+At N=1 the whole step (forward, backward, gradient clip, Adam) is captured once into a hipGraph and
+replayed per batch (stp3_amd/graph.py); per batch the host only rebuilds the geometry-only pooling plan.
+With N>1 the step contains RCCL collectives and runs eagerly.
+
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      the voxel-pool forward kernel (stp3_lift_splat_fwd): algorithmic bytes per launch /
-                its HIP-event time on the stream it runs on, against the 8 TB/s HBM3E peak
+  roofline      the voxel-pool forward (stp3_lift_splat_fwd = its two kernels): algorithmic bytes per
+                launch / HIP-event time of launches on the stream they run on (measured live in this
+                process on the bench shape, right after the timed steps), against the 8 TB/s HBM3E peak;
+                `traffic` = PMC HBM bytes per launch from profiles/lift_pmc.json (rocprofv3 --pmc passes)
   cpu_baseline  the CPU port of the same step (oracle/cpu_model.py: reference algorithm for the
                 lift, same torch modules) timed on this box's host cores on a bounded sample
 """
@@ -101,28 +107,76 @@ def cpu_baseline(max_seconds=40.0):
                       f'cumsum VoxelsSumming)'}
 
 
+def lift_roofline(device, batch, batch_size, iters=30):
+    """HIP-event timing of the voxel-pool C-ABI calls at the bench shape, on the stream they are launched on."""
+    from stp3_amd import ops
+    from tests import helpers as H
+    cfg = H.FULL
+    frustum, res, start, dim = H.grid_params(cfg)
+    grid = ops.LiftGrid(frustum, res, start, dim, device)
+    plan = ops.LiftPlan.build(grid, batch['intrinsics'], batch['extrinsics'], batch['future_egomotion'], 64)
+    d = plan.dims
+    g = torch.Generator(device='cpu').manual_seed(7)
+    feat = torch.relu(torch.randn(d.BT, d.NPIX, d.C, generator=g)).to(device)
+    logits = (torch.randn(d.BT, d.NPIX, d.D, generator=g) * 2.0).to(device)
+    feat.requires_grad_(True)
+    logits.requires_grad_(True)
+    grad = torch.randn(d.B, d.T, d.C, d.X, d.Y, generator=g).to(device)
+    for _ in range(3):
+        bev = ops._LiftSplat.apply(feat, logits, plan, 0.5)
+        bev.backward(grad)
+    ops.PROFILE.clear()
+    ops.PROFILE_ENABLED = True
+    for _ in range(iters):
+        bev = ops._LiftSplat.apply(feat, logits, plan, 0.5)
+        bev.backward(grad)
+        ops.LiftPlan.build(grid, batch['intrinsics'], batch['extrinsics'], batch['future_egomotion'], 64, out=plan)
+    prof = ops.profile_summary()
+    ops.PROFILE_ENABLED = False
+    alg_fwd = d.BT * (d.NPIX * d.C * 4 + d.NPIX * d.D * 4 + d.C * d.V * 4)      # feat + depth prob + BEV planes
+    alg_bwd = d.BT * (d.C * d.V * 4 + 2 * d.NPIX * d.C * 4 + 2 * d.NPIX * d.D * 4)
+    fwd_ms = prof['lift_splat_fwd']['avg_ms']
+    ach = alg_fwd / (fwd_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, 'profiles', 'lift_pmc.json')
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path))
+            traffic = sum(pmc[k][f] for k in ('lift_runs', 'lift_gather') for f in ('hbm_read_bytes', 'hbm_write_bytes'))
+        except Exception:
+            traffic = None
+    roof = {'kernel': 'stp3_lift_splat_fwd (lift_runs_kernel + lift_gather_kernel)', 'bound': 'hbm',
+            'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+            'traffic': traffic, 'algorithmic_bytes_per_launch': alg_fwd, 'avg_launch_ms': round(fwd_ms, 4),
+            'launches': prof['lift_splat_fwd']['n'],
+            'backward': {'algorithmic_bytes_per_launch': alg_bwd,
+                         'avg_launch_ms': round(prof['lift_splat_bwd']['avg_ms'], 4),
+                         'achieved': round(alg_bwd / (prof['lift_splat_bwd']['avg_ms'] * 1e-3) / 1e9, 1)}}
+    return roof, {k: round(v['avg_ms'], 4) for k, v in prof.items()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=4, help='samples per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch the step eagerly even on one GPU')
     args = ap.parse_args()
 
-    from stp3_amd import ops
     from stp3_amd.parallel import FlatAdam, GradientBuckets, init_distributed
     rank, world, local = init_distributed()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
 
-    module, cfg = build_module(device, sync_bn=world > 1)
+    module, cfg = build_module(device, sync_bn=False)          # cross-replica BN statistics are built into bn_act
     buckets = GradientBuckets(module.model)
     opt = FlatAdam(buckets, lr=cfg.OPTIMIZER.LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY)   # trainer.py:456-462
     batch = make_device_batch(args.batch, device, seed=100 + rank)
 
-    def step():
+    def eager_step():
         buckets.zero_grad()
         with torch.autocast('cuda', dtype=torch.bfloat16):
             loss = module.training_step(batch)
@@ -132,10 +186,21 @@ def main():
         opt.step()
         return loss
 
+    mode = 'eager'
+    step = eager_step
+    if world == 1 and not args.no_graph:
+        from stp3_amd.graph import GraphedTrainStep
+        try:
+            runner = GraphedTrainStep(module, buckets, opt, cfg.GRAD_NORM_CLIP, batch)
+            step = lambda: runner(batch)
+            mode = 'hipGraph'
+        except Exception as e:                                  # capture is an optimisation, never a requirement
+            print(f'[bench] hipGraph capture failed ({e!r}); running eagerly', file=sys.stderr)
+            module.model.prebuilt_plan = None
+            torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         step()
-    ops.PROFILE.clear()
-    ops.PROFILE_ENABLED = True
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -146,7 +211,6 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    ops.PROFILE_ENABLED = False
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -154,17 +218,8 @@ def main():
     assert torch.isfinite(loss).item(), 'loss is not finite'
 
     if rank == 0:
-        prof = ops.profile_summary()
-        d = ops.make_dims(args.batch, 3, 6, 48, 28, 60, 64, 200, 200, 1)
-        alg_fwd = d.BT * (d.NPIX * d.C * 4 + d.NPIX * d.D * 4 + d.C * d.V * 4)   # feat + depth + BEV planes
-        fwd_ms = prof.get('lift_splat_fwd', {}).get('avg_ms')
-        roof = None
-        if fwd_ms:
-            ach = alg_fwd / (fwd_ms * 1e-3) / 1e9
-            roof = {'kernel': 'stp3_lift_splat_fwd', 'bound': 'hbm', 'achieved': round(ach, 1),
-                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
-                    'algorithmic_bytes_per_launch': alg_fwd, 'avg_launch_ms': round(fwd_ms, 4),
-                    'launches': prof['lift_splat_fwd']['n']}
+        module.model.prebuilt_plan = None
+        roof, kernel_ms = lift_roofline(device, batch, args.batch)
         line = {
             'metric': 'BEV samples/sec (6-cam x 3-frame fwd+bwd)', 'value': round(args.batch * world * args.steps / elapsed, 3),
             'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -172,9 +227,9 @@ def main():
             'vs_baseline': None, 'dtype': 'bf16 convs / f32 voxel pool', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[2]: batch=4/GPU, 6-cam 224x480, T=3, full STP3 fwd+bwd '
                                    '(seg+ped+hdmap losses), grad-clip 5, Adam; EfficientNet-B4, D=48, C=64, BEV 200x200',
-                       'global_batch': args.batch * world, 'parallelism': f'dp{world}'},
+                       'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'launch': mode},
             'roofline': roof,
-            'kernel_ms': {k: round(v['avg_ms'], 4) for k, v in prof.items()},
+            'kernel_ms': kernel_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

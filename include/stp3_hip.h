@@ -190,9 +190,10 @@ int stp3_dwconv2d_bwd_weight(const stp3_dwconv_dims* dims, const void* x, const 
  *                       save_invstd [C]; updates running_mean / running_var with `momentum` and the
  *                       unbiased variance when they are non-NULL); sums == NULL -> inference mode
  *                       (running statistics).
- *   stp3_bn_bwd_reduce: sample_sums [N][2][C] and sums [2][C] = sum of g and of g * xhat, where
+ *   stp3_bn_bwd_reduce: sample_sums [N][3][C] and sums [3][C] = sums of g, g * xhat and xhat, where
  *                       g = dy * oscale * act'(.) is the gradient at the BatchNorm output
- *                       (dbeta = sums[0], dgamma = sums[1]; per-sample sums give the sbias gradient)
+ *                       (dbeta = sums[0], dgamma = sums[1]; the per-sample sums give the sbias gradient
+ *                        gamma*invstd*(Sg_n - rows*sums[0]/count - Sxhat_n*sums[1]/count))
  *   stp3_bn_apply_bwd : dx = gamma * invstd * (g - sums[0]/count - xhat * sums[1]/count)
  *                       (sums == NULL: inference-mode BatchNorm, dx = gamma * invstd * g);
  *                       dres (BEFORE_ACT only, may be NULL) = g.  For AFTER_ACT dres is dy itself.

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
     }
 }
 
-// ---- backward reduce: per (sample, channel) sum of g and of g * xhat ----------------------------
+// ---- backward reduce: per (sample, channel) sums of g, g * xhat and xhat -----------------------
 // g = dy * oscale[n] * act'(pre), pre = xhat * gamma + beta [+ res]
 template <typename T, int VEC>
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
@@ -296,9 +296,9 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
     __shared__ float red[kThreads * VEC];
     const Map m = make_map<VEC>(d);
     const int n = blockIdx.y;
-    float acc[2][VEC];
+    float acc[3][VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = 0.f;
+    for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.f;
     if (m.live) {
         const int c0 = m.cv * VEC;
         float mu[VEC], is[VEC], ga[VEC], be[VEC];
@@ -332,10 +332,11 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
                 }
                 acc[0][j] += gg;
                 acc[1][j] = fmaf(gg, xh, acc[1][j]);
+                acc[2][j] += xh;                                    // needed for the per-sample bias gradient
             }
         }
     }
-    block_reduce_store<VEC, 2>(d, m, acc, red, partial);
+    block_reduce_store<VEC, 3>(d, m, acc, red, partial);
 }
 
 // ---- backward apply: dx = gamma * invstd * (g - sum(g)/M - xhat * sum(g*xhat)/M), dres ----------
@@ -454,7 +455,7 @@ inline int plan(const stp3_bn_dims* p, Launch* L, std::initializer_list<const vo
     } while (0)
 
 inline size_t ws_bytes(const stp3_bn_dims* p) {
-    return (size_t)p->N * STP3_BN_MAX_ROW_BLOCKS * 2 * p->C * sizeof(float);
+    return (size_t)p->N * STP3_BN_MAX_ROW_BLOCKS * 3 * p->C * sizeof(float);
 }
 
 // partial [groups][parts][width] -> out [groups][width]
@@ -533,8 +534,8 @@ int stp3_bn_bwd_reduce(const stp3_bn_dims* p, const void* dy, const void* x, con
     float* partial = (float*)workspace;
     BN_SWITCH(L, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC>), L.grid, dim3(kThreads), 0, s, L.d, (const T*)dy,
                                      (const T*)x, sbias, (const T*)res, oscale, mean, invstd, gamma, beta, partial));
-    reduce_partials(p->N, (int)L.grid.x, 2 * p->C, partial, sample_sums, s);     // [N][2][C]
-    reduce_partials(1, p->N, 2 * p->C, sample_sums, sums, s);                     // [2][C]
+    reduce_partials(p->N, (int)L.grid.x, 3 * p->C, partial, sample_sums, s);     // [N][3][C]
+    reduce_partials(1, p->N, 3 * p->C, sample_sums, sums, s);                     // [3][C]
     return status();
 }
 

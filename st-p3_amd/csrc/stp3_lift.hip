@@ -352,6 +352,11 @@ __global__ __launch_bounds__(256) void depth_softmax_kernel(int64_t npix_total, 
     }
 }
 
+// v_readlane_b32 on a float (the builtin is typed int: pass the bits, not the value)
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
 // ------------------------------------------------------------------------------------------
 // K2+K4: stage 1 -- depth (x) feature outer product reduced along image columns (camera side)
 // ------------------------------------------------------------------------------------------
@@ -368,12 +373,14 @@ __global__ __launch_bounds__(1024) void lift_runs_kernel(Dims dm, const float* _
                                                          const int32_t* __restrict__ run_base,
                                                          const int32_t* __restrict__ dest,
                                                          float* __restrict__ runs) {
+    extern __shared__ float fcol[];                       // [fH][64]: the column's feature rows
+    static_assert(DG == 8, "lane = (row of an 8-row block, bin) assumes 8 bins per wave");
     const int lane = threadIdx.x & 63;
     const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
     const int col = blockIdx.x, bt = blockIdx.y;
     const int n = col / dm.fW, w = col - n * dm.fW;
     const int d0 = g * DG;
-    if (d0 >= dm.D) return;
     const bool chan = lane < dm.C;
     const size_t pix0 = (size_t)bt * dm.NPIX + (size_t)n * dm.fH * dm.fW + w;   // pixel of row h = pix0 + h*fW
     const float* frow = feat + pix0 * dm.C + lane;
@@ -384,42 +391,59 @@ __global__ __launch_bounds__(1024) void lift_runs_kernel(Dims dm, const float* _
     const int32_t* dst = dest + (size_t)bt * dm.P;
     float* out = runs + (size_t)bt * dm.P * dm.C + lane;
 
+    // stage the feature rows once per workgroup: every wave (depth group) of the column reuses them
+    for (int h = g; h < dm.fH; h += nwaves) fcol[h * 64 + lane] = chan ? frow[(size_t)h * fstride] : 0.f;
+    __syncthreads();
+
     int cur[DG], rid[DG];
     float acc[DG];
 #pragma unroll
     for (int j = 0; j < DG; ++j) {
         cur[j] = -1;
-        rid[j] = (d0 + j < dm.D) ? rb[j] : 0;
+        rid[j] = (EXACT || d0 + j < dm.D) ? rb[j] : 0;
         acc[j] = 0.f;
     }
-    // bins past D (last group of a D that is not a multiple of DG) alias the group's last valid bin
-    int jj[DG];
+    // prob / voxel ids of 32 rows x 8 bins are fetched with 4 + 4 vector loads (lane = (row, bin)) and
+    // broadcast with v_readlane: the point loop itself touches no global memory except the run stores.
+    const int hl = lane >> 3;                                               // row inside an 8-row block
+    const int jl = EXACT ? (lane & 7) : min(lane & 7, dm.D - 1 - d0);       // bins past D alias the last valid bin
+    for (int h0 = 0; h0 < dm.fH; h0 += 32) {
+        float P[4];
+        int V[4];
 #pragma unroll
-    for (int j = 0; j < DG; ++j) jj[j] = EXACT ? j : min(j, dm.D - 1 - d0);
-    float f = chan ? frow[0] : 0.f;
-    for (int h = 0; h < dm.fH; ++h) {
-        const float fh = f;
-        if (h + 1 < dm.fH) f = chan ? frow[(size_t)(h + 1) * fstride] : 0.f;   // prefetch the next row
-        int v[DG];
-        float p[DG];
-#pragma unroll
-        for (int j = 0; j < DG; ++j) {                                         // wave-uniform: scalar loads
-            v[j] = vrow[(size_t)h * dstride + jj[j]];
-            p[j] = prow[(size_t)h * dstride + jj[j]];
+        for (int k = 0; k < 4; ++k) {
+            const int row = h0 + k * 8 + hl;
+            const bool ok = row < dm.fH;
+            P[k] = ok ? prow[(size_t)row * dstride + jl] : 0.f;
+            V[k] = ok ? vrow[(size_t)row * dstride + jl] : -1;
         }
 #pragma unroll
-        for (int j = 0; j < DG; ++j) {
-            if (EXACT || d0 + j < dm.D) {
-                if (v[j] != cur[j]) {
-                    if (cur[j] >= 0) {
-                        const int row = dst[rid[j]];
-                        if (chan) out[(size_t)row * dm.C] = acc[j];
-                        ++rid[j];
+        for (int k = 0; k < 4; ++k) {
+            const int hb = h0 + k * 8;
+            if (hb < dm.fH) {
+                const int nr = min(8, dm.fH - hb);
+                float fnext = fcol[hb * 64 + lane];
+                for (int r = 0; r < nr; ++r) {
+                    const float fh = fnext;
+                    if (r + 1 < nr) fnext = fcol[(hb + r + 1) * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < DG; ++j) {
+                        if (EXACT || d0 + j < dm.D) {
+                            const int v = __builtin_amdgcn_readlane(V[k], r * 8 + j);
+                            const float p = readlane_f(P[k], r * 8 + j);
+                            if (v != cur[j]) {
+                                if (cur[j] >= 0) {
+                                    const int row = dst[rid[j]];
+                                    if (chan) out[(size_t)row * dm.C] = acc[j];
+                                    ++rid[j];
+                                }
+                                acc[j] = 0.f;
+                                cur[j] = v;
+                            }
+                            acc[j] = fmaf(p, fh, acc[j]);
+                        }
                     }
-                    acc[j] = 0.f;
-                    cur[j] = v[j];
                 }
-                acc[j] = fmaf(p[j], fh, acc[j]);
             }
         }
     }
@@ -442,11 +466,6 @@ __global__ __launch_bounds__(1024) void lift_runs_kernel(Dims dm, const float* _
 // written out transposed, i.e. as 256-B coalesced rows of the reference's [C][X*Y] planes.
 constexpr int kTileV = 64;
 constexpr int kTilePad = 65;
-
-// v_readlane_b32 on a float (the builtin is typed int: pass the bits, not the value)
-__device__ __forceinline__ float readlane_f(float v, int lane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
 
 __global__ __launch_bounds__(256) void lift_gather_kernel(Dims dm, const float* __restrict__ runs,
                                                           const int32_t* __restrict__ vox_off, float discount,
@@ -724,11 +743,13 @@ int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const flo
     hipStream_t s = (hipStream_t)stream;
     constexpr int DG = 8;
     const int ndg = (dm.D + DG - 1) / DG;
+    const size_t lds = (size_t)dm.fH * 64 * sizeof(float);
+    if (lds > 64 * 1024) return STP3_EUNSUP;   // fH <= 256
     if (dm.D % DG == 0)
-        hipLaunchKernelGGL((lift_runs_kernel<DG, true>), dim3(dm.NCOL, dm.BT), dim3(64 * ndg), 0, s, dm, feat, prob,
+        hipLaunchKernelGGL((lift_runs_kernel<DG, true>), dim3(dm.NCOL, dm.BT), dim3(64 * ndg), lds, s, dm, feat, prob,
                            vox_pm, pv.run_base, pv.dest, (float*)workspace);
     else
-        hipLaunchKernelGGL((lift_runs_kernel<DG, false>), dim3(dm.NCOL, dm.BT), dim3(64 * ndg), 0, s, dm, feat, prob,
+        hipLaunchKernelGGL((lift_runs_kernel<DG, false>), dim3(dm.NCOL, dm.BT), dim3(64 * ndg), lds, s, dm, feat, prob,
                            vox_pm, pv.run_base, pv.dest, (float*)workspace);
     hipLaunchKernelGGL(lift_gather_kernel, dim3((dm.V + kTileV - 1) / kTileV, dm.B), dim3(256), 0, s, dm,
                        (const float*)workspace, pv.vox_off, discount, bev);

@@ -83,9 +83,8 @@ class ASPPPooling(nn.Sequential):
     def forward(self, x):
         """Returns the (N, C, 1, 1) pooled descriptor; bilinear upsampling of a 1x1 map is a
         broadcast, which ``ASPP`` folds into its projection."""
-        for mod in self:
-            x = mod(x)
-        return x
+        pool, conv, bn, _ = self
+        return bn_act(bn, conv(pool(x)), ACT_RELU)       # 1x1 map: plain-torch path (statistics still cross-replica)
 
 
 class ASPP(nn.Module):

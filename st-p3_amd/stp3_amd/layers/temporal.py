@@ -123,7 +123,8 @@ class PyramidSpatioTemporalPooling(nn.Module):
                 # all T+1 (so the BatchNorm batch statistics include the last, right-padded window) and
                 # only then drops it.
                 pooled = torch.cat([sp[:, :, :1], 0.5 * (sp[:, :, 1:] + sp[:, :, :-1]), sp[:, :, -1:]], dim=2)
-                out.append(f.conv_bn_relu(pooled.to(x.dtype))[:, :, :-1])
+                cbr = f.conv_bn_relu
+                out.append(bn_act(cbr.norm, cbr.conv(pooled.to(x.dtype)), ACT_RELU)[:, :, :-1])
             else:
                 out.append(f(x)[:, :, :-1])
         return out

@@ -37,7 +37,8 @@ class SpatialRegressionLoss(nn.Module):
 class SegmentationLoss(nn.Module):
     def __init__(self, class_weights, ignore_index=255, use_top_k=False, top_k_ratio=1.0, future_discount=1.0):
         super().__init__()
-        self.class_weights = class_weights
+        # a (non-persistent) buffer: moves with the module, so the step does no host->device copy
+        self.register_buffer('class_weights', torch.as_tensor(class_weights, dtype=torch.float32), persistent=False)
         self.ignore_index, self.use_top_k, self.top_k_ratio = ignore_index, use_top_k, top_k_ratio
         self.future_discount = future_discount
 
@@ -61,7 +62,8 @@ class SegmentationLoss(nn.Module):
 class HDmapLoss(nn.Module):
     def __init__(self, class_weights, training_weights, use_top_k, top_k_ratio, ignore_index=255):
         super().__init__()
-        self.class_weights, self.training_weights = class_weights, training_weights
+        self.register_buffer('class_weights', torch.as_tensor(class_weights, dtype=torch.float32), persistent=False)
+        self.training_weights = training_weights
         self.ignore_index, self.use_top_k, self.top_k_ratio = ignore_index, use_top_k, top_k_ratio
 
     def forward(self, prediction, target):

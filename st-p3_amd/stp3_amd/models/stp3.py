@@ -98,6 +98,7 @@ class STP3(nn.Module):
         self.deterministic_pool = True      # canonical per-voxel summation order (bit-reproducible)
         self._grid = None
         self._side_stream = None
+        self.prebuilt_plan = None           # set by ``prepare_plan``: forward then does no host work at all
 
     # ------------------------------------------------------------------------------------------
     def create_frustum(self):
@@ -118,12 +119,28 @@ class STP3(nn.Module):
                                       self.bev_dimension, device)
         return self._grid
 
+    def prepare_plan(self, intrinsics, extrinsics, future_egomotion, device, out=None):
+        """Build the geometry-only pooling plan of a batch ahead of ``forward`` (host-side pose math, one
+        small upload, index kernels).  With a plan prepared, ``forward`` touches no host data, so the
+        whole training step can be captured into a hipGraph; ``out`` reuses a previous plan's buffers."""
+        rf = self.receptive_field
+        grid = self.lift_grid(device)
+        self.prebuilt_plan = ops.LiftPlan.build(grid, intrinsics[:, :rf], extrinsics[:, :rf], future_egomotion[:, :rf],
+                                                self.encoder_out_channels, deterministic=self.deterministic_pool,
+                                                out=out)
+        return self.prebuilt_plan
+
     def calculate_birds_eye_view_features(self, image, intrinsics, extrinsics, future_egomotion):
         """(B,S,N,3,H,W) images -> BEV features (B,S,C,X,Y) float32 + depth logits (B,S,N,D,fH,fW).
         Replaces stp3.py:303-318 (and everything it calls)."""
         b, s, n, c, h, w = image.shape
         dev = image.device
         grid = self.lift_grid(dev)
+        if self.prebuilt_plan is not None:
+            feat, depth = self.encoder(image.reshape(b * s * n, c, h, w))
+            feat = feat.view(b, s, n, *feat.shape[1:])
+            depth = depth.view(b, s, n, *depth.shape[1:])
+            return ops.lift_splat(feat, depth, self.prebuilt_plan, self.discount), depth, None
         # geometry-only work goes to a side stream: it overlaps the image encoder below
         cur = torch.cuda.current_stream(dev)
         if self._side_stream is None:

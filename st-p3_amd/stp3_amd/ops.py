@@ -140,11 +140,11 @@ class LiftGrid:
         self.res = self.consts[o:o + 3]
 
 
-def voxel_index(grid, dims, cam_m, cam_t, ego_r, ego_t, order=VOX_REFERENCE, counts=None):
+def voxel_index(grid, dims, cam_m, cam_t, ego_r, ego_t, order=VOX_REFERENCE, counts=None, out=None):
     """Raw ``stp3_voxel_index``: int32 voxel ids [B*T, P] in ``order``; cam/ego matrices are
     device float32 tensors laid out as ``lift_matrices`` returns them."""
     _need_gpu(cam_m, cam_t, ego_r, ego_t)
-    vox = torch.empty(dims.BT, dims.P, dtype=torch.int32, device=cam_m.device)
+    vox = out if out is not None else torch.empty(dims.BT, dims.P, dtype=torch.int32, device=cam_m.device)
     rc = _lib.lib().stp3_voxel_index(ctypes.byref(dims), _ptr(cam_m), _ptr(cam_t), _ptr(ego_r), _ptr(ego_t),
                                      _ptr(grid.xs), _ptr(grid.ys), _ptr(grid.ds), _ptr(grid.off), _ptr(grid.res),
                                      int(order), _ptr(vox), _ptr(counts) if counts is not None else None, _stream())
@@ -163,31 +163,42 @@ class LiftPlan:
         self.dims, self.vox_pm, self.plan, self.counts = dims, vox_pm, plan, counts
 
     @staticmethod
-    def build(grid, intrinsics, extrinsics, future_egomotion, channels, deterministic=True):
+    def build(grid, intrinsics, extrinsics, future_egomotion, channels, deterministic=True, out=None):
+        """``out``: a plan of the same shape whose device buffers are overwritten in place (static
+        addresses: what a captured hipGraph of the training step needs)."""
         b, s, n = intrinsics.shape[:3]
         dims = make_dims(b, s, n, grid.D, grid.fH, grid.fW, channels, grid.X, grid.Y, grid.Z)
         mats = torch.cat([m.reshape(-1) for m in lift_matrices(intrinsics, extrinsics, future_egomotion)])
-        mats = mats.to(grid.device, non_blocking=True)
+        if out is not None:
+            assert bytes(out.dims) == bytes(dims), 'LiftPlan.build(out=...): shape changed'
+            out.mats.copy_(mats, non_blocking=True)
+            mats = out.mats
+            out.counts.zero_()
+            counts = out.counts
+        else:
+            mats = mats.to(grid.device, non_blocking=True)
+            counts = torch.zeros(dims.BT, dims.V, dtype=torch.int32, device=grid.device)
         n_cam = b * s * n
         cam_m = mats[:n_cam * 9]
         cam_t = mats[n_cam * 9:n_cam * 12]
         ego_r = mats[n_cam * 12:n_cam * 12 + b * s * 9]
         ego_t = mats[n_cam * 12 + b * s * 9:]
-        counts = torch.zeros(dims.BT, dims.V, dtype=torch.int32, device=grid.device)
         with _timed('plan_build'):
-            vox_pm = voxel_index(grid, dims, cam_m, cam_t, ego_r, ego_t, VOX_PIXELMAJOR)
-            plan = LiftPlan._finish(grid, dims, vox_pm, counts, deterministic)
+            vox_pm = voxel_index(grid, dims, cam_m, cam_t, ego_r, ego_t, VOX_PIXELMAJOR,
+                                 out=None if out is None else out.vox_pm)
+            plan = LiftPlan._finish(grid, dims, vox_pm, counts, deterministic, out)
+        plan.mats = mats
         return plan
 
     @staticmethod
-    def _finish(grid, dims, vox_pm, counts, deterministic):
+    def _finish(grid, dims, vox_pm, counts, deterministic, out=None):
         nbytes = ctypes.c_size_t()
         check(_lib.lib().stp3_lift_plan_bytes(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_lift_plan_bytes')
-        plan = torch.empty(nbytes.value, dtype=torch.uint8, device=grid.device)
+        plan = out.plan if out is not None else torch.empty(nbytes.value, dtype=torch.uint8, device=grid.device)
         rc = _lib.lib().stp3_lift_plan_build(ctypes.byref(dims), _ptr(vox_pm), _ptr(counts), _ptr(plan),
                                              ctypes.c_size_t(nbytes.value), int(bool(deterministic)), _stream())
         check(rc, 'stp3_lift_plan_build')
-        return LiftPlan(dims, vox_pm, plan, counts)
+        return out if out is not None else LiftPlan(dims, vox_pm, plan, counts)
 
     @staticmethod
     def _align256(n):
@@ -473,8 +484,8 @@ class _BnAct(torch.autograd.Function):
         if ldy != c:
             dy = dy.contiguous(memory_format=torch.channels_last)
         ws, ws_bytes = _bn_workspace(dims, x.device)
-        sample_sums = torch.empty(n, 2, c, dtype=torch.float32, device=x.device)
-        sums = torch.empty(2, c, dtype=torch.float32, device=x.device)
+        sample_sums = torch.empty(n, 3, c, dtype=torch.float32, device=x.device)
+        sums = torch.empty(3, c, dtype=torch.float32, device=x.device)
         check(lib.stp3_bn_bwd_reduce(ctypes.byref(dims), _ptr(dy), _ptr(x), _opt_ptr(sb), _opt_ptr(res), _opt_ptr(osc),
                                      _ptr(mean), _ptr(invstd), _opt_ptr(gamma), _opt_ptr(beta), _ptr(ws),
                                      ctypes.c_size_t(ws_bytes), _ptr(sample_sums), _ptr(sums), _stream()),
@@ -513,7 +524,7 @@ class _BnAct(torch.autograd.Function):
             g = gamma if gamma is not None else torch.ones_like(invstd)
             if ctx.training:
                 k = gsums / ctx.count
-                dsbias = g * invstd * (sample_sums[:, 0] - rows * k[0] - sample_sums[:, 1] * k[1])
+                dsbias = g * invstd * (sample_sums[:, 0] - rows * k[0] - sample_sums[:, 2] * k[1])
             else:
                 dsbias = g * invstd * sample_sums[:, 0]
         return dx, dgamma, dbeta, dres, dsbias, None, None, None, None, None, None, None, None, None

@@ -142,23 +142,30 @@ class FlatAdam:
     def __init__(self, buckets, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.buckets = buckets
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
-        self.step_count = 0
+        dev = buckets.flat_params[0].device
+        # the step counter lives on the device so that a captured hipGraph of the step advances it on replay
+        self.step_t = torch.zeros((), dtype=torch.float32, device=dev)
         self.exp_avg = [torch.zeros_like(p) for p in buckets.flat_params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in buckets.flat_params]
 
+    @property
+    def step_count(self):
+        return int(self.step_t.item())
+
     @torch.no_grad()
     def step(self):
-        self.step_count += 1
         b1, b2 = self.betas
-        bc1 = 1.0 - b1 ** self.step_count
-        bc2_sqrt = (1.0 - b2 ** self.step_count) ** 0.5
+        self.step_t.add_(1.0)
+        bc1 = 1.0 - torch.pow(b1, self.step_t)                      # bias corrections, device scalars
+        bc2_sqrt = torch.sqrt(1.0 - torch.pow(b2, self.step_t))
+        step_size = self.lr / bc1
         for (grad, _), param, m, v in zip(self.buckets.buckets, self.buckets.flat_params, self.exp_avg,
                                           self.exp_avg_sq):
             g = grad.add(param, alpha=self.weight_decay) if self.weight_decay else grad
             m.lerp_(g, 1.0 - b1)
             v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
             denom = (v.sqrt() / bc2_sqrt).add_(self.eps)
-            param.addcdiv_(m, denom, value=-self.lr / bc1)
+            param.sub_((m / denom) * step_size)
 
     def state_dict(self):
         return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq}
