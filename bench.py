@@ -155,6 +155,14 @@ def lift_roofline(device, batch, batch_size, iters=30):
     return roof, {k: round(v['avg_ms'], 4) for k, v in prof.items()}
 
 
+def _log(msg):
+    if os.environ.get('STP3_BENCH_VERBOSE'):
+        print(f'[bench +{time.perf_counter() - _T0:7.1f}s] {msg}', file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -191,7 +199,7 @@ def main():
     if world == 1 and not args.no_graph:
         from stp3_amd.graph import GraphedTrainStep
         try:
-            runner = GraphedTrainStep(module, buckets, opt, cfg.GRAD_NORM_CLIP, batch)
+            runner = GraphedTrainStep(module, buckets, opt, cfg.GRAD_NORM_CLIP, batch, log=_log)
             step = lambda: runner(batch)
             mode = 'hipGraph'
         except Exception as e:                                  # capture is an optimisation, never a requirement
@@ -199,8 +207,11 @@ def main():
             module.model.prebuilt_plan = None
             torch.cuda.synchronize()
 
+    _log(f'mode {mode}: warm-up')
     for _ in range(args.warmup):
         step()
+        torch.cuda.synchronize()
+        _log('warm-up step done')
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -215,11 +226,13 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    _log(f'timed steps done: {elapsed / args.steps * 1e3:.2f} ms/step')
     assert torch.isfinite(loss).item(), 'loss is not finite'
 
     if rank == 0:
         module.model.prebuilt_plan = None
         roof, kernel_ms = lift_roofline(device, batch, args.batch)
+        _log('roofline microbench done')
         line = {
             'metric': 'BEV samples/sec (6-cam x 3-frame fwd+bwd)', 'value': round(args.batch * world * args.steps / elapsed, 3),
             'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

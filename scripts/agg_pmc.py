@@ -23,9 +23,14 @@ def pick(tab, key):
     return None if rows.empty else float(rows['mean'].iloc[0]) * 1024.0
 
 
+def pick_max(tab, key):
+    rows = tab[tab.index.str.contains(key)]
+    return None if rows.empty else float(rows['mean'].max()) * 1024.0
+
+
 fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
-cal_f = pick(fetch, 'CUDAFunctorOnOther_add|AddFunctor|CUDAFunctor_add')
-cal_w = pick(write, 'CUDAFunctorOnOther_add|AddFunctor|CUDAFunctor_add')
+cal_f = pick_max(fetch, 'CUDAFunctorOnOther_add|AddFunctor|CUDAFunctor_add')
+cal_w = pick_max(write, 'CUDAFunctorOnOther_add|AddFunctor|CUDAFunctor_add')
 out = {'calibration': {'kernel': 'torch.add over 256 MiB float32', 'true_read_bytes': CAL_BYTES, 'true_write_bytes': CAL_BYTES,
                        'FETCH_SIZE_bytes': cal_f, 'WRITE_SIZE_bytes': cal_w,
                        'fetch_correction': None if not cal_f else CAL_BYTES / cal_f,

@@ -19,7 +19,8 @@ _POSE_KEYS = ('intrinsics', 'extrinsics', 'future_egomotion')
 
 
 class GraphedTrainStep:
-    def __init__(self, module, buckets, optimizer, grad_clip, batch, autocast_dtype=torch.bfloat16, warmup=3):
+    def __init__(self, module, buckets, optimizer, grad_clip, batch, autocast_dtype=torch.bfloat16, warmup=3,
+                 log=lambda msg: None):
         self.module, self.buckets, self.optimizer = module, buckets, optimizer
         self.grad_clip, self.autocast_dtype = grad_clip, autocast_dtype
         self.model = module.model
@@ -38,13 +39,17 @@ class GraphedTrainStep:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            for _ in range(warmup):
+            for i in range(warmup):
                 self._body()
+                torch.cuda.synchronize(dev)
+                log(f'graph: eager warm-up {i} done')
         cur.wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._body()
+        torch.cuda.synchronize(dev)
+        log('graph: captured')
 
     def _graph_batch(self):
         b = dict(self.static)
