@@ -231,6 +231,32 @@ int stp3_bn_apply_bwd(const stp3_bn_dims* dims, const void* dy, const void* x, c
                       const float* gamma, const float* beta, const float* sums, double count, void* dx,
                       void* dres, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Dense 2-D convolution, bf16 MFMA implicit GEMM, NHWC.
+ * Replaces the nn.Conv2d (and frame-folded nn.Conv3d) contractions of stp3/layers/convolutions.py:183-280,
+ * stp3/layers/temporal.py:252-273,315-325, stp3/models/decoder.py:22-140 and the 1x1 expand / project
+ * convolutions of the MBConv blocks driven by stp3/models/encoder.py:57-97 (groups == 1).
+ *   x [N][H][W][ldx >= Cin]  bf16 (row stride ldx lets the kernel read a channel-slice / concat view)
+ *   w [Cout][KH][KW][Cin]    bf16 (= channels-last memory of the (Cout, Cin, KH, KW) parameter)
+ *   bias [Cout] float32 or NULL
+ *   y [N][Ho][Wo][ldy >= Cout]  out_dtype = STP3_DTYPE_BF16 or STP3_DTYPE_F32, float32 accumulation
+ *   y[n][ho][wo][co] = bias[co] + sum_{kh,kw,ci} x[n][ho*stride - pad_h + kh*dil_h][wo*stride - pad_w + kw*dil_w][ci]
+ *                                                 * w[co][kh][kw][ci]           (zero padding)
+ * Requires Cin % 8 == 0, ldx % 8 == 0, 16-byte aligned x / w.  The data gradient of a stride-1 convolution
+ * is the same call on dy with the taps flipped and Cin / Cout swapped (the host prepares that weight).
+ */
+typedef struct stp3_conv_dims {
+    int32_t N, H, W, Cin;
+    int32_t Ho, Wo, Cout;
+    int32_t KH, KW, stride;
+    int32_t pad_h, pad_w, dil_h, dil_w;
+    int32_t ldx, ldy;
+    int32_t out_dtype, has_bias;
+} stp3_conv_dims;
+
+int stp3_conv2d_fwd(const stp3_conv_dims* dims, const void* x, const void* w, const float* bias, void* y,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,12 @@ class BnDims(ctypes.Structure):
                                               'has_sbias', 'has_oscale')]
 
 
+class ConvDims(ctypes.Structure):
+    """struct stp3_conv_dims (include/stp3_hip.h)."""
+    _fields_ = [(k, ctypes.c_int32) for k in ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'stride', 'pad_h',
+                                              'pad_w', 'dil_h', 'dil_w', 'ldx', 'ldy', 'out_dtype', 'has_bias')]
+
+
 DTYPE_F32 = 0
 DTYPE_BF16 = 1
 
@@ -84,6 +90,7 @@ SIGNATURES = {
                           + [c_void_p] * 6),
     'stp3_bn_bwd_reduce': (c_int, [_BN_P] + [c_void_p] * 10 + [c_size_t, c_void_p, c_void_p, c_void_p]),
     'stp3_bn_apply_bwd': (c_int, [_BN_P] + [c_void_p] * 10 + [c_double, c_void_p, c_void_p, c_void_p]),
+    'stp3_conv2d_fwd': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

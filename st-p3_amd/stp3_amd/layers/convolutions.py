@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, run_fused
+from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, conv2d, conv_module, run_fused
 
 
 def _conv_bn_relu(in_ch, out_ch, k, padding=0, dilation=1):
@@ -46,7 +46,7 @@ class UpsamplingAdd(nn.Module):
 
     def forward(self, x, x_skip):
         up, conv, bn = self.upsample_layer
-        return bn_act(bn, conv(up(x)), ACT_NONE, res=x_skip, res_mode=RES_AFTER_ACT)
+        return bn_act(bn, conv_module(conv, up(x)), ACT_NONE, res=x_skip, res_mode=RES_AFTER_ACT)
 
 
 class ASPPConv(nn.Sequential):
@@ -63,13 +63,13 @@ class ASPPConv(nn.Sequential):
         d = self.dilation
         wgt = conv.weight
         if d >= h and d >= w:                       # only the centre tap can ever be in range
-            y = F.conv2d(x, wgt[:, :, 1:2, 1:2])
+            y = conv2d(x, wgt[:, :, 1:2, 1:2])
         elif d >= h:                                # centre row only: 1x3
-            y = F.conv2d(x, wgt[:, :, 1:2, :], padding=(0, d), dilation=(1, d))
+            y = conv2d(x, wgt[:, :, 1:2, :], padding=(0, d), dilation=(1, d))
         elif d >= w:                                # centre column only: 3x1
-            y = F.conv2d(x, wgt[:, :, :, 1:2], padding=(d, 0), dilation=(d, 1))
+            y = conv2d(x, wgt[:, :, :, 1:2], padding=(d, 0), dilation=(d, 1))
         else:
-            y = conv(x)
+            y = conv_module(conv, x)
         return bn_act(bn, y, ACT_RELU)
 
 
@@ -104,7 +104,7 @@ class ASPP(nn.Module):
         pooled = self.convs[-1](x)                                   # (N, C, 1, 1)
         proj, bn, act, drop = self.project
         n_sp = spatial.shape[1]
-        y = F.conv2d(spatial, proj.weight[:, :n_sp])
+        y = conv2d(spatial, proj.weight[:, :n_sp])
         # the pooled branch is a constant plane per sample: its projection is a per-sample bias, folded
         # into the fused BatchNorm instead of a broadcast add over the whole map
         sbias = F.conv2d(pooled.to(y.dtype), proj.weight[:, n_sp:]).flatten(1).float()

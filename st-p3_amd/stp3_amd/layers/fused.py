@@ -12,6 +12,8 @@ CPU tensors (the gloo data-parallel tests, the CPU port timed by ``bench.py``) a
 take ``bn_act_reference``: the same arithmetic written with torch ops.  GPU tensors never fall back: a
 missing ``libstp3hip.so`` raises.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -103,6 +105,26 @@ def bn_act(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=
                       act=act, res=res, res_mode=res_mode, sbias=sbias, oscale=oscale, group=group)
 
 
+# Dense convolutions: the hand-written bf16 MFMA implicit-GEMM kernel (stp3_conv.hip) whenever the operands
+# are bf16 (autocast) on the GPU and the shape is supported; the vendor library otherwise (fp32 parity runs,
+# the 3-channel stem, CPU).  STP3_MFMA_CONV=0 switches the kernel off for A/B measurements.
+USE_MFMA_CONV = os.environ.get('STP3_MFMA_CONV', '1') != '0'
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
+    if (USE_MFMA_CONV and x.is_cuda and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled())
+            and ops.conv2d_supported(x, weight, stride)):
+        return ops.conv2d(x, weight, bias, stride, padding, dilation)
+    return F.conv2d(x, weight, bias, stride, padding, dilation)
+
+
+def conv_module(m, x):
+    """``m(x)`` for an ``nn.Conv2d`` through ``conv2d`` when it is a plain dense zero-padded convolution."""
+    if m.groups == 1 and m.padding_mode == 'zeros' and not isinstance(m.padding, str):
+        return conv2d(x, m.weight, m.bias, m.stride, m.padding, m.dilation)
+    return m(x)
+
+
 def run_fused(seq, x):
     """Run an ``nn.Sequential`` with every ``BatchNorm -> ReLU`` pair (or lone BatchNorm) fused."""
     mods = list(seq)
@@ -117,6 +139,8 @@ def run_fused(seq, x):
             x = bn_act(m, x, ACT_NONE)
         elif isinstance(m, nn.Sequential):
             x = run_fused(m, x)
+        elif type(m) is nn.Conv2d:
+            x = conv_module(m, x)
         else:
             x = m(x)
         i += 1

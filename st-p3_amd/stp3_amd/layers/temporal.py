@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act
+from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, conv2d
 
 
 def _pad8(c):
@@ -33,7 +33,7 @@ def _conv2d_padded_channels(x, weight, padding=0):
         weight = F.pad(weight, (0, 0, 0, 0, 0, cip - ci))
     if cop != co:
         weight = F.pad(weight, (0, 0, 0, 0, 0, 0, 0, cop - co))
-    y = F.conv2d(x, weight, None, 1, padding)
+    y = conv2d(x, weight, None, 1, padding)
     return y[:, :co] if cop != co else y
 
 

@@ -4,7 +4,7 @@ dictionary (``None`` for disabled heads)."""
 import torch.nn as nn
 
 from ..layers.convolutions import UpsamplingAdd
-from ..layers.fused import ACT_RELU, bn_act, run_fused
+from ..layers.fused import ACT_RELU, bn_act, conv_module, run_fused
 from .resnet import resnet18
 
 
@@ -56,7 +56,7 @@ class Decoder(nn.Module):
         b, s, c, h, w = x.shape
         x = x.reshape(b * s, c, h, w)
         skip1 = x
-        x = self.layer1(bn_act(self.bn1, self.first_conv(x), ACT_RELU))  # 1/2
+        x = self.layer1(bn_act(self.bn1, conv_module(self.first_conv, x), ACT_RELU))  # 1/2
         skip2 = x
         x = self.layer2(x)                                            # 1/4
         skip3 = x

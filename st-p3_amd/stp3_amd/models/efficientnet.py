@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..layers.fused import ACT_NONE, ACT_SWISH, RES_AFTER_ACT, bn_act
+from ..layers.fused import ACT_NONE, ACT_SWISH, RES_AFTER_ACT, bn_act, conv2d
 
 # (repeats, kernel, stride, expand, in, out) of the 7 base stages, SE ratio 0.25 everywhere
 _BASE_STAGES = ((1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
@@ -63,6 +63,8 @@ class StaticSamePadConv2d(nn.Conv2d):
             return y.view(*y.shape, 1, 1)
         if any(self._pad):
             x = F.pad(x, self._pad)
+        if self.groups == 1:
+            return conv2d(x, self.weight, self.bias, self.stride, 0, self.dilation)
         return F.conv2d(x, self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
 
 

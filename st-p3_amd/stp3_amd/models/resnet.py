@@ -9,7 +9,7 @@ normal fan_out, last BN gamma of every block zero).  PARITY UNPINNED against the
 """
 import torch.nn as nn
 
-from ..layers.fused import ACT_NONE, ACT_RELU, RES_BEFORE_ACT, bn_act
+from ..layers.fused import ACT_NONE, ACT_RELU, RES_BEFORE_ACT, bn_act, conv_module
 
 
 class BasicBlock(nn.Module):
@@ -26,9 +26,9 @@ class BasicBlock(nn.Module):
                                             nn.BatchNorm2d(out_ch))
 
     def forward(self, x):
-        skip = x if self.downsample is None else bn_act(self.downsample[1], self.downsample[0](x), ACT_NONE)
-        y = bn_act(self.bn1, self.conv1(x), ACT_RELU)
-        return bn_act(self.bn2, self.conv2(y), ACT_RELU, res=skip, res_mode=RES_BEFORE_ACT)
+        skip = x if self.downsample is None else bn_act(self.downsample[1], conv_module(self.downsample[0], x), ACT_NONE)
+        y = bn_act(self.bn1, conv_module(self.conv1, x), ACT_RELU)
+        return bn_act(self.bn2, conv_module(self.conv2, y), ACT_RELU, res=skip, res_mode=RES_BEFORE_ACT)
 
 
 class ResNet18Stages(nn.Module):

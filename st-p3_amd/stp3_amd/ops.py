@@ -538,3 +538,80 @@ def bn_act(x, weight, bias, running_mean, running_var, training, momentum, eps, 
         res_mode = RES_NONE
     return _BnAct.apply(x, weight, bias, res, sbias, oscale, running_mean, running_var, bool(training),
                         float(momentum if momentum is not None else 0.1), float(eps), int(act), int(res_mode), group)
+
+
+# ----------------------------------------------------------------------------------------------
+# dense 2-D convolution: bf16 MFMA implicit GEMM (forward and stride-1 data gradient)
+# ----------------------------------------------------------------------------------------------
+def _pair(v):
+    return (int(v), int(v)) if not isinstance(v, (tuple, list)) else (int(v[0]), int(v[1]))
+
+
+def _conv_out(size, k, stride, pad, dil):
+    return (size + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def _conv2d_launch(x, wb, bias, stride, pad, dil, out_dtype):
+    """x (N,Cin,H,W) bf16 with channels-last memory (row stride ld >= Cin); wb (Cout,Cin,KH,KW) bf16 channels-last."""
+    n, cin, h, w = x.shape
+    cout, _, kh, kw = wb.shape
+    x, ldx = _rows_view(x)
+    ho, wo = _conv_out(h, kh, stride, pad[0], dil[0]), _conv_out(w, kw, stride, pad[1], dil[1])
+    y = torch.empty((n, cout, ho, wo), dtype=out_dtype, device=x.device, memory_format=torch.channels_last)
+    dims = _lib.ConvDims(n, h, w, cin, ho, wo, cout, kh, kw, stride, pad[0], pad[1], dil[0], dil[1], ldx, cout,
+                         _lib.DTYPE_F32 if out_dtype == torch.float32 else _lib.DTYPE_BF16, int(bias is not None))
+    check(_lib.lib().stp3_conv2d_fwd(ctypes.byref(dims), _ptr(x), _ptr(wb), _opt_ptr(bias), _ptr(y), _stream()),
+          'stp3_conv2d_fwd')
+    return y
+
+
+def conv2d_supported(x, weight, stride, groups=1):
+    """What stp3_conv2d_fwd takes: GPU, dense (groups == 1), square stride, input channels a multiple of 8."""
+    s = _pair(stride)
+    return x.is_cuda and x.dim() == 4 and groups == 1 and s[0] == s[1] and weight.shape[1] % 8 == 0
+
+
+class _Conv2dMfma(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil, out_dtype):
+        _need_gpu(x, weight)
+        x = x.to(torch.bfloat16)
+        wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        fb = _f32(bias)
+        y = _conv2d_launch(x, wb, fb, stride, pad, dil, out_dtype)
+        ctx.save_for_backward(x, wb)
+        ctx.cfg = (stride, pad, dil, bias is not None, weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wb = ctx.saved_tensors
+        stride, pad, dil, has_bias, wdtype, bdtype = ctx.cfg
+        cout, cin, kh, kw = wb.shape
+        dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dx = dw = db = None
+        bpad = (dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1])
+        need_dx = ctx.needs_input_grad[0]
+        hip_dx = need_dx and stride == 1 and cout % 8 == 0 and bpad[0] >= 0 and bpad[1] >= 0
+        if hip_dx:
+            # dL/dx of a stride-1 convolution = convolution of dy with the taps flipped and Cin / Cout swapped
+            wt = wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+            dx = _conv2d_launch(dy, wt, None, 1, bpad, dil, torch.bfloat16)
+        mask = [need_dx and not hip_dx, ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]]
+        if any(mask):
+            xd = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+            gx, gw, gb = torch.ops.aten.convolution_backward(dy, xd, wb, [cout] if has_bias else None, [stride, stride],
+                                                             list(pad), list(dil), False, [0, 0], 1, mask)
+            if mask[0]:
+                dx = gx
+            if mask[1]:
+                dw = gw.to(wdtype)
+            if mask[2]:
+                db = gb.to(bdtype)
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, out_dtype=torch.bfloat16):
+    """Dense conv through the MFMA implicit-GEMM kernel (bf16 operands, float32 accumulation)."""
+    s = _pair(stride)
+    return _Conv2dMfma.apply(x, weight, bias, s[0], _pair(padding), _pair(dilation), out_dtype)

@@ -1,0 +1,66 @@
+"""GPU parity of the bf16 MFMA implicit-GEMM convolution (through the C ABI) against a float32 torch
+convolution of the same bf16-rounded operands.
+
+Tolerances: float32 output rtol 2e-3 / atol 2e-3 (float32 accumulation in a different order over up to
+K = 7*7*64 products of O(1) values); bf16 output additionally carries one bf16 rounding (2^-8 relative):
+rtol 1e-2 / atol 2e-2.  Gradients: input gradient through the same kernel (same tolerances); weight / bias
+gradients come from the vendor library and are only sanity-checked (rtol 5e-2).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # n, cin, h, w, cout, k, stride, pad, dil, bias, sliced
+    (3, 24, 28, 60, 144, 1, 1, 0, 1, False, False),     # MBConv expand (K = 24 < one k-step)
+    (2, 144, 28, 60, 32, 1, 1, 0, 1, False, False),     # MBConv project
+    (2, 216, 28, 60, 64, 3, 1, 1, 1, False, False),     # UpsamplingConcat first 3x3
+    (1, 64, 50, 50, 64, 7, 2, 3, 1, False, False),      # decoder stem 7x7 / 2
+    (2, 64, 40, 40, 128, 3, 1, 12, 12, False, False),   # ASPP dilated 3x3
+    (2, 64, 33, 17, 2, 1, 1, 0, 1, True, False),        # head: 2 output channels + bias, ragged pixel count
+    (2, 160, 14, 30, 64, 3, 1, 24, 24, False, False),   # dilation > map: only the centre row is ever in range
+    (3, 40, 20, 20, 35, 3, 1, 1, 1, False, True),       # channel-sliced input view (35 -> 40 padded), odd Cout
+    (1, 128, 25, 25, 256, 3, 2, 1, 1, False, False),    # ResNet stage transition, stride 2
+    (2, 960, 14, 30, 160, 1, 1, 0, 1, False, False),    # widest trunk projection (K = 960)
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv2d_forward_and_input_gradient(case):
+    from stp3_amd import ops
+    n, cin, h, w, cout, k, stride, pad, dil, use_bias, sliced = case
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    cs = cin + 8 if sliced else cin
+    xfull = torch.randn(n, cs, h, w, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wgt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).cuda()
+    bias = torch.randn(cout, generator=g).cuda() if use_bias else None
+    xa = xfull.detach().clone().requires_grad_(True)
+    wa = wgt.detach().clone().requires_grad_(True)
+    xin = xa[:, :cin] if sliced else xa
+    assert ops.conv2d_supported(xin, wa, stride)
+    y32 = ops.conv2d(xin, wa, bias, stride, pad, dil, out_dtype=torch.float32)
+    y16 = ops.conv2d(xin, wa, bias, stride, pad, dil)
+    xb = xfull.float()[:, :cin].detach().clone().requires_grad_(True)
+    wb = wgt.to(torch.bfloat16).float().detach().clone().requires_grad_(True)
+    ref = F.conv2d(xb, wb, bias, stride, pad, dil)
+    assert y32.shape == ref.shape and y16.dtype == torch.bfloat16
+    torch.testing.assert_close(y32, ref, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(y16.float(), ref, rtol=1e-2, atol=2e-2)
+    gy = torch.randn(ref.shape, generator=g).cuda().to(torch.bfloat16)
+    y16.backward(gy)
+    ref.backward(gy.float())
+    torch.testing.assert_close(xa.grad.float()[:, :cin], xb.grad, rtol=1e-2, atol=2e-2)
+    torch.testing.assert_close(wa.grad, wb.grad, rtol=5e-2, atol=5e-2 * float(wb.grad.abs().max()))
+
+
+def test_conv2d_rejects_what_it_cannot_do():
+    from stp3_amd import ops
+    x = torch.randn(1, 3, 8, 8).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(4, 3, 3, 3).cuda()
+    assert not ops.conv2d_supported(x, w, 1)                      # Cin % 8 != 0
+    with pytest.raises(Exception):
+        ops.conv2d(x, w, None, 1, 1, 1)
+    with pytest.raises(Exception):
+        ops.conv2d(x.cpu(), w.cpu(), None, 1, 1, 1)               # no CPU fallback
