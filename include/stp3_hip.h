@@ -257,6 +257,16 @@ typedef struct stp3_conv_dims {
 int stp3_conv2d_fwd(const stp3_conv_dims* dims, const void* x, const void* w, const float* bias, void* y,
                     void* stream);
 
+/* stp3_conv2d_wgrad -- dw[co][kh][kw][ci] = sum_{n,ho,wo} dy[n][ho][wo][co] * x[n][ho*stride-pad_h+kh*dil_h][..][ci]
+ * (the weight gradient autograd derives for the convolutions above), float32 output in the weight's own
+ * [Cout][KH][KW][Cin] layout.  dy [N][Ho][Wo][ldy >= Cout] and x [N][H][W][ldx >= Cin] are bf16; the pixel
+ * contraction is split over workgroups and reduced deterministically through `workspace`
+ * (stp3_conv2d_wgrad_workspace(dims) bytes).  Requires Cin % 4 == 0, Cout % 4 == 0, ldx % 4 == 0, ldy % 4 == 0.
+ * dims.out_dtype / has_bias are ignored. */
+int stp3_conv2d_wgrad_workspace(const stp3_conv_dims* dims, size_t* bytes);
+int stp3_conv2d_wgrad(const stp3_conv_dims* dims, const void* dy, const void* x, float* dw, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,24 @@ def log(m):
     print(f'[{stage}] {m}', flush=True)
 
 
+def snapshot():
+    snap = {'param:' + k: v.detach().clone() for k, v in module.named_parameters()}
+    snap.update({'buf:' + k: v.detach().clone() for k, v in module.named_buffers()})
+    return snap
+
+
+def diff(snap, tag):
+    cur = {'param:' + k: v for k, v in module.named_parameters()}
+    cur.update({'buf:' + k: v for k, v in module.named_buffers()})
+    for k, v in cur.items():
+        if 'running_' in k or 'num_batches' in k:
+            continue
+        if not torch.equal(v, snap[k]):
+            d = (v.float() - snap[k].float()).abs()
+            log(f'{tag}: CHANGED {k} shape={tuple(v.shape)} ptr={v.data_ptr():#x} n_changed={int((d > 0).sum())} max={float(d.max()):.4g} '
+                f'first_idx={int((d.reshape(-1) > 0).nonzero()[0])}')
+
+
 def run(body, n_replay=3):
     cur = torch.cuda.current_stream()
     side = torch.cuda.Stream()
@@ -40,10 +58,12 @@ def run(body, n_replay=3):
         out = body()
     torch.cuda.synchronize()
     log('captured')
+    snap = snapshot()
     for i in range(n_replay):
         g.replay()
         torch.cuda.synchronize()
         log(f'replay {i} ok, out={float(out):.5f}')
+        diff(snap, f'after replay {i}')
 
 
 img = dbatch['image']
@@ -105,6 +125,55 @@ elif stage in ('temporal_copy', 'temporal_fwd', 'temporal_nodrop', 'temporal_nop
         loss.backward()
         return loss.detach()
     run(body)
+elif stage == 'temporal_trace':
+    from stp3_amd.layers.fused import bn_act, conv_module, run_fused, ACT_RELU
+    tm = model.temporal_model
+    xs = torch.randn(b, 3, 70, 200, 200, device=dev)
+    stats = torch.zeros(12, device=dev)
+    def body():
+        with torch.autocast('cuda', dtype=torch.bfloat16), torch.no_grad():
+            x = tm.model(xs.permute(0, 2, 1, 3, 4)).permute(0, 2, 1, 3, 4)
+            bb, ss, cc, hh, ww = x.shape
+            x = x.reshape(bb * ss, cc, hh, ww)
+            stats[0] = x.float().abs().mean()
+            head = tm.final_conv
+            aspp = head[0]
+            branches = [run_fused(aspp.convs[0], x)] + [conv(x) for conv in aspp.convs[1:-1]]
+            spatial = torch.cat(branches, dim=1)
+            stats[1] = spatial.float().abs().mean()
+            pooled = aspp.convs[-1](x)
+            stats[2] = pooled.float().abs().mean()
+            proj, bn, act, drop = aspp.project
+            n_sp = spatial.shape[1]
+            from stp3_amd.layers.fused import conv2d
+            y = conv2d(spatial, proj.weight[:, :n_sp])
+            stats[3] = y.float().abs().mean()
+            sbias = torch.nn.functional.conv2d(pooled.to(y.dtype), proj.weight[:, n_sp:]).flatten(1).float()
+            stats[4] = sbias.abs().mean()
+            y = bn_act(bn, y, ACT_RELU, sbias=sbias)
+            stats[5] = y.float().abs().mean()
+            y = drop(y)
+            stats[6] = y.float().abs().mean()
+            y = conv_module(head[1], y)
+            stats[7] = y.float().abs().mean()
+            y = bn_act(head[2], y, ACT_RELU)
+            stats[8] = y.float().abs().mean()
+            y = conv_module(head[4], y)
+            stats[9] = y.float().abs().mean()
+            stats[10] = head[4].weight.float().abs().mean()
+            stats[11] = head[2].weight.float().abs().mean()
+            return y.float().mean()
+    cur = torch.cuda.current_stream(); side = torch.cuda.Stream(); side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        for _ in range(3): o = body()
+    cur.wait_stream(side); torch.cuda.synchronize()
+    log(f'eager out={float(o):.5f} stats={[round(float(v), 4) for v in stats]}')
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        o = body()
+    for i in range(3):
+        g.replay(); torch.cuda.synchronize()
+        log(f'replay {i} out={float(o):.5f} stats={[round(float(v), 4) for v in stats]}')
 elif stage in ('tblock', 'tfinal', 'pyramid', 'padconv', 'dilated'):
     from stp3_amd.layers import temporal as T
     from stp3_amd.layers.fused import bn_act, ACT_RELU

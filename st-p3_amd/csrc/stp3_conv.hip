@@ -176,6 +176,139 @@ __global__ __launch_bounds__(256) void conv2d_fwd_kernel(ConvDims d, const uint1
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient:  dW[co][tap][ci] = sum_m dY[m][co] * X[pixel(m) + tap][ci]
+// ------------------------------------------------------------------------------------------------
+// The contraction runs over pixels, the SLOW dimension of both NHWC operands, while an MFMA fragment wants 8
+// consecutive k per lane.  Each lane therefore loads 8 consecutive pixels x 4 channels (8 x 8 bytes) per operand
+// and transposes the 8x4 block in registers (v_perm_b32): lane (i, kq) ends up with, for each of its 4 channels
+// c = 8*i + 4*half + a, the 8 pixels kq*8 .. kq*8+7 -- fragment `a` of an MFMA whose row i stands for channel
+// 8*i + 4*half + a.  One k-step (32 pixels) feeds a 128 x 128 (co x ci) tile; the 4 waves of a workgroup own
+// the 4 (co half, ci half) quadrants: 4 x 4 MFMAs and 64 accumulator registers each.
+// Pixels are split over gridDim.z workgroups (partial sums in float32, reduced deterministically afterwards).
+constexpr int kWgTile = 128;
+
+__device__ __forceinline__ uint32_t perm_lo(uint32_t x, uint32_t y) {   // (x.lo, y.lo)
+    return __builtin_amdgcn_perm(y, x, 0x05040100u);
+}
+__device__ __forceinline__ uint32_t perm_hi(uint32_t x, uint32_t y) {   // (x.hi, y.hi)
+    return __builtin_amdgcn_perm(y, x, 0x07060302u);
+}
+
+// in[p] = channels (c0,c1 | c2,c3) of pixel p (p = 0..7)  ->  out[a] = pixels 0..7 of channel a
+__device__ __forceinline__ void transpose8x4(const uint2 (&in)[8], Frag (&out)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint2 x = in[2 * q], y = in[2 * q + 1];
+        const uint32_t c0 = perm_lo(x.x, y.x), c1 = perm_hi(x.x, y.x);
+        const uint32_t c2 = perm_lo(x.y, y.y), c3 = perm_hi(x.y, y.y);
+        uint32_t* o0 = reinterpret_cast<uint32_t*>(&out[0].u);
+        uint32_t* o1 = reinterpret_cast<uint32_t*>(&out[1].u);
+        uint32_t* o2 = reinterpret_cast<uint32_t*>(&out[2].u);
+        uint32_t* o3 = reinterpret_cast<uint32_t*>(&out[3].u);
+        o0[q] = c0; o1[q] = c1; o2[q] = c2; o3[q] = c3;
+    }
+}
+
+__global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles_ci, int ksteps_per_block,
+                                                           const uint16_t* __restrict__ dy,
+                                                           const uint16_t* __restrict__ x,
+                                                           float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int wa = wave & 1, wb = wave >> 1;                 // co half / ci half of the 128 x 128 tile
+    const int tco = blockIdx.x / tiles_ci, tci = blockIdx.x - tco * tiles_ci;
+    const int tap = blockIdx.y;
+    const int kh = tap / d.KW, kw = tap - kh * d.KW;
+    const int co_l = tco * kWgTile + 8 * li + 4 * wa;        // this lane's 4 output channels (operand A rows)
+    const int ci_l = tci * kWgTile + 8 * li + 4 * wb;        // this lane's 4 input channels  (operand B columns)
+    const bool co_ok = co_l < d.Cout;                        // Cout, Cin are multiples of 4 here (checked by the host)
+    const bool ci_ok = ci_l < d.Cin;
+    const int step0 = blockIdx.z * ksteps_per_block;
+    const int total_steps = (d.M + 31) / 32;
+    const int step1 = min(step0 + ksteps_per_block, total_steps);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const uint2 zero2 = make_uint2(0, 0);
+    auto load_step = [&](int step, uint2 (&ga)[8], uint2 (&gb)[8]) {
+        const int m0 = step * 32 + kq * 8;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int m = m0 + p;
+            const bool mv = m < d.M;
+            ga[p] = (mv && co_ok) ? *reinterpret_cast<const uint2*>(dy + (size_t)m * d.ldy + co_l) : zero2;
+            const int mm = mv ? m : 0;
+            const int wo = mm % d.Wo;
+            const int t = mm / d.Wo;
+            const int ho = t % d.Ho;
+            const int n = t / d.Ho;
+            const int hi = ho * d.stride - d.pad_h + kh * d.dil_h;
+            const int wi = wo * d.stride - d.pad_w + kw * d.dil_w;
+            const bool ok = mv && ci_ok && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
+            gb[p] = ok ? *reinterpret_cast<const uint2*>(x + ((size_t)(n * d.H + hi) * d.W + wi) * d.ldx + ci_l) : zero2;
+        }
+    };
+
+    uint2 ga0[8], gb0[8], ga1[8], gb1[8];
+    if (step0 < step1) load_step(step0, ga0, gb0);
+    for (int step = step0; step < step1; step += 2) {
+        if (step + 1 < step1) load_step(step + 1, ga1, gb1);
+        {
+            Frag fa[4], fb[4];
+            transpose8x4(ga0, fa);
+            transpose8x4(gb0, fb);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a].v, fb[b].v, acc[a][b], 0, 0, 0);
+        }
+        if (step + 1 < step1) {
+            if (step + 2 < step1) load_step(step + 2, ga0, gb0);
+            Frag fa[4], fb[4];
+            transpose8x4(ga1, fa);
+            transpose8x4(gb1, fb);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a].v, fb[b].v, acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // D[row][col]: row (A index) = (lane>>4)*4 + r -> co = tile + 8*row + 4*wa + a; col = lane&15 -> ci = tile + 8*col + 4*wb + b
+    const size_t wsize = (size_t)d.Cout * d.KH * d.KW * d.Cin;
+    float* out = partial + (size_t)blockIdx.z * wsize;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = tco * kWgTile + 8 * (kq * 4 + r) + 4 * wa + a;
+            if (co >= d.Cout) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int ci = tci * kWgTile + 8 * li + 4 * wb + b;
+                if (ci < d.Cin) out[((size_t)co * d.KH * d.KW + tap) * d.Cin + ci] = acc[a][b][r];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(int splits, size_t n, const float* __restrict__ partial,
+                                                                  float* __restrict__ dw) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += partial[(size_t)k * n + i];
+    dw[i] = s;
+}
+
 inline int status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? STP3_OK : -(int)e;
@@ -206,6 +339,60 @@ int stp3_conv2d_fwd(const stp3_conv_dims* p, const void* x, const void* w, const
     dim3 grid((unsigned)((M + kTilePix - 1) / kTilePix), (unsigned)((p->Cout + kTileCo - 1) / kTileCo));
     hipLaunchKernelGGL(conv2d_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, (const uint16_t*)x,
                        (const uint16_t*)w, bias, y);
+    return status();
+}
+
+
+static int wgrad_plan(const stp3_conv_dims* p, int* tiles_co, int* tiles_ci, int* splits, int* ksteps) {
+    const int64_t M = (int64_t)p->N * p->Ho * p->Wo;
+    *tiles_co = (p->Cout + kWgTile - 1) / kWgTile;
+    *tiles_ci = (p->Cin + kWgTile - 1) / kWgTile;
+    const int64_t total_steps = (M + 31) / 32;
+    const int64_t base = (int64_t)(*tiles_co) * (*tiles_ci) * p->KH * p->KW;
+    int64_t want = (1024 + base - 1) / base;                 // ~1024 workgroups
+    const int64_t max_splits = (total_steps + 7) / 8;        // at least 8 k-steps per workgroup
+    if (want > max_splits) want = max_splits;
+    if (want < 1) want = 1;
+    if (want > 512) want = 512;
+    *ksteps = (int)((total_steps + want - 1) / want);
+    *splits = (int)((total_steps + *ksteps - 1) / *ksteps);
+    return STP3_OK;
+}
+
+int stp3_conv2d_wgrad_workspace(const stp3_conv_dims* p, size_t* bytes) {
+    if (!p || !bytes || p->N <= 0 || p->Cout <= 0 || p->Cin <= 0 || p->KH <= 0 || p->KW <= 0 || p->Ho <= 0 || p->Wo <= 0)
+        return STP3_EINVAL;
+    int tco, tci, splits, ksteps;
+    wgrad_plan(p, &tco, &tci, &splits, &ksteps);
+    *bytes = (size_t)splits * p->Cout * p->KH * p->KW * p->Cin * sizeof(float);
+    return STP3_OK;
+}
+
+int stp3_conv2d_wgrad(const stp3_conv_dims* p, const void* dy, const void* x, float* dw, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    if (!p || !dy || !x || !dw || !workspace) return STP3_EINVAL;
+    if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->Cin <= 0 || p->Cout <= 0 || p->Ho <= 0 || p->Wo <= 0 || p->KH <= 0 ||
+        p->KW <= 0 || p->stride <= 0 || p->dil_h <= 0 || p->dil_w <= 0 || p->pad_h < 0 || p->pad_w < 0)
+        return STP3_EINVAL;
+    // 8-byte channel quads of both operands
+    if (p->Cin % 4 || p->Cout % 4 || p->ldx % 4 || p->ldy % 4 || p->ldx < p->Cin || p->ldy < p->Cout) return STP3_EUNSUP;
+    if (((uintptr_t)x & 7) || ((uintptr_t)dy & 7)) return STP3_EUNSUP;
+    const int64_t M = (int64_t)p->N * p->Ho * p->Wo;
+    if (M >= (1LL << 31) - 64 || (int64_t)p->N * p->H * p->W >= (1LL << 31)) return STP3_EUNSUP;
+    int tco, tci, splits, ksteps;
+    wgrad_plan(p, &tco, &tci, &splits, &ksteps);
+    const size_t wsize = (size_t)p->Cout * p->KH * p->KW * p->Cin;
+    if (workspace_bytes < (size_t)splits * wsize * sizeof(float)) return STP3_ENOSPACE;
+    ConvDims d;
+    d.N = p->N; d.H = p->H; d.W = p->W; d.Cin = p->Cin; d.Ho = p->Ho; d.Wo = p->Wo; d.Cout = p->Cout;
+    d.KH = p->KH; d.KW = p->KW; d.stride = p->stride; d.pad_h = p->pad_h; d.pad_w = p->pad_w;
+    d.dil_h = p->dil_h; d.dil_w = p->dil_w; d.ldx = p->ldx; d.ldy = p->ldy;
+    d.out_f32 = 1; d.has_bias = 0; d.M = (int)M; d.kchunks = 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv2d_wgrad_kernel, dim3(tco * tci, p->KH * p->KW, splits), dim3(256), 0, s, d, tci, ksteps,
+                       (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace);
+    hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((wsize + 255) / 256)), dim3(256), 0, s, splits, wsize,
+                       (const float*)workspace, dw);
     return status();
 }
 

@@ -8,6 +8,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .utils import staged_mean
+
 
 def _future_discounts(future_discount, seq_len, n_present, like):
     fut = future_discount ** torch.arange(1, seq_len - n_present + 1, device=like.device, dtype=like.dtype)
@@ -56,7 +58,7 @@ class SegmentationLoss(nn.Module):
         if self.use_top_k:
             k = int(self.top_k_ratio * loss.shape[2])
             loss = loss.topk(k, dim=2, sorted=False).values
-        return loss.mean()
+        return staged_mean(loss)
 
 
 class HDmapLoss(nn.Module):
@@ -76,7 +78,7 @@ class HDmapLoss(nn.Module):
             if self.use_top_k[i]:
                 k = int(self.top_k_ratio[i] * loss.shape[1])
                 loss = loss.topk(k, dim=1, sorted=False).values
-            total = total + loss.mean() * self.training_weights[i]
+            total = total + staged_mean(loss) * self.training_weights[i]
         return total
 
 
@@ -89,4 +91,4 @@ class DepthLoss(nn.Module):
         b, s, n, d, h, w = prediction.shape
         loss = F.cross_entropy(prediction.reshape(b * s * n, d, h, w).float(), target.reshape(b * s * n, h, w),
                                ignore_index=self.ignore_index, reduction='none', weight=self.class_weights)
-        return loss.mean()
+        return staged_mean(loss)

@@ -565,6 +565,32 @@ def _conv2d_launch(x, wb, bias, stride, pad, dil, out_dtype):
     return y
 
 
+_CONV_WORKSPACE = {}
+
+
+def _conv2d_wgrad(dy, x, wshape, stride, pad, dil):
+    """dw (Cout,Cin,KH,KW) float32, channels-last memory, through stp3_conv2d_wgrad (bf16 operands)."""
+    cout, cin, kh, kw = wshape
+    n, _, h, w = x.shape
+    x, ldx = _rows_view(x)
+    dy, ldy = _rows_view(dy)
+    ho, wo = dy.shape[2], dy.shape[3]
+    dims = _lib.ConvDims(n, h, w, cin, ho, wo, cout, kh, kw, stride, pad[0], pad[1], dil[0], dil[1], ldx, ldy,
+                         _lib.DTYPE_F32, 0)
+    lib = _lib.lib()
+    nbytes = ctypes.c_size_t()
+    check(lib.stp3_conv2d_wgrad_workspace(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_conv2d_wgrad_workspace')
+    key = torch.device(x.device)
+    ws = _CONV_WORKSPACE.get(key)
+    if ws is None or ws.numel() < nbytes.value:
+        ws = torch.empty(max(nbytes.value, 64 << 20), dtype=torch.uint8, device=key)
+        _CONV_WORKSPACE[key] = ws
+    dw = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    check(lib.stp3_conv2d_wgrad(ctypes.byref(dims), _ptr(dy), _ptr(x), _ptr(dw), _ptr(ws), ctypes.c_size_t(nbytes.value),
+                                _stream()), 'stp3_conv2d_wgrad')
+    return dw
+
+
 def conv2d_supported(x, weight, stride, groups=1):
     """What stp3_conv2d_fwd takes: GPU, dense (groups == 1), square stride, input channels a multiple of 8."""
     s = _pair(stride)
@@ -597,7 +623,14 @@ class _Conv2dMfma(torch.autograd.Function):
             # dL/dx of a stride-1 convolution = convolution of dy with the taps flipped and Cin / Cout swapped
             wt = wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
             dx = _conv2d_launch(dy, wt, None, 1, bpad, dil, torch.bfloat16)
-        mask = [need_dx and not hip_dx, ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]]
+        need_dw = ctx.needs_input_grad[1]
+        need_db = has_bias and ctx.needs_input_grad[2]
+        hip_dw = need_dw and cin % 4 == 0 and cout % 4 == 0
+        if hip_dw:
+            dw = _conv2d_wgrad(dy, x, (cout, cin, kh, kw), stride, pad, dil).to(wdtype)
+            if need_db:
+                db = dy.float().sum(dim=(0, 2, 3)).to(bdtype)
+        mask = [need_dx and not hip_dx, need_dw and not hip_dw, need_db and not hip_dw]
         if any(mask):
             xd = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
             gx, gw, gb = torch.ops.aten.convolution_backward(dy, xd, wb, [cout] if has_bias else None, [stride, stride],

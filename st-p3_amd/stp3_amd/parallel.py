@@ -126,7 +126,8 @@ class GradientBuckets:
 
     def clip_grad_norm_(self, max_norm):
         """Global-norm clipping on the flat buckets (train.py:48 ``gradient_clip_val``)."""
-        total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(f.float()) for f, _ in self.buckets]))
+        from .utils import staged_sum
+        total = torch.sqrt(torch.stack([staged_sum(f.float().square()) for f, _ in self.buckets]).sum())
         scale = torch.clamp(max_norm / (total + 1e-6), max=1.0)
         for flat, _ in self.buckets:
             flat.mul_(scale.to(flat.dtype))

@@ -13,3 +13,23 @@ def to_channels_last(module):
         elif isinstance(m, nn.Conv3d):
             m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last_3d)
     return module
+
+
+def staged_sum(x, chunk=4096):
+    """Sum of all elements as a cascade of row sums, each row reduced inside one workgroup.
+
+    A direct ``x.sum()`` / ``x.mean()`` of a large tensor is a multi-workgroup reduction whose cross-block
+    scratch (semaphores) is zeroed with a memset node; replayed from a hipGraph on ROCm 7.2 that scratch was
+    observed stale (first replay right, later replays garbage).  The cascade needs no scratch, is
+    deterministic, and costs one extra tiny kernel."""
+    flat = x.reshape(-1)
+    while flat.numel() > 2 * chunk:
+        pad = (-flat.numel()) % chunk
+        if pad:
+            flat = torch.nn.functional.pad(flat, (0, pad))
+        flat = flat.view(-1, chunk).sum(1)
+    return flat.sum()
+
+
+def staged_mean(x, chunk=4096):
+    return staged_sum(x, chunk) / x.numel()

@@ -3,8 +3,10 @@ convolution of the same bf16-rounded operands.
 
 Tolerances: float32 output rtol 2e-3 / atol 2e-3 (float32 accumulation in a different order over up to
 K = 7*7*64 products of O(1) values); bf16 output additionally carries one bf16 rounding (2^-8 relative):
-rtol 1e-2 / atol 2e-2.  Gradients: input gradient through the same kernel (same tolerances); weight / bias
-gradients come from the vendor library and are only sanity-checked (rtol 5e-2).
+rtol 1e-2 / atol 2e-2.  Gradients: input gradient through the same kernel (same tolerances); weight gradient through the MFMA
+weight-gradient kernel (float32 accumulation over up to ~1e5 pixels of bf16 products): rtol 2e-2 and an
+absolute term of 2e-2 of the largest entry (bf16 rounding of dy and x in the reference is identical, the
+difference is summation order); Cout = 2 falls back to the vendor library (sanity only).
 """
 import pytest
 import torch
@@ -52,7 +54,9 @@ def test_conv2d_forward_and_input_gradient(case):
     y16.backward(gy)
     ref.backward(gy.float())
     torch.testing.assert_close(xa.grad.float()[:, :cin], xb.grad, rtol=1e-2, atol=2e-2)
-    torch.testing.assert_close(wa.grad, wb.grad, rtol=5e-2, atol=5e-2 * float(wb.grad.abs().max()))
+    torch.testing.assert_close(wa.grad, wb.grad, rtol=2e-2, atol=2e-2 * float(wb.grad.abs().max()))
+    if use_bias:
+        assert wa.grad.shape == wgt.shape
 
 
 def test_conv2d_rejects_what_it_cannot_do():
