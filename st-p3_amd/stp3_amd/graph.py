@@ -67,6 +67,11 @@ class GraphedTrainStep:
         return loss.detach()
 
     def __call__(self, batch):
+        # One stream synchronisation per step, before the plan buffers of the previous replay are rewritten.
+        # Back-to-back replays with the plan rebuild enqueued in between, host running several steps ahead,
+        # fault on ROCm 7.2 ("write access to a read-only page"); with the host at most one step ahead they
+        # do not.  The host work per step is ~1 ms, so this costs a few percent at most.
+        torch.cuda.current_stream(self.device).synchronize()
         for k, dst in self.static_dev.items():
             src = batch[k]
             if src is not dst:

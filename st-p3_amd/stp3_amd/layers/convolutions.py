@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, conv2d, conv_module, run_fused
+from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, conv1x1_on_vector, conv2d, conv_module, run_fused
 
 
 def _conv_bn_relu(in_ch, out_ch, k, padding=0, dilation=1):
@@ -84,7 +84,7 @@ class ASPPPooling(nn.Sequential):
         """Returns the (N, C, 1, 1) pooled descriptor; bilinear upsampling of a 1x1 map is a
         broadcast, which ``ASPP`` folds into its projection."""
         pool, conv, bn, _ = self
-        return bn_act(bn, conv(pool(x)), ACT_RELU)       # 1x1 map: plain-torch path (statistics still cross-replica)
+        return bn_act(bn, conv_module(conv, pool(x)), ACT_RELU)   # 1x1 map: GEMM + plain-torch BN (still cross-replica)
 
 
 class ASPP(nn.Module):
@@ -107,7 +107,7 @@ class ASPP(nn.Module):
         y = conv2d(spatial, proj.weight[:, :n_sp])
         # the pooled branch is a constant plane per sample: its projection is a per-sample bias, folded
         # into the fused BatchNorm instead of a broadcast add over the whole map
-        sbias = F.conv2d(pooled.to(y.dtype), proj.weight[:, n_sp:]).flatten(1).float()
+        sbias = conv1x1_on_vector(pooled.to(y.dtype), proj.weight[:, n_sp:]).flatten(1).float()
         return drop(bn_act(bn, y, ACT_RELU, sbias=sbias))
 
 

@@ -118,9 +118,22 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     return F.conv2d(x, weight, bias, stride, padding, dilation)
 
 
+def conv1x1_on_vector(x, weight, bias=None):
+    """A 1x1 convolution of a (N, C, 1, 1) map (or (N, C, T, 1, 1) with a 1x1x1 kernel) is a plain GEMM."""
+    w2 = weight.flatten(1)
+    if x.dim() == 5:
+        n, c, t = x.shape[:3]
+        y = F.linear(x.reshape(n, c, t).transpose(1, 2), w2, bias)           # (N, T, Co)
+        return y.transpose(1, 2).reshape(n, -1, t, 1, 1)
+    y = F.linear(x.flatten(1), w2, bias)
+    return y.view(*y.shape, 1, 1)
+
+
 def conv_module(m, x):
     """``m(x)`` for an ``nn.Conv2d`` through ``conv2d`` when it is a plain dense zero-padded convolution."""
     if m.groups == 1 and m.padding_mode == 'zeros' and not isinstance(m.padding, str):
+        if m.kernel_size == (1, 1) and x.shape[-2:] == (1, 1):
+            return conv1x1_on_vector(x, m.weight, m.bias)
         return conv2d(x, m.weight, m.bias, m.stride, m.padding, m.dilation)
     return m(x)
 

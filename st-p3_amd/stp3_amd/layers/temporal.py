@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, conv2d
+from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, conv1x1_on_vector, conv2d
 
 
 def _pad8(c):
@@ -124,7 +124,7 @@ class PyramidSpatioTemporalPooling(nn.Module):
                 # only then drops it.
                 pooled = torch.cat([sp[:, :, :1], 0.5 * (sp[:, :, 1:] + sp[:, :, :-1]), sp[:, :, -1:]], dim=2)
                 cbr = f.conv_bn_relu
-                out.append(bn_act(cbr.norm, cbr.conv(pooled.to(x.dtype)), ACT_RELU)[:, :, :-1])
+                out.append(bn_act(cbr.norm, conv1x1_on_vector(pooled.to(x.dtype), cbr.conv.weight), ACT_RELU)[:, :, :-1])
             else:
                 out.append(f(x)[:, :, :-1])
         return out
@@ -190,7 +190,8 @@ class TemporalBlock(nn.Module):
             for pooled in self.pyramid_pooling(x):                       # (B, C', T, h', w')
                 cp = pooled.shape[1]
                 p2 = pooled.permute(0, 2, 1, 3, 4).reshape(b * t, cp, *pooled.shape[-2:])
-                contrib = F.conv2d(p2.to(y.dtype), wgt[:, off:off + cp].to(y.dtype))
+                contrib = (conv1x1_on_vector(p2.to(y.dtype), wgt[:, off:off + cp].to(y.dtype))
+                           if p2.shape[-2:] == (1, 1) else F.conv2d(p2.to(y.dtype), wgt[:, off:off + cp].to(y.dtype)))
                 if contrib.shape[-2:] == (1, 1):
                     # whole-plane pooling (the reference's only setting): a constant plane per frame, i.e. a
                     # per-sample bias of the aggregation -- folded into the fused BatchNorm

@@ -61,6 +61,12 @@ class StaticSamePadConv2d(nn.Conv2d):
             # squeeze-excite 1x1 convs on a pooled 1x1 map are plain GEMMs
             y = F.linear(x.flatten(1), self.weight.flatten(1), self.bias)
             return y.view(*y.shape, 1, 1)
+        if self.groups == 1 and x.is_cuda and self.in_channels % 8 and torch.is_autocast_enabled():
+            # the 3-channel stem: zero-pad the channels to 8 (together with the "same" padding, one copy) so that
+            # it runs on the MFMA kernel too; the padded weight columns are zero and their gradient is dropped
+            cp = (-self.in_channels) % 8
+            x = F.pad(x, (*self._pad, 0, cp))
+            return conv2d(x, F.pad(self.weight, (0, 0, 0, 0, 0, cp)), self.bias, self.stride, 0, self.dilation)
         if any(self._pad):
             x = F.pad(x, self._pad)
         if self.groups == 1:

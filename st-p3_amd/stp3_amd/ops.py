@@ -171,6 +171,7 @@ class LiftPlan:
         mats = torch.cat([m.reshape(-1) for m in lift_matrices(intrinsics, extrinsics, future_egomotion)])
         if out is not None:
             assert bytes(out.dims) == bytes(dims), 'LiftPlan.build(out=...): shape changed'
+            out.mats_host = mats                    # keep the staging source alive until the next rebuild
             out.mats.copy_(mats, non_blocking=True)
             mats = out.mats
             out.counts.zero_()
@@ -618,11 +619,21 @@ class _Conv2dMfma(torch.autograd.Function):
         dx = dw = db = None
         bpad = (dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1])
         need_dx = ctx.needs_input_grad[0]
-        hip_dx = need_dx and stride == 1 and cout % 8 == 0 and bpad[0] >= 0 and bpad[1] >= 0
+        hip_dx = need_dx and cout % 8 == 0 and bpad[0] >= 0 and bpad[1] >= 0
         if hip_dx:
-            # dL/dx of a stride-1 convolution = convolution of dy with the taps flipped and Cin / Cout swapped
+            # dL/dx = stride-1 convolution of dy (zero-stuffed to the input resolution when stride > 1) with the
+            # taps flipped and Cin / Cout swapped
             wt = wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
-            dx = _conv2d_launch(dy, wt, None, 1, bpad, dil, torch.bfloat16)
+            g = dy
+            if stride > 1:
+                n, _, h, w = x.shape
+                ho, wo = dy.shape[2], dy.shape[3]
+                # rows / columns the forward never reached (floor in the output-size formula) get zero gradient
+                uh = h + 2 * pad[0] - dil[0] * (kh - 1)
+                uw = w + 2 * pad[1] - dil[1] * (kw - 1)
+                g = torch.zeros((n, cout, uh, uw), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+                g[:, :, ::stride, ::stride][:, :, :ho, :wo] = dy
+            dx = _conv2d_launch(g, wt, None, 1, bpad, dil, torch.bfloat16)
         need_dw = ctx.needs_input_grad[1]
         need_db = has_bias and ctx.needs_input_grad[2]
         hip_dw = need_dw and cin % 4 == 0 and cout % 4 == 0
