@@ -631,7 +631,7 @@ class _Conv2dMfma(torch.autograd.Function):
                 # rows / columns the forward never reached (floor in the output-size formula) get zero gradient
                 uh = h + 2 * pad[0] - dil[0] * (kh - 1)
                 uw = w + 2 * pad[1] - dil[1] * (kw - 1)
-                g = torch.zeros((n, cout, uh, uw), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+                g = torch.empty((n, cout, uh, uw), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last).zero_()
                 g[:, :, ::stride, ::stride][:, :, :ho, :wo] = dy
             dx = _conv2d_launch(g, wt, None, 1, bpad, dil, torch.bfloat16)
         need_dw = ctx.needs_input_grad[1]
@@ -640,7 +640,9 @@ class _Conv2dMfma(torch.autograd.Function):
         if hip_dw:
             dw = _conv2d_wgrad(dy, x, (cout, cin, kh, kw), stride, pad, dil).to(wdtype)
             if need_db:
-                db = dy.float().sum(dim=(0, 2, 3)).to(bdtype)
+                # bias gradient = column sums of the [pixels][Cout] matrix, as a GEMV (no multi-block reduction)
+                rows = dy.permute(0, 2, 3, 1).reshape(-1, cout).float()
+                db = torch.mv(rows.t(), torch.ones(rows.shape[0], dtype=torch.float32, device=rows.device)).to(bdtype)
         mask = [need_dx and not hip_dx, need_dw and not hip_dw, need_db and not hip_dw]
         if any(mask):
             xd = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
