@@ -10,9 +10,9 @@ EfficientNet-B4 encoder -> HIP lift / voxel pool -> temporal model -> BEV decode
 weak scaling: every rank gets its own B=4 (global batch 4N), gradients are all-reduced over RCCL
 and BatchNorm statistics are synchronised (the reference's DDP + sync_batchnorm recipe).
 
-At N=1 the whole step (forward, backward, gradient clip, Adam) is captured once into a hipGraph and
-replayed per batch (stp3_amd/graph.py); per batch the host only rebuilds the geometry-only pooling plan.
-With N>1 the step contains RCCL collectives and runs eagerly.
+The step is launched eagerly.  `--graph` (N=1 only) captures the whole step into one hipGraph
+(stp3_amd/graph.py); on ROCm 7.2 replays of the captured step were observed to be slower than the eager
+launch and numerically unreliable, so it is off by default.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      the voxel-pool forward (stp3_lift_splat_fwd = its two kernels): algorithmic bytes per
@@ -170,7 +170,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=4, help='samples per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true', help='launch the step eagerly even on one GPU')
+    ap.add_argument('--graph', action='store_true', help='capture the step into a hipGraph (N=1 only, experimental)')
     args = ap.parse_args()
 
     from stp3_amd.parallel import FlatAdam, GradientBuckets, init_distributed
@@ -196,7 +196,7 @@ def main():
 
     mode = 'eager'
     step = eager_step
-    if world == 1 and not args.no_graph:
+    if world == 1 and args.graph:
         from stp3_amd.graph import GraphedTrainStep
         try:
             runner = GraphedTrainStep(module, buckets, opt, cfg.GRAD_NORM_CLIP, batch, log=_log)
