@@ -171,6 +171,7 @@ def main():
     ap.add_argument('--batch', type=int, default=4, help='samples per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='capture the step into a hipGraph (N=1 only, experimental)')
+    ap.add_argument('--no-roofline', action='store_true', help='skip the voxel-pool micro-benchmark (profiling runs)')
     args = ap.parse_args()
 
     from stp3_amd.parallel import FlatAdam, GradientBuckets, init_distributed
@@ -231,7 +232,7 @@ def main():
 
     if rank == 0:
         module.model.prebuilt_plan = None
-        roof, kernel_ms = lift_roofline(device, batch, args.batch)
+        roof, kernel_ms = (None, {}) if args.no_roofline else lift_roofline(device, batch, args.batch)
         _log('roofline microbench done')
         line = {
             'metric': 'BEV samples/sec (6-cam x 3-frame fwd+bwd)', 'value': round(args.batch * world * args.steps / elapsed, 3),

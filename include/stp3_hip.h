@@ -230,6 +230,18 @@ int stp3_bn_apply_bwd(const stp3_bn_dims* dims, const void* dy, const void* x, c
                       const void* res, const float* oscale, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, const float* sums, double count, void* dx,
                       void* dres, void* stream);
+/* Single-process composites (no cross-replica exchange between the passes; same kernels, one call):
+ *   stp3_bn_fwd_train : stats + apply.  stat_buf [4][C] float32 receives sum, sum of squares, mean, invstd.
+ *   stp3_bn_bwd_train : reduce + apply. dres as in stp3_bn_apply_bwd; mean / invstd from the forward;
+ *                       sum_buf [N+1][3][C] float32 receives the per-sample sums and, last, their totals. */
+int stp3_bn_fwd_train(const stp3_bn_dims* dims, const void* x, const float* sbias, const void* res,
+                      const float* oscale, const float* gamma, const float* beta, float eps, float momentum,
+                      float* running_mean, float* running_var, float* stat_buf, void* workspace,
+                      size_t workspace_bytes, void* y, void* stream);
+int stp3_bn_bwd_train(const stp3_bn_dims* dims, const void* dy, const void* x, const float* sbias,
+                      const void* res, const float* oscale, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, void* workspace, size_t workspace_bytes,
+                      float* sum_buf, void* dx, void* dres, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense 2-D convolution, bf16 MFMA implicit GEMM, NHWC.

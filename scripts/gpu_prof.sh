@@ -6,7 +6,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 STEPS=4
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python bench.py --steps $STEPS --warmup 3 --no-cpu-baseline "$@" > $OUT/prof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-roofline "$@" > $OUT/prof.log 2>&1
 grep '^{' $OUT/prof.log | tail -1 > $OUT/bench_profiled.json
 KT=$(find /tmp/prof_$TAG -name '*kernel_trace.csv' | head -1)
 MS=$(python -c "import json;print(json.load(open('$OUT/bench_profiled.json'))['ms_per_step']*($STEPS-1))" 2>/dev/null || echo 300)

@@ -1,0 +1,42 @@
+"""HIP-event timing of the MFMA convolution kernels on the model's dominant shapes (B=4, T=3)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'st-p3_amd'))
+import torch
+from stp3_amd import ops
+
+SHAPES = [
+    # name, N, Cin, H, W, Cout, K, stride, pad, dil
+    ('temporal head 3x3 128->128 @200x200', 12, 128, 200, 200, 128, 3, 1, 1, 1),
+    ('temporal ASPP 3x3 d12 64->128 @200x200', 12, 64, 200, 200, 128, 3, 1, 12, 12),
+    ('temporal ASPP project 1x1 512->128', 12, 512, 200, 200, 128, 1, 1, 0, 1),
+    ('decoder stem 7x7/2 64->64 @200x200', 12, 64, 200, 200, 64, 7, 2, 3, 1),
+    ('decoder head 3x3 64->64 @200x200', 12, 64, 200, 200, 64, 3, 1, 1, 1),
+    ('encoder upconcat 3x3 216->64 @28x60', 72, 216, 28, 60, 64, 3, 1, 1, 1),
+    ('trunk expand 1x1 24->144 @112x240', 72, 24, 112, 240, 144, 1, 1, 0, 1),
+    ('trunk project 1x1 144->32 @56x120', 72, 144, 56, 120, 32, 1, 1, 0, 1),
+    ('trunk expand 1x1 160->960 @14x30', 72, 160, 14, 30, 960, 1, 1, 0, 1),
+    ('trunk project 1x1 960->160 @14x30', 72, 960, 14, 30, 160, 1, 1, 0, 1),
+]
+
+
+def ev(fn, iters=10, warm=2):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+for name, n, cin, h, w, cout, k, st, pad, dil in SHAPES:
+    x = torch.randn(n, cin, h, w, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wgt = torch.randn(cout, cin, k, k, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = ops._conv2d_launch(x, wgt, None, st, (pad, pad), (dil, dil), torch.bfloat16)
+    flops = 2.0 * y.numel() * cin * k * k
+    t_f = ev(lambda: ops._conv2d_launch(x, wgt, None, st, (pad, pad), (dil, dil), torch.bfloat16))
+    dy = torch.randn_like(y)
+    t_w = ev(lambda: ops._conv2d_wgrad(dy, x, (cout, cin, k, k), st, (pad, pad), (dil, dil)))
+    byts = (x.numel() + y.numel() + wgt.numel()) * 2
+    print(f'{name:45s} fwd {t_f*1e3:8.1f} us {flops/t_f/1e9:7.1f} TF/s {byts/t_f/1e6:7.1f} GB/s | wgrad {t_w*1e3:8.1f} us {flops/t_w/1e9:7.1f} TF/s')

@@ -29,6 +29,7 @@ struct BnDims {
 };
 
 constexpr int kThreads = 256;
+constexpr int kUnroll = 4;   // rows per thread per iteration: independent 16-byte loads in flight
 
 // ---- element access ---------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
@@ -158,14 +159,22 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(BnDims d, const T* _
 #pragma unroll
         for (int j = 0; j < VEC; ++j) sb[j] = (d.has_sbias && c0 + j < d.C) ? sbias[(size_t)n * d.C + c0 + j] : 0.f;
         const T* xs = x + (size_t)n * d.rows * d.ldx + c0;
-        for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += gridDim.x * m.RL) {
-            float v[VEC];
-            Io<T, VEC>::load(xs + (size_t)r * d.ldx, v);
+        const int step = gridDim.x * m.RL;
+        for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += kUnroll * step) {
+            float v[kUnroll][VEC];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const float t = v[j] + sb[j];
-                acc[0][j] += t;
-                acc[1][j] = fmaf(t, t, acc[1][j]);
+            for (int u = 0; u < kUnroll; ++u)                       // kUnroll independent loads in flight
+                if (r + u * step < d.rows) Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                if (r + u * step < d.rows) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const float t = v[u][j] + sb[j];
+                        acc[0][j] += t;
+                        acc[1][j] = fmaf(t, t, acc[1][j]);
+                    }
+                }
             }
         }
     }
@@ -269,19 +278,30 @@ __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
     const T* xs = x + (size_t)n * d.rows * d.ldx + c0;
     const T* rs = d.res_mode ? res + (size_t)n * d.rows * d.ldr + c0 : nullptr;
     T* ys = y + (size_t)n * d.rows * d.ldy + c0;
-    for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += gridDim.x * m.RL) {
-        float v[VEC], rv[VEC];
-        Io<T, VEC>::load(xs + (size_t)r * d.ldx, v);
-        if (d.res_mode) Io<T, VEC>::load(rs + (size_t)r * d.ldr, rv);
+    const int step = gridDim.x * m.RL;
+    for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += kUnroll * step) {
+        float v[kUnroll][VEC], rv[kUnroll][VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            float t = fmaf(v[j], scale[j], shift[j]);
-            if (d.res_mode == STP3_RES_BEFORE_ACT) t += rv[j];
-            t = act_fwd(d.act, t) * os;
-            if (d.res_mode == STP3_RES_AFTER_ACT) t += rv[j];
-            v[j] = t;
+        for (int u = 0; u < kUnroll; ++u) {
+            if (r + u * step < d.rows) {
+                Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
+                if (d.res_mode) Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
+            }
         }
-        Io<T, VEC>::store(ys + (size_t)r * d.ldy, v);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            if (r + u * step < d.rows) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    float t = fmaf(v[u][j], scale[j], shift[j]);
+                    if (d.res_mode == STP3_RES_BEFORE_ACT) t += rv[u][j];
+                    t = act_fwd(d.act, t) * os;
+                    if (d.res_mode == STP3_RES_AFTER_ACT) t += rv[u][j];
+                    v[u][j] = t;
+                }
+                Io<T, VEC>::store(ys + (size_t)(r + u * step) * d.ldy, v[u]);
+            }
+        }
     }
 }
 
@@ -316,23 +336,35 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
         const T* xs = x + (size_t)n * d.rows * d.ldx + c0;
         const T* gs = dy + (size_t)n * d.rows * d.ldy + c0;
         const T* rs = d.res_mode == STP3_RES_BEFORE_ACT ? res + (size_t)n * d.rows * d.ldr + c0 : nullptr;
-        for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += gridDim.x * m.RL) {
-            float v[VEC], g[VEC], rv[VEC];
-            Io<T, VEC>::load(xs + (size_t)r * d.ldx, v);
-            Io<T, VEC>::load(gs + (size_t)r * d.ldy, g);
-            if (rs) Io<T, VEC>::load(rs + (size_t)r * d.ldr, rv);
+        const int step = gridDim.x * m.RL;
+        constexpr int U = 2;
+        for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += U * step) {
+            float v[U][VEC], g[U][VEC], rv[U][VEC];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const float xh = (v[j] - mu[j]) * is[j];
-                float gg = g[j] * os;
-                if (d.act != STP3_ACT_NONE) {
-                    float pre = fmaf(xh, ga[j], be[j]);
-                    if (rs) pre += rv[j];
-                    gg *= act_grad(d.act, pre);
+            for (int u = 0; u < U; ++u) {
+                if (r + u * step < d.rows) {
+                    Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
+                    Io<T, VEC>::load(gs + (size_t)(r + u * step) * d.ldy, g[u]);
+                    if (rs) Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
                 }
-                acc[0][j] += gg;
-                acc[1][j] = fmaf(gg, xh, acc[1][j]);
-                acc[2][j] += xh;                                    // needed for the per-sample bias gradient
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (r + u * step < d.rows) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const float xh = (v[u][j] - mu[j]) * is[j];
+                        float gg = g[u][j] * os;
+                        if (d.act != STP3_ACT_NONE) {
+                            float pre = fmaf(xh, ga[j], be[j]);
+                            if (rs) pre += rv[u][j];
+                            gg *= act_grad(d.act, pre);
+                        }
+                        acc[0][j] += gg;
+                        acc[1][j] = fmaf(gg, xh, acc[1][j]);
+                        acc[2][j] += xh;                            // needed for the per-sample bias gradient
+                    }
+                }
             }
         }
     }
@@ -371,25 +403,37 @@ __global__ __launch_bounds__(kThreads) void bn_apply_bwd_kernel(
     const T* rs = pre_res ? res + (size_t)n * d.rows * d.ldr + c0 : nullptr;
     T* dxs = dx + (size_t)n * d.rows * d.ldx + c0;
     T* drs = (pre_res && dres) ? dres + (size_t)n * d.rows * d.ldr + c0 : nullptr;
-    for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += gridDim.x * m.RL) {
-        float v[VEC], g[VEC], rv[VEC];
-        Io<T, VEC>::load(xs + (size_t)r * d.ldx, v);
-        Io<T, VEC>::load(gs + (size_t)r * d.ldy, g);
-        if (rs) Io<T, VEC>::load(rs + (size_t)r * d.ldr, rv);
+    const int step = gridDim.x * m.RL;
+    constexpr int U = 2;
+    for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += U * step) {
+        float v[U][VEC], g[U][VEC], rv[U][VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const float xh = (v[j] - mu[j]) * is[j];
-            float gg = g[j] * os;
-            if (d.act != STP3_ACT_NONE) {
-                float pre = fmaf(xh, ga[j], be[j]);
-                if (rs) pre += rv[j];
-                gg *= act_grad(d.act, pre);
+        for (int u = 0; u < U; ++u) {
+            if (r + u * step < d.rows) {
+                Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
+                Io<T, VEC>::load(gs + (size_t)(r + u * step) * d.ldy, g[u]);
+                if (rs) Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
             }
-            g[j] = gg;                                             // gradient w.r.t. the pre-activation
-            v[j] = ga[j] * is[j] * (gg - k0[j] - xh * k1[j]);
         }
-        Io<T, VEC>::store(dxs + (size_t)r * d.ldx, v);
-        if (drs) Io<T, VEC>::store(drs + (size_t)r * d.ldr, g);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (r + u * step < d.rows) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float xh = (v[u][j] - mu[j]) * is[j];
+                    float gg = g[u][j] * os;
+                    if (d.act != STP3_ACT_NONE) {
+                        float pre = fmaf(xh, ga[j], be[j]);
+                        if (rs) pre += rv[u][j];
+                        gg *= act_grad(d.act, pre);
+                    }
+                    g[u][j] = gg;                                  // gradient w.r.t. the pre-activation
+                    v[u][j] = ga[j] * is[j] * (gg - k0[j] - xh * k1[j]);
+                }
+                Io<T, VEC>::store(dxs + (size_t)(r + u * step) * d.ldx, v[u]);
+                if (drs) Io<T, VEC>::store(drs + (size_t)(r + u * step) * d.ldr, g[u]);
+            }
+        }
     }
 }
 
@@ -561,6 +605,34 @@ int stp3_bn_apply_bwd(const stp3_bn_dims* p, const void* dy, const void* x, cons
                                          (const T*)dy, (const T*)x, sbias, (const T*)res, oscale, mean, invstd, gamma,
                                          beta, sums, inv_count, (T*)dx, (T*)dres));
     return status();
+}
+
+
+// ---- single-process composites: the same launches as the split calls above, one host crossing each ----
+int stp3_bn_fwd_train(const stp3_bn_dims* p, const void* x, const float* sbias, const void* res, const float* oscale,
+                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, float* stat_buf, void* workspace, size_t workspace_bytes, void* y,
+                      void* stream) {
+    if (!p || !stat_buf) return STP3_EINVAL;
+    const int C = p->C;
+    int rc = stp3_bn_stats(p, x, sbias, workspace, workspace_bytes, stat_buf, stream);
+    if (rc) return rc;
+    return stp3_bn_apply_fwd(p, x, sbias, res, oscale, stat_buf, (double)p->N * p->rows, gamma, beta, eps, momentum,
+                             running_mean, running_var, stat_buf + 2 * C, stat_buf + 3 * C, y, stream);
+}
+
+int stp3_bn_bwd_train(const stp3_bn_dims* p, const void* dy, const void* x, const float* sbias, const void* res,
+                      const float* oscale, const float* mean, const float* invstd, const float* gamma,
+                      const float* beta, void* workspace, size_t workspace_bytes, float* sum_buf, void* dx, void* dres,
+                      void* stream) {
+    if (!p || !sum_buf) return STP3_EINVAL;
+    float* sample_sums = sum_buf;                                  // [N][3][C]
+    float* sums = sum_buf + (size_t)p->N * 3 * p->C;               // [3][C]
+    int rc = stp3_bn_bwd_reduce(p, dy, x, sbias, res, oscale, mean, invstd, gamma, beta, workspace, workspace_bytes,
+                                sample_sums, sums, stream);
+    if (rc) return rc;
+    return stp3_bn_apply_bwd(p, dy, x, sbias, res, oscale, mean, invstd, gamma, beta, sums, (double)p->N * p->rows, dx,
+                             dres, stream);
 }
 
 }  // extern "C"

@@ -300,13 +300,22 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
     }
 }
 
+// dw[i] = sum_k partial[k][i]: 16 columns x 16 split lanes per workgroup, fixed tree order (deterministic)
 __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(int splits, size_t n, const float* __restrict__ partial,
                                                                   float* __restrict__ dw) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float red[256];
+    const int il = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * 16 + il;
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += partial[(size_t)k * n + i];
-    dw[i] = s;
+    if (i < n)
+        for (int k = kl; k < splits; k += 16) s += partial[(size_t)k * n + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 8; st > 0; st >>= 1) {
+        if (kl < st) red[threadIdx.x] += red[threadIdx.x + st * 16];
+        __syncthreads();
+    }
+    if (kl == 0 && i < n) dw[i] = red[il];
 }
 
 inline int status() {
@@ -391,7 +400,7 @@ int stp3_conv2d_wgrad(const stp3_conv_dims* p, const void* dy, const void* x, fl
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(conv2d_wgrad_kernel, dim3(tco * tci, p->KH * p->KW, splits), dim3(256), 0, s, d, tci, ksteps,
                        (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace);
-    hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((wsize + 255) / 256)), dim3(256), 0, s, splits, wsize,
+    hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((wsize + 15) / 16)), dim3(256), 0, s, splits, wsize,
                        (const float*)workspace, dw);
     return status();
 }

@@ -235,13 +235,22 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwDims d, const 
     }
 }
 
+// dw[i] = sum_b partial[b][i]: 16 columns x 16 block lanes per workgroup, fixed tree order (deterministic)
 __global__ __launch_bounds__(256) void dwconv_reduce_partials_kernel(int nblocks, int n, const float* __restrict__ partial,
                                                                      float* __restrict__ dw) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float red[256];
+    const int il = threadIdx.x & 15, bl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + il;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * n + i];
-    dw[i] = s;
+    if (i < n)
+        for (int b = bl; b < nblocks; b += 16) s += partial[(int64_t)b * n + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 8; st > 0; st >>= 1) {
+        if (bl < st) red[threadIdx.x] += red[threadIdx.x + st * 16];
+        __syncthreads();
+    }
+    if (bl == 0 && i < n) dw[i] = red[il];
 }
 
 constexpr int kWgradBlocks = 512;
@@ -294,7 +303,7 @@ int launch_bwd_weight(const DwDims& d, const void* x, const void* dy, float* dw,
     hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, S>), dim3(bx, by, K), dim3(256), lds, s, d, (const T*)x,
                        (const T*)dy, ws);
     const int n = K * K * d.C;
-    hipLaunchKernelGGL(dwconv_reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, bx, n, ws, dw);
+    hipLaunchKernelGGL(dwconv_reduce_partials_kernel, dim3((n + 15) / 16), dim3(256), 0, s, bx, n, ws, dw);
     return status();
 }
 

@@ -395,13 +395,24 @@ __global__ __launch_bounds__(1024) void lift_runs_kernel(Dims dm, const float* _
     for (int h = g; h < dm.fH; h += nwaves) fcol[h * 64 + lane] = chan ? frow[(size_t)h * fstride] : 0.f;
     __syncthreads();
 
-    int cur[DG], rid[DG];
+    int cur[DG], rid[DG], cnt[DG];
     float acc[DG];
 #pragma unroll
     for (int j = 0; j < DG; ++j) {
         cur[j] = -1;
         rid[j] = (EXACT || d0 + j < dm.D) ? rb[j] : 0;
+        cnt[j] = 0;
         acc[j] = 0.f;
+    }
+    // destination rows of the first 8 runs of every bin, fetched up front (lane = (bin, k)): a flush then
+    // costs a v_readlane instead of a dependent scalar load (a column-bin has 2-3 runs on average)
+    int destv;
+    {
+        const int bj = lane >> 3, bk = lane & 7;
+        const bool bin_ok = EXACT || d0 + bj < dm.D;
+        const int first = bin_ok ? rb[bj] : 0;
+        const int next = bin_ok ? rb[bj + 1] : 0;
+        destv = (first + bk < next) ? dst[first + bk] : 0;
     }
     // prob / voxel ids of 32 rows x 8 bins are fetched with 4 + 4 vector loads (lane = (row, bin)) and
     // broadcast with v_readlane: the point loop itself touches no global memory except the run stores.
@@ -433,9 +444,10 @@ __global__ __launch_bounds__(1024) void lift_runs_kernel(Dims dm, const float* _
                             const float p = readlane_f(P[k], r * 8 + j);
                             if (v != cur[j]) {
                                 if (cur[j] >= 0) {
-                                    const int row = dst[rid[j]];
+                                    const int row = cnt[j] < 8 ? __builtin_amdgcn_readlane(destv, j * 8 + cnt[j])
+                                                               : dst[rid[j] + cnt[j]];
                                     if (chan) out[(size_t)row * dm.C] = acc[j];
-                                    ++rid[j];
+                                    ++cnt[j];
                                 }
                                 acc[j] = 0.f;
                                 cur[j] = v;
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(1024) void lift_runs_kernel(Dims dm, const float* _
 #pragma unroll
     for (int j = 0; j < DG; ++j) {
         if ((EXACT || d0 + j < dm.D) && cur[j] >= 0) {
-            const int row = dst[rid[j]];
+            const int row = cnt[j] < 8 ? __builtin_amdgcn_readlane(destv, j * 8 + cnt[j]) : dst[rid[j] + cnt[j]];
             if (chan) out[(size_t)row * dm.C] = acc[j];
         }
     }

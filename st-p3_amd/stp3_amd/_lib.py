@@ -90,6 +90,9 @@ SIGNATURES = {
                           + [c_void_p] * 6),
     'stp3_bn_bwd_reduce': (c_int, [_BN_P] + [c_void_p] * 10 + [c_size_t, c_void_p, c_void_p, c_void_p]),
     'stp3_bn_apply_bwd': (c_int, [_BN_P] + [c_void_p] * 10 + [c_double, c_void_p, c_void_p, c_void_p]),
+    'stp3_bn_fwd_train': (c_int, [_BN_P] + [c_void_p] * 6 + [c_float, c_float] + [c_void_p] * 4 + [c_size_t, c_void_p,
+                                                                                                 c_void_p]),
+    'stp3_bn_bwd_train': (c_int, [_BN_P] + [c_void_p] * 10 + [c_size_t] + [c_void_p] * 4),
     'stp3_conv2d_fwd': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_conv2d_wgrad_workspace': (c_int, [ctypes.POINTER(ConvDims), ctypes.POINTER(c_size_t)]),
     'stp3_conv2d_wgrad': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -105,15 +105,29 @@ def bn_act(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=
                       act=act, res=res, res_mode=res_mode, sbias=sbias, oscale=oscale, group=group)
 
 
-# Dense convolutions: the hand-written bf16 MFMA implicit-GEMM kernel (stp3_conv.hip) whenever the operands
-# are bf16 (autocast) on the GPU and the shape is supported; the vendor library otherwise (fp32 parity runs,
-# the 3-channel stem, CPU).  STP3_MFMA_CONV=0 switches the kernel off for A/B measurements.
-USE_MFMA_CONV = os.environ.get('STP3_MFMA_CONV', '1') != '0'
+# Dense convolutions.  The hand-written bf16 MFMA implicit-GEMM kernels (stp3_conv.hip) are parity-tested on
+# every layer shape of the model; the dispatch below uses them where they are at least on par with the vendor
+# library on MI355X (profiles/r01_time_conv.txt): layers with >= 64 input AND output channels (the BEV-side
+# 3x3 / dilated / 7x7 / wide 1x1 contractions, where they run at 160-200 TFLOP/s).  The thin-channel,
+# activation-bandwidth-bound pointwise layers of the EfficientNet trunk (24..56 channels) stay on the vendor
+# kernels until the narrow-tile variants land.
+#   STP3_MFMA_CONV=all  every supported shape      STP3_MFMA_CONV=0  never (A/B measurements)
+_MFMA_MODE = os.environ.get('STP3_MFMA_CONV', 'auto')
+MFMA_MIN_CHANNELS = 64
+
+
+def _use_mfma(x, weight, stride):
+    if _MFMA_MODE == '0' or not x.is_cuda:
+        return False
+    if not (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()):
+        return False
+    if not ops.conv2d_supported(x, weight, stride):
+        return False
+    return _MFMA_MODE == 'all' or min(weight.shape[0], weight.shape[1]) >= MFMA_MIN_CHANNELS
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
-    if (USE_MFMA_CONV and x.is_cuda and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled())
-            and ops.conv2d_supported(x, weight, stride)):
+    if _use_mfma(x, weight, stride):
         return ops.conv2d(x, weight, bias, stride, padding, dilation)
     return F.conv2d(x, weight, bias, stride, padding, dilation)
 

@@ -22,7 +22,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..layers import fused as _fused
 from ..layers.fused import ACT_NONE, ACT_SWISH, RES_AFTER_ACT, bn_act, conv2d
+
+_MFMA_ALL = _fused._MFMA_MODE == 'all'
 
 # (repeats, kernel, stride, expand, in, out) of the 7 base stages, SE ratio 0.25 everywhere
 _BASE_STAGES = ((1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
@@ -61,7 +64,7 @@ class StaticSamePadConv2d(nn.Conv2d):
             # squeeze-excite 1x1 convs on a pooled 1x1 map are plain GEMMs
             y = F.linear(x.flatten(1), self.weight.flatten(1), self.bias)
             return y.view(*y.shape, 1, 1)
-        if self.groups == 1 and x.is_cuda and self.in_channels % 8 and torch.is_autocast_enabled():
+        if self.groups == 1 and x.is_cuda and self.in_channels % 8 and torch.is_autocast_enabled() and _MFMA_ALL:
             # the 3-channel stem: zero-pad the channels to 8 (together with the "same" padding, one copy) so that
             # it runs on the MFMA kernel too; the padded weight columns are zero and their gradient is dropped
             cp = (-self.in_channels) % 8

@@ -27,6 +27,10 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _stream_handle():
+    return torch.cuda.current_stream().cuda_stream
+
+
 # Optional live timing of the HIP operators with events recorded on the stream they are launched on
 # (bench.py's roofline numbers).  Off by default: zero overhead in normal use.
 PROFILE_ENABLED = False
@@ -373,23 +377,25 @@ ACT_NONE, ACT_RELU, ACT_SWISH = _lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_SWISH
 RES_NONE, RES_BEFORE_ACT, RES_AFTER_ACT = _lib.RES_NONE, _lib.RES_BEFORE_ACT, _lib.RES_AFTER_ACT
 
 _BN_WORKSPACE = {}
+_BN_MAX_ROW_BLOCKS = 128          # STP3_BN_MAX_ROW_BLOCKS
 
 
-def _bn_workspace(dims, device):
-    nbytes = ctypes.c_size_t()
-    check(_lib.lib().stp3_bn_workspace_bytes(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_bn_workspace_bytes')
-    key = torch.device(device)
-    ws = _BN_WORKSPACE.get(key)
-    if ws is None or ws.numel() < nbytes.value:
-        ws = torch.empty(max(nbytes.value, 1 << 20), dtype=torch.uint8, device=key)
-        _BN_WORKSPACE[key] = ws
-    return ws, nbytes.value
+def _bn_workspace(n, c, device):
+    """Scratch of the two-stage reductions: N * 128 * 3 * C floats at most (one buffer per device, grown on demand)."""
+    need = n * _BN_MAX_ROW_BLOCKS * 3 * c * 4
+    ws = _BN_WORKSPACE.get(device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 8 << 20), dtype=torch.uint8, device=device)
+        _BN_WORKSPACE[device] = ws
+    return ws, need
 
 
 def _rows_view(t):
     """(N, C, H, W) tensor -> (tensor whose memory is [N][H*W][ld] channels-last, ld).  Channels-last tensors
     and channel-slices of them are used in place; anything else is copied to channels-last once."""
     n, c, h, w = t.shape
+    if t.is_contiguous(memory_format=torch.channels_last):
+        return t, c
     sn, sc, sh, sw = t.stride()
     if c > 1 and sc != 1:
         ok = False
@@ -403,11 +409,13 @@ def _rows_view(t):
 
 
 def _opt_ptr(t):
-    return _ptr(t) if t is not None else None
+    return t.data_ptr() if t is not None else None
 
 
 def _f32(t):
-    return None if t is None else t.detach().float().contiguous()
+    if t is None or (t.dtype == torch.float32 and t.is_contiguous()):
+        return t
+    return t.detach().float().contiguous()
 
 
 class _BnAct(torch.autograd.Function):
@@ -424,50 +432,54 @@ class _BnAct(torch.autograd.Function):
         else:
             raise _lib.Stp3HipError(f'bn_act supports float32 / bfloat16, got {x.dtype}')
         n, c, h, w = x.shape
+        dev = x.device
         x, ldx = _rows_view(x)
         ldr = c
         if res is not None:
             if res.shape != x.shape:
                 raise _lib.Stp3HipError('bn_act: residual shape mismatch')
-            res, ldr = _rows_view(res.to(x.dtype))
+            res, ldr = _rows_view(res if res.dtype == x.dtype else res.to(x.dtype))
         else:
             res_mode = RES_NONE
-        y = torch.empty((n, c, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        dims = _lib.BnDims(n, h * w, c, ldx, c, ldr, dt, int(act), int(res_mode), int(sbias is not None),
-                           int(oscale is not None))
+        y = torch.empty((n, c, h, w), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+        dims = _lib.BnDims(n, h * w, c, ldx, c, ldr, dt, act, res_mode, sbias is not None, oscale is not None)
         lib = _lib.lib()
         gamma, beta = _f32(weight), _f32(bias)
         sb, osc = _f32(sbias), _f32(oscale)
+        stream = _stream_handle()
         world = 1
+        stat = None
         if training:
-            ws, ws_bytes = _bn_workspace(dims, x.device)
-            packed = torch.empty(2 * c + 1, dtype=torch.float32, device=x.device)
-            check(lib.stp3_bn_stats(ctypes.byref(dims), _ptr(x), _opt_ptr(sb), _ptr(ws), ctypes.c_size_t(ws_bytes),
-                                    _ptr(packed), _stream()), 'stp3_bn_stats')
-            count = float(n * h * w)
+            ws, ws_bytes = _bn_workspace(n, c, dev)
+            stat = torch.empty(4 * c, dtype=torch.float32, device=dev)       # sum | sum of squares | mean | invstd
+            base = stat.data_ptr()
             if group is not False and torch.distributed.is_available() and torch.distributed.is_initialized():
                 world = torch.distributed.get_world_size(group)
-            if world > 1:
+            if world == 1:
+                check(lib.stp3_bn_fwd_train(ctypes.byref(dims), x.data_ptr(), _opt_ptr(sb), _opt_ptr(res), _opt_ptr(osc),
+                                            _opt_ptr(gamma), _opt_ptr(beta), eps, momentum, _opt_ptr(running_mean),
+                                            _opt_ptr(running_var), base, ws.data_ptr(), ws_bytes, y.data_ptr(), stream),
+                      'stp3_bn_fwd_train')
+                count = float(n * h * w)
+            else:
+                check(lib.stp3_bn_stats(ctypes.byref(dims), x.data_ptr(), _opt_ptr(sb), ws.data_ptr(), ws_bytes, base,
+                                        stream), 'stp3_bn_stats')
                 # cross-replica statistics (train.py:47 sync_batchnorm): one small all-reduce per layer;
                 # every rank holds the same number of elements (the batch is sharded evenly)
-                torch.distributed.all_reduce(packed[:2 * c], group=group)
-                count *= world
-            mean = torch.empty(c, dtype=torch.float32, device=x.device)
-            invstd = torch.empty(c, dtype=torch.float32, device=x.device)
-            check(lib.stp3_bn_apply_fwd(ctypes.byref(dims), _ptr(x), _opt_ptr(sb), _opt_ptr(res), _opt_ptr(osc),
-                                        _ptr(packed), ctypes.c_double(count), _opt_ptr(gamma), _opt_ptr(beta),
-                                        ctypes.c_float(eps), ctypes.c_float(momentum), _opt_ptr(running_mean),
-                                        _opt_ptr(running_var), _ptr(mean), _ptr(invstd), _ptr(y), _stream()),
-                  'stp3_bn_apply_fwd')
+                torch.distributed.all_reduce(stat[:2 * c], group=group)
+                count = float(n * h * w) * world
+                check(lib.stp3_bn_apply_fwd(ctypes.byref(dims), x.data_ptr(), _opt_ptr(sb), _opt_ptr(res), _opt_ptr(osc),
+                                            base, count, _opt_ptr(gamma), _opt_ptr(beta), eps, momentum,
+                                            _opt_ptr(running_mean), _opt_ptr(running_var), base + 8 * c, base + 12 * c,
+                                            y.data_ptr(), stream), 'stp3_bn_apply_fwd')
         else:
             count = 0.0
-            mean = running_mean.detach().float()
-            invstd = torch.rsqrt(running_var.detach().float() + eps)
-            check(lib.stp3_bn_apply_fwd(ctypes.byref(dims), _ptr(x), _opt_ptr(sb), _opt_ptr(res), _opt_ptr(osc),
-                                        None, ctypes.c_double(0.0), _opt_ptr(gamma), _opt_ptr(beta),
-                                        ctypes.c_float(eps), ctypes.c_float(0.0), _ptr(running_mean),
-                                        _ptr(running_var), None, None, _ptr(y), _stream()), 'stp3_bn_apply_fwd')
-        ctx.save_for_backward(x, res if res_mode == RES_BEFORE_ACT else None, sb, osc, gamma, beta, mean, invstd)
+            stat = torch.cat([running_mean.detach().float(), running_var.detach().float(), running_mean.detach().float(),
+                              torch.rsqrt(running_var.detach().float() + eps)])
+            check(lib.stp3_bn_apply_fwd(ctypes.byref(dims), x.data_ptr(), _opt_ptr(sb), _opt_ptr(res), _opt_ptr(osc),
+                                        None, 0.0, _opt_ptr(gamma), _opt_ptr(beta), eps, 0.0, running_mean.data_ptr(),
+                                        running_var.data_ptr(), None, None, y.data_ptr(), stream), 'stp3_bn_apply_fwd')
+        ctx.save_for_backward(x, res if res_mode == RES_BEFORE_ACT else None, sb, osc, gamma, beta, stat)
         ctx.dims, ctx.training, ctx.count, ctx.world, ctx.group = dims, training, count, world, group
         ctx.res_dtype = None if res is None else res.dtype
         ctx.has_affine = (weight is not None, bias is not None)
@@ -476,58 +488,76 @@ class _BnAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, res, sb, osc, gamma, beta, mean, invstd = ctx.saved_tensors
+        x, res, sb, osc, gamma, beta, stat = ctx.saved_tensors
         dims = ctx.dims
         n, rows, c = dims.N, dims.rows, dims.C
+        dev = x.device
         lib = _lib.lib()
-        dy = dy.to(x.dtype)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
         dy, ldy = _rows_view(dy)
         if ldy != c:
             dy = dy.contiguous(memory_format=torch.channels_last)
-        ws, ws_bytes = _bn_workspace(dims, x.device)
-        sample_sums = torch.empty(n, 3, c, dtype=torch.float32, device=x.device)
-        sums = torch.empty(3, c, dtype=torch.float32, device=x.device)
-        check(lib.stp3_bn_bwd_reduce(ctypes.byref(dims), _ptr(dy), _ptr(x), _opt_ptr(sb), _opt_ptr(res), _opt_ptr(osc),
-                                     _ptr(mean), _ptr(invstd), _opt_ptr(gamma), _opt_ptr(beta), _ptr(ws),
-                                     ctypes.c_size_t(ws_bytes), _ptr(sample_sums), _ptr(sums), _stream()),
-              'stp3_bn_bwd_reduce')
-        dgamma = sums[1].to(ctx.in_dtypes[0]) if ctx.has_affine[0] and ctx.needs_input_grad[1] else None
-        dbeta = sums[0].to(ctx.in_dtypes[1]) if ctx.has_affine[1] and ctx.needs_input_grad[2] else None
-        gsums = sums
-        if ctx.training and ctx.world > 1:
-            gsums = sums.clone()
-            torch.distributed.all_reduce(gsums, group=ctx.group)
-        dx = torch.empty_like(x)                      # same (possibly channel-sliced) strides as x
-        if dx.stride() != x.stride():
-            dx = torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device)
-        dres = None
-        if dims.res_mode == RES_BEFORE_ACT and ctx.needs_input_grad[3]:
-            dres = torch.empty((n, c) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device,
-                               memory_format=torch.channels_last)
-            bdims = _lib.BnDims(dims.N, dims.rows, dims.C, dims.ldx, dims.ldy, c, dims.dtype, dims.act,
-                                dims.res_mode, dims.has_sbias, dims.has_oscale)
-            # the reduce pass read `res` with its own stride; the apply pass writes dres densely, so it needs
-            # res dense too (one stride for both)
-            if dims.ldr != c:
-                res = res.contiguous(memory_format=torch.channels_last)
+        ws, ws_bytes = _bn_workspace(n, c, dev)
+        sumbuf = torch.empty((n + 1) * 3 * c, dtype=torch.float32, device=dev)   # [N][3][C] per sample | [3][C] total
+        sums_off = n * 3 * c
+        mean_p, invstd_p = stat.data_ptr() + 8 * c, stat.data_ptr() + 12 * c
+        stream = _stream_handle()
+        if x.is_contiguous(memory_format=torch.channels_last):
+            dx = torch.empty_like(x)
         else:
-            bdims = dims
-        check(lib.stp3_bn_apply_bwd(ctypes.byref(bdims), _ptr(dy), _ptr(x), _opt_ptr(sb), _opt_ptr(res),
-                                    _opt_ptr(osc), _ptr(mean), _ptr(invstd), _opt_ptr(gamma), _opt_ptr(beta),
-                                    _ptr(gsums) if ctx.training else None, ctypes.c_double(max(ctx.count, 1.0)),
-                                    _ptr(dx), _opt_ptr(dres), _stream()), 'stp3_bn_apply_bwd')
+            dx = torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=dev)   # channel-sliced view of a wider tensor
+        dres = None
+        bdims = dims
+        if dims.res_mode == RES_BEFORE_ACT and ctx.needs_input_grad[3]:
+            dres = torch.empty((n, c) + tuple(x.shape[2:]), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+        simple = ctx.training and ctx.world == 1 and (dres is None or dims.ldr == c)
+        if simple:
+            check(lib.stp3_bn_bwd_train(ctypes.byref(dims), dy.data_ptr(), x.data_ptr(), _opt_ptr(sb), _opt_ptr(res),
+                                        _opt_ptr(osc), mean_p, invstd_p, _opt_ptr(gamma), _opt_ptr(beta), ws.data_ptr(),
+                                        ws_bytes, sumbuf.data_ptr(), dx.data_ptr(), _opt_ptr(dres), stream),
+                  'stp3_bn_bwd_train')
+            gsums = sumbuf[sums_off:].view(3, c)
+            lsums = gsums
+        else:
+            check(lib.stp3_bn_bwd_reduce(ctypes.byref(dims), dy.data_ptr(), x.data_ptr(), _opt_ptr(sb), _opt_ptr(res),
+                                         _opt_ptr(osc), mean_p, invstd_p, _opt_ptr(gamma), _opt_ptr(beta), ws.data_ptr(),
+                                         ws_bytes, sumbuf.data_ptr(), sumbuf.data_ptr() + 4 * sums_off, stream),
+                  'stp3_bn_bwd_reduce')
+            lsums = sumbuf[sums_off:].view(3, c)
+            gsums = lsums
+            if ctx.training and ctx.world > 1:
+                gsums = lsums.clone()
+                torch.distributed.all_reduce(gsums, group=ctx.group)
+            if dres is not None and dims.ldr != c:
+                # the reduce pass read `res` with its own stride; the apply pass writes dres densely and reads res
+                # with the same stride
+                res = res.contiguous(memory_format=torch.channels_last)
+                bdims = _lib.BnDims(dims.N, dims.rows, dims.C, dims.ldx, dims.ldy, c, dims.dtype, dims.act,
+                                    dims.res_mode, dims.has_sbias, dims.has_oscale)
+            check(lib.stp3_bn_apply_bwd(ctypes.byref(bdims), dy.data_ptr(), x.data_ptr(), _opt_ptr(sb), _opt_ptr(res),
+                                        _opt_ptr(osc), mean_p, invstd_p, _opt_ptr(gamma), _opt_ptr(beta),
+                                        gsums.data_ptr() if ctx.training else None, max(ctx.count, 1.0), dx.data_ptr(),
+                                        _opt_ptr(dres), stream), 'stp3_bn_apply_bwd')
+        dgamma = dbeta = None
+        if ctx.has_affine[0] and ctx.needs_input_grad[1]:
+            dgamma = lsums[1] if ctx.in_dtypes[0] == torch.float32 else lsums[1].to(ctx.in_dtypes[0])
+        if ctx.has_affine[1] and ctx.needs_input_grad[2]:
+            dbeta = lsums[0] if ctx.in_dtypes[1] == torch.float32 else lsums[0].to(ctx.in_dtypes[1])
         if dims.res_mode == RES_AFTER_ACT and ctx.needs_input_grad[3]:
             dres = dy
         if dres is not None and ctx.res_dtype is not None and dres.dtype != ctx.res_dtype:
             dres = dres.to(ctx.res_dtype)
         dsbias = None
         if sb is not None and ctx.needs_input_grad[4]:
-            g = gamma if gamma is not None else torch.ones_like(invstd)
+            g = gamma if gamma is not None else 1.0
+            invstd = stat[3 * c:]
+            sample = sumbuf[:sums_off].view(n, 3, c)
             if ctx.training:
                 k = gsums / ctx.count
-                dsbias = g * invstd * (sample_sums[:, 0] - rows * k[0] - sample_sums[:, 2] * k[1])
+                dsbias = g * invstd * (sample[:, 0] - rows * k[0] - sample[:, 2] * k[1])
             else:
-                dsbias = g * invstd * sample_sums[:, 0]
+                dsbias = g * invstd * sample[:, 0]
         return dx, dgamma, dbeta, dres, dsbias, None, None, None, None, None, None, None, None, None
 
 
@@ -567,6 +597,9 @@ def _conv2d_launch(x, wb, bias, stride, pad, dil, out_dtype):
 
 
 _CONV_WORKSPACE = {}
+# The weight-gradient kernel works on 128 x 128 (Cout x Cin) tiles: below that the vendor kernel is faster today
+# (profiles/r01_time_conv.txt).  Tests set this to 0 to exercise the kernel on every shape.
+WGRAD_MIN_CHANNELS = 128
 
 
 def _conv2d_wgrad(dy, x, wshape, stride, pad, dil):
@@ -636,13 +669,11 @@ class _Conv2dMfma(torch.autograd.Function):
             dx = _conv2d_launch(g, wt, None, 1, bpad, dil, torch.bfloat16)
         need_dw = ctx.needs_input_grad[1]
         need_db = has_bias and ctx.needs_input_grad[2]
-        hip_dw = need_dw and cin % 4 == 0 and cout % 4 == 0
+        hip_dw = need_dw and cin % 4 == 0 and cout % 4 == 0 and (WGRAD_MIN_CHANNELS <= min(cin, cout))
         if hip_dw:
             dw = _conv2d_wgrad(dy, x, (cout, cin, kh, kw), stride, pad, dil).to(wdtype)
             if need_db:
-                # bias gradient = column sums of the [pixels][Cout] matrix, as a GEMV (no multi-block reduction)
-                rows = dy.permute(0, 2, 3, 1).reshape(-1, cout).float()
-                db = torch.mv(rows.t(), torch.ones(rows.shape[0], dtype=torch.float32, device=rows.device)).to(bdtype)
+                db = dy.float().sum(dim=(0, 2, 3)).to(bdtype)
         mask = [need_dx and not hip_dx, need_dw and not hip_dw, need_db and not hip_dw]
         if any(mask):
             xd = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)

@@ -32,6 +32,7 @@ CASES = [
 @pytest.mark.parametrize('case', CASES)
 def test_conv2d_forward_and_input_gradient(case):
     from stp3_amd import ops
+    ops.WGRAD_MIN_CHANNELS = 0          # exercise the MFMA weight-gradient kernel on every shape
     n, cin, h, w, cout, k, stride, pad, dil, use_bias, sliced = case
     g = torch.Generator().manual_seed(cin * 7 + cout)
     cs = cin + 8 if sliced else cin
