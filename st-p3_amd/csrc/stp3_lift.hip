@@ -360,112 +360,90 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 // ------------------------------------------------------------------------------------------
 // K2+K4: stage 1 -- depth (x) feature outer product reduced along image columns (camera side)
 // ------------------------------------------------------------------------------------------
-// Workgroup = one image column (bt, n, w); wave g owns the DG depth bins [g*DG, g*DG+DG); lane =
-// channel.  The wave streams the column's fH feature rows (one coalesced 256-B row per h, shared
-// by the workgroup's waves through L1) and keeps DG running sums acc[j] = sum_h prob[h][d]*feat[h];
-// prob and voxel ids of a row are wave-uniform (scalar loads).  When the voxel id of bin j changes
-// the finished run vector is stored as one 256-B row of `runs` at the row the plan assigned to it
-// (dest[run id]) -- ~10-20x fewer rows than frustum points, nothing is read twice, no atomics.
-template <int DG, bool EXACT>  // EXACT: D is a multiple of DG (no partial group)
-__global__ __launch_bounds__(1024) void lift_runs_kernel(Dims dm, const float* __restrict__ feat,
+// Workgroup = one image column (bt, n, w); wave g owns the 8 depth bins [8g, 8g+8).  The column's fH
+// feature rows, depth probabilities and voxel ids are staged in LDS once per workgroup.
+// Lane = (bin, 8-channel chunk): a lane keeps the running sum of ITS bin for ITS 8 channels,
+//   acc[k] += prob[h][bin] * feat[h][8*chunk + k],
+// so one wave instruction advances 8 frustum points x 64 channels (the earlier lane = channel version
+// spent 6 scalar/vector instructions per point and was issue-bound at 83 us).  When the voxel id of a bin
+// changes from one image row to the next, the 8 lanes of that bin store the finished run vector as one
+// 256-B row of `runs`, at the row the plan assigned to it (dest[run id]) -- ~12x fewer rows than frustum
+// points, every input read once, no atomics.
+template <bool VEC8>  // VEC8: C is a multiple of 8 (two float4 stores per lane)
+__global__ __launch_bounds__(1024) void lift_runs_kernel(Dims dm, int Dp, const float* __restrict__ feat,
                                                          const float* __restrict__ prob,
                                                          const int32_t* __restrict__ vox_pm,
                                                          const int32_t* __restrict__ run_base,
                                                          const int32_t* __restrict__ dest,
                                                          float* __restrict__ runs) {
-    extern __shared__ float fcol[];                       // [fH][64]: the column's feature rows
-    static_assert(DG == 8, "lane = (row of an 8-row block, bin) assumes 8 bins per wave");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* fcol = smem;                                   // [fH][64]
+    float* pcol = smem + (size_t)dm.fH * 64;              // [fH][Dp]
+    int* vcol = reinterpret_cast<int*>(pcol + (size_t)dm.fH * Dp);   // [fH][Dp]
     const int lane = threadIdx.x & 63;
-    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = threadIdx.x >> 6;
     const int nwaves = blockDim.x >> 6;
     const int col = blockIdx.x, bt = blockIdx.y;
     const int n = col / dm.fW, w = col - n * dm.fW;
-    const int d0 = g * DG;
-    const bool chan = lane < dm.C;
     const size_t pix0 = (size_t)bt * dm.NPIX + (size_t)n * dm.fH * dm.fW + w;   // pixel of row h = pix0 + h*fW
-    const float* frow = feat + pix0 * dm.C + lane;
-    const float* prow = prob + pix0 * dm.D + d0;
-    const int32_t* vrow = vox_pm + pix0 * dm.D + d0;
-    const size_t fstride = (size_t)dm.fW * dm.C, dstride = (size_t)dm.fW * dm.D;
-    const int32_t* rb = run_base + (size_t)bt * (dm.NQ + 1) + (size_t)col * dm.D + d0;
-    const int32_t* dst = dest + (size_t)bt * dm.P;
-    float* out = runs + (size_t)bt * dm.P * dm.C + lane;
 
-    // stage the feature rows once per workgroup: every wave (depth group) of the column reuses them
-    for (int h = g; h < dm.fH; h += nwaves) fcol[h * 64 + lane] = chan ? frow[(size_t)h * fstride] : 0.f;
+    // ---- stage the column: feature rows (zero-padded to 64 channels), probabilities, voxel ids ----
+    for (int h = g; h < dm.fH; h += nwaves)
+        fcol[h * 64 + lane] = lane < dm.C ? feat[(pix0 + (size_t)h * dm.fW) * dm.C + lane] : 0.f;
+    for (int i = threadIdx.x; i < dm.fH * Dp; i += blockDim.x) {
+        const int h = i / Dp, d = i - h * Dp;
+        const size_t src = (pix0 + (size_t)h * dm.fW) * dm.D + d;
+        pcol[i] = d < dm.D ? prob[src] : 0.f;
+        vcol[i] = d < dm.D ? vox_pm[src] : -1;
+    }
     __syncthreads();
 
-    int cur[DG], rid[DG], cnt[DG];
-    float acc[DG];
+    const int bin = lane >> 3, chunk = lane & 7;
+    const int d = g * 8 + bin;
+    const bool bin_ok = d < dm.D;
+    const int32_t* dst = dest + (size_t)bt * dm.P;
+    float* out = runs + (size_t)bt * dm.P * dm.C + chunk * 8;
+    int rid = bin_ok ? run_base[(size_t)bt * (dm.NQ + 1) + (size_t)col * dm.D + d] : 0;
+    int cur = -1;
+    float acc[8];
 #pragma unroll
-    for (int j = 0; j < DG; ++j) {
-        cur[j] = -1;
-        rid[j] = (EXACT || d0 + j < dm.D) ? rb[j] : 0;
-        cnt[j] = 0;
-        acc[j] = 0.f;
-    }
-    // destination rows of the first 8 runs of every bin, fetched up front (lane = (bin, k)): a flush then
-    // costs a v_readlane instead of a dependent scalar load (a column-bin has 2-3 runs on average)
-    int destv;
-    {
-        const int bj = lane >> 3, bk = lane & 7;
-        const bool bin_ok = EXACT || d0 + bj < dm.D;
-        const int first = bin_ok ? rb[bj] : 0;
-        const int next = bin_ok ? rb[bj + 1] : 0;
-        destv = (first + bk < next) ? dst[first + bk] : 0;
-    }
-    // prob / voxel ids of 32 rows x 8 bins are fetched with 4 + 4 vector loads (lane = (row, bin)) and
-    // broadcast with v_readlane: the point loop itself touches no global memory except the run stores.
-    const int hl = lane >> 3;                                               // row inside an 8-row block
-    const int jl = EXACT ? (lane & 7) : min(lane & 7, dm.D - 1 - d0);       // bins past D alias the last valid bin
-    for (int h0 = 0; h0 < dm.fH; h0 += 32) {
-        float P[4];
-        int V[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int row = h0 + k * 8 + hl;
-            const bool ok = row < dm.fH;
-            P[k] = ok ? prow[(size_t)row * dstride + jl] : 0.f;
-            V[k] = ok ? vrow[(size_t)row * dstride + jl] : -1;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int hb = h0 + k * 8;
-            if (hb < dm.fH) {
-                const int nr = min(8, dm.fH - hb);
-                float fnext = fcol[hb * 64 + lane];
-                for (int r = 0; r < nr; ++r) {
-                    const float fh = fnext;
-                    if (r + 1 < nr) fnext = fcol[(hb + r + 1) * 64 + lane];
-#pragma unroll
-                    for (int j = 0; j < DG; ++j) {
-                        if (EXACT || d0 + j < dm.D) {
-                            const int v = __builtin_amdgcn_readlane(V[k], r * 8 + j);
-                            const float p = readlane_f(P[k], r * 8 + j);
-                            if (v != cur[j]) {
-                                if (cur[j] >= 0) {
-                                    const int row = cnt[j] < 8 ? __builtin_amdgcn_readlane(destv, j * 8 + cnt[j])
-                                                               : dst[rid[j] + cnt[j]];
-                                    if (chan) out[(size_t)row * dm.C] = acc[j];
-                                    ++cnt[j];
-                                }
-                                acc[j] = 0.f;
-                                cur[j] = v;
-                            }
-                            acc[j] = fmaf(p, fh, acc[j]);
-                        }
-                    }
-                }
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+
+    auto flush = [&]() {
+        const int row = dst[rid];
+        float* o = out + (size_t)row * dm.C;
+        if (VEC8) {
+            if (chunk * 8 < dm.C) {
+                *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
             }
-        }
-    }
+        } else {
 #pragma unroll
-    for (int j = 0; j < DG; ++j) {
-        if ((EXACT || d0 + j < dm.D) && cur[j] >= 0) {
-            const int row = cnt[j] < 8 ? __builtin_amdgcn_readlane(destv, j * 8 + cnt[j]) : dst[rid[j] + cnt[j]];
-            if (chan) out[(size_t)row * dm.C] = acc[j];
+            for (int k = 0; k < 8; ++k)
+                if (chunk * 8 + k < dm.C) o[k] = acc[k];
         }
+        ++rid;
+    };
+
+    const float4* f4 = reinterpret_cast<const float4*>(fcol) + chunk * 2;
+    const float* pc = pcol + d;
+    const int* vc = vcol + d;
+    for (int h = 0; h < dm.fH; ++h) {
+        const float p = pc[h * Dp];
+        const int v = vc[h * Dp];
+        const float4 a = f4[h * 16], b = f4[h * 16 + 1];
+        if (v != cur) {                                        // run boundary of this lane's bin
+            if (cur >= 0) flush();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+            cur = v;
+        }
+        acc[0] = fmaf(p, a.x, acc[0]); acc[1] = fmaf(p, a.y, acc[1]);
+        acc[2] = fmaf(p, a.z, acc[2]); acc[3] = fmaf(p, a.w, acc[3]);
+        acc[4] = fmaf(p, b.x, acc[4]); acc[5] = fmaf(p, b.y, acc[5]);
+        acc[6] = fmaf(p, b.z, acc[6]); acc[7] = fmaf(p, b.w, acc[7]);
     }
+    if (cur >= 0) flush();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -753,15 +731,15 @@ int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const flo
     if (workspace_bytes < (size_t)dm.BT * dm.P * dm.C * sizeof(float)) return STP3_ENOSPACE;
     PlanView pv = plan_view(dm, const_cast<void*>(plan));
     hipStream_t s = (hipStream_t)stream;
-    constexpr int DG = 8;
-    const int ndg = (dm.D + DG - 1) / DG;
-    const size_t lds = (size_t)dm.fH * 64 * sizeof(float);
-    if (lds > 64 * 1024) return STP3_EUNSUP;   // fH <= 256
-    if (dm.D % DG == 0)
-        hipLaunchKernelGGL((lift_runs_kernel<DG, true>), dim3(dm.NCOL, dm.BT), dim3(64 * ndg), lds, s, dm, feat, prob,
+    const int ndg = (dm.D + 7) / 8;                        // waves per column: 8 depth bins each
+    const int Dp = ndg * 8;
+    const size_t lds = ((size_t)dm.fH * 64 + 2 * (size_t)dm.fH * Dp) * sizeof(float);
+    if (lds > 160 * 1024) return STP3_EUNSUP;
+    if (dm.C % 8 == 0)
+        hipLaunchKernelGGL((lift_runs_kernel<true>), dim3(dm.NCOL, dm.BT), dim3(64 * ndg), lds, s, dm, Dp, feat, prob,
                            vox_pm, pv.run_base, pv.dest, (float*)workspace);
     else
-        hipLaunchKernelGGL((lift_runs_kernel<DG, false>), dim3(dm.NCOL, dm.BT), dim3(64 * ndg), lds, s, dm, feat, prob,
+        hipLaunchKernelGGL((lift_runs_kernel<false>), dim3(dm.NCOL, dm.BT), dim3(64 * ndg), lds, s, dm, Dp, feat, prob,
                            vox_pm, pv.run_base, pv.dest, (float*)workspace);
     hipLaunchKernelGGL(lift_gather_kernel, dim3((dm.V + kTileV - 1) / kTileV, dm.B), dim3(256), 0, s, dm,
                        (const float*)workspace, pv.vox_off, discount, bev);
