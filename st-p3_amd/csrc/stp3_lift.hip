@@ -380,6 +380,7 @@ __global__ __launch_bounds__(1024) void lift_runs_kernel(Dims dm, int Dp, const 
     float* fcol = smem;                                   // [fH][64]
     float* pcol = smem + (size_t)dm.fH * 64;              // [fH][Dp]
     int* vcol = reinterpret_cast<int*>(pcol + (size_t)dm.fH * Dp);   // [fH][Dp]
+    int* dcol = vcol + (size_t)dm.fH * Dp;                // destination rows of the column's runs (<= fH*D)
     const int lane = threadIdx.x & 63;
     const int g = threadIdx.x >> 6;
     const int nwaves = blockDim.x >> 6;
@@ -396,21 +397,25 @@ __global__ __launch_bounds__(1024) void lift_runs_kernel(Dims dm, int Dp, const 
         pcol[i] = d < dm.D ? prob[src] : 0.f;
         vcol[i] = d < dm.D ? vox_pm[src] : -1;
     }
+    const int32_t* dst = dest + (size_t)bt * dm.P;
+    const int32_t* rb_col = run_base + (size_t)bt * (dm.NQ + 1) + (size_t)col * dm.D;
+    const int col_base = rb_col[0], col_runs = rb_col[dm.D] - rb_col[0];      // the column's runs are contiguous ids
+    for (int i = threadIdx.x; i < col_runs; i += blockDim.x) dcol[i] = dst[col_base + i];
     __syncthreads();
 
     const int bin = lane >> 3, chunk = lane & 7;
     const int d = g * 8 + bin;
     const bool bin_ok = d < dm.D;
-    const int32_t* dst = dest + (size_t)bt * dm.P;
     float* out = runs + (size_t)bt * dm.P * dm.C + chunk * 8;
-    int rid = bin_ok ? run_base[(size_t)bt * (dm.NQ + 1) + (size_t)col * dm.D + d] : 0;
+    const int* drow = dcol + (bin_ok ? rb_col[d] - col_base : 0);   // rows of this lane's bin, in run order
+    int cnt = 0;                                              // runs flushed so far
     int cur = -1;
     float acc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0.f;
 
     auto flush = [&]() {
-        const int row = dst[rid];
+        const int row = drow[cnt];
         float* o = out + (size_t)row * dm.C;
         if (VEC8) {
             if (chunk * 8 < dm.C) {
@@ -422,7 +427,6 @@ __global__ __launch_bounds__(1024) void lift_runs_kernel(Dims dm, int Dp, const 
             for (int k = 0; k < 8; ++k)
                 if (chunk * 8 + k < dm.C) o[k] = acc[k];
         }
-        ++rid;
     };
 
     const float4* f4 = reinterpret_cast<const float4*>(fcol) + chunk * 2;
@@ -432,16 +436,17 @@ __global__ __launch_bounds__(1024) void lift_runs_kernel(Dims dm, int Dp, const 
         const float p = pc[h * Dp];
         const int v = vc[h * Dp];
         const float4 a = f4[h * 16], b = f4[h * 16 + 1];
-        if (v != cur) {                                        // run boundary of this lane's bin
-            if (cur >= 0) flush();
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-            cur = v;
+        const bool changed = v != cur;                         // run boundary of this lane's bin
+        if (changed && cur >= 0) {
+            flush();
+            ++cnt;
         }
-        acc[0] = fmaf(p, a.x, acc[0]); acc[1] = fmaf(p, a.y, acc[1]);
-        acc[2] = fmaf(p, a.z, acc[2]); acc[3] = fmaf(p, a.w, acc[3]);
-        acc[4] = fmaf(p, b.x, acc[4]); acc[5] = fmaf(p, b.y, acc[5]);
-        acc[6] = fmaf(p, b.z, acc[6]); acc[7] = fmaf(p, b.w, acc[7]);
+        cur = v;
+        // branch-free restart of the running sum (the store above only READS acc)
+        acc[0] = fmaf(p, a.x, changed ? 0.f : acc[0]); acc[1] = fmaf(p, a.y, changed ? 0.f : acc[1]);
+        acc[2] = fmaf(p, a.z, changed ? 0.f : acc[2]); acc[3] = fmaf(p, a.w, changed ? 0.f : acc[3]);
+        acc[4] = fmaf(p, b.x, changed ? 0.f : acc[4]); acc[5] = fmaf(p, b.y, changed ? 0.f : acc[5]);
+        acc[6] = fmaf(p, b.z, changed ? 0.f : acc[6]); acc[7] = fmaf(p, b.w, changed ? 0.f : acc[7]);
     }
     if (cur >= 0) flush();
 }
@@ -733,7 +738,7 @@ int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const flo
     hipStream_t s = (hipStream_t)stream;
     const int ndg = (dm.D + 7) / 8;                        // waves per column: 8 depth bins each
     const int Dp = ndg * 8;
-    const size_t lds = ((size_t)dm.fH * 64 + 2 * (size_t)dm.fH * Dp) * sizeof(float);
+    const size_t lds = ((size_t)dm.fH * 64 + 3 * (size_t)dm.fH * Dp) * sizeof(float);
     if (lds > 160 * 1024) return STP3_EUNSUP;
     if (dm.C % 8 == 0)
         hipLaunchKernelGGL((lift_runs_kernel<true>), dim3(dm.NCOL, dm.BT), dim3(64 * ndg), lds, s, dm, Dp, feat, prob,

@@ -24,6 +24,8 @@ class GraphedTrainStep:
         self.module, self.buckets, self.optimizer = module, buckets, optimizer
         self.grad_clip, self.autocast_dtype = grad_clip, autocast_dtype
         self.model = module.model
+        from . import ops
+        ops.WEIGHT_CACHE_ENABLED = False     # weight casts must be captured into (and replayed with) the graph
         dev = next(module.parameters()).device
         self.device = dev
         # static inputs: device tensors are used in place (the caller may keep writing new batches into them)

@@ -631,14 +631,44 @@ def conv2d_supported(x, weight, stride, groups=1):
     return x.is_cuda and x.dim() == 4 and groups == 1 and s[0] == s[1] and weight.shape[1] % 8 == 0
 
 
+# bf16 copies of the convolution weights (forward layout and the tap-flipped / channel-swapped layout of the
+# data gradient), keyed by the parameter and invalidated by its version counter: one cast per optimizer step
+# instead of one per use.
+_WEIGHT_CACHE = {}
+_WEIGHT_EPOCH = [0]
+WEIGHT_CACHE_ENABLED = True          # graph.GraphedTrainStep turns it off: the casts must be part of every replay
+
+
+def invalidate_weight_cache():
+    """Call after updating parameters through storage the parameter's version counter does not see (the flat
+    buffers of ``parallel.FlatAdam``); in-place updates of the parameters themselves are detected automatically."""
+    _WEIGHT_EPOCH[0] += 1
+
+
+def _bf16_weights(weight, need_flipped=False):
+    key = id(weight)
+    ent = _WEIGHT_CACHE.get(key) if WEIGHT_CACHE_ENABLED else None
+    ver = (weight._version, _WEIGHT_EPOCH[0])
+    if ent is None or ent[0] != ver or ent[1] != weight.data_ptr():
+        wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        ent = [ver, weight.data_ptr(), wb, None]
+        if WEIGHT_CACHE_ENABLED and weight.is_leaf and weight.requires_grad:   # parameters only: temporaries die
+            _WEIGHT_CACHE[key] = ent
+    if need_flipped and ent[3] is None:
+        ent[3] = ent[2].flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+    return ent[2], ent[3]
+
+
 class _Conv2dMfma(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil, out_dtype):
         _need_gpu(x, weight)
-        x = x.to(torch.bfloat16)
-        wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        if x.dtype != torch.bfloat16:
+            x = x.to(torch.bfloat16)
+        wb, _ = _bf16_weights(weight)
         fb = _f32(bias)
         y = _conv2d_launch(x, wb, fb, stride, pad, dil, out_dtype)
+        ctx.weight_ref = weight
         ctx.save_for_backward(x, wb)
         ctx.cfg = (stride, pad, dil, bias is not None, weight.dtype, None if bias is None else bias.dtype)
         return y
@@ -656,7 +686,11 @@ class _Conv2dMfma(torch.autograd.Function):
         if hip_dx:
             # dL/dx = stride-1 convolution of dy (zero-stuffed to the input resolution when stride > 1) with the
             # taps flipped and Cin / Cout swapped
-            wt = wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+            w_now = ctx.weight_ref
+            if w_now is not None and w_now.is_leaf and w_now.requires_grad:
+                wt = _bf16_weights(w_now, need_flipped=True)[1]
+            else:
+                wt = wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
             g = dy
             if stride > 1:
                 n, _, h, w = x.shape

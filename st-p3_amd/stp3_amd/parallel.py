@@ -167,6 +167,8 @@ class FlatAdam:
             v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
             denom = (v.sqrt() / bc2_sqrt).add_(self.eps)
             param.sub_((m / denom) * step_size)
+        from . import ops
+        ops.invalidate_weight_cache()        # the parameters are views of `param`: their version counters did not move
 
     def state_dict(self):
         return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq}
