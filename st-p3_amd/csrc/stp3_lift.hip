@@ -634,155 +634,6 @@ __global__ __launch_bounds__(256) void lift_splat_bwd_kernel(Dims dm, int hsplit
     }
 }
 
-// (b') column kernel, lane = (depth bin, 8-channel chunk) -- the layout of the forward stage 1.
-//     Workgroup = one image column; wave g owns bins [8g, 8g+8); features, probabilities and voxel ids of the
-//     column are staged in LDS.  A lane keeps the 8 channels of its bin's CURRENT voxel-gradient row in
-//     registers (the rows of the bin's first NPRE runs are fetched up front, all in flight together).
-//     Per image row: dprob = <feat, G> is 8 FMAs + a 3-step DPP sum over the bin's 8 lanes (instead of a
-//     6-step 64-lane reduction per point); prob * G is added into a wave-private LDS slab of dfeat
-//     (ds_add_f32), and prob * dprob goes to LDS.  After a barrier the workgroup sums the slabs in wave order
-//     (deterministic), applies the softmax backward and writes both gradients with coalesced rows.
-template <int NPRE>
-__global__ __launch_bounds__(1024) void lift_bwd_cols_kernel(Dims dm, int Dp, const float* __restrict__ gacc,
-                                                             const float* __restrict__ feat,
-                                                             const float* __restrict__ prob,
-                                                             const int32_t* __restrict__ vox_pm,
-                                                             float* __restrict__ grad_feat,
-                                                             float* __restrict__ grad_logits) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int fH = dm.fH;
-    float* fcol = smem;                                   // [fH][64]
-    float* pcol = fcol + (size_t)fH * 64;                 // [fH][Dp]
-    int* vcol = reinterpret_cast<int*>(pcol + (size_t)fH * Dp);
-    float* tcol = reinterpret_cast<float*>(vcol + (size_t)fH * Dp);   // prob * dprob
-    float* dfw = tcol + (size_t)fH * Dp;                  // [waves][fH][64] per-wave dfeat slabs
-    const int lane = threadIdx.x & 63;
-    const int g = threadIdx.x >> 6;
-    const int nwaves = blockDim.x >> 6;
-    const int col = blockIdx.x, bt = blockIdx.y;
-    const int n = col / dm.fW, w = col - n * dm.fW;
-    const size_t pix0 = (size_t)bt * dm.NPIX + (size_t)n * fH * dm.fW + w;
-
-    for (int h = g; h < fH; h += nwaves)
-        fcol[h * 64 + lane] = lane < dm.C ? feat[(pix0 + (size_t)h * dm.fW) * dm.C + lane] : 0.f;
-    for (int i = threadIdx.x; i < fH * Dp; i += blockDim.x) {
-        const int h = i / Dp, d = i - h * Dp;
-        const size_t src = (pix0 + (size_t)h * dm.fW) * dm.D + d;
-        pcol[i] = d < dm.D ? prob[src] : 0.f;
-        vcol[i] = d < dm.D ? vox_pm[src] : -1;
-        tcol[i] = 0.f;
-    }
-    for (int i = threadIdx.x; i < nwaves * fH * 64; i += blockDim.x) dfw[i] = 0.f;
-    __syncthreads();
-
-    const int bin = lane >> 3, chunk = lane & 7;
-    const int d = g * 8 + bin;
-    const bool bin_ok = d < dm.D;
-    const bool ch_ok = chunk * 8 < dm.C;                  // C is a multiple of 8 here (checked by the host)
-    const float* gb = gacc + (size_t)bt * dm.V * dm.C + chunk * 8;
-    const float* pc = pcol + d;
-    const int* vc = vcol + d;
-
-    // voxels of the bin's first NPRE runs -> their gradient rows, fetched together
-    int rv[NPRE];
-#pragma unroll
-    for (int q = 0; q < NPRE; ++q) rv[q] = -1;
-    {
-        int found = 0, prev = -1;
-        for (int h = 0; h < fH; ++h) {
-            const int v = bin_ok ? vc[h * Dp] : -1;
-            if (v != prev) {
-                if (v >= 0) {
-#pragma unroll
-                    for (int q = 0; q < NPRE; ++q)
-                        if (found == q) rv[q] = v;
-                    ++found;
-                }
-                prev = v;
-            }
-        }
-    }
-    float Gq[NPRE][8];
-#pragma unroll
-    for (int q = 0; q < NPRE; ++q) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        if (rv[q] >= 0 && ch_ok) {
-            const float4* src = reinterpret_cast<const float4*>(gb + (size_t)rv[q] * dm.C);
-            a = src[0];
-            b = src[1];
-        }
-        Gq[q][0] = a.x; Gq[q][1] = a.y; Gq[q][2] = a.z; Gq[q][3] = a.w;
-        Gq[q][4] = b.x; Gq[q][5] = b.y; Gq[q][6] = b.z; Gq[q][7] = b.w;
-    }
-
-    float Gc[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) Gc[k] = 0.f;
-    int cur = -1, qi = 0;
-    const float4* f4 = reinterpret_cast<const float4*>(fcol) + chunk * 2;
-    float* dfl = dfw + (size_t)g * fH * 64 + chunk * 8;
-    for (int h = 0; h < fH; ++h) {
-        const float p = pc[h * Dp];
-        const int v = bin_ok ? vc[h * Dp] : -1;
-        const float4 fa = f4[h * 16], fb = f4[h * 16 + 1];
-        if (v != cur) {                                        // run boundary: switch to the next gradient row
-            cur = v;
-            if (v >= 0) {
-                if (qi < NPRE) {
-#pragma unroll
-                    for (int q = 0; q < NPRE; ++q)
-                        if (qi == q) {
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) Gc[k] = Gq[q][k];
-                        }
-                } else {                                       // more than NPRE runs in this bin: fetch on demand
-                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-                    if (ch_ok) {
-                        const float4* src = reinterpret_cast<const float4*>(gb + (size_t)v * dm.C);
-                        a = src[0];
-                        b = src[1];
-                    }
-                    Gc[0] = a.x; Gc[1] = a.y; Gc[2] = a.z; Gc[3] = a.w; Gc[4] = b.x; Gc[5] = b.y; Gc[6] = b.z; Gc[7] = b.w;
-                }
-                ++qi;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) Gc[k] = 0.f;
-            }
-        }
-        float dot = fa.x * Gc[0];
-        dot = fmaf(fa.y, Gc[1], dot); dot = fmaf(fa.z, Gc[2], dot); dot = fmaf(fa.w, Gc[3], dot);
-        dot = fmaf(fb.x, Gc[4], dot); dot = fmaf(fb.y, Gc[5], dot); dot = fmaf(fb.z, Gc[6], dot);
-        dot = fmaf(fb.w, Gc[7], dot);
-        dot += dpp_f<0xB1, 0xF>(dot);    // quad_perm [1,0,3,2]
-        dot += dpp_f<0x4E, 0xF>(dot);    // quad_perm [2,3,0,1]
-        dot += dpp_f<0x141, 0xF>(dot);   // row_half_mirror: all 8 lanes of the bin now hold <feat, G>
-        if (chunk == 0 && bin_ok) tcol[h * Dp + d] = p * dot;
-        if (v >= 0) {
-            float* o = dfl + h * 64;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) atomicAdd(o + k, p * Gc[k]);       // ds_add_f32, 8 bins per address
-        }
-    }
-    __syncthreads();
-
-    // dfeat rows: slabs summed in wave order (deterministic), coalesced 256-B rows
-    for (int i = threadIdx.x; i < fH * 64; i += blockDim.x) {
-        const int h = i >> 6, c = i & 63;
-        float sum = 0.f;
-        for (int wv = 0; wv < nwaves; ++wv) sum += dfw[((size_t)wv * fH + h) * 64 + c];
-        if (c < dm.C) grad_feat[(pix0 + (size_t)h * dm.fW) * dm.C + c] = sum;
-    }
-    // softmax backward per pixel: dlogit = prob * (dprob - sum_d prob * dprob) = t - prob * sum_d t
-    for (int i = threadIdx.x; i < fH * Dp; i += blockDim.x) {
-        const int h = i / Dp, dd = i - h * Dp;
-        if (dd >= dm.D) continue;
-        float sum = 0.f;
-        for (int e = 0; e < dm.D; ++e) sum += tcol[h * Dp + e];
-        grad_logits[(pix0 + (size_t)h * dm.fW) * dm.D + dd] = tcol[i] - pcol[i] * sum;
-    }
-}
-
 }  // namespace
 
 // ==========================================================================================
@@ -911,16 +762,6 @@ int stp3_lift_splat_bwd(const stp3_lift_dims* dims, const float* grad_bev, const
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bev_grad_accumulate_kernel, dim3((dm.V + kTileV - 1) / kTileV, dm.B), dim3(256), 0, s, dm,
                        grad_bev, discount, gacc);
-    {
-        const int ndg = (dm.D + 7) / 8;
-        const int Dp = ndg * 8;
-        const size_t lds = ((size_t)dm.fH * 64 + 3 * (size_t)dm.fH * Dp + (size_t)ndg * dm.fH * 64) * sizeof(float);
-        if (dm.C % 8 == 0 && lds <= 96 * 1024) {
-            hipLaunchKernelGGL((lift_bwd_cols_kernel<4>), dim3(dm.NCOL, dm.BT), dim3(64 * ndg), lds, s, dm, Dp, gacc, feat,
-                               prob, vox_pm, grad_feat, grad_logits);
-            return launch_status();
-        }
-    }
     // enough waves to fill the chip: split the rows of a column when there are few columns
     const int64_t cols = (int64_t)dm.BT * dm.NCOL;
     int hsplit = (int)((8192 + cols - 1) / cols);
