@@ -121,14 +121,14 @@ def cpu_baseline(timeout_s=240.0):
     return json.loads(lines[-1])
 
 
-def lift_roofline(device, batch, batch_size, iters=30):
-    """HIP-event timing of the voxel-pool C-ABI calls at the bench shape, on the stream they are launched on."""
+def lift_roofline(device, batch, model, iters=30):
+    """HIP-event timing of the voxel-pool C-ABI calls at the bench shape (the model's own frustum / BEV grid and the
+    batch's poses, random features), on the stream they are launched on."""
     from stp3_amd import ops
-    from tests import helpers as H
-    cfg = H.FULL
-    frustum, res, start, dim = H.grid_params(cfg)
-    grid = ops.LiftGrid(frustum, res, start, dim, device)
-    plan = ops.LiftPlan.build(grid, batch['intrinsics'], batch['extrinsics'], batch['future_egomotion'], 64)
+    grid = model.lift_grid(device)
+    rf = model.receptive_field
+    poses = [batch[k][:, :rf] for k in ('intrinsics', 'extrinsics', 'future_egomotion')]
+    plan = ops.LiftPlan.build(grid, *poses, model.encoder_out_channels)
     d = plan.dims
     g = torch.Generator(device='cpu').manual_seed(7)
     feat = torch.relu(torch.randn(d.BT, d.NPIX, d.C, generator=g)).to(device)
@@ -144,7 +144,7 @@ def lift_roofline(device, batch, batch_size, iters=30):
     for _ in range(iters):
         bev = ops._LiftSplat.apply(feat, logits, plan, 0.5)
         bev.backward(grad)
-        ops.LiftPlan.build(grid, batch['intrinsics'], batch['extrinsics'], batch['future_egomotion'], 64, out=plan)
+        ops.LiftPlan.build(grid, *poses, model.encoder_out_channels, out=plan)
     prof = ops.profile_summary()
     ops.PROFILE_ENABLED = False
     alg_fwd = d.BT * (d.NPIX * d.C * 4 + d.NPIX * d.D * 4 + d.C * d.V * 4)      # feat + depth prob + BEV planes
@@ -250,7 +250,7 @@ def main():
 
     if rank == 0:
         module.model.prebuilt_plan = None
-        roof, kernel_ms = (None, {}) if args.no_roofline else lift_roofline(device, batch, args.batch)
+        roof, kernel_ms = (None, {}) if args.no_roofline else lift_roofline(device, batch, module.model)
         _log('roofline microbench done')
         line = {
             'metric': 'BEV samples/sec (6-cam x 3-frame fwd+bwd)', 'value': round(args.batch * world * args.steps / elapsed, 3),
