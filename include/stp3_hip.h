@@ -279,6 +279,16 @@ int stp3_conv2d_wgrad_workspace(const stp3_conv_dims* dims, size_t* bytes);
 int stp3_conv2d_wgrad(const stp3_conv_dims* dims, const void* dy, const void* x, float* dw, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* stp3_conv2d_fwd_v2 -- second-generation forward (csrc/stp3_conv2.hip; EXPERIMENTAL, selected with STP3_CONV_V2=1):
+ * same contract as stp3_conv2d_fwd for bf16 outputs, with 128-byte contiguous output stores per pixel and, when
+ * `sums` is non-NULL, the BatchNorm statistics of the output fused into the epilogue:
+ *   sums [2][Cout] float32 = per-channel sum and sum of squares of the bf16-rounded outputs over all N*Ho*Wo pixels
+ *   workspace: stp3_conv2d_fwd_v2_workspace(dims) bytes (one partial row per 128-pixel workgroup; deterministic)
+ * The result feeds stp3_bn_apply_fwd directly (no stp3_bn_stats pass over the convolution output). */
+int stp3_conv2d_fwd_v2_workspace(const stp3_conv_dims* dims, size_t* bytes);
+int stp3_conv2d_fwd_v2(const stp3_conv_dims* dims, const void* x, const void* w, const float* bias, void* y,
+                       float* sums, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,12 +152,31 @@ def conv_module(m, x):
     return m(x)
 
 
+# EXPERIMENTAL, off by default: conv -> BN (-> ReLU) through one operator whose convolution epilogue produces the
+# BatchNorm statistics (ops_fused.py / csrc/stp3_conv2.hip).  Not validated on hardware yet.
+_CONV_V2 = os.environ.get('STP3_CONV_V2', '0') == '1'
+
+
+def _fusable_conv_bn(conv, bn, x):
+    return (_CONV_V2 and type(conv) is nn.Conv2d and isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.training
+            and bn.track_running_stats and conv.groups == 1 and conv.padding_mode == 'zeros'
+            and not isinstance(conv.padding, str) and x.dim() == 4 and _use_mfma(x, conv.weight, conv.stride))
+
+
 def run_fused(seq, x):
     """Run an ``nn.Sequential`` with every ``BatchNorm -> ReLU`` pair (or lone BatchNorm) fused."""
     mods = list(seq)
     i = 0
     while i < len(mods):
         m = mods[i]
+        if _CONV_V2 and i + 1 < len(mods) and _fusable_conv_bn(m, mods[i + 1], x):
+            from .. import ops_fused
+            relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+            group = None if _sync_world(mods[i + 1]) > 1 else False
+            x = ops_fused.conv_bn_act(x, m.weight, m.bias, mods[i + 1], ACT_RELU if relu else ACT_NONE, None, RES_NONE,
+                                      m.stride, m.padding, m.dilation, group=group)
+            i += 3 if relu else 2
+            continue
         if isinstance(m, nn.modules.batchnorm._BatchNorm):
             if i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
                 x = bn_act(m, x, ACT_RELU)

@@ -1,0 +1,182 @@
+"""EXPERIMENTAL (off unless STP3_CONV_V2=1): convolution -> BatchNorm -> activation (-> + skip) as one
+autograd operator on top of ``stp3_conv2d_fwd_v2`` (csrc/stp3_conv2.hip), whose epilogue produces the BatchNorm
+statistics, so the forward makes ONE pass over the convolution output less than ``conv2d`` + ``bn_act``:
+
+    y = act(BN(conv(x, w) + b) [+ res]) [+ res]
+
+Replaces the same reference chains as ``ops.conv2d`` + ``ops.bn_act`` (stp3/layers/convolutions.py:183-280,
+stp3/layers/temporal.py:252-325, stp3/models/decoder.py:22-140, MBConv 1x1 -> BN -> swish).  Training mode only;
+everything else (evaluation, float32 parity runs, unsupported shapes) takes the two separate operators.
+Not yet validated on hardware: tests/test_conv_v2_gpu.py runs only with STP3_EXPERIMENTAL=1.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+from ._lib import check
+
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    ws = _WS.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 32 << 20), dtype=torch.uint8, device=device)
+        _WS[device] = ws
+    return ws
+
+
+def conv2d_v2(x, wb, bias, stride, pad, dil, sums_ptr=None):
+    """Raw launch: x (N,Cin,H,W) bf16 channels-last view, wb (Cout,Cin,KH,KW) bf16 channels-last -> y bf16.
+    ``sums_ptr``: device address of a float32 [2][Cout] buffer that receives the BatchNorm statistics of y."""
+    n, cin, h, w = x.shape
+    cout, _, kh, kw = wb.shape
+    x, ldx = ops._rows_view(x)
+    ho, wo = ops._conv_out(h, kh, stride, pad[0], dil[0]), ops._conv_out(w, kw, stride, pad[1], dil[1])
+    y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    dims = _lib.ConvDims(n, h, w, cin, ho, wo, cout, kh, kw, stride, pad[0], pad[1], dil[0], dil[1], ldx, cout,
+                         _lib.DTYPE_BF16, int(bias is not None))
+    lib = _lib.lib()
+    ws_ptr, ws_bytes = None, 0
+    if sums_ptr is not None:
+        nbytes = ctypes.c_size_t()
+        check(lib.stp3_conv2d_fwd_v2_workspace(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_conv2d_fwd_v2_workspace')
+        ws = _workspace(nbytes.value, x.device)
+        ws_ptr, ws_bytes = ws.data_ptr(), nbytes.value
+    check(lib.stp3_conv2d_fwd_v2(ctypes.byref(dims), x.data_ptr(), wb.data_ptr(), ops._opt_ptr(bias), y.data_ptr(), sums_ptr,
+                                 ws_ptr, ws_bytes, ops._stream_handle()), 'stp3_conv2d_fwd_v2')
+    return y
+
+
+class _ConvBnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, cbias, gamma, beta, res, running_mean, running_var, momentum, eps, act, res_mode,
+                stride, pad, dil, group):
+        ops._need_gpu(x, weight)
+        if x.dtype != torch.bfloat16:
+            x = x.to(torch.bfloat16)
+        wb, _ = ops._bf16_weights(weight)
+        cout = wb.shape[0]
+        dev = x.device
+        stat = torch.empty(4 * cout, dtype=torch.float32, device=dev)       # sum | sum of squares | mean | invstd
+        base = stat.data_ptr()
+        yc = conv2d_v2(x, wb, ops._f32(cbias), stride, pad, dil, sums_ptr=base)
+        n, _, ho, wo = yc.shape
+        count = float(n * ho * wo)
+        world = 1
+        if group is not False and torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size(group)
+        if world > 1:
+            torch.distributed.all_reduce(stat[:2 * cout], group=group)
+            count *= world
+        ldr = cout
+        if res is not None:
+            res, ldr = ops._rows_view(res if res.dtype == torch.bfloat16 else res.to(torch.bfloat16))
+        else:
+            res_mode = ops.RES_NONE
+        out = torch.empty_like(yc)
+        dims = _lib.BnDims(n, ho * wo, cout, cout, cout, ldr, _lib.DTYPE_BF16, act, res_mode, 0, 0)
+        g32, b32 = ops._f32(gamma), ops._f32(beta)
+        check(_lib.lib().stp3_bn_apply_fwd(ctypes.byref(dims), yc.data_ptr(), None, ops._opt_ptr(res), None, base, count,
+                                           ops._opt_ptr(g32), ops._opt_ptr(b32), eps, momentum, ops._opt_ptr(running_mean),
+                                           ops._opt_ptr(running_var), base + 8 * cout, base + 12 * cout, out.data_ptr(),
+                                           ops._stream_handle()), 'stp3_bn_apply_fwd')
+        ctx.save_for_backward(x, wb, yc, res if res_mode == ops.RES_BEFORE_ACT else None, g32, b32, stat)
+        ctx.cfg = (dims, count, world, group, stride, pad, dil, cbias is not None)
+        ctx.weight_ref = weight
+        ctx.dtypes = (weight.dtype, None if cbias is None else cbias.dtype, None if gamma is None else gamma.dtype,
+                      None if beta is None else beta.dtype, None if res is None else res.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wb, yc, res, g32, b32, stat = ctx.saved_tensors
+        dims, count, world, group, stride, pad, dil, has_cbias = ctx.cfg
+        wdt, cbdt, gdt, bdt, rdt = ctx.dtypes
+        n, rows, c = dims.N, dims.rows, dims.C
+        dev = x.device
+        lib = _lib.lib()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        ws, ws_bytes = ops._bn_workspace(n, c, dev)
+        sumbuf = torch.empty((n + 1) * 3 * c, dtype=torch.float32, device=dev)
+        sums_off = n * 3 * c
+        mean_p, invstd_p = stat.data_ptr() + 8 * c, stat.data_ptr() + 12 * c
+        dconv = torch.empty_like(yc)                                   # gradient at the convolution output
+        dres = None
+        if dims.res_mode == ops.RES_BEFORE_ACT and ctx.needs_input_grad[5]:
+            dres = torch.empty_like(yc)
+            if dims.ldr != c:
+                res = res.contiguous(memory_format=torch.channels_last)
+                dims = _lib.BnDims(dims.N, dims.rows, dims.C, dims.ldx, dims.ldy, c, dims.dtype, dims.act, dims.res_mode, 0, 0)
+        stream = ops._stream_handle()
+        check(lib.stp3_bn_bwd_reduce(ctypes.byref(dims), dy.data_ptr(), yc.data_ptr(), None, ops._opt_ptr(res), None, mean_p,
+                                     invstd_p, ops._opt_ptr(g32), ops._opt_ptr(b32), ws.data_ptr(), ws_bytes,
+                                     sumbuf.data_ptr(), sumbuf.data_ptr() + 4 * sums_off, stream), 'stp3_bn_bwd_reduce')
+        lsums = sumbuf[sums_off:].view(3, c)
+        gsums = lsums
+        if world > 1:
+            gsums = lsums.clone()
+            torch.distributed.all_reduce(gsums, group=group)
+        check(lib.stp3_bn_apply_bwd(ctypes.byref(dims), dy.data_ptr(), yc.data_ptr(), None, ops._opt_ptr(res), None, mean_p,
+                                    invstd_p, ops._opt_ptr(g32), ops._opt_ptr(b32), gsums.data_ptr(), count,
+                                    dconv.data_ptr(), ops._opt_ptr(dres), stream), 'stp3_bn_apply_bwd')
+        dgamma = lsums[1].to(gdt) if gdt is not None and ctx.needs_input_grad[3] else None
+        dbeta = lsums[0].to(bdt) if bdt is not None and ctx.needs_input_grad[4] else None
+        if dims.res_mode == ops.RES_AFTER_ACT and ctx.needs_input_grad[5]:
+            dres = dy
+        if dres is not None and rdt is not None and dres.dtype != rdt:
+            dres = dres.to(rdt)
+        # ---- convolution backward (same routes as ops._Conv2dMfma.backward) ------------------------------------
+        cout, cin, kh, kw = wb.shape
+        dx = dw = dcb = None
+        bpad = (dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1])
+        need_dx = ctx.needs_input_grad[0]
+        hip_dx = need_dx and cout % 8 == 0 and bpad[0] >= 0 and bpad[1] >= 0
+        if hip_dx:
+            w_now = ctx.weight_ref
+            if w_now is not None and w_now.is_leaf and w_now.requires_grad:
+                wt = ops._bf16_weights(w_now, need_flipped=True)[1]
+            else:
+                wt = wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+            g = dconv
+            if stride > 1:
+                nn_, _, h, w = x.shape
+                ho, wo = dconv.shape[2], dconv.shape[3]
+                uh, uw = h + 2 * pad[0] - dil[0] * (kh - 1), w + 2 * pad[1] - dil[1] * (kw - 1)
+                g = torch.empty((nn_, cout, uh, uw), dtype=dconv.dtype, device=dev, memory_format=torch.channels_last).zero_()
+                g[:, :, ::stride, ::stride][:, :, :ho, :wo] = dconv
+            dx = conv2d_v2(g, wt, None, 1, bpad, dil)
+        need_dw = ctx.needs_input_grad[1]
+        need_db = has_cbias and ctx.needs_input_grad[2]
+        hip_dw = need_dw and cin % 4 == 0 and cout % 4 == 0 and ops.WGRAD_MIN_CHANNELS <= min(cin, cout)
+        if hip_dw:
+            dw = ops._conv2d_wgrad(dconv, x, (cout, cin, kh, kw), stride, pad, dil).to(wdt)
+            if need_db:
+                dcb = dconv.float().sum(dim=(0, 2, 3)).to(cbdt)
+        mask = [need_dx and not hip_dx, need_dw and not hip_dw, need_db and not hip_dw]
+        if any(mask):
+            xd = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+            gx, gw, gb = torch.ops.aten.convolution_backward(dconv, xd, wb, [cout] if has_cbias else None, [stride, stride],
+                                                             list(pad), list(dil), False, [0, 0], 1, mask)
+            if mask[0]:
+                dx = gx
+            if mask[1]:
+                dw = gw.to(wdt)
+            if mask[2]:
+                dcb = gb.to(cbdt)
+        return (dx, dw, dcb, dgamma, dbeta, dres) + (None,) * 10
+
+
+def conv_bn_act(x, weight, cbias, bn, act=ops.ACT_NONE, res=None, res_mode=ops.RES_NONE, stride=1, padding=0, dilation=1,
+                group=None):
+    """Training-mode conv -> BatchNorm -> activation (-> + skip) through the fused kernels (GPU, bf16)."""
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    s = ops._pair(stride)
+    return _ConvBnAct.apply(x, weight, cbias, bn.weight, bn.bias, res, bn.running_mean if bn.track_running_stats else None,
+                            bn.running_var if bn.track_running_stats else None,
+                            float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps), int(act), int(res_mode),
+                            s[0], ops._pair(padding), ops._pair(dilation), group)

@@ -1,0 +1,80 @@
+"""GPU parity of the EXPERIMENTAL second-generation convolution forward (stp3_conv2d_fwd_v2: 128-byte output
+stores, BatchNorm statistics in the epilogue) and of the fused conv -> BN -> activation operator built on it.
+Runs only with STP3_EXPERIMENTAL=1: these kernels are not on the default path yet.
+
+Tolerances as in test_conv_gpu.py / test_bnact_gpu.py (bf16 outputs: rtol 1e-2 / atol 2e-2; statistics: float32
+sums of bf16-rounded values, rtol 1e-4 against the same sums computed by torch from the kernel's own output)."""
+import os
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get('STP3_EXPERIMENTAL') != '1', reason='experimental kernels (STP3_EXPERIMENTAL=1)')]
+
+CASES = [
+    # n, cin, h, w, cout, k, stride, pad, dil, bias
+    (3, 24, 28, 60, 144, 1, 1, 0, 1, False),
+    (2, 144, 28, 60, 32, 1, 1, 0, 1, False),
+    (2, 216, 28, 60, 64, 3, 1, 1, 1, False),
+    (1, 64, 50, 50, 64, 7, 2, 3, 1, False),
+    (2, 64, 40, 40, 128, 3, 1, 12, 12, False),
+    (2, 64, 33, 17, 2, 1, 1, 0, 1, True),
+    (3, 40, 20, 20, 35, 3, 1, 1, 1, False),
+    (2, 960, 14, 30, 160, 1, 1, 0, 1, False),
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv_v2_forward_and_statistics(case):
+    from stp3_amd import ops, ops_fused
+    n, cin, h, w, cout, k, stride, pad, dil, use_bias = case
+    g = torch.Generator().manual_seed(cin + 3 * cout)
+    x = torch.randn(n, cin, h, w, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wgt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).cuda()
+    wb = wgt.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(cout, generator=g).cuda() if use_bias else None
+    sums = torch.empty(2, cout, dtype=torch.float32, device='cuda')
+    y = ops_fused.conv2d_v2(x, wb, bias, stride, (pad, pad), (dil, dil), sums_ptr=sums.data_ptr())
+    y0 = ops_fused.conv2d_v2(x, wb, bias, stride, (pad, pad), (dil, dil))
+    ref = F.conv2d(x.float(), wb.float(), bias, stride, pad, dil)
+    torch.testing.assert_close(y.float(), ref, rtol=1e-2, atol=2e-2)
+    assert torch.equal(y, y0)                                              # the statistics epilogue does not change y
+    v1 = ops._conv2d_launch(x, wb, bias, stride, (pad, pad), (dil, dil), torch.bfloat16)
+    assert torch.equal(y, v1)                                              # same arithmetic as the first-generation kernel
+    yf = y.float()
+    torch.testing.assert_close(sums[0], yf.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(sums[1], (yf * yf).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize('act,res_mode', [('relu', 'none'), ('swish', 'none'), ('none', 'after'), ('relu', 'before')])
+def test_fused_conv_bn_act_matches_the_two_operators(act, res_mode):
+    from stp3_amd import ops, ops_fused
+    from stp3_amd.layers import fused
+    ops.WGRAD_MIN_CHANNELS = 0
+    act_id = {'none': ops.ACT_NONE, 'relu': ops.ACT_RELU, 'swish': ops.ACT_SWISH}[act]
+    rm = {'none': ops.RES_NONE, 'before': ops.RES_BEFORE_ACT, 'after': ops.RES_AFTER_ACT}[res_mode]
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(3, 64, 24, 20, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = torch.randn(3, 96, 24, 20, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(3, 96, 24, 20, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    conv_a, conv_b = nn.Conv2d(64, 96, 3, padding=1, bias=False).cuda(), nn.Conv2d(64, 96, 3, padding=1, bias=False).cuda()
+    conv_b.load_state_dict(conv_a.state_dict())
+    bn_a, bn_b = nn.BatchNorm2d(96).cuda(), nn.BatchNorm2d(96).cuda()
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ra = res.clone().requires_grad_(True) if rm else None
+    rb = res.clone().requires_grad_(True) if rm else None
+    ya = ops_fused.conv_bn_act(xa, conv_a.weight, None, bn_a, act_id, ra, rm, 1, 1, 1)
+    yb = fused.bn_act(bn_b, ops.conv2d(xb, conv_b.weight, None, 1, 1, 1), act_id, res=rb, res_mode=rm)
+    torch.testing.assert_close(ya.float(), yb.float(), rtol=2e-2, atol=2e-2)
+    ya.backward(gy)
+    yb.backward(gy)
+    torch.testing.assert_close(xa.grad.float(), xb.grad.float(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(conv_a.weight.grad, conv_b.weight.grad, rtol=2e-2, atol=2e-2 * float(conv_b.weight.grad.abs().max()))
+    torch.testing.assert_close(bn_a.weight.grad, bn_b.weight.grad, rtol=2e-2, atol=5e-2)
+    torch.testing.assert_close(bn_a.bias.grad, bn_b.bias.grad, rtol=2e-2, atol=5e-2)
+    torch.testing.assert_close(bn_a.running_var, bn_b.running_var, rtol=1e-3, atol=1e-4)
+    if rm:
+        torch.testing.assert_close(ra.grad.float(), rb.grad.float(), rtol=2e-2, atol=2e-2)
