@@ -289,6 +289,24 @@ int stp3_conv2d_fwd_v2_workspace(const stp3_conv_dims* dims, size_t* bytes);
 int stp3_conv2d_fwd_v2(const stp3_conv_dims* dims, const void* x, const void* w, const float* bias, void* y,
                        float* sums, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Squeeze-and-excitation data passes (csrc/stp3_se.hip; EXPERIMENTAL, host side selected with STP3_FUSED_SE=1).
+ * Replace the pooling, the gate multiply and the elementwise / reduction passes of their backward inside the
+ * EfficientNet MBConv blocks driven by stp3/models/encoder.py:57-97.
+ *   x, dy, y : [N][rows][ld >= C] channels-last, dtype STP3_DTYPE_F32 / _BF16
+ *   stp3_se_pool  : out [N][C] float32 = sum over rows of x (dy == NULL) or of dy * x (dy != NULL); deterministic
+ *   stp3_se_scale : y = x * gate[n][c] + add[n][c]   (gate, add [N][C] float32; add may be NULL)
+ */
+typedef struct stp3_se_dims {
+    int32_t N, rows, C, ld;
+    int32_t dtype;
+} stp3_se_dims;
+
+int stp3_se_workspace_bytes(const stp3_se_dims* dims, size_t* bytes);
+int stp3_se_pool(const stp3_se_dims* dims, const void* x, const void* dy, void* workspace, size_t workspace_bytes,
+                 float* out, void* stream);
+int stp3_se_scale(const stp3_se_dims* dims, const void* x, const float* gate, const float* add, void* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,11 @@ class ConvDims(ctypes.Structure):
                                               'pad_w', 'dil_h', 'dil_w', 'ldx', 'ldy', 'out_dtype', 'has_bias')]
 
 
+class SeDims(ctypes.Structure):
+    """struct stp3_se_dims (include/stp3_hip.h)."""
+    _fields_ = [(k, ctypes.c_int32) for k in ('N', 'rows', 'C', 'ld', 'dtype')]
+
+
 DTYPE_F32 = 0
 DTYPE_BF16 = 1
 
@@ -94,6 +99,9 @@ SIGNATURES = {
                                                                                                  c_void_p]),
     'stp3_bn_bwd_train': (c_int, [_BN_P] + [c_void_p] * 10 + [c_size_t] + [c_void_p] * 4),
     'stp3_conv2d_fwd': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'stp3_se_workspace_bytes': (c_int, [ctypes.POINTER(SeDims), ctypes.POINTER(c_size_t)]),
+    'stp3_se_pool': (c_int, [ctypes.POINTER(SeDims), c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    'stp3_se_scale': (c_int, [ctypes.POINTER(SeDims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_conv2d_fwd_v2_workspace': (c_int, [ctypes.POINTER(ConvDims), ctypes.POINTER(c_size_t)]),
     'stp3_conv2d_fwd_v2': (c_int, [ctypes.POINTER(ConvDims)] + [c_void_p] * 6 + [c_size_t, c_void_p]),
     'stp3_conv2d_wgrad_workspace': (c_int, [ctypes.POINTER(ConvDims), ctypes.POINTER(c_size_t)]),

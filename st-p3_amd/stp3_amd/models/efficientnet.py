@@ -26,6 +26,7 @@ from ..layers import fused as _fused
 from ..layers.fused import ACT_NONE, ACT_SWISH, RES_AFTER_ACT, bn_act, conv2d
 
 _MFMA_ALL = _fused._MFMA_MODE == 'all'
+_FUSED_SE = __import__('os').environ.get('STP3_FUSED_SE', '0') == '1'
 
 # (repeats, kernel, stride, expand, in, out) of the 7 base stages, SE ratio 0.25 everywhere
 _BASE_STAGES = ((1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
@@ -107,9 +108,13 @@ class MBConvBlock(nn.Module):
             x = bn_act(self._bn0, self._expand_conv(x), ACT_SWISH)
         x = bn_act(self._bn1, self._depthwise_conv(x), ACT_SWISH)
         # squeeze and excitation
-        s = x.mean((2, 3), keepdim=True)
-        s = self._se_expand(self._swish(self._se_reduce(s)))
-        x = torch.sigmoid(s) * x
+        if _FUSED_SE and x.is_cuda:
+            from .. import ops_fused
+            x = ops_fused.se_block(x, self._se_reduce, self._se_expand)      # EXPERIMENTAL, off by default
+        else:
+            s = x.mean((2, 3), keepdim=True)
+            s = self._se_expand(self._swish(self._se_reduce(s)))
+            x = torch.sigmoid(s) * x
         x = self._project_conv(x)
         if self.stride == 1 and self.in_ch == self.out_ch:
             oscale = None

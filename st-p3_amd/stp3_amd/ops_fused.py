@@ -180,3 +180,87 @@ def conv_bn_act(x, weight, cbias, bn, act=ops.ACT_NONE, res=None, res_mode=ops.R
                             bn.running_var if bn.track_running_stats else None,
                             float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps), int(act), int(res_mode),
                             s[0], ops._pair(padding), ops._pair(dilation), group)
+
+
+# ----------------------------------------------------------------------------------------------
+# squeeze-and-excitation block as one operator (EXPERIMENTAL, STP3_FUSED_SE=1)
+# ----------------------------------------------------------------------------------------------
+def _se_dims(x):
+    n, c, h, w = x.shape
+    x, ld = ops._rows_view(x)
+    if x.dtype == torch.bfloat16:
+        dt = _lib.DTYPE_BF16
+    elif x.dtype == torch.float32:
+        dt = _lib.DTYPE_F32
+    else:
+        raise _lib.Stp3HipError(f'se_block supports float32 / bfloat16, got {x.dtype}')
+    return x, _lib.SeDims(n, h * w, c, ld, dt)
+
+
+def _se_pool(x, dims, dy=None):
+    lib = _lib.lib()
+    nbytes = ctypes.c_size_t()
+    check(lib.stp3_se_workspace_bytes(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_se_workspace_bytes')
+    ws = _workspace(nbytes.value, x.device)
+    out = torch.empty(dims.N, dims.C, dtype=torch.float32, device=x.device)
+    check(lib.stp3_se_pool(ctypes.byref(dims), x.data_ptr(), ops._opt_ptr(dy), ws.data_ptr(), nbytes.value, out.data_ptr(),
+                           ops._stream_handle()), 'stp3_se_pool')
+    return out
+
+
+def _se_scale(x, dims, gate, add=None):
+    y = torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device)
+    check(_lib.lib().stp3_se_scale(ctypes.byref(dims), x.data_ptr(), gate.data_ptr(), ops._opt_ptr(add), y.data_ptr(),
+                                   ops._stream_handle()), 'stp3_se_scale')
+    return y
+
+
+class _SeBlock(torch.autograd.Function):
+    """y = x * sigmoid(W2 swish(W1 mean_hw(x) + b1) + b2): pooling and gating through stp3_se_pool / stp3_se_scale,
+    the two tiny fully-connected layers in float32 torch ops on (N, C) tensors."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        ops._need_gpu(x)
+        x, dims = _se_dims(x)
+        hw = float(dims.rows)
+        pooled = _se_pool(x, dims) / hw                                       # (N, C)
+        w1f, w2f = w1.detach().flatten(1).float(), w2.detach().flatten(1).float()
+        z1 = torch.addmm(b1.detach().float(), pooled, w1f.t())               # (N, S)
+        h = torch.nn.functional.silu(z1)
+        gate = torch.sigmoid(torch.addmm(b2.detach().float(), h, w2f.t()))   # (N, C)
+        y = _se_scale(x, dims, gate)
+        ctx.save_for_backward(x, gate, pooled, z1, h, w1f, w2f)
+        ctx.dims = dims
+        ctx.meta = (w1.shape, w2.shape, w1.dtype, b1.dtype, w2.dtype, b2.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gate, pooled, z1, h, w1f, w2f = ctx.saved_tensors
+        dims = ctx.dims
+        w1s, w2s, w1d, b1d, w2d, b2d = ctx.meta
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        if dy.stride() != x.stride():
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            if dy.stride() != x.stride():                                     # x was a channel-sliced view
+                xd = x.contiguous(memory_format=torch.channels_last)
+                x, dims = _se_dims(xd)
+        dgate = _se_pool(x, dims, dy)                                         # sum_hw dy * x
+        dz2 = dgate * gate * (1.0 - gate)
+        dw2 = dz2.t().mm(h)
+        db2 = dz2.sum(0)
+        dh = dz2.mm(w2f)
+        sg = torch.sigmoid(z1)
+        dz1 = dh * sg * (1.0 + z1 * (1.0 - sg))
+        dw1 = dz1.t().mm(pooled)
+        db1 = dz1.sum(0)
+        dpooled = dz1.mm(w1f) / float(dims.rows)
+        dx = _se_scale(dy, dims, gate, dpooled.contiguous())
+        return dx, dw1.view(w1s).to(w1d), db1.to(b1d), dw2.view(w2s).to(w2d), db2.to(b2d)
+
+
+def se_block(x, se_reduce, se_expand):
+    """Squeeze-and-excitation of an MBConv block; ``se_reduce`` / ``se_expand`` are its two 1x1 conv modules."""
+    return _SeBlock.apply(x, se_reduce.weight, se_reduce.bias, se_expand.weight, se_expand.bias)

@@ -78,3 +78,29 @@ def test_fused_conv_bn_act_matches_the_two_operators(act, res_mode):
     torch.testing.assert_close(bn_a.running_var, bn_b.running_var, rtol=1e-3, atol=1e-4)
     if rm:
         torch.testing.assert_close(ra.grad.float(), rb.grad.float(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_fused_se_block_matches_torch(dtype):
+    from stp3_amd import ops_fused
+    g = torch.Generator().manual_seed(5)
+    n, c, sq, h, w = 5, 144, 6, 28, 30
+    x = torch.randn(n, c, h, w, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, c, h, w, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    red_a, exp_a = nn.Conv2d(c, sq, 1).cuda(), nn.Conv2d(sq, c, 1).cuda()
+    red_b, exp_b = nn.Conv2d(c, sq, 1).cuda(), nn.Conv2d(sq, c, 1).cuda()
+    red_b.load_state_dict(red_a.state_dict())
+    exp_b.load_state_dict(exp_a.state_dict())
+    xa = x.clone().requires_grad_(True)
+    xb = x.float().clone().requires_grad_(True)
+    ya = ops_fused.se_block(xa, red_a, exp_a)
+    s = xb.mean((2, 3), keepdim=True)
+    yb = torch.sigmoid(exp_b(F.silu(red_b(s)))) * xb
+    tol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(ya.float(), yb, **tol)
+    ya.backward(gy)
+    yb.backward(gy.float())
+    torch.testing.assert_close(xa.grad.float(), xb.grad, **tol)
+    ptol = dict(rtol=1e-3, atol=1e-4) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2)
+    for pa, pb in zip(list(red_a.parameters()) + list(exp_a.parameters()), list(red_b.parameters()) + list(exp_b.parameters())):
+        torch.testing.assert_close(pa.grad, pb.grad, **ptol)
