@@ -1,0 +1,104 @@
+"""CPU: host-side pieces of the path against the fixtures generated from the reference's own classes
+(tests/golden/modules.npz, oracle/make_golden_modules.py) -- the dense modules through the plain-torch
+statement of the fused operators, the losses, the label warp and the IoU metric.  These are the same
+fixtures tests/test_modules_gpu.py replays on the MI355X through the HIP kernels.
+
+Tolerance: float32 CPU vs float32 CPU of the reference (same torch build in the container that generated the
+fixtures): rtol 2e-3 / atol 2e-4 as on the GPU (other BLAS / thread counts may reorder sums); losses rtol 1e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+from stp3_amd import synthetic
+from tests import helpers as H
+
+G = H.load('modules.npz')
+
+
+def close(actual, key, rtol=2e-3, atol=2e-4):
+    torch.testing.assert_close(H.sample(actual).float(), torch.from_numpy(G[key]), rtol=rtol, atol=atol)
+
+
+def prep(m):
+    return H.fill_deterministic(m).eval()
+
+
+@torch.no_grad()
+def test_heads_upsampling_and_temporal_block_match_the_reference_modules():
+    from stp3_amd.layers.convolutions import DeepLabHead, UpsamplingAdd, UpsamplingConcat
+    from stp3_amd.layers.temporal import TemporalBlock
+    close(prep(DeepLabHead(160, 160, hidden_channel=64))(H.det_tensor((2, 160, 14, 30), 1)), 'deeplab_enc')
+    close(prep(UpsamplingConcat(216, 64))(H.det_tensor((2, 160, 14, 30), 3), H.det_tensor((2, 56, 28, 60), 4)), 'upconcat')
+    close(prep(UpsamplingAdd(256, 128))(H.det_tensor((2, 256, 25, 25), 5), H.det_tensor((2, 128, 50, 50), 6)), 'upadd')
+    m = prep(TemporalBlock(70, 64, use_pyramid_pooling=True, pool_sizes=[(2, 40, 40)]))
+    close(m(H.det_tensor((2, 70, 3, 40, 40), 7)), 'tblock')
+
+
+def test_losses_and_label_warp_match_the_reference():
+    from stp3_amd import geometry as geo
+    from stp3_amd import losses as L
+    pred = H.det_tensor((2, 3, 2, 200, 200), 11, 3.0)
+    seg, ped, hd = synthetic.make_labels(2, 3, seed=4)
+    l1 = L.SegmentationLoss(torch.Tensor([1.0, 2.0]), use_top_k=True, top_k_ratio=0.25, future_discount=0.95)(pred, seg, 3)
+    l2 = L.HDmapLoss(torch.Tensor([[1.0, 5.0], [1.0, 1.0]]), [1, 1], [True, False], [0.25, 0.25])(
+        H.det_tensor((2, 4, 200, 200), 12, 3.0), hd[:, 2])
+    l3 = L.DepthLoss()(H.det_tensor((1, 2, 2, 48, 28, 60), 13, 3.0), (H.det_tensor((1, 2, 2, 28, 60), 14).abs() * 47).long())
+    tgt = H.det_tensor((2, 3, 2, 50, 50), 15)
+    tgt[:, :, :, :10] = 255
+    l4 = L.SpatialRegressionLoss(norm=1, future_discount=0.95)(H.det_tensor((2, 3, 2, 50, 50), 16), tgt, 2)
+    got = torch.stack([l1, l2, l3, l4]).double()
+    torch.testing.assert_close(got, torch.from_numpy(G['losses']), rtol=1e-5, atol=1e-6)
+    ego = synthetic.make_rig(2, 3, seed=6)[2]
+    wp = geo.cumulative_warp_features(seg.float(), ego, 'nearest', (50.0, 50.0))
+    wr = geo.cumulative_warp_features_reverse(seg.float(), ego, 'nearest', (50.0, 50.0))
+    torch.testing.assert_close(wp.sum(dim=(-1, -2, -3)), torch.from_numpy(G['warp_past_sum']))
+    torch.testing.assert_close(wr.sum(dim=(-1, -2, -3)), torch.from_numpy(G['warp_rev_sum']))
+    assert torch.equal(H.sample(wp), torch.from_numpy(G['warp_past_sample']))
+
+
+def test_iou_metric_counts():
+    from stp3_amd.metrics import IntersectionOverUnion
+    g = torch.Generator().manual_seed(2)
+    pred = (torch.rand(2, 1, 1, 50, 50, generator=g) > 0.6).long()
+    tgt = (torch.rand(2, 1, 1, 50, 50, generator=g) > 0.5).long()
+    m = IntersectionOverUnion(2)
+    m(pred, tgt)
+    tp = int(((pred == 1) & (tgt == 1)).sum())
+    fp = int(((pred == 1) & (tgt == 0)).sum())
+    fn = int(((pred == 0) & (tgt == 1)).sum())
+    assert abs(float(m.compute()[1]) - tp / (tp + fp + fn)) < 1e-6          # stp3/metrics.py:37-65
+
+
+def test_staged_sum_equals_sum():
+    from stp3_amd.utils import staged_mean, staged_sum
+    g = torch.Generator().manual_seed(0)
+    for n in (1, 4095, 4096, 8193, 1_000_003):
+        x = torch.randn(n, generator=g, dtype=torch.float64)
+        torch.testing.assert_close(staged_sum(x), x.sum(), rtol=1e-12, atol=1e-9)
+        torch.testing.assert_close(staged_mean(x), x.mean(), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize('train', [True, False])
+def test_bn_act_reference_equals_torch_modules(train):
+    import torch.nn as nn
+    from stp3_amd.layers import fused
+    torch.manual_seed(0)
+    bn, ref = nn.BatchNorm2d(12), nn.BatchNorm2d(12)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_var.uniform_(0.5, 1.5)
+    ref.load_state_dict(bn.state_dict())
+    bn.train(train)
+    ref.train(train)
+    x = torch.randn(3, 12, 5, 7, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    res = torch.randn(3, 12, 5, 7)
+    y = fused.bn_act(bn, x, fused.ACT_SWISH, res=res, res_mode=fused.RES_AFTER_ACT)
+    y2 = torch.nn.functional.silu(ref(x2)) + res
+    torch.testing.assert_close(y, y2, rtol=1e-5, atol=1e-5)
+    y.sum().backward()
+    y2.sum().backward()
+    torch.testing.assert_close(x.grad, x2.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(bn.running_var, ref.running_var)
