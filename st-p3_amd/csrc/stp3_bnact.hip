@@ -16,6 +16,7 @@
 //   backward: reduce pass reads dy, x (+res); apply pass reads dy, x (+res), writes dx (+dres)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <initializer_list>
 
@@ -82,13 +83,19 @@ struct Map {
     int CV, CVB, RL, cv, rl;
     bool live;
 };
-template <int VEC>
+// FULL (experimental geometry, STP3_BN_GEOM=1): every thread of the workgroup is a live row lane
+// (RL = 256 / CVB, not rounded down to a power of two) -- with C = 144 that is 252 instead of 144 threads.
+template <int VEC, bool FULL>
 __device__ __forceinline__ Map make_map(const BnDims& d) {
     Map m;
     m.CV = (d.C + VEC - 1) / VEC;
     m.CVB = min(m.CV, kThreads);
     int rl = 1;
-    while (rl * 2 * m.CVB <= kThreads) rl *= 2;
+    if (FULL) {
+        rl = kThreads / m.CVB;
+    } else {
+        while (rl * 2 * m.CVB <= kThreads) rl *= 2;
+    }
     m.RL = rl;
     const int cvb = threadIdx.x % m.CVB;
     m.rl = threadIdx.x / m.CVB;
@@ -113,7 +120,7 @@ __device__ __forceinline__ float act_grad(int act, float pre) {
 
 // In-block tree reduction over the row lanes of K values per thread, then one partial row per block:
 // partial[((n * gridDim.x + bx) * K + k) * C + c]
-template <int VEC, int K>
+template <int VEC, int K, bool FULL>
 __device__ __forceinline__ void block_reduce_store(const BnDims& d, const Map& m, float (*acc)[VEC], float* red,
                                                    float* __restrict__ partial) {
     const int cvb = threadIdx.x % m.CVB;
@@ -126,12 +133,24 @@ __device__ __forceinline__ void block_reduce_store(const BnDims& d, const Map& m
             for (int j = 0; j < VEC; ++j) red[m.rl * width + cvb * VEC + j] = m.live ? acc[k][j] : 0.f;
         }
         __syncthreads();
-        for (int s = m.RL >> 1; s > 0; s >>= 1) {
-            if (m.rl < s) {
+        if (FULL) {                                           // RL need not be a power of two
+            int p2 = 1;
+            while (p2 < m.RL) p2 <<= 1;
+            for (int s = p2 >> 1; s > 0; s >>= 1) {
+                if (m.rl < s && m.rl + s < m.RL) {
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) red[m.rl * width + cvb * VEC + j] += red[(m.rl + s) * width + cvb * VEC + j];
+                    for (int j = 0; j < VEC; ++j) red[m.rl * width + cvb * VEC + j] += red[(m.rl + s) * width + cvb * VEC + j];
+                }
+                __syncthreads();
             }
-            __syncthreads();
+        } else {
+            for (int s = m.RL >> 1; s > 0; s >>= 1) {
+                if (m.rl < s) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) red[m.rl * width + cvb * VEC + j] += red[(m.rl + s) * width + cvb * VEC + j];
+                }
+                __syncthreads();
+            }
         }
         if (m.rl == 0 && m.cv < m.CV) {
             float* out = partial + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * K + k) * d.C + m.cv * VEC;
@@ -143,12 +162,12 @@ __device__ __forceinline__ void block_reduce_store(const BnDims& d, const Map& m
 }
 
 // ---- forward statistics: per-channel sum and sum of squares of (x + sbias) ------------------------
-template <typename T, int VEC>
+template <typename T, int VEC, bool FULL>
 __global__ __launch_bounds__(kThreads) void bn_stats_kernel(BnDims d, const T* __restrict__ x,
                                                             const float* __restrict__ sbias,
                                                             float* __restrict__ partial) {
     __shared__ float red[kThreads * VEC];
-    const Map m = make_map<VEC>(d);
+    const Map m = make_map<VEC, FULL>(d);
     const int n = blockIdx.y;
     float acc[2][VEC];
 #pragma unroll
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(BnDims d, const T* _
             }
         }
     }
-    block_reduce_store<VEC, 2>(d, m, acc, red, partial);
+    block_reduce_store<VEC, 2, FULL>(d, m, acc, red, partial);
 }
 
 // ---- sums over partial rows: out[g][i] = sum_p partial[(g * parts + p) * width + i], in double ------
@@ -227,14 +246,14 @@ __device__ __forceinline__ void channel_affine(const BnDims& d, const Map& m, co
 // ---- forward apply -------------------------------------------------------------------------------
 // y = act(((x + sbias) - mean) * invstd * gamma + beta [+ res]) [* oscale[n]] [+ res]
 // TRAIN: mean / invstd from `sums` (of `count` elements); else from the running statistics.
-template <typename T, int VEC, bool TRAIN>
+template <typename T, int VEC, bool TRAIN, bool FULL>
 __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
     BnDims d, const T* __restrict__ x, const float* __restrict__ sbias, const T* __restrict__ res,
     const float* __restrict__ oscale, const float* __restrict__ sums, float inv_count, float unbias,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ save_mean,
     float* __restrict__ save_invstd, T* __restrict__ y) {
-    const Map m = make_map<VEC>(d);
+    const Map m = make_map<VEC, FULL>(d);
     if (!m.live) return;
     const int n = blockIdx.y;
     const int c0 = m.cv * VEC;
@@ -307,14 +326,14 @@ __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
 
 // ---- backward reduce: per (sample, channel) sums of g, g * xhat and xhat -----------------------
 // g = dy * oscale[n] * act'(pre), pre = xhat * gamma + beta [+ res]
-template <typename T, int VEC>
+template <typename T, int VEC, bool FULL>
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
     BnDims d, const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ sbias,
     const T* __restrict__ res, const float* __restrict__ oscale, const float* __restrict__ mean_,
     const float* __restrict__ invstd_, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ partial) {
     __shared__ float red[kThreads * VEC];
-    const Map m = make_map<VEC>(d);
+    const Map m = make_map<VEC, FULL>(d);
     const int n = blockIdx.y;
     float acc[3][VEC];
 #pragma unroll
@@ -368,18 +387,18 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
             }
         }
     }
-    block_reduce_store<VEC, 3>(d, m, acc, red, partial);
+    block_reduce_store<VEC, 3, FULL>(d, m, acc, red, partial);
 }
 
 // ---- backward apply: dx = gamma * invstd * (g - sum(g)/M - xhat * sum(g*xhat)/M), dres ----------
 // TRAIN == false (running statistics are constants): dx = gamma * invstd * g
-template <typename T, int VEC, bool TRAIN>
+template <typename T, int VEC, bool TRAIN, bool FULL>
 __global__ __launch_bounds__(kThreads) void bn_apply_bwd_kernel(
     BnDims d, const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ sbias,
     const T* __restrict__ res, const float* __restrict__ oscale, const float* __restrict__ mean_,
     const float* __restrict__ invstd_, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ gsums, float inv_count, T* __restrict__ dx, T* __restrict__ dres) {
-    const Map m = make_map<VEC>(d);
+    const Map m = make_map<VEC, FULL>(d);
     if (!m.live) return;
     const int n = blockIdx.y;
     const int c0 = m.cv * VEC;
@@ -447,6 +466,7 @@ struct Launch {
     BnDims d;
     int vec;       // 8 / 4 (vector path) or 1
     bool bf16;
+    bool full;     // experimental geometry (STP3_BN_GEOM=1): all row lanes live, ~4096 workgroups
     dim3 grid;
     int parts;     // partial rows = N * grid.x
 };
@@ -470,13 +490,20 @@ inline int plan(const stp3_bn_dims* p, Launch* L, std::initializer_list<const vo
     BnDims& d = L->d;
     d.N = p->N; d.rows = p->rows; d.C = p->C; d.ldx = p->ldx; d.ldy = p->ldy; d.ldr = p->ldr;
     d.act = p->act; d.res_mode = p->res_mode; d.has_sbias = p->has_sbias; d.has_oscale = p->has_oscale;
+    static const bool geom_full = [] { const char* e = getenv("STP3_BN_GEOM"); return e && e[0] == '1'; }();
+    L->full = geom_full;
     const int CV = (p->C + L->vec - 1) / L->vec;
     const int CVB = CV < kThreads ? CV : kThreads;
     int RL = 1;
-    while (RL * 2 * CVB <= kThreads) RL *= 2;
+    if (L->full) {
+        RL = kThreads / CVB;
+    } else {
+        while (RL * 2 * CVB <= kThreads) RL *= 2;
+    }
     const int ctiles = (CV + CVB - 1) / CVB;
-    // ~1024 blocks in total, at least 8 rows per row lane
-    int bx = (1024 + p->N * ctiles - 1) / (p->N * ctiles);
+    // ~1024 blocks in total (4096 with the experimental geometry), at least 8 rows per row lane
+    const int target = L->full ? 4096 : 1024;
+    int bx = (target + p->N * ctiles - 1) / (p->N * ctiles);
     const int max_bx = (p->rows + RL * 8 - 1) / (RL * 8);
     if (bx > max_bx) bx = max_bx;
     if (bx < 1) bx = 1;
@@ -486,9 +513,10 @@ inline int plan(const stp3_bn_dims* p, Launch* L, std::initializer_list<const vo
     return STP3_OK;
 }
 
-// run CALL with `T` / `VEC` bound to the launch's element type and vector width
-#define BN_SWITCH(L, ...)                                                       \
-    do {                                                                        \
+// run CALL with `T` / `VEC` / `FULL` bound to the launch's element type, vector width and geometry
+#define BN_SWITCH_V(L, F, ...)                                                  \
+    {                                                                           \
+        constexpr bool FULL = F;                                                \
         if ((L).bf16) {                                                         \
             if ((L).vec == 8) { using T = uint16_t; constexpr int VEC = 8; __VA_ARGS__; } \
             else              { using T = uint16_t; constexpr int VEC = 1; __VA_ARGS__; } \
@@ -496,6 +524,11 @@ inline int plan(const stp3_bn_dims* p, Launch* L, std::initializer_list<const vo
             if ((L).vec == 4) { using T = float; constexpr int VEC = 4; __VA_ARGS__; }    \
             else              { using T = float; constexpr int VEC = 1; __VA_ARGS__; }    \
         }                                                                       \
+    }
+#define BN_SWITCH(L, ...)                                                       \
+    do {                                                                        \
+        if ((L).full) BN_SWITCH_V(L, true, __VA_ARGS__)                         \
+        else BN_SWITCH_V(L, false, __VA_ARGS__)                                 \
     } while (0)
 
 inline size_t ws_bytes(const stp3_bn_dims* p) {
@@ -527,7 +560,7 @@ int stp3_bn_stats(const stp3_bn_dims* p, const void* x, const float* sbias, void
     if (workspace_bytes < ws_bytes(p)) return STP3_ENOSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)workspace;
-    BN_SWITCH(L, hipLaunchKernelGGL((bn_stats_kernel<T, VEC>), L.grid, dim3(kThreads), 0, s, L.d, (const T*)x, sbias,
+    BN_SWITCH(L, hipLaunchKernelGGL((bn_stats_kernel<T, VEC, FULL>), L.grid, dim3(kThreads), 0, s, L.d, (const T*)x, sbias,
                                      partial));
     reduce_partials(1, L.parts, 2 * p->C, partial, sums, s);
     return status();
@@ -551,12 +584,12 @@ int stp3_bn_apply_fwd(const stp3_bn_dims* p, const void* x, const float* sbias, 
     const float inv_count = train ? (float)(1.0 / count) : 0.f;
     const float unbias = (train && count > 1.0) ? (float)(count / (count - 1.0)) : 1.f;
     if (train)
-        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_fwd_kernel<T, VEC, true>), L.grid, dim3(kThreads), 0, s, L.d,
+        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_fwd_kernel<T, VEC, true, FULL>), L.grid, dim3(kThreads), 0, s, L.d,
                                          (const T*)x, sbias, (const T*)res, oscale, sums, inv_count, unbias, gamma,
                                          beta, eps, momentum, running_mean, running_var, save_mean, save_invstd,
                                          (T*)y));
     else
-        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_fwd_kernel<T, VEC, false>), L.grid, dim3(kThreads), 0, s, L.d,
+        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_fwd_kernel<T, VEC, false, FULL>), L.grid, dim3(kThreads), 0, s, L.d,
                                          (const T*)x, sbias, (const T*)res, oscale, sums, inv_count, unbias, gamma,
                                          beta, eps, momentum, running_mean, running_var, save_mean, save_invstd,
                                          (T*)y));
@@ -576,7 +609,7 @@ int stp3_bn_bwd_reduce(const stp3_bn_dims* p, const void* dy, const void* x, con
     if (workspace_bytes < ws_bytes(p)) return STP3_ENOSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)workspace;
-    BN_SWITCH(L, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC>), L.grid, dim3(kThreads), 0, s, L.d, (const T*)dy,
+    BN_SWITCH(L, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, FULL>), L.grid, dim3(kThreads), 0, s, L.d, (const T*)dy,
                                      (const T*)x, sbias, (const T*)res, oscale, mean, invstd, gamma, beta, partial));
     reduce_partials(p->N, (int)L.grid.x, 3 * p->C, partial, sample_sums, s);     // [N][3][C]
     reduce_partials(1, p->N, 3 * p->C, sample_sums, sums, s);                     // [3][C]
@@ -597,11 +630,11 @@ int stp3_bn_apply_bwd(const stp3_bn_dims* p, const void* dy, const void* x, cons
     hipStream_t s = (hipStream_t)stream;
     const float inv_count = train ? (float)(1.0 / count) : 0.f;
     if (train)
-        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, VEC, true>), L.grid, dim3(kThreads), 0, s, L.d,
+        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, VEC, true, FULL>), L.grid, dim3(kThreads), 0, s, L.d,
                                          (const T*)dy, (const T*)x, sbias, (const T*)res, oscale, mean, invstd, gamma,
                                          beta, sums, inv_count, (T*)dx, (T*)dres));
     else
-        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, VEC, false>), L.grid, dim3(kThreads), 0, s, L.d,
+        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, VEC, false, FULL>), L.grid, dim3(kThreads), 0, s, L.d,
                                          (const T*)dy, (const T*)x, sbias, (const T*)res, oscale, mean, invstd, gamma,
                                          beta, sums, inv_count, (T*)dx, (T*)dres));
     return status();
