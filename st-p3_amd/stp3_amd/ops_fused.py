@@ -226,9 +226,10 @@ class _SeBlock(torch.autograd.Function):
         hw = float(dims.rows)
         pooled = _se_pool(x, dims) / hw                                       # (N, C)
         w1f, w2f = w1.detach().flatten(1).float(), w2.detach().flatten(1).float()
-        z1 = torch.addmm(b1.detach().float(), pooled, w1f.t())               # (N, S)
-        h = torch.nn.functional.silu(z1)
-        gate = torch.sigmoid(torch.addmm(b2.detach().float(), h, w2f.t()))   # (N, C)
+        with torch.autocast('cuda', enabled=False):                           # the kernels read float32 gates
+            z1 = torch.addmm(b1.detach().float(), pooled, w1f.t())           # (N, S)
+            h = torch.nn.functional.silu(z1)
+            gate = torch.sigmoid(torch.addmm(b2.detach().float(), h, w2f.t()))   # (N, C)
         y = _se_scale(x, dims, gate)
         ctx.save_for_backward(x, gate, pooled, z1, h, w1f, w2f)
         ctx.dims = dims
@@ -248,6 +249,12 @@ class _SeBlock(torch.autograd.Function):
                 xd = x.contiguous(memory_format=torch.channels_last)
                 x, dims = _se_dims(xd)
         dgate = _se_pool(x, dims, dy)                                         # sum_hw dy * x
+        with torch.autocast('cuda', enabled=False):
+            return _SeBlock._mlp_backward(dims, dy, dgate, gate, pooled, z1, h, w1f, w2f, ctx.meta)
+
+    @staticmethod
+    def _mlp_backward(dims, dy, dgate, gate, pooled, z1, h, w1f, w2f, meta):
+        w1s, w2s, w1d, b1d, w2d, b2d = meta
         dz2 = dgate * gate * (1.0 - gate)
         dw2 = dz2.t().mm(h)
         db2 = dz2.sum(0)

@@ -93,7 +93,8 @@ def test_fused_se_block_matches_torch(dtype):
     exp_b.load_state_dict(exp_a.state_dict())
     xa = x.clone().requires_grad_(True)
     xb = x.float().clone().requires_grad_(True)
-    ya = ops_fused.se_block(xa, red_a, exp_a)
+    with torch.autocast('cuda', dtype=torch.bfloat16):                 # as in the training step: must not leak into the op
+        ya = ops_fused.se_block(xa, red_a, exp_a)
     s = xb.mean((2, 3), keepdim=True)
     yb = torch.sigmoid(exp_b(F.silu(red_b(s)))) * xb
     tol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
