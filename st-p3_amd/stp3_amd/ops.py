@@ -12,6 +12,7 @@ Mirrors the reference's operator surface for this path:
 PyTorch is used for device memory, streams and autograd plumbing only.
 """
 import ctypes
+import os
 
 import torch
 
@@ -21,6 +22,14 @@ from ._lib import LiftDims, VOX_PIXELMAJOR, VOX_REFERENCE, check
 
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
+
+
+# EXPERIMENTAL: C++ launch path of the custom operators (csrc/host/stp3_host.cpp), selected with STP3_CPP_OPS=1.
+# Same C ABI, same arithmetic, ~4x less host time per call; single-process BatchNorm only.
+_CPP = None
+if os.environ.get('STP3_CPP_OPS', '0') == '1':
+    from . import _stp3_host as _CPP          # built by csrc/host/build_host.py (see __graft_entry__.build)
+    _CPP.init(_lib.LIB_PATH)
 
 
 def _stream():
@@ -367,6 +376,10 @@ def depthwise_conv2d(x, weight, stride=1, pad=(0, 0, 0, 0)):
     run in the autocast dtype (bf16); the weights are consumed in float32 either way."""
     if torch.is_autocast_enabled():
         x = x.to(torch.get_autocast_gpu_dtype())
+    if _CPP is not None:
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            raise _lib.Stp3HipError(f'depthwise conv supports float32 / bfloat16, got {x.dtype}')
+        return _CPP.depthwise_conv2d(x, weight, int(stride), int(pad[0]), int(pad[1]), int(pad[2]), int(pad[3]))
     return _DepthwiseConv2d.apply(x, weight, int(stride), tuple(int(p) for p in pad))
 
 
@@ -567,6 +580,10 @@ def bn_act(x, weight, bias, running_mean, running_var, training, momentum, eps, 
     ``group=False`` disables the cross-replica statistics even when torch.distributed is initialised."""
     if res is None:
         res_mode = RES_NONE
+    if _CPP is not None and (group is False or not (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                                    and torch.distributed.get_world_size(group) > 1)):
+        return _CPP.bn_act(x, weight, bias, res, sbias, oscale, running_mean, running_var, bool(training),
+                           float(momentum if momentum is not None else 0.1), float(eps), int(act), int(res_mode))
     return _BnAct.apply(x, weight, bias, res, sbias, oscale, running_mean, running_var, bool(training),
                         float(momentum if momentum is not None else 0.1), float(eps), int(act), int(res_mode), group)
 
@@ -643,6 +660,8 @@ def invalidate_weight_cache():
     """Call after updating parameters through storage the parameter's version counter does not see (the flat
     buffers of ``parallel.FlatAdam``); in-place updates of the parameters themselves are detected automatically."""
     _WEIGHT_EPOCH[0] += 1
+    if _CPP is not None:
+        _CPP.invalidate_weight_cache()
 
 
 def _bf16_weights(weight, need_flipped=False):
@@ -725,4 +744,8 @@ class _Conv2dMfma(torch.autograd.Function):
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, out_dtype=torch.bfloat16):
     """Dense conv through the MFMA implicit-GEMM kernel (bf16 operands, float32 accumulation)."""
     s = _pair(stride)
+    if _CPP is not None:
+        p, d = _pair(padding), _pair(dilation)
+        _CPP.set_wgrad_min_channels(int(WGRAD_MIN_CHANNELS))
+        return _CPP.conv2d(x, weight, bias, s[0], p[0], p[1], d[0], d[1], out_dtype == torch.float32)
     return _Conv2dMfma.apply(x, weight, bias, s[0], _pair(padding), _pair(dilation), out_dtype)
