@@ -104,8 +104,17 @@ class MBConvBlock(nn.Module):
 
     def forward(self, inputs, drop_connect_rate=None):
         x = inputs
+        # EXPERIMENTAL (STP3_CONV_V2=1 with STP3_MFMA_CONV=all): 1x1 conv -> BN -> activation as one operator
+        fuse = (_fused._CONV_V2 and _MFMA_ALL and self.training and x.is_cuda and torch.is_autocast_enabled()
+                and self.in_ch % 8 == 0 and (self.in_ch * self.expand) % 8 == 0)
+        if fuse:
+            from .. import ops_fused
+            group = None if _fused._sync_world(self._bn1) > 1 else False
         if self.expand != 1:
-            x = bn_act(self._bn0, self._expand_conv(x), ACT_SWISH)
+            if fuse:
+                x = ops_fused.conv_bn_act(x, self._expand_conv.weight, None, self._bn0, ACT_SWISH, group=group)
+            else:
+                x = bn_act(self._bn0, self._expand_conv(x), ACT_SWISH)
         x = bn_act(self._bn1, self._depthwise_conv(x), ACT_SWISH)
         # squeeze and excitation
         if _FUSED_SE and x.is_cuda:
@@ -115,13 +124,17 @@ class MBConvBlock(nn.Module):
             s = x.mean((2, 3), keepdim=True)
             s = self._se_expand(self._swish(self._se_reduce(s)))
             x = torch.sigmoid(s) * x
+        skip = self.stride == 1 and self.in_ch == self.out_ch
+        oscale = None
+        if skip and drop_connect_rate and self.training:
+            # drop-connect: the branch of sample n is scaled by mask_n / keep before the skip is added
+            keep = 1.0 - drop_connect_rate
+            oscale = torch.floor(keep + torch.rand(x.shape[0], dtype=torch.float32, device=x.device)) / keep
+        if fuse:
+            return ops_fused.conv_bn_act(x, self._project_conv.weight, None, self._bn2, ACT_NONE, inputs if skip else None,
+                                         RES_AFTER_ACT if skip else _fused.RES_NONE, group=group, oscale=oscale)
         x = self._project_conv(x)
-        if self.stride == 1 and self.in_ch == self.out_ch:
-            oscale = None
-            if drop_connect_rate and self.training:
-                # drop-connect: the branch of sample n is scaled by mask_n / keep before the skip is added
-                keep = 1.0 - drop_connect_rate
-                oscale = torch.floor(keep + torch.rand(x.shape[0], dtype=torch.float32, device=x.device)) / keep
+        if skip:
             return bn_act(self._bn2, x, ACT_NONE, res=inputs, res_mode=RES_AFTER_ACT, oscale=oscale)
         return bn_act(self._bn2, x, ACT_NONE)
 

@@ -52,7 +52,7 @@ def conv2d_v2(x, wb, bias, stride, pad, dil, sums_ptr=None):
 class _ConvBnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, cbias, gamma, beta, res, running_mean, running_var, momentum, eps, act, res_mode,
-                stride, pad, dil, group):
+                stride, pad, dil, group, oscale=None):
         ops._need_gpu(x, weight)
         if x.dtype != torch.bfloat16:
             x = x.to(torch.bfloat16)
@@ -76,13 +76,14 @@ class _ConvBnAct(torch.autograd.Function):
         else:
             res_mode = ops.RES_NONE
         out = torch.empty_like(yc)
-        dims = _lib.BnDims(n, ho * wo, cout, cout, cout, ldr, _lib.DTYPE_BF16, act, res_mode, 0, 0)
+        osc = ops._f32(oscale)
+        dims = _lib.BnDims(n, ho * wo, cout, cout, cout, ldr, _lib.DTYPE_BF16, act, res_mode, 0, int(osc is not None))
         g32, b32 = ops._f32(gamma), ops._f32(beta)
-        check(_lib.lib().stp3_bn_apply_fwd(ctypes.byref(dims), yc.data_ptr(), None, ops._opt_ptr(res), None, base, count,
+        check(_lib.lib().stp3_bn_apply_fwd(ctypes.byref(dims), yc.data_ptr(), None, ops._opt_ptr(res), ops._opt_ptr(osc), base, count,
                                            ops._opt_ptr(g32), ops._opt_ptr(b32), eps, momentum, ops._opt_ptr(running_mean),
                                            ops._opt_ptr(running_var), base + 8 * cout, base + 12 * cout, out.data_ptr(),
                                            ops._stream_handle()), 'stp3_bn_apply_fwd')
-        ctx.save_for_backward(x, wb, yc, res if res_mode == ops.RES_BEFORE_ACT else None, g32, b32, stat)
+        ctx.save_for_backward(x, wb, yc, res if res_mode == ops.RES_BEFORE_ACT else None, g32, b32, stat, osc)
         ctx.cfg = (dims, count, world, group, stride, pad, dil, cbias is not None)
         ctx.weight_ref = weight
         ctx.dtypes = (weight.dtype, None if cbias is None else cbias.dtype, None if gamma is None else gamma.dtype,
@@ -91,7 +92,7 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, wb, yc, res, g32, b32, stat = ctx.saved_tensors
+        x, wb, yc, res, g32, b32, stat, osc = ctx.saved_tensors
         dims, count, world, group, stride, pad, dil, has_cbias = ctx.cfg
         wdt, cbdt, gdt, bdt, rdt = ctx.dtypes
         n, rows, c = dims.N, dims.rows, dims.C
@@ -110,9 +111,10 @@ class _ConvBnAct(torch.autograd.Function):
             dres = torch.empty_like(yc)
             if dims.ldr != c:
                 res = res.contiguous(memory_format=torch.channels_last)
-                dims = _lib.BnDims(dims.N, dims.rows, dims.C, dims.ldx, dims.ldy, c, dims.dtype, dims.act, dims.res_mode, 0, 0)
+                dims = _lib.BnDims(dims.N, dims.rows, dims.C, dims.ldx, dims.ldy, c, dims.dtype, dims.act, dims.res_mode, 0,
+                                   dims.has_oscale)
         stream = ops._stream_handle()
-        check(lib.stp3_bn_bwd_reduce(ctypes.byref(dims), dy.data_ptr(), yc.data_ptr(), None, ops._opt_ptr(res), None, mean_p,
+        check(lib.stp3_bn_bwd_reduce(ctypes.byref(dims), dy.data_ptr(), yc.data_ptr(), None, ops._opt_ptr(res), ops._opt_ptr(osc), mean_p,
                                      invstd_p, ops._opt_ptr(g32), ops._opt_ptr(b32), ws.data_ptr(), ws_bytes,
                                      sumbuf.data_ptr(), sumbuf.data_ptr() + 4 * sums_off, stream), 'stp3_bn_bwd_reduce')
         lsums = sumbuf[sums_off:].view(3, c)
@@ -120,7 +122,7 @@ class _ConvBnAct(torch.autograd.Function):
         if world > 1:
             gsums = lsums.clone()
             torch.distributed.all_reduce(gsums, group=group)
-        check(lib.stp3_bn_apply_bwd(ctypes.byref(dims), dy.data_ptr(), yc.data_ptr(), None, ops._opt_ptr(res), None, mean_p,
+        check(lib.stp3_bn_apply_bwd(ctypes.byref(dims), dy.data_ptr(), yc.data_ptr(), None, ops._opt_ptr(res), ops._opt_ptr(osc), mean_p,
                                     invstd_p, ops._opt_ptr(g32), ops._opt_ptr(b32), gsums.data_ptr(), count,
                                     dconv.data_ptr(), ops._opt_ptr(dres), stream), 'stp3_bn_apply_bwd')
         dgamma = lsums[1].to(gdt) if gdt is not None and ctx.needs_input_grad[3] else None
@@ -167,11 +169,11 @@ class _ConvBnAct(torch.autograd.Function):
                 dw = gw.to(wdt)
             if mask[2]:
                 dcb = gb.to(cbdt)
-        return (dx, dw, dcb, dgamma, dbeta, dres) + (None,) * 10
+        return (dx, dw, dcb, dgamma, dbeta, dres) + (None,) * 11
 
 
 def conv_bn_act(x, weight, cbias, bn, act=ops.ACT_NONE, res=None, res_mode=ops.RES_NONE, stride=1, padding=0, dilation=1,
-                group=None):
+                group=None, oscale=None):
     """Training-mode conv -> BatchNorm -> activation (-> + skip) through the fused kernels (GPU, bf16)."""
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
@@ -179,7 +181,7 @@ def conv_bn_act(x, weight, cbias, bn, act=ops.ACT_NONE, res=None, res_mode=ops.R
     return _ConvBnAct.apply(x, weight, cbias, bn.weight, bn.bias, res, bn.running_mean if bn.track_running_stats else None,
                             bn.running_var if bn.track_running_stats else None,
                             float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps), int(act), int(res_mode),
-                            s[0], ops._pair(padding), ops._pair(dilation), group)
+                            s[0], ops._pair(padding), ops._pair(dilation), group, oscale)
 
 
 # ----------------------------------------------------------------------------------------------

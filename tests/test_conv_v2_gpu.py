@@ -105,3 +105,29 @@ def test_fused_se_block_matches_torch(dtype):
     ptol = dict(rtol=1e-3, atol=1e-4) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2)
     for pa, pb in zip(list(red_a.parameters()) + list(exp_a.parameters()), list(red_b.parameters()) + list(exp_b.parameters())):
         torch.testing.assert_close(pa.grad, pb.grad, **ptol)
+
+
+def test_fused_project_conv_with_drop_connect_and_skip():
+    """The MBConv tail: 1x1 conv (thin channels) -> BN -> * drop-connect scale -> + skip, fused vs the two operators."""
+    from stp3_amd import ops, ops_fused
+    from stp3_amd.layers import fused
+    ops.WGRAD_MIN_CHANNELS = 0
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 144, 20, 24, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    skip = torch.randn(4, 32, 20, 24, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(4, 32, 20, 24, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    oscale = torch.tensor([1.25, 0.0, 1.25, 1.25]).cuda()
+    conv_a, conv_b = nn.Conv2d(144, 32, 1, bias=False).cuda(), nn.Conv2d(144, 32, 1, bias=False).cuda()
+    conv_b.load_state_dict(conv_a.state_dict())
+    bn_a, bn_b = nn.BatchNorm2d(32).cuda(), nn.BatchNorm2d(32).cuda()
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    sa, sb = skip.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+    ya = ops_fused.conv_bn_act(xa, conv_a.weight, None, bn_a, ops.ACT_NONE, sa, ops.RES_AFTER_ACT, group=False, oscale=oscale)
+    yb = fused.bn_act(bn_b, ops.conv2d(xb, conv_b.weight), ops.ACT_NONE, res=sb, res_mode=ops.RES_AFTER_ACT, oscale=oscale)
+    torch.testing.assert_close(ya.float(), yb.float(), rtol=2e-2, atol=2e-2)
+    ya.backward(gy)
+    yb.backward(gy)
+    torch.testing.assert_close(xa.grad.float(), xb.grad.float(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(sa.grad.float(), sb.grad.float(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(conv_a.weight.grad, conv_b.weight.grad, rtol=2e-2, atol=2e-2 * float(conv_b.weight.grad.abs().max()))
+    torch.testing.assert_close(bn_a.weight.grad, bn_b.weight.grad, rtol=2e-2, atol=5e-2)
