@@ -4,6 +4,8 @@
 TAG=${1:-r02a}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 run() { echo "=== $*"; "$@" 2>&1 | grep -v "amdgpu.ids\|MIOpen(HIP)" | tail -${TAILN:-4}; }
 TAILN=4 run env STP3_EXPERIMENTAL=1 STP3_BN_GEOM=1 timeout 200 python -m pytest tests/test_conv_v2_gpu.py tests/test_bnact_gpu.py -q -x
+TAILN=4 run env STP3_LIFT_BWD=mfma timeout 300 python -m pytest tests/test_lift_gpu.py -q -x
+TAILN=10 run env STP3_LIFT_BWD=mfma timeout 100 python scripts/time_lift.py
 TAILN=6 run env STP3_CPP_OPS=1 timeout 400 python -m pytest tests -m gpu -q -x
 TAILN=12 run env STP3_BN_GEOM=0 timeout 100 python scripts/time_bn.py
 TAILN=12 run env STP3_BN_GEOM=1 timeout 100 python scripts/time_bn.py
@@ -13,6 +15,7 @@ bench base STP3_BN_GEOM=0
 bench bngeom STP3_BN_GEOM=1
 bench se STP3_BN_GEOM=1 STP3_FUSED_SE=1
 bench convv2 STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1
+bench liftmfma STP3_BN_GEOM=0 STP3_LIFT_BWD=mfma
 bench cpp STP3_BN_GEOM=1 STP3_CPP_OPS=1
 bench trunkfused STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1 STP3_MFMA_CONV=all
 bench all STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1 STP3_CPP_OPS=1

@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "stp3_hip.h"
 
@@ -634,6 +636,191 @@ __global__ __launch_bounds__(256) void lift_splat_bwd_kernel(Dims dm, int hsplit
     }
 }
 
+// (b') EXPERIMENTAL (STP3_LIFT_BWD=mfma): the same backward as two small fp32 GEMMs per image column
+//      on the matrix cores.  With the column's runs r = (depth bin d_r, rows [h0_r, h1_r), voxel v_r):
+//          Ghat[r][c] = G[v_r][c]                        (one 256-B row fetched per run)
+//          Phat[h][r] = prob[h][d_r] if h0_r <= h < h1_r else 0
+//          dfeat[h][c]   = sum_r Phat[h][r] * Ghat[r][c]               ([fH x R] x [R x C])
+//          dprob[h][d_r] = sum_c feat[h][c] * Ghat[r][c], h in the run ([fH x C] x [C x R], masked)
+//      One block (4 waves) per column; wave w owns the 16-channel slice w of dfeat and every
+//      fourth 16-run tile of dprob.  Runs are enumerated in the block from the voxel ids (bin-major,
+//      the order the forward plan uses), processed in chunks of kBwdRunCap.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kBwdRunCap = 128;  // runs per chunk (rows of Ghat resident in LDS)
+constexpr int kBwdRows = 32;     // image rows covered by the two 16-row MFMA tiles
+constexpr int kBwdStride = 66;   // row stride (floats) of the 64-wide LDS tiles: 2h + k spreads the banks
+
+inline size_t lift_bwd_mfma_lds(int Dp) {
+    return ((size_t)(kBwdRows + kBwdRunCap) * kBwdStride + 3 * (size_t)kBwdRows * Dp + 2 * kBwdRunCap + 64) *
+           sizeof(float);
+}
+
+__global__ __launch_bounds__(256) void lift_bwd_mfma_kernel(Dims dm, int Dp, const float* __restrict__ gacc,
+                                                            const float* __restrict__ feat,
+                                                            const float* __restrict__ prob,
+                                                            const int32_t* __restrict__ vox_pm,
+                                                            float* __restrict__ grad_feat,
+                                                            float* __restrict__ grad_logits) {
+    extern __shared__ float smem[];
+    float* fcol = smem;                                      // [32][66]  features of the column
+    float* ghat = fcol + kBwdRows * kBwdStride;              // [128][66] gradient row of each run
+    float* pcol = ghat + kBwdRunCap * kBwdStride;            // [32][Dp]  depth probabilities
+    float* tcol = pcol + kBwdRows * Dp;                      // [32][Dp]  dL/dprob
+    int* vcol = (int*)(tcol + kBwdRows * Dp);                // [32][Dp]  voxel ids
+    int* rdesc = vcol + kBwdRows * Dp;                       // [128] d | h0 << 8 | h1 << 16
+    int* rvox = rdesc + kBwdRunCap;                          // [128] voxel id of the run (-1: padding)
+    int* rcnt = rvox + kBwdRunCap;                           // [64]  runs per depth bin
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = blockIdx.x, bt = blockIdx.y;
+    const int n = col / dm.fW, w = col - n * dm.fW;
+    const size_t pix0 = (size_t)bt * dm.NPIX + (size_t)n * dm.fH * dm.fW + w;  // + h * fW
+
+    // ---- stage the column (rows >= fH and channels >= C are zero) ----
+#pragma unroll
+    for (int i = 0; i < kBwdRows / 4; ++i) {
+        const int h = wv + 4 * i;
+        const size_t gp = pix0 + (size_t)h * dm.fW;
+        const bool row = h < dm.fH;
+        fcol[h * kBwdStride + lane] = (row && lane < dm.C) ? feat[gp * dm.C + lane] : 0.f;
+        if (lane < Dp) {
+            const bool ok = row && lane < dm.D;
+            pcol[h * Dp + lane] = ok ? prob[gp * dm.D + lane] : 0.f;
+            vcol[h * Dp + lane] = ok ? vox_pm[gp * dm.D + lane] : -1;
+            tcol[h * Dp + lane] = 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- count the runs of every depth bin (thread = bin) ----
+    if (tid < 64) {
+        int cnt = 0;
+        if (tid < dm.D) {
+            int prev = -1;
+            for (int h = 0; h < dm.fH; ++h) {
+                const int v = vcol[h * Dp + tid];
+                cnt += (v >= 0 && v != prev) ? 1 : 0;
+                prev = v;
+            }
+        }
+        rcnt[tid] = cnt;
+    }
+    __syncthreads();
+    int my_off = 0, total = 0;
+    for (int d = 0; d < dm.D; ++d) {
+        const int c = rcnt[d];
+        my_off += (d < tid) ? c : 0;
+        total += c;
+    }
+
+    const int li = lane & 15, kk = lane >> 4;
+    f32x4 dacc[2];
+    dacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int base = 0; base < total; base += kBwdRunCap) {
+        const int rc = min(kBwdRunCap, total - base);
+        const int rc16 = (rc + 15) & ~15;
+        // ---- describe the runs of this chunk ----
+        if (tid < dm.D) {
+            int idx = my_off - base, prev = -1, h0 = 0;
+            for (int h = 0; h <= dm.fH; ++h) {
+                const int v = h < dm.fH ? vcol[h * Dp + tid] : -1;
+                if (v != prev) {
+                    if (prev >= 0) {
+                        if (idx >= 0 && idx < kBwdRunCap) {
+                            rdesc[idx] = tid | (h0 << 8) | (h << 16);
+                            rvox[idx] = prev;
+                        }
+                        ++idx;
+                    }
+                    h0 = h;
+                    prev = v;
+                }
+            }
+        }
+        for (int idx = rc + tid; idx < rc16; idx += 256) {
+            rdesc[idx] = 0;  // empty row range
+            rvox[idx] = -1;
+        }
+        __syncthreads();
+        // ---- Ghat: one gradient row per run, 8 rows in flight per wave ----
+        for (int r0 = wv * 8; r0 < rc16; r0 += 32) {
+            float g[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = r0 + j;
+                const int v = r < rc16 ? rvox[r] : -1;
+                g[j] = (v >= 0 && lane < dm.C) ? gacc[((size_t)bt * dm.V + v) * dm.C + lane] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (r0 + j < rc16) ghat[(r0 + j) * kBwdStride + lane] = g[j];
+        }
+        __syncthreads();
+        // ---- dfeat += Phat x Ghat (wave = 16-channel slice) ----
+        if (wv * 16 < dm.C) {
+            for (int k0 = 0; k0 < rc16; k0 += 4) {
+                const int r = k0 + kk;
+                const int desc = rdesc[r];
+                const int d = desc & 255, h0 = (desc >> 8) & 255, h1 = desc >> 16;
+                const float b = ghat[r * kBwdStride + wv * 16 + li];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int h = m * 16 + li;
+                    const float a = (h >= h0 && h < h1) ? pcol[h * Dp + d] : 0.f;
+                    dacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, dacc[m], 0, 0, 0);
+                }
+            }
+        }
+        // ---- dprob = feat x Ghat^T on the runs' row ranges (wave = every fourth 16-run tile) ----
+        for (int rt = wv; rt * 16 < rc16; rt += 4) {
+            f32x4 pacc[2];
+            pacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int k0 = 0; k0 < 64; k0 += 4) {
+                const float b = ghat[(rt * 16 + li) * kBwdStride + k0 + kk];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const float a = fcol[(m * 16 + li) * kBwdStride + k0 + kk];
+                    pacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, pacc[m], 0, 0, 0);
+                }
+            }
+            const int desc = rdesc[rt * 16 + li];
+            const int d = desc & 255, h0 = (desc >> 8) & 255, h1 = desc >> 16;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int h = m * 16 + kk * 4 + q;
+                    if (h >= h0 && h < h1) tcol[h * Dp + d] = pacc[m][q];
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- dfeat out: lane holds rows 4*kk + q of tile m, channel 16*wv + li ----
+    if (wv * 16 < dm.C) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int h = m * 16 + kk * 4 + q;
+                if (h < dm.fH) grad_feat[(pix0 + (size_t)h * dm.fW) * dm.C + wv * 16 + li] = dacc[m][q];
+            }
+    }
+    // ---- softmax backward per pixel: dlogit = p * (dprob - sum_d p * dprob) ----
+    for (int h = wv; h < dm.fH; h += 4) {
+        const bool bin = lane < dm.D;
+        const float pr = bin ? pcol[h * Dp + lane] : 0.f;
+        const float dp = bin ? tcol[h * Dp + lane] : 0.f;
+        const float sdot = wave_sum(pr * dp);
+        if (bin) grad_logits[(pix0 + (size_t)h * dm.fW) * dm.D + lane] = pr * (dp - sdot);
+    }
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -762,6 +949,20 @@ int stp3_lift_splat_bwd(const stp3_lift_dims* dims, const float* grad_bev, const
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bev_grad_accumulate_kernel, dim3((dm.V + kTileV - 1) / kTileV, dm.B), dim3(256), 0, s, dm,
                        grad_bev, discount, gacc);
+    // experimental matrix-core variant, opt-in (see lift_bwd_mfma_kernel)
+    static const bool want_mfma = [] {
+        const char* e = getenv("STP3_LIFT_BWD");
+        return e && !strcmp(e, "mfma");
+    }();
+    if (want_mfma && dm.fH <= kBwdRows && dm.C % 16 == 0 && dm.BT <= 65535) {
+        const int Dp = dm.D | 1;
+        const size_t lds = lift_bwd_mfma_lds(Dp);
+        if (lds <= 64 * 1024) {
+            hipLaunchKernelGGL(lift_bwd_mfma_kernel, dim3(dm.NCOL, dm.BT), dim3(256), lds, s, dm, Dp, gacc, feat, prob,
+                               vox_pm, grad_feat, grad_logits);
+            return launch_status();
+        }
+    }
     // enough waves to fill the chip: split the rows of a column when there are few columns
     const int64_t cols = (int64_t)dm.BT * dm.NCOL;
     int hsplit = (int)((8192 + cols - 1) / cols);
