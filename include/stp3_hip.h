@@ -307,6 +307,22 @@ int stp3_se_pool(const stp3_se_dims* dims, const void* x, const void* dy, void* 
                  float* out, void* stream);
 int stp3_se_scale(const stp3_se_dims* dims, const void* x, const float* gate, const float* add, void* y, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Stand-alone voxel summing (csrc/stp3_voxsum.hip): the operator-level twin of the reference's
+ * VoxelsSumming.forward / .backward (stp3/utils/geometry.py:302-318 / :320-330) for callers that hold the
+ * rank-sorted row matrix; the fused path above never builds it.
+ *   x        [M][channels] float32, rows sorted by voxel rank
+ *   seg_off  [n_segments + 1] int32, ascending, seg_off[0] = 0, seg_off[n_segments] = M: voxel s owns the rows
+ *            [seg_off[s], seg_off[s+1])  (the host derives it from ranks[1:] != ranks[:-1], geometry.py:308-309)
+ *   fwd: out [n_segments][channels] = per-voxel row sums, rows added in ascending order (deterministic; no
+ *        running sum over the whole matrix, so no cancellation against preceding voxels)
+ *   bwd: grad_x [M][channels], every row receives its voxel's grad_out row (geometry.py:326-328)
+ * n_segments == 0 is a no-op. */
+int stp3_voxels_sum_fwd(const float* x, const int32_t* seg_off, int32_t n_segments, int32_t channels, float* out,
+                        void* stream);
+int stp3_voxels_sum_bwd(const float* grad_out, const int32_t* seg_off, int32_t n_segments, int32_t channels,
+                        float* grad_x, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

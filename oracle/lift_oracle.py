@@ -275,6 +275,34 @@ def pool_backward_exact(grad_out, feat, depth_logits, vox, discount, dtype=torch
     return gfeat, glogit
 
 
+def voxels_summing(x, geometry, ranks):
+    """Operator-level restatement of the reference's ``VoxelsSumming.forward``
+    (stp3/utils/geometry.py:302-318) with exact per-voxel sums: rows of ``x`` (M,C), already sorted
+    by rank, are summed (float64) over every run of equal consecutive ``ranks``; ``geometry`` keeps
+    the LAST row of each run (the rows the reference's mask ``ranks[1:] != ranks[:-1]`` selects).
+    -> (x_sum (V',C) float64, geometry_kept (V',...), seg_off (V'+1,) int64)."""
+    x = np.asarray(x, dtype=np.float64)
+    ranks = np.asarray(ranks)
+    m = x.shape[0]
+    kept = np.ones(m, dtype=bool)
+    if m > 1:
+        kept[:-1] = ranks[1:] != ranks[:-1]                              # geometry.py:308-309
+    ends = np.nonzero(kept)[0]
+    seg_off = np.concatenate([[0], ends + 1]).astype(np.int64)
+    out = np.zeros((len(ends), x.shape[1]), dtype=np.float64)
+    for s in range(len(ends)):
+        out[s] = x[seg_off[s]:seg_off[s + 1]].sum(axis=0)
+    return out, np.asarray(geometry)[kept], seg_off
+
+
+def voxels_summing_backward(grad_x, seg_off):
+    """``VoxelsSumming.backward`` (geometry.py:320-330): every input row receives the gradient row
+    of the voxel it was summed into."""
+    grad_x = np.asarray(grad_x, dtype=np.float64)
+    seg_off = np.asarray(seg_off)
+    return np.repeat(grad_x, np.diff(seg_off), axis=0)
+
+
 def egomotion_planes(future_egomotion, receptive_field, bev_hw):
     """reference stp3.py:145-152: six broadcast ego-motion planes, shifted by one frame
     (frame 0 gets zeros, frame t gets future_egomotion[t-1]).  -> (B,S,6,X,Y)."""

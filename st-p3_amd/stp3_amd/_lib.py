@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'libstp3hip.so')
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
+c_int32 = ctypes.c_int32
 c_float = ctypes.c_float
 c_size_t = ctypes.c_size_t
 
@@ -106,6 +107,8 @@ SIGNATURES = {
     'stp3_conv2d_fwd_v2': (c_int, [ctypes.POINTER(ConvDims)] + [c_void_p] * 6 + [c_size_t, c_void_p]),
     'stp3_conv2d_wgrad_workspace': (c_int, [ctypes.POINTER(ConvDims), ctypes.POINTER(c_size_t)]),
     'stp3_conv2d_wgrad': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'stp3_voxels_sum_fwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    'stp3_voxels_sum_bwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -3,9 +3,12 @@
 Restates the pieces of ``stp3/utils/geometry.py`` the perception path needs: ``mat2pose_vec``
 (:97-121), ``euler2mat`` / ``pose_vec2mat`` (:124-172), ``invert_pose_matrix`` (:175-193),
 ``warp_features`` (:196-238) and the two cumulative warps (:241-296), which
-``TrainingModule.prepare_future_labels`` applies to the label maps (nearest sampling)."""
+``TrainingModule.prepare_future_labels`` applies to the label maps (nearest sampling).
+``VoxelsSumming`` (:299-330) is re-exported from ``stp3_amd.ops`` (HIP operator, GPU only)."""
 import torch
 import torch.nn.functional as F
+
+from .ops import VoxelsSumming  # noqa: F401  (same import path as the reference: stp3.utils.geometry)
 
 
 def euler2mat(angle):

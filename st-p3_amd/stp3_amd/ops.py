@@ -309,6 +309,51 @@ def lift_splat(feat, depth_logits, lift_plan, discount):
 
 
 # ----------------------------------------------------------------------------------------------
+# stand-alone voxel summing (compatibility with the reference's operator boundary)
+# ----------------------------------------------------------------------------------------------
+class VoxelsSumming(torch.autograd.Function):
+    """Drop-in for the reference's ``VoxelsSumming`` (stp3/utils/geometry.py:299-330).
+
+    ``VoxelsSumming.apply(x (M,C) float32 sorted by rank, geometry (M,3), ranks (M,)) ->
+    (x_sum (V',C), geometry_kept (V',3))``: one output row per distinct consecutive rank, the
+    geometry of the LAST point of each voxel (the rows the reference's boolean mask keeps,
+    geometry.py:308-311).  The model itself uses the fused ``lift_splat``; this operator is for
+    callers that hold the sorted point matrix.  Like the reference's boolean indexing, deriving
+    the number of voxels synchronises with the host once."""
+
+    @staticmethod
+    def forward(ctx, x, geometry, ranks):
+        _need_gpu(x, geometry, ranks)
+        if x.dim() != 2 or ranks.dim() != 1 or ranks.shape[0] != x.shape[0] or geometry.shape[0] != x.shape[0]:
+            raise _lib.Stp3HipError('VoxelsSumming expects x (M,C), geometry (M,...), ranks (M,)')
+        m, c = x.shape
+        xf = x.contiguous().float()
+        kept = torch.ones(m, dtype=torch.bool, device=x.device)
+        if m > 1:
+            kept[:-1] = ranks[1:] != ranks[:-1]
+        ends = kept.nonzero().flatten()                         # last row of every voxel (host sync)
+        seg_off = torch.zeros(ends.numel() + 1, dtype=torch.int32, device=x.device)
+        seg_off[1:] = ends + 1
+        out = torch.empty(ends.numel(), c, dtype=torch.float32, device=x.device)
+        check(_lib.lib().stp3_voxels_sum_fwd(_ptr(xf), _ptr(seg_off), int(ends.numel()), int(c), _ptr(out), _stream()),
+              'stp3_voxels_sum_fwd')
+        geometry_kept = geometry[kept]
+        ctx.save_for_backward(seg_off)
+        ctx.rows, ctx.x_dtype = m, x.dtype
+        ctx.mark_non_differentiable(geometry_kept)
+        return out.to(x.dtype), geometry_kept
+
+    @staticmethod
+    def backward(ctx, grad_x, grad_geometry):
+        (seg_off,) = ctx.saved_tensors
+        g = grad_x.contiguous().float()
+        out = torch.empty(ctx.rows, g.shape[1], dtype=torch.float32, device=g.device)
+        check(_lib.lib().stp3_voxels_sum_bwd(_ptr(g), _ptr(seg_off), int(seg_off.numel() - 1), int(g.shape[1]),
+                                             _ptr(out), _stream()), 'stp3_voxels_sum_bwd')
+        return out.to(ctx.x_dtype), None, None
+
+
+# ----------------------------------------------------------------------------------------------
 # depthwise convolution (EfficientNet MBConv blocks)
 # ----------------------------------------------------------------------------------------------
 def _dw_dims(x, k, stride, pad_top, pad_left, ho, wo):

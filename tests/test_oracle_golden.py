@@ -63,3 +63,22 @@ def test_truncation_not_floor():
     assert v[3] == -1
     nan = np.array([[[np.nan, 0.0, 0.0]], [[np.inf, 0.0, 0.0]]], dtype=np.float32)
     assert (lo.voxel_index(nan, lo.bev_offset(start, res), res.numpy(), dim.tolist()) == -1).all()
+
+
+CASES_VOXSUM = ('ragged', 'singles', 'onevoxel', 'onerow')
+
+
+def test_voxels_summing_operator_against_reference_golden():
+    """oracle.voxels_summing == the reference's VoxelsSumming evaluated in float64
+    (oracle/make_golden_voxsum.py), forward, kept geometry rows and backward."""
+    g = H.load('voxsum.npz')
+    for name in CASES_VOXSUM:
+        out, geom, seg_off = lo.voxels_summing(g[f'{name}_x'], g[f'{name}_geometry'], g[f'{name}_ranks'])
+        np.testing.assert_allclose(out, g[f'{name}_sum64'], rtol=0, atol=1e-10)
+        assert np.array_equal(geom, g[f'{name}_geomkept'])
+        gx = lo.voxels_summing_backward(g[f'{name}_grad'], seg_off)
+        assert np.array_equal(gx, g[f'{name}_gradx64'].astype(np.float64))
+        # the reference at its working precision differs from the exact sums by its own rounding only
+        assert np.abs(g[f'{name}_sum32'] - out).max() < 1e-4
+    out, geom, seg_off = lo.voxels_summing(np.zeros((0, 4)), np.zeros((0, 3)), np.zeros((0,), dtype=np.int64))
+    assert out.shape == (0, 4) and geom.shape == (0, 3) and seg_off.tolist() == [0]
