@@ -12,6 +12,7 @@
 #include <torch/extension.h>
 #include <ATen/ATen.h>
 #include <c10/hip/HIPStream.h>
+#include <cstdlib>
 #include <dlfcn.h>
 
 #include <string>
@@ -53,10 +54,14 @@ inline void check(int rc, const char* what) {
     TORCH_CHECK(rc == 0, what, " failed: ", rc == STP3_EINVAL ? "STP3_EINVAL" : rc == STP3_EUNSUP ? "STP3_EUNSUP"
                                           : rc == STP3_ENOSPACE ? "STP3_ENOSPACE" : "hipError ", rc);
 }
-inline void* stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
+// STP3_HOST_DRYRUN (scripts/host_overhead.py only): measure the host cost of this launch path on a machine
+// without a GPU against a library whose entry points do nothing -- CPU tensors accepted, null stream.
+const bool g_dryrun = getenv("STP3_HOST_DRYRUN") != nullptr;
+inline void* stream() { return g_dryrun ? nullptr : (void*)c10::hip::getCurrentHIPStream().stream(); }
 inline void need_gpu(const Tensor& t) {
     TORCH_CHECK(g_ready, "stp3_host.init(path to libstp3hip.so) has not been called");
-    TORCH_CHECK(t.is_cuda(), "stp3_amd operators run on the GPU only (got a CPU tensor); there is no fallback");
+    TORCH_CHECK(t.is_cuda() || g_dryrun,
+                "stp3_amd operators run on the GPU only (got a CPU tensor); there is no fallback");
 }
 inline const void* ptr(const Tensor& t) { return t.defined() ? t.data_ptr() : nullptr; }
 inline const float* fptr(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
@@ -120,6 +125,12 @@ struct BnActFn : public torch::autograd::Function<BnActFn> {
                           int64_t res_mode) {
         Tensor weight = opt(weight_), bias = opt(bias_), res = opt(res_), sbias = opt(sbias_), oscale = opt(oscale_);
         Tensor running_mean = opt(running_mean_), running_var = opt(running_var_);
+        {   // autograd numbers its edges over the tensor arguments that are PRESENT, not over argument positions
+            int64_t e = 1;
+            std::vector<int64_t> edge{0, weight.defined() ? e++ : -1, bias.defined() ? e++ : -1, res.defined() ? e++ : -1,
+                                      sbias.defined() ? e++ : -1};
+            ctx->saved_data["edge"] = edge;
+        }
         need_gpu(x);
         const int dt = dtype_code(x);
         const int64_t n = x.size(0), c = x.size(1), h = x.size(2), w = x.size(3);
@@ -184,7 +195,9 @@ struct BnActFn : public torch::autograd::Function<BnActFn> {
         Tensor dx = x.is_contiguous(at::MemoryFormat::ChannelsLast) ? at::empty_like(x)
                                                                     : at::empty_strided(x.sizes(), x.strides(), x.options());
         Tensor dres;
-        const bool want_res = ctx->needs_input_grad(3);
+        auto edge = ctx->saved_data["edge"].toIntVector();
+        auto wants = [&](int arg) { return edge[arg] >= 0 && ctx->needs_input_grad((size_t)edge[arg]); };
+        const bool want_res = wants(3);
         if (d.res_mode == STP3_RES_BEFORE_ACT && want_res) dres = empty_cl(n, c, x.size(2), x.size(3), x.options());
         if (training && (!dres.defined() || d.ldr == c)) {
             check(api.stp3_bn_bwd_train(&d, dy.data_ptr(), x.data_ptr(), fptr(sb), ptr(res), fptr(osc), mean_p, invstd_p,
@@ -203,19 +216,19 @@ struct BnActFn : public torch::autograd::Function<BnActFn> {
             }
             check(api.stp3_bn_apply_bwd(&bd, dy.data_ptr(), x.data_ptr(), fptr(sb), ptr(res), fptr(osc), mean_p, invstd_p,
                                         fptr(gamma), fptr(beta), training ? sumbuf.data_ptr<float>() + sums_off : nullptr,
-                                        (double)std::max<int64_t>(n * rows, 1), dx.data_ptr(),
+                                        training ? (double)std::max<int64_t>(n * rows, 1) : 1.0, dx.data_ptr(),
                                         dres.defined() ? dres.data_ptr() : nullptr, stream()),
                   "stp3_bn_apply_bwd");
         }
         Tensor sums = sumbuf.narrow(0, sums_off, 3 * c).view({3, c});
         Tensor dgamma, dbeta, dsbias;
         const int64_t wdt = ctx->saved_data["w_dtype"].toInt(), bdt = ctx->saved_data["b_dtype"].toInt();
-        if (wdt >= 0 && ctx->needs_input_grad(1)) dgamma = sums[1].to((at::ScalarType)wdt);
-        if (bdt >= 0 && ctx->needs_input_grad(2)) dbeta = sums[0].to((at::ScalarType)bdt);
+        if (wdt >= 0 && wants(1)) dgamma = sums[1].to((at::ScalarType)wdt);
+        if (bdt >= 0 && wants(2)) dbeta = sums[0].to((at::ScalarType)bdt);
         if (d.res_mode == STP3_RES_AFTER_ACT && want_res) dres = dy;
         const int64_t rdt = ctx->saved_data["res_dtype"].toInt();
         if (dres.defined() && rdt >= 0 && (int64_t)dres.scalar_type() != rdt) dres = dres.to((at::ScalarType)rdt);
-        if (sb.defined() && ctx->needs_input_grad(4)) {
+        if (sb.defined() && wants(4)) {
             Tensor invstd = stat.narrow(0, 3 * c, c);
             Tensor sample = sumbuf.narrow(0, 0, sums_off).view({n, 3, c});
             Tensor g = gamma.defined() ? gamma * invstd : invstd;
