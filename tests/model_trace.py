@@ -1,0 +1,70 @@
+"""CPU test infrastructure: dry run of ONE TRAINING STEP through the GPU code path, without a GPU.
+
+Driver for tests/test_model_dryrun_cpu.py.  It loads the recording stand-in for libstp3hip.so (tests/host_trace.py),
+makes every tensor claim ``is_cuda`` and autocast claim to be on (the real autocast runs for the CPU type, so the
+torch operators between the custom ones see the dtypes they would see on the GPU), and runs
+``TrainingModule.training_step`` + backward of a small configuration.  The custom kernels do nothing, so values
+are meaningless -- what the run establishes is that the host code of the selected path (default or the
+experimental switches given in the environment) executes end to end, and which C-ABI calls it makes.
+
+    STP3_TRACE_LOG=... STP3_REAL_LIB=.../libstp3hip.so [STP3_CONV_V2=1 ...] python tests/model_trace.py recorder.so
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def drive(recorder):
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'st-p3_amd'))
+    from stp3_amd import _lib
+    _lib.LIB_PATH = recorder
+    from stp3_amd import ops
+    ops._need_gpu = lambda *a: None
+    ops._stream = lambda: None
+    ops._stream_handle = lambda: 0
+    torch.Tensor.is_cuda = property(lambda self: True)
+    torch.is_autocast_enabled = lambda *a: True
+    torch.get_autocast_gpu_dtype = lambda: torch.bfloat16
+    torch.set_num_threads(4)
+    # uninitialised memory (what the do-nothing kernels leave in their outputs) becomes a fixed NaN / max-int
+    # pattern, so the buffer checksums in the trace are reproducible from run to run and from path to path
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    torch.utils.deterministic.fill_uninitialized_memory = True
+
+    from stp3_amd import synthetic
+    from stp3_amd.config import perception_cfg
+    from stp3_amd.trainer import TrainingModule
+    from stp3_amd.utils import to_channels_last
+
+    log = open(os.environ['STP3_TRACE_LOG'], 'a')
+
+    def mark(text):
+        log.write(f'# {text}\n')
+        log.flush()
+
+    final_dim = (64, 96)
+    torch.manual_seed(1234)
+    cfg = perception_cfg(**{'IMAGE.FINAL_DIM': final_dim, 'LIFT.X_BOUND': [-16.0, 16.0, 0.5],
+                            'LIFT.Y_BOUND': [-16.0, 16.0, 0.5]})
+    module = to_channels_last(TrainingModule(cfg.convert_to_dict()))
+    module.train()
+    batch = synthetic.make_batch(batch=2, seq=3, final_dim=final_dim, bev=(64, 64), seed=0)
+    model = module.model
+    mark('plan')
+    model.prepare_plan(batch['intrinsics'], batch['extrinsics'], batch['future_egomotion'], torch.device('cpu'))
+    mark('forward')
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        loss = module.training_step(batch)
+    mark(f'backward loss={tuple(loss.shape)}/{loss.dtype}')
+    loss.backward()
+    missing = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
+    mark(f'parameters without gradient: {missing}')
+    shapes_ok = all(p.grad.shape == p.shape for p in model.parameters() if p.grad is not None)
+    mark(f'gradient shapes ok: {shapes_ok}')
+    mark('end')
+
+
+if __name__ == '__main__':
+    drive(sys.argv[1])
