@@ -308,6 +308,27 @@ int stp3_se_pool(const stp3_se_dims* dims, const void* x, const void* dy, void* 
 int stp3_se_scale(const stp3_se_dims* dims, const void* x, const float* gate, const float* add, void* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * bf16 shadow copies of all convolution weights in ONE launch (csrc/stp3_wprep.hip; EXPERIMENTAL, host side
+ * selected with STP3_WEIGHT_PREP=1).  Replaces the per-layer cast / flip / transpose / re-layout the host would
+ * otherwise redo after every optimizer step for the operands of stp3_conv2d_fwd (forward: [Cout][KH][KW][Cin];
+ * data gradient: [Cin][KH][KW][Cout] with the taps flipped).
+ *   table : n_entries structs in DEVICE memory, sorted by first_block
+ *   src   : fp32 master weight, element (co, ci, r, s) at src[co*stride_co + ci*stride_ci + r*stride_kh + s*stride_kw]
+ *   fwd / flip : bf16 destinations (either may be NULL)
+ *   first_block : exclusive scan over the table of ceil(cout*cin*kh*kw / 256); total_blocks = the scan's total
+ * Rounding: to nearest even, as torch's .to(bfloat16). */
+typedef struct stp3_wprep_entry {
+    const float* src;
+    void* fwd;
+    void* flip;
+    int64_t stride_co, stride_ci, stride_kh, stride_kw;
+    int64_t first_block;
+    int32_t cout, cin, kh, kw;
+} stp3_wprep_entry;
+
+int stp3_conv2d_prep_weights(const stp3_wprep_entry* table, int32_t n_entries, int64_t total_blocks, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Stand-alone voxel summing (csrc/stp3_voxsum.hip): the operator-level twin of the reference's
  * VoxelsSumming.forward / .backward (stp3/utils/geometry.py:302-318 / :320-330) for callers that hold the
  * rank-sorted row matrix; the fused path above never builds it.

@@ -61,6 +61,14 @@ class SeDims(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in ('N', 'rows', 'C', 'ld', 'dtype')]
 
 
+class WprepEntry(ctypes.Structure):
+    """struct stp3_wprep_entry (include/stp3_hip.h)."""
+    _fields_ = [('src', ctypes.c_void_p), ('fwd', ctypes.c_void_p), ('flip', ctypes.c_void_p),
+                ('stride_co', ctypes.c_int64), ('stride_ci', ctypes.c_int64), ('stride_kh', ctypes.c_int64),
+                ('stride_kw', ctypes.c_int64), ('first_block', ctypes.c_int64),
+                ('cout', ctypes.c_int32), ('cin', ctypes.c_int32), ('kh', ctypes.c_int32), ('kw', ctypes.c_int32)]
+
+
 DTYPE_F32 = 0
 DTYPE_BF16 = 1
 
@@ -107,6 +115,7 @@ SIGNATURES = {
     'stp3_conv2d_fwd_v2': (c_int, [ctypes.POINTER(ConvDims)] + [c_void_p] * 6 + [c_size_t, c_void_p]),
     'stp3_conv2d_wgrad_workspace': (c_int, [ctypes.POINTER(ConvDims), ctypes.POINTER(c_size_t)]),
     'stp3_conv2d_wgrad': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'stp3_conv2d_prep_weights': (c_int, [c_void_p, c_int32, ctypes.c_int64, c_void_p]),
     'stp3_voxels_sum_fwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     'stp3_voxels_sum_bwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
 }

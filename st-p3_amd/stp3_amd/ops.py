@@ -701,15 +701,88 @@ _WEIGHT_EPOCH = [0]
 WEIGHT_CACHE_ENABLED = True          # graph.GraphedTrainStep turns it off: the casts must be part of every replay
 
 
+# EXPERIMENTAL (STP3_WEIGHT_PREP=1): the bf16 copies become persistent SHADOW buffers that one launch of
+# stp3_conv2d_prep_weights rewrites for all layers after an optimizer step, instead of ~5 torch operators per layer.
+_WEIGHT_PREP = os.environ.get('STP3_WEIGHT_PREP', '0') == '1'
+
+
+class _WeightShadows:
+    def __init__(self):
+        self.entries = {}            # id(parameter) -> entry
+        self.order = []
+        self.table = None            # stp3_wprep_entry[n] in device memory
+        self.total_blocks = 0
+
+    def lookup(self, weight):
+        ent = self.entries.get(id(weight))
+        if ent is None or ent['ref']() is not weight or ent['ptr'] != weight.data_ptr():
+            return None
+        if ent['version'] != weight._version:          # updated in place behind our back (a torch optimizer)
+            self.refresh()
+        return ent
+
+    def register(self, weight):
+        import weakref
+        cout, cin, kh, kw = weight.shape
+        opts = dict(dtype=torch.bfloat16, device=weight.device, memory_format=torch.channels_last)
+        ent = {'ref': weakref.ref(weight), 'ptr': weight.data_ptr(), 'version': weight._version,
+               'wb': torch.empty((cout, cin, kh, kw), **opts),         # memory [Cout][KH][KW][Cin]
+               'wt': torch.empty((cin, cout, kh, kw), **opts)}         # memory [Cin][KH][KW][Cout], taps flipped
+        self.entries[id(weight)] = ent
+        self.order = [e for e in self.order if e['ref']() is not None and e is not ent] + [ent]
+        self._build_table(weight.device)
+        self.refresh()
+        return ent
+
+    def _build_table(self, device):
+        arr = (_lib.WprepEntry * len(self.order))()
+        block = 0
+        for rec, e in zip(arr, self.order):
+            w = e['ref']()
+            cout, cin, kh, kw = w.shape
+            rec.src, rec.fwd, rec.flip = w.data_ptr(), e['wb'].data_ptr(), e['wt'].data_ptr()
+            rec.stride_co, rec.stride_ci, rec.stride_kh, rec.stride_kw = w.stride()
+            rec.first_block = block
+            rec.cout, rec.cin, rec.kh, rec.kw = cout, cin, kh, kw
+            block += (w.numel() + 255) // 256
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.table = host.to(device)
+        self.total_blocks = block
+
+    def refresh(self):
+        """Rewrite every shadow from its fp32 master: one launch."""
+        if not self.order:
+            return
+        if any(e['ref']() is None or e['ref']().data_ptr() != e['ptr'] for e in self.order):
+            self.order = [e for e in self.order if e['ref']() is not None and e['ref']().data_ptr() == e['ptr']]
+            self.entries = {id(e['ref']()): e for e in self.order}
+            if not self.order:
+                return
+            self._build_table(self.table.device)
+        check(_lib.lib().stp3_conv2d_prep_weights(_ptr(self.table), len(self.order), self.total_blocks, _stream()),
+              'stp3_conv2d_prep_weights')
+        for e in self.order:
+            e['version'] = e['ref']()._version
+
+
+_SHADOWS = _WeightShadows()
+
+
 def invalidate_weight_cache():
     """Call after updating parameters through storage the parameter's version counter does not see (the flat
     buffers of ``parallel.FlatAdam``); in-place updates of the parameters themselves are detected automatically."""
     _WEIGHT_EPOCH[0] += 1
     if _CPP is not None:
         _CPP.invalidate_weight_cache()
+    if _WEIGHT_PREP and WEIGHT_CACHE_ENABLED:
+        _SHADOWS.refresh()
 
 
 def _bf16_weights(weight, need_flipped=False):
+    if _WEIGHT_PREP and WEIGHT_CACHE_ENABLED and weight.is_leaf and weight.requires_grad \
+            and weight.dtype == torch.float32:
+        ent = _SHADOWS.lookup(weight) or _SHADOWS.register(weight)
+        return ent['wb'], ent['wt']
     key = id(weight)
     ent = _WEIGHT_CACHE.get(key) if WEIGHT_CACHE_ENABLED else None
     ver = (weight._version, _WEIGHT_EPOCH[0])

@@ -48,7 +48,17 @@ def convert_sync_batchnorm(module, process_group=None):
 
 
 class GradientBuckets:
-    def __init__(self, module, bucket_bytes=8 << 20, process_group=None, average=True):
+    """Flat fp32 parameter / gradient buckets in backward order, all-reduced while backward continues.
+
+    ``gather=False`` (default): every ``p.grad`` IS a view of its bucket, autograd accumulates into it in place (one
+    small ``add_`` per parameter per step, ~480 launches for this model).
+    ``gather=True`` (``STP3_GRAD_GATHER=1``): ``p.grad`` is reset to ``None`` before backward so autograd keeps
+    the incoming gradient tensors as they are, and a finished bucket is filled with one multi-tensor copy; the
+    values are identical (``0 + g`` vs ``g``), the per-parameter launches are gone.  Experimental: switch it on
+    after an A/B on the MI355X."""
+
+    def __init__(self, module, bucket_bytes=8 << 20, process_group=None, average=True, gather=None):
+        self.gather = (os.environ.get('STP3_GRAD_GATHER', '0') == '1') if gather is None else bool(gather)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
@@ -56,6 +66,7 @@ class GradientBuckets:
         self.params = params[::-1]                       # backward order
         self.buckets = []                                # (flat gradient, [params])
         self.flat_params = []                            # flat parameter buffer per bucket
+        self.grad_views = []                             # per bucket: the gradient view of every parameter
         self._bucket_of = {}
         cur, cur_bytes = [], 0
         for p in self.params:
@@ -68,6 +79,7 @@ class GradientBuckets:
         if cur:
             self._close(cur)
         self._pending = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
         self._works = []
         self._hooks = []
         if self.world > 1:
@@ -80,6 +92,7 @@ class GradientBuckets:
         flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
         flat_param = torch.empty(n, dtype=params[0].dtype, device=params[0].device)
         off = 0
+        views = []
         with torch.no_grad():
             for p in params:
                 # Parameters AND gradients become views into the bucket's flat buffers, with the parameter's
@@ -90,9 +103,11 @@ class GradientBuckets:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = torch.as_strided(flat, size, stride, off)
+                views.append(p.grad)
                 off += p.numel()
                 self._bucket_of[p] = len(self.buckets)
         self.buckets.append((flat, list(params)))
+        self.grad_views.append(views)
         self.flat_params.append(flat_param)
 
     def broadcast_parameters(self, module):
@@ -101,20 +116,50 @@ class GradientBuckets:
                 dist.broadcast(t.data, src=0, group=self.group)
 
     def zero_grad(self):
-        for flat, _ in self.buckets:
-            flat.zero_()
+        if self.gather:
+            for p in self.params:
+                p.grad = None
+        else:
+            for flat, _ in self.buckets:
+                flat.zero_()
         self._pending = [len(ps) for _, ps in self.buckets]
+        self._launched = [False] * len(self.buckets)
         self._works = []
+
+    @torch.no_grad()
+    def _gather(self, i):
+        """gather mode: move the gradients autograd left on the parameters of bucket ``i`` into its flat buffer
+        (one multi-tensor copy) and point every ``p.grad`` back at its view."""
+        flat, params = self.buckets[i]
+        views = self.grad_views[i]
+        have = [(v, p.grad) for v, p in zip(views, params) if p.grad is not None and p.grad is not v]
+        if len(have) < len(params):
+            flat.zero_()                                 # parameters that took no part in this step
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v, p in zip(views, params):
+            p.grad = v
+
+    def _launch(self, i):
+        self._launched[i] = True
+        if self.gather:
+            self._gather(i)
+        if self.world > 1:
+            flat = self.buckets[i][0]
+            self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _on_grad(self, p):
         i = self._bucket_of[p]
         self._pending[i] -= 1
         if self._pending[i] == 0:
-            flat = self.buckets[i][0]
-            self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._launch(i)
 
     def finish(self):
-        """Wait for the in-flight all-reduces (call after ``backward``); averages over ranks."""
+        """Call after ``backward``: completes buckets that were not launched from the hooks (single process, or
+        parameters that received no gradient), waits for the in-flight all-reduces and averages over ranks."""
+        for i in range(len(self.buckets)):
+            if not self._launched[i] and (self.gather or self.world > 1):
+                self._launch(i)
         if self.world == 1:
             return
         for w in self._works:

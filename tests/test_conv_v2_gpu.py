@@ -131,3 +131,41 @@ def test_fused_project_conv_with_drop_connect_and_skip():
     torch.testing.assert_close(sa.grad.float(), sb.grad.float(), rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(conv_a.weight.grad, conv_b.weight.grad, rtol=2e-2, atol=2e-2 * float(conv_b.weight.grad.abs().max()))
     torch.testing.assert_close(bn_a.weight.grad, bn_b.weight.grad, rtol=2e-2, atol=5e-2)
+
+
+def test_weight_shadows_match_the_torch_built_copies():
+    """stp3_conv2d_prep_weights (STP3_WEIGHT_PREP): one launch rewrites the bf16 forward / flipped copies of all
+    registered weights; bit-identical with the per-layer torch operators of the default path."""
+    from stp3_amd import ops
+    torch.manual_seed(0)
+    shapes = [(64, 64, 3, 3), (144, 24, 1, 1), (35, 70, 3, 3), (64, 64, 7, 7), (2, 64, 1, 1), (160, 160, 3, 3)]
+    weights = []
+    for k, shp in enumerate(shapes):
+        w = torch.randn(*shp, device='cuda')
+        if k % 2 == 0:
+            w = w.contiguous(memory_format=torch.channels_last)
+        weights.append(nn.Parameter(w))
+    sh = ops._WeightShadows()
+    for w in weights:
+        sh.register(w)
+
+    def check():
+        for w in weights:
+            ent = sh.lookup(w)
+            ref_b = w.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            ref_t = ref_b.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+            assert torch.equal(ent['wb'], ref_b) and torch.equal(ent['wt'], ref_t)
+            assert ent['wb'].permute(0, 2, 3, 1).is_contiguous() and ent['wt'].permute(0, 2, 3, 1).is_contiguous()
+
+    check()
+    with torch.no_grad():
+        for w in weights:
+            w.data.mul_(-0.37)
+    sh.refresh()
+    check()
+    # and a convolution fed from the shadows equals one fed from the torch-built copies
+    x = torch.randn(2, 64, 20, 28, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ent = sh.lookup(weights[0])
+    y_shadow = ops._conv2d_launch(x, ent['wb'], None, 1, (1, 1), (1, 1), torch.bfloat16)
+    ref_b = weights[0].detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert torch.equal(y_shadow, ops._conv2d_launch(x, ref_b, None, 1, (1, 1), (1, 1), torch.bfloat16))

@@ -2,6 +2,7 @@
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -54,12 +55,53 @@ def test_clip_grad_norm_matches_torch():
         torch.testing.assert_close(pb.grad, pa.grad, rtol=1e-5, atol=1e-7)
 
 
-def _worker(rank, world, port, out):
+class _WithUnusedParameter(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.used = _toy()
+        self.unused = nn.Linear(3, 3)               # never part of the graph: its gradient has to stay zero
+
+    def forward(self, x):
+        return self.used(x)
+
+
+def test_gather_mode_equals_view_mode_bitwise():
+    """STP3_GRAD_GATHER: gradients collected with one multi-tensor copy per bucket == accumulated in place."""
+    torch.manual_seed(11)
+    a, b = _WithUnusedParameter(), _WithUnusedParameter()
+    b.load_state_dict(a.state_dict())
+    a.used[0].weight.data = a.used[0].weight.data.contiguous(memory_format=torch.channels_last)
+    b.used[0].weight.data = b.used[0].weight.data.contiguous(memory_format=torch.channels_last)
+    ba, bb = GradientBuckets(a, bucket_bytes=1024, gather=False), GradientBuckets(b, bucket_bytes=1024, gather=True)
+    assert len(bb.buckets) > 2
+    oa, ob = FlatAdam(ba, lr=1e-2, weight_decay=1e-3), FlatAdam(bb, lr=1e-2, weight_decay=1e-3)
+    g = torch.Generator().manual_seed(1)
+    for it in range(4):
+        x = torch.randn(6, 3, 6, 6, generator=g)
+        for model, buckets, opt in ((a, ba, oa), (b, bb, ob)):
+            buckets.zero_grad()
+            loss = model(x).square().mean()
+            if it == 2:                                # a parameter used twice in one graph still accumulates
+                loss = loss + model(x * 0.5).abs().mean()
+            loss.backward()
+            buckets.finish()
+            buckets.clip_grad_norm_(0.5)
+            opt.step()
+        for (fa, _), (fb, _) in zip(ba.buckets, bb.buckets):
+            assert torch.equal(fa, fb)
+        for p, views in ((p, v) for bucket, vs in zip(bb.buckets, bb.grad_views) for p, v in zip(bucket[1], vs)):
+            assert p.grad is views                     # every .grad points into its flat bucket again
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)
+    assert torch.count_nonzero(b.unused.weight.grad) == 0
+
+
+def _worker(rank, world, port, out, gather=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.manual_seed(100 + rank)                      # different initial weights: broadcast must fix that
     model = nn.Sequential(nn.Linear(6, 16), nn.ReLU(), nn.Linear(16, 3))
-    buckets = GradientBuckets(model, bucket_bytes=256)
+    buckets = GradientBuckets(model, bucket_bytes=256, gather=gather)
     opt = FlatAdam(buckets, lr=1e-2)
     g = torch.Generator().manual_seed(7)
     data = torch.randn(8, 6, generator=g)
@@ -75,13 +117,14 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process_on_the_concatenated_batch():
+@pytest.mark.parametrize('gather', [False, True])
+def test_two_ranks_equal_one_process_on_the_concatenated_batch(gather):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, gather), nprocs=2, join=True)
     torch.testing.assert_close(out[0], out[1], rtol=0, atol=0)         # replicas stay identical
     # single process, full batch, same initial weights as rank 0
     torch.manual_seed(100)
