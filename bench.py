@@ -5,8 +5,12 @@
 
 One "step" = one full training pass of the hot path over one batch of synthetic input that is
 already resident in HBM: 6 cameras x 224x480 x T=3 frames, B=4 samples per GPU (BASELINE.json
-configs[2]: forward + backward with the Perception.yml losses, gradient clip, Adam step) --
-EfficientNet-B4 encoder -> HIP lift / voxel pool -> temporal model -> BEV decoder.  Multi-GPU is
+configs[2]: forward + backward with the segmentation + pedestrian + HD-map losses of Perception.yml PLUS the
+depth cross-entropy (LIFT.GT_DEPTH) and the instance centerness / offset / flow regression losses
+(INSTANCE_SEG / INSTANCE_FLOW) -- SURVEY.md section 8d "c3" --, gradient clip, Adam step) --
+EfficientNet-B4 encoder -> HIP lift / voxel pool -> temporal model -> BEV decoder with all heads.
+`--workload perception` times the plain Perception.yml step (train_perceive.sh: no depth / instance / flow
+branches), the configuration the round-1 profiles under profiles/ were taken with.  Multi-GPU is
 weak scaling: every rank gets its own B=4 (global batch 4N), gradients are all-reduced over RCCL
 and BatchNorm statistics are synchronised (the reference's DDP + sync_batchnorm recipe).
 
@@ -36,15 +40,39 @@ for _p in (ROOT, os.path.join(ROOT, 'st-p3_amd')):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+# Test hook (tests/test_bench_dryrun_cpu.py): run this script's control flow on the CPU against a do-nothing stand-in
+# for libstp3hip.so.  Never set outside that test: the numbers it prints are meaningless.
+DRYRUN = os.environ.get('STP3_BENCH_DRYRUN') == '1'
+DEV_TYPE = 'cpu' if DRYRUN else 'cuda'
+
+
+def _sync():
+    if not DRYRUN:
+        torch.cuda.synchronize()
+
+
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def build_module(device, sync_bn):
+# BASELINE.json configs[2] = Perception.yml + these three switches (Perception.yml itself leaves them off,
+# stp3/configs/carla/Perception.yml:17-39)
+FULL_LOSSES = {'LIFT.GT_DEPTH': True, 'INSTANCE_SEG.ENABLED': True, 'INSTANCE_FLOW.ENABLED': True}
+WORKLOADS = {
+    'c3': 'BASELINE configs[2]: batch=4/GPU, 6-cam 224x480, T=3, full STP3 fwd+bwd with segmentation + pedestrian + '
+          'hdmap + depth CE + instance centerness/offset + flow losses, grad-clip 5, Adam; EfficientNet-B4, D=48, '
+          'C=64, BEV 200x200',
+    'perception': 'Perception.yml (train_perceive.sh = BASELINE configs[3] per-GPU shard): batch=4/GPU, 6-cam 224x480, '
+                  'T=3, full STP3 fwd+bwd (seg+ped+hdmap losses; no depth / instance / flow branches), grad-clip 5, '
+                  'Adam; EfficientNet-B4, D=48, C=64, BEV 200x200',
+}
+
+
+def build_module(device, sync_bn, workload='c3'):
     from stp3_amd.config import perception_cfg
     from stp3_amd.trainer import TrainingModule
     from stp3_amd.utils import to_channels_last
     torch.manual_seed(1234)
-    cfg = perception_cfg()
+    cfg = perception_cfg(**(FULL_LOSSES if workload == 'c3' else {}))
     module = TrainingModule(cfg.convert_to_dict())
     if sync_bn:
         from stp3_amd.parallel import convert_sync_batchnorm
@@ -54,9 +82,10 @@ def build_module(device, sync_bn):
     return module, cfg
 
 
-def make_device_batch(batch_size, device, seed):
+def make_device_batch(batch_size, device, seed, workload='c3'):
     from stp3_amd import synthetic
-    batch = synthetic.make_batch(batch=batch_size, seq=3, seed=seed)
+    full = workload == 'c3'
+    batch = synthetic.make_batch(batch=batch_size, seq=3, seed=seed, gt_depth=full, instance=full)
     out = {}
     for k, v in batch.items():
         if not torch.is_tensor(v):
@@ -72,7 +101,7 @@ def make_device_batch(batch_size, device, seed):
 CPU_BASELINE_THREADS = 16      # the CPU port scales badly past ~16 threads (256 threads: 724 s per step on the GPU box)
 
 
-def _cpu_baseline_worker():
+def _cpu_baseline_worker(workload='c3'):
     """One B=1 training step of the CPU port (reference lift algorithm) on CPU_BASELINE_THREADS host threads."""
     from oracle.cpu_model import CpuPortSTP3
     from stp3_amd import synthetic
@@ -82,15 +111,18 @@ def _cpu_baseline_worker():
     threads = min(cores, CPU_BASELINE_THREADS)
     torch.set_num_threads(threads)
     torch.manual_seed(1234)
-    cfg = perception_cfg()
+    full = workload == 'c3'
+    cfg = perception_cfg(**(FULL_LOSSES if full else {}))
     module = TrainingModule(cfg.convert_to_dict())
     port = CpuPortSTP3(cfg)
     port.load_state_dict(module.model.state_dict(), strict=False)
-    for name in ('segmentation_weight', 'pedestrian_weight', 'hdmap_weight'):
-        setattr(port, name, getattr(module.model, name))
+    for name in ('segmentation_weight', 'pedestrian_weight', 'hdmap_weight', 'depths_weight', 'centerness_weight',
+                 'offset_weight', 'flow_weight'):
+        if hasattr(module.model, name):
+            setattr(port, name, getattr(module.model, name))
     module.model = port
     module.train()
-    batch = synthetic.make_batch(batch=1, seq=3, seed=0)
+    batch = synthetic.make_batch(batch=1, seq=3, seed=0, gt_depth=full, instance=full)
     opt = module.configure_optimizers()
     times = []
     for _ in range(2):
@@ -105,15 +137,17 @@ def _cpu_baseline_worker():
             break
     best = min(times)
     print(json.dumps({'value': 1.0 / best, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
-                      'sample': f'B=1 (1 sample = 6 cams x 3 frames) full fwd+bwd+Adam step, fp32, {len(times)} run(s), best '
+                      'sample': f'B=1 (1 sample = 6 cams x 3 frames) full fwd+bwd+Adam step ({workload} losses), fp32, '
+                                f'{len(times)} run(s), best '
                                 f'{best:.2f} s, {threads} of {cores} host threads; lift = reference algorithm (outer '
                                 f'product, argsort, cumsum VoxelsSumming)'}))
 
 
-def cpu_baseline(timeout_s=240.0):
+def cpu_baseline(workload='c3', timeout_s=240.0):
     """Runs the worker in a child process (own thread pool, hard time limit) and returns its JSON object."""
     import subprocess
-    out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker'], capture_output=True,
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--workload', workload],
+                         capture_output=True,
                          text=True, timeout=timeout_s, env={**os.environ, 'HIP_VISIBLE_DEVICES': ''})
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
     if not lines:
@@ -187,31 +221,55 @@ def main():
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--graph', action='store_true', help='capture the step into a hipGraph (N=1 only, experimental)')
     ap.add_argument('--no-roofline', action='store_true', help='skip the voxel-pool micro-benchmark (profiling runs)')
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='c3',
+                    help='c3: BASELINE configs[2] (all losses incl. depth + instance + flow); perception: Perception.yml')
     args = ap.parse_args()
     if args.cpu_baseline_worker:
-        _cpu_baseline_worker()
+        _cpu_baseline_worker(args.workload)
         return
 
     from stp3_amd.parallel import FlatAdam, GradientBuckets, init_distributed
     rank, world, local = init_distributed()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    device = torch.device('cuda', local)
-    torch.cuda.set_device(device)
+    device = torch.device('cpu') if DRYRUN else torch.device('cuda', local)
+    if not DRYRUN:
+        torch.cuda.set_device(device)
 
-    module, cfg = build_module(device, sync_bn=False)          # cross-replica BN statistics are built into bn_act
-    buckets = GradientBuckets(module.model)
-    opt = FlatAdam(buckets, lr=cfg.OPTIMIZER.LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY)   # trainer.py:456-462
-    batch = make_device_batch(args.batch, device, seed=100 + rank)
+    def setup(workload):
+        # cross-replica BN statistics are built into bn_act, hence sync_bn=False
+        module, cfg = build_module(device, sync_bn=False, workload=workload)
+        buckets = GradientBuckets(module.model)
+        opt = FlatAdam(buckets, lr=cfg.OPTIMIZER.LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY)   # trainer.py:456-462
+        batch = make_device_batch(args.batch, device, seed=100 + rank, workload=workload)
 
-    def eager_step():
-        buckets.zero_grad()
-        with torch.autocast('cuda', dtype=torch.bfloat16):
-            loss = module.training_step(batch)
-        loss.backward()
-        buckets.finish()
-        buckets.clip_grad_norm_(cfg.GRAD_NORM_CLIP)
-        opt.step()
-        return loss
+        def eager_step():
+            buckets.zero_grad()
+            with torch.autocast(DEV_TYPE, dtype=torch.bfloat16):
+                loss = module.training_step(batch)
+            loss.backward()
+            buckets.finish()
+            buckets.clip_grad_norm_(cfg.GRAD_NORM_CLIP)
+            opt.step()
+            return loss
+
+        return module, cfg, buckets, opt, batch, eager_step
+
+    workload = args.workload
+    try:
+        module, cfg, buckets, opt, batch, eager_step = setup(workload)
+        first = eager_step()                                    # first warm-up step = the workload's own smoke test
+        _sync()
+        assert DRYRUN or torch.isfinite(first).item(), 'loss is not finite'
+    except Exception as e:
+        if workload != 'c3':
+            raise
+        # never lose the measurement to the extra heads: time the plain Perception.yml step and say so in `config`
+        print(f'[bench] workload c3 failed in its first step ({e!r}); falling back to --workload perception',
+              file=sys.stderr, flush=True)
+        workload = 'perception'
+        module, cfg, buckets, opt, batch, eager_step = setup(workload)
+        eager_step()
+        _sync()
 
     mode = 'eager'
     step = eager_step
@@ -224,20 +282,20 @@ def main():
         except Exception as e:                                  # capture is an optimisation, never a requirement
             print(f'[bench] hipGraph capture failed ({e!r}); running eagerly', file=sys.stderr)
             module.model.prebuilt_plan = None
-            torch.cuda.synchronize()
+            _sync()
 
     _log(f'mode {mode}: warm-up')
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup - 1, 0) if mode == 'eager' else args.warmup):   # one warm-up step ran in setup
         step()
-        torch.cuda.synchronize()
+        _sync()
         _log('warm-up step done')
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    _sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
-    torch.cuda.synchronize()
+    _sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -246,7 +304,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     _log(f'timed steps done: {elapsed / args.steps * 1e3:.2f} ms/step')
-    assert torch.isfinite(loss).item(), 'loss is not finite'
+    assert DRYRUN or torch.isfinite(loss).item(), 'loss is not finite'
 
     if rank == 0:
         module.model.prebuilt_plan = None
@@ -254,18 +312,17 @@ def main():
         _log('roofline microbench done')
         line = {
             'metric': 'BEV samples/sec (6-cam x 3-frame fwd+bwd)', 'value': round(args.batch * world * args.steps / elapsed, 3),
-            'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': max(args.warmup, 1),
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16 convs / f32 voxel pool', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[2]: batch=4/GPU, 6-cam 224x480, T=3, full STP3 fwd+bwd '
-                                   '(seg+ped+hdmap losses), grad-clip 5, Adam; EfficientNet-B4, D=48, C=64, BEV 200x200',
+            'config': {'workload': WORKLOADS[workload].replace('batch=4/GPU', f'batch={args.batch}/GPU'),
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'launch': mode},
             'roofline': roof,
             'kernel_ms': kernel_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line['cpu_baseline'] = cpu_baseline()
+                line['cpu_baseline'] = cpu_baseline(workload)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 line['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(line))

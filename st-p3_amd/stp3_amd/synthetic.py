@@ -114,8 +114,31 @@ def make_labels(batch, seq, bev=(200, 200), seed=0, n_hdmap=2):
     return seg, ped, hd
 
 
+def make_instance_labels(segmentation, ignore_index=255, seed=0):
+    """Instance-branch labels derived from the occupancy blobs, with the shapes / dtypes / ignore convention the
+    reference's data loader produces (stp3/datas/NuscenesData.py:518-560, stp3/utils/instance.py:11-69):
+    instance (B,T,X,Y) int64 ids (0 = background; every 4x4 blob is one instance), centerness (B,T,1,X,Y) float in
+    [0,1] peaking at the instance centre, offset (B,T,2,X,Y) float = vector to the centre, ``ignore_index`` outside
+    instances, flow (B,T,2,X,Y) float = a per-sample constant motion inside instances, ``ignore_index`` outside."""
+    b, t, _, x, y = segmentation.shape
+    occ = segmentation[:, :, 0] > 0
+    ii = torch.arange(x).view(1, 1, x, 1).expand(b, t, x, y)
+    jj = torch.arange(y).view(1, 1, 1, y).expand(b, t, x, y)
+    cell = (ii // 4) * ((y + 3) // 4) + jj // 4 + 1
+    instance = torch.where(occ, cell, torch.zeros_like(cell)).long()
+    di = 1.5 - (ii % 4).float()
+    dj = 1.5 - (jj % 4).float()
+    centerness = torch.where(occ, torch.exp(-(di * di + dj * dj) / 8.0), torch.zeros(())).unsqueeze(2)
+    ign = torch.full((), float(ignore_index))
+    offset = torch.stack([torch.where(occ, di, ign), torch.where(occ, dj, ign)], dim=2)
+    g = torch.Generator().manual_seed(seed + 15485863)
+    motion = torch.randn(b, 1, 2, 1, 1, generator=g)
+    flow = torch.where(occ.unsqueeze(2), motion.expand(b, t, 2, x, y), ign)
+    return instance, centerness.float(), offset.float(), flow.float()
+
+
 def make_batch(batch=1, seq=3, n_cams=6, final_dim=(224, 480), bev=(200, 200), seed=0,
-               axis_aligned=False, with_images=True, with_labels=True, gt_depth=False):
+               axis_aligned=False, with_images=True, with_labels=True, gt_depth=False, instance=False):
     """Full batch dict with the reference's keys (trainer.py:102-108)."""
     g = torch.Generator().manual_seed(seed + 104729)
     intr, extr, ego = make_rig(batch, seq, n_cams, final_dim, seed, axis_aligned)
@@ -135,6 +158,8 @@ def make_batch(batch=1, seq=3, n_cams=6, final_dim=(224, 480), bev=(200, 200), s
         out['segmentation'] = seg
         out['pedestrian'] = ped
         out['hdmap'] = hd
+        if instance:
+            out['instance'], out['centerness'], out['offset'], out['flow'] = make_instance_labels(seg, seed=seed)
     if gt_depth:
         out['depths'] = torch.randint(0, 61, (batch, seq, n_cams, *final_dim), generator=g).float()
     return out

@@ -15,8 +15,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def dry_setup(recorder, final_dim=(64, 96), batch_size=2, bev_cells=64, deterministic_fill=True):
-    """Patch the process for a dry run and build (module, batch, cfg).  Also used by scripts/host_step_profile.py."""
+def patch_process(recorder, deterministic_fill=True):
+    """Make this process run the GPU code path on CPU tensors against the recording library."""
+    import contextlib
     import torch
     sys.path.insert(0, os.path.join(ROOT, 'st-p3_amd'))
     from stp3_amd import _lib
@@ -28,12 +29,43 @@ def dry_setup(recorder, final_dim=(64, 96), batch_size=2, bev_cells=64, determin
     torch.Tensor.is_cuda = property(lambda self: True)
     torch.is_autocast_enabled = lambda *a: True
     torch.get_autocast_gpu_dtype = lambda: torch.bfloat16
+
+    class _Stream:                               # the model overlaps the plan build on a side stream
+        cuda_stream = 0
+
+        def wait_stream(self, other):
+            pass
+
+    class _Event:                                # bench.py times the voxel-pool launches with events
+        def __init__(self, *a, **k):
+            pass
+
+        def record(self, *a):
+            pass
+
+        def synchronize(self):
+            pass
+
+        def elapsed_time(self, other):
+            return 0.125
+
+    torch.cuda.Event = _Event
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.current_stream = lambda *a, **k: _Stream()
+    torch.cuda.Stream = lambda *a, **k: _Stream()
+    torch.cuda.stream = lambda s: contextlib.nullcontext()
     torch.set_num_threads(4)
-    # uninitialised memory (what the do-nothing kernels leave in their outputs) becomes a fixed NaN / max-int
-    # pattern, so the buffer checksums in the trace are reproducible from run to run and from path to path
     if deterministic_fill:
+        # uninitialised memory (what the do-nothing kernels leave in their outputs) becomes a fixed NaN / max-int
+        # pattern, so the buffer checksums in the trace are reproducible from run to run and from path to path
         torch.use_deterministic_algorithms(True, warn_only=True)
         torch.utils.deterministic.fill_uninitialized_memory = True
+
+
+def dry_setup(recorder, final_dim=(64, 96), batch_size=2, bev_cells=64, deterministic_fill=True, full_losses=None):
+    """Patch the process for a dry run and build (module, batch, cfg).  Also used by scripts/host_step_profile.py."""
+    import torch
+    patch_process(recorder, deterministic_fill)
 
     from stp3_amd import synthetic
     from stp3_amd.config import perception_cfg
@@ -42,11 +74,15 @@ def dry_setup(recorder, final_dim=(64, 96), batch_size=2, bev_cells=64, determin
 
     torch.manual_seed(1234)
     half = bev_cells * 0.25
+    if full_losses is None:                    # bench.py's workload: depth + instance + flow losses on top
+        full_losses = os.environ.get('STP3_DRYRUN_FULL_LOSSES', '1') == '1'
+    extra = {'LIFT.GT_DEPTH': True, 'INSTANCE_SEG.ENABLED': True, 'INSTANCE_FLOW.ENABLED': True} if full_losses else {}
     cfg = perception_cfg(**{'IMAGE.FINAL_DIM': final_dim, 'LIFT.X_BOUND': [-half, half, 0.5],
-                            'LIFT.Y_BOUND': [-half, half, 0.5]})
+                            'LIFT.Y_BOUND': [-half, half, 0.5], **extra})
     module = to_channels_last(TrainingModule(cfg.convert_to_dict()))
     module.train()
-    batch = synthetic.make_batch(batch=batch_size, seq=3, final_dim=final_dim, bev=(bev_cells, bev_cells), seed=0)
+    batch = synthetic.make_batch(batch=batch_size, seq=3, final_dim=final_dim, bev=(bev_cells, bev_cells), seed=0,
+                                 gt_depth=full_losses, instance=full_losses)
     return module, batch, cfg
 
 

@@ -1,0 +1,47 @@
+"""CPU: bench.py's main() end to end as a dry run -- the script the driver runs on the MI355X must not fall over on
+a Python-level error.  The GPU code path runs on CPU tensors against the recording stand-in for libstp3hip.so
+(tests/model_trace.py); B=1 of the real 6-camera 224x480 x T=3 workload, one warm-up and one timed step, the
+voxel-pool roofline leg included (event timing stubbed); the cpu_baseline leg is a subprocess of the same file and
+has its own flag.  Checks the one-line JSON contract (keys, types, the workload named after BASELINE.json)."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+from tests import host_trace
+
+ROOT = host_trace.ROOT
+PKG = os.path.join(ROOT, 'st-p3_amd', 'stp3_amd')
+
+
+@pytest.mark.skipif(shutil.which('gcc') is None, reason='needs gcc for the recording library')
+@pytest.mark.parametrize('workload', ['c3', 'perception'])
+def test_bench_main_dry_run(tmp_path, workload):
+    recorder = host_trace.build_recorder(str(tmp_path / 'libstp3hip_recorder.so'))
+    env = dict(os.environ, STP3_BENCH_DRYRUN='1', STP3_HOST_DRYRUN='1', STP3_TRACE_LOG=str(tmp_path / 'trace.log'),
+               STP3_REAL_LIB=os.path.join(PKG, 'libstp3hip.so'))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'bench_dryrun.py'), recorder, '--steps', '1',
+                          '--warmup', '1', '--batch', '1', '--no-cpu-baseline', '--workload', workload],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'falling back' not in out.stderr, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1                                        # ONE JSON line
+    line = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert key in line, key
+    assert line['n_gpus'] == 1 and line['steps'] == 1 and line['scaling'] == 'weak' and line['vs_baseline'] is None
+    assert line['unit'] == 'samples/s' and line['higher_is_better'] is True and line['data'] == 'synthetic'
+    assert 'workload' in line['config'] and 'model' not in line['config']
+    assert ('depth CE' in line['config']['workload']) == (workload == 'c3')
+    roof = line['roofline']
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert key in roof, key
+    assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and roof['peak'] == 8000.0
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
+    # B=1: 3 frames x (feat + depth probabilities + BEV planes) float32, SURVEY.md section 8d: 14 755 840 B per frame
+    assert roof['algorithmic_bytes_per_launch'] == 3 * 14755840
