@@ -5,13 +5,15 @@ TAG=${1:-r02a}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 run() { echo "=== $*"; "$@" 2>&1 | grep -v "amdgpu.ids\|MIOpen(HIP)" | tail -${TAILN:-4}; }
 TAILN=4 run env STP3_EXPERIMENTAL=1 STP3_BN_GEOM=1 timeout 200 python -m pytest tests/test_conv_v2_gpu.py tests/test_bnact_gpu.py -q -x
 TAILN=4 run env STP3_LIFT_BWD=mfma timeout 300 python -m pytest tests/test_lift_gpu.py -q -x
+TAILN=4 run env STP3_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_lift_stress_gpu.py -q -x
 TAILN=10 run env STP3_LIFT_BWD=mfma timeout 100 python scripts/time_lift.py
 TAILN=6 run env STP3_CPP_OPS=1 timeout 400 python -m pytest tests -m gpu -q -x
 TAILN=12 run env STP3_BN_GEOM=0 timeout 100 python scripts/time_bn.py
 TAILN=12 run env STP3_BN_GEOM=1 timeout 100 python scripts/time_bn.py
-bench() { name=$1; shift; env "$@" timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $OUT/bench_$name.log 2> $OUT/bench_$name.err
+bench() { name=$1; shift; env "$@" timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --workload ${WL:-c3} > $OUT/bench_$name.log 2> $OUT/bench_$name.err
           echo "bench $name: $(grep -o '"ms_per_step": [0-9.]*' $OUT/bench_$name.log) $(grep -v "amdgpu.ids\|MIOpen(HIP)" $OUT/bench_$name.err | tail -2 | cut -c1-200)"; }
 bench base STP3_BN_GEOM=0
+WL=perception bench base_perception STP3_BN_GEOM=0     # continuity with the round-1 numbers (88.5 ms/step)
 bench bngeom STP3_BN_GEOM=1
 bench se STP3_BN_GEOM=1 STP3_FUSED_SE=1
 bench convv2 STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1

@@ -927,6 +927,14 @@ int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const flo
     const int Dp = ndg * 8;
     const size_t lds = ((size_t)dm.fH * 64 + 3 * (size_t)dm.fH * Dp) * sizeof(float);
     if (lds > 160 * 1024) return STP3_EUNSUP;
+    if (lds > 64 * 1024) {
+        // tall feature maps (BASELINE configs[4]: 112 rows x 64 bins = 112 KB per column): above the default
+        // dynamic-LDS limit of a launch, raise it for this kernel (gfx950 has 160 KB per workgroup)
+        const void* fn = dm.C % 8 == 0 ? reinterpret_cast<const void*>(&lift_runs_kernel<true>)
+                                       : reinterpret_cast<const void*>(&lift_runs_kernel<false>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+    }
     if (dm.C % 8 == 0)
         hipLaunchKernelGGL((lift_runs_kernel<true>), dim3(dm.NCOL, dm.BT), dim3(64 * ndg), lds, s, dm, Dp, feat, prob,
                            vox_pm, pv.run_base, pv.dest, (float*)workspace);
