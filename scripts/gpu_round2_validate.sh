@@ -20,6 +20,7 @@ bench convv2 STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1
 bench liftmfma STP3_BN_GEOM=0 STP3_LIFT_BWD=mfma
 bench gather STP3_GRAD_GATHER=1
 bench wprep STP3_WEIGHT_PREP=1
+bench labelwarp STP3_LABEL_WARP=batched
 bench cpp STP3_BN_GEOM=1 STP3_CPP_OPS=1
 bench trunkfused STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1 STP3_MFMA_CONV=all
-bench all STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1 STP3_MFMA_CONV=all STP3_WEIGHT_PREP=1 STP3_GRAD_GATHER=1 STP3_LIFT_BWD=mfma
+bench all STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1 STP3_MFMA_CONV=all STP3_WEIGHT_PREP=1 STP3_GRAD_GATHER=1 STP3_LIFT_BWD=mfma STP3_LABEL_WARP=batched

@@ -50,18 +50,46 @@ def invert_pose_matrix(x):
     return torch.cat([inv, bottom], dim=1)
 
 
-def warp_features(x, flow, mode='nearest', spatial_extent=None):
-    """In-plane rigid warp of a BEV map (b,c,h,w) by the xy / yaw part of a 6-DoF flow (b,6)."""
-    if flow is None:
-        return x
-    b = x.shape[0]
+def warp_theta(flow, spatial_extent):
+    """(b,6) flow -> the (b,2,3) affine matrix ``warp_features`` samples with."""
+    b = flow.shape[0]
     angle = flow[:, 5]
     t0 = -flow[:, 0] / spatial_extent[0]       # forward axis is inverted
     t1 = flow[:, 1] / spatial_extent[1]
     c, s = torch.cos(angle), torch.sin(angle)
-    theta = torch.stack([c, -s, t1, s, c, t0], dim=-1).view(b, 2, 3)
+    return torch.stack([c, -s, t1, s, c, t0], dim=-1).view(b, 2, 3)
+
+
+def warp_with_theta(x, theta, mode='nearest'):
     grid = F.affine_grid(theta, size=x.shape, align_corners=False).to(x.dtype)
     return F.grid_sample(x, grid, mode=mode, padding_mode='zeros', align_corners=False)
+
+
+def warp_features(x, flow, mode='nearest', spatial_extent=None):
+    """In-plane rigid warp of a BEV map (b,c,h,w) by the xy / yaw part of a 6-DoF flow (b,6)."""
+    if flow is None:
+        return x
+    return warp_with_theta(x, warp_theta(flow, spatial_extent), mode)
+
+
+def label_warp_thetas(flow, receptive_field, spatial_extent):
+    """The affine matrices ``cumulative_warp_features(x[:, :rf], flow[:, :rf])`` and
+    ``cumulative_warp_features_reverse(x[:, rf-1:], flow[:, rf-1:])`` apply, computed ONCE for a batch:
+    {frame index: (b,2,3) theta}; the present frame rf-1 is not warped and has no entry.  ``flow`` (b,s,6)."""
+    rf, seq = receptive_field, flow.shape[1]
+    thetas = {}
+    mats = pose_vec2mat(flow)
+    if rf > 1:
+        cum = mats[:, rf - 2]
+        for t in reversed(range(rf - 1)):
+            thetas[t] = warp_theta(mat2pose_vec(cum), spatial_extent)
+            cum = mats[:, t - 1] @ cum
+    cum = None
+    for i in range(1, seq - rf + 1):
+        inv = invert_pose_matrix(mats[:, rf - 1 + i - 1])
+        cum = inv if cum is None else cum @ inv
+        thetas[rf - 1 + i] = warp_theta(mat2pose_vec(cum), spatial_extent)
+    return thetas
 
 
 def cumulative_warp_features(x, flow, mode='nearest', spatial_extent=None):

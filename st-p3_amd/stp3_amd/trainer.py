@@ -8,14 +8,21 @@ the reference's checkpoints (``model.*`` incl. the learned uncertainty scalars
 Perception path only: instance / flow / planning heads follow the config gates exactly as the
 reference does, but the prediction and planning stages are rejected by ``STP3``.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from .config import get_cfg
-from .geometry import cumulative_warp_features, cumulative_warp_features_reverse
+from .geometry import (cumulative_warp_features, cumulative_warp_features_reverse, label_warp_thetas,
+                       warp_with_theta)
 from .losses import DepthLoss, HDmapLoss, SegmentationLoss, SpatialRegressionLoss
 from .metrics import IntersectionOverUnion
 from .models.stp3 import STP3
+
+
+# EXPERIMENTAL (STP3_LABEL_WARP=batched): see TrainingModule._prepare_future_labels_batched
+_BATCHED_LABEL_WARP = os.environ.get('STP3_LABEL_WARP', 'per_label') == 'batched'
 
 
 def _scalar():
@@ -127,7 +134,48 @@ class TrainingModule(nn.Module):
             past, fut = past.long(), fut.long()
         return torch.cat([past.contiguous()[:, :-1], fut.contiguous()], dim=1)
 
+    def _prepare_future_labels_batched(self, batch):
+        """``prepare_future_labels`` with the pose chains evaluated once per batch (on the host, where the pose
+        tensors live) and ALL label maps warped together: one ``grid_sample`` per past / future frame over the
+        channel concatenation instead of one per label type and frame, each preceded by its own ~40 tiny pose
+        operators.  Nearest sampling acts per channel, so the result equals the per-label warps bit for bit."""
+        cfg, rf = self.cfg, self.model.receptive_field
+        dev = batch['segmentation'].device
+        labels = {'hdmap': batch['hdmap'][:, rf - 1].long().contiguous(), 'gt_trajectory': batch['gt_trajectory']}
+        if cfg.LIFT.GT_DEPTH:
+            ds = self.model.encoder_downsample
+            depth = batch['depths'][:, :rf, :, ::ds, ::ds]
+            depth = torch.clamp(depth, cfg.LIFT.D_BOUND[0], cfg.LIFT.D_BOUND[1] - 1) - cfg.LIFT.D_BOUND[0]
+            labels['depths'] = depth.long().contiguous()
+        items = [('segmentation', batch['segmentation'], True)]
+        if cfg.SEMANTIC_SEG.PEDESTRIAN.ENABLED:
+            items.append(('pedestrian', batch['pedestrian'], True))
+        if cfg.INSTANCE_SEG.ENABLED:
+            items += [('instance', batch['instance'].unsqueeze(2), True), ('centerness', batch['centerness'], False),
+                      ('offset', batch['offset'], False)]
+        if cfg.INSTANCE_FLOW.ENABLED:
+            items.append(('flow', batch['flow'], False))
+        stacked = torch.cat([x.float() for _, x, _ in items], dim=2)                  # (B,S,sum C,H,W)
+        thetas = label_warp_thetas(batch['future_egomotion'].detach().float().cpu(), rf, self.spatial_extent)
+        frames = []
+        for t in range(stacked.shape[1]):
+            frame = stacked[:, t]
+            if t in thetas:
+                frame = warp_with_theta(frame, thetas[t].to(dev), mode='nearest')
+            frames.append(frame)
+        warped = torch.stack(frames, dim=1)
+        c0 = 0
+        for name, x, to_long in items:
+            part = warped[:, :, c0:c0 + x.shape[2]]
+            c0 += x.shape[2]
+            labels[name] = (part.long() if to_long else part).contiguous()
+        if 'instance' in labels:
+            labels['instance'] = labels['instance'][:, :, 0]
+        return labels
+
     def prepare_future_labels(self, batch):
+        if _BATCHED_LABEL_WARP:
+            return self._prepare_future_labels_batched(batch)
         cfg, rf = self.cfg, self.model.receptive_field
         dev = batch['segmentation'].device
         ego = batch['future_egomotion'].to(dev)

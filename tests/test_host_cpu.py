@@ -102,3 +102,23 @@ def test_bn_act_reference_equals_torch_modules(train):
     y2.sum().backward()
     torch.testing.assert_close(x.grad, x2.grad, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(bn.running_var, ref.running_var)
+
+
+def test_batched_label_warp_equals_per_label_warps():
+    """STP3_LABEL_WARP=batched: pose chains once per batch + one grid_sample per frame over all label maps ==
+    the reference-shaped per-label ``cumulative_warp_features`` calls (trainer.py:254-360), bit for bit."""
+    import torch
+    from stp3_amd import synthetic, trainer
+    from stp3_amd.config import perception_cfg
+    for extra in ({}, {'LIFT.GT_DEPTH': True, 'INSTANCE_SEG.ENABLED': True, 'INSTANCE_FLOW.ENABLED': True}):
+        cfg = perception_cfg(**{'IMAGE.FINAL_DIM': (64, 96), **extra})
+        module = trainer.TrainingModule(cfg.convert_to_dict())
+        full = bool(extra)
+        batch = synthetic.make_batch(batch=3, seq=3, final_dim=(64, 96), seed=4, gt_depth=full, instance=full)
+        batch['future_egomotion'][..., 5] *= 5.0            # a real turn: the warps move pixels
+        old = module.prepare_future_labels(batch)
+        new = module._prepare_future_labels_batched(batch)
+        assert old.keys() == new.keys()
+        for k in old:
+            assert old[k].dtype == new[k].dtype and torch.equal(old[k], new[k]), k
+        assert (old['segmentation'][:, 0] != batch['segmentation'][:, 0]).any()
