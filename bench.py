@@ -191,6 +191,7 @@ def lift_roofline(device, batch, model, iters=30):
         try:
             pmc = json.load(open(pmc_path))
             traffic = sum(pmc[k][f] for k in ('lift_runs', 'lift_gather') for f in ('hbm_read_bytes', 'hbm_write_bytes'))
+            traffic *= d.BT / float(pmc.get('frames_per_launch', 12))     # counters were collected at B=4, T=3
         except Exception:
             traffic = None
     roof = {'kernel': 'stp3_lift_splat_fwd (lift_runs_kernel + lift_gather_kernel)', 'bound': 'hbm',

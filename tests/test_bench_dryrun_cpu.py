@@ -45,3 +45,31 @@ def test_bench_main_dry_run(tmp_path, workload):
     assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
     # B=1: 3 frames x (feat + depth probabilities + BEV planes) float32, SURVEY.md section 8d: 14 755 840 B per frame
     assert roof['algorithmic_bytes_per_launch'] == 3 * 14755840
+
+
+@pytest.mark.skipif(shutil.which('gcc') is None, reason='needs gcc for the recording library')
+def test_bench_main_dry_run_two_ranks(tmp_path):
+    """The driver's N>1 launch line (torch.distributed.run, one rank per GPU) with the gloo backend: barrier,
+    max-over-ranks timing, cross-replica BatchNorm statistics and bucketed gradient all-reduce all execute; rank 0
+    prints the one JSON line with the whole-job value."""
+    import socket
+    recorder = host_trace.build_recorder(str(tmp_path / 'libstp3hip_recorder.so'))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, STP3_BENCH_DRYRUN='1', STP3_HOST_DRYRUN='1', STP3_TRACE_LOG=str(tmp_path / 'trace.log'),
+               STP3_REAL_LIB=os.path.join(PKG, 'libstp3hip.so'))
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', str(port),
+                          os.path.join(ROOT, 'tests', 'bench_dryrun.py'), recorder, '--gpus', '2', '--steps', '1',
+                          '--warmup', '1', '--batch', '1', '--no-cpu-baseline', '--no-roofline'],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1                                        # rank 0 only
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['config']['global_batch'] == 2 and line['config']['parallelism'] == 'dp2'
+    assert abs(line['value'] - 2 * 1000.0 / line['ms_per_step']) < 1e-2 * line['value'] + 1e-3   # whole-job rate
+    calls = [l for l in open(tmp_path / 'trace.log') if l.startswith('stp3_bn_')]
+    # more than one rank: the BatchNorm operator runs split (statistics | all-reduce | apply), never the composite
+    assert any(l.startswith('stp3_bn_stats ') for l in calls) and not any(l.startswith('stp3_bn_fwd_train ') for l in calls)
