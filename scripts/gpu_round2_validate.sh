@@ -19,6 +19,7 @@ bench se STP3_BN_GEOM=1 STP3_FUSED_SE=1
 bench convv2 STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1
 bench liftmfma STP3_BN_GEOM=0 STP3_LIFT_BWD=mfma
 bench mfmaall STP3_MFMA_CONV=all
+bench wgrad64 STP3_WGRAD_MIN_CHANNELS=64
 bench gather STP3_GRAD_GATHER=1
 bench wprep STP3_WEIGHT_PREP=1
 bench labelwarp STP3_LABEL_WARP=batched

@@ -661,7 +661,7 @@ def _conv2d_launch(x, wb, bias, stride, pad, dil, out_dtype):
 _CONV_WORKSPACE = {}
 # The weight-gradient kernel works on 128 x 128 (Cout x Cin) tiles: below that the vendor kernel is faster today
 # (profiles/r01_time_conv.txt).  Tests set this to 0 to exercise the kernel on every shape.
-WGRAD_MIN_CHANNELS = 128
+WGRAD_MIN_CHANNELS = int(os.environ.get('STP3_WGRAD_MIN_CHANNELS', '128'))   # A/B knob; 128 = measured break-even
 
 
 def _conv2d_wgrad(dy, x, wshape, stride, pad, dil):
