@@ -249,8 +249,7 @@ def main():
                 loss = module.training_step(batch)
             loss.backward()
             buckets.finish()
-            buckets.clip_grad_norm_(cfg.GRAD_NORM_CLIP)
-            opt.step()
+            opt.clip_and_step(cfg.GRAD_NORM_CLIP)                # gradient clip + Adam (trainer.py:456-462, train.py:48)
             return loss
 
         return module, cfg, buckets, opt, batch, eager_step

@@ -329,6 +329,31 @@ typedef struct stp3_wprep_entry {
 int stp3_conv2d_prep_weights(const stp3_wprep_entry* table, int32_t n_entries, int64_t total_blocks, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Gradient-norm clipping + Adam on flat fp32 buckets in three launches (csrc/stp3_optim.hip; EXPERIMENTAL, host
+ * side selected with STP3_FUSED_ADAM=1).  Replaces, for the flat buckets of stp3_amd/parallel.py, the reference's
+ * gradient_clip_val (train.py:48, torch clip_grad_norm_ semantics: scale = min(max_norm / (norm + 1e-6), 1)) and
+ * torch.optim.Adam step (trainer.py:456-462: L2 weight decay folded into the gradient, bias correction, no amsgrad).
+ *   table : n_buckets structs in DEVICE memory, sorted by first_block; grad / param / exp_avg / exp_avg_sq are
+ *           float32 arrays of numel elements; first_block = exclusive scan of ceil(numel / 4096)
+ *   state : 5 floats in device memory, [0] = step count (in/out, incremented by the call), out: [1] clip scale,
+ *           [2] lr / (1 - beta1^t), [3] sqrt(1 - beta2^t), [4] total gradient norm before clipping
+ *   max_norm <= 0 : no clipping.  The clipped gradient is written back to grad (as clip_grad_norm_ does).
+ *   workspace : stp3_optim_workspace_bytes(total_blocks) bytes.  No host synchronisation; deterministic. */
+typedef struct stp3_optim_bucket {
+    float* grad;
+    float* param;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel;
+    int64_t first_block;
+} stp3_optim_bucket;
+
+int stp3_optim_workspace_bytes(int64_t total_blocks, size_t* bytes);
+int stp3_optim_clip_adam(const stp3_optim_bucket* table, int32_t n_buckets, int64_t total_blocks, float max_norm,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, float* state,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Stand-alone voxel summing (csrc/stp3_voxsum.hip): the operator-level twin of the reference's
  * VoxelsSumming.forward / .backward (stp3/utils/geometry.py:302-318 / :320-330) for callers that hold the
  * rank-sorted row matrix; the fused path above never builds it.

@@ -69,6 +69,12 @@ class WprepEntry(ctypes.Structure):
                 ('cout', ctypes.c_int32), ('cin', ctypes.c_int32), ('kh', ctypes.c_int32), ('kw', ctypes.c_int32)]
 
 
+class OptimBucket(ctypes.Structure):
+    """struct stp3_optim_bucket (include/stp3_hip.h)."""
+    _fields_ = [('grad', ctypes.c_void_p), ('param', ctypes.c_void_p), ('exp_avg', ctypes.c_void_p),
+                ('exp_avg_sq', ctypes.c_void_p), ('numel', ctypes.c_int64), ('first_block', ctypes.c_int64)]
+
+
 DTYPE_F32 = 0
 DTYPE_BF16 = 1
 
@@ -116,6 +122,9 @@ SIGNATURES = {
     'stp3_conv2d_wgrad_workspace': (c_int, [ctypes.POINTER(ConvDims), ctypes.POINTER(c_size_t)]),
     'stp3_conv2d_wgrad': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'stp3_conv2d_prep_weights': (c_int, [c_void_p, c_int32, ctypes.c_int64, c_void_p]),
+    'stp3_optim_workspace_bytes': (c_int, [ctypes.c_int64, ctypes.POINTER(c_size_t)]),
+    'stp3_optim_clip_adam': (c_int, [c_void_p, c_int32, ctypes.c_int64] + [c_float] * 6 + [c_void_p, c_void_p, c_size_t,
+                                                                                          c_void_p]),
     'stp3_voxels_sum_fwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     'stp3_voxels_sum_bwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
 }

@@ -24,6 +24,10 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+# EXPERIMENTAL: clipping + Adam through stp3_optim_clip_adam (csrc/stp3_optim.hip), see FlatAdam.clip_and_step
+_FUSED_ADAM = os.environ.get('STP3_FUSED_ADAM', '0') == '1'
+
+
 def init_distributed(backend=None):
     """Initialise ``torch.distributed`` from the torchrun environment.  Returns (rank, world, local_rank)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -193,6 +197,7 @@ class FlatAdam:
         self.step_t = torch.zeros((), dtype=torch.float32, device=dev)
         self.exp_avg = [torch.zeros_like(p) for p in buckets.flat_params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in buckets.flat_params]
+        self._table = None                                       # stp3_optim_bucket[] for the fused path
 
     @property
     def step_count(self):
@@ -214,6 +219,43 @@ class FlatAdam:
             param.sub_((m / denom) * step_size)
         from . import ops
         ops.invalidate_weight_cache()        # the parameters are views of `param`: their version counters did not move
+
+    def clip_and_step(self, max_norm):
+        """Gradient-norm clipping followed by the Adam update (the tail of every training step).  Default: the
+        two torch-operator methods above.  ``STP3_FUSED_ADAM=1`` on GPU buckets: three launches of
+        ``stp3_optim_clip_adam`` for all buckets together (EXPERIMENTAL).  Returns the total gradient norm."""
+        if not (_FUSED_ADAM and self.buckets.flat_params[0].is_cuda):
+            total = self.buckets.clip_grad_norm_(max_norm)
+            self.step()
+            return total
+        import ctypes
+        from . import _lib, ops
+        if self._table is None:
+            arr = (_lib.OptimBucket * len(self.buckets.buckets))()
+            block = 0
+            for rec, (grad, _), param, m, v in zip(arr, self.buckets.buckets, self.buckets.flat_params, self.exp_avg,
+                                                   self.exp_avg_sq):
+                assert grad.dtype == param.dtype == torch.float32 and grad.is_contiguous() and param.is_contiguous()
+                rec.grad, rec.param, rec.exp_avg, rec.exp_avg_sq = (grad.data_ptr(), param.data_ptr(), m.data_ptr(),
+                                                                    v.data_ptr())
+                rec.numel, rec.first_block = grad.numel(), block
+                block += (grad.numel() + 4095) // 4096
+            dev = self.buckets.flat_params[0].device
+            self._table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            self._blocks = block
+            need = ctypes.c_size_t()
+            _lib.check(_lib.lib().stp3_optim_workspace_bytes(block, ctypes.byref(need)), 'stp3_optim_workspace_bytes')
+            self._workspace = torch.empty(need.value, dtype=torch.uint8, device=dev)
+            self._state = torch.zeros(5, dtype=torch.float32, device=dev)
+            self._state[0:1].copy_(self.step_t.reshape(1))
+            self.step_t = self._state[0]                         # one device-side step counter for both paths
+        b1, b2 = self.betas
+        _lib.check(_lib.lib().stp3_optim_clip_adam(
+            ops._ptr(self._table), len(self.buckets.buckets), self._blocks, float(max_norm or 0.0), float(self.lr),
+            float(b1), float(b2), float(self.eps), float(self.weight_decay), ops._ptr(self._state),
+            ops._ptr(self._workspace), self._workspace.numel(), ops._stream()), 'stp3_optim_clip_adam')
+        ops.invalidate_weight_cache()
+        return self._state[4]
 
     def state_dict(self):
         return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq}

@@ -49,10 +49,16 @@ def recorder_source():
         names = [p.split('*')[-1].split()[-1] for p in params]
         lines.append(f'{ret} {name}({", ".join(params)}) {{')
         lines.append(f'    FILE* f = logf(); fprintf(f, "{name}");')
-        if name.endswith('_bytes') or name.endswith('_workspace'):
-            lines.append(f'    int rc = ((int (*)(const void*, size_t*))real("{name}"))({names[0]}, {names[1]});')
-            lines.append(f'    fprintf(f, " dims="); hex(f, {names[0]}, sizeof(*{names[0]}));')
-            lines.append(f'    fprintf(f, " -> rc=%d bytes=%zu\\n", rc, *{names[1]}); fflush(f); return rc;')
+        if name.endswith('_bytes') or name.endswith('_workspace'):      # size queries: answered by the real library
+            types = ', '.join(p.rsplit(' ', 1)[0] if '*' not in p.rsplit(' ', 1)[1] else p.rsplit('*', 1)[0] + '*'
+                              for p in params)
+            lines.append(f'    int rc = ((int (*)({types}))real("{name}"))({", ".join(names)});')
+            for p, n in zip(params[:-1], names[:-1]):
+                if '_dims*' in p:
+                    lines.append(f'    fprintf(f, " {n}="); hex(f, {n}, sizeof(*{n}));')
+                else:
+                    lines.append(f'    fprintf(f, " {n}=%lld", (long long){n});')
+            lines.append(f'    fprintf(f, " -> rc=%d bytes=%zu\\n", rc, *{names[-1]}); fflush(f); return rc;')
             lines.append('}')
             continue
         ptrs = [n for p, n in zip(params, names) if '*' in p and '_dims*' not in p and n != 'stream']

@@ -115,8 +115,7 @@ def drive(recorder):
         in_buckets = all(p.grad is v for (_, ps), vs in zip(buckets.buckets, buckets.grad_views) for p, v in zip(ps, vs))
         mark(f'gradient shapes ok: {shapes_ok and in_buckets}')
         mark(f'step {it}: clip + optimizer')
-        buckets.clip_grad_norm_(5.0)
-        opt.step()
+        opt.clip_and_step(5.0)
     mark('end')
 
 

@@ -169,3 +169,44 @@ def test_weight_shadows_match_the_torch_built_copies():
     y_shadow = ops._conv2d_launch(x, ent['wb'], None, 1, (1, 1), (1, 1), torch.bfloat16)
     ref_b = weights[0].detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     assert torch.equal(y_shadow, ops._conv2d_launch(x, ref_b, None, 1, (1, 1), (1, 1), torch.bfloat16))
+
+
+def test_fused_clip_adam_matches_the_torch_operator_path(monkeypatch):
+    """stp3_optim_clip_adam (STP3_FUSED_ADAM): one update from identical state == clip_grad_norm_ + FlatAdam.step."""
+    from stp3_amd import parallel
+    from stp3_amd.parallel import FlatAdam, GradientBuckets
+
+    def make():
+        torch.manual_seed(5)
+        return nn.Sequential(nn.Conv2d(3, 64, 3, padding=1), nn.BatchNorm2d(64), nn.ReLU(), nn.Conv2d(64, 64, 3, padding=1),
+                             nn.Flatten(), nn.Linear(64 * 6 * 6, 500), nn.ReLU(), nn.Linear(500, 5)).cuda()
+
+    ref_model, fus_model = make(), make()
+    ref_b, fus_b = GradientBuckets(ref_model, bucket_bytes=1 << 20), GradientBuckets(fus_model, bucket_bytes=1 << 20)
+    assert len(ref_b.buckets) >= 3
+    ref_opt = FlatAdam(ref_b, lr=1e-2, weight_decay=1e-3)
+    fus_opt = FlatAdam(fus_b, lr=1e-2, weight_decay=1e-3)
+    g = torch.Generator().manual_seed(2)
+    for it in range(3):
+        x = torch.randn(8, 3, 6, 6, generator=g).cuda()
+        ref_b.zero_grad()
+        ref_model(x).square().mean().backward()
+        ref_b.finish()
+        with torch.no_grad():
+            for k in range(len(ref_b.buckets)):
+                fus_b.buckets[k][0].copy_(ref_b.buckets[k][0])
+                fus_b.flat_params[k].copy_(ref_b.flat_params[k])
+                fus_opt.exp_avg[k].copy_(ref_opt.exp_avg[k])
+                fus_opt.exp_avg_sq[k].copy_(ref_opt.exp_avg_sq[k])
+            fus_opt.step_t.copy_(ref_opt.step_t)
+        max_norm = 0.05 if it != 1 else 1e9
+        n_ref = float(ref_opt.clip_and_step(max_norm))
+        monkeypatch.setattr(parallel, '_FUSED_ADAM', True)
+        n_fus = float(fus_opt.clip_and_step(max_norm))
+        monkeypatch.setattr(parallel, '_FUSED_ADAM', False)
+        assert abs(n_fus - n_ref) <= 1e-5 * n_ref and fus_opt.step_count == ref_opt.step_count == it + 1
+        for k in range(len(ref_b.buckets)):
+            torch.testing.assert_close(fus_b.buckets[k][0], ref_b.buckets[k][0], rtol=5e-5, atol=1e-10)
+            torch.testing.assert_close(fus_opt.exp_avg[k], ref_opt.exp_avg[k], rtol=5e-5, atol=1e-10)
+            torch.testing.assert_close(fus_opt.exp_avg_sq[k], ref_opt.exp_avg_sq[k], rtol=5e-5, atol=1e-12)
+            torch.testing.assert_close(fus_b.flat_params[k], ref_b.flat_params[k], rtol=1e-5, atol=1e-5)
