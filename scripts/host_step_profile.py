@@ -54,8 +54,7 @@ def main():
             loss = module.training_step(batch)
         loss.backward()
         buckets.finish()
-        buckets.clip_grad_norm_(cfg.GRAD_NORM_CLIP)
-        opt.step()
+        opt.clip_and_step(5.0)
 
     for _ in range(2):
         step()

@@ -35,8 +35,7 @@ def worker(recorder, log):
             loss = module.training_step(batch)
         loss.backward()
         buckets.finish()
-        buckets.clip_grad_norm_(5.0)
-        opt.step()
+        opt.clip_and_step(5.0)
 
     step()
     step()
@@ -60,7 +59,7 @@ def worker(recorder, log):
     print(f'top-level operators per step: {sum(top.values())}   torch operators that launch kernels: {aten_leaf}   '
           f'C-ABI launches: {sum(calls.values())}')
     print('  largest top-level groups: ' + ', '.join(f'{k.split(": ")[-1]} x{v}' for k, v in top.most_common(8)))
-    print('  torch kernels: ' + ', '.join(f'{k} x{v}' for k, v in kernels.most_common(14)))
+    print('  torch kernels: ' + ', '.join(f'{k} x{v}' for k, v in kernels.most_common(int(os.environ.get("CENSUS_TOP", "14")))))
     print('  C-ABI: ' + ', '.join(f'{k[5:]} x{v}' for k, v in calls.most_common()))
 
 
