@@ -5,11 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'st-p3_amd'))
 import torch
 from stp3_amd import ops
-from tests import helpers as H
+from stp3_amd import synthetic
 
-cfg = H.FULL
-intr, extr, ego, feat, logits = H.lift_inputs(cfg, 4, 3, 6, seed=31)
-frustum, res, start, dim = H.grid_params(cfg)
+(frustum, res, start, dim), intr, extr, ego, feat, logits = synthetic.lift_case(batch=4, seq=3, seed=31)
 grid = ops.LiftGrid(frustum, res, start, dim, 'cuda')
 plan = ops.LiftPlan.build(grid, intr, extr, ego, 64)
 f = feat.cuda().requires_grad_(True)

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'st-p3_amd'))
 import torch
 from stp3_amd import ops, _lib
-from tests import helpers as H
+from stp3_amd import synthetic
 
 def ev_time(fn, iters=20, warm=3):
     for _ in range(warm): fn()
@@ -16,9 +16,7 @@ def ev_time(fn, iters=20, warm=3):
     return s.elapsed_time(e) / iters * 1e3  # us
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-cfg = H.FULL
-intr, extr, ego, feat, logits = H.lift_inputs(cfg, B, 3, 6, seed=31)
-frustum, res, start, dim = H.grid_params(cfg)
+(frustum, res, start, dim), intr, extr, ego, feat, logits = synthetic.lift_case(batch=B, seq=3, seed=31)
 grid = ops.LiftGrid(frustum, res, start, dim, 'cuda')
 t0 = time.time(); plan = ops.LiftPlan.build(grid, intr, extr, ego, 64); torch.cuda.synchronize(); print('first plan build (host+dev) s', time.time() - t0)
 d = plan.dims

@@ -163,3 +163,25 @@ def make_batch(batch=1, seq=3, n_cams=6, final_dim=(224, 480), bev=(200, 200), s
     if gt_depth:
         out['depths'] = torch.randint(0, 61, (batch, seq, n_cams, *final_dim), generator=g).float()
     return out
+
+
+def lift_case(batch=4, seq=3, n_cams=6, final_dim=(224, 480), downsample=8, d_bound=(2.0, 50.0, 1.0),
+              x_bound=(-50.0, 50.0, 0.5), y_bound=(-50.0, 50.0, 0.5), z_bound=(-10.0, 10.0, 20.0), channels=64, seed=31):
+    """Inputs of the voxel pool alone, for kernel micro-benchmarks and counter runs (scripts/time_lift.py,
+    scripts/pmc_lift.py): ((frustum, bev_resolution, bev_start, bev_dimension), intrinsics, extrinsics,
+    future_egomotion, feat (B,S,N,C,fH,fW), depth_logits (B,S,N,D,fH,fW)).  Product-side constants only: the
+    frustum of ``STP3.create_frustum`` (stp3.py:111-130) and ``models.stp3.bev_parameters``."""
+    from .models.stp3 import bev_parameters
+    h, w = final_dim
+    fh, fw = h // downsample, w // downsample
+    depth = torch.arange(*d_bound, dtype=torch.float)
+    n_d = depth.shape[0]
+    frustum = torch.stack((torch.linspace(0, w - 1, fw, dtype=torch.float).view(1, 1, fw).expand(n_d, fh, fw),
+                           torch.linspace(0, h - 1, fh, dtype=torch.float).view(1, fh, 1).expand(n_d, fh, fw),
+                           depth.view(n_d, 1, 1).expand(n_d, fh, fw)), -1)
+    res, start, dim = bev_parameters(list(x_bound), list(y_bound), list(z_bound))
+    intr, extr, ego = make_rig(batch, seq, n_cams, final_dim, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    feat = torch.relu(torch.randn(batch, seq, n_cams, channels, fh, fw, generator=g))
+    logits = torch.randn(batch, seq, n_cams, n_d, fh, fw, generator=g) * 2.0
+    return (frustum, res, start, dim), intr, extr, ego, feat, logits
