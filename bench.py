@@ -194,7 +194,8 @@ def lift_roofline(device, batch, model, iters=30):
             traffic *= d.BT / float(pmc.get('frames_per_launch', 12))     # counters were collected at B=4, T=3
         except Exception:
             traffic = None
-    roof = {'kernel': 'stp3_lift_splat_fwd (lift_runs_kernel + lift_gather_kernel)', 'bound': 'hbm',
+    stage1 = 'lift_runs_mfma_kernel' if os.environ.get('STP3_LIFT_FWD') == 'mfma' else 'lift_runs_kernel'
+    roof = {'kernel': f'stp3_lift_splat_fwd ({stage1} + lift_gather_kernel)', 'bound': 'hbm',
             'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
             'traffic': traffic, 'algorithmic_bytes_per_launch': alg_fwd, 'avg_launch_ms': round(fwd_ms, 4),
             'launches': prof['lift_splat_fwd']['n'],

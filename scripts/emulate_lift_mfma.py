@@ -1,13 +1,13 @@
-"""Lane-level numpy model of `lift_bwd_mfma_kernel` (st-p3_amd/csrc/stp3_lift.hip).
+"""Lane-level numpy model of `lift_bwd_mfma_kernel` and `lift_runs_mfma_kernel` (st-p3_amd/csrc/stp3_lift.hip).
 
 The matrix-core backward of the voxel pool cannot be run in the build container (no GPU), so its
 index arithmetic -- LDS layout, run enumeration and chunking, MFMA operand / result lane maps
 (A[l&15][l>>4], B[l>>4][l&15], D[4*(l>>4)+q][l&15], cdna_hip_programming.md section 3) -- is
 mirrored here statement by statement and compared with the closed-form gradient of one image
 column.  This is a development aid, not a parity test: the GPU test of the real kernel is
-tests/test_lift_gpu.py run with STP3_LIFT_BWD=mfma.
+tests/test_lift_gpu.py run with STP3_LIFT_BWD=mfma / STP3_LIFT_FWD=mfma.
 
-    python scripts/emulate_lift_bwd_mfma.py
+    python scripts/emulate_lift_mfma.py
 """
 import numpy as np
 
@@ -151,6 +151,87 @@ def kernel_column(fH, D, C, V, feat, prob, vox, gacc, run_cap=RUN_CAP):
     return grad_feat, grad_logits
 
 
+FWD_ROWS, FWD_STRIDE_F = 32, 80
+
+
+def fwd_kernel_column(fH, D, C, feat, prob, vox, rb_col, dest_col, n_rows):
+    """lift_runs_mfma_kernel for one column.  rb_col [D+1]: exclusive scan of runs per bin (col_base = rb_col[0]);
+    dest_col [col_runs]: destination row of every run of the column.  -> runs [n_rows][C] (NaN = never written)."""
+    Dp = D | 1
+    cap = (fH * Dp + 15) & ~15
+    fcol = np.full(FWD_ROWS * FWD_STRIDE_F, np.nan, np.float32)
+    pcol = np.full(FWD_ROWS * Dp, np.nan, np.float32)
+    vcol = np.full(FWD_ROWS * Dp, -777, np.int64)
+    rdesc = np.full(cap, -12345, np.int64)
+    rdst = np.full(cap, -12345, np.int64)
+    out = np.full((n_rows, C), np.nan, np.float32)
+    lanes = np.arange(64)
+    for wv in range(4):
+        for i in range(FWD_ROWS // 4):
+            h = wv + 4 * i
+            row = h < fH
+            for lane in range(64):
+                fcol[h * FWD_STRIDE_F + lane] = feat[h, lane] if (row and lane < C) else 0.0
+                if lane < Dp:
+                    ok = row and lane < D
+                    pcol[h * Dp + lane] = prob[h, lane] if ok else 0.0
+                    vcol[h * Dp + lane] = vox[h, lane] if ok else -1
+    col_base, col_runs = rb_col[0], rb_col[D] - rb_col[0]
+    runs16 = (col_runs + 15) & ~15
+    for tid in range(256):
+        i = tid
+        while i < runs16:
+            rdst[i] = dest_col[i] if i < col_runs else -1
+            if i >= col_runs:
+                rdesc[i] = 0
+            i += 256
+    for tid in range(D):
+        idx, prev, h0 = rb_col[tid] - col_base, -1, 0
+        for h in range(fH + 1):
+            v = vcol[h * Dp + tid] if h < fH else -1
+            if v != prev:
+                if prev >= 0:
+                    rdesc[idx] = tid | (h0 << 8) | (h << 16)
+                    idx += 1
+                h0, prev = h, v
+    li, kk = lanes & 15, lanes >> 4
+    for wv in range(4):
+        if wv * 16 >= C:
+            continue
+        bq = [fcol[(4 * ks + kk) * FWD_STRIDE_F + wv * 16 + li] for ks in range(FWD_ROWS // 4)]
+        for r0 in range(0, runs16, 16):
+            desc = rdesc[r0 + li]
+            d, h0, h1 = desc & 255, (desc >> 8) & 255, desc >> 16
+            acc = np.zeros((64, 4), np.float32)
+            for ks in range(FWD_ROWS // 4):
+                h = 4 * ks + kk
+                a = np.where((h >= h0) & (h < h1), pcol[h * Dp + d], 0.0).astype(np.float32)
+                acc = mfma_16x16x4(a, bq[ks], acc)
+            for q in range(4):
+                row = rdst[r0 + 4 * kk + q]
+                sel = row >= 0
+                out[row[sel], (wv * 16 + li)[sel]] = acc[sel, q]
+    return out
+
+
+def fwd_reference(fH, D, C, feat, prob, vox, rb_col, dest_col, n_rows):
+    out = np.full((n_rows, C), np.nan, np.float64)
+    for d in range(D):
+        j, h = 0, 0
+        while h < fH:
+            v = vox[h, d]
+            h1 = h
+            while h1 < fH and vox[h1, d] == v:
+                h1 += 1
+            if v >= 0:
+                row = dest_col[rb_col[d] - rb_col[0] + j]
+                out[row] = (prob[h:h1, d].astype(np.float64)[:, None] * feat[h:h1].astype(np.float64)).sum(0)
+                j += 1
+            h = h1
+        assert j == rb_col[d + 1] - rb_col[d]
+    return out
+
+
 def closed_form(feat, prob, vox, gacc):
     fH, D = prob.shape
     g = np.where((vox >= 0)[..., None], gacc[np.maximum(vox, 0)], 0.0).astype(np.float64)   # [fH][D][C]
@@ -200,7 +281,26 @@ def main():
         print(f'fH={fH} D={D} C={C} runs/col={int((np.diff(vox, axis=0, prepend=-7) != 0).sum())}: '
               f'dfeat rel err {ef:.2e}, dlogit rel err {el:.2e}')
         assert ef < 1e-5 and el < 1e-5
-    print('OK, worst', worst)
+    print('backward OK, worst', worst)
+    # forward: stage 1 as a GEMM per column
+    worst = 0.0
+    for fH, D, C, V, mr, pi, _ in cases:
+        feat, prob, vox, _ = random_column(rng, fH, D, C, V, mr, pi)
+        starts = (np.diff(vox, axis=0, prepend=-7) != 0) & (vox >= 0)
+        per_bin = starts.sum(0)
+        rb_col = 1000 + np.concatenate([[0], np.cumsum(per_bin)])          # col_base = 1000: ids are plan-global
+        col_runs = int(per_bin.sum())
+        n_rows = col_runs + 9
+        dest_col = rng.permutation(n_rows)[:col_runs]
+        got = fwd_kernel_column(fH, D, C, feat, prob, vox, rb_col, dest_col, n_rows)
+        ref = fwd_reference(fH, D, C, feat, prob, vox, rb_col, dest_col, n_rows)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), 'rows written / left alone differ'
+        m = ~np.isnan(ref)
+        err = np.abs(got[m] - ref[m]).max() / max(np.abs(ref[m]).max(), 1e-6) if m.any() else 0.0
+        worst = max(worst, err)
+        print(f'fwd fH={fH} D={D} C={C} runs/col={col_runs}: rel err {err:.2e}')
+        assert err < 1e-5
+    print('forward OK, worst', worst)
 
 
 if __name__ == '__main__':

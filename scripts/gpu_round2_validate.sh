@@ -4,9 +4,9 @@
 TAG=${1:-r02a}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 run() { echo "=== $*"; "$@" 2>&1 | grep -v "amdgpu.ids\|MIOpen(HIP)" | tail -${TAILN:-4}; }
 TAILN=4 run env STP3_EXPERIMENTAL=1 STP3_BN_GEOM=1 timeout 200 python -m pytest tests/test_conv_v2_gpu.py tests/test_bnact_gpu.py -q -x
-TAILN=4 run env STP3_LIFT_BWD=mfma timeout 300 python -m pytest tests/test_lift_gpu.py -q -x
+TAILN=4 run env STP3_LIFT_BWD=mfma STP3_LIFT_FWD=mfma timeout 300 python -m pytest tests/test_lift_gpu.py -q -x
 TAILN=4 run env STP3_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_lift_stress_gpu.py -q -x
-TAILN=10 run env STP3_LIFT_BWD=mfma timeout 100 python scripts/time_lift.py
+TAILN=10 run env STP3_LIFT_BWD=mfma STP3_LIFT_FWD=mfma timeout 100 python scripts/time_lift.py
 TAILN=6 run env STP3_CPP_OPS=1 timeout 400 python -m pytest tests -m gpu -q -x
 TAILN=12 run env STP3_BN_GEOM=0 timeout 100 python scripts/time_bn.py
 TAILN=12 run env STP3_BN_GEOM=1 timeout 100 python scripts/time_bn.py
@@ -17,7 +17,7 @@ WL=perception bench base_perception STP3_BN_GEOM=0     # continuity with the rou
 bench bngeom STP3_BN_GEOM=1
 bench se STP3_BN_GEOM=1 STP3_FUSED_SE=1
 bench convv2 STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1
-bench liftmfma STP3_BN_GEOM=0 STP3_LIFT_BWD=mfma
+bench liftmfma STP3_BN_GEOM=0 STP3_LIFT_BWD=mfma STP3_LIFT_FWD=mfma
 bench mfmaall STP3_MFMA_CONV=all
 bench wgrad64 STP3_WGRAD_MIN_CHANNELS=64
 bench gather STP3_GRAD_GATHER=1
@@ -26,4 +26,4 @@ bench labelwarp STP3_LABEL_WARP=batched
 bench fusedadam STP3_FUSED_ADAM=1
 bench cpp STP3_BN_GEOM=1 STP3_CPP_OPS=1
 bench trunkfused STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1 STP3_MFMA_CONV=all
-bench all STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1 STP3_MFMA_CONV=all STP3_WEIGHT_PREP=1 STP3_GRAD_GATHER=1 STP3_LIFT_BWD=mfma STP3_LABEL_WARP=batched STP3_FUSED_ADAM=1
+bench all STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1 STP3_MFMA_CONV=all STP3_WEIGHT_PREP=1 STP3_GRAD_GATHER=1 STP3_LIFT_BWD=mfma STP3_LIFT_FWD=mfma STP3_LABEL_WARP=batched STP3_FUSED_ADAM=1

@@ -821,6 +821,103 @@ __global__ __launch_bounds__(256) void lift_bwd_mfma_kernel(Dims dm, int Dp, con
     }
 }
 
+// (c) EXPERIMENTAL (STP3_LIFT_FWD=mfma): stage 1 of the forward on the fp32 matrix cores.  With the column's runs
+//     r = (depth bin d_r, rows [h0_r, h1_r)) the run vectors are one small GEMM per image column,
+//         R[r][c] = sum_h Phat[r][h] * feat[h][c],   Phat[r][h] = prob[h][d_r] if h0_r <= h < h1_r else 0
+//     ([runs x fH] x [fH x C]; v_mfma_f32_16x16x4_f32 is an exact fp32 FMA chain over h in ascending order, the
+//     same order the lane-per-bin kernel adds in).  Wave w owns the 16-channel slice w and walks the 16-run tiles;
+//     B (the feature rows) is loaded into registers once per column, A is built from the run descriptors.
+//     The column's run ids are contiguous in the plan, their destination rows are staged with one coalesced read.
+constexpr int kFwdRows = 32;      // image rows covered by the 8 k-steps
+constexpr int kFwdStrideF = 80;   // feature row stride in LDS: 16-lane groups of consecutive k land on disjoint banks
+
+inline size_t lift_runs_mfma_lds(int fH, int Dp) {
+    const size_t cap = (((size_t)fH * Dp) + 15) & ~(size_t)15;               // worst case: every point its own run
+    return ((size_t)kFwdRows * kFwdStrideF + 2 * (size_t)kFwdRows * Dp + 2 * cap) * sizeof(float);
+}
+
+__global__ __launch_bounds__(256) void lift_runs_mfma_kernel(Dims dm, int Dp, const float* __restrict__ feat,
+                                                             const float* __restrict__ prob,
+                                                             const int32_t* __restrict__ vox_pm,
+                                                             const int32_t* __restrict__ run_base,
+                                                             const int32_t* __restrict__ dest,
+                                                             float* __restrict__ runs) {
+    extern __shared__ float smem[];
+    float* fcol = smem;                                              // [32][80]
+    float* pcol = fcol + kFwdRows * kFwdStrideF;                     // [32][Dp]
+    int* vcol = (int*)(pcol + kFwdRows * Dp);                        // [32][Dp]
+    const int cap = (dm.fH * Dp + 15) & ~15;
+    int* rdesc = vcol + kFwdRows * Dp;                               // [cap] d | h0 << 8 | h1 << 16
+    int* rdst = rdesc + cap;                                         // [cap] row of the run in `runs` (-1: padding)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = blockIdx.x, bt = blockIdx.y;
+    const int n = col / dm.fW, w = col - n * dm.fW;
+    const size_t pix0 = (size_t)bt * dm.NPIX + (size_t)n * dm.fH * dm.fW + w;
+
+    // ---- stage the column (rows >= fH, channels >= C, bins >= D are zero / -1) ----
+#pragma unroll
+    for (int i = 0; i < kFwdRows / 4; ++i) {
+        const int h = wv + 4 * i;
+        const size_t gp = pix0 + (size_t)h * dm.fW;
+        const bool row = h < dm.fH;
+        fcol[h * kFwdStrideF + lane] = (row && lane < dm.C) ? feat[gp * dm.C + lane] : 0.f;
+        if (lane < Dp) {
+            const bool ok = row && lane < dm.D;
+            pcol[h * Dp + lane] = ok ? prob[gp * dm.D + lane] : 0.f;
+            vcol[h * Dp + lane] = ok ? vox_pm[gp * dm.D + lane] : -1;
+        }
+    }
+    const int32_t* rb_col = run_base + (size_t)bt * (dm.NQ + 1) + (size_t)col * dm.D;
+    const int col_base = rb_col[0], col_runs = rb_col[dm.D] - col_base;
+    const int runs16 = (col_runs + 15) & ~15;
+    const int32_t* dst = dest + (size_t)bt * dm.P + col_base;
+    for (int i = tid; i < runs16; i += 256) {
+        rdst[i] = i < col_runs ? dst[i] : -1;
+        if (i >= col_runs) rdesc[i] = 0;                             // empty row range
+    }
+    __syncthreads();
+    // ---- describe the runs: thread = depth bin, ids in plan order (bin-major, rows ascending) ----
+    if (tid < dm.D) {
+        int idx = rb_col[tid] - col_base, prev = -1, h0 = 0;
+        for (int h = 0; h <= dm.fH; ++h) {
+            const int v = h < dm.fH ? vcol[h * Dp + tid] : -1;
+            if (v != prev) {
+                if (prev >= 0) rdesc[idx++] = tid | (h0 << 8) | (h << 16);
+                h0 = h;
+                prev = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (wv * 16 >= dm.C) return;
+
+    // ---- R = Phat x F: B fragments (feature rows of this wave's 16 channels) live in registers ----
+    const int li = lane & 15, kk = lane >> 4;
+    float bq[kFwdRows / 4];
+#pragma unroll
+    for (int ks = 0; ks < kFwdRows / 4; ++ks) bq[ks] = fcol[(4 * ks + kk) * kFwdStrideF + wv * 16 + li];
+    float* out = runs + (size_t)bt * dm.P * dm.C + wv * 16 + li;
+    for (int r0 = 0; r0 < runs16; r0 += 16) {
+        const int desc = rdesc[r0 + li];
+        const int d = desc & 255, h0 = (desc >> 8) & 255, h1 = desc >> 16;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < kFwdRows / 4; ++ks) {
+            const int h = 4 * ks + kk;
+            const float a = (h >= h0 && h < h1) ? pcol[h * Dp + d] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq[ks], acc, 0, 0, 0);
+        }
+        // lane holds runs r0 + 4*kk + q (q = 0..3), channel 16*wv + li
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = rdst[r0 + 4 * kk + q];
+            if (row >= 0) out[(size_t)row * dm.C] = acc[q];
+        }
+    }
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -926,6 +1023,22 @@ int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const flo
     const int ndg = (dm.D + 7) / 8;                        // waves per column: 8 depth bins each
     const int Dp = ndg * 8;
     const size_t lds = ((size_t)dm.fH * 64 + 3 * (size_t)dm.fH * Dp) * sizeof(float);
+    // experimental matrix-core variant of stage 1, opt-in (see lift_runs_mfma_kernel)
+    static const bool want_mfma = [] {
+        const char* e = getenv("STP3_LIFT_FWD");
+        return e && !strcmp(e, "mfma");
+    }();
+    if (want_mfma && dm.fH <= kFwdRows && dm.C % 16 == 0 && dm.D <= 64 && dm.BT <= 65535) {
+        const int Dq = dm.D | 1;
+        const size_t lds_m = lift_runs_mfma_lds(dm.fH, Dq);
+        if (lds_m <= 64 * 1024) {
+            hipLaunchKernelGGL(lift_runs_mfma_kernel, dim3(dm.NCOL, dm.BT), dim3(256), lds_m, s, dm, Dq, feat, prob, vox_pm,
+                               pv.run_base, pv.dest, (float*)workspace);
+            hipLaunchKernelGGL(lift_gather_kernel, dim3((dm.V + kTileV - 1) / kTileV, dm.B), dim3(256), 0, s, dm,
+                               (const float*)workspace, pv.vox_off, discount, bev);
+            return launch_status();
+        }
+    }
     if (lds > 160 * 1024) return STP3_EUNSUP;
     if (lds > 64 * 1024) {
         // tall feature maps (BASELINE configs[4]: 112 rows x 64 bins = 112 KB per column): above the default
