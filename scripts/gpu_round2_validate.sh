@@ -24,6 +24,7 @@ bench gather STP3_GRAD_GATHER=1
 bench wprep STP3_WEIGHT_PREP=1
 bench labelwarp STP3_LABEL_WARP=batched
 bench fusedadam STP3_FUSED_ADAM=1
+bench lazycount STP3_LAZY_BN_COUNTER=1
 bench cpp STP3_BN_GEOM=1 STP3_CPP_OPS=1
 bench trunkfused STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1 STP3_MFMA_CONV=all
-bench all STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1 STP3_MFMA_CONV=all STP3_WEIGHT_PREP=1 STP3_GRAD_GATHER=1 STP3_LIFT_BWD=mfma STP3_LIFT_FWD=mfma STP3_LABEL_WARP=batched STP3_FUSED_ADAM=1
+bench all STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1 STP3_MFMA_CONV=all STP3_WEIGHT_PREP=1 STP3_GRAD_GATHER=1 STP3_LIFT_BWD=mfma STP3_LIFT_FWD=mfma STP3_LABEL_WARP=batched STP3_FUSED_ADAM=1 STP3_LAZY_BN_COUNTER=1

@@ -122,3 +122,29 @@ def test_batched_label_warp_equals_per_label_warps():
         for k in old:
             assert old[k].dtype == new[k].dtype and torch.equal(old[k], new[k]), k
         assert (old['segmentation'][:, 0] != batch['segmentation'][:, 0]).any()
+
+
+def test_lazy_batch_counters_match_immediate_increments(monkeypatch):
+    """STP3_LAZY_BN_COUNTER: num_batches_tracked counted on the host, applied by flush / before state_dict()."""
+    import torch
+    import torch.nn as nn
+    from stp3_amd import ops
+    from stp3_amd.layers import fused
+    monkeypatch.setattr(fused, '_LAZY_COUNTERS', True)
+    monkeypatch.setattr(torch.Tensor, 'is_cuda', property(lambda self: True))
+    monkeypatch.setattr(ops, 'bn_act', lambda x, *a, **k: x)              # the kernel path is not under test here
+    a, b, c = nn.BatchNorm2d(4), nn.BatchNorm2d(4), nn.BatchNorm2d(4, momentum=None)
+    x = torch.randn(2, 4, 3, 3)
+    for _ in range(3):
+        fused.bn_act(a, x)
+    fused.bn_act(b, x)
+    fused.bn_act(c, x)                                    # cumulative-average mode: immediate
+    assert int(c.num_batches_tracked) == 1 and int(a.num_batches_tracked) == 0
+    assert int(a.state_dict()['num_batches_tracked']) == 3          # the pre-hook flushed every pending counter
+    assert int(b.num_batches_tracked) == 1
+    fused.bn_act(a, x)
+    a.eval()
+    fused.bn_act(a, x)                                    # evaluation does not count
+    fused.flush_batch_counters()
+    fused.flush_batch_counters()
+    assert int(a.num_batches_tracked) == 4 and not fused._PENDING_COUNTS
