@@ -85,37 +85,7 @@ def bn_act_reference(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=Non
     return y
 
 
-# EXPERIMENTAL (STP3_LAZY_BN_COUNTER=1): ``num_batches_tracked`` -- one int64 increment KERNEL per BatchNorm layer and
-# step in the reference -- is counted on the host and applied to all layers with one multi-tensor add, at the end of
-# the optimizer step (parallel.FlatAdam) and before any ``state_dict()`` of a BatchNorm module.  The counter only
-# feeds the cumulative-average mode (momentum=None), which keeps the immediate increment.
-_LAZY_COUNTERS = os.environ.get('STP3_LAZY_BN_COUNTER', '0') == '1'
-_PENDING_COUNTS = {}          # id(buffer) -> [buffer, increments]
-
-
-def _count_later(bn):
-    t = bn.num_batches_tracked
-    ent = _PENDING_COUNTS.get(id(t))
-    if ent is None or ent[0] is not t:
-        _PENDING_COUNTS[id(t)] = [t, 1]
-        if not getattr(bn, '_stp3_counter_hook', False):
-            bn.register_state_dict_pre_hook(lambda module, prefix, keep_vars: flush_batch_counters())
-            bn._stp3_counter_hook = True
-    else:
-        ent[1] += 1
-
-
-def flush_batch_counters():
-    """Apply the increments counted since the last flush (no-op when there are none)."""
-    if not _PENDING_COUNTS:
-        return
-    by_count = {}
-    for t, k in _PENDING_COUNTS.values():
-        by_count.setdefault(k, []).append(t)
-    _PENDING_COUNTS.clear()
-    with torch.no_grad():
-        for k, tensors in by_count.items():
-            torch._foreach_add_(tensors, k)
+flush_batch_counters = ops.flush_batch_counters          # re-export (parallel.FlatAdam, tests)
 
 
 def bn_act(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=None):
@@ -131,10 +101,7 @@ def bn_act(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=
         x = x.to(torch.get_autocast_gpu_dtype())
     training = bn.training or not bn.track_running_stats
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        if _LAZY_COUNTERS and bn.momentum is not None:
-            _count_later(bn)
-        else:
-            bn.num_batches_tracked.add_(1)
+        ops.bump_batch_counter(bn)
     group = None if _sync_world(bn) > 1 else False
     return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                       bn.running_var if bn.track_running_stats else None, training, bn.momentum, bn.eps,

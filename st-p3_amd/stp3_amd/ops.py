@@ -438,6 +438,47 @@ def depthwise_conv2d(x, weight, stride=1, pad=(0, 0, 0, 0)):
     return _DW_APPLY(x, weight, int(stride), tuple(int(p) for p in pad))
 
 
+# EXPERIMENTAL (STP3_LAZY_BN_COUNTER=1): ``num_batches_tracked`` -- one int64 increment KERNEL per BatchNorm layer and
+# step in the reference -- is counted on the host and applied to all layers with one multi-tensor add, at the end of
+# the optimizer step (parallel.FlatAdam) and before any ``state_dict()`` of a BatchNorm module.  The counter only
+# feeds the cumulative-average mode (momentum=None), which keeps the immediate increment.
+LAZY_COUNTERS = os.environ.get('STP3_LAZY_BN_COUNTER', '0') == '1'
+_PENDING_COUNTS = {}          # id(buffer) -> [buffer, increments]
+
+
+def _count_later(bn):
+    t = bn.num_batches_tracked
+    ent = _PENDING_COUNTS.get(id(t))
+    if ent is None or ent[0] is not t:
+        _PENDING_COUNTS[id(t)] = [t, 1]
+        if not getattr(bn, '_stp3_counter_hook', False):
+            bn.register_state_dict_pre_hook(lambda module, prefix, keep_vars: flush_batch_counters())
+            bn._stp3_counter_hook = True
+    else:
+        ent[1] += 1
+
+
+def flush_batch_counters():
+    """Apply the increments counted since the last flush (no-op when there are none)."""
+    if not _PENDING_COUNTS:
+        return
+    by_count = {}
+    for t, k in _PENDING_COUNTS.values():
+        by_count.setdefault(k, []).append(t)
+    _PENDING_COUNTS.clear()
+    with torch.no_grad():
+        for k, tensors in by_count.items():
+            torch._foreach_add_(tensors, k)
+
+
+def bump_batch_counter(bn):
+    """``bn.num_batches_tracked += 1`` for a training-mode forward of ``bn`` (immediately, or counted for the flush)."""
+    if LAZY_COUNTERS and bn.momentum is not None:
+        _count_later(bn)
+    else:
+        bn.num_batches_tracked.add_(1)
+
+
 # ----------------------------------------------------------------------------------------------
 # fused BatchNorm (+ per-sample bias) + activation (+ residual), cross-replica statistics
 # ----------------------------------------------------------------------------------------------

@@ -176,7 +176,7 @@ def conv_bn_act(x, weight, cbias, bn, act=ops.ACT_NONE, res=None, res_mode=ops.R
                 group=None, oscale=None):
     """Training-mode conv -> BatchNorm -> activation (-> + skip) through the fused kernels (GPU, bf16)."""
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        ops.bump_batch_counter(bn)
     s = ops._pair(stride)
     return _ConvBnAct.apply(x, weight, cbias, bn.weight, bn.bias, res, bn.running_mean if bn.track_running_stats else None,
                             bn.running_var if bn.track_running_stats else None,

@@ -218,9 +218,8 @@ class FlatAdam:
             denom = (v.sqrt() / bc2_sqrt).add_(self.eps)
             param.sub_((m / denom) * step_size)
         from . import ops
-        from .layers import fused
         ops.invalidate_weight_cache()        # the parameters are views of `param`: their version counters did not move
-        fused.flush_batch_counters()         # STP3_LAZY_BN_COUNTER: num_batches_tracked of all layers, one launch
+        ops.flush_batch_counters()           # STP3_LAZY_BN_COUNTER: num_batches_tracked of all layers, one launch
 
     def clip_and_step(self, max_norm):
         """Gradient-norm clipping followed by the Adam update (the tail of every training step).  Default: the
@@ -257,8 +256,7 @@ class FlatAdam:
             float(b1), float(b2), float(self.eps), float(self.weight_decay), ops._ptr(self._state),
             ops._ptr(self._workspace), self._workspace.numel(), ops._stream()), 'stp3_optim_clip_adam')
         ops.invalidate_weight_cache()
-        from .layers import fused
-        fused.flush_batch_counters()
+        ops.flush_batch_counters()
         return self._state[4]
 
     def state_dict(self):

@@ -130,7 +130,7 @@ def test_lazy_batch_counters_match_immediate_increments(monkeypatch):
     import torch.nn as nn
     from stp3_amd import ops
     from stp3_amd.layers import fused
-    monkeypatch.setattr(fused, '_LAZY_COUNTERS', True)
+    monkeypatch.setattr(ops, 'LAZY_COUNTERS', True)
     monkeypatch.setattr(torch.Tensor, 'is_cuda', property(lambda self: True))
     monkeypatch.setattr(ops, 'bn_act', lambda x, *a, **k: x)              # the kernel path is not under test here
     a, b, c = nn.BatchNorm2d(4), nn.BatchNorm2d(4), nn.BatchNorm2d(4, momentum=None)
@@ -147,4 +147,4 @@ def test_lazy_batch_counters_match_immediate_increments(monkeypatch):
     fused.bn_act(a, x)                                    # evaluation does not count
     fused.flush_batch_counters()
     fused.flush_batch_counters()
-    assert int(a.num_batches_tracked) == 4 and not fused._PENDING_COUNTS
+    assert int(a.num_batches_tracked) == 4 and not ops._PENDING_COUNTS
