@@ -308,6 +308,29 @@ int stp3_se_pool(const stp3_se_dims* dims, const void* x, const void* dy, void* 
 int stp3_se_scale(const stp3_se_dims* dims, const void* x, const float* gate, const float* add, void* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The two fully-connected layers of a squeeze-and-excitation block (csrc/stp3_se_mlp.hip; EXPERIMENTAL, host side
+ * selected with STP3_SE_MLP=1 on top of STP3_FUSED_SE=1): the MBConv gate
+ *     gate = sigmoid(W2 swish(W1 mean_hw(x) + b1) + b2)
+ * (efficientnet_pytorch MBConvBlock as driven by stp3/models/encoder.py:57-97) and its backward, float32.
+ *   pooled_sum [N][C] : sum over the map (stp3_se_pool); the mean is pooled_sum * inv_rows
+ *   w1 [S][C], b1 [S], w2 [C][S], b2 [C]
+ *   fwd : z1 [N][S] (pre-activation, kept for the backward), gate [N][C]
+ *   bwd : dgate [N][C] = sum_hw dy * x (stp3_se_pool with dy)  ->  dpooled [N][C] (gradient at pooled_sum... of the
+ *         MEAN, already scaled by inv_rows, i.e. what stp3_se_scale adds per pixel), dw1 [S][C], db1 [S], dw2 [C][S],
+ *         db2 [C]; dz2 [N][C] and dz1 [N][S] are caller-provided scratch.  Samples are reduced in ascending order.
+ * Limits: (C + 2 S) and 2 N S floats must fit in 60 KB of LDS, else STP3_EUNSUP. */
+typedef struct stp3_se_mlp_dims {
+    int32_t N, C, S;
+    float inv_rows;
+} stp3_se_mlp_dims;
+
+int stp3_se_mlp_fwd(const stp3_se_mlp_dims* dims, const float* pooled_sum, const float* w1, const float* b1,
+                    const float* w2, const float* b2, float* z1, float* gate, void* stream);
+int stp3_se_mlp_bwd(const stp3_se_mlp_dims* dims, const float* dgate, const float* gate, const float* pooled_sum,
+                    const float* z1, const float* w1, const float* w2, float* dz2, float* dz1, float* dpooled,
+                    float* dw1, float* db1, float* dw2, float* db2, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * bf16 shadow copies of all convolution weights in ONE launch (csrc/stp3_wprep.hip; EXPERIMENTAL, host side
  * selected with STP3_WEIGHT_PREP=1).  Replaces the per-layer cast / flip / transpose / re-layout the host would
  * otherwise redo after every optimizer step for the operands of stp3_conv2d_fwd (forward: [Cout][KH][KW][Cin];

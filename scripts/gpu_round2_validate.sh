@@ -16,6 +16,7 @@ bench base STP3_BN_GEOM=0
 WL=perception bench base_perception STP3_BN_GEOM=0     # continuity with the round-1 numbers (88.5 ms/step)
 bench bngeom STP3_BN_GEOM=1
 bench se STP3_BN_GEOM=1 STP3_FUSED_SE=1
+bench semlp STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_SE_MLP=1
 bench convv2 STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1
 bench liftmfma STP3_BN_GEOM=0 STP3_LIFT_BWD=mfma STP3_LIFT_FWD=mfma
 bench mfmaall STP3_MFMA_CONV=all
@@ -27,4 +28,4 @@ bench fusedadam STP3_FUSED_ADAM=1
 bench lazycount STP3_LAZY_BN_COUNTER=1
 bench cpp STP3_BN_GEOM=1 STP3_CPP_OPS=1
 bench trunkfused STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1 STP3_MFMA_CONV=all
-bench all STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1 STP3_MFMA_CONV=all STP3_WEIGHT_PREP=1 STP3_GRAD_GATHER=1 STP3_LIFT_BWD=mfma STP3_LIFT_FWD=mfma STP3_LABEL_WARP=batched STP3_FUSED_ADAM=1 STP3_LAZY_BN_COUNTER=1
+bench all STP3_BN_GEOM=1 STP3_FUSED_SE=1 STP3_CONV_V2=1 STP3_MFMA_CONV=all STP3_WEIGHT_PREP=1 STP3_GRAD_GATHER=1 STP3_LIFT_BWD=mfma STP3_LIFT_FWD=mfma STP3_LABEL_WARP=batched STP3_FUSED_ADAM=1 STP3_LAZY_BN_COUNTER=1 STP3_SE_MLP=1

@@ -1,0 +1,192 @@
+// stp3_se_mlp.hip -- the two tiny fully-connected layers of a squeeze-and-excitation block as single launches.
+//
+// An MBConv block's gate is  sigmoid(W2 swish(W1 mean_hw(x) + b1) + b2)  on (N, C) / (N, S) tensors with
+// N = B*T*cameras = 72, C <= 960, S <= 40 in the EfficientNet-B4 trunk (stp3/models/encoder.py:57-97 drives
+// efficientnet_pytorch's MBConvBlock).  Written with torch operators that is ~10 launches forward and ~15 backward
+// per block, 22 blocks per step, every one of them launch-latency bound.  Here: one launch forward (a workgroup per
+// sample), two backward (per-sample chain, then the weight gradients reduced over the samples in a fixed order).
+// EXPERIMENTAL: host side selected with STP3_SE_MLP=1 on top of STP3_FUSED_SE=1.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "stp3_hip.h"
+
+namespace {
+
+inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? STP3_OK : -(int)e;
+}
+
+__device__ __forceinline__ float wave_sum_xor(float v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
+
+// forward: grid = N, LDS = (C + S) floats
+__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(stp3_se_mlp_dims d, const float* __restrict__ pooled_sum,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         float* __restrict__ z1, float* __restrict__ gate) {
+    extern __shared__ float smem[];
+    float* p = smem;            // [C] pooled mean
+    float* h = smem + d.C;      // [S] swish(z1)
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < d.C; c += 256) p[c] = pooled_sum[(size_t)n * d.C + c] * d.inv_rows;
+    __syncthreads();
+    for (int s = wave; s < d.S; s += 4) {
+        float acc = 0.f;
+        for (int c = lane; c < d.C; c += 64) acc = fmaf(w1[(size_t)s * d.C + c], p[c], acc);
+        acc = wave_sum_xor(acc);
+        if (lane == 0) {
+            const float z = acc + b1[s];
+            z1[(size_t)n * d.S + s] = z;
+            h[s] = z * sigmoidf_(z);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < d.C; c += 256) {
+        float a = b2[c];
+        for (int s = 0; s < d.S; ++s) a = fmaf(w2[(size_t)c * d.S + s], h[s], a);
+        gate[(size_t)n * d.C + c] = sigmoidf_(a);
+    }
+}
+
+// backward, per sample: dz2 = dgate * gate * (1 - gate); dh = dz2 W2; dz1 = dh * swish'(z1); dpooled = dz1 W1 / rows
+// grid = N, LDS = (C + 2 S) floats
+__global__ __launch_bounds__(256) void se_mlp_bwd_sample_kernel(stp3_se_mlp_dims d, const float* __restrict__ dgate,
+                                                                const float* __restrict__ gate,
+                                                                const float* __restrict__ z1,
+                                                                const float* __restrict__ w1,
+                                                                const float* __restrict__ w2, float* __restrict__ dz2,
+                                                                float* __restrict__ dz1, float* __restrict__ dpooled) {
+    extern __shared__ float smem[];
+    float* g2 = smem;               // [C] dz2 of this sample
+    float* g1 = smem + d.C;         // [S] dz1 of this sample
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < d.C; c += 256) {
+        const float g = gate[(size_t)n * d.C + c];
+        const float v = dgate[(size_t)n * d.C + c] * g * (1.0f - g);
+        g2[c] = v;
+        dz2[(size_t)n * d.C + c] = v;
+    }
+    __syncthreads();
+    for (int s = wave; s < d.S; s += 4) {
+        float acc = 0.f;
+        for (int c = lane; c < d.C; c += 64) acc = fmaf(g2[c], w2[(size_t)c * d.S + s], acc);
+        acc = wave_sum_xor(acc);
+        if (lane == 0) {
+            const float z = z1[(size_t)n * d.S + s];
+            const float sg = sigmoidf_(z);
+            const float v = acc * sg * (1.0f + z * (1.0f - sg));
+            g1[s] = v;
+            dz1[(size_t)n * d.S + s] = v;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < d.C; c += 256) {
+        float a = 0.f;
+        for (int s = 0; s < d.S; ++s) a = fmaf(g1[s], w1[(size_t)s * d.C + c], a);
+        dpooled[(size_t)n * d.C + c] = a * d.inv_rows;
+    }
+}
+
+// backward, weights: thread = channel c, samples added in ascending order (deterministic)
+//   dw2[c][s] = sum_n dz2[n][c] swish(z1[n][s]);  db2[c] = sum_n dz2[n][c]
+//   dw1[s][c] = sum_n dz1[n][s] pooled[n][c];      db1[s] = sum_n dz1[n][s]   (workgroup 0)
+// LDS = 2 * N * S floats (swish(z1) and dz1 of all samples)
+constexpr int kSChunk = 8;
+
+__global__ __launch_bounds__(256) void se_mlp_bwd_weight_kernel(stp3_se_mlp_dims d, const float* __restrict__ pooled_sum,
+                                                                const float* __restrict__ z1,
+                                                                const float* __restrict__ dz2,
+                                                                const float* __restrict__ dz1, float* __restrict__ dw1,
+                                                                float* __restrict__ db1, float* __restrict__ dw2,
+                                                                float* __restrict__ db2) {
+    extern __shared__ float smem[];
+    float* hs = smem;                         // [N][S]
+    float* g1 = smem + (size_t)d.N * d.S;     // [N][S]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < d.N * d.S; i += 256) {
+        const float z = z1[i];
+        hs[i] = z * sigmoidf_(z);
+        g1[i] = dz1[i];
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < d.S) {
+        float a = 0.f;
+        for (int n = 0; n < d.N; ++n) a += g1[n * d.S + tid];
+        db1[tid] = a;
+    }
+    const int c = blockIdx.x * 256 + tid;
+    if (c >= d.C) return;
+    float sb = 0.f;
+    for (int s0 = 0; s0 < d.S; s0 += kSChunk) {
+        float a2[kSChunk], a1[kSChunk];
+#pragma unroll
+        for (int k = 0; k < kSChunk; ++k) a2[k] = a1[k] = 0.f;
+        for (int n = 0; n < d.N; ++n) {
+            const float x2 = dz2[(size_t)n * d.C + c];
+            const float pc = pooled_sum[(size_t)n * d.C + c] * d.inv_rows;
+            if (s0 == 0) sb += x2;
+#pragma unroll
+            for (int k = 0; k < kSChunk; ++k) {
+                const int s = s0 + k;
+                const float hv = s < d.S ? hs[n * d.S + s] : 0.f;
+                const float gv = s < d.S ? g1[n * d.S + s] : 0.f;
+                a2[k] = fmaf(x2, hv, a2[k]);
+                a1[k] = fmaf(gv, pc, a1[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kSChunk; ++k) {
+            const int s = s0 + k;
+            if (s < d.S) {
+                dw2[(size_t)c * d.S + s] = a2[k];
+                dw1[(size_t)s * d.C + c] = a1[k];
+            }
+        }
+    }
+    db2[c] = sb;
+}
+
+inline int check(const stp3_se_mlp_dims* d) {
+    if (!d) return STP3_EINVAL;
+    if (d->N <= 0 || d->C <= 0 || d->S <= 0) return STP3_EINVAL;
+    if ((size_t)(d->C + 2 * d->S) * 4 > 60 * 1024 || (size_t)2 * d->N * d->S * 4 > 60 * 1024) return STP3_EUNSUP;
+    return STP3_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int stp3_se_mlp_fwd(const stp3_se_mlp_dims* dims, const float* pooled_sum, const float* w1, const float* b1,
+                    const float* w2, const float* b2, float* z1, float* gate, void* stream) {
+    int rc = check(dims);
+    if (rc) return rc;
+    if (!pooled_sum || !w1 || !b1 || !w2 || !b2 || !z1 || !gate) return STP3_EINVAL;
+    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(dims->N), dim3(256), (size_t)(dims->C + dims->S) * 4, (hipStream_t)stream,
+                       *dims, pooled_sum, w1, b1, w2, b2, z1, gate);
+    return launch_status();
+}
+
+int stp3_se_mlp_bwd(const stp3_se_mlp_dims* dims, const float* dgate, const float* gate, const float* pooled_sum,
+                    const float* z1, const float* w1, const float* w2, float* dz2, float* dz1, float* dpooled,
+                    float* dw1, float* db1, float* dw2, float* db2, void* stream) {
+    int rc = check(dims);
+    if (rc) return rc;
+    if (!dgate || !gate || !pooled_sum || !z1 || !w1 || !w2 || !dz2 || !dz1 || !dpooled || !dw1 || !db1 || !dw2 || !db2)
+        return STP3_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(se_mlp_bwd_sample_kernel, dim3(dims->N), dim3(256), (size_t)(dims->C + 2 * dims->S) * 4, s, *dims,
+                       dgate, gate, z1, w1, w2, dz2, dz1, dpooled);
+    hipLaunchKernelGGL(se_mlp_bwd_weight_kernel, dim3((dims->C + 255) / 256), dim3(256),
+                       (size_t)2 * dims->N * dims->S * 4, s, *dims, pooled_sum, z1, dz2, dz1, dw1, db1, dw2, db2);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -69,6 +69,11 @@ class WprepEntry(ctypes.Structure):
                 ('cout', ctypes.c_int32), ('cin', ctypes.c_int32), ('kh', ctypes.c_int32), ('kw', ctypes.c_int32)]
 
 
+class SeMlpDims(ctypes.Structure):
+    """struct stp3_se_mlp_dims (include/stp3_hip.h)."""
+    _fields_ = [('N', ctypes.c_int32), ('C', ctypes.c_int32), ('S', ctypes.c_int32), ('inv_rows', ctypes.c_float)]
+
+
 class OptimBucket(ctypes.Structure):
     """struct stp3_optim_bucket (include/stp3_hip.h)."""
     _fields_ = [('grad', ctypes.c_void_p), ('param', ctypes.c_void_p), ('exp_avg', ctypes.c_void_p),
@@ -122,6 +127,8 @@ SIGNATURES = {
     'stp3_conv2d_wgrad_workspace': (c_int, [ctypes.POINTER(ConvDims), ctypes.POINTER(c_size_t)]),
     'stp3_conv2d_wgrad': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'stp3_conv2d_prep_weights': (c_int, [c_void_p, c_int32, ctypes.c_int64, c_void_p]),
+    'stp3_se_mlp_fwd': (c_int, [c_void_p] * 9),
+    'stp3_se_mlp_bwd': (c_int, [c_void_p] * 15),
     'stp3_optim_workspace_bytes': (c_int, [ctypes.c_int64, ctypes.POINTER(c_size_t)]),
     'stp3_optim_clip_adam': (c_int, [c_void_p, c_int32, ctypes.c_int64] + [c_float] * 6 + [c_void_p, c_void_p, c_size_t,
                                                                                           c_void_p]),

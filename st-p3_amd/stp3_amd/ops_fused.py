@@ -10,6 +10,7 @@ everything else (evaluation, float32 parity runs, unsupported shapes) takes the 
 Not yet validated on hardware: tests/test_conv_v2_gpu.py runs only with STP3_EXPERIMENTAL=1.
 """
 import ctypes
+import os
 
 import torch
 
@@ -17,6 +18,8 @@ from . import _lib, ops
 from ._lib import check
 
 _WS = {}
+# EXPERIMENTAL on top of STP3_FUSED_SE: the gate's two fully-connected layers through stp3_se_mlp_fwd / _bwd
+_SE_MLP = os.environ.get('STP3_SE_MLP', '0') == '1'
 
 
 def _workspace(nbytes, device):
@@ -226,6 +229,20 @@ class _SeBlock(torch.autograd.Function):
         ops._need_gpu(x)
         x, dims = _se_dims(x)
         hw = float(dims.rows)
+        if _SE_MLP:                                                           # gate MLP as one launch
+            pooled_sum = _se_pool(x, dims)
+            w1f, w2f = w1.detach().flatten(1).float().contiguous(), w2.detach().flatten(1).float().contiguous()
+            md = _lib.SeMlpDims(dims.N, dims.C, w1f.shape[0], 1.0 / hw)
+            z1 = torch.empty(dims.N, md.S, dtype=torch.float32, device=x.device)
+            gate = torch.empty(dims.N, dims.C, dtype=torch.float32, device=x.device)
+            check(_lib.lib().stp3_se_mlp_fwd(ctypes.byref(md), pooled_sum.data_ptr(), w1f.data_ptr(),
+                                             ops._f32(b1).data_ptr(), w2f.data_ptr(), ops._f32(b2).data_ptr(),
+                                             z1.data_ptr(), gate.data_ptr(), ops._stream_handle()), 'stp3_se_mlp_fwd')
+            y = _se_scale(x, dims, gate)
+            ctx.save_for_backward(x, gate, pooled_sum, z1, w1f, w2f)
+            ctx.dims, ctx.mlp_dims = dims, md
+            ctx.meta = (w1.shape, w2.shape, w1.dtype, b1.dtype, w2.dtype, b2.dtype)
+            return y
         pooled = _se_pool(x, dims) / hw                                       # (N, C)
         w1f, w2f = w1.detach().flatten(1).float(), w2.detach().flatten(1).float()
         with torch.autocast('cuda', enabled=False):                           # the kernels read float32 gates
@@ -234,12 +251,39 @@ class _SeBlock(torch.autograd.Function):
             gate = torch.sigmoid(torch.addmm(b2.detach().float(), h, w2f.t()))   # (N, C)
         y = _se_scale(x, dims, gate)
         ctx.save_for_backward(x, gate, pooled, z1, h, w1f, w2f)
-        ctx.dims = dims
+        ctx.dims, ctx.mlp_dims = dims, None
         ctx.meta = (w1.shape, w2.shape, w1.dtype, b1.dtype, w2.dtype, b2.dtype)
         return y
 
     @staticmethod
+    def _backward_mlp_kernels(ctx, dy):
+        x, gate, pooled_sum, z1, w1f, w2f = ctx.saved_tensors
+        dims, md = ctx.dims, ctx.mlp_dims
+        w1s, w2s, w1d, b1d, w2d, b2d = ctx.meta
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        if dy.stride() != x.stride():
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            if dy.stride() != x.stride():                                     # x was a channel-sliced view
+                x, dims = _se_dims(x.contiguous(memory_format=torch.channels_last))
+        dgate = _se_pool(x, dims, dy)                                         # sum_hw dy * x
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dz2, dz1 = torch.empty(md.N, md.C, **f32), torch.empty(md.N, md.S, **f32)
+        dpooled = torch.empty(md.N, md.C, **f32)
+        dw1, db1 = torch.empty(md.S, md.C, **f32), torch.empty(md.S, **f32)
+        dw2, db2 = torch.empty(md.C, md.S, **f32), torch.empty(md.C, **f32)
+        check(_lib.lib().stp3_se_mlp_bwd(ctypes.byref(md), dgate.data_ptr(), gate.data_ptr(), pooled_sum.data_ptr(),
+                                         z1.data_ptr(), w1f.data_ptr(), w2f.data_ptr(), dz2.data_ptr(), dz1.data_ptr(),
+                                         dpooled.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
+                                         db2.data_ptr(), ops._stream_handle()), 'stp3_se_mlp_bwd')
+        dx = _se_scale(dy, dims, gate, dpooled)
+        return dx, dw1.view(w1s).to(w1d), db1.to(b1d), dw2.view(w2s).to(w2d), db2.to(b2d)
+
+    @staticmethod
     def backward(ctx, dy):
+        if ctx.mlp_dims is not None:
+            return _SeBlock._backward_mlp_kernels(ctx, dy)
         x, gate, pooled, z1, h, w1f, w2f = ctx.saved_tensors
         dims = ctx.dims
         w1s, w2s, w1d, b1d, w2d, b2d = ctx.meta

@@ -19,7 +19,7 @@ PKG = os.path.join(ROOT, 'st-p3_amd', 'stp3_amd')
 
 ALL_SWITCHES = dict(STP3_BN_GEOM='1', STP3_FUSED_SE='1', STP3_CONV_V2='1', STP3_MFMA_CONV='all', STP3_WEIGHT_PREP='1',
                     STP3_GRAD_GATHER='1', STP3_LABEL_WARP='batched', STP3_FUSED_ADAM='1', STP3_LIFT_FWD='mfma',
-                    STP3_LIFT_BWD='mfma', STP3_LAZY_BN_COUNTER='1')
+                    STP3_LIFT_BWD='mfma', STP3_LAZY_BN_COUNTER='1', STP3_SE_MLP='1')
 
 
 @pytest.mark.skipif(shutil.which('gcc') is None, reason='needs gcc for the recording library')

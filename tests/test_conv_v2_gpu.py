@@ -210,3 +210,27 @@ def test_fused_clip_adam_matches_the_torch_operator_path(monkeypatch):
             torch.testing.assert_close(fus_opt.exp_avg[k], ref_opt.exp_avg[k], rtol=5e-5, atol=1e-10)
             torch.testing.assert_close(fus_opt.exp_avg_sq[k], ref_opt.exp_avg_sq[k], rtol=5e-5, atol=1e-12)
             torch.testing.assert_close(fus_b.flat_params[k], ref_b.flat_params[k], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_se_mlp_kernels_match_the_torch_operator_mlp(monkeypatch, dtype):
+    """stp3_se_mlp_fwd / _bwd (STP3_SE_MLP): the squeeze-excite block with the gate MLP as single launches == the
+    same block with the MLP written in torch operators (float32 in both), forward and all five gradients."""
+    from stp3_amd import ops_fused
+    torch.manual_seed(0)
+    for n, c, s, hh, ww in [(72, 144, 6, 14, 30), (12, 960, 40, 7, 15), (3, 48, 12, 5, 9)]:
+        x0 = torch.randn(n, c, hh, ww, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
+        params0 = [torch.randn(s, c, 1, 1, device='cuda') * 0.1, torch.randn(s, device='cuda') * 0.1,
+                   torch.randn(c, s, 1, 1, device='cuda') * 0.1, torch.randn(c, device='cuda') * 0.1]
+        gy = torch.randn_like(x0)
+        results = []
+        for flag in (False, True):
+            monkeypatch.setattr(ops_fused, '_SE_MLP', flag)
+            x = x0.clone().requires_grad_()
+            params = [p.clone().requires_grad_() for p in params0]
+            y = ops_fused._SeBlock.apply(x, *params)
+            y.backward(gy)
+            results.append([y.detach().float()] + [t.grad.float() for t in [x] + params])
+        tol = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+        for a, b in zip(*results):
+            torch.testing.assert_close(b, a, **tol)

@@ -23,7 +23,7 @@ ROOT = host_trace.ROOT
 PKG = os.path.join(ROOT, 'st-p3_amd', 'stp3_amd')
 FLAGS = ('STP3_CPP_OPS', 'STP3_BN_GEOM', 'STP3_FUSED_SE', 'STP3_CONV_V2', 'STP3_MFMA_CONV', 'STP3_LIFT_BWD',
          'STP3_WEIGHT_PREP', 'STP3_GRAD_GATHER', 'STP3_LABEL_WARP', 'STP3_FUSED_ADAM', 'STP3_LAZY_BN_COUNTER',
-         'STP3_LIFT_FWD')
+         'STP3_LIFT_FWD', 'STP3_SE_MLP')
 
 pytestmark = pytest.mark.skipif(shutil.which('gcc') is None, reason='needs gcc for the recording library')
 
@@ -82,8 +82,8 @@ def test_cpp_launch_path_makes_the_same_calls_for_the_whole_step(recorder, tmp_p
     ('weight_prep', dict(STP3_WEIGHT_PREP='1'), ('stp3_conv2d_prep_weights',)),
     ('everything', dict(STP3_BN_GEOM='1', STP3_FUSED_SE='1', STP3_CONV_V2='1', STP3_MFMA_CONV='all',
                         STP3_WEIGHT_PREP='1', STP3_GRAD_GATHER='1', STP3_LABEL_WARP='batched', STP3_FUSED_ADAM='1',
-                        STP3_LAZY_BN_COUNTER='1', STP3_LIFT_FWD='mfma', STP3_LIFT_BWD='mfma'),
-     ('stp3_conv2d_prep_weights', 'stp3_se_pool', 'stp3_optim_clip_adam')),
+                        STP3_LAZY_BN_COUNTER='1', STP3_LIFT_FWD='mfma', STP3_LIFT_BWD='mfma', STP3_SE_MLP='1'),
+     ('stp3_conv2d_prep_weights', 'stp3_se_pool', 'stp3_optim_clip_adam', 'stp3_se_mlp_fwd', 'stp3_se_mlp_bwd')),
 ])
 def test_experimental_switches_run_end_to_end(recorder, tmp_path, name, flags, expect):
     _, calls = _step(recorder, tmp_path / f'{name}.log', **flags)
