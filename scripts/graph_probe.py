@@ -1,6 +1,6 @@
 """Bisect hipGraph capture of the training step: python scripts/graph_probe.py <stage>
 stages: encoder | lift | temporal | decoder | loss | optim | full"""
-import os, sys, time
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'st-p3_amd'))
 import torch

@@ -1,6 +1,6 @@
 """Workload for the rocprofv3 --pmc passes: a calibration stream (known bytes) + the lift forward / backward at
 the bench shape (B=4, T=3).  See scripts/gpu_pmc.sh."""
-import ctypes, os, sys
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'st-p3_amd'))
 import torch

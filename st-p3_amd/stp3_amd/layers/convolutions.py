@@ -12,7 +12,6 @@ Exact work reductions relative to a literal translation (no approximation):
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, conv1x1_on_vector, conv2d, conv_module, run_fused
 

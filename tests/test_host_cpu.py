@@ -6,7 +6,6 @@ fixtures tests/test_modules_gpu.py replays on the MI355X through the HIP kernels
 Tolerance: float32 CPU vs float32 CPU of the reference (same torch build in the container that generated the
 fixtures): rtol 2e-3 / atol 2e-4 as on the GPU (other BLAS / thread counts may reorder sums); losses rtol 1e-5.
 """
-import numpy as np
 import pytest
 import torch
 
