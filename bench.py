@@ -230,6 +230,10 @@ def main():
         _cpu_baseline_worker(args.workload)
         return
 
+    if os.environ.get('STP3_MIOPEN_FIND') == '1':
+        # A/B knob: let the vendor library benchmark its solvers per convolution shape (slow first step) instead of
+        # the immediate-mode heuristic pick; only the thin trunk layers and a few weight gradients still go there
+        torch.backends.cudnn.benchmark = True
     from stp3_amd.parallel import FlatAdam, GradientBuckets, init_distributed
     rank, world, local = init_distributed()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
