@@ -332,6 +332,7 @@ def main():
                 line['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()              # rank 0 may still be in its roofline micro-benchmark: leave together
         dist.destroy_process_group()
 
 
