@@ -241,10 +241,16 @@ def main():
     if not DRYRUN:
         torch.cuda.set_device(device)
 
-    def setup(workload):
+    def setup(workload, fast_host):
         # cross-replica BN statistics are built into bn_act, hence sync_bn=False
+        from stp3_amd import trainer as _trainer
         module, cfg = build_module(device, sync_bn=False, workload=workload)
-        buckets = GradientBuckets(module.model)
+        # Host-side options that are bit-identical to the plain path (tests/test_parallel_cpu.py, tests/test_host_cpu.py)
+        # and remove ~1 400 tiny launches per step: gradients gathered per bucket, label maps warped together.
+        # An explicit STP3_GRAD_GATHER / STP3_LABEL_WARP in the environment wins (A/B runs).
+        gather = os.environ.get('STP3_GRAD_GATHER', '1' if fast_host else '0') == '1'
+        _trainer._BATCHED_LABEL_WARP = os.environ.get('STP3_LABEL_WARP', 'batched' if fast_host else 'per_label') == 'batched'
+        buckets = GradientBuckets(module.model, gather=gather)
         opt = FlatAdam(buckets, lr=cfg.OPTIMIZER.LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY)   # trainer.py:456-462
         batch = make_device_batch(args.batch, device, seed=100 + rank, workload=workload)
 
@@ -257,24 +263,27 @@ def main():
             opt.clip_and_step(cfg.GRAD_NORM_CLIP)                # gradient clip + Adam (trainer.py:456-462, train.py:48)
             return loss
 
-        return module, cfg, buckets, opt, batch, eager_step
+        options = f"grad_gather={int(gather)} label_warp={'batched' if _trainer._BATCHED_LABEL_WARP else 'per_label'}"
+        return module, cfg, buckets, opt, batch, eager_step, options
 
-    workload = args.workload
-    try:
-        module, cfg, buckets, opt, batch, eager_step = setup(workload)
-        first = eager_step()                                    # first warm-up step = the workload's own smoke test
-        _sync()
-        assert DRYRUN or torch.isfinite(first).item(), 'loss is not finite'
-    except Exception as e:
-        if workload != 'c3':
-            raise
-        # never lose the measurement to the extra heads: time the plain Perception.yml step and say so in `config`
-        print(f'[bench] workload c3 failed in its first step ({e!r}); falling back to --workload perception',
-              file=sys.stderr, flush=True)
-        workload = 'perception'
-        module, cfg, buckets, opt, batch, eager_step = setup(workload)
-        eager_step()
-        _sync()
+    # The first warm-up step doubles as the smoke test of the configuration; never lose the measurement to an option:
+    # fall back first to the plain host path, then to the plain Perception.yml workload, and say so in `config`.
+    attempts = [(args.workload, True), (args.workload, False)]
+    if args.workload == 'c3':
+        attempts.append(('perception', False))
+    for attempt, (workload, fast_host) in enumerate(attempts):
+        try:
+            module, cfg, buckets, opt, batch, eager_step, host_options = setup(workload, fast_host)
+            first = eager_step()
+            _sync()
+            assert DRYRUN or torch.isfinite(first).item(), 'loss is not finite'
+            break
+        except Exception as e:
+            if attempt == len(attempts) - 1:
+                raise
+            nxt = attempts[attempt + 1]
+            print(f'[bench] workload {workload} (fast host options: {fast_host}) failed in its first step ({e!r}); '
+                  f'falling back to workload {nxt[0]} (fast host options: {nxt[1]})', file=sys.stderr, flush=True)
 
     mode = 'eager'
     step = eager_step
@@ -321,7 +330,8 @@ def main():
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16 convs / f32 voxel pool', 'data': 'synthetic',
             'config': {'workload': WORKLOADS[workload].replace('batch=4/GPU', f'batch={args.batch}/GPU'),
-                       'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'launch': mode},
+                       'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'launch': mode,
+                       'host_options': host_options},
             'roofline': roof,
             'kernel_ms': kernel_ms,
         }

@@ -12,5 +12,13 @@ if __name__ == '__main__':
     from tests import model_trace
     model_trace.patch_process(sys.argv[1], deterministic_fill=False)
     import bench
+    if os.environ.get('STP3_TEST_BREAK_GATHER') == '1':          # fault injection for the fallback-ladder test
+        from stp3_amd import parallel
+        _gather = parallel.GradientBuckets._gather
+
+        def broken(self, i):
+            raise RuntimeError('injected failure in gather mode')
+
+        parallel.GradientBuckets._gather = broken
     sys.argv = ['bench.py'] + sys.argv[2:]
     bench.main()

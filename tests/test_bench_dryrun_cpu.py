@@ -44,6 +44,7 @@ def test_bench_main_dry_run(tmp_path, workload, switches):
     assert line['unit'] == 'samples/s' and line['higher_is_better'] is True and line['data'] == 'synthetic'
     assert 'workload' in line['config'] and 'model' not in line['config']
     assert ('depth CE' in line['config']['workload']) == (workload == 'c3')
+    assert line['config']['host_options'] == 'grad_gather=1 label_warp=batched'      # bit-identical host options
     roof = line['roofline']
     for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert key in roof, key
@@ -83,3 +84,20 @@ def test_bench_main_dry_run_two_ranks(tmp_path):
     calls = [l for l in open(tmp_path / 'trace.log') if l.startswith('stp3_bn_')]
     # more than one rank: the BatchNorm operator runs split (statistics | all-reduce | apply), never the composite
     assert any(l.startswith('stp3_bn_stats ') for l in calls) and not any(l.startswith('stp3_bn_fwd_train ') for l in calls)
+
+
+@pytest.mark.skipif(shutil.which('gcc') is None, reason='needs gcc for the recording library')
+def test_bench_falls_back_when_an_option_breaks(tmp_path):
+    """The fallback ladder: a failure in the first step with the fast host options must not cost the measurement."""
+    recorder = host_trace.build_recorder(str(tmp_path / 'libstp3hip_recorder.so'))
+    env = {k: v for k, v in os.environ.items() if not k.startswith('STP3_')}
+    env.update(STP3_BENCH_DRYRUN='1', STP3_HOST_DRYRUN='1', STP3_TRACE_LOG=str(tmp_path / 'trace.log'),
+               STP3_REAL_LIB=os.path.join(PKG, 'libstp3hip.so'), STP3_TEST_BREAK_GATHER='1')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'bench_dryrun.py'), recorder, '--steps', '1',
+                          '--warmup', '1', '--batch', '1', '--no-cpu-baseline', '--no-roofline'],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'falling back' in out.stderr
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+    assert line['config']['host_options'] == 'grad_gather=0 label_warp=per_label'
+    assert 'depth CE' in line['config']['workload']                  # still the c3 workload
