@@ -279,7 +279,7 @@ def main():
             assert DRYRUN or torch.isfinite(first).item(), 'loss is not finite'
             break
         except Exception as e:
-            if attempt == len(attempts) - 1:
+            if attempt == len(attempts) - 1 or world > 1:       # N > 1: the ranks' collectives are out of step, fail loudly
                 raise
             nxt = attempts[attempt + 1]
             print(f'[bench] workload {workload} (fast host options: {fast_host}) failed in its first step ({e!r}); '
