@@ -222,7 +222,7 @@ def _make_module():
     return module, cfg
 
 
-def _step_worker(rank, world, port, out, local_stats):
+def _step_worker(rank, world, port, out, local_stats, fast_host=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(2)
@@ -231,7 +231,10 @@ def _step_worker(rank, world, port, out, local_stats):
         for m in module.modules():
             if isinstance(m, nn.modules.batchnorm._BatchNorm):
                 m.stp3_local_stats = True
-    buckets = GradientBuckets(module.model)
+    if fast_host:                                     # what bench.py runs with: bit-identical host options
+        from stp3_amd import trainer
+        trainer._BATCHED_LABEL_WARP = True
+    buckets = GradientBuckets(module.model, gather=fast_host)
     batch = {k: v[rank:rank + 1] for k, v in _small_batch(2).items()}
     buckets.zero_grad()
     loss = module.training_step(batch)
@@ -245,17 +248,20 @@ def test_full_step_two_ranks_equal_one_process_on_the_concatenated_batch():
     """Whole perception training step (encoder, reference-algorithm lift, temporal model, decoder, losses) on 2 gloo
     ranks with one sample each: cross-replica BatchNorm statistics + averaged bucketed gradients must reproduce the
     single-process gradients of the 2-sample batch (what the reference's DDP + sync_batchnorm recipe guarantees)."""
-    def two_ranks(local_stats):
+    def two_ranks(local_stats, fast_host=False):
         with socket.socket() as s:
             s.bind(('127.0.0.1', 0))
             port = s.getsockname()[1]
         mgr = mp.Manager()
         res = mgr.dict()
-        mp.spawn(_step_worker, args=(2, port, res, local_stats), nprocs=2, join=True)
+        mp.spawn(_step_worker, args=(2, port, res, local_stats, fast_host), nprocs=2, join=True)
         return {k: v for k, v in res.items()}
 
     out = two_ranks(False)
     torch.testing.assert_close(out[0][1], out[1][1], rtol=0, atol=0)        # identical averaged gradients on both ranks
+    fast = two_ranks(False, fast_host=True)        # gradient gather + batched label warp: the same bits, rank by rank
+    for r in (0, 1):
+        assert fast[r][0] == out[r][0] and torch.equal(fast[r][1], out[r][1])
     torch.set_num_threads(4)
     module, cfg = _make_module()
     buckets = GradientBuckets(module.model)
