@@ -246,10 +246,13 @@ def main():
         from stp3_amd import trainer as _trainer
         module, cfg = build_module(device, sync_bn=False, workload=workload)
         # Host-side options that are bit-identical to the plain path (tests/test_parallel_cpu.py, tests/test_host_cpu.py)
-        # and remove ~1 400 tiny launches per step: gradients gathered per bucket, label maps warped together.
-        # An explicit STP3_GRAD_GATHER / STP3_LABEL_WARP in the environment wins (A/B runs).
+        # and remove ~1 500 tiny launches per step: gradients gathered per bucket, label maps warped together,
+        # BatchNorm batch counters applied once per step.
+        # An explicit STP3_GRAD_GATHER / STP3_LABEL_WARP / STP3_LAZY_BN_COUNTER in the environment wins (A/B runs).
         gather = os.environ.get('STP3_GRAD_GATHER', '1' if fast_host else '0') == '1'
         _trainer._BATCHED_LABEL_WARP = os.environ.get('STP3_LABEL_WARP', 'batched' if fast_host else 'per_label') == 'batched'
+        from stp3_amd import ops as _ops
+        _ops.LAZY_COUNTERS = os.environ.get('STP3_LAZY_BN_COUNTER', '1' if fast_host else '0') == '1'
         buckets = GradientBuckets(module.model, gather=gather)
         opt = FlatAdam(buckets, lr=cfg.OPTIMIZER.LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY)   # trainer.py:456-462
         batch = make_device_batch(args.batch, device, seed=100 + rank, workload=workload)
@@ -263,7 +266,8 @@ def main():
             opt.clip_and_step(cfg.GRAD_NORM_CLIP)                # gradient clip + Adam (trainer.py:456-462, train.py:48)
             return loss
 
-        options = f"grad_gather={int(gather)} label_warp={'batched' if _trainer._BATCHED_LABEL_WARP else 'per_label'}"
+        options = (f"grad_gather={int(gather)} label_warp={'batched' if _trainer._BATCHED_LABEL_WARP else 'per_label'} "
+                   f"lazy_bn_counter={int(_ops.LAZY_COUNTERS)}")
         return module, cfg, buckets, opt, batch, eager_step, options
 
     # The first warm-up step doubles as the smoke test of the configuration; never lose the measurement to an option:

@@ -40,7 +40,7 @@ PASS_THROUGH = ('STP3_BENCH_DRYRUN', 'STP3_HOST_DRYRUN', 'STP3_TRACE_LOG', 'STP3
 
 def run(env_extra, args):
     env = {k: v for k, v in os.environ.items() if not k.startswith('STP3_') or k in PASS_THROUGH}
-    env.update(STP3_GRAD_GATHER='0', STP3_LABEL_WARP='per_label')      # bench.py turns these on unless told otherwise
+    env.update(STP3_GRAD_GATHER='0', STP3_LABEL_WARP='per_label', STP3_LAZY_BN_COUNTER='0')      # bench.py turns these on unless told otherwise
     env.update(env_extra)
     cmd = [sys.executable] + (args.bench_cmd.split() if args.bench_cmd else [os.path.join(ROOT, 'bench.py')]) + [
         '--steps', str(args.steps), '--warmup', str(args.warmup), '--batch', str(args.batch), '--no-cpu-baseline',

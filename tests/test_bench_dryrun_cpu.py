@@ -44,7 +44,7 @@ def test_bench_main_dry_run(tmp_path, workload, switches):
     assert line['unit'] == 'samples/s' and line['higher_is_better'] is True and line['data'] == 'synthetic'
     assert 'workload' in line['config'] and 'model' not in line['config']
     assert ('depth CE' in line['config']['workload']) == (workload == 'c3')
-    assert line['config']['host_options'] == 'grad_gather=1 label_warp=batched'      # bit-identical host options
+    assert line['config']['host_options'] == 'grad_gather=1 label_warp=batched lazy_bn_counter=1'   # bit-identical host options
     roof = line['roofline']
     for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert key in roof, key
@@ -99,5 +99,5 @@ def test_bench_falls_back_when_an_option_breaks(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     assert 'falling back' in out.stderr
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
-    assert line['config']['host_options'] == 'grad_gather=0 label_warp=per_label'
+    assert line['config']['host_options'] == 'grad_gather=0 label_warp=per_label lazy_bn_counter=0'
     assert 'depth CE' in line['config']['workload']                  # still the c3 workload
