@@ -67,6 +67,13 @@ def test_iou_metric_counts():
     fp = int(((pred == 1) & (tgt == 0)).sum())
     fn = int(((pred == 0) & (tgt == 1)).sum())
     assert abs(float(m.compute()[1]) - tp / (tp + fp + fn)) < 1e-6          # stp3/metrics.py:37-65
+    # an independent implementation of the same quantity (scikit-learn's Jaccard index), accumulated over two updates
+    sk = pytest.importorskip('sklearn.metrics')
+    m.reset()
+    m(pred[:1], tgt[:1])
+    m(pred[1:], tgt[1:])
+    want = sk.jaccard_score(tgt.reshape(-1).numpy(), pred.reshape(-1).numpy(), average=None)
+    assert abs(float(m.compute()[0]) - want[0]) < 1e-6 and abs(float(m.compute()[1]) - want[1]) < 1e-6
 
 
 def test_staged_sum_equals_sum():
