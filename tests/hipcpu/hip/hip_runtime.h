@@ -1,0 +1,282 @@
+// TEST INFRASTRUCTURE -- a host-side stand-in for <hip/hip_runtime.h> that lets the repository's .hip sources be
+// compiled for x86 (clang++) and EXECUTED on CPU threads, one OS thread per HIP thread, one workgroup at a time.
+// Purpose: this build container has no GPU; with this shim the real kernel source -- index arithmetic, LDS layouts,
+// barriers, wave-level intrinsics (DPP, readlane, ballot, shuffles) and the MFMA lane maps -- runs under the same C ABI
+// (tests/hipcpu/build.py -> libstp3hip_cpu.so) and is compared with the oracle on small problems.  It checks the
+// LOGIC of a kernel, not its performance, and it cannot see hardware-only effects (memory model, occupancy limits).
+//
+// Semantics implemented (what the kernels in st-p3_amd/csrc use, nothing more):
+//   * blocks run sequentially; the threads of a block are real threads; __syncthreads() is a barrier over the
+//     threads of the block that have not returned yet (a returned thread drops out, as on the GPU)
+//   * a wave = 64 consecutive threads; wave intrinsics exchange values through a per-wave buffer with two wave
+//     barriers, so they must be reached by all live lanes of the wave (convergent use) -- otherwise the run aborts
+//     after a timeout with a message instead of hanging
+//   * v_mfma_f32_16x16x4_f32 and v_mfma_f32_16x16x32_bf16 with the operand / result lane maps of the CDNA3/4 ISA
+//     (cdna_hip_programming.md section 3): A[i = l & 15][k-chunk = l >> 4], B[k-chunk = l >> 4][j = l & 15],
+//     D[4 * (l >> 4) + r][l & 15]; fp32 products are chained with fmaf in ascending k
+//   * __shared__ arrays are `static` (one block at a time); `extern __shared__` declarations are rewritten by the
+//     build script into a pointer to one 160 KB buffer
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#define warpSize 64
+
+typedef void* hipStream_t;
+enum hipError_t { hipSuccess = 0, hipErrorInvalidValue = 1 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+inline float2 make_float2(float x, float y) { return {x, y}; }
+inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
+inline int2 make_int2(int x, int y) { return {x, y}; }
+
+namespace hipcpu {
+
+constexpr int kWave = 64;
+constexpr size_t kDynLds = 160 * 1024;
+
+[[noreturn]] inline void die(const char* what) {
+    std::fprintf(stderr, "hipcpu: %s\n", what);
+    std::fflush(stderr);
+    std::abort();
+}
+
+// barrier over the threads that are still alive; drop() removes a participant for good
+class Barrier {
+public:
+    void reset(int n) { std::lock_guard<std::mutex> g(m_); expected_ = n; waiting_ = 0; ++gen_; }
+    void wait() {
+        std::unique_lock<std::mutex> g(m_);
+        const unsigned gen = gen_;
+        if (++waiting_ >= expected_) { waiting_ = 0; ++gen_; cv_.notify_all(); return; }
+        if (!cv_.wait_for(g, std::chrono::seconds(600), [&] { return gen != gen_; }))
+            die("barrier timeout: a barrier or wave intrinsic was not reached by all live threads (divergent use?)");
+    }
+    void drop() {
+        std::lock_guard<std::mutex> g(m_);
+        --expected_;
+        if (expected_ > 0 && waiting_ >= expected_) { waiting_ = 0; ++gen_; cv_.notify_all(); }
+    }
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    int expected_ = 0, waiting_ = 0;
+    unsigned gen_ = 0;
+};
+
+struct Wave {
+    Barrier bar;
+    alignas(16) unsigned char slot[2][kWave][32];   // two operands, up to 32 bytes per lane
+};
+
+struct Block {
+    Barrier bar;
+    std::vector<Wave> waves;
+};
+
+struct Ctx {
+    dim3 tid, bid, bdim, gdim;
+    int lane = 0, wave = 0;
+    Block* block = nullptr;
+};
+extern thread_local Ctx tls;
+extern unsigned char g_dyn_lds[kDynLds];
+inline void* dyn_lds() { return g_dyn_lds; }
+
+inline Wave& my_wave() { return tls.block->waves[tls.wave]; }
+
+// every live lane of the wave deposits `v`, then reads the value deposited by lane `src`
+template <typename T>
+inline T exchange(T v, int src) {
+    static_assert(sizeof(T) <= 32, "exchange payload");
+    Wave& w = my_wave();
+    std::memcpy(w.slot[0][tls.lane], &v, sizeof(T));
+    w.bar.wait();
+    T r;
+    std::memcpy(&r, w.slot[0][src & (kWave - 1)], sizeof(T));
+    w.bar.wait();
+    return r;
+}
+
+void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& kernel);
+
+}  // namespace hipcpu
+
+#define threadIdx (hipcpu::tls.tid)
+#define blockIdx (hipcpu::tls.bid)
+#define blockDim (hipcpu::tls.bdim)
+#define gridDim (hipcpu::tls.gdim)
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+    hipcpu::launch((grid), (block), (size_t)(lds), [=]() { kernel(__VA_ARGS__); })
+
+inline void __syncthreads() { hipcpu::tls.block->bar.wait(); }
+inline void __builtin_amdgcn_wave_barrier_() { hipcpu::my_wave().bar.wait(); }
+#define __builtin_amdgcn_wave_barrier __builtin_amdgcn_wave_barrier_
+#define __builtin_amdgcn_fence(order, scope) std::atomic_thread_fence(std::memory_order_seq_cst)
+
+// ---- bit casts / math ----
+inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
+inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
+inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); return f; }
+inline float __expf(float x) { return std::exp(x); }
+using std::min;
+using std::max;
+inline int min(int a, unsigned b) { return a < (int)b ? a : (int)b; }
+
+template <typename T>
+inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+
+// ---- wave intrinsics ----
+inline int readlane_i(int v, int lane) { return hipcpu::exchange<int>(v, lane); }
+#define __builtin_amdgcn_readlane(v, lane) readlane_i((int)(v), (int)(lane))
+// used on wave-uniform values only in this code base (wave index, values loaded from one address)
+#define __builtin_amdgcn_readfirstlane(v) (v)
+
+template <typename T>
+inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return hipcpu::exchange<T>(v, hipcpu::tls.lane ^ mask); }
+template <typename T>
+inline T __shfl_up(T v, unsigned delta, int width = 64) {
+    (void)width;
+    const int src = hipcpu::tls.lane - (int)delta;
+    const T r = hipcpu::exchange<T>(v, src < 0 ? hipcpu::tls.lane : src);
+    return src < 0 ? v : r;
+}
+inline unsigned long long __ballot(int pred) {
+    hipcpu::Wave& w = hipcpu::my_wave();
+    const int p = pred ? 1 : 0;
+    std::memcpy(w.slot[0][hipcpu::tls.lane], &p, 4);
+    std::memset(w.slot[1][hipcpu::tls.lane], 1, 1);                  // "this lane is alive and voted"
+    w.bar.wait();
+    unsigned long long m = 0;
+    for (int l = 0; l < hipcpu::kWave; ++l) {
+        int q = 0;
+        std::memcpy(&q, w.slot[0][l], 4);
+        if (w.slot[1][l][0] == 1 && q) m |= 1ull << l;
+    }
+    w.bar.wait();
+    w.slot[1][hipcpu::tls.lane][0] = 0;
+    return m;
+}
+
+// v_perm_b32: byte select from {a (bytes 7..4), b (bytes 3..0)}; selectors 0..7 pick a byte, 0x0c gives 0x00
+inline unsigned __builtin_amdgcn_perm_(unsigned a, unsigned b, unsigned sel) {
+    const unsigned long long src = ((unsigned long long)a << 32) | b;
+    unsigned r = 0;
+    for (int i = 0; i < 4; ++i) {
+        const unsigned s = (sel >> (8 * i)) & 0xff;
+        unsigned byte = 0;
+        if (s < 8) byte = (unsigned)(src >> (8 * s)) & 0xff;
+        else if (s == 0x0c) byte = 0x00;
+        else if (s >= 0x0d) byte = 0xff;
+        else hipcpu::die("v_perm_b32 selector not modelled");
+        r |= byte << (8 * i);
+    }
+    return r;
+}
+#define __builtin_amdgcn_perm __builtin_amdgcn_perm_
+
+// DPP: the controls used here -- quad_perm (0x00..0xff), row_mirror 0x140, row_half_mirror 0x141, row_bcast15 0x142,
+// row_bcast31 0x143; lanes of rows that row_mask disables (or without a valid source) receive `old`
+inline int update_dpp_(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    (void)bank_mask; (void)bound_ctrl;
+    const int lane = hipcpu::tls.lane, row = lane >> 4;
+    int from = -1;
+    if (ctrl >= 0 && ctrl <= 0xff) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+    else if (ctrl == 0x140) from = (lane & ~15) | (15 - (lane & 15));
+    else if (ctrl == 0x141) from = (lane & ~7) | (7 - (lane & 7));
+    else if (ctrl == 0x142) from = row >= 1 ? 16 * (row - 1) + 15 : -1;
+    else if (ctrl == 0x143) from = row >= 2 ? 31 : -1;
+    else hipcpu::die("DPP control not modelled");
+    const int got = hipcpu::exchange<int>(src, from < 0 ? lane : from);
+    if (from < 0 || !((row_mask >> row) & 1)) return old;
+    return got;
+}
+#define __builtin_amdgcn_update_dpp update_dpp_
+
+// ---- MFMA ----
+typedef float hipcpu_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 hipcpu_bf16x8 __attribute__((ext_vector_type(8)));
+
+inline hipcpu_f32x4 mfma_f32_16x16x4f32_(float a, float b, hipcpu_f32x4 c, int, int, int) {
+    hipcpu::Wave& w = hipcpu::my_wave();
+    const int lane = hipcpu::tls.lane;
+    std::memcpy(w.slot[0][lane], &a, 4);
+    std::memcpy(w.slot[1][lane], &b, 4);
+    w.bar.wait();
+    hipcpu_f32x4 d = c;
+    const int j = lane & 15;
+    for (int q = 0; q < 4; ++q) {
+        const int i = 4 * (lane >> 4) + q;
+        float acc = c[q];
+        for (int k = 0; k < 4; ++k) {
+            float av, bv;
+            std::memcpy(&av, w.slot[0][i + 16 * k], 4);
+            std::memcpy(&bv, w.slot[1][j + 16 * k], 4);
+            acc = std::fmaf(av, bv, acc);
+        }
+        d[q] = acc;
+    }
+    w.bar.wait();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 mfma_f32_16x16x4f32_
+
+inline float hipcpu_bf16_to_float(const unsigned char* p) {
+    unsigned short h;
+    std::memcpy(&h, p, 2);
+    return __uint_as_float((unsigned)h << 16);
+}
+
+template <typename V>
+inline hipcpu_f32x4 mfma_f32_16x16x32_bf16_(V a, V b, hipcpu_f32x4 c, int, int, int) {
+    static_assert(sizeof(V) == 16, "8 x bf16 per lane");
+    hipcpu::Wave& w = hipcpu::my_wave();
+    const int lane = hipcpu::tls.lane;
+    std::memcpy(w.slot[0][lane], &a, 16);
+    std::memcpy(w.slot[1][lane], &b, 16);
+    w.bar.wait();
+    hipcpu_f32x4 d = c;
+    const int j = lane & 15;
+    for (int q = 0; q < 4; ++q) {
+        const int i = 4 * (lane >> 4) + q;
+        float acc = c[q];
+        for (int kk = 0; kk < 4; ++kk)
+            for (int t = 0; t < 8; ++t)
+                acc += hipcpu_bf16_to_float(w.slot[0][i + 16 * kk] + 2 * t) * hipcpu_bf16_to_float(w.slot[1][j + 16 * kk] + 2 * t);
+        d[q] = acc;
+    }
+    w.bar.wait();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 mfma_f32_16x16x32_bf16_

@@ -1,0 +1,313 @@
+"""TEST INFRASTRUCTURE -- run one operator of stp3_amd.ops on CPU tensors through libstp3hip_cpu.so (the real kernel
+sources executed on CPU threads, tests/hipcpu/build.py) and print the deviations from the oracle / torch as JSON.
+
+    python tests/hipcpu/run_case.py <libstp3hip_cpu.so> <case>
+
+Driver of tests/test_kernels_on_cpu.py; one process per case because the library reads its switches (STP3_LIFT_FWD,
+STP3_LIFT_BWD, STP3_BN_GEOM) from the environment once."""
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'st-p3_amd'))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def setup(lib_path):
+    from stp3_amd import _lib
+    _lib.LIB_PATH = lib_path
+    from stp3_amd import ops
+    ops._need_gpu = lambda *a: None
+    ops._stream = lambda: None
+    ops._stream_handle = lambda: 0
+    torch.Tensor.is_cuda = property(lambda self: True)            # operators take their GPU route
+    return ops
+
+
+def err(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).abs().max())
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def case_lift(ops, cfg, batch, seq, cams, seed, golden=None):
+    from oracle import lift_oracle as lo
+    from tests import helpers as H
+    if golden is not None:
+        g = H.load(golden)
+        intr, extr, ego = (torch.from_numpy(g[k]) for k in ('intrinsics', 'extrinsics', 'future_egomotion'))
+        feat, logits = torch.from_numpy(g['feat']), torch.from_numpy(g['depth_logits'])
+    else:
+        intr, extr, ego, feat, logits = H.lift_inputs(cfg, batch, seq, cams, seed=seed)
+    frustum, res, start, dim = H.grid_params(cfg)
+    grid = ops.LiftGrid(frustum, res, start, dim, 'cpu')
+    b, s, n = intr.shape[:3]
+    dims = ops.make_dims(b, s, n, grid.D, grid.fH, grid.fW, cfg['out_channels'], grid.X, grid.Y, grid.Z)
+    ids = ops.voxel_index(grid, dims, *ops.lift_matrices(intr, extr, ego), order=ops.VOX_REFERENCE)
+    ids = ids.view(b, s, n, grid.D, grid.fH, grid.fW).numpy()
+    vox = H.oracle_vox(cfg, intr, extr, ego)
+    plan = ops.LiftPlan.build(grid, intr, extr, ego, cfg['out_channels'])
+    pm = plan.vox_pm.view(b, s, n, grid.fH, grid.fW, grid.D).permute(0, 1, 2, 5, 3, 4).numpy()
+    f, lg = feat.clone().requires_grad_(), logits.clone().requires_grad_()
+    bev = ops.lift_splat(f, lg, plan, cfg['discount'])
+    again = ops.lift_splat(feat, logits, plan, cfg['discount'])
+    go = torch.randn(bev.shape, generator=torch.Generator().manual_seed(seed + 5))
+    bev.backward(go)
+    exact = lo.pool_exact(feat, logits, vox, (grid.X, grid.Y), cfg['discount'])
+    gf, gl = lo.pool_backward_exact(go, feat, logits, vox, cfg['discount'])
+    out = {'ids_equal_oracle': bool(np.array_equal(ids, vox)), 'pixel_major_ids_equal': bool(np.array_equal(pm, vox)),
+           'valid_fraction': float((vox >= 0).mean()), 'fwd_err': err(bev.detach(), exact), 'fwd_scale': float(exact.abs().max()),
+           'reproducible': bool(torch.equal(bev.detach(), again)), 'dfeat_err': err(f.grad, gf), 'dlogit_err': err(lg.grad, gl),
+           'grad_scale': float(min(gf.abs().max(), gl.abs().max())), 'dims': [grid.D, grid.fH, grid.fW, cfg['out_channels']]}
+    if golden is not None:
+        out['ids_equal_reference'] = bool(np.array_equal(ids, g['ref_vox']))
+        out['fwd_err_reference'] = err(bev.detach(), g['ref_bev'])
+    return out
+
+
+def lift_small(ops):
+    from tests import helpers as H
+    return case_lift(ops, H.SMALL, 2, 3, 2, 0, golden='lift_small.npz')
+
+
+def lift_c16(ops):                  # 16 channels: the matrix-core variants apply (STP3_LIFT_FWD / _BWD = mfma)
+    from tests import helpers as H
+    return case_lift(ops, dict(H.SMALL, out_channels=16, final_dim=(64, 48)), 1, 2, 2, 3)
+
+
+def lift_c16_rows32(ops):           # the same with 32 image rows per column (both 16-row MFMA tiles in use)
+    from tests import helpers as H
+    return case_lift(ops, dict(H.SMALL, out_channels=16, final_dim=(64, 48), downsample=2), 1, 2, 2, 3)
+
+
+def lift_c64_many_runs(ops):        # 64 channels, ~190 runs per column: the matrix-core backward works in two chunks
+    from tests import helpers as H
+    cfg = dict(H.SMALL, out_channels=64, final_dim=(64, 16), downsample=2, d_bound=(2.0, 34.0, 1.0),
+               x_bound=(-36.0, 36.0, 0.25), y_bound=(-36.0, 36.0, 0.25))
+    return case_lift(ops, cfg, 1, 1, 1, 7)
+
+
+def lift_tall(ops):                 # 112 rows x 64 bins per column: 112 KB of LDS in the default forward
+    from tests import helpers as H
+    cfg = dict(H.FULL, out_channels=8, final_dim=(224, 32), downsample=2, d_bound=(2.0, 66.0, 1.0))
+    return case_lift(ops, cfg, 1, 1, 1, 9)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def voxsum(ops):
+    from oracle import lift_oracle as lo
+    from tests import helpers as H
+    g = H.load('voxsum.npz')
+    out = {}
+    for name in ('singles', 'onevoxel', 'onerow'):
+        x = torch.tensor(g[f'{name}_x'], requires_grad=True)
+        y, kept = ops.VoxelsSumming.apply(x, torch.tensor(g[f'{name}_geometry']), torch.tensor(g[f'{name}_ranks']))
+        y.backward(torch.tensor(g[f'{name}_grad']))
+        out[name] = {'sum_err': err(y.detach(), g[f'{name}_sum64']), 'geometry_equal': bool(np.array_equal(kept.numpy(), g[f'{name}_geomkept'])),
+                     'grad_equal': bool(np.array_equal(x.grad.numpy(), g[f'{name}_gradx64']))}
+    rng = np.random.default_rng(3)                                  # ragged, long voxels, 70 channels (two lane passes)
+    lengths = np.concatenate([rng.integers(1, 9, 40), [130, 1, 67]])
+    ranks = np.repeat(np.sort(rng.choice(5000, len(lengths), replace=False)), lengths).astype(np.int64)
+    xs = rng.standard_normal((len(ranks), 70)).astype(np.float32)
+    ref, _, seg = lo.voxels_summing(xs, np.zeros((len(ranks), 3)), ranks)
+    x = torch.tensor(xs, requires_grad=True)
+    y, _ = ops.VoxelsSumming.apply(x, torch.zeros(len(ranks), 3), torch.tensor(ranks))
+    gy = rng.standard_normal(ref.shape).astype(np.float32)
+    y.backward(torch.tensor(gy))
+    out['ragged'] = {'sum_err': err(y.detach(), ref), 'grad_equal': bool(np.array_equal(x.grad.numpy(), lo.voxels_summing_backward(gy, seg).astype(np.float32)))}
+    return out
+
+
+def wprep(ops):
+    torch.manual_seed(0)
+    ws = [torch.nn.Parameter((torch.randn(*s) * 3).contiguous(memory_format=torch.channels_last if i % 2 else torch.contiguous_format))
+          for i, s in enumerate([(8, 16, 3, 3), (24, 8, 1, 1), (5, 40, 7, 7), (64, 64, 3, 3), (3, 8, 5, 5)])]
+    sh = ops._WeightShadows()
+    for w in ws:
+        sh.register(w)
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(-0.7)
+    bad = 0
+    for w in ws:
+        ent = sh.lookup(w)                                      # notices the in-place update, refreshes
+        rb = w.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        rt = rb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+        bad += int(not torch.equal(ent['wb'], rb)) + int(not torch.equal(ent['wt'], rt))
+    return {'mismatching_tensors': bad}
+
+
+def optim(ops):
+    from stp3_amd import parallel
+    from stp3_amd.parallel import FlatAdam, GradientBuckets
+
+    def make():
+        torch.manual_seed(5)
+        return torch.nn.Sequential(torch.nn.Conv2d(3, 16, 3, padding=1), torch.nn.Flatten(), torch.nn.Linear(16 * 36, 40),
+                                   torch.nn.ReLU(), torch.nn.Linear(40, 5))
+    ref_m, fus_m = make(), make()
+    ref_b, fus_b = GradientBuckets(ref_m, bucket_bytes=20000), GradientBuckets(fus_m, bucket_bytes=20000)
+    ref_o, fus_o = FlatAdam(ref_b, lr=1e-2, weight_decay=1e-3), FlatAdam(fus_b, lr=1e-2, weight_decay=1e-3)
+    worst = {'grad': 0.0, 'm': 0.0, 'v': 0.0, 'param': 0.0, 'norm': 0.0}
+    g = torch.Generator().manual_seed(2)
+    for it in range(3):
+        x = torch.randn(8, 3, 6, 6, generator=g)
+        ref_b.zero_grad()
+        ref_m(x).square().mean().backward()
+        with torch.no_grad():
+            for k in range(len(ref_b.buckets)):
+                fus_b.buckets[k][0].copy_(ref_b.buckets[k][0])
+                fus_b.flat_params[k].copy_(ref_b.flat_params[k])
+                fus_o.exp_avg[k].copy_(ref_o.exp_avg[k])
+                fus_o.exp_avg_sq[k].copy_(ref_o.exp_avg_sq[k])
+            fus_o.step_t.copy_(ref_o.step_t)
+        max_norm = 0.05 if it != 1 else 1e9
+        parallel._FUSED_ADAM = False
+        n_ref = float(ref_o.clip_and_step(max_norm))
+        parallel._FUSED_ADAM = True
+        n_fus = float(fus_o.clip_and_step(max_norm))
+        worst['norm'] = max(worst['norm'], abs(n_fus - n_ref) / n_ref)
+        for k in range(len(ref_b.buckets)):
+            worst['grad'] = max(worst['grad'], rel(fus_b.buckets[k][0], ref_b.buckets[k][0]))
+            worst['m'] = max(worst['m'], rel(fus_o.exp_avg[k], ref_o.exp_avg[k]))
+            worst['v'] = max(worst['v'], rel(fus_o.exp_avg_sq[k], ref_o.exp_avg_sq[k]))
+            worst['param'] = max(worst['param'], err(fus_b.flat_params[k], ref_b.flat_params[k]))
+    worst['steps'] = fus_o.step_count
+    worst['buckets'] = len(fus_b.buckets)
+    return worst
+
+
+def se_block(ops):
+    from stp3_amd import ops_fused
+    out = {}
+    for mlp in (False, True):
+        ops_fused._SE_MLP = mlp
+        torch.manual_seed(0)
+        worst = 0.0
+        for n, c, s, hh, ww in [(5, 48, 12, 6, 7), (3, 200, 9, 4, 4), (2, 16, 4, 1, 3)]:
+            x = torch.randn(n, c, hh, ww).contiguous(memory_format=torch.channels_last).requires_grad_()
+            params = [(torch.randn(s, c, 1, 1) * 0.3).requires_grad_(), torch.randn(s).requires_grad_(),
+                      (torch.randn(c, s, 1, 1) * 0.3).requires_grad_(), torch.randn(c).requires_grad_()]
+            y = ops_fused._SeBlock.apply(x, *params)
+            gy = torch.randn_like(y)
+            y.backward(gy)
+            got = [y.detach()] + [t.grad.clone() for t in [x] + params]
+            for t in [x] + params:
+                t.grad = None
+            w1, b1, w2, b2 = params
+            gate = torch.sigmoid(torch.nn.functional.silu(x.mean(dim=(2, 3)) @ w1.flatten(1).t() + b1) @ w2.flatten(1).t() + b2)
+            ref = x * gate[:, :, None, None]
+            ref.backward(gy)
+            want = [ref.detach()] + [t.grad for t in [x] + params]
+            worst = max([worst] + [rel(a, b) for a, b in zip(got, want)])
+        out['mlp_kernels' if mlp else 'torch_mlp'] = worst
+    return out
+
+
+def bn_act(ops):
+    from stp3_amd.layers import fused
+    out = {}
+    torch.manual_seed(1)
+    for training in (True, False):
+        for dtype, tag in ((torch.float32, 'f32'), (torch.bfloat16, 'bf16')):
+            worst = 0.0
+            for act, res_mode, with_sbias, with_oscale in [(ops.ACT_RELU, ops.RES_NONE, False, False),
+                                                           (ops.ACT_SWISH, ops.RES_BEFORE_ACT, False, False),
+                                                           (ops.ACT_NONE, ops.RES_AFTER_ACT, False, True),
+                                                           (ops.ACT_RELU, ops.RES_NONE, True, False)]:
+                n, c, h, w = 4, 24, 5, 9
+                bn_a, bn_b = torch.nn.BatchNorm2d(c, eps=1e-3), torch.nn.BatchNorm2d(c, eps=1e-3)
+                with torch.no_grad():
+                    bn_a.weight.uniform_(0.5, 1.5); bn_a.bias.normal_(0, 0.2)
+                    bn_a.running_mean.normal_(0, 0.2); bn_a.running_var.uniform_(0.5, 1.5)
+                bn_b.load_state_dict(bn_a.state_dict())
+                bn_a.train(training); bn_b.train(training)
+                x0 = torch.randn(n, c, h, w).to(dtype).contiguous(memory_format=torch.channels_last)
+                r0 = torch.randn(n, c, h, w).to(dtype).contiguous(memory_format=torch.channels_last) if res_mode else None
+                sb0 = torch.randn(n, c) * 0.3 if with_sbias else None
+                osc = torch.rand(n) + 0.5 if with_oscale else None
+                gy = torch.randn(n, c, h, w).to(dtype).contiguous(memory_format=torch.channels_last)
+                res = []
+                for kernel, bn in ((True, bn_a), (False, bn_b)):
+                    # the torch statement always runs in float32 on the same (bf16-representable) inputs: the kernels
+                    # compute in float32 internally, a bf16 reference would round x + sbias first and flip ReLU masks
+                    cast = (lambda t: t.clone()) if kernel else (lambda t: t.float())
+                    x = cast(x0).requires_grad_()
+                    r = cast(r0).requires_grad_() if r0 is not None else None
+                    sb = sb0.clone().requires_grad_() if sb0 is not None else None
+                    fn = fused.bn_act if kernel else fused.bn_act_reference
+                    y = fn(bn, x, act, r, res_mode, sb, osc)
+                    y.backward(gy if kernel else gy.float())
+                    res.append([y.detach().float(), x.grad.float(), bn.weight.grad, bn.bias.grad] +
+                               ([r.grad.float()] if r is not None else []) + ([sb.grad] if sb is not None else []) +
+                               [bn.running_mean.clone(), bn.running_var.clone()])
+                worst = max([worst] + [rel(a, b) for a, b in zip(*res)])
+            out[f'{"train" if training else "eval"}_{tag}'] = worst
+    return out
+
+
+def conv(ops):
+    import torch.nn.functional as F
+    out = {}
+    ops.WGRAD_MIN_CHANNELS = 0
+    torch.manual_seed(2)
+    for name, (cin, cout, k, s, p, d, bias) in {'3x3': (16, 24, 3, 1, 1, 1, True), '1x1': (8, 40, 1, 1, 0, 1, False),
+                                                 '3x3s2': (16, 16, 3, 2, 1, 1, False), 'dil2': (8, 8, 3, 1, 2, 2, False)}.items():
+        x0 = torch.randn(2, cin, 9, 12).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w0 = (torch.randn(cout, cin, k, k) * 0.2).to(torch.bfloat16).float()       # bf16-representable weights
+        b0 = torch.randn(cout) if bias else None
+        x = x0.clone().requires_grad_()
+        w = w0.clone().requires_grad_()
+        b = b0.clone().requires_grad_() if bias else None
+        y = ops.conv2d(x, w, b, s, p, d, out_dtype=torch.float32)
+        gy = torch.randn_like(y).to(torch.bfloat16).float()
+        y.backward(gy)
+        xr = x0.float().requires_grad_()
+        wr = w0.clone().requires_grad_()
+        br = b0.clone().requires_grad_() if bias else None
+        yr = F.conv2d(xr, wr, br, s, p, d)
+        yr.backward(gy)
+        out[name] = {'y': rel(y.detach(), yr.detach()), 'dx': rel(x.grad.float(), xr.grad), 'dw': rel(w.grad, wr.grad),
+                     'db': rel(b.grad, br.grad) if bias else 0.0}
+    return out
+
+
+def dwconv(ops):
+    import torch.nn.functional as F
+    out = {}
+    torch.manual_seed(3)
+    for name, (k, s, pad) in {'k3s1': (3, 1, (1, 1, 1, 1)), 'k5s2': (5, 2, (1, 2, 1, 2)), 'k3s2': (3, 2, (0, 1, 0, 1))}.items():
+        c = 24
+        x0 = torch.randn(2, c, 9, 12).contiguous(memory_format=torch.channels_last)
+        w0 = torch.randn(c, 1, k, k) * 0.3
+        x, w = x0.clone().requires_grad_(), w0.clone().requires_grad_()
+        y = ops.depthwise_conv2d(x, w, s, pad)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        xr, wr = x0.clone().requires_grad_(), w0.clone().requires_grad_()
+        yr = F.conv2d(F.pad(xr, pad), wr, None, s, 0, 1, c)
+        yr.backward(gy)
+        out[name] = {'y': rel(y.detach(), yr.detach()), 'dx': rel(x.grad, xr.grad), 'dw': rel(w.grad, wr.grad)}
+    return out
+
+
+CASES = {f.__name__: f for f in (lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
+                                 conv, dwconv)}
+
+if __name__ == '__main__':
+    ops_mod = setup(sys.argv[1])
+    t0 = time.time()
+    result = CASES[sys.argv[2]](ops_mod)
+    result['seconds'] = round(time.time() - t0, 1)
+    print('RESULT ' + json.dumps(result))
