@@ -302,7 +302,49 @@ def dwconv(ops):
     return out
 
 
-CASES = {f.__name__: f for f in (lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
+def conv_bn(ops):
+    """conv -> BatchNorm -> act (+ skip / drop-connect) as ONE operator (conv v2 with the statistics in its epilogue)
+    against the two separate operators, and both against float32 torch on the same bf16-representable data."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from stp3_amd import ops_fused
+    from stp3_amd.layers import fused
+    ops.WGRAD_MIN_CHANNELS = 0
+    out = {}
+    cases = {'3x3 relu': (16, 24, 3, 1, ops.ACT_RELU, ops.RES_NONE, False),
+             '1x1 project + drop-connect + skip': (40, 16, 1, 0, ops.ACT_NONE, ops.RES_AFTER_ACT, True),
+             '3x3 swish + skip before': (16, 16, 3, 1, ops.ACT_SWISH, ops.RES_BEFORE_ACT, False)}
+    for name, (cin, cout, k, pad, act, rm, with_oscale) in cases.items():
+        g = torch.Generator().manual_seed(7)
+        cl = torch.channels_last
+        x0 = torch.randn(4, cin, 7, 10, generator=g).to(torch.bfloat16).contiguous(memory_format=cl)
+        r0 = torch.randn(4, cout, 7, 10, generator=g).to(torch.bfloat16).contiguous(memory_format=cl) if rm else None
+        gy = torch.randn(4, cout, 7, 10, generator=g).to(torch.bfloat16).contiguous(memory_format=cl)
+        osc = torch.tensor([1.25, 0.0, 1.25, 1.25]) if with_oscale else None
+        w0 = (torch.randn(cout, cin, k, k, generator=g) * 0.2).to(torch.bfloat16).float()
+        res = []
+        for mode in ('fused', 'separate', 'torch'):
+            conv = nn.Conv2d(cin, cout, k, padding=pad, bias=False)
+            with torch.no_grad():
+                conv.weight.copy_(w0)
+            bn = nn.BatchNorm2d(cout)
+            x = (x0.float() if mode == 'torch' else x0.clone()).requires_grad_()
+            r = None if r0 is None else (r0.float() if mode == 'torch' else r0.clone()).requires_grad_()
+            if mode == 'fused':
+                y = ops_fused.conv_bn_act(x, conv.weight, None, bn, act, r, rm, 1, pad, 1, group=False, oscale=osc)
+            elif mode == 'separate':
+                y = fused.bn_act(bn, ops.conv2d(x, conv.weight, None, 1, pad, 1), act, res=r, res_mode=rm, oscale=osc)
+            else:
+                y = fused.bn_act_reference(bn, F.conv2d(x, conv.weight, None, 1, pad), act, r, rm, None, osc)
+            y.backward(gy.float() if mode == 'torch' else gy)
+            res.append([y.detach().float(), x.grad.float(), conv.weight.grad, bn.weight.grad, bn.bias.grad, bn.running_mean,
+                        bn.running_var] + ([r.grad.float()] if r is not None else []))
+        out[name] = {'fused_vs_separate': max(rel(a, b) for a, b in zip(res[0], res[1])),
+                     'fused_vs_torch_f32': max(rel(a, b) for a, b in zip(res[0], res[2]))}
+    return out
+
+
+CASES = {f.__name__: f for f in (conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
                                  conv, dwconv)}
 
 if __name__ == '__main__':

@@ -29,8 +29,12 @@ sys.path.insert(0, HIPCPU)
 import build as hipcpu_build  # noqa: E402
 
 MFMA = {'STP3_LIFT_FWD': 'mfma', 'STP3_LIFT_BWD': 'mfma'}
+CPP = {'STP3_CPP_OPS': '1', 'STP3_HOST_DRYRUN': '1'}       # the C++ launch path, driving the same (CPU-built) library
+BN_GEOM = {'STP3_BN_GEOM': '1'}
+HAVE_CPP = os.path.exists(os.path.join(ROOT, 'st-p3_amd', 'stp3_amd', '_stp3_host.so'))
 ROUTINE = [('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('conv', {}),
-           ('lift_c16', {}), ('lift_c16', MFMA)]
+           ('conv_bn', {}), ('bn_act', BN_GEOM), ('lift_c16', {}), ('lift_c16', MFMA)] + \
+          ([('bn_act', CPP), ('conv', CPP), ('dwconv', CPP)] if HAVE_CPP else [])
 SLOW = [('lift_small', {}), ('lift_c16_rows32', MFMA), ('lift_c64_many_runs', MFMA), ('lift_tall', {})]
 
 pytestmark = pytest.mark.skipif(not os.path.exists(hipcpu_build.CLANG) or shutil.which('gcc') is None,
@@ -110,6 +114,28 @@ def test_batchnorm_kernels(results):
     r = _get(results, 'bn_act')
     assert r['train_f32'] <= 1e-4 and r['eval_f32'] <= 1e-4            # tests/test_bnact_gpu.py: float32 rtol 1e-4
     assert r['train_bf16'] <= 2e-2 and r['eval_bf16'] <= 2e-2          # bf16 rtol 2e-2
+
+
+def test_batchnorm_full_occupancy_geometry(results):
+    r = _get(results, 'bn_act', BN_GEOM)
+    assert r['train_f32'] <= 1e-4 and r['eval_f32'] <= 1e-4 and r['train_bf16'] <= 2e-2 and r['eval_bf16'] <= 2e-2
+
+
+def test_fused_conv_batchnorm_operator(results):
+    for name, r in _get(results, 'conv_bn').items():
+        if name == 'seconds':
+            continue
+        assert r['fused_vs_separate'] <= 1e-5, (name, r)         # same kernels underneath: the statistics only move
+        assert r['fused_vs_torch_f32'] <= 1e-1, (name, r)        # bf16 convolution output in front of a ReLU
+
+
+@pytest.mark.skipif(not HAVE_CPP, reason='C++ launch path not built')
+def test_cpp_launch_path_computes_the_same_numbers(results):
+    """Same kernels, driven by csrc/host/stp3_host.cpp instead of the ctypes path: identical deviations."""
+    for case in ('bn_act', 'conv', 'dwconv'):
+        a, b = dict(_get(results, case)), dict(_get(results, case, CPP))
+        a.pop('seconds'), b.pop('seconds')
+        assert a == b, (case, a, b)
 
 
 def test_convolution_kernels(results):
