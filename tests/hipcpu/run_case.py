@@ -344,7 +344,97 @@ def conv_bn(ops):
     return out
 
 
-CASES = {f.__name__: f for f in (conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
+def _model_step(ops, autocast, flags=None):
+    """One whole training step (encoder, lift, temporal model, decoder, losses, backward) through the kernels, against
+    the CPU port of the same model (oracle/cpu_model.py: reference-algorithm lift, plain torch everywhere else)."""
+    import torch.nn as nn
+    from oracle.cpu_model import CpuPortSTP3
+    from stp3_amd import synthetic
+    from stp3_amd.config import perception_cfg
+    from stp3_amd.trainer import TrainingModule
+    from stp3_amd.utils import to_channels_last
+    for mod, name, val in (flags or []):
+        setattr(mod, name, val)
+    cfg = perception_cfg(**{'IMAGE.FINAL_DIM': (64, 96), 'LIFT.X_BOUND': [-10.0, 10.0, 0.5], 'LIFT.Y_BOUND': [-10.0, 10.0, 0.5],
+                            'LIFT.D_BOUND': [2.0, 10.0, 1.0]})
+    g = torch.Generator().manual_seed(3)
+    intr, extr, ego = synthetic.make_rig(1, 3, 6, (64, 96), seed=3)
+    batch = {'image': torch.randn(1, 3, 6, 3, 64, 96, generator=g), 'intrinsics': intr, 'extrinsics': extr,
+             'future_egomotion': ego, 'segmentation': (torch.rand(1, 3, 1, 40, 40, generator=g) > 0.9).long(),
+             'pedestrian': (torch.rand(1, 3, 1, 40, 40, generator=g) > 0.95).long(),
+             'hdmap': (torch.rand(1, 3, 2, 40, 40, generator=g) > 0.7).long(), 'gt_trajectory': torch.zeros(1, 3, 3)}
+
+    def quiet(module):
+        module.train()
+        for m in module.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0
+        module.model.encoder.backbone._global_params.drop_connect_rate = 0.0
+        return module
+
+    torch.manual_seed(11)
+    module = quiet(to_channels_last(TrainingModule(cfg.convert_to_dict())))
+    state = {k: v.clone() for k, v in module.model.state_dict().items()}
+    # ---- reference first, with tensors that say what they are (CPU): plain torch + the oracle's lift ----
+    del torch.Tensor.is_cuda
+    ref = quiet(TrainingModule(cfg.convert_to_dict()))
+    port = CpuPortSTP3(cfg)
+    port.load_state_dict(state, strict=False)
+    for name in ('segmentation_weight', 'pedestrian_weight', 'hdmap_weight'):
+        setattr(port, name, getattr(ref.model, name))
+    ref.model = port
+    quiet(ref)
+    ref_loss = ref.training_step(batch)
+    ref_loss.backward()
+    ref_grads = {n: p.grad.clone() for n, p in ref.model.named_parameters() if p.grad is not None}
+    # ---- the GPU code path on the kernels ----
+    torch.Tensor.is_cuda = property(lambda self: True)
+    if autocast:
+        torch.is_autocast_enabled = lambda *a: True
+        torch.get_autocast_gpu_dtype = lambda: torch.bfloat16
+    module.model.prepare_plan(intr, extr, ego, torch.device('cpu'))
+    if autocast:
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            loss = module.training_step(batch)
+    else:
+        loss = module.training_step(batch)
+    loss.backward()
+    num = den = 0.0
+    worst, worst_name, missing = 0.0, '', []
+    for n, p in module.model.named_parameters():
+        if n not in ref_grads:
+            continue
+        if p.grad is None:
+            missing.append(n)
+            continue
+        a, b = p.grad.double(), ref_grads[n].double()
+        num += float((a - b).pow(2).sum())
+        den += float(b.pow(2).sum())
+        e = float((a - b).norm() / b.norm().clamp_min(1e-12))
+        if e > worst and float(b.norm()) > 1e-6:
+            worst, worst_name = e, n
+    return {'loss': float(loss), 'ref_loss': float(ref_loss), 'grad_rel_l2': (num / max(den, 1e-30)) ** 0.5,
+            'worst_param_rel_l2': worst, 'worst_param': worst_name, 'params_without_grad': missing}
+
+
+def model_step_f32(ops):            # float32: BatchNorm / depthwise / voxel-pool kernels (dense convolutions stay on torch)
+    return _model_step(ops, autocast=False)
+
+
+def model_step_bf16(ops):           # bf16 autocast: the MFMA convolution kernels too
+    return _model_step(ops, autocast=True)
+
+
+def model_step_bf16_switches(ops):  # ... with the fused trunk operators, SE kernels and weight shadows switched on
+    from stp3_amd import ops_fused
+    from stp3_amd.layers import fused
+    from stp3_amd.models import efficientnet
+    flags = [(fused, '_CONV_V2', True), (efficientnet, '_FUSED_SE', True), (ops_fused, '_SE_MLP', True),
+             (ops, '_WEIGHT_PREP', True), (fused, '_MFMA_MODE', 'all'), (efficientnet, '_MFMA_ALL', True)]
+    return _model_step(ops, autocast=True, flags=flags)
+
+
+CASES = {f.__name__: f for f in (model_step_f32, model_step_bf16, model_step_bf16_switches, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
                                  conv, dwconv)}
 
 if __name__ == '__main__':
