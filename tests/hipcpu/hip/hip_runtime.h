@@ -6,28 +6,26 @@
 // LOGIC of a kernel, not its performance, and it cannot see hardware-only effects (memory model, occupancy limits).
 //
 // Semantics implemented (what the kernels in st-p3_amd/csrc use, nothing more):
-//   * blocks run sequentially; the threads of a block are real threads; __syncthreads() is a barrier over the
-//     threads of the block that have not returned yet (a returned thread drops out, as on the GPU)
+//   * every HIP thread is a FIBER (ucontext); the fibers of a workgroup are scheduled round-robin on one OS thread,
+//     several workgroups run in parallel on a small pool of OS threads (shared memory is thread_local to the pool
+//     thread).  __syncthreads() is a barrier over the threads of the block that have not returned yet (a returned
+//     thread drops out, as on the GPU)
 //   * a wave = 64 consecutive threads; wave intrinsics exchange values through a per-wave buffer with two wave
-//     barriers, so they must be reached by all live lanes of the wave (convergent use) -- otherwise the run aborts
-//     after a timeout with a message instead of hanging
+//     barriers, so they must be reached by all live lanes of the wave (convergent use) -- if no fiber of a block can
+//     make progress the run aborts with a message (exact deadlock detection, no timeouts)
 //   * v_mfma_f32_16x16x4_f32 and v_mfma_f32_16x16x32_bf16 with the operand / result lane maps of the CDNA3/4 ISA
 //     (cdna_hip_programming.md section 3): A[i = l & 15][k-chunk = l >> 4], B[k-chunk = l >> 4][j = l & 15],
 //     D[4 * (l >> 4) + r][l & 15]; fp32 products are chained with fmaf in ascending k
-//   * __shared__ arrays are `static` (one block at a time); `extern __shared__` declarations are rewritten by the
-//     build script into a pointer to one 160 KB buffer
+//   * __shared__ arrays are `static thread_local` (one block per pool thread at a time); `extern __shared__`
+//     declarations are rewritten by the build script into a pointer to a 160 KB thread_local buffer
 #pragma once
 #include <atomic>
-#include <chrono>
 #include <cmath>
-#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
-#include <mutex>
-#include <thread>
 #include <vector>
 
 #define __global__
@@ -35,7 +33,7 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static thread_local
 #define warpSize 64
 
 typedef void* hipStream_t;
@@ -71,27 +69,19 @@ constexpr size_t kDynLds = 160 * 1024;
     std::abort();
 }
 
-// barrier over the threads that are still alive; drop() removes a participant for good
-class Barrier {
-public:
-    void reset(int n) { std::lock_guard<std::mutex> g(m_); expected_ = n; waiting_ = 0; ++gen_; }
-    void wait() {
-        std::unique_lock<std::mutex> g(m_);
-        const unsigned gen = gen_;
-        if (++waiting_ >= expected_) { waiting_ = 0; ++gen_; cv_.notify_all(); return; }
-        if (!cv_.wait_for(g, std::chrono::seconds(600), [&] { return gen != gen_; }))
-            die("barrier timeout: a barrier or wave intrinsic was not reached by all live threads (divergent use?)");
-    }
+void yield_to_scheduler();
+
+// barrier over the fibers that are still alive; drop() removes a participant for good.  All fibers of a block live on
+// one OS thread, so plain counters suffice.
+struct Barrier {
+    int live = 0, arrived = 0;
+    unsigned gen = 0;
+    void reset(int n) { live = n; arrived = 0; ++gen; }
+    void wait();
     void drop() {
-        std::lock_guard<std::mutex> g(m_);
-        --expected_;
-        if (expected_ > 0 && waiting_ >= expected_) { waiting_ = 0; ++gen_; cv_.notify_all(); }
+        --live;
+        if (live > 0 && arrived >= live) { arrived = 0; ++gen; }
     }
-private:
-    std::mutex m_;
-    std::condition_variable cv_;
-    int expected_ = 0, waiting_ = 0;
-    unsigned gen_ = 0;
 };
 
 struct Wave {
@@ -108,19 +98,30 @@ struct Ctx {
     dim3 tid, bid, bdim, gdim;
     int lane = 0, wave = 0;
     Block* block = nullptr;
+    const Barrier* waiting_on = nullptr;      // set while parked in a barrier
+    unsigned wait_gen = 0;
 };
-extern thread_local Ctx tls;
-extern unsigned char g_dyn_lds[kDynLds];
+extern thread_local Ctx* cur;                 // the fiber that is running on this OS thread
+extern thread_local unsigned char g_dyn_lds[kDynLds];
 inline void* dyn_lds() { return g_dyn_lds; }
 
-inline Wave& my_wave() { return tls.block->waves[tls.wave]; }
+inline void Barrier::wait() {
+    const unsigned g = gen;
+    if (++arrived >= live) { arrived = 0; ++gen; return; }
+    cur->waiting_on = this;
+    cur->wait_gen = g;
+    while (gen == g) yield_to_scheduler();
+    cur->waiting_on = nullptr;
+}
+
+inline Wave& my_wave() { return cur->block->waves[cur->wave]; }
 
 // every live lane of the wave deposits `v`, then reads the value deposited by lane `src`
 template <typename T>
 inline T exchange(T v, int src) {
     static_assert(sizeof(T) <= 32, "exchange payload");
     Wave& w = my_wave();
-    std::memcpy(w.slot[0][tls.lane], &v, sizeof(T));
+    std::memcpy(w.slot[0][cur->lane], &v, sizeof(T));
     w.bar.wait();
     T r;
     std::memcpy(&r, w.slot[0][src & (kWave - 1)], sizeof(T));
@@ -132,14 +133,14 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
 
 }  // namespace hipcpu
 
-#define threadIdx (hipcpu::tls.tid)
-#define blockIdx (hipcpu::tls.bid)
-#define blockDim (hipcpu::tls.bdim)
-#define gridDim (hipcpu::tls.gdim)
+#define threadIdx (hipcpu::cur->tid)
+#define blockIdx (hipcpu::cur->bid)
+#define blockDim (hipcpu::cur->bdim)
+#define gridDim (hipcpu::cur->gdim)
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
     hipcpu::launch((grid), (block), (size_t)(lds), [=]() { kernel(__VA_ARGS__); })
 
-inline void __syncthreads() { hipcpu::tls.block->bar.wait(); }
+inline void __syncthreads() { hipcpu::cur->block->bar.wait(); }
 inline void __builtin_amdgcn_wave_barrier_() { hipcpu::my_wave().bar.wait(); }
 #define __builtin_amdgcn_wave_barrier __builtin_amdgcn_wave_barrier_
 #define __builtin_amdgcn_fence(order, scope) std::atomic_thread_fence(std::memory_order_seq_cst)
@@ -164,19 +165,19 @@ inline int readlane_i(int v, int lane) { return hipcpu::exchange<int>(v, lane); 
 #define __builtin_amdgcn_readfirstlane(v) (v)
 
 template <typename T>
-inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return hipcpu::exchange<T>(v, hipcpu::tls.lane ^ mask); }
+inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return hipcpu::exchange<T>(v, hipcpu::cur->lane ^ mask); }
 template <typename T>
 inline T __shfl_up(T v, unsigned delta, int width = 64) {
     (void)width;
-    const int src = hipcpu::tls.lane - (int)delta;
-    const T r = hipcpu::exchange<T>(v, src < 0 ? hipcpu::tls.lane : src);
+    const int src = hipcpu::cur->lane - (int)delta;
+    const T r = hipcpu::exchange<T>(v, src < 0 ? hipcpu::cur->lane : src);
     return src < 0 ? v : r;
 }
 inline unsigned long long __ballot(int pred) {
     hipcpu::Wave& w = hipcpu::my_wave();
     const int p = pred ? 1 : 0;
-    std::memcpy(w.slot[0][hipcpu::tls.lane], &p, 4);
-    std::memset(w.slot[1][hipcpu::tls.lane], 1, 1);                  // "this lane is alive and voted"
+    std::memcpy(w.slot[0][hipcpu::cur->lane], &p, 4);
+    std::memset(w.slot[1][hipcpu::cur->lane], 1, 1);                  // "this lane is alive and voted"
     w.bar.wait();
     unsigned long long m = 0;
     for (int l = 0; l < hipcpu::kWave; ++l) {
@@ -185,7 +186,7 @@ inline unsigned long long __ballot(int pred) {
         if (w.slot[1][l][0] == 1 && q) m |= 1ull << l;
     }
     w.bar.wait();
-    w.slot[1][hipcpu::tls.lane][0] = 0;
+    w.slot[1][hipcpu::cur->lane][0] = 0;
     return m;
 }
 
@@ -210,7 +211,7 @@ inline unsigned __builtin_amdgcn_perm_(unsigned a, unsigned b, unsigned sel) {
 // row_bcast31 0x143; lanes of rows that row_mask disables (or without a valid source) receive `old`
 inline int update_dpp_(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     (void)bank_mask; (void)bound_ctrl;
-    const int lane = hipcpu::tls.lane, row = lane >> 4;
+    const int lane = hipcpu::cur->lane, row = lane >> 4;
     int from = -1;
     if (ctrl >= 0 && ctrl <= 0xff) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
     else if (ctrl == 0x140) from = (lane & ~15) | (15 - (lane & 15));
@@ -230,7 +231,7 @@ typedef __bf16 hipcpu_bf16x8 __attribute__((ext_vector_type(8)));
 
 inline hipcpu_f32x4 mfma_f32_16x16x4f32_(float a, float b, hipcpu_f32x4 c, int, int, int) {
     hipcpu::Wave& w = hipcpu::my_wave();
-    const int lane = hipcpu::tls.lane;
+    const int lane = hipcpu::cur->lane;
     std::memcpy(w.slot[0][lane], &a, 4);
     std::memcpy(w.slot[1][lane], &b, 4);
     w.bar.wait();
@@ -262,7 +263,7 @@ template <typename V>
 inline hipcpu_f32x4 mfma_f32_16x16x32_bf16_(V a, V b, hipcpu_f32x4 c, int, int, int) {
     static_assert(sizeof(V) == 16, "8 x bf16 per lane");
     hipcpu::Wave& w = hipcpu::my_wave();
-    const int lane = hipcpu::tls.lane;
+    const int lane = hipcpu::cur->lane;
     std::memcpy(w.slot[0][lane], &a, 16);
     std::memcpy(w.slot[1][lane], &b, 16);
     w.bar.wait();

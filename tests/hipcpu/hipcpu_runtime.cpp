@@ -1,53 +1,134 @@
 // TEST INFRASTRUCTURE -- execution engine of the CPU stand-in for HIP (see hip/hip_runtime.h in this directory).
+//
+// A launch hands its workgroups to a small pool of OS threads.  A pool thread runs one workgroup at a time: every HIP
+// thread of the group is a fiber (ucontext) with its own stack; the fibers run round-robin until each has returned.
+// A fiber that reaches a barrier parks until the barrier's generation moves; if a full pass over the live fibers
+// resumes none and none has finished, the workgroup is deadlocked (a barrier or wave intrinsic reached by only part
+// of its threads) and the process aborts with a message.
 #include <hip/hip_runtime.h>
+
+#include <sys/mman.h>
+#include <ucontext.h>
+
+#include <thread>
 
 namespace hipcpu {
 
-thread_local Ctx tls;
-alignas(64) unsigned char g_dyn_lds[kDynLds];
+thread_local Ctx* cur = nullptr;
+alignas(64) thread_local unsigned char g_dyn_lds[kDynLds];
 
-// One launch: `nthreads` OS threads walk the grid together, block after block.  An outer (never dropped) barrier
-// separates the blocks so that static / dynamic shared memory of one block is not reused while threads of the
-// previous block are still running; a thread whose kernel body returned drops out of the block's barriers.
+namespace {
+
+constexpr size_t kStack = 256 * 1024;
+
+struct Fiber {
+    ucontext_t ctx;
+    void* stack = nullptr;
+    Ctx c;
+    bool done = false;
+};
+
+struct Worker {
+    ucontext_t sched;
+    std::vector<Fiber> fibers;
+    const std::function<void()>* kernel = nullptr;
+    int running = -1;
+};
+thread_local Worker* wk = nullptr;
+
+void trampoline() {
+    Worker* w = wk;
+    Fiber& f = w->fibers[w->running];
+    (*w->kernel)();
+    f.done = true;
+    f.c.block->waves[f.c.wave].bar.drop();
+    f.c.block->bar.drop();
+    swapcontext(&f.ctx, &w->sched);
+}
+
+void run_block(Worker& w, Block& blk, dim3 grid, dim3 block, long long b, int nthreads, int nwaves) {
+    blk.bar.reset(nthreads);
+    for (int v = 0; v < nwaves; ++v) {
+        blk.waves[v].bar.reset(std::min(kWave, nthreads - v * kWave));
+        std::memset(blk.waves[v].slot, 0, sizeof(blk.waves[v].slot));
+    }
+    const dim3 bid((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long long)grid.x * grid.y)));
+    for (int t = 0; t < nthreads; ++t) {
+        Fiber& f = w.fibers[t];
+        f.done = false;
+        f.c = Ctx();
+        f.c.block = &blk;
+        f.c.bdim = block;
+        f.c.gdim = grid;
+        f.c.bid = bid;
+        f.c.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+        f.c.lane = t % kWave;
+        f.c.wave = t / kWave;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = kStack;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, trampoline, 0);
+    }
+    int left = nthreads;
+    while (left > 0) {
+        bool progressed = false;
+        for (int t = 0; t < nthreads; ++t) {
+            Fiber& f = w.fibers[t];
+            if (f.done) continue;
+            if (f.c.waiting_on && f.c.waiting_on->gen == f.c.wait_gen) continue;     // still parked
+            w.running = t;
+            cur = &f.c;
+            swapcontext(&w.sched, &f.ctx);
+            progressed = true;
+            if (f.done) --left;
+        }
+        if (!progressed) die("deadlock inside a workgroup: a barrier or wave intrinsic was reached by only part of its threads");
+    }
+    cur = nullptr;
+}
+
+}  // namespace
+
+void yield_to_scheduler() {
+    Worker* w = wk;
+    swapcontext(&w->fibers[w->running].ctx, &w->sched);
+}
+
 void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& kernel) {
     const int nthreads = (int)(block.x * block.y * block.z);
     if (nthreads <= 0 || nthreads > 1024) die("block size out of range");
     if (lds_bytes > kDynLds) die("dynamic LDS request above 160 KB");
     const int nwaves = (nthreads + kWave - 1) / kWave;
-    Block blk;
-    blk.waves = std::vector<Wave>(nwaves);
-    Barrier outer;
-    outer.reset(nthreads);
     const long long nblocks = (long long)grid.x * grid.y * grid.z;
-    auto worker = [&](int t) {
-        Ctx& c = tls;
-        c.block = &blk;
-        c.bdim = block;
-        c.gdim = grid;
-        c.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-        c.lane = t % kWave;
-        c.wave = t / kWave;
-        for (long long b = 0; b < nblocks; ++b) {
-            c.bid = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long long)grid.x * grid.y)));
-            if (t == 0) {
-                blk.bar.reset(nthreads);
-                for (int w = 0; w < nwaves; ++w) {
-                    const int live = std::min(kWave, nthreads - w * kWave);
-                    blk.waves[w].bar.reset(live);
-                    std::memset(blk.waves[w].slot, 0, sizeof(blk.waves[w].slot));
-                }
-            }
-            outer.wait();
-            kernel();
-            blk.waves[c.wave].bar.drop();
-            blk.bar.drop();
-            outer.wait();
+    if (nblocks <= 0) return;
+    static const int pool = [] {
+        const char* e = std::getenv("HIPCPU_THREADS");
+        int n = e ? std::atoi(e) : (int)std::thread::hardware_concurrency();
+        return n < 1 ? 1 : (n > 16 ? 16 : n);
+    }();
+    const int nworkers = (int)std::min<long long>(pool, nblocks);
+    std::atomic<long long> next{0};
+    auto body = [&]() {
+        Worker w;
+        w.kernel = &kernel;
+        w.fibers.resize(nthreads);
+        for (auto& f : w.fibers) {
+            f.stack = mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+            if (f.stack == MAP_FAILED) die("cannot map a fiber stack");
         }
+        wk = &w;
+        Block blk;
+        blk.waves = std::vector<Wave>(nwaves);
+        for (long long b = next.fetch_add(1); b < nblocks; b = next.fetch_add(1))
+            run_block(w, blk, grid, block, b, nthreads, nwaves);
+        wk = nullptr;
+        for (auto& f : w.fibers) munmap(f.stack, kStack);
     };
-    std::vector<std::thread> pool;
-    pool.reserve(nthreads);
-    for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker, t);
-    for (auto& th : pool) th.join();
+    std::vector<std::thread> threads;
+    for (int i = 1; i < nworkers; ++i) threads.emplace_back(body);
+    body();
+    for (auto& t : threads) t.join();
 }
 
 }  // namespace hipcpu
