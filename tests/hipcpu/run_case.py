@@ -344,7 +344,7 @@ def conv_bn(ops):
     return out
 
 
-def _model_step(ops, autocast, flags=None):
+def _model_step(ops, autocast, flags=None, bn_eval=False):
     """One whole training step (encoder, lift, temporal model, decoder, losses, backward) through the kernels, against
     the CPU port of the same model (oracle/cpu_model.py: reference-algorithm lift, plain torch everywhere else)."""
     import torch.nn as nn
@@ -370,6 +370,10 @@ def _model_step(ops, autocast, flags=None):
             if isinstance(m, nn.Dropout):
                 m.p = 0.0
         module.model.encoder.backbone._global_params.drop_connect_rate = 0.0
+        if bn_eval:            # running statistics: without batch statistics over 4x6 maps the step is a smooth function
+            for m in module.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()
         return module
 
     torch.manual_seed(11)
@@ -401,6 +405,16 @@ def _model_step(ops, autocast, flags=None):
     loss.backward()
     num = den = 0.0
     worst, worst_name, missing = 0.0, '', []
+    groups = {}
+
+    def group_of(n):                                  # from the loss backwards: decoder, temporal model, encoder heads, trunk
+        parts = n.split('.')
+        if parts[0] != 'encoder':
+            return parts[0]
+        if parts[1] != 'backbone':
+            return 'encoder.' + parts[1]
+        return 'trunk.' + (f'block{int(parts[3]):02d}' if parts[2] == '_blocks' else parts[2])
+
     for n, p in module.model.named_parameters():
         if n not in ref_grads:
             continue
@@ -410,11 +424,15 @@ def _model_step(ops, autocast, flags=None):
         a, b = p.grad.double(), ref_grads[n].double()
         num += float((a - b).pow(2).sum())
         den += float(b.pow(2).sum())
+        gacc = groups.setdefault(group_of(n), [0.0, 0.0])
+        gacc[0] += float((a - b).pow(2).sum())
+        gacc[1] += float(b.pow(2).sum())
         e = float((a - b).norm() / b.norm().clamp_min(1e-12))
         if e > worst and float(b.norm()) > 1e-6:
             worst, worst_name = e, n
     return {'loss': float(loss), 'ref_loss': float(ref_loss), 'grad_rel_l2': (num / max(den, 1e-30)) ** 0.5,
-            'worst_param_rel_l2': worst, 'worst_param': worst_name, 'params_without_grad': missing}
+            'worst_param_rel_l2': worst, 'worst_param': worst_name, 'params_without_grad': missing,
+            'grad_rel_l2_by_group': {k: round((v[0] / max(v[1], 1e-30)) ** 0.5, 4) for k, v in sorted(groups.items())}}
 
 
 def model_step_f32(ops):            # float32: BatchNorm / depthwise / voxel-pool kernels (dense convolutions stay on torch)
@@ -423,6 +441,10 @@ def model_step_f32(ops):            # float32: BatchNorm / depthwise / voxel-poo
 
 def model_step_bf16(ops):           # bf16 autocast: the MFMA convolution kernels too
     return _model_step(ops, autocast=True)
+
+
+def model_step_bf16_bn_eval(ops):   # the same with BatchNorm on its running statistics (see _model_step)
+    return _model_step(ops, autocast=True, bn_eval=True)
 
 
 def model_step_bf16_switches(ops):  # ... with the fused trunk operators, SE kernels and weight shadows switched on
@@ -434,7 +456,16 @@ def model_step_bf16_switches(ops):  # ... with the fused trunk operators, SE ker
     return _model_step(ops, autocast=True, flags=flags)
 
 
-CASES = {f.__name__: f for f in (model_step_f32, model_step_bf16, model_step_bf16_switches, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
+def model_step_bf16_switches_bn_eval(ops):
+    from stp3_amd import ops_fused
+    from stp3_amd.layers import fused
+    from stp3_amd.models import efficientnet
+    flags = [(efficientnet, '_FUSED_SE', True), (ops_fused, '_SE_MLP', True), (ops, '_WEIGHT_PREP', True),
+             (fused, '_MFMA_MODE', 'all'), (efficientnet, '_MFMA_ALL', True)]
+    return _model_step(ops, autocast=True, flags=flags, bn_eval=True)
+
+
+CASES = {f.__name__: f for f in (model_step_bf16_switches_bn_eval, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, model_step_bf16_switches, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
                                  conv, dwconv)}
 
 if __name__ == '__main__':
