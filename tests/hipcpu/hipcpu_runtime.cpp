@@ -10,6 +10,7 @@
 #include <sys/mman.h>
 #include <ucontext.h>
 
+#include <algorithm>
 #include <thread>
 
 namespace hipcpu {
@@ -70,10 +71,26 @@ void run_block(Worker& w, Block& blk, dim3 grid, dim3 block, long long b, int nt
         f.ctx.uc_link = nullptr;
         makecontext(&f.ctx, trampoline, 0);
     }
+    // The order in which runnable fibers are resumed is not part of HIP's contract.  HIPCPU_ORDER=reverse / random
+    // changes it, so that a missing barrier (an LDS / global hand-off that only works because thread i happened to run
+    // before thread j) shows up as a wrong result under one of the orders.
+    static const int order_mode = [] {
+        const char* e = std::getenv("HIPCPU_ORDER");
+        return !e ? 0 : !std::strcmp(e, "reverse") ? 1 : !std::strcmp(e, "random") ? 2 : 0;
+    }();
+    std::vector<int> order(nthreads);
+    for (int t = 0; t < nthreads; ++t) order[t] = order_mode == 1 ? nthreads - 1 - t : t;
+    unsigned rng = 12345u + (unsigned)b * 2654435761u;
     int left = nthreads;
     while (left > 0) {
         bool progressed = false;
-        for (int t = 0; t < nthreads; ++t) {
+        if (order_mode == 2)
+            for (int i = nthreads - 1; i > 0; --i) {                      // Fisher-Yates with an LCG, new order every pass
+                rng = rng * 1664525u + 1013904223u;
+                std::swap(order[i], order[(rng >> 8) % (unsigned)(i + 1)]);
+            }
+        for (int k = 0; k < nthreads; ++k) {
+            const int t = order[k];
             Fiber& f = w.fibers[t];
             if (f.done) continue;
             if (f.c.waiting_on && f.c.waiting_on->gen == f.c.wait_gen) continue;     // still parked

@@ -31,9 +31,13 @@ MFMA = {'STP3_LIFT_FWD': 'mfma', 'STP3_LIFT_BWD': 'mfma'}
 CPP = {'STP3_CPP_OPS': '1', 'STP3_HOST_DRYRUN': '1'}       # the C++ launch path, driving the same (CPU-built) library
 BN_GEOM = {'STP3_BN_GEOM': '1'}
 HAVE_CPP = os.path.exists(os.path.join(ROOT, 'st-p3_amd', 'stp3_amd', '_stp3_host.so'))
+REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
 ROUTINE = [('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('conv', {}),
            ('conv_bn', {}), ('bn_act', BN_GEOM), ('lift_c16', {}), ('lift_c16', MFMA)] + \
           ([('bn_act', CPP), ('conv', CPP), ('dwconv', CPP)] if HAVE_CPP else [])
+ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'lift_c16']
+ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)] + \
+           [('lift_c16', dict(MFMA, **o)) for o in (REVERSE, RANDOM)] + [('bn_act', dict(BN_GEOM, **REVERSE))]
 MODEL = [('model_step_f32', {}), ('model_step_bf16_bn_eval', {}), ('model_step_bf16_switches', {}),
          ('model_step_bf16_switches_bn_eval', {})]        # whole training steps: minutes, STP3_SLOW_TESTS=1
 SLOW = [('lift_small', {}),   # (minutes each on the first, OS-thread engine; seconds on fibers)
@@ -44,7 +48,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(hipcpu_build.CLANG) or shutil
 
 
 def _run(lib, case, env_extra):
-    env = {k: v for k, v in os.environ.items() if not k.startswith('STP3_')}
+    env = {k: v for k, v in os.environ.items() if not k.startswith(('STP3_', 'HIPCPU_'))}
     env.update(env_extra)
     out = subprocess.run([sys.executable, os.path.join(HIPCPU, 'run_case.py'), lib, case], env=env, capture_output=True,
                          text=True, timeout=3000)
@@ -195,3 +199,22 @@ def test_whole_step_with_every_trunk_switch_on(results):
     e = _get(results, 'model_step_bf16_switches_bn_eval')
     assert not e['params_without_grad']
     assert abs(e['loss'] - e['ref_loss']) <= 2e-2 * abs(e['ref_loss']) and e['grad_rel_l2'] <= 5e-2
+
+
+def test_results_do_not_depend_on_the_thread_schedule(results):
+    """Every kernel case again with the fibers of a workgroup resumed in reverse and in random order: a hand-off through
+    LDS or global memory that lacks its barrier gives different numbers under one of them."""
+    for case in ORDER_CASES:
+        base = dict(_get(results, case))
+        base.pop('seconds')
+        for order in (REVERSE, RANDOM):
+            other = dict(_get(results, case, order))
+            other.pop('seconds')
+            assert other == base, (case, order, base, other)
+    for order in (REVERSE, RANDOM):
+        a, b = dict(_get(results, 'lift_c16', MFMA)), dict(_get(results, 'lift_c16', dict(MFMA, **order)))
+        a.pop('seconds'), b.pop('seconds')
+        assert a == b, order
+    a, b = dict(_get(results, 'bn_act', BN_GEOM)), dict(_get(results, 'bn_act', dict(BN_GEOM, **REVERSE)))
+    a.pop('seconds'), b.pop('seconds')
+    assert a == b
