@@ -47,7 +47,10 @@ void trampoline() {
     swapcontext(&f.ctx, &w->sched);
 }
 
-void run_block(Worker& w, Block& blk, dim3 grid, dim3 block, long long b, int nthreads, int nwaves) {
+void run_block(Worker& w, Block& blk, dim3 grid, dim3 block, long long b, int nthreads, int nwaves, size_t lds_bytes) {
+    // LDS is not initialised on the GPU: poison the dynamic part (NaN as float, -1 as int) so that a read of a
+    // location the block never wrote cannot go unnoticed
+    std::memset(g_dyn_lds, 0xFF, lds_bytes ? lds_bytes : 0);
     blk.bar.reset(nthreads);
     for (int v = 0; v < nwaves; ++v) {
         blk.waves[v].bar.reset(std::min(kWave, nthreads - v * kWave));
@@ -138,7 +141,7 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
         Block blk;
         blk.waves = std::vector<Wave>(nwaves);
         for (long long b = next.fetch_add(1); b < nblocks; b = next.fetch_add(1))
-            run_block(w, blk, grid, block, b, nthreads, nwaves);
+            run_block(w, blk, grid, block, b, nthreads, nwaves, lds_bytes);
         wk = nullptr;
         for (auto& f : w.fibers) munmap(f.stack, kStack);
     };
