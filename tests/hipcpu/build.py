@@ -21,7 +21,12 @@ DEFAULT_OUT = os.path.join(HERE, 'libstp3hip_cpu.so')
 EXTERN_SHARED = re.compile(r'extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\[\];')
 
 
-def build(out=DEFAULT_OUT, sources=None):
+def asan_runtime():
+    """Path of the AddressSanitizer runtime to LD_PRELOAD when running a library built with HIPCPU_ASAN=1."""
+    return subprocess.check_output([CLANG, '-print-file-name=libclang_rt.asan-x86_64.so'], text=True).strip()
+
+
+def build(out=DEFAULT_OUT, sources=None, asan=False):
     sources = sources or sorted(glob.glob(os.path.join(ROOT, 'st-p3_amd', 'csrc', '*.hip')))
     newest = max(os.path.getmtime(p) for p in sources + glob.glob(os.path.join(HERE, '*.cpp')) +
                  glob.glob(os.path.join(HERE, 'hip', '*.h')) + [os.path.abspath(__file__)])
@@ -36,7 +41,8 @@ def build(out=DEFAULT_OUT, sources=None):
             with open(dst, 'w') as f:
                 f.write(f'#line 1 "{src}"\n' + text)
             cpps.append(dst)
-        cmd = [CLANG, '-std=c++17', '-O1', '-fPIC', '-shared', '-pthread', '-ffp-contract=off', '-w',
+        extra = ['-fsanitize=address', '-shared-libasan', '-fno-omit-frame-pointer', '-g'] if asan else []
+        cmd = [CLANG, '-std=c++17', '-O1', '-fPIC', '-shared', '-pthread', '-ffp-contract=off', '-w'] + extra + [
                '-I', HERE, '-I', os.path.join(ROOT, 'include'), '-I', os.path.join(ROOT, 'st-p3_amd', 'csrc'),
                os.path.join(HERE, 'hipcpu_runtime.cpp')] + cpps + ['-o', out]
         subprocess.check_call(cmd)
@@ -44,4 +50,4 @@ def build(out=DEFAULT_OUT, sources=None):
 
 
 if __name__ == '__main__':
-    print(build(sys.argv[1] if len(sys.argv) > 1 else DEFAULT_OUT))
+    print(build(sys.argv[1] if len(sys.argv) > 1 else DEFAULT_OUT, asan=os.environ.get('HIPCPU_ASAN') == '1'))

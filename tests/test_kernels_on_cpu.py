@@ -218,3 +218,27 @@ def test_results_do_not_depend_on_the_thread_schedule(results):
     a, b = dict(_get(results, 'bn_act', BN_GEOM)), dict(_get(results, 'bn_act', dict(BN_GEOM, **REVERSE)))
     a.pop('seconds'), b.pop('seconds')
     assert a == b
+
+
+@pytest.mark.skipif(os.environ.get('STP3_SLOW_TESTS') != '1', reason='AddressSanitizer pass: set STP3_SLOW_TESTS=1')
+def test_no_out_of_bounds_access_under_address_sanitizer(tmp_path):
+    """The same kernel cases with the library built with -fsanitize=address: an access outside a torch allocation
+    (which a GPU would turn into a fault, or silently into garbage) is reported with its source line."""
+    lib = hipcpu_build.build(str(tmp_path / 'libstp3hip_cpu_asan.so'), asan=True)
+    runtime = hipcpu_build.asan_runtime()
+    base = {k: v for k, v in os.environ.items() if not k.startswith(('STP3_', 'HIPCPU_'))}
+    base.update(LD_PRELOAD=runtime, ASAN_OPTIONS='detect_leaks=0:detect_stack_use_after_return=0')
+
+    def run(case, extra):
+        out = subprocess.run([sys.executable, os.path.join(HIPCPU, 'run_case.py'), lib, case], env=dict(base, **extra),
+                             capture_output=True, text=True, timeout=3000)
+        return case, extra, out
+
+    jobs = [(c, {}) for c in ('voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'lift_c16',
+                              'lift_small', 'lift_tall')] + \
+           [(c, MFMA) for c in ('lift_c16', 'lift_c16_rows32', 'lift_c64_many_runs')] + [('bn_act', BN_GEOM)]
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        done = list(pool.map(lambda j: run(*j), jobs))
+    for case, extra, out in done:
+        assert 'AddressSanitizer' not in out.stderr, (case, extra, out.stderr[-3000:])
+        assert out.returncode == 0 and 'RESULT ' in out.stdout, (case, extra, out.stderr[-1500:])
