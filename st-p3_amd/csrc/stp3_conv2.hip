@@ -99,22 +99,29 @@ __global__ __launch_bounds__(256) void conv2d_fwd_v2_kernel(ConvDims2 d, const u
         for (int j = 0; j < PT2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int steps = d.KH * d.KW * d.kchunks;
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
     auto load_step = [&](int step, Frag2 (&a)[CT2], Frag2 (&b)[PT2]) {
         const int tap = step / d.kchunks;
         const int cbase = (step - tap * d.kchunks) * 32;
         const int c0 = cbase + kq * 8;
         const bool kvalid = c0 < d.Cin;
         const int kh = tap / d.KW, kw = tap - kh * d.KW;
+        // Out-of-range fragments load from a valid GLOBAL address (the tensor's first element) and are zeroed in
+        // registers, component by component.  Written as `ok ? *p : zero4` the compiler selects between the global
+        // address and the address of a zero constant in scratch, which turns every operand load into a flat_load
+        // (both wait counters, 32 bytes of scratch); v1 (stp3_conv.hip) still has that form.
 #pragma unroll
-        for (int i = 0; i < CT2; ++i)
-            a[i].u = (cvalid[i] && kvalid) ? *reinterpret_cast<const uint4*>(wp[i] + (size_t)tap * d.Cin + cbase) : zero4;
+        for (int i = 0; i < CT2; ++i) {
+            const bool ok = cvalid[i] && kvalid;
+            const uint4 v = *reinterpret_cast<const uint4*>(ok ? wp[i] + (size_t)tap * d.Cin + cbase : w);
+            a[i].u = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+        }
 #pragma unroll
         for (int j = 0; j < PT2; ++j) {
             const int hi = ph[j] + kh * d.dil_h;
             const int wi = pw[j] + kw * d.dil_w;
             const bool ok = pvalid[j] && kvalid && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
-            b[j].u = ok ? *reinterpret_cast<const uint4*>(x + ((size_t)(pn[j] * d.H + hi) * d.W + wi) * d.ldx + c0) : zero4;
+            const uint4 v = *reinterpret_cast<const uint4*>(ok ? x + ((size_t)(pn[j] * d.H + hi) * d.W + wi) * d.ldx + c0 : x);
+            b[j].u = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
         }
     };
 
