@@ -25,6 +25,7 @@ CANDIDATES = [
     ('grad_gather', {'STP3_GRAD_GATHER': '1'}),
     ('weight_prep', {'STP3_WEIGHT_PREP': '1'}),
     ('cpp_ops', {'STP3_CPP_OPS': '1'}),
+    ('conv_kernel_v2', {'STP3_CONV_KERNEL': 'v2'}),
     ('conv_v2', {'STP3_CONV_V2': '1'}),
     ('fused_adam', {'STP3_FUSED_ADAM': '1'}),
     ('lazy_bn_counter', {'STP3_LAZY_BN_COUNTER': '1'}),

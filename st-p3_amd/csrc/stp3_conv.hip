@@ -18,6 +18,8 @@
 // buffer).  A k-step is 32 input channels of one tap.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "stp3_hip.h"
 
@@ -345,6 +347,14 @@ int stp3_conv2d_fwd(const stp3_conv_dims* p, const void* x, const void* w, const
     d.dil_h = p->dil_h; d.dil_w = p->dil_w; d.ldx = p->ldx; d.ldy = p->ldy;
     d.out_f32 = p->out_dtype == STP3_DTYPE_F32; d.has_bias = p->has_bias;
     d.M = (int)M; d.kchunks = (p->Cin + 31) / 32;
+    // A/B switch (STP3_CONV_KERNEL=v2): bf16-output convolutions through the v2 kernel of stp3_conv2.hip (16-channel
+    // stores, operand loads that stay global: no scratch, 3 waves per SIMD) instead of the kernel below
+    static const bool use_v2 = [] {
+        const char* e = getenv("STP3_CONV_KERNEL");
+        return e && !strcmp(e, "v2");
+    }();
+    if (use_v2 && p->out_dtype == STP3_DTYPE_BF16 && p->ldx % 8 == 0 && !((uintptr_t)y & 15))
+        return stp3_conv2d_fwd_v2(p, x, w, bias, y, nullptr, nullptr, 0, stream);
     dim3 grid((unsigned)((M + kTilePix - 1) / kTilePix), (unsigned)((p->Cout + kTileCo - 1) / kTileCo));
     hipLaunchKernelGGL(conv2d_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, (const uint16_t*)x,
                        (const uint16_t*)w, bias, y);

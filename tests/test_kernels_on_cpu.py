@@ -30,10 +30,11 @@ import build as hipcpu_build  # noqa: E402
 MFMA = {'STP3_LIFT_FWD': 'mfma', 'STP3_LIFT_BWD': 'mfma'}
 CPP = {'STP3_CPP_OPS': '1', 'STP3_HOST_DRYRUN': '1'}       # the C++ launch path, driving the same (CPU-built) library
 BN_GEOM = {'STP3_BN_GEOM': '1'}
+CONV_V2K = {'STP3_CONV_KERNEL': 'v2'}      # bf16-output convolutions (incl. every data gradient) through the v2 kernel
 HAVE_CPP = os.path.exists(os.path.join(ROOT, 'st-p3_amd', 'stp3_amd', '_stp3_host.so'))
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
 ROUTINE = [('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('conv', {}),
-           ('conv_bn', {}), ('bn_act', BN_GEOM), ('lift_c16', {}), ('lift_c16', MFMA)] + \
+           ('conv_bn', {}), ('bn_act', BN_GEOM), ('conv', CONV_V2K), ('lift_c16', {}), ('lift_c16', MFMA)] + \
           ([('bn_act', CPP), ('conv', CPP), ('dwconv', CPP)] if HAVE_CPP else [])
 ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)] + \
@@ -142,6 +143,12 @@ def test_cpp_launch_path_computes_the_same_numbers(results):
         a, b = dict(_get(results, case)), dict(_get(results, case, CPP))
         a.pop('seconds'), b.pop('seconds')
         assert a == b, (case, a, b)
+
+
+def test_v2_convolution_kernel_as_a_drop_in(results):
+    a, b = dict(_get(results, 'conv')), dict(_get(results, 'conv', CONV_V2K))
+    a.pop('seconds'), b.pop('seconds')
+    assert a == b                                   # same tiles, same MFMA order: identical numbers
 
 
 def test_convolution_kernels(results):
