@@ -465,7 +465,96 @@ def model_step_bf16_switches_bn_eval(ops):
     return _model_step(ops, autocast=True, flags=flags, bn_eval=True)
 
 
-CASES = {f.__name__: f for f in (model_step_bf16_switches_bn_eval, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, model_step_bf16_switches, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
+def fuzz(ops, seed=1):
+    """Random shapes / modes of the depthwise, BatchNorm and dense convolution operators against torch in float32."""
+    import random
+    import torch.nn.functional as F
+    from stp3_amd.layers import fused
+    cl = torch.channels_last
+    bad = []
+    random.seed(seed)
+    def chk(tag, cfgd, pairs, tol):
+        for name, a, b in pairs:
+            e = rel(a, b)
+            if not (e <= tol):
+                bad.append((tag, cfgd, name, e))
+    ops.WGRAD_MIN_CHANNELS = 0
+    # ---- depthwise
+    for it in range(40):
+        c = random.choice([8, 24, 40, 64]); k = random.choice([3, 5]); s = random.choice([1, 2])
+        h, w = random.randint(k, 11), random.randint(k, 13); n = random.randint(1, 3)
+        pad = tuple(random.randint(0, k // 2 + 1) for _ in range(4))
+        dt = random.choice([torch.float32, torch.bfloat16])
+        cfgd = dict(c=c, k=k, s=s, h=h, w=w, n=n, pad=pad, dt=str(dt))
+        try:
+            x0 = torch.randn(n, c, h, w).to(dt).contiguous(memory_format=cl); w0 = torch.randn(c, 1, k, k) * 0.3
+            if (h + pad[2] + pad[3] - k) < 0 or (w + pad[0] + pad[1] - k) < 0: continue
+            x, wt = x0.clone().requires_grad_(), w0.clone().requires_grad_()
+            y = ops.depthwise_conv2d(x, wt, s, pad); gy = torch.randn_like(y); y.backward(gy)
+            xr, wr = x0.float().requires_grad_(), w0.clone().requires_grad_()
+            yr = F.conv2d(F.pad(xr, pad), wr, None, s, 0, 1, c); yr.backward(gy.float())
+            tol = 1e-4 if dt == torch.float32 else 3e-2
+            chk('dw', cfgd, [('y', y.detach().float(), yr.detach()), ('dx', x.grad.float(), xr.grad), ('dw', wt.grad, wr.grad)], tol)
+        except Exception as e:
+            bad.append(('dw', cfgd, 'EXC', repr(e)))
+    # ---- batchnorm
+    for it in range(60):
+        n = random.randint(2, 4); c = random.choice([1, 3, 7, 8, 9, 16, 24, 33, 40, 64, 70]); h, w = random.randint(1, 9), random.randint(2, 9)
+        if h * w <= 1: continue
+        dt = random.choice([torch.float32, torch.bfloat16]); training = random.random() < 0.7
+        act = random.choice([ops.ACT_NONE, ops.ACT_RELU, ops.ACT_SWISH]); rm = random.choice([ops.RES_NONE, ops.RES_BEFORE_ACT, ops.RES_AFTER_ACT])
+        with_sb, with_os = random.random() < 0.3, random.random() < 0.3
+        sliced = random.random() < 0.3
+        cfgd = dict(n=n, c=c, h=h, w=w, dt=str(dt), tr=training, act=act, rm=rm, sb=with_sb, os=with_os, sliced=sliced)
+        try:
+            bn_a, bn_b = torch.nn.BatchNorm2d(c, eps=1e-3), torch.nn.BatchNorm2d(c, eps=1e-3)
+            with torch.no_grad():
+                bn_a.weight.uniform_(0.5, 1.5); bn_a.bias.normal_(0, 0.2); bn_a.running_mean.normal_(0, 0.2); bn_a.running_var.uniform_(0.5, 1.5)
+            bn_b.load_state_dict(bn_a.state_dict()); bn_a.train(training); bn_b.train(training)
+            if sliced:
+                wide = torch.randn(n, c + 8, h, w).to(dt).contiguous(memory_format=cl); x0 = wide[:, 3:3 + c]
+            else:
+                x0 = torch.randn(n, c, h, w).to(dt).contiguous(memory_format=cl)
+            r0 = torch.randn(n, c, h, w).to(dt).contiguous(memory_format=cl) if rm else None
+            sb0 = torch.randn(n, c) * 0.3 if with_sb else None; osc = torch.rand(n) + 0.5 if with_os else None
+            gy = torch.randn(n, c, h, w).to(dt).contiguous(memory_format=cl)
+            res = []
+            for kernel, bn in ((True, bn_a), (False, bn_b)):
+                cast = (lambda t: t.clone()) if kernel else (lambda t: t.float())
+                x = cast(x0).detach().requires_grad_(); r = cast(r0).requires_grad_() if r0 is not None else None
+                sb = sb0.clone().requires_grad_() if sb0 is not None else None
+                y = (fused.bn_act if kernel else fused.bn_act_reference)(bn, x, act, r, rm, sb, osc)
+                y.backward(gy if kernel else gy.float())
+                res.append([('y', y.detach().float()), ('dx', x.grad.float()), ('dg', bn.weight.grad), ('db', bn.bias.grad)] + ([('dr', r.grad.float())] if r is not None else []) + ([('dsb', sb.grad)] if sb is not None else []) + [('rm', bn.running_mean.clone()), ('rv', bn.running_var.clone())])
+            tol = 2e-4 if dt == torch.float32 else 3e-2
+            chk('bn', cfgd, [(a[0], a[1], b[1]) for a, b in zip(*res)], tol)
+        except Exception as e:
+            bad.append(('bn', cfgd, 'EXC', repr(e)))
+    # ---- dense conv
+    for it in range(40):
+        cin = random.choice([8, 16, 24, 40, 72]); cout = random.choice([1, 2, 3, 8, 24, 35, 70]); k = random.choice([1, 3, 5, 7]); s = random.choice([1, 2])
+        d = 1 if k == 1 else random.choice([1, 1, 2, 3])        # torch's own CPU convolution corrupts the heap for 1x1 + dilation
+        p = random.choice([0, (k - 1) // 2 * d, d]); n = random.randint(1, 2)
+        lo = max(1, d * (k - 1) + 1 - 2 * p)
+        h, w = random.randint(lo, max(lo, 12)), random.randint(lo, max(lo, 14))
+        if h + 2 * p - d * (k - 1) < 1 or w + 2 * p - d * (k - 1) < 1: continue
+        bias = random.random() < 0.5
+        cfgd = dict(cin=cin, cout=cout, k=k, s=s, d=d, p=p, n=n, h=h, w=w, bias=bias)
+        try:
+            x0 = torch.randn(n, cin, h, w).to(torch.bfloat16).contiguous(memory_format=cl)
+            w0 = (torch.randn(cout, cin, k, k) * 0.2).to(torch.bfloat16).float(); b0 = torch.randn(cout) if bias else None
+            x, wt = x0.clone().requires_grad_(), w0.clone().requires_grad_(); b = b0.clone().requires_grad_() if bias else None
+            y = ops.conv2d(x, wt, b, s, p, d, out_dtype=torch.float32); gy = torch.randn_like(y).to(torch.bfloat16).float(); y.backward(gy)
+            xr, wr = x0.float().requires_grad_(), w0.clone().requires_grad_(); br = b0.clone().requires_grad_() if bias else None
+            yr = F.conv2d(xr, wr, br, s, p, d); yr.backward(gy)
+            pairs = [('y', y.detach(), yr.detach()), ('dx', x.grad.float(), xr.grad), ('dw', wt.grad, wr.grad)] + ([('db', b.grad, br.grad)] if bias else [])
+            chk('conv', cfgd, pairs, 2e-2)
+        except Exception as e:
+            bad.append(('conv', cfgd, 'EXC', repr(e)))
+    return {'problems': [[t, str(c), n, str(e)] for t, c, n, e in bad]}
+
+
+CASES = {f.__name__: f for f in (fuzz, model_step_bf16_switches_bn_eval, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, model_step_bf16_switches, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
                                  conv, dwconv)}
 
 if __name__ == '__main__':

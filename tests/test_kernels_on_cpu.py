@@ -33,7 +33,7 @@ BN_GEOM = {'STP3_BN_GEOM': '1'}
 CONV_V2K = {'STP3_CONV_KERNEL': 'v2'}      # bf16-output convolutions (incl. every data gradient) through the v2 kernel
 HAVE_CPP = os.path.exists(os.path.join(ROOT, 'st-p3_amd', 'stp3_amd', '_stp3_host.so'))
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
-ROUTINE = [('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('conv', {}),
+ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('conv', {}),
            ('conv_bn', {}), ('bn_act', BN_GEOM), ('conv', CONV_V2K), ('lift_c16', {}), ('lift_c16', MFMA)] + \
           ([('bn_act', CPP), ('conv', CPP), ('dwconv', CPP)] if HAVE_CPP else [])
 ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'lift_c16']
@@ -249,3 +249,9 @@ def test_no_out_of_bounds_access_under_address_sanitizer(tmp_path):
     for case, extra, out in done:
         assert 'AddressSanitizer' not in out.stderr, (case, extra, out.stderr[-3000:])
         assert out.returncode == 0 and 'RESULT ' in out.stdout, (case, extra, out.stderr[-1500:])
+
+
+def test_random_shapes_of_the_dense_operators(results):
+    """140 random configurations of the depthwise / BatchNorm / dense convolution operators (odd channel counts, tiny
+    maps, asymmetric padding, dilation, stride, channel-sliced inputs, every activation / residual / bias mode)."""
+    assert _get(results, 'fuzz')['problems'] == []
