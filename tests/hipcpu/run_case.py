@@ -98,6 +98,35 @@ def lift_c64_many_runs(ops):        # 64 channels, ~190 runs per column: the mat
     return case_lift(ops, cfg, 1, 1, 1, 7)
 
 
+def lift_full(ops):                 # the real geometry: 6 cameras x 224x480, D = 48, C = 64, BEV 200x200, T = 3 (golden digests)
+    import hashlib
+    from oracle import lift_oracle as lo
+    from tests import helpers as H
+    g = H.load('lift_full.npz')
+    cfg = H.FULL
+    intr, extr, ego, feat, logits = H.lift_inputs(cfg, 1, 3, 6, seed=5)
+    frustum, res, start, dim = H.grid_params(cfg)
+    grid = ops.LiftGrid(frustum, res, start, dim, 'cpu')
+    dims = ops.make_dims(1, 3, 6, grid.D, grid.fH, grid.fW, 64, grid.X, grid.Y, grid.Z)
+    ids = ops.voxel_index(grid, dims, *ops.lift_matrices(intr, extr, ego), order=ops.VOX_REFERENCE)
+    ids = ids.view(1, 3, 6, grid.D, grid.fH, grid.fW).numpy()
+    sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(ids).tobytes()).digest(), dtype=np.uint8)
+    plan = ops.LiftPlan.build(grid, intr, extr, ego, 64)
+    f, lg = feat.clone().requires_grad_(), logits.clone().requires_grad_()
+    bev = ops.lift_splat(f, lg, plan, 0.5)
+    go = torch.randn(1, 3, 64, 200, 200, generator=torch.Generator().manual_seed(17))
+    bev.backward(go)
+    vox = H.oracle_vox(cfg, intr, extr, ego)
+    gf, gl = lo.pool_backward_exact(go, feat, logits, vox, 0.5)
+    flat = bev.detach().reshape(-1)
+    return {'ids_sha256_equal_reference': bool(np.array_equal(sha, g['generic_vox_sha256'])),
+            'ids_equal_oracle': bool(np.array_equal(ids, vox)),
+            'bev_exact_sample_err': err(flat[::257], g['generic_bev_exact_sample']),
+            'bev_reference_sample_err': err(flat[::257], g['generic_bev_sample']),
+            'bev_sum_err': err(bev.detach().double().sum(dim=(-1, -2))[0], g['generic_bev_sum_tc']),
+            'dfeat_err': err(f.grad, gf), 'dlogit_err': err(lg.grad, gl)}
+
+
 def lift_tall(ops):                 # 112 rows x 64 bins per column: 112 KB of LDS in the default forward
     from tests import helpers as H
     cfg = dict(H.FULL, out_channels=8, final_dim=(224, 32), downsample=2, d_bound=(2.0, 66.0, 1.0))
@@ -554,7 +583,7 @@ def fuzz(ops, seed=1):
     return {'problems': [[t, str(c), n, str(e)] for t, c, n, e in bad]}
 
 
-CASES = {f.__name__: f for f in (fuzz, model_step_bf16_switches_bn_eval, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, model_step_bf16_switches, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
+CASES = {f.__name__: f for f in (lift_full, fuzz, model_step_bf16_switches_bn_eval, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, model_step_bf16_switches, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
                                  conv, dwconv)}
 
 if __name__ == '__main__':

@@ -33,13 +33,13 @@ BN_GEOM = {'STP3_BN_GEOM': '1'}
 CONV_V2K = {'STP3_CONV_KERNEL': 'v2'}      # bf16-output convolutions (incl. every data gradient) through the v2 kernel
 HAVE_CPP = os.path.exists(os.path.join(ROOT, 'st-p3_amd', 'stp3_amd', '_stp3_host.so'))
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
-ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('conv', {}),
+ROUTINE = [('lift_full', MFMA), ('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('conv', {}),
            ('conv_bn', {}), ('bn_act', BN_GEOM), ('conv', CONV_V2K), ('lift_c16', {}), ('lift_c16', MFMA)] + \
           ([('bn_act', CPP), ('conv', CPP), ('dwconv', CPP)] if HAVE_CPP else [])
 ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)] + \
            [('lift_c16', dict(MFMA, **o)) for o in (REVERSE, RANDOM)] + [('bn_act', dict(BN_GEOM, **REVERSE))]
-MODEL = [('model_step_f32', {}), ('model_step_bf16_bn_eval', {}), ('model_step_bf16_switches', {}),
+MODEL = [('lift_full', {}), ('model_step_f32', {}), ('model_step_bf16_bn_eval', {}), ('model_step_bf16_switches', {}),
          ('model_step_bf16_switches_bn_eval', {})]        # whole training steps: minutes, STP3_SLOW_TESTS=1
 SLOW = [('lift_small', {}),   # (minutes each on the first, OS-thread engine; seconds on fibers)
         ('lift_c16_rows32', MFMA), ('lift_c64_many_runs', MFMA), ('lift_tall', {})]
@@ -255,3 +255,24 @@ def test_random_shapes_of_the_dense_operators(results):
     """140 random configurations of the depthwise / BatchNorm / dense convolution operators (odd channel counts, tiny
     maps, asymmetric padding, dilation, stride, channel-sliced inputs, every activation / residual / bias mode)."""
     assert _get(results, 'fuzz')['problems'] == []
+
+
+def _check_full(r):
+    assert r['ids_sha256_equal_reference'] and r['ids_equal_oracle']     # 1.45 M voxel ids, digest of the reference's own
+    assert r['bev_exact_sample_err'] <= 1e-5 and r['bev_reference_sample_err'] <= 1e-3 and r['bev_sum_err'] <= 1e-3
+    assert r['dfeat_err'] <= 1e-4 and r['dlogit_err'] <= 1e-4
+
+
+def test_voxel_pool_at_the_bench_geometry_on_the_matrix_cores(results):
+    """6 cameras x 224x480, D = 48, C = 64, BEV 200x200, T = 3 -- the geometry of tests/golden/lift_full.npz and of
+    bench.py -- through lift_runs_mfma_kernel / lift_bwd_mfma_kernel: the tolerances of tests/test_lift_gpu.py."""
+    _check_full(_get(results, 'lift_full', MFMA))
+
+
+def test_voxel_pool_at_the_bench_geometry_default_kernels(results):
+    d = _get(results, 'lift_full')                      # STP3_SLOW_TESTS=1: the first backward kernel is slow to emulate
+    _check_full(d)
+    m = dict(_get(results, 'lift_full', MFMA))
+    d = dict(d)
+    d.pop('seconds'), m.pop('seconds')
+    assert d == m                                       # the two kernel families agree to the last printed digit
