@@ -12,6 +12,8 @@ TAILN=4 run env STP3_EXPERIMENTAL=1 STP3_BN_GEOM=1 timeout 300 python -m pytest 
 TAILN=4 run env STP3_LIFT_BWD=mfma STP3_LIFT_FWD=mfma timeout 300 python -m pytest tests/test_lift_gpu.py -q -x
 # BASELINE configs[4] geometry (112 KB of LDS per column)
 TAILN=4 run env STP3_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_lift_stress_gpu.py -q -x
+# the v2 convolution kernel as a drop-in for every bf16-output convolution (forward and data gradient)
+TAILN=4 run env STP3_CONV_KERNEL=v2 timeout 300 python -m pytest tests/test_conv_gpu.py tests/test_modules_gpu.py -q -x
 # the whole GPU suite through the C++ launch path
 TAILN=6 run env STP3_CPP_OPS=1 timeout 400 python -m pytest tests -m gpu -q -x
 # the model-level parity tests with the fused trunk operators and the new host options on
