@@ -464,6 +464,83 @@ def _model_step(ops, autocast, flags=None, bn_eval=False):
             'grad_rel_l2_by_group': {k: round((v[0] / max(v[1], 1e-30)) ** 0.5, 4) for k, v in sorted(groups.items())}}
 
 
+def _kernel_path_grads(lib_path, samples, rank=None, world=1, port=0, out=None, local_stats=False):
+    """Float32 training step of the GPU code path on the kernels for the given samples of a fixed 2-sample batch;
+    with world > 1 the process joins a gloo group first (cross-replica BatchNorm statistics, bucketed gradients)."""
+    import torch.distributed as dist
+    import torch.nn as nn
+    ops = setup(lib_path)
+    from stp3_amd import synthetic
+    from stp3_amd.config import perception_cfg
+    from stp3_amd.parallel import GradientBuckets
+    from stp3_amd.trainer import TrainingModule
+    from stp3_amd.utils import to_channels_last
+    torch.set_num_threads(2)
+    if world > 1:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    cfg = perception_cfg(**{'IMAGE.FINAL_DIM': (64, 96), 'LIFT.X_BOUND': [-10.0, 10.0, 0.5], 'LIFT.Y_BOUND': [-10.0, 10.0, 0.5],
+                            'LIFT.D_BOUND': [2.0, 10.0, 1.0], 'SEMANTIC_SEG.VEHICLE.USE_TOP_K': False,
+                            'SEMANTIC_SEG.PEDESTRIAN.USE_TOP_K': False, 'SEMANTIC_SEG.HDMAP.USE_TOP_K': [False, False]})
+    g = torch.Generator().manual_seed(3)
+    intr, extr, ego = synthetic.make_rig(2, 3, 6, (64, 96), seed=3)
+    full = {'image': torch.randn(2, 3, 6, 3, 64, 96, generator=g), 'intrinsics': intr, 'extrinsics': extr, 'future_egomotion': ego,
+            'segmentation': (torch.rand(2, 3, 1, 40, 40, generator=g) > 0.9).long(),
+            'pedestrian': (torch.rand(2, 3, 1, 40, 40, generator=g) > 0.95).long(),
+            'hdmap': (torch.rand(2, 3, 2, 40, 40, generator=g) > 0.7).long(), 'gt_trajectory': torch.zeros(2, 3, 3)}
+    batch = {k: v[samples] for k, v in full.items()}
+    torch.manual_seed(11)
+    module = to_channels_last(TrainingModule(cfg.convert_to_dict())).train()
+    for m in module.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+        if local_stats and isinstance(m, nn.modules.batchnorm._BatchNorm):
+            m.stp3_local_stats = True                                   # negative control: per-rank statistics
+    module.model.encoder.backbone._global_params.drop_connect_rate = 0.0
+    buckets = GradientBuckets(module.model)
+    module.model.prepare_plan(batch['intrinsics'], batch['extrinsics'], batch['future_egomotion'], torch.device('cpu'))
+    buckets.zero_grad()
+    loss = module.training_step(batch)
+    loss.backward()
+    buckets.finish()
+    flat = torch.cat([f.clone() for f, _ in buckets.buckets])
+    if world > 1:
+        out[rank] = (float(loss), flat)
+        dist.destroy_process_group()
+        return None
+    return float(loss), flat
+
+
+def _two_rank_worker(rank, lib_path, port, out, local_stats):
+    _kernel_path_grads(lib_path, slice(rank, rank + 1), rank=rank, world=2, port=port, out=out, local_stats=local_stats)
+
+
+def model_step_two_ranks(ops):
+    """2 gloo ranks x 1 sample through the kernels (split BatchNorm operator: statistics | all-reduce | apply; bucketed
+    gradient all-reduce) against 1 process x 2 samples through the same kernels (the composite BatchNorm operator)."""
+    import socket
+    import torch.multiprocessing as mp
+    lib_path = sys.argv[1]
+
+    def two(local_stats):
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        mgr = mp.Manager()
+        res = mgr.dict()
+        mp.spawn(_two_rank_worker, args=(lib_path, port, res, local_stats), nprocs=2, join=True)
+        return {k: v for k, v in res.items()}
+
+    out = two(False)
+    loss, ref = _kernel_path_grads(lib_path, slice(0, 2))
+    ctl = two(True)
+
+    def rel_l2(a):
+        return float((a.double() - ref.double()).norm() / ref.double().norm())
+    return {'ranks_identical': bool(torch.equal(out[0][1], out[1][1])), 'loss_two_rank_mean': 0.5 * (out[0][0] + out[1][0]),
+            'loss_one_process': loss, 'grad_rel_l2': rel_l2(out[0][1]), 'grad_rel_l2_per_rank_statistics': rel_l2(ctl[0][1])}
+
+
 def model_step_f32(ops):            # float32: BatchNorm / depthwise / voxel-pool kernels (dense convolutions stay on torch)
     return _model_step(ops, autocast=False)
 
@@ -583,7 +660,7 @@ def fuzz(ops, seed=1):
     return {'problems': [[t, str(c), n, str(e)] for t, c, n, e in bad]}
 
 
-CASES = {f.__name__: f for f in (lift_full, fuzz, model_step_bf16_switches_bn_eval, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, model_step_bf16_switches, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
+CASES = {f.__name__: f for f in (model_step_two_ranks, lift_full, fuzz, model_step_bf16_switches_bn_eval, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, model_step_bf16_switches, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
                                  conv, dwconv)}
 
 if __name__ == '__main__':

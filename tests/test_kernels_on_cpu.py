@@ -39,7 +39,7 @@ ROUTINE = [('lift_full', MFMA), ('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('o
 ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)] + \
            [('lift_c16', dict(MFMA, **o)) for o in (REVERSE, RANDOM)] + [('bn_act', dict(BN_GEOM, **REVERSE))]
-MODEL = [('lift_full', {}), ('model_step_f32', {}), ('model_step_bf16_bn_eval', {}), ('model_step_bf16_switches', {}),
+MODEL = [('lift_full', {}), ('model_step_two_ranks', {}), ('model_step_f32', {}), ('model_step_bf16_bn_eval', {}), ('model_step_bf16_switches', {}),
          ('model_step_bf16_switches_bn_eval', {})]        # whole training steps: minutes, STP3_SLOW_TESTS=1
 SLOW = [('lift_small', {}),   # (minutes each on the first, OS-thread engine; seconds on fibers)
         ('lift_c16_rows32', MFMA), ('lift_c64_many_runs', MFMA), ('lift_tall', {})]
@@ -276,3 +276,14 @@ def test_voxel_pool_at_the_bench_geometry_default_kernels(results):
     d = dict(d)
     d.pop('seconds'), m.pop('seconds')
     assert d == m                                       # the two kernel families agree to the last printed digit
+
+
+def test_two_ranks_through_the_kernels_equal_one_process(results):
+    """Data parallelism on the kernel path (STP3_SLOW_TESTS=1): 2 gloo ranks x 1 sample -- BatchNorm as statistics kernel,
+    all-reduce, apply kernel; bucketed gradient all-reduce -- against 1 process x 2 samples (composite BatchNorm kernels).
+    Same loss; gradients within the round-off amplification of this configuration (see tests/test_parallel_cpu.py);
+    per-rank statistics (negative control) are off by O(1)."""
+    r = _get(results, 'model_step_two_ranks')
+    assert r['ranks_identical']
+    assert abs(r['loss_two_rank_mean'] - r['loss_one_process']) <= 1e-5 * abs(r['loss_one_process'])
+    assert r['grad_rel_l2'] < 3e-2 and r['grad_rel_l2_per_rank_statistics'] > 10 * r['grad_rel_l2']
