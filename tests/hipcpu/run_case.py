@@ -373,7 +373,7 @@ def conv_bn(ops):
     return out
 
 
-def _model_step(ops, autocast, flags=None, bn_eval=False):
+def _model_step(ops, autocast, flags=None, bn_eval=False, full_losses=False):
     """One whole training step (encoder, lift, temporal model, decoder, losses, backward) through the kernels, against
     the CPU port of the same model (oracle/cpu_model.py: reference-algorithm lift, plain torch everywhere else)."""
     import torch.nn as nn
@@ -384,14 +384,19 @@ def _model_step(ops, autocast, flags=None, bn_eval=False):
     from stp3_amd.utils import to_channels_last
     for mod, name, val in (flags or []):
         setattr(mod, name, val)
+    extra = {'LIFT.GT_DEPTH': True, 'INSTANCE_SEG.ENABLED': True, 'INSTANCE_FLOW.ENABLED': True} if full_losses else {}
     cfg = perception_cfg(**{'IMAGE.FINAL_DIM': (64, 96), 'LIFT.X_BOUND': [-10.0, 10.0, 0.5], 'LIFT.Y_BOUND': [-10.0, 10.0, 0.5],
-                            'LIFT.D_BOUND': [2.0, 10.0, 1.0]})
+                            'LIFT.D_BOUND': [2.0, 10.0, 1.0], **extra})
     g = torch.Generator().manual_seed(3)
     intr, extr, ego = synthetic.make_rig(1, 3, 6, (64, 96), seed=3)
     batch = {'image': torch.randn(1, 3, 6, 3, 64, 96, generator=g), 'intrinsics': intr, 'extrinsics': extr,
              'future_egomotion': ego, 'segmentation': (torch.rand(1, 3, 1, 40, 40, generator=g) > 0.9).long(),
              'pedestrian': (torch.rand(1, 3, 1, 40, 40, generator=g) > 0.95).long(),
              'hdmap': (torch.rand(1, 3, 2, 40, 40, generator=g) > 0.7).long(), 'gt_trajectory': torch.zeros(1, 3, 3)}
+    if full_losses:          # bench.py's default workload: depth cross-entropy + instance centerness / offset + flow
+        batch['instance'], batch['centerness'], batch['offset'], batch['flow'] = \
+            synthetic.make_instance_labels(batch['segmentation'], seed=3)
+        batch['depths'] = torch.randint(0, 14, (1, 3, 6, 64, 96), generator=g).float()
 
     def quiet(module):
         module.train()
@@ -413,8 +418,10 @@ def _model_step(ops, autocast, flags=None, bn_eval=False):
     ref = quiet(TrainingModule(cfg.convert_to_dict()))
     port = CpuPortSTP3(cfg)
     port.load_state_dict(state, strict=False)
-    for name in ('segmentation_weight', 'pedestrian_weight', 'hdmap_weight'):
-        setattr(port, name, getattr(ref.model, name))
+    for name in ('segmentation_weight', 'pedestrian_weight', 'hdmap_weight', 'depths_weight', 'centerness_weight',
+                 'offset_weight', 'flow_weight'):
+        if hasattr(ref.model, name):
+            setattr(port, name, getattr(ref.model, name))
     ref.model = port
     quiet(ref)
     ref_loss = ref.training_step(batch)
@@ -545,6 +552,10 @@ def model_step_f32(ops):            # float32: BatchNorm / depthwise / voxel-poo
     return _model_step(ops, autocast=False)
 
 
+def model_step_f32_full_losses(ops):    # BASELINE configs[2] = bench.py's default: + depth CE, instance centerness / offset, flow
+    return _model_step(ops, autocast=False, full_losses=True)
+
+
 def model_step_bf16(ops):           # bf16 autocast: the MFMA convolution kernels too
     return _model_step(ops, autocast=True)
 
@@ -660,7 +671,7 @@ def fuzz(ops, seed=1):
     return {'problems': [[t, str(c), n, str(e)] for t, c, n, e in bad]}
 
 
-CASES = {f.__name__: f for f in (model_step_two_ranks, lift_full, fuzz, model_step_bf16_switches_bn_eval, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, model_step_bf16_switches, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
+CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_bf16_switches_bn_eval, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, model_step_bf16_switches, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
                                  conv, dwconv)}
 
 if __name__ == '__main__':

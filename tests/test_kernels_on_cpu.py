@@ -39,7 +39,7 @@ ROUTINE = [('lift_full', MFMA), ('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('o
 ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)] + \
            [('lift_c16', dict(MFMA, **o)) for o in (REVERSE, RANDOM)] + [('bn_act', dict(BN_GEOM, **REVERSE))]
-MODEL = [('lift_full', {}), ('model_step_two_ranks', {}), ('model_step_f32', {}), ('model_step_bf16_bn_eval', {}), ('model_step_bf16_switches', {}),
+MODEL = [('lift_full', {}), ('model_step_two_ranks', {}), ('model_step_f32_full_losses', {}), ('model_step_f32', {}), ('model_step_bf16_bn_eval', {}), ('model_step_bf16_switches', {}),
          ('model_step_bf16_switches_bn_eval', {})]        # whole training steps: minutes, STP3_SLOW_TESTS=1
 SLOW = [('lift_small', {}),   # (minutes each on the first, OS-thread engine; seconds on fibers)
         ('lift_c16_rows32', MFMA), ('lift_c64_many_runs', MFMA), ('lift_tall', {})]
@@ -287,3 +287,12 @@ def test_two_ranks_through_the_kernels_equal_one_process(results):
     assert r['ranks_identical']
     assert abs(r['loss_two_rank_mean'] - r['loss_one_process']) <= 1e-5 * abs(r['loss_one_process'])
     assert r['grad_rel_l2'] < 3e-2 and r['grad_rel_l2_per_rank_statistics'] > 10 * r['grad_rel_l2']
+
+
+def test_whole_step_of_the_bench_workload(results):
+    """bench.py's default workload (BASELINE configs[2]: + depth cross-entropy, instance centerness / offset, flow) on the
+    kernel path against the CPU port, float32 (STP3_SLOW_TESTS=1)."""
+    r = _get(results, 'model_step_f32_full_losses')
+    assert not r['params_without_grad']
+    assert abs(r['loss'] - r['ref_loss']) <= 1e-5 * abs(r['ref_loss']) and r['grad_rel_l2'] <= 2e-2
+    assert r['grad_rel_l2_by_group']['decoder'] <= 5e-3
