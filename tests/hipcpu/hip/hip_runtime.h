@@ -86,6 +86,7 @@ struct Barrier {
 
 struct Wave {
     Barrier bar;
+    unsigned long long live = 0;                    // lanes whose thread has not returned yet
     alignas(16) unsigned char slot[2][kWave][32];   // two operands, up to 32 bytes per lane
 };
 
@@ -161,8 +162,18 @@ inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST
 // ---- wave intrinsics ----
 inline int readlane_i(int v, int lane) { return hipcpu::exchange<int>(v, lane); }
 #define __builtin_amdgcn_readlane(v, lane) readlane_i((int)(v), (int)(lane))
-// used on wave-uniform values only in this code base (wave index, values loaded from one address)
-#define __builtin_amdgcn_readfirstlane(v) (v)
+// v_readfirstlane_b32: the value of the lowest live lane, for every lane (NOT the lane's own value: a kernel that
+// applies it to a non-uniform quantity behaves here as it would on the GPU)
+inline int readfirstlane_i(int v) {
+    hipcpu::Wave& w = hipcpu::my_wave();
+    std::memcpy(w.slot[0][hipcpu::cur->lane], &v, 4);
+    w.bar.wait();
+    int r;
+    std::memcpy(&r, w.slot[0][__builtin_ctzll(w.live)], 4);
+    w.bar.wait();
+    return r;
+}
+#define __builtin_amdgcn_readfirstlane(v) readfirstlane_i((int)(v))
 
 template <typename T>
 inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return hipcpu::exchange<T>(v, hipcpu::cur->lane ^ mask); }

@@ -42,6 +42,7 @@ void trampoline() {
     Fiber& f = w->fibers[w->running];
     (*w->kernel)();
     f.done = true;
+    f.c.block->waves[f.c.wave].live &= ~(1ull << f.c.lane);
     f.c.block->waves[f.c.wave].bar.drop();
     f.c.block->bar.drop();
     swapcontext(&f.ctx, &w->sched);
@@ -53,7 +54,9 @@ void run_block(Worker& w, Block& blk, dim3 grid, dim3 block, long long b, int nt
     std::memset(g_dyn_lds, 0xFF, lds_bytes ? lds_bytes : 0);
     blk.bar.reset(nthreads);
     for (int v = 0; v < nwaves; ++v) {
-        blk.waves[v].bar.reset(std::min(kWave, nthreads - v * kWave));
+        const int lanes = std::min(kWave, nthreads - v * kWave);
+        blk.waves[v].bar.reset(lanes);
+        blk.waves[v].live = lanes == 64 ? ~0ull : ((1ull << lanes) - 1);
         std::memset(blk.waves[v].slot, 0, sizeof(blk.waves[v].slot));
     }
     const dim3 bid((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long long)grid.x * grid.y)));
