@@ -31,6 +31,7 @@ CANDIDATES = [
     ('lazy_bn_counter', {'STP3_LAZY_BN_COUNTER': '1'}),
     ('lift_mfma', {'STP3_LIFT_FWD': 'mfma', 'STP3_LIFT_BWD': 'mfma'}),
     ('wgrad_64', {'STP3_WGRAD_MIN_CHANNELS': '64'}),
+    ('wgrad_all', {'STP3_WGRAD_MIN_CHANNELS': '0'}),      # no vendor-library weight gradients at all
     ('mfma_conv_all', {'STP3_MFMA_CONV': 'all'}),
     ('miopen_find', {'STP3_MIOPEN_FIND': '1'}),           # slow first step: give it --timeout 900
 ]
