@@ -25,5 +25,5 @@ TAILN=12 run env STP3_BN_GEOM=0 timeout 100 python scripts/time_bn.py
 TAILN=12 run env STP3_BN_GEOM=1 timeout 100 python scripts/time_bn.py
 # -- which switches pay off --------------------------------------------------------------------------------------
 if [ "$2" = "ab" ]; then
-  TAILN=40 run timeout 1500 python scripts/ab_greedy.py --steps 10 --warmup 3 --out $OUT/ab_greedy.json
+  TAILN=40 run timeout 1500 python scripts/ab_greedy.py --steps 10 --warmup 3 --only bn_geom,fused_se,se_mlp,label_warp,grad_gather,weight_prep,cpp_ops,conv_kernel_v2,conv_v2,fused_adam,lazy_bn_counter,lift_mfma --out $OUT/ab_greedy.json
 fi

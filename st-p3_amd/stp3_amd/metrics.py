@@ -23,12 +23,18 @@ class IntersectionOverUnion(nn.Module):
     def update(self, prediction, target):
         pred, tgt = prediction.reshape(-1).long(), target.reshape(-1).long()
         n = self.n_classes
-        conf = torch.bincount(tgt * n + pred, minlength=n * n).view(n, n).to(self.true_positive.dtype)
+        # stat_scores_multiple_classes (metrics.py:38): per-class counts; labels outside [0, n) (an ignore value such
+        # as 255) contribute to no class of their own but still make the other side's class a false positive / negative
+        in_p, in_t = (pred >= 0) & (pred < n), (tgt >= 0) & (tgt < n)
+        both = in_p & in_t
+        conf = torch.bincount(tgt[both] * n + pred[both], minlength=n * n).view(n, n).to(self.true_positive.dtype)
         tp = conf.diag()
+        stray_p = torch.bincount(pred[in_p & ~in_t], minlength=n).to(tp.dtype)
+        stray_t = torch.bincount(tgt[in_t & ~in_p], minlength=n).to(tp.dtype)
         self.true_positive += tp
-        self.false_positive += conf.sum(0) - tp
-        self.false_negative += conf.sum(1) - tp
-        self.support += conf.sum(1)
+        self.false_positive += conf.sum(0) - tp + stray_p
+        self.false_negative += conf.sum(1) - tp + stray_t
+        self.support += conf.sum(1) + stray_t
 
     def forward(self, prediction, target):
         self.update(prediction, target)

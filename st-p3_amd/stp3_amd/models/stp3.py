@@ -153,6 +153,10 @@ class STP3(nn.Module):
                                       deterministic=self.deterministic_pool)
         feat, depth = self.encoder(image.reshape(b * s * n, c, h, w))
         cur.wait_stream(side)
+        # the plan's buffers were allocated on the side stream but are read by the pooling kernels (forward AND
+        # backward) on the main stream: tell the allocator, or the next step's build may reuse them too early
+        for buf in (plan.mats, plan.counts, plan.vox_pm, plan.plan):
+            buf.record_stream(cur)
         feat = feat.view(b, s, n, *feat.shape[1:])
         depth = depth.view(b, s, n, *depth.shape[1:])
         bev = ops.lift_splat(feat, depth, plan, self.discount)

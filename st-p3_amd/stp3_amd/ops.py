@@ -13,6 +13,7 @@ PyTorch is used for device memory, streams and autograd plumbing only.
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -776,7 +777,6 @@ class _WeightShadows:
         return ent
 
     def register(self, weight):
-        import weakref
         cout, cin, kh, kw = weight.shape
         opts = dict(dtype=torch.bfloat16, device=weight.device, memory_format=torch.channels_last)
         ent = {'ref': weakref.ref(weight), 'ptr': weight.data_ptr(), 'version': weight._version,
@@ -840,14 +840,28 @@ def _bf16_weights(weight, need_flipped=False):
     key = id(weight)
     ent = _WEIGHT_CACHE.get(key) if WEIGHT_CACHE_ENABLED else None
     ver = (weight._version, _WEIGHT_EPOCH[0])
-    if ent is None or ent[0] != ver or ent[1] != weight.data_ptr():
+    # id() values are recycled: an entry only counts when it still points at THIS live parameter (weak reference),
+    # at the same storage, shape and strides
+    if ent is not None and (ent[4]() is not weight or ent[0] != ver or ent[1] != weight.data_ptr()
+                            or ent[5] != (tuple(weight.shape), tuple(weight.stride()))):
+        ent = None
+    if ent is None:
         wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        ent = [ver, weight.data_ptr(), wb, None]
-        if WEIGHT_CACHE_ENABLED and weight.is_leaf and weight.requires_grad:   # parameters only: temporaries die
+        ent = [ver, weight.data_ptr(), wb, None, None, None]
+        if WEIGHT_CACHE_ENABLED and isinstance(weight, torch.nn.Parameter) and weight.requires_grad:
+            # parameters only: temporaries (weight slices, padded copies) die with the call
+            ent[4] = weakref.ref(weight)
+            ent[5] = (tuple(weight.shape), tuple(weight.stride()))
             _WEIGHT_CACHE[key] = ent
+            weakref.finalize(weight, _evict_weight, key, ent)
     if need_flipped and ent[3] is None:
         ent[3] = ent[2].flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
     return ent[2], ent[3]
+
+
+def _evict_weight(key, ent):
+    if _WEIGHT_CACHE.get(key) is ent:
+        del _WEIGHT_CACHE[key]
 
 
 class _Conv2dMfma(torch.autograd.Function):
