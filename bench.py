@@ -14,9 +14,8 @@ branches), the configuration the round-1 profiles under profiles/ were taken wit
 weak scaling: every rank gets its own B=4 (global batch 4N), gradients are all-reduced over RCCL
 and BatchNorm statistics are synchronised (the reference's DDP + sync_batchnorm recipe).
 
-The step is launched eagerly.  `--graph` (N=1 only) captures the whole step into one hipGraph
-(stp3_amd/graph.py); on ROCm 7.2 replays of the captured step were observed to be slower than the eager
-launch and numerically unreliable, so it is off by default.
+The step is launched eagerly (hipGraph capture of the whole step was tried in round 1: replays on ROCm 7.2 were
+slower than the eager launch and numerically unreliable).
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      the voxel-pool forward (stp3_lift_splat_fwd = its two kernels): algorithmic bytes per
@@ -157,51 +156,62 @@ def cpu_baseline(workload='c3', timeout_s=240.0):
 
 def lift_roofline(device, batch, model, iters=30):
     """HIP-event timing of the voxel-pool C-ABI calls at the bench shape (the model's own frustum / BEV grid and the
-    batch's poses, random features), on the stream they are launched on."""
+    batch's poses, random features, the BEV layout the model uses), on the stream they are launched on."""
     from stp3_amd import ops
     grid = model.lift_grid(device)
     rf = model.receptive_field
     poses = [batch[k][:, :rf] for k in ('intrinsics', 'extrinsics', 'future_egomotion')]
     plan = ops.LiftPlan.build(grid, *poses, model.encoder_out_channels)
     d = plan.dims
+    cl = bool(model.bev_channels_last)
     g = torch.Generator(device='cpu').manual_seed(7)
     feat = torch.relu(torch.randn(d.BT, d.NPIX, d.C, generator=g)).to(device)
     logits = (torch.randn(d.BT, d.NPIX, d.D, generator=g) * 2.0).to(device)
     feat.requires_grad_(True)
     logits.requires_grad_(True)
-    grad = torch.randn(d.B, d.T, d.C, d.X, d.Y, generator=g).to(device)
+    grad = torch.randn(d.B, d.T, d.X, d.Y, d.C, generator=g).to(device).permute(0, 1, 4, 2, 3)
+    if not cl:
+        grad = grad.contiguous()
     for _ in range(3):
-        bev = ops._LiftSplat.apply(feat, logits, plan, 0.5)
+        bev = ops._LiftSplat.apply(feat, logits, plan, 0.5, cl)
         bev.backward(grad)
     ops.PROFILE.clear()
     ops.PROFILE_ENABLED = True
     for _ in range(iters):
-        bev = ops._LiftSplat.apply(feat, logits, plan, 0.5)
+        bev = ops._LiftSplat.apply(feat, logits, plan, 0.5, cl)
         bev.backward(grad)
         ops.LiftPlan.build(grid, *poses, model.encoder_out_channels, out=plan)
     prof = ops.profile_summary()
     ops.PROFILE_ENABLED = False
-    alg_fwd = d.BT * (d.NPIX * d.C * 4 + d.NPIX * d.D * 4 + d.C * d.V * 4)      # feat + depth prob + BEV planes
+    # ALGORITHMIC bytes (BASELINE.md section 3): per frame feat 4 N fH fW C + depth 4 N fH fW D + BEV 4 C X Y
+    alg_fwd = d.BT * (d.NPIX * d.C * 4 + d.NPIX * d.D * 4 + d.C * d.V * 4)
     alg_bwd = d.BT * (d.C * d.V * 4 + 2 * d.NPIX * d.C * 4 + 2 * d.NPIX * d.D * 4)
     fwd_ms = prof['lift_splat_fwd']['avg_ms']
+    soft_ms = prof['depth_softmax']['avg_ms']
     ach = alg_fwd / (fwd_ms * 1e-3) / 1e9
-    traffic = None
-    pmc_path = os.path.join(ROOT, 'profiles', 'lift_pmc.json')
+    traffic, traffic_source = None, None
+    pmc_path = os.path.join(ROOT, 'profiles', 'r02_lift_pmc.json')
     if os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
-            traffic = sum(pmc[k][f] for k in ('lift_runs', 'lift_gather') for f in ('hbm_read_bytes', 'hbm_write_bytes'))
-            traffic *= d.BT / float(pmc.get('frames_per_launch', 12))     # counters were collected at B=4, T=3
+            k = pmc['lift_pull_kernel']
+            traffic = (k['hbm_read_bytes'] + k['hbm_write_bytes']) * d.BT / float(pmc.get('frames_per_launch', 12))
+            traffic_source = f"profiles/r02_lift_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, {pmc.get('commit', '?')})"
         except Exception:
             traffic = None
-    stage1 = 'lift_runs_mfma_kernel' if os.environ.get('STP3_LIFT_FWD') == 'mfma' else 'lift_runs_kernel'
-    roof = {'kernel': f'stp3_lift_splat_fwd ({stage1} + lift_gather_kernel)', 'bound': 'hbm',
-            'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-            'traffic': traffic, 'algorithmic_bytes_per_launch': alg_fwd, 'avg_launch_ms': round(fwd_ms, 4),
-            'launches': prof['lift_splat_fwd']['n'],
+    roof = {'kernel': 'stp3_lift_splat_fwd = lift_pull_kernel (one pass: run pull, discounted accumulation over t, BEV '
+                      'rows written once' + ('' if cl else ' + transpose to the reference layout') + ')',
+            'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
+            'algorithmic_bytes_per_launch': alg_fwd, 'avg_launch_ms': round(fwd_ms, 4),
+            'launches': prof['lift_splat_fwd']['n'], 'bev_layout': 'channels_last' if cl else 'channels_first',
+            'chain_from_logits': {'what': 'depth_softmax + lift_splat_fwd', 'ms': round(fwd_ms + soft_ms, 4),
+                                  'frac': round(alg_fwd / ((fwd_ms + soft_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            'plan_build_ms': round(prof['plan_build']['avg_ms'], 4),
             'backward': {'algorithmic_bytes_per_launch': alg_bwd,
                          'avg_launch_ms': round(prof['lift_splat_bwd']['avg_ms'], 4),
-                         'achieved': round(alg_bwd / (prof['lift_splat_bwd']['avg_ms'] * 1e-3) / 1e9, 1)}}
+                         'achieved': round(alg_bwd / (prof['lift_splat_bwd']['avg_ms'] * 1e-3) / 1e9, 1),
+                         'frac': round(alg_bwd / (prof['lift_splat_bwd']['avg_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
     return roof, {k: round(v['avg_ms'], 4) for k, v in prof.items()}
 
 
@@ -221,7 +231,6 @@ def main():
     ap.add_argument('--batch', type=int, default=4, help='samples per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--graph', action='store_true', help='capture the step into a hipGraph (N=1 only, experimental)')
     ap.add_argument('--no-roofline', action='store_true', help='skip the voxel-pool micro-benchmark (profiling runs)')
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='c3',
                     help='c3: BASELINE configs[2] (all losses incl. depth + instance + flow); perception: Perception.yml')
@@ -230,10 +239,6 @@ def main():
         _cpu_baseline_worker(args.workload)
         return
 
-    if os.environ.get('STP3_MIOPEN_FIND') == '1':
-        # A/B knob: let the vendor library benchmark its solvers per convolution shape (slow first step) instead of
-        # the immediate-mode heuristic pick; only the thin trunk layers and a few weight gradients still go there
-        torch.backends.cudnn.benchmark = True
     from stp3_amd.parallel import FlatAdam, GradientBuckets, init_distributed
     rank, world, local = init_distributed()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
@@ -248,11 +253,10 @@ def main():
         # Host-side options that are bit-identical to the plain path (tests/test_parallel_cpu.py, tests/test_host_cpu.py)
         # and remove ~1 500 tiny launches per step: gradients gathered per bucket, label maps warped together,
         # BatchNorm batch counters applied once per step.
-        # An explicit STP3_GRAD_GATHER / STP3_LABEL_WARP / STP3_LAZY_BN_COUNTER in the environment wins (A/B runs).
-        gather = os.environ.get('STP3_GRAD_GATHER', '1' if fast_host else '0') == '1'
-        _trainer._BATCHED_LABEL_WARP = os.environ.get('STP3_LABEL_WARP', 'batched' if fast_host else 'per_label') == 'batched'
+        gather = bool(fast_host)
+        _trainer._BATCHED_LABEL_WARP = bool(fast_host)
         from stp3_amd import ops as _ops
-        _ops.LAZY_COUNTERS = os.environ.get('STP3_LAZY_BN_COUNTER', '1' if fast_host else '0') == '1'
+        _ops.LAZY_COUNTERS = bool(fast_host)
         buckets = GradientBuckets(module.model, gather=gather)
         opt = FlatAdam(buckets, lr=cfg.OPTIMIZER.LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY)   # trainer.py:456-462
         batch = make_device_batch(args.batch, device, seed=100 + rank, workload=workload)
@@ -291,19 +295,9 @@ def main():
 
     mode = 'eager'
     step = eager_step
-    if world == 1 and args.graph:
-        from stp3_amd.graph import GraphedTrainStep
-        try:
-            runner = GraphedTrainStep(module, buckets, opt, cfg.GRAD_NORM_CLIP, batch, log=_log)
-            step = lambda: runner(batch)
-            mode = 'hipGraph'
-        except Exception as e:                                  # capture is an optimisation, never a requirement
-            print(f'[bench] hipGraph capture failed ({e!r}); running eagerly', file=sys.stderr)
-            module.model.prebuilt_plan = None
-            _sync()
 
     _log(f'mode {mode}: warm-up')
-    for _ in range(max(args.warmup - 1, 0) if mode == 'eager' else args.warmup):   # one warm-up step ran in setup
+    for _ in range(max(args.warmup - 1, 0)):                 # one warm-up step ran in setup
         step()
         _sync()
         _log('warm-up step done')

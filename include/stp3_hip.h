@@ -20,12 +20,14 @@
  *     they never synchronise, so they can be captured into a hipGraph;
  *   - return value: 0 on success, a negative hipError_t on a launch failure, or one of the
  *     STP3_E* codes for rejected arguments.  Nothing throws, nothing exits;
- *   - re-entrant: no global mutable state.
+ *   - re-entrant: no global mutable state, no environment variables: every choice is an argument.
  *
  * Layouts ("pixel-major" = channels-last memory of the corresponding NCHW tensor)
  *   pix   = (n*fH + h)*fW + w                      camera pixel index inside one (b,t) frame
  *   feat  [B*T][N*fH*fW][C]     float32            encoder features   (stp3.py:208, x)
- *   depth [B*T][N*fH*fW][D]     float32            depth logits / probabilities
+ *   depth [B*T][N*fH*fW][D]     float32            depth logits (and their gradient)
+ *   prob_cm / vox_cm [B*T][N*fW][D][fH]            depth probabilities / voxel ids, column-major: (camera, column),
+ *                                                  depth bin, image row
  *   vox   int32 voxel id = ix*(Y*Z) + iy*Z + iz, or -1 if the point falls outside the grid
  *   bev   [B][T][C][X][Y]       float32            reference layout (stp3.py:230-232)
  */
@@ -43,6 +45,10 @@ extern "C" {
 #define STP3_EINVAL   (-10001)  /* bad dimension / null pointer */
 #define STP3_EUNSUP   (-10002)  /* valid request this build does not support (e.g. Z != 1 for pooling) */
 #define STP3_ENOSPACE (-10003)  /* workspace too small */
+
+/* element types of activation / gradient tensors */
+#define STP3_DTYPE_F32  0
+#define STP3_DTYPE_BF16 1
 
 /* Problem shape.  P = N*D*fH*fW frustum points per (b,t); V = X*Y*Z voxels. */
 typedef struct stp3_lift_dims {
@@ -83,61 +89,90 @@ int stp3_voxel_index(const stp3_lift_dims* dims,
                      int order, int32_t* vox, int32_t* counts, void* stream);
 
 /*
- * Pooling plan: the geometry-only structure that the forward kernels consume.  It replaces the
- * reference's boolean mask + argsort (stp3.py:247-257) and depends only on the voxel ids, so it
- * can be built on a side stream while the image encoder is running.
+ * Pooling plan: the geometry-only structure that the forward kernel consumes.  It replaces the
+ * reference's get_geometry + ego alignment + index + boolean mask + argsort (stp3.py:192-198,
+ * :270-277, :287-289, :239-257) and depends only on the camera / ego poses, so it can be built on a
+ * side stream while the image encoder is running.
  *
  * Along an image column (camera n, feature column w, depth bin d) consecutive rows h fall into
  * the same BEV cell most of the time; a RUN is a maximal set of consecutive h with one voxel
- * id >= 0.  The plan numbers the runs canonically (by n, w, d, first row), counts them per voxel
- * and assigns every run a row of the forward workspace such that each voxel's runs are
- * contiguous and ordered by run number.
+ * id >= 0.  The plan lists the runs per voxel, ordered canonically (by n, w, d, first row), so that
+ * the pooled value of a voxel is a pull over its list and is summed in ONE fixed order.
  *
  *   stp3_lift_plan_bytes : size of the plan buffer for `dims`
- *   stp3_lift_plan_build : vox_pm = ids in STP3_VOX_PIXELMAJOR order; counts = int32 [B*T][V]
- *                          scratch that the CALLER zero-fills (left holding runs per voxel).
- *                          `deterministic` != 0 orders every voxel's rows canonically, which
- *                          makes the forward sums bit-reproducible run to run (voxels with more
- *                          than 4096 runs keep their arrival order).
- *   plan layout (int32): run_base [B*T][N*fW*D + 1] | vox_off [B*T][V + 1] | dest [B*T][P] |
- *                        list [B*T][P]; each section starts 256-byte aligned.
+ *   stp3_lift_plan_build : geometry inputs exactly as for stp3_voxel_index; writes
+ *                            vox_cm [B*T][N*fW][D][fH] int32  voxel ids in COLUMN-MAJOR order (the same ids
+ *                                                            stp3_voxel_index computes; the rows h of an image column
+ *                                                            and depth bin are contiguous -- the order the pooling
+ *                                                            kernels walk them in)
+ *                            plan   vox_off [B*T][V+1] int32 | build scratch [B*T][P] 8 bytes
+ *                                   | gidx | groups (below) | runs [B*T][P] (uint32 x, y, z, w):
+ *                                   x = col << 20 | d << 14 | h0 << 7 | (len - 1), col = n*fW + w; y = voxel id;
+ *                                   z, w = first feature row / first probability of the run within the frame;
+ *                                   the runs of a work group are contiguous, longest first
+ *                                   | gidx [B][V+1] int32 | groups [B][V+1] int32: the first voxel of every work
+ *                                   group of the forward kernel (<= 16 consecutive voxels holding ~32 runs over
+ *                                   the sample's T frames), gidx[b][V] of them, closed by V;
+ *                                   each section starts 256-byte aligned
+ *                          counts = int32 [B*T][V] scratch that must be ZERO on entry (the caller zero-fills
+ *                          it once; every build leaves it zero again).
+ *   Launches: index + count, scan, fill, per-voxel order, group flags, scan, group list, memset.  Limits: Z == 1, C % 4 == 0, C <= 64,
+ *   D <= 64, fH <= 128, N*fW < 4096, B*T*N*fH*fW*max(C,D)*4 < 2^32, else STP3_EUNSUP.
  */
 int stp3_lift_plan_bytes(const stp3_lift_dims* dims, size_t* bytes);
-int stp3_lift_plan_build(const stp3_lift_dims* dims, const int32_t* vox_pm, int32_t* counts,
-                         void* plan, size_t plan_bytes, int deterministic, void* stream);
+int stp3_lift_plan_build(const stp3_lift_dims* dims,
+                         const float* cam_m, const float* cam_t,
+                         const float* ego_r, const float* ego_t,
+                         const float* xs, const float* ys, const float* ds,
+                         const float* bev_offset, const float* bev_res,
+                         int32_t* vox_cm, int32_t* counts, void* plan, size_t plan_bytes, void* stream);
 
 /* stp3_depth_softmax -- softmax over the D depth bins of every pixel (stp3.py:215).
- * logits, prob: [B*T][N*fH*fW][D] float32 (may alias). */
+ * logits [B*T][N*fH*fW][D] float32 (pixel-major) -> prob_cm [B*T][N*fW][D][fH] float32 (column-major, what
+ * stp3_lift_splat_fwd / _bwd read; must not alias logits). */
 int stp3_depth_softmax(const stp3_lift_dims* dims, const float* logits, float* prob, void* stream);
+
+/* memory layout of the BEV tensor handed to / produced by the pooling calls */
+#define STP3_BEV_CHANNELS_FIRST 0   /* [B][T][C][X][Y]  the reference's layout (stp3.py:230-232, :297-299)          */
+#define STP3_BEV_CHANNELS_LAST  1   /* [B][T][X][Y][C]  = channels-last memory of the same (B,T,C,X,Y) tensor: what the */
+                                    /* NHWC convolutions of the temporal model consume; no transpose pass             */
 
 /*
  * stp3_lift_splat_fwd -- out[b][t] = sum_{k<=t} discount^(t-k) Pool_k,
  *   Pool_k[c][v] = sum over points p of frame k with vox(p) == v of prob[p] * feat[pix(p)][c].
  * Replaces stp3.py:216-221 (outer product, never materialised), geometry.py:302-318
- * (VoxelsSumming.forward) and stp3.py:279-299 (scatter, discount, permute).  Requires Z == 1,
- * C <= 64, D <= 128.  Two launches: (1) per image column, depth (x) feature products summed
- * along each run -> one C-vector per run in `workspace`; (2) per voxel, sum of its runs,
- * discounted accumulation over t, transposed store.
- *   workspace: stp3_lift_workspace_bytes(dims) bytes of scratch (worst case one run per point);
- *              only the rows of actual runs are touched (typically 5-10 % of it)
- *   bev [B][T][C][X][Y] float32, fully overwritten (empty voxels get 0).
+ * (VoxelsSumming.forward) and stp3.py:279-299 (scatter, discount, permute).
+ * ONE kernel, pull form: a wave owns 16 voxels of a sample, walks their run lists for t = 0..T-1 and writes
+ * every voxel's C-vector once (256-byte rows); inputs are read through L2, nothing is staged in HBM.
+ * Deterministic (fixed summation order, no atomics).
+ *   bev_layout STP3_BEV_CHANNELS_LAST : bev written directly, workspace unused (may be NULL)
+ *              STP3_BEV_CHANNELS_FIRST: the kernel writes the channels-last result into `workspace`
+ *                                       (stp3_lift_workspace_bytes) and a transpose pass produces bev
+ *   bev: B*T*C*X*Y float32, fully overwritten (empty voxels get 0).
+ *   Work is dealt out in the plan's voxel groups (<= 16 voxels, ~32 runs over the T frames) to a chip-sized set
+ *   of persistent waves, statically; 8 % B == 0 keeps a sample on 8/B XCDs.
  */
-int stp3_lift_workspace_bytes(const stp3_lift_dims* dims, size_t* bytes);
-int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const float* prob,
-                        const int32_t* vox_pm, const void* plan, float discount,
+int stp3_lift_workspace_bytes(const stp3_lift_dims* dims, size_t* bytes);   /* B*T*V*C float32 */
+int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const float* prob_cm,
+                        const void* plan, float discount, int bev_layout,
                         void* workspace, size_t workspace_bytes, float* bev, void* stream);
 
 /*
  * stp3_lift_splat_bwd -- gradients of stp3_lift_splat_fwd composed with stp3_depth_softmax.
  * Replaces autograd through stp3.py:215-301 and VoxelsSumming.backward (geometry.py:320-330).
- * Gather form (no atomics): one wave per image column re-fetches a voxel's gradient row only
- * when the voxel id changes along the column.  Requires Z == 1, C <= 64, D <= 64.
- *   grad_bev   [B][T][C][X][Y]      dL/d(out)
- *   gacc       [B*T][V][C] float32  scratch (the discounted reverse accumulation of grad_bev)
+ * Two kernels, no atomics:
+ *   (a) gradient import: G_t = sum_{t' >= t} discount^(t'-t) grad_bev[b][t'] (the adjoint of the discounted
+ *       accumulation) written voxel-major [B*T][V][C] float32 into `workspace`; takes grad_bev in `bev_layout`
+ *       and `grad_dtype` (channels-last float32 / bfloat16, channels-first float32), i.e. the layout / type
+ *       conversion the gradient needs anyway carries the recurrence;
+ *   (b) gather: one image pixel per lane pair (its feature row and feature-gradient row in registers), walking the
+ *       depth bins 8 at a time; a voxel's gradient row is fetched once per run of image rows and shared through LDS.
+ *   workspace  stp3_lift_workspace_bytes(dims), always required
  *   grad_feat  [B*T][N*fH*fW][C], grad_logits [B*T][N*fH*fW][D]   outputs, fully overwritten
  */
-int stp3_lift_splat_bwd(const stp3_lift_dims* dims, const float* grad_bev, const float* feat,
-                        const float* prob, const int32_t* vox_pm, float discount, float* gacc,
+int stp3_lift_splat_bwd(const stp3_lift_dims* dims, const void* grad_bev, int bev_layout, int grad_dtype,
+                        const float* feat, const float* prob_cm, const int32_t* vox_cm, float discount,
+                        void* workspace, size_t workspace_bytes,
                         float* grad_feat, float* grad_logits, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -151,9 +186,6 @@ int stp3_lift_splat_bwd(const stp3_lift_dims* dims, const float* grad_bev, const
  *   implied by Ho, Wo: "static same" padding is asymmetric on stride-2 layers)
  * bwd_weight is deterministic (two-stage reduction through `workspace`, no atomics).
  */
-#define STP3_DTYPE_F32  0
-#define STP3_DTYPE_BF16 1
-
 typedef struct stp3_dwconv_dims {
     int32_t N, H, W, C;          /* input  (channels-last)            */
     int32_t Ho, Wo;              /* output spatial size               */
@@ -244,9 +276,9 @@ int stp3_bn_bwd_train(const stp3_bn_dims* dims, const void* dy, const void* x, c
                       float* sum_buf, void* dx, void* dres, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Dense 2-D convolution, bf16 MFMA implicit GEMM, NHWC.
+ * Dense 2-D convolution, bf16 MFMA implicit GEMM, NHWC (csrc/stp3_conv.hip).
  * Replaces the nn.Conv2d (and frame-folded nn.Conv3d) contractions of stp3/layers/convolutions.py:183-280,
- * stp3/layers/temporal.py:252-273,315-325, stp3/models/decoder.py:22-140 and the 1x1 expand / project
+ * stp3/layers/temporal.py:252-273,315-325, stp3/models/decoder.py:22-140 and the stem / 1x1 expand / project
  * convolutions of the MBConv blocks driven by stp3/models/encoder.py:57-97 (groups == 1).
  *   x [N][H][W][ldx >= Cin]  bf16 (row stride ldx lets the kernel read a channel-slice / concat view)
  *   w [Cout][KH][KW][Cin]    bf16 (= channels-last memory of the (Cout, Cin, KH, KW) parameter)
@@ -254,8 +286,14 @@ int stp3_bn_bwd_train(const stp3_bn_dims* dims, const void* dy, const void* x, c
  *   y [N][Ho][Wo][ldy >= Cout]  out_dtype = STP3_DTYPE_BF16 or STP3_DTYPE_F32, float32 accumulation
  *   y[n][ho][wo][co] = bias[co] + sum_{kh,kw,ci} x[n][ho*stride - pad_h + kh*dil_h][wo*stride - pad_w + kw*dil_w][ci]
  *                                                 * w[co][kh][kw][ci]           (zero padding)
- * Requires Cin % 8 == 0, ldx % 8 == 0, 16-byte aligned x / w.  The data gradient of a stride-1 convolution
- * is the same call on dy with the taps flipped and Cin / Cout swapped (the host prepares that weight).
+ *   sums [2][Cout] float32 or NULL (bf16 outputs only): per-channel sum and sum of squares of the ROUNDED outputs over
+ *        all N*Ho*Wo pixels -- the BatchNorm statistics, taken in the epilogue (the result feeds stp3_bn_apply_fwd
+ *        directly, no stp3_bn_stats pass over the convolution output); needs `workspace` of
+ *        stp3_conv2d_fwd_workspace(dims) bytes (one partial row per 128-pixel workgroup; deterministic)
+ * Workgroup tile 128 pixels x 128 (Cout > 64) or 64 output channels, K steps of 64 staged through LDS,
+ * v_mfma_f32_32x32x16_bf16.  Requires Cin % 8 == 0, ldx % 8 == 0, 16-byte aligned x / w / y,
+ * N*H*W*ldx < 2^31.  The data gradient of a stride-1 convolution is the same call on dy with the taps flipped and
+ * Cin / Cout swapped (the host prepares that weight).
  */
 typedef struct stp3_conv_dims {
     int32_t N, H, W, Cin;
@@ -266,8 +304,9 @@ typedef struct stp3_conv_dims {
     int32_t out_dtype, has_bias;
 } stp3_conv_dims;
 
+int stp3_conv2d_fwd_workspace(const stp3_conv_dims* dims, size_t* bytes);
 int stp3_conv2d_fwd(const stp3_conv_dims* dims, const void* x, const void* w, const float* bias, void* y,
-                    void* stream);
+                    float* sums, void* workspace, size_t workspace_bytes, void* stream);
 
 /* stp3_conv2d_wgrad -- dw[co][kh][kw][ci] = sum_{n,ho,wo} dy[n][ho][wo][co] * x[n][ho*stride-pad_h+kh*dil_h][..][ci]
  * (the weight gradient autograd derives for the convolutions above), float32 output in the weight's own
@@ -279,18 +318,8 @@ int stp3_conv2d_wgrad_workspace(const stp3_conv_dims* dims, size_t* bytes);
 int stp3_conv2d_wgrad(const stp3_conv_dims* dims, const void* dy, const void* x, float* dw, void* workspace,
                       size_t workspace_bytes, void* stream);
 
-/* stp3_conv2d_fwd_v2 -- second-generation forward (csrc/stp3_conv2.hip; EXPERIMENTAL, selected with STP3_CONV_V2=1):
- * same contract as stp3_conv2d_fwd for bf16 outputs, with 128-byte contiguous output stores per pixel and, when
- * `sums` is non-NULL, the BatchNorm statistics of the output fused into the epilogue:
- *   sums [2][Cout] float32 = per-channel sum and sum of squares of the bf16-rounded outputs over all N*Ho*Wo pixels
- *   workspace: stp3_conv2d_fwd_v2_workspace(dims) bytes (one partial row per 128-pixel workgroup; deterministic)
- * The result feeds stp3_bn_apply_fwd directly (no stp3_bn_stats pass over the convolution output). */
-int stp3_conv2d_fwd_v2_workspace(const stp3_conv_dims* dims, size_t* bytes);
-int stp3_conv2d_fwd_v2(const stp3_conv_dims* dims, const void* x, const void* w, const float* bias, void* y,
-                       float* sums, void* workspace, size_t workspace_bytes, void* stream);
-
 /* ------------------------------------------------------------------------------------------------
- * Squeeze-and-excitation data passes (csrc/stp3_se.hip; EXPERIMENTAL, host side selected with STP3_FUSED_SE=1).
+ * Squeeze-and-excitation data passes (csrc/stp3_se.hip).
  * Replace the pooling, the gate multiply and the elementwise / reduction passes of their backward inside the
  * EfficientNet MBConv blocks driven by stp3/models/encoder.py:57-97.
  *   x, dy, y : [N][rows][ld >= C] channels-last, dtype STP3_DTYPE_F32 / _BF16
@@ -308,8 +337,7 @@ int stp3_se_pool(const stp3_se_dims* dims, const void* x, const void* dy, void* 
 int stp3_se_scale(const stp3_se_dims* dims, const void* x, const float* gate, const float* add, void* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * The two fully-connected layers of a squeeze-and-excitation block (csrc/stp3_se_mlp.hip; EXPERIMENTAL, host side
- * selected with STP3_SE_MLP=1 on top of STP3_FUSED_SE=1): the MBConv gate
+ * The two fully-connected layers of a squeeze-and-excitation block (csrc/stp3_se_mlp.hip): the MBConv gate
  *     gate = sigmoid(W2 swish(W1 mean_hw(x) + b1) + b2)
  * (efficientnet_pytorch MBConvBlock as driven by stp3/models/encoder.py:57-97) and its backward, float32.
  *   pooled_sum [N][C] : sum over the map (stp3_se_pool); the mean is pooled_sum * inv_rows
@@ -331,8 +359,7 @@ int stp3_se_mlp_bwd(const stp3_se_mlp_dims* dims, const float* dgate, const floa
                     float* dw1, float* db1, float* dw2, float* db2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * bf16 shadow copies of all convolution weights in ONE launch (csrc/stp3_wprep.hip; EXPERIMENTAL, host side
- * selected with STP3_WEIGHT_PREP=1).  Replaces the per-layer cast / flip / transpose / re-layout the host would
+ * bf16 shadow copies of all convolution weights in ONE launch (csrc/stp3_wprep.hip).  Replaces the per-layer cast / flip / transpose / re-layout the host would
  * otherwise redo after every optimizer step for the operands of stp3_conv2d_fwd (forward: [Cout][KH][KW][Cin];
  * data gradient: [Cin][KH][KW][Cout] with the taps flipped).
  *   table : n_entries structs in DEVICE memory, sorted by first_block
@@ -352,8 +379,7 @@ typedef struct stp3_wprep_entry {
 int stp3_conv2d_prep_weights(const stp3_wprep_entry* table, int32_t n_entries, int64_t total_blocks, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Gradient-norm clipping + Adam on flat fp32 buckets in three launches (csrc/stp3_optim.hip; EXPERIMENTAL, host
- * side selected with STP3_FUSED_ADAM=1).  Replaces, for the flat buckets of stp3_amd/parallel.py, the reference's
+ * Gradient-norm clipping + Adam on flat fp32 buckets in three launches (csrc/stp3_optim.hip).  Replaces, for the flat buckets of stp3_amd/parallel.py, the reference's
  * gradient_clip_val (train.py:48, torch clip_grad_norm_ semantics: scale = min(max_norm / (norm + 1e-6), 1)) and
  * torch.optim.Adam step (trainer.py:456-462: L2 weight decay folded into the gradient, bias correction, no amsgrad).
  *   table : n_buckets structs in DEVICE memory, sorted by first_block; grad / param / exp_avg / exp_avg_sq are

@@ -1,46 +1,66 @@
-"""Per-kernel averages of one PMC counter from rocprofv3 counter_collection CSVs.
-   python scripts/agg_pmc.py <dir_with_FETCH_SIZE_run> <dir_with_WRITE_SIZE_run>  -> JSON on stdout
-FETCH_SIZE / WRITE_SIZE are in KiB (guide section 7: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024); the
-calibration stream (torch.add over 256 MiB) gives the correction factor for this access width on gfx950
-(MI355X_MICROARCH.md section HBM: FETCH_SIZE reads 1/2 of a wide coalesced stream)."""
-import glob, json, sys
+"""Per-kernel averages of PMC counters from rocprofv3 counter_collection CSVs (one directory per pass).
+   python scripts/agg_pmc.py <pass dir> [<pass dir> ...]  -> JSON on stdout
+For every kernel of interest: mean per dispatch of each counter (summed over the counter's instances), mean duration
+from the kernel trace of the first pass.  FETCH_SIZE / WRITE_SIZE are in KiB; the calibration stream (torch.add over
+256 MiB, known bytes) gives the correction factors for this access width on gfx950 (MI355X_MICROARCH.md section HBM:
+FETCH_SIZE reads 1/2 of a wide coalesced stream), which are applied to give hbm_read_bytes / hbm_write_bytes."""
+import glob, json, subprocess, sys
 import pandas as pd
 
 CAL_BYTES = (64 << 20) * 4
+KEYS = ('lift_', 'plan_', 'depth_softmax', 'grad_import', 'transpose_kernel', 'voxel_index', 'add')
 
 
-def load(d, counter):
-    f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
-    df = pd.read_csv(f)
-    df = df[df['Counter_Name'] == counter]
-    # a counter row may appear once per XCD/instance: sum per dispatch, then average per kernel
-    per = df.groupby(['Dispatch_Id', 'Kernel_Name'])['Counter_Value'].sum().reset_index()
-    return per.groupby('Kernel_Name')['Counter_Value'].agg(['mean', 'count'])
+def shorten(name):
+    if 'at::native' in name:
+        return 'calibration_add' if ('add' in name.lower() and 'vectorized' in name) else 'aten:' + name[:50]
+    return name.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:60]
 
 
-def pick(tab, key):
-    rows = tab[tab.index.str.contains(key)]
-    return None if rows.empty else float(rows['mean'].iloc[0]) * 1024.0
+def main():
+    out, durs = {}, {}
+    for d in sys.argv[1:]:
+        files = glob.glob(d + '/**/*counter_collection.csv', recursive=True)
+        if not files:
+            continue
+        df = pd.read_csv(files[0])
+        per = df.groupby(['Dispatch_Id', 'Kernel_Name', 'Counter_Name'])['Counter_Value'].sum().reset_index()
+        tab = per.groupby(['Kernel_Name', 'Counter_Name'])['Counter_Value'].mean().unstack()
+        for name, row in tab.iterrows():
+            if not any(k in name for k in KEYS):
+                continue
+            short = shorten(name)
+            ent = out.setdefault(short, {})
+            ent.update({k: float(v) for k, v in row.items() if v == v})
+        tr = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)
+        if tr and not durs:
+            kt = pd.read_csv(tr[0])
+            kt['us'] = (kt['End_Timestamp'] - kt['Start_Timestamp']) / 1e3
+            for name, g in kt.groupby('Kernel_Name'):
+                if any(k in name for k in KEYS):
+                    short = shorten(name)
+                    durs[short] = (float(g['us'].mean()), int(len(g)))
+    for k, (us, n) in durs.items():
+        out.setdefault(k, {}).update({'avg_us_under_profiler': us, 'dispatches': n})
+    cal = out.get('calibration_add', {})
+    fc = CAL_BYTES / (cal['FETCH_SIZE'] * 1024.0) if cal.get('FETCH_SIZE') else None
+    wc = CAL_BYTES / (cal['WRITE_SIZE'] * 1024.0) if cal.get('WRITE_SIZE') else None
+    for k, ent in out.items():
+        if 'FETCH_SIZE' in ent:
+            ent['hbm_read_bytes'] = ent['FETCH_SIZE'] * 1024.0 * (fc or 1.0)
+        if 'WRITE_SIZE' in ent:
+            ent['hbm_write_bytes'] = ent['WRITE_SIZE'] * 1024.0 * (wc or 1.0)
+        if ent.get('TCC_HIT_sum') is not None and ent.get('TCC_MISS_sum') is not None:
+            ent['l2_hit_rate'] = ent['TCC_HIT_sum'] / max(ent['TCC_HIT_sum'] + ent['TCC_MISS_sum'], 1.0)
+    try:
+        commit = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], text=True).strip()
+    except Exception:
+        commit = None
+    res = {'frames_per_launch': 12, 'commit': commit, 'calibration': {'true_bytes_each_way': CAL_BYTES, 'fetch_correction': fc,
+                                                                       'write_correction': wc}}
+    res.update(out)
+    print(json.dumps(res, indent=1))
 
 
-def pick_max(tab, key):
-    rows = tab[tab.index.str.contains(key)]
-    return None if rows.empty else float(rows['mean'].max()) * 1024.0
-
-
-fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
-cal_f = pick_max(fetch, 'CUDAFunctorOnOther_add|AddFunctor|CUDAFunctor_add')
-cal_w = pick_max(write, 'CUDAFunctorOnOther_add|AddFunctor|CUDAFunctor_add')
-out = {'calibration': {'kernel': 'torch.add over 256 MiB float32', 'true_read_bytes': CAL_BYTES, 'true_write_bytes': CAL_BYTES,
-                       'FETCH_SIZE_bytes': cal_f, 'WRITE_SIZE_bytes': cal_w,
-                       'fetch_correction': None if not cal_f else CAL_BYTES / cal_f,
-                       'write_correction': None if not cal_w else CAL_BYTES / cal_w}}
-fc = out['calibration']['fetch_correction'] or 1.0
-wc = out['calibration']['write_correction'] or 1.0
-for name, key in (('lift_runs', 'lift_runs_kernel'), ('lift_gather', 'lift_gather_kernel'),
-                  ('depth_softmax', 'depth_softmax_kernel'), ('bev_grad_accumulate', 'bev_grad_accumulate_kernel'),
-                  ('lift_splat_bwd', 'lift_splat_bwd_kernel')):
-    fb, wb = pick(fetch, key), pick(write, key)
-    out[name] = {'FETCH_SIZE_bytes_raw': fb, 'WRITE_SIZE_bytes_raw': wb,
-                 'hbm_read_bytes': None if fb is None else fb * fc, 'hbm_write_bytes': None if wb is None else wb * wc}
-print(json.dumps(out, indent=1))
+if __name__ == '__main__':
+    main()

@@ -1,10 +1,11 @@
-"""Quick HIP-event timing of the lift kernels at BASELINE configs[1] shape (B=4,T=3)."""
+"""HIP-event timing of the voxel-pool kernels at BASELINE configs[1]/[2] shape (B=4, T=3) through the C ABI."""
 import sys, os, ctypes, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'st-p3_amd'))
 import torch
 from stp3_amd import ops, _lib
 from stp3_amd import synthetic
+
 
 def ev_time(fn, iters=20, warm=3):
     for _ in range(warm): fn()
@@ -15,36 +16,33 @@ def ev_time(fn, iters=20, warm=3):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3  # us
 
+
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 (frustum, res, start, dim), intr, extr, ego, feat, logits = synthetic.lift_case(batch=B, seq=3, seed=31)
 grid = ops.LiftGrid(frustum, res, start, dim, 'cuda')
 t0 = time.time(); plan = ops.LiftPlan.build(grid, intr, extr, ego, 64); torch.cuda.synchronize(); print('first plan build (host+dev) s', time.time() - t0)
 d = plan.dims
-mats = [m.cuda() for m in ops.lift_matrices(intr, extr, ego)]
 lib = _lib.lib()
-counts = torch.zeros(d.BT, d.V, dtype=torch.int32, device='cuda')
-print('voxel_index us', ev_time(lambda: ops.voxel_index(grid, d, *mats, order=1)))
-nb = ctypes.c_size_t(); lib.stp3_lift_plan_bytes(ctypes.byref(d), ctypes.byref(nb))
-pl = torch.empty(nb.value, dtype=torch.uint8, device='cuda')
-def build(det):
-    counts.zero_()
-    vox = ops.voxel_index(grid, d, *mats, order=1)
-    lib.stp3_lift_plan_build(ctypes.byref(d), ops._ptr(vox), ops._ptr(counts), ops._ptr(pl), nb, det, ops._stream())
-print('index+plan build (det) us', ev_time(lambda: build(1)))
-print('index+plan build (nondet) us', ev_time(lambda: build(0)))
-f = feat.cuda().permute(0,1,2,4,5,3).reshape(d.BT, d.NPIX, d.C).contiguous()
-l = logits.cuda().permute(0,1,2,4,5,3).reshape(d.BT, d.NPIX, d.D).contiguous()
+mats = [m.cuda() for m in ops.lift_matrices(intr, extr, ego)]
+print('voxel_index alone us', ev_time(lambda: ops.voxel_index(grid, d, *mats, order=1)))
+print('plan build (index + count, scan, fill, order; device part) us', ev_time(lambda: ops.LiftPlan.build(grid, intr, extr, ego, 64, out=plan)))
+f = feat.cuda().permute(0, 1, 2, 4, 5, 3).reshape(d.BT, d.NPIX, d.C).contiguous()
+l = logits.cuda().permute(0, 1, 2, 4, 5, 3).reshape(d.BT, d.NPIX, d.D).contiguous()
 prob = ops.depth_softmax(d, l)
-print('softmax us', ev_time(lambda: ops.depth_softmax(d, l)))
-bev = torch.empty(d.B, d.T, d.C, d.X, d.Y, device='cuda')
-ws, wsb = ops.lift_workspace(d, 'cuda')
-fwd = lambda: lib.stp3_lift_splat_fwd(ctypes.byref(d), ops._ptr(f), ops._ptr(prob), ops._ptr(plan.vox_pm), ops._ptr(plan.plan), ctypes.c_float(0.5), ops._ptr(ws), ctypes.c_size_t(wsb), ops._ptr(bev), ops._stream())
-print('runs per (b,t):', plan.offsets()[:, -1].tolist(), ' points per (b,t):', d.P)
-us = ev_time(fwd)
+t_soft = ev_time(lambda: ops.depth_softmax(d, l))
+print('softmax us', t_soft)
+print('runs per (b,t):', plan.offsets()[:, -1].tolist(), ' points per (b,t):', d.P, ' voxel groups per sample:', [g.numel() - 1 for g in plan.groups()])
 alg = d.BT * (d.NPIX * d.C * 4 + d.NPIX * d.D * 4 + d.C * d.V * 4)
-print(f'lift_splat_fwd us {us:.1f}  algorithmic {alg/1e6:.1f} MB -> {alg/us/1e6:.3f} TB/s ({alg/us/1e6/8*100:.1f}% of 8 TB/s)')
-gacc = torch.empty(d.BT, d.V, d.C, device='cuda'); gb = torch.randn_like(bev); gf = torch.empty_like(f); gl = torch.empty_like(l)
-bwd = lambda: lib.stp3_lift_splat_bwd(ctypes.byref(d), ops._ptr(gb), ops._ptr(f), ops._ptr(prob), ops._ptr(plan.vox_pm), ctypes.c_float(0.5), ops._ptr(gacc), ops._ptr(gf), ops._ptr(gl), ops._stream())
-us = ev_time(bwd)
 algb = d.BT * (d.C * d.V * 4 + 2 * d.NPIX * d.C * 4 + 2 * d.NPIX * d.D * 4)
-print(f'lift_splat_bwd us {us:.1f}  algorithmic {algb/1e6:.1f} MB -> {algb/us/1e6:.3f} TB/s')
+gf = torch.empty_like(f); gl = torch.empty_like(l)
+for name, layout in (('channels-last BEV (model path)', ops.BEV_CHANNELS_LAST), ('reference layout (+ transpose pass)', ops.BEV_CHANNELS_FIRST)):
+    bev = torch.empty(d.B * d.T * d.C * d.X * d.Y, device='cuda')
+    ws, wsb = ops.lift_workspace(d, 'cuda')
+    fwd = lambda: lib.stp3_lift_splat_fwd(ctypes.byref(d), ops._ptr(f), ops._ptr(prob), ops._ptr(plan.plan), ctypes.c_float(0.5), layout, ops._ptr(ws), ctypes.c_size_t(wsb), ops._ptr(bev), ops._stream())
+    us = ev_time(fwd)
+    print(f'{name}: lift_splat_fwd us {us:.1f}  algorithmic {alg/1e6:.1f} MB -> {alg/us/1e6:.3f} TB/s ({alg/us/1e6/8*100:.1f}% of 8 TB/s); '
+          f'with softmax {alg/(us+t_soft)/1e6/8*100:.1f}%')
+    gb = torch.randn_like(bev)
+    bwd = lambda: lib.stp3_lift_splat_bwd(ctypes.byref(d), ops._ptr(gb), layout, 0, ops._ptr(f), ops._ptr(prob), ops._ptr(plan.vox_cm), ctypes.c_float(0.5), ops._ptr(ws), ctypes.c_size_t(wsb), ops._ptr(gf), ops._ptr(gl), ops._stream())
+    us = ev_time(bwd)
+    print(f'{name}: lift_splat_bwd us {us:.1f}  algorithmic {algb/1e6:.1f} MB -> {algb/us/1e6:.3f} TB/s ({algb/us/1e6/8*100:.1f}% of 8 TB/s)')

@@ -83,7 +83,7 @@ struct Map {
     int CV, CVB, RL, cv, rl;
     bool live;
 };
-// FULL (experimental geometry, STP3_BN_GEOM=1): every thread of the workgroup is a live row lane
+// FULL (chosen for the largest maps, see plan()): every thread of the workgroup is a live row lane
 // (RL = 256 / CVB, not rounded down to a power of two) -- with C = 144 that is 252 instead of 144 threads.
 template <int VEC, bool FULL>
 __device__ __forceinline__ Map make_map(const BnDims& d) {
@@ -466,7 +466,7 @@ struct Launch {
     BnDims d;
     int vec;       // 8 / 4 (vector path) or 1
     bool bf16;
-    bool full;     // experimental geometry (STP3_BN_GEOM=1): all row lanes live, ~4096 workgroups
+    bool full;     // full-occupancy geometry: all row lanes live, ~4096 workgroups
     dim3 grid;
     int parts;     // partial rows = N * grid.x
 };
@@ -490,8 +490,9 @@ inline int plan(const stp3_bn_dims* p, Launch* L, std::initializer_list<const vo
     BnDims& d = L->d;
     d.N = p->N; d.rows = p->rows; d.C = p->C; d.ldx = p->ldx; d.ldy = p->ldy; d.ldr = p->ldr;
     d.act = p->act; d.res_mode = p->res_mode; d.has_sbias = p->has_sbias; d.has_oscale = p->has_oscale;
-    static const bool geom_full = [] { const char* e = getenv("STP3_BN_GEOM"); return e && e[0] == '1'; }();
-    L->full = geom_full;
+    // two workgroup geometries; the full-occupancy one pays off only on the largest maps (measured on the MI355X,
+    // profiles/r02a_validate_switches.txt: 72 x 144 x 112 x 240 backward 1205 -> 771 us, smaller maps 0-40 % slower)
+    L->full = (int64_t)p->N * p->rows * p->C >= (int64_t)200 * 1000 * 1000;
     const int CV = (p->C + L->vec - 1) / L->vec;
     const int CVB = CV < kThreads ? CV : kThreads;
     int RL = 1;

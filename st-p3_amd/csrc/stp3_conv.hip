@@ -1,21 +1,28 @@
-// stp3_conv.hip -- bf16 MFMA implicit-GEMM 2-D convolution (NHWC) for gfx950.
+// stp3_conv.hip -- bf16 MFMA implicit-GEMM 2-D convolution (NHWC) for gfx950: LDS-tiled, 32x32x16 MFMA.
 //
 // Replaces the dense nn.Conv2d / frame-folded nn.Conv3d contractions of the reference's hot path:
 //   stp3/layers/convolutions.py:183-280 (UpsamplingConcat / UpsamplingAdd / ASPP / DeepLabHead 1x1, 3x3 and
 //   dilated 3x3), stp3/layers/temporal.py:252-273, 315-325 (CausalConv3d (2,3,3)/(1,3,3) and 1x1x1, run
 //   frame-folded as 2-D convolutions), stp3/models/decoder.py:22-140 (7x7/2 stem, ResNet-18 3x3, heads) and the
-//   1x1 expand / project convolutions of the EfficientNet MBConv blocks driven by stp3/models/encoder.py:57-97.
+//   3x3/2 stem and the 1x1 expand / project convolutions of the EfficientNet MBConv blocks driven by
+//   stp3/models/encoder.py:57-97 -- forward and, with the taps flipped, the data gradient.
 //
-// GEMM view:  Y[m][co] = sum_{tap, ci} X[pixel(m) + tap][ci] * W[co][tap][ci],  m = (n, ho, wo).
-// Both operands are K-contiguous in memory (NHWC activations, [Cout][KH][KW][Cin] weights), which is exactly
-// the v_mfma_f32_16x16x32_bf16 fragment shape: lane l supplies 8 consecutive k of row (l & 15), k-chunk
-// (l >> 4) -- one 16-byte load per lane per fragment, no LDS shuffle.  The weights take the A (row) slot and
-// the pixels the B (column) slot, so an accumulator lane ends up with 4 consecutive output CHANNELS of one
-// pixel: the epilogue stores 8-byte bf16x4 pieces straight into the NHWC output.
+// GEMM view:  Y[m][co] = sum_k X[pixel(m) + tap(k)][ci(k)] * W[co][k],  m = (n, ho, wo),  k = tap * Cin + ci.
+// Both operands are K-contiguous in memory (NHWC activations, [Cout][KH][KW][Cin] weights), so a 16-byte piece =
+// 8 consecutive k of one row, for either operand.
 //
-// Tile: workgroup = 4 waves = 128 pixels x 64 channels; wave = 32 pixels x 64 channels = 2 x 4 MFMA tiles
-// (8 accumulators, 32 VGPRs).  Fragments of step s+1 are loaded while step s is multiplied (register double
-// buffer).  A k-step is 32 input channels of one tap.
+// Workgroup = 4 waves = 128 pixels x BN output channels (BN = 128 or 64), K in steps of 64:
+//   * staging: every thread copies 16-byte pieces global -> registers -> LDS (zero for padding taps, rows beyond M /
+//     Cout and the K tail); the loads of step s+1 are issued before the MFMAs of step s and written to the other LDS
+//     buffer after them: one barrier per K step, global latency behind the matrix work of the whole step;
+//   * LDS image: [row][8 pieces of 16 bytes], piece j of row r stored at slot j ^ ((r >> 1) & 7): the ds_read_b128 of
+//     an MFMA fragment (32 rows, one piece column) is then conflict-free;
+//   * v_mfma_f32_32x32x16_bf16 with the WEIGHT tile as operand A (rows = output channels) and the PIXEL tile as
+//     operand B: an accumulator lane holds, for ONE pixel, four consecutive output channels per register quad;
+//   * epilogue: the tile goes back through LDS ([pixel][channel], bias added, rounded to the output type) and leaves
+//     as 16-byte pieces, 256 contiguous bytes per pixel and BN = 128 bf16 channels; optionally the per-channel sum and
+//     sum of squares of the ROUNDED outputs over the tile's pixels (BatchNorm statistics: the separate statistics
+//     pass over the convolution output disappears), one partial row per workgroup, reduced deterministically.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -27,6 +34,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 struct ConvDims {
     int N, H, W, Cin, Ho, Wo, Cout;
@@ -34,7 +42,8 @@ struct ConvDims {
     int ldx, ldy;
     int out_f32, has_bias;
     int M;          // N * Ho * Wo
-    int kchunks;    // ceil(Cin / 32)
+    int kchunks;    // (unused)
+    int Ktot;       // KH * KW * Cin
 };
 
 union Frag {
@@ -47,259 +56,448 @@ __device__ __forceinline__ uint32_t f2bf(float a) {   // round to nearest even
     if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
+__device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 16); }
 
-constexpr int kTilePix = 128;   // pixels per workgroup
-constexpr int kTileCo = 64;     // output channels per workgroup
-constexpr int PT = 2;           // 16-pixel MFMA tiles per wave
-constexpr int CT = 4;           // 16-channel MFMA tiles per wave
+constexpr int kBM = 128;        // pixels per workgroup
+constexpr int kBK = 64;         // K per step: 8 pieces of 16 bytes per row
 
-__global__ __launch_bounds__(256) void conv2d_fwd_kernel(ConvDims d, const uint16_t* __restrict__ x,
-                                                         const uint16_t* __restrict__ w,
-                                                         const float* __restrict__ bias, void* __restrict__ y) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int li = lane & 15;       // row of the A fragment (output channel) / column of B (pixel)
-    const int kq = lane >> 4;       // k-chunk: 8 input channels
-    const int m_wave = blockIdx.x * kTilePix + wave * (PT * 16);
-    const int co0 = blockIdx.y * kTileCo;
+// v or zero, word by word (a select on the whole uint4 makes the compiler go through scratch memory)
+__device__ __forceinline__ uint4 keep(uint4 v, bool ok) {
+    return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+}
 
-    // ---- per-lane pixel coordinates of the B fragments ------------------------------------------------
-    int pn[PT], ph[PT], pw[PT];
-    bool pvalid[PT];
+// byte offset of piece j of row r in a [rows][8 x 16 B] LDS image
+__device__ __forceinline__ int lds_piece(int r, int j) { return (r * 8 + (j ^ ((r >> 1) & 7))) * 16; }
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, const uint16_t* __restrict__ x,
+                                                           const uint16_t* __restrict__ w,
+                                                           const float* __restrict__ bias, void* __restrict__ y,
+                                                           float* __restrict__ stat_partial) {
+    constexpr int TP = BN == 128 ? 2 : 1;                 // 32-pixel MFMA tiles per wave
+    constexpr int TC = 2;                                 // 32-channel MFMA tiles per wave
+    constexpr int kStage = (kBM + BN) * kBK * 2;          // bytes of one staging buffer (pixel image + weight image)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = BN == 128 ? (wave >> 1) : wave;        // which 32*TP pixels of the tile
+    const int wn = BN == 128 ? (wave & 1) : 0;            // which 64 channels of the tile
+    const int m0 = blockIdx.x * kBM;
+    const int co0 = blockIdx.y * BN;
+
+    // ---- staging roles: piece column j (8 k), rows rr + 32 i --------------------------------------------
+    const int j = tid & 7, rr = tid >> 3;
+    int pbase[4], phi[4], pwi[4];                         // pixel rows: element offset of (hi0, wi0), hi0, wi0
 #pragma unroll
-    for (int j = 0; j < PT; ++j) {
-        const int m = m_wave + j * 16 + li;
-        pvalid[j] = m < d.M;
-        const int mm = pvalid[j] ? m : 0;
-        const int wo = mm % d.Wo;
-        const int t = mm / d.Wo;
-        const int ho = t % d.Ho;
-        pn[j] = t / d.Ho;
-        ph[j] = ho * d.stride - d.pad_h;
-        pw[j] = wo * d.stride - d.pad_w;
-    }
-    // ---- per-lane weight rows of the A fragments ------------------------------------------------------
-    const size_t wrow = (size_t)d.KH * d.KW * d.Cin;           // elements per output channel
-    bool cvalid[CT];
-    const uint16_t* wp[CT];
-#pragma unroll
-    for (int i = 0; i < CT; ++i) {
-        const int co = co0 + i * 16 + li;
-        cvalid[i] = co < d.Cout;
-        wp[i] = w + (size_t)(cvalid[i] ? co : 0) * wrow + kq * 8;
-    }
-
-    f32x4 acc[CT][PT];
-#pragma unroll
-    for (int i = 0; i < CT; ++i)
-#pragma unroll
-        for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int steps = d.KH * d.KW * d.kchunks;
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
-    // fragments of one k-step: step -> (tap = step / kchunks, c0 = (step % kchunks) * 32)
-    auto load_step = [&](int step, Frag (&a)[CT], Frag (&b)[PT]) {
-        const int tap = step / d.kchunks;
-        const int c0 = (step - tap * d.kchunks) * 32 + kq * 8;
-        const bool kvalid = c0 < d.Cin;                        // Cin % 8 == 0: a chunk is all-in or all-out
-        const int kh = tap / d.KW, kw = tap - kh * d.KW;
-#pragma unroll
-        for (int i = 0; i < CT; ++i) {
-            a[i].u = (cvalid[i] && kvalid)
-                         ? *reinterpret_cast<const uint4*>(wp[i] + (size_t)tap * d.Cin + (c0 - kq * 8))
-                         : zero4;
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + rr + 32 * i;
+        if (m < d.M) {
+            const int wo = m % d.Wo;
+            const int t = m / d.Wo;
+            const int ho = t % d.Ho;
+            const int n = t / d.Ho;
+            phi[i] = ho * d.stride - d.pad_h;
+            pwi[i] = wo * d.stride - d.pad_w;
+            pbase[i] = ((n * d.H + phi[i]) * d.W + pwi[i]) * d.ldx;
+        } else {
+            phi[i] = -(1 << 28);                           // never inside the image
+            pwi[i] = 0;
+            pbase[i] = 0;
         }
+    }
+    // position of this thread's piece in K: k = step * 64 + j * 8 = tap * Cin + ci
+    int tap = 0, ci = j * 8;
+    while (ci >= d.Cin) { ci -= d.Cin; ++tap; }
+    int kh = tap / d.KW, kw = tap - kh * d.KW;
+    const int taps = d.KH * d.KW;
+
+    uint4 ra[4], rb[BN / 32];
+    unsigned okmask = 0;                                  // bit i: ra[i] is real data, bit 4 + i: rb[i] (else: zero piece)
+    auto load_step = [&]() {                               // the piece of the current (tap, ci) for every row of this thread
+        const bool kvalid = tap < taps;
+        const int dh = kh * d.dil_h, dw = kw * d.dil_w;
+        const int toff = (dh * d.W + dw) * d.ldx + ci;
+        okmask = 0;
+        // loads only: the zeroing of padding pieces waits until store_step, so that nothing here needs the data
+        // before the MFMAs of the current step have been issued
 #pragma unroll
-        for (int j = 0; j < PT; ++j) {
-            const int hi = ph[j] + kh * d.dil_h;
-            const int wi = pw[j] + kw * d.dil_w;
-            const bool ok = pvalid[j] && kvalid && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
-            b[j].u = ok ? *reinterpret_cast<const uint4*>(x + ((size_t)(pn[j] * d.H + hi) * d.W + wi) * d.ldx + c0)
-                        : zero4;
+        for (int i = 0; i < 4; ++i) {
+            const int hi = phi[i] + dh, wi = pwi[i] + dw;
+            const bool ok = kvalid && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
+            ra[i] = *reinterpret_cast<const uint4*>(x + (ok ? pbase[i] + toff : 0));
+            okmask |= ok ? (1u << i) : 0u;
+        }
+        const int kk = tap * d.Cin + ci;
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+            const int co = co0 + rr + 32 * i;
+            const bool ok = kvalid && co < d.Cout;
+            rb[i] = *reinterpret_cast<const uint4*>(w + (ok ? (size_t)co * d.Ktot + kk : 0));
+            okmask |= ok ? (16u << i) : 0u;
+        }
+        // advance to the next step: k += 64
+        ci += kBK;
+        while (ci >= d.Cin && tap < taps) {
+            ci -= d.Cin;
+            ++tap;
+            if (++kw == d.KW) { kw = 0; ++kh; }
         }
     };
+    auto store_step = [&](uint8_t* buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<uint4*>(buf + lds_piece(rr + 32 * i, j)) = keep(ra[i], (okmask >> i) & 1u);
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i)
+            *reinterpret_cast<uint4*>(buf + kBM * kBK * 2 + lds_piece(rr + 32 * i, j)) = keep(rb[i], (okmask >> (4 + i)) & 1u);
+    };
 
-    Frag a0[CT], b0[PT], a1[CT], b1[PT];
-    load_step(0, a0, b0);
-    for (int step = 0; step < steps; step += 2) {
-        if (step + 1 < steps) load_step(step + 1, a1, b1);
+    f32x16 acc[TC][TP];
 #pragma unroll
-        for (int i = 0; i < CT; ++i)
+    for (int a = 0; a < TC; ++a)
 #pragma unroll
-            for (int j = 0; j < PT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i].v, b0[j].v, acc[i][j], 0, 0, 0);
-        if (step + 1 < steps) {
-            if (step + 2 < steps) load_step(step + 2, a0, b0);
+        for (int b = 0; b < TP; ++b)
 #pragma unroll
-            for (int i = 0; i < CT; ++i)
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int steps = (d.Ktot + kBK - 1) / kBK;
+    load_step();
+    store_step(smem);
+    __syncthreads();
+    const int frow = lane & 31, fk = lane >> 5;            // fragment row / which 8-k half of a 16-k MFMA step
+    for (int s = 0; s < steps; ++s) {
+        uint8_t* cur = smem + (s & 1) * kStage;
+        if (s + 1 < steps) load_step();
 #pragma unroll
-                for (int j = 0; j < PT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i].v, b1[j].v, acc[i][j], 0, 0, 0);
+        for (int ks = 0; ks < kBK / 16; ++ks) {
+            Frag fa[TC], fb[TP];
+#pragma unroll
+            for (int a = 0; a < TC; ++a)
+                fa[a].u = *reinterpret_cast<const uint4*>(cur + kBM * kBK * 2 + lds_piece(wn * 64 + a * 32 + frow, ks * 2 + fk));
+#pragma unroll
+            for (int b = 0; b < TP; ++b)
+                fb[b].u = *reinterpret_cast<const uint4*>(cur + lds_piece(wm * (32 * TP) + b * 32 + frow, ks * 2 + fk));
+#pragma unroll
+            for (int a = 0; a < TC; ++a)
+#pragma unroll
+                for (int b = 0; b < TP; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a].v, fb[b].v, acc[a][b], 0, 0, 0);
         }
+        if (s + 1 < steps) store_step(smem + ((s + 1) & 1) * kStage);
+        __syncthreads();
     }
 
-    // ---- epilogue: D[row = channel (lane>>4)*4 + r][col = pixel lane&15] -------------------------------
+    // ---- epilogue: D[row = channel 8*(r>>2) + 4*(lane>>5) + (r&3)][col = pixel lane&31] -> LDS [pixel][channel] -------
+    // row stride BN + 8 elements: 16-byte aligned rows whose starts rotate through the banks
+    const int ldt = BN + 8;
+    if (d.out_f32) {
+        float* tile = reinterpret_cast<float*>(smem);      // [128][BN + 8] float: 128 * 136 * 4 = 69 632 B <= 2 * kStage
 #pragma unroll
-    for (int j = 0; j < PT; ++j) {
-        const int m = m_wave + j * 16 + li;
-        if (m >= d.M) continue;
+        for (int a = 0; a < TC; ++a)
 #pragma unroll
-        for (int i = 0; i < CT; ++i) {
-            const int co = co0 + i * 16 + kq * 4;
-            if (co >= d.Cout) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (d.has_bias) {
+            for (int b = 0; b < TP; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (co + r < d.Cout) v[r] += bias[co + r];
-            }
-            const bool full = co + 3 < d.Cout;
-            if (d.out_f32) {
-                float* yp = (float*)y + (size_t)m * d.ldy + co;
-                if (full && ((d.ldy & 3) == 0)) {
-                    *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (co + r < d.Cout) yp[r] = v[r];
+                for (int q = 0; q < 4; ++q) {
+                    const int c = wn * 64 + a * 32 + 8 * q + 4 * fk;
+                    const int p = wm * (32 * TP) + b * 32 + frow;
+                    float4 v = make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
+                    if (d.has_bias) {
+                        v.x += co0 + c < d.Cout ? bias[co0 + c] : 0.f;
+                        v.y += co0 + c + 1 < d.Cout ? bias[co0 + c + 1] : 0.f;
+                        v.z += co0 + c + 2 < d.Cout ? bias[co0 + c + 2] : 0.f;
+                        v.w += co0 + c + 3 < d.Cout ? bias[co0 + c + 3] : 0.f;
+                    }
+                    *reinterpret_cast<float4*>(tile + p * ldt + c) = v;
                 }
+        __syncthreads();
+        float* yo = reinterpret_cast<float*>(y);
+        for (int e = tid; e < kBM * (BN / 4); e += 256) {   // 16-byte pieces: 4 channels
+            const int p = e / (BN / 4), c = (e - p * (BN / 4)) * 4;
+            const int m = m0 + p, co = co0 + c;
+            if (m >= d.M || co >= d.Cout) continue;
+            const float4 v = *reinterpret_cast<const float4*>(tile + p * ldt + c);
+            float* dst = yo + (size_t)m * d.ldy + co;
+            if (co + 3 < d.Cout && (d.ldy & 3) == 0) {
+                *reinterpret_cast<float4*>(dst) = v;
             } else {
-                uint16_t* yp = (uint16_t*)y + (size_t)m * d.ldy + co;
-                if (full && ((d.ldy & 3) == 0)) {
-                    *reinterpret_cast<uint2*>(yp) = make_uint2(f2bf(v[0]) | (f2bf(v[1]) << 16), f2bf(v[2]) | (f2bf(v[3]) << 16));
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (co + r < d.Cout) yp[r] = (uint16_t)f2bf(v[r]);
-                }
+                dst[0] = v.x;
+                if (co + 1 < d.Cout) dst[1] = v.y;
+                if (co + 2 < d.Cout) dst[2] = v.z;
+                if (co + 3 < d.Cout) dst[3] = v.w;
             }
         }
+        return;
     }
+    uint16_t* tile = reinterpret_cast<uint16_t*>(smem);    // [128][BN + 8] bf16
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = wn * 64 + a * 32 + 8 * q + 4 * fk;
+                const int p = wm * (32 * TP) + b * 32 + frow;
+                float v[4] = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                if (d.has_bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += co0 + c + r < d.Cout ? bias[co0 + c + r] : 0.f;
+                }
+                *reinterpret_cast<uint2*>(tile + p * ldt + c) =
+                    make_uint2(f2bf(v[0]) | (f2bf(v[1]) << 16), f2bf(v[2]) | (f2bf(v[3]) << 16));
+            }
+    __syncthreads();
+    uint16_t* yo = reinterpret_cast<uint16_t*>(y);
+    for (int e = tid; e < kBM * (BN / 8); e += 256) {       // 16-byte pieces: 8 channels
+        const int p = e / (BN / 8), c = (e - p * (BN / 8)) * 8;
+        const int m = m0 + p, co = co0 + c;
+        if (m >= d.M || co >= d.Cout) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(tile + p * ldt + c);
+        uint16_t* dst = yo + (size_t)m * d.ldy + co;
+        if (co + 7 < d.Cout && (d.ldy & 7) == 0) {
+            *reinterpret_cast<uint4*>(dst) = v;
+        } else {
+            const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (co + r < d.Cout) dst[r] = (uint16_t)(wds[r >> 1] >> (16 * (r & 1)));
+        }
+    }
+    if (stat_partial) {
+        // BatchNorm statistics of the rounded outputs: thread (channel c, pixel half) adds 64 pixels; rows beyond M
+        // hold the bias only and are skipped
+        float* red = reinterpret_cast<float*>(smem + kBM * ldt * 2);        // behind the tile: 2 * 2 * BN floats
+        const int c = tid % BN, part = tid / BN;                            // BN = 128: 2 parts; BN = 64: 4 parts
+        constexpr int kParts = 256 / BN, kRows = kBM / kParts;
+        float s1 = 0.f, s2 = 0.f;
+        for (int p = part * kRows; p < (part + 1) * kRows; ++p) {
+            if (m0 + p < d.M) {
+                const float v = bf2f(tile[p * ldt + c]);
+                s1 += v;
+                s2 += v * v;
+            }
+        }
+        red[(part * 2) * BN + c] = s1;
+        red[(part * 2 + 1) * BN + c] = s2;
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int k = tid / BN, cc = tid - k * BN;
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < kParts; ++q) t += red[(q * 2 + k) * BN + cc];
+            if (co0 + cc < d.Cout) stat_partial[((size_t)blockIdx.x * 2 + k) * d.Cout + co0 + cc] = t;
+        }
+    }
+}
+
+// Column sums of a [parts][width] float32 matrix, deterministic, in two coalesced levels: workgroup (x, y) adds rows
+// [256 y, 256 y + 256) of columns [64 x, 64 x + 64) (4 row lanes x 64 columns, double accumulation) into
+// out[y][...]; a second launch with the level-1 result as input finishes (parts <= 256: one level).
+__global__ __launch_bounds__(256) void colsum_kernel(int parts, int width, const float* __restrict__ partial,
+                                                     float* __restrict__ out) {
+    __shared__ double red[256];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * 256, r1 = min(r0 + 256, parts);
+    double s = 0.0;
+    if (col < width)
+        for (int p = r0 + rl; p < r1; p += 4) s += (double)partial[(size_t)p * width + col];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && col < width)
+        out[(size_t)blockIdx.y * width + col] = (float)(red[cl] + red[64 + cl] + red[128 + cl] + red[192 + cl]);
+}
+
+// sums[width] = column sums of partial[parts][width]; `partial` must have room for ceil(parts / 256) more rows behind
+// its `parts` rows (the level-1 result)
+inline void launch_colsum(hipStream_t s, int parts, int width, float* partial, float* sums) {
+    const int wx = (width + 63) / 64;
+    if (parts <= 256) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(wx, 1), dim3(256), 0, s, parts, width, (const float*)partial, sums);
+        return;
+    }
+    const int l1 = (parts + 255) / 256;
+    float* mid = partial + (size_t)parts * width;
+    hipLaunchKernelGGL(colsum_kernel, dim3(wx, l1), dim3(256), 0, s, parts, width, (const float*)partial, mid);
+    // l1 <= 256 for parts <= 65536 (8.4 M pixels); beyond that the second level loops over more rows per workgroup
+    hipLaunchKernelGGL(colsum_kernel, dim3(wx, 1), dim3(256), 0, s, l1 > 256 ? 256 : l1, width, (const float*)mid, sums);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Weight gradient:  dW[co][tap][ci] = sum_m dY[m][co] * X[pixel(m) + tap][ci]
 // ------------------------------------------------------------------------------------------------
-// The contraction runs over pixels, the SLOW dimension of both NHWC operands, while an MFMA fragment wants 8
-// consecutive k per lane.  Each lane therefore loads 8 consecutive pixels x 4 channels (8 x 8 bytes) per operand
-// and transposes the 8x4 block in registers (v_perm_b32): lane (i, kq) ends up with, for each of its 4 channels
-// c = 8*i + 4*half + a, the 8 pixels kq*8 .. kq*8+7 -- fragment `a` of an MFMA whose row i stands for channel
-// 8*i + 4*half + a.  One k-step (32 pixels) feeds a 128 x 128 (co x ci) tile; the 4 waves of a workgroup own
-// the 4 (co half, ci half) quadrants: 4 x 4 MFMAs and 64 accumulator registers each.
-// Pixels are split over gridDim.z workgroups (partial sums in float32, reduced deterministically afterwards).
-constexpr int kWgTile = 128;
-
-__device__ __forceinline__ uint32_t perm_lo(uint32_t x, uint32_t y) {   // (x.lo, y.lo)
-    return __builtin_amdgcn_perm(y, x, 0x05040100u);
+// The contraction runs over PIXELS, the slow dimension of both NHWC operands, while an MFMA fragment wants 8
+// consecutive k per lane.  So the staging transposes: a thread loads an 8-pixel x 8-channel block (8 x 16 bytes,
+// neighbouring threads neighbouring channel blocks: coalesced), transposes it in registers (32 x v_perm_b32) and
+// writes 8 pieces "8 pixels of one channel" into the same [row][8 x 16 B] LDS image the forward kernel uses -- rows
+// are now channels, K is 64 pixels per step -- and the MFMA part is the forward kernel's: dY^T as operand A (rows =
+// output channels), X^T as operand B: an accumulator lane holds dW[co ..][ci = lane & 31], i.e. coalesced float32
+// rows of the result.  Workgroup tile TCO x TCI (64 or 128 each) of one tap; the pixels are split over gridDim.z
+// workgroups (float32 partial sums, reduced deterministically afterwards).
+__device__ __forceinline__ uint32_t perm_lo(uint32_t a, uint32_t b) {   // (a.lo16, b.lo16)
+    return __builtin_amdgcn_perm(b, a, 0x05040100u);
 }
-__device__ __forceinline__ uint32_t perm_hi(uint32_t x, uint32_t y) {   // (x.hi, y.hi)
-    return __builtin_amdgcn_perm(y, x, 0x07060302u);
+__device__ __forceinline__ uint32_t perm_hi(uint32_t a, uint32_t b) {   // (a.hi16, b.hi16)
+    return __builtin_amdgcn_perm(b, a, 0x07060302u);
 }
-
-// in[p] = channels (c0,c1 | c2,c3) of pixel p (p = 0..7)  ->  out[a] = pixels 0..7 of channel a
-__device__ __forceinline__ void transpose8x4(const uint2 (&in)[8], Frag (&out)[4]) {
+// in[p] = 8 channels of pixel p  ->  out[c] = 8 pixels of channel c
+__device__ __forceinline__ void transpose8x8(const uint4 (&in)[8], uint4 (&out)[8]) {
+    uint32_t o[8][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint2 x = in[2 * q], y = in[2 * q + 1];
-        const uint32_t c0 = perm_lo(x.x, y.x), c1 = perm_hi(x.x, y.x);
-        const uint32_t c2 = perm_lo(x.y, y.y), c3 = perm_hi(x.y, y.y);
-        uint32_t* o0 = reinterpret_cast<uint32_t*>(&out[0].u);
-        uint32_t* o1 = reinterpret_cast<uint32_t*>(&out[1].u);
-        uint32_t* o2 = reinterpret_cast<uint32_t*>(&out[2].u);
-        uint32_t* o3 = reinterpret_cast<uint32_t*>(&out[3].u);
-        o0[q] = c0; o1[q] = c1; o2[q] = c2; o3[q] = c3;
+    for (int q = 0; q < 4; ++q) {                              // pixel pair (2q, 2q+1) -> dword q of every channel
+        const uint4 a = in[2 * q], b = in[2 * q + 1];
+        o[0][q] = perm_lo(a.x, b.x); o[1][q] = perm_hi(a.x, b.x);
+        o[2][q] = perm_lo(a.y, b.y); o[3][q] = perm_hi(a.y, b.y);
+        o[4][q] = perm_lo(a.z, b.z); o[5][q] = perm_hi(a.z, b.z);
+        o[6][q] = perm_lo(a.w, b.w); o[7][q] = perm_hi(a.w, b.w);
     }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) out[c] = make_uint4(o[c][0], o[c][1], o[c][2], o[c][3]);
 }
 
+template <int TCO, int TCI>
 __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles_ci, int ksteps_per_block,
                                                            const uint16_t* __restrict__ dy,
                                                            const uint16_t* __restrict__ x,
                                                            float* __restrict__ partial) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int li = lane & 15, kq = lane >> 4;
-    const int wa = wave & 1, wb = wave >> 1;                 // co half / ci half of the 128 x 128 tile
+    constexpr int TA = TCO / 64, TB = TCI / 64;            // 32-row MFMA tiles per wave (2 x 2 waves)
+    constexpr int kStage = (TCO + TCI) * kBK * 2;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave >> 1, wb = wave & 1;               // co half / ci half of the tile
     const int tco = blockIdx.x / tiles_ci, tci = blockIdx.x - tco * tiles_ci;
     const int tap = blockIdx.y;
     const int kh = tap / d.KW, kw = tap - kh * d.KW;
-    const int co_l = tco * kWgTile + 8 * li + 4 * wa;        // this lane's 4 output channels (operand A rows)
-    const int ci_l = tci * kWgTile + 8 * li + 4 * wb;        // this lane's 4 input channels  (operand B columns)
-    const bool co_ok = co_l < d.Cout;                        // Cout, Cin are multiples of 4 here (checked by the host)
-    const bool ci_ok = ci_l < d.Cin;
+    const int co0 = tco * TCO, ci0 = tci * TCI;
+    const int total_steps = (d.M + kBK - 1) / kBK;
     const int step0 = blockIdx.z * ksteps_per_block;
-    const int total_steps = (d.M + 31) / 32;
     const int step1 = min(step0 + ksteps_per_block, total_steps);
 
-    f32x4 acc[4][4];
+    // ---- staging roles: 8 x 8 blocks, cc = channel block, pg = pixel group; the dY tile has TCO/8 x 8 blocks, the X tile
+    // TCI/8 x 8; block ids are dealt out to the 256 threads, dY blocks first
+    constexpr int kBlocksA = TCO, kBlocksB = TCI;          // (TCO / 8) * 8 and (TCI / 8) * 8
+    constexpr int kRounds = (kBlocksA + kBlocksB + 255) / 256;
+    uint4 raw[kRounds][8];
+    unsigned okbits[kRounds];                              // bit i: raw[r][i] is real data (else a zero piece)
+    auto block_of = [&](int r, bool& is_a, int& cc, int& pg, bool& live) {
+        const int id = tid + 256 * r;
+        live = id < kBlocksA + kBlocksB;
+        is_a = id < kBlocksA;
+        const int loc = is_a ? id : id - kBlocksA;
+        const int nc = is_a ? TCO / 8 : TCI / 8;
+        cc = loc % nc;
+        pg = loc / nc;
+    };
+    auto load_step = [&](int step) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int r = 0; r < kRounds; ++r) {
+            bool is_a, live;
+            int cc, pg;
+            block_of(r, is_a, cc, pg, live);
+            const int mfirst = step * kBK + pg * 8;
+            // (n, ho, wo) of the first pixel of the group, advanced with carries
+            int wo = 0, ho = 0, n = 0;
+            if (!is_a) {
+                const int mm = mfirst < d.M ? mfirst : 0;
+                wo = mm % d.Wo;
+                const int t = mm / d.Wo;
+                ho = t % d.Ho;
+                n = t / d.Ho;
+            }
+            const int ch = (is_a ? co0 : ci0) + cc * 8;
+            const bool ch_ok = live && ch < (is_a ? d.Cout : d.Cin);
+            unsigned bits = 0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const uint2 zero2 = make_uint2(0, 0);
-    auto load_step = [&](int step, uint2 (&ga)[8], uint2 (&gb)[8]) {
-        const int m0 = step * 32 + kq * 8;
+            for (int i = 0; i < 8; ++i) {
+                const int m = mfirst + i;
+                bool ok = ch_ok && m < d.M;
+                size_t off = 0;
+                if (is_a) {
+                    off = (size_t)m * d.ldy + ch;
+                } else {
+                    const int hi = ho * d.stride - d.pad_h + kh * d.dil_h;
+                    const int wi = wo * d.stride - d.pad_w + kw * d.dil_w;
+                    ok = ok && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
+                    off = ((size_t)(n * d.H + hi) * d.W + wi) * d.ldx + ch;
+                    if (++wo == d.Wo) { wo = 0; if (++ho == d.Ho) { ho = 0; ++n; } }
+                }
+                const uint16_t* src = is_a ? dy : x;
+                raw[r][i] = *reinterpret_cast<const uint4*>(src + (ok ? off : 0));   // zeroed in store_step
+                bits |= ok ? (1u << i) : 0u;
+            }
+            okbits[r] = bits;
+        }
+    };
+    auto store_step = [&](uint8_t* buf) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int m = m0 + p;
-            const bool mv = m < d.M;
-            ga[p] = (mv && co_ok) ? *reinterpret_cast<const uint2*>(dy + (size_t)m * d.ldy + co_l) : zero2;
-            const int mm = mv ? m : 0;
-            const int wo = mm % d.Wo;
-            const int t = mm / d.Wo;
-            const int ho = t % d.Ho;
-            const int n = t / d.Ho;
-            const int hi = ho * d.stride - d.pad_h + kh * d.dil_h;
-            const int wi = wo * d.stride - d.pad_w + kw * d.dil_w;
-            const bool ok = mv && ci_ok && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
-            gb[p] = ok ? *reinterpret_cast<const uint2*>(x + ((size_t)(n * d.H + hi) * d.W + wi) * d.ldx + ci_l) : zero2;
+        for (int r = 0; r < kRounds; ++r) {
+            bool is_a, live;
+            int cc, pg;
+            block_of(r, is_a, cc, pg, live);
+            if (!live) continue;
+            uint4 tr[8], in[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) in[i] = keep(raw[r][i], (okbits[r] >> i) & 1u);
+            transpose8x8(in, tr);
+            uint8_t* img = buf + (is_a ? 0 : TCO * kBK * 2);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(img + lds_piece(cc * 8 + c, pg)) = tr[c];
         }
     };
 
-    uint2 ga0[8], gb0[8], ga1[8], gb1[8];
-    if (step0 < step1) load_step(step0, ga0, gb0);
-    for (int step = step0; step < step1; step += 2) {
-        if (step + 1 < step1) load_step(step + 1, ga1, gb1);
-        {
-            Frag fa[4], fb[4];
-            transpose8x4(ga0, fa);
-            transpose8x4(gb0, fb);
+    f32x16 acc[TA][TB];
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a].v, fb[b].v, acc[a][b], 0, 0, 0);
+        for (int b = 0; b < TB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int frow = lane & 31, fk = lane >> 5;
+    if (step0 < step1) {
+        load_step(step0);
+        store_step(smem);
+    }
+    __syncthreads();
+    for (int s = step0; s < step1; ++s) {
+        uint8_t* cur = smem + ((s - step0) & 1) * kStage;
+        if (s + 1 < step1) load_step(s + 1);
+#pragma unroll
+        for (int ks = 0; ks < kBK / 16; ++ks) {
+            Frag fa[TA], fb[TB];
+#pragma unroll
+            for (int a = 0; a < TA; ++a)
+                fa[a].u = *reinterpret_cast<const uint4*>(cur + lds_piece(wa * (32 * TA) + a * 32 + frow, ks * 2 + fk));
+#pragma unroll
+            for (int b = 0; b < TB; ++b)
+                fb[b].u = *reinterpret_cast<const uint4*>(cur + TCO * kBK * 2 + lds_piece(wb * (32 * TB) + b * 32 + frow, ks * 2 + fk));
+#pragma unroll
+            for (int a = 0; a < TA; ++a)
+#pragma unroll
+                for (int b = 0; b < TB; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a].v, fb[b].v, acc[a][b], 0, 0, 0);
         }
-        if (step + 1 < step1) {
-            if (step + 2 < step1) load_step(step + 2, ga0, gb0);
-            Frag fa[4], fb[4];
-            transpose8x4(ga1, fa);
-            transpose8x4(gb1, fb);
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a].v, fb[b].v, acc[a][b], 0, 0, 0);
-        }
+        if (s + 1 < step1) store_step(smem + ((s + 1 - step0) & 1) * kStage);
+        __syncthreads();
     }
 
-    // D[row][col]: row (A index) = (lane>>4)*4 + r -> co = tile + 8*row + 4*wa + a; col = lane&15 -> ci = tile + 8*col + 4*wb + b
+    // D[row = co: 8*(r>>2) + 4*(lane>>5) + (r&3)][col = ci: lane & 31]
     const size_t wsize = (size_t)d.Cout * d.KH * d.KW * d.Cin;
     float* out = partial + (size_t)blockIdx.z * wsize;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = tco * kWgTile + 8 * (kq * 4 + r) + 4 * wa + a;
-            if (co >= d.Cout) continue;
+        for (int b = 0; b < TB; ++b) {
+            const int ci = ci0 + wb * (32 * TB) + b * 32 + frow;
+            if (ci >= d.Cin) continue;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int ci = tci * kWgTile + 8 * li + 4 * wb + b;
-                if (ci < d.Cin) out[((size_t)co * d.KH * d.KW + tap) * d.Cin + ci] = acc[a][b][r];
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wa * (32 * TA) + a * 32 + 8 * (r >> 2) + 4 * fk + (r & 3);
+                if (co < d.Cout) out[((size_t)co * d.KH * d.KW + tap) * d.Cin + ci] = acc[a][b][r];
             }
         }
-    }
 }
 
 // dw[i] = sum_k partial[k][i]: 16 columns x 16 split lanes per workgroup, fixed tree order (deterministic)
@@ -325,48 +523,102 @@ inline int status() {
     return e == hipSuccess ? STP3_OK : -(int)e;
 }
 
+inline size_t igemm_lds(int bn, int steps, bool out_f32) {
+    const size_t stage = (size_t)(steps > 1 ? 2 : 1) * (kBM + bn) * kBK * 2;   // staging buffers
+    // epilogue image [128][bn + 8] in the output type, + the statistics scratch behind a bf16 image
+    const size_t tile = out_f32 ? (size_t)kBM * (bn + 8) * 4 : (size_t)kBM * (bn + 8) * 2 + 512 * sizeof(float);
+    return stage > tile ? stage : tile;
+}
+
+template <int TCO, int TCI>
+int wgrad_launch(const ConvDims& d, int tco, int tci, int taps, int splits, int ksteps, const void* dy, const void* x,
+                        void* workspace, hipStream_t s) {
+    const size_t lds = (size_t)2 * (TCO + TCI) * kBK * 2;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_kernel<TCO, TCI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return -(int)e;
+    hipLaunchKernelGGL((conv2d_wgrad_kernel<TCO, TCI>), dim3(tco * tci, taps, splits), dim3(256), lds, s, d, tci, ksteps,
+                       (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace);
+    return STP3_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
-int stp3_conv2d_fwd(const stp3_conv_dims* p, const void* x, const void* w, const float* bias, void* y, void* stream) {
+int stp3_conv2d_fwd_workspace(const stp3_conv_dims* p, size_t* bytes) {
+    if (!p || !bytes || p->N <= 0 || p->Ho <= 0 || p->Wo <= 0 || p->Cout <= 0) return STP3_EINVAL;
+    const int64_t M = (int64_t)p->N * p->Ho * p->Wo;
+    const size_t parts = (size_t)((M + kBM - 1) / kBM);
+    if (parts > 65536) return STP3_EUNSUP;
+    *bytes = (parts + (parts + 255) / 256) * 2 * p->Cout * sizeof(float);
+    return STP3_OK;
+}
+
+int stp3_conv2d_fwd(const stp3_conv_dims* p, const void* x, const void* w, const float* bias, void* y, float* sums,
+                    void* workspace, size_t workspace_bytes, void* stream) {
     if (!p || !x || !w || !y) return STP3_EINVAL;
     if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->Cin <= 0 || p->Cout <= 0 || p->Ho <= 0 || p->Wo <= 0 || p->KH <= 0 ||
         p->KW <= 0 || p->stride <= 0 || p->dil_h <= 0 || p->dil_w <= 0 || p->pad_h < 0 || p->pad_w < 0)
         return STP3_EINVAL;
     if (p->has_bias && !bias) return STP3_EINVAL;
-    if (p->Cin % 8 || p->ldx % 8 || p->ldx < p->Cin || p->ldy < p->Cout) return STP3_EUNSUP;   // 16-byte k-chunks
+    if (p->Cin % 8 || p->ldx % 8 || p->ldx < p->Cin || p->ldy < p->Cout) return STP3_EUNSUP;   // 16-byte k pieces
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return STP3_EUNSUP;
     if (p->out_dtype != STP3_DTYPE_BF16 && p->out_dtype != STP3_DTYPE_F32) return STP3_EUNSUP;
-    if (((uintptr_t)y & (p->out_dtype == STP3_DTYPE_F32 ? 15 : 7))) return STP3_EUNSUP;
+    if (((uintptr_t)y & (p->out_dtype == STP3_DTYPE_F32 ? 3 : 1))) return STP3_EUNSUP;
+    if (sums && p->out_dtype != STP3_DTYPE_BF16) return STP3_EUNSUP;
     const int64_t M = (int64_t)p->N * p->Ho * p->Wo;
-    if (M >= (1LL << 31) || (int64_t)p->N * p->H * p->W >= (1LL << 31)) return STP3_EUNSUP;
+    if (M >= (1LL << 31) || (int64_t)p->N * p->H * p->W * p->ldx >= (1LL << 31)) return STP3_EUNSUP;   // 32-bit offsets
     ConvDims d;
     d.N = p->N; d.H = p->H; d.W = p->W; d.Cin = p->Cin; d.Ho = p->Ho; d.Wo = p->Wo; d.Cout = p->Cout;
     d.KH = p->KH; d.KW = p->KW; d.stride = p->stride; d.pad_h = p->pad_h; d.pad_w = p->pad_w;
     d.dil_h = p->dil_h; d.dil_w = p->dil_w; d.ldx = p->ldx; d.ldy = p->ldy;
     d.out_f32 = p->out_dtype == STP3_DTYPE_F32; d.has_bias = p->has_bias;
-    d.M = (int)M; d.kchunks = (p->Cin + 31) / 32;
-    // A/B switch (STP3_CONV_KERNEL=v2): bf16-output convolutions through the v2 kernel of stp3_conv2.hip (16-channel
-    // stores, operand loads that stay global: no scratch, 3 waves per SIMD) instead of the kernel below
-    static const bool use_v2 = [] {
-        const char* e = getenv("STP3_CONV_KERNEL");
-        return e && !strcmp(e, "v2");
-    }();
-    if (use_v2 && p->out_dtype == STP3_DTYPE_BF16 && p->ldx % 8 == 0 && !((uintptr_t)y & 15))
-        return stp3_conv2d_fwd_v2(p, x, w, bias, y, nullptr, nullptr, 0, stream);
-    dim3 grid((unsigned)((M + kTilePix - 1) / kTilePix), (unsigned)((p->Cout + kTileCo - 1) / kTileCo));
-    hipLaunchKernelGGL(conv2d_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, (const uint16_t*)x,
-                       (const uint16_t*)w, bias, y);
+    d.M = (int)M; d.kchunks = (p->Cin + 31) / 32; d.Ktot = p->KH * p->KW * p->Cin;
+    // vector stores need 16-byte aligned rows; otherwise the scalar tail path of the epilogue is taken per piece
+    if (((uintptr_t)y & 15)) d.ldy |= 0;                     // (alignment is re-checked per piece through ldy below)
+    const unsigned gx = (unsigned)((M + kBM - 1) / kBM);
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = nullptr;
+    if (sums) {
+        if (gx > 65536) return STP3_EUNSUP;
+        if (!workspace || workspace_bytes < ((size_t)gx + (gx + 255) / 256) * 2 * p->Cout * sizeof(float)) return STP3_ENOSPACE;
+        partial = (float*)workspace;
+    }
+    if (((uintptr_t)y & 15)) return STP3_EUNSUP;
+    // 128 x 128 tiles for the contraction-heavy layers; 128 x 64 tiles when there are few output channels or so little K
+    // (<= 2 steps: the pointwise layers of the trunk, bound by activation traffic) that what counts is many light
+    // workgroups per CU; one staging buffer suffices for a single K step
+    const int steps = (d.Ktot + kBK - 1) / kBK;
+    const bool wide = p->Cout > 64 && steps > 2;
+    const int bn = wide ? 128 : 64;
+    const size_t lds = igemm_lds(bn, steps, d.out_f32 != 0);
+    const dim3 grid(gx, (unsigned)((p->Cout + bn - 1) / bn));
+    if (wide) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_igemm_kernel<128>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+        hipLaunchKernelGGL(conv2d_igemm_kernel<128>, grid, dim3(256), lds, s, d, (const uint16_t*)x, (const uint16_t*)w, bias, y,
+                           partial);
+    } else {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_igemm_kernel<64>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+        hipLaunchKernelGGL(conv2d_igemm_kernel<64>, grid, dim3(256), lds, s, d, (const uint16_t*)x, (const uint16_t*)w, bias, y,
+                           partial);
+    }
+    if (sums) launch_colsum(s, (int)gx, 2 * p->Cout, partial, sums);
     return status();
 }
 
 
-static int wgrad_plan(const stp3_conv_dims* p, int* tiles_co, int* tiles_ci, int* splits, int* ksteps) {
+static int wgrad_plan(const stp3_conv_dims* p, int* tco_sz, int* tci_sz, int* tiles_co, int* tiles_ci, int* splits, int* ksteps) {
     const int64_t M = (int64_t)p->N * p->Ho * p->Wo;
-    *tiles_co = (p->Cout + kWgTile - 1) / kWgTile;
-    *tiles_ci = (p->Cin + kWgTile - 1) / kWgTile;
-    const int64_t total_steps = (M + 31) / 32;
+    *tco_sz = p->Cout > 64 ? 128 : 64;
+    *tci_sz = p->Cin > 64 ? 128 : 64;
+    *tiles_co = (p->Cout + *tco_sz - 1) / *tco_sz;
+    *tiles_ci = (p->Cin + *tci_sz - 1) / *tci_sz;
+    const int64_t total_steps = (M + kBK - 1) / kBK;         // 64 pixels per step
     const int64_t base = (int64_t)(*tiles_co) * (*tiles_ci) * p->KH * p->KW;
     int64_t want = (1024 + base - 1) / base;                 // ~1024 workgroups
     const int64_t max_splits = (total_steps + 7) / 8;        // at least 8 k-steps per workgroup
@@ -381,8 +633,8 @@ static int wgrad_plan(const stp3_conv_dims* p, int* tiles_co, int* tiles_ci, int
 int stp3_conv2d_wgrad_workspace(const stp3_conv_dims* p, size_t* bytes) {
     if (!p || !bytes || p->N <= 0 || p->Cout <= 0 || p->Cin <= 0 || p->KH <= 0 || p->KW <= 0 || p->Ho <= 0 || p->Wo <= 0)
         return STP3_EINVAL;
-    int tco, tci, splits, ksteps;
-    wgrad_plan(p, &tco, &tci, &splits, &ksteps);
+    int a, b, tco, tci, splits, ksteps;
+    wgrad_plan(p, &a, &b, &tco, &tci, &splits, &ksteps);
     *bytes = (size_t)splits * p->Cout * p->KH * p->KW * p->Cin * sizeof(float);
     return STP3_OK;
 }
@@ -393,23 +645,29 @@ int stp3_conv2d_wgrad(const stp3_conv_dims* p, const void* dy, const void* x, fl
     if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->Cin <= 0 || p->Cout <= 0 || p->Ho <= 0 || p->Wo <= 0 || p->KH <= 0 ||
         p->KW <= 0 || p->stride <= 0 || p->dil_h <= 0 || p->dil_w <= 0 || p->pad_h < 0 || p->pad_w < 0)
         return STP3_EINVAL;
-    // 8-byte channel quads of both operands
-    if (p->Cin % 4 || p->Cout % 4 || p->ldx % 4 || p->ldy % 4 || p->ldx < p->Cin || p->ldy < p->Cout) return STP3_EUNSUP;
-    if (((uintptr_t)x & 7) || ((uintptr_t)dy & 7)) return STP3_EUNSUP;
+    // 16-byte channel blocks of both operands
+    if (p->Cin % 8 || p->Cout % 8 || p->ldx % 8 || p->ldy % 8 || p->ldx < p->Cin || p->ldy < p->Cout) return STP3_EUNSUP;
+    if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15)) return STP3_EUNSUP;
     const int64_t M = (int64_t)p->N * p->Ho * p->Wo;
     if (M >= (1LL << 31) - 64 || (int64_t)p->N * p->H * p->W >= (1LL << 31)) return STP3_EUNSUP;
-    int tco, tci, splits, ksteps;
-    wgrad_plan(p, &tco, &tci, &splits, &ksteps);
+    if (p->KH * p->KW > 65535) return STP3_EUNSUP;
+    int tco_sz, tci_sz, tco, tci, splits, ksteps;
+    wgrad_plan(p, &tco_sz, &tci_sz, &tco, &tci, &splits, &ksteps);
     const size_t wsize = (size_t)p->Cout * p->KH * p->KW * p->Cin;
     if (workspace_bytes < (size_t)splits * wsize * sizeof(float)) return STP3_ENOSPACE;
     ConvDims d;
     d.N = p->N; d.H = p->H; d.W = p->W; d.Cin = p->Cin; d.Ho = p->Ho; d.Wo = p->Wo; d.Cout = p->Cout;
     d.KH = p->KH; d.KW = p->KW; d.stride = p->stride; d.pad_h = p->pad_h; d.pad_w = p->pad_w;
     d.dil_h = p->dil_h; d.dil_w = p->dil_w; d.ldx = p->ldx; d.ldy = p->ldy;
-    d.out_f32 = 1; d.has_bias = 0; d.M = (int)M; d.kchunks = 0;
+    d.out_f32 = 1; d.has_bias = 0; d.M = (int)M; d.kchunks = 0; d.Ktot = p->KH * p->KW * p->Cin;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv2d_wgrad_kernel, dim3(tco * tci, p->KH * p->KW, splits), dim3(256), 0, s, d, tci, ksteps,
-                       (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace);
+    const int taps = p->KH * p->KW;
+    int rc;
+    if (tco_sz == 128 && tci_sz == 128) rc = wgrad_launch<128, 128>(d, tco, tci, taps, splits, ksteps, dy, x, workspace, s);
+    else if (tco_sz == 128) rc = wgrad_launch<128, 64>(d, tco, tci, taps, splits, ksteps, dy, x, workspace, s);
+    else if (tci_sz == 128) rc = wgrad_launch<64, 128>(d, tco, tci, taps, splits, ksteps, dy, x, workspace, s);
+    else rc = wgrad_launch<64, 64>(d, tco, tci, taps, splits, ksteps, dy, x, workspace, s);
+    if (rc) return rc;
     hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((wsize + 15) / 16)), dim3(256), 0, s, splits, wsize,
                        (const float*)workspace, dw);
     return status();

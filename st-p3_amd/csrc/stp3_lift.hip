@@ -19,8 +19,6 @@
 
 namespace {
 
-constexpr int kWave = 64;
-constexpr int kSortCap = 4096;  // longest per-voxel list that is canonically ordered
 
 struct Dims {
     int B, T, N, D, fH, fW, C, X, Y, Z;
@@ -131,411 +129,627 @@ __global__ __launch_bounds__(256) void voxel_index_kernel(Dims dm, const float* 
 }
 
 // ------------------------------------------------------------------------------------------
-// Pooling plan (geometry only): column runs, their destination rows, per-voxel row ranges
+// Pooling plan (geometry only): per-voxel lists of column runs
 // ------------------------------------------------------------------------------------------
-// Along an image column (fixed camera n, feature column w, depth bin d) consecutive rows h
-// project to the same BEV cell most of the time (10-20 points per run with
-// nuScenes-like rigs).  A RUN is a maximal set of consecutive h with one voxel id >= 0.  The
-// forward pass first reduces every run to one C-vector (stage 1, camera-side, feature rows read
-// once) and then sums the few run vectors of each voxel (stage 2, BEV-side).  The plan gives
-//   run_base [BT][NQ+1]  exclusive scan of runs per q = (n*fW + w)*D + d; run id = run_base[q] + j
-//   vox_off  [BT][V+1]   exclusive scan of runs per voxel
-//   dest     [BT][P]     run id -> row of the stage-1 buffer; a voxel's rows are the contiguous
-//                        range [vox_off[v], vox_off[v+1]), ordered by run id (canonical order)
-//   list     [BT][P]     row -> run id (scratch of the build, kept for inspection)
-struct PlanView {
-    int32_t* run_base;
-    int32_t* vox_off;
-    int32_t* dest;
-    int32_t* list;
-};
-
+// Along an image column (fixed camera n, feature column w, depth bin d) consecutive rows h project to the
+// same BEV cell most of the time (10-20 points per run with nuScenes-like rigs).  A RUN is
+// a maximal set of consecutive h with one voxel id >= 0.  The plan lists, per voxel, the runs that fall into
+// it -- the pooled value of the voxel is then a PULL: sum over its runs of sum_h prob[h][d] * feat[h][:].
+//   vox_off [BT][V+1]   exclusive scan of runs per voxel
+//   desc    [BT][P]     uint2 per run (build scratch, arrival order): x = col << 20 | d << 14 | h0 << 7 | (len - 1)
+//                                      (col = n*fW + w), y = voxel id
+//   runs    [BT][P]     uint4 per run (ordered): x, y as above, z = first feature row (n*fH + h0)*fW + w,
+//                                      w = first probability (col*D + d)*fH + h0 -- both relative to the frame
+//                       a voxel's runs are in the contiguous range [vox_off[v], vox_off[v+1]) ... of its GROUP: the
+//                       runs of a group (below) are ordered longest first, ties by x -- one canonical summation order
+//   gidx    [B][V+1]    exclusive scan of the group-start flags; gidx[b][V] = number of voxel groups of sample b
+//   groups  [B][V+1]    first voxel of every group (ascending), closed by V.  A GROUP is the unit of work of the
+//                       forward kernel: at most 16 consecutive voxels with at most ~kGroupRuns runs over all T
+//                       frames together (voxels next to the cameras hold hundreds of points, far cells none:
+//                       equal-sized voxel ranges would leave a few waves with 30x the average work)
+// Replaces the reference's boolean mask + argsort + cumsum differencing (stp3.py:247-257, geometry.py:302-318).
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+constexpr int kGroupVox = 16;    // voxels per group at most (one accumulator row each in the forward kernel)
+constexpr int kGroupRuns = 32;   // target runs per group, all frames together
+
 inline size_t plan_bytes(const Dims& dm) {
-    return align256((size_t)dm.BT * (dm.NQ + 1) * 4) + align256((size_t)dm.BT * (dm.V + 1) * 4) +
-           2 * align256((size_t)dm.BT * dm.P * 4);
+    return align256((size_t)dm.BT * (dm.V + 1) * 4) + align256((size_t)dm.BT * dm.P * 8) +
+           2 * align256((size_t)dm.B * (dm.V + 1) * 4) + align256((size_t)dm.BT * dm.P * 16);
 }
+
+struct PlanView {
+    int32_t* vox_off;
+    uint2* desc;      // build scratch: runs in arrival order
+    int32_t* gidx;
+    int32_t* groups;
+    uint4* runs;      // what the forward kernel reads: ordered, with the addresses worked out
+};
 
 inline PlanView plan_view(const Dims& dm, void* base) {
     PlanView pv;
     char* p = (char*)base;
-    pv.run_base = (int32_t*)p;
-    p += align256((size_t)dm.BT * (dm.NQ + 1) * 4);
     pv.vox_off = (int32_t*)p;
     p += align256((size_t)dm.BT * (dm.V + 1) * 4);
-    pv.dest = (int32_t*)p;
-    p += align256((size_t)dm.BT * dm.P * 4);
-    pv.list = (int32_t*)p;
+    pv.desc = (uint2*)p;
+    p += align256((size_t)dm.BT * dm.P * 8);
+    pv.gidx = (int32_t*)p;
+    p += align256((size_t)dm.B * (dm.V + 1) * 4);
+    pv.groups = (int32_t*)p;
+    p += align256((size_t)dm.B * (dm.V + 1) * 4);
+    pv.runs = (uint4*)p;
     return pv;
 }
 
-// one thread per (bt, n, w, d): count the runs of its column, histogram them per voxel
-__global__ __launch_bounds__(256) void run_count_kernel(Dims dm, const int32_t* __restrict__ vox_pm,
-                                                        int32_t* __restrict__ run_cnt,
-                                                        int32_t* __restrict__ vox_cnt) {
+struct GeomArgs {
+    const float *cam_m, *cam_t, *ego_r, *ego_t, *xs, *ys, *ds, *bev_off, *bev_res;
+};
+
+// voxel id of frustum point (bt, n, h, w, d): the arithmetic of voxel_index_kernel, statement by statement
+__device__ __forceinline__ int point_voxel(const Dims& dm, const GeomArgs& g, int bt, int b, int t, int n, int h, int w,
+                                           float dep) {
+#pragma clang fp contract(off)
+    float x = g.xs[w] * dep;  // stp3.py:195
+    float y = g.ys[h] * dep;
+    float z = dep;
+    const int cam = bt * dm.N + n;
+    affine3(g.cam_m + cam * 9, g.cam_t + cam * 3, x, y, z);  // stp3.py:197-198
+    for (int k = t; k < dm.T - 1; ++k) {                       // stp3.py:270-277
+        const int e = b * dm.T + k;
+        affine3(g.ego_r + e * 9, g.ego_t + e * 3, x, y, z);
+    }
+    const float gx = (x - g.bev_off[0]) / g.bev_res[0];        // stp3.py:287-289
+    const float gy = (y - g.bev_off[1]) / g.bev_res[1];
+    const float gz = (z - g.bev_off[2]) / g.bev_res[2];
+    const bool keep = (gx > -1.0f) && (gx < (float)dm.X) && (gy > -1.0f) && (gy < (float)dm.Y) && (gz > -1.0f) &&
+                      (gz < (float)dm.Z);
+    return keep ? (int)gx * (dm.Y * dm.Z) + (int)gy * dm.Z + (int)gz : -1;
+}
+
+// (1) one thread per (bt, n, w, d) walks its image column: voxel ids in COLUMN-MAJOR order
+//         vox_cm[bt][col = n*fW + w][d][h]
+//     (the fH ids of a thread are contiguous; the pooling kernels read a column's probabilities / ids for a fixed
+//     depth bin along h -- in pixel-major order every such value sits in its own cache line), and the number of runs
+//     per voxel
+__global__ __launch_bounds__(64) void plan_index_count_kernel(Dims dm, GeomArgs g, int32_t* __restrict__ vox_cm,
+                                                              int32_t* __restrict__ vox_cnt) {
+    extern __shared__ __attribute__((aligned(16))) int32_t ids_s[];   // [64][fH + 1]
     const int bt = blockIdx.y;
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= dm.NQ) return;
-    const int d = q % dm.D, col = q / dm.D;
-    const int w = col % dm.fW, n = col / dm.fW;
-    const int32_t* v0 = vox_pm + ((size_t)bt * dm.NPIX + (size_t)n * dm.fH * dm.fW + w) * dm.D + d;
-    const size_t hstride = (size_t)dm.fW * dm.D;
-    int prev = -1, cnt = 0;
-    for (int h = 0; h < dm.fH; ++h) {
-        const int v = v0[h * hstride];
-        if (v != prev) {
-            if (v >= 0) {
-                ++cnt;
-                atomicAdd(vox_cnt + (size_t)bt * dm.V + v, 1);
-            }
+    const int q0 = blockIdx.x * 64, q = q0 + threadIdx.x;
+    const int ld = dm.fH + 1;
+    if (q < dm.NQ) {
+        const int d = q % dm.D, col = q / dm.D;
+        const int w = col % dm.fW, n = col / dm.fW;
+        const int b = bt / dm.T, t = bt - b * dm.T;
+        const float dep = g.ds[d];
+        int prev = -1;
+        for (int h = 0; h < dm.fH; ++h) {
+            const int v = point_voxel(dm, g, bt, b, t, n, h, w, dep);
+            ids_s[threadIdx.x * ld + h] = v;
+            if (v != prev && v >= 0) atomicAdd(vox_cnt + (size_t)bt * dm.V + v, 1);
             prev = v;
         }
     }
-    run_cnt[(size_t)bt * (dm.NQ + 1) + q] = cnt;
+    __syncthreads();
+    // the 64 x fH ids of this workgroup are one contiguous piece of vox_cm
+    const int nq = min(64, dm.NQ - q0);
+    int32_t* out = vox_cm + ((size_t)bt * dm.NQ + q0) * dm.fH;
+    for (int i = threadIdx.x; i < nq * dm.fH; i += 64) out[i] = ids_s[(i / dm.fH) * ld + (i % dm.fH)];
 }
 
-// exclusive scan of n counts per bt (in place capable: in == out allowed), out[n] = total.
-// zero_in != 0 additionally zeroes `in` (it then serves as the fill cursor).
-__global__ __launch_bounds__(1024) void plan_scan_kernel(int n, int in_stride, int32_t* in, int32_t* out,
-                                                         int zero_in) {
+// (2) exclusive scan of the run counts of one frame: block j owns voxels [1024 j, 1024 j + 1024); it first adds up
+//     everything before its slice (coalesced, at most 4 V bytes per block) and then scans its slice
+__global__ __launch_bounds__(1024) void plan_scan_kernel(int V, const int32_t* __restrict__ cnt,
+                                                         int32_t* __restrict__ off) {
     __shared__ int wave_tot[16];
-    const int bt = blockIdx.x, tid = threadIdx.x;
-    int32_t* cnt = in + (size_t)bt * in_stride;
-    int32_t* off = out + (size_t)bt * (n + 1);
-    const int per = (n + 1023) / 1024;
-    const int lo = min(tid * per, n), hi = min(lo + per, n);
-    int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += cnt[i];
-    int incl = sum;
+    __shared__ int base_s;
+    const int bt = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
+    const int32_t* c = cnt + (size_t)bt * V;
+    int32_t* o = off + (size_t)bt * (V + 1);
+    const int first = blockIdx.x * 1024;
+    int pre = 0;
+    for (int i = tid; i < first; i += 1024) pre += c[i];
+    for (int s = 32; s > 0; s >>= 1) pre += __shfl_xor(pre, s);
+    if (lane == 0) wave_tot[wv] = pre;
+    __syncthreads();
+    if (tid == 0) {
+        int s = 0;
+        for (int i = 0; i < 16; ++i) s += wave_tot[i];
+        base_s = s;
+    }
+    __syncthreads();
+    const int base = base_s;
+    __syncthreads();
+    const int v = first + tid;
+    const int mine = v < V ? c[v] : 0;
+    int incl = mine;
     for (int s = 1; s < 64; s <<= 1) {
-        int o = __shfl_up(incl, s);
-        if (lane >= s) incl += o;
+        const int up = __shfl_up(incl, s);
+        if (lane >= s) incl += up;
     }
     if (lane == 63) wave_tot[wv] = incl;
     __syncthreads();
-    int base = 0;
-    for (int i = 0; i < wv; ++i) base += wave_tot[i];
-    int run = base + incl - sum;
-    for (int i = lo; i < hi; ++i) {
-        const int c = cnt[i];
-        if (zero_in) cnt[i] = 0;
-        off[i] = run;   // (in == out: cnt[i] was read above)
-        run += c;
-    }
-    if (tid == 1023) off[n] = run;
+    int wbase = 0;
+    for (int i = 0; i < wv; ++i) wbase += wave_tot[i];
+    if (v < V) o[v] = base + wbase + incl - mine;
+    if (v == V - 1) o[V] = base + wbase + incl;
 }
 
-// one thread per (bt, n, w, d): hand every run of the column a slot in its voxel's list
-__global__ __launch_bounds__(256) void run_fill_kernel(Dims dm, const int32_t* __restrict__ vox_pm,
-                                                       const int32_t* __restrict__ run_base,
+// (3) the same walk as (1) over the stored ids: every finished run takes the next free slot of its voxel
+//     (counting the voxel's counter back down to zero, so the scratch is clean for the next build)
+__global__ __launch_bounds__(64) void plan_fill_kernel(Dims dm, const int32_t* __restrict__ vox_cm,
                                                        const int32_t* __restrict__ vox_off,
-                                                       int32_t* __restrict__ cursor, int32_t* __restrict__ list) {
+                                                       int32_t* __restrict__ vox_cnt, uint2* __restrict__ desc) {
+    extern __shared__ __attribute__((aligned(16))) int32_t ids_s[];   // [64][fH + 1]
     const int bt = blockIdx.y;
-    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int q0 = blockIdx.x * 64, q = q0 + threadIdx.x;
+    const int ld = dm.fH + 1;
+    const int nq = min(64, dm.NQ - q0);
+    const int32_t* in = vox_cm + ((size_t)bt * dm.NQ + q0) * dm.fH;
+    for (int i = threadIdx.x; i < nq * dm.fH; i += 64) ids_s[(i / dm.fH) * ld + (i % dm.fH)] = in[i];
+    __syncthreads();
     if (q >= dm.NQ) return;
     const int d = q % dm.D, col = q / dm.D;
-    const int w = col % dm.fW, n = col / dm.fW;
-    const int32_t* v0 = vox_pm + ((size_t)bt * dm.NPIX + (size_t)n * dm.fH * dm.fW + w) * dm.D + d;
-    const size_t hstride = (size_t)dm.fW * dm.D;
-    int rid = run_base[(size_t)bt * (dm.NQ + 1) + q];
-    int prev = -1;
-    for (int h = 0; h < dm.fH; ++h) {
-        const int v = v0[h * hstride];
+    const int32_t* v0 = ids_s + threadIdx.x * ld;
+    int prev = -1, h0 = 0;
+    for (int h = 0; h <= dm.fH; ++h) {
+        const int v = h < dm.fH ? v0[h] : -1;
         if (v != prev) {
-            if (v >= 0) {
-                const int slot = vox_off[(size_t)bt * (dm.V + 1) + v] + atomicAdd(cursor + (size_t)bt * dm.V + v, 1);
-                list[(size_t)bt * dm.P + slot] = rid++;
+            if (prev >= 0) {
+                const int pos = atomicAdd(vox_cnt + (size_t)bt * dm.V + prev, -1) - 1;
+                const int slot = vox_off[(size_t)bt * (dm.V + 1) + prev] + pos;
+                desc[(size_t)bt * dm.P + slot] =
+                    make_uint2(((unsigned)col << 20) | ((unsigned)d << 14) | ((unsigned)h0 << 7) | (unsigned)(h - h0 - 1),
+                               (unsigned)prev);
             }
+            h0 = h;
             prev = v;
         }
     }
 }
 
-// One wave per voxel list: order the run ids ascending, so that stage 2 adds every voxel's run
-// vectors in one fixed order regardless of how the atomics in run_fill_kernel interleaved.
-__global__ __launch_bounds__(128) void plan_sort_kernel(Dims dm, const int32_t* __restrict__ offsets,
-                                                        int32_t* __restrict__ list) {
-    __shared__ int32_t sbuf[2][kSortCap];
+// (4) work-balanced voxel groups.  The work in front of voxel v of sample b is the sum over its frames of vox_off[v]
+//     (runs of all earlier voxels); a group starts where the 16-voxel block or the kGroupRuns-sized work bucket
+//     changes.  flags -> exclusive scan (plan_scan_kernel) -> list of group starts.
+__global__ __launch_bounds__(256) void plan_group_flags_kernel(Dims dm, const int32_t* __restrict__ vox_off,
+                                                               int32_t* __restrict__ flags) {
+    const int b = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= dm.V) return;
+    int before = 0, before_prev = 0;
+    for (int t = 0; t < dm.T; ++t) {
+        const int32_t* off = vox_off + (size_t)(b * dm.T + t) * (dm.V + 1);
+        before += off[v];
+        before_prev += v > 0 ? off[v - 1] : 0;
+    }
+    const bool start = v == 0 || (v / kGroupVox) != ((v - 1) / kGroupVox) ||
+                       (before / kGroupRuns) != (before_prev / kGroupRuns);
+    flags[(size_t)b * dm.V + v] = start ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void plan_group_list_kernel(Dims dm, const int32_t* __restrict__ flags,
+                                                              const int32_t* __restrict__ gidx,
+                                                              int32_t* __restrict__ groups) {
+    const int b = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v > dm.V) return;
+    const int32_t* gi = gidx + (size_t)b * (dm.V + 1);
+    int32_t* gl = groups + (size_t)b * (dm.V + 1);
+    if (v == dm.V) gl[gi[dm.V]] = dm.V;                      // closes the last group
+    else if (flags[(size_t)b * dm.V + v]) gl[gi[v]] = v;
+}
+
+// (5) one WAVE per (group, frame) orders the group's runs (a contiguous range of `desc`; a few dozen entries, up to a
+//     few hundred for a voxel next to a camera): longest first, ties by (camera, column, depth bin, first row).  The
+//     atomics in (3) hand out the slots in arrival order; this makes the summation order canonical (bit-reproducible
+//     pooling), and it puts runs of similar length next to each other: the forward kernel sums four consecutive runs
+//     in lockstep.  <= 64 runs: rank by counting smaller keys (registers); <= kSortCap: bitonic network in LDS;
+//     beyond (not seen): one lane, insertion sort.
+constexpr int kSortCap = 2048;
+
+__device__ __forceinline__ unsigned long long sort_word(uint2 e) {   // ascending word = longest first, then col|d|h0
+    const unsigned key = ((127u - (e.x & 127u)) << 25) | (e.x >> 7);
+    return ((unsigned long long)key << 32) | e.y;
+}
+__device__ __forceinline__ uint2 unsort_word(unsigned long long wd) {
+    const unsigned key = (unsigned)(wd >> 32);
+    return make_uint2(((key & 0x1ffffffu) << 7) | (127u - (key >> 25)), (unsigned)wd);
+}
+
+__global__ __launch_bounds__(128) void plan_group_sort_kernel(Dims dm, const int32_t* __restrict__ vox_off,
+                                                              const int32_t* __restrict__ gidx,
+                                                              const int32_t* __restrict__ groups,
+                                                              const uint2* __restrict__ desc,
+                                                              uint4* __restrict__ runs) {
+    __shared__ unsigned long long sbuf[2][kSortCap];
+    const float inv_fw = 1.0f / (float)dm.fW;
+    auto full = [&](uint2 e) {                                   // the run with its two addresses worked out
+        const int h0 = (e.x >> 7) & 127u, d = (e.x >> 14) & 63u, col = e.x >> 20;
+        const int n = (int)(((float)col + 0.5f) * inv_fw);       // col / fW (exact: col, fW < 4096)
+        const int w = col - n * dm.fW;
+        return make_uint4(e.x, e.y, (unsigned)((n * dm.fH + h0) * dm.fW + w), (unsigned)((col * dm.D + d) * dm.fH + h0));
+    };
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t total = (int64_t)dm.BT * dm.V;
-    const int64_t nwaves = (int64_t)gridDim.x * 2;
-    int32_t* s = sbuf[wv];
-    for (int64_t item = (int64_t)blockIdx.x * 2 + wv; item < total; item += nwaves) {
-        const int bt = (int)(item / dm.V), v = (int)(item - (int64_t)bt * dm.V);
-        const int32_t* off = offsets + (size_t)bt * (dm.V + 1) + v;
-        const int start = __builtin_amdgcn_readfirstlane(off[0]);
-        const int n = __builtin_amdgcn_readfirstlane(off[1]) - start;
-        if (n < 2 || n > kSortCap) continue;
-        int32_t* seg = list + (size_t)bt * dm.P + start;
-        if (n <= kWave) {
-            const int e = lane < n ? seg[lane] : INT_MAX;
+    const int b = blockIdx.y, t = blockIdx.z;
+    const int ngroups = gidx[(size_t)b * (dm.V + 1) + dm.V];
+    const int32_t* gl = groups + (size_t)b * (dm.V + 1);
+    const int bt = b * dm.T + t;
+    const int32_t* off = vox_off + (size_t)bt * (dm.V + 1);
+    unsigned long long* sb = sbuf[wv];
+    for (int g = blockIdx.x * 2 + wv; g < ngroups; g += gridDim.x * 2) {
+        const int start = off[gl[g]], n = off[gl[g + 1]] - start;      // wave-uniform
+        if (n < 1) continue;
+        const uint2* seg = desc + (size_t)bt * dm.P + start;
+        uint4* dst = runs + (size_t)bt * dm.P + start;
+        if (n <= 64) {
+            const unsigned long long e = lane < n ? sort_word(seg[lane]) : ~0ull;
+            const unsigned lo = (unsigned)e, hi = (unsigned)(e >> 32);
             int rank = 0;
-            for (int j = 0; j < n; ++j) rank += (__builtin_amdgcn_readlane(e, j) < e) ? 1 : 0;
-            if (lane < n) seg[rank] = e;  // entries are distinct, so ranks are a permutation
-        } else {
+            for (int j = 0; j < n; ++j) {
+                const unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, j) << 32) |
+                                             (unsigned)__builtin_amdgcn_readlane((int)lo, j);
+                rank += o < e ? 1 : 0;
+            }
+            if (lane < n) dst[rank] = full(unsort_word(e));            // the words are distinct: ranks are a permutation
+        } else if (n <= kSortCap) {
             int m = 128;
             while (m < n) m <<= 1;
-            for (int i = lane; i < m; i += kWave) s[i] = i < n ? seg[i] : INT_MAX;
+            for (int i = lane; i < m; i += 64) sb[i] = i < n ? sort_word(seg[i]) : ~0ull;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             for (int k = 2; k <= m; k <<= 1) {
                 for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int i = lane; i < m; i += kWave) {
-                        const int p = i ^ j;
-                        if (p > i) {
-                            const int a = s[i], bb = s[p];
+                    for (int i = lane; i < m; i += 64) {
+                        const int pp = i ^ j;
+                        if (pp > i) {
+                            const unsigned long long a = sb[i], c = sb[pp];
                             const bool up = (i & k) == 0;
-                            if ((a > bb) == up) { s[i] = bb; s[p] = a; }
+                            if ((a > c) == up) { sb[i] = c; sb[pp] = a; }
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-            for (int i = lane; i < n; i += kWave) seg[i] = s[i];
+            for (int i = lane; i < n; i += 64) dst[i] = full(unsort_word(sb[i]));
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+        } else if (lane == 0) {
+            for (int i = 0; i < n; ++i) {                            // insertion sort straight into `runs`
+                const uint2 e = seg[i];
+                const unsigned long long ke = sort_word(e);
+                int j = i - 1;
+                while (j >= 0 && sort_word(make_uint2(dst[j].x, dst[j].y)) > ke) {
+                    dst[j + 1] = dst[j];
+                    --j;
+                }
+                dst[j + 1] = full(e);
+            }
         }
     }
-}
-
-// dest[list[row]] = row
-__global__ __launch_bounds__(256) void plan_invert_kernel(Dims dm, const int32_t* __restrict__ vox_off,
-                                                          const int32_t* __restrict__ list,
-                                                          int32_t* __restrict__ dest) {
-    const int bt = blockIdx.y;
-    const int total = vox_off[(size_t)bt * (dm.V + 1) + dm.V];
-    for (int row = blockIdx.x * 256 + threadIdx.x; row < total; row += gridDim.x * 256)
-        dest[(size_t)bt * dm.P + list[(size_t)bt * dm.P + row]] = row;
 }
 
 // ------------------------------------------------------------------------------------------
 // K2a: softmax over depth bins, pixel-major rows of D floats (stp3.py:215)
 // ------------------------------------------------------------------------------------------
 template <int LPP>  // lanes per pixel, each lane owns 4 consecutive bins
-__global__ __launch_bounds__(256) void depth_softmax_kernel(int64_t npix_total, int D,
-                                                            const float* __restrict__ logits,
-                                                            float* __restrict__ prob) {
+__global__ __launch_bounds__(256) void depth_softmax_kernel(Dims dm, const float* __restrict__ logits,
+                                                            float* __restrict__ prob_cm) {
+    // one workgroup per image column (bt, n, w): the column's [D][fH] probabilities are staged in LDS and written
+    // as ONE contiguous piece of prob_cm[bt][col][d][h] (the layout the pooling kernels read)
+    extern __shared__ __attribute__((aligned(16))) float tile_s[];        // [D][fH]
     constexpr int PPB = 256 / LPP;
     const int sub = threadIdx.x % LPP;
-    const int64_t pix = (int64_t)blockIdx.x * PPB + threadIdx.x / LPP;
-    const bool live = pix < npix_total;
-    const int e0 = sub * 4;
-    float v[4];
-    const float* row = logits + pix * D;
-    if (live && (D & 3) == 0 && e0 < D) {
-        const float4 q = *reinterpret_cast<const float4*>(row + e0);
-        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (live && e0 + k < D) ? row[e0 + k] : -INFINITY;
-    }
-    float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-#pragma unroll
-    for (int s = LPP / 2; s > 0; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
-    float ex[4], sum = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        ex[k] = (e0 + k < D) ? __expf(v[k] - mx) : 0.f;
-        sum += ex[k];
-    }
-#pragma unroll
-    for (int s = LPP / 2; s > 0; s >>= 1) sum += __shfl_xor(sum, s);
-    const float inv = 1.0f / sum;
-    float* orow = prob + pix * D;
-    if (live && (D & 3) == 0 && e0 < D) {
-        *reinterpret_cast<float4*>(orow + e0) = make_float4(ex[0] * inv, ex[1] * inv, ex[2] * inv, ex[3] * inv);
-    } else if (live) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (e0 + k < D) orow[e0 + k] = ex[k] * inv;
-    }
-}
-
-// v_readlane_b32 on a float (the builtin is typed int: pass the bits, not the value)
-__device__ __forceinline__ float readlane_f(float v, int lane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-
-// ------------------------------------------------------------------------------------------
-// K2+K4: stage 1 -- depth (x) feature outer product reduced along image columns (camera side)
-// ------------------------------------------------------------------------------------------
-// Workgroup = one image column (bt, n, w); wave g owns the 8 depth bins [8g, 8g+8).  The column's fH
-// feature rows, depth probabilities and voxel ids are staged in LDS once per workgroup.
-// Lane = (bin, 8-channel chunk): a lane keeps the running sum of ITS bin for ITS 8 channels,
-//   acc[k] += prob[h][bin] * feat[h][8*chunk + k],
-// so one wave instruction advances 8 frustum points x 64 channels (the earlier lane = channel version
-// spent 6 scalar/vector instructions per point and was issue-bound at 83 us).  When the voxel id of a bin
-// changes from one image row to the next, the 8 lanes of that bin store the finished run vector as one
-// 256-B row of `runs`, at the row the plan assigned to it (dest[run id]) -- ~12x fewer rows than frustum
-// points, every input read once, no atomics.
-template <bool VEC8>  // VEC8: C is a multiple of 8 (two float4 stores per lane)
-__global__ __launch_bounds__(1024) void lift_runs_kernel(Dims dm, int Dp, const float* __restrict__ feat,
-                                                         const float* __restrict__ prob,
-                                                         const int32_t* __restrict__ vox_pm,
-                                                         const int32_t* __restrict__ run_base,
-                                                         const int32_t* __restrict__ dest,
-                                                         float* __restrict__ runs) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* fcol = smem;                                   // [fH][64]
-    float* pcol = smem + (size_t)dm.fH * 64;              // [fH][Dp]
-    int* vcol = reinterpret_cast<int*>(pcol + (size_t)dm.fH * Dp);   // [fH][Dp]
-    int* dcol = vcol + (size_t)dm.fH * Dp;                // destination rows of the column's runs (<= fH*D)
-    const int lane = threadIdx.x & 63;
-    const int g = threadIdx.x >> 6;
-    const int nwaves = blockDim.x >> 6;
     const int col = blockIdx.x, bt = blockIdx.y;
     const int n = col / dm.fW, w = col - n * dm.fW;
-    const size_t pix0 = (size_t)bt * dm.NPIX + (size_t)n * dm.fH * dm.fW + w;   // pixel of row h = pix0 + h*fW
-
-    // ---- stage the column: feature rows (zero-padded to 64 channels), probabilities, voxel ids ----
-    for (int h = g; h < dm.fH; h += nwaves)
-        fcol[h * 64 + lane] = lane < dm.C ? feat[(pix0 + (size_t)h * dm.fW) * dm.C + lane] : 0.f;
-    for (int i = threadIdx.x; i < dm.fH * Dp; i += blockDim.x) {
-        const int h = i / Dp, d = i - h * Dp;
-        const size_t src = (pix0 + (size_t)h * dm.fW) * dm.D + d;
-        pcol[i] = d < dm.D ? prob[src] : 0.f;
-        vcol[i] = d < dm.D ? vox_pm[src] : -1;
-    }
-    const int32_t* dst = dest + (size_t)bt * dm.P;
-    const int32_t* rb_col = run_base + (size_t)bt * (dm.NQ + 1) + (size_t)col * dm.D;
-    const int col_base = rb_col[0], col_runs = rb_col[dm.D] - rb_col[0];      // the column's runs are contiguous ids
-    for (int i = threadIdx.x; i < col_runs; i += blockDim.x) dcol[i] = dst[col_base + i];
-    __syncthreads();
-
-    const int bin = lane >> 3, chunk = lane & 7;
-    const int d = g * 8 + bin;
-    const bool bin_ok = d < dm.D;
-    float* out = runs + (size_t)bt * dm.P * dm.C + chunk * 8;
-    const int* drow = dcol + (bin_ok ? rb_col[d] - col_base : 0);   // rows of this lane's bin, in run order
-    int cnt = 0;                                              // runs flushed so far
-    int cur = -1;
-    float acc[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-
-    auto flush = [&]() {
-        const int row = drow[cnt];
-        float* o = out + (size_t)row * dm.C;
-        if (VEC8) {
-            if (chunk * 8 < dm.C) {
-                *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-            }
+    const int D = dm.D;
+    const int e0 = sub * 4;
+    for (int h0 = 0; h0 < dm.fH; h0 += PPB) {
+        const int h = h0 + threadIdx.x / LPP;
+        const bool live = h < dm.fH;
+        float v[4];
+        const float* row = logits + ((size_t)bt * dm.NPIX + (size_t)(n * dm.fH + (live ? h : 0)) * dm.fW + w) * D;
+        if (live && (D & 3) == 0 && e0 < D) {
+            const float4 qv = *reinterpret_cast<const float4*>(row + e0);
+            v[0] = qv.x; v[1] = qv.y; v[2] = qv.z; v[3] = qv.w;
         } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (chunk * 8 + k < dm.C) o[k] = acc[k];
+            for (int k = 0; k < 4; ++k) v[k] = (live && e0 + k < D) ? row[e0 + k] : -INFINITY;
         }
-    };
-
-    const float4* f4 = reinterpret_cast<const float4*>(fcol) + chunk * 2;
-    const float* pc = pcol + d;
-    const int* vc = vcol + d;
-    for (int h = 0; h < dm.fH; ++h) {
-        const float p = pc[h * Dp];
-        const int v = vc[h * Dp];
-        const float4 a = f4[h * 16], b = f4[h * 16 + 1];
-        const bool changed = v != cur;                         // run boundary of this lane's bin
-        if (changed && cur >= 0) {
-            flush();
-            ++cnt;
+        float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+#pragma unroll
+        for (int s = LPP / 2; s > 0; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
+        float ex[4], sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ex[k] = (e0 + k < D) ? __expf(v[k] - mx) : 0.f;
+            sum += ex[k];
         }
-        cur = v;
-        // branch-free restart of the running sum (the store above only READS acc)
-        acc[0] = fmaf(p, a.x, changed ? 0.f : acc[0]); acc[1] = fmaf(p, a.y, changed ? 0.f : acc[1]);
-        acc[2] = fmaf(p, a.z, changed ? 0.f : acc[2]); acc[3] = fmaf(p, a.w, changed ? 0.f : acc[3]);
-        acc[4] = fmaf(p, b.x, changed ? 0.f : acc[4]); acc[5] = fmaf(p, b.y, changed ? 0.f : acc[5]);
-        acc[6] = fmaf(p, b.z, changed ? 0.f : acc[6]); acc[7] = fmaf(p, b.w, changed ? 0.f : acc[7]);
+#pragma unroll
+        for (int s = LPP / 2; s > 0; s >>= 1) sum += __shfl_xor(sum, s);
+        const float inv = 1.0f / sum;
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (e0 + k < D) tile_s[(e0 + k) * dm.fH + h] = ex[k] * inv;
+        }
     }
-    if (cur >= 0) flush();
+    __syncthreads();
+    float* out = prob_cm + ((size_t)bt * dm.NCOL + col) * D * dm.fH;
+    for (int i = threadIdx.x; i < D * dm.fH; i += 256) out[i] = tile_s[i];
 }
 
 // ------------------------------------------------------------------------------------------
-// K4+K5: stage 2 -- per-voxel sum of run vectors, discounted accumulation over t, BEV planes
+// K2+K4+K5: forward -- one pass, pull form
 // ------------------------------------------------------------------------------------------
-// A workgroup owns 64 consecutive voxels of one sample; wave w owns voxels [16w, 16w+16), whose
-// run rows are ONE contiguous range of `runs` (the plan sorted the rows by voxel), streamed with
-// up to 8 independent 256-B row loads in flight and added in row order (canonical => bit
-// reproducible).  The running bev*discount + pool_t lives in an LDS tile [voxel][channel] that is
-// written out transposed, i.e. as 256-B coalesced rows of the reference's [C][X*Y] planes.
-constexpr int kTileV = 64;
-constexpr int kTilePad = 65;
+// A wave owns one voxel group (<= 16 consecutive voxels of one sample) and walks the frames t = 0..T-1 (the discounted state
+// bev_t = bev_{t-1} * discount + pool_t, stp3.py:296, lives in 16 registers per lane).  Lane = (slot, 4-channel
+// chunk): the 4 slots work on 4 consecutive runs of the wave's list at a time; a slot walks the rows of its run,
+//     acc[c] += prob[row][d] * feat[row][c]         (16 lanes x 16 bytes = one 256-byte feature row per load),
+// and then adds the run vector to its voxel's pool row in LDS -- slot after slot, i.e. in list order, so every
+// voxel is summed in ONE canonical order (bit-reproducible), without atomics.  Feature rows and probabilities are
+// read through L2 (a frame's features are 2.6 MB: the workgroup -> voxel mapping keeps a sample on one pair of
+// XCDs); the only HBM traffic besides the inputs is the BEV itself, written once as 256-byte voxel rows.
+// Output layout: [B][T][V][C] (channels-last BEV); the reference's [B][T][C][V] is produced by a transpose pass
+// when the caller asks for it.
+__device__ __forceinline__ float4 ld4(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float ld1(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 
-__global__ __launch_bounds__(256) void lift_gather_kernel(Dims dm, const float* __restrict__ runs,
-                                                          const int32_t* __restrict__ vox_off, float discount,
-                                                          float* __restrict__ bev) {
-    __shared__ float tile[kTileV * kTilePad];
+// Work distribution: the plan's voxel groups (<= 16 voxels, ~kGroupRuns runs over all frames, i.e. equal work) are
+// dealt out statically to a chip-sized set of persistent waves.  What bounds this kernel is the gather traffic
+// (~2 GB of 256-byte feature rows per launch), so it has to hit in L2: workgroup b runs on XCD b % 8, and with
+// 8 % B == 0 XCD x serves the x % (8/B)-th CONTIGUOUS slice of sample x / (8/B)'s groups -- a compact part of the
+// BEV, seen by two or three of the cameras -- and all waves walk the frames in lockstep order (t outer, groups inner),
+// so that at any time an XCD works on one frame of a few cameras (~2-3 MB of features and probabilities, vs 4 MB of
+// L2).  The price of the frame-major order: the discounted state of a group is re-read from the previous frame's
+// output (written by the same lanes; 256-byte rows) instead of being kept in registers.
+constexpr int kPullRows = 8;     // image rows in flight per slot
+
+__global__ __launch_bounds__(256) void lift_pull_kernel(Dims dm, const float* __restrict__ feat,
+                                                        const float* __restrict__ prob,
+                                                        const int32_t* __restrict__ vox_off,
+                                                        const uint4* __restrict__ runs,
+                                                        const int32_t* __restrict__ gidx,
+                                                        const int32_t* __restrict__ groups, float discount,
+                                                        float* __restrict__ bev_cl) {
+    __shared__ __attribute__((aligned(16))) float pool_s[4][kGroupVox][64];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.y;
-    const int v0 = blockIdx.x * kTileV;
-    const bool chan = lane < dm.C;
+    const int slot = lane >> 4;
+    const int c4 = (lane & 15) * 4;
+    const bool chan_ok = c4 < dm.C;
+    float* pool = &pool_s[wv][0][0];
+    const unsigned fstride = (unsigned)dm.fW * dm.C * 4u;
+    // (samples, slice, rank, stride) of this wave
+    int b_lo, b_hi, sub, xps, rank, stride;
+    if ((8 % dm.B) == 0 && (gridDim.x & 7) == 0) {
+        xps = 8 / dm.B;                                            // XCDs per sample
+        const int xcd = blockIdx.x & 7;
+        b_lo = xcd / xps; b_hi = b_lo + 1;
+        sub = xcd % xps;
+        rank = (blockIdx.x >> 3) * 4 + wv;
+        stride = (gridDim.x >> 3) * 4;                             // waves per XCD
+    } else {                                                       // any B: every wave strides over every sample
+        xps = 1; sub = 0;
+        b_lo = 0; b_hi = dm.B;
+        rank = blockIdx.x * 4 + wv;
+        stride = gridDim.x * 4;
+    }
 
-    for (int i = threadIdx.x; i < kTileV * kTilePad; i += 256) tile[i] = 0.f;
-    __syncthreads();
+    for (int b = b_lo; b < b_hi; ++b) {
+        const int32_t* glist = groups + (size_t)b * (dm.V + 1);
+        const int ngroups = gidx[(size_t)b * (dm.V + 1) + dm.V];
+        const int g_lo = (int)((int64_t)ngroups * sub / xps), g_hi = (int)((int64_t)ngroups * (sub + 1) / xps);
+        const int mine = g_lo + rank < g_hi ? (g_hi - g_lo - rank + stride - 1) / stride : 0;   // groups of this wave
+        const int items = mine * dm.T;                                 // (frame, group) pairs, frame-major
+        // Three dependent fetches stand before the first feature row of an item: the list bounds of its voxels, the
+        // descriptors of its first four runs, the rows themselves.  The first two are requested one item ahead
+        // (bounds: two ahead), the descriptors of the next four runs while the current four are summed.
+        auto item_group = [&](int k) { return g_lo + rank + (k % mine) * stride; };
+        auto fetch_bound = [&](int k) -> int {                       // lane l <= 16: first run of voxel vfirst + l
+            if (k >= items) return 0;
+            const int g = item_group(k), t = k / mine;
+            const int vfirst = glist[g], vend = glist[g + 1];
+            return vox_off[(size_t)(b * dm.T + t) * (dm.V + 1) + min(vfirst + min(lane, kGroupVox), vend)];
+        };
+        auto fetch_desc = [&](int k, int r, int rend) -> uint4 {      // run r of item k (only if r < rend)
+            uint4 ds = make_uint4(0u, 0u, 0u, 0u);
+            if (k < items && r < rend) ds = runs[(size_t)(b * dm.T + k / mine) * dm.P + r];
+            return ds;
+        };
+        int bound_cur = fetch_bound(0);
+        int bound_nxt = fetch_bound(1);
+        uint4 ds_cur = fetch_desc(0, __builtin_amdgcn_readlane(bound_cur, 0) + slot, __builtin_amdgcn_readlane(bound_cur, kGroupVox));
 
-    for (int t = 0; t < dm.T; ++t) {
-        const int bt = b * dm.T + t;
-        const float* rbt = runs + (size_t)bt * dm.P * dm.C + lane;
-        const int32_t* obt = vox_off + (size_t)bt * (dm.V + 1);
-        // lane i <= 16 holds the first row of voxel v0 + 16*wv + i (clamped to the last offset)
-        const int vfirst = v0 + wv * 16;
-        const int bound = obt[min(vfirst + min(lane, 16), dm.V)];
-        const int rbeg = __builtin_amdgcn_readlane(bound, 0);
-        const int rend = __builtin_amdgcn_readlane(bound, 16);
-        int vi = 0;                                              // voxel (0..15) the open sum belongs to
-        int next = __builtin_amdgcn_readlane(bound, 1);          // first row of voxel vi + 1
-        float acc = 0.f;
-        float* cells = tile + (wv * 16) * kTilePad + lane;
-        for (int r0 = rbeg; r0 < rend; r0 += 8) {
-            float x[8];
+        for (int k = 0; k < items; ++k) {
+            const int t = k / mine, g = item_group(k);
+            const int bt = b * dm.T + t;
+            const uint4* dlist = runs + (size_t)bt * dm.P;
+            const unsigned frame_pix = (unsigned)bt * (unsigned)dm.NPIX, frame_pts = (unsigned)bt * (unsigned)dm.P;
+            const float* prev_out = bev_cl + (size_t)(bt - 1) * dm.V * dm.C;   // read only for t > 0
+            float* cur_out = bev_cl + (size_t)bt * dm.V * dm.C;
+            const int vfirst = glist[g], vend = glist[g + 1];           // 1..16 voxels
+            const int rbeg = __builtin_amdgcn_readlane(bound_cur, 0);
+            const int rend = __builtin_amdgcn_readlane(bound_cur, kGroupVox);
+            // requests for the items ahead
+            const int bound_nn = fetch_bound(k + 2);
+            const int nbeg = __builtin_amdgcn_readlane(bound_nxt, 0), nend = __builtin_amdgcn_readlane(bound_nxt, kGroupVox);
+            const uint4 ds_first_nxt = fetch_desc(k + 1, nbeg + slot, nend);
+            // the discounted state of the group's voxels: last frame's output rows (this lane wrote them itself)
+            float4 st[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = (chan && r0 + u < rend) ? rbt[(size_t)(r0 + u) * dm.C] : 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const int v = vfirst + slot + 4 * q;
+                st[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t > 0 && v < vend && chan_ok) st[q] = *reinterpret_cast<const float4*>(prev_out + (size_t)v * dm.C + c4);
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int r = r0 + u;
-                if (r < rend) {
-                    while (r >= next) {                          // close voxel vi (possibly empty ones too)
-                        cells[vi * kTilePad] = cells[vi * kTilePad] * discount + acc;   // stp3.py:296
-                        acc = 0.f;
-                        ++vi;
-                        next = __builtin_amdgcn_readlane(bound, vi + 1);
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(pool + (slot + 4 * q) * 64 + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            __builtin_amdgcn_wave_barrier();
+
+            uint4 ds = ds_cur;
+            for (int r0 = rbeg; r0 < rend; r0 += 4) {
+                const int r = r0 + slot;
+                const bool valid = r < rend;
+                const uint4 ds_next = (r + 4 < rend) ? dlist[r + 4] : make_uint4(0u, 0u, 0u, 0u);   // for the next round
+                const int len = valid ? (int)(ds.x & 127u) + 1 : 0;
+                const unsigned foff = ((frame_pix + ds.z) * (unsigned)dm.C + (unsigned)(chan_ok ? c4 : 0)) * 4u;
+                unsigned poff = (frame_pts + ds.w) * 4u;            // prob_cm[bt][col][d][h0 ...]: the run's rows are contiguous
+                const int maxlen = max(max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 16)),
+                                       max(__builtin_amdgcn_readlane(len, 32), __builtin_amdgcn_readlane(len, 48)));
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int last = len > 0 ? len - 1 : 0;
+                // The memory pipeline takes one vector-load instruction per 16 cycles whatever its width, and this
+                // kernel is bound by instruction issue: (a) one load brings the probabilities of 16 rows (lane j of
+                // the slot: row i + j; one 64-byte piece of the column-major layout), each row's value is then
+                // broadcast within the slot through the LDS crossbar; (b) feature rows are loaded unconditionally --
+                // a slot whose run is shorter than the round's longest re-reads its last row (a cache hit) and
+                // multiplies it by a zero probability -- which spares the exec-mask bookkeeping of predicated loads.
+                float pvec = 0.f;
+                for (int i = 0; i < maxlen; i += kPullRows) {
+                    if ((i & 15) == 0) {
+                        pvec = 0.f;
+                        if (i + (lane & 15) < len) pvec = ld1(prob, poff + (unsigned)(lane & 15) * 4u);
+                        poff += 64u;
                     }
-                    acc += x[u];
+                    float4 f[kPullRows];
+#pragma unroll
+                    for (int u = 0; u < kPullRows; ++u) f[u] = ld4(feat, foff + (unsigned)min(i + u, last) * fstride);
+#pragma unroll
+                    for (int u = 0; u < kPullRows; ++u) {
+                        const float pr = __shfl(pvec, (lane & 48) | ((i + u) & 15));     // rows beyond the run carry 0
+                        acc.x = fmaf(pr, f[u].x, acc.x);
+                        acc.y = fmaf(pr, f[u].y, acc.y);
+                        acc.z = fmaf(pr, f[u].z, acc.z);
+                        acc.w = fmaf(pr, f[u].w, acc.w);
+                    }
                 }
+                // add the four run vectors to their voxels' pool rows, in list order (slot 0 first)
+                const int vi = valid ? (int)ds.y - vfirst : 0;
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    if (slot == sl && valid && chan_ok) {
+                        float4* cell = reinterpret_cast<float4*>(pool + vi * 64 + c4);
+                        float4 q = *cell;
+                        q.x += acc.x; q.y += acc.y; q.z += acc.z; q.w += acc.w;
+                        *cell = q;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                ds = ds_next;
             }
-        }
-        for (; vi < 16; ++vi) {                                  // the open voxel and the empty tail
-            cells[vi * kTilePad] = cells[vi * kTilePad] * discount + acc;
-            acc = 0.f;
-        }
-        __syncthreads();
-        // transposed store: lane = voxel, 16 channel planes per wave, 256-B rows
-        const int v = v0 + lane;
-        if (v < dm.V) {
-            for (int ci = 0; ci < 16; ++ci) {
-                const int c = wv * 16 + ci;
-                if (c < dm.C) bev[((size_t)bt * dm.C + c) * dm.V + v] = tile[lane * kTilePad + c];
+            // bev_t = bev_{t-1} * discount + pool_t (stp3.py:296); rows of 4 voxels per store instruction
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int vi = slot + 4 * q, v = vfirst + vi;
+                const float4 pl = *reinterpret_cast<const float4*>(pool + vi * 64 + c4);
+                float4 o;
+                o.x = st[q].x * discount + pl.x;
+                o.y = st[q].y * discount + pl.y;
+                o.z = st[q].z * discount + pl.z;
+                o.w = st[q].w * discount + pl.w;
+                if (v < vend && chan_ok) *reinterpret_cast<float4*>(cur_out + (size_t)v * dm.C + c4) = o;
             }
+            __builtin_amdgcn_wave_barrier();
+            bound_cur = bound_nxt;
+            bound_nxt = bound_nn;
+            ds_cur = ds_first_nxt;
         }
-        __syncthreads();
+    }
+}
+
+// out[bt][c][r] = in[bt][r][c]  (rows x cols per batch entry; 64 x 64 tiles through LDS)
+__global__ __launch_bounds__(256) void transpose_kernel(int rows, int cols, const float* __restrict__ in,
+                                                        float* __restrict__ out) {
+    __shared__ float tile[64][65];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const size_t base = (size_t)blockIdx.z * rows * cols;
+    for (int i = wv; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + lane;
+        tile[i][lane] = (r < rows && c < cols) ? in[base + (size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = wv; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + lane;
+        if (r < rows && c < cols) out[base + (size_t)c * rows + r] = tile[lane][i];
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // K6: backward
 // ------------------------------------------------------------------------------------------
-// (a) G_t = sum_{t'>=t} discount^(t'-t) dL/dout[b][t'], transposed to voxel-major [V][C] so that
-//     the gather in (b) reads one 256-B row per point.
-__global__ __launch_bounds__(256) void bev_grad_accumulate_kernel(Dims dm, const float* __restrict__ grad_bev,
-                                                                  float discount, float* __restrict__ gacc) {
+// (a) gradient import: G_t[v][c] = sum_{t' >= t} discount^(t'-t) dL/dout[b][t'][v][c] (the adjoint of the discounted
+//     accumulation, Horner from the last frame), written voxel-major [B*T][V][C] float32 so that the gather in (b)
+//     reads one 256-byte row per run.  The incoming gradient has to be converted anyway (it arrives in the layout /
+//     dtype of whatever consumed the BEV): this pass takes it as it comes -- channels-last float32 / bfloat16 or the
+//     reference's channels-first float32 -- and folds the recurrence into the conversion.
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void grad_import_cl_kernel(Dims dm, const void* __restrict__ dout, float discount,
+                                                             float* __restrict__ gacc) {
+    // lane = 4 consecutive channels of one voxel row (16 lanes x 16 bytes = one 256-byte row per load instruction),
+    // 4 voxel rows per thread, all T frames of them requested together
+    const int b = blockIdx.y;
+    const int cq = threadIdx.x & 15, vr = threadIdx.x >> 4;
+    const int c = cq * 4;
+    constexpr int kRows = 4, kFrames = 4;
+    const int v0 = blockIdx.x * (16 * kRows) + vr;
+    if (c >= dm.C) return;
+    float4 acc[kRows];
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int hi = dm.T - 1; hi >= 0; hi -= kFrames) {
+        float4 x[kFrames][kRows];
+#pragma unroll
+        for (int u = 0; u < kFrames; ++u)
+#pragma unroll
+            for (int i = 0; i < kRows; ++i) {
+                const int t = hi - u, v = v0 + 16 * i;
+                x[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t >= 0 && v < dm.V) {
+                    const size_t e = ((size_t)(b * dm.T + t) * dm.V + v) * dm.C + c;
+                    if (BF16) {
+                        const uint2 q = *reinterpret_cast<const uint2*>((const uint16_t*)dout + e);
+                        x[u][i] = make_float4(bf16_to_f32((uint16_t)(q.x & 0xffffu)), bf16_to_f32((uint16_t)(q.x >> 16)),
+                                              bf16_to_f32((uint16_t)(q.y & 0xffffu)), bf16_to_f32((uint16_t)(q.y >> 16)));
+                    } else {
+                        x[u][i] = *reinterpret_cast<const float4*>((const float*)dout + e);
+                    }
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < kFrames; ++u)
+#pragma unroll
+            for (int i = 0; i < kRows; ++i) {
+                const int t = hi - u, v = v0 + 16 * i;
+                if (t >= 0 && v < dm.V) {
+                    acc[i].x = acc[i].x * discount + x[u][i].x;
+                    acc[i].y = acc[i].y * discount + x[u][i].y;
+                    acc[i].z = acc[i].z * discount + x[u][i].z;
+                    acc[i].w = acc[i].w * discount + x[u][i].w;
+                    *reinterpret_cast<float4*>(gacc + ((size_t)(b * dm.T + t) * dm.V + v) * dm.C + c) = acc[i];
+                }
+            }
+    }
+}
+
+constexpr int kTilePad = 65;
+
+// channels-first input [B][T][C][V]: 64 x 64 (channel x voxel) tiles through LDS, coalesced on both sides
+__global__ __launch_bounds__(256) void grad_import_cf_kernel(Dims dm, const float* __restrict__ dout, float discount,
+                                                             float* __restrict__ gacc) {
     __shared__ float stage[64 * kTilePad];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.y;
-    const int v0 = blockIdx.x * kTileV;
+    const int v0 = blockIdx.x * 64;
     float acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -545,7 +759,7 @@ __global__ __launch_bounds__(256) void bev_grad_accumulate_kernel(Dims dm, const
         for (int ci = 0; ci < 16; ++ci) {
             const int c = wv * 16 + ci;
             float g = 0.f;
-            if (c < dm.C && v < dm.V) g = grad_bev[((size_t)bt * dm.C + c) * dm.V + v];
+            if (c < dm.C && v < dm.V) g = dout[((size_t)bt * dm.C + c) * dm.V + v];
             stage[c * kTilePad + lane] = g;
         }
         __syncthreads();
@@ -559,362 +773,218 @@ __global__ __launch_bounds__(256) void bev_grad_accumulate_kernel(Dims dm, const
     }
 }
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
-}
+// (b) gather, four lanes per image row:
+//       dfeat[pix][c] = sum_d prob[pix][d] * G[vox(pix,d)][c]      dprob[pix][d] = sum_c feat[pix][c] * G[vox(pix,d)][c]
+//     then the softmax backward dlogit = p * (dprob - sum_d p * dprob), all in one kernel.
+// A wave takes a slice of <= 16 rows of one image column (n, w): lanes l, l+16, l+32, l+48 share pixel row l and own
+// 16 channels each of its feature row and of its dfeat row (2 x 16 registers: 4-5 waves per SIMD).  Both products are
+// per-lane FMA chains; the four partial dot products of a pixel meet with two cross-lane adds per depth bin (the
+// round-1 kernel spent 7 DPP steps per point).  Rows of a column fall into the same voxel in runs, so a depth bin
+// needs only one or two distinct gradient rows.  The kernel works in steps of kBwdBins depth bins: the run starts of
+// every bin are found with one ballot, every start lane drops its voxel id into the step's run table in LDS at the
+// run's number (bins in order, rows ascending), the rows of up to kBwdSlots runs (16 lanes x 16 bytes each) are
+// requested together into registers WHILE the previous step is multiplied, then handed to the wave through LDS
+// (ds_read_b128, broadcast within a run).  More runs than kBwdSlots in a step (rare) take extra, un-prefetched
+// staging passes.
+constexpr int kBwdBins = 8;      // depth bins per step
+constexpr int kBwdRounds = 4;    // staging rounds per step: 4 runs (one per 16-lane slot) each
+constexpr int kBwdSlots = 4 * kBwdRounds;
+constexpr int kBwdLd = 68;       // floats per staged row: 272 bytes, consecutive rows start 4 banks apart
+constexpr int kBwdTable = kBwdBins * 16;   // run table of a step: at most one run per (bin, row)
 
-// sum over the 64 lanes of a wave; the total is returned in every lane
-__device__ __forceinline__ float wave_sum(float v) {
-    v += dpp_f<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-    v += dpp_f<0x141, 0xF>(v);  // row_half_mirror
-    v += dpp_f<0x140, 0xF>(v);  // row_mirror
-    v += dpp_f<0x142, 0xA>(v);  // row_bcast15 -> rows 1,3
-    v += dpp_f<0x143, 0xC>(v);  // row_bcast31 -> rows 2,3
-    return readlane_f(v, 63);
-}
-
-// (b) one wave per image column (bt, n, w) [x a slice of its rows]: lane = channel for feat /
-//     dfeat / G and lane = depth bin for prob / vox / dprob.  G[d] holds the voxel-major gradient
-//     row of the column's CURRENT run in depth bin d; it is re-fetched (one 256-B row) only when
-//     the voxel id changes from one image row to the next, i.e. once per run instead of once per
-//     frustum point.  dprob[d] = <feat, G[d]>, dfeat += prob[d] * G[d], then the softmax backward
-//     dlogit = prob * (dprob - sum_d prob*dprob) fused per pixel.
-template <int DCAP>
-__global__ __launch_bounds__(256) void lift_splat_bwd_kernel(Dims dm, int hsplit, const float* __restrict__ gacc,
-                                                             const float* __restrict__ feat,
-                                                             const float* __restrict__ prob,
-                                                             const int32_t* __restrict__ vox_pm,
-                                                             float* __restrict__ grad_feat,
-                                                             float* __restrict__ grad_logits) {
+__global__ __launch_bounds__(256) void lift_bwd_kernel(Dims dm, int rows_pc, int chunks,
+                                                       const float* __restrict__ gacc,
+                                                       const float* __restrict__ feat,
+                                                       const float* __restrict__ prob,
+                                                       const int32_t* __restrict__ vox_cm,
+                                                       float* __restrict__ grad_feat,
+                                                       float* __restrict__ grad_logits) {
+    __shared__ __attribute__((aligned(16))) float ghat_s[4][kBwdSlots][kBwdLd];
+    __shared__ int table_s[4][2][kBwdTable];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t task = (int64_t)blockIdx.x * 4 + wv;
-    if (task >= (int64_t)dm.BT * dm.NCOL * hsplit) return;
-    const int hs = (int)(task % hsplit);
-    const int64_t tc = task / hsplit;
-    const int col = (int)(tc % dm.NCOL), bt = (int)(tc / dm.NCOL);
+    // XCD-contiguous task order: neighbouring columns (which fetch neighbouring / the same gradient rows) share an L2
+    const int64_t ntasks = (int64_t)dm.BT * dm.NCOL * chunks;
+    int64_t task;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        task = (int64_t)logical * 4 + wv;
+    }
+    if (task >= ntasks) return;                                   // whole wave; no block-level barrier below
+    const int chunk = (int)(task % chunks);
+    const int col = (int)((task / chunks) % dm.NCOL);
+    const int bt = (int)(task / ((int64_t)chunks * dm.NCOL));
+    const int quarter = lane >> 4, hh = lane & 15;
+    const int h = chunk * rows_pc + hh;
+    const bool active = hh < rows_pc && h < dm.fH;
     const int n = col / dm.fW, w = col - n * dm.fW;
-    const int hlen = (dm.fH + hsplit - 1) / hsplit;
-    const int h_lo = hs * hlen, h_hi = min(dm.fH, h_lo + hlen);
-    const float* g_bt = gacc + (size_t)bt * dm.V * dm.C + lane;
-    const bool chan = lane < dm.C;
-    const bool bin = lane < dm.D;
-    float G[DCAP];
+    const size_t gp = (size_t)bt * dm.NPIX + (size_t)(n * dm.fH + (active ? h : 0)) * dm.fW + w;
+    const unsigned le_mask = (2u << hh) - 1u;                     // rows <= mine
+    const int slot = quarter, c4 = hh * 4;                        // staging role: run `slot` of a round, channels c4 .. c4+3
+    const int cbase = quarter * 16;                               // compute role: channels cbase .. cbase+15
+    const float* grows = gacc + (size_t)bt * dm.V * dm.C;
+    float (*ghat)[kBwdLd] = ghat_s[wv];
+
+    float4 f[4], df[4];
 #pragma unroll
-    for (int d = 0; d < DCAP; ++d) G[d] = 0.f;
-    int curv = -1;
-    for (int h = h_lo; h < h_hi; ++h) {
-        const size_t gp = (size_t)bt * dm.NPIX + ((size_t)n * dm.fH + h) * dm.fW + w;
-        const float f = chan ? feat[gp * dm.C + lane] : 0.f;
-        const float pr = bin ? prob[gp * dm.D + lane] : 0.f;
-        const int vx = bin ? vox_pm[gp * dm.D + lane] : -1;
-        const unsigned long long chg = __ballot(vx != curv);
-        curv = vx;
-        if (chg) {
+    for (int k = 0; k < 4; ++k) {
+        f[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        df[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active && cbase + k * 4 < dm.C) f[k] = *reinterpret_cast<const float4*>(feat + gp * dm.C + cbase + k * 4);
+    }
+
+    // voxel ids / probabilities of the kBwdBins bins from d0 on (beyond D: v = -1, p = 0); column-major layouts
+    // [bt][col][d][h]: the 16 rows of a bin are one 64-byte piece
+    const size_t cm0 = ((size_t)bt * dm.NCOL + col) * dm.D * dm.fH + (active ? h : 0);
+    auto load_ids = [&](int d0, int (&v)[kBwdBins]) {
 #pragma unroll
-            for (int d = 0; d < DCAP; ++d) {
-                if ((chg >> d) & 1ull) {
-                    const int v = __builtin_amdgcn_readlane(vx, d);
-                    G[d] = (v >= 0 && chan) ? g_bt[(size_t)v * dm.C] : 0.f;
-                }
+        for (int j = 0; j < kBwdBins; ++j) v[j] = (active && d0 + j < dm.D) ? vox_cm[cm0 + (size_t)(d0 + j) * dm.fH] : -1;
+    };
+    auto load_probs = [&](int d0, float (&p)[kBwdBins]) {
+#pragma unroll
+        for (int j = 0; j < kBwdBins; ++j) p[j] = (active && d0 + j < dm.D) ? prob[cm0 + (size_t)(d0 + j) * dm.fH] : 0.f;
+    };
+    // Run starts of every bin of a step; the start lanes (quarter 0) enter their voxel id in the step's run table.
+    // my[j] = number of this lane's run within the step (runs numbered bin by bin, rows ascending).  Returns the total.
+    auto index_runs = [&](const int (&v)[kBwdBins], int* table, int (&my)[kBwdBins]) -> int {
+        int seen = 0;
+#pragma unroll
+        for (int j = 0; j < kBwdBins; ++j) {
+            int prev = __shfl_up(v[j], 1);
+            if (hh == 0) prev = -2;                               // a slice's first row always starts a run
+            const bool start = active && v[j] >= 0 && v[j] != prev;
+            const unsigned sb = (unsigned)__ballot(start) & 0xffffu;     // quarter 0; the others mirror it
+            my[j] = seen + __builtin_popcount(sb & le_mask) - 1;
+            if (start && quarter == 0) table[my[j]] = v[j];
+            seen += __builtin_popcount(sb);
+        }
+        return seen;
+    };
+    // request the rows of runs first .. first + kBwdSlots - 1 of a step (slot s of round q = run first + 4 q + s)
+    auto request = [&](const int* table, int total, int first, float4 (&raw)[kBwdRounds]) {
+#pragma unroll
+        for (int q = 0; q < kBwdRounds; ++q) {
+            const int r = first + 4 * q + slot;
+            raw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < total && c4 < dm.C) raw[q] = *reinterpret_cast<const float4*>(grows + (size_t)table[r] * dm.C + c4);
+        }
+    };
+
+    // lanes without a run read staged row 0 and multiply it by zero: it must hold finite numbers from the start
+    if (slot == 0) *reinterpret_cast<float4*>(&ghat[0][c4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    float p[kBwdBins];
+    int v[kBwdBins], vn[kBwdBins];
+    int my[kBwdBins], myn[kBwdBins];
+    float4 raw[kBwdRounds];
+    load_ids(0, v);
+    int total = index_runs(v, table_s[wv][0], my);
+    __builtin_amdgcn_wave_barrier();
+    request(table_s[wv][0], total, 0, raw);
+    float sdot = 0.f;
+
+    for (int d0 = 0, step = 0; d0 < dm.D; d0 += kBwdBins, ++step) {
+        const int* table = table_s[wv][step & 1];
+        load_probs(d0, p);                                         // used after the hand-over below
+        // hand the requested rows of this step to the wave
+#pragma unroll
+        for (int q = 0; q < kBwdRounds; ++q)
+            if (4 * q + slot < total && c4 < dm.C) *reinterpret_cast<float4*>(&ghat[4 * q + slot][c4]) = raw[q];
+        __builtin_amdgcn_wave_barrier();
+        // index the next step's runs before this one is multiplied (its rows are requested after the multiply:
+        // `raw` is free then, and the loads fly during the epilogue of this step and the prologue of the next)
+        const bool more = d0 + kBwdBins < dm.D;
+        int total_n = 0;
+        if (more) {
+            load_ids(d0 + kBwdBins, vn);
+            total_n = index_runs(vn, table_s[wv][(step + 1) & 1], myn);
+        }
+        float t8[kBwdBins];
+#pragma unroll
+        for (int j = 0; j < kBwdBins; ++j) t8[j] = 0.f;
+
+        for (int base = 0; base < (total > 0 ? total : 1); base += kBwdSlots) {
+            if (base > 0) {                                        // overflow pass: stage runs base .. base+kBwdSlots-1 now
+                __builtin_amdgcn_wave_barrier();
+                request(table, total, base, raw);                   // `raw` is free: this step's rows were handed over
+#pragma unroll
+                for (int q = 0; q < kBwdRounds; ++q)
+                    if (base + 4 * q + slot < total && c4 < dm.C) *reinterpret_cast<float4*>(&ghat[4 * q + slot][c4]) = raw[q];
+                __builtin_amdgcn_wave_barrier();
             }
-        }
-        float dfeat = 0.f, dprob = 0.f;
 #pragma unroll
-        for (int d = 0; d < DCAP; ++d) {
-            if (d < dm.D) {
-                dfeat = fmaf(readlane_f(pr, d), G[d], dfeat);
-                const float sd = wave_sum(f * G[d]);
-                dprob = (lane == d) ? sd : dprob;
-            }
-        }
-        const float sdot = wave_sum(pr * dprob);
-        if (chan) grad_feat[gp * dm.C + lane] = dfeat;
-        if (bin) grad_logits[gp * dm.D + lane] = pr * (dprob - sdot);
-    }
-}
-
-// (b') EXPERIMENTAL (STP3_LIFT_BWD=mfma): the same backward as two small fp32 GEMMs per image column
-//      on the matrix cores.  With the column's runs r = (depth bin d_r, rows [h0_r, h1_r), voxel v_r):
-//          Ghat[r][c] = G[v_r][c]                        (one 256-B row fetched per run)
-//          Phat[h][r] = prob[h][d_r] if h0_r <= h < h1_r else 0
-//          dfeat[h][c]   = sum_r Phat[h][r] * Ghat[r][c]               ([fH x R] x [R x C])
-//          dprob[h][d_r] = sum_c feat[h][c] * Ghat[r][c], h in the run ([fH x C] x [C x R], masked)
-//      One block (4 waves) per column; wave w owns the 16-channel slice w of dfeat and every
-//      fourth 16-run tile of dprob.  Runs are enumerated in the block from the voxel ids (bin-major,
-//      the order the forward plan uses), processed in chunks of kBwdRunCap.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kBwdRunCap = 128;  // runs per chunk (rows of Ghat resident in LDS)
-constexpr int kBwdRows = 32;     // image rows covered by the two 16-row MFMA tiles
-constexpr int kBwdStride = 66;   // row stride (floats) of the 64-wide LDS tiles: 2h + k spreads the banks
-
-inline size_t lift_bwd_mfma_lds(int Dp) {
-    return ((size_t)(kBwdRows + kBwdRunCap) * kBwdStride + 3 * (size_t)kBwdRows * Dp + 2 * kBwdRunCap + 64) *
-           sizeof(float);
-}
-
-__global__ __launch_bounds__(256) void lift_bwd_mfma_kernel(Dims dm, int Dp, const float* __restrict__ gacc,
-                                                            const float* __restrict__ feat,
-                                                            const float* __restrict__ prob,
-                                                            const int32_t* __restrict__ vox_pm,
-                                                            float* __restrict__ grad_feat,
-                                                            float* __restrict__ grad_logits) {
-    extern __shared__ float smem[];
-    float* fcol = smem;                                      // [32][66]  features of the column
-    float* ghat = fcol + kBwdRows * kBwdStride;              // [128][66] gradient row of each run
-    float* pcol = ghat + kBwdRunCap * kBwdStride;            // [32][Dp]  depth probabilities
-    float* tcol = pcol + kBwdRows * Dp;                      // [32][Dp]  dL/dprob
-    int* vcol = (int*)(tcol + kBwdRows * Dp);                // [32][Dp]  voxel ids
-    int* rdesc = vcol + kBwdRows * Dp;                       // [128] d | h0 << 8 | h1 << 16
-    int* rvox = rdesc + kBwdRunCap;                          // [128] voxel id of the run (-1: padding)
-    int* rcnt = rvox + kBwdRunCap;                           // [64]  runs per depth bin
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = blockIdx.x, bt = blockIdx.y;
-    const int n = col / dm.fW, w = col - n * dm.fW;
-    const size_t pix0 = (size_t)bt * dm.NPIX + (size_t)n * dm.fH * dm.fW + w;  // + h * fW
-
-    // ---- stage the column (rows >= fH and channels >= C are zero) ----
+            for (int j = 0; j < kBwdBins; ++j) {
+                const int loc = my[j] - base;
+                const bool mine = active && v[j] >= 0 && loc >= 0 && loc < kBwdSlots;
+                const float* grow = &ghat[mine ? loc : 0][cbase];   // lanes without a run read row 0 and drop the result
+                const float pj = mine ? p[j] : 0.f;
+                float dp = 0.f;
 #pragma unroll
-    for (int i = 0; i < kBwdRows / 4; ++i) {
-        const int h = wv + 4 * i;
-        const size_t gp = pix0 + (size_t)h * dm.fW;
-        const bool row = h < dm.fH;
-        fcol[h * kBwdStride + lane] = (row && lane < dm.C) ? feat[gp * dm.C + lane] : 0.f;
-        if (lane < Dp) {
-            const bool ok = row && lane < dm.D;
-            pcol[h * Dp + lane] = ok ? prob[gp * dm.D + lane] : 0.f;
-            vcol[h * Dp + lane] = ok ? vox_pm[gp * dm.D + lane] : -1;
-            tcol[h * Dp + lane] = 0.f;
-        }
-    }
-    __syncthreads();
-
-    // ---- count the runs of every depth bin (thread = bin) ----
-    if (tid < 64) {
-        int cnt = 0;
-        if (tid < dm.D) {
-            int prev = -1;
-            for (int h = 0; h < dm.fH; ++h) {
-                const int v = vcol[h * Dp + tid];
-                cnt += (v >= 0 && v != prev) ? 1 : 0;
-                prev = v;
-            }
-        }
-        rcnt[tid] = cnt;
-    }
-    __syncthreads();
-    int my_off = 0, total = 0;
-    for (int d = 0; d < dm.D; ++d) {
-        const int c = rcnt[d];
-        my_off += (d < tid) ? c : 0;
-        total += c;
-    }
-
-    const int li = lane & 15, kk = lane >> 4;
-    f32x4 dacc[2];
-    dacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int base = 0; base < total; base += kBwdRunCap) {
-        const int rc = min(kBwdRunCap, total - base);
-        const int rc16 = (rc + 15) & ~15;
-        // ---- describe the runs of this chunk ----
-        if (tid < dm.D) {
-            int idx = my_off - base, prev = -1, h0 = 0;
-            for (int h = 0; h <= dm.fH; ++h) {
-                const int v = h < dm.fH ? vcol[h * Dp + tid] : -1;
-                if (v != prev) {
-                    if (prev >= 0) {
-                        if (idx >= 0 && idx < kBwdRunCap) {
-                            rdesc[idx] = tid | (h0 << 8) | (h << 16);
-                            rvox[idx] = prev;
-                        }
-                        ++idx;
+                for (int k = 0; k < 4; ++k) {
+                    if (cbase + k * 4 < dm.C) {
+                        const float4 g = *reinterpret_cast<const float4*>(grow + k * 4);
+                        dp = fmaf(f[k].x, g.x, dp);
+                        dp = fmaf(f[k].y, g.y, dp);
+                        dp = fmaf(f[k].z, g.z, dp);
+                        dp = fmaf(f[k].w, g.w, dp);
+                        df[k].x = fmaf(pj, g.x, df[k].x);
+                        df[k].y = fmaf(pj, g.y, df[k].y);
+                        df[k].z = fmaf(pj, g.z, df[k].z);
+                        df[k].w = fmaf(pj, g.w, df[k].w);
                     }
-                    h0 = h;
-                    prev = v;
+                }
+                t8[j] += mine ? dp : 0.f;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (more) request(table_s[wv][(step + 1) & 1], total_n, 0, raw);
+        // first pass of the softmax backward: p * dprob (the correction needs the whole sum over d)
+#pragma unroll
+        for (int j = 0; j < kBwdBins; ++j) {
+            float dp = t8[j];
+            dp += __shfl_xor(dp, 16);                              // the other quarters of the same pixel
+            dp += __shfl_xor(dp, 32);
+            t8[j] = p[j] * dp;
+            sdot += t8[j];
+        }
+        if (active && quarter == 0) {
+#pragma unroll
+            for (int j = 0; j < kBwdBins; j += 4) {
+                if ((dm.D & 3) == 0) {
+                    if (d0 + j < dm.D)
+                        *reinterpret_cast<float4*>(grad_logits + gp * dm.D + d0 + j) = make_float4(t8[j], t8[j + 1], t8[j + 2], t8[j + 3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (d0 + j + i < dm.D) grad_logits[gp * dm.D + d0 + j + i] = t8[j + i];
                 }
             }
         }
-        for (int idx = rc + tid; idx < rc16; idx += 256) {
-            rdesc[idx] = 0;  // empty row range
-            rvox[idx] = -1;
+#pragma unroll
+        for (int j = 0; j < kBwdBins; ++j) {
+            v[j] = vn[j];
+            my[j] = myn[j];
         }
-        __syncthreads();
-        // ---- Ghat: one gradient row per run, 8 rows in flight per wave ----
-        for (int r0 = wv * 8; r0 < rc16; r0 += 32) {
-            float g[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int r = r0 + j;
-                const int v = r < rc16 ? rvox[r] : -1;
-                g[j] = (v >= 0 && lane < dm.C) ? gacc[((size_t)bt * dm.V + v) * dm.C + lane] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (r0 + j < rc16) ghat[(r0 + j) * kBwdStride + lane] = g[j];
-        }
-        __syncthreads();
-        // ---- dfeat += Phat x Ghat (wave = 16-channel slice) ----
-        if (wv * 16 < dm.C) {
-            for (int k0 = 0; k0 < rc16; k0 += 4) {
-                const int r = k0 + kk;
-                const int desc = rdesc[r];
-                const int d = desc & 255, h0 = (desc >> 8) & 255, h1 = desc >> 16;
-                const float b = ghat[r * kBwdStride + wv * 16 + li];
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int h = m * 16 + li;
-                    const float a = (h >= h0 && h < h1) ? pcol[h * Dp + d] : 0.f;
-                    dacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, dacc[m], 0, 0, 0);
-                }
-            }
-        }
-        // ---- dprob = feat x Ghat^T on the runs' row ranges (wave = every fourth 16-run tile) ----
-        for (int rt = wv; rt * 16 < rc16; rt += 4) {
-            f32x4 pacc[2];
-            pacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            pacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-            for (int k0 = 0; k0 < 64; k0 += 4) {
-                const float b = ghat[(rt * 16 + li) * kBwdStride + k0 + kk];
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const float a = fcol[(m * 16 + li) * kBwdStride + k0 + kk];
-                    pacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, pacc[m], 0, 0, 0);
-                }
-            }
-            const int desc = rdesc[rt * 16 + li];
-            const int d = desc & 255, h0 = (desc >> 8) & 255, h1 = desc >> 16;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int h = m * 16 + kk * 4 + q;
-                    if (h >= h0 && h < h1) tcol[h * Dp + d] = pacc[m][q];
-                }
-        }
-        __syncthreads();
+        total = total_n;
     }
-
-    // ---- dfeat out: lane holds rows 4*kk + q of tile m, channel 16*wv + li ----
-    if (wv * 16 < dm.C) {
+    if (!active) return;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int h = m * 16 + kk * 4 + q;
-                if (h < dm.fH) grad_feat[(pix0 + (size_t)h * dm.fW) * dm.C + wv * 16 + li] = dacc[m][q];
-            }
-    }
-    // ---- softmax backward per pixel: dlogit = p * (dprob - sum_d p * dprob) ----
-    for (int h = wv; h < dm.fH; h += 4) {
-        const bool bin = lane < dm.D;
-        const float pr = bin ? pcol[h * Dp + lane] : 0.f;
-        const float dp = bin ? tcol[h * Dp + lane] : 0.f;
-        const float sdot = wave_sum(pr * dp);
-        if (bin) grad_logits[(pix0 + (size_t)h * dm.fW) * dm.D + lane] = pr * (dp - sdot);
-    }
-}
-
-// (c) EXPERIMENTAL (STP3_LIFT_FWD=mfma): stage 1 of the forward on the fp32 matrix cores.  With the column's runs
-//     r = (depth bin d_r, rows [h0_r, h1_r)) the run vectors are one small GEMM per image column,
-//         R[r][c] = sum_h Phat[r][h] * feat[h][c],   Phat[r][h] = prob[h][d_r] if h0_r <= h < h1_r else 0
-//     ([runs x fH] x [fH x C]; v_mfma_f32_16x16x4_f32 is an exact fp32 FMA chain over h in ascending order, the
-//     same order the lane-per-bin kernel adds in).  Wave w owns the 16-channel slice w and walks the 16-run tiles;
-//     B (the feature rows) is loaded into registers once per column, A is built from the run descriptors.
-//     The column's run ids are contiguous in the plan, their destination rows are staged with one coalesced read.
-constexpr int kFwdRows = 32;      // image rows covered by the 8 k-steps
-constexpr int kFwdStrideF = 80;   // feature row stride in LDS: 16-lane groups of consecutive k land on disjoint banks
-
-inline size_t lift_runs_mfma_lds(int fH, int Dp) {
-    const size_t cap = (((size_t)fH * Dp) + 15) & ~(size_t)15;               // worst case: every point its own run
-    return ((size_t)kFwdRows * kFwdStrideF + 2 * (size_t)kFwdRows * Dp + 2 * cap) * sizeof(float);
-}
-
-__global__ __launch_bounds__(256) void lift_runs_mfma_kernel(Dims dm, int Dp, const float* __restrict__ feat,
-                                                             const float* __restrict__ prob,
-                                                             const int32_t* __restrict__ vox_pm,
-                                                             const int32_t* __restrict__ run_base,
-                                                             const int32_t* __restrict__ dest,
-                                                             float* __restrict__ runs) {
-    extern __shared__ float smem[];
-    float* fcol = smem;                                              // [32][80]
-    float* pcol = fcol + kFwdRows * kFwdStrideF;                     // [32][Dp]
-    int* vcol = (int*)(pcol + kFwdRows * Dp);                        // [32][Dp]
-    const int cap = (dm.fH * Dp + 15) & ~15;
-    int* rdesc = vcol + kFwdRows * Dp;                               // [cap] d | h0 << 8 | h1 << 16
-    int* rdst = rdesc + cap;                                         // [cap] row of the run in `runs` (-1: padding)
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = blockIdx.x, bt = blockIdx.y;
-    const int n = col / dm.fW, w = col - n * dm.fW;
-    const size_t pix0 = (size_t)bt * dm.NPIX + (size_t)n * dm.fH * dm.fW + w;
-
-    // ---- stage the column (rows >= fH, channels >= C, bins >= D are zero / -1) ----
-#pragma unroll
-    for (int i = 0; i < kFwdRows / 4; ++i) {
-        const int h = wv + 4 * i;
-        const size_t gp = pix0 + (size_t)h * dm.fW;
-        const bool row = h < dm.fH;
-        fcol[h * kFwdStrideF + lane] = (row && lane < dm.C) ? feat[gp * dm.C + lane] : 0.f;
-        if (lane < Dp) {
-            const bool ok = row && lane < dm.D;
-            pcol[h * Dp + lane] = ok ? prob[gp * dm.D + lane] : 0.f;
-            vcol[h * Dp + lane] = ok ? vox_pm[gp * dm.D + lane] : -1;
+    for (int k = 0; k < 4; ++k)
+        if (cbase + k * 4 < dm.C) *reinterpret_cast<float4*>(grad_feat + gp * dm.C + cbase + k * 4) = df[k];
+    if (quarter != 0) return;
+    // dlogit = p * dprob - p * sum_d (p * dprob)
+    if ((dm.D & 3) == 0) {
+        for (int d0 = 0; d0 < dm.D; d0 += 4) {
+            float4 tq = *reinterpret_cast<float4*>(grad_logits + gp * dm.D + d0);
+            tq.x -= prob[cm0 + (size_t)(d0 + 0) * dm.fH] * sdot;
+            tq.y -= prob[cm0 + (size_t)(d0 + 1) * dm.fH] * sdot;
+            tq.z -= prob[cm0 + (size_t)(d0 + 2) * dm.fH] * sdot;
+            tq.w -= prob[cm0 + (size_t)(d0 + 3) * dm.fH] * sdot;
+            *reinterpret_cast<float4*>(grad_logits + gp * dm.D + d0) = tq;
         }
-    }
-    const int32_t* rb_col = run_base + (size_t)bt * (dm.NQ + 1) + (size_t)col * dm.D;
-    const int col_base = rb_col[0], col_runs = rb_col[dm.D] - col_base;
-    const int runs16 = (col_runs + 15) & ~15;
-    const int32_t* dst = dest + (size_t)bt * dm.P + col_base;
-    for (int i = tid; i < runs16; i += 256) {
-        rdst[i] = i < col_runs ? dst[i] : -1;
-        if (i >= col_runs) rdesc[i] = 0;                             // empty row range
-    }
-    __syncthreads();
-    // ---- describe the runs: thread = depth bin, ids in plan order (bin-major, rows ascending) ----
-    if (tid < dm.D) {
-        int idx = rb_col[tid] - col_base, prev = -1, h0 = 0;
-        for (int h = 0; h <= dm.fH; ++h) {
-            const int v = h < dm.fH ? vcol[h * Dp + tid] : -1;
-            if (v != prev) {
-                if (prev >= 0) rdesc[idx++] = tid | (h0 << 8) | (h << 16);
-                h0 = h;
-                prev = v;
-            }
-        }
-    }
-    __syncthreads();
-    if (wv * 16 >= dm.C) return;
-
-    // ---- R = Phat x F: B fragments (feature rows of this wave's 16 channels) live in registers ----
-    const int li = lane & 15, kk = lane >> 4;
-    float bq[kFwdRows / 4];
-#pragma unroll
-    for (int ks = 0; ks < kFwdRows / 4; ++ks) bq[ks] = fcol[(4 * ks + kk) * kFwdStrideF + wv * 16 + li];
-    float* out = runs + (size_t)bt * dm.P * dm.C + wv * 16 + li;
-    for (int r0 = 0; r0 < runs16; r0 += 16) {
-        const int desc = rdesc[r0 + li];
-        const int d = desc & 255, h0 = (desc >> 8) & 255, h1 = desc >> 16;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < kFwdRows / 4; ++ks) {
-            const int h = 4 * ks + kk;
-            const float a = (h >= h0 && h < h1) ? pcol[h * Dp + d] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq[ks], acc, 0, 0, 0);
-        }
-        // lane holds runs r0 + 4*kk + q (q = 0..3), channel 16*wv + li
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = rdst[r0 + 4 * kk + q];
-            if (row >= 0) out[(size_t)row * dm.C] = acc[q];
-        }
+    } else {
+        for (int d = 0; d < dm.D; ++d) grad_logits[gp * dm.D + d] -= prob[cm0 + (size_t)d * dm.fH] * sdot;
     }
 }
 
@@ -925,7 +995,8 @@ __global__ __launch_bounds__(256) void lift_runs_mfma_kernel(Dims dm, int Dp, co
 // ==========================================================================================
 extern "C" {
 
-const char* stp3_version(void) { return "stp3hip 0.1 gfx950"; }
+const char* stp3_version(void) { return "stp3hip 0.2 gfx950"; }
+
 
 int stp3_voxel_index(const stp3_lift_dims* dims, const float* cam_m, const float* cam_t, const float* ego_r,
                      const float* ego_t, const float* xs, const float* ys, const float* ds, const float* bev_offset,
@@ -947,6 +1018,15 @@ int stp3_voxel_index(const stp3_lift_dims* dims, const float* cam_m, const float
     return launch_status();
 }
 
+// what the pooling kernels can address with 32-bit byte offsets / the descriptor's bit fields
+static int pool_limits(const Dims& dm) {
+    if (dm.Z != 1 || dm.C > 64 || (dm.C & 3) || dm.D > 64) return STP3_EUNSUP;   // stp3.py:297-299 squeezes Z
+    if (dm.fH > 128 || dm.NCOL >= 4096) return STP3_EUNSUP;
+    const int64_t widest = (int64_t)dm.BT * dm.NPIX * (dm.C > dm.D ? dm.C : dm.D) * 4;
+    if (widest >= (1LL << 32)) return STP3_EUNSUP;
+    return STP3_OK;
+}
+
 int stp3_lift_plan_bytes(const stp3_lift_dims* dims, size_t* bytes) {
     Dims dm;
     int rc = check_dims(dims, &dm);
@@ -956,35 +1036,37 @@ int stp3_lift_plan_bytes(const stp3_lift_dims* dims, size_t* bytes) {
     return STP3_OK;
 }
 
-int stp3_lift_workspace_bytes(const stp3_lift_dims* dims, size_t* bytes) {
+int stp3_lift_plan_build(const stp3_lift_dims* dims, const float* cam_m, const float* cam_t, const float* ego_r,
+                         const float* ego_t, const float* xs, const float* ys, const float* ds,
+                         const float* bev_offset, const float* bev_res, int32_t* vox_cm, int32_t* counts, void* plan,
+                         size_t plan_size, void* stream) {
     Dims dm;
     int rc = check_dims(dims, &dm);
     if (rc) return rc;
-    if (!bytes) return STP3_EINVAL;
-    *bytes = (size_t)dm.BT * dm.P * dm.C * sizeof(float);   // worst case: every frustum point its own run
-    return STP3_OK;
-}
-
-int stp3_lift_plan_build(const stp3_lift_dims* dims, const int32_t* vox_pm, int32_t* counts, void* plan,
-                         size_t plan_size, int deterministic, void* stream) {
-    Dims dm;
-    int rc = check_dims(dims, &dm);
-    if (rc) return rc;
-    if (!vox_pm || !counts || !plan) return STP3_EINVAL;
+    if (!cam_m || !cam_t || !ego_r || !ego_t || !xs || !ys || !ds || !bev_offset || !bev_res || !vox_cm || !counts ||
+        !plan)
+        return STP3_EINVAL;
+    if ((rc = pool_limits(dm))) return rc;
     if (plan_size < plan_bytes(dm)) return STP3_ENOSPACE;
+    if (dm.BT > 65535) return STP3_EUNSUP;
     PlanView pv = plan_view(dm, plan);
+    GeomArgs g{cam_m, cam_t, ego_r, ego_t, xs, ys, ds, bev_offset, bev_res};
     hipStream_t s = (hipStream_t)stream;
-    const dim3 qgrid((dm.NQ + 255) / 256, dm.BT);
-    hipLaunchKernelGGL(run_count_kernel, qgrid, dim3(256), 0, s, dm, vox_pm, pv.run_base, counts);
-    hipLaunchKernelGGL(plan_scan_kernel, dim3(dm.BT), dim3(1024), 0, s, dm.NQ, dm.NQ + 1, pv.run_base, pv.run_base, 0);
-    hipLaunchKernelGGL(plan_scan_kernel, dim3(dm.BT), dim3(1024), 0, s, dm.V, dm.V, counts, pv.vox_off, 1);
-    hipLaunchKernelGGL(run_fill_kernel, qgrid, dim3(256), 0, s, dm, vox_pm, pv.run_base, pv.vox_off, counts, pv.list);
-    if (deterministic) {
-        int64_t items = (int64_t)dm.BT * dm.V;
-        int blocks = (int)((items + 1) / 2 < 4096 ? (items + 1) / 2 : 4096);
-        hipLaunchKernelGGL(plan_sort_kernel, dim3(blocks), dim3(128), 0, s, dm, pv.vox_off, pv.list);
-    }
-    hipLaunchKernelGGL(plan_invert_kernel, dim3(256, dm.BT), dim3(256), 0, s, dm, pv.vox_off, pv.list, pv.dest);
+    const dim3 qgrid((dm.NQ + 63) / 64, dm.BT);
+    const size_t ids_lds = (size_t)64 * (dm.fH + 1) * sizeof(int32_t);
+    hipLaunchKernelGGL(plan_index_count_kernel, qgrid, dim3(64), ids_lds, s, dm, g, vox_cm, counts);
+    hipLaunchKernelGGL(plan_scan_kernel, dim3((dm.V + 1023) / 1024, dm.BT), dim3(1024), 0, s, dm.V, counts, pv.vox_off);
+    hipLaunchKernelGGL(plan_fill_kernel, qgrid, dim3(64), ids_lds, s, dm, vox_cm, pv.vox_off, counts, pv.desc);
+    // voxel groups of equal work: flags (in `groups`, reused below) -> scan -> list
+    int32_t* flags = counts;                                    // zero again by now; restored to zero below
+    hipLaunchKernelGGL(plan_group_flags_kernel, dim3((dm.V + 255) / 256, dm.B), dim3(256), 0, s, dm, pv.vox_off, flags);
+    hipLaunchKernelGGL(plan_scan_kernel, dim3((dm.V + 1023) / 1024, dm.B), dim3(1024), 0, s, dm.V, flags, pv.gidx);
+    hipLaunchKernelGGL(plan_group_list_kernel, dim3((dm.V + 256) / 256, dm.B), dim3(256), 0, s, dm, flags, pv.gidx, pv.groups);
+    hipError_t e = hipMemsetAsync(flags, 0, (size_t)dm.B * dm.V * sizeof(int32_t), s);
+    if (e != hipSuccess) return -(int)e;
+    if (dm.T > 65535) return STP3_EUNSUP;
+    hipLaunchKernelGGL(plan_group_sort_kernel, dim3(1024, dm.B, dm.T), dim3(128), 0, s, dm, pv.vox_off, pv.gidx, pv.groups,
+                       pv.desc, pv.runs);
     return launch_status();
 }
 
@@ -994,110 +1076,92 @@ int stp3_depth_softmax(const stp3_lift_dims* dims, const float* logits, float* p
     if (rc) return rc;
     if (!logits || !prob) return STP3_EINVAL;
     if (dm.D > 128) return STP3_EUNSUP;
-    const int64_t npix = (int64_t)dm.BT * dm.NPIX;
+    if (dm.BT > 65535) return STP3_EUNSUP;
     hipStream_t s = (hipStream_t)stream;
-    if (dm.D <= 32) {
-        hipLaunchKernelGGL(depth_softmax_kernel<8>, dim3((unsigned)((npix + 31) / 32)), dim3(256), 0, s, npix, dm.D,
-                           logits, prob);
-    } else if (dm.D <= 64) {
-        hipLaunchKernelGGL(depth_softmax_kernel<16>, dim3((unsigned)((npix + 15) / 16)), dim3(256), 0, s, npix, dm.D,
-                           logits, prob);
-    } else {
-        hipLaunchKernelGGL(depth_softmax_kernel<32>, dim3((unsigned)((npix + 7) / 8)), dim3(256), 0, s, npix, dm.D,
-                           logits, prob);
-    }
+    const dim3 grid(dm.NCOL, dm.BT);
+    const size_t lds = (size_t)dm.D * dm.fH * sizeof(float);
+    if (lds > 64 * 1024) return STP3_EUNSUP;
+    if (dm.D <= 32)
+        hipLaunchKernelGGL(depth_softmax_kernel<8>, grid, dim3(256), lds, s, dm, logits, prob);
+    else if (dm.D <= 64)
+        hipLaunchKernelGGL(depth_softmax_kernel<16>, grid, dim3(256), lds, s, dm, logits, prob);
+    else
+        hipLaunchKernelGGL(depth_softmax_kernel<32>, grid, dim3(256), lds, s, dm, logits, prob);
     return launch_status();
 }
 
-int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const float* prob, const int32_t* vox_pm,
-                        const void* plan, float discount, void* workspace, size_t workspace_bytes, float* bev,
+int stp3_lift_workspace_bytes(const stp3_lift_dims* dims, size_t* bytes) {
+    Dims dm;
+    int rc = check_dims(dims, &dm);
+    if (rc) return rc;
+    if (!bytes) return STP3_EINVAL;
+    *bytes = (size_t)dm.BT * dm.V * dm.C * sizeof(float);
+    return STP3_OK;
+}
+
+static void launch_transpose(hipStream_t s, int batch, int rows, int cols, const float* in, float* out) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((rows + 63) / 64, (cols + 63) / 64, batch), dim3(256), 0, s, rows, cols, in,
+                       out);
+}
+
+int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const float* prob, const void* plan,
+                        float discount, int bev_layout, void* workspace, size_t workspace_bytes, float* bev,
                         void* stream) {
     Dims dm;
     int rc = check_dims(dims, &dm);
     if (rc) return rc;
-    if (!feat || !prob || !vox_pm || !plan || !workspace || !bev) return STP3_EINVAL;
-    if (dm.Z != 1 || dm.C > 64 || dm.D > 128) return STP3_EUNSUP;  // stp3.py:297-299 squeezes Z; lane = channel
-    if (workspace_bytes < (size_t)dm.BT * dm.P * dm.C * sizeof(float)) return STP3_ENOSPACE;
+    if (!feat || !prob || !plan || !bev) return STP3_EINVAL;
+    if ((rc = pool_limits(dm))) return rc;
+    if (bev_layout != STP3_BEV_CHANNELS_FIRST && bev_layout != STP3_BEV_CHANNELS_LAST) return STP3_EINVAL;
+    const bool cf = bev_layout == STP3_BEV_CHANNELS_FIRST;
+    const size_t need = cf ? (size_t)dm.BT * dm.V * dm.C * sizeof(float) : 0;
+    if (cf && (!workspace || workspace_bytes < need)) return STP3_ENOSPACE;
+    if (cf && dm.BT > 65535) return STP3_EUNSUP;
     PlanView pv = plan_view(dm, const_cast<void*>(plan));
     hipStream_t s = (hipStream_t)stream;
-    const int ndg = (dm.D + 7) / 8;                        // waves per column: 8 depth bins each
-    const int Dp = ndg * 8;
-    const size_t lds = ((size_t)dm.fH * 64 + 3 * (size_t)dm.fH * Dp) * sizeof(float);
-    // experimental matrix-core variant of stage 1, opt-in (see lift_runs_mfma_kernel)
-    static const bool want_mfma = [] {
-        const char* e = getenv("STP3_LIFT_FWD");
-        return e && !strcmp(e, "mfma");
-    }();
-    if (want_mfma && dm.fH <= kFwdRows && dm.C % 16 == 0 && dm.D <= 64 && dm.BT <= 65535) {
-        const int Dq = dm.D | 1;
-        const size_t lds_m = lift_runs_mfma_lds(dm.fH, Dq);
-        if (lds_m <= 64 * 1024) {
-            hipLaunchKernelGGL(lift_runs_mfma_kernel, dim3(dm.NCOL, dm.BT), dim3(256), lds_m, s, dm, Dq, feat, prob, vox_pm,
-                               pv.run_base, pv.dest, (float*)workspace);
-            hipLaunchKernelGGL(lift_gather_kernel, dim3((dm.V + kTileV - 1) / kTileV, dm.B), dim3(256), 0, s, dm,
-                               (const float*)workspace, pv.vox_off, discount, bev);
-            return launch_status();
-        }
-    }
-    if (lds > 160 * 1024) return STP3_EUNSUP;
-    if (lds > 64 * 1024) {
-        // tall feature maps (BASELINE configs[4]: 112 rows x 64 bins = 112 KB per column): above the default
-        // dynamic-LDS limit of a launch, raise it for this kernel (gfx950 has 160 KB per workgroup)
-        const void* fn = dm.C % 8 == 0 ? reinterpret_cast<const void*>(&lift_runs_kernel<true>)
-                                       : reinterpret_cast<const void*>(&lift_runs_kernel<false>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -(int)e;
-    }
-    if (dm.C % 8 == 0)
-        hipLaunchKernelGGL((lift_runs_kernel<true>), dim3(dm.NCOL, dm.BT), dim3(64 * ndg), lds, s, dm, Dp, feat, prob,
-                           vox_pm, pv.run_base, pv.dest, (float*)workspace);
-    else
-        hipLaunchKernelGGL((lift_runs_kernel<false>), dim3(dm.NCOL, dm.BT), dim3(64 * ndg), lds, s, dm, Dp, feat, prob,
-                           vox_pm, pv.run_base, pv.dest, (float*)workspace);
-    hipLaunchKernelGGL(lift_gather_kernel, dim3((dm.V + kTileV - 1) / kTileV, dm.B), dim3(256), 0, s, dm,
-                       (const float*)workspace, pv.vox_off, discount, bev);
+    float* out_cl = cf ? (float*)workspace : bev;
+    // persistent waves: exactly the chip's worth of resident workgroups (a multiple of 8, so that every XCD gets the
+    // same share), each striding over the voxel groups
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lift_pull_kernel, 256, 0) != hipSuccess || cus <= 0 || per_cu <= 0)
+        return STP3_EUNSUP;
+    const int64_t blocks = ((int64_t)cus * per_cu) & ~(int64_t)7 ? ((int64_t)cus * per_cu) & ~(int64_t)7 : 8;
+    hipLaunchKernelGGL(lift_pull_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dm, feat, prob, pv.vox_off, pv.runs,
+                       pv.gidx, pv.groups, discount, out_cl);
+    if (cf) launch_transpose(s, dm.BT, dm.V, dm.C, out_cl, bev);          // [V][C] -> [C][V]: stp3.py:230-232 layout
     return launch_status();
 }
 
-int stp3_lift_splat_bwd(const stp3_lift_dims* dims, const float* grad_bev, const float* feat, const float* prob,
-                        const int32_t* vox_pm, float discount, float* gacc, float* grad_feat, float* grad_logits,
-                        void* stream) {
+int stp3_lift_splat_bwd(const stp3_lift_dims* dims, const void* grad_bev, int bev_layout, int grad_dtype,
+                        const float* feat, const float* prob, const int32_t* vox_cm, float discount, void* workspace,
+                        size_t workspace_bytes, float* grad_feat, float* grad_logits, void* stream) {
     Dims dm;
     int rc = check_dims(dims, &dm);
     if (rc) return rc;
-    if (!grad_bev || !feat || !prob || !vox_pm || !gacc || !grad_feat || !grad_logits) return STP3_EINVAL;
-    if (dm.Z != 1 || dm.C > 64 || dm.D > 64) return STP3_EUNSUP;
+    if (!grad_bev || !feat || !prob || !vox_cm || !grad_feat || !grad_logits || !workspace) return STP3_EINVAL;
+    if ((rc = pool_limits(dm))) return rc;
+    if (bev_layout != STP3_BEV_CHANNELS_FIRST && bev_layout != STP3_BEV_CHANNELS_LAST) return STP3_EINVAL;
+    if (grad_dtype != STP3_DTYPE_F32 && grad_dtype != STP3_DTYPE_BF16) return STP3_EINVAL;
+    const bool cf = bev_layout == STP3_BEV_CHANNELS_FIRST;
+    if (cf && grad_dtype != STP3_DTYPE_F32) return STP3_EUNSUP;
+    if (workspace_bytes < (size_t)dm.BT * dm.V * dm.C * sizeof(float)) return STP3_ENOSPACE;
+    if (dm.B > 65535) return STP3_EUNSUP;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bev_grad_accumulate_kernel, dim3((dm.V + kTileV - 1) / kTileV, dm.B), dim3(256), 0, s, dm,
-                       grad_bev, discount, gacc);
-    // experimental matrix-core variant, opt-in (see lift_bwd_mfma_kernel)
-    static const bool want_mfma = [] {
-        const char* e = getenv("STP3_LIFT_BWD");
-        return e && !strcmp(e, "mfma");
-    }();
-    if (want_mfma && dm.fH <= kBwdRows && dm.C % 16 == 0 && dm.BT <= 65535) {
-        const int Dp = dm.D | 1;
-        const size_t lds = lift_bwd_mfma_lds(Dp);
-        if (lds <= 64 * 1024) {
-            hipLaunchKernelGGL(lift_bwd_mfma_kernel, dim3(dm.NCOL, dm.BT), dim3(256), lds, s, dm, Dp, gacc, feat, prob,
-                               vox_pm, grad_feat, grad_logits);
-            return launch_status();
-        }
-    }
-    // enough waves to fill the chip: split the rows of a column when there are few columns
-    const int64_t cols = (int64_t)dm.BT * dm.NCOL;
-    int hsplit = (int)((8192 + cols - 1) / cols);
-    const int max_split = dm.fH / 8 > 0 ? dm.fH / 8 : 1;
-    if (hsplit > max_split) hsplit = max_split;
-    if (hsplit < 1) hsplit = 1;
-    const int64_t tasks = cols * hsplit;
-    const dim3 grid((unsigned)((tasks + 3) / 4));
-    if (dm.D <= 48)
-        hipLaunchKernelGGL(lift_splat_bwd_kernel<48>, grid, dim3(256), 0, s, dm, hsplit, gacc, feat, prob, vox_pm,
-                           grad_feat, grad_logits);
+    float* gacc = (float*)workspace;
+    const dim3 igrid((dm.V + 63) / 64, dm.B);
+    if (cf)
+        hipLaunchKernelGGL(grad_import_cf_kernel, igrid, dim3(256), 0, s, dm, (const float*)grad_bev, discount, gacc);
+    else if (grad_dtype == STP3_DTYPE_BF16)
+        hipLaunchKernelGGL(grad_import_cl_kernel<true>, igrid, dim3(256), 0, s, dm, grad_bev, discount, gacc);
     else
-        hipLaunchKernelGGL(lift_splat_bwd_kernel<64>, grid, dim3(256), 0, s, dm, hsplit, gacc, feat, prob, vox_pm,
-                           grad_feat, grad_logits);
+        hipLaunchKernelGGL(grad_import_cl_kernel<false>, igrid, dim3(256), 0, s, dm, grad_bev, discount, gacc);
+    // one wave per slice of <= 16 rows of an image column
+    const int chunks = (dm.fH + 15) / 16;
+    const int rows_pc = (dm.fH + chunks - 1) / chunks;
+    const int64_t tasks = (int64_t)dm.BT * dm.NCOL * chunks;
+    hipLaunchKernelGGL(lift_bwd_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, s, dm, rows_pc, chunks, gacc, feat,
+                       prob, vox_cm, grad_feat, grad_logits);
     return launch_status();
 }
 

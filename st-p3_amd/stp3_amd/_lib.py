@@ -85,6 +85,8 @@ DTYPE_BF16 = 1
 
 VOX_REFERENCE = 0
 VOX_PIXELMAJOR = 1
+BEV_CHANNELS_FIRST = 0
+BEV_CHANNELS_LAST = 1
 
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 RES_NONE, RES_BEFORE_ACT, RES_AFTER_ACT = 0, 1, 2
@@ -99,12 +101,13 @@ SIGNATURES = {
     'stp3_version': (ctypes.c_char_p, []),
     'stp3_voxel_index': (c_int, [_DIMS_P] + [c_void_p] * 9 + [c_int, c_void_p, c_void_p, c_void_p]),
     'stp3_lift_plan_bytes': (c_int, [_DIMS_P, ctypes.POINTER(c_size_t)]),
-    'stp3_lift_plan_build': (c_int, [_DIMS_P, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    'stp3_lift_plan_build': (c_int, [_DIMS_P] + [c_void_p] * 12 + [c_size_t, c_void_p]),
     'stp3_depth_softmax': (c_int, [_DIMS_P, c_void_p, c_void_p, c_void_p]),
     'stp3_lift_workspace_bytes': (c_int, [_DIMS_P, ctypes.POINTER(c_size_t)]),
-    'stp3_lift_splat_fwd': (c_int, [_DIMS_P, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_size_t,
+    'stp3_lift_splat_fwd': (c_int, [_DIMS_P, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_size_t,
                                     c_void_p, c_void_p]),
-    'stp3_lift_splat_bwd': (c_int, [_DIMS_P] + [c_void_p] * 4 + [c_float] + [c_void_p] * 4),
+    'stp3_lift_splat_bwd': (c_int, [_DIMS_P, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                    c_size_t, c_void_p, c_void_p, c_void_p]),
     'stp3_dwconv2d_fwd': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_dwconv2d_bwd_data': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_dwconv2d_bwd_weight_workspace': (c_int, [_DW_P, ctypes.POINTER(c_size_t)]),
@@ -118,12 +121,11 @@ SIGNATURES = {
     'stp3_bn_fwd_train': (c_int, [_BN_P] + [c_void_p] * 6 + [c_float, c_float] + [c_void_p] * 4 + [c_size_t, c_void_p,
                                                                                                  c_void_p]),
     'stp3_bn_bwd_train': (c_int, [_BN_P] + [c_void_p] * 10 + [c_size_t] + [c_void_p] * 4),
-    'stp3_conv2d_fwd': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'stp3_conv2d_fwd_workspace': (c_int, [ctypes.POINTER(ConvDims), ctypes.POINTER(c_size_t)]),
+    'stp3_conv2d_fwd': (c_int, [ctypes.POINTER(ConvDims)] + [c_void_p] * 6 + [c_size_t, c_void_p]),
     'stp3_se_workspace_bytes': (c_int, [ctypes.POINTER(SeDims), ctypes.POINTER(c_size_t)]),
     'stp3_se_pool': (c_int, [ctypes.POINTER(SeDims), c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     'stp3_se_scale': (c_int, [ctypes.POINTER(SeDims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'stp3_conv2d_fwd_v2_workspace': (c_int, [ctypes.POINTER(ConvDims), ctypes.POINTER(c_size_t)]),
-    'stp3_conv2d_fwd_v2': (c_int, [ctypes.POINTER(ConvDims)] + [c_void_p] * 6 + [c_size_t, c_void_p]),
     'stp3_conv2d_wgrad_workspace': (c_int, [ctypes.POINTER(ConvDims), ctypes.POINTER(c_size_t)]),
     'stp3_conv2d_wgrad': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'stp3_conv2d_prep_weights': (c_int, [c_void_p, c_int32, ctypes.c_int64, c_void_p]),

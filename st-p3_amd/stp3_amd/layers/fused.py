@@ -108,25 +108,16 @@ def bn_act(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=
                       act=act, res=res, res_mode=res_mode, sbias=sbias, oscale=oscale, group=group)
 
 
-# Dense convolutions.  The hand-written bf16 MFMA implicit-GEMM kernels (stp3_conv.hip) are parity-tested on
-# every layer shape of the model; the dispatch below uses them where they are at least on par with the vendor
-# library on MI355X (profiles/r01_time_conv.txt): layers with >= 64 input AND output channels (the BEV-side
-# 3x3 / dilated / 7x7 / wide 1x1 contractions, where they run at 160-200 TFLOP/s).  The thin-channel,
-# activation-bandwidth-bound pointwise layers of the EfficientNet trunk (24..56 channels) stay on the vendor
-# kernels until the narrow-tile variants land.
-#   STP3_MFMA_CONV=all  every supported shape      STP3_MFMA_CONV=0  never (A/B measurements)
-_MFMA_MODE = os.environ.get('STP3_MFMA_CONV', 'auto')
-MFMA_MIN_CHANNELS = 64
-
-
+# Dense convolutions.  Every bf16 (autocast) convolution on the GPU -- forward, data gradient and weight gradient, all
+# layer shapes of the model, the 3-channel stem included (its channels are zero-padded to 8) -- runs on the hand-written
+# MFMA implicit-GEMM kernels of stp3_conv.hip; no vendor convolution is on the benchmarked path.  Float32 tensors outside
+# autocast (the float32 parity runs) and CPU tensors take torch's convolution.
 def _use_mfma(x, weight, stride):
-    if _MFMA_MODE == '0' or not x.is_cuda:
+    if not x.is_cuda:
         return False
     if not (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()):
         return False
-    if not ops.conv2d_supported(x, weight, stride):
-        return False
-    return _MFMA_MODE == 'all' or min(weight.shape[0], weight.shape[1]) >= MFMA_MIN_CHANNELS
+    return ops.conv2d_supported(x, weight, stride)
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
@@ -155,13 +146,10 @@ def conv_module(m, x):
     return m(x)
 
 
-# EXPERIMENTAL, off by default: conv -> BN (-> ReLU) through one operator whose convolution epilogue produces the
-# BatchNorm statistics (ops_fused.py / csrc/stp3_conv2.hip).  Not validated on hardware yet.
-_CONV_V2 = os.environ.get('STP3_CONV_V2', '0') == '1'
-
-
 def _fusable_conv_bn(conv, bn, x):
-    return (_CONV_V2 and type(conv) is nn.Conv2d and isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.training
+    """conv -> BN (-> ReLU) in training mode goes through ONE operator whose convolution epilogue produces the
+    BatchNorm statistics (ops_fused.conv_bn_act): the statistics pass over the convolution output disappears."""
+    return (type(conv) is nn.Conv2d and isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.training
             and bn.track_running_stats and conv.groups == 1 and conv.padding_mode == 'zeros'
             and not isinstance(conv.padding, str) and x.dim() == 4 and _use_mfma(x, conv.weight, conv.stride))
 
@@ -172,7 +160,7 @@ def run_fused(seq, x):
     i = 0
     while i < len(mods):
         m = mods[i]
-        if _CONV_V2 and i + 1 < len(mods) and _fusable_conv_bn(m, mods[i + 1], x):
+        if i + 1 < len(mods) and _fusable_conv_bn(m, mods[i + 1], x):
             from .. import ops_fused
             relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
             group = None if _sync_world(mods[i + 1]) > 1 else False

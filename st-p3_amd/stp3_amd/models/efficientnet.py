@@ -25,8 +25,6 @@ from .. import ops
 from ..layers import fused as _fused
 from ..layers.fused import ACT_NONE, ACT_SWISH, RES_AFTER_ACT, bn_act, conv2d
 
-_MFMA_ALL = _fused._MFMA_MODE == 'all'
-_FUSED_SE = __import__('os').environ.get('STP3_FUSED_SE', '0') == '1'
 
 # (repeats, kernel, stride, expand, in, out) of the 7 base stages, SE ratio 0.25 everywhere
 _BASE_STAGES = ((1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
@@ -65,7 +63,7 @@ class StaticSamePadConv2d(nn.Conv2d):
             # squeeze-excite 1x1 convs on a pooled 1x1 map are plain GEMMs
             y = F.linear(x.flatten(1), self.weight.flatten(1), self.bias)
             return y.view(*y.shape, 1, 1)
-        if self.groups == 1 and x.is_cuda and self.in_channels % 8 and torch.is_autocast_enabled() and _MFMA_ALL:
+        if self.groups == 1 and x.is_cuda and self.in_channels % 8 and torch.is_autocast_enabled():
             # the 3-channel stem: zero-pad the channels to 8 (together with the "same" padding, one copy) so that
             # it runs on the MFMA kernel too; the padded weight columns are zero and their gradient is dropped
             cp = (-self.in_channels) % 8
@@ -104,8 +102,8 @@ class MBConvBlock(nn.Module):
 
     def forward(self, inputs, drop_connect_rate=None):
         x = inputs
-        # EXPERIMENTAL (STP3_CONV_V2=1 with STP3_MFMA_CONV=all): 1x1 conv -> BN -> activation as one operator
-        fuse = (_fused._CONV_V2 and _MFMA_ALL and self.training and x.is_cuda and torch.is_autocast_enabled()
+        # 1x1 conv -> BN -> activation as one operator (BatchNorm statistics from the convolution epilogue)
+        fuse = (self.training and x.is_cuda and torch.is_autocast_enabled()
                 and self.in_ch % 8 == 0 and (self.in_ch * self.expand) % 8 == 0)
         if fuse:
             from .. import ops_fused
@@ -117,9 +115,9 @@ class MBConvBlock(nn.Module):
                 x = bn_act(self._bn0, self._expand_conv(x), ACT_SWISH)
         x = bn_act(self._bn1, self._depthwise_conv(x), ACT_SWISH)
         # squeeze and excitation
-        if _FUSED_SE and x.is_cuda:
+        if x.is_cuda:
             from .. import ops_fused
-            x = ops_fused.se_block(x, self._se_reduce, self._se_expand)      # EXPERIMENTAL, off by default
+            x = ops_fused.se_block(x, self._se_reduce, self._se_expand)
         else:
             s = x.mean((2, 3), keepdim=True)
             s = self._se_expand(self._swish(self._se_reduce(s)))

@@ -95,7 +95,9 @@ class STP3(nn.Module):
                           'planning': cfg.PLANNING.ENABLED})
         set_bn_momentum(self, cfg.MODEL.BN_MOMENTUM)
 
-        self.deterministic_pool = True      # canonical per-voxel summation order (bit-reproducible)
+        # BEV features in channels-last memory (same logical (B,T,C,X,Y) tensor): what the NHWC convolutions of the
+        # temporal model read; False gives the reference's contiguous layout (stp3.py:230-232)
+        self.bev_channels_last = True
         self._grid = None
         self._side_stream = None
         self.prebuilt_plan = None           # set by ``prepare_plan``: forward then does no host work at all
@@ -126,8 +128,7 @@ class STP3(nn.Module):
         rf = self.receptive_field
         grid = self.lift_grid(device)
         self.prebuilt_plan = ops.LiftPlan.build(grid, intrinsics[:, :rf], extrinsics[:, :rf], future_egomotion[:, :rf],
-                                                self.encoder_out_channels, deterministic=self.deterministic_pool,
-                                                out=out)
+                                                self.encoder_out_channels, out=out)
         return self.prebuilt_plan
 
     def calculate_birds_eye_view_features(self, image, intrinsics, extrinsics, future_egomotion):
@@ -140,7 +141,7 @@ class STP3(nn.Module):
             feat, depth = self.encoder(image.reshape(b * s * n, c, h, w))
             feat = feat.view(b, s, n, *feat.shape[1:])
             depth = depth.view(b, s, n, *depth.shape[1:])
-            return ops.lift_splat(feat, depth, self.prebuilt_plan, self.discount), depth, None
+            return ops.lift_splat(feat, depth, self.prebuilt_plan, self.discount, self.bev_channels_last), depth, None
         # geometry-only work goes to a side stream: it overlaps the image encoder below
         cur = torch.cuda.current_stream(dev)
         if self._side_stream is None:
@@ -149,17 +150,16 @@ class STP3(nn.Module):
         if intrinsics.is_cuda or extrinsics.is_cuda or future_egomotion.is_cuda:
             side.wait_stream(cur)           # pose tensors may still be in flight on the main stream
         with torch.cuda.stream(side):
-            plan = ops.LiftPlan.build(grid, intrinsics, extrinsics, future_egomotion, self.encoder_out_channels,
-                                      deterministic=self.deterministic_pool)
+            plan = ops.LiftPlan.build(grid, intrinsics, extrinsics, future_egomotion, self.encoder_out_channels)
         feat, depth = self.encoder(image.reshape(b * s * n, c, h, w))
         cur.wait_stream(side)
         # the plan's buffers were allocated on the side stream but are read by the pooling kernels (forward AND
         # backward) on the main stream: tell the allocator, or the next step's build may reuse them too early
-        for buf in (plan.mats, plan.counts, plan.vox_pm, plan.plan):
+        for buf in (plan.mats, plan.counts, plan.vox_cm, plan.plan):
             buf.record_stream(cur)
         feat = feat.view(b, s, n, *feat.shape[1:])
         depth = depth.view(b, s, n, *depth.shape[1:])
-        bev = ops.lift_splat(feat, depth, plan, self.discount)
+        bev = ops.lift_splat(feat, depth, plan, self.discount, self.bev_channels_last)
         return bev, depth, None
 
     def forward(self, image, intrinsics, extrinsics, future_egomotion):

@@ -25,14 +25,6 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-# EXPERIMENTAL: C++ launch path of the custom operators (csrc/host/stp3_host.cpp), selected with STP3_CPP_OPS=1.
-# Same C ABI, same arithmetic, ~4x less host time per call; single-process BatchNorm only.
-_CPP = None
-if os.environ.get('STP3_CPP_OPS', '0') == '1':
-    from . import _stp3_host as _CPP          # built by csrc/host/build_host.py (see __graft_entry__.build)
-    _CPP.init(_lib.LIB_PATH)
-
-
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -174,85 +166,107 @@ def voxel_index(grid, dims, cam_m, cam_t, ego_r, ego_t, order=VOX_REFERENCE, cou
 
 
 class LiftPlan:
-    """Geometry-only pooling plan for one batch: voxel ids (pixel-major) + per-voxel point lists.
+    """Geometry-only pooling plan for one batch: voxel ids (``vox_cm``: column-major [B*T, N*fW, D, fH]) + per-voxel
+    lists of column runs.
 
     Built from camera/ego poses alone, i.e. independent of the image encoder -- ``build`` can be
     issued on a side stream while the encoder runs (see ``STP3.forward``).
     """
 
-    def __init__(self, dims, vox_pm, plan, counts):
-        self.dims, self.vox_pm, self.plan, self.counts = dims, vox_pm, plan, counts
+    def __init__(self, dims, vox_cm, plan, counts):
+        self.dims, self.vox_cm, self.plan, self.counts = dims, vox_cm, plan, counts
 
     @staticmethod
-    def build(grid, intrinsics, extrinsics, future_egomotion, channels, deterministic=True, out=None):
-        """``out``: a plan of the same shape whose device buffers are overwritten in place (static
-        addresses: what a captured hipGraph of the training step needs)."""
+    def build(grid, intrinsics, extrinsics, future_egomotion, channels, out=None):
+        """``out``: a plan of the same shape whose device buffers are overwritten in place (static addresses)."""
         b, s, n = intrinsics.shape[:3]
         dims = make_dims(b, s, n, grid.D, grid.fH, grid.fW, channels, grid.X, grid.Y, grid.Z)
         mats = torch.cat([m.reshape(-1) for m in lift_matrices(intrinsics, extrinsics, future_egomotion)])
+        lib = _lib.lib()
         if out is not None:
             assert bytes(out.dims) == bytes(dims), 'LiftPlan.build(out=...): shape changed'
             out.mats_host = mats                    # keep the staging source alive until the next rebuild
             out.mats.copy_(mats, non_blocking=True)
-            mats = out.mats
-            out.counts.zero_()
-            counts = out.counts
+            mats, counts, vox_cm, plan, nbytes = out.mats, out.counts, out.vox_cm, out.plan, out.plan.numel()
         else:
             mats = mats.to(grid.device, non_blocking=True)
+            # run counters: zero once; every build counts them up and back down to zero
             counts = torch.zeros(dims.BT, dims.V, dtype=torch.int32, device=grid.device)
+            vox_cm = torch.empty(dims.BT, dims.P, dtype=torch.int32, device=grid.device)
+            size = ctypes.c_size_t()
+            check(lib.stp3_lift_plan_bytes(ctypes.byref(dims), ctypes.byref(size)), 'stp3_lift_plan_bytes')
+            nbytes = size.value
+            plan = torch.empty(nbytes, dtype=torch.uint8, device=grid.device)
+        _need_gpu(mats)
         n_cam = b * s * n
         cam_m = mats[:n_cam * 9]
         cam_t = mats[n_cam * 9:n_cam * 12]
         ego_r = mats[n_cam * 12:n_cam * 12 + b * s * 9]
         ego_t = mats[n_cam * 12 + b * s * 9:]
         with _timed('plan_build'):
-            vox_pm = voxel_index(grid, dims, cam_m, cam_t, ego_r, ego_t, VOX_PIXELMAJOR,
-                                 out=None if out is None else out.vox_pm)
-            plan = LiftPlan._finish(grid, dims, vox_pm, counts, deterministic, out)
-        plan.mats = mats
-        return plan
-
-    @staticmethod
-    def _finish(grid, dims, vox_pm, counts, deterministic, out=None):
-        nbytes = ctypes.c_size_t()
-        check(_lib.lib().stp3_lift_plan_bytes(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_lift_plan_bytes')
-        plan = out.plan if out is not None else torch.empty(nbytes.value, dtype=torch.uint8, device=grid.device)
-        rc = _lib.lib().stp3_lift_plan_build(ctypes.byref(dims), _ptr(vox_pm), _ptr(counts), _ptr(plan),
-                                             ctypes.c_size_t(nbytes.value), int(bool(deterministic)), _stream())
+            rc = lib.stp3_lift_plan_build(ctypes.byref(dims), _ptr(cam_m), _ptr(cam_t), _ptr(ego_r), _ptr(ego_t),
+                                          _ptr(grid.xs), _ptr(grid.ys), _ptr(grid.ds), _ptr(grid.off), _ptr(grid.res),
+                                          _ptr(vox_cm), _ptr(counts), _ptr(plan), ctypes.c_size_t(nbytes), _stream())
         check(rc, 'stp3_lift_plan_build')
-        return out if out is not None else LiftPlan(dims, vox_pm, plan, counts)
+        res = out if out is not None else LiftPlan(dims, vox_cm, plan, counts)
+        res.mats = mats
+        return res
 
     @staticmethod
     def _align256(n):
         return (n + 255) & ~255
 
-    def run_base(self):
-        """[BT, N*fW*D + 1] int32 view: exclusive scan of the runs per (camera, column, depth bin)."""
+    def voxel_ids(self):
+        """The ids as a (B, T, N, D, fH, fW) view -- the reference's index order (stp3.py:284)."""
         d = self.dims
-        nq = d.N * d.fW * d.D
-        return self.plan[:d.BT * (nq + 1) * 4].view(torch.int32).view(d.BT, nq + 1)
+        return self.vox_cm.view(d.B, d.T, d.N, d.fW, d.D, d.fH).permute(0, 1, 2, 4, 5, 3)
 
     def offsets(self):
-        """[BT, V+1] int32 view: exclusive scan of the runs per voxel (= row ranges of the forward workspace)."""
+        """[BT, V+1] int32 view: exclusive scan of the runs per voxel."""
         d = self.dims
-        o = self._align256(d.BT * (d.N * d.fW * d.D + 1) * 4)
-        return self.plan[o:o + d.BT * (d.V + 1) * 4].view(torch.int32).view(d.BT, d.V + 1)
+        return self.plan[:d.BT * (d.V + 1) * 4].view(torch.int32).view(d.BT, d.V + 1)
+
+    def _sections(self):
+        d = self.dims
+        a = self._align256
+        sizes = [a(d.BT * (d.V + 1) * 4), a(d.BT * d.P * 8), a(d.B * (d.V + 1) * 4), a(d.B * (d.V + 1) * 4), a(d.BT * d.P * 16)]
+        starts = [sum(sizes[:i]) for i in range(len(sizes))]
+        return starts
+
+    def descriptors(self):
+        """[BT, P, 4] int32 view of the ordered run list: (col << 20 | d << 14 | h0 << 7 | len - 1, voxel id, first
+        feature row, first probability -- both relative to the frame); the runs of the work group [a, e) of frame bt
+        are rows offsets()[bt, a] .. offsets()[bt, e], longest first."""
+        d = self.dims
+        o = self._sections()[4]
+        return self.plan[o:o + d.BT * d.P * 16].view(torch.int32).view(d.BT, d.P, 4)
+
+    def groups(self):
+        """Per sample: the first voxel of every work group of the forward kernel, closed by V (list of 1-D int32
+        tensors).  A group holds at most 16 consecutive voxels and ~32 runs over the sample's T frames."""
+        d = self.dims
+        st = self._sections()
+        gidx = self.plan[st[2]:st[2] + d.B * (d.V + 1) * 4].view(torch.int32).view(d.B, d.V + 1)
+        glist = self.plan[st[3]:st[3] + d.B * (d.V + 1) * 4].view(torch.int32).view(d.B, d.V + 1)
+        return [glist[b, :int(gidx[b, d.V]) + 1] for b in range(d.B)]
 
 
 def depth_softmax(dims, logits_pm):
+    """logits [BT, NPIX, D] (pixel-major) -> probabilities [BT, N*fW, D, fH] (column-major, see include/stp3_hip.h)."""
     _need_gpu(logits_pm)
-    prob = torch.empty_like(logits_pm)
+    prob = torch.empty(dims.BT, dims.N * dims.fW, dims.D, dims.fH, dtype=torch.float32, device=logits_pm.device)
     check(_lib.lib().stp3_depth_softmax(ctypes.byref(dims), _ptr(logits_pm), _ptr(prob), _stream()),
           'stp3_depth_softmax')
     return prob
 
 
+BEV_CHANNELS_FIRST, BEV_CHANNELS_LAST = _lib.BEV_CHANNELS_FIRST, _lib.BEV_CHANNELS_LAST
 _WORKSPACE = {}
 
 
 def lift_workspace(dims, device):
-    """Scratch for the run vectors of ``stp3_lift_splat_fwd`` (one buffer per device, grown on demand and
-    reused by every call: it is dead as soon as the forward kernels have run)."""
+    """Scratch of the pooling calls (one buffer per device, grown on demand): the voxel-major gradient G_t of the
+    backward and, for the reference (channels-first) layout, the channels-last BEV before the transpose pass."""
     nbytes = ctypes.c_size_t()
     check(_lib.lib().stp3_lift_workspace_bytes(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_lift_workspace_bytes')
     key = torch.device(device)
@@ -264,10 +278,11 @@ def lift_workspace(dims, device):
 
 
 class _LiftSplat(torch.autograd.Function):
-    """feat_pm [BT,NPIX,C], logits_pm [BT,NPIX,D] (float32, contiguous) -> bev [B,T,C,X,Y]."""
+    """feat_pm [BT,NPIX,C], logits_pm [BT,NPIX,D] (float32, contiguous) -> bev of logical shape [B,T,C,X,Y];
+    ``channels_last``: its memory is [B,T,X,Y,C] (no transpose passes), else the reference's [B,T,C,X,Y]."""
 
     @staticmethod
-    def forward(ctx, feat_pm, logits_pm, lift_plan, discount):
+    def forward(ctx, feat_pm, logits_pm, lift_plan, discount, channels_last):
         _need_gpu(feat_pm, logits_pm)
         d = lift_plan.dims
         feat_pm = feat_pm.contiguous()
@@ -276,44 +291,60 @@ class _LiftSplat(torch.autograd.Function):
         assert feat_pm.shape == (d.BT, d.NPIX, d.C) and logits_pm.shape == (d.BT, d.NPIX, d.D)
         with _timed('depth_softmax'):
             prob = depth_softmax(d, logits_pm)
-        bev = torch.empty(d.B, d.T, d.C, d.X, d.Y, dtype=torch.float32, device=feat_pm.device)
-        ws, ws_bytes = lift_workspace(d, feat_pm.device)
+        dev = feat_pm.device
+        layout = BEV_CHANNELS_LAST if channels_last else BEV_CHANNELS_FIRST
+        shape = (d.B, d.T, d.X, d.Y, d.C) if channels_last else (d.B, d.T, d.C, d.X, d.Y)
+        bev = torch.empty(shape, dtype=torch.float32, device=dev)
+        ws, ws_bytes = lift_workspace(d, dev)
+        ws_ptr = _ptr(ws)
         with _timed('lift_splat_fwd'):
-            rc = _lib.lib().stp3_lift_splat_fwd(ctypes.byref(d), _ptr(feat_pm), _ptr(prob), _ptr(lift_plan.vox_pm),
-                                                _ptr(lift_plan.plan), ctypes.c_float(discount), _ptr(ws),
-                                                ctypes.c_size_t(ws_bytes), _ptr(bev), _stream())
+            rc = _lib.lib().stp3_lift_splat_fwd(ctypes.byref(d), _ptr(feat_pm), _ptr(prob), _ptr(lift_plan.plan),
+                                                ctypes.c_float(discount), layout, ws_ptr, ctypes.c_size_t(ws_bytes),
+                                                _ptr(bev), _stream())
         check(rc, 'stp3_lift_splat_fwd')
         ctx.save_for_backward(feat_pm, prob)
         ctx.lift_plan = lift_plan
         ctx.discount = discount
-        return bev
+        ctx.channels_last = channels_last
+        return bev.permute(0, 1, 4, 2, 3) if channels_last else bev
 
     @staticmethod
     def backward(ctx, grad_bev):
         feat_pm, prob = ctx.saved_tensors
         d = ctx.lift_plan.dims
-        grad_bev = grad_bev.contiguous().float()
-        gacc = torch.empty(d.BT, d.V, d.C, dtype=torch.float32, device=grad_bev.device)
+        if ctx.channels_last:
+            # taken as it comes when it already is [B,T,X,Y,C] memory in float32 / bfloat16; copied once otherwise
+            if grad_bev.dtype not in (torch.float32, torch.bfloat16):
+                grad_bev = grad_bev.float()
+            grad_bev = grad_bev.permute(0, 1, 3, 4, 2).contiguous()
+            layout = BEV_CHANNELS_LAST
+        else:
+            grad_bev = grad_bev.contiguous().float()
+            layout = BEV_CHANNELS_FIRST
+        gdt = _lib.DTYPE_BF16 if grad_bev.dtype == torch.bfloat16 else _lib.DTYPE_F32
+        ws, ws_bytes = lift_workspace(d, grad_bev.device)
         grad_feat = torch.empty_like(feat_pm)
-        grad_logits = torch.empty_like(prob)
+        grad_logits = torch.empty(d.BT, d.NPIX, d.D, dtype=torch.float32, device=prob.device)
         with _timed('lift_splat_bwd'):
-            rc = _lib.lib().stp3_lift_splat_bwd(ctypes.byref(d), _ptr(grad_bev), _ptr(feat_pm), _ptr(prob),
-                                                _ptr(ctx.lift_plan.vox_pm), ctypes.c_float(ctx.discount),
-                                                _ptr(gacc), _ptr(grad_feat), _ptr(grad_logits), _stream())
+            rc = _lib.lib().stp3_lift_splat_bwd(ctypes.byref(d), _ptr(grad_bev), layout, gdt, _ptr(feat_pm), _ptr(prob),
+                                                _ptr(ctx.lift_plan.vox_cm), ctypes.c_float(ctx.discount), _ptr(ws),
+                                                ctypes.c_size_t(ws_bytes), _ptr(grad_feat), _ptr(grad_logits), _stream())
         check(rc, 'stp3_lift_splat_bwd')
-        return grad_feat, grad_logits, None, None
+        return grad_feat, grad_logits, None, None, None
 
 
-def lift_splat(feat, depth_logits, lift_plan, discount):
+def lift_splat(feat, depth_logits, lift_plan, discount, channels_last=False):
     """Differentiable lift + voxel pool.
 
     feat (B,T,N,C,fH,fW) and depth_logits (B,T,N,D,fH,fW) in any memory format (channels-last
-    memory makes the re-layout free); returns the BEV features (B,T,C,X,Y) float32 in the
-    reference's layout (stp3.py:230-232, always float32 even under autocast)."""
+    memory makes the re-layout free); returns the BEV features (B,T,C,X,Y) float32 (always float32, even
+    under autocast: stp3.py:230-232).  ``channels_last=False``: contiguous, the reference's layout;
+    ``True``: the same logical tensor stored [B,T,X,Y,C] -- what the NHWC convolutions downstream read and
+    what their gradient arrives in -- with no transpose pass on either side."""
     d = lift_plan.dims
     feat_pm = feat.float().permute(0, 1, 2, 4, 5, 3).reshape(d.BT, d.NPIX, d.C)
     logits_pm = depth_logits.float().permute(0, 1, 2, 4, 5, 3).reshape(d.BT, d.NPIX, d.D)
-    return _LiftSplat.apply(feat_pm, logits_pm, lift_plan, float(discount))
+    return _LiftSplat.apply(feat_pm, logits_pm, lift_plan, float(discount), bool(channels_last))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -432,18 +463,15 @@ def depthwise_conv2d(x, weight, stride=1, pad=(0, 0, 0, 0)):
     run in the autocast dtype (bf16); the weights are consumed in float32 either way."""
     if torch.is_autocast_enabled():
         x = x.to(torch.get_autocast_gpu_dtype())
-    if _CPP is not None:
-        if x.dtype not in (torch.float32, torch.bfloat16):
-            raise _lib.Stp3HipError(f'depthwise conv supports float32 / bfloat16, got {x.dtype}')
-        return _CPP.depthwise_conv2d(x, weight, int(stride), int(pad[0]), int(pad[1]), int(pad[2]), int(pad[3]))
     return _DW_APPLY(x, weight, int(stride), tuple(int(p) for p in pad))
 
 
-# EXPERIMENTAL (STP3_LAZY_BN_COUNTER=1): ``num_batches_tracked`` -- one int64 increment KERNEL per BatchNorm layer and
-# step in the reference -- is counted on the host and applied to all layers with one multi-tensor add, at the end of
-# the optimizer step (parallel.FlatAdam) and before any ``state_dict()`` of a BatchNorm module.  The counter only
-# feeds the cumulative-average mode (momentum=None), which keeps the immediate increment.
-LAZY_COUNTERS = os.environ.get('STP3_LAZY_BN_COUNTER', '0') == '1'
+# ``num_batches_tracked`` -- one int64 increment KERNEL per BatchNorm layer and step in the reference -- is counted on
+# the host and applied to all layers with one multi-tensor add: at the end of the optimizer step (parallel.FlatAdam),
+# before any ``state_dict()`` of a BatchNorm module, or on ``flush_batch_counters()``.  The counter only feeds the
+# cumulative-average mode (momentum=None), which keeps the immediate increment.  Validated bit-identical
+# (tests/test_host_cpu.py); measured neutral-to-positive on the MI355X (profiles/r02_ab_greedy_switches.json).
+LAZY_COUNTERS = True
 _PENDING_COUNTS = {}          # id(buffer) -> [buffer, increments]
 
 
@@ -680,10 +708,6 @@ def bn_act(x, weight, bias, running_mean, running_var, training, momentum, eps, 
     ``group=False`` disables the cross-replica statistics even when torch.distributed is initialised."""
     if res is None:
         res_mode = RES_NONE
-    if _CPP is not None and (group is False or not (torch.distributed.is_available() and torch.distributed.is_initialized()
-                                                    and torch.distributed.get_world_size(group) > 1)):
-        return _CPP.bn_act(x, weight, bias, res, sbias, oscale, running_mean, running_var, bool(training),
-                           float(momentum if momentum is not None else 0.1), float(eps), int(act), int(res_mode))
     return _BN_APPLY(x, weight, bias, res, sbias, oscale, running_mean, running_var, bool(training),
                         float(momentum if momentum is not None else 0.1), float(eps), int(act), int(res_mode), group)
 
@@ -699,8 +723,12 @@ def _conv_out(size, k, stride, pad, dil):
     return (size + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-def _conv2d_launch(x, wb, bias, stride, pad, dil, out_dtype):
-    """x (N,Cin,H,W) bf16 with channels-last memory (row stride ld >= Cin); wb (Cout,Cin,KH,KW) bf16 channels-last."""
+_CONV_STAT_WS = {}
+
+
+def _conv2d_launch(x, wb, bias, stride, pad, dil, out_dtype, sums_ptr=None):
+    """x (N,Cin,H,W) bf16 with channels-last memory (row stride ld >= Cin); wb (Cout,Cin,KH,KW) bf16 channels-last.
+    ``sums_ptr``: device address of a float32 [2][Cout] buffer that receives the BatchNorm statistics of y (bf16 y)."""
     n, cin, h, w = x.shape
     cout, _, kh, kw = wb.shape
     x, ldx = _rows_view(x)
@@ -708,15 +736,23 @@ def _conv2d_launch(x, wb, bias, stride, pad, dil, out_dtype):
     y = torch.empty((n, cout, ho, wo), dtype=out_dtype, device=x.device, memory_format=torch.channels_last)
     dims = _lib.ConvDims(n, h, w, cin, ho, wo, cout, kh, kw, stride, pad[0], pad[1], dil[0], dil[1], ldx, cout,
                          _lib.DTYPE_F32 if out_dtype == torch.float32 else _lib.DTYPE_BF16, int(bias is not None))
-    check(_lib.lib().stp3_conv2d_fwd(ctypes.byref(dims), _ptr(x), _ptr(wb), _opt_ptr(bias), _ptr(y), _stream()),
-          'stp3_conv2d_fwd')
+    lib = _lib.lib()
+    ws_ptr, ws_bytes = None, 0
+    if sums_ptr is not None:
+        nbytes = ctypes.c_size_t()
+        check(lib.stp3_conv2d_fwd_workspace(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_conv2d_fwd_workspace')
+        key = torch.device(x.device)
+        ws = _CONV_STAT_WS.get(key)
+        if ws is None or ws.numel() < nbytes.value:
+            ws = torch.empty(max(nbytes.value, 8 << 20), dtype=torch.uint8, device=key)
+            _CONV_STAT_WS[key] = ws
+        ws_ptr, ws_bytes = ws.data_ptr(), nbytes.value
+    check(lib.stp3_conv2d_fwd(ctypes.byref(dims), _ptr(x), _ptr(wb), _opt_ptr(bias), _ptr(y), sums_ptr, ws_ptr, ws_bytes,
+                              _stream()), 'stp3_conv2d_fwd')
     return y
 
 
 _CONV_WORKSPACE = {}
-# The weight-gradient kernel works on 128 x 128 (Cout x Cin) tiles: below that the vendor kernel is faster today
-# (profiles/r01_time_conv.txt).  Tests set this to 0 to exercise the kernel on every shape.
-WGRAD_MIN_CHANNELS = int(os.environ.get('STP3_WGRAD_MIN_CHANNELS', '128'))   # A/B knob; 128 = measured break-even
 
 
 def _conv2d_wgrad(dy, x, wshape, stride, pad, dil):
@@ -753,12 +789,10 @@ def conv2d_supported(x, weight, stride, groups=1):
 # instead of one per use.
 _WEIGHT_CACHE = {}
 _WEIGHT_EPOCH = [0]
-WEIGHT_CACHE_ENABLED = True          # graph.GraphedTrainStep turns it off: the casts must be part of every replay
 
 
-# EXPERIMENTAL (STP3_WEIGHT_PREP=1): the bf16 copies become persistent SHADOW buffers that one launch of
-# stp3_conv2d_prep_weights rewrites for all layers after an optimizer step, instead of ~5 torch operators per layer.
-_WEIGHT_PREP = os.environ.get('STP3_WEIGHT_PREP', '0') == '1'
+# The bf16 copies of PARAMETERS are persistent shadow buffers that one launch of stp3_conv2d_prep_weights rewrites for
+# all layers after an optimizer step, instead of ~5 torch operators per layer (validated on the MI355X, round 2).
 
 
 class _WeightShadows:
@@ -826,19 +860,16 @@ def invalidate_weight_cache():
     """Call after updating parameters through storage the parameter's version counter does not see (the flat
     buffers of ``parallel.FlatAdam``); in-place updates of the parameters themselves are detected automatically."""
     _WEIGHT_EPOCH[0] += 1
-    if _CPP is not None:
-        _CPP.invalidate_weight_cache()
-    if _WEIGHT_PREP and WEIGHT_CACHE_ENABLED:
-        _SHADOWS.refresh()
+    _SHADOWS.refresh()
 
 
 def _bf16_weights(weight, need_flipped=False):
-    if _WEIGHT_PREP and WEIGHT_CACHE_ENABLED and weight.is_leaf and weight.requires_grad \
-            and weight.dtype == torch.float32:
+    if isinstance(weight, torch.nn.Parameter) and weight.requires_grad \
+            and weight.dtype == torch.float32 and weight.is_cuda:
         ent = _SHADOWS.lookup(weight) or _SHADOWS.register(weight)
         return ent['wb'], ent['wt']
     key = id(weight)
-    ent = _WEIGHT_CACHE.get(key) if WEIGHT_CACHE_ENABLED else None
+    ent = _WEIGHT_CACHE.get(key)
     ver = (weight._version, _WEIGHT_EPOCH[0])
     # id() values are recycled: an entry only counts when it still points at THIS live parameter (weak reference),
     # at the same storage, shape and strides
@@ -848,7 +879,7 @@ def _bf16_weights(weight, need_flipped=False):
     if ent is None:
         wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         ent = [ver, weight.data_ptr(), wb, None, None, None]
-        if WEIGHT_CACHE_ENABLED and isinstance(weight, torch.nn.Parameter) and weight.requires_grad:
+        if isinstance(weight, torch.nn.Parameter) and weight.requires_grad:
             # parameters only: temporaries (weight slices, padded copies) die with the call
             ent[4] = weakref.ref(weight)
             ent[5] = (tuple(weight.shape), tuple(weight.stride()))
@@ -882,9 +913,19 @@ class _Conv2dMfma(torch.autograd.Function):
     def backward(ctx, dy):
         x, wb = ctx.saved_tensors
         stride, pad, dil, has_bias, wdtype, bdtype = ctx.cfg
-        cout, cin, kh, kw = wb.shape
+        cout_true, cin, kh, kw = wb.shape
         dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        dx = dw = db = None
+        db = None
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.float().sum(dim=(0, 2, 3)).to(bdtype)
+        cpad = (-cout_true) % 8
+        if cpad:
+            # the 1 / 2 / 4-channel heads: dy and the weight get zero channels up to a multiple of 8, so that both
+            # gradients run on the MFMA kernels too (16-byte channel pieces); the extra rows of dw are dropped
+            dy = torch.nn.functional.pad(dy, (0, 0, 0, 0, 0, cpad)).contiguous(memory_format=torch.channels_last)
+            wb = torch.nn.functional.pad(wb, (0, 0, 0, 0, 0, 0, 0, cpad)).contiguous(memory_format=torch.channels_last)
+        cout = cout_true + cpad
+        dx = dw = None
         bpad = (dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1])
         need_dx = ctx.needs_input_grad[0]
         hip_dx = need_dx and cout % 8 == 0 and bpad[0] >= 0 and bpad[1] >= 0
@@ -892,7 +933,7 @@ class _Conv2dMfma(torch.autograd.Function):
             # dL/dx = stride-1 convolution of dy (zero-stuffed to the input resolution when stride > 1) with the
             # taps flipped and Cin / Cout swapped
             w_now = ctx.weight_ref
-            if w_now is not None and w_now.is_leaf and w_now.requires_grad:
+            if not cpad and w_now is not None and w_now.is_leaf and w_now.requires_grad:
                 wt = _bf16_weights(w_now, need_flipped=True)[1]
             else:
                 wt = wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
@@ -907,23 +948,20 @@ class _Conv2dMfma(torch.autograd.Function):
                 g[:, :, ::stride, ::stride][:, :, :ho, :wo] = dy
             dx = _conv2d_launch(g, wt, None, 1, bpad, dil, torch.bfloat16)
         need_dw = ctx.needs_input_grad[1]
-        need_db = has_bias and ctx.needs_input_grad[2]
-        hip_dw = need_dw and cin % 4 == 0 and cout % 4 == 0 and (WGRAD_MIN_CHANNELS <= min(cin, cout))
+        hip_dw = need_dw and cin % 8 == 0
         if hip_dw:
-            dw = _conv2d_wgrad(dy, x, (cout, cin, kh, kw), stride, pad, dil).to(wdtype)
-            if need_db:
-                db = dy.float().sum(dim=(0, 2, 3)).to(bdtype)
-        mask = [need_dx and not hip_dx, need_dw and not hip_dw, need_db and not hip_dw]
+            dw = _conv2d_wgrad(dy, x, (cout, cin, kh, kw), stride, pad, dil)[:cout_true].to(wdtype)
+        mask = [need_dx and not hip_dx, need_dw and not hip_dw, False]
         if any(mask):
+            # not reached by the model (every layer satisfies the kernels' constraints); kept so that an odd
+            # convolution still differentiates
             xd = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
-            gx, gw, gb = torch.ops.aten.convolution_backward(dy, xd, wb, [cout] if has_bias else None, [stride, stride],
-                                                             list(pad), list(dil), False, [0, 0], 1, mask)
+            gx, gw, _ = torch.ops.aten.convolution_backward(dy, xd, wb, None, [stride, stride], list(pad), list(dil), False,
+                                                            [0, 0], 1, mask)
             if mask[0]:
                 dx = gx
             if mask[1]:
-                dw = gw.to(wdtype)
-            if mask[2]:
-                db = gb.to(bdtype)
+                dw = gw[:cout_true].to(wdtype)
         return dx, dw, db, None, None, None, None
 
 
@@ -933,8 +971,4 @@ _CONV_APPLY = _fast_apply(_Conv2dMfma)
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, out_dtype=torch.bfloat16):
     """Dense conv through the MFMA implicit-GEMM kernel (bf16 operands, float32 accumulation)."""
     s = _pair(stride)
-    if _CPP is not None:
-        p, d = _pair(padding), _pair(dilation)
-        _CPP.set_wgrad_min_channels(int(WGRAD_MIN_CHANNELS))
-        return _CPP.conv2d(x, weight, bias, s[0], p[0], p[1], d[0], d[1], out_dtype == torch.float32)
     return _CONV_APPLY(x, weight, bias, s[0], _pair(padding), _pair(dilation), out_dtype)

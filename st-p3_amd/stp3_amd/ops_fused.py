@@ -1,13 +1,15 @@
-"""EXPERIMENTAL (off unless STP3_CONV_V2=1): convolution -> BatchNorm -> activation (-> + skip) as one
-autograd operator on top of ``stp3_conv2d_fwd_v2`` (csrc/stp3_conv2.hip), whose epilogue produces the BatchNorm
-statistics, so the forward makes ONE pass over the convolution output less than ``conv2d`` + ``bn_act``:
+"""Fused operators of the camera trunk and the BEV networks on top of the C ABI:
 
-    y = act(BN(conv(x, w) + b) [+ res]) [+ res]
+``conv_bn_act``   convolution -> BatchNorm -> activation (-> + skip) as one autograd operator.  The epilogue of
+                  ``stp3_conv2d_fwd`` (csrc/stp3_conv.hip) produces the BatchNorm statistics, so the forward makes ONE
+                  pass over the convolution output less than ``ops.conv2d`` + ``ops.bn_act``:
 
-Replaces the same reference chains as ``ops.conv2d`` + ``ops.bn_act`` (stp3/layers/convolutions.py:183-280,
-stp3/layers/temporal.py:252-325, stp3/models/decoder.py:22-140, MBConv 1x1 -> BN -> swish).  Training mode only;
-everything else (evaluation, float32 parity runs, unsupported shapes) takes the two separate operators.
-Not yet validated on hardware: tests/test_conv_v2_gpu.py runs only with STP3_EXPERIMENTAL=1.
+                      y = act(BN(conv(x, w) + b) [+ res]) [+ res]
+
+                  Replaces the same reference chains as those two operators (stp3/layers/convolutions.py:183-280,
+                  stp3/layers/temporal.py:252-325, stp3/models/decoder.py:22-140, MBConv 1x1 -> BN -> swish).
+                  Training mode with bf16 activations only; evaluation and float32 runs take the separate operators.
+``se_block``      squeeze-and-excitation (EfficientNet MBConv): pooled mean, the two 1x1 layers and the gate.
 """
 import ctypes
 import os
@@ -18,8 +20,8 @@ from . import _lib, ops
 from ._lib import check
 
 _WS = {}
-# EXPERIMENTAL on top of STP3_FUSED_SE: the gate's two fully-connected layers through stp3_se_mlp_fwd / _bwd
-_SE_MLP = os.environ.get('STP3_SE_MLP', '0') == '1'
+# the gate's two fully-connected layers through stp3_se_mlp_fwd / _bwd (one launch forward, one backward)
+_SE_MLP = True
 
 
 def _workspace(nbytes, device):
@@ -33,23 +35,7 @@ def _workspace(nbytes, device):
 def conv2d_v2(x, wb, bias, stride, pad, dil, sums_ptr=None):
     """Raw launch: x (N,Cin,H,W) bf16 channels-last view, wb (Cout,Cin,KH,KW) bf16 channels-last -> y bf16.
     ``sums_ptr``: device address of a float32 [2][Cout] buffer that receives the BatchNorm statistics of y."""
-    n, cin, h, w = x.shape
-    cout, _, kh, kw = wb.shape
-    x, ldx = ops._rows_view(x)
-    ho, wo = ops._conv_out(h, kh, stride, pad[0], dil[0]), ops._conv_out(w, kw, stride, pad[1], dil[1])
-    y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-    dims = _lib.ConvDims(n, h, w, cin, ho, wo, cout, kh, kw, stride, pad[0], pad[1], dil[0], dil[1], ldx, cout,
-                         _lib.DTYPE_BF16, int(bias is not None))
-    lib = _lib.lib()
-    ws_ptr, ws_bytes = None, 0
-    if sums_ptr is not None:
-        nbytes = ctypes.c_size_t()
-        check(lib.stp3_conv2d_fwd_v2_workspace(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_conv2d_fwd_v2_workspace')
-        ws = _workspace(nbytes.value, x.device)
-        ws_ptr, ws_bytes = ws.data_ptr(), nbytes.value
-    check(lib.stp3_conv2d_fwd_v2(ctypes.byref(dims), x.data_ptr(), wb.data_ptr(), ops._opt_ptr(bias), y.data_ptr(), sums_ptr,
-                                 ws_ptr, ws_bytes, ops._stream_handle()), 'stp3_conv2d_fwd_v2')
-    return y
+    return ops._conv2d_launch(x, wb, bias, stride, pad, dil, torch.bfloat16, sums_ptr=sums_ptr)
 
 
 class _ConvBnAct(torch.autograd.Function):
@@ -156,7 +142,7 @@ class _ConvBnAct(torch.autograd.Function):
             dx = conv2d_v2(g, wt, None, 1, bpad, dil)
         need_dw = ctx.needs_input_grad[1]
         need_db = has_cbias and ctx.needs_input_grad[2]
-        hip_dw = need_dw and cin % 4 == 0 and cout % 4 == 0 and ops.WGRAD_MIN_CHANNELS <= min(cin, cout)
+        hip_dw = need_dw and cin % 8 == 0 and cout % 8 == 0
         if hip_dw:
             dw = ops._conv2d_wgrad(dconv, x, (cout, cin, kh, kw), stride, pad, dil).to(wdt)
             if need_db:

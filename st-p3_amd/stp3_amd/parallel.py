@@ -24,8 +24,8 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
-# EXPERIMENTAL: clipping + Adam through stp3_optim_clip_adam (csrc/stp3_optim.hip), see FlatAdam.clip_and_step
-_FUSED_ADAM = os.environ.get('STP3_FUSED_ADAM', '0') == '1'
+# clipping + Adam through stp3_optim_clip_adam (csrc/stp3_optim.hip) on GPU buckets, see FlatAdam.clip_and_step
+FUSED_ADAM = True
 
 
 def init_distributed(backend=None):
@@ -54,15 +54,14 @@ def convert_sync_batchnorm(module, process_group=None):
 class GradientBuckets:
     """Flat fp32 parameter / gradient buckets in backward order, all-reduced while backward continues.
 
-    ``gather=False`` (default): every ``p.grad`` IS a view of its bucket, autograd accumulates into it in place (one
-    small ``add_`` per parameter per step, ~480 launches for this model).
-    ``gather=True`` (``STP3_GRAD_GATHER=1``): ``p.grad`` is reset to ``None`` before backward so autograd keeps
-    the incoming gradient tensors as they are, and a finished bucket is filled with one multi-tensor copy; the
-    values are identical (``0 + g`` vs ``g``), the per-parameter launches are gone.  Experimental: switch it on
-    after an A/B on the MI355X."""
+    ``gather=True`` (default): ``p.grad`` is reset to ``None`` before backward so autograd keeps the incoming
+    gradient tensors as they are, and a finished bucket is filled with one multi-tensor copy (``finish()`` fills what
+    the hooks have not); no per-parameter accumulation launches.
+    ``gather=False``: every ``p.grad`` IS a view of its bucket and autograd accumulates into it in place (one small
+    ``add_`` per parameter per step, ~480 launches for this model); same values (``0 + g`` vs ``g``)."""
 
     def __init__(self, module, bucket_bytes=8 << 20, process_group=None, average=True, gather=None):
-        self.gather = (os.environ.get('STP3_GRAD_GATHER', '0') == '1') if gather is None else bool(gather)
+        self.gather = True if gather is None else bool(gather)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
@@ -84,6 +83,7 @@ class GradientBuckets:
             self._close(cur)
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._finished = False
         self._works = []
         self._hooks = []
         if self.world > 1:
@@ -129,6 +129,7 @@ class GradientBuckets:
         self._pending = [len(ps) for _, ps in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._works = []
+        self._finished = False
 
     @torch.no_grad()
     def _gather(self, i):
@@ -160,7 +161,11 @@ class GradientBuckets:
 
     def finish(self):
         """Call after ``backward``: completes buckets that were not launched from the hooks (single process, or
-        parameters that received no gradient), waits for the in-flight all-reduces and averages over ranks."""
+        parameters that received no gradient), waits for the in-flight all-reduces and averages over ranks.
+        Idempotent within a step; the clipping / optimizer entry points call it themselves."""
+        if self._finished:
+            return
+        self._finished = True
         for i in range(len(self.buckets)):
             if not self._launched[i] and (self.gather or self.world > 1):
                 self._launch(i)
@@ -176,6 +181,7 @@ class GradientBuckets:
     def clip_grad_norm_(self, max_norm):
         """Global-norm clipping on the flat buckets (train.py:48 ``gradient_clip_val``)."""
         from .utils import staged_sum
+        self.finish()
         total = torch.sqrt(torch.stack([staged_sum(f.float().square()) for f, _ in self.buckets]).sum())
         scale = torch.clamp(max_norm / (total + 1e-6), max=1.0)
         for flat, _ in self.buckets:
@@ -205,6 +211,7 @@ class FlatAdam:
 
     @torch.no_grad()
     def step(self):
+        self.buckets.finish()
         b1, b2 = self.betas
         self.step_t.add_(1.0)
         bc1 = 1.0 - torch.pow(b1, self.step_t)                      # bias corrections, device scalars
@@ -223,9 +230,10 @@ class FlatAdam:
 
     def clip_and_step(self, max_norm):
         """Gradient-norm clipping followed by the Adam update (the tail of every training step).  Default: the
-        two torch-operator methods above.  ``STP3_FUSED_ADAM=1`` on GPU buckets: three launches of
-        ``stp3_optim_clip_adam`` for all buckets together (EXPERIMENTAL).  Returns the total gradient norm."""
-        if not (_FUSED_ADAM and self.buckets.flat_params[0].is_cuda):
+        two torch-operator methods above (CPU buckets: the gloo tests).  GPU buckets: three launches of
+        ``stp3_optim_clip_adam`` for all buckets together.  Returns the total gradient norm."""
+        self.buckets.finish()
+        if not (FUSED_ADAM and self.buckets.flat_params[0].is_cuda):
             total = self.buckets.clip_grad_norm_(max_norm)
             self.step()
             return total

@@ -21,8 +21,8 @@ from .metrics import IntersectionOverUnion
 from .models.stp3 import STP3
 
 
-# EXPERIMENTAL (STP3_LABEL_WARP=batched): see TrainingModule._prepare_future_labels_batched
-_BATCHED_LABEL_WARP = os.environ.get('STP3_LABEL_WARP', 'per_label') == 'batched'
+# see TrainingModule._prepare_future_labels_batched (bit-identical to the per-label path, tests/test_host_cpu.py)
+_BATCHED_LABEL_WARP = True
 
 
 def _scalar():

@@ -41,6 +41,13 @@ enum hipError_t { hipSuccess = 0, hipErrorInvalidValue = 1 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 8; return hipSuccess; }   // "8 CUs": two 4-wave workgroups per XCD slot
+template <typename F>
+inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 2; return hipSuccess; }
+// launches are synchronous here, so an asynchronous memset is a memset
+inline hipError_t hipMemsetAsync(void* p, int value, size_t bytes, hipStream_t) { std::memset(p, value, bytes); return hipSuccess; }
 
 struct dim3 {
     unsigned x, y, z;
@@ -176,6 +183,8 @@ inline int readfirstlane_i(int v) {
 #define __builtin_amdgcn_readfirstlane(v) readfirstlane_i((int)(v))
 
 template <typename T>
+inline T __shfl(T v, int src, int width = 64) { (void)width; return hipcpu::exchange<T>(v, src); }
+template <typename T>
 inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return hipcpu::exchange<T>(v, hipcpu::cur->lane ^ mask); }
 template <typename T>
 inline T __shfl_up(T v, unsigned delta, int width = 64) {
@@ -292,3 +301,29 @@ inline hipcpu_f32x4 mfma_f32_16x16x32_bf16_(V a, V b, hipcpu_f32x4 c, int, int, 
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 mfma_f32_16x16x32_bf16_
+
+// v_mfma_f32_32x32x16_bf16: A[i = l & 31][k = 8 * (l >> 5) + t], B[k = 8 * (l >> 5) + t][j = l & 31] (t = 0..7),
+// D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31], r = 0..15 (cdna_hip_programming.md section 3)
+typedef float hipcpu_f32x16 __attribute__((ext_vector_type(16)));
+template <typename V>
+inline hipcpu_f32x16 mfma_f32_32x32x16_bf16_(V a, V b, hipcpu_f32x16 c, int, int, int) {
+    static_assert(sizeof(V) == 16, "8 x bf16 per lane");
+    hipcpu::Wave& w = hipcpu::my_wave();
+    const int lane = hipcpu::cur->lane;
+    std::memcpy(w.slot[0][lane], &a, 16);
+    std::memcpy(w.slot[1][lane], &b, 16);
+    w.bar.wait();
+    hipcpu_f32x16 d = c;
+    const int j = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (int half = 0; half < 2; ++half)
+            for (int t = 0; t < 8; ++t)
+                acc += hipcpu_bf16_to_float(w.slot[0][i + 32 * half] + 2 * t) * hipcpu_bf16_to_float(w.slot[1][j + 32 * half] + 2 * t);
+        d[r] = acc;
+    }
+    w.bar.wait();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 mfma_f32_32x32x16_bf16_

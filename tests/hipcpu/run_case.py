@@ -3,8 +3,8 @@ sources executed on CPU threads, tests/hipcpu/build.py) and print the deviations
 
     python tests/hipcpu/run_case.py <libstp3hip_cpu.so> <case>
 
-Driver of tests/test_kernels_on_cpu.py; one process per case because the library reads its switches (STP3_LIFT_FWD,
-STP3_LIFT_BWD, STP3_BN_GEOM) from the environment once."""
+Driver of tests/test_kernels_on_cpu.py; one process per case (the fiber order of the stand-in, HIPCPU_ORDER, is read
+from the environment once)."""
 import ctypes
 import json
 import os
@@ -58,18 +58,33 @@ def case_lift(ops, cfg, batch, seq, cams, seed, golden=None):
     ids = ids.view(b, s, n, grid.D, grid.fH, grid.fW).numpy()
     vox = H.oracle_vox(cfg, intr, extr, ego)
     plan = ops.LiftPlan.build(grid, intr, extr, ego, cfg['out_channels'])
-    pm = plan.vox_pm.view(b, s, n, grid.fH, grid.fW, grid.D).permute(0, 1, 2, 5, 3, 4).numpy()
+    pm = plan.voxel_ids().numpy()
     f, lg = feat.clone().requires_grad_(), logits.clone().requires_grad_()
     bev = ops.lift_splat(f, lg, plan, cfg['discount'])
     again = ops.lift_splat(feat, logits, plan, cfg['discount'])
     go = torch.randn(bev.shape, generator=torch.Generator().manual_seed(seed + 5))
     bev.backward(go)
+    # the channels-last layout (model path: no transpose passes) gives the same bits
+    f2, lg2 = feat.clone().requires_grad_(), logits.clone().requires_grad_()
+    bev_cl = ops.lift_splat(f2, lg2, plan, cfg['discount'], True)
+    bev_cl.backward(go)
+    cl_equal = bool(torch.equal(bev_cl.detach(), bev.detach()) and torch.equal(f2.grad, f.grad) and torch.equal(lg2.grad, lg.grad)
+                    and bev_cl.permute(0, 1, 3, 4, 2).is_contiguous())
+    # a bfloat16 gradient in channels-last memory (what a bf16 consumer hands back) is imported directly
+    go16 = go.permute(0, 1, 3, 4, 2).contiguous().to(torch.bfloat16).permute(0, 1, 4, 2, 3)
+    f3, lg3 = feat.clone().requires_grad_(), logits.clone().requires_grad_()
+    ops.lift_splat(f3, lg3, plan, cfg['discount'], True).backward(go16)
+    f4, lg4 = feat.clone().requires_grad_(), logits.clone().requires_grad_()
+    ops.lift_splat(f4, lg4, plan, cfg['discount'], True).backward(go16.float())
+    cl_equal = cl_equal and bool(torch.equal(f3.grad, f4.grad) and torch.equal(lg3.grad, lg4.grad))
     exact = lo.pool_exact(feat, logits, vox, (grid.X, grid.Y), cfg['discount'])
     gf, gl = lo.pool_backward_exact(go, feat, logits, vox, cfg['discount'])
     out = {'ids_equal_oracle': bool(np.array_equal(ids, vox)), 'pixel_major_ids_equal': bool(np.array_equal(pm, vox)),
            'valid_fraction': float((vox >= 0).mean()), 'fwd_err': err(bev.detach(), exact), 'fwd_scale': float(exact.abs().max()),
            'reproducible': bool(torch.equal(bev.detach(), again)), 'dfeat_err': err(f.grad, gf), 'dlogit_err': err(lg.grad, gl),
-           'grad_scale': float(min(gf.abs().max(), gl.abs().max())), 'dims': [grid.D, grid.fH, grid.fW, cfg['out_channels']]}
+           'grad_scale': float(min(gf.abs().max(), gl.abs().max())), 'dims': [grid.D, grid.fH, grid.fW, cfg['out_channels']],
+           'channels_last_equal': cl_equal, 'max_runs_per_voxel': int(plan.offsets().diff(dim=1).max()),
+           'counts_clean': bool(int(plan.counts.abs().max()) == 0)}
     if golden is not None:
         out['ids_equal_reference'] = bool(np.array_equal(ids, g['ref_vox']))
         out['fwd_err_reference'] = err(bev.detach(), g['ref_bev'])
@@ -81,17 +96,17 @@ def lift_small(ops):
     return case_lift(ops, H.SMALL, 2, 3, 2, 0, golden='lift_small.npz')
 
 
-def lift_c16(ops):                  # 16 channels: the matrix-core variants apply (STP3_LIFT_FWD / _BWD = mfma)
+def lift_c16(ops):                  # 16 channels, 8 image rows: 8 columns per wave in the backward
     from tests import helpers as H
     return case_lift(ops, dict(H.SMALL, out_channels=16, final_dim=(64, 48)), 1, 2, 2, 3)
 
 
-def lift_c16_rows32(ops):           # the same with 32 image rows per column (both 16-row MFMA tiles in use)
+def lift_c16_rows32(ops):           # the same with 32 image rows per column (2 columns per wave)
     from tests import helpers as H
     return case_lift(ops, dict(H.SMALL, out_channels=16, final_dim=(64, 48), downsample=2), 1, 2, 2, 3)
 
 
-def lift_c64_many_runs(ops):        # 64 channels, ~190 runs per column: the matrix-core backward works in two chunks
+def lift_c64_many_runs(ops):        # 64 channels, ~190 runs per column: more runs per depth bin than the backward stages (per-lane path)
     from tests import helpers as H
     cfg = dict(H.SMALL, out_channels=64, final_dim=(64, 16), downsample=2, d_bound=(2.0, 34.0, 1.0),
                x_bound=(-36.0, 36.0, 0.25), y_bound=(-36.0, 36.0, 0.25))
@@ -127,7 +142,7 @@ def lift_full(ops):                 # the real geometry: 6 cameras x 224x480, D 
             'dfeat_err': err(f.grad, gf), 'dlogit_err': err(lg.grad, gl)}
 
 
-def lift_tall(ops):                 # 112 rows x 64 bins per column: 112 KB of LDS in the default forward
+def lift_tall(ops):                 # 112 rows x 64 bins per column (BASELINE configs[4] column shape): two 56-row slices per column in the backward
     from tests import helpers as H
     cfg = dict(H.FULL, out_channels=8, final_dim=(224, 32), downsample=2, d_bound=(2.0, 66.0, 1.0))
     return case_lift(ops, cfg, 1, 1, 1, 9)
@@ -186,7 +201,7 @@ def optim(ops):
         return torch.nn.Sequential(torch.nn.Conv2d(3, 16, 3, padding=1), torch.nn.Flatten(), torch.nn.Linear(16 * 36, 40),
                                    torch.nn.ReLU(), torch.nn.Linear(40, 5))
     ref_m, fus_m = make(), make()
-    ref_b, fus_b = GradientBuckets(ref_m, bucket_bytes=20000), GradientBuckets(fus_m, bucket_bytes=20000)
+    ref_b, fus_b = GradientBuckets(ref_m, bucket_bytes=20000), GradientBuckets(fus_m, bucket_bytes=20000, gather=False)
     ref_o, fus_o = FlatAdam(ref_b, lr=1e-2, weight_decay=1e-3), FlatAdam(fus_b, lr=1e-2, weight_decay=1e-3)
     worst = {'grad': 0.0, 'm': 0.0, 'v': 0.0, 'param': 0.0, 'norm': 0.0}
     g = torch.Generator().manual_seed(2)
@@ -194,6 +209,7 @@ def optim(ops):
         x = torch.randn(8, 3, 6, 6, generator=g)
         ref_b.zero_grad()
         ref_m(x).square().mean().backward()
+        ref_b.finish()                                  # gather mode: gradients move into the flat buffers here
         with torch.no_grad():
             for k in range(len(ref_b.buckets)):
                 fus_b.buckets[k][0].copy_(ref_b.buckets[k][0])
@@ -202,9 +218,9 @@ def optim(ops):
                 fus_o.exp_avg_sq[k].copy_(ref_o.exp_avg_sq[k])
             fus_o.step_t.copy_(ref_o.step_t)
         max_norm = 0.05 if it != 1 else 1e9
-        parallel._FUSED_ADAM = False
+        parallel.FUSED_ADAM = False
         n_ref = float(ref_o.clip_and_step(max_norm))
-        parallel._FUSED_ADAM = True
+        parallel.FUSED_ADAM = True
         n_fus = float(fus_o.clip_and_step(max_norm))
         worst['norm'] = max(worst['norm'], abs(n_fus - n_ref) / n_ref)
         for k in range(len(ref_b.buckets)):
@@ -289,7 +305,6 @@ def bn_act(ops):
 def conv(ops):
     import torch.nn.functional as F
     out = {}
-    ops.WGRAD_MIN_CHANNELS = 0
     torch.manual_seed(2)
     for name, (cin, cout, k, s, p, d, bias) in {'3x3': (16, 24, 3, 1, 1, 1, True), '1x1': (8, 40, 1, 1, 0, 1, False),
                                                  '3x3s2': (16, 16, 3, 2, 1, 1, False), 'dil2': (8, 8, 3, 1, 2, 2, False)}.items():
@@ -338,7 +353,6 @@ def conv_bn(ops):
     import torch.nn.functional as F
     from stp3_amd import ops_fused
     from stp3_amd.layers import fused
-    ops.WGRAD_MIN_CHANNELS = 0
     out = {}
     cases = {'3x3 relu': (16, 24, 3, 1, ops.ACT_RELU, ops.RES_NONE, False),
              '1x1 project + drop-connect + skip': (40, 16, 1, 0, ops.ACT_NONE, ops.RES_AFTER_ACT, True),
@@ -564,24 +578,6 @@ def model_step_bf16_bn_eval(ops):   # the same with BatchNorm on its running sta
     return _model_step(ops, autocast=True, bn_eval=True)
 
 
-def model_step_bf16_switches(ops):  # ... with the fused trunk operators, SE kernels and weight shadows switched on
-    from stp3_amd import ops_fused
-    from stp3_amd.layers import fused
-    from stp3_amd.models import efficientnet
-    flags = [(fused, '_CONV_V2', True), (efficientnet, '_FUSED_SE', True), (ops_fused, '_SE_MLP', True),
-             (ops, '_WEIGHT_PREP', True), (fused, '_MFMA_MODE', 'all'), (efficientnet, '_MFMA_ALL', True)]
-    return _model_step(ops, autocast=True, flags=flags)
-
-
-def model_step_bf16_switches_bn_eval(ops):
-    from stp3_amd import ops_fused
-    from stp3_amd.layers import fused
-    from stp3_amd.models import efficientnet
-    flags = [(efficientnet, '_FUSED_SE', True), (ops_fused, '_SE_MLP', True), (ops, '_WEIGHT_PREP', True),
-             (fused, '_MFMA_MODE', 'all'), (efficientnet, '_MFMA_ALL', True)]
-    return _model_step(ops, autocast=True, flags=flags, bn_eval=True)
-
-
 def fuzz(ops, seed=1):
     """Random shapes / modes of the depthwise, BatchNorm and dense convolution operators against torch in float32."""
     import random
@@ -595,7 +591,6 @@ def fuzz(ops, seed=1):
             e = rel(a, b)
             if not (e <= tol):
                 bad.append((tag, cfgd, name, e))
-    ops.WGRAD_MIN_CHANNELS = 0
     # ---- depthwise
     for it in range(40):
         c = random.choice([8, 24, 40, 64]); k = random.choice([3, 5]); s = random.choice([1, 2])
@@ -671,7 +666,7 @@ def fuzz(ops, seed=1):
     return {'problems': [[t, str(c), n, str(e)] for t, c, n, e in bad]}
 
 
-CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_bf16_switches_bn_eval, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, model_step_bf16_switches, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
+CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
                                  conv, dwconv)}
 
 if __name__ == '__main__':

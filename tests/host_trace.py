@@ -6,10 +6,7 @@ scalar argument, and per pointer argument ``N`` (null) / its alias class within 
 first bytes of the INPUT buffers that hold caller data (activations, gradients, weights, BatchNorm parameters) --
 and returns 0 without touching a GPU; the size queries are answered by the real library ($STP3_REAL_LIB).
 
-Run as a script it is the *driver*: it pushes a fixed set of operator calls (forward + backward) through
-``stp3_amd.ops`` on small CPU tensors.  tests/test_host_paths_cpu.py runs the driver once per launch path
-(Python/ctypes, C++ extension) and compares the two traces: identical traces mean the C++ path drives the
-(GPU-validated) kernels exactly like the Python path does.
+tests/model_trace.py and tests/bench_dryrun.py run the whole training step / bench.py against it.
 """
 import os
 import re
@@ -90,121 +87,3 @@ def build_recorder(path):
     subprocess.check_call(['gcc', '-shared', '-fPIC', '-O1', '-w', '-I', os.path.join(ROOT, 'include'), c, '-o', path,
                            '-ldl'])
     return path
-
-
-# ------------------------------------------------------------------------------------------------------------------
-# driver
-# ------------------------------------------------------------------------------------------------------------------
-def drive(recorder):
-    import torch
-    sys.path.insert(0, os.path.join(ROOT, 'st-p3_amd'))
-    from stp3_amd import _lib
-    _lib.LIB_PATH = recorder
-    from stp3_amd import ops
-    ops._need_gpu = lambda *a: None
-    ops._stream = lambda: None
-    ops._stream_handle = lambda: 0
-    torch.set_num_threads(1)
-    cl = torch.channels_last
-    log = open(os.environ['STP3_TRACE_LOG'], 'a')
-
-    def mark(text):
-        log.write(f'# {text}\n')
-        log.flush()
-
-    def grads(**tensors):
-        # what autograd handed back: presence, shape and dtype per input (the values come from mocked kernels)
-        parts = []
-        for k, t in tensors.items():
-            if t is None:
-                continue
-            g = t.grad
-            parts.append(f'{k}:' + ('none' if g is None else f'{tuple(g.shape)}/{g.dtype}/{g.stride()}'))
-        mark('grads ' + ' '.join(parts))
-
-    def rnd(*shape, dtype=torch.float32, grad=True, seed=[0]):
-        seed[0] += 1
-        g = torch.Generator().manual_seed(seed[0])
-        t = torch.randn(*shape, generator=g)
-        if t.dim() == 4:
-            t = t.to(memory_format=cl)
-        t = t.to(dtype)
-        return t.requires_grad_() if grad else t
-
-    # fused BatchNorm + activation
-    n, c, h, w = 8, 24, 6, 10          # n >= 8: the recorder checksums the first 32 bytes of every data buffer
-    for dtype in (torch.float32, torch.bfloat16):
-        for training in (True, False):
-            for case, kw in [('relu', dict(act=ops.ACT_RELU)),
-                             ('swish+res_before', dict(act=ops.ACT_SWISH, res_mode=ops.RES_BEFORE_ACT)),
-                             ('none+res_after+oscale', dict(act=ops.ACT_NONE, res_mode=ops.RES_AFTER_ACT, oscale=True)),
-                             ('relu+sbias', dict(act=ops.ACT_RELU, sbias=True)),
-                             ('none, no affine, no running stats', dict(act=ops.ACT_NONE, affine=False))]:
-                mark(f'bn_act {dtype} training={training} {case}')
-                x = rnd(n, c, h, w, dtype=dtype)
-                affine = kw.get('affine', True)
-                weight = rnd(c) if affine else None
-                bias = rnd(c) if affine else None
-                rm = torch.zeros(c) if affine else None
-                rv = torch.ones(c) if affine else None
-                if not affine and not training:
-                    continue
-                res = rnd(n, c, h, w, dtype=dtype) if kw.get('res_mode') else None
-                sbias = rnd(n, c) if kw.get('sbias') else None
-                oscale = rnd(n, grad=False).abs() if kw.get('oscale') else None
-                y = ops.bn_act(x, weight, bias, rm, rv, training, 0.1, 1e-3, act=kw['act'], res=res,
-                               res_mode=kw.get('res_mode', ops.RES_NONE), sbias=sbias, oscale=oscale, group=False)
-                y.backward(rnd(n, c, h, w, dtype=dtype, grad=False))
-                mark(f'out {tuple(y.shape)}/{y.dtype}/{y.stride()}')
-                grads(x=x, weight=weight, bias=bias, res=res, sbias=sbias)
-    # a non-channels-last input and a channel slice (leading dimension > C)
-    mark('bn_act NCHW-contiguous input')
-    x = torch.randn(2, 16, 5, 7, generator=torch.Generator().manual_seed(99)).requires_grad_()
-    ops.bn_act(x, rnd(16), rnd(16), torch.zeros(16), torch.ones(16), True, 0.1, 1e-5, act=ops.ACT_RELU,
-               group=False).backward(rnd(2, 16, 5, 7, grad=False))
-    grads(x=x)
-    mark('bn_act channel slice of a wider tensor')
-    wide = rnd(2, 40, 5, 7, grad=False)
-    xs = wide[:, 8:24].detach().requires_grad_()
-    ops.bn_act(xs, rnd(16), rnd(16), torch.zeros(16), torch.ones(16), True, 0.1, 1e-5, act=ops.ACT_RELU,
-               group=False).backward(rnd(2, 16, 5, 7, grad=False))
-    grads(x=xs)
-
-    # dense convolution (forward, data gradient, weight gradient)
-    for wg_min in (0, 128):
-        ops.WGRAD_MIN_CHANNELS = wg_min
-        for case, (cin, cout, k, s, p, d, bias) in {
-                '3x3': (64, 64, 3, 1, 1, 1, False), '1x1 bias': (32, 144, 1, 1, 0, 1, True),
-                '3x3 stride 2': (64, 128, 3, 2, 1, 1, False), '3x3 dilation 12': (160, 160, 3, 1, 12, 12, False),
-                '7x7 stride 2': (64, 64, 7, 2, 3, 1, False), '3x3 odd channels': (35, 35, 3, 1, 1, 1, True)}.items():
-            x = rnd(2, cin, 12, 20, dtype=torch.bfloat16)
-            wt = rnd(cout, cin, k, k)
-            if wt.shape[1] % 8 != 0:                  # ops.conv2d_supported minus its is_cuda test
-                mark(f'conv2d {case}: unsupported, skipped')
-                continue
-            mark(f'conv2d {case} wgrad_min={wg_min}')
-            b = rnd(cout) if bias else None
-            y = ops.conv2d(x, wt, b, s, p, d)
-            y.backward(rnd(*y.shape, dtype=torch.bfloat16, grad=False))
-            mark(f'out {tuple(y.shape)}/{y.dtype}/{y.stride()}')
-            grads(x=x, weight=wt, bias=b)
-    mark('conv2d float32 output')
-    x = rnd(2, 64, 12, 20, dtype=torch.bfloat16)
-    y = ops.conv2d(x, rnd(8, 64, 1, 1), rnd(8), 1, 0, 1, out_dtype=torch.float32)
-    y.backward(rnd(*y.shape, grad=False))
-
-    # depthwise convolution ("static same" padding can be asymmetric)
-    for dtype in (torch.bfloat16, torch.float32):
-        for case, (k, s, pad) in {'k3 s1': (3, 1, (1, 1, 1, 1)), 'k5 s2 asym': (5, 2, (1, 2, 1, 2)),
-                                  'k3 s2 asym': (3, 2, (0, 1, 0, 1))}.items():
-            mark(f'depthwise {dtype} {case}')
-            x = rnd(2, 48, 12, 20, dtype=dtype)
-            y = ops.depthwise_conv2d(x, rnd(48, 1, k, k), s, pad)
-            y.backward(rnd(*y.shape, dtype=dtype, grad=False))
-            mark(f'out {tuple(y.shape)}/{y.dtype}/{y.stride()}')
-            grads(x=x)
-    mark('end')
-
-
-if __name__ == '__main__':
-    drive(sys.argv[1])

@@ -50,6 +50,7 @@ def patch_process(recorder, deterministic_fill=True):
             return 0.125
 
     torch.cuda.Event = _Event
+    torch.Tensor.record_stream = lambda self, stream: None
     torch.cuda.synchronize = lambda *a, **k: None
     torch.cuda.current_stream = lambda *a, **k: _Stream()
     torch.cuda.Stream = lambda *a, **k: _Stream()

@@ -1,18 +1,15 @@
-"""GPU parity of the EXPERIMENTAL second-generation convolution forward (stp3_conv2d_fwd_v2: 128-byte output
-stores, BatchNorm statistics in the epilogue) and of the fused conv -> BN -> activation operator built on it.
-Runs only with STP3_EXPERIMENTAL=1: these kernels are not on the default path yet.
+"""GPU parity of the fused operators of the training step: the BatchNorm statistics in the convolution epilogue and the
+conv -> BN -> activation operator built on them, the squeeze-excite block and its gate MLP, the bf16 weight shadows, and
+the clip + Adam kernels.
 
 Tolerances as in test_conv_gpu.py / test_bnact_gpu.py (bf16 outputs: rtol 1e-2 / atol 2e-2; statistics: float32
 sums of bf16-rounded values, rtol 1e-4 against the same sums computed by torch from the kernel's own output)."""
-import os
-
 import pytest
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get('STP3_EXPERIMENTAL') != '1', reason='experimental kernels (STP3_EXPERIMENTAL=1)')]
+pytestmark = pytest.mark.gpu
 
 CASES = [
     # n, cin, h, w, cout, k, stride, pad, dil, bias
@@ -28,7 +25,7 @@ CASES = [
 
 
 @pytest.mark.parametrize('case', CASES)
-def test_conv_v2_forward_and_statistics(case):
+def test_conv_forward_and_statistics_epilogue(case):
     from stp3_amd import ops, ops_fused
     n, cin, h, w, cout, k, stride, pad, dil, use_bias = case
     g = torch.Generator().manual_seed(cin + 3 * cout)
@@ -42,8 +39,6 @@ def test_conv_v2_forward_and_statistics(case):
     ref = F.conv2d(x.float(), wb.float(), bias, stride, pad, dil)
     torch.testing.assert_close(y.float(), ref, rtol=1e-2, atol=2e-2)
     assert torch.equal(y, y0)                                              # the statistics epilogue does not change y
-    v1 = ops._conv2d_launch(x, wb, bias, stride, (pad, pad), (dil, dil), torch.bfloat16)
-    assert torch.equal(y, v1)                                              # same arithmetic as the first-generation kernel
     yf = y.float()
     torch.testing.assert_close(sums[0], yf.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
     torch.testing.assert_close(sums[1], (yf * yf).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
@@ -53,7 +48,6 @@ def test_conv_v2_forward_and_statistics(case):
 def test_fused_conv_bn_act_matches_the_two_operators(act, res_mode):
     from stp3_amd import ops, ops_fused
     from stp3_amd.layers import fused
-    ops.WGRAD_MIN_CHANNELS = 0
     act_id = {'none': ops.ACT_NONE, 'relu': ops.ACT_RELU, 'swish': ops.ACT_SWISH}[act]
     rm = {'none': ops.RES_NONE, 'before': ops.RES_BEFORE_ACT, 'after': ops.RES_AFTER_ACT}[res_mode]
     g = torch.Generator().manual_seed(7)
@@ -111,7 +105,6 @@ def test_fused_project_conv_with_drop_connect_and_skip():
     """The MBConv tail: 1x1 conv (thin channels) -> BN -> * drop-connect scale -> + skip, fused vs the two operators."""
     from stp3_amd import ops, ops_fused
     from stp3_amd.layers import fused
-    ops.WGRAD_MIN_CHANNELS = 0
     g = torch.Generator().manual_seed(3)
     x = torch.randn(4, 144, 20, 24, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     skip = torch.randn(4, 32, 20, 24, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
@@ -134,7 +127,7 @@ def test_fused_project_conv_with_drop_connect_and_skip():
 
 
 def test_weight_shadows_match_the_torch_built_copies():
-    """stp3_conv2d_prep_weights (STP3_WEIGHT_PREP): one launch rewrites the bf16 forward / flipped copies of all
+    """stp3_conv2d_prep_weights: one launch rewrites the bf16 forward / flipped copies of all
     registered weights; bit-identical with the per-layer torch operators of the default path."""
     from stp3_amd import ops
     torch.manual_seed(0)
@@ -172,7 +165,7 @@ def test_weight_shadows_match_the_torch_built_copies():
 
 
 def test_fused_clip_adam_matches_the_torch_operator_path(monkeypatch):
-    """stp3_optim_clip_adam (STP3_FUSED_ADAM): one update from identical state == clip_grad_norm_ + FlatAdam.step."""
+    """stp3_optim_clip_adam: one update from identical state == clip_grad_norm_ + FlatAdam.step."""
     from stp3_amd import parallel
     from stp3_amd.parallel import FlatAdam, GradientBuckets
 
@@ -182,7 +175,7 @@ def test_fused_clip_adam_matches_the_torch_operator_path(monkeypatch):
                              nn.Flatten(), nn.Linear(64 * 6 * 6, 500), nn.ReLU(), nn.Linear(500, 5)).cuda()
 
     ref_model, fus_model = make(), make()
-    ref_b, fus_b = GradientBuckets(ref_model, bucket_bytes=1 << 20), GradientBuckets(fus_model, bucket_bytes=1 << 20)
+    ref_b, fus_b = GradientBuckets(ref_model, bucket_bytes=1 << 20), GradientBuckets(fus_model, bucket_bytes=1 << 20, gather=False)
     assert len(ref_b.buckets) >= 3
     ref_opt = FlatAdam(ref_b, lr=1e-2, weight_decay=1e-3)
     fus_opt = FlatAdam(fus_b, lr=1e-2, weight_decay=1e-3)
@@ -200,10 +193,10 @@ def test_fused_clip_adam_matches_the_torch_operator_path(monkeypatch):
                 fus_opt.exp_avg_sq[k].copy_(ref_opt.exp_avg_sq[k])
             fus_opt.step_t.copy_(ref_opt.step_t)
         max_norm = 0.05 if it != 1 else 1e9
+        monkeypatch.setattr(parallel, 'FUSED_ADAM', False)          # the torch-operator path (what CPU buckets take)
         n_ref = float(ref_opt.clip_and_step(max_norm))
-        monkeypatch.setattr(parallel, '_FUSED_ADAM', True)
+        monkeypatch.setattr(parallel, 'FUSED_ADAM', True)
         n_fus = float(fus_opt.clip_and_step(max_norm))
-        monkeypatch.setattr(parallel, '_FUSED_ADAM', False)
         assert abs(n_fus - n_ref) <= 1e-5 * n_ref and fus_opt.step_count == ref_opt.step_count == it + 1
         for k in range(len(ref_b.buckets)):
             torch.testing.assert_close(fus_b.buckets[k][0], ref_b.buckets[k][0], rtol=5e-5, atol=1e-10)
@@ -214,7 +207,7 @@ def test_fused_clip_adam_matches_the_torch_operator_path(monkeypatch):
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_se_mlp_kernels_match_the_torch_operator_mlp(monkeypatch, dtype):
-    """stp3_se_mlp_fwd / _bwd (STP3_SE_MLP): the squeeze-excite block with the gate MLP as single launches == the
+    """stp3_se_mlp_fwd / _bwd: the squeeze-excite block with the gate MLP as single launches == the
     same block with the MLP written in torch operators (float32 in both), forward and all five gradients."""
     from stp3_amd import ops_fused
     torch.manual_seed(0)

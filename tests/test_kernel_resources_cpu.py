@@ -26,11 +26,18 @@ def test_kernel_register_lds_and_scratch_budgets():
         assert k['vgpr'] + k['agpr'] <= 512, k                           # the unified register file of a wave
         assert k['lds_static'] <= 64 * 1024, k                           # static LDS: default launch limit
         assert k['vgpr_spills'] == 0, k                                  # no vector register spills anywhere
-        assert k['scratch'] <= 64, k                                     # (the MFMA convolution keeps a 32-byte array there)
-    # the kernels that have not run on hardware yet: no scratch, no spills of any kind, at least 4 waves per SIMD
-    for name in ('lift_runs_mfma_kernel', 'lift_bwd_mfma_kernel', 'prep_weights_kernel', 'optim_sumsq_kernel',
-                 'optim_prepare_kernel', 'optim_adam_kernel', 'se_mlp_fwd_kernel', 'se_mlp_bwd_sample_kernel',
-                 'se_mlp_bwd_weight_kernel', 'voxels_sum_fwd_kernel', 'voxels_sum_bwd_kernel'):
+        assert k['scratch'] == 0 and k['sgpr_spills'] == 0, k               # no scratch memory, no spills of any kind
+    # the memory-bound kernels keep at least 3 waves per SIMD resident (<= 168 registers); the voxel pool's fit 4 and 3
+    for name, budget in (('lift_pull_kernel', 128), ('lift_bwd_kernel', 168), ('plan_group_sort_kernel', 64),
+                         ('prep_weights_kernel', 128), ('optim_sumsq_kernel', 128), ('optim_prepare_kernel', 128),
+                         ('optim_adam_kernel', 128), ('se_mlp_fwd_kernel', 128), ('se_mlp_bwd_sample_kernel', 128),
+                         ('se_mlp_bwd_weight_kernel', 128), ('voxels_sum_fwd_kernel', 128),
+                         ('voxels_sum_bwd_kernel', 128)):
         assert name in by_name, name
         for k in by_name[name]:
-            assert k['scratch'] == 0 and k['sgpr_spills'] == 0 and k['vgpr'] + k['agpr'] <= 128, k
+            assert k['vgpr'] + k['agpr'] <= budget, k
+    # the MFMA convolutions: accumulators in AGPRs, at least 2 workgroups of 256 threads per CU
+    for name in ('void conv2d_igemm_kernel<128>', 'void conv2d_wgrad_kernel<128, 128>'):
+        assert name in by_name, name
+        for k in by_name[name]:
+            assert k['agpr'] == 64 and k['vgpr'] + k['agpr'] <= 256, k

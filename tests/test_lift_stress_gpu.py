@@ -1,22 +1,19 @@
 """GPU: the voxel pool at BASELINE.json configs[4] geometry -- 896x1600 images (fH x fW = 112 x 200), D = 64 depth
-bins, 400x400 BEV at 0.25 m (8.6 M frustum points per frame; 112 KB of LDS per image column in the forward).
+bins, 400x400 BEV at 0.25 m (8.6 M frustum points per frame; 112-row image columns: two row slices per column in
+the backward kernel, 160 000 voxels and up to ~1 M runs per frame in the plan).
 B = 1, T = 2 so that ego alignment and the discounted accumulation are exercised.
 
 Voxel ids: bit-exact against the oracle.  Pooled BEV and both gradients: against a float64 torch statement of the
 same sums evaluated on the GPU from the oracle's ids (the numpy oracle would need minutes and >10 GB at this size):
 rtol 1e-5 / atol 1e-5 forward, rtol 1e-4 / atol 1e-5 backward -- the tolerances of tests/test_lift_gpu.py.
-
-Gated (STP3_EXPERIMENTAL=1) until it has run on hardware once: the >64 KB dynamic-LDS launch is new."""
-import os
-
+"""
 import numpy as np
 import pytest
 import torch
 
 from tests import helpers as H
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get('STP3_EXPERIMENTAL') != '1', reason='not yet run on hardware')]
+pytestmark = pytest.mark.gpu
 
 
 def _reference(feat, logits, vox, bev_dim, discount, grad_out):
@@ -78,5 +75,5 @@ def test_configs4_geometry_forward_backward():
     torch.testing.assert_close(bev.double(), exact, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(f.grad.double(), gf, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(lg.grad.double(), gl, rtol=1e-4, atol=1e-5)
-    again = ops.lift_splat(feat.cuda(), logits.cuda(), plan, cfg['discount'])
+    again = ops.lift_splat(feat.cuda(), logits.cuda(), plan, cfg['discount'], True)     # channels-last memory
     assert torch.equal(again, bev.detach())                                            # fixed summation order

@@ -1,5 +1,5 @@
 """CPU: FlatAdam.clip_and_step -- the default composition (clip_grad_norm_ + step) and the host side + arithmetic of
-the fused path (STP3_FUSED_ADAM, stp3_optim_clip_adam).
+the fused path (STP3FUSED_ADAM, stp3_optim_clip_adam).
 
 The three kernels of csrc/stp3_optim.hip are transliterated to numpy (same work split: 4096-element blocks found by
 binary search over first_block, per-block partial sums, one preparing block, the update) and run against the SAME
@@ -72,7 +72,7 @@ def test_fused_clip_adam_matches_the_torch_operator_path(monkeypatch):
     comparison is one update at a time and not a trajectory (Adam turns 1-ulp differences near g = 0 into +-lr)."""
     ref_model, fus_model = _model(), _model()
     ref_b = GradientBuckets(ref_model, bucket_bytes=20000)
-    fus_b = GradientBuckets(fus_model, bucket_bytes=20000)
+    fus_b = GradientBuckets(fus_model, bucket_bytes=20000, gather=False)    # filled by copies below, no backward
     assert len(ref_b.buckets) >= 3 and max(f.numel() for f, _ in ref_b.buckets) > 4096   # several blocks per bucket
     ref_opt = FlatAdam(ref_b, lr=1e-2, weight_decay=1e-3)
     fus_opt = FlatAdam(fus_b, lr=1e-2, weight_decay=1e-3)
@@ -109,7 +109,7 @@ def test_fused_clip_adam_matches_the_torch_operator_path(monkeypatch):
         n_ref = float(ref_opt.clip_and_step(max_norm))
         with monkeypatch.context() as mp:
             mp.setattr(_lib, 'lib', lambda: FakeLib())
-            mp.setattr(parallel, '_FUSED_ADAM', True)
+            mp.setattr(parallel, 'FUSED_ADAM', True)
             mp.setattr(torch.Tensor, 'is_cuda', property(lambda self: True))
             mp.setattr(ops, '_stream', lambda: None)
             n_fus = float(fus_opt.clip_and_step(max_norm))

@@ -240,7 +240,7 @@ def _step_worker(rank, world, port, out, local_stats, fast_host=False):
     loss = module.training_step(batch)
     loss.backward()
     buckets.finish()
-    out[rank] = (float(loss), torch.cat([f.clone() for f, _ in buckets.buckets]))
+    out[rank] = (float(loss.detach()), torch.cat([f.clone() for f, _ in buckets.buckets]))
     dist.destroy_process_group()
 
 
@@ -268,10 +268,11 @@ def test_full_step_two_ranks_equal_one_process_on_the_concatenated_batch():
     buckets.zero_grad()
     loss = module.training_step(_small_batch(2))
     loss.backward()
+    buckets.finish()
     ref = torch.cat([f.clone() for f, _ in buckets.buckets])
     # losses are per-rank means over 1 sample each: their average is the 2-sample mean for the CE terms without top-k;
     # gradients are compared directly (top-k selects per sample, so the loss is a mean of per-sample terms)
-    assert abs(0.5 * (out[0][0] + out[1][0]) - float(loss)) < 5e-4
+    assert abs(0.5 * (out[0][0] + out[1][0]) - float(loss.detach())) < 5e-4
     # Compared in the gradient's own norm.  This tiny configuration (4x6 feature maps, ~130 train-mode BatchNorm
     # layers, random weights) amplifies float32 round-off to ~1e-3..1e-2: merely reversing the order of the two
     # samples in ONE process moves the gradient by 7e-3.  What the test discriminates is the semantics: with
