@@ -223,6 +223,9 @@ def _log(msg):
 _T0 = time.perf_counter()
 
 
+ENTRY = [os.path.abspath(__file__)]          # what the self-launcher starts per rank (tests substitute their wrapper)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -238,6 +241,17 @@ def main():
     if args.cpu_baseline_worker:
         _cpu_baseline_worker(args.workload)
         return
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher -- one rank per GPU over RCCL, exactly the line
+        # the driver uses (torch.distributed.run, rendezvous on 127.0.0.1); rank 0 prints the JSON line
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port)] + ENTRY + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')))
 
     from stp3_amd.parallel import FlatAdam, GradientBuckets, init_distributed
     rank, world, local = init_distributed()

@@ -56,6 +56,24 @@ def test_bench_main_dry_run(tmp_path, workload):
 
 
 @pytest.mark.skipif(shutil.which('gcc') is None, reason='needs gcc for the recording library')
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher around it: bench.py starts torch.distributed.run itself (one rank
+    per GPU, rendezvous on 127.0.0.1) and the job prints the one whole-job JSON line."""
+    recorder = host_trace.build_recorder(str(tmp_path / 'libstp3hip_recorder.so'))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(STP3_BENCH_DRYRUN='1', STP3_HOST_DRYRUN='1', STP3_TRACE_LOG=str(tmp_path / 'trace.log'),
+               STP3_REAL_LIB=os.path.join(PKG, 'libstp3hip.so'))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'bench_dryrun.py'), recorder, '--gpus', '2',
+                          '--steps', '1', '--warmup', '1', '--batch', '1', '--no-cpu-baseline', '--no-roofline'],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['config']['parallelism'] == 'dp2' and line['config']['global_batch'] == 2
+
+
+@pytest.mark.skipif(shutil.which('gcc') is None, reason='needs gcc for the recording library')
 def test_bench_main_dry_run_two_ranks(tmp_path):
     """The driver's N>1 launch line (torch.distributed.run, one rank per GPU) with the gloo backend: barrier,
     max-over-ranks timing, cross-replica BatchNorm statistics and bucketed gradient all-reduce all execute; rank 0

@@ -229,12 +229,18 @@ def test_training_step_c3_bf16_losses():
     assert not bad, bad[:5]
 
 
-BLOCK_TOL = dict(out=2e-2, dparam=6e-2, dx=0.15)
+BLOCK_TOL = dict(out=2e-2, dparam=2e-2, dx=2e-2)          # bf16 accuracy for a well-conditioned block
+PROBE_FACTOR = 6.0                                        # ... or this many times the block's own sensitivity
 
 
 def test_bf16_blocks_teacher_forced_from_the_float32_step():
-    """Link 2 of the module docstring.  Tolerances: outputs 2e-2, parameter gradients 6e-2 (relative L2 over all
-    parameters of the block), input gradients 0.15 (cancellation, see the decoder case)."""
+    """Link 2 of the module docstring.  A block passes when outputs, input gradients and parameter gradients
+    (relative L2 over all parameters of the block) are within 2e-2 of its float32 run -- or, for the blocks whose
+    gradients are ill-conditioned (BatchNorm over the 12-sample population of the ASPP pooling branch, 3-D BatchNorm
+    chains of the temporal blocks, smooth fixture weights that cancel in the data gradient), within PROBE_FACTOR
+    times the block's measured sensitivity: the change of the FLOAT32 result when only its input and output-gradient
+    are rounded to bf16 once.  A bf16 run rounds after every one of the block's 3..10 layers, so a factor of 6 over the
+    single-rounding probe is what rounding alone explains; an indexing or accumulation bug is O(1)."""
     from stp3_amd.layers.convolutions import DeepLabHead, UpsamplingAdd, UpsamplingConcat
     from stp3_amd.layers.temporal import TemporalBlock
     from stp3_amd.models.efficientnet import MBConvBlock
@@ -296,25 +302,29 @@ def test_bf16_blocks_teacher_forced_from_the_float32_step():
         for a in args:
             if torch.is_tensor(a) and a.is_floating_point():
                 a = a.clone()
+                if mode == 'probe':
+                    a = a.to(torch.bfloat16).float()
                 if mode == 'bf16':
                     a = a.to(torch.bfloat16)
                     a = a.contiguous(memory_format=torch.channels_last) if a.dim() == 4 else a
                 a.requires_grad_(True)
             ins.append(a)
-        with ctx(mode):
+        with ctx('bf16' if mode == 'bf16' else 'fp32'):
             y = run_fused(mod, *ins) if mod in heads else mod(*ins, **kwargs)
-        y.backward(gout.to(y.dtype))
+        y.backward(gout.to(torch.bfloat16).to(y.dtype) if mode == 'probe' else gout.to(y.dtype))
         dxs = [a.grad.float() for a in ins if torch.is_tensor(a) and a.requires_grad and a.grad is not None]
         dps = [p.grad.float().flatten().clone() for p in mod.parameters() if p.grad is not None]
         return y.detach().float(), dxs, torch.cat(dps) if dps else torch.zeros(1, device=y.device)
 
     def r2(a, b):
         return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
-    worst, rows = dict(out=0.0, dparam=0.0, dx=0.0), {}
+    worst, rows, probes = dict(out=0.0, dparam=0.0, dx=0.0), {}, {}
     for n, (args, kwargs, gout) in sorted(work.items()):
         y0, dx0, dp0 = run(blocks[n], args, kwargs, gout, 'fp32')
         y1, dx1, dp1 = run(blocks[n], args, kwargs, gout, 'bf16')
+        y2, dx2, dp2 = run(blocks[n], args, kwargs, gout, 'probe')
         e = dict(out=r2(y1, y0), dparam=r2(dp1, dp0), dx=max([r2(a, b) for a, b in zip(dx1, dx0)] + [0.0]))
+        probes[n] = dict(out=r2(y2, y0), dparam=r2(dp2, dp0), dx=max([r2(a, b) for a, b in zip(dx2, dx0)] + [0.0]))
         rows[n] = e
         for k in worst:
             worst[k] = max(worst[k], e[k])
@@ -322,5 +332,8 @@ def test_bf16_blocks_teacher_forced_from_the_float32_step():
     record('bf16_blocks', 'per_block_out', {n: e['out'] for n, e in rows.items()})
     record('bf16_blocks', 'per_block_dparam', {n: e['dparam'] for n, e in rows.items()})
     record('bf16_blocks', 'per_block_dx', {n: e['dx'] for n, e in rows.items()})
-    over = {n: e for n, e in rows.items() if any(e[k] > BLOCK_TOL[k] for k in BLOCK_TOL)}
+    record('bf16_blocks', 'probe_dparam', {n: e['dparam'] for n, e in probes.items()})
+    record('bf16_blocks', 'probe_dx', {n: e['dx'] for n, e in probes.items()})
+    over = {n: (e, probes[n]) for n, e in rows.items()
+            if any(e[k] > max(BLOCK_TOL[k], PROBE_FACTOR * probes[n][k]) for k in BLOCK_TOL)}
     assert not over, over
