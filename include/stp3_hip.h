@@ -96,28 +96,33 @@ int stp3_voxel_index(const stp3_lift_dims* dims,
  *
  * Along an image column (camera n, feature column w, depth bin d) consecutive rows h fall into
  * the same BEV cell most of the time; a RUN is a maximal set of consecutive h with one voxel
- * id >= 0.  The plan lists the runs per voxel, ordered canonically (by n, w, d, first row), so that
- * the pooled value of a voxel is a pull over its list and is summed in ONE fixed order.
+ * id >= 0.  The forward pass sums every run once (pass 1, per image column) into the run's SLOT and
+ * then every voxel over its runs (pass 2); the plan numbers the runs (slot = position in the
+ * enumeration frame, column, last row, depth bin) and lists them per voxel in ascending order, so
+ * that every voxel is summed in ONE fixed order.
  *
  *   stp3_lift_plan_bytes : size of the plan buffer for `dims`
  *   stp3_lift_plan_build : geometry inputs exactly as for stp3_voxel_index; writes
  *                            vox_cm [B*T][N*fW][D][fH] int32  voxel ids in COLUMN-MAJOR order (the same ids
  *                                                            stp3_voxel_index computes; the rows h of an image column
- *                                                            and depth bin are contiguous -- the order the pooling
- *                                                            kernels walk them in)
- *                            plan   vox_off [B*T][V+1] int32 | build scratch [B*T][P] 8 bytes
- *                                   | gidx | groups (below) | runs [B*T][P] (uint32 x, y, z, w):
- *                                   x = col << 20 | d << 14 | h0 << 7 | (len - 1), col = n*fW + w; y = voxel id;
- *                                   z, w = first feature row / first probability of the run within the frame;
- *                                   the runs of a work group are contiguous, longest first
- *                                   | gidx [B][V+1] int32 | groups [B][V+1] int32: the first voxel of every work
- *                                   group of the forward kernel (<= 16 consecutive voxels holding ~32 runs over
- *                                   the sample's T frames), gidx[b][V] of them, closed by V;
- *                                   each section starts 256-byte aligned
+ *                                                            and depth bin are contiguous -- the order the backward
+ *                                                            kernel walks them in)
+ *                            plan   sections, each 256-byte aligned, in this order:
+ *                                   vox_off  [B*T][V+1] int32   exclusive scan of runs per voxel, per frame
+ *                                   masks    [B*T][N*fW][fH] 2 x uint64: bit d of word 0 = a run of depth bin d ENDS
+ *                                            at this row, bit d of word 1 = point (d, h) lies inside the BEV grid
+ *                                   col_cnt  [B*T*N*fW] int32   runs per column (scratch)
+ *                                   col_off  [B*T*N*fW + 1] int32  exclusive scan over all frames: slot of the
+ *                                            column's first run; col_off[bt*N*fW] = first slot of frame bt; the
+ *                                            last entry = total number of runs
+ *                                   tmp      [B*T*P] int32      (scratch)
+ *                                   vox_runs [B*T*P] int32      slots of voxel v of frame bt, ascending, at
+ *                                            col_off[bt*N*fW] + vox_off[bt][v] .. + vox_off[bt][v+1]
  *                          counts = int32 [B*T][V] scratch that must be ZERO on entry (the caller zero-fills
  *                          it once; every build leaves it zero again).
- *   Launches: index + count, scan, fill, per-voxel order, group flags, scan, group list, memset.  Limits: Z == 1, C % 4 == 0, C <= 64,
- *   D <= 64, fH <= 128, N*fW < 4096, B*T*N*fH*fW*max(C,D)*4 < 2^32, else STP3_EUNSUP.
+ *   Launches: columns (ids, masks, counts), scan of the columns, scan of the voxels, fill, per-voxel order.
+ *   Limits: Z == 1, C % 4 == 0, C <= 64, D <= 64, fH <= 128, N*fW < 4096, B*T*N*fH*fW*max(C,D)*4 < 2^32,
+ *   else STP3_EUNSUP.
  */
 int stp3_lift_plan_bytes(const stp3_lift_dims* dims, size_t* bytes);
 int stp3_lift_plan_build(const stp3_lift_dims* dims,
@@ -128,8 +133,9 @@ int stp3_lift_plan_build(const stp3_lift_dims* dims,
                          int32_t* vox_cm, int32_t* counts, void* plan, size_t plan_bytes, void* stream);
 
 /* stp3_depth_softmax -- softmax over the D depth bins of every pixel (stp3.py:215).
- * logits [B*T][N*fH*fW][D] float32 (pixel-major) -> prob_cm [B*T][N*fW][D][fH] float32 (column-major, what
- * stp3_lift_splat_fwd / _bwd read; must not alias logits). */
+ * logits [B*T][N*fH*fW][D] float32 (pixel-major) -> prob_cm [B*T][N*fW][D][fH] float32 (column-major; must not
+ * alias logits).  stp3_lift_splat_fwd computes the same values on the fly; this entry point is the stand-alone
+ * operator. */
 int stp3_depth_softmax(const stp3_lift_dims* dims, const float* logits, float* prob, void* stream);
 
 /* memory layout of the BEV tensor handed to / produced by the pooling calls */
@@ -139,23 +145,27 @@ int stp3_depth_softmax(const stp3_lift_dims* dims, const float* logits, float* p
 
 /*
  * stp3_lift_splat_fwd -- out[b][t] = sum_{k<=t} discount^(t-k) Pool_k,
- *   Pool_k[c][v] = sum over points p of frame k with vox(p) == v of prob[p] * feat[pix(p)][c].
- * Replaces stp3.py:216-221 (outer product, never materialised), geometry.py:302-318
- * (VoxelsSumming.forward) and stp3.py:279-299 (scatter, discount, permute).
- * ONE kernel, pull form: a wave owns 16 voxels of a sample, walks their run lists for t = 0..T-1 and writes
- * every voxel's C-vector once (256-byte rows); inputs are read through L2, nothing is staged in HBM.
+ *   Pool_k[c][v] = sum over points p of frame k with vox(p) == v of softmax_D(logits)[p] * feat[pix(p)][c].
+ * Replaces stp3.py:215 (depth softmax), :216-221 (outer product, never materialised), geometry.py:302-318
+ * (VoxelsSumming.forward) and stp3.py:279-299 (scatter, discount, permute).  Two kernels:
+ *   pass 1  one wave per image column, lane = channel: softmax of the column's logits (kept in LDS, written to
+ *           prob_cm for the backward pass), then ONE walk over the rows with an accumulator per depth bin; every
+ *           feature and logit is read from memory exactly once; a finished run's C-vector goes to its slot
+ *   pass 2  16 lanes per voxel add the voxel's slots (ascending) and carry the discounted state through the T
+ *           frames in registers; every BEV row (256 bytes) is written once
  * Deterministic (fixed summation order, no atomics).
- *   bev_layout STP3_BEV_CHANNELS_LAST : bev written directly, workspace unused (may be NULL)
- *              STP3_BEV_CHANNELS_FIRST: the kernel writes the channels-last result into `workspace`
- *                                       (stp3_lift_workspace_bytes) and a transpose pass produces bev
+ *   feat    [B*T][N*fH*fW][C] float32, logits [B*T][N*fH*fW][D] float32 (pixel-major)
+ *   prob_cm [B*T][N*fW][D][fH] float32 out (what stp3_lift_splat_bwd reads), or NULL
+ *   workspace  stp3_lift_workspace_bytes(dims): one slot per possible run (B*T*P*C floats -- the geometry decides how
+ *              many are touched: ~7 % for nuScenes-like rigs) + one BEV-sized buffer
+ *   bev_layout STP3_BEV_CHANNELS_LAST : pass 2 writes bev directly
+ *              STP3_BEV_CHANNELS_FIRST: pass 2 writes into the workspace and a transpose pass produces bev
  *   bev: B*T*C*X*Y float32, fully overwritten (empty voxels get 0).
- *   Work is dealt out in the plan's voxel groups (<= 16 voxels, ~32 runs over the T frames) to a chip-sized set
- *   of persistent waves, statically; 8 % B == 0 keeps a sample on 8/B XCDs.
  */
-int stp3_lift_workspace_bytes(const stp3_lift_dims* dims, size_t* bytes);   /* B*T*V*C float32 */
-int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const float* prob_cm,
+int stp3_lift_workspace_bytes(const stp3_lift_dims* dims, size_t* bytes);
+int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const float* logits,
                         const void* plan, float discount, int bev_layout,
-                        void* workspace, size_t workspace_bytes, float* bev, void* stream);
+                        void* workspace, size_t workspace_bytes, float* prob_cm, float* bev, void* stream);
 
 /*
  * stp3_lift_splat_bwd -- gradients of stp3_lift_splat_fwd composed with stp3_depth_softmax.

@@ -3,7 +3,10 @@ import sys, os, ctypes, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'st-p3_amd'))
 import torch
-from stp3_amd import ops, _lib
+from stp3_amd import _lib
+if os.environ.get('EXP_LIB'):          # experiment builds of the library (scripts/gpu_exp.sh)
+    _lib.LIB_PATH = os.environ['EXP_LIB']
+from stp3_amd import ops
 from stp3_amd import synthetic
 
 
@@ -28,20 +31,18 @@ print('voxel_index alone us', ev_time(lambda: ops.voxel_index(grid, d, *mats, or
 print('plan build (index + count, scan, fill, order; device part) us', ev_time(lambda: ops.LiftPlan.build(grid, intr, extr, ego, 64, out=plan)))
 f = feat.cuda().permute(0, 1, 2, 4, 5, 3).reshape(d.BT, d.NPIX, d.C).contiguous()
 l = logits.cuda().permute(0, 1, 2, 4, 5, 3).reshape(d.BT, d.NPIX, d.D).contiguous()
-prob = ops.depth_softmax(d, l)
-t_soft = ev_time(lambda: ops.depth_softmax(d, l))
-print('softmax us', t_soft)
-print('runs per (b,t):', plan.offsets()[:, -1].tolist(), ' points per (b,t):', d.P, ' voxel groups per sample:', [g.numel() - 1 for g in plan.groups()])
+prob = torch.empty(d.BT, d.N * d.fW, d.D, d.fH, device='cuda')
+print('stand-alone softmax operator us', ev_time(lambda: ops.depth_softmax(d, l)))
+print('runs per (b,t):', plan.offsets()[:, -1].tolist(), ' points per (b,t):', d.P, ' total runs:', int(plan.column_offsets()[-1]))
 alg = d.BT * (d.NPIX * d.C * 4 + d.NPIX * d.D * 4 + d.C * d.V * 4)
 algb = d.BT * (d.C * d.V * 4 + 2 * d.NPIX * d.C * 4 + 2 * d.NPIX * d.D * 4)
 gf = torch.empty_like(f); gl = torch.empty_like(l)
 for name, layout in (('channels-last BEV (model path)', ops.BEV_CHANNELS_LAST), ('reference layout (+ transpose pass)', ops.BEV_CHANNELS_FIRST)):
     bev = torch.empty(d.B * d.T * d.C * d.X * d.Y, device='cuda')
     ws, wsb = ops.lift_workspace(d, 'cuda')
-    fwd = lambda: lib.stp3_lift_splat_fwd(ctypes.byref(d), ops._ptr(f), ops._ptr(prob), ops._ptr(plan.plan), ctypes.c_float(0.5), layout, ops._ptr(ws), ctypes.c_size_t(wsb), ops._ptr(bev), ops._stream())
+    fwd = lambda: lib.stp3_lift_splat_fwd(ctypes.byref(d), ops._ptr(f), ops._ptr(l), ops._ptr(plan.plan), ctypes.c_float(0.5), layout, ops._ptr(ws), ctypes.c_size_t(wsb), ops._ptr(prob), ops._ptr(bev), ops._stream())
     us = ev_time(fwd)
-    print(f'{name}: lift_splat_fwd us {us:.1f}  algorithmic {alg/1e6:.1f} MB -> {alg/us/1e6:.3f} TB/s ({alg/us/1e6/8*100:.1f}% of 8 TB/s); '
-          f'with softmax {alg/(us+t_soft)/1e6/8*100:.1f}%')
+    print(f'{name}: lift_splat_fwd (logits -> BEV) us {us:.1f}  algorithmic {alg/1e6:.1f} MB -> {alg/us/1e6:.3f} TB/s ({alg/us/1e6/8*100:.1f}% of 8 TB/s)')
     gb = torch.randn_like(bev)
     bwd = lambda: lib.stp3_lift_splat_bwd(ctypes.byref(d), ops._ptr(gb), layout, 0, ops._ptr(f), ops._ptr(prob), ops._ptr(plan.vox_cm), ctypes.c_float(0.5), ops._ptr(ws), ctypes.c_size_t(wsb), ops._ptr(gf), ops._ptr(gl), ops._stream())
     us = ev_time(bwd)

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "stp3_dpp.h"
 #include "stp3_hip.h"
 
 namespace {
@@ -129,55 +130,69 @@ __global__ __launch_bounds__(256) void voxel_index_kernel(Dims dm, const float* 
 }
 
 // ------------------------------------------------------------------------------------------
-// Pooling plan (geometry only): per-voxel lists of column runs
+// Pooling plan (geometry only): the column runs, enumerated once, listed per voxel
 // ------------------------------------------------------------------------------------------
 // Along an image column (fixed camera n, feature column w, depth bin d) consecutive rows h project to the
 // same BEV cell most of the time (10-20 points per run with nuScenes-like rigs).  A RUN is
-// a maximal set of consecutive h with one voxel id >= 0.  The plan lists, per voxel, the runs that fall into
-// it -- the pooled value of the voxel is then a PULL: sum over its runs of sum_h prob[h][d] * feat[h][:].
-//   vox_off [BT][V+1]   exclusive scan of runs per voxel
-//   desc    [BT][P]     uint2 per run (build scratch, arrival order): x = col << 20 | d << 14 | h0 << 7 | (len - 1)
-//                                      (col = n*fW + w), y = voxel id
-//   runs    [BT][P]     uint4 per run (ordered): x, y as above, z = first feature row (n*fH + h0)*fW + w,
-//                                      w = first probability (col*D + d)*fH + h0 -- both relative to the frame
-//                       a voxel's runs are in the contiguous range [vox_off[v], vox_off[v+1]) ... of its GROUP: the
-//                       runs of a group (below) are ordered longest first, ties by x -- one canonical summation order
-//   gidx    [B][V+1]    exclusive scan of the group-start flags; gidx[b][V] = number of voxel groups of sample b
-//   groups  [B][V+1]    first voxel of every group (ascending), closed by V.  A GROUP is the unit of work of the
-//                       forward kernel: at most 16 consecutive voxels with at most ~kGroupRuns runs over all T
-//                       frames together (voxels next to the cameras hold hundreds of points, far cells none:
-//                       equal-sized voxel ranges would leave a few waves with 30x the average work)
+// a maximal set of consecutive h with one voxel id >= 0.  The forward pass is a PUSH per image column (the
+// column's features are read once and serve all D depth bins) followed by a PULL per voxel:
+//   pass 1  one wave per column walks the rows h = 0..fH-1 with one accumulator per depth bin; where a run ends it
+//           stores the run's C-vector in the run's SLOT
+//   pass 2  a voxel sums the slots of its runs (fixed order: ascending slot id) and applies the discount recurrence
+// The slot of a run is its position in the enumeration  frame, column, last row, depth bin  (the order pass 1 meets
+// the run ends in).  The plan holds
+//   vox_off  [BT][V+1]          exclusive scan of runs per voxel, per frame
+//   masks    [BT][NCOL][fH]     two 64-bit words per image-column row: bit d of .x = a run of depth bin d ENDS at this
+//                               row, bit d of .y = the point (d, h) falls inside the BEV grid
+//   col_cnt  [BT*NCOL]          runs per column (build scratch)
+//   col_off  [BT*NCOL+1]        exclusive scan of col_cnt over ALL frames = slot of the column's first run;
+//                               col_off[bt*NCOL] = first slot of frame bt, col_off[BT*NCOL] = total number of runs
+//   tmp      [BT*P]             per-voxel slot lists in arrival order (build scratch)
+//   vox_runs [BT*P]             per-voxel slot lists, ascending: the runs of voxel v of frame bt are
+//                               vox_runs[col_off[bt*NCOL] + vox_off[bt][v] ... + vox_off[bt][v+1])
 // Replaces the reference's boolean mask + argsort + cumsum differencing (stp3.py:247-257, geometry.py:302-318).
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-constexpr int kGroupVox = 16;    // voxels per group at most (one accumulator row each in the forward kernel)
-constexpr int kGroupRuns = 32;   // target runs per group, all frames together
-
-inline size_t plan_bytes(const Dims& dm) {
-    return align256((size_t)dm.BT * (dm.V + 1) * 4) + align256((size_t)dm.BT * dm.P * 8) +
-           2 * align256((size_t)dm.B * (dm.V + 1) * 4) + align256((size_t)dm.BT * dm.P * 16);
-}
+struct __attribute__((aligned(16))) Mask2 {
+    unsigned long long x, y;
+};
 
 struct PlanView {
     int32_t* vox_off;
-    uint2* desc;      // build scratch: runs in arrival order
-    int32_t* gidx;
-    int32_t* groups;
-    uint4* runs;      // what the forward kernel reads: ordered, with the addresses worked out
+    Mask2* masks;
+    int32_t* col_cnt;
+    int32_t* col_off;
+    int32_t* tmp;
+    int32_t* vox_runs;
 };
 
+inline size_t plan_sections(const Dims& dm, size_t* o) {
+    size_t p = 0;
+    o[0] = p; p += align256((size_t)dm.BT * (dm.V + 1) * 4);
+    o[1] = p; p += align256((size_t)dm.BT * dm.NCOL * dm.fH * 16);
+    o[2] = p; p += align256((size_t)dm.BT * dm.NCOL * 4);
+    o[3] = p; p += align256(((size_t)dm.BT * dm.NCOL + 1) * 4);
+    o[4] = p; p += align256((size_t)dm.BT * dm.P * 4);
+    o[5] = p; p += align256((size_t)dm.BT * dm.P * 4);
+    return p;
+}
+
+inline size_t plan_bytes(const Dims& dm) {
+    size_t o[6];
+    return plan_sections(dm, o);
+}
+
 inline PlanView plan_view(const Dims& dm, void* base) {
-    PlanView pv;
+    size_t o[6];
+    plan_sections(dm, o);
     char* p = (char*)base;
-    pv.vox_off = (int32_t*)p;
-    p += align256((size_t)dm.BT * (dm.V + 1) * 4);
-    pv.desc = (uint2*)p;
-    p += align256((size_t)dm.BT * dm.P * 8);
-    pv.gidx = (int32_t*)p;
-    p += align256((size_t)dm.B * (dm.V + 1) * 4);
-    pv.groups = (int32_t*)p;
-    p += align256((size_t)dm.B * (dm.V + 1) * 4);
-    pv.runs = (uint4*)p;
+    PlanView pv;
+    pv.vox_off = (int32_t*)(p + o[0]);
+    pv.masks = (Mask2*)(p + o[1]);
+    pv.col_cnt = (int32_t*)(p + o[2]);
+    pv.col_off = (int32_t*)(p + o[3]);
+    pv.tmp = (int32_t*)(p + o[4]);
+    pv.vox_runs = (int32_t*)(p + o[5]);
     return pv;
 }
 
@@ -206,38 +221,77 @@ __device__ __forceinline__ int point_voxel(const Dims& dm, const GeomArgs& g, in
     return keep ? (int)gx * (dm.Y * dm.Z) + (int)gy * dm.Z + (int)gz : -1;
 }
 
-// (1) one thread per (bt, n, w, d) walks its image column: voxel ids in COLUMN-MAJOR order
-//         vox_cm[bt][col = n*fW + w][d][h]
-//     (the fH ids of a thread are contiguous; the pooling kernels read a column's probabilities / ids for a fixed
-//     depth bin along h -- in pixel-major order every such value sits in its own cache line), and the number of runs
-//     per voxel
-__global__ __launch_bounds__(64) void plan_index_count_kernel(Dims dm, GeomArgs g, int32_t* __restrict__ vox_cm,
-                                                              int32_t* __restrict__ vox_cnt) {
-    extern __shared__ __attribute__((aligned(16))) int32_t ids_s[];   // [64][fH + 1]
-    const int bt = blockIdx.y;
-    const int q0 = blockIdx.x * 64, q = q0 + threadIdx.x;
-    const int ld = dm.fH + 1;
-    if (q < dm.NQ) {
-        const int d = q % dm.D, col = q / dm.D;
-        const int w = col % dm.fW, n = col / dm.fW;
-        const int b = bt / dm.T, t = bt - b * dm.T;
-        const float dep = g.ds[d];
-        int prev = -1;
-        for (int h = 0; h < dm.fH; ++h) {
-            const int v = point_voxel(dm, g, bt, b, t, n, h, w, dep);
-            ids_s[threadIdx.x * ld + h] = v;
-            if (v != prev && v >= 0) atomicAdd(vox_cnt + (size_t)bt * dm.V + v, 1);
-            prev = v;
-        }
+__device__ __forceinline__ unsigned long long lanes_below(int lane) { return (1ull << lane) - 1ull; }
+
+// (1) one WAVE per image column (bt, n, w), lane = depth bin: walks the rows; the ballots over the lanes ARE the
+//     row's mask words.  Writes the column's ids in COLUMN-MAJOR order vox_cm[bt][col][d][h] (one contiguous piece
+//     per column; the backward kernel reads them along h), the masks, the column's run count, and counts the runs per
+//     voxel.
+__global__ __launch_bounds__(256) void plan_columns_kernel(Dims dm, GeomArgs g, int32_t* __restrict__ vox_cm,
+                                                           int32_t* __restrict__ vox_cnt,
+                                                           Mask2* __restrict__ masks,
+                                                           int32_t* __restrict__ col_cnt, int stage) {
+    extern __shared__ __attribute__((aligned(16))) int32_t ids_s[];   // [4][D][fH] (stage != 0)
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int colg = blockIdx.x * 4 + wv;                  // column over all frames
+    if (colg >= dm.BT * dm.NCOL) return;
+    const int bt = colg / dm.NCOL, col = colg - bt * dm.NCOL;
+    const int n = col / dm.fW, w = col - n * dm.fW;
+    const int b = bt / dm.T, t = bt - b * dm.T;
+    const int d = lane;
+    const bool live = d < dm.D;
+    const float dep = live ? g.ds[d] : 0.f;
+    int32_t* out = vox_cm + (size_t)colg * dm.D * dm.fH;
+    int32_t* ids = stage ? ids_s + (size_t)wv * dm.D * dm.fH : out;     // very tall columns: straight to memory
+    int cur = live ? point_voxel(dm, g, bt, b, t, n, 0, w, dep) : -1;
+    int runs = 0;
+    for (int h = 0; h < dm.fH; ++h) {
+        const int nxt = (live && h + 1 < dm.fH) ? point_voxel(dm, g, bt, b, t, n, h + 1, w, dep) : -1;
+        const bool valid = cur >= 0;
+        const bool end = valid && nxt != cur;
+        const unsigned long long ends_w = __ballot(end), valid_w = __ballot(valid);
+        if (end) atomicAdd(vox_cnt + (size_t)bt * dm.V + cur, 1);
+        if (live) ids[d * dm.fH + h] = cur;
+        if (lane == 0) masks[(size_t)colg * dm.fH + h] = Mask2{ends_w, valid_w};
+        runs += __popcll(ends_w);
+        cur = nxt;
     }
-    __syncthreads();
-    // the 64 x fH ids of this workgroup are one contiguous piece of vox_cm
-    const int nq = min(64, dm.NQ - q0);
-    int32_t* out = vox_cm + ((size_t)bt * dm.NQ + q0) * dm.fH;
-    for (int i = threadIdx.x; i < nq * dm.fH; i += 64) out[i] = ids_s[(i / dm.fH) * ld + (i % dm.fH)];
+    if (lane == 0) col_cnt[colg] = runs;
+    if (!stage) return;
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < dm.D * dm.fH; i += 64) out[i] = ids[i];
 }
 
-// (2) exclusive scan of the run counts of one frame: block j owns voxels [1024 j, 1024 j + 1024); it first adds up
+// (2) exclusive scan of n counts by ONE workgroup (the run counts of all B*T*N*fW columns: a few thousand values)
+__global__ __launch_bounds__(1024) void plan_scan_all_kernel(int n, const int32_t* __restrict__ cnt,
+                                                             int32_t* __restrict__ off) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int first = 0; first < n; first += 1024) {
+        const int i = first + tid;
+        const int mine = i < n ? cnt[i] : 0;
+        int incl = mine;
+        for (int s = 1; s < 64; s <<= 1) {
+            const int up = __shfl_up(incl, s);
+            if (lane >= s) incl += up;
+        }
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        int wbase = carry_s;
+        for (int k = 0; k < wv; ++k) wbase += wave_tot[k];
+        if (i < n) off[i] = wbase + incl - mine;
+        __syncthreads();
+        if (tid == 1023) carry_s = wbase + incl;
+        __syncthreads();
+    }
+    if (tid == 0) off[n] = carry_s;
+}
+
+// (3) exclusive scan of the run counts of one frame: block j owns voxels [1024 j, 1024 j + 1024); it first adds up
 //     everything before its slice (coalesced, at most 4 V bytes per block) and then scans its slice
 __global__ __launch_bounds__(1024) void plan_scan_kernel(int V, const int32_t* __restrict__ cnt,
                                                          int32_t* __restrict__ off) {
@@ -276,156 +330,68 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(int V, const int32_t* _
     if (v == V - 1) o[V] = base + wbase + incl;
 }
 
-// (3) the same walk as (1) over the stored ids: every finished run takes the next free slot of its voxel
-//     (counting the voxel's counter back down to zero, so the scratch is clean for the next build)
-__global__ __launch_bounds__(64) void plan_fill_kernel(Dims dm, const int32_t* __restrict__ vox_cm,
-                                                       const int32_t* __restrict__ vox_off,
-                                                       int32_t* __restrict__ vox_cnt, uint2* __restrict__ desc) {
-    extern __shared__ __attribute__((aligned(16))) int32_t ids_s[];   // [64][fH + 1]
+// (4) one wave per column again: every run end takes its slot (position in the enumeration) and the next free place
+//     of its voxel's list (counting the voxel's counter back down to zero: the scratch is clean for the next build)
+__global__ __launch_bounds__(256) void plan_fill_kernel(Dims dm, const int32_t* __restrict__ vox_cm,
+                                                        const Mask2* __restrict__ masks,
+                                                        const int32_t* __restrict__ col_off,
+                                                        const int32_t* __restrict__ vox_off,
+                                                        int32_t* __restrict__ vox_cnt, int32_t* __restrict__ tmp) {
+    const int lane = threadIdx.x & 63;
+    const int colg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (colg >= dm.BT * dm.NCOL) return;
+    const int bt = colg / dm.NCOL;
+    int slot0 = col_off[colg];
+    const int frame0 = col_off[bt * dm.NCOL];
+    const int32_t* ids = vox_cm + (size_t)colg * dm.D * dm.fH;
+    for (int h = 0; h < dm.fH; ++h) {
+        const unsigned long long ends_w = masks[(size_t)colg * dm.fH + h].x;
+        if ((ends_w >> lane) & 1ull) {
+            const int v = ids[lane * dm.fH + h];
+            const int slot = slot0 + __popcll(ends_w & lanes_below(lane));
+            const int pos = atomicAdd(vox_cnt + (size_t)bt * dm.V + v, -1) - 1;
+            tmp[(size_t)frame0 + vox_off[(size_t)bt * (dm.V + 1) + v] + pos] = slot;
+        }
+        slot0 += __popcll(ends_w);
+    }
+}
+
+// (5) the atomics in (4) hand out the places in arrival order; this makes every voxel's list ascending -- ONE canonical
+//     summation order (bit-reproducible results, no floating-point atomics anywhere).  Lane = voxel for the usual short
+//     lists (rank sort: a handful of entries); a list longer than 32 is ranked by the whole wave.
+__global__ __launch_bounds__(256) void plan_sort_kernel(Dims dm, const int32_t* __restrict__ vox_off,
+                                                        const int32_t* __restrict__ col_off,
+                                                        const int32_t* __restrict__ tmp, int32_t* __restrict__ vox_runs) {
     const int bt = blockIdx.y;
-    const int q0 = blockIdx.x * 64, q = q0 + threadIdx.x;
-    const int ld = dm.fH + 1;
-    const int nq = min(64, dm.NQ - q0);
-    const int32_t* in = vox_cm + ((size_t)bt * dm.NQ + q0) * dm.fH;
-    for (int i = threadIdx.x; i < nq * dm.fH; i += 64) ids_s[(i / dm.fH) * ld + (i % dm.fH)] = in[i];
-    __syncthreads();
-    if (q >= dm.NQ) return;
-    const int d = q % dm.D, col = q / dm.D;
-    const int32_t* v0 = ids_s + threadIdx.x * ld;
-    int prev = -1, h0 = 0;
-    for (int h = 0; h <= dm.fH; ++h) {
-        const int v = h < dm.fH ? v0[h] : -1;
-        if (v != prev) {
-            if (prev >= 0) {
-                const int pos = atomicAdd(vox_cnt + (size_t)bt * dm.V + prev, -1) - 1;
-                const int slot = vox_off[(size_t)bt * (dm.V + 1) + prev] + pos;
-                desc[(size_t)bt * dm.P + slot] =
-                    make_uint2(((unsigned)col << 20) | ((unsigned)d << 14) | ((unsigned)h0 << 7) | (unsigned)(h - h0 - 1),
-                               (unsigned)prev);
-            }
-            h0 = h;
-            prev = v;
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const int frame0 = col_off[bt * dm.NCOL];
+    const int32_t* off = vox_off + (size_t)bt * (dm.V + 1);
+    int beg = 0, n = 0;
+    if (v < dm.V) {
+        beg = off[v];
+        n = off[v + 1] - beg;
+    }
+    const int32_t* src = tmp + (size_t)frame0;
+    int32_t* dst = vox_runs + (size_t)frame0;
+    if (n <= 32) {
+        for (int i = 0; i < n; ++i) {
+            const int e = src[beg + i];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += src[beg + j] < e ? 1 : 0;       // slots are distinct
+            dst[beg + rank] = e;
         }
     }
-}
-
-// (4) work-balanced voxel groups.  The work in front of voxel v of sample b is the sum over its frames of vox_off[v]
-//     (runs of all earlier voxels); a group starts where the 16-voxel block or the kGroupRuns-sized work bucket
-//     changes.  flags -> exclusive scan (plan_scan_kernel) -> list of group starts.
-__global__ __launch_bounds__(256) void plan_group_flags_kernel(Dims dm, const int32_t* __restrict__ vox_off,
-                                                               int32_t* __restrict__ flags) {
-    const int b = blockIdx.y;
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= dm.V) return;
-    int before = 0, before_prev = 0;
-    for (int t = 0; t < dm.T; ++t) {
-        const int32_t* off = vox_off + (size_t)(b * dm.T + t) * (dm.V + 1);
-        before += off[v];
-        before_prev += v > 0 ? off[v - 1] : 0;
-    }
-    const bool start = v == 0 || (v / kGroupVox) != ((v - 1) / kGroupVox) ||
-                       (before / kGroupRuns) != (before_prev / kGroupRuns);
-    flags[(size_t)b * dm.V + v] = start ? 1 : 0;
-}
-
-__global__ __launch_bounds__(256) void plan_group_list_kernel(Dims dm, const int32_t* __restrict__ flags,
-                                                              const int32_t* __restrict__ gidx,
-                                                              int32_t* __restrict__ groups) {
-    const int b = blockIdx.y;
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    if (v > dm.V) return;
-    const int32_t* gi = gidx + (size_t)b * (dm.V + 1);
-    int32_t* gl = groups + (size_t)b * (dm.V + 1);
-    if (v == dm.V) gl[gi[dm.V]] = dm.V;                      // closes the last group
-    else if (flags[(size_t)b * dm.V + v]) gl[gi[v]] = v;
-}
-
-// (5) one WAVE per (group, frame) orders the group's runs (a contiguous range of `desc`; a few dozen entries, up to a
-//     few hundred for a voxel next to a camera): longest first, ties by (camera, column, depth bin, first row).  The
-//     atomics in (3) hand out the slots in arrival order; this makes the summation order canonical (bit-reproducible
-//     pooling), and it puts runs of similar length next to each other: the forward kernel sums four consecutive runs
-//     in lockstep.  <= 64 runs: rank by counting smaller keys (registers); <= kSortCap: bitonic network in LDS;
-//     beyond (not seen): one lane, insertion sort.
-constexpr int kSortCap = 2048;
-
-__device__ __forceinline__ unsigned long long sort_word(uint2 e) {   // ascending word = longest first, then col|d|h0
-    const unsigned key = ((127u - (e.x & 127u)) << 25) | (e.x >> 7);
-    return ((unsigned long long)key << 32) | e.y;
-}
-__device__ __forceinline__ uint2 unsort_word(unsigned long long wd) {
-    const unsigned key = (unsigned)(wd >> 32);
-    return make_uint2(((key & 0x1ffffffu) << 7) | (127u - (key >> 25)), (unsigned)wd);
-}
-
-__global__ __launch_bounds__(128) void plan_group_sort_kernel(Dims dm, const int32_t* __restrict__ vox_off,
-                                                              const int32_t* __restrict__ gidx,
-                                                              const int32_t* __restrict__ groups,
-                                                              const uint2* __restrict__ desc,
-                                                              uint4* __restrict__ runs) {
-    __shared__ unsigned long long sbuf[2][kSortCap];
-    const float inv_fw = 1.0f / (float)dm.fW;
-    auto full = [&](uint2 e) {                                   // the run with its two addresses worked out
-        const int h0 = (e.x >> 7) & 127u, d = (e.x >> 14) & 63u, col = e.x >> 20;
-        const int n = (int)(((float)col + 0.5f) * inv_fw);       // col / fW (exact: col, fW < 4096)
-        const int w = col - n * dm.fW;
-        return make_uint4(e.x, e.y, (unsigned)((n * dm.fH + h0) * dm.fW + w), (unsigned)((col * dm.D + d) * dm.fH + h0));
-    };
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int b = blockIdx.y, t = blockIdx.z;
-    const int ngroups = gidx[(size_t)b * (dm.V + 1) + dm.V];
-    const int32_t* gl = groups + (size_t)b * (dm.V + 1);
-    const int bt = b * dm.T + t;
-    const int32_t* off = vox_off + (size_t)bt * (dm.V + 1);
-    unsigned long long* sb = sbuf[wv];
-    for (int g = blockIdx.x * 2 + wv; g < ngroups; g += gridDim.x * 2) {
-        const int start = off[gl[g]], n = off[gl[g + 1]] - start;      // wave-uniform
-        if (n < 1) continue;
-        const uint2* seg = desc + (size_t)bt * dm.P + start;
-        uint4* dst = runs + (size_t)bt * dm.P + start;
-        if (n <= 64) {
-            const unsigned long long e = lane < n ? sort_word(seg[lane]) : ~0ull;
-            const unsigned lo = (unsigned)e, hi = (unsigned)(e >> 32);
+    unsigned long long big = __ballot(n > 32);
+    while (big) {
+        const int l = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const int bb = __shfl(beg, l), nn = __shfl(n, l);
+        for (int i = lane; i < nn; i += 64) {
+            const int e = src[bb + i];
             int rank = 0;
-            for (int j = 0; j < n; ++j) {
-                const unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, j) << 32) |
-                                             (unsigned)__builtin_amdgcn_readlane((int)lo, j);
-                rank += o < e ? 1 : 0;
-            }
-            if (lane < n) dst[rank] = full(unsort_word(e));            // the words are distinct: ranks are a permutation
-        } else if (n <= kSortCap) {
-            int m = 128;
-            while (m < n) m <<= 1;
-            for (int i = lane; i < m; i += 64) sb[i] = i < n ? sort_word(seg[i]) : ~0ull;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (int k = 2; k <= m; k <<= 1) {
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int i = lane; i < m; i += 64) {
-                        const int pp = i ^ j;
-                        if (pp > i) {
-                            const unsigned long long a = sb[i], c = sb[pp];
-                            const bool up = (i & k) == 0;
-                            if ((a > c) == up) { sb[i] = c; sb[pp] = a; }
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            for (int i = lane; i < n; i += 64) dst[i] = full(unsort_word(sb[i]));
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        } else if (lane == 0) {
-            for (int i = 0; i < n; ++i) {                            // insertion sort straight into `runs`
-                const uint2 e = seg[i];
-                const unsigned long long ke = sort_word(e);
-                int j = i - 1;
-                while (j >= 0 && sort_word(make_uint2(dst[j].x, dst[j].y)) > ke) {
-                    dst[j + 1] = dst[j];
-                    --j;
-                }
-                dst[j + 1] = full(e);
-            }
+            for (int j = 0; j < nn; ++j) rank += src[bb + j] < e ? 1 : 0;
+            dst[bb + rank] = e;
         }
     }
 }
@@ -481,186 +447,202 @@ __global__ __launch_bounds__(256) void depth_softmax_kernel(Dims dm, const float
 }
 
 // ------------------------------------------------------------------------------------------
-// K2+K4+K5: forward -- one pass, pull form
+// K2+K4+K5: forward -- depth softmax + lift + voxel pooling + temporal accumulation, two passes
 // ------------------------------------------------------------------------------------------
-// A wave owns one voxel group (<= 16 consecutive voxels of one sample) and walks the frames t = 0..T-1 (the discounted state
-// bev_t = bev_{t-1} * discount + pool_t, stp3.py:296, lives in 16 registers per lane).  Lane = (slot, 4-channel
-// chunk): the 4 slots work on 4 consecutive runs of the wave's list at a time; a slot walks the rows of its run,
-//     acc[c] += prob[row][d] * feat[row][c]         (16 lanes x 16 bytes = one 256-byte feature row per load),
-// and then adds the run vector to its voxel's pool row in LDS -- slot after slot, i.e. in list order, so every
-// voxel is summed in ONE canonical order (bit-reproducible), without atomics.  Feature rows and probabilities are
-// read through L2 (a frame's features are 2.6 MB: the workgroup -> voxel mapping keeps a sample on one pair of
-// XCDs); the only HBM traffic besides the inputs is the BEV itself, written once as 256-byte voxel rows.
+// Pass 1 (lift_column_kernel): one WAVE per image column (bt, n, w), lane = channel.  The wave turns the column's
+// logits into probabilities (softmax over D per pixel, stp3.py:215; written out column-major for the backward pass),
+// keeps them in LDS, and then walks the rows: the row's feature value f (one coalesced 256-byte read per row -- every
+// feature and every logit is read from memory exactly ONCE) is multiplied into one accumulator per depth bin,
+//     acc[d] += prob[h][d] * f            (prob: LDS broadcast; 0 where the point falls outside the grid),
+// and where the plan's mask says that a run of bin d ends at this row, acc[d] -- the run's C-vector -- is stored in the
+// run's slot (256 bytes, coalesced) and cleared.  Slots are handed out in the order the wave meets the run ends.
+// Pass 2 (lift_gather_kernel): 16 lanes per voxel (4 channels each) add up the voxel's slots in ascending order and
+// carry the discounted state  bev_t = bev_{t-1} * discount + pool_t  (stp3.py:296) through the T frames in
+// registers; every BEV row is written once.  No atomics, one fixed summation order: bit-reproducible.
 // Output layout: [B][T][V][C] (channels-last BEV); the reference's [B][T][C][V] is produced by a transpose pass
 // when the caller asks for it.
-__device__ __forceinline__ float4 ld4(const float* base, unsigned byte_off) {
-    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-__device__ __forceinline__ float ld1(const float* base, unsigned byte_off) {
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+constexpr int kColRows = 16;     // rows of a column staged per round (taller columns take several rounds)
+constexpr int kProbLd = 68;      // floats per staged probability row: 16-byte aligned, rows 4 banks apart
+
+// acc[4g .. 4g+3] += prob[bins 4g .. 4g+3] * f ; the bins of group g sit in lanes (4g & 15) .. + 3 of pv[g >> 2]
+template <int GRP>
+__device__ __forceinline__ void fma_group(float (&acc)[64], const float (&pv)[4], float f) {
+    fmac_row_bcast<(4 * GRP + 0) & 15>(acc[4 * GRP + 0], pv[GRP >> 2], f);
+    fmac_row_bcast<(4 * GRP + 1) & 15>(acc[4 * GRP + 1], pv[GRP >> 2], f);
+    fmac_row_bcast<(4 * GRP + 2) & 15>(acc[4 * GRP + 2], pv[GRP >> 2], f);
+    fmac_row_bcast<(4 * GRP + 3) & 15>(acc[4 * GRP + 3], pv[GRP >> 2], f);
 }
 
-// Work distribution: the plan's voxel groups (<= 16 voxels, ~kGroupRuns runs over all frames, i.e. equal work) are
-// dealt out statically to a chip-sized set of persistent waves.  What bounds this kernel is the gather traffic
-// (~2 GB of 256-byte feature rows per launch), so it has to hit in L2: workgroup b runs on XCD b % 8, and with
-// 8 % B == 0 XCD x serves the x % (8/B)-th CONTIGUOUS slice of sample x / (8/B)'s groups -- a compact part of the
-// BEV, seen by two or three of the cameras -- and all waves walk the frames in lockstep order (t outer, groups inner),
-// so that at any time an XCD works on one frame of a few cameras (~2-3 MB of features and probabilities, vs 4 MB of
-// L2).  The price of the frame-major order: the discounted state of a group is re-read from the previous frame's
-// output (written by the same lanes; 256-byte rows) instead of being kept in registers.
-constexpr int kPullRows = 8;     // image rows in flight per slot
+// the runs of bins 4g .. 4g+3 that end at this row (nib: their 4 mask bits, wave-uniform): store and clear
+template <int GRP>
+__device__ __forceinline__ void emit_group(float (&acc)[64], unsigned nib, bool chan, float*& sp, int C) {
+    if (nib == 0u) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if ((nib >> k) & 1u) {
+            if (chan) *sp = acc[4 * GRP + k];
+            acc[4 * GRP + k] = 0.f;
+            sp += C;
+        }
+    }
+}
 
-__global__ __launch_bounds__(256) void lift_pull_kernel(Dims dm, const float* __restrict__ feat,
-                                                        const float* __restrict__ prob,
-                                                        const int32_t* __restrict__ vox_off,
-                                                        const uint4* __restrict__ runs,
-                                                        const int32_t* __restrict__ gidx,
-                                                        const int32_t* __restrict__ groups, float discount,
-                                                        float* __restrict__ bev_cl) {
-    __shared__ __attribute__((aligned(16))) float pool_s[4][kGroupVox][64];
+template <int G, int GRP>
+struct ColumnRow {
+    static __device__ __forceinline__ void run(float (&acc)[64], const float (&pv)[4], float f, unsigned lo, unsigned hi,
+                                               bool chan, float*& sp, int C) {
+        fma_group<GRP>(acc, pv, f);
+        emit_group<GRP>(acc, ((GRP < 8 ? lo : hi) >> ((4 * GRP) & 31)) & 15u, chan, sp, C);
+        ColumnRow<G, GRP + 1>::run(acc, pv, f, lo, hi, chan, sp, C);
+    }
+};
+template <int G>
+struct ColumnRow<G, G> {
+    static __device__ __forceinline__ void run(float (&)[64], const float (&)[4], float, unsigned, unsigned, bool, float*&,
+                                               int) {}
+};
+
+template <int G>   // depth bins in groups of 4: D <= 4 G
+__global__ __launch_bounds__(256) void lift_column_kernel(Dims dm, const float* __restrict__ feat,
+                                                          const float* __restrict__ logits,
+                                                          const Mask2* __restrict__ masks,
+                                                          const int32_t* __restrict__ col_off,
+                                                          float* __restrict__ prob_cm, float* __restrict__ slots) {
+    __shared__ __attribute__((aligned(16))) float prob_s[4][kColRows][kProbLd];
+    __shared__ __attribute__((aligned(16))) float feat_s[4][kColRows][64];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = lane >> 4;
-    const int c4 = (lane & 15) * 4;
-    const bool chan_ok = c4 < dm.C;
-    float* pool = &pool_s[wv][0][0];
-    const unsigned fstride = (unsigned)dm.fW * dm.C * 4u;
-    // (samples, slice, rank, stride) of this wave
-    int b_lo, b_hi, sub, xps, rank, stride;
-    if ((8 % dm.B) == 0 && (gridDim.x & 7) == 0) {
-        xps = 8 / dm.B;                                            // XCDs per sample
-        const int xcd = blockIdx.x & 7;
-        b_lo = xcd / xps; b_hi = b_lo + 1;
-        sub = xcd % xps;
-        rank = (blockIdx.x >> 3) * 4 + wv;
-        stride = (gridDim.x >> 3) * 4;                             // waves per XCD
-    } else {                                                       // any B: every wave strides over every sample
-        xps = 1; sub = 0;
-        b_lo = 0; b_hi = dm.B;
-        rank = blockIdx.x * 4 + wv;
-        stride = gridDim.x * 4;
-    }
+    const int colg = blockIdx.x * 4 + wv;
+    if (colg >= dm.BT * dm.NCOL) return;
+    const int bt = colg / dm.NCOL, col = colg - bt * dm.NCOL;
+    const int n = col / dm.fW, w = col - n * dm.fW;
+    const int D = dm.D, C = dm.C;
+    float (*ps)[kProbLd] = prob_s[wv];
+    float (*fs)[64] = feat_s[wv];
+    const Mask2* mk = masks + (size_t)colg * dm.fH;
+    const size_t pix0 = (size_t)bt * dm.NPIX + (size_t)n * dm.fH * dm.fW + w;      // pixel (h = 0) of the column
+    const bool chan = lane < C;
+    float* sp = slots + (size_t)col_off[colg] * C + (chan ? lane : 0);            // slot of the next run that ends
+    float acc[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) acc[k] = 0.f;
 
-    for (int b = b_lo; b < b_hi; ++b) {
-        const int32_t* glist = groups + (size_t)b * (dm.V + 1);
-        const int ngroups = gidx[(size_t)b * (dm.V + 1) + dm.V];
-        const int g_lo = (int)((int64_t)ngroups * sub / xps), g_hi = (int)((int64_t)ngroups * (sub + 1) / xps);
-        const int mine = g_lo + rank < g_hi ? (g_hi - g_lo - rank + stride - 1) / stride : 0;   // groups of this wave
-        const int items = mine * dm.T;                                 // (frame, group) pairs, frame-major
-        // Three dependent fetches stand before the first feature row of an item: the list bounds of its voxels, the
-        // descriptors of its first four runs, the rows themselves.  The first two are requested one item ahead
-        // (bounds: two ahead), the descriptors of the next four runs while the current four are summed.
-        auto item_group = [&](int k) { return g_lo + rank + (k % mine) * stride; };
-        auto fetch_bound = [&](int k) -> int {                       // lane l <= 16: first run of voxel vfirst + l
-            if (k >= items) return 0;
-            const int g = item_group(k), t = k / mine;
-            const int vfirst = glist[g], vend = glist[g + 1];
-            return vox_off[(size_t)(b * dm.T + t) * (dm.V + 1) + min(vfirst + min(lane, kGroupVox), vend)];
-        };
-        auto fetch_desc = [&](int k, int r, int rend) -> uint4 {      // run r of item k (only if r < rend)
-            uint4 ds = make_uint4(0u, 0u, 0u, 0u);
-            if (k < items && r < rend) ds = runs[(size_t)(b * dm.T + k / mine) * dm.P + r];
-            return ds;
-        };
-        int bound_cur = fetch_bound(0);
-        int bound_nxt = fetch_bound(1);
-        uint4 ds_cur = fetch_desc(0, __builtin_amdgcn_readlane(bound_cur, 0) + slot, __builtin_amdgcn_readlane(bound_cur, kGroupVox));
-
-        for (int k = 0; k < items; ++k) {
-            const int t = k / mine, g = item_group(k);
-            const int bt = b * dm.T + t;
-            const uint4* dlist = runs + (size_t)bt * dm.P;
-            const unsigned frame_pix = (unsigned)bt * (unsigned)dm.NPIX, frame_pts = (unsigned)bt * (unsigned)dm.P;
-            const float* prev_out = bev_cl + (size_t)(bt - 1) * dm.V * dm.C;   // read only for t > 0
-            float* cur_out = bev_cl + (size_t)bt * dm.V * dm.C;
-            const int vfirst = glist[g], vend = glist[g + 1];           // 1..16 voxels
-            const int rbeg = __builtin_amdgcn_readlane(bound_cur, 0);
-            const int rend = __builtin_amdgcn_readlane(bound_cur, kGroupVox);
-            // requests for the items ahead
-            const int bound_nn = fetch_bound(k + 2);
-            const int nbeg = __builtin_amdgcn_readlane(bound_nxt, 0), nend = __builtin_amdgcn_readlane(bound_nxt, kGroupVox);
-            const uint4 ds_first_nxt = fetch_desc(k + 1, nbeg + slot, nend);
-            // the discounted state of the group's voxels: last frame's output rows (this lane wrote them itself)
-            float4 st[4];
+    const int rsub = lane >> 4;                 // staging: 16 lanes per pixel, 4 bins / 4 channels per lane
+    const int e0 = (lane & 15) * 4;
+    const bool vec = (D & 3) == 0;
+    for (int h0 = 0; h0 < dm.fH; h0 += kColRows) {
+        const int rows = min(kColRows, dm.fH - h0);
+        // ---- every global read of the round is issued before the first use: logits and features of 4 pixels per
+        //      load instruction, the two mask words of row `lane`
+        float lg[kColRows / 4][4];
+        float4 fq[kColRows / 4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int v = vfirst + slot + 4 * q;
-                st[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t > 0 && v < vend && chan_ok) st[q] = *reinterpret_cast<const float4*>(prev_out + (size_t)v * dm.C + c4);
+        for (int i = 0; i < kColRows / 4; ++i) {
+            const int r = 4 * i + rsub;
+            const bool live = r < rows;
+            const size_t pix = pix0 + (size_t)(h0 + (live ? r : 0)) * dm.fW;
+            const float* row = logits + pix * D;
+            if (live && vec && e0 < D) {
+                const float4 qv = *reinterpret_cast<const float4*>(row + e0);
+                lg[i][0] = qv.x; lg[i][1] = qv.y; lg[i][2] = qv.z; lg[i][3] = qv.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lg[i][k] = (live && e0 + k < D) ? row[e0 + k] : -INFINITY;
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4*>(pool + (slot + 4 * q) * 64 + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
-            __builtin_amdgcn_wave_barrier();
-
-            uint4 ds = ds_cur;
-            for (int r0 = rbeg; r0 < rend; r0 += 4) {
-                const int r = r0 + slot;
-                const bool valid = r < rend;
-                const uint4 ds_next = (r + 4 < rend) ? dlist[r + 4] : make_uint4(0u, 0u, 0u, 0u);   // for the next round
-                const int len = valid ? (int)(ds.x & 127u) + 1 : 0;
-                const unsigned foff = ((frame_pix + ds.z) * (unsigned)dm.C + (unsigned)(chan_ok ? c4 : 0)) * 4u;
-                unsigned poff = (frame_pts + ds.w) * 4u;            // prob_cm[bt][col][d][h0 ...]: the run's rows are contiguous
-                const int maxlen = max(max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 16)),
-                                       max(__builtin_amdgcn_readlane(len, 32), __builtin_amdgcn_readlane(len, 48)));
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int last = len > 0 ? len - 1 : 0;
-                // The memory pipeline takes one vector-load instruction per 16 cycles whatever its width, and this
-                // kernel is bound by instruction issue: (a) one load brings the probabilities of 16 rows (lane j of
-                // the slot: row i + j; one 64-byte piece of the column-major layout), each row's value is then
-                // broadcast within the slot through the LDS crossbar; (b) feature rows are loaded unconditionally --
-                // a slot whose run is shorter than the round's longest re-reads its last row (a cache hit) and
-                // multiplies it by a zero probability -- which spares the exec-mask bookkeeping of predicated loads.
-                float pvec = 0.f;
-                for (int i = 0; i < maxlen; i += kPullRows) {
-                    if ((i & 15) == 0) {
-                        pvec = 0.f;
-                        if (i + (lane & 15) < len) pvec = ld1(prob, poff + (unsigned)(lane & 15) * 4u);
-                        poff += 64u;
-                    }
-                    float4 f[kPullRows];
-#pragma unroll
-                    for (int u = 0; u < kPullRows; ++u) f[u] = ld4(feat, foff + (unsigned)min(i + u, last) * fstride);
-#pragma unroll
-                    for (int u = 0; u < kPullRows; ++u) {
-                        const float pr = __shfl(pvec, (lane & 48) | ((i + u) & 15));     // rows beyond the run carry 0
-                        acc.x = fmaf(pr, f[u].x, acc.x);
-                        acc.y = fmaf(pr, f[u].y, acc.y);
-                        acc.z = fmaf(pr, f[u].z, acc.z);
-                        acc.w = fmaf(pr, f[u].w, acc.w);
-                    }
-                }
-                // add the four run vectors to their voxels' pool rows, in list order (slot 0 first)
-                const int vi = valid ? (int)ds.y - vfirst : 0;
-#pragma unroll
-                for (int sl = 0; sl < 4; ++sl) {
-                    if (slot == sl && valid && chan_ok) {
-                        float4* cell = reinterpret_cast<float4*>(pool + vi * 64 + c4);
-                        float4 q = *cell;
-                        q.x += acc.x; q.y += acc.y; q.z += acc.z; q.w += acc.w;
-                        *cell = q;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                ds = ds_next;
-            }
-            // bev_t = bev_{t-1} * discount + pool_t (stp3.py:296); rows of 4 voxels per store instruction
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int vi = slot + 4 * q, v = vfirst + vi;
-                const float4 pl = *reinterpret_cast<const float4*>(pool + vi * 64 + c4);
-                float4 o;
-                o.x = st[q].x * discount + pl.x;
-                o.y = st[q].y * discount + pl.y;
-                o.z = st[q].z * discount + pl.z;
-                o.w = st[q].w * discount + pl.w;
-                if (v < vend && chan_ok) *reinterpret_cast<float4*>(cur_out + (size_t)v * dm.C + c4) = o;
-            }
-            __builtin_amdgcn_wave_barrier();
-            bound_cur = bound_nxt;
-            bound_nxt = bound_nn;
-            ds_cur = ds_first_nxt;
+            fq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live && e0 < C) fq[i] = *reinterpret_cast<const float4*>(feat + pix * C + e0);
         }
+        Mask2 mrow = Mask2{0ull, 0ull};
+        if (lane < rows) mrow = mk[h0 + lane];
+        const unsigned ends_lo = (unsigned)mrow.x, ends_hi = (unsigned)(mrow.x >> 32);
+        const unsigned valid_lo = (unsigned)mrow.y, valid_hi = (unsigned)(mrow.y >> 32);
+        // ---- softmax over the bins of each pixel (16 lanes) -> LDS, unmasked; features -> LDS
+        float pr[kColRows / 4][4];
+#pragma unroll
+        for (int i = 0; i < kColRows / 4; ++i) {
+            const int r = 4 * i + rsub;
+            const bool live = r < rows;
+            float mx = fmaxf(fmaxf(lg[i][0], lg[i][1]), fmaxf(lg[i][2], lg[i][3]));
+#pragma unroll
+            for (int s = 8; s > 0; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pr[i][k] = (e0 + k < D) ? __expf(lg[i][k] - mx) : 0.f;
+                sum += pr[i][k];
+            }
+#pragma unroll
+            for (int s = 8; s > 0; s >>= 1) sum += __shfl_xor(sum, s);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pr[i][k] = live ? pr[i][k] * inv : 0.f;
+            *reinterpret_cast<float4*>(&ps[r][e0]) = make_float4(pr[i][0], pr[i][1], pr[i][2], pr[i][3]);
+            *reinterpret_cast<float4*>(&fs[r][e0]) = fq[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- prob_cm[bt][col][d][h0 .. h0+rows): 16 consecutive rows of 4 bins per store instruction
+        if (prob_cm) {
+            float* out = prob_cm + (size_t)colg * D * dm.fH + h0;
+            const int r = lane & (kColRows - 1);
+            for (int d = lane / kColRows; d < D; d += 64 / kColRows)
+                if (r < rows) out[(size_t)d * dm.fH + r] = ps[r][d];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- points outside the grid contribute nothing: zero their probabilities in the staged copy
+#pragma unroll
+        for (int i = 0; i < kColRows / 4; ++i) {
+            const int r = 4 * i + rsub;
+            const unsigned vlo = __shfl(valid_lo, r), vhi = __shfl(valid_hi, r);
+            const unsigned vbits = ((e0 < 32 ? vlo : vhi) >> (e0 & 31)) & 15u;
+            float4 q;
+            q.x = (vbits & 1u) ? pr[i][0] : 0.f;
+            q.y = (vbits & 2u) ? pr[i][1] : 0.f;
+            q.z = (vbits & 4u) ? pr[i][2] : 0.f;
+            q.w = (vbits & 8u) ? pr[i][3] : 0.f;
+            *reinterpret_cast<float4*>(&ps[r][e0]) = q;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- walk the rows
+        for (int i = 0; i < rows; ++i) {
+            const float f = fs[i][lane];
+            const unsigned lo = __builtin_amdgcn_readlane(ends_lo, i);
+            const unsigned hi = __builtin_amdgcn_readlane(ends_hi, i);
+            // the row's probabilities: lane l holds bins 16k + (l & 15), k = 0..3; bin d reaches every lane as the
+            // DPP row broadcast of lane d & 15 of register d >> 4, folded into the multiply-add (stp3_dpp.h)
+            float pv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pv[k] = (4 * k < G) ? ps[i][16 * k + (lane & 15)] : 0.f;
+            ColumnRow<G, 0>::run(acc, pv, f, lo, hi, chan, sp, C);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(256) void lift_gather_kernel(Dims dm, const float* __restrict__ slots,
+                                                          const int32_t* __restrict__ vox_off,
+                                                          const int32_t* __restrict__ col_off,
+                                                          const int32_t* __restrict__ vox_runs, float discount,
+                                                          float* __restrict__ bev_cl) {
+    const int b = blockIdx.y;
+    const int v = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int c4 = (threadIdx.x & 15) * 4;
+    if (v >= dm.V || c4 >= dm.C) return;
+    float4 st = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < dm.T; ++t) {
+        const int bt = b * dm.T + t;
+        const int32_t* off = vox_off + (size_t)bt * (dm.V + 1) + v;
+        const int beg = off[0], end = off[1];
+        const int32_t* list = vox_runs + (size_t)col_off[bt * dm.NCOL];
+        float4 pool = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = beg; i < end; ++i) {
+            const float4 q = *reinterpret_cast<const float4*>(slots + (size_t)list[i] * dm.C + c4);
+            pool.x += q.x; pool.y += q.y; pool.z += q.z; pool.w += q.w;
+        }
+        st.x = st.x * discount + pool.x;              // stp3.py:296
+        st.y = st.y * discount + pool.y;
+        st.z = st.z * discount + pool.z;
+        st.w = st.w * discount + pool.w;
+        *reinterpret_cast<float4*>(bev_cl + ((size_t)bt * dm.V + v) * dm.C + c4) = st;
     }
 }
 
@@ -995,7 +977,7 @@ __global__ __launch_bounds__(256) void lift_bwd_kernel(Dims dm, int rows_pc, int
 // ==========================================================================================
 extern "C" {
 
-const char* stp3_version(void) { return "stp3hip 0.2 gfx950"; }
+const char* stp3_version(void) { return "stp3hip 0.3 gfx950"; }
 
 
 int stp3_voxel_index(const stp3_lift_dims* dims, const float* cam_m, const float* cam_t, const float* ego_r,
@@ -1052,21 +1034,17 @@ int stp3_lift_plan_build(const stp3_lift_dims* dims, const float* cam_m, const f
     PlanView pv = plan_view(dm, plan);
     GeomArgs g{cam_m, cam_t, ego_r, ego_t, xs, ys, ds, bev_offset, bev_res};
     hipStream_t s = (hipStream_t)stream;
-    const dim3 qgrid((dm.NQ + 63) / 64, dm.BT);
-    const size_t ids_lds = (size_t)64 * (dm.fH + 1) * sizeof(int32_t);
-    hipLaunchKernelGGL(plan_index_count_kernel, qgrid, dim3(64), ids_lds, s, dm, g, vox_cm, counts);
+    const int ncols = dm.BT * dm.NCOL;
+    const dim3 cgrid((ncols + 3) / 4);
+    size_t ids_lds = (size_t)4 * dm.D * dm.fH * sizeof(int32_t);
+    const int stage = ids_lds <= 48 * 1024;
+    if (!stage) ids_lds = 0;
+    hipLaunchKernelGGL(plan_columns_kernel, cgrid, dim3(256), ids_lds, s, dm, g, vox_cm, counts, pv.masks, pv.col_cnt, stage);
+    hipLaunchKernelGGL(plan_scan_all_kernel, dim3(1), dim3(1024), 0, s, ncols, pv.col_cnt, pv.col_off);
     hipLaunchKernelGGL(plan_scan_kernel, dim3((dm.V + 1023) / 1024, dm.BT), dim3(1024), 0, s, dm.V, counts, pv.vox_off);
-    hipLaunchKernelGGL(plan_fill_kernel, qgrid, dim3(64), ids_lds, s, dm, vox_cm, pv.vox_off, counts, pv.desc);
-    // voxel groups of equal work: flags (in `groups`, reused below) -> scan -> list
-    int32_t* flags = counts;                                    // zero again by now; restored to zero below
-    hipLaunchKernelGGL(plan_group_flags_kernel, dim3((dm.V + 255) / 256, dm.B), dim3(256), 0, s, dm, pv.vox_off, flags);
-    hipLaunchKernelGGL(plan_scan_kernel, dim3((dm.V + 1023) / 1024, dm.B), dim3(1024), 0, s, dm.V, flags, pv.gidx);
-    hipLaunchKernelGGL(plan_group_list_kernel, dim3((dm.V + 256) / 256, dm.B), dim3(256), 0, s, dm, flags, pv.gidx, pv.groups);
-    hipError_t e = hipMemsetAsync(flags, 0, (size_t)dm.B * dm.V * sizeof(int32_t), s);
-    if (e != hipSuccess) return -(int)e;
-    if (dm.T > 65535) return STP3_EUNSUP;
-    hipLaunchKernelGGL(plan_group_sort_kernel, dim3(1024, dm.B, dm.T), dim3(128), 0, s, dm, pv.vox_off, pv.gidx, pv.groups,
-                       pv.desc, pv.runs);
+    hipLaunchKernelGGL(plan_fill_kernel, cgrid, dim3(256), 0, s, dm, vox_cm, pv.masks, pv.col_off, pv.vox_off, counts, pv.tmp);
+    hipLaunchKernelGGL(plan_sort_kernel, dim3((dm.V + 255) / 256, dm.BT), dim3(256), 0, s, dm, pv.vox_off, pv.col_off, pv.tmp,
+                       pv.vox_runs);
     return launch_status();
 }
 
@@ -1090,12 +1068,20 @@ int stp3_depth_softmax(const stp3_lift_dims* dims, const float* logits, float* p
     return launch_status();
 }
 
+// forward: one slot (C floats) per run, at most one run per frustum point, then (channels-first output only) the
+// channels-last result in front of the transpose; backward: the imported gradient [BT][V][C]
+static size_t workspace_need(const Dims& dm) {
+    const size_t slots = (size_t)dm.BT * dm.P * dm.C * sizeof(float);
+    const size_t planes = (size_t)dm.BT * dm.V * dm.C * sizeof(float);
+    return slots + planes;
+}
+
 int stp3_lift_workspace_bytes(const stp3_lift_dims* dims, size_t* bytes) {
     Dims dm;
     int rc = check_dims(dims, &dm);
     if (rc) return rc;
     if (!bytes) return STP3_EINVAL;
-    *bytes = (size_t)dm.BT * dm.V * dm.C * sizeof(float);
+    *bytes = workspace_need(dm);
     return STP3_OK;
 }
 
@@ -1104,31 +1090,32 @@ static void launch_transpose(hipStream_t s, int batch, int rows, int cols, const
                        out);
 }
 
-int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const float* prob, const void* plan,
-                        float discount, int bev_layout, void* workspace, size_t workspace_bytes, float* bev,
-                        void* stream) {
+int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const float* logits, const void* plan,
+                        float discount, int bev_layout, void* workspace, size_t workspace_bytes, float* prob_cm,
+                        float* bev, void* stream) {
     Dims dm;
     int rc = check_dims(dims, &dm);
     if (rc) return rc;
-    if (!feat || !prob || !plan || !bev) return STP3_EINVAL;
+    if (!feat || !logits || !plan || !bev || !workspace) return STP3_EINVAL;
     if ((rc = pool_limits(dm))) return rc;
     if (bev_layout != STP3_BEV_CHANNELS_FIRST && bev_layout != STP3_BEV_CHANNELS_LAST) return STP3_EINVAL;
     const bool cf = bev_layout == STP3_BEV_CHANNELS_FIRST;
-    const size_t need = cf ? (size_t)dm.BT * dm.V * dm.C * sizeof(float) : 0;
-    if (cf && (!workspace || workspace_bytes < need)) return STP3_ENOSPACE;
-    if (cf && dm.BT > 65535) return STP3_EUNSUP;
+    if (workspace_bytes < workspace_need(dm)) return STP3_ENOSPACE;
+    if (dm.B > 65535) return STP3_EUNSUP;
     PlanView pv = plan_view(dm, const_cast<void*>(plan));
     hipStream_t s = (hipStream_t)stream;
-    float* out_cl = cf ? (float*)workspace : bev;
-    // persistent waves: exactly the chip's worth of resident workgroups (a multiple of 8, so that every XCD gets the
-    // same share), each striding over the voxel groups
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lift_pull_kernel, 256, 0) != hipSuccess || cus <= 0 || per_cu <= 0)
-        return STP3_EUNSUP;
-    const int64_t blocks = ((int64_t)cus * per_cu) & ~(int64_t)7 ? ((int64_t)cus * per_cu) & ~(int64_t)7 : 8;
-    hipLaunchKernelGGL(lift_pull_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dm, feat, prob, pv.vox_off, pv.runs,
-                       pv.gidx, pv.groups, discount, out_cl);
+    float* slots = (float*)workspace;
+    float* out_cl = cf ? slots + (size_t)dm.BT * dm.P * dm.C : bev;
+    const int ncols = dm.BT * dm.NCOL;
+    const dim3 cgrid((ncols + 3) / 4);
+    if (dm.D <= 32)
+        hipLaunchKernelGGL(lift_column_kernel<8>, cgrid, dim3(256), 0, s, dm, feat, logits, pv.masks, pv.col_off, prob_cm, slots);
+    else if (dm.D <= 48)
+        hipLaunchKernelGGL(lift_column_kernel<12>, cgrid, dim3(256), 0, s, dm, feat, logits, pv.masks, pv.col_off, prob_cm, slots);
+    else
+        hipLaunchKernelGGL(lift_column_kernel<16>, cgrid, dim3(256), 0, s, dm, feat, logits, pv.masks, pv.col_off, prob_cm, slots);
+    hipLaunchKernelGGL(lift_gather_kernel, dim3((dm.V + 15) / 16, dm.B), dim3(256), 0, s, dm, slots, pv.vox_off, pv.col_off,
+                       pv.vox_runs, discount, out_cl);
     if (cf) launch_transpose(s, dm.BT, dm.V, dm.C, out_cl, bev);          // [V][C] -> [C][V]: stp3.py:230-232 layout
     return launch_status();
 }

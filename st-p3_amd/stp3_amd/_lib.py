@@ -105,7 +105,7 @@ SIGNATURES = {
     'stp3_depth_softmax': (c_int, [_DIMS_P, c_void_p, c_void_p, c_void_p]),
     'stp3_lift_workspace_bytes': (c_int, [_DIMS_P, ctypes.POINTER(c_size_t)]),
     'stp3_lift_splat_fwd': (c_int, [_DIMS_P, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_size_t,
-                                    c_void_p, c_void_p]),
+                                    c_void_p, c_void_p, c_void_p]),
     'stp3_lift_splat_bwd': (c_int, [_DIMS_P, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
                                     c_size_t, c_void_p, c_void_p, c_void_p]),
     'stp3_dwconv2d_fwd': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -221,34 +221,40 @@ class LiftPlan:
         d = self.dims
         return self.vox_cm.view(d.B, d.T, d.N, d.fW, d.D, d.fH).permute(0, 1, 2, 4, 5, 3)
 
+    def _sections(self):
+        """Byte offsets of the plan's sections (include/stp3_hip.h: vox_off, masks, col_cnt, col_off, tmp, vox_runs)."""
+        d = self.dims
+        a = self._align256
+        ncol = d.BT * d.N * d.fW
+        sizes = [a(d.BT * (d.V + 1) * 4), a(ncol * d.fH * 16), a(ncol * 4), a((ncol + 1) * 4), a(d.BT * d.P * 4),
+                 a(d.BT * d.P * 4)]
+        return [sum(sizes[:i]) for i in range(len(sizes))]
+
     def offsets(self):
-        """[BT, V+1] int32 view: exclusive scan of the runs per voxel."""
+        """[BT, V+1] int32 view: exclusive scan of the runs per voxel (per frame)."""
         d = self.dims
         return self.plan[:d.BT * (d.V + 1) * 4].view(torch.int32).view(d.BT, d.V + 1)
 
-    def _sections(self):
+    def masks(self):
+        """[BT, N*fW, fH, 2] int64 view: bit d of [..., 0] = a run of depth bin d ends at this row of the image column,
+        bit d of [..., 1] = point (d, h) lies inside the BEV grid."""
         d = self.dims
-        a = self._align256
-        sizes = [a(d.BT * (d.V + 1) * 4), a(d.BT * d.P * 8), a(d.B * (d.V + 1) * 4), a(d.B * (d.V + 1) * 4), a(d.BT * d.P * 16)]
-        starts = [sum(sizes[:i]) for i in range(len(sizes))]
-        return starts
+        o = self._sections()[1]
+        return self.plan[o:o + d.BT * d.N * d.fW * d.fH * 16].view(torch.int64).view(d.BT, d.N * d.fW, d.fH, 2)
 
-    def descriptors(self):
-        """[BT, P, 4] int32 view of the ordered run list: (col << 20 | d << 14 | h0 << 7 | len - 1, voxel id, first
-        feature row, first probability -- both relative to the frame); the runs of the work group [a, e) of frame bt
-        are rows offsets()[bt, a] .. offsets()[bt, e], longest first."""
+    def column_offsets(self):
+        """[BT*N*fW + 1] int32 view: slot of every image column's first run (exclusive scan over all frames); the
+        last entry is the total number of runs."""
         d = self.dims
-        o = self._sections()[4]
-        return self.plan[o:o + d.BT * d.P * 16].view(torch.int32).view(d.BT, d.P, 4)
+        o = self._sections()[3]
+        return self.plan[o:o + (d.BT * d.N * d.fW + 1) * 4].view(torch.int32)
 
-    def groups(self):
-        """Per sample: the first voxel of every work group of the forward kernel, closed by V (list of 1-D int32
-        tensors).  A group holds at most 16 consecutive voxels and ~32 runs over the sample's T frames."""
+    def run_lists(self):
+        """[BT*P] int32 view: the per-voxel slot lists; voxel v of frame bt owns
+        ``[column_offsets()[bt*N*fW] + offsets()[bt, v], ... + offsets()[bt, v+1])``, ascending."""
         d = self.dims
-        st = self._sections()
-        gidx = self.plan[st[2]:st[2] + d.B * (d.V + 1) * 4].view(torch.int32).view(d.B, d.V + 1)
-        glist = self.plan[st[3]:st[3] + d.B * (d.V + 1) * 4].view(torch.int32).view(d.B, d.V + 1)
-        return [glist[b, :int(gidx[b, d.V]) + 1] for b in range(d.B)]
+        o = self._sections()[5]
+        return self.plan[o:o + d.BT * d.P * 4].view(torch.int32)
 
 
 def depth_softmax(dims, logits_pm):
@@ -265,8 +271,9 @@ _WORKSPACE = {}
 
 
 def lift_workspace(dims, device):
-    """Scratch of the pooling calls (one buffer per device, grown on demand): the voxel-major gradient G_t of the
-    backward and, for the reference (channels-first) layout, the channels-last BEV before the transpose pass."""
+    """Scratch of the pooling calls (one buffer per device, grown on demand): the run slots of the forward, the
+    voxel-major gradient G_t of the backward and, for the reference (channels-first) layout, the channels-last BEV
+    before the transpose pass."""
     nbytes = ctypes.c_size_t()
     check(_lib.lib().stp3_lift_workspace_bytes(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_lift_workspace_bytes')
     key = torch.device(device)
@@ -289,18 +296,18 @@ class _LiftSplat(torch.autograd.Function):
         logits_pm = logits_pm.contiguous()
         assert feat_pm.dtype == torch.float32 and logits_pm.dtype == torch.float32
         assert feat_pm.shape == (d.BT, d.NPIX, d.C) and logits_pm.shape == (d.BT, d.NPIX, d.D)
-        with _timed('depth_softmax'):
-            prob = depth_softmax(d, logits_pm)
         dev = feat_pm.device
+        # the probabilities are a by-product of the forward kernel (column-major, what the backward kernel reads)
+        prob = torch.empty(d.BT, d.N * d.fW, d.D, d.fH, dtype=torch.float32, device=dev)
         layout = BEV_CHANNELS_LAST if channels_last else BEV_CHANNELS_FIRST
         shape = (d.B, d.T, d.X, d.Y, d.C) if channels_last else (d.B, d.T, d.C, d.X, d.Y)
         bev = torch.empty(shape, dtype=torch.float32, device=dev)
         ws, ws_bytes = lift_workspace(d, dev)
         ws_ptr = _ptr(ws)
         with _timed('lift_splat_fwd'):
-            rc = _lib.lib().stp3_lift_splat_fwd(ctypes.byref(d), _ptr(feat_pm), _ptr(prob), _ptr(lift_plan.plan),
+            rc = _lib.lib().stp3_lift_splat_fwd(ctypes.byref(d), _ptr(feat_pm), _ptr(logits_pm), _ptr(lift_plan.plan),
                                                 ctypes.c_float(discount), layout, ws_ptr, ctypes.c_size_t(ws_bytes),
-                                                _ptr(bev), _stream())
+                                                _ptr(prob), _ptr(bev), _stream())
         check(rc, 'stp3_lift_splat_fwd')
         ctx.save_for_backward(feat_pm, prob)
         ctx.lift_plan = lift_plan

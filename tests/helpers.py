@@ -96,3 +96,40 @@ def sample(t, n=4096):
     flat = t.detach().reshape(-1)
     step = max(1, flat.numel() // n)
     return flat[::step].contiguous()
+
+
+def check_plan_structure(plan, vox):
+    """The pooling plan against the voxel ids it was built from (include/stp3_hip.h, plan sections).
+    ``vox``: (BT, N, D, fH, fW) ids in the reference's order.  A RUN is a maximal stretch of consecutive rows of an
+    image column and depth bin with one id >= 0; its SLOT is its position in the enumeration frame, column, LAST row,
+    depth bin.  Checks the row masks, the column scan, the per-voxel scan and that every voxel lists exactly the slots
+    of its runs in ascending order.  Returns the total number of runs."""
+    d = plan.dims
+    vox = np.asarray(vox).reshape(d.BT, d.N, d.D, d.fH, d.fW)
+    nxt = np.concatenate([vox[:, :, :, 1:], np.full_like(vox[:, :, :, :1], -1)], axis=3)
+    valid = vox >= 0
+    ends = valid & (nxt != vox)
+    # (BT, N, D, fH, fW) -> (BT, col = n*fW + w, fH, D)
+    order = lambda a: a.transpose(0, 1, 4, 3, 2).reshape(d.BT, d.N * d.fW, d.fH, d.D)
+    ends_c, valid_c, vox_c = order(ends), order(valid), order(vox)
+    bits = (np.uint64(1) << np.arange(d.D, dtype=np.uint64))
+    want_masks = np.stack([(ends_c * bits).sum(-1, dtype=np.uint64), (valid_c * bits).sum(-1, dtype=np.uint64)], -1)
+    got_masks = plan.masks().cpu().numpy().view(np.uint64)
+    assert np.array_equal(got_masks, want_masks), 'row masks'
+    per_col = ends_c.reshape(d.BT * d.N * d.fW, -1).sum(1)
+    col_off = plan.column_offsets().cpu().numpy()
+    assert np.array_equal(col_off, np.concatenate([[0], np.cumsum(per_col)])), 'column scan'
+    slot = np.cumsum(ends_c.reshape(-1)) - 1                       # C order of (bt, col, h, d) IS the enumeration
+    off = plan.offsets().cpu().numpy()
+    lists = plan.run_lists().cpu().numpy()
+    for bt in range(d.BT):
+        e = ends_c[bt].reshape(-1)
+        ids = vox_c[bt].reshape(-1)[e]
+        slots = slot.reshape(d.BT, -1)[bt][e]
+        assert np.array_equal(np.diff(off[bt]), np.bincount(ids, minlength=d.V)), 'voxel scan'
+        frame0 = col_off[bt * d.N * d.fW]
+        assert off[bt][-1] == col_off[(bt + 1) * d.N * d.fW] - frame0
+        by_voxel = np.lexsort((slots, ids))                        # voxel ascending, then slot ascending
+        assert np.array_equal(lists[frame0:frame0 + len(slots)], slots[by_voxel]), f'run lists of frame {bt}'
+    assert int(plan.counts.abs().max()) == 0, 'count scratch not left clean'
+    return int(col_off[-1])

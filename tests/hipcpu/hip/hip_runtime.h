@@ -210,6 +210,9 @@ inline unsigned long long __ballot(int pred) {
     return m;
 }
 
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+
 // v_perm_b32: byte select from {a (bytes 7..4), b (bytes 3..0)}; selectors 0..7 pick a byte, 0x0c gives 0x00
 inline unsigned __builtin_amdgcn_perm_(unsigned a, unsigned b, unsigned sel) {
     const unsigned long long src = ((unsigned long long)a << 32) | b;
@@ -228,7 +231,7 @@ inline unsigned __builtin_amdgcn_perm_(unsigned a, unsigned b, unsigned sel) {
 #define __builtin_amdgcn_perm __builtin_amdgcn_perm_
 
 // DPP: the controls used here -- quad_perm (0x00..0xff), row_mirror 0x140, row_half_mirror 0x141, row_bcast15 0x142,
-// row_bcast31 0x143; lanes of rows that row_mask disables (or without a valid source) receive `old`
+// row_bcast31 0x143, row_newbcast:n 0x150+n; lanes of rows that row_mask disables (or without a valid source) receive `old`
 inline int update_dpp_(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     (void)bank_mask; (void)bound_ctrl;
     const int lane = hipcpu::cur->lane, row = lane >> 4;
@@ -238,6 +241,7 @@ inline int update_dpp_(int old, int src, int ctrl, int row_mask, int bank_mask, 
     else if (ctrl == 0x141) from = (lane & ~7) | (7 - (lane & 7));
     else if (ctrl == 0x142) from = row >= 1 ? 16 * (row - 1) + 15 : -1;
     else if (ctrl == 0x143) from = row >= 2 ? 31 : -1;
+    else if (ctrl >= 0x150 && ctrl <= 0x15f) from = (lane & ~15) | (ctrl & 15);          // row_newbcast:n (gfx90a+)
     else hipcpu::die("DPP control not modelled");
     const int got = hipcpu::exchange<int>(src, from < 0 ? lane : from);
     if (from < 0 || !((row_mask >> row) & 1)) return old;

@@ -85,6 +85,11 @@ def case_lift(ops, cfg, batch, seq, cams, seed, golden=None):
            'grad_scale': float(min(gf.abs().max(), gl.abs().max())), 'dims': [grid.D, grid.fH, grid.fW, cfg['out_channels']],
            'channels_last_equal': cl_equal, 'max_runs_per_voxel': int(plan.offsets().diff(dim=1).max()),
            'counts_clean': bool(int(plan.counts.abs().max()) == 0)}
+    try:
+        out['plan_runs'] = H.check_plan_structure(plan, vox)
+        out['plan_ok'] = True
+    except AssertionError as e:
+        out['plan_ok'], out['plan_error'] = False, str(e)
     if golden is not None:
         out['ids_equal_reference'] = bool(np.array_equal(ids, g['ref_vox']))
         out['fwd_err_reference'] = err(bev.detach(), g['ref_bev'])
@@ -140,6 +145,12 @@ def lift_full(ops):                 # the real geometry: 6 cameras x 224x480, D 
             'bev_reference_sample_err': err(flat[::257], g['generic_bev_sample']),
             'bev_sum_err': err(bev.detach().double().sum(dim=(-1, -2))[0], g['generic_bev_sum_tc']),
             'dfeat_err': err(f.grad, gf), 'dlogit_err': err(lg.grad, gl)}
+
+
+def lift_coarse_grid(ops):          # 4 x 4 voxels of 8 m: hundreds of runs per voxel (the wave-wide ordering of long lists)
+    from tests import helpers as H
+    cfg = dict(H.SMALL, out_channels=16, final_dim=(64, 48), x_bound=(-16.0, 16.0, 8.0), y_bound=(-16.0, 16.0, 8.0))
+    return case_lift(ops, cfg, 1, 2, 2, 11)
 
 
 def lift_tall(ops):                 # 112 rows x 64 bins per column (BASELINE configs[4] column shape): two 56-row slices per column in the backward
@@ -666,7 +677,7 @@ def fuzz(ops, seed=1):
     return {'problems': [[t, str(c), n, str(e)] for t, c, n, e in bad]}
 
 
-CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_tall, voxsum, wprep, optim, se_block, bn_act,
+CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_coarse_grid, lift_tall, voxsum, wprep, optim, se_block, bn_act,
                                  conv, dwconv)}
 
 if __name__ == '__main__':

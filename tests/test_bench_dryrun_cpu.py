@@ -49,7 +49,7 @@ def test_bench_main_dry_run(tmp_path, workload):
     assert roof['algorithmic_bytes_per_launch'] == 3 * 14755840
     # what ships is what runs: every operator family of the C ABI shows up in the call trace of one step
     trace = open(tmp_path / 'trace.log').read()
-    for entry in ('stp3_lift_plan_build', 'stp3_depth_softmax', 'stp3_lift_splat_fwd', 'stp3_lift_splat_bwd',
+    for entry in ('stp3_lift_plan_build', 'stp3_lift_splat_fwd', 'stp3_lift_splat_bwd',
                   'stp3_conv2d_fwd', 'stp3_conv2d_wgrad', 'stp3_conv2d_prep_weights', 'stp3_bn_fwd_train',
                   'stp3_dwconv2d_fwd', 'stp3_se_pool', 'stp3_se_mlp_fwd', 'stp3_optim_clip_adam'):
         assert entry + ' ' in trace, entry

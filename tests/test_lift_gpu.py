@@ -25,13 +25,6 @@ def _sha(a):
     return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
 
 
-def _column_runs(vox):
-    """vox (BT, N, D, fH, fW) -> (run-start mask, ids): a run starts where the id differs from the
-    row above (same camera, depth bin and column) and is >= 0."""
-    prev = np.concatenate([np.full_like(vox[:, :, :, :1], -1), vox[:, :, :, :-1]], axis=3)
-    return (vox != prev) & (vox >= 0), vox
-
-
 def _grid(cfg, dev='cuda'):
     from stp3_amd import ops
     frustum, res, start, dim = H.grid_params(cfg)
@@ -72,46 +65,8 @@ def test_small_case_against_reference_golden():
     bev, plan, grads = _run_lift(H.SMALL, intr, extr, ego, feat, logits, torch.from_numpy(g['grad_out']))
     # the plan's column-major ids are the same ids, permuted
     assert np.array_equal(plan.voxel_ids().cpu().numpy(), g['ref_vox'])
-    # plan structure: runs (maximal stretches of equal voxel id along an image column) counted per voxel (exclusive
-    # scan = histogram of run starts); the work groups of the forward kernel -- ascending, cover [0, V), <= 16 voxels
-    # each inside one 16-voxel block, and (unless a single voxel) inside one work bucket of 32 runs over the sample's
-    # frames; every (group, frame) range of the descriptor list holds exactly the runs of the group's voxels, longest
-    # first, ties by (camera, column, depth bin, first row)
-    starts, ids = _column_runs(g['ref_vox'].reshape(6, 2, grid.D, grid.fH, grid.fW))
-    off = plan.offsets().cpu().numpy()
-    desc = plan.descriptors().cpu().numpy()
-    runs = []
-    for bt in range(6):
-        hist = np.bincount(ids[bt][starts[bt]], minlength=dims.V)
-        assert np.array_equal(np.diff(off[bt]), hist)
-        assert off[bt][-1] == starts[bt].sum()
-        per_voxel = {}
-        nn, dd, hh, ww = np.nonzero(starts[bt])
-        for n_, d_, h_, w_ in zip(nn, dd, hh, ww):
-            v = int(ids[bt][n_, d_, h_, w_])
-            ln = 1
-            while h_ + ln < grid.fH and ids[bt][n_, d_, h_ + ln, w_] == v and not starts[bt][n_, d_, h_ + ln, w_]:
-                ln += 1
-            per_voxel.setdefault(v, []).append((-ln, ((n_ * grid.fW + w_) << 20) | (d_ << 14) | (h_ << 7) | (ln - 1), v))
-        runs.append(per_voxel)
-    work = np.diff(off.reshape(2, 3, -1), axis=2).sum(axis=1)            # runs per voxel, all frames of a sample
-    for b, gl in enumerate(plan.groups()):
-        gl = gl.cpu().numpy()
-        assert gl[0] == 0 and gl[-1] == dims.V and (np.diff(gl) > 0).all() and np.diff(gl).max() <= 16
-        assert ((gl[:-1] // 16) == ((gl[1:] - 1) // 16)).all()
-        before = np.concatenate([[0], np.cumsum(work[b])])
-        for a, e in zip(gl[:-1], gl[1:]):
-            assert before[e - 1] // 32 == before[a] // 32                   # all voxels of a group start in one bucket
-            for t in range(3):
-                bt = b * 3 + t
-                want = sorted(r for v in range(a, e) for r in runs[bt].get(v, []))
-                rows = desc[bt][off[bt][a]:off[bt][e]]
-                assert [(int(r[0]), int(r[1])) for r in rows] == [(k, v) for _, k, v in want]
-                for k, v, frow, prow in rows:                              # the two precomputed addresses
-                    col, d_, h_ = int(k) >> 20, (int(k) >> 14) & 63, (int(k) >> 7) & 127
-                    n_, w_ = divmod(col, grid.fW)
-                    assert frow == (n_ * grid.fH + h_) * grid.fW + w_ and prow == (col * grid.D + d_) * grid.fH + h_
-    assert int(plan.counts.abs().max()) == 0                              # the scratch is left clean for the next build
+    # plan structure: row masks, run slots, per-voxel slot lists (ascending), scratch left clean
+    assert H.check_plan_structure(plan, g['ref_vox']) > 0
     exact = lo.pool_exact(feat, logits, g['ref_vox'], (32, 32), 0.5)
     torch.testing.assert_close(bev.double(), exact, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(bev, torch.from_numpy(g['ref_bev']), rtol=0, atol=1e-3)

@@ -45,7 +45,7 @@ STEPS = 2          # tests/model_trace.py runs bench.py's eager step twice (the 
 def test_step_runs_and_call_mix(recorder, tmp_path):
     _, calls = _step(recorder, tmp_path / 'default.log')
     assert calls['stp3_lift_plan_build'] == 1, calls                                # the plan is prepared once
-    for per_step in ('stp3_depth_softmax', 'stp3_lift_splat_fwd', 'stp3_lift_splat_bwd', 'stp3_optim_clip_adam'):
+    for per_step in ('stp3_lift_splat_fwd', 'stp3_lift_splat_bwd', 'stp3_optim_clip_adam'):
         assert calls[per_step] == STEPS, (per_step, calls[per_step])
     # one BatchNorm forward/backward pair per BatchNorm layer: the composite entry points, or -- where the convolution
     # in front produces the statistics in its epilogue -- apply-only forward and reduce + apply backward
