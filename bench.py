@@ -193,13 +193,14 @@ def lift_roofline(device, batch, model, iters=30):
     if os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
-            ks = [pmc[name] for name in ('lift_column_kernel', 'lift_gather_kernel')]
+            ks = [v for k, v in pmc.items() if k.startswith(('lift_column', 'lift_gather'))]
+            assert len(ks) == 2, sorted(pmc)
             traffic = sum(k['hbm_read_bytes'] + k['hbm_write_bytes'] for k in ks) * d.BT / float(pmc.get('frames_per_launch', 12))
             traffic_source = f"profiles/r02_lift_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, {pmc.get('commit', '?')})"
         except Exception:
             traffic = None
-    roof = {'kernel': 'stp3_lift_splat_fwd = lift_column_kernel + lift_gather_kernel (logits -> BEV: depth softmax and '
-                      'run sums per image column, then per-voxel sum + discounted accumulation over t, BEV rows '
+    roof = {'kernel': 'stp3_lift_splat_fwd = lift_column_mma_kernel + lift_gather_kernel (logits -> BEV: depth softmax and '
+                      'run sums per image column on the matrix cores, then per-voxel sum + discounted accumulation over t, BEV rows '
                       'written once' + ('' if cl else ' + transpose to the reference layout') + ')',
             'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_source,

@@ -118,6 +118,7 @@ int stp3_voxel_index(const stp3_lift_dims* dims,
  *                                   tmp      [B*T*P] int32      (scratch)
  *                                   vox_runs [B*T*P] int32      slots of voxel v of frame bt, ascending, at
  *                                            col_off[bt*N*fW] + vox_off[bt][v] .. + vox_off[bt][v+1]
+ *                                   run_desc [B*T*P] uint32     per slot: depth bin | first row << 8 | last row << 16
  *                          counts = int32 [B*T][V] scratch that must be ZERO on entry (the caller zero-fills
  *                          it once; every build leaves it zero again).
  *   Launches: columns (ids, masks, counts), scan of the columns, scan of the voxels, fill, per-voxel order.
@@ -148,9 +149,12 @@ int stp3_depth_softmax(const stp3_lift_dims* dims, const float* logits, float* p
  *   Pool_k[c][v] = sum over points p of frame k with vox(p) == v of softmax_D(logits)[p] * feat[pix(p)][c].
  * Replaces stp3.py:215 (depth softmax), :216-221 (outer product, never materialised), geometry.py:302-318
  * (VoxelsSumming.forward) and stp3.py:279-299 (scatter, discount, permute).  Two kernels:
- *   pass 1  one wave per image column, lane = channel: softmax of the column's logits (kept in LDS, written to
- *           prob_cm for the backward pass), then ONE walk over the rows with an accumulator per depth bin; every
- *           feature and logit is read from memory exactly once; a finished run's C-vector goes to its slot
+ *   pass 1  one wave per image column: softmax of the column's logits (global -> LDS directly, kept in LDS, written
+ *           to prob_cm for the backward pass); every feature and logit is read from memory exactly once.  Columns of
+ *           at most 32 rows with C == 64: the run sums are a matrix product  masked probabilities [runs x rows] x
+ *           features [rows x C]  on the matrix cores (v_mfma_f32_32x32x2_f32), 32 runs = 32 slots per tile.  Other
+ *           shapes: lane = channel, ONE walk over the rows with an accumulator per depth bin (v_fmac_f32 with a DPP row
+ *           broadcast of the probability); a finished run's C-vector goes to its slot
  *   pass 2  16 lanes per voxel add the voxel's slots (ascending) and carry the discounted state through the T
  *           frames in registers; every BEV row (256 bytes) is written once
  * Deterministic (fixed summation order, no atomics).

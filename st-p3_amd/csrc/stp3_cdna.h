@@ -1,0 +1,44 @@
+// stp3_cdna.h -- the CDNA-specific instructions the kernels issue by hand (gfx90a+ / gfx950).
+// (tests/hipcpu provides a header of the same name that models them for the CPU stand-in.)
+#pragma once
+
+// fmac_row_bcast<J>(acc, v, f):  acc += v[(lane & ~15) | J] * f   in ONE VALU instruction: v_fmac_f32 with the DPP
+// row_newbcast control (lane J of every 16-lane row is broadcast to the row).  Written with
+// __builtin_amdgcn_update_dpp the compiler emits the broadcast as a separate v_mov_b32_dpp (row_newbcast is not folded
+// into the multiply-add), which doubles the instruction count of the lift kernel's inner loop.
+template <int J>
+__device__ __forceinline__ void fmac_row_bcast(float& acc, float v, float f) {
+    static_assert(J >= 0 && J < 16, "row_newbcast lane");
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(f), "n"(J));
+}
+
+// lds_dma16(src, lds_base): global -> LDS without passing through registers (global_load_lds_dwordx4).  Every ACTIVE
+// lane moves the 16 bytes at its own `src` to  lds_base + 16 * lane  (the destination is a wave-uniform base plus the
+// lane's slot; inactive lanes leave their slot untouched).  Completion is counted by vmcnt: lds_dma_wait() before the
+// wave reads the data.
+__device__ __forceinline__ void lds_dma16(const float* src, float* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+__device__ __forceinline__ void lds_dma_wait() {
+    __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0) expcnt(0) lgkmcnt(0)
+}
+
+// All-reduce over the 16 lanes of a DPP row with four rotations (row_ror 8, 4, 2, 1): one VALU instruction per step,
+// no LDS round trip (what __shfl_xor costs).
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, row_ror<8>(v));
+    v = fmaxf(v, row_ror<4>(v));
+    v = fmaxf(v, row_ror<2>(v));
+    return fmaxf(v, row_ror<1>(v));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += row_ror<8>(v);
+    v += row_ror<4>(v);
+    v += row_ror<2>(v);
+    return v + row_ror<1>(v);
+}

@@ -15,7 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "stp3_dpp.h"
+#include "stp3_cdna.h"
 #include "stp3_hip.h"
 
 namespace {
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void voxel_index_kernel(Dims dm, const float* 
 //   tmp      [BT*P]             per-voxel slot lists in arrival order (build scratch)
 //   vox_runs [BT*P]             per-voxel slot lists, ascending: the runs of voxel v of frame bt are
 //                               vox_runs[col_off[bt*NCOL] + vox_off[bt][v] ... + vox_off[bt][v+1])
+//   run_desc [BT*P]             per slot: depth bin | first row << 8 | last row << 16 of the run
 // Replaces the reference's boolean mask + argsort + cumsum differencing (stp3.py:247-257, geometry.py:302-318).
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -164,6 +165,7 @@ struct PlanView {
     int32_t* col_off;
     int32_t* tmp;
     int32_t* vox_runs;
+    uint32_t* run_desc;
 };
 
 inline size_t plan_sections(const Dims& dm, size_t* o) {
@@ -174,16 +176,17 @@ inline size_t plan_sections(const Dims& dm, size_t* o) {
     o[3] = p; p += align256(((size_t)dm.BT * dm.NCOL + 1) * 4);
     o[4] = p; p += align256((size_t)dm.BT * dm.P * 4);
     o[5] = p; p += align256((size_t)dm.BT * dm.P * 4);
+    o[6] = p; p += align256((size_t)dm.BT * dm.P * 4);
     return p;
 }
 
 inline size_t plan_bytes(const Dims& dm) {
-    size_t o[6];
+    size_t o[7];
     return plan_sections(dm, o);
 }
 
 inline PlanView plan_view(const Dims& dm, void* base) {
-    size_t o[6];
+    size_t o[7];
     plan_sections(dm, o);
     char* p = (char*)base;
     PlanView pv;
@@ -193,6 +196,7 @@ inline PlanView plan_view(const Dims& dm, void* base) {
     pv.col_off = (int32_t*)(p + o[3]);
     pv.tmp = (int32_t*)(p + o[4]);
     pv.vox_runs = (int32_t*)(p + o[5]);
+    pv.run_desc = (uint32_t*)(p + o[6]);
     return pv;
 }
 
@@ -336,7 +340,8 @@ __global__ __launch_bounds__(256) void plan_fill_kernel(Dims dm, const int32_t* 
                                                         const Mask2* __restrict__ masks,
                                                         const int32_t* __restrict__ col_off,
                                                         const int32_t* __restrict__ vox_off,
-                                                        int32_t* __restrict__ vox_cnt, int32_t* __restrict__ tmp) {
+                                                        int32_t* __restrict__ vox_cnt, int32_t* __restrict__ tmp,
+                                                        uint32_t* __restrict__ run_desc) {
     const int lane = threadIdx.x & 63;
     const int colg = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (colg >= dm.BT * dm.NCOL) return;
@@ -344,11 +349,16 @@ __global__ __launch_bounds__(256) void plan_fill_kernel(Dims dm, const int32_t* 
     int slot0 = col_off[colg];
     const int frame0 = col_off[bt * dm.NCOL];
     const int32_t* ids = vox_cm + (size_t)colg * dm.D * dm.fH;
+    int first = -1;                                       // first row of the run bin `lane` is in, or -1
     for (int h = 0; h < dm.fH; ++h) {
-        const unsigned long long ends_w = masks[(size_t)colg * dm.fH + h].x;
+        const Mask2 m = masks[(size_t)colg * dm.fH + h];
+        const unsigned long long ends_w = m.x;
+        if (first < 0 && ((m.y >> lane) & 1ull)) first = h;
         if ((ends_w >> lane) & 1ull) {
             const int v = ids[lane * dm.fH + h];
             const int slot = slot0 + __popcll(ends_w & lanes_below(lane));
+            run_desc[slot] = (unsigned)lane | ((unsigned)first << 8) | ((unsigned)h << 16);
+            first = -1;
             const int pos = atomicAdd(vox_cnt + (size_t)bt * dm.V + v, -1) - 1;
             tmp[(size_t)frame0 + vox_off[(size_t)bt * (dm.V + 1) + v] + pos] = slot;
         }
@@ -462,7 +472,9 @@ __global__ __launch_bounds__(256) void depth_softmax_kernel(Dims dm, const float
 // Output layout: [B][T][V][C] (channels-last BEV); the reference's [B][T][C][V] is produced by a transpose pass
 // when the caller asks for it.
 constexpr int kColRows = 16;     // rows of a column staged per round (taller columns take several rounds)
-constexpr int kProbLd = 68;      // floats per staged probability row: 16-byte aligned, rows 4 banks apart
+// staged probability rows are rotated by 4 floats per row (bank-conflict-free column reads, no padding: the two staging
+// arrays of a workgroup are exactly 32 KiB, five workgroups per CU)
+__device__ __forceinline__ int prob_col(int r, int d) { return (d + 4 * r) & 63; }
 
 // acc[4g .. 4g+3] += prob[bins 4g .. 4g+3] * f ; the bins of group g sit in lanes (4g & 15) .. + 3 of pv[g >> 2]
 template <int GRP>
@@ -475,12 +487,12 @@ __device__ __forceinline__ void fma_group(float (&acc)[64], const float (&pv)[4]
 
 // the runs of bins 4g .. 4g+3 that end at this row (nib: their 4 mask bits, wave-uniform): store and clear
 template <int GRP>
-__device__ __forceinline__ void emit_group(float (&acc)[64], unsigned nib, bool chan, float*& sp, int C) {
+__device__ __forceinline__ void emit_group(float (&acc)[64], unsigned nib, int lane_c, float*& sp, int C) {
     if (nib == 0u) return;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if ((nib >> k) & 1u) {
-            if (chan) *sp = acc[4 * GRP + k];
+            if (lane_c >= 0) sp[lane_c] = acc[4 * GRP + k];         // sp: wave-uniform, the run's slot
             acc[4 * GRP + k] = 0.f;
             sp += C;
         }
@@ -490,25 +502,25 @@ __device__ __forceinline__ void emit_group(float (&acc)[64], unsigned nib, bool 
 template <int G, int GRP>
 struct ColumnRow {
     static __device__ __forceinline__ void run(float (&acc)[64], const float (&pv)[4], float f, unsigned lo, unsigned hi,
-                                               bool chan, float*& sp, int C) {
+                                               int lane_c, float*& sp, int C) {
         fma_group<GRP>(acc, pv, f);
-        emit_group<GRP>(acc, ((GRP < 8 ? lo : hi) >> ((4 * GRP) & 31)) & 15u, chan, sp, C);
-        ColumnRow<G, GRP + 1>::run(acc, pv, f, lo, hi, chan, sp, C);
+        emit_group<GRP>(acc, ((GRP < 8 ? lo : hi) >> ((4 * GRP) & 31)) & 15u, lane_c, sp, C);
+        ColumnRow<G, GRP + 1>::run(acc, pv, f, lo, hi, lane_c, sp, C);
     }
 };
 template <int G>
 struct ColumnRow<G, G> {
-    static __device__ __forceinline__ void run(float (&)[64], const float (&)[4], float, unsigned, unsigned, bool, float*&,
+    static __device__ __forceinline__ void run(float (&)[64], const float (&)[4], float, unsigned, unsigned, int, float*&,
                                                int) {}
 };
 
 template <int G>   // depth bins in groups of 4: D <= 4 G
-__global__ __launch_bounds__(256) void lift_column_kernel(Dims dm, const float* __restrict__ feat,
+__global__ __launch_bounds__(256, G <= 12 ? 5 : 4) void lift_column_kernel(Dims dm, const float* __restrict__ feat,
                                                           const float* __restrict__ logits,
                                                           const Mask2* __restrict__ masks,
                                                           const int32_t* __restrict__ col_off,
                                                           float* __restrict__ prob_cm, float* __restrict__ slots) {
-    __shared__ __attribute__((aligned(16))) float prob_s[4][kColRows][kProbLd];
+    __shared__ __attribute__((aligned(16))) float prob_s[4][kColRows][64];
     __shared__ __attribute__((aligned(16))) float feat_s[4][kColRows][64];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -517,67 +529,58 @@ __global__ __launch_bounds__(256) void lift_column_kernel(Dims dm, const float* 
     const int bt = colg / dm.NCOL, col = colg - bt * dm.NCOL;
     const int n = col / dm.fW, w = col - n * dm.fW;
     const int D = dm.D, C = dm.C;
-    float (*ps)[kProbLd] = prob_s[wv];
+    float (*ps)[64] = prob_s[wv];
     float (*fs)[64] = feat_s[wv];
     const Mask2* mk = masks + (size_t)colg * dm.fH;
     const size_t pix0 = (size_t)bt * dm.NPIX + (size_t)n * dm.fH * dm.fW + w;      // pixel (h = 0) of the column
+    const float* fcol = feat + pix0 * C;        // wave-uniform bases; the per-lane parts fit 32 bits (pool_limits)
+    const float* lcol = logits + pix0 * D;
     const bool chan = lane < C;
-    float* sp = slots + (size_t)col_off[colg] * C + (chan ? lane : 0);            // slot of the next run that ends
+    float* sp = slots + (size_t)__builtin_amdgcn_readfirstlane(col_off[colg]) * C;   // slot of the next run that ends
+    const int lane_c = chan ? lane : -1;
     float acc[64];
 #pragma unroll
     for (int k = 0; k < 64; ++k) acc[k] = 0.f;
 
     const int rsub = lane >> 4;                 // staging: 16 lanes per pixel, 4 bins / 4 channels per lane
     const int e0 = (lane & 15) * 4;
-    const bool vec = (D & 3) == 0;
     for (int h0 = 0; h0 < dm.fH; h0 += kColRows) {
         const int rows = min(kColRows, dm.fH - h0);
-        // ---- every global read of the round is issued before the first use: logits and features of 4 pixels per
-        //      load instruction, the two mask words of row `lane`
-        float lg[kColRows / 4][4];
-        float4 fq[kColRows / 4];
+        // ---- features and logits of the round: global -> LDS directly (no staging registers), 4 pixels per
+        //      instruction.  A lane's data lands at slot `lane` of the 1 KiB piece, so the rotation of the probability
+        //      rows is applied to the SOURCE: slot s of row r receives the bins 4 ((s - r) & 15) ...
 #pragma unroll
         for (int i = 0; i < kColRows / 4; ++i) {
             const int r = 4 * i + rsub;
-            const bool live = r < rows;
-            const size_t pix = pix0 + (size_t)(h0 + (live ? r : 0)) * dm.fW;
-            const float* row = logits + pix * D;
-            if (live && vec && e0 < D) {
-                const float4 qv = *reinterpret_cast<const float4*>(row + e0);
-                lg[i][0] = qv.x; lg[i][1] = qv.y; lg[i][2] = qv.z; lg[i][3] = qv.w;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) lg[i][k] = (live && e0 + k < D) ? row[e0 + k] : -INFINITY;
-            }
-            fq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (live && e0 < C) fq[i] = *reinterpret_cast<const float4*>(feat + pix * C + e0);
+            const unsigned rel = (unsigned)(h0 + r) * (unsigned)dm.fW;      // pixel of row r, relative to the column's first
+            const int gb = (((lane & 15) - r) & 15) * 4;           // first bin of this lane's slot
+            if (r < rows && e0 < C) lds_dma16(fcol + (rel * (unsigned)C + (unsigned)e0), &fs[4 * i][0]);
+            if (r < rows && gb < D) lds_dma16(lcol + (rel * (unsigned)D + (unsigned)gb), &ps[4 * i][0]);
         }
-        Mask2 mrow = Mask2{0ull, 0ull};
-        if (lane < rows) mrow = mk[h0 + lane];
-        const unsigned ends_lo = (unsigned)mrow.x, ends_hi = (unsigned)(mrow.x >> 32);
-        const unsigned valid_lo = (unsigned)mrow.y, valid_hi = (unsigned)(mrow.y >> 32);
-        // ---- softmax over the bins of each pixel (16 lanes) -> LDS, unmasked; features -> LDS
-        float pr[kColRows / 4][4];
-#pragma unroll
+        unsigned long long vrow = 0ull;
+        if (lane < rows) vrow = mk[h0 + lane].y;                    // "inside the grid" bits of row `lane`
+        const unsigned valid_lo = (unsigned)vrow, valid_hi = (unsigned)(vrow >> 32);
+        lds_dma_wait();
+        __builtin_amdgcn_wave_barrier();
+        // ---- softmax over the bins of each pixel (its 16 lanes), in place
+#pragma unroll 1
         for (int i = 0; i < kColRows / 4; ++i) {
             const int r = 4 * i + rsub;
-            const bool live = r < rows;
-            float mx = fmaxf(fmaxf(lg[i][0], lg[i][1]), fmaxf(lg[i][2], lg[i][3]));
-#pragma unroll
-            for (int s = 8; s > 0; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
-            float sum = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                pr[i][k] = (e0 + k < D) ? __expf(lg[i][k] - mx) : 0.f;
-                sum += pr[i][k];
-            }
-#pragma unroll
-            for (int s = 8; s > 0; s >>= 1) sum += __shfl_xor(sum, s);
-            const float inv = 1.0f / sum;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pr[i][k] = live ? pr[i][k] * inv : 0.f;
-            *reinterpret_cast<float4*>(&ps[r][e0]) = make_float4(pr[i][0], pr[i][1], pr[i][2], pr[i][3]);
-            *reinterpret_cast<float4*>(&fs[r][e0]) = fq[i];
+            const int gb = (((lane & 15) - r) & 15) * 4;
+            const bool live = r < rows && gb < D;
+            float4 q = *reinterpret_cast<const float4*>(&ps[r][e0]);
+            if (!live) q = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            const float mx = row16_max(fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
+            q.x = live ? __expf(q.x - mx) : 0.f;
+            q.y = live ? __expf(q.y - mx) : 0.f;
+            q.z = live ? __expf(q.z - mx) : 0.f;
+            q.w = live ? __expf(q.w - mx) : 0.f;
+            const float inv = 1.0f / row16_sum((q.x + q.y) + (q.z + q.w));
+            q.x = live ? q.x * inv : 0.f;
+            q.y = live ? q.y * inv : 0.f;
+            q.z = live ? q.z * inv : 0.f;
+            q.w = live ? q.w * inv : 0.f;
+            *reinterpret_cast<float4*>(&ps[r][e0]) = q;
         }
         __builtin_amdgcn_wave_barrier();
         // ---- prob_cm[bt][col][d][h0 .. h0+rows): 16 consecutive rows of 4 bins per store instruction
@@ -585,36 +588,163 @@ __global__ __launch_bounds__(256) void lift_column_kernel(Dims dm, const float* 
             float* out = prob_cm + (size_t)colg * D * dm.fH + h0;
             const int r = lane & (kColRows - 1);
             for (int d = lane / kColRows; d < D; d += 64 / kColRows)
-                if (r < rows) out[(size_t)d * dm.fH + r] = ps[r][d];
+                if (r < rows) out[d * dm.fH + r] = ps[r][prob_col(r, d)];
         }
         __builtin_amdgcn_wave_barrier();
         // ---- points outside the grid contribute nothing: zero their probabilities in the staged copy
-#pragma unroll
+#pragma unroll 1
         for (int i = 0; i < kColRows / 4; ++i) {
             const int r = 4 * i + rsub;
+            const int gb = (((lane & 15) - r) & 15) * 4;
             const unsigned vlo = __shfl(valid_lo, r), vhi = __shfl(valid_hi, r);
-            const unsigned vbits = ((e0 < 32 ? vlo : vhi) >> (e0 & 31)) & 15u;
-            float4 q;
-            q.x = (vbits & 1u) ? pr[i][0] : 0.f;
-            q.y = (vbits & 2u) ? pr[i][1] : 0.f;
-            q.z = (vbits & 4u) ? pr[i][2] : 0.f;
-            q.w = (vbits & 8u) ? pr[i][3] : 0.f;
+            const unsigned vbits = ((gb < 32 ? vlo : vhi) >> (gb & 31)) & 15u;
+            float4 q = *reinterpret_cast<const float4*>(&ps[r][e0]);
+            q.x = (vbits & 1u) ? q.x : 0.f;
+            q.y = (vbits & 2u) ? q.y : 0.f;
+            q.z = (vbits & 4u) ? q.z : 0.f;
+            q.w = (vbits & 8u) ? q.w : 0.f;
             *reinterpret_cast<float4*>(&ps[r][e0]) = q;
         }
         __builtin_amdgcn_wave_barrier();
         // ---- walk the rows
+        unsigned long long ends_next = mk[h0].x;                    // wave-uniform address: scalar loads, one row ahead
         for (int i = 0; i < rows; ++i) {
             const float f = fs[i][lane];
-            const unsigned lo = __builtin_amdgcn_readlane(ends_lo, i);
-            const unsigned hi = __builtin_amdgcn_readlane(ends_hi, i);
+            const unsigned long long ends_w = ends_next;
+            ends_next = mk[min(h0 + i + 1, dm.fH - 1)].x;
+            const unsigned lo = (unsigned)ends_w, hi = (unsigned)(ends_w >> 32);
             // the row's probabilities: lane l holds bins 16k + (l & 15), k = 0..3; bin d reaches every lane as the
             // DPP row broadcast of lane d & 15 of register d >> 4, folded into the multiply-add (stp3_dpp.h)
             float pv[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pv[k] = (4 * k < G) ? ps[i][16 * k + (lane & 15)] : 0.f;
-            ColumnRow<G, 0>::run(acc, pv, f, lo, hi, chan, sp, C);
+            for (int k = 0; k < 4; ++k) pv[k] = (4 * k < G) ? ps[i][prob_col(i, 16 * k + (lane & 15))] : 0.f;
+            ColumnRow<G, 0>::run(acc, pv, f, lo, hi, lane_c, sp, C);
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Pass 1 on the matrix cores, for columns of at most 32 rows and C == 64 (the shapes of the reference's configurations):
+// the run sums of a column are ONE small matrix product
+//     S[run][c] = sum_h  M[run][h] * F[h][c],      M[run][h] = prob[h][bin(run)] if first(run) <= h <= last(run) else 0,
+// evaluated 32 runs at a time with v_mfma_f32_32x32x2_f32 (K = 2 rows per instruction).  F (the B operand: lane l holds
+// rows 2s + (l >> 5), channel 32 nb + (l & 31)) is loaded once into registers and serves every run block; the A operand is
+// gathered from the staged probabilities with the run descriptors of the plan (slot order), so the 32 x 64 result tile IS
+// the block's 32 consecutive slots.  No per-row bookkeeping at all: ~4 VALU instructions per MFMA.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMmaRows = 32;
+
+__global__ __launch_bounds__(256, 4) void lift_column_mma_kernel(Dims dm, const float* __restrict__ feat,
+                                                                const float* __restrict__ logits,
+                                                                const int32_t* __restrict__ col_off,
+                                                                const uint32_t* __restrict__ run_desc,
+                                                                float* __restrict__ prob_cm,
+                                                                float* __restrict__ slots) {
+    __shared__ __attribute__((aligned(16))) float prob_s[4][kMmaRows][64];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int colg = blockIdx.x * 4 + wv;
+    if (colg >= dm.BT * dm.NCOL) return;
+    const int bt = colg / dm.NCOL, col = colg - bt * dm.NCOL;
+    const int n = col / dm.fW, w = col - n * dm.fW;
+    const int D = dm.D, fH = dm.fH;
+    constexpr int C = 64;
+    float (*ps)[64] = prob_s[wv];
+    const size_t pix0 = (size_t)bt * dm.NPIX + (size_t)n * fH * dm.fW + w;      // pixel (h = 0) of the column
+    const float* fcol = feat + pix0 * C;        // wave-uniform bases; the per-lane parts fit 32 bits (pool_limits)
+    const float* lcol = logits + pix0 * D;
+    const int rsub = lane >> 4, e0 = (lane & 15) * 4;
+    const int half = lane >> 5, l32 = lane & 31;
+
+    // ---- logits: global -> LDS directly, 4 pixels per instruction (rotated rows, see prob_col)
+#pragma unroll
+    for (int i = 0; i < kMmaRows / 4; ++i) {
+        const int r = 4 * i + rsub;
+        const int gb = (((lane & 15) - r) & 15) * 4;
+        if (r < fH && gb < D) lds_dma16(lcol + ((unsigned)r * (unsigned)dm.fW * (unsigned)D + (unsigned)gb), &ps[4 * i][0]);
+    }
+    // ---- features: the B operands of all K steps
+    float fb[kMmaRows / 2][2];
+    const unsigned lane_off = (unsigned)half * (unsigned)dm.fW * (unsigned)C + (unsigned)l32;
+#pragma unroll
+    for (int s = 0; s < kMmaRows / 2; ++s) {
+        const int h = 2 * s + half;
+        const float* rowp = fcol + (unsigned)(2 * s) * (unsigned)dm.fW * (unsigned)C;      // wave-uniform
+        fb[s][0] = h < fH ? rowp[lane_off] : 0.f;
+        fb[s][1] = h < fH ? rowp[lane_off + 32u] : 0.f;
+    }
+    const int slot0 = __builtin_amdgcn_readfirstlane(col_off[colg]);
+    const int nruns = __builtin_amdgcn_readfirstlane(col_off[colg + 1]) - slot0;
+    // ---- the run descriptors of the first 256 runs (every load of the wave is issued before its first store: a load
+    //      behind stores waits for their completion, the memory counter retires in order)
+    unsigned dv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dv[j] = (64 * j + lane < nruns) ? run_desc[slot0 + 64 * j + lane] : 0x00000100u;
+    lds_dma_wait();
+    __builtin_amdgcn_wave_barrier();
+    // ---- softmax over the bins of each pixel (its 16 lanes), in place
+#pragma unroll
+    for (int i = 0; i < kMmaRows / 4; ++i) {
+        const int r = 4 * i + rsub;
+        const int gb = (((lane & 15) - r) & 15) * 4;
+        const bool live = r < fH && gb < D;
+        float4 q = *reinterpret_cast<const float4*>(&ps[r][e0]);
+        if (!live) q = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        const float mx = row16_max(fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
+        q.x = live ? __expf(q.x - mx) : 0.f;
+        q.y = live ? __expf(q.y - mx) : 0.f;
+        q.z = live ? __expf(q.z - mx) : 0.f;
+        q.w = live ? __expf(q.w - mx) : 0.f;
+        const float inv = 1.0f / row16_sum((q.x + q.y) + (q.z + q.w));
+        q.x = live ? q.x * inv : 0.f;
+        q.y = live ? q.y * inv : 0.f;
+        q.z = live ? q.z * inv : 0.f;
+        q.w = live ? q.w * inv : 0.f;
+        *reinterpret_cast<float4*>(&ps[r][e0]) = q;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- prob_cm[bt][col][d][0 .. fH): 32 consecutive rows of 2 bins per store instruction
+    if (prob_cm) {
+        float* out = prob_cm + (size_t)colg * D * fH;
+        for (int d = half; d < D; d += 2)
+            if (l32 < fH) out[d * fH + l32] = ps[l32][prob_col(l32, d)];
+    }
+    // ---- 32 runs (= 32 consecutive slots) per block
+    const int ksteps = (fH + 1) >> 1;
+    for (int r0 = 0; r0 < nruns; r0 += 32) {
+        unsigned ds;                                         // descriptor of run r0 + l32; empty: first row 1 > last row 0
+        if (r0 < 256) {
+            const int j = r0 >> 6;
+            const unsigned pick = j == 0 ? dv[0] : j == 1 ? dv[1] : j == 2 ? dv[2] : dv[3];
+            ds = __shfl(pick, (r0 & 63) + l32);
+        } else {
+            ds = (r0 + l32 < nruns) ? run_desc[slot0 + r0 + l32] : 0x00000100u;
+        }
+        const int bin = (int)(ds & 255u), first = (int)((ds >> 8) & 255u), last = (int)(ds >> 16);
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc0[k] = acc1[k] = 0.f;
+#pragma unroll
+        for (int s = 0; s < kMmaRows / 2; ++s) {
+            if (s < ksteps) {
+                const int h = 2 * s + half;
+                const float pr = ps[h][prob_col(h, bin)];
+                const float a = ((h >= first) & (h <= last)) ? pr : 0.f;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, fb[s][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, fb[s][1], acc1, 0, 0, 0);
+            }
+        }
+        // D[row = (k & 3) + 8 (k >> 2) + 4 half][col = l32]: two 128-byte pieces of two slots per store
+        float* tile = slots + (size_t)(slot0 + r0) * C + (4 * half * C + l32);
+        const int left = nruns - r0 - 4 * half;              // rows of this half that exist
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int row = (k & 3) + 8 * (k >> 2);
+            if (row < left) {
+                tile[row * C] = acc0[k];
+                tile[row * C + 32] = acc1[k];
+            }
+        }
     }
 }
 
@@ -1002,7 +1132,7 @@ int stp3_voxel_index(const stp3_lift_dims* dims, const float* cam_m, const float
 
 // what the pooling kernels can address with 32-bit byte offsets / the descriptor's bit fields
 static int pool_limits(const Dims& dm) {
-    if (dm.Z != 1 || dm.C > 64 || (dm.C & 3) || dm.D > 64) return STP3_EUNSUP;   // stp3.py:297-299 squeezes Z
+    if (dm.Z != 1 || dm.C > 64 || (dm.C & 3) || dm.D > 64 || (dm.D & 3)) return STP3_EUNSUP;   // stp3.py:297-299 squeezes Z
     if (dm.fH > 128 || dm.NCOL >= 4096) return STP3_EUNSUP;
     const int64_t widest = (int64_t)dm.BT * dm.NPIX * (dm.C > dm.D ? dm.C : dm.D) * 4;
     if (widest >= (1LL << 32)) return STP3_EUNSUP;
@@ -1042,7 +1172,8 @@ int stp3_lift_plan_build(const stp3_lift_dims* dims, const float* cam_m, const f
     hipLaunchKernelGGL(plan_columns_kernel, cgrid, dim3(256), ids_lds, s, dm, g, vox_cm, counts, pv.masks, pv.col_cnt, stage);
     hipLaunchKernelGGL(plan_scan_all_kernel, dim3(1), dim3(1024), 0, s, ncols, pv.col_cnt, pv.col_off);
     hipLaunchKernelGGL(plan_scan_kernel, dim3((dm.V + 1023) / 1024, dm.BT), dim3(1024), 0, s, dm.V, counts, pv.vox_off);
-    hipLaunchKernelGGL(plan_fill_kernel, cgrid, dim3(256), 0, s, dm, vox_cm, pv.masks, pv.col_off, pv.vox_off, counts, pv.tmp);
+    hipLaunchKernelGGL(plan_fill_kernel, cgrid, dim3(256), 0, s, dm, vox_cm, pv.masks, pv.col_off, pv.vox_off, counts, pv.tmp,
+                       pv.run_desc);
     hipLaunchKernelGGL(plan_sort_kernel, dim3((dm.V + 255) / 256, dm.BT), dim3(256), 0, s, dm, pv.vox_off, pv.col_off, pv.tmp,
                        pv.vox_runs);
     return launch_status();
@@ -1108,7 +1239,10 @@ int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const flo
     float* out_cl = cf ? slots + (size_t)dm.BT * dm.P * dm.C : bev;
     const int ncols = dm.BT * dm.NCOL;
     const dim3 cgrid((ncols + 3) / 4);
-    if (dm.D <= 32)
+    if (dm.fH <= kMmaRows && dm.C == 64)
+        hipLaunchKernelGGL(lift_column_mma_kernel, cgrid, dim3(256), 0, s, dm, feat, logits, pv.col_off, pv.run_desc, prob_cm,
+                           slots);
+    else if (dm.D <= 32)
         hipLaunchKernelGGL(lift_column_kernel<8>, cgrid, dim3(256), 0, s, dm, feat, logits, pv.masks, pv.col_off, prob_cm, slots);
     else if (dm.D <= 48)
         hipLaunchKernelGGL(lift_column_kernel<12>, cgrid, dim3(256), 0, s, dm, feat, logits, pv.masks, pv.col_off, prob_cm, slots);

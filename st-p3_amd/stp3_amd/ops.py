@@ -222,12 +222,13 @@ class LiftPlan:
         return self.vox_cm.view(d.B, d.T, d.N, d.fW, d.D, d.fH).permute(0, 1, 2, 4, 5, 3)
 
     def _sections(self):
-        """Byte offsets of the plan's sections (include/stp3_hip.h: vox_off, masks, col_cnt, col_off, tmp, vox_runs)."""
+        """Byte offsets of the plan's sections (include/stp3_hip.h: vox_off, masks, col_cnt, col_off, tmp, vox_runs,
+        run_desc)."""
         d = self.dims
         a = self._align256
         ncol = d.BT * d.N * d.fW
         sizes = [a(d.BT * (d.V + 1) * 4), a(ncol * d.fH * 16), a(ncol * 4), a((ncol + 1) * 4), a(d.BT * d.P * 4),
-                 a(d.BT * d.P * 4)]
+                 a(d.BT * d.P * 4), a(d.BT * d.P * 4)]
         return [sum(sizes[:i]) for i in range(len(sizes))]
 
     def offsets(self):
@@ -248,6 +249,12 @@ class LiftPlan:
         d = self.dims
         o = self._sections()[3]
         return self.plan[o:o + (d.BT * d.N * d.fW + 1) * 4].view(torch.int32)
+
+    def run_descriptors(self):
+        """[BT*P] int32 view, one word per slot: depth bin | first row << 8 | last row << 16 of the run."""
+        d = self.dims
+        o = self._sections()[6]
+        return self.plan[o:o + d.BT * d.P * 4].view(torch.int32)
 
     def run_lists(self):
         """[BT*P] int32 view: the per-voxel slot lists; voxel v of frame bt owns

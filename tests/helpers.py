@@ -120,6 +120,18 @@ def check_plan_structure(plan, vox):
     col_off = plan.column_offsets().cpu().numpy()
     assert np.array_equal(col_off, np.concatenate([[0], np.cumsum(per_col)])), 'column scan'
     slot = np.cumsum(ends_c.reshape(-1)) - 1                       # C order of (bt, col, h, d) IS the enumeration
+    # run descriptors in slot order: bin | first row << 8 | last row << 16
+    prv = np.concatenate([np.full_like(vox[:, :, :, :1], -1), vox[:, :, :, :-1]], axis=3)
+    starts_c = order(valid & (prv != vox))
+    bt_i, col_i, h_i, d_i = np.nonzero(ends_c)                     # C order = slot order
+    first = np.empty(len(h_i), dtype=np.int64)
+    for k, (b_, c_, h_, dd) in enumerate(zip(bt_i, col_i, h_i, d_i)):
+        hh = h_
+        while not starts_c[b_, c_, hh, dd]:
+            hh -= 1
+        first[k] = hh
+    want_desc = d_i | (first << 8) | (h_i << 16)
+    assert np.array_equal(plan.run_descriptors().cpu().numpy()[:len(want_desc)], want_desc), 'run descriptors'
     off = plan.offsets().cpu().numpy()
     lists = plan.run_lists().cpu().numpy()
     for bt in range(d.BT):

@@ -231,7 +231,7 @@ inline unsigned __builtin_amdgcn_perm_(unsigned a, unsigned b, unsigned sel) {
 #define __builtin_amdgcn_perm __builtin_amdgcn_perm_
 
 // DPP: the controls used here -- quad_perm (0x00..0xff), row_mirror 0x140, row_half_mirror 0x141, row_bcast15 0x142,
-// row_bcast31 0x143, row_newbcast:n 0x150+n; lanes of rows that row_mask disables (or without a valid source) receive `old`
+// row_bcast31 0x143, row_newbcast:n 0x150+n, row_ror:n 0x120+n; lanes of rows that row_mask disables (or without a valid source) receive `old`
 inline int update_dpp_(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     (void)bank_mask; (void)bound_ctrl;
     const int lane = hipcpu::cur->lane, row = lane >> 4;
@@ -242,6 +242,7 @@ inline int update_dpp_(int old, int src, int ctrl, int row_mask, int bank_mask, 
     else if (ctrl == 0x142) from = row >= 1 ? 16 * (row - 1) + 15 : -1;
     else if (ctrl == 0x143) from = row >= 2 ? 31 : -1;
     else if (ctrl >= 0x150 && ctrl <= 0x15f) from = (lane & ~15) | (ctrl & 15);          // row_newbcast:n (gfx90a+)
+    else if (ctrl >= 0x121 && ctrl <= 0x12f) from = (lane & ~15) | ((lane - (ctrl & 15)) & 15);   // row_ror:n
     else hipcpu::die("DPP control not modelled");
     const int got = hipcpu::exchange<int>(src, from < 0 ? lane : from);
     if (from < 0 || !((row_mask >> row) & 1)) return old;
@@ -305,6 +306,33 @@ inline hipcpu_f32x4 mfma_f32_16x16x32_bf16_(V a, V b, hipcpu_f32x4 c, int, int, 
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 mfma_f32_16x16x32_bf16_
+
+// v_mfma_f32_32x32x2_f32: A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31], D as for every 32x32 MFMA:
+// D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31], r = 0..15
+typedef float hipcpu_f32x16a __attribute__((ext_vector_type(16)));
+inline hipcpu_f32x16a mfma_f32_32x32x2f32_(float a, float b, hipcpu_f32x16a c, int, int, int) {
+    hipcpu::Wave& w = hipcpu::my_wave();
+    const int lane = hipcpu::cur->lane;
+    std::memcpy(w.slot[0][lane], &a, 4);
+    std::memcpy(w.slot[1][lane], &b, 4);
+    w.bar.wait();
+    hipcpu_f32x16a d = c;
+    const int j = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            float av, bv;
+            std::memcpy(&av, w.slot[0][i + 32 * k], 4);
+            std::memcpy(&bv, w.slot[1][j + 32 * k], 4);
+            acc = std::fmaf(av, bv, acc);
+        }
+        d[r] = acc;
+    }
+    w.bar.wait();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 mfma_f32_32x32x2f32_
 
 // v_mfma_f32_32x32x16_bf16: A[i = l & 31][k = 8 * (l >> 5) + t], B[k = 8 * (l >> 5) + t][j = l & 31] (t = 0..7),
 // D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31], r = 0..15 (cdna_hip_programming.md section 3)

@@ -1,0 +1,30 @@
+// TEST INFRASTRUCTURE: CPU model of st-p3_amd/csrc/stp3_cdna.h (found first on the stand-in's include path).
+#pragma once
+#include <cstring>
+template <int J>
+inline void fmac_row_bcast(float& acc, float v, float f) {
+    const float b = hipcpu::exchange<float>(v, (hipcpu::cur->lane & ~15) | J);     // row_newbcast:J
+    acc = fmaf(b, f, acc);
+}
+// every lane that executes the call moves 16 bytes to lds_base + 16 * lane (lanes that skip it touch nothing)
+inline void lds_dma16(const float* src, float* lds_base) {
+    std::memcpy(reinterpret_cast<char*>(lds_base) + 16 * hipcpu::cur->lane, src, 16);
+}
+inline void lds_dma_wait() {}
+
+template <int N>
+inline float row_ror(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+inline float row16_max(float v) {
+    v = fmaxf(v, row_ror<8>(v));
+    v = fmaxf(v, row_ror<4>(v));
+    v = fmaxf(v, row_ror<2>(v));
+    return fmaxf(v, row_ror<1>(v));
+}
+inline float row16_sum(float v) {
+    v += row_ror<8>(v);
+    v += row_ror<4>(v);
+    v += row_ror<2>(v);
+    return v + row_ror<1>(v);
+}
