@@ -627,65 +627,59 @@ __global__ __launch_bounds__(256, G <= 12 ? 5 : 4) void lift_column_kernel(Dims 
 // Pass 1 on the matrix cores, for columns of at most 32 rows and C == 64 (the shapes of the reference's configurations):
 // the run sums of a column are ONE small matrix product
 //     S[run][c] = sum_h  M[run][h] * F[h][c],      M[run][h] = prob[h][bin(run)] if first(run) <= h <= last(run) else 0,
-// evaluated 32 runs at a time with v_mfma_f32_32x32x2_f32 (K = 2 rows per instruction).  F (the B operand: lane l holds
-// rows 2s + (l >> 5), channel 32 nb + (l & 31)) is loaded once into registers and serves every run block; the A operand is
-// gathered from the staged probabilities with the run descriptors of the plan (slot order), so the 32 x 64 result tile IS
-// the block's 32 consecutive slots.  No per-row bookkeeping at all: ~4 VALU instructions per MFMA.
+// evaluated 32 runs at a time with v_mfma_f32_32x32x2_f32 (K = 2 rows per instruction).  One WORKGROUP per column, its
+// four waves share the staged logits / features (LDS DMA) and split everything else: 8 rows of the softmax each, a
+// quarter of the probability write-out each, and the 32-run tiles round-robin -- a column is ~4 tiles, so the serial
+// chain of a wave is stage -> 2 softmax steps -> ONE tile (14 K-steps), a quarter of what one wave per column costs
+// (that variant was latency-bound: 27 us per wave on an otherwise empty GPU).  F is the B operand (lane l: rows
+// 2s + (l >> 5), channel 32 nb + (l & 31)), read from LDS per K-step; the A operand is gathered from the staged
+// probabilities with the run descriptors of the plan (slot order), so the 32 x 64 result tile IS the tile's 32
+// consecutive slots.  No per-row bookkeeping at all: ~4 VALU instructions per MFMA.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kMmaRows = 32;
 
-__global__ __launch_bounds__(256, 4) void lift_column_mma_kernel(Dims dm, const float* __restrict__ feat,
+__global__ __launch_bounds__(256, 6) void lift_column_mma_kernel(Dims dm, const float* __restrict__ feat,
                                                                 const float* __restrict__ logits,
                                                                 const int32_t* __restrict__ col_off,
                                                                 const uint32_t* __restrict__ run_desc,
                                                                 float* __restrict__ prob_cm,
                                                                 float* __restrict__ slots) {
-    __shared__ __attribute__((aligned(16))) float prob_s[4][kMmaRows][64];
+    __shared__ __attribute__((aligned(16))) float ps[kMmaRows][64];       // logits, then probabilities (rotated rows)
+    __shared__ __attribute__((aligned(16))) float fs[kMmaRows][64];       // features
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int colg = blockIdx.x * 4 + wv;
-    if (colg >= dm.BT * dm.NCOL) return;
+    const int colg = blockIdx.x;
     const int bt = colg / dm.NCOL, col = colg - bt * dm.NCOL;
     const int n = col / dm.fW, w = col - n * dm.fW;
     const int D = dm.D, fH = dm.fH;
     constexpr int C = 64;
-    float (*ps)[64] = prob_s[wv];
     const size_t pix0 = (size_t)bt * dm.NPIX + (size_t)n * fH * dm.fW + w;      // pixel (h = 0) of the column
     const float* fcol = feat + pix0 * C;        // wave-uniform bases; the per-lane parts fit 32 bits (pool_limits)
     const float* lcol = logits + pix0 * D;
     const int rsub = lane >> 4, e0 = (lane & 15) * 4;
     const int half = lane >> 5, l32 = lane & 31;
 
-    // ---- logits: global -> LDS directly, 4 pixels per instruction (rotated rows, see prob_col)
+    // ---- rows 8 wv .. 8 wv + 7: logits and features global -> LDS directly, 4 pixels per instruction (the rotation of
+    //      the probability rows is applied to the source, see prob_col); rows beyond the column are zero features
 #pragma unroll
-    for (int i = 0; i < kMmaRows / 4; ++i) {
-        const int r = 4 * i + rsub;
+    for (int i = 0; i < 2; ++i) {
+        const int r = 8 * wv + 4 * i + rsub;
         const int gb = (((lane & 15) - r) & 15) * 4;
-        if (r < fH && gb < D) lds_dma16(lcol + ((unsigned)r * (unsigned)dm.fW * (unsigned)D + (unsigned)gb), &ps[4 * i][0]);
-    }
-    // ---- features: the B operands of all K steps
-    float fb[kMmaRows / 2][2];
-    const unsigned lane_off = (unsigned)half * (unsigned)dm.fW * (unsigned)C + (unsigned)l32;
-#pragma unroll
-    for (int s = 0; s < kMmaRows / 2; ++s) {
-        const int h = 2 * s + half;
-        const float* rowp = fcol + (unsigned)(2 * s) * (unsigned)dm.fW * (unsigned)C;      // wave-uniform
-        fb[s][0] = h < fH ? rowp[lane_off] : 0.f;
-        fb[s][1] = h < fH ? rowp[lane_off + 32u] : 0.f;
+        const unsigned rel = (unsigned)r * (unsigned)dm.fW;
+        if (r < fH && gb < D) lds_dma16(lcol + (rel * (unsigned)D + (unsigned)gb), &ps[8 * wv + 4 * i][0]);
+        if (r < fH) lds_dma16(fcol + (rel * (unsigned)C + (unsigned)e0), &fs[8 * wv + 4 * i][0]);
+        else *reinterpret_cast<float4*>(&fs[r][e0]) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int slot0 = __builtin_amdgcn_readfirstlane(col_off[colg]);
     const int nruns = __builtin_amdgcn_readfirstlane(col_off[colg + 1]) - slot0;
-    // ---- the run descriptors of the first 256 runs (every load of the wave is issued before its first store: a load
-    //      behind stores waits for their completion, the memory counter retires in order)
-    unsigned dv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dv[j] = (64 * j + lane < nruns) ? run_desc[slot0 + 64 * j + lane] : 0x00000100u;
+    // descriptor of this wave's first tile (issued with the other loads: a load behind stores waits for them)
+    unsigned ds = (32 * wv + l32 < nruns) ? run_desc[slot0 + 32 * wv + l32] : 0x00000100u;   // empty: first 1 > last 0
     lds_dma_wait();
     __builtin_amdgcn_wave_barrier();
     // ---- softmax over the bins of each pixel (its 16 lanes), in place
 #pragma unroll
-    for (int i = 0; i < kMmaRows / 4; ++i) {
-        const int r = 4 * i + rsub;
+    for (int i = 0; i < 2; ++i) {
+        const int r = 8 * wv + 4 * i + rsub;
         const int gb = (((lane & 15) - r) & 15) * 4;
         const bool live = r < fH && gb < D;
         float4 q = *reinterpret_cast<const float4*>(&ps[r][e0]);
@@ -702,25 +696,19 @@ __global__ __launch_bounds__(256, 4) void lift_column_mma_kernel(Dims dm, const 
         q.w = live ? q.w * inv : 0.f;
         *reinterpret_cast<float4*>(&ps[r][e0]) = q;
     }
-    __builtin_amdgcn_wave_barrier();
-    // ---- prob_cm[bt][col][d][0 .. fH): 32 consecutive rows of 2 bins per store instruction
+    __syncthreads();
+    // ---- prob_cm[bt][col][d][0 .. fH): 32 consecutive rows of 2 bins per store instruction, bins dealt to the waves
     if (prob_cm) {
         float* out = prob_cm + (size_t)colg * D * fH;
-        for (int d = half; d < D; d += 2)
+        for (int d = 2 * wv + half; d < D; d += 8)
             if (l32 < fH) out[d * fH + l32] = ps[l32][prob_col(l32, d)];
     }
-    // ---- 32 runs (= 32 consecutive slots) per block
+    if (32 * wv >= nruns) return;
+    // ---- this wave's tiles: 32 runs (= 32 consecutive slots) each
     const int ksteps = (fH + 1) >> 1;
-    for (int r0 = 0; r0 < nruns; r0 += 32) {
-        unsigned ds;                                         // descriptor of run r0 + l32; empty: first row 1 > last row 0
-        if (r0 < 256) {
-            const int j = r0 >> 6;
-            const unsigned pick = j == 0 ? dv[0] : j == 1 ? dv[1] : j == 2 ? dv[2] : dv[3];
-            ds = __shfl(pick, (r0 & 63) + l32);
-        } else {
-            ds = (r0 + l32 < nruns) ? run_desc[slot0 + r0 + l32] : 0x00000100u;
-        }
+    for (int r0 = 32 * wv; r0 < nruns; r0 += 128) {
         const int bin = (int)(ds & 255u), first = (int)((ds >> 8) & 255u), last = (int)(ds >> 16);
+        if (r0 + 128 < nruns) ds = (r0 + 128 + l32 < nruns) ? run_desc[slot0 + r0 + 128 + l32] : 0x00000100u;
         f32x16 acc0, acc1;
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc0[k] = acc1[k] = 0.f;
@@ -730,8 +718,8 @@ __global__ __launch_bounds__(256, 4) void lift_column_mma_kernel(Dims dm, const 
                 const int h = 2 * s + half;
                 const float pr = ps[h][prob_col(h, bin)];
                 const float a = ((h >= first) & (h <= last)) ? pr : 0.f;
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, fb[s][0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, fb[s][1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, fs[h][l32], acc0, 0, 0, 0);       // B: rows 2s + half
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, fs[h][32 + l32], acc1, 0, 0, 0);
             }
         }
         // D[row = (k & 3) + 8 (k >> 2) + 4 half][col = l32]: two 128-byte pieces of two slots per store
@@ -1240,8 +1228,8 @@ int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const flo
     const int ncols = dm.BT * dm.NCOL;
     const dim3 cgrid((ncols + 3) / 4);
     if (dm.fH <= kMmaRows && dm.C == 64)
-        hipLaunchKernelGGL(lift_column_mma_kernel, cgrid, dim3(256), 0, s, dm, feat, logits, pv.col_off, pv.run_desc, prob_cm,
-                           slots);
+        hipLaunchKernelGGL(lift_column_mma_kernel, dim3(ncols), dim3(256), 0, s, dm, feat, logits, pv.col_off, pv.run_desc,
+                           prob_cm, slots);
     else if (dm.D <= 32)
         hipLaunchKernelGGL(lift_column_kernel<8>, cgrid, dim3(256), 0, s, dm, feat, logits, pv.masks, pv.col_off, prob_cm, slots);
     else if (dm.D <= 48)
