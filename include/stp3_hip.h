@@ -119,6 +119,7 @@ int stp3_voxel_index(const stp3_lift_dims* dims,
  *                                   vox_runs [B*T*P] int32      slots of voxel v of frame bt, ascending, at
  *                                            col_off[bt*N*fW] + vox_off[bt][v] .. + vox_off[bt][v+1]
  *                                   run_desc [B*T*P] uint32     per slot: depth bin | first row << 8 | last row << 16
+ *                                   run_vox  [B*T*P] int32      per slot: the run's voxel
  *                          counts = int32 [B*T][V] scratch that must be ZERO on entry (the caller zero-fills
  *                          it once; every build leaves it zero again).
  *   Launches: columns (ids, masks, counts), scan of the columns, scan of the voxels, fill, per-voxel order.
@@ -159,7 +160,7 @@ int stp3_depth_softmax(const stp3_lift_dims* dims, const float* logits, float* p
  *           frames in registers; every BEV row (256 bytes) is written once
  * Deterministic (fixed summation order, no atomics).
  *   feat    [B*T][N*fH*fW][C] float32, logits [B*T][N*fH*fW][D] float32 (pixel-major)
- *   prob_cm [B*T][N*fW][D][fH] float32 out (what stp3_lift_splat_bwd reads), or NULL
+ *   prob_cm [B*T][N*fW][D][fH] float32 out, or NULL (needed by the backward only when stp3_lift_bwd_needs_prob says so)
  *   workspace  stp3_lift_workspace_bytes(dims): one slot per possible run (B*T*P*C floats -- the geometry decides how
  *              many are touched: ~7 % for nuScenes-like rigs) + one BEV-sized buffer
  *   bev_layout STP3_BEV_CHANNELS_LAST : pass 2 writes bev directly
@@ -172,20 +173,27 @@ int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const flo
                         void* workspace, size_t workspace_bytes, float* prob_cm, float* bev, void* stream);
 
 /*
- * stp3_lift_splat_bwd -- gradients of stp3_lift_splat_fwd composed with stp3_depth_softmax.
- * Replaces autograd through stp3.py:215-301 and VoxelsSumming.backward (geometry.py:320-330).
- * Two kernels, no atomics:
- *   (a) gradient import: G_t = sum_{t' >= t} discount^(t'-t) grad_bev[b][t'] (the adjoint of the discounted
- *       accumulation) written voxel-major [B*T][V][C] float32 into `workspace`; takes grad_bev in `bev_layout`
- *       and `grad_dtype` (channels-last float32 / bfloat16, channels-first float32), i.e. the layout / type
- *       conversion the gradient needs anyway carries the recurrence;
- *   (b) gather: one image pixel per lane pair (its feature row and feature-gradient row in registers), walking the
- *       depth bins 8 at a time; a voxel's gradient row is fetched once per run of image rows and shared through LDS.
+ * stp3_lift_splat_bwd -- gradients of stp3_lift_splat_fwd (softmax included).
+ * Replaces autograd through stp3.py:215-301 and VoxelsSumming.backward (geometry.py:320-330).  No atomics.
+ *   grad_bev   in `bev_layout` and `grad_dtype` (channels-last float32 / bfloat16, channels-first float32)
+ * Columns of at most 32 rows with C == 64 (stp3_lift_bwd_needs_prob -> 0): ONE kernel, one workgroup per image column,
+ * the adjoint of the forward's matrix product on the matrix cores,
+ *       dM[run][h] = sum_c G[run][c] feat[h][c],    dfeat[h][c] = sum_run M[run][h] G[run][c],
+ *   G[run] = the gradient row of the run's voxel, G_t = sum_{t' >= t} discount^(t'-t) grad_bev[b][t'] summed on the fly
+ *   over the frames of a channels-last gradient (a channels-first gradient goes through an import pass that transposes
+ *   and sums it into `workspace`); probabilities recomputed from `logits` exactly as in the forward; softmax backward
+ *   fused.  Reads `logits` and `plan`; prob_cm / vox_cm are not used and may be NULL.
+ * Other shapes (stp3_lift_bwd_needs_prob -> 1): import pass (layout / dtype conversion carrying the recurrence,
+ *   voxel-major [B*T][V][C] float32 into `workspace`) + a gather kernel, one image pixel per lane pair, walking the depth
+ *   bins 8 at a time with the run table and gradient rows staged in LDS.  Reads prob_cm (written by the forward) and
+ *   vox_cm; logits / plan are not used and may be NULL.
  *   workspace  stp3_lift_workspace_bytes(dims), always required
  *   grad_feat  [B*T][N*fH*fW][C], grad_logits [B*T][N*fH*fW][D]   outputs, fully overwritten
  */
+int stp3_lift_bwd_needs_prob(const stp3_lift_dims* dims, int* needs);
 int stp3_lift_splat_bwd(const stp3_lift_dims* dims, const void* grad_bev, int bev_layout, int grad_dtype,
-                        const float* feat, const float* prob_cm, const int32_t* vox_cm, float discount,
+                        const float* feat, const float* logits, const float* prob_cm, const int32_t* vox_cm,
+                        const void* plan, float discount,
                         void* workspace, size_t workspace_bytes,
                         float* grad_feat, float* grad_logits, void* stream);
 

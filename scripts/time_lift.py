@@ -32,6 +32,9 @@ print('plan build (index + count, scan, fill, order; device part) us', ev_time(l
 f = feat.cuda().permute(0, 1, 2, 4, 5, 3).reshape(d.BT, d.NPIX, d.C).contiguous()
 l = logits.cuda().permute(0, 1, 2, 4, 5, 3).reshape(d.BT, d.NPIX, d.D).contiguous()
 prob = torch.empty(d.BT, d.N * d.fW, d.D, d.fH, device='cuda')
+needs = ctypes.c_int()
+lib.stp3_lift_bwd_needs_prob(ctypes.byref(d), ctypes.byref(needs))
+prob_ptr = ops._ptr(prob) if needs.value else None          # the matrix-core backward recomputes the probabilities
 print('stand-alone softmax operator us', ev_time(lambda: ops.depth_softmax(d, l)))
 print('runs per (b,t):', plan.offsets()[:, -1].tolist(), ' points per (b,t):', d.P, ' total runs:', int(plan.column_offsets()[-1]))
 alg = d.BT * (d.NPIX * d.C * 4 + d.NPIX * d.D * 4 + d.C * d.V * 4)
@@ -40,10 +43,10 @@ gf = torch.empty_like(f); gl = torch.empty_like(l)
 for name, layout in (('channels-last BEV (model path)', ops.BEV_CHANNELS_LAST), ('reference layout (+ transpose pass)', ops.BEV_CHANNELS_FIRST)):
     bev = torch.empty(d.B * d.T * d.C * d.X * d.Y, device='cuda')
     ws, wsb = ops.lift_workspace(d, 'cuda')
-    fwd = lambda: lib.stp3_lift_splat_fwd(ctypes.byref(d), ops._ptr(f), ops._ptr(l), ops._ptr(plan.plan), ctypes.c_float(0.5), layout, ops._ptr(ws), ctypes.c_size_t(wsb), ops._ptr(prob), ops._ptr(bev), ops._stream())
+    fwd = lambda: lib.stp3_lift_splat_fwd(ctypes.byref(d), ops._ptr(f), ops._ptr(l), ops._ptr(plan.plan), ctypes.c_float(0.5), layout, ops._ptr(ws), ctypes.c_size_t(wsb), prob_ptr, ops._ptr(bev), ops._stream())
     us = ev_time(fwd)
     print(f'{name}: lift_splat_fwd (logits -> BEV) us {us:.1f}  algorithmic {alg/1e6:.1f} MB -> {alg/us/1e6:.3f} TB/s ({alg/us/1e6/8*100:.1f}% of 8 TB/s)')
     gb = torch.randn_like(bev)
-    bwd = lambda: lib.stp3_lift_splat_bwd(ctypes.byref(d), ops._ptr(gb), layout, 0, ops._ptr(f), ops._ptr(prob), ops._ptr(plan.vox_cm), ctypes.c_float(0.5), ops._ptr(ws), ctypes.c_size_t(wsb), ops._ptr(gf), ops._ptr(gl), ops._stream())
+    bwd = lambda: lib.stp3_lift_splat_bwd(ctypes.byref(d), ops._ptr(gb), layout, 0, ops._ptr(f), ops._ptr(l), prob_ptr, ops._ptr(plan.vox_cm), ops._ptr(plan.plan), ctypes.c_float(0.5), ops._ptr(ws), ctypes.c_size_t(wsb), ops._ptr(gf), ops._ptr(gl), ops._stream())
     us = ev_time(bwd)
     print(f'{name}: lift_splat_bwd us {us:.1f}  algorithmic {algb/1e6:.1f} MB -> {algb/us/1e6:.3f} TB/s ({algb/us/1e6/8*100:.1f}% of 8 TB/s)')

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void voxel_index_kernel(Dims dm, const float* 
 //   vox_runs [BT*P]             per-voxel slot lists, ascending: the runs of voxel v of frame bt are
 //                               vox_runs[col_off[bt*NCOL] + vox_off[bt][v] ... + vox_off[bt][v+1])
 //   run_desc [BT*P]             per slot: depth bin | first row << 8 | last row << 16 of the run
+//   run_vox  [BT*P]             per slot: the run's voxel
 // Replaces the reference's boolean mask + argsort + cumsum differencing (stp3.py:247-257, geometry.py:302-318).
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -166,6 +167,7 @@ struct PlanView {
     int32_t* tmp;
     int32_t* vox_runs;
     uint32_t* run_desc;
+    int32_t* run_vox;
 };
 
 inline size_t plan_sections(const Dims& dm, size_t* o) {
@@ -177,16 +179,17 @@ inline size_t plan_sections(const Dims& dm, size_t* o) {
     o[4] = p; p += align256((size_t)dm.BT * dm.P * 4);
     o[5] = p; p += align256((size_t)dm.BT * dm.P * 4);
     o[6] = p; p += align256((size_t)dm.BT * dm.P * 4);
+    o[7] = p; p += align256((size_t)dm.BT * dm.P * 4);
     return p;
 }
 
 inline size_t plan_bytes(const Dims& dm) {
-    size_t o[7];
+    size_t o[8];
     return plan_sections(dm, o);
 }
 
 inline PlanView plan_view(const Dims& dm, void* base) {
-    size_t o[7];
+    size_t o[8];
     plan_sections(dm, o);
     char* p = (char*)base;
     PlanView pv;
@@ -197,6 +200,7 @@ inline PlanView plan_view(const Dims& dm, void* base) {
     pv.tmp = (int32_t*)(p + o[4]);
     pv.vox_runs = (int32_t*)(p + o[5]);
     pv.run_desc = (uint32_t*)(p + o[6]);
+    pv.run_vox = (int32_t*)(p + o[7]);
     return pv;
 }
 
@@ -341,7 +345,8 @@ __global__ __launch_bounds__(256) void plan_fill_kernel(Dims dm, const int32_t* 
                                                         const int32_t* __restrict__ col_off,
                                                         const int32_t* __restrict__ vox_off,
                                                         int32_t* __restrict__ vox_cnt, int32_t* __restrict__ tmp,
-                                                        uint32_t* __restrict__ run_desc) {
+                                                        uint32_t* __restrict__ run_desc,
+                                                        int32_t* __restrict__ run_vox) {
     const int lane = threadIdx.x & 63;
     const int colg = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (colg >= dm.BT * dm.NCOL) return;
@@ -358,6 +363,7 @@ __global__ __launch_bounds__(256) void plan_fill_kernel(Dims dm, const int32_t* 
             const int v = ids[lane * dm.fH + h];
             const int slot = slot0 + __popcll(ends_w & lanes_below(lane));
             run_desc[slot] = (unsigned)lane | ((unsigned)first << 8) | ((unsigned)h << 16);
+            run_vox[slot] = v;
             first = -1;
             const int pos = atomicAdd(vox_cnt + (size_t)bt * dm.V + v, -1) - 1;
             tmp[(size_t)frame0 + vox_off[(size_t)bt * (dm.V + 1) + v] + pos] = slot;
@@ -1088,6 +1094,221 @@ __global__ __launch_bounds__(256) void lift_bwd_kernel(Dims dm, int rows_pc, int
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Backward on the matrix cores (columns of at most 32 rows, C == 64): the adjoint of lift_column_mma_kernel + gather
+// ------------------------------------------------------------------------------------------
+// One workgroup per image column, 32 runs (one tile) at a time.  With G[run][c] = the gradient row of the run's voxel
+// (G_t = sum_{t' >= t} discount^(t'-t) dbev_{t'}: summed on the fly over the frames of a channels-last gradient, so the
+// import pass and its 2 x 123 MB disappear; a channels-first gradient arrives pre-summed from grad_import_cf_kernel),
+// M[run][h] = prob[h][bin(run)] on the run's rows and F the column's features:
+//     dM[run][h]  = sum_c G[run][c] F[h][c]        four 16 x 16 output tiles, one per wave (v_mfma_f32_16x16x4_f32)
+//     dF[h][c]   += sum_run M[run][h] G[run][c]    wave = (channel half, run half)      (v_mfma_f32_32x32x2_f32)
+// dM is scattered to dP[h][bin] (every point belongs to at most one run), and after the last tile the softmax backward
+// dlogit = P (dP - <P, dP>) runs per pixel.  The probabilities are recomputed from the logits exactly as in the forward
+// (same code, same bits), so the forward does not have to write them.  Gradient rows are fetched once per run (the
+// first backward fetched them once per run and row slice) into a double-buffered LDS tile, the next tile's rows
+// travelling while the current tile is multiplied.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kGLd = 68;          // floats per staged gradient row: 16-byte aligned, rows 4 banks apart
+constexpr int kBwdRuns = 256;     // run descriptors / voxels staged per pass (a column has ~110 runs)
+
+template <bool BF16, bool SUMMED>   // gradient dtype; SUMMED: `grad` is G_t itself ([BT][V][C] float32)
+__global__ __launch_bounds__(256, 3) void lift_bwd_column_kernel(Dims dm, const void* __restrict__ grad, float discount,
+                                                                const float* __restrict__ feat,
+                                                                const float* __restrict__ logits,
+                                                                const int32_t* __restrict__ col_off,
+                                                                const uint32_t* __restrict__ run_desc,
+                                                                const int32_t* __restrict__ run_vox,
+                                                                float* __restrict__ grad_feat,
+                                                                float* __restrict__ grad_logits) {
+    __shared__ __attribute__((aligned(16))) float ps[kMmaRows][64];       // logits, then probabilities (rotated rows)
+    __shared__ __attribute__((aligned(16))) float fs[kMmaRows][64];       // features
+    __shared__ __attribute__((aligned(16))) float dps[kMmaRows][64];      // dP, same rotation as ps
+    __shared__ __attribute__((aligned(16))) float gs[2][32][kGLd];        // gradient rows of the current / next tile
+    __shared__ unsigned rd_s[kBwdRuns];
+    __shared__ int rv_s[kBwdRuns];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int colg = blockIdx.x;
+    const int bt = colg / dm.NCOL, col = colg - bt * dm.NCOL;
+    const int n = col / dm.fW, w = col - n * dm.fW;
+    const int b = bt / dm.T, t = bt - b * dm.T;
+    const int D = dm.D, fH = dm.fH;
+    constexpr int C = 64;
+    const size_t pix0 = (size_t)bt * dm.NPIX + (size_t)n * fH * dm.fW + w;
+    const float* fcol = feat + pix0 * C;
+    const float* lcol = logits + pix0 * D;
+    const int rsub = lane >> 4, e0 = (lane & 15) * 4;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int l16 = lane & 15, q16 = lane >> 4;
+
+    // ---- stage the column exactly like the forward (rows 8 wv .. 8 wv + 7 per wave)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 8 * wv + 4 * i + rsub;
+        const int gb = ((l16 - r) & 15) * 4;
+        const unsigned rel = (unsigned)r * (unsigned)dm.fW;
+        if (r < fH && gb < D) lds_dma16(lcol + (rel * (unsigned)D + (unsigned)gb), &ps[8 * wv + 4 * i][0]);
+        if (r < fH) lds_dma16(fcol + (rel * (unsigned)C + (unsigned)gb), &fs[8 * wv + 4 * i][0]);     // rotated like ps
+        else *reinterpret_cast<float4*>(&fs[r][e0]) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&dps[r][e0]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int slot0 = __builtin_amdgcn_readfirstlane(col_off[colg]);
+    const int nruns = __builtin_amdgcn_readfirstlane(col_off[colg + 1]) - slot0;
+    // the gradient rows of 32 runs from run `first_run` (8 per wave, 4 per instruction): G_t of the run's voxel
+    const float* gf = (const float*)grad;
+    const uint16_t* gh = (const uint16_t*)grad;
+    struct Rows { float4 g[2]; };
+    auto load_rows = [&](int first_run, int chunk_base) -> Rows {
+        Rows out;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int run = first_run + 8 * wv + 4 * i + rsub;
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (run < min(nruns, chunk_base + kBwdRuns)) {
+                const int v = rv_s[run - chunk_base];
+                if (SUMMED) {
+                    g = *reinterpret_cast<const float4*>(gf + ((size_t)bt * dm.V + v) * C + e0);
+                } else {
+                    for (int tt = dm.T - 1; tt >= t; --tt) {         // stp3.py:296, adjoint of the recurrence
+                        const size_t e = ((size_t)(b * dm.T + tt) * dm.V + v) * C + e0;
+                        float4 x;
+                        if (BF16) {
+                            const uint2 qv = *reinterpret_cast<const uint2*>(gh + e);
+                            x = make_float4(bf16_to_f32((uint16_t)(qv.x & 0xffffu)), bf16_to_f32((uint16_t)(qv.x >> 16)),
+                                            bf16_to_f32((uint16_t)(qv.y & 0xffffu)), bf16_to_f32((uint16_t)(qv.y >> 16)));
+                        } else {
+                            x = *reinterpret_cast<const float4*>(gf + e);
+                        }
+                        g.x = g.x * discount + x.x;
+                        g.y = g.y * discount + x.y;
+                        g.z = g.z * discount + x.z;
+                        g.w = g.w * discount + x.w;
+                    }
+                }
+            }
+            out.g[i] = g;
+        }
+        return out;
+    };
+
+    // dF accumulators of this wave: channel half nb, run half kh of every tile
+    const int nb = wv & 1, kh = wv >> 1;
+    f32x16 dF;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dF[k] = 0.f;
+    const int mi = wv & 1, nj = wv >> 1;          // dM: runs 16 mi .. + 15, rows 16 nj .. + 15 of the tile
+
+    for (int base = 0; base < nruns; base += kBwdRuns) {
+        if (base > 0) __syncthreads();            // rd_s / rv_s free again
+        const int cnt = min(kBwdRuns, nruns - base);
+        if (tid < cnt) {
+            rd_s[tid] = run_desc[slot0 + base + tid];
+            rv_s[tid] = run_vox[slot0 + base + tid];
+        }
+        if (base == 0) lds_dma_wait();            // (waits for the two loads above as well)
+        __syncthreads();
+        // the gradient rows travel two tiles ahead of the tile that is being multiplied
+        Rows ga = load_rows(base, base), gb2 = load_rows(base + 32, base);
+        if (base == 0) {
+            // ---- softmax over the bins of each pixel (its 16 lanes), in place -- while the first rows travel
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = 8 * wv + 4 * i + rsub;
+                const int gb = ((l16 - r) & 15) * 4;
+                const bool live = r < fH && gb < D;
+                float4 q = *reinterpret_cast<const float4*>(&ps[r][e0]);
+                if (!live) q = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                const float mx = row16_max(fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
+                q.x = live ? __expf(q.x - mx) : 0.f;
+                q.y = live ? __expf(q.y - mx) : 0.f;
+                q.z = live ? __expf(q.z - mx) : 0.f;
+                q.w = live ? __expf(q.w - mx) : 0.f;
+                const float inv = 1.0f / row16_sum((q.x + q.y) + (q.z + q.w));
+                q.x = live ? q.x * inv : 0.f;
+                q.y = live ? q.y * inv : 0.f;
+                q.z = live ? q.z * inv : 0.f;
+                q.w = live ? q.w * inv : 0.f;
+                *reinterpret_cast<float4*>(&ps[r][e0]) = q;
+            }
+        }
+        for (int t0 = 0; t0 < cnt; t0 += 32) {
+            const int buf = (t0 >> 5) & 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                *reinterpret_cast<float4*>(&gs[buf][8 * wv + 4 * i + rsub][e0]) = ga.g[i];
+            ga = gb2;
+            gb2 = load_rows(base + t0 + 64, base);
+            __syncthreads();                      // gs[buf] (and, first time, ps / dps) complete; gs[buf ^ 1] free next time
+            const float (*g)[kGLd] = gs[buf];
+            // ---- dM tile (runs 16 mi + i, rows 16 nj + j), K = 64 channels
+            f32x4 dm4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                dm4 = __builtin_amdgcn_mfma_f32_16x16x4f32(g[16 * mi + l16][4 * s + q16],
+                                                           fs[16 * nj + l16][prob_col(16 * nj + l16, 4 * s + q16)], dm4, 0, 0, 0);
+            // D[i = 4 q16 + k][j = l16]: run 16 mi + 4 q16 + k, row h = 16 nj + l16
+            {
+                const int h = 16 * nj + l16;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int rr = t0 + 16 * mi + 4 * q16 + k;
+                    const unsigned ds = rr < cnt ? rd_s[rr] : 0x00000100u;
+                    const int bin = (int)(ds & 255u), first = (int)((ds >> 8) & 255u), last = (int)(ds >> 16);
+                    if ((h >= first) & (h <= last)) dps[h][prob_col(h, bin)] = dm4[k];
+                }
+            }
+            // ---- dF += M^T G over the runs 16 kh .. 16 kh + 15 of the tile, channels 32 nb ..
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int rr = 16 * kh + 2 * s + half;                // run within the tile (the K index)
+                const unsigned ds = t0 + rr < cnt ? rd_s[t0 + rr] : 0x00000100u;
+                const int bin = (int)(ds & 255u), first = (int)((ds >> 8) & 255u), last = (int)(ds >> 16);
+                const float pr = ps[l32][prob_col(l32, bin)];
+                const float a = ((l32 >= first) & (l32 <= last)) ? pr : 0.f;   // M^T[h = l32][run]
+                dF = __builtin_amdgcn_mfma_f32_32x32x2f32(a, g[rr][32 * nb + l32], dF, 0, 0, 0);
+            }
+        }
+    }
+    if (nruns == 0) {                             // (no tile loop ran: the staged column still has to land)
+        lds_dma_wait();
+    }
+    __syncthreads();
+    // ---- dfeat: the two run halves of a channel half are added in LDS (fixed order), rows written by the kh = 0 waves
+    float (*red)[kGLd] = gs[0];                   // [32 rows][64 channels]
+    if (kh == 1) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) red[(k & 3) + 8 * (k >> 2) + 4 * half][32 * nb + l32] = dF[k];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int h = (k & 3) + 8 * (k >> 2) + 4 * half;
+            if (h < fH)
+                grad_feat[(pix0 + (size_t)h * dm.fW) * C + 32 * nb + l32] = dF[k] + red[h][32 * nb + l32];
+        }
+    }
+    // ---- softmax backward per pixel (its 16 lanes): dlogit = P (dP - <P, dP>)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 8 * wv + 4 * i + rsub;
+        const int gb = ((l16 - r) & 15) * 4;
+        const float4 pq = *reinterpret_cast<const float4*>(&ps[r][e0]);
+        const float4 dq = *reinterpret_cast<const float4*>(&dps[r][e0]);
+        const float dot = row16_sum((pq.x * dq.x + pq.y * dq.y) + (pq.z * dq.z + pq.w * dq.w));
+        if (r < fH && gb < D) {
+            float4 o;
+            o.x = pq.x * (dq.x - dot);
+            o.y = pq.y * (dq.y - dot);
+            o.z = pq.z * (dq.z - dot);
+            o.w = pq.w * (dq.w - dot);
+            *reinterpret_cast<float4*>(grad_logits + (pix0 + (size_t)r * dm.fW) * D + gb) = o;
+        }
+    }
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -1117,6 +1338,9 @@ int stp3_voxel_index(const stp3_lift_dims* dims, const float* cam_m, const float
                            ego_t, xs, ys, ds, bev_offset, bev_res, vox, counts);
     return launch_status();
 }
+
+// the shapes the matrix-core kernels cover (the backward one recomputes the probabilities from the logits)
+static bool column_mma_shape(const Dims& dm) { return dm.fH <= kMmaRows && dm.C == 64; }
 
 // what the pooling kernels can address with 32-bit byte offsets / the descriptor's bit fields
 static int pool_limits(const Dims& dm) {
@@ -1161,7 +1385,7 @@ int stp3_lift_plan_build(const stp3_lift_dims* dims, const float* cam_m, const f
     hipLaunchKernelGGL(plan_scan_all_kernel, dim3(1), dim3(1024), 0, s, ncols, pv.col_cnt, pv.col_off);
     hipLaunchKernelGGL(plan_scan_kernel, dim3((dm.V + 1023) / 1024, dm.BT), dim3(1024), 0, s, dm.V, counts, pv.vox_off);
     hipLaunchKernelGGL(plan_fill_kernel, cgrid, dim3(256), 0, s, dm, vox_cm, pv.masks, pv.col_off, pv.vox_off, counts, pv.tmp,
-                       pv.run_desc);
+                       pv.run_desc, pv.run_vox);
     hipLaunchKernelGGL(plan_sort_kernel, dim3((dm.V + 255) / 256, dm.BT), dim3(256), 0, s, dm, pv.vox_off, pv.col_off, pv.tmp,
                        pv.vox_runs);
     return launch_status();
@@ -1227,7 +1451,7 @@ int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const flo
     float* out_cl = cf ? slots + (size_t)dm.BT * dm.P * dm.C : bev;
     const int ncols = dm.BT * dm.NCOL;
     const dim3 cgrid((ncols + 3) / 4);
-    if (dm.fH <= kMmaRows && dm.C == 64)
+    if (column_mma_shape(dm))
         hipLaunchKernelGGL(lift_column_mma_kernel, dim3(ncols), dim3(256), 0, s, dm, feat, logits, pv.col_off, pv.run_desc,
                            prob_cm, slots);
     else if (dm.D <= 32)
@@ -1242,13 +1466,23 @@ int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const flo
     return launch_status();
 }
 
-int stp3_lift_splat_bwd(const stp3_lift_dims* dims, const void* grad_bev, int bev_layout, int grad_dtype,
-                        const float* feat, const float* prob, const int32_t* vox_cm, float discount, void* workspace,
-                        size_t workspace_bytes, float* grad_feat, float* grad_logits, void* stream) {
+int stp3_lift_bwd_needs_prob(const stp3_lift_dims* dims, int* needs) {
     Dims dm;
     int rc = check_dims(dims, &dm);
     if (rc) return rc;
-    if (!grad_bev || !feat || !prob || !vox_cm || !grad_feat || !grad_logits || !workspace) return STP3_EINVAL;
+    if (!needs) return STP3_EINVAL;
+    *needs = column_mma_shape(dm) ? 0 : 1;
+    return STP3_OK;
+}
+
+int stp3_lift_splat_bwd(const stp3_lift_dims* dims, const void* grad_bev, int bev_layout, int grad_dtype,
+                        const float* feat, const float* logits, const float* prob_cm, const int32_t* vox_cm,
+                        const void* plan, float discount, void* workspace, size_t workspace_bytes, float* grad_feat,
+                        float* grad_logits, void* stream) {
+    Dims dm;
+    int rc = check_dims(dims, &dm);
+    if (rc) return rc;
+    if (!grad_bev || !feat || !grad_feat || !grad_logits || !workspace) return STP3_EINVAL;
     if ((rc = pool_limits(dm))) return rc;
     if (bev_layout != STP3_BEV_CHANNELS_FIRST && bev_layout != STP3_BEV_CHANNELS_LAST) return STP3_EINVAL;
     if (grad_dtype != STP3_DTYPE_F32 && grad_dtype != STP3_DTYPE_BF16) return STP3_EINVAL;
@@ -1259,6 +1493,24 @@ int stp3_lift_splat_bwd(const stp3_lift_dims* dims, const void* grad_bev, int be
     hipStream_t s = (hipStream_t)stream;
     float* gacc = (float*)workspace;
     const dim3 igrid((dm.V + 63) / 64, dm.B);
+    if (column_mma_shape(dm)) {
+        if (!logits || !plan) return STP3_EINVAL;
+        PlanView pv = plan_view(dm, const_cast<void*>(plan));
+        const dim3 grid(dm.BT * dm.NCOL);
+        if (cf) {       // reference layout: transpose + recurrence in the import pass, then rows of G_t
+            hipLaunchKernelGGL(grad_import_cf_kernel, igrid, dim3(256), 0, s, dm, (const float*)grad_bev, discount, gacc);
+            hipLaunchKernelGGL((lift_bwd_column_kernel<false, true>), grid, dim3(256), 0, s, dm, (const void*)gacc, discount,
+                               feat, logits, pv.col_off, pv.run_desc, pv.run_vox, grad_feat, grad_logits);
+        } else if (grad_dtype == STP3_DTYPE_BF16) {
+            hipLaunchKernelGGL((lift_bwd_column_kernel<true, false>), grid, dim3(256), 0, s, dm, grad_bev, discount, feat,
+                               logits, pv.col_off, pv.run_desc, pv.run_vox, grad_feat, grad_logits);
+        } else {
+            hipLaunchKernelGGL((lift_bwd_column_kernel<false, false>), grid, dim3(256), 0, s, dm, grad_bev, discount, feat,
+                               logits, pv.col_off, pv.run_desc, pv.run_vox, grad_feat, grad_logits);
+        }
+        return launch_status();
+    }
+    if (!prob_cm || !vox_cm) return STP3_EINVAL;
     if (cf)
         hipLaunchKernelGGL(grad_import_cf_kernel, igrid, dim3(256), 0, s, dm, (const float*)grad_bev, discount, gacc);
     else if (grad_dtype == STP3_DTYPE_BF16)
@@ -1270,7 +1522,7 @@ int stp3_lift_splat_bwd(const stp3_lift_dims* dims, const void* grad_bev, int be
     const int rows_pc = (dm.fH + chunks - 1) / chunks;
     const int64_t tasks = (int64_t)dm.BT * dm.NCOL * chunks;
     hipLaunchKernelGGL(lift_bwd_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, s, dm, rows_pc, chunks, gacc, feat,
-                       prob, vox_cm, grad_feat, grad_logits);
+                       prob_cm, vox_cm, grad_feat, grad_logits);
     return launch_status();
 }
 

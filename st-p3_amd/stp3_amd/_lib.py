@@ -106,8 +106,9 @@ SIGNATURES = {
     'stp3_lift_workspace_bytes': (c_int, [_DIMS_P, ctypes.POINTER(c_size_t)]),
     'stp3_lift_splat_fwd': (c_int, [_DIMS_P, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_size_t,
                                     c_void_p, c_void_p, c_void_p]),
-    'stp3_lift_splat_bwd': (c_int, [_DIMS_P, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
-                                    c_size_t, c_void_p, c_void_p, c_void_p]),
+    'stp3_lift_bwd_needs_prob': (c_int, [_DIMS_P, ctypes.POINTER(c_int)]),
+    'stp3_lift_splat_bwd': (c_int, [_DIMS_P, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_float, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     'stp3_dwconv2d_fwd': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_dwconv2d_bwd_data': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_dwconv2d_bwd_weight_workspace': (c_int, [_DW_P, ctypes.POINTER(c_size_t)]),

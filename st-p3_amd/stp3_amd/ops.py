@@ -223,12 +223,12 @@ class LiftPlan:
 
     def _sections(self):
         """Byte offsets of the plan's sections (include/stp3_hip.h: vox_off, masks, col_cnt, col_off, tmp, vox_runs,
-        run_desc)."""
+        run_desc, run_vox)."""
         d = self.dims
         a = self._align256
         ncol = d.BT * d.N * d.fW
         sizes = [a(d.BT * (d.V + 1) * 4), a(ncol * d.fH * 16), a(ncol * 4), a((ncol + 1) * 4), a(d.BT * d.P * 4),
-                 a(d.BT * d.P * 4), a(d.BT * d.P * 4)]
+                 a(d.BT * d.P * 4), a(d.BT * d.P * 4), a(d.BT * d.P * 4)]
         return [sum(sizes[:i]) for i in range(len(sizes))]
 
     def offsets(self):
@@ -254,6 +254,12 @@ class LiftPlan:
         """[BT*P] int32 view, one word per slot: depth bin | first row << 8 | last row << 16 of the run."""
         d = self.dims
         o = self._sections()[6]
+        return self.plan[o:o + d.BT * d.P * 4].view(torch.int32)
+
+    def run_voxels(self):
+        """[BT*P] int32 view, one word per slot: the voxel the run falls into."""
+        d = self.dims
+        o = self._sections()[7]
         return self.plan[o:o + d.BT * d.P * 4].view(torch.int32)
 
     def run_lists(self):
@@ -304,8 +310,12 @@ class _LiftSplat(torch.autograd.Function):
         assert feat_pm.dtype == torch.float32 and logits_pm.dtype == torch.float32
         assert feat_pm.shape == (d.BT, d.NPIX, d.C) and logits_pm.shape == (d.BT, d.NPIX, d.D)
         dev = feat_pm.device
-        # the probabilities are a by-product of the forward kernel (column-major, what the backward kernel reads)
-        prob = torch.empty(d.BT, d.N * d.fW, d.D, d.fH, dtype=torch.float32, device=dev)
+        # the probabilities are a by-product of the forward kernel (column-major); only the backward kernel of the
+        # general shapes reads them -- the matrix-core one recomputes them from the logits
+        needs = ctypes.c_int()
+        check(_lib.lib().stp3_lift_bwd_needs_prob(ctypes.byref(d), ctypes.byref(needs)), 'stp3_lift_bwd_needs_prob')
+        prob = (torch.empty(d.BT, d.N * d.fW, d.D, d.fH, dtype=torch.float32, device=dev)
+                if needs.value and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None)
         layout = BEV_CHANNELS_LAST if channels_last else BEV_CHANNELS_FIRST
         shape = (d.B, d.T, d.X, d.Y, d.C) if channels_last else (d.B, d.T, d.C, d.X, d.Y)
         bev = torch.empty(shape, dtype=torch.float32, device=dev)
@@ -314,9 +324,9 @@ class _LiftSplat(torch.autograd.Function):
         with _timed('lift_splat_fwd'):
             rc = _lib.lib().stp3_lift_splat_fwd(ctypes.byref(d), _ptr(feat_pm), _ptr(logits_pm), _ptr(lift_plan.plan),
                                                 ctypes.c_float(discount), layout, ws_ptr, ctypes.c_size_t(ws_bytes),
-                                                _ptr(prob), _ptr(bev), _stream())
+                                                _ptr(prob) if prob is not None else None, _ptr(bev), _stream())
         check(rc, 'stp3_lift_splat_fwd')
-        ctx.save_for_backward(feat_pm, prob)
+        ctx.save_for_backward(feat_pm, logits_pm, prob)
         ctx.lift_plan = lift_plan
         ctx.discount = discount
         ctx.channels_last = channels_last
@@ -324,7 +334,7 @@ class _LiftSplat(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_bev):
-        feat_pm, prob = ctx.saved_tensors
+        feat_pm, logits_pm, prob = ctx.saved_tensors
         d = ctx.lift_plan.dims
         if ctx.channels_last:
             # taken as it comes when it already is [B,T,X,Y,C] memory in float32 / bfloat16; copied once otherwise
@@ -338,11 +348,13 @@ class _LiftSplat(torch.autograd.Function):
         gdt = _lib.DTYPE_BF16 if grad_bev.dtype == torch.bfloat16 else _lib.DTYPE_F32
         ws, ws_bytes = lift_workspace(d, grad_bev.device)
         grad_feat = torch.empty_like(feat_pm)
-        grad_logits = torch.empty(d.BT, d.NPIX, d.D, dtype=torch.float32, device=prob.device)
+        grad_logits = torch.empty(d.BT, d.NPIX, d.D, dtype=torch.float32, device=feat_pm.device)
         with _timed('lift_splat_bwd'):
-            rc = _lib.lib().stp3_lift_splat_bwd(ctypes.byref(d), _ptr(grad_bev), layout, gdt, _ptr(feat_pm), _ptr(prob),
-                                                _ptr(ctx.lift_plan.vox_cm), ctypes.c_float(ctx.discount), _ptr(ws),
-                                                ctypes.c_size_t(ws_bytes), _ptr(grad_feat), _ptr(grad_logits), _stream())
+            rc = _lib.lib().stp3_lift_splat_bwd(ctypes.byref(d), _ptr(grad_bev), layout, gdt, _ptr(feat_pm),
+                                                _ptr(logits_pm), _ptr(prob) if prob is not None else None,
+                                                _ptr(ctx.lift_plan.vox_cm), _ptr(ctx.lift_plan.plan),
+                                                ctypes.c_float(ctx.discount), _ptr(ws), ctypes.c_size_t(ws_bytes),
+                                                _ptr(grad_feat), _ptr(grad_logits), _stream())
         check(rc, 'stp3_lift_splat_bwd')
         return grad_feat, grad_logits, None, None, None
 

@@ -132,6 +132,7 @@ def check_plan_structure(plan, vox):
         first[k] = hh
     want_desc = d_i | (first << 8) | (h_i << 16)
     assert np.array_equal(plan.run_descriptors().cpu().numpy()[:len(want_desc)], want_desc), 'run descriptors'
+    assert np.array_equal(plan.run_voxels().cpu().numpy()[:len(want_desc)], vox_c[bt_i, col_i, h_i, d_i]), 'run voxels'
     off = plan.offsets().cpu().numpy()
     lists = plan.run_lists().cpu().numpy()
     for bt in range(d.BT):

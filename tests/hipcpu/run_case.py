@@ -147,6 +147,11 @@ def lift_full(ops):                 # the real geometry: 6 cameras x 224x480, D 
             'dfeat_err': err(f.grad, gf), 'dlogit_err': err(lg.grad, gl)}
 
 
+def lift_c64_frames(ops):           # 64 channels, 16 rows, 3 frames: the matrix-core kernels with the discount recurrence in the backward
+    from tests import helpers as H
+    return case_lift(ops, dict(H.SMALL, out_channels=64, final_dim=(64, 48), downsample=4), 2, 3, 2, 13)
+
+
 def lift_coarse_grid(ops):          # 4 x 4 voxels of 8 m: hundreds of runs per voxel (the wave-wide ordering of long lists)
     from tests import helpers as H
     cfg = dict(H.SMALL, out_channels=16, final_dim=(64, 48), x_bound=(-16.0, 16.0, 8.0), y_bound=(-16.0, 16.0, 8.0))
@@ -677,7 +682,7 @@ def fuzz(ops, seed=1):
     return {'problems': [[t, str(c), n, str(e)] for t, c, n, e in bad]}
 
 
-CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_coarse_grid, lift_tall, voxsum, wprep, optim, se_block, bn_act,
+CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_frames, lift_coarse_grid, lift_tall, voxsum, wprep, optim, se_block, bn_act,
                                  conv, dwconv)}
 
 if __name__ == '__main__':

@@ -29,7 +29,7 @@ import build as hipcpu_build  # noqa: E402
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
 ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}),
            ('conv', {}), ('conv_bn', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
-           ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
+           ('lift_c64_frames', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
 ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)]
 MODEL = [('lift_full', {}), ('model_step_two_ranks', {}), ('model_step_f32_full_losses', {}), ('model_step_f32', {}),
@@ -137,6 +137,12 @@ def test_voxel_pool_many_runs_per_voxel(results):
     _check_lift(_get(results, 'lift_c64_many_runs'))
 
 
+def test_voxel_pool_matrix_core_kernels_over_frames(results):
+    r = _get(results, 'lift_c64_frames')
+    _check_lift(r)
+    assert r['dims'][3] == 64 and r['channels_last_equal']
+
+
 def test_voxel_pool_long_run_lists(results):
     r = _get(results, 'lift_coarse_grid')
     _check_lift(r)
@@ -193,7 +199,7 @@ def test_no_out_of_bounds_access_under_address_sanitizer(tmp_path):
         return case, extra, out
 
     jobs = [(c, {}) for c in ('voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'lift_c16',
-                              'lift_c16_rows32', 'lift_c64_many_runs', 'lift_coarse_grid', 'lift_small', 'lift_tall')]
+                              'lift_c16_rows32', 'lift_c64_many_runs', 'lift_c64_frames', 'lift_coarse_grid', 'lift_small', 'lift_tall')]
     with ThreadPoolExecutor(max_workers=4) as pool:
         done = list(pool.map(lambda j: run(*j), jobs))
     for case, extra, out in done:
