@@ -231,19 +231,19 @@ __device__ __forceinline__ int point_voxel(const Dims& dm, const GeomArgs& g, in
 
 __device__ __forceinline__ unsigned long long lanes_below(int lane) { return (1ull << lane) - 1ull; }
 
-// (1) one WAVE per image column (bt, n, w), lane = depth bin: walks the rows; the ballots over the lanes ARE the
-//     row's mask words.  Writes the column's ids in COLUMN-MAJOR order vox_cm[bt][col][d][h] (one contiguous piece
-//     per column; the backward kernel reads them along h), the masks, the column's run count, and counts the runs per
-//     voxel.
+// (1) one WORKGROUP per image column (bt, n, w), lane = depth bin, the rows dealt to the four waves in contiguous
+//     pieces: the ballots over the lanes ARE the row's mask words.  Writes the column's ids in COLUMN-MAJOR order
+//     vox_cm[bt][col][d][h] (one contiguous piece per column; the general backward kernel reads them along h), the
+//     masks, the column's run count, and counts the runs per voxel.
 __global__ __launch_bounds__(256) void plan_columns_kernel(Dims dm, GeomArgs g, int32_t* __restrict__ vox_cm,
                                                            int32_t* __restrict__ vox_cnt,
                                                            Mask2* __restrict__ masks,
                                                            int32_t* __restrict__ col_cnt, int stage) {
-    extern __shared__ __attribute__((aligned(16))) int32_t ids_s[];   // [4][D][fH] (stage != 0)
+    extern __shared__ __attribute__((aligned(16))) int32_t ids_s[];   // [D][fH] (stage != 0)
+    __shared__ int runs_s[4];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int colg = blockIdx.x * 4 + wv;                  // column over all frames
-    if (colg >= dm.BT * dm.NCOL) return;
+    const int colg = blockIdx.x;                           // column over all frames
     const int bt = colg / dm.NCOL, col = colg - bt * dm.NCOL;
     const int n = col / dm.fW, w = col - n * dm.fW;
     const int b = bt / dm.T, t = bt - b * dm.T;
@@ -251,10 +251,12 @@ __global__ __launch_bounds__(256) void plan_columns_kernel(Dims dm, GeomArgs g, 
     const bool live = d < dm.D;
     const float dep = live ? g.ds[d] : 0.f;
     int32_t* out = vox_cm + (size_t)colg * dm.D * dm.fH;
-    int32_t* ids = stage ? ids_s + (size_t)wv * dm.D * dm.fH : out;     // very tall columns: straight to memory
-    int cur = live ? point_voxel(dm, g, bt, b, t, n, 0, w, dep) : -1;
+    int32_t* ids = stage ? ids_s : out;                    // very tall columns: straight to memory
+    const int per = (dm.fH + 3) >> 2;
+    const int h_lo = min(per * wv, dm.fH), h_hi = min(h_lo + per, dm.fH);
+    int cur = (live && h_lo < h_hi) ? point_voxel(dm, g, bt, b, t, n, h_lo, w, dep) : -1;
     int runs = 0;
-    for (int h = 0; h < dm.fH; ++h) {
+    for (int h = h_lo; h < h_hi; ++h) {
         const int nxt = (live && h + 1 < dm.fH) ? point_voxel(dm, g, bt, b, t, n, h + 1, w, dep) : -1;
         const bool valid = cur >= 0;
         const bool end = valid && nxt != cur;
@@ -265,10 +267,11 @@ __global__ __launch_bounds__(256) void plan_columns_kernel(Dims dm, GeomArgs g, 
         runs += __popcll(ends_w);
         cur = nxt;
     }
-    if (lane == 0) col_cnt[colg] = runs;
+    if (lane == 0) runs_s[wv] = runs;
+    __syncthreads();
+    if (threadIdx.x == 0) col_cnt[colg] = runs_s[0] + runs_s[1] + runs_s[2] + runs_s[3];
     if (!stage) return;
-    __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < dm.D * dm.fH; i += 64) out[i] = ids[i];
+    for (int i = threadIdx.x; i < dm.D * dm.fH; i += 256) out[i] = ids[i];
 }
 
 // (2) exclusive scan of n counts by ONE workgroup (the run counts of all B*T*N*fW columns: a few thousand values)
@@ -338,8 +341,10 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(int V, const int32_t* _
     if (v == V - 1) o[V] = base + wbase + incl;
 }
 
-// (4) one wave per column again: every run end takes its slot (position in the enumeration) and the next free place
-//     of its voxel's list (counting the voxel's counter back down to zero: the scratch is clean for the next build)
+// (4) one workgroup per column again, rows dealt to the waves as in (1): every run end takes its slot (position in
+//     the enumeration) and the next free place of its voxel's list (counting the voxel's counter back down to zero: the
+//     scratch is clean for the next build).  The returning atomics of a wave's rows are independent of each other (the
+//     rows are unrolled: they travel together).
 __global__ __launch_bounds__(256) void plan_fill_kernel(Dims dm, const int32_t* __restrict__ vox_cm,
                                                         const Mask2* __restrict__ masks,
                                                         const int32_t* __restrict__ col_off,
@@ -348,15 +353,26 @@ __global__ __launch_bounds__(256) void plan_fill_kernel(Dims dm, const int32_t* 
                                                         uint32_t* __restrict__ run_desc,
                                                         int32_t* __restrict__ run_vox) {
     const int lane = threadIdx.x & 63;
-    const int colg = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (colg >= dm.BT * dm.NCOL) return;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int colg = blockIdx.x;
     const int bt = colg / dm.NCOL;
-    int slot0 = col_off[colg];
     const int frame0 = col_off[bt * dm.NCOL];
     const int32_t* ids = vox_cm + (size_t)colg * dm.D * dm.fH;
-    int first = -1;                                       // first row of the run bin `lane` is in, or -1
-    for (int h = 0; h < dm.fH; ++h) {
-        const Mask2 m = masks[(size_t)colg * dm.fH + h];
+    const Mask2* mk = masks + (size_t)colg * dm.fH;
+    const int per = (dm.fH + 3) >> 2;
+    const int h_lo = min(per * wv, dm.fH), h_hi = min(h_lo + per, dm.fH);
+    // slot of the first run end of this wave's piece, and the first row of the run bin `lane` is in at its start
+    int slot0 = col_off[colg];
+    for (int h = 0; h < h_lo; ++h) slot0 += __popcll(mk[h].x);
+    int first = -1;
+    for (int h = h_lo - 1; h >= 0; --h) {                  // walk back while the run that reaches row h_lo is open
+        const Mask2 m = mk[h];
+        if (!((m.y >> lane) & 1ull) || ((m.x >> lane) & 1ull)) break;
+        first = h;
+    }
+#pragma unroll 8
+    for (int h = h_lo; h < h_hi; ++h) {
+        const Mask2 m = mk[h];
         const unsigned long long ends_w = m.x;
         if (first < 0 && ((m.y >> lane) & 1ull)) first = h;
         if ((ends_w >> lane) & 1ull) {
@@ -1377,8 +1393,8 @@ int stp3_lift_plan_build(const stp3_lift_dims* dims, const float* cam_m, const f
     GeomArgs g{cam_m, cam_t, ego_r, ego_t, xs, ys, ds, bev_offset, bev_res};
     hipStream_t s = (hipStream_t)stream;
     const int ncols = dm.BT * dm.NCOL;
-    const dim3 cgrid((ncols + 3) / 4);
-    size_t ids_lds = (size_t)4 * dm.D * dm.fH * sizeof(int32_t);
+    const dim3 cgrid(ncols);
+    size_t ids_lds = (size_t)dm.D * dm.fH * sizeof(int32_t);
     const int stage = ids_lds <= 48 * 1024;
     if (!stage) ids_lds = 0;
     hipLaunchKernelGGL(plan_columns_kernel, cgrid, dim3(256), ids_lds, s, dm, g, vox_cm, counts, pv.masks, pv.col_cnt, stage);
