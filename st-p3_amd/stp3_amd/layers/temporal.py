@@ -109,16 +109,22 @@ class PyramidSpatioTemporalPooling(nn.Module):
                 ('conv_bn_relu', conv_1x1x1_norm_activated(in_channels, reduction_channels))])))
         self.features = nn.ModuleList(feats)
 
-    def forward(self, x):
+    def forward(self, x, extra=None):
+        """``extra`` (B, E, T): channels that are constant over each frame's plane (the ego-motion planes of
+        stp3.py:145-152) -- their window mean is the value itself, so they join after the spatial mean."""
         out = []
         for f, pool in zip(self.features, self.pool_sizes):
             _, ph, pw = pool
             b, c, t, h, w = x.shape
+            if extra is not None:
+                assert h == ph and w == pw, 'constant planes are folded for whole-plane pooling only'
             if h % ph == 0 and w % pw == 0:
                 # spatial mean over each pool window, then the causal 2-frame mean with
                 # count_include_pad=False (frame 0 averages only itself): identical to the padded
                 # AvgPool3d + [:, :, :-1] of the reference (temporal.py:396-413), as plain reductions
                 sp = x.float().view(b, c, t, h // ph, ph, w // pw, pw).mean(dim=(4, 6))
+                if extra is not None:
+                    sp = torch.cat([sp, extra.float().view(b, -1, t, 1, 1)], dim=1)
                 # T+1 causal windows: {0}, {0,1}, ..., {T-2,T-1}, {T-1}.  The reference runs conv+BN+ReLU on
                 # all T+1 (so the BatchNorm batch statistics include the last, right-padded window) and
                 # only then drops it.
@@ -161,25 +167,36 @@ class TemporalBlock(nn.Module):
             self.projection = None
 
     @staticmethod
-    def _pointwise(seq, x2, relu=True):
-        """conv_1x1x1_norm_activated (or projection) on the frame-folded tensor: a 1x1 2-D convolution."""
+    def _pointwise(seq, x2, relu=True, extra2=None):
+        """conv_1x1x1_norm_activated (or projection) on the frame-folded tensor: a 1x1 2-D convolution.
+        ``extra2`` (B*T, E): input channels that are constant over the plane -- their part of the 1x1 convolution is
+        a per-frame bias, W[:, C:] @ extra, added inside the fused BatchNorm (exact; no concatenated tensor)."""
         conv, norm = seq[0], seq[1]
-        y = _conv2d_padded_channels(x2, conv.weight[:, :, 0])
-        return _bn_act_2d(norm, y, relu)
+        wgt = conv.weight[:, :, 0]
+        if extra2 is None:
+            return _bn_act_2d(norm, _conv2d_padded_channels(x2, wgt), relu)
+        c = x2.shape[1]
+        y = _conv2d_padded_channels(x2, wgt[:, :c])
+        sbias = extra2.float() @ wgt[:, c:, 0, 0].float().t()
+        return _bn_act_2d(norm, y, relu, sbias=sbias)
 
-    def forward(self, x):
+    def forward(self, x, extra=None):
         """x (B, C, T, H, W) -> (B, C', T, H, W).  Everything runs frame-folded as 2-D ops on
         (B*T, C, H, W): the block only couples frames through the causal 2-tap convolution and the
-        causal pyramid pooling, both of which are expressed explicitly."""
+        causal pyramid pooling, both of which are expressed explicitly.  ``extra`` (B, E, T): the last E of the
+        block's ``in_channels`` given as per-frame constants instead of planes (every consumer of the block's input is
+        a 1x1x1 convolution or the whole-plane pooling, so the fold is exact)."""
         b, c, t, h, w = x.shape
+        extra2 = None if extra is None else extra.permute(0, 2, 1).reshape(b * t, -1)
+        assert c + (0 if extra is None else extra.shape[1]) == self.in_channels
         x2 = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
         if x2.is_cuda:
             x2 = x2.contiguous(memory_format=torch.channels_last)
         outs = []
         for path in self.convolution_paths[:-1]:
-            y = self._pointwise(path[0], x2)
+            y = self._pointwise(path[0], x2, extra2=extra2)
             outs.append(path[1].forward_folded(y, b, t))
-        outs.append(self._pointwise(self.convolution_paths[-1], x2))
+        outs.append(self._pointwise(self.convolution_paths[-1], x2, extra2=extra2))
         paths = torch.cat(outs, dim=1)
         agg = self.aggregation[0]
         wgt = agg.conv.weight[:, :, 0]                                   # (Cout, Cin_total, 1, 1)
@@ -187,7 +204,7 @@ class TemporalBlock(nn.Module):
         sbias = None
         if self.use_pyramid_pooling:
             off = self._paths_channels
-            for pooled in self.pyramid_pooling(x):                       # (B, C', T, h', w')
+            for pooled in self.pyramid_pooling(x, extra):                # (B, C', T, h', w')
                 cp = pooled.shape[1]
                 p2 = pooled.permute(0, 2, 1, 3, 4).reshape(b * t, cp, *pooled.shape[-2:])
                 contrib = (conv1x1_on_vector(p2.to(y.dtype), wgt[:, off:off + cp].to(y.dtype))
@@ -202,6 +219,7 @@ class TemporalBlock(nn.Module):
                         contrib = F.interpolate(contrib, (h, w), mode='bilinear', align_corners=False)
                     y = y + contrib
                 off += cp
-        skip = x2 if self.projection is None else self._pointwise(self.projection, x2, relu=False)
+        assert self.projection is not None or extra is None
+        skip = x2 if self.projection is None else self._pointwise(self.projection, x2, relu=False, extra2=extra2)
         out = _bn_act_2d(agg.norm, y, res=skip, sbias=sbias)
         return out.view(b, t, -1, h, w).permute(0, 2, 1, 3, 4)

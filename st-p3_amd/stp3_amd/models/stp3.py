@@ -173,13 +173,17 @@ class STP3(nn.Module):
         output = {'depth_prediction': depth, 'cam_front': cam_front}
 
         if self.cfg.MODEL.TEMPORAL_MODEL.INPUT_EGOPOSE:
-            # stp3.py:145-152: six broadcast ego-motion planes; frame 0 gets zeros, frame t gets ego[t-1]
-            b, s, c = future_egomotion.shape
-            hh, ww = x.shape[-2:]
+            # stp3.py:145-152: six broadcast ego-motion planes; frame 0 gets zeros, frame t gets ego[t-1].  The planes
+            # are never built: every consumer of the temporal model's input is a 1x1x1 convolution or the whole-plane
+            # pooling, so they enter the first block as per-frame constants (a bias of its fused BatchNorms)
             ego = future_egomotion.to(x.device, non_blocking=True).to(x.dtype)
             ego = torch.cat([torch.zeros_like(ego[:, :1]), ego[:, :rf - 1]], dim=1)
-            x = torch.cat([x, ego.view(b, s, c, 1, 1).expand(b, s, c, hh, ww)], dim=2)
-
-        states = self.temporal_model(x)
+            if isinstance(self.temporal_model, TemporalModel) and len(self.temporal_model.model) > 0:
+                states = self.temporal_model(x, ego)
+            else:
+                b, s, c = ego.shape
+                states = self.temporal_model(torch.cat([x, ego.view(b, s, c, 1, 1).expand(b, s, c, *x.shape[-2:])], dim=2))
+        else:
+            states = self.temporal_model(x)
         output.update(self.decoder(states))
         return output

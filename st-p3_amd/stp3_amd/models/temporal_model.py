@@ -26,9 +26,12 @@ class TemporalModel(nn.Module):
         self.final_conv = DeepLabHead(block_out, block_out, hidden_channel=128)
         self.model = nn.Sequential(*blocks)
 
-    def forward(self, x):
-        """(B, T, C, X, Y) -> (B, T, C', X, Y)."""
-        x = self.model(x.permute(0, 2, 1, 3, 4))            # (B, C, T, X, Y)
+    def forward(self, x, extra=None):
+        """(B, T, C, X, Y) -> (B, T, C', X, Y).  ``extra`` (B, T, E): the last E input channels as per-frame
+        constants (the six ego-motion planes of stp3.py:145-152) -- folded into the first block, never materialised."""
+        x = x.permute(0, 2, 1, 3, 4)                        # (B, C, T, X, Y)
+        for i, blk in enumerate(self.model):
+            x = blk(x, extra.permute(0, 2, 1)) if (i == 0 and extra is not None) else blk(x)
         x = x.permute(0, 2, 1, 3, 4)
         b, s, c, h, w = x.shape
         x = self.final_conv(x.reshape(b * s, c, h, w))

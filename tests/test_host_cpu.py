@@ -154,3 +154,29 @@ def test_lazy_batch_counters_match_immediate_increments(monkeypatch):
     fused.flush_batch_counters()
     fused.flush_batch_counters()
     assert int(a.num_batches_tracked) == 4 and not ops._PENDING_COUNTS
+
+
+def test_ego_motion_planes_folded_into_the_first_temporal_block():
+    """stp3.py:145-152 concatenates six broadcast ego-motion planes to the BEV features; here they enter the temporal
+    model as per-frame constants (bias of the fused BatchNorms of the first block's 1x1x1 convolutions, appended to
+    the whole-plane pooling).  Same outputs and gradients as the concatenated 70-channel tensor, train mode."""
+    import copy
+    from stp3_amd.models.temporal_model import TemporalModel
+    from tests import helpers as H
+    torch.manual_seed(0)
+    m = H.fill_deterministic(TemporalModel(70, 3, input_shape=(20, 20), start_out_channels=64)).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m2 = copy.deepcopy(m)
+    x, ego = torch.randn(2, 3, 64, 20, 20), torch.randn(2, 3, 6)
+    xa = torch.cat([x, ego.view(2, 3, 6, 1, 1).expand(2, 3, 6, 20, 20)], 2).requires_grad_()
+    ya = m(xa)
+    ya.square().mean().backward()
+    xb = x.clone().requires_grad_()
+    yb = m2(xb, ego)
+    yb.square().mean().backward()
+    torch.testing.assert_close(yb, ya, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(xb.grad, xa.grad[:, :, :64], rtol=1e-4, atol=1e-7)
+    for (n, p), q in zip(m.named_parameters(), m2.parameters()):
+        torch.testing.assert_close(q.grad, p.grad, rtol=1e-3, atol=1e-5, msg=n)
