@@ -27,13 +27,14 @@ class SpatialRegressionLoss(nn.Module):
     def forward(self, prediction, target, n_present=3):
         assert prediction.dim() == 5, 'Must be a 5D tensor'
         mask = target[:, :, :1] != self.ignore_index
-        if mask.sum() == 0:
-            return prediction.new_zeros(1)[0].float()
         loss = self.loss_fn(prediction, target, reduction='none').sum(dim=-3, keepdim=True)
         seq_len = loss.shape[1]
         assert seq_len >= n_present
         loss = loss * _future_discounts(self.future_discount, seq_len, n_present, loss).view(1, seq_len, 1, 1, 1)
-        return loss[mask].mean()
+        # mean over the unmasked pixels, 0 when there are none (losses.py:31-33, :43) -- as a masked sum: boolean
+        # indexing and the emptiness test would each cost a device -> host synchronisation per call
+        count = mask.sum()
+        return (loss * mask).sum() / count.clamp_min(1).to(loss.dtype)
 
 
 class SegmentationLoss(nn.Module):

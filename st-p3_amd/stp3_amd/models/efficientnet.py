@@ -174,5 +174,9 @@ class EfficientNet(nn.Module):
     def from_pretrained(cls, name):
         """The package would download ImageNet weights here; there is no network, so this is a
         seeded random initialisation of the same architecture (load real weights with
-        ``load_state_dict`` -- the parameter names match)."""
+        ``load_state_dict`` -- the parameter names match).  Said out loud, once: a silently random backbone is the
+        kind of surprise that costs a training run."""
+        import warnings
+        warnings.warn(f'EfficientNet.from_pretrained({name!r}): no ImageNet weights are available offline -- the '
+                      f'backbone is RANDOMLY initialised; load real weights with load_state_dict()', stacklevel=2)
         return cls(name)

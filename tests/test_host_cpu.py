@@ -180,3 +180,14 @@ def test_ego_motion_planes_folded_into_the_first_temporal_block():
     torch.testing.assert_close(xb.grad, xa.grad[:, :, :64], rtol=1e-4, atol=1e-7)
     for (n, p), q in zip(m.named_parameters(), m2.parameters()):
         torch.testing.assert_close(q.grad, p.grad, rtol=1e-3, atol=1e-5, msg=n)
+
+
+def test_regression_loss_with_everything_ignored_is_zero_and_differentiable():
+    """losses.py:31-33: no unmasked pixel -> 0.  The masked-sum form keeps that without asking the host."""
+    from stp3_amd import losses as L
+    pred = torch.randn(1, 2, 2, 6, 6, requires_grad=True)
+    tgt = torch.full((1, 2, 2, 6, 6), 255.0)
+    loss = L.SpatialRegressionLoss(norm=1, ignore_index=255)(pred, tgt, 2)
+    assert loss.item() == 0.0
+    loss.backward()
+    assert pred.grad.abs().max().item() == 0.0
