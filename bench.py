@@ -215,6 +215,21 @@ def lift_roofline(device, batch, model, iters=30):
     return roof, {k: round(v['avg_ms'], 4) for k, v in prof.items()}
 
 
+def gpu_busy_from_profile():
+    """Kernel time / wall time of the steady-state steps of this workload, from the committed rocprofv3 kernel trace
+    (scripts/gpu_prof.sh -> profiles/*_c3_steady_kernels.txt): a profile of the same command, not of this run."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_c3_steady_kernels.txt')))
+    for path in reversed(files):
+        if path.endswith('_before.txt'):
+            continue
+        m = re.search(r'window wall ([\d.]+) ms, kernel-time sum ([\d.]+) ms \(GPU busy (\d+)%\)', open(path).readline())
+        if m:
+            return {'value': round(float(m.group(2)) / float(m.group(1)), 3), 'source': os.path.relpath(path, ROOT)}
+    return None
+
+
 def _log(msg):
     if os.environ.get('STP3_BENCH_VERBOSE'):
         print(f'[bench +{time.perf_counter() - _T0:7.1f}s] {msg}', file=sys.stderr, flush=True)
@@ -346,6 +361,7 @@ def main():
                        'host_options': host_options},
             'roofline': roof,
             'kernel_ms': kernel_ms,
+            'gpu_busy': gpu_busy_from_profile(),
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
