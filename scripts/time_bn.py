@@ -1,10 +1,13 @@
 """HIP-event timing of the fused BatchNorm kernels on the model's dominant shapes, as GB/s of the bytes each pass
-must move (run with STP3_BN_GEOM=0/1 to compare the two workgroup geometries)."""
+must move (3 passes forward: statistics read, apply read + write; 5 backward)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'st-p3_amd'))
 import torch
 import torch.nn as nn
+from stp3_amd import _lib
+if os.environ.get('EXP_LIB'):          # experiment builds of the library
+    _lib.LIB_PATH = os.environ['EXP_LIB']
 from stp3_amd import ops
 
 SHAPES = [('trunk b2 expand', 72, 144, 112, 240), ('trunk b6 expand', 72, 192, 56, 120), ('trunk b10 expand', 72, 336, 28, 60),
@@ -22,7 +25,7 @@ def ev(fn, iters=10, warm=2):
     return s.elapsed_time(e) / iters * 1e-3
 
 
-print('geometry:', os.environ.get('STP3_BN_GEOM', '0'))
+print('batch of 72 camera images (B=4 x T=3 x 6), bf16, channels-last')
 for name, n, c, h, w in SHAPES:
     cp = (c + 7) // 8 * 8
     xf = torch.randn(n, cp, h, w, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)

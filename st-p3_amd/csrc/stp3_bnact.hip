@@ -20,6 +20,7 @@
 
 #include <initializer_list>
 
+#include "stp3_cdna.h"
 #include "stp3_hip.h"
 
 namespace {
@@ -34,11 +35,6 @@ constexpr int kUnroll = 4;   // rows per thread per iteration: independent 16-by
 
 // ---- element access ---------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
-__device__ __forceinline__ uint16_t f2bf(float a) {   // round to nearest even
-    uint32_t u = __float_as_uint(a);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
 
 template <typename T, int VEC> struct Io;
 template <> struct Io<float, 4> {
@@ -67,13 +63,13 @@ template <> struct Io<uint16_t, 8> {
     static __device__ void store(uint16_t* p, const float* f) {
         uint32_t w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(f[2 * i]) | ((uint32_t)f2bf(f[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = pack_bf16(f[2 * i], f[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
 template <> struct Io<uint16_t, 1> {
     static __device__ void load(const uint16_t* p, float* f) { f[0] = bf2f(p[0]); }
-    static __device__ void store(uint16_t* p, const float* f) { p[0] = f2bf(f[0]); }
+    static __device__ void store(uint16_t* p, const float* f) { p[0] = (uint16_t)pack_bf16(f[0], 0.f); }
 };
 
 // ---- thread -> (row lane, channel vector) mapping shared by all streaming kernels ---------------
@@ -106,13 +102,13 @@ __device__ __forceinline__ Map make_map(const BnDims& d) {
 
 __device__ __forceinline__ float act_fwd(int act, float v) {
     if (act == STP3_ACT_RELU) return fmaxf(v, 0.f);
-    if (act == STP3_ACT_SWISH) return v / (1.f + __expf(-v));
+    if (act == STP3_ACT_SWISH) return v * fast_sigmoid(v);
     return v;
 }
 __device__ __forceinline__ float act_grad(int act, float pre) {
     if (act == STP3_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
     if (act == STP3_ACT_SWISH) {
-        const float s = 1.f / (1.f + __expf(-pre));
+        const float s = fast_sigmoid(pre);
         return s * (1.f + pre * (1.f - s));
     }
     return 1.f;

@@ -42,3 +42,17 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += row_ror<2>(v);
     return v + row_ror<1>(v);
 }
+
+// Two float32 -> one packed bf16 pair (lo in bits 0..15), round to nearest even: v_cvt_pk_bf16_f32, ONE instruction for
+// two elements on gfx950 (the integer round-and-shift it replaces costs ~7 per element -- the memory-bound kernels of
+// this library were VALU-bound on it).
+typedef __bf16 stp3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float stp3_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    const stp3_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, stp3_bf16x2));
+}
+// 1 / x as v_rcp_f32 (1 ulp) -- for activation functions, where the IEEE division sequence (~10 instructions) buys
+// nothing: the results are rounded to bf16 or compared at 1e-4
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + __expf(-x)); }

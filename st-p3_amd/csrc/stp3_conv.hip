@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "stp3_cdna.h"
 #include "stp3_hip.h"
 
 namespace {
@@ -51,11 +52,6 @@ union Frag {
     bf16x8 v;
 };
 
-__device__ __forceinline__ uint32_t f2bf(float a) {   // round to nearest even
-    uint32_t u = __float_as_uint(a);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
 __device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 16); }
 
 constexpr int kBM = 128;        // pixels per workgroup
@@ -244,7 +240,7 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, const uin
                     for (int r = 0; r < 4; ++r) v[r] += co0 + c + r < d.Cout ? bias[co0 + c + r] : 0.f;
                 }
                 *reinterpret_cast<uint2*>(tile + p * ldt + c) =
-                    make_uint2(f2bf(v[0]) | (f2bf(v[1]) << 16), f2bf(v[2]) | (f2bf(v[3]) << 16));
+                    make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
             }
     __syncthreads();
     uint16_t* yo = reinterpret_cast<uint16_t*>(y);

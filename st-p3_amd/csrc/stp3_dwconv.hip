@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "stp3_cdna.h"
 #include "stp3_hip.h"
 
 namespace {
@@ -45,15 +46,10 @@ template <> struct Vec<uint16_t> {
             f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
         }
     }
-    __device__ static uint32_t rne(float a) {  // fp32 -> bf16 bits, round to nearest even
-        uint32_t u = __float_as_uint(a);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;  // NaN
-        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-    }
     __device__ void from_float(const float* f) {
         uint32_t w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = rne(f[2 * i]) | (rne(f[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = pack_bf16(f[2 * i], f[2 * i + 1]);
         v = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };

@@ -14,6 +14,7 @@
 
 #include <initializer_list>
 
+#include "stp3_cdna.h"
 #include "stp3_hip.h"
 
 namespace {
@@ -36,11 +37,6 @@ template <> struct Io2<float, 1> {
     static __device__ void load(const float* p, float* f) { f[0] = p[0]; }
     static __device__ void store(float* p, const float* f) { p[0] = f[0]; }
 };
-__device__ __forceinline__ uint32_t f2bf3(float a) {
-    uint32_t u = __float_as_uint(a);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
 template <> struct Io2<uint16_t, 8> {
     static __device__ void load(const uint16_t* p, float* f) {
         const uint4 v = *reinterpret_cast<const uint4*>(p);
@@ -54,13 +50,13 @@ template <> struct Io2<uint16_t, 8> {
     static __device__ void store(uint16_t* p, const float* f) {
         uint32_t w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = f2bf3(f[2 * i]) | (f2bf3(f[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = pack_bf16(f[2 * i], f[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
 template <> struct Io2<uint16_t, 1> {
     static __device__ void load(const uint16_t* p, float* f) { f[0] = __uint_as_float((uint32_t)p[0] << 16); }
-    static __device__ void store(uint16_t* p, const float* f) { p[0] = (uint16_t)f2bf3(f[0]); }
+    static __device__ void store(uint16_t* p, const float* f) { p[0] = (uint16_t)pack_bf16(f[0], 0.f); }
 };
 
 // thread -> (row lane, channel vector); grid = (row blocks, N, channel tiles)

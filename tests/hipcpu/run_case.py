@@ -654,7 +654,7 @@ def fuzz(ops, seed=1):
                 y = (fused.bn_act if kernel else fused.bn_act_reference)(bn, x, act, r, rm, sb, osc)
                 y.backward(gy if kernel else gy.float())
                 res.append([('y', y.detach().float()), ('dx', x.grad.float()), ('dg', bn.weight.grad), ('db', bn.bias.grad)] + ([('dr', r.grad.float())] if r is not None else []) + ([('dsb', sb.grad)] if sb is not None else []) + [('rm', bn.running_mean.clone()), ('rv', bn.running_var.clone())])
-            tol = 2e-4 if dt == torch.float32 else 3e-2
+            tol = 5e-4 if dt == torch.float32 else 3e-2          # float32: sums of <= 40 values that cancel (C = 1, 3 x 4 maps)
             chk('bn', cfgd, [(a[0], a[1], b[1]) for a, b in zip(*res)], tol)
         except Exception as e:
             bad.append(('bn', cfgd, 'EXC', repr(e)))

@@ -28,3 +28,17 @@ inline float row16_sum(float v) {
     v += row_ror<2>(v);
     return v + row_ror<1>(v);
 }
+
+#include <cstdint>
+#include <cmath>
+inline uint32_t pack_bf16(float lo, float hi) {
+    auto one = [](float a) -> uint32_t {
+        uint32_t u;
+        std::memcpy(&u, &a, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;          // NaN stays NaN
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;                          // round to nearest even
+    };
+    return one(lo) | (one(hi) << 16);
+}
+inline float fast_rcp(float x) { return 1.0f / x; }
+inline float fast_sigmoid(float x) { return 1.0f / (1.0f + std::exp(-x)); }

@@ -169,7 +169,9 @@ def test_whole_step_bf16_matches_the_cpu_port(results):
     r = _get(results, 'model_step_bf16_bn_eval')
     assert not r['params_without_grad']
     assert abs(r['loss'] - r['ref_loss']) <= 2e-2 * abs(r['ref_loss']) and r['grad_rel_l2'] <= 5e-2
-    assert r['grad_rel_l2_by_group']['decoder'] <= 5e-2 and r['grad_rel_l2_by_group']['temporal_model'] <= 8e-2
+    # every convolution (forward, data and weight gradient) runs in bf16 on the hand-written kernels now: the decoder's
+    # ResNet blocks carry 3-6 % of bf16 gradient noise each (tests/test_train_parity_gpu.py measures the same, block by block)
+    assert r['grad_rel_l2_by_group']['decoder'] <= 8e-2 and r['grad_rel_l2_by_group']['temporal_model'] <= 8e-2
 
 
 def test_results_do_not_depend_on_the_thread_schedule(results):
