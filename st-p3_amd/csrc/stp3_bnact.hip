@@ -100,18 +100,35 @@ __device__ __forceinline__ Map make_map(const BnDims& d) {
     return m;
 }
 
-__device__ __forceinline__ float act_fwd(int act, float v) {
-    if (act == STP3_ACT_RELU) return fmaxf(v, 0.f);
-    if (act == STP3_ACT_SWISH) return v * fast_sigmoid(v);
+// The row loops are instantiated per (activation, residual mode) INSIDE each kernel: with the two as run-time values
+// the element loop carried ~2 scalar branches per element, which made these streaming kernels instruction-bound.
+template <int V> struct IntC { static constexpr int value = V; };
+template <int ACT>
+__device__ __forceinline__ float act_fwd_c(float v) {
+    if (ACT == STP3_ACT_RELU) return fmaxf(v, 0.f);
+    if (ACT == STP3_ACT_SWISH) return v * fast_sigmoid(v);
     return v;
 }
-__device__ __forceinline__ float act_grad(int act, float pre) {
-    if (act == STP3_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
-    if (act == STP3_ACT_SWISH) {
+template <int ACT>
+__device__ __forceinline__ float act_grad_c(float pre) {
+    if (ACT == STP3_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
+    if (ACT == STP3_ACT_SWISH) {
         const float s = fast_sigmoid(pre);
         return s * (1.f + pre * (1.f - s));
     }
     return 1.f;
+}
+template <class F>
+__device__ __forceinline__ void dispatch_res(int res_mode, F&& f) {
+    if (res_mode == STP3_RES_NONE) f(IntC<STP3_RES_NONE>{});
+    else if (res_mode == STP3_RES_BEFORE_ACT) f(IntC<STP3_RES_BEFORE_ACT>{});
+    else f(IntC<STP3_RES_AFTER_ACT>{});
+}
+template <class F>
+__device__ __forceinline__ void dispatch_act_res(int act, int res_mode, F&& f) {
+    if (act == STP3_ACT_NONE) dispatch_res(res_mode, [&](auto r) { f(IntC<STP3_ACT_NONE>{}, r); });
+    else if (act == STP3_ACT_RELU) dispatch_res(res_mode, [&](auto r) { f(IntC<STP3_ACT_RELU>{}, r); });
+    else dispatch_res(res_mode, [&](auto r) { f(IntC<STP3_ACT_SWISH>{}, r); });
 }
 
 // In-block tree reduction over the row lanes of K values per thread, then one partial row per block:
@@ -294,30 +311,33 @@ __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
     const T* rs = d.res_mode ? res + (size_t)n * d.rows * d.ldr + c0 : nullptr;
     T* ys = y + (size_t)n * d.rows * d.ldy + c0;
     const int step = gridDim.x * m.RL;
-    for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += kUnroll * step) {
-        float v[kUnroll][VEC], rv[kUnroll][VEC];
+    dispatch_act_res(d.act, d.res_mode, [&](auto act_c, auto res_c) {
+        constexpr int ACT = decltype(act_c)::value, RESM = decltype(res_c)::value;
+        for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += kUnroll * step) {
+            float v[kUnroll][VEC], rv[kUnroll][VEC];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            if (r + u * step < d.rows) {
-                Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
-                if (d.res_mode) Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            if (r + u * step < d.rows) {
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    float t = fmaf(v[u][j], scale[j], shift[j]);
-                    if (d.res_mode == STP3_RES_BEFORE_ACT) t += rv[u][j];
-                    t = act_fwd(d.act, t) * os;
-                    if (d.res_mode == STP3_RES_AFTER_ACT) t += rv[u][j];
-                    v[u][j] = t;
+            for (int u = 0; u < kUnroll; ++u) {
+                if (r + u * step < d.rows) {
+                    Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
+                    if (RESM != STP3_RES_NONE) Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
                 }
-                Io<T, VEC>::store(ys + (size_t)(r + u * step) * d.ldy, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                if (r + u * step < d.rows) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        float t = fmaf(v[u][j], scale[j], shift[j]);
+                        if (RESM == STP3_RES_BEFORE_ACT) t += rv[u][j];
+                        t = act_fwd_c<ACT>(t) * os;
+                        if (RESM == STP3_RES_AFTER_ACT) t += rv[u][j];
+                        v[u][j] = t;
+                    }
+                    Io<T, VEC>::store(ys + (size_t)(r + u * step) * d.ldy, v[u]);
+                }
             }
         }
-    }
+    });
 }
 
 // ---- backward reduce: per (sample, channel) sums of g, g * xhat and xhat -----------------------
@@ -353,35 +373,40 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
         const T* rs = d.res_mode == STP3_RES_BEFORE_ACT ? res + (size_t)n * d.rows * d.ldr + c0 : nullptr;
         const int step = gridDim.x * m.RL;
         constexpr int U = 2;
-        for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += U * step) {
-            float v[U][VEC], g[U][VEC], rv[U][VEC];
+        // (the residual only matters when it is added in front of the activation)
+        dispatch_act_res(d.act, rs ? STP3_RES_BEFORE_ACT : STP3_RES_NONE, [&](auto act_c, auto res_c) {
+            constexpr int ACT = decltype(act_c)::value;
+            constexpr bool PRE_RES = decltype(res_c)::value == STP3_RES_BEFORE_ACT;
+            for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += U * step) {
+                float v[U][VEC], g[U][VEC], rv[U][VEC];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (r + u * step < d.rows) {
-                    Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
-                    Io<T, VEC>::load(gs + (size_t)(r + u * step) * d.ldy, g[u]);
-                    if (rs) Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
+                for (int u = 0; u < U; ++u) {
+                    if (r + u * step < d.rows) {
+                        Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
+                        Io<T, VEC>::load(gs + (size_t)(r + u * step) * d.ldy, g[u]);
+                        if (PRE_RES) Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
+                    }
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (r + u * step < d.rows) {
+                for (int u = 0; u < U; ++u) {
+                    if (r + u * step < d.rows) {
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) {
-                        const float xh = (v[u][j] - mu[j]) * is[j];
-                        float gg = g[u][j] * os;
-                        if (d.act != STP3_ACT_NONE) {
-                            float pre = fmaf(xh, ga[j], be[j]);
-                            if (rs) pre += rv[u][j];
-                            gg *= act_grad(d.act, pre);
+                        for (int j = 0; j < VEC; ++j) {
+                            const float xh = (v[u][j] - mu[j]) * is[j];
+                            float gg = g[u][j] * os;
+                            if (ACT != STP3_ACT_NONE) {
+                                float pre = fmaf(xh, ga[j], be[j]);
+                                if (PRE_RES) pre += rv[u][j];
+                                gg *= act_grad_c<ACT>(pre);
+                            }
+                            acc[0][j] += gg;
+                            acc[1][j] = fmaf(gg, xh, acc[1][j]);
+                            acc[2][j] += xh;                            // needed for the per-sample bias gradient
                         }
-                        acc[0][j] += gg;
-                        acc[1][j] = fmaf(gg, xh, acc[1][j]);
-                        acc[2][j] += xh;                            // needed for the per-sample bias gradient
                     }
                 }
             }
-        }
+        });
     }
     block_reduce_store<VEC, 3, FULL>(d, m, acc, red, partial);
 }
@@ -420,36 +445,40 @@ __global__ __launch_bounds__(kThreads) void bn_apply_bwd_kernel(
     T* drs = (pre_res && dres) ? dres + (size_t)n * d.rows * d.ldr + c0 : nullptr;
     const int step = gridDim.x * m.RL;
     constexpr int U = 2;
-    for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += U * step) {
-        float v[U][VEC], g[U][VEC], rv[U][VEC];
+    dispatch_act_res(d.act, rs ? STP3_RES_BEFORE_ACT : STP3_RES_NONE, [&](auto act_c, auto res_c) {
+        constexpr int ACT = decltype(act_c)::value;
+        constexpr bool PRE_RES = decltype(res_c)::value == STP3_RES_BEFORE_ACT;
+        for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += U * step) {
+            float v[U][VEC], g[U][VEC], rv[U][VEC];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (r + u * step < d.rows) {
-                Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
-                Io<T, VEC>::load(gs + (size_t)(r + u * step) * d.ldy, g[u]);
-                if (rs) Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (r + u * step < d.rows) {
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    const float xh = (v[u][j] - mu[j]) * is[j];
-                    float gg = g[u][j] * os;
-                    if (d.act != STP3_ACT_NONE) {
-                        float pre = fmaf(xh, ga[j], be[j]);
-                        if (rs) pre += rv[u][j];
-                        gg *= act_grad(d.act, pre);
-                    }
-                    g[u][j] = gg;                                  // gradient w.r.t. the pre-activation
-                    v[u][j] = ga[j] * is[j] * (gg - k0[j] - xh * k1[j]);
+            for (int u = 0; u < U; ++u) {
+                if (r + u * step < d.rows) {
+                    Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
+                    Io<T, VEC>::load(gs + (size_t)(r + u * step) * d.ldy, g[u]);
+                    if (PRE_RES) Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
                 }
-                Io<T, VEC>::store(dxs + (size_t)(r + u * step) * d.ldx, v[u]);
-                if (drs) Io<T, VEC>::store(drs + (size_t)(r + u * step) * d.ldr, g[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (r + u * step < d.rows) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const float xh = (v[u][j] - mu[j]) * is[j];
+                        float gg = g[u][j] * os;
+                        if (ACT != STP3_ACT_NONE) {
+                            float pre = fmaf(xh, ga[j], be[j]);
+                            if (PRE_RES) pre += rv[u][j];
+                            gg *= act_grad_c<ACT>(pre);
+                        }
+                        g[u][j] = gg;                                  // gradient w.r.t. the pre-activation
+                        v[u][j] = ga[j] * is[j] * (gg - k0[j] - xh * k1[j]);
+                    }
+                    Io<T, VEC>::store(dxs + (size_t)(r + u * step) * d.ldx, v[u]);
+                    if (drs) Io<T, VEC>::store(drs + (size_t)(r + u * step) * d.ldr, g[u]);
+                }
             }
         }
-    }
+    });
 }
 
 // ---- host side --------------------------------------------------------------------------------
