@@ -57,7 +57,10 @@ template <> struct Vec<uint16_t> {
 // ---- forward: y[n,ho,wo,c] = sum_{kh,kw} x[n, ho*S+kh-pt, wo*S+kw-pl, c] * w[kh,kw,c] ----------
 // One thread = one channel vector x TW consecutive output columns: the input row segment and the
 // K weight vectors of a kernel row are loaded once and reused across the TW outputs.
-template <typename T, int K, int S, int TW>
+// FLIP: the taps are read in reverse order -- the data gradient of a stride-1 depthwise convolution IS a depthwise
+// convolution of dy with the flipped kernel (padding K - 1 - p), so it shares this kernel and its register reuse
+// (TW outputs per thread share one input span per kernel row; the tap-major weights are read once per row).
+template <typename T, int K, int S, int TW, bool FLIP>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwDims d, const T* __restrict__ x,
                                                          const float* __restrict__ w, T* __restrict__ y) {
     constexpr int VN = Vec<T>::N;
@@ -89,7 +92,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwDims d, const T* __re
 #pragma unroll
         for (int kw = 0; kw < K; ++kw)
 #pragma unroll
-            for (int j = 0; j < VN; ++j) wk[kw][j] = w[(kh * K + kw) * d.C + c0 + j];
+            for (int j = 0; j < VN; ++j)
+                wk[kw][j] = w[(FLIP ? (K - 1 - kh) * K + (K - 1 - kw) : kh * K + kw) * d.C + c0 + j];
         const T* xrow = x + ((int64_t)(n * d.H + hi) * d.W) * d.C + c0;
         float xin[SPAN][VN];
 #pragma unroll
@@ -172,6 +176,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwDims d, const 
                                                                 float* __restrict__ partial) {
     constexpr int VN = Vec<T>::N;
     constexpr int KK = K * K;
+    constexpr int TW = 4;                            // consecutive output pixels of a row per thread and step:
+    constexpr int SPAN = (TW - 1) * S + K;           // they share one input span (SPAN loads for TW * K products)
     extern __shared__ __attribute__((aligned(16))) float red[];   // [PL][K][CVB*VN]
     const int CV = d.C / VN;
     const int CVB = min(CV, 256);                    // channel vectors handled by this block column
@@ -186,31 +192,40 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwDims d, const 
     for (int t = 0; t < K; ++t)
 #pragma unroll
         for (int j = 0; j < VN; ++j) acc[t][j] = 0.f;
-    const int64_t npix = (int64_t)d.N * d.Ho * d.Wo;
+    const int wgroups = (d.Wo + TW - 1) / TW;
+    const int ngroups = d.N * d.Ho * wgroups;        // < 2^31 (checked by the launcher)
     if (live) {
-        for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < npix; p += (int64_t)gridDim.x * PL) {
-            const int wo = (int)(p % d.Wo);
-            const int64_t r = p / d.Wo;
-            const int ho = (int)(r % d.Ho);
-            const int n = (int)(r / d.Ho);
+        for (int p = blockIdx.x * PL + pl; p < ngroups; p += gridDim.x * PL) {
+            const int wg = p % wgroups;
+            const int r = p / wgroups;
+            const int ho = r % d.Ho;
+            const int n = r / d.Ho;
             const int hi = ho * S + kh - d.pad_t;
             if (hi < 0 || hi >= d.H) continue;
-            Vec<T> gv;
-            gv.load(dy + p * d.C + c0);
-            float g[VN];
-            gv.to_float(g);
-            const T* xrow = x + ((int64_t)(n * d.H + hi) * d.W) * d.C + c0;
+            const int wo0 = wg * TW;
+            const T* grow = dy + ((size_t)(n * d.Ho + ho) * d.Wo + wo0) * d.C + c0;
+            const T* xrow = x + ((size_t)(n * d.H + hi) * d.W) * d.C + c0;
+            const int wi0 = wo0 * S - d.pad_l;
+            float g[TW][VN], xin[SPAN][VN];
 #pragma unroll
-            for (int kw = 0; kw < K; ++kw) {
-                const int wi = wo * S + kw - d.pad_l;
-                if (wi < 0 || wi >= d.W) continue;
-                Vec<T> xv;
-                xv.load(xrow + (int64_t)wi * d.C);
-                float xf[VN];
-                xv.to_float(xf);
-#pragma unroll
-                for (int j = 0; j < VN; ++j) acc[kw][j] = fmaf(g[j], xf[j], acc[kw][j]);
+            for (int o = 0; o < TW; ++o) {
+                Vec<T> v;
+                if (wo0 + o < d.Wo) v.load(grow + (size_t)o * d.C); else v.zero();
+                v.to_float(g[o]);
             }
+#pragma unroll
+            for (int i = 0; i < SPAN; ++i) {
+                const int wi = wi0 + i;
+                Vec<T> v;
+                if (wi >= 0 && wi < d.W) v.load(xrow + (size_t)wi * d.C); else v.zero();
+                v.to_float(xin[i]);
+            }
+#pragma unroll
+            for (int o = 0; o < TW; ++o)
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                    for (int j = 0; j < VN; ++j) acc[kw][j] = fmaf(g[o][j], xin[o * S + kw][j], acc[kw][j]);
         }
     }
     const int rowlen = CVB * VN;
@@ -274,16 +289,27 @@ int launch_fwd(const DwDims& d, const void* x, const float* w, void* y, hipStrea
     constexpr int TW = 4;
     const int CV = d.C / Vec<T>::N;
     const int64_t total = (int64_t)d.N * d.Ho * ((d.Wo + TW - 1) / TW) * CV;
-    hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, S, TW>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d,
+    hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, S, TW, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d,
                        (const T*)x, w, (T*)y);
     return status();
 }
 template <typename T, int K, int S>
 int launch_bwd_data(const DwDims& d, const void* dy, const float* w, void* dx, hipStream_t s) {
-    const int64_t total = (int64_t)d.N * d.H * d.W * (d.C / Vec<T>::N);
-    hipLaunchKernelGGL((dwconv_bwd_data_kernel<T, K, S>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d,
-                       (const T*)dy, w, (T*)dx);
-    return status();
+    if constexpr (S == 1) {           // convolution of dy (Ho x Wo) with the flipped taps -> dx (H x W)
+        constexpr int TW = 4;
+        DwDims f = d;
+        f.H = d.Ho; f.W = d.Wo; f.Ho = d.H; f.Wo = d.W;
+        f.pad_t = K - 1 - d.pad_t; f.pad_l = K - 1 - d.pad_l;
+        const int64_t n = (int64_t)f.N * f.Ho * ((f.Wo + TW - 1) / TW) * (f.C / Vec<T>::N);
+        hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, 1, TW, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, f,
+                           (const T*)dy, w, (T*)dx);
+        return status();
+    } else {
+        const int64_t total = (int64_t)d.N * d.H * d.W * (d.C / Vec<T>::N);
+        hipLaunchKernelGGL((dwconv_bwd_data_kernel<T, K, S>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d,
+                           (const T*)dy, w, (T*)dx);
+        return status();
+    }
 }
 template <typename T, int K, int S>
 int launch_bwd_weight(const DwDims& d, const void* x, const void* dy, float* dw, float* ws, hipStream_t s) {
@@ -291,7 +317,8 @@ int launch_bwd_weight(const DwDims& d, const void* x, const void* dy, float* dw,
     const int CV = d.C / VN;
     const int CVB = CV < 256 ? CV : 256;
     const int PL = 256 / CVB;
-    const int64_t npix = (int64_t)d.N * d.Ho * d.Wo;
+    const int64_t npix = (int64_t)d.N * d.Ho * ((d.Wo + 3) / 4);       // groups of 4 output pixels
+    if (npix >= (1LL << 31)) return STP3_EUNSUP;
     int64_t want = (npix + PL - 1) / PL;
     const int bx = (int)(want < kWgradBlocks ? want : kWgradBlocks);
     const int by = (CV + CVB - 1) / CVB;
