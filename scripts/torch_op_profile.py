@@ -1,0 +1,40 @@
+"""Which torch operators (not our kernels) cost GPU time in one bench step, with input shapes: torch.profiler over two
+steady-state steps of bench.py's workload.   python scripts/torch_op_profile.py [top_n]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'st-p3_amd'))
+import torch
+from torch.profiler import ProfilerActivity, profile
+import bench
+from stp3_amd.parallel import FlatAdam, GradientBuckets
+
+dev = torch.device('cuda', 0)
+module, cfg = bench.build_module(dev, sync_bn=False, workload='c3')
+buckets = GradientBuckets(module.model)
+opt = FlatAdam(buckets, lr=cfg.OPTIMIZER.LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY)
+batch = bench.make_device_batch(4, dev, seed=100, workload='c3')
+
+
+def step():
+    buckets.zero_grad()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        loss = module.training_step(batch)
+    loss.backward()
+    opt.clip_and_step(cfg.GRAD_NORM_CLIP)
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    step()
+    step()
+    torch.cuda.synchronize()
+rows = prof.key_averages(group_by_input_shape=True)
+rows = sorted(rows, key=lambda e: -e.self_device_time_total)
+top = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+print(f'{"self GPU ms/step":>16s} {"calls/step":>10s}  op  shapes')
+for e in rows[:top]:
+    if e.self_device_time_total <= 0:
+        continue
+    print(f'{e.self_device_time_total / 2e3:16.3f} {e.count / 2:10.1f}  {e.key[:40]:40s} {str(e.input_shapes)[:150]}')

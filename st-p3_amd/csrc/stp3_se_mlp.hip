@@ -94,63 +94,65 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_sample_kernel(stp3_se_mlp_dims
     }
 }
 
-// backward, weights: thread = channel c, samples added in ascending order (deterministic)
+// backward, weights: thread = channel c, workgroup = (64 channels, 8 squeezed channels); samples added in ascending
+// order (deterministic)
 //   dw2[c][s] = sum_n dz2[n][c] swish(z1[n][s]);  db2[c] = sum_n dz2[n][c]
-//   dw1[s][c] = sum_n dz1[n][s] pooled[n][c];      db1[s] = sum_n dz1[n][s]   (workgroup 0)
-// LDS = 2 * N * S floats (swish(z1) and dz1 of all samples)
+//   dw1[s][c] = sum_n dz1[n][s] pooled[n][c];      db1[s] = sum_n dz1[n][s]   (workgroup (0, 0))
+// LDS = 2 * N * 8 floats (swish(z1) and dz1 of all samples for the workgroup's 8 squeezed channels).  The grid is
+// C/64 x S/8 workgroups: the first version ran C/256 workgroups (1-4 on the whole chip) for 78 us per call.
 constexpr int kSChunk = 8;
+constexpr int kWgtThreads = 64;
 
-__global__ __launch_bounds__(256) void se_mlp_bwd_weight_kernel(stp3_se_mlp_dims d, const float* __restrict__ pooled_sum,
-                                                                const float* __restrict__ z1,
-                                                                const float* __restrict__ dz2,
-                                                                const float* __restrict__ dz1, float* __restrict__ dw1,
-                                                                float* __restrict__ db1, float* __restrict__ dw2,
-                                                                float* __restrict__ db2) {
+__global__ __launch_bounds__(kWgtThreads) void se_mlp_bwd_weight_kernel(stp3_se_mlp_dims d,
+                                                                        const float* __restrict__ pooled_sum,
+                                                                        const float* __restrict__ z1,
+                                                                        const float* __restrict__ dz2,
+                                                                        const float* __restrict__ dz1,
+                                                                        float* __restrict__ dw1, float* __restrict__ db1,
+                                                                        float* __restrict__ dw2, float* __restrict__ db2) {
     extern __shared__ float smem[];
-    float* hs = smem;                         // [N][S]
-    float* g1 = smem + (size_t)d.N * d.S;     // [N][S]
+    float* hs = smem;                         // [N][8]
+    float* g1 = smem + (size_t)d.N * kSChunk; // [N][8]
     const int tid = threadIdx.x;
-    for (int i = tid; i < d.N * d.S; i += 256) {
-        const float z = z1[i];
+    const int s0 = blockIdx.y * kSChunk;
+    for (int i = tid; i < d.N * kSChunk; i += kWgtThreads) {
+        const int n = i / kSChunk, s = s0 + i % kSChunk;
+        const float z = s < d.S ? z1[n * d.S + s] : 0.f;
         hs[i] = z * sigmoidf_(z);
-        g1[i] = dz1[i];
+        g1[i] = s < d.S ? dz1[n * d.S + s] : 0.f;
     }
     __syncthreads();
-    if (blockIdx.x == 0 && tid < d.S) {
+    if (blockIdx.x == 0 && tid < kSChunk && s0 + tid < d.S) {
         float a = 0.f;
-        for (int n = 0; n < d.N; ++n) a += g1[n * d.S + tid];
-        db1[tid] = a;
+        for (int n = 0; n < d.N; ++n) a += g1[n * kSChunk + tid];
+        db1[s0 + tid] = a;
     }
-    const int c = blockIdx.x * 256 + tid;
+    const int c = blockIdx.x * kWgtThreads + tid;
     if (c >= d.C) return;
     float sb = 0.f;
-    for (int s0 = 0; s0 < d.S; s0 += kSChunk) {
-        float a2[kSChunk], a1[kSChunk];
+    float a2[kSChunk], a1[kSChunk];
 #pragma unroll
-        for (int k = 0; k < kSChunk; ++k) a2[k] = a1[k] = 0.f;
-        for (int n = 0; n < d.N; ++n) {
-            const float x2 = dz2[(size_t)n * d.C + c];
-            const float pc = pooled_sum[(size_t)n * d.C + c] * d.inv_rows;
-            if (s0 == 0) sb += x2;
-#pragma unroll
-            for (int k = 0; k < kSChunk; ++k) {
-                const int s = s0 + k;
-                const float hv = s < d.S ? hs[n * d.S + s] : 0.f;
-                const float gv = s < d.S ? g1[n * d.S + s] : 0.f;
-                a2[k] = fmaf(x2, hv, a2[k]);
-                a1[k] = fmaf(gv, pc, a1[k]);
-            }
-        }
+    for (int k = 0; k < kSChunk; ++k) a2[k] = a1[k] = 0.f;
+#pragma unroll 4
+    for (int n = 0; n < d.N; ++n) {
+        const float x2 = dz2[(size_t)n * d.C + c];
+        const float pc = pooled_sum[(size_t)n * d.C + c] * d.inv_rows;
+        sb += x2;
 #pragma unroll
         for (int k = 0; k < kSChunk; ++k) {
-            const int s = s0 + k;
-            if (s < d.S) {
-                dw2[(size_t)c * d.S + s] = a2[k];
-                dw1[(size_t)s * d.C + c] = a1[k];
-            }
+            a2[k] = fmaf(x2, hs[n * kSChunk + k], a2[k]);
+            a1[k] = fmaf(g1[n * kSChunk + k], pc, a1[k]);
         }
     }
-    db2[c] = sb;
+#pragma unroll
+    for (int k = 0; k < kSChunk; ++k) {
+        const int s = s0 + k;
+        if (s < d.S) {
+            dw2[(size_t)c * d.S + s] = a2[k];
+            dw1[(size_t)s * d.C + c] = a1[k];
+        }
+    }
+    if (blockIdx.y == 0) db2[c] = sb;
 }
 
 inline int check(const stp3_se_mlp_dims* d) {
@@ -184,8 +186,9 @@ int stp3_se_mlp_bwd(const stp3_se_mlp_dims* dims, const float* dgate, const floa
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(se_mlp_bwd_sample_kernel, dim3(dims->N), dim3(256), (size_t)(dims->C + 2 * dims->S) * 4, s, *dims,
                        dgate, gate, z1, w1, w2, dz2, dz1, dpooled);
-    hipLaunchKernelGGL(se_mlp_bwd_weight_kernel, dim3((dims->C + 255) / 256), dim3(256),
-                       (size_t)2 * dims->N * dims->S * 4, s, *dims, pooled_sum, z1, dz2, dz1, dw1, db1, dw2, db2);
+    hipLaunchKernelGGL(se_mlp_bwd_weight_kernel, dim3((dims->C + kWgtThreads - 1) / kWgtThreads, (dims->S + kSChunk - 1) / kSChunk),
+                       dim3(kWgtThreads), (size_t)2 * dims->N * kSChunk * 4, s, *dims, pooled_sum, z1, dz2, dz1, dw1, db1,
+                       dw2, db2);
     return launch_status();
 }
 
