@@ -1,8 +1,8 @@
 """Operator census of one training step (no GPU needed): how many torch operators and how many C-ABI launches does
-the host issue per step under a given set of switches?  Dry run (tests/model_trace.py); the COUNT of operators does
+the host issue per step?  Dry run (tests/model_trace.py); the COUNT of operators does
 not depend on tensor sizes, so a tiny configuration is used.
 
-    [STP3_FUSED_SE=1 STP3_CONV_V2=1 ...] python scripts/op_census.py
+    python scripts/op_census.py
 """
 import collections
 import os
