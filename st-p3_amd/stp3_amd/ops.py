@@ -661,7 +661,13 @@ class _BnAct(torch.autograd.Function):
             dy = dy.to(x.dtype)
         dy, ldy = _rows_view(dy)
         if ldy != c:
-            dy = dy.contiguous(memory_format=torch.channels_last)
+            if ldy % 8 == 0 and dy.data_ptr() % 16 == 0:
+                # a channel slice of a wider channels-last tensor (the gradient of a torch.cat): read in place with its
+                # own row stride instead of being copied dense first
+                dims = _lib.BnDims(dims.N, dims.rows, dims.C, dims.ldx, ldy, dims.ldr, dims.dtype, dims.act,
+                                   dims.res_mode, dims.has_sbias, dims.has_oscale)
+            else:
+                dy = dy.contiguous(memory_format=torch.channels_last)
         ws, ws_bytes = _bn_workspace(n, c, dev)
         sumbuf = torch.empty((n + 1) * 3 * c, dtype=torch.float32, device=dev)   # [N][3][C] per sample | [3][C] total
         sums_off = n * 3 * c

@@ -142,3 +142,22 @@ def test_cross_replica_statistics_two_ranks_one_gpu():
     torch.testing.assert_close(torch.cat([out[0][1], out[1][1]]), xa.grad.cpu(), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(out[0][2] + out[1][2], bn.weight.grad.cpu(), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(out[0][3], bn.running_var.cpu(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_backward_reads_a_channel_slice_of_the_gradient_in_place(dtype):
+    """The gradient of a ``torch.cat`` arrives as a channel slice of a wider channels-last tensor: the backward kernels
+    read it with its own row stride (no dense copy) and give the same bits as for a dense gradient."""
+    from stp3_amd.layers import fused
+    x, res, sbias, oscale, gy, bn = _mk(64, 3, 20, 24, dtype, False, seed=3)
+    wide = torch.randn(3, 192, 20, 24, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
+    wide[:, 64:128] = gy
+    out = []
+    for g in (gy, wide[:, 64:128]):
+        xa = x.detach().clone().requires_grad_(True)
+        bn.zero_grad()
+        fused.bn_act(bn, xa, fused.ACT_SWISH).backward(g)
+        out.append((xa.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()))
+    assert not wide[:, 64:128].is_contiguous(memory_format=torch.channels_last)
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
