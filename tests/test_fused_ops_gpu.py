@@ -227,3 +227,56 @@ def test_se_mlp_kernels_match_the_torch_operator_mlp(monkeypatch, dtype):
         tol = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
         for a, b in zip(*results):
             torch.testing.assert_close(b, a, **tol)
+
+
+def _conv_bn_sync_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    from stp3_amd import ops, ops_fused
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)     # gloo moves CUDA tensors through the host
+    torch.cuda.set_device(0)
+    x, gy, conv, bn = _conv_bn_case()
+    sl = slice(2 * rank, 2 * rank + 2)
+    xa = x[sl].detach().clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ops_fused.conv_bn_act(xa, conv.weight, None, bn, ops.ACT_SWISH, None, ops.RES_NONE, 1, 1, 1)
+    y.backward(gy[sl].contiguous(memory_format=torch.channels_last))
+    out[rank] = (y.detach().float().cpu(), xa.grad.float().cpu(), conv.weight.grad.cpu(), bn.weight.grad.cpu(),
+                 bn.running_var.cpu())
+    dist.destroy_process_group()
+
+
+def _conv_bn_case():
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 64, 24, 20, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(4, 96, 24, 20, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    torch.manual_seed(3)
+    conv = nn.Conv2d(64, 96, 3, padding=1, bias=False).cuda()
+    bn = nn.BatchNorm2d(96).cuda()
+    return x, gy, conv, bn
+
+
+def test_fused_conv_bn_act_cross_replica_statistics_two_ranks_one_gpu():
+    """The fused conv -> BatchNorm operator with the statistics of its epilogue all-reduced over two ranks (half the
+    batch each, both on cuda:0) == one rank with the whole batch: outputs, input gradient, summed weight gradients,
+    running statistics (reference recipe: sync_batchnorm, /root/reference/train.py:47)."""
+    import socket
+    import torch.multiprocessing as mp
+    from stp3_amd import ops, ops_fused
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    mgr = ctx.Manager()
+    out = mgr.dict()
+    mp.spawn(_conv_bn_sync_worker, args=(2, port, out), nprocs=2, join=True)
+    x, gy, conv, bn = _conv_bn_case()
+    xa = x.detach().clone().requires_grad_(True)
+    y = ops_fused.conv_bn_act(xa, conv.weight, None, bn, ops.ACT_SWISH, None, ops.RES_NONE, 1, 1, 1)
+    y.backward(gy)
+    torch.testing.assert_close(torch.cat([out[0][0], out[1][0]]), y.detach().float().cpu(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(torch.cat([out[0][1], out[1][1]]), xa.grad.float().cpu(), rtol=2e-2, atol=2e-2)
+    wg = conv.weight.grad.cpu()
+    torch.testing.assert_close(out[0][2] + out[1][2], wg, rtol=2e-2, atol=2e-2 * float(wg.abs().max()))
+    torch.testing.assert_close(out[0][3] + out[1][3], bn.weight.grad.cpu(), rtol=2e-2, atol=5e-2)
+    torch.testing.assert_close(out[0][4], bn.running_var.cpu(), rtol=1e-3, atol=1e-4)
