@@ -33,6 +33,13 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
 rows = prof.key_averages(group_by_input_shape=True)
 rows = sorted(rows, key=lambda e: -e.self_device_time_total)
 top = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+if len(sys.argv) > 2 and sys.argv[2] == 'aten':          # only torch's own operators, by GPU time incl. children
+    rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith('aten::')]
+    rows = sorted(rows, key=lambda e: -e.device_time_total)
+    print(f'{"GPU ms/step":>12s} {"calls/step":>10s}  op  shapes')
+    for e in rows[:top]:
+        print(f'{e.device_time_total / 2e3:12.3f} {e.count / 2:10.1f}  {e.key[:28]:28s} {str(e.input_shapes)[:170]}')
+    sys.exit(0)
 print(f'{"self GPU ms/step":>16s} {"calls/step":>10s}  op  shapes')
 for e in rows[:top]:
     if e.self_device_time_total <= 0:

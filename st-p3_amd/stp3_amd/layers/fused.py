@@ -98,7 +98,7 @@ def bn_act(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=
     if not (x.is_cuda and x.dim() == 4 and x.shape[2] * x.shape[3] > 1):
         return bn_act_reference(bn, x, act, res, res_mode, sbias, oscale)
     if torch.is_autocast_enabled() and x.dtype == torch.float32:
-        x = x.to(torch.get_autocast_gpu_dtype())
+        x = x.to(torch.get_autocast_dtype('cuda'))
     training = bn.training or not bn.track_running_stats
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         ops.bump_batch_counter(bn)

@@ -109,16 +109,26 @@ class PyramidSpatioTemporalPooling(nn.Module):
                 ('conv_bn_relu', conv_1x1x1_norm_activated(in_channels, reduction_channels))])))
         self.features = nn.ModuleList(feats)
 
-    def forward(self, x, extra=None):
+    def forward(self, x, extra=None, folded=None):
         """``extra`` (B, E, T): channels that are constant over each frame's plane (the ego-motion planes of
-        stp3.py:145-152) -- their window mean is the value itself, so they join after the spatial mean."""
+        stp3.py:145-152) -- their window mean is the value itself, so they join after the spatial mean.
+        ``folded``: the same input as a frame-folded (B*T, C, H, W) tensor (what ``TemporalBlock`` holds anyway, in
+        channels-last memory): whole-plane means are taken from it -- a column reduction over contiguous rows instead
+        of a strided 7-D reduction, and its gradient joins the block's other input gradients in the same layout."""
         out = []
         for f, pool in zip(self.features, self.pool_sizes):
             _, ph, pw = pool
             b, c, t, h, w = x.shape
             if extra is not None:
                 assert h == ph and w == pw, 'constant planes are folded for whole-plane pooling only'
-            if h % ph == 0 and w % pw == 0:
+            if folded is not None and h == ph and w == pw:
+                sp = folded.mean(dim=(2, 3), dtype=torch.float32).view(b, t, c).permute(0, 2, 1)[..., None, None]
+                if extra is not None:
+                    sp = torch.cat([sp, extra.float().view(b, -1, t, 1, 1)], dim=1)
+                pooled = torch.cat([sp[:, :, :1], 0.5 * (sp[:, :, 1:] + sp[:, :, :-1]), sp[:, :, -1:]], dim=2)
+                cbr = f.conv_bn_relu
+                out.append(bn_act(cbr.norm, conv1x1_on_vector(pooled.to(x.dtype), cbr.conv.weight), ACT_RELU)[:, :, :-1])
+            elif h % ph == 0 and w % pw == 0:
                 # spatial mean over each pool window, then the causal 2-frame mean with
                 # count_include_pad=False (frame 0 averages only itself): identical to the padded
                 # AvgPool3d + [:, :, :-1] of the reference (temporal.py:396-413), as plain reductions
@@ -192,6 +202,10 @@ class TemporalBlock(nn.Module):
         x2 = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
         if x2.is_cuda:
             x2 = x2.contiguous(memory_format=torch.channels_last)
+            if torch.is_autocast_enabled() and x2.dtype == torch.float32:
+                # the float32 BEV feeds five consumers of this block: cast it ONCE (each convolution would otherwise
+                # cast its own copy, and the five float32 input gradients would be added up in float32)
+                x2 = x2.to(torch.get_autocast_dtype('cuda'))
         outs = []
         for path in self.convolution_paths[:-1]:
             y = self._pointwise(path[0], x2, extra2=extra2)
@@ -204,7 +218,7 @@ class TemporalBlock(nn.Module):
         sbias = None
         if self.use_pyramid_pooling:
             off = self._paths_channels
-            for pooled in self.pyramid_pooling(x, extra):                # (B, C', T, h', w')
+            for pooled in self.pyramid_pooling(x, extra, folded=x2):     # (B, C', T, h', w')
                 cp = pooled.shape[1]
                 p2 = pooled.permute(0, 2, 1, 3, 4).reshape(b * t, cp, *pooled.shape[-2:])
                 contrib = (conv1x1_on_vector(p2.to(y.dtype), wgt[:, off:off + cp].to(y.dtype))

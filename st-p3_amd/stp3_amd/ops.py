@@ -488,7 +488,7 @@ def depthwise_conv2d(x, weight, stride=1, pad=(0, 0, 0, 0)):
     """Depthwise conv (groups == channels) through the HIP kernels.  Under autocast the activations
     run in the autocast dtype (bf16); the weights are consumed in float32 either way."""
     if torch.is_autocast_enabled():
-        x = x.to(torch.get_autocast_gpu_dtype())
+        x = x.to(torch.get_autocast_dtype('cuda'))
     return _DW_APPLY(x, weight, int(stride), tuple(int(p) for p in pad))
 
 

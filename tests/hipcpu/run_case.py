@@ -462,6 +462,7 @@ def _model_step(ops, autocast, flags=None, bn_eval=False, full_losses=False):
     if autocast:
         torch.is_autocast_enabled = lambda *a: True
         torch.get_autocast_gpu_dtype = lambda: torch.bfloat16
+        torch.get_autocast_dtype = lambda *a: torch.bfloat16
     module.model.prepare_plan(intr, extr, ego, torch.device('cpu'))
     if autocast:
         with torch.autocast('cpu', dtype=torch.bfloat16):

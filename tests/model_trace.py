@@ -29,6 +29,7 @@ def patch_process(recorder, deterministic_fill=True):
     torch.Tensor.is_cuda = property(lambda self: True)
     torch.is_autocast_enabled = lambda *a: True
     torch.get_autocast_gpu_dtype = lambda: torch.bfloat16
+    torch.get_autocast_dtype = lambda *a: torch.bfloat16
 
     class _Stream:                               # the model overlaps the plan build on a side stream
         cuda_stream = 0
