@@ -13,7 +13,7 @@ Exact work reductions relative to a literal translation (no approximation):
 import torch
 import torch.nn as nn
 
-from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, conv1x1_on_vector, conv2d, conv_module, run_fused
+from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, conv1x1_on_vector, conv2d, conv_module, plane_mean, run_fused
 
 
 def _conv_bn_relu(in_ch, out_ch, k, padding=0, dilation=1):
@@ -31,7 +31,13 @@ class UpsamplingConcat(nn.Module):
                                   *_conv_bn_relu(out_channels, out_channels, 3, padding=1))
 
     def forward(self, x_to_upsample, x):
-        return run_fused(self.conv, torch.cat([x, self.upsample(x_to_upsample)], dim=1))
+        up = self.upsample(x_to_upsample)
+        if up.dtype != x.dtype and torch.is_autocast_enabled():
+            # autocast runs the bilinear interpolation in float32: round it to the skip's dtype before the concatenation
+            # (the convolution behind it does exactly that rounding anyway) instead of concatenating and casting a
+            # float32 tensor of 216 channels
+            up = up.to(x.dtype)
+        return run_fused(self.conv, torch.cat([x, up], dim=1))
 
 
 class UpsamplingAdd(nn.Module):
@@ -83,7 +89,9 @@ class ASPPPooling(nn.Sequential):
         """Returns the (N, C, 1, 1) pooled descriptor; bilinear upsampling of a 1x1 map is a
         broadcast, which ``ASPP`` folds into its projection."""
         pool, conv, bn, _ = self
-        return bn_act(bn, conv_module(conv, pool(x)), ACT_RELU)   # 1x1 map: GEMM + plain-torch BN (still cross-replica)
+        # the global average through fused.plane_mean: same value as AdaptiveAvgPool2d(1), gradient in the layout of x
+        pooled = plane_mean(x).to(x.dtype)[:, :, None, None] if x.is_cuda else pool(x)
+        return bn_act(bn, conv_module(conv, pooled), ACT_RELU)   # 1x1 map: GEMM + plain-torch BN (still cross-replica)
 
 
 class ASPP(nn.Module):

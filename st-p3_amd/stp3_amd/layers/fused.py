@@ -126,6 +126,29 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     return F.conv2d(x, weight, bias, stride, padding, dilation)
 
 
+class _PlaneMean(torch.autograd.Function):
+    """Mean over the plane of every (sample, channel) of an (N, C, H, W) tensor, float32 result (N, C).  torch's own
+    ``mean`` / ``AdaptiveAvgPool2d(1)`` give the same value, but their backward hands back the broadcast gradient in
+    NCHW-contiguous memory whatever the layout of x; for a channels-last x that puts every later addition of input
+    gradients on torch's strided element-wise kernel (3x slower).  Here the gradient is laid out like x."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.meta = (tuple(x.shape), x.dtype, x.is_contiguous(memory_format=torch.channels_last))
+        return x.mean(dim=(2, 3), dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (n, c, h, w), dtype, cl = ctx.meta
+        g = (g * (1.0 / (h * w))).to(dtype).view(n, c, 1, 1).expand(n, c, h, w)
+        return g.contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format)
+
+
+def plane_mean(x):
+    """(N, C, H, W) -> (N, C) float32 mean over H x W (see ``_PlaneMean``)."""
+    return _PlaneMean.apply(x)
+
+
 def conv1x1_on_vector(x, weight, bias=None):
     """A 1x1 convolution of a (N, C, 1, 1) map (or (N, C, T, 1, 1) with a 1x1x1 kernel) is a plain GEMM."""
     w2 = weight.flatten(1)

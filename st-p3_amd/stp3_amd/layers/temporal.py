@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, conv1x1_on_vector, conv2d
+from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, conv1x1_on_vector, conv2d, plane_mean
 
 
 def _pad8(c):
@@ -122,7 +122,7 @@ class PyramidSpatioTemporalPooling(nn.Module):
             if extra is not None:
                 assert h == ph and w == pw, 'constant planes are folded for whole-plane pooling only'
             if folded is not None and h == ph and w == pw:
-                sp = folded.mean(dim=(2, 3), dtype=torch.float32).view(b, t, c).permute(0, 2, 1)[..., None, None]
+                sp = plane_mean(folded).view(b, t, c).permute(0, 2, 1)[..., None, None]
                 if extra is not None:
                     sp = torch.cat([sp, extra.float().view(b, -1, t, 1, 1)], dim=1)
                 pooled = torch.cat([sp[:, :, :1], 0.5 * (sp[:, :, 1:] + sp[:, :, :-1]), sp[:, :, -1:]], dim=2)
