@@ -21,3 +21,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+
+
+@pytest.fixture(autouse=True)
+def restore_thread_count():
+    """Some tests pin torch's intra-op thread count; the oracle's bit-exact comparisons (float32 cumsum) depend on it,
+    so it is put back after every test."""
+    import torch
+    n = torch.get_num_threads()
+    yield
+    if torch.get_num_threads() != n:
+        torch.set_num_threads(n)
