@@ -267,6 +267,12 @@ typedef struct stp3_bn_dims {
     int32_t dtype;             /* STP3_DTYPE_*                                       */
     int32_t act, res_mode;     /* STP3_ACT_*, STP3_RES_*                             */
     int32_t has_sbias, has_oscale;
+    int32_t cpad;              /* 0, or the padded channel count of ZERO-PADDED ROWS: C <= cpad <= ldx, ldy (, ldr), cpad a
+                                  multiple of 8.  Lanes [C, cpad) of every row of x / res / dy are read as zero whatever
+                                  they hold, and the kernels write zeros there in y / dx / dres: a 35-channel layer
+                                  lives in 40-lane rows that the MFMA convolutions (Cin, Cout % 8 == 0) consume and
+                                  produce in place, and it runs on the 16-byte vector path.  The per-channel arrays
+                                  keep C entries.                                                                  */
 } stp3_bn_dims;
 
 int stp3_bn_workspace_bytes(const stp3_bn_dims* dims, size_t* bytes);
@@ -423,6 +429,39 @@ int stp3_optim_workspace_bytes(int64_t total_blocks, size_t* bytes);
 int stp3_optim_clip_adam(const stp3_optim_bucket* table, int32_t n_buckets, int64_t total_blocks, float max_norm,
                          float lr, float beta1, float beta2, float eps, float weight_decay, float* state,
                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Causal two-frame channel pairing of the frame-folded BEV sequence (csrc/stp3_temporal.hip): the operand of the
+ * (2,3,3) convolution of CausalConv3d, stp3/layers/temporal.py:252-273 (time padded on the left by one frame:
+ * y[t] = W[:, :, 0] * x[t-1] + W[:, :, 1] * x[t], x[-1] = 0), as ONE 2-D convolution over 2C channels.
+ *   x  [frames][rows][ldx >= C]  bf16 / float32, channels-last; frames = B*T, the T frames of a sample consecutive
+ *   y  [frames][rows][2C] : y[n][r][0:C] = x[n-1][r][0:C] (zero when n % T == 0) ; y[n][r][C:2C] = x[n][r][0:C]
+ *   bwd: dy [frames][rows][2C] -> dx [frames][rows][C] (dense),
+ *        dx[n][r][c] = dy[n][r][C + c] + (dy[n+1][r][c] unless n % T == T - 1)      (float32 add, rounded once)
+ * C and ldx multiples of 16 bytes (8 bf16 / 4 float32), 16-byte aligned pointers (STP3_EUNSUP otherwise). */
+typedef struct stp3_pair_dims {
+    int32_t frames, T, rows, C, ldx, dtype;
+} stp3_pair_dims;
+int stp3_causal_pair_fwd(const stp3_pair_dims* dims, const void* x, void* y, void* stream);
+int stp3_causal_pair_bwd(const stp3_pair_dims* dims, const void* dy, void* dx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Bilinear up-sampling by an integer factor, align_corners = False (csrc/stp3_upsample.hip): nn.Upsample(scale_factor=2,
+ * mode='bilinear') of UpsamplingConcat / UpsamplingAdd, stp3/layers/convolutions.py:183-215 (encoder merge and the three
+ * BEV decoder stages).
+ *   x  [N][H][W][ldx >= C]            bf16 / float32, channels-last (ldx: a channel slice is read in place)
+ *   y  [N][H*scale][W*scale][ldy >= C] same type (ldy: the result may be written into a slice of a concatenation)
+ *   y[oh][ow] = l0h * (l0w * x[h0][w0] + l1w * x[h0][w1]) + l1h * (l0w * x[h1][w0] + l1w * x[h1][w1]),
+ *       src = max((o + 0.5) / scale - 0.5, 0), i0 = floor(src), i1 = min(i0 + 1, size - 1), l1 = src - i0, l0 = 1 - l1
+ *       (float32 arithmetic in this order -- torch's -- then one rounding to the element type)
+ *   bwd: dy [N][H*scale][W*scale][ldy] -> dx [N][H][W][ldx]: every input pixel gathers the gradients of the outputs
+ *        that read it (float32 accumulation, deterministic, no atomics)
+ * scale 1..4; C, ldx, ldy multiples of 16 bytes; 16-byte aligned pointers; < 2^31 vectors (STP3_EUNSUP otherwise). */
+typedef struct stp3_upsample_dims {
+    int32_t N, H, W, C, scale, ldx, ldy, dtype;
+} stp3_upsample_dims;
+int stp3_upsample_bilinear_fwd(const stp3_upsample_dims* dims, const void* x, void* y, void* stream);
+int stp3_upsample_bilinear_bwd(const stp3_upsample_dims* dims, const void* dy, void* dx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stand-alone voxel summing (csrc/stp3_voxsum.hip): the operator-level twin of the reference's

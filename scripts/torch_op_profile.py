@@ -26,13 +26,24 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+STACKS = len(sys.argv) > 2 and sys.argv[2] == 'stacks'
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=STACKS) as prof:
     step()
     step()
     torch.cuda.synchronize()
 rows = prof.key_averages(group_by_input_shape=True)
 rows = sorted(rows, key=lambda e: -e.self_device_time_total)
 top = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+if STACKS:                    # torch's own operators with the repo frames that called them (forward only: the autograd
+    rows = [e for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=30)   # thread has no Python stack)
+            if e.key.startswith('aten::') and e.device_time_total / 2e3 > 0.03]
+    rows = sorted(rows, key=lambda e: -e.device_time_total)
+    for e in rows[:top]:
+        frames = [f for f in e.stack if 'stp3_amd' in f or 'bench.py' in f][:4]
+        print(f'{e.device_time_total / 2e3:8.3f} {e.count / 2:6.1f}  {e.key[:26]:26s} {str(e.input_shapes)[:90]}')
+        for f in frames:
+            print('            ', f[-110:])
+    sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == 'aten':          # only torch's own operators, by GPU time incl. children
     rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith('aten::')]
     rows = sorted(rows, key=lambda e: -e.device_time_total)

@@ -28,6 +28,7 @@ namespace {
 struct BnDims {
     int N, rows, C, ldx, ldy, ldr;
     int act, res_mode, has_sbias, has_oscale;
+    int CL;     // channel lanes per row that belong to the tensors: C, or stp3_bn_dims::cpad (zero-padded rows)
 };
 
 constexpr int kThreads = 256;
@@ -77,6 +78,7 @@ template <> struct Io<uint16_t, 1> {
 // RL a power of two so that the in-block reduction is a tree.
 struct Map {
     int CV, CVB, RL, cv, rl;
+    int nvalid;   // channels of this thread's vector that exist (< VEC only in the last vector of zero-padded rows)
     bool live;
 };
 // FULL (chosen for the largest maps, see plan()): every thread of the workgroup is a live row lane
@@ -84,7 +86,7 @@ struct Map {
 template <int VEC, bool FULL>
 __device__ __forceinline__ Map make_map(const BnDims& d) {
     Map m;
-    m.CV = (d.C + VEC - 1) / VEC;
+    m.CV = (d.CL + VEC - 1) / VEC;
     m.CVB = min(m.CV, kThreads);
     int rl = 1;
     if (FULL) {
@@ -97,7 +99,18 @@ __device__ __forceinline__ Map make_map(const BnDims& d) {
     m.rl = threadIdx.x / m.CVB;
     m.cv = blockIdx.z * m.CVB + cvb;
     m.live = m.rl < m.RL && m.cv < m.CV;
+    m.nvalid = min(max(d.C - m.cv * VEC, 0), VEC);
     return m;
+}
+// Padding lanes (channels >= C of rows padded to stp3_bn_dims::cpad) are READ AS ZERO whatever the memory holds, so
+// that what the kernels write there is exactly zero.  Thread-constant branch: free for every other vector.
+template <int VEC>
+__device__ __forceinline__ void mask_tail(const Map& m, float* f) {
+    if (m.nvalid < VEC) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            if (j >= m.nvalid) f[j] = 0.f;
+    }
 }
 
 // The row loops are instantiated per (activation, residual mode) INSIDE each kernel: with the two as run-time values
@@ -196,7 +209,10 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(BnDims d, const T* _
             float v[kUnroll][VEC];
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u)                       // kUnroll independent loads in flight
-                if (r + u * step < d.rows) Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
+                if (r + u * step < d.rows) {
+                    Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
+                    mask_tail<VEC>(m, v[u]);
+                }
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
                 if (r + u * step < d.rows) {
@@ -319,7 +335,11 @@ __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
             for (int u = 0; u < kUnroll; ++u) {
                 if (r + u * step < d.rows) {
                     Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
-                    if (RESM != STP3_RES_NONE) Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
+                    mask_tail<VEC>(m, v[u]);
+                    if (RESM != STP3_RES_NONE) {
+                        Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
+                        mask_tail<VEC>(m, rv[u]);
+                    }
                 }
             }
 #pragma unroll
@@ -384,7 +404,12 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
                     if (r + u * step < d.rows) {
                         Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
                         Io<T, VEC>::load(gs + (size_t)(r + u * step) * d.ldy, g[u]);
-                        if (PRE_RES) Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
+                        mask_tail<VEC>(m, v[u]);
+                        mask_tail<VEC>(m, g[u]);
+                        if (PRE_RES) {
+                            Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
+                            mask_tail<VEC>(m, rv[u]);
+                        }
                     }
                 }
 #pragma unroll
@@ -455,7 +480,12 @@ __global__ __launch_bounds__(kThreads) void bn_apply_bwd_kernel(
                 if (r + u * step < d.rows) {
                     Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
                     Io<T, VEC>::load(gs + (size_t)(r + u * step) * d.ldy, g[u]);
-                    if (PRE_RES) Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
+                    mask_tail<VEC>(m, v[u]);
+                    mask_tail<VEC>(m, g[u]);
+                    if (PRE_RES) {
+                        Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
+                        mask_tail<VEC>(m, rv[u]);
+                    }
                 }
             }
 #pragma unroll
@@ -506,19 +536,23 @@ inline int plan(const stp3_bn_dims* p, Launch* L, std::initializer_list<const vo
     if (p->res_mode < STP3_RES_NONE || p->res_mode > STP3_RES_AFTER_ACT) return STP3_EINVAL;
     if (p->res_mode != STP3_RES_NONE && p->ldr < p->C) return STP3_EINVAL;
     if ((int64_t)p->N * p->rows >= (1LL << 31)) return STP3_EUNSUP;
+    // zero-padded rows: lanes [C, cpad) belong to x / y / dy / dx / res (/ dres) too
+    const int CL = p->cpad ? p->cpad : p->C;
+    if (CL < p->C || p->ldx < CL || p->ldy < CL || (p->res_mode != STP3_RES_NONE && p->ldr < CL)) return STP3_EINVAL;
     L->bf16 = p->dtype == STP3_DTYPE_BF16;
     const int wide = L->bf16 ? 8 : 4;
-    bool vec_ok = p->C % wide == 0 && p->ldx % wide == 0 && p->ldy % wide == 0 &&
+    bool vec_ok = CL % wide == 0 && p->ldx % wide == 0 && p->ldy % wide == 0 &&
                   (p->res_mode == STP3_RES_NONE || p->ldr % wide == 0);
     for (const void* q : vec_ptrs) vec_ok = vec_ok && (q == nullptr || aligned16(q));
     L->vec = vec_ok ? wide : 1;
     BnDims& d = L->d;
     d.N = p->N; d.rows = p->rows; d.C = p->C; d.ldx = p->ldx; d.ldy = p->ldy; d.ldr = p->ldr;
     d.act = p->act; d.res_mode = p->res_mode; d.has_sbias = p->has_sbias; d.has_oscale = p->has_oscale;
+    d.CL = CL;
     // two workgroup geometries; the full-occupancy one pays off only on the largest maps (measured on the MI355X,
     // profiles/r02a_validate_switches.txt: 72 x 144 x 112 x 240 backward 1205 -> 771 us, smaller maps 0-40 % slower)
     L->full = (int64_t)p->N * p->rows * p->C >= (int64_t)200 * 1000 * 1000;
-    const int CV = (p->C + L->vec - 1) / L->vec;
+    const int CV = (CL + L->vec - 1) / L->vec;
     const int CVB = CV < kThreads ? CV : kThreads;
     int RL = 1;
     if (L->full) {

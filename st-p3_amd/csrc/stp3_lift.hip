@@ -1332,7 +1332,7 @@ __global__ __launch_bounds__(256, 3) void lift_bwd_column_kernel(Dims dm, const 
 // ==========================================================================================
 extern "C" {
 
-const char* stp3_version(void) { return "stp3hip 0.3 gfx950"; }
+const char* stp3_version(void) { return "stp3hip 0.4 gfx950"; }
 
 
 int stp3_voxel_index(const stp3_lift_dims* dims, const float* cam_m, const float* cam_t, const float* ego_r,

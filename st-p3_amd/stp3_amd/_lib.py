@@ -47,7 +47,7 @@ class DwConvDims(ctypes.Structure):
 class BnDims(ctypes.Structure):
     """struct stp3_bn_dims (include/stp3_hip.h)."""
     _fields_ = [(k, ctypes.c_int32) for k in ('N', 'rows', 'C', 'ldx', 'ldy', 'ldr', 'dtype', 'act', 'res_mode',
-                                              'has_sbias', 'has_oscale')]
+                                              'has_sbias', 'has_oscale', 'cpad')]
 
 
 class ConvDims(ctypes.Structure):
@@ -72,6 +72,16 @@ class WprepEntry(ctypes.Structure):
 class SeMlpDims(ctypes.Structure):
     """struct stp3_se_mlp_dims (include/stp3_hip.h)."""
     _fields_ = [('N', ctypes.c_int32), ('C', ctypes.c_int32), ('S', ctypes.c_int32), ('inv_rows', ctypes.c_float)]
+
+
+class PairDims(ctypes.Structure):
+    """struct stp3_pair_dims (include/stp3_hip.h)."""
+    _fields_ = [(k, ctypes.c_int32) for k in ('frames', 'T', 'rows', 'C', 'ldx', 'dtype')]
+
+
+class UpsampleDims(ctypes.Structure):
+    """struct stp3_upsample_dims (include/stp3_hip.h)."""
+    _fields_ = [(k, ctypes.c_int32) for k in ('N', 'H', 'W', 'C', 'scale', 'ldx', 'ldy', 'dtype')]
 
 
 class OptimBucket(ctypes.Structure):
@@ -135,6 +145,10 @@ SIGNATURES = {
     'stp3_optim_workspace_bytes': (c_int, [ctypes.c_int64, ctypes.POINTER(c_size_t)]),
     'stp3_optim_clip_adam': (c_int, [c_void_p, c_int32, ctypes.c_int64] + [c_float] * 6 + [c_void_p, c_void_p, c_size_t,
                                                                                           c_void_p]),
+    'stp3_causal_pair_fwd': (c_int, [ctypes.POINTER(PairDims), c_void_p, c_void_p, c_void_p]),
+    'stp3_causal_pair_bwd': (c_int, [ctypes.POINTER(PairDims), c_void_p, c_void_p, c_void_p]),
+    'stp3_upsample_bilinear_fwd': (c_int, [ctypes.POINTER(UpsampleDims), c_void_p, c_void_p, c_void_p]),
+    'stp3_upsample_bilinear_bwd': (c_int, [ctypes.POINTER(UpsampleDims), c_void_p, c_void_p, c_void_p]),
     'stp3_voxels_sum_fwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     'stp3_voxels_sum_bwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
 }

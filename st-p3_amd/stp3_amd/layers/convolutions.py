@@ -13,6 +13,7 @@ Exact work reductions relative to a literal translation (no approximation):
 import torch
 import torch.nn as nn
 
+from .. import ops
 from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, conv1x1_on_vector, conv2d, conv_module, plane_mean, run_fused
 
 
@@ -22,9 +23,18 @@ def _conv_bn_relu(in_ch, out_ch, k, padding=0, dilation=1):
 
 
 def _upsample(module, x, dtype):
-    """``module(x)`` for an ``nn.Upsample``, rounded to ``dtype``.  Under autocast torch runs the interpolation in
-    float32 (its bf16 kernels, the atomics of the backward in particular, measured 4.6 ms per step slower on the
-    MI355X); the float32 result is rounded once here instead of being concatenated / consumed as float32."""
+    """``module(x)`` for an ``nn.Upsample``, in ``dtype``.  Bilinear integer-factor up-sampling of GPU tensors runs on
+    the kernels of stp3_upsample.hip in the tensor's own type (float32 arithmetic in torch's order, one rounding).
+    Anything else takes torch's operator, which under autocast interpolates in float32 -- that result is rounded once
+    here instead of being concatenated / consumed as float32."""
+    scale = module.scale_factor
+    if isinstance(scale, (tuple, list)) and len(set(scale)) == 1:
+        scale = scale[0]
+    if (x.is_cuda and module.mode == 'bilinear' and not module.align_corners and module.size is None
+            and isinstance(scale, (int, float))):
+        xin = x.to(dtype) if x.dtype != dtype and torch.is_autocast_enabled() else x
+        if ops.upsample_bilinear_supported(xin, scale):
+            return ops.upsample_bilinear(xin, scale)
     y = module(x)
     return y.to(dtype) if y.dtype != dtype and torch.is_autocast_enabled() else y
 
@@ -53,7 +63,7 @@ class UpsamplingAdd(nn.Module):
 
     def forward(self, x, x_skip):
         up, conv, bn = self.upsample_layer
-        return bn_act(bn, conv_module(conv, up(x)), ACT_NONE, res=x_skip, res_mode=RES_AFTER_ACT)
+        return bn_act(bn, conv_module(conv, _upsample(up, x, x.dtype)), ACT_NONE, res=x_skip, res_mode=RES_AFTER_ACT)
 
 
 class ASPPConv(nn.Sequential):

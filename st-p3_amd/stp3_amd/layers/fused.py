@@ -43,6 +43,10 @@ def _act(act, y):
 
 def bn_act_reference(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=None):
     """Plain-torch statement of ``bn_act`` (any device, any rank count; differentiable)."""
+    c = bn.num_features
+    if x.shape[1] != c:                             # zero-padded channel lanes (see ``bn_act``)
+        y = bn_act_reference(bn, x[:, :c], act, None if res is None else res[:, :c], res_mode, sbias, oscale)
+        return F.pad(y, [0, 0] * (x.dim() - 2) + [0, x.shape[1] - c])
     shape = [1, -1] + [1] * (x.dim() - 2)
     lead = [x.shape[0], -1] + [1] * (x.dim() - 2)
     if sbias is not None:
@@ -92,7 +96,12 @@ def bn_act(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=
     """y = act(bn(x + sbias) [+ res if BEFORE_ACT]) * oscale [+ res if AFTER_ACT].
 
     ``bn``: the nn.BatchNorm2d / nn.BatchNorm3d / nn.SyncBatchNorm module (its forward is not called);
-    x (N, C, H, W); sbias (N, C) per-sample bias; oscale (N,) per-sample scale; res like x."""
+    x (N, C, H, W); sbias (N, C) per-sample bias; oscale (N,) per-sample scale; res like x.
+
+    Zero-padded channel lanes: x (and res) may carry ``pad8(bn.num_features)`` channels, the extra ones padding (the
+    output channels a convolution with zero-padded weights produced).  They are ignored on input and zero in the result,
+    which keeps the padded shape: a 35-channel layer then lives in 40-lane rows that the MFMA convolutions (channel
+    counts in multiples of 8) read and write in place, with no pad / slice copies between the operators."""
     if res is None:
         res_mode = RES_NONE
     if not (x.is_cuda and x.dim() == 4 and x.shape[2] * x.shape[3] > 1):
@@ -105,7 +114,8 @@ def bn_act(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=
     group = None if _sync_world(bn) > 1 else False
     return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                       bn.running_var if bn.track_running_stats else None, training, bn.momentum, bn.eps,
-                      act=act, res=res, res_mode=res_mode, sbias=sbias, oscale=oscale, group=group)
+                      act=act, res=res, res_mode=res_mode, sbias=sbias, oscale=oscale, group=group,
+                      channels=bn.num_features if x.shape[1] != bn.num_features else None)
 
 
 # Dense convolutions.  Every bf16 (autocast) convolution on the GPU -- forward, data gradient and weight gradient, all

@@ -14,11 +14,33 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, conv1x1_on_vector, conv2d, plane_mean
 
 
 def _pad8(c):
     return (c + 7) // 8 * 8
+
+
+# Zero-padded channel lanes.  The first TemporalBlock works on 35-channel tensors (half of 64 + 6); the MFMA convolutions
+# take channel counts in multiples of 8.  On the GPU those layers therefore live in 40-LANE rows from end to end: the
+# (small) weights get zero rows / columns, the convolutions produce exact zeros in lanes 35..39, the fused BatchNorm
+# (``fused.bn_act``: stp3_bn_dims.cpad) ignores them on input and writes zeros there, and nothing pads, slices or
+# copies an activation (1.2 ms per step of torch pad / slice_backward / contiguous copies before).
+def _pad_out(w, lanes):
+    """(Co, Ci, kh, kw) weight with its output channels zero-padded to ``lanes``."""
+    co = w.shape[0]
+    return w if co == lanes else F.pad(w, (0, 0, 0, 0, 0, 0, 0, lanes - co))
+
+
+def _pad_in(w, groups, lanes):
+    """(Co, groups * g, kh, kw) weight whose input channels are ``groups`` runs of g, each run zero-padded to ``lanes``
+    (the layout of a concatenation of ``groups`` lane-padded tensors)."""
+    co, ci, kh, kw = w.shape
+    g = ci // groups
+    if g == lanes:
+        return w
+    return F.pad(w.reshape(co, groups, g, kh, kw), (0, 0, 0, 0, 0, lanes - g)).reshape(co, groups * lanes, kh, kw)
 
 
 def _conv2d_padded_channels(x, weight, padding=0):
@@ -68,18 +90,26 @@ class CausalConv3d(nn.Module):
     def forward_folded(self, x2, batch, frames):
         """Same layer on the frame-folded tensor x2 (B*T, C, H, W).  A causal (2,3,3) convolution is
         y[t] = W[:, :, 0] * x[t-1] + W[:, :, 1] * x[t] with x[-1] = 0, i.e. ONE 2-D 3x3 convolution over
-        the channel concatenation [x[t-1], x[t]]; a (1,3,3) convolution is a per-frame 2-D 3x3."""
+        the channel pairing [x[t-1], x[t]] (one kernel pass: ``ops.causal_pair``); a (1,3,3) convolution is a per-frame
+        2-D 3x3.  x2 may carry zero-padded channel lanes (see ``_pad_out``); on the GPU the result does too."""
         w = self.conv.weight
         kt = w.shape[2]
         assert self.conv.bias is None and self.conv.dilation == (1, 1, 1) and kt in (1, 2)
+        lanes_in = x2.shape[1]
+        taps = [_pad_in(w[:, :, k], 1, lanes_in) for k in range(kt)]
         if kt == 2:
-            c, h, ww = x2.shape[1:]
-            x5 = x2.view(batch, frames, c, h, ww)
-            prev = torch.cat([torch.zeros_like(x5[:, :1]), x5[:, :-1]], dim=1).view(batch * frames, c, h, ww)
-            x2 = torch.cat([prev, x2], dim=1)
-            w2 = torch.cat([w[:, :, 0], w[:, :, 1]], dim=1)
+            if ops.causal_pair_supported(x2):
+                x2 = ops.causal_pair(x2, frames)
+            else:
+                c, h, ww = x2.shape[1:]
+                x5 = x2.view(batch, frames, c, h, ww)
+                prev = torch.cat([torch.zeros_like(x5[:, :1]), x5[:, :-1]], dim=1).view(batch * frames, c, h, ww)
+                x2 = torch.cat([prev, x2], dim=1)
+            w2 = torch.cat(taps, dim=1)
         else:
-            w2 = w[:, :, 0]
+            w2 = taps[0]
+        if x2.is_cuda:
+            w2 = _pad_out(w2, _pad8(w2.shape[0]))
         y = _conv2d_padded_channels(x2, w2, padding=self._hw_pad[1:])
         return _bn_act_2d(self.norm, y)
 
@@ -177,16 +207,18 @@ class TemporalBlock(nn.Module):
             self.projection = None
 
     @staticmethod
-    def _pointwise(seq, x2, relu=True, extra2=None):
+    def _pointwise(seq, x2, relu=True, extra2=None, lanes=None):
         """conv_1x1x1_norm_activated (or projection) on the frame-folded tensor: a 1x1 2-D convolution.
         ``extra2`` (B*T, E): input channels that are constant over the plane -- their part of the 1x1 convolution is
-        a per-frame bias, W[:, C:] @ extra, added inside the fused BatchNorm (exact; no concatenated tensor)."""
+        a per-frame bias, W[:, C:] @ extra, added inside the fused BatchNorm (exact; no concatenated tensor).
+        ``lanes``: output channel lanes (>= the layer's channels; the extra ones come out zero, see ``_pad_out``)."""
         conv, norm = seq[0], seq[1]
         wgt = conv.weight[:, :, 0]
-        if extra2 is None:
-            return _bn_act_2d(norm, _conv2d_padded_channels(x2, wgt), relu)
         c = x2.shape[1]
-        y = _conv2d_padded_channels(x2, wgt[:, :c])
+        w_x = wgt if extra2 is None else wgt[:, :c]
+        y = _conv2d_padded_channels(x2, w_x if lanes is None else _pad_out(w_x, lanes))
+        if extra2 is None:
+            return _bn_act_2d(norm, y, relu)
         sbias = extra2.float() @ wgt[:, c:, 0, 0].float().t()
         return _bn_act_2d(norm, y, relu, sbias=sbias)
 
@@ -206,15 +238,17 @@ class TemporalBlock(nn.Module):
                 # the float32 BEV feeds five consumers of this block: cast it ONCE (each convolution would otherwise
                 # cast its own copy, and the five float32 input gradients would be added up in float32)
                 x2 = x2.to(torch.get_autocast_dtype('cuda'))
+        # the half_channels-wide paths run in lanes of 8 channels on the GPU (see ``_pad_out``)
+        lanes = _pad8(self.half_channels) if x2.is_cuda else self.half_channels
         outs = []
         for path in self.convolution_paths[:-1]:
-            y = self._pointwise(path[0], x2, extra2=extra2)
+            y = self._pointwise(path[0], x2, extra2=extra2, lanes=lanes)
             outs.append(path[1].forward_folded(y, b, t))
-        outs.append(self._pointwise(self.convolution_paths[-1], x2, extra2=extra2))
+        outs.append(self._pointwise(self.convolution_paths[-1], x2, extra2=extra2, lanes=lanes))
         paths = torch.cat(outs, dim=1)
         agg = self.aggregation[0]
         wgt = agg.conv.weight[:, :, 0]                                   # (Cout, Cin_total, 1, 1)
-        y = _conv2d_padded_channels(paths, wgt[:, :self._paths_channels])
+        y = _conv2d_padded_channels(paths, _pad_in(wgt[:, :self._paths_channels], len(outs), lanes))
         sbias = None
         if self.use_pyramid_pooling:
             off = self._paths_channels

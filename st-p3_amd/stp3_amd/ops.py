@@ -587,7 +587,7 @@ class _BnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, res, sbias, oscale, running_mean, running_var, training, momentum, eps,
-                act, res_mode, group):
+                act, res_mode, group, channels=None):
         _need_gpu(x)
         if x.dtype == torch.bfloat16:
             dt = _lib.DTYPE_BF16
@@ -595,18 +595,26 @@ class _BnAct(torch.autograd.Function):
             dt = _lib.DTYPE_F32
         else:
             raise _lib.Stp3HipError(f'bn_act supports float32 / bfloat16, got {x.dtype}')
-        n, c, h, w = x.shape
+        n, cx, h, w = x.shape
+        c = cx if channels is None else int(channels)
+        # zero-padded rows (stp3_bn_dims.cpad): x carries cx = pad8(c) lanes per row, the last cx - c of them padding
+        # that reads as zero; y / dx get zeros there.  The MFMA convolutions on either side take the rows as they are.
+        cpad = 0
+        if cx != c:
+            if cx != (c + 7) // 8 * 8:
+                raise _lib.Stp3HipError(f'bn_act: {cx} channel lanes for {c} channels (want {(c + 7) // 8 * 8})')
+            cpad = cx
         dev = x.device
         x, ldx = _rows_view(x)
-        ldr = c
+        ldr = cx
         if res is not None:
             if res.shape != x.shape:
                 raise _lib.Stp3HipError('bn_act: residual shape mismatch')
             res, ldr = _rows_view(res if res.dtype == x.dtype else res.to(x.dtype))
         else:
             res_mode = RES_NONE
-        y = torch.empty((n, c, h, w), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
-        dims = _lib.BnDims(n, h * w, c, ldx, c, ldr, dt, act, res_mode, sbias is not None, oscale is not None)
+        y = torch.empty((n, cx, h, w), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+        dims = _lib.BnDims(n, h * w, c, ldx, cx, ldr, dt, act, res_mode, sbias is not None, oscale is not None, cpad)
         lib = _lib.lib()
         gamma, beta = _f32(weight), _f32(bias)
         sb, osc = _f32(sbias), _f32(oscale)
@@ -660,12 +668,13 @@ class _BnAct(torch.autograd.Function):
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
         dy, ldy = _rows_view(dy)
-        if ldy != c:
+        cx = x.shape[1]                                    # channel lanes per row (> c for zero-padded rows)
+        if ldy != cx:
             if ldy % 8 == 0 and dy.data_ptr() % 16 == 0:
                 # a channel slice of a wider channels-last tensor (the gradient of a torch.cat): read in place with its
                 # own row stride instead of being copied dense first
                 dims = _lib.BnDims(dims.N, dims.rows, dims.C, dims.ldx, ldy, dims.ldr, dims.dtype, dims.act,
-                                   dims.res_mode, dims.has_sbias, dims.has_oscale)
+                                   dims.res_mode, dims.has_sbias, dims.has_oscale, dims.cpad)
             else:
                 dy = dy.contiguous(memory_format=torch.channels_last)
         ws, ws_bytes = _bn_workspace(n, c, dev)
@@ -680,8 +689,8 @@ class _BnAct(torch.autograd.Function):
         dres = None
         bdims = dims
         if dims.res_mode == RES_BEFORE_ACT and ctx.needs_input_grad[3]:
-            dres = torch.empty((n, c) + tuple(x.shape[2:]), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
-        simple = ctx.training and ctx.world == 1 and (dres is None or dims.ldr == c)
+            dres = torch.empty((n, cx) + tuple(x.shape[2:]), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+        simple = ctx.training and ctx.world == 1 and (dres is None or dims.ldr == cx)
         if simple:
             check(lib.stp3_bn_bwd_train(ctypes.byref(dims), dy.data_ptr(), x.data_ptr(), _opt_ptr(sb), _opt_ptr(res),
                                         _opt_ptr(osc), mean_p, invstd_p, _opt_ptr(gamma), _opt_ptr(beta), ws.data_ptr(),
@@ -699,12 +708,12 @@ class _BnAct(torch.autograd.Function):
             if ctx.training and ctx.world > 1:
                 gsums = lsums.clone()
                 torch.distributed.all_reduce(gsums, group=ctx.group)
-            if dres is not None and dims.ldr != c:
+            if dres is not None and dims.ldr != cx:
                 # the reduce pass read `res` with its own stride; the apply pass writes dres densely and reads res
                 # with the same stride
                 res = res.contiguous(memory_format=torch.channels_last)
-                bdims = _lib.BnDims(dims.N, dims.rows, dims.C, dims.ldx, dims.ldy, c, dims.dtype, dims.act,
-                                    dims.res_mode, dims.has_sbias, dims.has_oscale)
+                bdims = _lib.BnDims(dims.N, dims.rows, dims.C, dims.ldx, dims.ldy, cx, dims.dtype, dims.act,
+                                    dims.res_mode, dims.has_sbias, dims.has_oscale, dims.cpad)
             check(lib.stp3_bn_apply_bwd(ctypes.byref(bdims), dy.data_ptr(), x.data_ptr(), _opt_ptr(sb), _opt_ptr(res),
                                         _opt_ptr(osc), mean_p, invstd_p, _opt_ptr(gamma), _opt_ptr(beta),
                                         gsums.data_ptr() if ctx.training else None, max(ctx.count, 1.0), dx.data_ptr(),
@@ -728,20 +737,111 @@ class _BnAct(torch.autograd.Function):
                 dsbias = g * invstd * (sample[:, 0] - rows * k[0] - sample[:, 2] * k[1])
             else:
                 dsbias = g * invstd * sample[:, 0]
-        return dx, dgamma, dbeta, dres, dsbias, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, dsbias, None, None, None, None, None, None, None, None, None, None
 
 
 _BN_APPLY = _fast_apply(_BnAct)
 
 
 def bn_act(x, weight, bias, running_mean, running_var, training, momentum, eps, act=ACT_NONE, res=None,
-           res_mode=RES_NONE, sbias=None, oscale=None, group=None):
+           res_mode=RES_NONE, sbias=None, oscale=None, group=None, channels=None):
     """Fused BatchNorm + activation (+ residual) through the HIP kernels (GPU tensors only).
-    ``group=False`` disables the cross-replica statistics even when torch.distributed is initialised."""
+    ``group=False`` disables the cross-replica statistics even when torch.distributed is initialised.
+    ``channels``: the BatchNorm's channel count when x (and res) carry rows zero-padded to a multiple of 8 lanes
+    (``x.shape[1] == pad8(channels)``); the result has the same padded shape with zeros in the extra lanes."""
     if res is None:
         res_mode = RES_NONE
     return _BN_APPLY(x, weight, bias, res, sbias, oscale, running_mean, running_var, bool(training),
-                        float(momentum if momentum is not None else 0.1), float(eps), int(act), int(res_mode), group)
+                        float(momentum if momentum is not None else 0.1), float(eps), int(act), int(res_mode), group,
+                        channels)
+
+
+class _UpsampleBilinear(torch.autograd.Function):
+    """Bilinear up-sampling by an integer factor, align_corners=False (stp3_upsample_bilinear_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        _need_gpu(x)
+        n, c, h, w = x.shape
+        x, ldx = _rows_view(x)
+        dt = _lib.DTYPE_BF16 if x.dtype == torch.bfloat16 else _lib.DTYPE_F32
+        y = torch.empty((n, c, h * scale, w * scale), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        dims = _lib.UpsampleDims(n, h, w, c, scale, ldx, c, dt)
+        check(_lib.lib().stp3_upsample_bilinear_fwd(ctypes.byref(dims), x.data_ptr(), y.data_ptr(), _stream_handle()),
+              'stp3_upsample_bilinear_fwd')
+        ctx.shape = (n, c, h, w, scale, dt)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w, scale, dt = ctx.shape
+        want = torch.bfloat16 if dt == _lib.DTYPE_BF16 else torch.float32
+        if dy.dtype != want:
+            dy = dy.to(want)
+        dy, ldy = _rows_view(dy)
+        if ldy % (8 if dt == _lib.DTYPE_BF16 else 4) != 0 or dy.data_ptr() % 16 != 0:
+            dy, ldy = dy.contiguous(memory_format=torch.channels_last), c
+        dx = torch.empty((n, c, h, w), dtype=want, device=dy.device, memory_format=torch.channels_last)
+        dims = _lib.UpsampleDims(n, h, w, c, scale, c, ldy, dt)
+        check(_lib.lib().stp3_upsample_bilinear_bwd(ctypes.byref(dims), dy.data_ptr(), dx.data_ptr(), _stream_handle()),
+              'stp3_upsample_bilinear_bwd')
+        return dx, None
+
+
+def upsample_bilinear_supported(x, scale):
+    """stp3_upsample_bilinear_fwd: GPU bf16 / float32 (N, C, H, W), C in whole 16-byte vectors, integer scale 1..4."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32)):
+        return False
+    per = 8 if x.dtype == torch.bfloat16 else 4
+    return float(scale) == int(scale) and 1 <= int(scale) <= 4 and x.shape[1] % per == 0
+
+
+def upsample_bilinear(x, scale):
+    """F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=False) for channels-last GPU tensors, in the
+    tensor's own dtype (float32 arithmetic, one rounding); a channel slice of a concatenation's gradient is read in
+    place by the backward."""
+    return _UpsampleBilinear.apply(x, int(scale))
+
+
+class _CausalPair(torch.autograd.Function):
+    """[x[t-1], x[t]] channel pairing of the frame-folded sequence (stp3_causal_pair_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, frames_per_sample):
+        _need_gpu(x)
+        n, c, h, w = x.shape
+        x, ldx = _rows_view(x)
+        dt = _lib.DTYPE_BF16 if x.dtype == torch.bfloat16 else _lib.DTYPE_F32
+        dims = _lib.PairDims(n, int(frames_per_sample), h * w, c, ldx, dt)
+        y = torch.empty((n, 2 * c, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        check(_lib.lib().stp3_causal_pair_fwd(ctypes.byref(dims), x.data_ptr(), y.data_ptr(), _stream_handle()),
+              'stp3_causal_pair_fwd')
+        ctx.dims = dims
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        d = ctx.dims
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        n, c2, h, w = dy.shape
+        dx = torch.empty((n, c2 // 2, h, w), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+        dims = _lib.PairDims(d.frames, d.T, d.rows, d.C, d.C,
+                             _lib.DTYPE_BF16 if dy.dtype == torch.bfloat16 else _lib.DTYPE_F32)
+        check(_lib.lib().stp3_causal_pair_bwd(ctypes.byref(dims), dy.data_ptr(), dx.data_ptr(), _stream_handle()),
+              'stp3_causal_pair_bwd')
+        return dx, None
+
+
+def causal_pair_supported(x):
+    """stp3_causal_pair_fwd takes GPU bf16 / float32 (N, C, H, W) tensors whose C channels fill 16-byte vectors."""
+    per = 8 if x.dtype == torch.bfloat16 else 4
+    return x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32) and x.shape[1] % per == 0
+
+
+def causal_pair(x, frames_per_sample):
+    """x (B*T, C, H, W), the T frames of a sample consecutive -> (B*T, 2C, H, W) = [previous frame (zero for the first
+    of each sample), this frame] along the channels: the operand of the causal (2,3,3) convolution."""
+    return _CausalPair.apply(x, frames_per_sample)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -318,6 +318,117 @@ def bn_act(ops):
     return out
 
 
+def bn_act_padded(ops):
+    """35-channel BatchNorm layers in 40-lane rows (stp3_bn_dims.cpad): the padding lanes of every input hold NaN, the
+    results must equal the float32 torch statement on the 35 real channels and be EXACTLY zero in the padding lanes."""
+    from stp3_amd.layers import fused
+    out = {}
+    torch.manual_seed(11)
+    n, c, cp, h, w = 3, 35, 40, 6, 7
+    for training in (True, False):
+        for dtype, tag in ((torch.float32, 'f32'), (torch.bfloat16, 'bf16')):
+            worst, pad_clean = 0.0, True
+            for act, res_mode, with_sbias in [(ops.ACT_RELU, ops.RES_NONE, True), (ops.ACT_SWISH, ops.RES_BEFORE_ACT, False),
+                                              (ops.ACT_RELU, ops.RES_AFTER_ACT, False)]:
+                bn_a, bn_b = torch.nn.BatchNorm2d(c, eps=1e-3), torch.nn.BatchNorm2d(c, eps=1e-3)
+                with torch.no_grad():
+                    bn_a.weight.uniform_(0.5, 1.5); bn_a.bias.normal_(0, 0.2)
+                    bn_a.running_mean.normal_(0, 0.2); bn_a.running_var.uniform_(0.5, 1.5)
+                bn_b.load_state_dict(bn_a.state_dict())
+                bn_a.train(training); bn_b.train(training)
+
+                def padded(t):
+                    full = torch.full((n, cp, h, w), float('nan'), dtype=dtype).contiguous(memory_format=torch.channels_last)
+                    full[:, :c] = t
+                    return full
+                x0 = torch.randn(n, c, h, w).to(dtype)
+                r0 = torch.randn(n, c, h, w).to(dtype) if res_mode else None
+                gy = torch.randn(n, c, h, w).to(dtype)
+                sb0 = torch.randn(n, c) * 0.3 if with_sbias else None
+                xk = padded(x0).requires_grad_()
+                rk = padded(r0).requires_grad_() if r0 is not None else None
+                sbk = sb0.clone().requires_grad_() if sb0 is not None else None
+                yk = fused.bn_act(bn_a, xk, act, rk, res_mode, sbk)
+                yk.backward(padded(gy))
+                xr = x0.float().requires_grad_()
+                rr = r0.float().requires_grad_() if r0 is not None else None
+                sbr = sb0.clone().requires_grad_() if sb0 is not None else None
+                yr = fused.bn_act_reference(bn_b, xr, act, rr, res_mode, sbr)
+                yr.backward(gy.float())
+                got = [yk.detach()[:, :c].float(), xk.grad[:, :c].float(), bn_a.weight.grad, bn_a.bias.grad,
+                       bn_a.running_mean, bn_a.running_var]
+                want = [yr.detach(), xr.grad, bn_b.weight.grad, bn_b.bias.grad, bn_b.running_mean, bn_b.running_var]
+                if rr is not None:
+                    got.append(rk.grad[:, :c].float()); want.append(rr.grad)
+                if sbr is not None:
+                    got.append(sbk.grad); want.append(sbr.grad)
+                worst = max([worst] + [rel(a, b) for a, b in zip(got, want)])
+                pads = [yk.detach()[:, c:], xk.grad[:, c:]]
+                if rk is not None and res_mode == ops.RES_BEFORE_ACT:
+                    pads.append(rk.grad[:, c:])
+                pad_clean = pad_clean and all(bool((t == 0).all()) for t in pads) and tuple(yk.shape) == (n, cp, h, w)
+            out[f'{"train" if training else "eval"}_{tag}'] = worst
+            out[f'{"train" if training else "eval"}_{tag}_pad_zero'] = pad_clean
+    return out
+
+
+def causal_pair(ops):
+    """stp3_causal_pair_fwd / _bwd against the torch construction (zero frame, two concatenations) -- copies and one
+    two-term addition: bit-exact."""
+    out = {}
+    torch.manual_seed(12)
+    b, t, h, w = 2, 3, 5, 6
+    for dtype, c, tag in ((torch.bfloat16, 40, 'bf16'), (torch.float32, 12, 'f32'), (torch.bfloat16, 8, 'bf16_c8')):
+        x0 = torch.randn(b * t, c, h, w).to(dtype).contiguous(memory_format=torch.channels_last)
+        gy = torch.randn(b * t, 2 * c, h, w).to(dtype).contiguous(memory_format=torch.channels_last)
+        xk = x0.clone().requires_grad_()
+        yk = ops.causal_pair(xk, t)
+        yk.backward(gy)
+        xr = x0.clone().requires_grad_()
+        x5 = xr.view(b, t, c, h, w)
+        prev = torch.cat([torch.zeros_like(x5[:, :1]), x5[:, :-1]], dim=1).view(b * t, c, h, w)
+        yr = torch.cat([prev, xr], dim=1)
+        yr.backward(gy)
+        out[tag] = bool(torch.equal(yk.detach(), yr.detach()) and torch.equal(xk.grad, xr.grad))
+    xs = torch.randn(b * t, 24, h, w).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)[:, :16]
+    out['strided'] = bool(torch.equal(ops.causal_pair(xs, t)[:, 16:], xs))     # a channel slice read in place (ldx = 24)
+    return out
+
+
+def upsample(ops):
+    """stp3_upsample_bilinear_fwd / _bwd against F.interpolate (float32) and its autograd."""
+    import torch.nn.functional as F
+    out = {}
+    torch.manual_seed(13)
+    for tag, dtype, c, h, w, scale in (('f32_x2', torch.float32, 8, 5, 7, 2), ('bf16_x2', torch.bfloat16, 16, 6, 5, 2),
+                                       ('bf16_x3', torch.bfloat16, 8, 4, 3, 3), ('f32_x4', torch.float32, 4, 3, 1, 4),
+                                       ('bf16_1x1', torch.bfloat16, 8, 1, 1, 2)):
+        x0 = torch.randn(2, c, h, w).to(dtype).contiguous(memory_format=torch.channels_last)
+        gy = torch.randn(2, c, h * scale, w * scale).to(dtype).contiguous(memory_format=torch.channels_last)
+        xk = x0.clone().requires_grad_()
+        yk = ops.upsample_bilinear(xk, scale)
+        yk.backward(gy)
+        xr = x0.float().requires_grad_()
+        yr = F.interpolate(xr, scale_factor=scale, mode='bilinear', align_corners=False)
+        yr.backward(gy.float())
+        out[tag] = {'y': rel(yk.detach().float(), yr.detach().to(dtype).float()),
+                    'dx': rel(xk.grad.float(), xr.grad.to(dtype).float()),
+                    'shape': list(yk.shape) == list(yr.shape) and yk.dtype == dtype}
+    # channel slices: x read with its own row stride, the gradient of a concatenation read in place
+    wide = torch.randn(2, 24, 4, 5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xs = wide[:, 8:24].detach().requires_grad_()
+    skip = torch.randn(2, 8, 8, 10).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    cat = torch.cat([skip, ops.upsample_bilinear(xs, 2)], dim=1)
+    g = torch.randn_like(cat)
+    cat.backward(g)
+    xr = wide[:, 8:24].float().requires_grad_()
+    F.interpolate(xr, scale_factor=2, mode='bilinear', align_corners=False).backward(g[:, 8:].float())
+    out['sliced'] = {'y': rel(cat[:, 8:].detach().float(), F.interpolate(xr.detach(), scale_factor=2, mode='bilinear',
+                                                                         align_corners=False).to(torch.bfloat16).float()),
+                     'dx': rel(xs.grad.float(), xr.grad.to(torch.bfloat16).float()), 'shape': True}
+    return out
+
+
 def conv(ops):
     import torch.nn.functional as F
     out = {}
@@ -683,7 +794,7 @@ def fuzz(ops, seed=1):
     return {'problems': [[t, str(c), n, str(e)] for t, c, n, e in bad]}
 
 
-CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_frames, lift_coarse_grid, lift_tall, voxsum, wprep, optim, se_block, bn_act,
+CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_frames, lift_coarse_grid, lift_tall, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
                                  conv, dwconv)}
 
 if __name__ == '__main__':

@@ -51,7 +51,8 @@ def test_bench_main_dry_run(tmp_path, workload):
     trace = open(tmp_path / 'trace.log').read()
     for entry in ('stp3_lift_plan_build', 'stp3_lift_splat_fwd', 'stp3_lift_splat_bwd',
                   'stp3_conv2d_fwd', 'stp3_conv2d_wgrad', 'stp3_conv2d_prep_weights', 'stp3_bn_fwd_train',
-                  'stp3_dwconv2d_fwd', 'stp3_se_pool', 'stp3_se_mlp_fwd', 'stp3_optim_clip_adam'):
+                  'stp3_dwconv2d_fwd', 'stp3_se_pool', 'stp3_se_mlp_fwd', 'stp3_optim_clip_adam',
+                  'stp3_causal_pair_fwd', 'stp3_causal_pair_bwd', 'stp3_upsample_bilinear_fwd', 'stp3_upsample_bilinear_bwd'):
         assert entry + ' ' in trace, entry
 
 

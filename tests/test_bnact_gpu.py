@@ -161,3 +161,115 @@ def test_backward_reads_a_channel_slice_of_the_gradient_in_place(dtype):
     assert not wide[:, 64:128].is_contiguous(memory_format=torch.channels_last)
     for a, b in zip(*out):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('train', [True, False])
+@pytest.mark.parametrize('mode', ['relu', 'swish_before', 'relu_after_sbias'])
+def test_zero_padded_channel_lanes(mode, train, dtype):
+    """stp3_bn_dims.cpad: a 35-channel layer in 40-lane rows.  The padding lanes of x / res / dy hold NaN; the real
+    channels must match the float32 torch statement and the padding lanes of y / dx (/ dres) must be exactly zero."""
+    from stp3_amd.layers import fused
+    n, c, cp, h, w = 6, 35, 40, 50, 40
+    act, res_mode, use_sb = {'relu': (fused.ACT_RELU, fused.RES_NONE, False),
+                             'swish_before': (fused.ACT_SWISH, fused.RES_BEFORE_ACT, False),
+                             'relu_after_sbias': (fused.ACT_RELU, fused.RES_AFTER_ACT, True)}[mode]
+    x, res, sbias, _, gy, bn = _mk(c, n, h, w, dtype, False, seed=77)
+    ref_bn = nn.BatchNorm2d(c, momentum=0.05, eps=1e-3).cuda()
+    ref_bn.load_state_dict(bn.state_dict())
+    bn.train(train)
+    ref_bn.train(train)
+
+    def padded(t):
+        full = torch.full((n, cp, h, w), float('nan'), dtype=dtype, device='cuda').contiguous(memory_format=torch.channels_last)
+        full[:, :c] = t
+        return full
+    xk = padded(x).requires_grad_()
+    rk = padded(res).requires_grad_() if res_mode != fused.RES_NONE else None
+    sbk = sbias.clone().requires_grad_() if use_sb else None
+    y = fused.bn_act(bn, xk, act, rk, res_mode, sbk)
+    y.backward(padded(gy))
+    xr = x.float().requires_grad_()
+    rr = res.float().requires_grad_() if rk is not None else None
+    sbr = sbias.clone().requires_grad_() if use_sb else None
+    yr = fused.bn_act_reference(ref_bn, xr, act, rr, res_mode, sbr)
+    yr.backward(gy.float())
+    assert y.shape == (n, cp, h, w) and y.is_contiguous(memory_format=torch.channels_last)
+    assert bool((y.detach()[:, c:] == 0).all()) and bool((xk.grad[:, c:] == 0).all())
+    if res_mode == fused.RES_BEFORE_ACT:
+        assert bool((rk.grad[:, c:] == 0).all())
+    tol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    ptol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(y.detach()[:, :c].float(), yr.detach().to(dtype).float(), **tol)
+    torch.testing.assert_close(xk.grad[:, :c].float(), xr.grad.to(dtype).float(), **tol)
+    if rr is not None:
+        torch.testing.assert_close(rk.grad[:, :c].float(), rr.grad.to(dtype).float(), **tol)
+    if use_sb:
+        torch.testing.assert_close(sbk.grad, sbr.grad, rtol=ptol['rtol'], atol=ptol['atol'] * h * w ** 0.5)
+    scale = float(n * h * w) ** 0.5
+    torch.testing.assert_close(bn.weight.grad, ref_bn.weight.grad, rtol=ptol['rtol'], atol=ptol['atol'] * scale)
+    torch.testing.assert_close(bn.bias.grad, ref_bn.bias.grad, rtol=ptol['rtol'], atol=ptol['atol'] * scale)
+    torch.testing.assert_close(bn.running_mean, ref_bn.running_mean, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(bn.running_var, ref_bn.running_var, rtol=1e-3 if dtype == torch.float32 else 2e-2, atol=1e-4)
+
+
+@pytest.mark.parametrize('dtype,c', [(torch.bfloat16, 40), (torch.bfloat16, 32), (torch.float32, 12)])
+def test_causal_pair_is_bit_exact(dtype, c):
+    """stp3_causal_pair_fwd / _bwd (the operand of the causal (2,3,3) convolution) against the torch construction:
+    zero frame + two concatenations, and autograd's slice gradient + accumulation."""
+    from stp3_amd import ops
+    b, t, h, w = 4, 3, 50, 40
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(b * t, c, h, w, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(b * t, 2 * c, h, w, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    xk = x0.clone().requires_grad_()
+    yk = ops.causal_pair(xk, t)
+    yk.backward(gy)
+    xr = x0.clone().requires_grad_()
+    x5 = xr.view(b, t, c, h, w)
+    prev = torch.cat([torch.zeros_like(x5[:, :1]), x5[:, :-1]], dim=1).view(b * t, c, h, w)
+    yr = torch.cat([prev, xr], dim=1)
+    yr.backward(gy)
+    assert torch.equal(yk.detach(), yr.detach()) and torch.equal(xk.grad, xr.grad)
+    wide = torch.randn(b * t, c + 8, h, w, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    assert torch.equal(ops.causal_pair(wide[:, :c], t)[:, c:], wide[:, :c])      # channel slice read in place
+
+
+@pytest.mark.parametrize('case', [(torch.bfloat16, 12, 64, 100, 100, 2), (torch.bfloat16, 72, 160, 14, 30, 2),
+                                  (torch.float32, 3, 12, 25, 25, 2), (torch.bfloat16, 2, 8, 7, 5, 3),
+                                  (torch.float32, 2, 4, 1, 6, 4)])
+def test_bilinear_upsampling_matches_torch(case):
+    """stp3_upsample_bilinear_fwd / _bwd against F.interpolate(mode='bilinear', align_corners=False) in float32 and its
+    autograd (float32: 1e-6 relative; bf16: the float32 result rounded once, up to one bf16 ulp)."""
+    import torch.nn.functional as F
+    from stp3_amd import ops
+    dtype, n, c, h, w, scale = case
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(n, c, h, w, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, c, h * scale, w * scale, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    xk = x0.clone().requires_grad_()
+    yk = ops.upsample_bilinear(xk, scale)
+    yk.backward(gy)
+    xr = x0.float().requires_grad_()
+    yr = F.interpolate(xr, scale_factor=scale, mode='bilinear', align_corners=False)
+    yr.backward(gy.float())
+    assert yk.shape == yr.shape and yk.dtype == dtype and yk.is_contiguous(memory_format=torch.channels_last)
+    tol = dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=8e-3, atol=1e-3)
+    torch.testing.assert_close(yk.detach().float(), yr.detach().to(dtype).float(), **tol)
+    gtol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=8e-3, atol=8e-3)
+    torch.testing.assert_close(xk.grad.float(), xr.grad.to(dtype).float(), **gtol)
+
+
+def test_upsampling_reads_a_concatenation_gradient_in_place():
+    import torch.nn.functional as F
+    from stp3_amd import ops
+    g = torch.Generator().manual_seed(10)
+    x0 = torch.randn(4, 16, 14, 30, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    skip = torch.randn(4, 8, 28, 60, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xk = x0.clone().requires_grad_()
+    cat = torch.cat([skip, ops.upsample_bilinear(xk, 2)], dim=1)
+    gc = torch.randn(cat.shape, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    cat.backward(gc)
+    xr = x0.float().requires_grad_()
+    F.interpolate(xr, scale_factor=2, mode='bilinear', align_corners=False).backward(gc[:, 8:].float())
+    torch.testing.assert_close(xk.grad.float(), xr.grad.to(torch.bfloat16).float(), rtol=8e-3, atol=8e-3)

@@ -27,7 +27,7 @@ sys.path.insert(0, HIPCPU)
 import build as hipcpu_build  # noqa: E402
 
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
-ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}),
+ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
            ('conv', {}), ('conv_bn', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
            ('lift_c64_frames', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
 ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'lift_c16']
@@ -104,6 +104,27 @@ def test_batchnorm_kernels(results):
     r = _get(results, 'bn_act')
     assert r['train_f32'] <= 1e-4 and r['eval_f32'] <= 1e-4            # tests/test_bnact_gpu.py: float32 rtol 1e-4
     assert r['train_bf16'] <= 2e-2 and r['eval_bf16'] <= 2e-2          # bf16 rtol 2e-2
+
+
+def test_batchnorm_in_zero_padded_channel_lanes(results):
+    """stp3_bn_dims.cpad: 35 channels in 40-lane rows, NaN in the padding lanes of every input."""
+    r = _get(results, 'bn_act_padded')
+    assert r['train_f32'] <= 1e-4 and r['eval_f32'] <= 1e-4
+    assert r['train_bf16'] <= 2e-2 and r['eval_bf16'] <= 2e-2
+    assert all(r[f'{m}_{t}_pad_zero'] for m in ('train', 'eval') for t in ('f32', 'bf16'))
+
+
+def test_causal_pair_kernels_are_bit_exact(results):
+    r = _get(results, 'causal_pair')
+    assert r['bf16'] and r['f32'] and r['bf16_c8'] and r['strided']
+
+
+def test_bilinear_upsampling_kernels(results):
+    for name, r in _get(results, 'upsample').items():
+        if name == 'seconds':
+            continue
+        tol = 1e-6 if name.startswith('f32') else 8e-3          # bf16: a rare one-ulp difference after the rounding
+        assert r['shape'] and r['y'] <= tol and r['dx'] <= tol, (name, r)
 
 
 def test_fused_conv_batchnorm_operator(results):
@@ -203,7 +224,7 @@ def test_no_out_of_bounds_access_under_address_sanitizer(tmp_path):
                              capture_output=True, text=True, timeout=3000)
         return case, extra, out
 
-    jobs = [(c, {}) for c in ('voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'lift_c16',
+    jobs = [(c, {}) for c in ('voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'bn_act_padded', 'causal_pair', 'upsample', 'conv', 'conv_bn', 'lift_c16',
                               'lift_c16_rows32', 'lift_c64_many_runs', 'lift_c64_frames', 'lift_coarse_grid', 'lift_small', 'lift_tall')]
     with ThreadPoolExecutor(max_workers=4) as pool:
         done = list(pool.map(lambda j: run(*j), jobs))
