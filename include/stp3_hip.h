@@ -247,7 +247,8 @@ int stp3_dwconv2d_bwd_weight(const stp3_dwconv_dims* dims, const void* x, const 
  *   stp3_bn_bwd_reduce: sample_sums [N][3][C] and sums [3][C] = sums of g, g * xhat and xhat, where
  *                       g = dy * oscale * act'(.) is the gradient at the BatchNorm output
  *                       (dbeta = sums[0], dgamma = sums[1]; the per-sample sums give the sbias gradient
- *                        gamma*invstd*(Sg_n - rows*sums[0]/count - Sxhat_n*sums[1]/count))
+ *                        gamma*invstd*(Sg_n - rows*sums[0]/count - Sxhat_n*sums[1]/count));
+ *                       sample_sums is written only when has_sbias is set -- its one consumer)
  *   stp3_bn_apply_bwd : dx = gamma * invstd * (g - sums[0]/count - xhat * sums[1]/count)
  *                       (sums == NULL: inference-mode BatchNorm, dx = gamma * invstd * g);
  *                       dres (BEFORE_ACT only, may be NULL) = g.  For AFTER_ACT dres is dy itself.

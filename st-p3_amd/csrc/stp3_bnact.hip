@@ -230,20 +230,31 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(BnDims d, const T* _
 }
 
 // ---- sums over partial rows: out[g][i] = sum_p partial[(g * parts + p) * width + i], in double ------
+// 8 columns x 32 part lanes per workgroup, four independent loads in flight per thread: these launches sit between
+// every statistics / reduce pass and its apply pass (~300 per training step), so their latency is on the critical path
+constexpr int kRedCols = 8, kRedLanes = kThreads / kRedCols;
 __global__ __launch_bounds__(kThreads) void bn_reduce_partials_kernel(int parts, int width,
                                                                       const float* __restrict__ partial,
                                                                       float* __restrict__ out) {
     __shared__ double red[kThreads];
-    const int il = threadIdx.x % 16, pl = threadIdx.x / 16;          // 16 columns x 16 part lanes
-    const int i = blockIdx.x * 16 + il;
+    const int il = threadIdx.x % kRedCols, pl = threadIdx.x / kRedCols;
+    const int i = blockIdx.x * kRedCols + il;
     const int g = blockIdx.y;
-    double s = 0.0;
-    if (i < width)
-        for (int p = pl; p < parts; p += 16) s += (double)partial[((size_t)g * parts + p) * width + i];
-    red[threadIdx.x] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (i < width) {
+        const float* src = partial + (size_t)g * parts * width + i;
+        int p = pl;
+        for (; p + 3 * kRedLanes < parts; p += 4 * kRedLanes) {
+            const float a = src[(size_t)p * width], b = src[(size_t)(p + kRedLanes) * width];
+            const float c = src[(size_t)(p + 2 * kRedLanes) * width], d = src[(size_t)(p + 3 * kRedLanes) * width];
+            s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
+        }
+        for (; p < parts; p += kRedLanes) s0 += (double)src[(size_t)p * width];
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    for (int st = 8; st > 0; st >>= 1) {
-        if (pl < st) red[threadIdx.x] += red[threadIdx.x + st * 16];
+    for (int st = kRedLanes / 2; st > 0; st >>= 1) {
+        if (pl < st) red[threadIdx.x] += red[threadIdx.x + st * kRedCols];
         __syncthreads();
     }
     if (pl == 0 && i < width) out[(size_t)g * width + i] = (float)red[il];
@@ -597,8 +608,8 @@ inline size_t ws_bytes(const stp3_bn_dims* p) {
 
 // partial [groups][parts][width] -> out [groups][width]
 inline void reduce_partials(int groups, int parts, int width, const float* partial, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3((width + 15) / 16, groups), dim3(kThreads), 0, s, parts, width,
-                       partial, out);
+    hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3((width + kRedCols - 1) / kRedCols, groups), dim3(kThreads), 0, s,
+                       parts, width, partial, out);
 }
 
 }  // namespace
@@ -671,8 +682,13 @@ int stp3_bn_bwd_reduce(const stp3_bn_dims* p, const void* dy, const void* x, con
     float* partial = (float*)workspace;
     BN_SWITCH(L, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, FULL>), L.grid, dim3(kThreads), 0, s, L.d, (const T*)dy,
                                      (const T*)x, sbias, (const T*)res, oscale, mean, invstd, gamma, beta, partial));
-    reduce_partials(p->N, (int)L.grid.x, 3 * p->C, partial, sample_sums, s);     // [N][3][C]
-    reduce_partials(1, p->N, 3 * p->C, sample_sums, sums, s);                     // [3][C]
+    if (p->has_sbias) {
+        reduce_partials(p->N, (int)L.grid.x, 3 * p->C, partial, sample_sums, s);     // [N][3][C]
+        reduce_partials(1, p->N, 3 * p->C, sample_sums, sums, s);                     // [3][C]
+    } else {
+        // the per-sample sums only serve the gradient of the per-sample bias: without one, a single launch
+        reduce_partials(1, p->N * (int)L.grid.x, 3 * p->C, partial, sums, s);
+    }
     return status();
 }
 

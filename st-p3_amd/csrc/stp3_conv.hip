@@ -496,22 +496,26 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
         }
 }
 
-// dw[i] = sum_k partial[k][i]: 16 columns x 16 split lanes per workgroup, fixed tree order (deterministic)
+// dw[i] = sum_k partial[k][i]: 64 columns x 4 split lanes per workgroup (256-byte coalesced row segments, four loads in
+// flight per thread), fixed summation order (deterministic)
 __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(int splits, size_t n, const float* __restrict__ partial,
                                                                   float* __restrict__ dw) {
     __shared__ float red[256];
-    const int il = threadIdx.x & 15, kl = threadIdx.x >> 4;
-    const size_t i = (size_t)blockIdx.x * 16 + il;
-    float s = 0.f;
-    if (i < n)
-        for (int k = kl; k < splits; k += 16) s += partial[(size_t)k * n + i];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int st = 8; st > 0; st >>= 1) {
-        if (kl < st) red[threadIdx.x] += red[threadIdx.x + st * 16];
-        __syncthreads();
+    const int il = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + il;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int k = kl;
+        for (; k + 12 < splits; k += 16) {
+            const float a = partial[(size_t)k * n + i], b = partial[(size_t)(k + 4) * n + i];
+            const float c = partial[(size_t)(k + 8) * n + i], d = partial[(size_t)(k + 12) * n + i];
+            s0 += a; s1 += b; s2 += c; s3 += d;
+        }
+        for (; k < splits; k += 4) s0 += partial[(size_t)k * n + i];
     }
-    if (kl == 0 && i < n) dw[i] = red[il];
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (kl == 0 && i < n) dw[i] = (red[il] + red[64 + il]) + (red[128 + il] + red[192 + il]);
 }
 
 inline int status() {
@@ -664,7 +668,7 @@ int stp3_conv2d_wgrad(const stp3_conv_dims* p, const void* dy, const void* x, fl
     else if (tci_sz == 128) rc = wgrad_launch<64, 128>(d, tco, tci, taps, splits, ksteps, dy, x, workspace, s);
     else rc = wgrad_launch<64, 64>(d, tco, tci, taps, splits, ksteps, dy, x, workspace, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((wsize + 15) / 16)), dim3(256), 0, s, splits, wsize,
+    hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((wsize + 63) / 64)), dim3(256), 0, s, splits, wsize,
                        (const float*)workspace, dw);
     return status();
 }

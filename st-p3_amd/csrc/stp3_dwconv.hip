@@ -246,22 +246,26 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwDims d, const 
     }
 }
 
-// dw[i] = sum_b partial[b][i]: 16 columns x 16 block lanes per workgroup, fixed tree order (deterministic)
+// dw[i] = sum_b partial[b][i]: 64 columns x 4 block lanes per workgroup (256-byte coalesced row segments, four loads
+// in flight per thread), fixed summation order (deterministic)
 __global__ __launch_bounds__(256) void dwconv_reduce_partials_kernel(int nblocks, int n, const float* __restrict__ partial,
                                                                      float* __restrict__ dw) {
     __shared__ float red[256];
-    const int il = threadIdx.x & 15, bl = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + il;
-    float s = 0.f;
-    if (i < n)
-        for (int b = bl; b < nblocks; b += 16) s += partial[(int64_t)b * n + i];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int st = 8; st > 0; st >>= 1) {
-        if (bl < st) red[threadIdx.x] += red[threadIdx.x + st * 16];
-        __syncthreads();
+    const int il = threadIdx.x & 63, bl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int b = bl;
+        for (; b + 12 < nblocks; b += 16) {
+            const float a = partial[(int64_t)b * n + i], c = partial[(int64_t)(b + 4) * n + i];
+            const float e = partial[(int64_t)(b + 8) * n + i], f = partial[(int64_t)(b + 12) * n + i];
+            s0 += a; s1 += c; s2 += e; s3 += f;
+        }
+        for (; b < nblocks; b += 4) s0 += partial[(int64_t)b * n + i];
     }
-    if (bl == 0 && i < n) dw[i] = red[il];
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (bl == 0 && i < n) dw[i] = (red[il] + red[64 + il]) + (red[128 + il] + red[192 + il]);
 }
 
 constexpr int kWgradBlocks = 512;
@@ -326,7 +330,7 @@ int launch_bwd_weight(const DwDims& d, const void* x, const void* dy, float* dw,
     hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, S>), dim3(bx, by, K), dim3(256), lds, s, d, (const T*)x,
                        (const T*)dy, ws);
     const int n = K * K * d.C;
-    hipLaunchKernelGGL(dwconv_reduce_partials_kernel, dim3((n + 15) / 16), dim3(256), 0, s, bx, n, ws, dw);
+    hipLaunchKernelGGL(dwconv_reduce_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, s, bx, n, ws, dw);
     return status();
 }
 

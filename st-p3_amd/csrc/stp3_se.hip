@@ -128,15 +128,26 @@ __global__ __launch_bounds__(kT) void se_pool_kernel(SeDims d, const T* __restri
     }
 }
 
-// out[n][c] = sum_b partial[(n * parts + b) * C + c]
+// out[n][c] = sum_b partial[(n * parts + b) * C + c]: 64 channels x 4 part lanes per workgroup, fixed summation order
 __global__ __launch_bounds__(kT) void se_reduce_kernel(int parts, int C, const float* __restrict__ partial,
                                                        float* __restrict__ out) {
-    const int c = blockIdx.x * kT + threadIdx.x;
+    __shared__ float red[kT];
+    const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     const int n = blockIdx.y;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int b = 0; b < parts; ++b) s += partial[((size_t)n * parts + b) * C + c];
-    out[(size_t)n * C + c] = s;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        const float* src = partial + (size_t)n * parts * C + c;
+        int b = bl;
+        for (; b + 4 < parts; b += 8) {
+            const float a = src[(size_t)b * C], e = src[(size_t)(b + 4) * C];
+            s0 += a; s1 += e;
+        }
+        for (; b < parts; b += 4) s0 += src[(size_t)b * C];
+    }
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (bl == 0 && c < C) out[(size_t)n * C + c] = (red[cl] + red[64 + cl]) + (red[128 + cl] + red[192 + cl]);
 }
 
 template <typename T, int VEC>
@@ -245,7 +256,7 @@ int stp3_se_pool(const stp3_se_dims* p, const void* x, const void* dy, void* wor
     else
         SE_SWITCH(P, hipLaunchKernelGGL((se_pool_kernel<T, VEC, false>), P.grid, dim3(kT), 0, s, P.d, (const T*)x,
                                         (const T*)nullptr, partial));
-    hipLaunchKernelGGL(se_reduce_kernel, dim3((p->C + kT - 1) / kT, p->N), dim3(kT), 0, s, (int)P.grid.x, p->C, partial, out);
+    hipLaunchKernelGGL(se_reduce_kernel, dim3((p->C + 63) / 64, p->N), dim3(kT), 0, s, (int)P.grid.x, p->C, partial, out);
     return se_status();
 }
 

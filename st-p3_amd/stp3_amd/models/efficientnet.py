@@ -67,7 +67,17 @@ class StaticSamePadConv2d(nn.Conv2d):
             # the 3-channel stem: zero-pad the channels to 8 (together with the "same" padding, one copy) so that
             # it runs on the MFMA kernel too; the padded weight columns are zero and their gradient is dropped
             cp = (-self.in_channels) % 8
-            x = F.pad(x, (*self._pad, 0, cp))
+            if x.requires_grad:
+                x = F.pad(x, (*self._pad, 0, cp))
+            else:
+                # the camera images: ONE strided copy (with the cast) into the zeroed channels-last bf16 operand,
+                # instead of a float32 pad, a cast and a layout change (0.6 ms per step)
+                n, c, h, w = x.shape
+                left, right, top, bottom = self._pad
+                xp = torch.empty((n, c + cp, h + top + bottom, w + left + right), dtype=torch.get_autocast_dtype('cuda'),
+                                 device=x.device, memory_format=torch.channels_last).zero_()
+                xp[:, :c, top:top + h, left:left + w] = x
+                x = xp
             return conv2d(x, F.pad(self.weight, (0, 0, 0, 0, 0, cp)), self.bias, self.stride, 0, self.dilation)
         if any(self._pad):
             x = F.pad(x, self._pad)
