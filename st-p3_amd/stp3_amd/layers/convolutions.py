@@ -103,7 +103,7 @@ class ASPPPooling(nn.Sequential):
         pool, conv, bn, _ = self
         # the global average through fused.plane_mean: same value as AdaptiveAvgPool2d(1), gradient in the layout of x
         pooled = plane_mean(x).to(x.dtype)[:, :, None, None] if x.is_cuda else pool(x)
-        return bn_act(bn, conv_module(conv, pooled), ACT_RELU)   # 1x1 map: GEMM + plain-torch BN (still cross-replica)
+        return bn_act(bn, conv_module(conv, pooled), ACT_RELU)   # 1x1 map: GEMM + the fused BatchNorm on N vectors
 
 
 class ASPP(nn.Module):

@@ -8,8 +8,8 @@ runs the whole chain through the HIP kernels of ``stp3_bnact.hip`` on GPU tensor
 rank the batch statistics are all-reduced (the reference trains with ``sync_batchnorm=True``,
 train.py:47).
 
-CPU tensors (the gloo data-parallel tests, the CPU port timed by ``bench.py``) and degenerate 1x1 maps
-take ``bn_act_reference``: the same arithmetic written with torch ops.  GPU tensors never fall back: a
+CPU tensors (the gloo data-parallel tests, the CPU port timed by ``bench.py``) take ``bn_act_reference``: the same
+arithmetic written with torch ops.  GPU tensors never fall back: a
 missing ``libstp3hip.so`` raises.
 """
 import os
@@ -104,7 +104,15 @@ def bn_act(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=
     counts in multiples of 8) read and write in place, with no pad / slice copies between the operators."""
     if res is None:
         res_mode = RES_NONE
-    if not (x.is_cuda and x.dim() == 4 and x.shape[2] * x.shape[3] > 1):
+    if (x.is_cuda and x.dim() == 5 and x.shape[3] == 1 and x.shape[4] == 1 and res is None and sbias is None
+            and oscale is None):
+        # BatchNorm3d of a (B, C, T, 1, 1) descriptor (the pyramid-pooling branch): per-channel statistics over the
+        # B*T vectors, i.e. the 4-D operator on (B*T, C, 1, 1) -- a handful of kernel launches instead of the ~50
+        # tiny torch operators of the plain statement and its backward
+        b, c, t = x.shape[:3]
+        y = bn_act(bn, x.permute(0, 2, 1, 3, 4).reshape(b * t, c, 1, 1), act)
+        return y.view(b, t, c, 1, 1).permute(0, 2, 1, 3, 4)
+    if not (x.is_cuda and x.dim() == 4):
         return bn_act_reference(bn, x, act, res, res_mode, sbias, oscale)
     if torch.is_autocast_enabled() and x.dtype == torch.float32:
         x = x.to(torch.get_autocast_dtype('cuda'))

@@ -110,7 +110,9 @@ class MBConvBlock(nn.Module):
         self._swish = Swish()
         self.out_size = out_size
 
-    def forward(self, inputs, drop_connect_rate=None):
+    def forward(self, inputs, drop_connect_rate=None, drop_scale=None):
+        """``drop_scale`` (N,): this block's drop-connect factors mask_n / keep drawn by the caller (``Encoder.trunk``
+        draws those of all blocks together); otherwise they are drawn here from ``drop_connect_rate``."""
         x = inputs
         # 1x1 conv -> BN -> activation as one operator (BatchNorm statistics from the convolution epilogue)
         fuse = (self.training and x.is_cuda and torch.is_autocast_enabled()
@@ -133,8 +135,8 @@ class MBConvBlock(nn.Module):
             s = self._se_expand(self._swish(self._se_reduce(s)))
             x = torch.sigmoid(s) * x
         skip = self.stride == 1 and self.in_ch == self.out_ch
-        oscale = None
-        if skip and drop_connect_rate and self.training:
+        oscale = drop_scale if skip else None
+        if oscale is None and skip and drop_connect_rate and self.training:
             # drop-connect: the branch of sample n is scaled by mask_n / keep before the skip is added
             keep = 1.0 - drop_connect_rate
             oscale = torch.floor(keep + torch.rand(x.shape[0], dtype=torch.float32, device=x.device)) / keep
