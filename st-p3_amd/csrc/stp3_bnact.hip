@@ -103,10 +103,10 @@ __device__ __forceinline__ Map make_map(const BnDims& d) {
     return m;
 }
 // Padding lanes (channels >= C of rows padded to stp3_bn_dims::cpad) are READ AS ZERO whatever the memory holds, so
-// that what the kernels write there is exactly zero.  Thread-constant branch: free for every other vector.
-template <int VEC>
+// that what the kernels write there is exactly zero.  Compiled in (TAIL) only for launches with padded rows.
+template <int VEC, bool TAIL>
 __device__ __forceinline__ void mask_tail(const Map& m, float* f) {
-    if (m.nvalid < VEC) {
+    if (TAIL && m.nvalid < VEC) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
             if (j >= m.nvalid) f[j] = 0.f;
@@ -188,7 +188,7 @@ __device__ __forceinline__ void block_reduce_store(const BnDims& d, const Map& m
 }
 
 // ---- forward statistics: per-channel sum and sum of squares of (x + sbias) ------------------------
-template <typename T, int VEC, bool FULL>
+template <typename T, int VEC, bool FULL, bool TAIL>
 __global__ __launch_bounds__(kThreads) void bn_stats_kernel(BnDims d, const T* __restrict__ x,
                                                             const float* __restrict__ sbias,
                                                             float* __restrict__ partial) {
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(BnDims d, const T* _
             for (int u = 0; u < kUnroll; ++u)                       // kUnroll independent loads in flight
                 if (r + u * step < d.rows) {
                     Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
-                    mask_tail<VEC>(m, v[u]);
+                    mask_tail<VEC, TAIL>(m, v[u]);
                 }
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
@@ -286,7 +286,7 @@ __device__ __forceinline__ void channel_affine(const BnDims& d, const Map& m, co
 // ---- forward apply -------------------------------------------------------------------------------
 // y = act(((x + sbias) - mean) * invstd * gamma + beta [+ res]) [* oscale[n]] [+ res]
 // TRAIN: mean / invstd from `sums` (of `count` elements); else from the running statistics.
-template <typename T, int VEC, bool TRAIN, bool FULL>
+template <typename T, int VEC, bool TRAIN, bool FULL, bool TAIL>
 __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
     BnDims d, const T* __restrict__ x, const float* __restrict__ sbias, const T* __restrict__ res,
     const float* __restrict__ oscale, const float* __restrict__ sums, float inv_count, float unbias,
@@ -346,10 +346,10 @@ __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
             for (int u = 0; u < kUnroll; ++u) {
                 if (r + u * step < d.rows) {
                     Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
-                    mask_tail<VEC>(m, v[u]);
+                    mask_tail<VEC, TAIL>(m, v[u]);
                     if (RESM != STP3_RES_NONE) {
                         Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
-                        mask_tail<VEC>(m, rv[u]);
+                        mask_tail<VEC, TAIL>(m, rv[u]);
                     }
                 }
             }
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
 
 // ---- backward reduce: per (sample, channel) sums of g, g * xhat and xhat -----------------------
 // g = dy * oscale[n] * act'(pre), pre = xhat * gamma + beta [+ res]
-template <typename T, int VEC, bool FULL>
+template <typename T, int VEC, bool FULL, bool TAIL>
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
     BnDims d, const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ sbias,
     const T* __restrict__ res, const float* __restrict__ oscale, const float* __restrict__ mean_,
@@ -415,11 +415,11 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
                     if (r + u * step < d.rows) {
                         Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
                         Io<T, VEC>::load(gs + (size_t)(r + u * step) * d.ldy, g[u]);
-                        mask_tail<VEC>(m, v[u]);
-                        mask_tail<VEC>(m, g[u]);
+                        mask_tail<VEC, TAIL>(m, v[u]);
+                        mask_tail<VEC, TAIL>(m, g[u]);
                         if (PRE_RES) {
                             Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
-                            mask_tail<VEC>(m, rv[u]);
+                            mask_tail<VEC, TAIL>(m, rv[u]);
                         }
                     }
                 }
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
 
 // ---- backward apply: dx = gamma * invstd * (g - sum(g)/M - xhat * sum(g*xhat)/M), dres ----------
 // TRAIN == false (running statistics are constants): dx = gamma * invstd * g
-template <typename T, int VEC, bool TRAIN, bool FULL>
+template <typename T, int VEC, bool TRAIN, bool FULL, bool TAIL>
 __global__ __launch_bounds__(kThreads) void bn_apply_bwd_kernel(
     BnDims d, const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ sbias,
     const T* __restrict__ res, const float* __restrict__ oscale, const float* __restrict__ mean_,
@@ -491,11 +491,11 @@ __global__ __launch_bounds__(kThreads) void bn_apply_bwd_kernel(
                 if (r + u * step < d.rows) {
                     Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
                     Io<T, VEC>::load(gs + (size_t)(r + u * step) * d.ldy, g[u]);
-                    mask_tail<VEC>(m, v[u]);
-                    mask_tail<VEC>(m, g[u]);
+                    mask_tail<VEC, TAIL>(m, v[u]);
+                    mask_tail<VEC, TAIL>(m, g[u]);
                     if (PRE_RES) {
                         Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
-                        mask_tail<VEC>(m, rv[u]);
+                        mask_tail<VEC, TAIL>(m, rv[u]);
                     }
                 }
             }
@@ -533,6 +533,7 @@ struct Launch {
     int vec;       // 8 / 4 (vector path) or 1
     bool bf16;
     bool full;     // full-occupancy geometry: all row lanes live, ~4096 workgroups
+    bool tail;     // zero-padded rows: the last channel vector masks its padding lanes
     dim3 grid;
     int parts;     // partial rows = N * grid.x
 };
@@ -562,7 +563,8 @@ inline int plan(const stp3_bn_dims* p, Launch* L, std::initializer_list<const vo
     d.CL = CL;
     // two workgroup geometries; the full-occupancy one pays off only on the largest maps (measured on the MI355X,
     // profiles/r02a_validate_switches.txt: 72 x 144 x 112 x 240 backward 1205 -> 771 us, smaller maps 0-40 % slower)
-    L->full = (int64_t)p->N * p->rows * p->C >= (int64_t)200 * 1000 * 1000;
+    L->tail = CL != p->C;
+    L->full = !L->tail && (int64_t)p->N * p->rows * p->C >= (int64_t)200 * 1000 * 1000;
     const int CV = (CL + L->vec - 1) / L->vec;
     const int CVB = CV < kThreads ? CV : kThreads;
     int RL = 1;
@@ -585,9 +587,10 @@ inline int plan(const stp3_bn_dims* p, Launch* L, std::initializer_list<const vo
 }
 
 // run CALL with `T` / `VEC` / `FULL` bound to the launch's element type, vector width and geometry
-#define BN_SWITCH_V(L, F, ...)                                                  \
+#define BN_SWITCH_V(L, F, TL, ...)                                              \
     {                                                                           \
         constexpr bool FULL = F;                                                \
+        constexpr bool TAIL = TL;                                               \
         if ((L).bf16) {                                                         \
             if ((L).vec == 8) { using T = uint16_t; constexpr int VEC = 8; __VA_ARGS__; } \
             else              { using T = uint16_t; constexpr int VEC = 1; __VA_ARGS__; } \
@@ -596,10 +599,12 @@ inline int plan(const stp3_bn_dims* p, Launch* L, std::initializer_list<const vo
             else              { using T = float; constexpr int VEC = 1; __VA_ARGS__; }    \
         }                                                                       \
     }
+// zero-padded rows (tail) always take the default geometry: one extra instantiation per kernel, not two
 #define BN_SWITCH(L, ...)                                                       \
     do {                                                                        \
-        if ((L).full) BN_SWITCH_V(L, true, __VA_ARGS__)                         \
-        else BN_SWITCH_V(L, false, __VA_ARGS__)                                 \
+        if ((L).tail) BN_SWITCH_V(L, false, true, __VA_ARGS__)                  \
+        else if ((L).full) BN_SWITCH_V(L, true, false, __VA_ARGS__)             \
+        else BN_SWITCH_V(L, false, false, __VA_ARGS__)                          \
     } while (0)
 
 inline size_t ws_bytes(const stp3_bn_dims* p) {
@@ -631,7 +636,7 @@ int stp3_bn_stats(const stp3_bn_dims* p, const void* x, const float* sbias, void
     if (workspace_bytes < ws_bytes(p)) return STP3_ENOSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)workspace;
-    BN_SWITCH(L, hipLaunchKernelGGL((bn_stats_kernel<T, VEC, FULL>), L.grid, dim3(kThreads), 0, s, L.d, (const T*)x, sbias,
+    BN_SWITCH(L, hipLaunchKernelGGL((bn_stats_kernel<T, VEC, FULL, TAIL>), L.grid, dim3(kThreads), 0, s, L.d, (const T*)x, sbias,
                                      partial));
     reduce_partials(1, L.parts, 2 * p->C, partial, sums, s);
     return status();
@@ -655,12 +660,12 @@ int stp3_bn_apply_fwd(const stp3_bn_dims* p, const void* x, const float* sbias, 
     const float inv_count = train ? (float)(1.0 / count) : 0.f;
     const float unbias = (train && count > 1.0) ? (float)(count / (count - 1.0)) : 1.f;
     if (train)
-        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_fwd_kernel<T, VEC, true, FULL>), L.grid, dim3(kThreads), 0, s, L.d,
+        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_fwd_kernel<T, VEC, true, FULL, TAIL>), L.grid, dim3(kThreads), 0, s, L.d,
                                          (const T*)x, sbias, (const T*)res, oscale, sums, inv_count, unbias, gamma,
                                          beta, eps, momentum, running_mean, running_var, save_mean, save_invstd,
                                          (T*)y));
     else
-        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_fwd_kernel<T, VEC, false, FULL>), L.grid, dim3(kThreads), 0, s, L.d,
+        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_fwd_kernel<T, VEC, false, FULL, TAIL>), L.grid, dim3(kThreads), 0, s, L.d,
                                          (const T*)x, sbias, (const T*)res, oscale, sums, inv_count, unbias, gamma,
                                          beta, eps, momentum, running_mean, running_var, save_mean, save_invstd,
                                          (T*)y));
@@ -680,7 +685,7 @@ int stp3_bn_bwd_reduce(const stp3_bn_dims* p, const void* dy, const void* x, con
     if (workspace_bytes < ws_bytes(p)) return STP3_ENOSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)workspace;
-    BN_SWITCH(L, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, FULL>), L.grid, dim3(kThreads), 0, s, L.d, (const T*)dy,
+    BN_SWITCH(L, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, FULL, TAIL>), L.grid, dim3(kThreads), 0, s, L.d, (const T*)dy,
                                      (const T*)x, sbias, (const T*)res, oscale, mean, invstd, gamma, beta, partial));
     if (p->has_sbias) {
         reduce_partials(p->N, (int)L.grid.x, 3 * p->C, partial, sample_sums, s);     // [N][3][C]
@@ -706,11 +711,11 @@ int stp3_bn_apply_bwd(const stp3_bn_dims* p, const void* dy, const void* x, cons
     hipStream_t s = (hipStream_t)stream;
     const float inv_count = train ? (float)(1.0 / count) : 0.f;
     if (train)
-        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, VEC, true, FULL>), L.grid, dim3(kThreads), 0, s, L.d,
+        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, VEC, true, FULL, TAIL>), L.grid, dim3(kThreads), 0, s, L.d,
                                          (const T*)dy, (const T*)x, sbias, (const T*)res, oscale, mean, invstd, gamma,
                                          beta, sums, inv_count, (T*)dx, (T*)dres));
     else
-        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, VEC, false, FULL>), L.grid, dim3(kThreads), 0, s, L.d,
+        BN_SWITCH(L, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, VEC, false, FULL, TAIL>), L.grid, dim3(kThreads), 0, s, L.d,
                                          (const T*)dy, (const T*)x, sbias, (const T*)res, oscale, mean, invstd, gamma,
                                          beta, sums, inv_count, (T*)dx, (T*)dres));
     return status();
