@@ -330,6 +330,10 @@ inline void launch_colsum(hipStream_t s, int parts, int width, float* partial, f
 // output channels), X^T as operand B: an accumulator lane holds dW[co ..][ci = lane & 31], i.e. coalesced float32
 // rows of the result.  Workgroup tile TCO x TCI (64 or 128 each) of one tap; the pixels are split over gridDim.z
 // workgroups (float32 partial sums, reduced deterministically afterwards).
+// Tap folding (tap_fold > 0; layers with Cin == 8, i.e. the 3-channel stem): one channel block holds ALL input
+// channels, so the TCI / 8 channel-block slots of the X tile carry tap_fold = TCI / 8 different TAPS instead -- the
+// tile's columns are (tap, ci) pairs, contiguous in dW -- and dY, the big operand (48 channels x 1.9 M pixels for the
+// stem), is read once per tap group instead of once per tap (9 x 186 MB before).
 __device__ __forceinline__ uint32_t perm_lo(uint32_t a, uint32_t b) {   // (a.lo16, b.lo16)
     return __builtin_amdgcn_perm(b, a, 0x05040100u);
 }
@@ -352,7 +356,7 @@ __device__ __forceinline__ void transpose8x8(const uint4 (&in)[8], uint4 (&out)[
 }
 
 template <int TCO, int TCI>
-__global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles_ci, int ksteps_per_block,
+__global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles_ci, int ksteps_per_block, int tap_fold,
                                                            const uint16_t* __restrict__ dy,
                                                            const uint16_t* __restrict__ x,
                                                            float* __restrict__ partial) {
@@ -402,8 +406,16 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
                 ho = t % d.Ho;
                 n = t / d.Ho;
             }
-            const int ch = (is_a ? co0 : ci0) + cc * 8;
-            const bool ch_ok = live && ch < (is_a ? d.Cout : d.Cin);
+            int ch = (is_a ? co0 : ci0) + cc * 8;
+            bool ch_ok = live && ch < (is_a ? d.Cout : d.Cin);
+            int khb = kh, kwb = kw;
+            if (tap_fold && !is_a) {                       // this channel-block slot is tap `t` of the group
+                const int t = tap * tap_fold + cc;
+                khb = t / d.KW;
+                kwb = t - khb * d.KW;
+                ch = 0;
+                ch_ok = live && t < d.KH * d.KW;
+            }
             unsigned bits = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -413,8 +425,8 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
                 if (is_a) {
                     off = (size_t)m * d.ldy + ch;
                 } else {
-                    const int hi = ho * d.stride - d.pad_h + kh * d.dil_h;
-                    const int wi = wo * d.stride - d.pad_w + kw * d.dil_w;
+                    const int hi = ho * d.stride - d.pad_h + khb * d.dil_h;
+                    const int wi = wo * d.stride - d.pad_w + kwb * d.dil_w;
                     ok = ok && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
                     off = ((size_t)(n * d.H + hi) * d.W + wi) * d.ldx + ch;
                     if (++wo == d.Wo) { wo = 0; if (++ho == d.Ho) { ho = 0; ++n; } }
@@ -487,11 +499,13 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
 #pragma unroll
         for (int b = 0; b < TB; ++b) {
             const int ci = ci0 + wb * (32 * TB) + b * 32 + frow;
-            if (ci >= d.Cin) continue;
+            // folded: column = (tap, ci) pair number tap * TCI + ci of this tap group, contiguous in dW (Cin == 8)
+            const int col = tap_fold ? tap * TCI + ci : tap * d.Cin + ci;
+            if (tap_fold ? col >= d.KH * d.KW * d.Cin : ci >= d.Cin) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wa * (32 * TA) + a * 32 + 8 * (r >> 2) + 4 * fk + (r & 3);
-                if (co < d.Cout) out[((size_t)co * d.KH * d.KW + tap) * d.Cin + ci] = acc[a][b][r];
+                if (co < d.Cout) out[(size_t)co * d.KH * d.KW * d.Cin + col] = acc[a][b][r];
             }
         }
 }
@@ -531,14 +545,14 @@ inline size_t igemm_lds(int bn, int steps, bool out_f32) {
 }
 
 template <int TCO, int TCI>
-int wgrad_launch(const ConvDims& d, int tco, int tci, int taps, int splits, int ksteps, const void* dy, const void* x,
-                        void* workspace, hipStream_t s) {
+int wgrad_launch(const ConvDims& d, int tco, int tci, int taps, int splits, int ksteps, int fold, const void* dy,
+                 const void* x, void* workspace, hipStream_t s) {
     const size_t lds = (size_t)2 * (TCO + TCI) * kBK * 2;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_kernel<TCO, TCI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return -(int)e;
     hipLaunchKernelGGL((conv2d_wgrad_kernel<TCO, TCI>), dim3(tco * tci, taps, splits), dim3(256), lds, s, d, tci, ksteps,
-                       (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace);
+                       fold, (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace);
     return STP3_OK;
 }
 
@@ -612,14 +626,25 @@ int stp3_conv2d_fwd(const stp3_conv_dims* p, const void* x, const void* w, const
 }
 
 
-static int wgrad_plan(const stp3_conv_dims* p, int* tco_sz, int* tci_sz, int* tiles_co, int* tiles_ci, int* splits, int* ksteps) {
+// *fold: taps per workgroup when the taps are folded into the ci tile (Cin == 8 with more than one tap), else 0;
+// *grid_y: tap groups (folded) or taps
+static int wgrad_plan(const stp3_conv_dims* p, int* tco_sz, int* tci_sz, int* tiles_co, int* tiles_ci, int* splits, int* ksteps,
+                      int* fold, int* grid_y) {
     const int64_t M = (int64_t)p->N * p->Ho * p->Wo;
+    const int taps = p->KH * p->KW;
     *tco_sz = p->Cout > 64 ? 128 : 64;
     *tci_sz = p->Cin > 64 ? 128 : 64;
+    *fold = 0;
+    *grid_y = taps;
+    if (p->Cin == 8 && taps > 1) {
+        *tci_sz = taps > 8 ? 128 : 64;
+        *fold = *tci_sz / 8;
+        *grid_y = (taps + *fold - 1) / *fold;
+    }
     *tiles_co = (p->Cout + *tco_sz - 1) / *tco_sz;
-    *tiles_ci = (p->Cin + *tci_sz - 1) / *tci_sz;
+    *tiles_ci = *fold ? 1 : (p->Cin + *tci_sz - 1) / *tci_sz;
     const int64_t total_steps = (M + kBK - 1) / kBK;         // 64 pixels per step
-    const int64_t base = (int64_t)(*tiles_co) * (*tiles_ci) * p->KH * p->KW;
+    const int64_t base = (int64_t)(*tiles_co) * (*tiles_ci) * (*grid_y);
     int64_t want = (1024 + base - 1) / base;                 // ~1024 workgroups
     const int64_t max_splits = (total_steps + 7) / 8;        // at least 8 k-steps per workgroup
     if (want > max_splits) want = max_splits;
@@ -633,8 +658,8 @@ static int wgrad_plan(const stp3_conv_dims* p, int* tco_sz, int* tci_sz, int* ti
 int stp3_conv2d_wgrad_workspace(const stp3_conv_dims* p, size_t* bytes) {
     if (!p || !bytes || p->N <= 0 || p->Cout <= 0 || p->Cin <= 0 || p->KH <= 0 || p->KW <= 0 || p->Ho <= 0 || p->Wo <= 0)
         return STP3_EINVAL;
-    int a, b, tco, tci, splits, ksteps;
-    wgrad_plan(p, &a, &b, &tco, &tci, &splits, &ksteps);
+    int a, b, tco, tci, splits, ksteps, fold, gy;
+    wgrad_plan(p, &a, &b, &tco, &tci, &splits, &ksteps, &fold, &gy);
     *bytes = (size_t)splits * p->Cout * p->KH * p->KW * p->Cin * sizeof(float);
     return STP3_OK;
 }
@@ -651,8 +676,8 @@ int stp3_conv2d_wgrad(const stp3_conv_dims* p, const void* dy, const void* x, fl
     const int64_t M = (int64_t)p->N * p->Ho * p->Wo;
     if (M >= (1LL << 31) - 64 || (int64_t)p->N * p->H * p->W >= (1LL << 31)) return STP3_EUNSUP;
     if (p->KH * p->KW > 65535) return STP3_EUNSUP;
-    int tco_sz, tci_sz, tco, tci, splits, ksteps;
-    wgrad_plan(p, &tco_sz, &tci_sz, &tco, &tci, &splits, &ksteps);
+    int tco_sz, tci_sz, tco, tci, splits, ksteps, fold, taps;
+    wgrad_plan(p, &tco_sz, &tci_sz, &tco, &tci, &splits, &ksteps, &fold, &taps);
     const size_t wsize = (size_t)p->Cout * p->KH * p->KW * p->Cin;
     if (workspace_bytes < (size_t)splits * wsize * sizeof(float)) return STP3_ENOSPACE;
     ConvDims d;
@@ -661,12 +686,11 @@ int stp3_conv2d_wgrad(const stp3_conv_dims* p, const void* dy, const void* x, fl
     d.dil_h = p->dil_h; d.dil_w = p->dil_w; d.ldx = p->ldx; d.ldy = p->ldy;
     d.out_f32 = 1; d.has_bias = 0; d.M = (int)M; d.kchunks = 0; d.Ktot = p->KH * p->KW * p->Cin;
     hipStream_t s = (hipStream_t)stream;
-    const int taps = p->KH * p->KW;
     int rc;
-    if (tco_sz == 128 && tci_sz == 128) rc = wgrad_launch<128, 128>(d, tco, tci, taps, splits, ksteps, dy, x, workspace, s);
-    else if (tco_sz == 128) rc = wgrad_launch<128, 64>(d, tco, tci, taps, splits, ksteps, dy, x, workspace, s);
-    else if (tci_sz == 128) rc = wgrad_launch<64, 128>(d, tco, tci, taps, splits, ksteps, dy, x, workspace, s);
-    else rc = wgrad_launch<64, 64>(d, tco, tci, taps, splits, ksteps, dy, x, workspace, s);
+    if (tco_sz == 128 && tci_sz == 128) rc = wgrad_launch<128, 128>(d, tco, tci, taps, splits, ksteps, fold, dy, x, workspace, s);
+    else if (tco_sz == 128) rc = wgrad_launch<128, 64>(d, tco, tci, taps, splits, ksteps, fold, dy, x, workspace, s);
+    else if (tci_sz == 128) rc = wgrad_launch<64, 128>(d, tco, tci, taps, splits, ksteps, fold, dy, x, workspace, s);
+    else rc = wgrad_launch<64, 64>(d, tco, tci, taps, splits, ksteps, fold, dy, x, workspace, s);
     if (rc) return rc;
     hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((wsize + 63) / 64)), dim3(256), 0, s, splits, wsize,
                        (const float*)workspace, dw);

@@ -26,6 +26,8 @@ CASES = [
     (3, 40, 20, 20, 35, 3, 1, 1, 1, False, True),       # channel-sliced input view (35 -> 40 padded), odd Cout
     (1, 128, 25, 25, 256, 3, 2, 1, 1, False, False),    # ResNet stage transition, stride 2
     (2, 960, 14, 30, 160, 1, 1, 0, 1, False, False),    # widest trunk projection (K = 960)
+    (3, 8, 57, 121, 48, 3, 2, 0, 1, False, False),      # trunk stem (3 -> 8 padded channels): taps folded in the weight gradient
+    (2, 8, 30, 22, 24, 5, 1, 2, 1, True, False),        # Cin == 8 with 25 taps: two folded tap groups
 ]
 
 
