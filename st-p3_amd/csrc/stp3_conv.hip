@@ -295,10 +295,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(int parts, int width, const
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cl;
     const int r0 = blockIdx.y * 256, r1 = min(r0 + 256, parts);
-    double s = 0.0;
-    if (col < width)
-        for (int p = r0 + rl; p < r1; p += 4) s += (double)partial[(size_t)p * width + col];
-    red[threadIdx.x] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (col < width) {
+        int p = r0 + rl;
+        for (; p + 12 < r1; p += 16) {                     // four independent loads in flight
+            const float a = partial[(size_t)p * width + col], b = partial[(size_t)(p + 4) * width + col];
+            const float c = partial[(size_t)(p + 8) * width + col], e = partial[(size_t)(p + 12) * width + col];
+            s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)e;
+        }
+        for (; p < r1; p += 4) s0 += (double)partial[(size_t)p * width + col];
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rl == 0 && col < width)
         out[(size_t)blockIdx.y * width + col] = (float)(red[cl] + red[64 + cl] + red[128 + cl] + red[192 + cl]);
