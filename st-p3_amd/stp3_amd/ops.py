@@ -1068,7 +1068,8 @@ class _Conv2dMfma(torch.autograd.Function):
             if not cpad and w_now is not None and w_now.is_leaf and w_now.requires_grad:
                 wt = _bf16_weights(w_now, need_flipped=True)[1]
             else:
-                wt = wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+                wt = wb if kh == kw == 1 else wb.flip(2, 3)              # a 1x1 kernel has nothing to flip
+                wt = wt.transpose(0, 1).contiguous(memory_format=torch.channels_last)
             g = dy
             if stride > 1:
                 n, _, h, w = x.shape

@@ -76,15 +76,31 @@ class TrainingModule(nn.Module):
                 norm=1, future_discount=cfg.FUTURE_DISCOUNT, ignore_index=cfg.DATASET.IGNORE_INDEX)
             self.model.flow_weight = _scalar()
         self.training_step_count = 0
+        self._fused_terms = None
 
     # ------------------------------------------------------------------------------------------
     def _weighted(self, loss, name, key, value):
-        """Learned-uncertainty weighting 1/(2 exp(w)) * L + w/2 (trainer.py:125-172)."""
+        """Learned-uncertainty weighting 1/(2 exp(w)) * L + w/2 (trainer.py:125-172).  With ``self._fused_terms`` set
+        (``training_step``) the term is only recorded: ``_fused_total`` then weighs and adds all of them with a
+        handful of operators instead of ~6 tiny ones per term in each direction."""
         w = getattr(self.model, f'{name}_weight')
+        if self._fused_terms is not None:
+            self._fused_terms.append((value, w))
+            return
         loss[key] = value / (2 * torch.exp(w))
         loss[f'{name}_uncertainty'] = 0.5 * w
 
-    def shared_step(self, batch, is_train):
+    @staticmethod
+    def _fused_total(terms):
+        """sum_k L_k / (2 exp(w_k)) + w_k / 2 over the recorded (L_k, w_k)."""
+        values = torch.stack([v.reshape(()) for v, _ in terms])
+        w = torch.stack([p.reshape(()) for _, p in terms]).to(values.dtype)
+        return (values * (0.5 * torch.exp(-w)) + 0.5 * w).sum()
+
+    def shared_step(self, batch, is_train, fused_total=False):
+        """``fused_total``: return ``{'total': sum of all weighted terms}`` instead of the per-term dictionary (what
+        ``training_step`` needs; the terms themselves are for logging)."""
+        self._fused_terms = [] if (fused_total and is_train) else None
         labels = self.prepare_future_labels(batch)
         output = self.model(batch['image'], batch['intrinsics'], batch['extrinsics'], batch['future_egomotion'])
         rf = self.model.receptive_field
@@ -109,6 +125,9 @@ class TrainingModule(nn.Module):
             if cfg.INSTANCE_FLOW.ENABLED:
                 self._weighted(loss, 'flow', 'instance_flow', self.losses_fn['instance_flow'](
                     output['instance_flow'], labels['flow'], rf))
+            if self._fused_terms is not None:
+                loss['total'] = self._fused_total(self._fused_terms)
+                self._fused_terms = None
             output = {**output, 'selected_traj': labels['gt_trajectory']}
         else:
             # evaluate.py:95-98 / trainer.py:216-236: argmax over classes, present frame onwards
@@ -197,9 +216,9 @@ class TrainingModule(nn.Module):
         return labels
 
     def training_step(self, batch, batch_idx=0):
-        _, _, loss = self.shared_step(batch, True)
+        _, _, loss = self.shared_step(batch, True, fused_total=True)
         self.training_step_count += 1
-        return sum(loss.values())
+        return loss['total']
 
     def validation_step(self, batch, batch_idx=0):
         output, labels, _ = self.shared_step(batch, False)

@@ -191,3 +191,19 @@ def test_regression_loss_with_everything_ignored_is_zero_and_differentiable():
     assert loss.item() == 0.0
     loss.backward()
     assert pred.grad.abs().max().item() == 0.0
+
+
+def test_fused_loss_total_equals_the_per_term_weighting():
+    """``TrainingModule._fused_total`` (what ``training_step`` returns) against the reference's per-term statement
+    1 / (2 exp(w)) * L + w / 2 (trainer.py:125-172), value and gradients."""
+    from stp3_amd.trainer import TrainingModule
+    g = torch.Generator().manual_seed(3)
+    vals = [(torch.rand((), generator=g) * 3).requires_grad_() for _ in range(7)]
+    ws = [torch.nn.Parameter(torch.randn((), generator=g)) for _ in range(7)]
+    per_term = sum(v / (2 * torch.exp(w)) + 0.5 * w for v, w in zip(vals, ws))
+    fused = TrainingModule._fused_total(list(zip(vals, ws)))
+    torch.testing.assert_close(fused, per_term, rtol=1e-6, atol=1e-6)
+    ga = torch.autograd.grad(per_term, vals + ws)
+    gb = torch.autograd.grad(fused, vals + ws)
+    for a, b in zip(ga, gb):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
