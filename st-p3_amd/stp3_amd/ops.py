@@ -858,13 +858,18 @@ def _conv_out(size, k, stride, pad, dil):
 _CONV_STAT_WS = {}
 
 
-def _conv2d_launch(x, wb, bias, stride, pad, dil, out_dtype, sums_ptr=None):
+def _conv2d_launch(x, wb, bias, stride, pad, dil, out_dtype, sums_ptr=None, out_hw=None):
     """x (N,Cin,H,W) bf16 with channels-last memory (row stride ld >= Cin); wb (Cout,Cin,KH,KW) bf16 channels-last.
-    ``sums_ptr``: device address of a float32 [2][Cout] buffer that receives the BatchNorm statistics of y (bf16 y)."""
+    ``sums_ptr``: device address of a float32 [2][Cout] buffer that receives the BatchNorm statistics of y (bf16 y).
+    ``out_hw``: output size when it is not the one ``pad`` implies on both sides (``pad`` is the top / left padding;
+    taps that fall off the bottom / right edge read zeros like any other padding)."""
     n, cin, h, w = x.shape
     cout, _, kh, kw = wb.shape
     x, ldx = _rows_view(x)
-    ho, wo = _conv_out(h, kh, stride, pad[0], dil[0]), _conv_out(w, kw, stride, pad[1], dil[1])
+    if out_hw is None:
+        ho, wo = _conv_out(h, kh, stride, pad[0], dil[0]), _conv_out(w, kw, stride, pad[1], dil[1])
+    else:
+        ho, wo = out_hw
     y = torch.empty((n, cout, ho, wo), dtype=out_dtype, device=x.device, memory_format=torch.channels_last)
     dims = _lib.ConvDims(n, h, w, cin, ho, wo, cout, kh, kw, stride, pad[0], pad[1], dil[0], dil[1], ldx, cout,
                          _lib.DTYPE_F32 if out_dtype == torch.float32 else _lib.DTYPE_BF16, int(bias is not None))
@@ -983,6 +988,7 @@ class _WeightShadows:
               'stp3_conv2d_prep_weights')
         for e in self.order:
             e['version'] = e['ref']()._version
+            e.pop('phases', None)                  # sub-kernels cut from the flipped shadow (_strided_dgrad)
 
 
 _SHADOWS = _WeightShadows()
@@ -1027,6 +1033,87 @@ def _evict_weight(key, ent):
         del _WEIGHT_CACHE[key]
 
 
+def _phase_taps(k, pad, stride, phase):
+    """Input rows hi = stride * i + phase of a strided convolution's data gradient: dx[hi] = sum over the taps kh with
+    (phase + pad - kh) % stride == 0 of dy[i + (phase + pad - kh) / stride] * w[kh] -- a STRIDE-1 correlation of dy
+    with every stride-th tap.  Returns (first index into the tap-FLIPPED kernel, number of taps, top padding) or None
+    when no tap lands on this phase; the flipped-kernel taps first, first + stride, ... are in increasing dy offset."""
+    khs = [kh for kh in range(k) if (phase + pad - kh) % stride == 0]
+    if not khs:
+        return None
+    top = -((phase + pad - khs[-1]) // stride)            # largest kh: smallest dy offset
+    return k - 1 - khs[-1], len(khs), top
+
+
+def _strided_dgrad(dy, wt, x_shape, stride, pad, cache):
+    """dL/dx of a stride-s convolution WITHOUT zero-stuffing dy to the input resolution: one stride-1 convolution per
+    input phase (s x s of them, each over dy at ITS resolution with the taps that land on the phase), results
+    interleaved into dx.  The zero-stuffed form multiplies s^2 - 1 zeros out of s^2 (decoder stem 7x7 / 2: 370 us where
+    the four phase convolutions need a quarter of the work).  ``wt`` (Cin,Cout,KH,KW): taps flipped, channels swapped.
+    ``cache``: dict that keeps the phase sub-kernels of a parameter's shadow until the shadows are rewritten.
+    Returns None when a phase would need negative padding (pad > what the taps reach): the caller zero-stuffs."""
+    n, cin, h, w = x_shape
+    kh, kw = wt.shape[2], wt.shape[3]
+    plans = []
+    for ph in range(stride):
+        th = _phase_taps(kh, pad[0], stride, ph)
+        for pw in range(stride):
+            tw = _phase_taps(kw, pad[1], stride, pw)
+            if th is not None and tw is not None and (th[2] < 0 or tw[2] < 0):
+                return None
+            plans.append((ph, pw, th, tw))
+    dx = torch.empty((n, cin, h, w), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    for ph, pw, th, tw in plans:
+        rows, cols = (h - ph + stride - 1) // stride, (w - pw + stride - 1) // stride
+        if rows <= 0 or cols <= 0:
+            continue
+        if th is None or tw is None:
+            dx[:, :, ph::stride, pw::stride] = 0
+            continue
+        key = (ph, pw)
+        sub = None if cache is None else cache.get(key)
+        if sub is None:
+            sub = wt[:, :, th[0]::stride, tw[0]::stride].contiguous(memory_format=torch.channels_last)
+            if cache is not None:
+                cache[key] = sub
+        part = _conv2d_launch(dy, sub, None, 1, (th[2], tw[2]), (1, 1), torch.bfloat16, out_hw=(rows, cols))
+        dx[:, :, ph::stride, pw::stride] = part
+    return dx
+
+
+def conv2d_data_grad(dy, wb, weight_ref, x_shape, stride, pad, dil):
+    """dL/dx of a dense convolution on the MFMA kernel: a stride-1 convolution of dy with the taps flipped and
+    Cin / Cout swapped -- per input phase for a strided layer (``_strided_dgrad``), over the zero-stuffed dy when that
+    does not apply.  dy (N,Cout,Ho,Wo) bf16 channels-last; wb (Cout,Cin,KH,KW) bf16; ``weight_ref``: the parameter wb
+    shadows (its flipped shadow and phase sub-kernels are cached per optimizer step) or None."""
+    cout, cin, kh, kw = wb.shape
+    bpad = (dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1])
+    phase_cache = None
+    if weight_ref is not None and weight_ref.is_leaf and weight_ref.requires_grad:
+        wt = _bf16_weights(weight_ref, need_flipped=True)[1]
+        ent = _SHADOWS.lookup(weight_ref) if isinstance(weight_ref, torch.nn.Parameter) else None
+        if ent is not None and ent['wt'] is wt:
+            phase_cache = ent.setdefault('phases', {})
+    else:
+        wt = wb if kh == kw == 1 else wb.flip(2, 3)              # a 1x1 kernel has nothing to flip
+        wt = wt.transpose(0, 1).contiguous(memory_format=torch.channels_last)
+    dx = None
+    if stride > 1 and tuple(dil) == (1, 1):
+        dx = _strided_dgrad(dy, wt, x_shape, stride, pad, phase_cache)
+    if dx is None:
+        g = dy
+        if stride > 1:
+            n, _, h, w = x_shape
+            ho, wo = dy.shape[2], dy.shape[3]
+            # rows / columns the forward never reached (floor in the output-size formula) get zero gradient
+            uh = h + 2 * pad[0] - dil[0] * (kh - 1)
+            uw = w + 2 * pad[1] - dil[1] * (kw - 1)
+            g = torch.empty((n, cout, uh, uw), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last).zero_()
+            g[:, :, ::stride, ::stride][:, :, :ho, :wo] = dy
+        dx = _conv2d_launch(g, wt, None, 1, bpad, dil, torch.bfloat16)
+    return dx
+
+
 class _Conv2dMfma(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil, out_dtype):
@@ -1062,24 +1149,7 @@ class _Conv2dMfma(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         hip_dx = need_dx and cout % 8 == 0 and bpad[0] >= 0 and bpad[1] >= 0
         if hip_dx:
-            # dL/dx = stride-1 convolution of dy (zero-stuffed to the input resolution when stride > 1) with the
-            # taps flipped and Cin / Cout swapped
-            w_now = ctx.weight_ref
-            if not cpad and w_now is not None and w_now.is_leaf and w_now.requires_grad:
-                wt = _bf16_weights(w_now, need_flipped=True)[1]
-            else:
-                wt = wb if kh == kw == 1 else wb.flip(2, 3)              # a 1x1 kernel has nothing to flip
-                wt = wt.transpose(0, 1).contiguous(memory_format=torch.channels_last)
-            g = dy
-            if stride > 1:
-                n, _, h, w = x.shape
-                ho, wo = dy.shape[2], dy.shape[3]
-                # rows / columns the forward never reached (floor in the output-size formula) get zero gradient
-                uh = h + 2 * pad[0] - dil[0] * (kh - 1)
-                uw = w + 2 * pad[1] - dil[1] * (kw - 1)
-                g = torch.empty((n, cout, uh, uw), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last).zero_()
-                g[:, :, ::stride, ::stride][:, :, :ho, :wo] = dy
-            dx = _conv2d_launch(g, wt, None, 1, bpad, dil, torch.bfloat16)
+            dx = conv2d_data_grad(dy, wb, None if cpad else ctx.weight_ref, x.shape, stride, pad, dil)
         need_dw = ctx.needs_input_grad[1]
         hip_dw = need_dw and cin % 8 == 0
         if hip_dw:

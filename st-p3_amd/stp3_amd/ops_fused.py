@@ -127,19 +127,7 @@ class _ConvBnAct(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         hip_dx = need_dx and cout % 8 == 0 and bpad[0] >= 0 and bpad[1] >= 0
         if hip_dx:
-            w_now = ctx.weight_ref
-            if w_now is not None and w_now.is_leaf and w_now.requires_grad:
-                wt = ops._bf16_weights(w_now, need_flipped=True)[1]
-            else:
-                wt = wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
-            g = dconv
-            if stride > 1:
-                nn_, _, h, w = x.shape
-                ho, wo = dconv.shape[2], dconv.shape[3]
-                uh, uw = h + 2 * pad[0] - dil[0] * (kh - 1), w + 2 * pad[1] - dil[1] * (kw - 1)
-                g = torch.empty((nn_, cout, uh, uw), dtype=dconv.dtype, device=dev, memory_format=torch.channels_last).zero_()
-                g[:, :, ::stride, ::stride][:, :, :ho, :wo] = dconv
-            dx = conv2d_v2(g, wt, None, 1, bpad, dil)
+            dx = ops.conv2d_data_grad(dconv, wb, ctx.weight_ref, x.shape, stride, pad, dil)
         need_dw = ctx.needs_input_grad[1]
         need_db = has_cbias and ctx.needs_input_grad[2]
         hip_dw = need_dw and cin % 8 == 0 and cout % 8 == 0

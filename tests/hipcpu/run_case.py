@@ -437,7 +437,11 @@ def conv(ops):
                                                  '3x3s2': (16, 16, 3, 2, 1, 1, False), 'dil2': (8, 8, 3, 1, 2, 2, False),
                                                  # Cin == 8: the weight gradient folds the taps into its ci tile (one / two tap groups)
                                                  'stem': (8, 48, 3, 2, 1, 1, False), 'c8_5x5': (8, 24, 5, 1, 2, 1, True),
-                                                 'c8_2x2taps': (8, 72, 3, 1, 1, 1, False)}.items():
+                                                 'c8_2x2taps': (8, 72, 3, 1, 1, 1, False),
+                                                 # strided layers: the data gradient runs per input phase
+                                                 '7x7s2': (16, 8, 7, 2, 3, 1, False), '1x1s2': (8, 16, 1, 2, 0, 1, False),
+                                                 '3x3s2p0': (8, 8, 3, 2, 0, 1, True), '3x3s3': (8, 8, 3, 3, 1, 1, False),
+                                                 '5x5s2': (8, 16, 5, 2, 2, 1, False)}.items():
         x0 = torch.randn(2, cin, 9, 12).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         w0 = (torch.randn(cout, cin, k, k) * 0.2).to(torch.bfloat16).float()       # bf16-representable weights
         b0 = torch.randn(cout) if bias else None

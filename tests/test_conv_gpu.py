@@ -28,6 +28,7 @@ CASES = [
     (2, 960, 14, 30, 160, 1, 1, 0, 1, False, False),    # widest trunk projection (K = 960)
     (3, 8, 57, 121, 48, 3, 2, 0, 1, False, False),      # trunk stem (3 -> 8 padded channels): taps folded in the weight gradient
     (2, 8, 30, 22, 24, 5, 1, 2, 1, True, False),        # Cin == 8 with 25 taps: two folded tap groups
+    (2, 64, 30, 31, 128, 1, 2, 0, 1, False, False),     # ResNet downsample 1x1 / 2: three of the four input phases get no tap
 ]
 
 
