@@ -207,3 +207,39 @@ def test_fused_loss_total_equals_the_per_term_weighting():
     gb = torch.autograd.grad(fused, vals + ws)
     for a, b in zip(ga, gb):
         torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+
+
+def test_strided_data_gradient_phase_plan(monkeypatch):
+    """``ops._strided_dgrad`` (one stride-1 sub-convolution per input phase instead of a convolution over the
+    zero-stuffed gradient): its tap / padding / output-size planning against autograd of F.conv2d, for many kernel
+    sizes, paddings, strides and ragged map sizes.  The sub-convolution launch is replaced by a float64 CPU statement
+    of what stp3_conv2d_fwd computes for (top / left padding, explicit output size, zeros beyond every edge)."""
+    import torch.nn.functional as F
+    from stp3_amd import ops
+
+    def launch(x, wb, bias, stride, pad, dil, out_dtype, sums_ptr=None, out_hw=None):
+        assert stride == 1 and dil == (1, 1) and bias is None and out_hw is not None
+        kh, kw = wb.shape[2:]
+        need_h, need_w = out_hw[0] + kh - 1, out_hw[1] + kw - 1
+        xp = F.pad(x.double(), (pad[1], max(need_w - pad[1] - x.shape[3], 0), pad[0], max(need_h - pad[0] - x.shape[2], 0)))
+        return F.conv2d(xp[:, :, :need_h, :need_w], wb.double()).to(torch.bfloat16)
+
+    monkeypatch.setattr(ops, '_conv2d_launch', launch)
+    g = torch.Generator().manual_seed(21)
+    checked = 0
+    for k, pad, stride, h, w in [(7, 3, 2, 20, 21), (3, 1, 2, 9, 12), (3, 0, 2, 11, 8), (1, 0, 2, 10, 7), (5, 2, 2, 13, 13),
+                                 (3, 1, 3, 10, 11), (4, 1, 2, 12, 9), (2, 0, 2, 8, 8), (5, 1, 2, 15, 10), (3, 2, 2, 7, 9)]:
+        cin, cout = 3, 4
+        x = torch.randn(2, cin, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+        wgt = torch.randn(cout, cin, k, k, generator=g, dtype=torch.float64)
+        y = F.conv2d(x, wgt, None, stride, pad)
+        gy = torch.randn(y.shape, generator=g, dtype=torch.float64).to(torch.bfloat16).double()
+        (want,) = torch.autograd.grad(y, x, gy)
+        wt = wgt.flip(2, 3).transpose(0, 1).contiguous()
+        got = ops._strided_dgrad(gy, wt, x.shape, stride, (pad, pad), {})
+        if got is None:                       # a phase would need negative padding: the caller zero-stuffs instead
+            assert any(t is not None and t[2] < 0 for ph in range(stride) for t in [ops._phase_taps(k, pad, stride, ph)])
+            continue
+        checked += 1
+        torch.testing.assert_close(got.double(), want, rtol=2e-2, atol=2e-2 * float(want.abs().max()))
+    assert checked >= 8
