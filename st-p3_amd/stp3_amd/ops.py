@@ -1098,8 +1098,14 @@ def conv2d_data_grad(dy, wb, weight_ref, x_shape, stride, pad, dil):
         wt = wb if kh == kw == 1 else wb.flip(2, 3)              # a 1x1 kernel has nothing to flip
         wt = wt.transpose(0, 1).contiguous(memory_format=torch.channels_last)
     dx = None
+    # per-phase sub-convolutions do 1 / stride^2 of the zero-stuffed form's multiplications in stride^2 launches plus
+    # as many interleaving copies: measured on the MI355X (scripts/time_strided_dgrad.py) they win on the decoder's
+    # 7x7 / 2 stem (361 -> 195 us, 193 GFLOP zero-stuffed) and lose 15-20 us on its 3x3 / 2 and 1x1 / 2 layers
+    # (<= 18 GFLOP), so the choice goes by the zero-stuffed work
     if stride > 1 and tuple(dil) == (1, 1):
-        dx = _strided_dgrad(dy, wt, x_shape, stride, pad, phase_cache)
+        stuffed_flops = 2.0 * x_shape[0] * x_shape[2] * x_shape[3] * cout * cin * kh * kw
+        if stuffed_flops >= 5e10:
+            dx = _strided_dgrad(dy, wt, x_shape, stride, pad, phase_cache)
     if dx is None:
         g = dy
         if stride > 1:

@@ -458,6 +458,12 @@ def conv(ops):
         yr.backward(gy)
         out[name] = {'y': rel(y.detach(), yr.detach()), 'dx': rel(x.grad.float(), xr.grad), 'dw': rel(w.grad, wr.grad),
                      'db': rel(b.grad, br.grad) if bias else 0.0}
+        if s > 1 and d == 1:
+            # the per-phase route of the data gradient (ops.conv2d_data_grad takes it for big layers only)
+            wt = w0.to(torch.bfloat16).flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+            gyb = gy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            dxp = ops._strided_dgrad(gyb, wt, tuple(x0.shape), s, (p, p), {})
+            out[name]['dx_phases'] = rel(dxp.float(), xr.grad) if dxp is not None else -1.0
     return out
 
 

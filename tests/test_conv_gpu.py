@@ -62,6 +62,31 @@ def test_conv2d_forward_and_input_gradient(case):
         assert wa.grad.shape == wgt.shape
 
 
+@pytest.mark.parametrize('case', [(2, 64, 50, 50, 64, 7, 3), (2, 64, 31, 30, 128, 3, 1), (2, 64, 30, 31, 128, 1, 0),
+                                  (1, 128, 25, 25, 256, 3, 1), (2, 16, 20, 21, 8, 5, 2), (2, 8, 57, 121, 48, 3, 0)])
+def test_strided_data_gradient_per_phase(case):
+    """``ops._strided_dgrad`` (what ``conv2d_data_grad`` takes for big strided layers: the decoder's 7x7 / 2 stem at the
+    bench size) on its own, against autograd of F.conv2d and against the zero-stuffed route."""
+    from stp3_amd import ops
+    n, cin, h, w, cout, k, pad = case
+    g = torch.Generator().manual_seed(k * 100 + cin)
+    x = torch.randn(n, cin, h, w, generator=g).cuda().requires_grad_()
+    wgt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).cuda().to(torch.bfloat16)
+    y = F.conv2d(x, wgt.float(), None, 2, pad)
+    gy = torch.randn(y.shape, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    (want,) = torch.autograd.grad(y, x, gy.float())
+    wb = wgt.contiguous(memory_format=torch.channels_last)
+    wt = wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+    cache = {}
+    got = ops._strided_dgrad(gy, wt, tuple(x.shape), 2, (pad, pad), cache)
+    assert got is not None and got.shape == x.shape and len(cache) >= 1
+    torch.testing.assert_close(got.float(), want, rtol=1e-2, atol=2e-2)
+    again = ops._strided_dgrad(gy, wt, tuple(x.shape), 2, (pad, pad), cache)          # cached sub-kernels
+    assert torch.equal(got, again)
+    stuffed = ops.conv2d_data_grad(gy, wb, None, tuple(x.shape), 2, (pad, pad), (1, 1))   # small layer: zero-stuffed route
+    torch.testing.assert_close(got.float(), stuffed.float(), rtol=1e-2, atol=2e-2)
+
+
 def test_conv2d_rejects_what_it_cannot_do():
     from stp3_amd import ops
     x = torch.randn(1, 3, 8, 8).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
