@@ -753,12 +753,15 @@ def fuzz(ops, seed=1):
     # ---- batchnorm
     for it in range(60):
         n = random.randint(2, 4); c = random.choice([1, 3, 7, 8, 9, 16, 24, 33, 40, 64, 70]); h, w = random.randint(1, 9), random.randint(2, 9)
-        if h * w <= 1: continue
+        if it % 6 == 5: h = w = 1                                # 1x1 descriptors (ASPP / pyramid pooling) run on the kernels too
         dt = random.choice([torch.float32, torch.bfloat16]); training = random.random() < 0.7
         act = random.choice([ops.ACT_NONE, ops.ACT_RELU, ops.ACT_SWISH]); rm = random.choice([ops.RES_NONE, ops.RES_BEFORE_ACT, ops.RES_AFTER_ACT])
         with_sb, with_os = random.random() < 0.3, random.random() < 0.3
         sliced = random.random() < 0.3
-        cfgd = dict(n=n, c=c, h=h, w=w, dt=str(dt), tr=training, act=act, rm=rm, sb=with_sb, os=with_os, sliced=sliced)
+        padded = (not sliced) and c % 8 != 0 and random.random() < 0.5     # zero-padded channel lanes (stp3_bn_dims.cpad)
+        cp = (c + 7) // 8 * 8
+        cfgd = dict(n=n, c=c, h=h, w=w, dt=str(dt), tr=training, act=act, rm=rm, sb=with_sb, os=with_os, sliced=sliced,
+                    padded=padded)
         try:
             bn_a, bn_b = torch.nn.BatchNorm2d(c, eps=1e-3), torch.nn.BatchNorm2d(c, eps=1e-3)
             with torch.no_grad():
@@ -772,13 +775,21 @@ def fuzz(ops, seed=1):
             sb0 = torch.randn(n, c) * 0.3 if with_sb else None; osc = torch.rand(n) + 0.5 if with_os else None
             gy = torch.randn(n, c, h, w).to(dt).contiguous(memory_format=cl)
             res = []
+            def lanes(t):                  # the tensor in cp-lane rows, NaN in the padding lanes
+                full = torch.full((n, cp, h, w), float('nan'), dtype=t.dtype).contiguous(memory_format=cl)
+                full[:, :c] = t
+                return full
             for kernel, bn in ((True, bn_a), (False, bn_b)):
                 cast = (lambda t: t.clone()) if kernel else (lambda t: t.float())
-                x = cast(x0).detach().requires_grad_(); r = cast(r0).requires_grad_() if r0 is not None else None
+                pad_in = lanes if (kernel and padded) else (lambda t: t)
+                x = pad_in(cast(x0).detach()).requires_grad_(); r = pad_in(cast(r0)).requires_grad_() if r0 is not None else None
                 sb = sb0.clone().requires_grad_() if sb0 is not None else None
                 y = (fused.bn_act if kernel else fused.bn_act_reference)(bn, x, act, r, rm, sb, osc)
-                y.backward(gy if kernel else gy.float())
-                res.append([('y', y.detach().float()), ('dx', x.grad.float()), ('dg', bn.weight.grad), ('db', bn.bias.grad)] + ([('dr', r.grad.float())] if r is not None else []) + ([('dsb', sb.grad)] if sb is not None else []) + [('rm', bn.running_mean.clone()), ('rv', bn.running_var.clone())])
+                y.backward(pad_in(gy) if kernel else gy.float())
+                cut = (lambda t: t[:, :c]) if (kernel and padded) else (lambda t: t)
+                if kernel and padded and not (bool((y.detach()[:, c:] == 0).all()) and bool((x.grad[:, c:] == 0).all())):
+                    bad.append(('bn', cfgd, 'padding lanes not zero', 0.0))
+                res.append([('y', cut(y.detach()).float()), ('dx', cut(x.grad).float()), ('dg', bn.weight.grad), ('db', bn.bias.grad)] + ([('dr', cut(r.grad).float())] if r is not None else []) + ([('dsb', sb.grad)] if sb is not None else []) + [('rm', bn.running_mean.clone()), ('rv', bn.running_var.clone())])
             tol = 5e-4 if dt == torch.float32 else 3e-2          # float32: sums of <= 40 values that cancel (C = 1, 3 x 4 maps)
             chk('bn', cfgd, [(a[0], a[1], b[1]) for a, b in zip(*res)], tol)
         except Exception as e:
