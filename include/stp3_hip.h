@@ -150,12 +150,15 @@ int stp3_depth_softmax(const stp3_lift_dims* dims, const float* logits, float* p
  *   Pool_k[c][v] = sum over points p of frame k with vox(p) == v of softmax_D(logits)[p] * feat[pix(p)][c].
  * Replaces stp3.py:215 (depth softmax), :216-221 (outer product, never materialised), geometry.py:302-318
  * (VoxelsSumming.forward) and stp3.py:279-299 (scatter, discount, permute).  Two kernels:
- *   pass 1  one wave per image column: softmax of the column's logits (global -> LDS directly, kept in LDS, written
- *           to prob_cm for the backward pass); every feature and logit is read from memory exactly once.  Columns of
- *           at most 32 rows with C == 64: the run sums are a matrix product  masked probabilities [runs x rows] x
- *           features [rows x C]  on the matrix cores (v_mfma_f32_32x32x2_f32), 32 runs = 32 slots per tile.  Other
- *           shapes: lane = channel, ONE walk over the rows with an accumulator per depth bin (v_fmac_f32 with a DPP row
- *           broadcast of the probability); a finished run's C-vector goes to its slot
+ *   pass 1  per image column; the column's logits and features go global -> LDS directly and every feature and logit
+ *           is read from memory exactly once.  Columns of at most 32 rows with C == 64 (lift_column_mma_kernel): ONE
+ *           WORKGROUP of four waves per column -- the waves share the staged column, split the rows of the softmax
+ *           (in place in LDS) and deal out the 32-run tiles; the run sums are a matrix product  masked probabilities
+ *           [runs x rows] x features [rows x C]  on the matrix cores (v_mfma_f32_32x32x2_f32), 32 runs = 32 slots per
+ *           tile; this path does NOT write prob_cm (its backward recomputes the probabilities from the logits).
+ *           Other shapes (lift_column_kernel): one wave per column, lane = channel, ONE walk over the rows with an
+ *           accumulator per depth bin (v_fmac_f32 with a DPP row broadcast of the probability); a finished run's
+ *           C-vector goes to its slot; the probabilities are written to prob_cm for the general backward
  *   pass 2  16 lanes per voxel add the voxel's slots (ascending) and carry the discounted state through the T
  *           frames in registers; every BEV row (256 bytes) is written once
  * Deterministic (fixed summation order, no atomics).

@@ -192,7 +192,8 @@ def _fusable_conv_bn(conv, bn, x):
     BatchNorm statistics (ops_fused.conv_bn_act): the statistics pass over the convolution output disappears."""
     return (type(conv) is nn.Conv2d and isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.training
             and bn.track_running_stats and conv.groups == 1 and conv.padding_mode == 'zeros'
-            and not isinstance(conv.padding, str) and x.dim() == 4 and _use_mfma(x, conv.weight, conv.stride))
+            and not isinstance(conv.padding, str) and x.dim() == 4 and _use_mfma(x, conv.weight, conv.stride)
+            and ops.conv2d_stats_supported(x, conv.weight, conv.stride, conv.padding, conv.dilation))
 
 
 def run_fused(seq, x):

@@ -33,8 +33,10 @@ class SpatialRegressionLoss(nn.Module):
         loss = loss * _future_discounts(self.future_discount, seq_len, n_present, loss).view(1, seq_len, 1, 1, 1)
         # mean over the unmasked pixels, 0 when there are none (losses.py:31-33, :43) -- as a masked sum: boolean
         # indexing and the emptiness test would each cost a device -> host synchronisation per call
+        # (torch.where, not a product: a non-finite prediction at an IGNORED pixel must not reach the sum -- inf * 0 is
+        # NaN, while the reference's loss[mask] drops the pixel)
         count = mask.sum()
-        return (loss * mask).sum() / count.clamp_min(1).to(loss.dtype)
+        return torch.where(mask, loss, loss.new_zeros(())).sum() / count.clamp_min(1).to(loss.dtype)
 
 
 class SegmentationLoss(nn.Module):

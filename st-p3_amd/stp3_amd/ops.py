@@ -915,10 +915,31 @@ def _conv2d_wgrad(dy, x, wshape, stride, pad, dil):
     return dw
 
 
+_CONV_MAX_STAT_TILES = 65536          # stp3_conv2d_fwd: row tiles of 128 pixels the statistics epilogue can reduce
+
+
 def conv2d_supported(x, weight, stride, groups=1):
-    """What stp3_conv2d_fwd takes: GPU, dense (groups == 1), square stride, input channels a multiple of 8."""
+    """What stp3_conv2d_fwd takes: GPU, dense (groups == 1), square stride, input channels a multiple of 8, and an
+    input small enough for the kernel's 32-bit element offsets (N*H*W*ld < 2^31; the output has at most as many
+    pixels for stride >= 1 up to the padding, checked again by the library)."""
     s = _pair(stride)
-    return x.is_cuda and x.dim() == 4 and groups == 1 and s[0] == s[1] and weight.shape[1] % 8 == 0
+    if not (x.is_cuda and x.dim() == 4 and groups == 1 and s[0] == s[1] and weight.shape[1] % 8 == 0):
+        return False
+    n, c, h, w = x.shape
+    return n * h * w * max(c, weight.shape[0]) < (1 << 31)
+
+
+def conv2d_stats_supported(x, weight, stride, padding=0, dilation=1):
+    """``conv2d_supported`` + the bound of the BatchNorm-statistics epilogue: at most 65 536 row tiles of 128 output
+    pixels (8.4 M pixels: batch 17 per GPU at the 112 x 240 trunk layers).  Beyond it the caller takes the
+    convolution and the BatchNorm as separate operators (the statistics pass has no such bound)."""
+    if not conv2d_supported(x, weight, stride):
+        return False
+    s, p, d = _pair(stride), _pair(padding), _pair(dilation)
+    n, _, h, w = x.shape
+    ho = _conv_out(h, weight.shape[2], s[0], p[0], d[0])
+    wo = _conv_out(w, weight.shape[3], s[1], p[1], d[1])
+    return (n * ho * wo + 127) // 128 <= _CONV_MAX_STAT_TILES
 
 
 # bf16 copies of the convolution weights (forward layout and the tap-flipped / channel-swapped layout of the
@@ -933,7 +954,11 @@ _WEIGHT_EPOCH = [0]
 
 
 class _WeightShadows:
-    def __init__(self):
+    """The shadows of the parameters of ONE device (the table holds device pointers and the rewrite is one launch
+    on that device)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
         self.entries = {}            # id(parameter) -> entry
         self.order = []
         self.table = None            # stp3_wprep_entry[n] in device memory
@@ -955,11 +980,11 @@ class _WeightShadows:
                'wt': torch.empty((cin, cout, kh, kw), **opts)}         # memory [Cin][KH][KW][Cout], taps flipped
         self.entries[id(weight)] = ent
         self.order = [e for e in self.order if e['ref']() is not None and e is not ent] + [ent]
-        self._build_table(weight.device)
+        self._build_table()
         self.refresh()
         return ent
 
-    def _build_table(self, device):
+    def _build_table(self):
         arr = (_lib.WprepEntry * len(self.order))()
         block = 0
         for rec, e in zip(arr, self.order):
@@ -971,7 +996,7 @@ class _WeightShadows:
             rec.cout, rec.cin, rec.kh, rec.kw = cout, cin, kh, kw
             block += (w.numel() + 255) // 256
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        self.table = host.to(device)
+        self.table = host.to(self.device)
         self.total_blocks = block
 
     def refresh(self):
@@ -983,28 +1008,55 @@ class _WeightShadows:
             self.entries = {id(e['ref']()): e for e in self.order}
             if not self.order:
                 return
-            self._build_table(self.table.device)
-        check(_lib.lib().stp3_conv2d_prep_weights(_ptr(self.table), len(self.order), self.total_blocks, _stream()),
-              'stp3_conv2d_prep_weights')
+            self._build_table()
+        with torch.cuda.device(self.device):       # the launch goes to the device that owns the pointers in the table
+            check(_lib.lib().stp3_conv2d_prep_weights(_ptr(self.table), len(self.order), self.total_blocks, _stream()),
+                  'stp3_conv2d_prep_weights')
         for e in self.order:
             e['version'] = e['ref']()._version
             e.pop('phases', None)                  # sub-kernels cut from the flipped shadow (_strided_dgrad)
 
 
-_SHADOWS = _WeightShadows()
+_SHADOW_TABLES = {}                                # device -> _WeightShadows
+
+
+def _shadows(device):
+    device = torch.device(device)
+    tab = _SHADOW_TABLES.get(device)
+    if tab is None:
+        tab = _SHADOW_TABLES[device] = _WeightShadows(device)
+    return tab
+
+
+def weight_stamp(weight):
+    """What identifies the VALUES a parameter's bf16 shadows were cut from: the parameter's version counter and the
+    epoch of out-of-band updates (``invalidate_weight_cache``).  The autograd operators record it at forward time and
+    compare at backward time: the shadows are rewritten in place behind autograd's back, so a weight update between a
+    forward and its backward would otherwise silently differentiate against the NEW weights where torch raises
+    'modified by an inplace operation'."""
+    return (weight._version, _WEIGHT_EPOCH[0])
+
+
+def check_weight_stamp(weight, stamp, what):
+    if stamp is not None and weight_stamp(weight) != stamp:
+        raise RuntimeError(f'{what}: the convolution weight was updated between this forward and its backward '
+                           f'(version / epoch {stamp} -> {weight_stamp(weight)}); its bf16 shadow no longer holds the '
+                           f'values the forward used')
 
 
 def invalidate_weight_cache():
     """Call after updating parameters through storage the parameter's version counter does not see (the flat
     buffers of ``parallel.FlatAdam``); in-place updates of the parameters themselves are detected automatically."""
     _WEIGHT_EPOCH[0] += 1
-    _SHADOWS.refresh()
+    for tab in _SHADOW_TABLES.values():
+        tab.refresh()
 
 
 def _bf16_weights(weight, need_flipped=False):
     if isinstance(weight, torch.nn.Parameter) and weight.requires_grad \
             and weight.dtype == torch.float32 and weight.is_cuda:
-        ent = _SHADOWS.lookup(weight) or _SHADOWS.register(weight)
+        tab = _shadows(weight.device)
+        ent = tab.lookup(weight) or tab.register(weight)
         return ent['wb'], ent['wt']
     key = id(weight)
     ent = _WEIGHT_CACHE.get(key)
@@ -1091,7 +1143,7 @@ def conv2d_data_grad(dy, wb, weight_ref, x_shape, stride, pad, dil):
     phase_cache = None
     if weight_ref is not None and weight_ref.is_leaf and weight_ref.requires_grad:
         wt = _bf16_weights(weight_ref, need_flipped=True)[1]
-        ent = _SHADOWS.lookup(weight_ref) if isinstance(weight_ref, torch.nn.Parameter) else None
+        ent = _shadows(weight_ref.device).lookup(weight_ref) if isinstance(weight_ref, torch.nn.Parameter) else None
         if ent is not None and ent['wt'] is wt:
             phase_cache = ent.setdefault('phases', {})
     else:
@@ -1130,6 +1182,7 @@ class _Conv2dMfma(torch.autograd.Function):
         fb = _f32(bias)
         y = _conv2d_launch(x, wb, fb, stride, pad, dil, out_dtype)
         ctx.weight_ref = weight
+        ctx.weight_stamp = weight_stamp(weight)
         ctx.save_for_backward(x, wb)
         ctx.cfg = (stride, pad, dil, bias is not None, weight.dtype, None if bias is None else bias.dtype)
         return y
@@ -1137,6 +1190,7 @@ class _Conv2dMfma(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, wb = ctx.saved_tensors
+        check_weight_stamp(ctx.weight_ref, ctx.weight_stamp, 'conv2d backward')
         stride, pad, dil, has_bias, wdtype, bdtype = ctx.cfg
         cout_true, cin, kh, kw = wb.shape
         dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)

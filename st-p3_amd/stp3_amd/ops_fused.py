@@ -75,6 +75,7 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.save_for_backward(x, wb, yc, res if res_mode == ops.RES_BEFORE_ACT else None, g32, b32, stat, osc)
         ctx.cfg = (dims, count, world, group, stride, pad, dil, cbias is not None)
         ctx.weight_ref = weight
+        ctx.weight_stamp = ops.weight_stamp(weight)
         ctx.dtypes = (weight.dtype, None if cbias is None else cbias.dtype, None if gamma is None else gamma.dtype,
                       None if beta is None else beta.dtype, None if res is None else res.dtype)
         return out
@@ -82,6 +83,7 @@ class _ConvBnAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, wb, yc, res, g32, b32, stat, osc = ctx.saved_tensors
+        ops.check_weight_stamp(ctx.weight_ref, ctx.weight_stamp, 'conv_bn_act backward')
         dims, count, world, group, stride, pad, dil, has_cbias = ctx.cfg
         wdt, cbdt, gdt, bdt, rdt = ctx.dtypes
         n, rows, c = dims.N, dims.rows, dims.C

@@ -45,10 +45,19 @@ def init_distributed(backend=None):
     return rank, world, local
 
 
-def convert_sync_batchnorm(module, process_group=None):
-    """BatchNorm -> cross-replica BatchNorm (train.py:47 ``sync_batchnorm=True``): the batch statistics
-    are those of the global batch, so N GPUs x B/N samples equal 1 GPU x B samples."""
-    return nn.SyncBatchNorm.convert_sync_batchnorm(module, process_group)
+def convert_sync_batchnorm(module, enabled=True):
+    """Cross-replica BatchNorm on / off for every BatchNorm layer of ``module`` (train.py:47 ``sync_batchnorm=True``:
+    the batch statistics are those of the global batch, so N GPUs x B/N samples equal 1 GPU x B samples).
+
+    Unlike ``nn.SyncBatchNorm.convert_sync_batchnorm`` no module is replaced: the statistics exchange is part of the
+    product's own BatchNorm operator (``layers.fused.bn_act`` / ``ops_fused.conv_bn_act``: one all-reduce of the
+    per-channel sums per layer and direction), which every BatchNorm module already runs through and which is ON by
+    default whenever ``torch.distributed`` is initialised.  This switch only sets the per-layer opt-out the operator
+    reads (``stp3_local_stats``); class, parameter names and state-dict keys stay the reference's."""
+    for m in module.modules():
+        if isinstance(m, nn.modules.batchnorm._BatchNorm):
+            m.stp3_local_stats = not enabled
+    return module
 
 
 class GradientBuckets:
@@ -106,8 +115,11 @@ class GradientBuckets:
                 view = torch.as_strided(flat_param, size, stride, off)
                 view.copy_(p.data)
                 p.data = view
-                p.grad = torch.as_strided(flat, size, stride, off)
-                views.append(p.grad)
+                gview = torch.as_strided(flat, size, stride, off)
+                views.append(gview)
+                # gather mode: autograd must find no gradient tensor on the parameter, or it accumulates in place into
+                # the view and ``_gather`` cannot tell "already in the bucket" from "took no part in this step"
+                p.grad = None if self.gather else gview
                 off += p.numel()
                 self._bucket_of[p] = len(self.buckets)
         self.buckets.append((flat, list(params)))
@@ -138,8 +150,13 @@ class GradientBuckets:
         flat, params = self.buckets[i]
         views = self.grad_views[i]
         have = [(v, p.grad) for v, p in zip(views, params) if p.grad is not None and p.grad is not v]
-        if len(have) < len(params):
-            flat.zero_()                                 # parameters that took no part in this step
+        # p.grad is its view: a backward that ran without a preceding ``zero_grad()`` accumulated in place -- already in
+        # the bucket, keep it.  p.grad is None: the parameter took no part in this step -- its slice must read zero.
+        absent = [v for v, p in zip(views, params) if p.grad is None]
+        if len(absent) == len(params):
+            flat.zero_()
+        elif absent:
+            torch._foreach_zero_(absent)
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         for v, p in zip(views, params):

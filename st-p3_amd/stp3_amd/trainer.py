@@ -224,6 +224,44 @@ class TrainingModule(nn.Module):
         output, labels, _ = self.shared_step(batch, False)
         return {'step_val_seg_iou_dynamic': self.metric_vehicle_val.compute()[1]}
 
+    # ------------------------------------------------------------------------------------------
+    # checkpoint surface: what train.py:21-29 and evaluate.py:31 call on the reference's module
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location='cpu', strict=True, **overrides):
+        """``TrainingModule.load_from_checkpoint(path, strict=True)`` of the Lightning surface (evaluate.py:31): the
+        checkpoint is the dictionary Lightning writes -- ``hyper_parameters`` (the config as a plain dict,
+        trainer.py:19) and ``state_dict`` (``model.*`` keys incl. the learned loss weights) -- and the module is
+        rebuilt from the former before the latter is loaded.  ``overrides`` replace top-level hyper-parameters."""
+        ckpt = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
+        hparams = ckpt.get('hyper_parameters', ckpt.get('hparams'))
+        if hparams is None:
+            raise KeyError(f'{checkpoint_path}: no "hyper_parameters" entry (not a Lightning checkpoint of TrainingModule)')
+        if isinstance(hparams, dict) and set(hparams) == {'hparams'}:        # saved through save_hyperparameters()
+            hparams = hparams['hparams']
+        hparams = {**dict(hparams), **overrides}
+        module = cls(hparams)
+        module.load_state_dict(ckpt['state_dict'], strict=strict)
+        return module
+
+    def load_pretrained_weights(self, path, map_location='cpu'):
+        """train.py:21-29 (``PRETRAINED.LOAD_WEIGHTS``): initialise from a single-image model -- every tensor of the
+        checkpoint's ``state_dict`` whose key exists here and does not belong to a decoder, non-strict.  Returns the
+        keys that were loaded."""
+        weights = torch.load(path, map_location=map_location, weights_only=False)['state_dict']
+        state = self.state_dict()
+        weights = {k: v for k, v in weights.items() if k in state and 'decoder' not in k}
+        self.load_state_dict(weights, strict=False)
+        from . import ops
+        if any(p.is_cuda for p in self.parameters()):
+            ops.invalidate_weight_cache()                # bf16 shadows of the convolution weights follow the new values
+        return sorted(weights)
+
+    def checkpoint(self):
+        """The dictionary ``load_from_checkpoint`` reads (Lightning's layout, minus optimizer / loop state)."""
+        from . import ops
+        ops.flush_batch_counters()
+        return {'hyper_parameters': dict(self.hparams), 'state_dict': self.state_dict()}
+
     def configure_optimizers(self):
         return torch.optim.Adam(self.model.parameters(), lr=self.cfg.OPTIMIZER.LR,
                                 weight_decay=self.cfg.OPTIMIZER.WEIGHT_DECAY)

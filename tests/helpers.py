@@ -146,3 +146,54 @@ def check_plan_structure(plan, vox):
         assert np.array_equal(lists[frame0:frame0 + len(slots)], slots[by_voxel]), f'run lists of frame {bt}'
     assert int(plan.counts.abs().max()) == 0, 'count scratch not left clean'
     return int(col_off[-1])
+
+
+# ----------------------------------------------------------------------------------------------
+# per-block taps of a whole training step (oracle/make_golden_step.py on the reference, tests/test_step_parity_gpu.py
+# on the product): input / output / output-gradient fingerprints of every block, same code on both sides
+# ----------------------------------------------------------------------------------------------
+BLOCK_CLASS_NAMES = ('MBConvBlock', 'BasicBlock', 'UpsamplingAdd', 'UpsamplingConcat', 'TemporalBlock', 'DeepLabHead')
+DECODER_HEADS = {'segmentation': 'segmentation_head', 'pedestrian': 'pedestrian_head', 'hdmap': 'hdmap_head',
+                 'instance_center': 'instance_center_head', 'instance_offset': 'instance_offset_head',
+                 'instance_flow': 'instance_future_head'}
+
+
+def fingerprint(t, n=512):
+    """(strided sample in logical element order, [norm]) of a tensor, float64 norm."""
+    t = t.detach()
+    return sample(t.float(), n).cpu().numpy(), np.array([t.double().norm().item()])
+
+
+class BlockTaps:
+    """Forward hooks on every block (by class NAME, so that the reference's classes and the product's match alike):
+    keeps the block's first tensor argument's fingerprint, the output tensor (gradient retained) and, after
+    ``collect()``, the fingerprints of output and output-gradient."""
+
+    def __init__(self, model, extra=()):
+        self.hooks, self.outs, self.fp = [], {}, {}
+        self.names = [n for n, m in model.named_modules() if type(m).__name__ in BLOCK_CLASS_NAMES]
+        self.names += list(extra)
+        mods = dict(model.named_modules())
+        for n in self.names:
+            self.hooks.append(mods[n].register_forward_hook(self._hook(n)))
+
+    def _hook(self, name):
+        def hook(mod, args, out):
+            if name in self.outs or not torch.is_tensor(out) or not out.requires_grad:
+                return
+            out.retain_grad()
+            self.outs[name] = out
+            x = next((a for a in args if torch.is_tensor(a) and a.is_floating_point()), None)
+            if x is not None:
+                self.fp[f'{name}/in'], self.fp[f'{name}/in_norm'] = fingerprint(x)
+        return hook
+
+    def collect(self):
+        for h in self.hooks:
+            h.remove()
+        for n, out in self.outs.items():
+            self.fp[f'{n}/out'], self.fp[f'{n}/out_norm'] = fingerprint(out)
+            if out.grad is not None:
+                self.fp[f'{n}/gout'], self.fp[f'{n}/gout_norm'] = fingerprint(out.grad)
+        self.outs = {}
+        return self.fp

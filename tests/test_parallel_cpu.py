@@ -55,6 +55,32 @@ def test_clip_grad_norm_matches_torch():
         torch.testing.assert_close(pb.grad, pa.grad, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize('gather', [True, False])
+def test_backward_without_zero_grad_keeps_the_gradients(gather):
+    """The first step after construction (and any step after ``model.zero_grad(set_to_none=False)``) has no
+    ``buckets.zero_grad()`` in front of it: the gradients must still reach the flat buffers, and a second backward must
+    accumulate like plain autograd does (round-2 advisor finding: gather mode wiped them)."""
+    a, b = _toy(), _toy()
+    buckets = GradientBuckets(b, bucket_bytes=2048, gather=gather)
+    x = torch.randn(4, 3, 6, 6)
+    a(x).square().sum().backward()
+    b(x).square().sum().backward()
+    buckets.finish()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert pb.grad is not None and pb.grad.abs().sum() > 0
+        torch.testing.assert_close(pb.grad, pa.grad, rtol=1e-6, atol=1e-7)
+    # second backward on top, still no zero_grad(): accumulation in place into the bucket views
+    a(x).square().sum().backward()
+    b(x).square().sum().backward()
+    buckets._finished = False
+    buckets._launched = [False] * len(buckets.buckets)
+    buckets.finish()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        torch.testing.assert_close(pb.grad, pa.grad, rtol=1e-6, atol=1e-7)
+    flat = torch.cat([f for f, _ in buckets.buckets])
+    assert flat.abs().sum() > 0
+
+
 class _WithUnusedParameter(nn.Module):
     def __init__(self):
         super().__init__()
