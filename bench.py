@@ -214,19 +214,45 @@ def lift_roofline(device, batch, model, iters=30):
     return roof, {k: round(v['avg_ms'], 4) for k, v in prof.items()}
 
 
-def gpu_busy_from_profile():
-    """Kernel time / wall time of the steady-state steps of this workload, from the committed rocprofv3 kernel trace
-    (scripts/gpu_prof.sh -> profiles/*_c3_steady_kernels.txt): a profile of the same command, not of this run."""
-    import glob
-    import re
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_c3_steady_kernels.txt')))
-    for path in reversed(files):
-        if path.endswith('_before.txt'):
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak of one MI355X (MI355X_MICROARCH.md; not the 2:1-sparsity headline)
+CONV_GFLOP_PER_SAMPLE_FWD = 292.4   # 2 x 146.2 GMAC (trunk, heads, temporal model, decoder), T = 3
+
+
+def family_rooflines(step, batch_size, steps=3):
+    """Per-family rooflines of the training step, MEASURED IN THIS RUN: `steps` extra steps (after the timed region, so
+    that `value` is untouched) with every C-ABI call bracketed by events on its own stream (stp3_amd/profiling.py).
+      conv       : algorithmic flops of SURVEY.md section 8(d) (forward x 3 for forward + data + weight gradient) / time
+                   of ALL stp3_conv2d_fwd / _wgrad calls / 2.5 PF; `executed_tflop` = the flops of the launched shapes
+                   (channel padding 3 -> 8 / 35 -> 40 and zero-stuffed strided data gradients included)
+      hbm families: compulsory bytes of every call (each tensor of its interface once) / time / 8 TB/s."""
+    from stp3_amd import profiling
+    profiling.enable(True)
+    for _ in range(steps):
+        step()
+    fam = profiling.summary()
+    profiling.enable(False)
+    out = {'steps': steps, 'timing': 'HIP events around each C-ABI call on its launch stream, in-run'}
+    conv = [fam[k] for k in ('conv_fwd_dgrad', 'conv_wgrad') if k in fam]
+    if conv:
+        ms = sum(f['ms'] for f in conv) / steps
+        alg = 3.0 * CONV_GFLOP_PER_SAMPLE_FWD * 1e9 * batch_size
+        ach = alg / (ms * 1e-3) / 1e12
+        out['conv'] = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                       'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'ms_per_step': round(ms, 3),
+                       'algorithmic_tflop_per_step': round(alg / 1e12, 3),
+                       'executed_tflop_per_step': round(sum(f['work'] for f in conv) / steps / 1e12, 3),
+                       'calls_per_step': sum(f['calls'] for f in conv) // steps,
+                       'split_ms': {k: round(fam[k]['ms'] / steps, 3) for k in ('conv_fwd_dgrad', 'conv_wgrad') if k in fam}}
+    for name in ('batchnorm', 'depthwise', 'squeeze_excite', 'mbconv'):
+        if name not in fam:
             continue
-        m = re.search(r'window wall ([\d.]+) ms, kernel-time sum ([\d.]+) ms \(GPU busy (\d+)%\)', open(path).readline())
-        if m:
-            return {'value': round(float(m.group(2)) / float(m.group(1)), 3), 'source': os.path.relpath(path, ROOT)}
-    return None
+        f = fam[name]
+        ms = f['ms'] / steps
+        ach = f['work'] / steps / (ms * 1e-3) / 1e9
+        out[name] = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(ach / HBM_PEAK_GBS, 4), 'ms_per_step': round(ms, 3),
+                     'algorithmic_gb_per_step': round(f['work'] / steps / 1e9, 3), 'calls_per_step': f['calls'] // steps}
+    return out
 
 
 def _log(msg):
@@ -346,6 +372,9 @@ def main():
     _log(f'timed steps done: {elapsed / args.steps * 1e3:.2f} ms/step')
     assert DRYRUN or torch.isfinite(loss).item(), 'loss is not finite'
 
+    fam = None
+    if not args.no_roofline and not DRYRUN:
+        fam = family_rooflines(step, args.batch)             # every rank: the steps contain the collectives
     if rank == 0:
         module.model.prebuilt_plan = None
         roof, kernel_ms = (None, {}) if args.no_roofline else lift_roofline(device, batch, module.model)
@@ -360,8 +389,11 @@ def main():
                        'host_options': host_options},
             'roofline': roof,
             'kernel_ms': kernel_ms,
-            'gpu_busy': gpu_busy_from_profile(),
+            'roofline_families': fam,
         }
+        if fam:
+            line['roofline_conv'] = fam.get('conv')
+            line['roofline_bn'] = fam.get('batchnorm')
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line['cpu_baseline'] = cpu_baseline(workload)

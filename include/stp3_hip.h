@@ -391,6 +391,53 @@ int stp3_se_mlp_bwd(const stp3_se_mlp_dims* dims, const float* dgate, const floa
                     float* dw1, float* db1, float* dw2, float* db2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * MBConv block passes (csrc/stp3_mbconv.hip, csrc/stp3_dwconv.hip): the EfficientNet block that
+ * stp3/models/encoder.py:57-97 drives 22 times per image,
+ *     E0 = expand(x) -> E1 = swish(BN0(E0)) -> E2 = depthwise(E1) -> S = swish(BN1(E2))
+ *     -> gate = sigmoid(MLP(mean_hw S)) -> A = S * gate -> y = BN2(project(A)) (+ x),
+ * with BatchNorm-1, its swish and the squeeze-excite gate applied where the data is consumed instead of in passes of
+ * their own over the expanded tensor (the tensor `S` is never written), forward and backward.
+ *
+ *   stp3_dwconv2d_fwd_stats : stp3_dwconv2d_fwd + sums [2][C] = per-channel sum / sum of squares of the ROUNDED outputs
+ *                             (the statistics of BN1; no stp3_bn_stats pass over E2).  workspace:
+ *                             stp3_dwconv2d_fwd_stats_workspace(dims) bytes; deterministic.
+ *   stp3_bn_finalize        : sums [2][C] over `count` elements -> coef [4][C] = scale (= gamma * invstd), shift
+ *                             (= beta - mean * scale), mean, invstd; updates running_mean / running_var (momentum, unbiased
+ *                             variance) when non-NULL -- the arithmetic of stp3_bn_apply_fwd's training mode, bit for bit.
+ *   stp3_se_pool_act        : out [N][C] = sum over rows of act(scale[c] * x + shift[c])    (the squeeze of S from E2)
+ *   stp3_mbconv_scale_act   : y = act(scale[c] * x + shift[c]) * gate[n][c]                  (A from E2; gate may be NULL)
+ *   stp3_mbconv_bwd_reduce  : ONE pass over (da = dL/dA, x = E2): sums5 [5][N][C] (quantity-major) =
+ *                               [0] sum da*S  (the gate's gradient, input of stp3_se_mlp_bwd)
+ *                               [1] sum da*S'   [2] sum da*S'*xhat   [3] sum S'   [4] sum S'*xhat
+ *                             with S = act(pre), S' = act'(pre), pre = scale*x + shift, xhat = (x - mean) * invstd.
+ *   stp3_mbconv_bwd_coef    : gsums [2][C]:  sum g = sum_n gate*[1] + dpooled*[3],  sum g*xhat = sum_n gate*[2] + dpooled*[4]
+ *                             where g = (da*gate + dpooled) * S' is the gradient at the BatchNorm-1 output
+ *                             (dbeta1 = gsums[0], dgamma1 = gsums[1]); the host may all-reduce gsums over ranks.
+ *   stp3_mbconv_bwd_apply   : dx = scale * (g - gsums[0]/count - xhat * gsums[1]/count)   (= dL/dE2), same dtype as x
+ *   x, da, dx, y : [N][rows][ld] channels-last, dims.dtype (bf16: C, ld multiples of 8; f32: of 4; 16-byte aligned),
+ *   dims.ld = row stride of x; ldg / ldy = row stride of da and dx / of y.  coef as written by stp3_bn_finalize.
+ *   gate, dpooled [N][C] float32 (dpooled: the per-pixel term stp3_se_mlp_bwd returns).  workspace:
+ *   stp3_mbconv_workspace_bytes(dims).  Deterministic, no atomics.
+ */
+int stp3_dwconv2d_fwd_stats_workspace(const stp3_dwconv_dims* dims, size_t* bytes);
+int stp3_dwconv2d_fwd_stats(const stp3_dwconv_dims* dims, const void* x, const float* w, void* y, float* sums,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int stp3_bn_finalize(const float* sums, int32_t C, double count, const float* gamma, const float* beta, float eps,
+                     float momentum, float* running_mean, float* running_var, float* coef, void* stream);
+int stp3_mbconv_workspace_bytes(const stp3_se_dims* dims, size_t* bytes);
+int stp3_se_pool_act(const stp3_se_dims* dims, const void* x, const float* scale, const float* shift, int32_t act,
+                     void* workspace, size_t workspace_bytes, float* out, void* stream);
+int stp3_mbconv_scale_act(const stp3_se_dims* dims, int32_t ldy, const void* x, const float* scale, const float* shift,
+                          int32_t act, const float* gate, void* y, void* stream);
+int stp3_mbconv_bwd_reduce(const stp3_se_dims* dims, int32_t ldg, const void* da, const void* x, const float* coef,
+                           int32_t act, void* workspace, size_t workspace_bytes, float* sums5, void* stream);
+int stp3_mbconv_bwd_coef(int32_t N, int32_t C, const float* sums5, const float* gate, const float* dpooled,
+                         float* gsums, void* stream);
+int stp3_mbconv_bwd_apply(const stp3_se_dims* dims, int32_t ldg, const void* da, const void* x, const float* coef,
+                          int32_t act, const float* gate, const float* dpooled, const float* gsums, double count,
+                          void* dx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * bf16 shadow copies of all convolution weights in ONE launch (csrc/stp3_wprep.hip).  Replaces the per-layer cast / flip / transpose / re-layout the host would
  * otherwise redo after every optimizer step for the operands of stp3_conv2d_fwd (forward: [Cout][KH][KW][Cin];
  * data gradient: [Cin][KH][KW][Cout] with the taps flipped).

@@ -268,6 +268,136 @@ __global__ __launch_bounds__(256) void dwconv_reduce_partials_kernel(int nblocks
     if (bl == 0 && i < n) dw[i] = (red[il] + red[64 + il]) + (red[128 + il] + red[192 + il]);
 }
 
+
+// ---- forward + BatchNorm statistics of the result -------------------------------------------------------------------
+// The forward kernel with a workgroup mapping made for reducing: CVB channel vectors x PL pixel lanes, the workgroup
+// walks the output pixels grid-stride, so that a thread keeps ONE channel vector and can carry that vector's sum and
+// sum of squares (of the ROUNDED outputs: what a statistics pass over y would read) in registers; one partial row
+// [2][C] per workgroup, reduced deterministically by dwconv_stat_reduce_kernel.  Saves the stp3_bn_stats pass over y.
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dwconv_fwd_stats_kernel(DwDims d, const T* __restrict__ x, const float* __restrict__ w,
+                                                               T* __restrict__ y, float* __restrict__ partial) {
+    constexpr int VN = Vec<T>::N;
+    constexpr int TW = 4;
+    constexpr int SPAN = (TW - 1) * S + K;
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [PL][2][CVB * VN]
+    const int CV = d.C / VN;
+    const int CVB = min(CV, 256);
+    const int PL = 256 / CVB;
+    const int cvb = threadIdx.x % CVB, pl = threadIdx.x / CVB;
+    const int cv = blockIdx.y * CVB + cvb;
+    const bool live = pl < PL && cv < CV;
+    const int c0 = cv * VN;
+    float s1[VN], s2[VN];
+#pragma unroll
+    for (int j = 0; j < VN; ++j) s1[j] = s2[j] = 0.f;
+    const int wgroups = (d.Wo + TW - 1) / TW;
+    const int ngroups = d.N * d.Ho * wgroups;            // < 2^31 (checked by the launcher)
+    if (live) {
+        for (int p = blockIdx.x * PL + pl; p < ngroups; p += gridDim.x * PL) {
+            const int wg = p % wgroups;
+            const int r = p / wgroups;
+            const int ho = r % d.Ho;
+            const int n = r / d.Ho;
+            const int wo0 = wg * TW;
+            float acc[TW][VN];
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int j = 0; j < VN; ++j) acc[i][j] = 0.f;
+            const int wi0 = wo0 * S - d.pad_l;
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh) {
+                const int hi = ho * S + kh - d.pad_t;
+                if (hi < 0 || hi >= d.H) continue;
+                float wk[K][VN];
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                    for (int j = 0; j < VN; ++j) wk[kw][j] = w[(kh * K + kw) * d.C + c0 + j];
+                const T* xrow = x + ((int64_t)(n * d.H + hi) * d.W) * d.C + c0;
+                float xin[SPAN][VN];
+#pragma unroll
+                for (int i = 0; i < SPAN; ++i) {
+                    const int wi = wi0 + i;
+                    Vec<T> v;
+                    if (wi >= 0 && wi < d.W) v.load(xrow + (int64_t)wi * d.C); else v.zero();
+                    v.to_float(xin[i]);
+                }
+#pragma unroll
+                for (int o = 0; o < TW; ++o)
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                        for (int j = 0; j < VN; ++j) acc[o][j] = fmaf(xin[o * S + kw][j], wk[kw][j], acc[o][j]);
+            }
+            T* yrow = y + ((int64_t)(n * d.Ho + ho) * d.Wo) * d.C + c0;
+#pragma unroll
+            for (int o = 0; o < TW; ++o) {
+                if (wo0 + o < d.Wo) {
+                    Vec<T> v;
+                    v.from_float(acc[o]);
+                    v.store(yrow + (int64_t)(wo0 + o) * d.C);
+                    float rv[VN];
+                    v.to_float(rv);                         // the stored (rounded) values
+#pragma unroll
+                    for (int j = 0; j < VN; ++j) {
+                        s1[j] += rv[j];
+                        s2[j] = fmaf(rv[j], rv[j], s2[j]);
+                    }
+                }
+            }
+        }
+    }
+    const int rowlen = CVB * VN;
+    if (pl < PL) {
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+            red[(pl * 2) * rowlen + cvb * VN + j] = live ? s1[j] : 0.f;
+            red[(pl * 2 + 1) * rowlen + cvb * VN + j] = live ? s2[j] : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * rowlen; i += 256) {
+        const int k = i / rowlen, cc = i - k * rowlen;
+        const int c = blockIdx.y * rowlen + cc;
+        if (c >= d.C) continue;
+        float t = 0.f;
+        for (int q = 0; q < PL; ++q) t += red[(q * 2 + k) * rowlen + cc];       // pixel lanes in ascending order
+        partial[((int64_t)blockIdx.x * 2 + k) * d.C + c] = t;
+    }
+}
+
+// sums[i] = sum_b partial[b][i] in double, fixed order: 8 columns x 32 block lanes per workgroup, four loads in flight
+// per thread (the launch sits between the depthwise pass and everything that needs the statistics: its latency is on the
+// critical path, and with up to 2048 partial rows a 64-column workgroup of 4 lanes took 44 us on the MI355X)
+constexpr int kRedCols = 8, kRedLanes = 256 / kRedCols;
+__global__ __launch_bounds__(256) void dwconv_stat_reduce_kernel(int nblocks, int n, const float* __restrict__ partial,
+                                                                 float* __restrict__ sums) {
+    __shared__ double red[256];
+    const int il = threadIdx.x % kRedCols, bl = threadIdx.x / kRedCols;
+    const int i = blockIdx.x * kRedCols + il;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (i < n) {
+        const float* src = partial + i;
+        int b = bl;
+        for (; b + 3 * kRedLanes < nblocks; b += 4 * kRedLanes) {
+            const float a = src[(int64_t)b * n], c = src[(int64_t)(b + kRedLanes) * n];
+            const float e = src[(int64_t)(b + 2 * kRedLanes) * n], f = src[(int64_t)(b + 3 * kRedLanes) * n];
+            s0 += (double)a; s1 += (double)c; s2 += (double)e; s3 += (double)f;
+        }
+        for (; b < nblocks; b += kRedLanes) s0 += (double)src[(int64_t)b * n];
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    for (int st = kRedLanes / 2; st > 0; st >>= 1) {
+        if (bl < st) red[threadIdx.x] += red[threadIdx.x + st * kRedCols];
+        __syncthreads();
+    }
+    if (bl == 0 && i < n) sums[i] = (float)red[il];
+}
+
+constexpr int kStatBlocks = 2048;
 constexpr int kWgradBlocks = 512;
 
 inline int status() {
@@ -295,6 +425,23 @@ int launch_fwd(const DwDims& d, const void* x, const float* w, void* y, hipStrea
     const int64_t total = (int64_t)d.N * d.Ho * ((d.Wo + TW - 1) / TW) * CV;
     hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, S, TW, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d,
                        (const T*)x, w, (T*)y);
+    return status();
+}
+template <typename T, int K, int S>
+int launch_fwd_stats(const DwDims& d, const void* x, const float* w, void* y, float* sums, float* ws, hipStream_t s) {
+    constexpr int VN = Vec<T>::N;
+    const int CV = d.C / VN;
+    const int CVB = CV < 256 ? CV : 256;
+    const int PL = 256 / CVB;
+    const int64_t ngroups = (int64_t)d.N * d.Ho * ((d.Wo + 3) / 4);
+    if (ngroups >= (1LL << 31)) return STP3_EUNSUP;
+    const int by = (CV + CVB - 1) / CVB;
+    int64_t want = (ngroups + PL - 1) / PL;
+    const int cap = kStatBlocks / by > 0 ? kStatBlocks / by : 1;
+    const int bx = (int)(want < cap ? want : cap);
+    const size_t lds = (size_t)PL * 2 * CVB * VN * sizeof(float);
+    hipLaunchKernelGGL((dwconv_fwd_stats_kernel<T, K, S>), dim3(bx, by), dim3(256), lds, s, d, (const T*)x, w, (T*)y, ws);
+    hipLaunchKernelGGL(dwconv_stat_reduce_kernel, dim3((2 * d.C + kRedCols - 1) / kRedCols), dim3(256), 0, s, bx, 2 * d.C, ws, sums);
     return status();
 }
 template <typename T, int K, int S>
@@ -353,6 +500,25 @@ int stp3_dwconv2d_fwd(const stp3_dwconv_dims* p, const void* x, const float* w, 
     if (rc) return rc;
     if (!x || !w || !y) return STP3_EINVAL;
     DISPATCH(launch_fwd, d, x, w, y, (hipStream_t)stream);
+}
+
+int stp3_dwconv2d_fwd_stats_workspace(const stp3_dwconv_dims* p, size_t* bytes) {
+    DwDims d; int vec;
+    int rc = check(p, &d, &vec);
+    if (rc) return rc;
+    if (!bytes) return STP3_EINVAL;
+    *bytes = (size_t)kStatBlocks * 2 * p->C * sizeof(float);
+    return STP3_OK;
+}
+
+int stp3_dwconv2d_fwd_stats(const stp3_dwconv_dims* p, const void* x, const float* w, void* y, float* sums, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    DwDims d; int vec;
+    int rc = check(p, &d, &vec);
+    if (rc) return rc;
+    if (!x || !w || !y || !sums || !workspace) return STP3_EINVAL;
+    if (workspace_bytes < (size_t)kStatBlocks * 2 * p->C * sizeof(float)) return STP3_ENOSPACE;
+    DISPATCH(launch_fwd_stats, d, x, w, y, sums, (float*)workspace, (hipStream_t)stream);
 }
 
 int stp3_dwconv2d_bwd_data(const stp3_dwconv_dims* p, const void* dy, const float* w, void* dx, void* stream) {

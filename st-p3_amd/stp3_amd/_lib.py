@@ -7,6 +7,8 @@ operator in ``stp3_amd.ops`` raises if it is handed non-GPU tensors.
 import ctypes
 import os
 
+from . import profiling
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libstp3hip.so')
 
@@ -149,11 +151,26 @@ SIGNATURES = {
     'stp3_causal_pair_bwd': (c_int, [ctypes.POINTER(PairDims), c_void_p, c_void_p, c_void_p]),
     'stp3_upsample_bilinear_fwd': (c_int, [ctypes.POINTER(UpsampleDims), c_void_p, c_void_p, c_void_p]),
     'stp3_upsample_bilinear_bwd': (c_int, [ctypes.POINTER(UpsampleDims), c_void_p, c_void_p, c_void_p]),
+    'stp3_dwconv2d_fwd_stats_workspace': (c_int, [_DW_P, ctypes.POINTER(c_size_t)]),
+    'stp3_dwconv2d_fwd_stats': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'stp3_bn_finalize': (c_int, [c_void_p, c_int32, c_double, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
+    'stp3_mbconv_workspace_bytes': (c_int, [ctypes.POINTER(SeDims), ctypes.POINTER(c_size_t)]),
+    'stp3_se_pool_act': (c_int, [ctypes.POINTER(SeDims), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p,
+                                 c_void_p]),
+    'stp3_mbconv_scale_act': (c_int, [ctypes.POINTER(SeDims), c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                                      c_void_p, c_void_p]),
+    'stp3_mbconv_bwd_reduce': (c_int, [ctypes.POINTER(SeDims), c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                                       c_size_t, c_void_p, c_void_p]),
+    'stp3_mbconv_bwd_coef': (c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'stp3_mbconv_bwd_apply': (c_int, [ctypes.POINTER(SeDims), c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                                      c_void_p, c_void_p, c_double, c_void_p, c_void_p]),
     'stp3_voxels_sum_fwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     'stp3_voxels_sum_bwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
 }
 
 _lib = None
+_timed = None
 
 
 class Stp3HipError(RuntimeError):
@@ -162,8 +179,12 @@ class Stp3HipError(RuntimeError):
 
 def lib():
     """Load libstp3hip.so once; fail loudly if it is absent or incomplete."""
-    global _lib
+    global _lib, _timed
     if _lib is not None:
+        if profiling.ENABLED:                 # bench.py's roofline steps: every call bracketed by stream events
+            if _timed is None:
+                _timed = profiling.TimedLib(_lib)
+            return _timed
         return _lib
     if not os.path.exists(LIB_PATH):
         raise Stp3HipError(

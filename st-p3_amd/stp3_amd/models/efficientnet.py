@@ -116,7 +116,9 @@ class MBConvBlock(nn.Module):
         x = inputs
         # 1x1 conv -> BN -> activation as one operator (BatchNorm statistics from the convolution epilogue)
         fuse = (self.training and x.is_cuda and torch.is_autocast_enabled()
-                and self.in_ch % 8 == 0 and (self.in_ch * self.expand) % 8 == 0)
+                and self.in_ch % 8 == 0 and (self.in_ch * self.expand) % 8 == 0
+                # the statistics epilogue of the convolution kernel reduces at most 65 536 row tiles of 128 pixels
+                and (x.shape[0] * x.shape[2] * x.shape[3] + 127) // 128 <= ops._CONV_MAX_STAT_TILES)
         if fuse:
             from .. import ops_fused
             group = None if _fused._sync_world(self._bn1) > 1 else False
@@ -125,12 +127,19 @@ class MBConvBlock(nn.Module):
                 x = ops_fused.conv_bn_act(x, self._expand_conv.weight, None, self._bn0, ACT_SWISH, group=group)
             else:
                 x = bn_act(self._bn0, self._expand_conv(x), ACT_SWISH)
-        x = bn_act(self._bn1, self._depthwise_conv(x), ACT_SWISH)
-        # squeeze and excitation
-        if x.is_cuda:
-            from .. import ops_fused
+        from .. import ops_fused
+        if x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.float32:
+            x = x.to(torch.get_autocast_dtype('cuda'))
+        if self.training and ops_fused.dw_bn_se_supported(x, self._depthwise_conv, self._bn1):
+            # depthwise -> BN1 -> swish -> squeeze-excite as one operator: the BatchNorm statistics come from the
+            # depthwise kernel's epilogue and swish(BN1(.)) is applied where it is consumed, never written
+            x = ops_fused.dw_bn_se(x, self._depthwise_conv, self._bn1, self._se_reduce, self._se_expand,
+                                   group=None if _fused._sync_world(self._bn1) > 1 else False)
+        elif x.is_cuda:
+            x = bn_act(self._bn1, self._depthwise_conv(x), ACT_SWISH)
             x = ops_fused.se_block(x, self._se_reduce, self._se_expand)
         else:
+            x = bn_act(self._bn1, self._depthwise_conv(x), ACT_SWISH)
             s = x.mean((2, 3), keepdim=True)
             s = self._se_expand(self._swish(self._se_reduce(s)))
             x = torch.sigmoid(s) * x

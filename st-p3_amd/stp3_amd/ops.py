@@ -1009,7 +1009,10 @@ class _WeightShadows:
             if not self.order:
                 return
             self._build_table()
-        with torch.cuda.device(self.device):       # the launch goes to the device that owns the pointers in the table
+        import contextlib
+        # the launch goes to the device that owns the pointers in the table (CPU tensors: the kernels-on-CPU test build)
+        guard = torch.cuda.device(self.device) if self.device.type == 'cuda' else contextlib.nullcontext()
+        with guard:
             check(_lib.lib().stp3_conv2d_prep_weights(_ptr(self.table), len(self.order), self.total_blocks, _stream()),
                   'stp3_conv2d_prep_weights')
         for e in self.order:

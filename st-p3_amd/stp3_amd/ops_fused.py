@@ -293,3 +293,151 @@ class _SeBlock(torch.autograd.Function):
 def se_block(x, se_reduce, se_expand):
     """Squeeze-and-excitation of an MBConv block; ``se_reduce`` / ``se_expand`` are its two 1x1 conv modules."""
     return _SeBlock.apply(x, se_reduce.weight, se_reduce.bias, se_expand.weight, se_expand.bias)
+
+
+# ----------------------------------------------------------------------------------------------
+# MBConv middle: depthwise conv -> BatchNorm -> swish -> squeeze-excite, as ONE operator
+# ----------------------------------------------------------------------------------------------
+class _DwBnSe(torch.autograd.Function):
+    """A = swish(BN1(depthwise(x))) * gate,  gate = sigmoid(W2 swish(W1 mean_hw swish(BN1(.)) + b1) + b2)
+    (efficientnet_pytorch MBConvBlock between the expand and the project convolution, driven by
+    stp3/models/encoder.py:57-97), training mode, without ever writing S = swish(BN1(.)):
+
+      forward   stp3_dwconv2d_fwd_stats (E2 + the BatchNorm statistics from its epilogue) -> stp3_bn_finalize ->
+                stp3_se_pool_act (squeeze straight from E2) -> stp3_se_mlp_fwd -> stp3_mbconv_scale_act (A from E2)
+      backward  stp3_mbconv_bwd_reduce (ONE pass over dA, E2 for the gate gradient and the BatchNorm reductions) ->
+                stp3_se_mlp_bwd -> stp3_mbconv_bwd_coef -> stp3_mbconv_bwd_apply (dE2) -> depthwise data / weight gradients
+
+    5 passes over the expanded tensor forward (8 as separate operators), 9 backward (13); saves x and E2 only (not S, A).
+    With more than one rank the statistics and the two backward sums are all-reduced like ``ops.bn_act`` does."""
+
+    @staticmethod
+    def forward(ctx, x, dw_weight, stride, pad, gamma, beta, running_mean, running_var, momentum, eps, w1, b1, w2, b2, group):
+        ops._need_gpu(x, dw_weight)
+        lib = _lib.lib()
+        c, _, k, _ = dw_weight.shape
+        left, right, top, bottom = pad
+        n, _, h, w = x.shape
+        ho = (h + top + bottom - k) // stride + 1
+        wo = (w + left + right - k) // stride + 1
+        x = x.contiguous(memory_format=torch.channels_last)
+        dev = x.device
+        wt = dw_weight.detach().float().reshape(c, k * k).t().contiguous()               # [K*K][C] float32
+        e2 = torch.empty((n, c, ho, wo), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+        dwd = ops._dw_dims(x, k, stride, top, left, ho, wo)
+        sd = _lib.SeDims(n, ho * wo, c, c, dwd.dtype)
+        need = ctypes.c_size_t()
+        check(lib.stp3_dwconv2d_fwd_stats_workspace(ctypes.byref(dwd), ctypes.byref(need)), 'stp3_dwconv2d_fwd_stats_workspace')
+        need2 = ctypes.c_size_t()
+        check(lib.stp3_mbconv_workspace_bytes(ctypes.byref(sd), ctypes.byref(need2)), 'stp3_mbconv_workspace_bytes')
+        ws_bytes = max(need.value, need2.value)
+        ws = _workspace(ws_bytes, dev)
+        stream = ops._stream_handle()
+        stat = torch.empty(6 * c, dtype=torch.float32, device=dev)        # sum | sum of squares | scale | shift | mean | invstd
+        check(lib.stp3_dwconv2d_fwd_stats(ctypes.byref(dwd), x.data_ptr(), wt.data_ptr(), e2.data_ptr(), stat.data_ptr(),
+                                          ws.data_ptr(), ws_bytes, stream), 'stp3_dwconv2d_fwd_stats')
+        count = float(n * ho * wo)
+        world = 1
+        if group is not False and torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size(group)
+        if world > 1:
+            torch.distributed.all_reduce(stat[:2 * c], group=group)
+            count *= world
+        g32, b32 = ops._f32(gamma), ops._f32(beta)
+        coef = stat[2 * c:]
+        check(lib.stp3_bn_finalize(stat.data_ptr(), c, count, ops._opt_ptr(g32), ops._opt_ptr(b32), eps, momentum,
+                                   ops._opt_ptr(running_mean), ops._opt_ptr(running_var), coef.data_ptr(), stream),
+              'stp3_bn_finalize')
+        scale_p, shift_p = coef.data_ptr(), coef.data_ptr() + 4 * c
+        pooled_sum = torch.empty(n, c, dtype=torch.float32, device=dev)
+        check(lib.stp3_se_pool_act(ctypes.byref(sd), e2.data_ptr(), scale_p, shift_p, ops.ACT_SWISH, ws.data_ptr(), ws_bytes,
+                                   pooled_sum.data_ptr(), stream), 'stp3_se_pool_act')
+        w1f, w2f = w1.detach().flatten(1).float().contiguous(), w2.detach().flatten(1).float().contiguous()
+        md = _lib.SeMlpDims(n, c, w1f.shape[0], 1.0 / float(ho * wo))
+        z1 = torch.empty(n, md.S, dtype=torch.float32, device=dev)
+        gate = torch.empty(n, c, dtype=torch.float32, device=dev)
+        check(lib.stp3_se_mlp_fwd(ctypes.byref(md), pooled_sum.data_ptr(), w1f.data_ptr(), ops._f32(b1).data_ptr(),
+                                  w2f.data_ptr(), ops._f32(b2).data_ptr(), z1.data_ptr(), gate.data_ptr(), stream),
+              'stp3_se_mlp_fwd')
+        a = torch.empty_like(e2)
+        check(lib.stp3_mbconv_scale_act(ctypes.byref(sd), c, e2.data_ptr(), scale_p, shift_p, ops.ACT_SWISH, gate.data_ptr(),
+                                        a.data_ptr(), stream), 'stp3_mbconv_scale_act')
+        ctx.save_for_backward(x, wt, e2, coef, gate, pooled_sum, z1, w1f, w2f)
+        ctx.cfg = (dwd, sd, md, count, world, group, ws_bytes)
+        ctx.meta = (dw_weight.shape, dw_weight.dtype, None if gamma is None else gamma.dtype,
+                    None if beta is None else beta.dtype, w1.shape, w2.shape, w1.dtype, b1.dtype, w2.dtype, b2.dtype)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x, wt, e2, coef, gate, pooled_sum, z1, w1f, w2f = ctx.saved_tensors
+        dwd, sd, md, count, world, group, ws_bytes = ctx.cfg
+        wshape, wdt, gdt, bdt, w1s, w2s, w1d, b1d, w2d, b2d = ctx.meta
+        lib = _lib.lib()
+        dev = x.device
+        n, c = sd.N, sd.C
+        if da.dtype != e2.dtype:
+            da = da.to(e2.dtype)
+        da = da.contiguous(memory_format=torch.channels_last)
+        ws = _workspace(ws_bytes, dev)
+        stream = ops._stream_handle()
+        f32 = dict(dtype=torch.float32, device=dev)
+        sums5 = torch.empty(5, n, c, **f32)
+        check(lib.stp3_mbconv_bwd_reduce(ctypes.byref(sd), c, da.data_ptr(), e2.data_ptr(), coef.data_ptr(), ops.ACT_SWISH,
+                                         ws.data_ptr(), ws_bytes, sums5.data_ptr(), stream), 'stp3_mbconv_bwd_reduce')
+        dz2, dz1 = torch.empty(n, c, **f32), torch.empty(n, md.S, **f32)
+        dpooled = torch.empty(n, c, **f32)
+        dw1, db1 = torch.empty(md.S, c, **f32), torch.empty(md.S, **f32)
+        dw2, db2 = torch.empty(c, md.S, **f32), torch.empty(c, **f32)
+        check(lib.stp3_se_mlp_bwd(ctypes.byref(md), sums5.data_ptr(), gate.data_ptr(), pooled_sum.data_ptr(), z1.data_ptr(),
+                                  w1f.data_ptr(), w2f.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), dpooled.data_ptr(),
+                                  dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), stream), 'stp3_se_mlp_bwd')
+        lsums = torch.empty(2, c, **f32)                                  # sum g (dbeta) | sum g * xhat (dgamma), this rank
+        check(lib.stp3_mbconv_bwd_coef(n, c, sums5.data_ptr(), gate.data_ptr(), dpooled.data_ptr(), lsums.data_ptr(), stream),
+              'stp3_mbconv_bwd_coef')
+        gsums = lsums
+        if world > 1:
+            gsums = lsums.clone()
+            torch.distributed.all_reduce(gsums, group=group)
+        de2 = torch.empty_like(e2)
+        check(lib.stp3_mbconv_bwd_apply(ctypes.byref(sd), c, da.data_ptr(), e2.data_ptr(), coef.data_ptr(), ops.ACT_SWISH,
+                                        gate.data_ptr(), dpooled.data_ptr(), gsums.data_ptr(), count, de2.data_ptr(), stream),
+              'stp3_mbconv_bwd_apply')
+        dx = dwg = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x, memory_format=torch.channels_last)
+            check(lib.stp3_dwconv2d_bwd_data(ctypes.byref(dwd), de2.data_ptr(), wt.data_ptr(), dx.data_ptr(), stream),
+                  'stp3_dwconv2d_bwd_data')
+        if ctx.needs_input_grad[1]:
+            nbytes = ctypes.c_size_t()
+            check(lib.stp3_dwconv2d_bwd_weight_workspace(ctypes.byref(dwd), ctypes.byref(nbytes)),
+                  'stp3_dwconv2d_bwd_weight_workspace')
+            ws2 = _workspace(max(nbytes.value, ws_bytes), dev)
+            dwt = torch.empty_like(wt)
+            check(lib.stp3_dwconv2d_bwd_weight(ctypes.byref(dwd), x.data_ptr(), de2.data_ptr(), dwt.data_ptr(), ws2.data_ptr(),
+                                               nbytes.value, stream), 'stp3_dwconv2d_bwd_weight')
+            dwg = dwt.t().reshape(wshape).to(wdt)
+        dgamma = lsums[1].to(gdt) if gdt is not None and ctx.needs_input_grad[4] else None
+        dbeta = lsums[0].to(bdt) if bdt is not None and ctx.needs_input_grad[5] else None
+        return (dx, dwg, None, None, dgamma, dbeta, None, None, None, None, dw1.view(w1s).to(w1d), db1.to(b1d),
+                dw2.view(w2s).to(w2d), db2.to(b2d), None)
+
+
+def dw_bn_se_supported(x, dw_conv, bn):
+    """The fused MBConv middle takes GPU bf16 / float32 activations in whole 16-byte channel vectors, training-mode
+    BatchNorm with running statistics, 3x3 / 5x5 depthwise kernels with stride 1 / 2."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32)):
+        return False
+    per = 8 if x.dtype == torch.bfloat16 else 4
+    return (bn.training and bn.track_running_stats and x.shape[1] % per == 0 and dw_conv.kernel_size[0] in (3, 5)
+            and dw_conv.stride[0] in (1, 2))
+
+
+def dw_bn_se(x, dw_conv, bn, se_reduce, se_expand, group=None):
+    """``se(swish(bn(dw_conv(x))))`` of an MBConv block through ``_DwBnSe``; ``dw_conv``: the block's
+    ``StaticSamePadConv2d`` depthwise module (its frozen padding is applied in-kernel)."""
+    if bn.num_batches_tracked is not None:
+        ops.bump_batch_counter(bn)
+    return _DwBnSe.apply(x, dw_conv.weight, int(dw_conv.stride[0]), tuple(int(p) for p in dw_conv._pad), bn.weight, bn.bias,
+                         bn.running_mean, bn.running_var, float(bn.momentum if bn.momentum is not None else 0.1),
+                         float(bn.eps), se_reduce.weight, se_reduce.bias, se_expand.weight, se_expand.bias, group)

@@ -486,6 +486,58 @@ def dwconv(ops):
     return out
 
 
+def mbconv_mid(ops):
+    """Depthwise -> BatchNorm -> swish -> squeeze-excite as ONE operator (ops_fused.dw_bn_se: statistics in the depthwise
+    epilogue, swish(BN(.)) never written, one backward pass for the gate gradient and the BatchNorm reductions) against
+    float32 torch autograd on the same (bf16-representable) data: outputs, input gradient and every parameter gradient,
+    running statistics; stride 1 and 2, kernel 3 and 5, float32 and bf16 activations."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from stp3_amd import ops_fused
+    from stp3_amd.models.efficientnet import StaticSamePadConv2d
+    out = {}
+    cases = {'k3s1_c24': (24, 3, 1, 3, 9, 12, 8), 'k5s2_c48': (48, 5, 2, 2, 11, 13, 24), 'k3s2_c16': (16, 3, 2, 5, 8, 8, 8),
+             'k5s1_c272': (272, 5, 1, 2, 6, 5, 8)}
+    for name, (c, k, stride, n, h, w, img) in cases.items():
+        for dtype, tag in ((torch.float32, 'f32'), (torch.bfloat16, 'bf16')):
+            g = torch.Generator().manual_seed(11)
+            cl = torch.channels_last
+            x0 = torch.randn(n, c, h, w, generator=g).to(dtype).contiguous(memory_format=cl)
+            s = max(1, c // 4)
+            res = []
+            for mode in ('fused', 'torch'):
+                dw = StaticSamePadConv2d(c, c, k, img, stride=stride, groups=c)
+                bn = nn.BatchNorm2d(c, momentum=0.01, eps=1e-3)
+                r1, r2 = StaticSamePadConv2d(c, s, 1, 1, bias=True), StaticSamePadConv2d(s, c, 1, 1, bias=True)
+                gp = torch.Generator().manual_seed(5)
+                with torch.no_grad():
+                    dw.weight.copy_(torch.randn(dw.weight.shape, generator=gp) * 0.3)
+                    bn.weight.copy_(torch.rand(c, generator=gp) + 0.5); bn.bias.copy_(torch.randn(c, generator=gp) * 0.2)
+                    r1.weight.copy_(torch.randn(r1.weight.shape, generator=gp) * 0.3); r1.bias.copy_(torch.randn(s, generator=gp) * 0.2)
+                    r2.weight.copy_(torch.randn(r2.weight.shape, generator=gp) * 0.3); r2.bias.copy_(torch.randn(c, generator=gp) * 0.2)
+                if mode == 'fused':
+                    x = x0.clone().requires_grad_()
+                    assert ops_fused.dw_bn_se_supported(x, dw, bn)
+                    y = ops_fused.dw_bn_se(x, dw, bn, r1, r2, group=False)
+                else:
+                    x = x0.float().requires_grad_()
+                    e2 = F.conv2d(F.pad(x, dw._pad), dw.weight, None, stride, 0, 1, c)
+                    if dtype == torch.bfloat16:
+                        e2 = e2 + (e2.to(torch.bfloat16).float() - e2).detach()        # the kernel stores E2 in bf16
+                    sact = F.silu(bn(e2))
+                    gate = torch.sigmoid(F.linear(F.silu(F.linear(sact.mean((2, 3)), r1.weight.flatten(1), r1.bias)),
+                                                  r2.weight.flatten(1), r2.bias))
+                    y = sact * gate[:, :, None, None]
+                if mode == 'fused':
+                    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(dtype).contiguous(memory_format=cl)
+                y.backward(gy if mode == 'fused' else gy.float())
+                res.append([y.detach().float(), x.grad.float(), dw.weight.grad, bn.weight.grad, bn.bias.grad, r1.weight.grad,
+                            r1.bias.grad, r2.weight.grad, r2.bias.grad, bn.running_mean.clone(), bn.running_var.clone()])
+            names = ['y', 'dx', 'ddw', 'dgamma', 'dbeta', 'dw1', 'db1', 'dw2', 'db2', 'rmean', 'rvar']
+            out[f'{name}_{tag}'] = {k_: rel(a, b) for k_, a, b in zip(names, *res)}
+    return out
+
+
 def conv_bn(ops):
     """conv -> BatchNorm -> act (+ skip / drop-connect) as ONE operator (conv v2 with the statistics in its epilogue)
     against the two separate operators, and both against float32 torch on the same bf16-representable data."""
@@ -819,7 +871,7 @@ def fuzz(ops, seed=1):
 
 
 CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_frames, lift_coarse_grid, lift_tall, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
-                                 conv, dwconv)}
+                                 conv, dwconv, mbconv_mid)}
 
 if __name__ == '__main__':
     ops_mod = setup(sys.argv[1])

@@ -47,11 +47,14 @@ def test_bench_main_dry_run(tmp_path, workload):
     assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
     # B=1: 3 frames x (feat + depth probabilities + BEV planes) float32, SURVEY.md section 8d: 14 755 840 B per frame
     assert roof['algorithmic_bytes_per_launch'] == 3 * 14755840
-    # what ships is what runs: every operator family of the C ABI shows up in the call trace of one step
+    # what ships is what runs: every operator family of the C ABI shows up in the call trace of one step (the plain
+    # stp3_dwconv2d_fwd / stp3_se_pool / stp3_se_scale serve the evaluation-mode forward: BatchNorm on running statistics)
     trace = open(tmp_path / 'trace.log').read()
     for entry in ('stp3_lift_plan_build', 'stp3_lift_splat_fwd', 'stp3_lift_splat_bwd',
                   'stp3_conv2d_fwd', 'stp3_conv2d_wgrad', 'stp3_conv2d_prep_weights', 'stp3_bn_fwd_train',
-                  'stp3_dwconv2d_fwd', 'stp3_se_pool', 'stp3_se_mlp_fwd', 'stp3_optim_clip_adam',
+                  'stp3_dwconv2d_fwd_stats', 'stp3_bn_finalize', 'stp3_se_pool_act', 'stp3_se_mlp_fwd', 'stp3_se_mlp_bwd',
+                  'stp3_mbconv_scale_act', 'stp3_mbconv_bwd_reduce', 'stp3_mbconv_bwd_coef', 'stp3_mbconv_bwd_apply',
+                  'stp3_dwconv2d_bwd_data', 'stp3_dwconv2d_bwd_weight', 'stp3_optim_clip_adam',
                   'stp3_causal_pair_fwd', 'stp3_causal_pair_bwd', 'stp3_upsample_bilinear_fwd', 'stp3_upsample_bilinear_bwd'):
         assert entry + ' ' in trace, entry
 

@@ -138,7 +138,7 @@ def test_weight_shadows_match_the_torch_built_copies():
         if k % 2 == 0:
             w = w.contiguous(memory_format=torch.channels_last)
         weights.append(nn.Parameter(w))
-    sh = ops._WeightShadows()
+    sh = ops._WeightShadows(weights[0].device)
     for w in weights:
         sh.register(w)
 
@@ -280,3 +280,68 @@ def test_fused_conv_bn_act_cross_replica_statistics_two_ranks_one_gpu():
     torch.testing.assert_close(out[0][2] + out[1][2], wg, rtol=2e-2, atol=2e-2 * float(wg.abs().max()))
     torch.testing.assert_close(out[0][3] + out[1][3], bn.weight.grad.cpu(), rtol=2e-2, atol=5e-2)
     torch.testing.assert_close(out[0][4], bn.running_var.cpu(), rtol=1e-3, atol=1e-4)
+
+
+# (c, kernel, stride, n, h, w, canonical image size of the "static same" padding): the trunk's depthwise layers at
+# batch 2 x 6 cameras, plus a small odd-sized one
+MBCONV_MID = [(48, 3, 1, 12, 112, 240, 190), (144, 3, 2, 12, 112, 240, 190), (192, 3, 1, 12, 56, 120, 95),
+              (192, 5, 2, 12, 56, 120, 95), (336, 5, 1, 12, 28, 60, 48), (672, 3, 1, 12, 14, 30, 24),
+              (960, 5, 1, 12, 14, 30, 24), (24, 3, 1, 3, 9, 13, 8)]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', MBCONV_MID)
+def test_mbconv_middle_operator_matches_torch_float32(case, dtype):
+    """ops_fused.dw_bn_se -- depthwise (statistics in its epilogue) -> BN1 -> swish -> squeeze-excite with swish(BN1(.))
+    applied on load and never written, one-pass backward reductions -- against float32 torch autograd on the same
+    (bf16-representable) data at the trunk's shapes.  float32: rtol 1e-4 everywhere.  bf16: what is stored in bf16 (the
+    output, the input gradient, and the depthwise weight gradient that is computed from the bf16 dE2) to 2e-2; every
+    other gradient is a float32 reduction of exactly representable inputs."""
+    from stp3_amd import ops_fused
+    from stp3_amd.models.efficientnet import StaticSamePadConv2d
+    c, k, stride, n, h, w, img = case
+    cl = torch.channels_last
+    g = torch.Generator().manual_seed(c + k)
+    x0 = torch.randn(n, c, h, w, generator=g).to(dtype).cuda().contiguous(memory_format=cl)
+    s = max(1, c // 24)
+    res = []
+    for mode in ('fused', 'torch'):
+        dw = StaticSamePadConv2d(c, c, k, img, stride=stride, groups=c)
+        bn = nn.BatchNorm2d(c, momentum=0.01, eps=1e-3)
+        r1, r2 = StaticSamePadConv2d(c, s, 1, 1, bias=True), StaticSamePadConv2d(s, c, 1, 1, bias=True)
+        gp = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            dw.weight.copy_(torch.randn(dw.weight.shape, generator=gp) * 0.3)
+            bn.weight.copy_(torch.rand(c, generator=gp) + 0.5); bn.bias.copy_(torch.randn(c, generator=gp) * 0.2)
+            r1.weight.copy_(torch.randn(r1.weight.shape, generator=gp) * 0.1); r1.bias.copy_(torch.randn(s, generator=gp) * 0.2)
+            r2.weight.copy_(torch.randn(r2.weight.shape, generator=gp) * 0.3); r2.bias.copy_(torch.randn(c, generator=gp) * 0.2)
+        for m in (dw, bn, r1, r2):
+            m.cuda()
+        if mode == 'fused':
+            x = x0.clone().requires_grad_()
+            assert ops_fused.dw_bn_se_supported(x, dw, bn)
+            y = ops_fused.dw_bn_se(x, dw, bn, r1, r2, group=False)
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(dtype).cuda().contiguous(memory_format=cl)
+            y.backward(gy)
+        else:
+            x = x0.double().requires_grad_()
+            for m in (dw, bn, r1, r2):
+                m.double()
+            e2 = F.conv2d(F.pad(x, dw._pad), dw.weight, None, stride, 0, 1, c)
+            if dtype == torch.bfloat16:
+                e2 = e2 + (e2.to(torch.bfloat16).double() - e2).detach()              # the kernel stores E2 in bf16
+            sact = F.silu(bn(e2))
+            gate = torch.sigmoid(F.linear(F.silu(F.linear(sact.mean((2, 3)), r1.weight.flatten(1), r1.bias)),
+                                          r2.weight.flatten(1), r2.bias))
+            y = sact * gate[:, :, None, None]
+            y.backward(gy.double())
+        res.append({'y': y.detach(), 'dx': x.grad, 'ddw': dw.weight.grad, 'dgamma': bn.weight.grad, 'dbeta': bn.bias.grad,
+                    'dw1': r1.weight.grad, 'db1': r1.bias.grad, 'dw2': r2.weight.grad, 'db2': r2.bias.grad,
+                    'rmean': bn.running_mean.clone(), 'rvar': bn.running_var.clone()})
+    got, want = res
+    stored = ('y', 'dx', 'ddw')
+    for name in got:
+        a, b = got[name].double(), want[name].double()
+        err = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+        tol = 1e-4 if dtype == torch.float32 else (2e-2 if name in stored else 2e-3)
+        assert err <= tol, (name, err)

@@ -28,9 +28,9 @@ import build as hipcpu_build  # noqa: E402
 
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
 ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
-           ('conv', {}), ('conv_bn', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
+           ('conv', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
            ('lift_c64_frames', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
-ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'lift_c16']
+ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'mbconv_mid', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)]
 MODEL = [('lift_full', {}), ('model_step_two_ranks', {}), ('model_step_f32_full_losses', {}), ('model_step_f32', {}),
          ('model_step_bf16_bn_eval', {})]        # whole training steps: minutes, STP3_SLOW_TESTS=1
@@ -133,6 +133,19 @@ def test_fused_conv_batchnorm_operator(results):
             continue
         assert r['fused_vs_separate'] <= 1e-5, (name, r)         # same kernels underneath: the statistics only move
         assert r['fused_vs_torch_f32'] <= 1e-1, (name, r)        # bf16 convolution output in front of a ReLU
+
+
+def test_mbconv_middle_operator(results):
+    """ops_fused.dw_bn_se (depthwise with statistics epilogue, BN + swish applied on load by the squeeze / the gate pass,
+    one-pass backward reductions) against float32 torch autograd, under all three fiber orders."""
+    for env in ({}, REVERSE, RANDOM):
+        for name, r in _get(results, 'mbconv_mid', env).items():
+            if name == 'seconds':
+                continue
+            tol = 2e-5 if name.endswith('_f32') else 2e-2
+            assert max(r.values()) <= tol, (name, r)
+            if name.endswith('_bf16'):                    # everything that is not stored in bf16 stays float32-accurate
+                assert max(r[k] for k in ('dgamma', 'dbeta', 'dw1', 'db1', 'dw2', 'db2', 'rmean', 'rvar')) <= 2e-5, (name, r)
 
 
 def test_convolution_kernels(results):
