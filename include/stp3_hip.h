@@ -144,6 +144,9 @@ int stp3_depth_softmax(const stp3_lift_dims* dims, const float* logits, float* p
 #define STP3_BEV_CHANNELS_FIRST 0   /* [B][T][C][X][Y]  the reference's layout (stp3.py:230-232, :297-299)          */
 #define STP3_BEV_CHANNELS_LAST  1   /* [B][T][X][Y][C]  = channels-last memory of the same (B,T,C,X,Y) tensor: what the */
                                     /* NHWC convolutions of the temporal model consume; no transpose pass             */
+#define STP3_BEV_CHANNELS_LAST_BF16 2 /* (forward output only) the same layout, every value rounded ONCE to bf16: what  */
+                                    /* a bf16 temporal model makes of the float32 BEV in its first operator anyway --  */
+                                    /* half the bytes written and no cast pass in the consumer                         */
 
 /*
  * stp3_lift_splat_fwd -- out[b][t] = sum_{k<=t} discount^(t-k) Pool_k,
@@ -173,7 +176,7 @@ int stp3_depth_softmax(const stp3_lift_dims* dims, const float* logits, float* p
 int stp3_lift_workspace_bytes(const stp3_lift_dims* dims, size_t* bytes);
 int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const float* logits,
                         const void* plan, float discount, int bev_layout,
-                        void* workspace, size_t workspace_bytes, float* prob_cm, float* bev, void* stream);
+                        void* workspace, size_t workspace_bytes, float* prob_cm, void* bev, void* stream);
 
 /*
  * stp3_lift_splat_bwd -- gradients of stp3_lift_splat_fwd (softmax included).

@@ -63,8 +63,11 @@ class CpuPortSTP3(STP3):
                 tmp = torch.zeros(xd * yd, cc)
                 if x_b.shape[0]:
                     sums, kept = _VoxelsSumming.apply(x_b, ranks)
-                    tmp = tmp.index_put((kept,), sums)
+                    # float32 scatter target and accumulation (stp3.py:280-296), whatever the point matrix's type: a
+                    # float64 evaluation (tests/test_step_truth_cpu.py) rounds the pooled sums here exactly like the
+                    # float64 reference fixture does (oracle/make_golden_step.py: to_float64)
+                    tmp = tmp.index_put((kept,), sums.to(tmp.dtype))
                 bev = bev * self.discount + tmp
                 frames.append(bev.t().reshape(cc, xd, yd))
-        out = torch.stack(frames).view(b, s, cc, xd, yd)
+        out = torch.stack(frames).view(b, s, cc, xd, yd).to(feat.dtype)
         return out, depth.view(b, s, n, *depth.shape[1:]), None

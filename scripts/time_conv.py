@@ -4,6 +4,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'st-p3_amd'))
 import torch
+from stp3_amd import _lib
+if os.environ.get('EXP_LIB'):          # an experiment build of the library
+    _lib.LIB_PATH = os.environ['EXP_LIB']
 from stp3_amd import ops
 
 SHAPES = [
@@ -14,6 +17,9 @@ SHAPES = [
     ('decoder stem 7x7/2 64->64 @200x200', 12, 64, 200, 200, 64, 7, 2, 3, 1),
     ('decoder head 3x3 64->64 @200x200', 12, 64, 200, 200, 64, 3, 1, 1, 1),
     ('temporal block 1x1 72->40 @200x200', 12, 72, 200, 200, 40, 1, 1, 0, 1),
+    ('temporal path 3x3 40->40 @200x200', 12, 40, 200, 200, 40, 3, 1, 1, 1),
+    ('decoder layer1 3x3 64->64 @100x100', 12, 64, 100, 100, 64, 3, 1, 1, 1),
+    ('decoder layer2 3x3 128->128 @50x50', 12, 128, 50, 50, 128, 3, 1, 1, 1),
     ('encoder upconcat 3x3 216->64 @28x60', 72, 216, 28, 60, 64, 3, 1, 1, 1),
     ('trunk stem 3x3/2 8->48 @224x480', 72, 8, 225, 481, 48, 3, 2, 0, 1),
     ('trunk expand 1x1 24->144 @112x240', 72, 24, 112, 240, 144, 1, 1, 0, 1),

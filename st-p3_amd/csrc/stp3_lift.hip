@@ -758,11 +758,15 @@ __global__ __launch_bounds__(256, 6) void lift_column_mma_kernel(Dims dm, const 
     }
 }
 
+// OUT = float: the reference's BEV type (stp3.py:230-232).  OUT = uint16_t: the same values rounded ONCE to bf16
+// (nearest even) -- what the bf16 temporal model makes of the float32 tensor in its first operator anyway: the kernel
+// then writes half the bytes and the consumer's cast pass (read 4, write 2 bytes per element) disappears.
+template <typename OUT>
 __global__ __launch_bounds__(256) void lift_gather_kernel(Dims dm, const float* __restrict__ slots,
                                                           const int32_t* __restrict__ vox_off,
                                                           const int32_t* __restrict__ col_off,
                                                           const int32_t* __restrict__ vox_runs, float discount,
-                                                          float* __restrict__ bev_cl) {
+                                                          OUT* __restrict__ bev_cl) {
     const int b = blockIdx.y;
     const int v = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int c4 = (threadIdx.x & 15) * 4;
@@ -782,7 +786,12 @@ __global__ __launch_bounds__(256) void lift_gather_kernel(Dims dm, const float* 
         st.y = st.y * discount + pool.y;
         st.z = st.z * discount + pool.z;
         st.w = st.w * discount + pool.w;
-        *reinterpret_cast<float4*>(bev_cl + ((size_t)bt * dm.V + v) * dm.C + c4) = st;
+        OUT* dst = bev_cl + ((size_t)bt * dm.V + v) * dm.C + c4;
+        if constexpr (sizeof(OUT) == 4) {
+            *reinterpret_cast<float4*>(dst) = st;
+        } else {
+            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16(st.x, st.y), pack_bf16(st.z, st.w));
+        }
     }
 }
 
@@ -1451,20 +1460,24 @@ static void launch_transpose(hipStream_t s, int batch, int rows, int cols, const
 
 int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const float* logits, const void* plan,
                         float discount, int bev_layout, void* workspace, size_t workspace_bytes, float* prob_cm,
-                        float* bev, void* stream) {
+                        void* bev, void* stream) {
     Dims dm;
     int rc = check_dims(dims, &dm);
     if (rc) return rc;
     if (!feat || !logits || !plan || !bev || !workspace) return STP3_EINVAL;
     if ((rc = pool_limits(dm))) return rc;
-    if (bev_layout != STP3_BEV_CHANNELS_FIRST && bev_layout != STP3_BEV_CHANNELS_LAST) return STP3_EINVAL;
+    if (bev_layout != STP3_BEV_CHANNELS_FIRST && bev_layout != STP3_BEV_CHANNELS_LAST &&
+        bev_layout != STP3_BEV_CHANNELS_LAST_BF16)
+        return STP3_EINVAL;
     const bool cf = bev_layout == STP3_BEV_CHANNELS_FIRST;
+    const bool out_bf16 = bev_layout == STP3_BEV_CHANNELS_LAST_BF16;
+    if (((uintptr_t)bev & (out_bf16 ? 7 : 15))) return STP3_EUNSUP;
     if (workspace_bytes < workspace_need(dm)) return STP3_ENOSPACE;
     if (dm.B > 65535) return STP3_EUNSUP;
     PlanView pv = plan_view(dm, const_cast<void*>(plan));
     hipStream_t s = (hipStream_t)stream;
     float* slots = (float*)workspace;
-    float* out_cl = cf ? slots + (size_t)dm.BT * dm.P * dm.C : bev;
+    float* out_cl = cf ? slots + (size_t)dm.BT * dm.P * dm.C : (float*)bev;
     const int ncols = dm.BT * dm.NCOL;
     const dim3 cgrid((ncols + 3) / 4);
     if (column_mma_shape(dm))
@@ -1476,9 +1489,13 @@ int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const flo
         hipLaunchKernelGGL(lift_column_kernel<12>, cgrid, dim3(256), 0, s, dm, feat, logits, pv.masks, pv.col_off, prob_cm, slots);
     else
         hipLaunchKernelGGL(lift_column_kernel<16>, cgrid, dim3(256), 0, s, dm, feat, logits, pv.masks, pv.col_off, prob_cm, slots);
-    hipLaunchKernelGGL(lift_gather_kernel, dim3((dm.V + 15) / 16, dm.B), dim3(256), 0, s, dm, slots, pv.vox_off, pv.col_off,
-                       pv.vox_runs, discount, out_cl);
-    if (cf) launch_transpose(s, dm.BT, dm.V, dm.C, out_cl, bev);          // [V][C] -> [C][V]: stp3.py:230-232 layout
+    if (out_bf16)
+        hipLaunchKernelGGL(lift_gather_kernel<uint16_t>, dim3((dm.V + 15) / 16, dm.B), dim3(256), 0, s, dm, slots, pv.vox_off,
+                           pv.col_off, pv.vox_runs, discount, (uint16_t*)bev);
+    else
+        hipLaunchKernelGGL(lift_gather_kernel<float>, dim3((dm.V + 15) / 16, dm.B), dim3(256), 0, s, dm, slots, pv.vox_off,
+                           pv.col_off, pv.vox_runs, discount, out_cl);
+    if (cf) launch_transpose(s, dm.BT, dm.V, dm.C, out_cl, (float*)bev);  // [V][C] -> [C][V]: stp3.py:230-232 layout
     return launch_status();
 }
 

@@ -99,6 +99,7 @@ VOX_REFERENCE = 0
 VOX_PIXELMAJOR = 1
 BEV_CHANNELS_FIRST = 0
 BEV_CHANNELS_LAST = 1
+BEV_CHANNELS_LAST_BF16 = 2
 
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 RES_NONE, RES_BEFORE_ACT, RES_AFTER_ACT = 0, 1, 2

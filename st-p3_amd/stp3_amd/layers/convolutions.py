@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..utils import hp
 from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, conv1x1_on_vector, conv2d, conv_module, plane_mean, run_fused
 
 
@@ -126,7 +127,7 @@ class ASPP(nn.Module):
         y = conv2d(spatial, proj.weight[:, :n_sp])
         # the pooled branch is a constant plane per sample: its projection is a per-sample bias, folded
         # into the fused BatchNorm instead of a broadcast add over the whole map
-        sbias = conv1x1_on_vector(pooled.to(y.dtype), proj.weight[:, n_sp:]).flatten(1).float()
+        sbias = hp(conv1x1_on_vector(pooled.to(y.dtype), proj.weight[:, n_sp:]).flatten(1))
         return drop(bn_act(bn, y, ACT_RELU, sbias=sbias))
 
 

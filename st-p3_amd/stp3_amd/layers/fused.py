@@ -20,6 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..utils import hp
 
 ACT_NONE, ACT_RELU, ACT_SWISH = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_SWISH
 RES_NONE, RES_BEFORE_ACT, RES_AFTER_ACT = ops.RES_NONE, ops.RES_BEFORE_ACT, ops.RES_AFTER_ACT
@@ -54,7 +55,7 @@ def bn_act_reference(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=Non
     use_batch = bn.training or not bn.track_running_stats
     if use_batch:
         dims = [0] + list(range(2, x.dim()))
-        xf = x.float()
+        xf = hp(x)
         count = float(xf.numel() // xf.shape[1])
         s, q = xf.sum(dims), (xf * xf).sum(dims)
         if _sync_world(bn) > 1:
@@ -72,13 +73,13 @@ def bn_act_reference(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=Non
                 if bn.num_batches_tracked is not None:
                     bn.num_batches_tracked.add_(1)
     else:
-        mean, var = bn.running_mean.float(), bn.running_var.float()
+        mean, var = hp(bn.running_mean), hp(bn.running_var)
     scale = torch.rsqrt(var + bn.eps)
     shift = -mean * scale
     if bn.weight is not None:
-        scale = scale * bn.weight.float()
-        shift = shift * bn.weight.float() + bn.bias.float()
-    y = (x.float() * scale.view(shape) + shift.view(shape)).to(x.dtype)
+        scale = scale * hp(bn.weight)
+        shift = shift * hp(bn.weight) + hp(bn.bias)
+    y = (hp(x) * scale.view(shape) + shift.view(shape)).to(x.dtype)
     if res is not None and res_mode == RES_BEFORE_ACT:
         y = y + res.to(y.dtype)
     y = _act(act, y)
@@ -112,7 +113,9 @@ def bn_act(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=
         b, c, t = x.shape[:3]
         y = bn_act(bn, x.permute(0, 2, 1, 3, 4).reshape(b * t, c, 1, 1), act)
         return y.view(b, t, c, 1, 1).permute(0, 2, 1, 3, 4)
-    if not (x.is_cuda and x.dim() == 4):
+    if not (x.is_cuda and x.dim() == 4) or x.dtype == torch.float64:
+        # CPU tensors, and float64 on any device: the library has float32 / bf16 kernels only; a float64 evaluation (the
+        # noise-free truth of the parity tests) takes the torch statement
         return bn_act_reference(bn, x, act, res, res_mode, sbias, oscale)
     if torch.is_autocast_enabled() and x.dtype == torch.float32:
         x = x.to(torch.get_autocast_dtype('cuda'))
@@ -153,7 +156,7 @@ class _PlaneMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         ctx.meta = (tuple(x.shape), x.dtype, x.is_contiguous(memory_format=torch.channels_last))
-        return x.mean(dim=(2, 3), dtype=torch.float32)
+        return x.mean(dim=(2, 3), dtype=torch.float64 if x.dtype == torch.float64 else torch.float32)
 
     @staticmethod
     def backward(ctx, g):

@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..utils import hp
 from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, conv1x1_on_vector, conv2d, plane_mean
 
 
@@ -154,7 +155,7 @@ class PyramidSpatioTemporalPooling(nn.Module):
             if folded is not None and h == ph and w == pw:
                 sp = plane_mean(folded).view(b, t, c).permute(0, 2, 1)[..., None, None]
                 if extra is not None:
-                    sp = torch.cat([sp, extra.float().view(b, -1, t, 1, 1)], dim=1)
+                    sp = torch.cat([sp, hp(extra).view(b, -1, t, 1, 1)], dim=1)
                 pooled = torch.cat([sp[:, :, :1], 0.5 * (sp[:, :, 1:] + sp[:, :, :-1]), sp[:, :, -1:]], dim=2)
                 cbr = f.conv_bn_relu
                 out.append(bn_act(cbr.norm, conv1x1_on_vector(pooled.to(x.dtype), cbr.conv.weight), ACT_RELU)[:, :, :-1])
@@ -162,9 +163,9 @@ class PyramidSpatioTemporalPooling(nn.Module):
                 # spatial mean over each pool window, then the causal 2-frame mean with
                 # count_include_pad=False (frame 0 averages only itself): identical to the padded
                 # AvgPool3d + [:, :, :-1] of the reference (temporal.py:396-413), as plain reductions
-                sp = x.float().view(b, c, t, h // ph, ph, w // pw, pw).mean(dim=(4, 6))
+                sp = hp(x).view(b, c, t, h // ph, ph, w // pw, pw).mean(dim=(4, 6))
                 if extra is not None:
-                    sp = torch.cat([sp, extra.float().view(b, -1, t, 1, 1)], dim=1)
+                    sp = torch.cat([sp, hp(extra).view(b, -1, t, 1, 1)], dim=1)
                 # T+1 causal windows: {0}, {0,1}, ..., {T-2,T-1}, {T-1}.  The reference runs conv+BN+ReLU on
                 # all T+1 (so the BatchNorm batch statistics include the last, right-padded window) and
                 # only then drops it.
@@ -219,7 +220,7 @@ class TemporalBlock(nn.Module):
         y = _conv2d_padded_channels(x2, w_x if lanes is None else _pad_out(w_x, lanes))
         if extra2 is None:
             return _bn_act_2d(norm, y, relu)
-        sbias = extra2.float() @ wgt[:, c:, 0, 0].float().t()
+        sbias = hp(extra2).to(hp(wgt).dtype) @ hp(wgt[:, c:, 0, 0]).t()
         return _bn_act_2d(norm, y, relu, sbias=sbias)
 
     def forward(self, x, extra=None):
@@ -260,7 +261,7 @@ class TemporalBlock(nn.Module):
                 if contrib.shape[-2:] == (1, 1):
                     # whole-plane pooling (the reference's only setting): a constant plane per frame, i.e. a
                     # per-sample bias of the aggregation -- folded into the fused BatchNorm
-                    contrib = contrib.flatten(1).float()
+                    contrib = hp(contrib.flatten(1))
                     sbias = contrib if sbias is None else sbias + contrib
                 else:
                     if contrib.shape[-2:] != (h, w):

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .utils import staged_mean
+from .utils import hp, staged_mean
 
 
 def _future_discounts(future_discount, seq_len, n_present, like):
@@ -27,7 +27,8 @@ class SpatialRegressionLoss(nn.Module):
     def forward(self, prediction, target, n_present=3):
         assert prediction.dim() == 5, 'Must be a 5D tensor'
         mask = target[:, :, :1] != self.ignore_index
-        loss = self.loss_fn(prediction, target, reduction='none').sum(dim=-3, keepdim=True)
+        prediction = hp(prediction)
+        loss = self.loss_fn(prediction, target.to(prediction.dtype), reduction='none').sum(dim=-3, keepdim=True)
         seq_len = loss.shape[1]
         assert seq_len >= n_present
         loss = loss * _future_discounts(self.future_discount, seq_len, n_present, loss).view(1, seq_len, 1, 1, 1)
@@ -51,9 +52,9 @@ class SegmentationLoss(nn.Module):
         if target.shape[-3] != 1:
             raise ValueError('segmentation label must be an index-label with channel dimension = 1.')
         b, s, c, h, w = prediction.shape
-        loss = F.cross_entropy(prediction.reshape(b * s, c, h, w).float(), target.reshape(b * s, h, w),
+        loss = F.cross_entropy(hp(prediction.reshape(b * s, c, h, w)), target.reshape(b * s, h, w),
                                ignore_index=self.ignore_index, reduction='none',
-                               weight=self.class_weights.to(prediction.device))
+                               weight=self.class_weights.to(device=prediction.device, dtype=hp(prediction).dtype))
         loss = loss.view(b, s, h, w)
         assert s >= n_present
         loss = loss * _future_discounts(self.future_discount, s, n_present, loss).view(1, s, 1, 1)
@@ -76,8 +77,9 @@ class HDmapLoss(nn.Module):
         for i in range(target.shape[-3]):
             cur = target[:, i]
             b = cur.shape[0]
-            loss = F.cross_entropy(prediction[:, 2 * i:2 * (i + 1)].float(), cur, ignore_index=self.ignore_index,
-                                   reduction='none', weight=self.class_weights[i].to(target.device)).view(b, -1)
+            loss = F.cross_entropy(hp(prediction[:, 2 * i:2 * (i + 1)]), cur, ignore_index=self.ignore_index,
+                                   reduction='none',
+                                   weight=self.class_weights[i].to(device=target.device, dtype=hp(prediction).dtype)).view(b, -1)
             if self.use_top_k[i]:
                 k = int(self.top_k_ratio[i] * loss.shape[1])
                 loss = loss.topk(k, dim=1, sorted=False).values
@@ -92,6 +94,6 @@ class DepthLoss(nn.Module):
 
     def forward(self, prediction, target):
         b, s, n, d, h, w = prediction.shape
-        loss = F.cross_entropy(prediction.reshape(b * s * n, d, h, w).float(), target.reshape(b * s * n, h, w),
+        loss = F.cross_entropy(hp(prediction.reshape(b * s * n, d, h, w)), target.reshape(b * s * n, h, w),
                                ignore_index=self.ignore_index, reduction='none', weight=self.class_weights)
         return staged_mean(loss)

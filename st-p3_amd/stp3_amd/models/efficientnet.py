@@ -56,7 +56,7 @@ class StaticSamePadConv2d(nn.Conv2d):
         self._pad = (pad // 2, pad - pad // 2, pad // 2, pad - pad // 2)   # left, right, top, bottom
 
     def forward(self, x):
-        if self.groups == self.in_channels == self.out_channels and self.groups > 1 and x.is_cuda:
+        if self.groups == self.in_channels == self.out_channels and self.groups > 1 and x.is_cuda and x.dtype != torch.float64:
             # depthwise: hand-written HIP kernels (padding handled in-kernel, no F.pad copy)
             return ops.depthwise_conv2d(x, self.weight, self.stride[0], self._pad)
         if self.kernel_size == (1, 1) and x.shape[-2:] == (1, 1) and self.stride == (1, 1):
@@ -135,7 +135,7 @@ class MBConvBlock(nn.Module):
             # depthwise kernel's epilogue and swish(BN1(.)) is applied where it is consumed, never written
             x = ops_fused.dw_bn_se(x, self._depthwise_conv, self._bn1, self._se_reduce, self._se_expand,
                                    group=None if _fused._sync_world(self._bn1) > 1 else False)
-        elif x.is_cuda:
+        elif x.is_cuda and x.dtype != torch.float64:
             x = bn_act(self._bn1, self._depthwise_conv(x), ACT_SWISH)
             x = ops_fused.se_block(x, self._se_reduce, self._se_expand)
         else:

@@ -131,6 +131,15 @@ class STP3(nn.Module):
                                                 self.encoder_out_channels, out=out)
         return self.prebuilt_plan
 
+    def _bev_dtype(self):
+        """float32 (stp3.py:230-232) -- or, under bf16 autocast with the channels-last BEV and a temporal model that runs
+        its convolutions in bf16 anyway, bf16: the pooling kernel rounds its float32 sums once as it writes them (the
+        cast the temporal model's first operator would make), half the bytes written, no cast pass."""
+        if (self.bev_channels_last and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
+                and isinstance(self.temporal_model, TemporalModel) and len(self.temporal_model.model) > 0):
+            return torch.bfloat16
+        return torch.float32
+
     def calculate_birds_eye_view_features(self, image, intrinsics, extrinsics, future_egomotion):
         """(B,S,N,3,H,W) images -> BEV features (B,S,C,X,Y) float32 + depth logits (B,S,N,D,fH,fW).
         Replaces stp3.py:303-318 (and everything it calls)."""
@@ -141,7 +150,8 @@ class STP3(nn.Module):
             feat, depth = self.encoder(image.reshape(b * s * n, c, h, w))
             feat = feat.view(b, s, n, *feat.shape[1:])
             depth = depth.view(b, s, n, *depth.shape[1:])
-            return ops.lift_splat(feat, depth, self.prebuilt_plan, self.discount, self.bev_channels_last), depth, None
+            return ops.lift_splat(feat, depth, self.prebuilt_plan, self.discount, self.bev_channels_last,
+                                  self._bev_dtype()), depth, None
         # geometry-only work goes to a side stream: it overlaps the image encoder below
         cur = torch.cuda.current_stream(dev)
         if self._side_stream is None:
@@ -159,7 +169,7 @@ class STP3(nn.Module):
             buf.record_stream(cur)
         feat = feat.view(b, s, n, *feat.shape[1:])
         depth = depth.view(b, s, n, *depth.shape[1:])
-        bev = ops.lift_splat(feat, depth, plan, self.discount, self.bev_channels_last)
+        bev = ops.lift_splat(feat, depth, plan, self.discount, self.bev_channels_last, self._bev_dtype())
         return bev, depth, None
 
     def forward(self, image, intrinsics, extrinsics, future_egomotion):
@@ -176,7 +186,7 @@ class STP3(nn.Module):
             # stp3.py:145-152: six broadcast ego-motion planes; frame 0 gets zeros, frame t gets ego[t-1].  The planes
             # are never built: every consumer of the temporal model's input is a 1x1x1 convolution or the whole-plane
             # pooling, so they enter the first block as per-frame constants (a bias of its fused BatchNorms)
-            ego = future_egomotion.to(x.device, non_blocking=True).to(x.dtype)
+            ego = future_egomotion.to(x.device, non_blocking=True).float()
             ego = torch.cat([torch.zeros_like(ego[:, :1]), ego[:, :rf - 1]], dim=1)
             if isinstance(self.temporal_model, TemporalModel) and len(self.temporal_model.model) > 0:
                 states = self.temporal_model(x, ego)

@@ -302,7 +302,7 @@ class _LiftSplat(torch.autograd.Function):
     ``channels_last``: its memory is [B,T,X,Y,C] (no transpose passes), else the reference's [B,T,C,X,Y]."""
 
     @staticmethod
-    def forward(ctx, feat_pm, logits_pm, lift_plan, discount, channels_last):
+    def forward(ctx, feat_pm, logits_pm, lift_plan, discount, channels_last, bf16_out=False):
         _need_gpu(feat_pm, logits_pm)
         d = lift_plan.dims
         feat_pm = feat_pm.contiguous()
@@ -316,9 +316,11 @@ class _LiftSplat(torch.autograd.Function):
         check(_lib.lib().stp3_lift_bwd_needs_prob(ctypes.byref(d), ctypes.byref(needs)), 'stp3_lift_bwd_needs_prob')
         prob = (torch.empty(d.BT, d.N * d.fW, d.D, d.fH, dtype=torch.float32, device=dev)
                 if needs.value and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None)
-        layout = BEV_CHANNELS_LAST if channels_last else BEV_CHANNELS_FIRST
+        if bf16_out and not channels_last:
+            raise _lib.Stp3HipError('lift_splat: the bf16 BEV output exists for the channels-last layout only')
+        layout = (_lib.BEV_CHANNELS_LAST_BF16 if bf16_out else BEV_CHANNELS_LAST) if channels_last else BEV_CHANNELS_FIRST
         shape = (d.B, d.T, d.X, d.Y, d.C) if channels_last else (d.B, d.T, d.C, d.X, d.Y)
-        bev = torch.empty(shape, dtype=torch.float32, device=dev)
+        bev = torch.empty(shape, dtype=torch.bfloat16 if bf16_out else torch.float32, device=dev)
         ws, ws_bytes = lift_workspace(d, dev)
         ws_ptr = _ptr(ws)
         with _timed('lift_splat_fwd'):
@@ -356,21 +358,25 @@ class _LiftSplat(torch.autograd.Function):
                                                 ctypes.c_float(ctx.discount), _ptr(ws), ctypes.c_size_t(ws_bytes),
                                                 _ptr(grad_feat), _ptr(grad_logits), _stream())
         check(rc, 'stp3_lift_splat_bwd')
-        return grad_feat, grad_logits, None, None, None
+        return grad_feat, grad_logits, None, None, None, None
 
 
-def lift_splat(feat, depth_logits, lift_plan, discount, channels_last=False):
+def lift_splat(feat, depth_logits, lift_plan, discount, channels_last=False, out_dtype=torch.float32):
     """Differentiable lift + voxel pool.
 
     feat (B,T,N,C,fH,fW) and depth_logits (B,T,N,D,fH,fW) in any memory format (channels-last
     memory makes the re-layout free); returns the BEV features (B,T,C,X,Y) float32 (always float32, even
     under autocast: stp3.py:230-232).  ``channels_last=False``: contiguous, the reference's layout;
     ``True``: the same logical tensor stored [B,T,X,Y,C] -- what the NHWC convolutions downstream read and
-    what their gradient arrives in -- with no transpose pass on either side."""
+    what their gradient arrives in -- with no transpose pass on either side.  ``out_dtype=torch.bfloat16`` (channels-last
+    only): the float32 sums are rounded once to bf16 as they are written -- the values a bf16 consumer would make of the
+    float32 tensor, without the tensor and without the consumer's cast pass; everything up to that rounding (softmax,
+    run sums, per-voxel sums, the discounted accumulation over the frames) stays float32."""
     d = lift_plan.dims
     feat_pm = feat.float().permute(0, 1, 2, 4, 5, 3).reshape(d.BT, d.NPIX, d.C)
     logits_pm = depth_logits.float().permute(0, 1, 2, 4, 5, 3).reshape(d.BT, d.NPIX, d.D)
-    return _LiftSplat.apply(feat_pm, logits_pm, lift_plan, float(discount), bool(channels_last))
+    return _LiftSplat.apply(feat_pm, logits_pm, lift_plan, float(discount), bool(channels_last),
+                            out_dtype == torch.bfloat16)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -432,6 +438,28 @@ def _dw_dims(x, k, stride, pad_top, pad_left, ho, wo):
     return _lib.DwConvDims(n, h, w, c, ho, wo, k, stride, pad_top, pad_left, dt)
 
 
+_DW_WEIGHT_CACHE = {}
+
+
+def _dw_weight_taps(weight):
+    """(C,1,K,K) depthwise weight -> [K*K][C] float32 (tap-major: what the kernels read, 16-byte vectors along C).  The
+    transposed copy of a PARAMETER is kept until the parameter changes (its version counter, or the epoch of
+    out-of-band updates ``invalidate_weight_cache`` bumps): one tiny transpose kernel per layer and optimizer step
+    instead of one per forward AND backward use."""
+    c, _, k, _ = weight.shape
+    if not (isinstance(weight, torch.nn.Parameter) and weight.is_leaf):
+        return weight.detach().float().reshape(c, k * k).t().contiguous()
+    key = id(weight)
+    stamp = (weight._version, _WEIGHT_EPOCH[0], weight.data_ptr(), tuple(weight.shape))
+    ent = _DW_WEIGHT_CACHE.get(key)
+    if ent is None or ent[0]() is not weight or ent[1] != stamp:
+        wt = weight.detach().float().reshape(c, k * k).t().contiguous()
+        ent = (weakref.ref(weight), stamp, wt)
+        _DW_WEIGHT_CACHE[key] = ent
+        weakref.finalize(weight, _DW_WEIGHT_CACHE.pop, key, None)
+    return ent[2]
+
+
 class _DepthwiseConv2d(torch.autograd.Function):
     """x (N,C,H,W) channels-last memory, weight (C,1,K,K) -> y (N,C,Ho,Wo) channels-last memory.
     pad = (left, right, top, bottom) explicit zero padding ("static same": may be asymmetric)."""
@@ -445,7 +473,7 @@ class _DepthwiseConv2d(torch.autograd.Function):
         ho = (h + top + bottom - k) // stride + 1
         wo = (w + left + right - k) // stride + 1
         x = x.contiguous(memory_format=torch.channels_last)
-        wt = weight.detach().float().reshape(c, k * k).t().contiguous()        # [K*K][C] float32
+        wt = _dw_weight_taps(weight)                                            # [K*K][C] float32
         y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         dims = _dw_dims(x, k, stride, top, left, ho, wo)
         check(_lib.lib().stp3_dwconv2d_fwd(ctypes.byref(dims), _ptr(x), _ptr(wt), _ptr(y), _stream()),

@@ -322,7 +322,7 @@ class _DwBnSe(torch.autograd.Function):
         wo = (w + left + right - k) // stride + 1
         x = x.contiguous(memory_format=torch.channels_last)
         dev = x.device
-        wt = dw_weight.detach().float().reshape(c, k * k).t().contiguous()               # [K*K][C] float32
+        wt = ops._dw_weight_taps(dw_weight)                                              # [K*K][C] float32, cached per step
         e2 = torch.empty((n, c, ho, wo), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
         dwd = ops._dw_dims(x, k, stride, top, left, ho, wo)
         sd = _lib.SeDims(n, ho * wo, c, c, dwd.dtype)

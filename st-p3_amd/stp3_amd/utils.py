@@ -3,6 +3,14 @@ import torch
 import torch.nn as nn
 
 
+def hp(x):
+    """``x`` in at least float32: bf16 / half are cast up, float32 AND float64 pass through.  Used wherever the host
+    code widens an intermediate for accuracy (statistics, per-sample biases, losses): written as ``.float()`` those places
+    would round a float64 evaluation of the model -- the noise-free truth the parity tests compare against
+    (tests/test_step_truth_cpu.py) -- back to float32."""
+    return x if x.dtype in (torch.float32, torch.float64) else x.float()
+
+
 def to_channels_last(module):
     """Put every 2-D / 3-D convolution weight in channels-last memory (what the MI355X conv kernels
     and the pixel-major lift operators want).  ``module.to(memory_format=...)`` cannot be used on

@@ -77,6 +77,12 @@ def case_lift(ops, cfg, batch, seq, cams, seed, golden=None):
     f4, lg4 = feat.clone().requires_grad_(), logits.clone().requires_grad_()
     ops.lift_splat(f4, lg4, plan, cfg['discount'], True).backward(go16.float())
     cl_equal = cl_equal and bool(torch.equal(f3.grad, f4.grad) and torch.equal(lg3.grad, lg4.grad))
+    # bf16 BEV output (STP3_BEV_CHANNELS_LAST_BF16): the float32 result rounded once, and a backward that does not care
+    f5, lg5 = feat.clone().requires_grad_(), logits.clone().requires_grad_()
+    bev16 = ops.lift_splat(f5, lg5, plan, cfg['discount'], True, torch.bfloat16)
+    bev16.backward(go16)
+    cl_equal = cl_equal and bool(bev16.dtype == torch.bfloat16 and torch.equal(bev16.detach(), bev_cl.detach().to(torch.bfloat16))
+                                 and torch.equal(f5.grad, f3.grad) and torch.equal(lg5.grad, lg3.grad))
     exact = lo.pool_exact(feat, logits, vox, (grid.X, grid.Y), cfg['discount'])
     gf, gl = lo.pool_backward_exact(go, feat, logits, vox, cfg['discount'])
     out = {'ids_equal_oracle': bool(np.array_equal(ids, vox)), 'pixel_major_ids_equal': bool(np.array_equal(pm, vox)),
@@ -193,7 +199,7 @@ def wprep(ops):
     torch.manual_seed(0)
     ws = [torch.nn.Parameter((torch.randn(*s) * 3).contiguous(memory_format=torch.channels_last if i % 2 else torch.contiguous_format))
           for i, s in enumerate([(8, 16, 3, 3), (24, 8, 1, 1), (5, 40, 7, 7), (64, 64, 3, 3), (3, 8, 5, 5)])]
-    sh = ops._WeightShadows()
+    sh = ops._WeightShadows('cpu')
     for w in ws:
         sh.register(w)
     with torch.no_grad():
@@ -441,7 +447,11 @@ def conv(ops):
                                                  # strided layers: the data gradient runs per input phase
                                                  '7x7s2': (16, 8, 7, 2, 3, 1, False), '1x1s2': (8, 16, 1, 2, 0, 1, False),
                                                  '3x3s2p0': (8, 8, 3, 2, 0, 1, True), '3x3s3': (8, 8, 3, 3, 1, 1, False),
-                                                 '5x5s2': (8, 16, 5, 2, 2, 1, False)}.items():
+                                                 '5x5s2': (8, 16, 5, 2, 2, 1, False),
+                                                 # weight gradient with several taps per workgroup: a kernel row of a wide
+                                                 # layer (128 x 64 and 64 x 128 tiles), several ci / co tiles
+                                                 '3x3_co96': (40, 96, 3, 1, 1, 1, False), '3x3_ci96': (96, 40, 3, 1, 1, 1, False),
+                                                 '3x3_d2_co136': (72, 136, 3, 1, 2, 2, False)}.items():
         x0 = torch.randn(2, cin, 9, 12).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         w0 = (torch.randn(cout, cin, k, k) * 0.2).to(torch.bfloat16).float()       # bf16-representable weights
         b0 = torch.randn(cout) if bias else None

@@ -122,6 +122,27 @@ def test_forward_is_bit_reproducible_and_layout_independent():
     assert torch.equal(ga[0], gc[0]) and torch.equal(ga[1], gc[1])
 
 
+def test_bf16_bev_output_is_the_float32_result_rounded_once():
+    """STP3_BEV_CHANNELS_LAST_BF16 (what the bf16 training step uses): bit-equal to rounding the float32 channels-last
+    BEV to bf16, and the backward of a bf16 gradient gives the same bits as through the float32 output."""
+    from stp3_amd import ops
+    intr, extr, ego, feat, logits = H.lift_inputs(H.FULL, 2, 3, 6, seed=23)
+    frustum, res, start, dim = H.grid_params(H.FULL)
+    grid = ops.LiftGrid(frustum, res, start, dim, 'cuda')
+    plan = ops.LiftPlan.build(grid, intr, extr, ego, 64)
+    go = torch.randn(2, 3, 200, 200, 64, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16).cuda().permute(0, 1, 4, 2, 3)
+    out = []
+    for dtype in (torch.float32, torch.bfloat16):
+        f, l = feat.cuda().requires_grad_(), logits.cuda().requires_grad_()
+        bev = ops.lift_splat(f, l, plan, 0.5, True, dtype)
+        assert bev.dtype == dtype and bev.permute(0, 1, 3, 4, 2).is_contiguous()
+        bev.backward(go if dtype == torch.bfloat16 else go)
+        out.append((bev.detach(), f.grad, l.grad))
+    (b32, gf32, gl32), (b16, gf16, gl16) = out
+    assert torch.equal(b16, b32.to(torch.bfloat16))
+    assert torch.equal(gf16, gf32) and torch.equal(gl16, gl32)
+
+
 def test_batch4_properties_at_bench_size():
     """BASELINE.json configs[1]/[2] shape (B=4, T=3): size-independent properties."""
     intr, extr, ego, feat, logits = H.lift_inputs(H.FULL, 4, 3, 6, seed=31)

@@ -1,0 +1,113 @@
+"""CPU: the product's MODEL MATH against the reference, free of rounding noise -- link 1 of the parity argument.
+
+The whole benchmarked step (BASELINE configs[2], top-k off) is an ill-conditioned function in float32: the reference's OWN
+float32 run differs from its OWN float64 evaluation by 4e-3 at the decoder outputs and by 8..11 % in the temporal /
+encoder / trunk gradients (ReLU masks flip; oracle/make_golden_step.py explains and measures it:
+step_b2k0.npz vs step_b2k0d.npz).  So a float32 whole-step comparison cannot pin anything tighter than that.  What CAN be
+pinned tightly is the mathematics: here the product's modules -- every restructuring included (dead dilated taps
+dropped, pooled branches as per-sample biases, ego-motion planes folded into the first temporal block, causal 3-D
+convolutions as paired 2-D ones, loss rewrites) -- are evaluated in FLOAT64 on the CPU (plain torch operators; lift by
+the reference's algorithm, oracle/cpu_model.py) on the fixture batch, and compared with the reference's float64 run
+(tests/golden/step_b2k0d.npz): every block's input, output and incoming gradient, every head output, every loss entry
+and every parameter gradient.  Both sides being noise-free, they must agree to float32-fixture precision.
+
+The kernels are then pinned against this same mathematics block by block (tests/test_train_parity_gpu.py, link 2), and
+the float32 / bf16 GPU step as a whole to within the reference's own noise (tests/test_step_parity_gpu.py, link 3).
+
+~4 minutes and ~25 GB on 8 cores: runs with STP3_SLOW_TESTS=1 (measured values: profiles/r03_step_truth_cpu.json).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+C3 = {'LIFT.GT_DEPTH': True, 'INSTANCE_SEG.ENABLED': True, 'INSTANCE_FLOW.ENABLED': True}
+NO_TOPK = {'SEMANTIC_SEG.VEHICLE.USE_TOP_K': False, 'SEMANTIC_SEG.PEDESTRIAN.USE_TOP_K': False,
+           'SEMANTIC_SEG.HDMAP.USE_TOP_K': [False, False]}
+GROUPS = [('encoder.backbone', 'trunk'), ('encoder', 'encoder_heads'), ('temporal_model', 'temporal'),
+          ('decoder', 'decoder')]
+
+
+def rel(a, ref):
+    a = torch.as_tensor(np.asarray(a)).double().flatten()
+    r = torch.as_tensor(np.asarray(ref)).double().flatten()
+    return ((a - r).norm() / r.norm().clamp_min(1e-30)).item()
+
+
+def product_step_float64(batch_size=2):
+    """The product's TrainingModule on the CPU in float64 (geometry constants and poses stay float32: voxel ids are
+    float32 arithmetic by contract), with the taps of tests/helpers.BlockTaps."""
+    from oracle.cpu_model import CpuPortSTP3
+    from stp3_amd import synthetic
+    from stp3_amd.config import perception_cfg
+    from stp3_amd.trainer import TrainingModule
+    from tests.test_train_parity_gpu import make_deterministic_train
+    tm = TrainingModule(perception_cfg(**C3, **NO_TOPK).convert_to_dict())
+    H.fill_deterministic(tm.model)
+    make_deterministic_train(tm)
+    tm.model.__class__ = CpuPortSTP3
+    geo = {k: getattr(tm.model, k).data.clone() for k in ('frustum', 'bev_resolution', 'bev_start_position', 'bev_dimension')}
+    tm.double()
+    for k, v in geo.items():
+        getattr(tm.model, k).data = v
+    taps = H.BlockTaps(tm.model)
+    batch = synthetic.make_batch(batch=batch_size, seq=3, seed=5, gt_depth=True, instance=True)
+    batch['image'] = batch['image'].double()
+    output, labels, loss = tm.shared_step(batch, True)
+    for k in H.DECODER_HEADS:
+        output[k].retain_grad()
+    total = sum(loss.values())
+    total.backward()
+    fp = taps.collect()
+    for k, attr in H.DECODER_HEADS.items():
+        o, g = output[k], output[k].grad
+        if k != 'hdmap':
+            o, g = o.flatten(0, 1), g.flatten(0, 1)
+        fp[f'decoder.{attr}/out'], _ = H.fingerprint(o)
+        fp[f'decoder.{attr}/gout'], _ = H.fingerprint(g)
+    return tm, output, loss, total, fp
+
+
+@pytest.mark.skipif(os.environ.get('STP3_SLOW_TESTS') != '1', reason='float64 whole step on the CPU: ~4 min, ~25 GB (STP3_SLOW_TESTS=1)')
+def test_product_math_in_float64_equals_the_reference_in_float64():
+    g = H.load('step_b2k0d.npz')
+    tm, output, loss, total, fp = product_step_float64()
+    errs = {'loss_total': abs(total.item() - g['loss_total'].item()) / abs(g['loss_total'].item())}
+    for k, v in loss.items():
+        errs[f'loss/{k}'] = abs(v.item() - g[f'loss/{k}'].item()) / max(abs(g[f'loss/{k}'].item()), 1e-3)
+    for k in ('segmentation', 'pedestrian', 'hdmap', 'instance_center', 'instance_offset', 'instance_flow', 'depth_prediction'):
+        errs[f'out/{k}'] = rel(H.sample(output[k], 256), g[f'out/{k}'])
+    acc, worst = {}, {}
+    for name, p in tm.model.named_parameters():
+        key = f'p/grad/{name}'
+        if key not in g.files:
+            continue
+        assert p.grad is not None, name
+        grp = next((v for k, v in GROUPS if name.startswith(k)), 'other')
+        a = acc.setdefault(grp, [[], []])
+        a[0].append(H.sample(p.grad, 256).double())
+        a[1].append(torch.from_numpy(g[key]).double())
+        worst[name] = ((a[0][-1] - a[1][-1]).norm() / torch.from_numpy(g[f'p/gnorm/{name}']).double().clamp_min(1e-30)
+                       * (p.grad.numel() / a[0][-1].numel()) ** 0.5).item()
+    gerr = {k: ((torch.cat(a) - torch.cat(r)).norm() / torch.cat(r).norm()).item() for k, (a, r) in acc.items()}
+    blocks = sorted({k.rsplit('/', 1)[0] for k in g.files if k.endswith('/out')})
+    tap_out = {b: rel(fp[f'{b}/out'], g[f'{b}/out']) for b in blocks}
+    tap_gout = {b: rel(fp[f'{b}/gout'], g[f'{b}/gout']) for b in blocks if f'{b}/gout' in g.files}
+    report = dict(errs=errs, grad=gerr, tap_out=tap_out, tap_gout=tap_gout,
+                  worst_params=dict(sorted(worst.items(), key=lambda kv: -kv[1])[:10]))
+    path = os.environ.get('STP3_TRUTH_REPORT')
+    if path:
+        json.dump(report, open(path, 'w'), indent=1, sort_keys=True)
+    print('[step truth] loss', errs['loss_total'], 'grads', gerr, 'worst tap out', max(tap_out.values()), 'gout',
+          max(tap_gout.values()))
+    assert len(blocks) >= 44
+    # the fixture stores float32 fingerprints of float64 values: 6e-8 per element is the floor
+    assert max(v for k, v in errs.items() if k.startswith('loss')) <= 1e-6, errs
+    assert max(v for k, v in errs.items() if k.startswith('out/')) <= 1e-5, errs
+    assert max(tap_out.values()) <= 1e-5, sorted(tap_out.items(), key=lambda kv: -kv[1])[:5]
+    assert max(tap_gout.values()) <= 1e-4, sorted(tap_gout.items(), key=lambda kv: -kv[1])[:5]
+    assert max(gerr.values()) <= 1e-4, gerr

@@ -9,17 +9,18 @@ with deterministic-fill weights is chaotic (a bf16 rounding of the image alone m
 40 %, for ANY implementation, so an end-to-end bf16-vs-float32 number says nothing about kernels):
 
   1. float32, whole modules and the whole c3 training step against the REFERENCE fixtures: outputs and every loss
-     entry to <= 2e-3 / 2e-4 (measured 1e-5), single-module gradients to <= 5e-3, whole-step gradients to <= 0.2.
-     The last tolerance is not a kernel tolerance: the product's own CPU float32 path (plain torch operators, reference
-     voxel-pool algorithm) differs from the reference by 0.129 (trunk) / 0.105 (encoder heads) / 0.058 (temporal) /
-     0.0099 (decoder) on the same step -- the top-k in the segmentation loss selects different pixels after 1e-6
-     differences and the BatchNorm chain amplifies; the MI355X float32 numbers are 0.116 / 0.092 / 0.085 / 0.0094.
-  2. bf16, block by block, TEACHER-FORCED from link 1: every MBConv block, ResNet block, up-sampling block, temporal
-     block and head of the float32 c3 step is re-run alone on its captured float32 input and output-gradient, once in
-     float32 and once exactly as bench.py runs it (bf16 autocast, channels-last, hand-written MFMA convolutions with
-     the BatchNorm statistics in the epilogue, SE kernels); outputs, input gradients and parameter gradients of the
-     two runs must agree to bf16 accuracy.  Every kernel of the bf16 step is covered at the shapes and value
-     distributions of the real step, without the chaos of the chain.
+     entry to <= 2e-3 / 2e-4 (measured 1e-5), single-module gradients to <= 5e-3 (the 4-image encoder: 5e-2).  The
+     whole-step GRADIENTS are compared in tests/test_step_parity_gpu.py, against the reference's float64 evaluation and
+     within the reference's own float32 rounding noise (8..11 % behind the decoder -- the reference's float32 run
+     differs that much from its own float64 run; the mathematics itself is pinned noise-free by
+     tests/test_step_truth_cpu.py).
+  2. block by block, TEACHER-FORCED from the float32 c3 step: every MBConv block, ResNet block, up-sampling block,
+     temporal block and head is re-run alone on its captured input and output-gradient,
+       a. in float32 on the kernels against the SAME block evaluated in float64 (torch statements) on the same inputs:
+          outputs <= 1e-4, input and parameter gradients <= 2e-3 -- the kernels against the mathematics, at the shapes
+          and value distributions of the real step, without the conditioning of the chain;
+       b. exactly as bench.py runs it (bf16 autocast, channels-last, hand-written MFMA convolutions with the BatchNorm
+          statistics in the epilogue, fused MBConv operators) against its float32 run: bf16 accuracy.
 The bf16 whole-step case checks every entry of the loss dictionary against the reference to 5 % (measured 1.6e-2).
 """
 import json
@@ -37,8 +38,8 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 C3 = {'LIFT.GT_DEPTH': True, 'INSTANCE_SEG.ENABLED': True, 'INSTANCE_FLOW.ENABLED': True}
-TOL = {          # mode -> (outputs, single-module gradients, whole-step gradients, loss)
-    'fp32': dict(out=2e-3, grad=5e-3, step_grad=0.2, loss=2e-4),
+TOL = {          # mode -> (outputs, single-module gradients, encoder-module gradients, loss)
+    'fp32': dict(out=2e-3, grad=5e-3, encoder_grad=5e-2, loss=2e-4),
     'bf16': dict(out=5e-2, grad=0.12),          # decoder only (well conditioned): measured 2.8e-2 / 6.5e-2
 }
 G = None
@@ -163,8 +164,8 @@ def test_encoder_train(mode):
     assert max(errs['feat'], errs['depth']) <= tol['out'], errs
     # 4 images x 14x30: tiny BatchNorm populations amplify rounding differences of mathematically identical
     # restructurings (pooled ASPP branch as a bias, dead dilated taps dropped): even the product's CPU float32 path
-    # differs from the reference by 4e-3 (heads) .. 1e-2 (trunk, image gradient) here -> whole-network tolerance
-    assert max(errs['depth_head'], errs['feature_head'], errs['trunk'], errs['dx']) <= tol['step_grad'], errs
+    # differs from the reference by 4e-3 (heads) .. 1e-2 (trunk, image gradient) here; MI355X: 0.8e-2 .. 1.9e-2
+    assert max(errs['depth_head'], errs['feature_head'], errs['trunk'], errs['dx']) <= tol['encoder_grad'], errs
 
 
 def _c3_module():
@@ -207,7 +208,9 @@ def test_training_step_c3_float32():
     assert max(v for k, v in errs.items() if k.startswith('loss')) <= tol['loss'], errs
     assert max(v for k, v in errs.items() if k.startswith('out/')) <= 3 * tol['out'], errs
     assert gerr['grad_decoder'] <= 2e-2, errs                       # closest to the losses: no amplification yet
-    assert max(gerr[k] for k in ('grad_trunk', 'grad_encoder_heads', 'grad_temporal')) <= tol['step_grad'], errs
+    # the gradients behind the decoder are compared where the comparison means something: against the reference's
+    # float64 evaluation and within the reference's own float32 noise (tests/test_step_parity_gpu.py); here they are
+    # only recorded
 
 
 def test_training_step_c3_bf16_losses():
@@ -229,6 +232,7 @@ def test_training_step_c3_bf16_losses():
     assert not bad, bad[:5]
 
 
+F32_BLOCK_TOL = dict(out=1e-4, grad=2e-3)                # float32 kernels vs the block in float64, same inputs
 BLOCK_TOL = dict(out=2e-2, dparam=2e-2, dx=2e-2)          # bf16 accuracy for a well-conditioned block
 PROBE_FACTOR = 6.0                                        # ... or this many times the block's own sensitivity
 
@@ -298,6 +302,8 @@ def test_bf16_blocks_teacher_forced_from_the_float32_step():
 
     def run(mod, args, kwargs, gout, mode):
         mod.zero_grad(set_to_none=True)
+        if mode == 'f64':
+            mod.double()                       # float64 tensors take the torch statements everywhere (layers/fused.bn_act)
         ins = []
         for a in args:
             if torch.is_tensor(a) and a.is_floating_point():
@@ -307,25 +313,36 @@ def test_bf16_blocks_teacher_forced_from_the_float32_step():
                 if mode == 'bf16':
                     a = a.to(torch.bfloat16)
                     a = a.contiguous(memory_format=torch.channels_last) if a.dim() == 4 else a
+                if mode == 'f64':
+                    a = a.double()
                 a.requires_grad_(True)
             ins.append(a)
+        kw = {k: (v.double() if (mode == 'f64' and torch.is_tensor(v) and v.is_floating_point()) else v)
+              for k, v in kwargs.items()}
         with ctx('bf16' if mode == 'bf16' else 'fp32'):
-            y = run_fused(mod, *ins) if mod in heads else mod(*ins, **kwargs)
+            y = run_fused(mod, *ins) if mod in heads else mod(*ins, **kw)
         y.backward(gout.to(torch.bfloat16).to(y.dtype) if mode == 'probe' else gout.to(y.dtype))
-        dxs = [a.grad.float() for a in ins if torch.is_tensor(a) and a.requires_grad and a.grad is not None]
-        dps = [p.grad.float().flatten().clone() for p in mod.parameters() if p.grad is not None]
-        return y.detach().float(), dxs, torch.cat(dps) if dps else torch.zeros(1, device=y.device)
+        dxs = [a.grad.double() for a in ins if torch.is_tensor(a) and a.requires_grad and a.grad is not None]
+        dps = [p.grad.double().flatten().clone() for p in mod.parameters() if p.grad is not None]
+        out = (y.detach().double(), dxs, torch.cat(dps) if dps else torch.zeros(1, device=y.device, dtype=torch.float64))
+        if mode == 'f64':
+            mod.float()                        # float32 -> float64 -> float32 is exact: the weights are back bit for bit
+            mod.zero_grad(set_to_none=True)
+        return out
 
     def r2(a, b):
         return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
-    worst, rows, probes = dict(out=0.0, dparam=0.0, dx=0.0), {}, {}
+
+    worst, rows, probes, rows64 = dict(out=0.0, dparam=0.0, dx=0.0), {}, {}, {}
     for n, (args, kwargs, gout) in sorted(work.items()):
+        yt, dxt, dpt = run(blocks[n], args, kwargs, gout, 'f64')          # the block's mathematics, noise-free
         y0, dx0, dp0 = run(blocks[n], args, kwargs, gout, 'fp32')
         y1, dx1, dp1 = run(blocks[n], args, kwargs, gout, 'bf16')
         y2, dx2, dp2 = run(blocks[n], args, kwargs, gout, 'probe')
         e = dict(out=r2(y1, y0), dparam=r2(dp1, dp0), dx=max([r2(a, b) for a, b in zip(dx1, dx0)] + [0.0]))
         probes[n] = dict(out=r2(y2, y0), dparam=r2(dp2, dp0), dx=max([r2(a, b) for a, b in zip(dx2, dx0)] + [0.0]))
         rows[n] = e
+        rows64[n] = dict(out=r2(y0, yt), dparam=r2(dp0, dpt), dx=max([r2(a, b) for a, b in zip(dx0, dxt)] + [0.0]))
         for k in worst:
             worst[k] = max(worst[k], e[k])
     record('bf16_blocks', 'worst', worst)
@@ -334,6 +351,13 @@ def test_bf16_blocks_teacher_forced_from_the_float32_step():
     record('bf16_blocks', 'per_block_dx', {n: e['dx'] for n, e in rows.items()})
     record('bf16_blocks', 'probe_dparam', {n: e['dparam'] for n, e in probes.items()})
     record('bf16_blocks', 'probe_dx', {n: e['dx'] for n, e in probes.items()})
+    for k in ('out', 'dparam', 'dx'):
+        record('fp32_blocks_vs_float64', k, {n: e[k] for n, e in rows64.items()})
+    # link 2a: the float32 kernel path of every block against the block's float64 evaluation on the SAME inputs
+    # (teacher-forced, so the chain's conditioning plays no part): outputs <= 1e-4, gradients <= 2e-3
+    over64 = {n: e for n, e in rows64.items() if e['out'] > F32_BLOCK_TOL['out'] or e['dparam'] > F32_BLOCK_TOL['grad']
+              or e['dx'] > F32_BLOCK_TOL['grad']}
+    assert not over64, over64
     over = {n: (e, probes[n]) for n, e in rows.items()
             if any(e[k] > max(BLOCK_TOL[k], PROBE_FACTOR * probes[n][k]) for k in BLOCK_TOL)}
     assert not over, over

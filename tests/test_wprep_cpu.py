@@ -77,7 +77,7 @@ def test_shadow_table_and_kernel_arithmetic(monkeypatch):
 
     monkeypatch.setattr(_lib, 'lib', lambda: FakeLib())
     monkeypatch.setattr(ops, '_stream', lambda: None)
-    sh = ops._WeightShadows()
+    sh = ops._WeightShadows('cpu')
     for w in weights:
         assert sh.lookup(w) is None
         sh.register(w)
