@@ -441,6 +441,53 @@ int stp3_mbconv_bwd_apply(const stp3_se_dims* dims, int32_t ldg, const void* da,
                           void* dx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training losses of the perception path and the label warp (csrc/stp3_loss.hip).
+ *
+ * stp3_ce_topk_fwd / _bwd -- weighted cross-entropy with ignore_index, per-row scale (future discount) and the mean of
+ * the k largest per-pixel losses of every row: stp3/losses.py:43-83 (SegmentationLoss: rows = B*S), :85-114 (HDmapLoss,
+ * one call per map element: rows = B), :116-134 (DepthLoss: k = 0, no selection).
+ *   logits  element (row, c, p) at logits[row*stride_row + c*stride_c + p*stride_p], dims.dtype f32 / bf16
+ *   labels  [rows][P] int64;  class_weights [C] float32 or NULL;  row_scale [rows] float32 or NULL
+ *   loss_px [rows][P] float32 out: scale[row] * w[y] * (logsumexp(z) - z[y]), 0 for ignored pixels (kept for the backward)
+ *   sel     [rows][2] float32 out: tau = the k-th largest loss of the row (found by a radix select on the float bits; the
+ *           reference sorts the row, losses.py:76-81) and the share of the elements EQUAL to tau in the top k
+ *   out[0]  = (accumulate ? out[0] : 0) + out_scale * sum_rows sum_{k largest} loss      (out_scale = weight / (rows*k))
+ *   bwd     dlogits (same strides / dtype as logits) = gout[0] * out_scale * take * scale[row] * w[y] * (softmax - onehot),
+ *           take = 1 above tau, the tie share at tau, 0 below: ties at the threshold share their part of the gradient
+ *           equally (torch.topk picks arbitrary ones; the loss value and the total gradient mass are the same)
+ *   k <= 0 or k >= P: no selection (mean over all pixels: out_scale = weight / (rows*P)).
+ * stp3_reg_loss_fwd / _bwd -- stp3/losses.py:6-40 SpatialRegressionLoss: pred, target [rows][C][P] contiguous;
+ *   out[0] = sum over pixels with target[row][0][p] != ignore_value of scale[row] * sum_c |d| (norm 1) or d^2 (norm 2),
+ *   divided by the number of such pixels (0 when there are none); out[1] = that number.  bwd: stat = out of the forward.
+ * stp3_warp_nearest -- stp3/utils/geometry.py:196-238 warp_features with mode='nearest' on label maps
+ *   (F.affine_grid + F.grid_sample, zeros padding, align_corners=False): x, y [frames][C][H][W] float32, theta [frames][6]
+ *   (row-major 2x3), identity [frames] int32 or NULL (non-zero: the frame is copied unchanged).
+ * Deterministic; float32 arithmetic; workspaces: stp3_ce_topk_workspace_bytes / stp3_reg_loss_workspace_bytes.
+ */
+typedef struct stp3_ce_dims {
+    int32_t rows, P, C, k;
+    int32_t ignore_index, dtype;
+    int64_t stride_row, stride_c, stride_p;
+} stp3_ce_dims;
+
+int stp3_ce_topk_workspace_bytes(const stp3_ce_dims* dims, size_t* bytes);
+int stp3_ce_topk_fwd(const stp3_ce_dims* dims, const void* logits, const int64_t* labels, const float* class_weights,
+                     const float* row_scale, float* loss_px, float* sel, double out_scale, int32_t accumulate, float* out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int stp3_ce_topk_bwd(const stp3_ce_dims* dims, const void* logits, const int64_t* labels, const float* class_weights,
+                     const float* row_scale, const float* loss_px, const float* sel, const float* gout, double out_scale,
+                     void* dlogits, void* stream);
+int stp3_reg_loss_workspace_bytes(size_t* bytes);
+int stp3_reg_loss_fwd(int32_t rows, int32_t C, int32_t P, int32_t norm, float ignore_value, int32_t dtype, const void* pred,
+                      const float* target, const float* row_scale, float* out, void* workspace, size_t workspace_bytes,
+                      void* stream);
+int stp3_reg_loss_bwd(int32_t rows, int32_t C, int32_t P, int32_t norm, float ignore_value, int32_t dtype, const void* pred,
+                      const float* target, const float* row_scale, const float* stat, const float* gout, void* dpred,
+                      void* stream);
+int stp3_warp_nearest(int32_t frames, int32_t C, int32_t H, int32_t W, const float* x, const float* theta,
+                      const int32_t* identity, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * bf16 shadow copies of all convolution weights in ONE launch (csrc/stp3_wprep.hip).  Replaces the per-layer cast / flip / transpose / re-layout the host would
  * otherwise redo after every optimizer step for the operands of stp3_conv2d_fwd (forward: [Cout][KH][KW][Cin];
  * data gradient: [Cin][KH][KW][Cout] with the taps flipped).

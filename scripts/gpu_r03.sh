@@ -6,13 +6,12 @@ out=gpurun_out/${1:-r03}; mkdir -p $out
 export STP3_PARITY_REPORT=$out/parity.json STP3_PARITY_REPORT_STEP=$out/parity_step.json TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_fused_ops_gpu.py tests/test_lift_gpu.py tests/test_conv_gpu.py -m gpu -q -x -p no:cacheprovider > $out/pytest_new.log 2>&1
 echo "new tests rc=$?" | tee -a $out/pytest_new.log; grep -E "passed|failed|Error|assert" $out/pytest_new.log | tail -8
-timeout 300 python scripts/time_conv.py 3x3 > $out/time_conv_3x3.log 2>&1; cat $out/time_conv_3x3.log
-if [ -f st-p3_amd/stp3_amd/libstp3hip_taps3.so ]; then
-  EXP_LIB=$PWD/st-p3_amd/stp3_amd/libstp3hip_taps3.so timeout 300 python scripts/time_conv.py 3x3 > $out/time_conv_3x3_taps3.log 2>&1; echo "--- taps3 build"; cat $out/time_conv_3x3_taps3.log
+timeout 300 python scripts/time_conv.py > $out/time_conv.log 2>&1; cat $out/time_conv.log
+if [ "$3" == "lift" ]; then
+  timeout 300 python scripts/time_lift.py 4 > $out/time_lift_c3.log 2>&1; tail -8 $out/time_lift_c3.log
+  timeout 600 python scripts/time_lift.py 1 stress 5 > $out/time_lift_c5_b1.log 2>&1; tail -8 $out/time_lift_c5_b1.log
+  timeout 600 python scripts/time_lift.py 4 stress 5 > $out/time_lift_c5_b4.log 2>&1; tail -8 $out/time_lift_c5_b4.log
 fi
-timeout 300 python scripts/time_lift.py 4 > $out/time_lift_c3.log 2>&1; tail -8 $out/time_lift_c3.log
-timeout 600 python scripts/time_lift.py 1 stress 5 > $out/time_lift_c5_b1.log 2>&1; tail -8 $out/time_lift_c5_b1.log
-timeout 600 python scripts/time_lift.py 4 stress 5 > $out/time_lift_c5_b4.log 2>&1; tail -8 $out/time_lift_c5_b4.log
 timeout 1500 python -m pytest tests/test_step_parity_gpu.py tests/test_train_parity_gpu.py -m gpu -q -s -p no:cacheprovider > $out/pytest_parity.log 2>&1
 echo "parity tests rc=$?" | tee -a $out/pytest_parity.log; grep -E "passed|failed|\[step parity\]|^E  " $out/pytest_parity.log | cut -c1-400 | tail -30
 if [ "$2" != "quick" ]; then
@@ -32,5 +31,7 @@ fi
 find /tmp/prof_r03 -name '*kernel_stats.csv' -exec cp {} $out/kernel_stats.csv \;
 rm -rf /tmp/prof_r03
 head -30 $out/steady_kernels.txt | cut -c1-180
-HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 180 python bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $out/two_ranks_one_gpu.log 2>&1; echo "2-rank launch on one GPU rc=$?"; grep -iE "error|duplicate|nccl|rccl" $out/two_ranks_one_gpu.log | head -5
+if [ "$3" == "ranks" ]; then
+  HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 180 python bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $out/two_ranks_one_gpu.log 2>&1; echo "2-rank launch on one GPU rc=$?"; grep -iE "error|duplicate|nccl|rccl" $out/two_ranks_one_gpu.log | head -5
+fi
 du -sh gpurun_out

@@ -62,11 +62,22 @@ __device__ __forceinline__ uint4 keep(uint4 v, bool ok) {
     return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
 }
 
+// XCD-aware workgroup order.  The dispatcher places workgroup b on XCD b % 8 and every XCD has its own L2, so workgroups
+// that are neighbours in the launch order -- which here read the same activation rows (adjacent pixel tiles share their
+// 3x3 halo, the output-channel tiles of a pixel tile share the whole input tile, the taps of a weight-gradient step read
+// the same dY block and shifted copies of the same X block) -- each pull their own copy through a different L2.  The
+// kernels are launched on a 1-D grid and take  v = xcd_order(blockIdx.x, gridDim.x)  as their position in that order:
+// XCD x runs the x-th CONTIGUOUS chunk of it (bijective for any grid size).
+__device__ __forceinline__ int xcd_order(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 // byte offset of piece j of row r in a [rows][8 x 16 B] LDS image
 __device__ __forceinline__ int lds_piece(int r, int j) { return (r * 8 + (j ^ ((r >> 1) & 7))) * 16; }
 
 template <int BN>
-__global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, const uint16_t* __restrict__ x,
+__global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles_co, const uint16_t* __restrict__ x,
                                                            const uint16_t* __restrict__ w,
                                                            const float* __restrict__ bias, void* __restrict__ y,
                                                            float* __restrict__ stat_partial) {
@@ -79,8 +90,11 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, const uin
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = BN == 128 ? (wave >> 1) : wave;        // which 32*TP pixels of the tile
     const int wn = BN == 128 ? (wave & 1) : 0;            // which 64 channels of the tile
-    const int m0 = blockIdx.x * kBM;
-    const int co0 = blockIdx.y * BN;
+    // position in the XCD-aware order: the output-channel tiles of one pixel tile are neighbours, then the next pixel tile
+    const int v = xcd_order(blockIdx.x, gridDim.x);
+    const int tile_m = v / tiles_co, tile_co = v - tile_m * tiles_co;
+    const int m0 = tile_m * kBM;
+    const int co0 = tile_co * BN;
 
     // ---- staging roles: piece column j (8 k), rows rr + 32 i --------------------------------------------
     const int j = tid & 7, rr = tid >> 3;
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, const uin
             float t = 0.f;
 #pragma unroll
             for (int q = 0; q < kParts; ++q) t += red[(q * 2 + k) * BN + cc];
-            if (co0 + cc < d.Cout) stat_partial[((size_t)blockIdx.x * 2 + k) * d.Cout + co0 + cc] = t;
+            if (co0 + cc < d.Cout) stat_partial[((size_t)tile_m * 2 + k) * d.Cout + co0 + cc] = t;
         }
     }
 }
@@ -363,7 +377,8 @@ __device__ __forceinline__ void transpose8x8(const uint4 (&in)[8], uint4 (&out)[
 }
 
 template <int TCO, int TCI>
-__global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles_ci, int ksteps_per_block, int tap_fold,
+__global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles, int tiles_ci, int groups, int ksteps_per_block,
+                                                           int tap_fold,
                                                            const uint16_t* __restrict__ dy,
                                                            const uint16_t* __restrict__ x,
                                                            float* __restrict__ partial) {
@@ -374,12 +389,17 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave >> 1, wb = wave & 1;               // co half / ci half of the tile
-    const int tco = blockIdx.x / tiles_ci, tci = blockIdx.x - tco * tiles_ci;
-    const int tap = blockIdx.y;
+    // position in the XCD-aware order: (co, ci) tile fastest, then the tap (group), then the pixel split -- the taps of
+    // one split, which read the same dY block and shifted copies of the same X block, run next to each other on one XCD
+    const int v = xcd_order(blockIdx.x, gridDim.x);
+    const int tile = v % tiles;
+    const int tap = (v / tiles) % groups;
+    const int split = v / (tiles * groups);
+    const int tco = tile / tiles_ci, tci = tile - tco * tiles_ci;
     const int kh = tap / d.KW, kw = tap - kh * d.KW;
     const int co0 = tco * TCO, ci0 = tci * TCI;
     const int total_steps = (d.M + kBK - 1) / kBK;
-    const int step0 = blockIdx.z * ksteps_per_block;
+    const int step0 = split * ksteps_per_block;
     const int step1 = min(step0 + ksteps_per_block, total_steps);
 
     // ---- staging roles: 8 x 8 blocks, cc = channel block, pg = pixel group; the dY tile has TCO/8 x 8 blocks, the X tile
@@ -500,7 +520,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
 
     // D[row = co: 8*(r>>2) + 4*(lane>>5) + (r&3)][col = ci: lane & 31]
     const size_t wsize = (size_t)d.Cout * d.KH * d.KW * d.Cin;
-    float* out = partial + (size_t)blockIdx.z * wsize;
+    float* out = partial + (size_t)split * wsize;
 #pragma unroll
     for (int a = 0; a < TA; ++a)
 #pragma unroll
@@ -515,165 +535,6 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
                 if (co < d.Cout) out[(size_t)co * d.KH * d.KW * d.Cin + col] = acc[a][b][r];
             }
         }
-}
-
-
-// ---- weight gradient, NT taps per workgroup ----------------------------------------------------------------------
-// For a KH x KW convolution the kernel above reads the dY tile once PER TAP: KH*KW workgroups stage the same 64-pixel x
-// TCO block (3x3 64 -> 64 at 200x200x12: dY and X, 61 MB each, through L2 nine times; 205 us = 172 TF/s where the
-// forward of the same layer makes 507).  Here a workgroup owns NT taps (a kernel row, or the whole 3x3): per 64-pixel
-// step the dY tile is staged ONCE into its own double buffer and the X tile once per tap into another, NT accumulator
-// sets live in registers (NT x TA x TB x 16), and the staging traffic per tap drops from (TCO + TCI) to
-// (TCO / NT + TCI) rows.  Same fragments, same LDS image, same deterministic split-K as conv2d_wgrad_kernel.
-template <int TCO, int TCI, int NT>
-__global__ __launch_bounds__(256) void conv2d_wgrad_taps_kernel(ConvDims d, int tiles_ci, int ksteps_per_block,
-                                                                const uint16_t* __restrict__ dy,
-                                                                const uint16_t* __restrict__ x,
-                                                                float* __restrict__ partial) {
-    constexpr int TA = TCO / 64, TB = TCI / 64;
-    constexpr int kImgA = TCO * kBK * 2, kImgB = TCI * kBK * 2;
-    static_assert(TCO + TCI <= 256, "one staging block per thread");
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];     // A[0] A[1] B[0] B[1]
-    uint8_t* const abuf = smem;
-    uint8_t* const bbuf = smem + 2 * kImgA;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wa = wave >> 1, wb = wave & 1;
-    const int tco = blockIdx.x / tiles_ci, tci = blockIdx.x - tco * tiles_ci;
-    const int taps = d.KH * d.KW;
-    const int tap0 = blockIdx.y * NT;
-    const int co0 = tco * TCO, ci0 = tci * TCI;
-    const int total_steps = (d.M + kBK - 1) / kBK;
-    const int step0 = blockIdx.z * ksteps_per_block;
-    const int step1 = min(step0 + ksteps_per_block, total_steps);
-
-    // staging role of this thread: one 8-pixel x 8-channel block of the dY tile (threads 0 .. TCO-1) or of the X tile
-    const bool live = tid < TCO + TCI;
-    const bool is_a = tid < TCO;
-    const int loc = is_a ? tid : tid - TCO;
-    const int nc = is_a ? TCO / 8 : TCI / 8;
-    const int cc = loc % nc, pg = loc / nc;
-    const int ch = (is_a ? co0 : ci0) + cc * 8;
-    const bool ch_ok = live && ch < (is_a ? d.Cout : d.Cin);
-    uint4 raw[8];
-    unsigned okbits = 0;
-    auto load_block = [&](int step, int tap, bool with_a) {
-        if (is_a && !with_a) return;
-        const int mfirst = step * kBK + pg * 8;
-        int wo = 0, ho = 0, n = 0, khb = 0, kwb = 0;
-        if (!is_a) {
-            const int mm = mfirst < d.M ? mfirst : 0;
-            wo = mm % d.Wo;
-            const int t = mm / d.Wo;
-            ho = t % d.Ho;
-            n = t / d.Ho;
-            khb = tap / d.KW;
-            kwb = tap - khb * d.KW;
-        }
-        const bool tap_ok = is_a || tap < taps;
-        unsigned bits = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = mfirst + i;
-            bool ok = ch_ok && tap_ok && m < d.M;
-            size_t off = 0;
-            if (is_a) {
-                off = (size_t)m * d.ldy + ch;
-            } else {
-                const int hi = ho * d.stride - d.pad_h + khb * d.dil_h;
-                const int wi = wo * d.stride - d.pad_w + kwb * d.dil_w;
-                ok = ok && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
-                off = ((size_t)(n * d.H + hi) * d.W + wi) * d.ldx + ch;
-                if (++wo == d.Wo) { wo = 0; if (++ho == d.Ho) { ho = 0; ++n; } }
-            }
-            const uint16_t* src = is_a ? dy : x;
-            raw[i] = *reinterpret_cast<const uint4*>(src + (ok ? off : 0));          // zeroed in store_block
-            bits |= ok ? (1u << i) : 0u;
-        }
-        okbits = bits;
-    };
-    auto store_block = [&](uint8_t* a_img, uint8_t* b_img, bool with_a) {
-        if (!live || (is_a && !with_a)) return;
-        uint4 tr[8], in[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) in[i] = keep(raw[i], (okbits >> i) & 1u);
-        transpose8x8(in, tr);
-        uint8_t* img = is_a ? a_img : b_img;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(img + lds_piece(cc * 8 + c, pg)) = tr[c];
-    };
-
-    f32x16 acc[NT][TA][TB];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int a = 0; a < TA; ++a)
-#pragma unroll
-            for (int b = 0; b < TB; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][a][b][r] = 0.f;
-
-    const int frow = lane & 31, fk = lane >> 5;
-    if (step0 < step1) {
-        load_block(step0, tap0, true);
-        store_block(abuf, bbuf, true);
-    }
-    __syncthreads();
-    int ub = 0;                                            // parity of the X buffer in use
-    for (int s = step0; s < step1; ++s) {
-        const int ab = (s - step0) & 1;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            constexpr bool kDummy = false; (void)kDummy;
-            const bool last_t = t == NT - 1;
-            const int ns = last_t ? s + 1 : s;
-            const int nt = last_t ? 0 : t + 1;
-            const bool has_next = ns < step1;
-            if (has_next) load_block(ns, tap0 + nt, last_t);
-            const uint8_t* a_cur = abuf + ab * kImgA;
-            const uint8_t* b_cur = bbuf + ub * kImgB;
-#pragma unroll
-            for (int ks = 0; ks < kBK / 16; ++ks) {
-                Frag fa[TA], fb[TB];
-#pragma unroll
-                for (int a = 0; a < TA; ++a)
-                    fa[a].u = *reinterpret_cast<const uint4*>(a_cur + lds_piece(wa * (32 * TA) + a * 32 + frow, ks * 2 + fk));
-#pragma unroll
-                for (int b = 0; b < TB; ++b)
-                    fb[b].u = *reinterpret_cast<const uint4*>(b_cur + lds_piece(wb * (32 * TB) + b * 32 + frow, ks * 2 + fk));
-#pragma unroll
-                for (int a = 0; a < TA; ++a)
-#pragma unroll
-                    for (int b = 0; b < TB; ++b)
-                        acc[t][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a].v, fb[b].v, acc[t][a][b], 0, 0, 0);
-            }
-            if (has_next) store_block(abuf + (ab ^ 1) * kImgA, bbuf + (ub ^ 1) * kImgB, last_t);
-            __syncthreads();
-            ub ^= 1;
-        }
-    }
-
-    const size_t wsize = (size_t)d.Cout * d.KH * d.KW * d.Cin;
-    float* out = partial + (size_t)blockIdx.z * wsize;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int tap = tap0 + t;
-        if (tap >= taps) continue;
-#pragma unroll
-        for (int a = 0; a < TA; ++a)
-#pragma unroll
-            for (int b = 0; b < TB; ++b) {
-                const int ci = ci0 + wb * (32 * TB) + b * 32 + frow;
-                if (ci >= d.Cin) continue;
-                const int col = tap * d.Cin + ci;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + wa * (32 * TA) + a * 32 + 8 * (r >> 2) + 4 * fk + (r & 3);
-                    if (co < d.Cout) out[(size_t)co * d.KH * d.KW * d.Cin + col] = acc[t][a][b][r];
-                }
-            }
-    }
 }
 
 // dw[i] = sum_k partial[k][i]: 64 columns x 4 split lanes per workgroup (256-byte coalesced row segments, four loads in
@@ -717,20 +578,9 @@ int wgrad_launch(const ConvDims& d, int tco, int tci, int taps, int splits, int 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_kernel<TCO, TCI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return -(int)e;
-    hipLaunchKernelGGL((conv2d_wgrad_kernel<TCO, TCI>), dim3(tco * tci, taps, splits), dim3(256), lds, s, d, tci, ksteps,
-                       fold, (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace);
-    return STP3_OK;
-}
-
-template <int TCO, int TCI, int NT>
-int wgrad_taps_launch(const ConvDims& d, int tco, int tci, int groups, int splits, int ksteps, const void* dy, const void* x,
-                      void* workspace, hipStream_t s) {
-    const size_t lds = (size_t)2 * (TCO + TCI) * kBK * 2;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_taps_kernel<TCO, TCI, NT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return -(int)e;
-    hipLaunchKernelGGL((conv2d_wgrad_taps_kernel<TCO, TCI, NT>), dim3(tco * tci, groups, splits), dim3(256), lds, s, d, tci,
-                       ksteps, (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace);
+    if ((int64_t)tco * tci * taps * splits >= (1LL << 31)) return STP3_EUNSUP;
+    hipLaunchKernelGGL((conv2d_wgrad_kernel<TCO, TCI>), dim3(tco * tci * taps * splits), dim3(256), lds, s, d, tco * tci, tci, taps,
+                       ksteps, fold, (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace);
     return STP3_OK;
 }
 
@@ -785,19 +635,21 @@ int stp3_conv2d_fwd(const stp3_conv_dims* p, const void* x, const void* w, const
     const bool wide = p->Cout > 64 && steps > 2;
     const int bn = wide ? 128 : 64;
     const size_t lds = igemm_lds(bn, steps, d.out_f32 != 0);
-    const dim3 grid(gx, (unsigned)((p->Cout + bn - 1) / bn));
+    const int tiles_co = (p->Cout + bn - 1) / bn;
+    if ((int64_t)gx * tiles_co >= (1LL << 31)) return STP3_EUNSUP;
+    const dim3 grid(gx * (unsigned)tiles_co);                // 1-D: the kernel derives (pixel tile, channel tile) itself
     if (wide) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_igemm_kernel<128>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return -(int)e;
-        hipLaunchKernelGGL(conv2d_igemm_kernel<128>, grid, dim3(256), lds, s, d, (const uint16_t*)x, (const uint16_t*)w, bias, y,
-                           partial);
+        hipLaunchKernelGGL(conv2d_igemm_kernel<128>, grid, dim3(256), lds, s, d, tiles_co, (const uint16_t*)x, (const uint16_t*)w,
+                           bias, y, partial);
     } else {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_igemm_kernel<64>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return -(int)e;
-        hipLaunchKernelGGL(conv2d_igemm_kernel<64>, grid, dim3(256), lds, s, d, (const uint16_t*)x, (const uint16_t*)w, bias, y,
-                           partial);
+        hipLaunchKernelGGL(conv2d_igemm_kernel<64>, grid, dim3(256), lds, s, d, tiles_co, (const uint16_t*)x, (const uint16_t*)w,
+                           bias, y, partial);
     }
     if (sums) launch_colsum(s, (int)gx, 2 * p->Cout, partial, sums);
     return status();
@@ -806,14 +658,8 @@ int stp3_conv2d_fwd(const stp3_conv_dims* p, const void* x, const void* w, const
 
 // *fold: taps per workgroup when the taps are folded into the ci tile (Cin == 8 with more than one tap), else 0;
 // *grid_y: tap groups (folded) or taps
-// *nt: taps per workgroup of conv2d_wgrad_taps_kernel (1: conv2d_wgrad_kernel)
-#ifndef STP3_WGRAD_TAPS_SMALL
-#define STP3_WGRAD_TAPS_SMALL 9
-#endif
-constexpr int kWgradTapsSmall = STP3_WGRAD_TAPS_SMALL;   // taps per workgroup for 3x3 layers with 64 x 64 tiles (9: the whole kernel; 3: a row)
-
 static int wgrad_plan(const stp3_conv_dims* p, int* tco_sz, int* tci_sz, int* tiles_co, int* tiles_ci, int* splits, int* ksteps,
-                      int* fold, int* grid_y, int* nt = nullptr) {
+                      int* fold, int* grid_y) {
     const int64_t M = (int64_t)p->N * p->Ho * p->Wo;
     const int taps = p->KH * p->KW;
     *tco_sz = p->Cout > 64 ? 128 : 64;
@@ -825,15 +671,6 @@ static int wgrad_plan(const stp3_conv_dims* p, int* tco_sz, int* tci_sz, int* ti
         *fold = *tci_sz / 8;
         *grid_y = (taps + *fold - 1) / *fold;
     }
-    int taps_per_wg = 1;
-    if (!*fold && taps > 1) {
-        const int acc_tiles = (*tco_sz / 64) * (*tci_sz / 64);           // 16 accumulator registers each, per tap
-        if (acc_tiles == 1 && taps == 9) taps_per_wg = kWgradTapsSmall;   // 3x3, <= 64 channels on both sides
-        else if (acc_tiles <= 2 && p->KW == 3) taps_per_wg = 3;           // one kernel row
-        else if (acc_tiles == 1 && p->KW == 7) taps_per_wg = 7;
-        if (taps_per_wg > 1) *grid_y = (taps + taps_per_wg - 1) / taps_per_wg;
-    }
-    if (nt) *nt = taps_per_wg;
     *tiles_co = (p->Cout + *tco_sz - 1) / *tco_sz;
     *tiles_ci = *fold ? 1 : (p->Cin + *tci_sz - 1) / *tci_sz;
     const int64_t total_steps = (M + kBK - 1) / kBK;         // 64 pixels per step
@@ -869,8 +706,8 @@ int stp3_conv2d_wgrad(const stp3_conv_dims* p, const void* dy, const void* x, fl
     const int64_t M = (int64_t)p->N * p->Ho * p->Wo;
     if (M >= (1LL << 31) - 64 || (int64_t)p->N * p->H * p->W >= (1LL << 31)) return STP3_EUNSUP;
     if (p->KH * p->KW > 65535) return STP3_EUNSUP;
-    int tco_sz, tci_sz, tco, tci, splits, ksteps, fold, taps, nt;
-    wgrad_plan(p, &tco_sz, &tci_sz, &tco, &tci, &splits, &ksteps, &fold, &taps, &nt);
+    int tco_sz, tci_sz, tco, tci, splits, ksteps, fold, taps;
+    wgrad_plan(p, &tco_sz, &tci_sz, &tco, &tci, &splits, &ksteps, &fold, &taps);
     const size_t wsize = (size_t)p->Cout * p->KH * p->KW * p->Cin;
     if (workspace_bytes < (size_t)splits * wsize * sizeof(float)) return STP3_ENOSPACE;
     ConvDims d;
@@ -880,12 +717,7 @@ int stp3_conv2d_wgrad(const stp3_conv_dims* p, const void* dy, const void* x, fl
     d.out_f32 = 1; d.has_bias = 0; d.M = (int)M; d.kchunks = 0; d.Ktot = p->KH * p->KW * p->Cin;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (nt == 9) rc = wgrad_taps_launch<64, 64, 9>(d, tco, tci, taps, splits, ksteps, dy, x, workspace, s);
-    else if (nt == 7) rc = wgrad_taps_launch<64, 64, 7>(d, tco, tci, taps, splits, ksteps, dy, x, workspace, s);
-    else if (nt == 3 && tco_sz == 64 && tci_sz == 64) rc = wgrad_taps_launch<64, 64, 3>(d, tco, tci, taps, splits, ksteps, dy, x, workspace, s);
-    else if (nt == 3 && tco_sz == 128) rc = wgrad_taps_launch<128, 64, 3>(d, tco, tci, taps, splits, ksteps, dy, x, workspace, s);
-    else if (nt == 3) rc = wgrad_taps_launch<64, 128, 3>(d, tco, tci, taps, splits, ksteps, dy, x, workspace, s);
-    else if (tco_sz == 128 && tci_sz == 128) rc = wgrad_launch<128, 128>(d, tco, tci, taps, splits, ksteps, fold, dy, x, workspace, s);
+    if (tco_sz == 128 && tci_sz == 128) rc = wgrad_launch<128, 128>(d, tco, tci, taps, splits, ksteps, fold, dy, x, workspace, s);
     else if (tco_sz == 128) rc = wgrad_launch<128, 64>(d, tco, tci, taps, splits, ksteps, fold, dy, x, workspace, s);
     else if (tci_sz == 128) rc = wgrad_launch<64, 128>(d, tco, tci, taps, splits, ksteps, fold, dy, x, workspace, s);
     else rc = wgrad_launch<64, 64>(d, tco, tci, taps, splits, ksteps, fold, dy, x, workspace, s);

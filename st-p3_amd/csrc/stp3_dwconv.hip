@@ -54,6 +54,14 @@ template <> struct Vec<uint16_t> {
     }
 };
 
+// XCD-aware workgroup order (see stp3_conv.hip): the dispatcher places workgroup b on XCD b % 8, each XCD has its own L2, and
+// neighbouring workgroups read overlapping input rows (every input row serves K output rows).  v = xcd_order(b, n): XCD x
+// runs the x-th contiguous chunk of the launch order, so the K - 1 halo rows are L2 hits instead of K separate fills.
+__device__ __forceinline__ int xcd_order(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 // ---- forward: y[n,ho,wo,c] = sum_{kh,kw} x[n, ho*S+kh-pt, wo*S+kw-pl, c] * w[kh,kw,c] ----------
 // One thread = one channel vector x TW consecutive output columns: the input row segment and the
 // K weight vectors of a kernel row are loaded once and reused across the TW outputs.
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwDims d, const T* __re
     const int CV = d.C / VN;
     const int wgroups = (d.Wo + TW - 1) / TW;
     const int64_t total = (int64_t)d.N * d.Ho * wgroups * CV;
-    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tid = (int64_t)xcd_order(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (tid >= total) return;
     const int cv = (int)(tid % CV);
     int64_t r = tid / CV;
@@ -293,8 +301,13 @@ __global__ __launch_bounds__(256) void dwconv_fwd_stats_kernel(DwDims d, const T
     for (int j = 0; j < VN; ++j) s1[j] = s2[j] = 0.f;
     const int wgroups = (d.Wo + TW - 1) / TW;
     const int ngroups = d.N * d.Ho * wgroups;            // < 2^31 (checked by the launcher)
+    // a workgroup owns a CONTIGUOUS run of pixel groups (consecutive output rows: the K - 1 input rows two of them share
+    // stay in this CU's L1 / this XCD's L2), and the runs are dealt out in the XCD-aware order
+    const int vb = xcd_order(blockIdx.x, gridDim.x);
+    const int per_block = ((ngroups + (int)gridDim.x - 1) / (int)gridDim.x + PL - 1) / PL * PL;
+    const int p_end = min(ngroups, (vb + 1) * per_block);
     if (live) {
-        for (int p = blockIdx.x * PL + pl; p < ngroups; p += gridDim.x * PL) {
+        for (int p = vb * per_block + pl; p < p_end; p += PL) {
             const int wg = p % wgroups;
             const int r = p / wgroups;
             const int ho = r % d.Ho;

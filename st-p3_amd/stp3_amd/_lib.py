@@ -86,6 +86,13 @@ class UpsampleDims(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in ('N', 'H', 'W', 'C', 'scale', 'ldx', 'ldy', 'dtype')]
 
 
+class CeDims(ctypes.Structure):
+    """struct stp3_ce_dims (include/stp3_hip.h)."""
+    _fields_ = [('rows', ctypes.c_int32), ('P', ctypes.c_int32), ('C', ctypes.c_int32), ('k', ctypes.c_int32),
+                ('ignore_index', ctypes.c_int32), ('dtype', ctypes.c_int32), ('stride_row', ctypes.c_int64),
+                ('stride_c', ctypes.c_int64), ('stride_p', ctypes.c_int64)]
+
+
 class OptimBucket(ctypes.Structure):
     """struct stp3_optim_bucket (include/stp3_hip.h)."""
     _fields_ = [('grad', ctypes.c_void_p), ('param', ctypes.c_void_p), ('exp_avg', ctypes.c_void_p),
@@ -166,6 +173,14 @@ SIGNATURES = {
     'stp3_mbconv_bwd_coef': (c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_mbconv_bwd_apply': (c_int, [ctypes.POINTER(SeDims), c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
                                       c_void_p, c_void_p, c_double, c_void_p, c_void_p]),
+    'stp3_ce_topk_workspace_bytes': (c_int, [ctypes.POINTER(CeDims), ctypes.POINTER(c_size_t)]),
+    'stp3_ce_topk_fwd': (c_int, [ctypes.POINTER(CeDims)] + [c_void_p] * 6 + [c_double, c_int32, c_void_p, c_void_p, c_size_t,
+                                                                           c_void_p]),
+    'stp3_ce_topk_bwd': (c_int, [ctypes.POINTER(CeDims)] + [c_void_p] * 7 + [c_double, c_void_p, c_void_p]),
+    'stp3_reg_loss_workspace_bytes': (c_int, [ctypes.POINTER(c_size_t)]),
+    'stp3_reg_loss_fwd': (c_int, [c_int32] * 4 + [c_float, c_int32] + [c_void_p] * 5 + [c_size_t, c_void_p]),
+    'stp3_reg_loss_bwd': (c_int, [c_int32] * 4 + [c_float, c_int32] + [c_void_p] * 7),
+    'stp3_warp_nearest': (c_int, [c_int32] * 4 + [c_void_p] * 5),
     'stp3_voxels_sum_fwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     'stp3_voxels_sum_bwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
 }

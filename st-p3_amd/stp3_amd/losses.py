@@ -3,12 +3,31 @@
 
 The reference ranks the per-pixel losses with a full descending sort and keeps the first k
 (:76-81, :108-111); only the *mean of the k largest* is used, so ``torch.topk`` computes the same
-quantity without ordering all 40 000 pixels."""
+quantity without ordering all 40 000 pixels.
+
+GPU float32 / bf16 tensors run every loss on the kernels of csrc/stp3_loss.hip (``ops_loss``: per-pixel loss, radix
+select of the k-th largest value and the top-k sum in three launches; one launch backward); CPU tensors and float64
+(the parity tests' noise-free evaluation) take the torch statements below."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops_loss
 from .utils import hp, staged_mean
+
+
+_ROW_SCALE = {}
+
+
+def _row_scale(future_discount, seq_len, n_present, batch, device):
+    """(batch * seq_len,) float32 future-discount factor of every (sample, frame) row, built once per configuration."""
+    key = (float(future_discount), seq_len, n_present, batch, str(device))
+    t = _ROW_SCALE.get(key)
+    if t is None:
+        one = torch.zeros((), dtype=torch.float32)
+        t = _future_discounts(future_discount, seq_len, n_present, one).repeat(batch).to(device)
+        _ROW_SCALE[key] = t
+    return t
 
 
 def _future_discounts(future_discount, seq_len, n_present, like):
@@ -26,6 +45,11 @@ class SpatialRegressionLoss(nn.Module):
 
     def forward(self, prediction, target, n_present=3):
         assert prediction.dim() == 5, 'Must be a 5D tensor'
+        if ops_loss.supported(prediction) and target.is_cuda:
+            seq_len = prediction.shape[1]
+            assert seq_len >= n_present
+            scale = _row_scale(self.future_discount, seq_len, n_present, prediction.shape[0], prediction.device)
+            return ops_loss.regression_loss(prediction, target, scale, self.norm, float(self.ignore_index))
         mask = target[:, :, :1] != self.ignore_index
         prediction = hp(prediction)
         loss = self.loss_fn(prediction, target.to(prediction.dtype), reduction='none').sum(dim=-3, keepdim=True)
@@ -52,6 +76,11 @@ class SegmentationLoss(nn.Module):
         if target.shape[-3] != 1:
             raise ValueError('segmentation label must be an index-label with channel dimension = 1.')
         b, s, c, h, w = prediction.shape
+        assert s >= n_present
+        if ops_loss.supported(prediction) and target.is_cuda:
+            scale = _row_scale(self.future_discount, s, n_present, b, prediction.device)
+            k = int(self.top_k_ratio * h * w) if self.use_top_k else 0
+            return ops_loss.ce_topk_mean(prediction, target.reshape(b, s, h, w), self.class_weights, scale, k, self.ignore_index)
         loss = F.cross_entropy(hp(prediction.reshape(b * s, c, h, w)), target.reshape(b * s, h, w),
                                ignore_index=self.ignore_index, reduction='none',
                                weight=self.class_weights.to(device=prediction.device, dtype=hp(prediction).dtype))
@@ -77,6 +106,11 @@ class HDmapLoss(nn.Module):
         for i in range(target.shape[-3]):
             cur = target[:, i]
             b = cur.shape[0]
+            if ops_loss.supported(prediction) and target.is_cuda:
+                k = int(self.top_k_ratio[i] * cur.shape[1] * cur.shape[2]) if self.use_top_k[i] else 0
+                total = total + ops_loss.ce_topk_mean(prediction[:, 2 * i:2 * (i + 1)], cur, self.class_weights[i], None, k,
+                                                      self.ignore_index) * self.training_weights[i]
+                continue
             loss = F.cross_entropy(hp(prediction[:, 2 * i:2 * (i + 1)]), cur, ignore_index=self.ignore_index,
                                    reduction='none',
                                    weight=self.class_weights[i].to(device=target.device, dtype=hp(prediction).dtype)).view(b, -1)
@@ -94,6 +128,9 @@ class DepthLoss(nn.Module):
 
     def forward(self, prediction, target):
         b, s, n, d, h, w = prediction.shape
+        if ops_loss.supported(prediction) and target.is_cuda:
+            return ops_loss.ce_topk_mean(prediction.reshape(b * s * n, d, h, w), target.reshape(b * s * n, h, w),
+                                         self.class_weights, None, 0, self.ignore_index)
         loss = F.cross_entropy(hp(prediction.reshape(b * s * n, d, h, w)), target.reshape(b * s * n, h, w),
                                ignore_index=self.ignore_index, reduction='none', weight=self.class_weights)
         return staged_mean(loss)

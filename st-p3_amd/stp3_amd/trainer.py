@@ -176,13 +176,23 @@ class TrainingModule(nn.Module):
             items.append(('flow', batch['flow'], False))
         stacked = torch.cat([x.float() for _, x, _ in items], dim=2)                  # (B,S,sum C,H,W)
         thetas = label_warp_thetas(batch['future_egomotion'].detach().float().cpu(), rf, self.spatial_extent)
-        frames = []
-        for t in range(stacked.shape[1]):
-            frame = stacked[:, t]
-            if t in thetas:
-                frame = warp_with_theta(frame, thetas[t].to(dev), mode='nearest')
-            frames.append(frame)
-        warped = torch.stack(frames, dim=1)
+        if stacked.is_cuda:
+            # all frames and all label channels in ONE launch (stp3_warp_nearest): frames without a theta are copied
+            from . import ops_loss
+            b_, s_ = stacked.shape[:2]
+            eye = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+            th = torch.stack([thetas[t].float().cpu() if t in thetas else eye.expand(b_, 2, 3) for t in range(s_)], dim=1)
+            ident = [0 if t in thetas else 1 for _ in range(b_) for t in range(s_)]
+            warped = ops_loss.warp_nearest(stacked.reshape(b_ * s_, *stacked.shape[2:]), th.reshape(b_ * s_, 2, 3),
+                                           ident).view(stacked.shape)
+        else:
+            frames = []
+            for t in range(stacked.shape[1]):
+                frame = stacked[:, t]
+                if t in thetas:
+                    frame = warp_with_theta(frame, thetas[t].to(dev), mode='nearest')
+                frames.append(frame)
+            warped = torch.stack(frames, dim=1)
         c0 = 0
         for name, x, to_long in items:
             part = warped[:, :, c0:c0 + x.shape[2]]

@@ -548,6 +548,67 @@ def mbconv_mid(ops):
     return out
 
 
+def losses(ops):
+    """csrc/stp3_loss.hip through stp3_amd.losses (GPU route) against the torch statements of the same module (CPU
+    route): values and gradients of the segmentation (top-k + future discount + class weights + ignore), HD-map
+    (two elements, one with top-k), depth (48 classes) and regression (L1 / L2, ignore mask) losses, float32 and bf16
+    logits in channels-last and contiguous memory; and the nearest label warp against F.grid_sample."""
+    import torch.nn.functional as F
+    from stp3_amd import losses as L, geometry as geo, ops_loss
+    out = {}
+    g = torch.Generator().manual_seed(9)
+    is_cuda = torch.Tensor.is_cuda
+
+    def both(make_loss, pred0, *args):
+        res = []
+        for kernel in (True, False):
+            torch.Tensor.is_cuda = is_cuda if kernel else property(lambda self: False)
+            p = (pred0.detach().clone() if kernel else pred0.detach().float().clone()).requires_grad_()
+            v = make_loss()(p, *args)
+            v.backward()
+            res.append((v.detach().double(), p.grad.double()))
+        torch.Tensor.is_cuda = is_cuda
+        return {'value': rel(res[0][0], res[1][0]), 'grad': rel(res[0][1], res[1][1])}
+
+    b, s_, h, w = 2, 3, 12, 17
+    seg = (torch.rand(b, s_, 1, h, w, generator=g) < 0.2).long()
+    seg[0, 1, 0, :2] = 255                                        # ignored pixels
+    for tag, dtype, cl in (('f32_nchw', torch.float32, False), ('bf16_nhwc', torch.bfloat16, True)):
+        pred = (torch.randn(b * s_, 2, h, w, generator=g) * 2).to(dtype)
+        if cl:
+            pred = pred.contiguous(memory_format=torch.channels_last)
+        pred = pred.view(b, s_, 2, h, w)
+        out[f'seg_topk_{tag}'] = both(lambda: L.SegmentationLoss(torch.Tensor([1.0, 2.0]), use_top_k=True, top_k_ratio=0.25,
+                                                                 future_discount=0.95), pred, seg, 2)
+        out[f'seg_all_{tag}'] = both(lambda: L.SegmentationLoss(torch.Tensor([1.0, 2.0]), use_top_k=False), pred, seg, 3)
+    # many exact ties at the threshold: logits on a coarse grid -> identical losses; value exact, gradient mass shared
+    predq = (torch.randint(-2, 3, (b * s_, 2, h, w), generator=g).float() * 0.5).view(b, s_, 2, h, w)
+    r = both(lambda: L.SegmentationLoss(torch.Tensor([1.0, 2.0]), use_top_k=True, top_k_ratio=0.25), predq, seg, 3)
+    out['seg_topk_ties'] = {'value': r['value']}
+    hd = (torch.rand(b, 2, h, w, generator=g) < 0.3).long()
+    predh = torch.randn(b, 4, h, w, generator=g).contiguous(memory_format=torch.channels_last)
+    out['hdmap'] = both(lambda: L.HDmapLoss(torch.Tensor([[1.0, 5.0], [1.0, 1.0]]), [1, 2], [True, False], [0.25, 0.25]), predh, hd)
+    dep = torch.randint(0, 48, (1, 2, 3, 7, 9), generator=g)
+    predd = torch.randn(1, 2, 3, 48, 7, 9, generator=g) * 3
+    out['depth'] = both(lambda: L.DepthLoss(), predd, dep)
+    tgt = torch.randn(b, s_, 2, h, w, generator=g)
+    tgt[:, :, :, :3] = 255.0
+    predr = torch.randn(b, s_, 2, h, w, generator=g)
+    out['reg_l1'] = both(lambda: L.SpatialRegressionLoss(norm=1, future_discount=0.95, ignore_index=255), predr, tgt, 2)
+    out['reg_l2'] = both(lambda: L.SpatialRegressionLoss(norm=2, future_discount=0.95, ignore_index=255), predr, tgt, 2)
+    out['reg_all_ignored'] = {'value': float(L.SpatialRegressionLoss(norm=1)(predr, torch.full_like(tgt, 255.0), 2).abs())}
+    # nearest warp
+    x = torch.randint(0, 5, (6, 3, 20, 24), generator=g).float()
+    ang = torch.randn(6, generator=g) * 0.1
+    theta = torch.stack([torch.cos(ang), -torch.sin(ang), torch.randn(6, generator=g) * 0.1, torch.sin(ang), torch.cos(ang),
+                         torch.randn(6, generator=g) * 0.1], dim=-1).view(6, 2, 3)
+    y = ops_loss.warp_nearest(x, theta, [0, 0, 1, 0, 0, 1])
+    ref = geo.warp_with_theta(x, theta, 'nearest')
+    ref[2], ref[5] = x[2], x[5]
+    out['warp'] = {'mismatch_fraction': float((y != ref).float().mean())}
+    return out
+
+
 def conv_bn(ops):
     """conv -> BatchNorm -> act (+ skip / drop-connect) as ONE operator (conv v2 with the statistics in its epilogue)
     against the two separate operators, and both against float32 torch on the same bf16-representable data."""
@@ -881,7 +942,7 @@ def fuzz(ops, seed=1):
 
 
 CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_frames, lift_coarse_grid, lift_tall, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
-                                 conv, dwconv, mbconv_mid)}
+                                 conv, dwconv, mbconv_mid, losses)}
 
 if __name__ == '__main__':
     ops_mod = setup(sys.argv[1])
