@@ -240,14 +240,16 @@ def lift_roofline(device, batch, model, iters=30):
     fwd_ms = prof['lift_splat_fwd']['avg_ms']
     ach = alg_fwd / (fwd_ms * 1e-3) / 1e9
     traffic, traffic_source = None, None
-    pmc_path = os.path.join(ROOT, 'profiles', 'r02_lift_pmc.json')
+    pmc_path = next((q for q in (os.path.join(ROOT, 'profiles', f) for f in ('r03_lift_pmc.json', 'r02_lift_pmc.json'))
+                     if os.path.exists(q)), '')
     if os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
             ks = [v for k, v in pmc.items() if k.startswith(('lift_column', 'lift_gather'))]
             assert len(ks) == 2, sorted(pmc)
             traffic = sum(k['hbm_read_bytes'] + k['hbm_write_bytes'] for k in ks) * d.BT / float(pmc.get('frames_per_launch', 12))
-            traffic_source = f"profiles/r02_lift_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, {pmc.get('commit', '?')})"
+            traffic_source = (f"profiles/{os.path.basename(pmc_path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                              f"scripts/gpu_pmc_lift.sh, commit {pmc.get('commit', '?')}; not collected inside this run)")
         except Exception:
             traffic = None
     roof = {'kernel': 'stp3_lift_splat_fwd = lift_column_mma_kernel + lift_gather_kernel (logits -> BEV: depth softmax and '

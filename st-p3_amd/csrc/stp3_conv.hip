@@ -377,8 +377,7 @@ __device__ __forceinline__ void transpose8x8(const uint4 (&in)[8], uint4 (&out)[
 }
 
 template <int TCO, int TCI>
-__global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles, int tiles_ci, int groups, int ksteps_per_block,
-                                                           int tap_fold,
+__global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles_ci, int ksteps_per_block, int tap_fold,
                                                            const uint16_t* __restrict__ dy,
                                                            const uint16_t* __restrict__ x,
                                                            float* __restrict__ partial) {
@@ -389,13 +388,12 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave >> 1, wb = wave & 1;               // co half / ci half of the tile
-    // position in the XCD-aware order: (co, ci) tile fastest, then the tap (group), then the pixel split -- the taps of
-    // one split, which read the same dY block and shifted copies of the same X block, run next to each other on one XCD
-    const int v = xcd_order(blockIdx.x, gridDim.x);
-    const int tile = v % tiles;
-    const int tap = (v / tiles) % groups;
-    const int split = v / (tiles * groups);
-    const int tco = tile / tiles_ci, tci = tile - tco * tiles_ci;
+    // (launch order as dispatched: tile, tap, split.  The XCD-contiguous order of the forward kernel was measured SLOWER
+    // here -- 3x3 64 -> 64 at 200x200x12: 205 -> 258 us, profiles/r03c_conv_timings.txt -- the nine taps of a pixel
+    // split then hit the same dY lines of one L2 at the same time)
+    const int tco = blockIdx.x / tiles_ci, tci = blockIdx.x - tco * tiles_ci;
+    const int tap = blockIdx.y;
+    const int split = blockIdx.z;
     const int kh = tap / d.KW, kw = tap - kh * d.KW;
     const int co0 = tco * TCO, ci0 = tci * TCI;
     const int total_steps = (d.M + kBK - 1) / kBK;
@@ -578,9 +576,8 @@ int wgrad_launch(const ConvDims& d, int tco, int tci, int taps, int splits, int 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_kernel<TCO, TCI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return -(int)e;
-    if ((int64_t)tco * tci * taps * splits >= (1LL << 31)) return STP3_EUNSUP;
-    hipLaunchKernelGGL((conv2d_wgrad_kernel<TCO, TCI>), dim3(tco * tci * taps * splits), dim3(256), lds, s, d, tco * tci, tci, taps,
-                       ksteps, fold, (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace);
+    hipLaunchKernelGGL((conv2d_wgrad_kernel<TCO, TCI>), dim3(tco * tci, taps, splits), dim3(256), lds, s, d, tci, ksteps,
+                       fold, (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace);
     return STP3_OK;
 }
 

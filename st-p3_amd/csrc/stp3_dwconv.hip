@@ -301,13 +301,9 @@ __global__ __launch_bounds__(256) void dwconv_fwd_stats_kernel(DwDims d, const T
     for (int j = 0; j < VN; ++j) s1[j] = s2[j] = 0.f;
     const int wgroups = (d.Wo + TW - 1) / TW;
     const int ngroups = d.N * d.Ho * wgroups;            // < 2^31 (checked by the launcher)
-    // a workgroup owns a CONTIGUOUS run of pixel groups (consecutive output rows: the K - 1 input rows two of them share
-    // stay in this CU's L1 / this XCD's L2), and the runs are dealt out in the XCD-aware order
-    const int vb = xcd_order(blockIdx.x, gridDim.x);
-    const int per_block = ((ngroups + (int)gridDim.x - 1) / (int)gridDim.x + PL - 1) / PL * PL;
-    const int p_end = min(ngroups, (vb + 1) * per_block);
+    // (grid-stride over the pixel groups; contiguous runs per workgroup in XCD order measured 3-6 % slower here)
     if (live) {
-        for (int p = vb * per_block + pl; p < p_end; p += PL) {
+        for (int p = blockIdx.x * PL + pl; p < ngroups; p += gridDim.x * PL) {
             const int wg = p % wgroups;
             const int r = p / wgroups;
             const int ho = r % d.Ho;

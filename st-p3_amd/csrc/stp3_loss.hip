@@ -96,10 +96,20 @@ __global__ __launch_bounds__(kSelT) void topk_select_kernel(int P, int k, const 
         if (threadIdx.x < 256) hist[threadIdx.x] = 0;
         __syncthreads();
         const unsigned mask_hi = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+        // run-length aggregation in registers: the losses of a row share their leading bytes (one or two exponents), so a
+        // plain atomic per element serialises 40 000 increments on one or two LDS words (64 us per call measured); a thread
+        // counts its consecutive equal digits and issues one atomic per run
+        unsigned cur = 0xffffffffu, cnt = 0;
         for (int i = threadIdx.x; i < P; i += kSelT) {
             const unsigned u = __float_as_uint(l[i]);
-            if ((u & mask_hi) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);      // integer counts: order-free
+            if ((u & mask_hi) != prefix) continue;
+            const unsigned b = (u >> shift) & 255u;
+            if (b == cur) { ++cnt; continue; }
+            if (cnt) atomicAdd(&hist[cur], cnt);                                         // integer counts: order-free
+            cur = b;
+            cnt = 1;
         }
+        if (cnt) atomicAdd(&hist[cur], cnt);
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned n = need, b = 255;
@@ -199,13 +209,17 @@ __global__ __launch_bounds__(kT) void reg_loss_kernel(int rows, int C, int P, in
     }
 }
 
-// out[0] = sum / max(count, 1); out[1] = count
-__global__ void reg_finalize_kernel(int parts, const double* __restrict__ partial, float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// out[0] = sum / max(count, 1); out[1] = count  (one workgroup: strided partial sums, then a fixed tree)
+__global__ __launch_bounds__(kT) void reg_finalize_kernel(int parts, const double* __restrict__ partial, float* __restrict__ out) {
+    __shared__ double red[kT];
     double s = 0.0, c = 0.0;
-    for (int i = 0; i < parts; ++i) { s += partial[2 * i]; c += partial[2 * i + 1]; }
-    out[0] = (float)(s / (c > 0.0 ? c : 1.0));
-    out[1] = (float)c;
+    for (int i = threadIdx.x; i < parts; i += kT) { s += partial[2 * i]; c += partial[2 * i + 1]; }
+    s = block_sum(s, red);
+    c = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        out[0] = (float)(s / (c > 0.0 ? c : 1.0));
+        out[1] = (float)c;
+    }
 }
 
 __global__ __launch_bounds__(kT) void reg_backward_kernel(int rows, int C, int P, int norm, float ignore, int bf16,
@@ -339,7 +353,7 @@ int stp3_reg_loss_fwd(int32_t rows, int32_t C, int32_t P, int32_t norm, float ig
     if (blocks > kRegBlocks) blocks = kRegBlocks;
     hipLaunchKernelGGL(reg_loss_kernel, dim3(blocks), dim3(kT), 0, s, (int)rows, (int)C, (int)P, (int)norm, ignore_value,
                        dtype == STP3_DTYPE_BF16 ? 1 : 0, pred, target, row_scale, (double*)workspace);
-    hipLaunchKernelGGL(reg_finalize_kernel, dim3(1), dim3(64), 0, s, blocks, (const double*)workspace, out);
+    hipLaunchKernelGGL(reg_finalize_kernel, dim3(1), dim3(kT), 0, s, blocks, (const double*)workspace, out);
     return status();
 }
 
