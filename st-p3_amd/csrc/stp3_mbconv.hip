@@ -317,15 +317,19 @@ __global__ __launch_bounds__(kT) void mbconv_bwd_apply_kernel(MbDims d, const T*
     mb_map<VEC>(d.C, cv, rl, RL, CVB, live);
     if (!live) return;
     const int n = blockIdx.y;
-    float sc[VEC], sh[VEC], mu[VEC], is[VEC], ga[VEC], dp[VEC], k0[VEC], k1[VEC];
+    // dx = scale * (gg - k0 - xhat * k1) with xhat = (x - mean) * invstd  ==  scale * gg - e1 * x - e0:
+    // six per-channel constants instead of eight (176 -> ~150 registers: a third wave per SIMD)
+    float sc[VEC], sh[VEC], ga[VEC], dp[VEC], e0[VEC], e1[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const int c = cv * VEC + j;
-        sc[j] = coef[c]; sh[j] = coef[d.C + c]; mu[j] = coef[2 * d.C + c]; is[j] = coef[3 * d.C + c];
+        sc[j] = coef[c]; sh[j] = coef[d.C + c];
+        const float mu = coef[2 * d.C + c], is = coef[3 * d.C + c];
         ga[j] = gate ? gate[(size_t)n * d.C + c] : 1.f;
         dp[j] = dpooled ? dpooled[(size_t)n * d.C + c] : 0.f;
-        k0[j] = gsums[c] * inv_count;
-        k1[j] = gsums[d.C + c] * inv_count;
+        const float k0 = gsums[c] * inv_count, k1 = gsums[d.C + c] * inv_count;
+        e1[j] = sc[j] * k1 * is;
+        e0[j] = sc[j] * (k0 - k1 * mu * is);
     }
     const T* xs = x + (size_t)n * d.rows * d.ldx + cv * VEC;
     const T* gs = da + (size_t)n * d.rows * d.ldg + cv * VEC;
@@ -347,10 +351,8 @@ __global__ __launch_bounds__(kT) void mbconv_bwd_apply_kernel(MbDims d, const T*
                 for (int j = 0; j < VEC; ++j) {
                     float val, der;
                     act_both<ACT>(fmaf(v[u][j], sc[j], sh[j]), val, der);
-                    const float xh = (v[u][j] - mu[j]) * is[j];
                     const float gg = fmaf(g[u][j], ga[j], dp[j]) * der;
-                    // scale = gamma * invstd
-                    g[u][j] = sc[j] * (gg - k0[j] - xh * k1[j]);
+                    g[u][j] = fmaf(sc[j], gg, -fmaf(e1[j], v[u][j], e0[j]));
                 }
                 Io3<T, VEC>::store(os + (size_t)(r + u * step) * d.ldg, g[u]);
             }

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(stp3_se_mlp_dims d, con
         float acc[kRows];
 #pragma unroll
         for (int k = 0; k < kRows; ++k) acc[k] = 0.f;
-        for (int c = lane; c < d.C; c += 64) {
+#pragma unroll 4
+        for (int c = lane; c < d.C; c += 64) {            // (unrolled: the loads of four iterations in flight)
             const float pc = p[c];
 #pragma unroll
             for (int k = 0; k < kRows; ++k) {
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(stp3_se_mlp_dims d, con
     __syncthreads();
     for (int c = tid; c < d.C; c += 256) {
         float a = b2[c];
+#pragma unroll 8
         for (int s = 0; s < d.S; ++s) a = fmaf(w2[(size_t)c * d.S + s], h[s], a);
         gate[(size_t)n * d.C + c] = sigmoidf_(a);
     }
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_sample_kernel(stp3_se_mlp_dims
         float acc[kRows];
 #pragma unroll
         for (int k = 0; k < kRows; ++k) acc[k] = 0.f;
+#pragma unroll 4
         for (int c = lane; c < d.C; c += 64) {
             const float gc = g2[c];
 #pragma unroll
@@ -125,6 +128,7 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_sample_kernel(stp3_se_mlp_dims
     __syncthreads();
     for (int c = tid; c < d.C; c += 256) {
         float a = 0.f;
+#pragma unroll 8
         for (int s = 0; s < d.S; ++s) a = fmaf(g1[s], w1[(size_t)s * d.C + c], a);
         dpooled[(size_t)n * d.C + c] = a * d.inv_rows;
     }

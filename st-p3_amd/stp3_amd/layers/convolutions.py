@@ -139,3 +139,127 @@ class DeepLabHead(nn.Sequential):
 
     def forward(self, x):
         return run_fused(self, x)
+
+
+# ----------------------------------------------------------------------------------------------
+# Blocks of the prediction stage: stp3/layers/convolutions.py:10-171 (ConvBlock, Bottleneck),
+# :283-380 (LayerNorm, ConvNeXt Block, Bottleblock).  Same constructors, attributes and parameter names as the
+# reference's; dense convolutions and BatchNorm + ReLU pairs go through the same operators as the perception path
+# (``conv_module`` -> MFMA implicit GEMM under bf16 autocast, ``run_fused`` -> stp3_bn_*), the 7x7 depthwise
+# convolution, LayerNorm and GELU are torch operators for now.
+# ----------------------------------------------------------------------------------------------
+import torch.nn.functional as F  # noqa: E402
+from collections import OrderedDict  # noqa: E402
+
+
+class Bottleneck(nn.Module):
+    """1x1 down-projection -> kxk (optionally stride-2) convolution -> 1x1 up-projection, BatchNorm + ReLU after each,
+    plus the (projected / max-pooled) skip: stp3/layers/convolutions.py:62-171.  The transposed-convolution up-sampling
+    variant is not used on ST-P3's prediction path and is rejected."""
+
+    def __init__(self, in_channels, out_channels=None, kernel_size=3, dilation=1, groups=1, upsample=False,
+                 downsample=False, dropout=0.0):
+        super().__init__()
+        if upsample:
+            raise NotImplementedError('Bottleneck(upsample=True) is not on the prediction path')
+        assert dilation == 1
+        self._downsample = downsample
+        mid = int(in_channels / 2)
+        out_channels = out_channels or in_channels
+        pad = ((kernel_size - 1) * dilation + 1) // 2
+        conv = nn.Conv2d(mid, mid, kernel_size=kernel_size, bias=False, dilation=dilation, stride=2 if downsample else 1,
+                         padding=pad, groups=groups)
+        self.layers = nn.Sequential(OrderedDict([
+            ('conv_down_project', nn.Conv2d(in_channels, mid, kernel_size=1, bias=False)),
+            ('abn_down_project', nn.Sequential(nn.BatchNorm2d(mid), nn.ReLU(inplace=True))),
+            ('conv', conv),
+            ('abn', nn.Sequential(nn.BatchNorm2d(mid), nn.ReLU(inplace=True))),
+            ('conv_up_project', nn.Conv2d(mid, out_channels, kernel_size=1, bias=False)),
+            ('abn_up_project', nn.Sequential(nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))),
+            ('dropout', nn.Dropout2d(p=dropout))]))
+        if out_channels == in_channels and not downsample:
+            self.projection = None
+        else:
+            proj = OrderedDict()
+            if downsample:
+                proj['upsample_skip_proj'] = nn.MaxPool2d(kernel_size=2, stride=2)
+            proj['conv_skip_proj'] = nn.Conv2d(in_channels, out_channels, kernel_size=1, bias=False)
+            proj['bn_skip_proj'] = nn.BatchNorm2d(out_channels)
+            self.projection = nn.Sequential(proj)
+
+    def forward(self, x):
+        y = run_fused(self.layers, x)
+        if self.projection is None:
+            return y + x
+        if self._downsample:
+            x = F.pad(x, (0, x.shape[-1] % 2, 0, x.shape[-2] % 2), value=0)
+        return y + run_fused(self.projection, x)
+
+
+class LayerNorm(nn.Module):
+    """LayerNorm over the channels in channels_last (N,H,W,C) or channels_first (N,C,H,W) data (convolutions.py:283-307)."""
+
+    def __init__(self, normalized_shape, eps=1e-6, data_format='channels_last'):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+        self.eps = eps
+        self.data_format = data_format
+        if data_format not in ('channels_last', 'channels_first'):
+            raise NotImplementedError
+        self.normalized_shape = (normalized_shape,)
+
+    def forward(self, x):
+        if self.data_format == 'channels_last':
+            return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
+        # channels_first: the same normalisation over dim 1 -- evaluated on the (N,H,W,C) VIEW, which for the
+        # channels-last tensors of this code base is contiguous memory: one fused layer_norm instead of five passes
+        y = F.layer_norm(x.permute(0, 2, 3, 1), self.normalized_shape, self.weight, self.bias, self.eps)
+        return y.permute(0, 3, 1, 2)
+
+
+class Block(nn.Module):
+    """ConvNeXt block: 7x7 depthwise -> LayerNorm -> Linear 4x -> GELU -> Linear -> layer scale, + skip
+    (convolutions.py:309-345)."""
+
+    def __init__(self, dim, drop_path=0.0, layer_scale_init_value=1e-6):
+        super().__init__()
+        self.dwconv = nn.Conv2d(dim, dim, kernel_size=7, padding=3, groups=dim)
+        self.norm = LayerNorm(dim, eps=1e-6)
+        self.pwconv1 = nn.Linear(dim, 4 * dim)
+        self.act = nn.GELU()
+        self.pwconv2 = nn.Linear(4 * dim, dim)
+        self.gamma = (nn.Parameter(layer_scale_init_value * torch.ones(dim), requires_grad=True)
+                      if layer_scale_init_value > 0 else None)
+        if drop_path > 0.0:
+            raise NotImplementedError('drop_path > 0 (timm DropPath) is not used by ST-P3')
+        self.drop_path = nn.Identity()
+
+    def forward(self, x):
+        y = self.dwconv(x).permute(0, 2, 3, 1)
+        y = self.pwconv2(self.act(self.pwconv1(self.norm(y))))
+        if self.gamma is not None:
+            y = self.gamma * y
+        return x + y.permute(0, 3, 1, 2)
+
+
+class Bottleblock(nn.Module):
+    """7x7 -> 1x1 -> 3x3 convolutions with channels-first LayerNorm + GELU, + (projected) skip (convolutions.py:347-380)."""
+
+    def __init__(self, in_channels, out_channels=None):
+        super().__init__()
+        mid = int(in_channels / 2)
+        out_channels = out_channels or in_channels
+        self.layers = nn.Sequential(
+            nn.Conv2d(in_channels, mid, kernel_size=7, bias=False, padding=3),
+            LayerNorm(mid, eps=1e-6, data_format='channels_first'), nn.GELU(),
+            nn.Conv2d(mid, mid, kernel_size=1, bias=False),
+            LayerNorm(mid, eps=1e-6, data_format='channels_first'), nn.GELU(),
+            nn.Conv2d(mid, out_channels, kernel_size=3, bias=False, padding=1),
+            LayerNorm(out_channels, eps=1e-6, data_format='channels_first'), nn.GELU())
+        self.projection = None if out_channels == in_channels else nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, kernel_size=1, bias=False), nn.GELU())
+
+    def forward(self, x):
+        y = run_fused(self.layers, x)
+        return y + (x if self.projection is None else run_fused(self.projection, x))

@@ -272,3 +272,106 @@ class TemporalBlock(nn.Module):
         skip = x2 if self.projection is None else self._pointwise(self.projection, x2, relu=False, extra2=extra2)
         out = _bn_act_2d(agg.norm, y, res=skip, sbias=sbias)
         return out.view(b, t, -1, h, w).permute(0, 2, 1, 3, 4)
+
+
+# ----------------------------------------------------------------------------------------------
+# Convolutional GRUs of the prediction stage: stp3/layers/temporal.py:11-145.
+# ----------------------------------------------------------------------------------------------
+def _conv(m, x):
+    from .fused import conv_module
+    return conv_module(m, x)
+
+
+def _gru_cell(x, state, conv_update, conv_reset, conv_state_tilde, bias_init):
+    """One convolutional GRU step (temporal.py:42-56): the update and reset gates read the same [x, state] operand, so
+    their two 3x3 convolutions run as ONE convolution with the output channels concatenated (exact: the operand tile
+    is staged once instead of twice)."""
+    xs = torch.cat([x, state], dim=1)
+    hidden = conv_update.out_channels
+    w = torch.cat([conv_update.weight, conv_reset.weight], dim=0)
+    b = torch.cat([conv_update.bias, conv_reset.bias], dim=0)
+    from .fused import conv2d
+    gates = torch.sigmoid(hp(conv2d(xs, w, b, 1, conv_update.padding, 1)) + bias_init)
+    update, reset = gates[:, :hidden], gates[:, hidden:]
+    state_f = hp(state)
+    tilde = hp(_conv(conv_state_tilde, torch.cat([x, ((1.0 - reset) * state_f).to(x.dtype)], dim=1)))
+    return ((1.0 - update) * state_f + update * tilde).to(state.dtype)
+
+
+class SpatialGRU(nn.Module):
+    """Convolutional GRU over a (B,T,C,H,W) sequence with a 1x1 decoder per step (temporal.py:11-56)."""
+
+    def __init__(self, input_size, hidden_size, gru_bias_init=0.0):
+        super().__init__()
+        self.input_size, self.hidden_size, self.gru_bias_init = input_size, hidden_size, gru_bias_init
+        self.conv_update = nn.Conv2d(input_size + hidden_size, hidden_size, kernel_size=3, bias=True, padding=1)
+        self.conv_reset = nn.Conv2d(input_size + hidden_size, hidden_size, kernel_size=3, bias=True, padding=1)
+        self.conv_state_tilde = nn.Conv2d(input_size + hidden_size, hidden_size, kernel_size=3, bias=True, padding=1)
+        self.conv_decoder = nn.Conv2d(hidden_size, input_size, kernel_size=1, bias=False)
+
+    def forward(self, x, state=None):
+        assert x.dim() == 5, 'Input tensor must be BxTxCxHxW.'
+        b, steps, c, h, w = x.shape
+        rnn_state = x.new_zeros(b, self.hidden_size, h, w) if state is None else state
+        out = []
+        for t in range(steps):
+            rnn_state = self.gru_cell(x[:, t], rnn_state)
+            out.append(_conv(self.conv_decoder, rnn_state))
+        return torch.stack(out, dim=1)
+
+    def gru_cell(self, x, state):
+        return _gru_cell(x, state.to(x.dtype), self.conv_update, self.conv_reset, self.conv_state_tilde, self.gru_bias_init)
+
+
+class Dual_GRU(nn.Module):
+    """Two coupled convolutional GRUs -- one driven by the latent sample, one by the past states -- mixed by a learned
+    per-pixel trust gate (temporal.py:58-145)."""
+
+    def __init__(self, in_channels, latent_dim, n_future, mixture=True, gru_bias_init=0.0):
+        super().__init__()
+        from .convolutions import Bottleblock
+        input_size, hidden_size = in_channels, latent_dim
+        self.n_future, self.mixture = n_future, mixture
+        self.input_size, self.hidden_size, self.gru_bias_init = input_size, hidden_size, gru_bias_init
+        conv3 = lambda ci, co: nn.Conv2d(ci, co, kernel_size=3, bias=True, padding=1)
+        self.conv_update_1 = conv3(input_size + hidden_size, hidden_size)
+        self.conv_reset_1 = conv3(input_size + hidden_size, hidden_size)
+        self.conv_state_tilde_1 = conv3(input_size + hidden_size, hidden_size)
+        self.conv_update_2 = conv3(2 * hidden_size, hidden_size)
+        self.conv_reset_2 = conv3(2 * hidden_size, hidden_size)
+        self.conv_state_tilde_2 = conv3(2 * hidden_size, hidden_size)
+        self.conv_decoder_2 = conv3(hidden_size, hidden_size)
+        self.trusting_gate = nn.Sequential(Bottleblock(2 * hidden_size, hidden_size),
+                                           nn.Conv2d(hidden_size, 2, kernel_size=1, bias=False))
+
+    def forward(self, x, state):
+        """x (B,1,input_size,H,W): the latent sample; state (B,n_present,hidden_size,H,W) -> (B,n_future,hidden,H,W)."""
+        b, s, c, hh, ww = x.shape
+        assert c == self.input_size, f'feature sizes must match, got input {c} for layer with size {self.input_size}'
+        n_present = state.shape[1]
+        h = state[:, 0]
+        for t in range(n_present - 1):                       # warm-up on the past frames
+            h = self.gru_cell_2(state[:, t], h)
+        rnn_state1 = rnn_state2 = state[:, -1]
+        x = x[:, 0]
+        pred = []
+        for _ in range(self.n_future):
+            rnn_state1 = self.gru_cell_1(x, rnn_state1)
+            h = self.gru_cell_2(rnn_state2, h)
+            rnn_state2 = _conv(self.conv_decoder_2, h)
+            mix = torch.cat([rnn_state1, rnn_state2.to(rnn_state1.dtype)], dim=1)
+            gate = _conv(self.trusting_gate[1], self.trusting_gate[0](mix))
+            gate = torch.softmax(hp(gate), dim=1)
+            cur = (hp(rnn_state2) * gate[:, 0:1] + hp(rnn_state1) * gate[:, 1:]).to(rnn_state1.dtype)
+            pred.append(cur)
+            if self.mixture:
+                rnn_state1 = rnn_state2 = cur
+        return torch.stack(pred, dim=1)
+
+    def gru_cell_1(self, x, state):
+        return _gru_cell(x.to(state.dtype), state, self.conv_update_1, self.conv_reset_1, self.conv_state_tilde_1,
+                         self.gru_bias_init)
+
+    def gru_cell_2(self, x, state):
+        return _gru_cell(x.to(state.dtype), state, self.conv_update_2, self.conv_reset_2, self.conv_state_tilde_2,
+                         self.gru_bias_init)

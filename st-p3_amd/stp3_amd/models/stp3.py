@@ -10,15 +10,18 @@ how the middle is computed: ``get_geometry`` + ``encoder_forward``'s outer produ
 voxel-pool / discounted-accumulate kernel), so the 1.5 GB lifted tensor and the per-(b,t) host
 syncs of the reference never exist.
 
-Out of scope: the prediction / planning stages (``N_FUTURE_FRAMES > 0``,
-``PLANNING.ENABLED``) raise ``NotImplementedError``.
+The prediction stage (``N_FUTURE_FRAMES > 0``: ``present_distribution``, ``future_prediction``, stp3.py:69-87, 157-176)
+is wired in as in the reference; the planner (``PLANNING.ENABLED``) raises
+``NotImplementedError``.
 """
 import torch
 import torch.nn as nn
 
 from .. import ops
 from .decoder import Decoder
+from .distributions import DistributionModule
 from .encoder import Encoder
+from .future_prediction import FuturePrediction
 from .temporal_model import TemporalModel, TemporalModelIdentity
 
 
@@ -60,9 +63,8 @@ class STP3(nn.Module):
         self.latent_dim = cfg.MODEL.DISTRIBUTION.LATENT_DIM
         self.spatial_extent = (cfg.LIFT.X_BOUND[1], cfg.LIFT.Y_BOUND[1])
         self.bev_size = (int(dim[0]), int(dim[1]))
-        if self.n_future > 0 or cfg.PLANNING.ENABLED:
-            raise NotImplementedError('prediction / planning stages are outside the accelerated perception path '
-                                      '(set N_FUTURE_FRAMES=0, PLANNING.ENABLED=False)')
+        if cfg.PLANNING.ENABLED:
+            raise NotImplementedError('the planning stage is outside the accelerated path (set PLANNING.ENABLED=False)')
         if not cfg.MODEL.ENCODER.USE_DEPTH_DISTRIBUTION:
             raise NotImplementedError('USE_DEPTH_DISTRIBUTION=False is not on the benchmarked path')
 
@@ -82,6 +84,15 @@ class STP3(nn.Module):
         else:
             raise NotImplementedError(f'Temporal module {name}.')
         self.future_pred_in_channels = self.temporal_model.out_channels
+        if self.n_future > 0:
+            # prediction stage (stp3.py:69-87): present distribution + future prediction
+            if cfg.PROBABILISTIC.ENABLED:
+                self.present_distribution = DistributionModule(self.future_pred_in_channels, self.latent_dim,
+                                                               method=cfg.PROBABILISTIC.METHOD)
+            fp = cfg.MODEL.FUTURE_PRED
+            self.future_prediction = FuturePrediction(in_channels=self.future_pred_in_channels, latent_dim=self.latent_dim,
+                                                      n_future=self.n_future, mixture=fp.MIXTURE,
+                                                      n_gru_blocks=fp.N_GRU_BLOCKS, n_res_layers=fp.N_RES_LAYERS)
 
         self.decoder = Decoder(
             in_channels=self.future_pred_in_channels,
@@ -195,5 +206,45 @@ class STP3(nn.Module):
                 states = self.temporal_model(torch.cat([x, ego.view(b, s, c, 1, 1).expand(b, s, c, *x.shape[-2:])], dim=2))
         else:
             states = self.temporal_model(x)
+        if self.n_future > 0:
+            # stp3.py:157-176: sample the present distribution, roll the present state forward, decode all frames
+            present = states[:, -1:].contiguous()
+            b, _, c, h, w = present.shape
+            if self.cfg.PROBABILISTIC.ENABLED:
+                dist = self.cfg.MODEL.DISTRIBUTION
+                sample = self.distribution_forward(present, dist.MIN_LOG_SIGMA, dist.MAX_LOG_SIGMA)
+            else:
+                sample = present.new_zeros(b, 1, self.latent_dim, h, w)
+            states = self.future_prediction(sample, states)
         output.update(self.decoder(states))
         return output
+
+    def distribution_forward(self, present_features, min_log_sigma, max_log_sigma):
+        """stp3.py:320-382: a sample of the present distribution, broadcast over the BEV plane
+        (B,1,latent,H,W).  Training draws Gaussian noise, evaluation uses the mean."""
+        b, s, _, h, w = present_features.shape
+        assert s == 1
+        latent, method = self.latent_dim, self.cfg.PROBABILISTIC.METHOD
+
+        def sample_of(mu_log_sigma):
+            mu = mu_log_sigma[:, :, :latent]
+            sigma = torch.exp(torch.clamp(mu_log_sigma[:, :, latent:2 * latent], min_log_sigma, max_log_sigma))
+            noise = (torch.randn((b, s, latent), device=present_features.device) if self.training
+                     else torch.zeros((b, s, latent), device=present_features.device))
+            return mu + sigma * noise.to(mu.dtype)
+
+        if method == 'GAUSSIAN':
+            sample = sample_of(self.present_distribution(present_features))
+            return sample.view(b, s, latent, 1, 1).expand(b, s, latent, h, w)
+        if method == 'BERNOULLI':
+            log_prob = self.present_distribution(present_features)
+            noise = (torch.randn((b, latent, h, w), device=present_features.device) if self.training
+                     else torch.zeros((b, latent, h, w), device=present_features.device))
+            return (torch.exp(log_prob) + noise.to(log_prob.dtype)).view(b, s, latent, h, w)
+        if method == 'MIXGAUSSIAN':
+            p = self.present_distribution(present_features)
+            parts = [sample_of(p[:, :, 2 * i * latent:2 * (i + 1) * latent]) for i in range(3)]
+            coef = torch.softmax(p[:, :, 6 * latent:], dim=-1)
+            sample = parts[0] * coef[:, :, 0:1] + parts[1] * coef[:, :, 1:2] + parts[2] * coef[:, :, 2:3]
+            return sample.view(b, s, latent, 1, 1).expand(b, s, latent, h, w)
+        raise NotImplementedError(method)

@@ -1,0 +1,43 @@
+"""GPU: the prediction stage on the MI355X against the reference fixtures
+(tests/golden/prediction.npz) -- float32 on the kernels (BatchNorm / convolution routes of the perception path), and
+bf16 autocast (MFMA convolutions) at bf16 accuracy; and one training step of the Prediction config end to end."""
+import pytest
+import torch
+
+from tests.test_prediction_cpu import PREDICTION, cases, run_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('name', sorted(cases()))
+def test_prediction_layers_float32(name):
+    errs = run_case(name, device='cuda')
+    assert errs['out'] <= 5e-4 and max(errs.values()) <= 5e-3, errs
+
+
+@pytest.mark.parametrize('name', ['bottleneck_ds', 'bottleblock', 'spatial_gru', 'dual_gru', 'future_prediction'])
+def test_prediction_layers_bf16(name):
+    errs = run_case(name, device='cuda', autocast=True)
+    assert errs['out'] <= 5e-2 and max(errs.values()) <= 0.25, errs
+
+
+def test_prediction_config_training_step_runs():
+    """nuscenes/Prediction.yml (N_FUTURE_FRAMES=4, GAUSSIAN present distribution): one bf16 training step of the whole
+    model -- 7 output frames per sample, finite loss, a finite gradient on every trainable parameter."""
+    from stp3_amd import synthetic
+    from stp3_amd.config import perception_cfg
+    from stp3_amd.trainer import TrainingModule
+    from stp3_amd.utils import to_channels_last
+    tm = to_channels_last(TrainingModule(perception_cfg(**PREDICTION).convert_to_dict()).cuda())
+    tm.train()
+    batch = synthetic.make_batch(batch=1, seq=7, seed=3, instance=True)
+    batch = {k: (v.cuda() if torch.is_tensor(v) and k not in ('intrinsics', 'extrinsics', 'future_egomotion') else v)
+             for k, v in batch.items()}
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        output, labels, loss = tm.shared_step(batch, True)
+    assert output['segmentation'].shape[:2] == (1, 7) and output['instance_flow'].shape[:2] == (1, 7)
+    total = sum(loss.values())
+    total.backward()
+    assert torch.isfinite(total).item()
+    bad = [n for n, p in tm.model.named_parameters() if p.requires_grad and (p.grad is None or not torch.isfinite(p.grad).all().item())]
+    assert not bad, bad[:5]
