@@ -57,6 +57,13 @@ __device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 
 constexpr int kBM = 128;        // pixels per workgroup
 constexpr int kBK = 64;         // K per step: 8 pieces of 16 bytes per row
 
+// 16 bytes of zeros in device memory: what a staging thread loads INSTEAD of a padding tap / a row beyond the matrix.
+// Selecting the ADDRESS (two v_cndmask) replaces selecting the loaded DATA afterwards (four v_cndmask per piece plus
+// the bookkeeping of which pieces were real): the PMC passes of round 3 showed both convolution kernels bound by their
+// VALU instruction count (196 VALU instructions beside 8 MFMAs per K-step in the forward kernel, 332 beside 4 in the
+// weight gradient), not by the matrix cores or by memory.
+__device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
 // v or zero, word by word (a select on the whole uint4 makes the compiler go through scratch memory)
 __device__ __forceinline__ uint4 keep(uint4 v, bool ok) {
     return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
@@ -98,7 +105,9 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
 
     // ---- staging roles: piece column j (8 k), rows rr + 32 i --------------------------------------------
     const int j = tid & 7, rr = tid >> 3;
-    int pbase[4], phi[4], pwi[4];                         // pixel rows: element offset of (hi0, wi0), hi0, wi0
+    const uint16_t* const zero = reinterpret_cast<const uint16_t*>(&g_zero16);
+    const uint16_t* prow[4];                              // pixel rows: address of (hi0, wi0, channel 0), or `zero`
+    int phi[4], pwi[4];                                   // ... and hi0, wi0
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + rr + 32 * i;
@@ -109,43 +118,45 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
             const int n = t / d.Ho;
             phi[i] = ho * d.stride - d.pad_h;
             pwi[i] = wo * d.stride - d.pad_w;
-            pbase[i] = ((n * d.H + phi[i]) * d.W + pwi[i]) * d.ldx;
+            prow[i] = x + (ptrdiff_t)((n * d.H + phi[i]) * d.W + pwi[i]) * d.ldx;
         } else {
             phi[i] = -(1 << 28);                           // never inside the image
             pwi[i] = 0;
-            pbase[i] = 0;
+            prow[i] = zero;
         }
+    }
+    const uint16_t* wrow[BN / 32];                        // weight rows: address of (co, k = 0), or `zero`
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) {
+        const int co = co0 + rr + 32 * i;
+        wrow[i] = co < d.Cout ? w + (size_t)co * d.Ktot : zero;
     }
     // position of this thread's piece in K: k = step * 64 + j * 8 = tap * Cin + ci
     int tap = 0, ci = j * 8;
     while (ci >= d.Cin) { ci -= d.Cin; ++tap; }
     int kh = tap / d.KW, kw = tap - kh * d.KW;
     const int taps = d.KH * d.KW;
+    // pointwise layers (1x1, no padding: half of the launches of a step) never leave the image: no bounds tests
+    const bool pointwise = taps == 1 && d.pad_h == 0 && d.pad_w == 0;
 
     uint4 ra[4], rb[BN / 32];
-    unsigned okmask = 0;                                  // bit i: ra[i] is real data, bit 4 + i: rb[i] (else: zero piece)
     auto load_step = [&]() {                               // the piece of the current (tap, ci) for every row of this thread
         const bool kvalid = tap < taps;
         const int dh = kh * d.dil_h, dw = kw * d.dil_w;
         const int toff = (dh * d.W + dw) * d.ldx + ci;
-        okmask = 0;
-        // loads only: the zeroing of padding pieces waits until store_step, so that nothing here needs the data
-        // before the MFMAs of the current step have been issued
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int hi = phi[i] + dh, wi = pwi[i] + dw;
-            const bool ok = kvalid && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
-            ra[i] = *reinterpret_cast<const uint4*>(x + (ok ? pbase[i] + toff : 0));
-            okmask |= ok ? (1u << i) : 0u;
+            bool ok = kvalid && prow[i] != zero;
+            if (!pointwise) {
+                const int hi = phi[i] + dh, wi = pwi[i] + dw;
+                ok = ok && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
+            }
+            ra[i] = *reinterpret_cast<const uint4*>(ok ? prow[i] + toff : zero);
         }
         const int kk = tap * d.Cin + ci;
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i) {
-            const int co = co0 + rr + 32 * i;
-            const bool ok = kvalid && co < d.Cout;
-            rb[i] = *reinterpret_cast<const uint4*>(w + (ok ? (size_t)co * d.Ktot + kk : 0));
-            okmask |= ok ? (16u << i) : 0u;
-        }
+        for (int i = 0; i < BN / 32; ++i)
+            rb[i] = *reinterpret_cast<const uint4*>((kvalid && wrow[i] != zero) ? wrow[i] + kk : zero);
         // advance to the next step: k += 64
         ci += kBK;
         while (ci >= d.Cin && tap < taps) {
@@ -156,11 +167,9 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
     };
     auto store_step = [&](uint8_t* buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<uint4*>(buf + lds_piece(rr + 32 * i, j)) = keep(ra[i], (okmask >> i) & 1u);
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(buf + lds_piece(rr + 32 * i, j)) = ra[i];
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i)
-            *reinterpret_cast<uint4*>(buf + kBM * kBK * 2 + lds_piece(rr + 32 * i, j)) = keep(rb[i], (okmask >> (4 + i)) & 1u);
+        for (int i = 0; i < BN / 32; ++i) *reinterpret_cast<uint4*>(buf + kBM * kBK * 2 + lds_piece(rr + 32 * i, j)) = rb[i];
     };
 
     f32x16 acc[TC][TP];
@@ -401,83 +410,75 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
     const int step1 = min(step0 + ksteps_per_block, total_steps);
 
     // ---- staging roles: 8 x 8 blocks, cc = channel block, pg = pixel group; the dY tile has TCO/8 x 8 blocks, the X tile
-    // TCI/8 x 8; block ids are dealt out to the 256 threads, dY blocks first
-    constexpr int kBlocksA = TCO, kBlocksB = TCI;          // (TCO / 8) * 8 and (TCI / 8) * 8
-    constexpr int kRounds = (kBlocksA + kBlocksB + 255) / 256;
-    uint4 raw[kRounds][8];
-    unsigned okbits[kRounds];                              // bit i: raw[r][i] is real data (else a zero piece)
-    auto block_of = [&](int r, bool& is_a, int& cc, int& pg, bool& live) {
-        const int id = tid + 256 * r;
-        live = id < kBlocksA + kBlocksB;
-        is_a = id < kBlocksA;
-        const int loc = is_a ? id : id - kBlocksA;
-        const int nc = is_a ? TCO / 8 : TCI / 8;
-        cc = loc % nc;
-        pg = loc / nc;
-    };
-    auto load_step = [&](int step) {
-#pragma unroll
-        for (int r = 0; r < kRounds; ++r) {
-            bool is_a, live;
-            int cc, pg;
-            block_of(r, is_a, cc, pg, live);
-            const int mfirst = step * kBK + pg * 8;
-            // (n, ho, wo) of the first pixel of the group, advanced with carries
-            int wo = 0, ho = 0, n = 0;
-            if (!is_a) {
-                const int mm = mfirst < d.M ? mfirst : 0;
-                wo = mm % d.Wo;
-                const int t = mm / d.Wo;
-                ho = t % d.Ho;
-                n = t / d.Ho;
-            }
-            int ch = (is_a ? co0 : ci0) + cc * 8;
-            bool ch_ok = live && ch < (is_a ? d.Cout : d.Cin);
-            int khb = kh, kwb = kw;
-            if (tap_fold && !is_a) {                       // this channel-block slot is tap `t` of the group
-                const int t = tap * tap_fold + cc;
-                khb = t / d.KW;
-                kwb = t - khb * d.KW;
-                ch = 0;
-                ch_ok = live && t < d.KH * d.KW;
-            }
-            unsigned bits = 0;
+    // TCI/8 x 8: TCO + TCI <= 256 blocks, one per thread, dY blocks first.  Everything that does not change from step to
+    // step is computed ONCE here -- the PMC run of round 3 showed this kernel VALU-bound (83 VALU instructions per MFMA,
+    // profiles/r03e_wgrad_pmc.json), most of them the per-step div / mod of the pixel index and 64-bit address products.
+    static_assert(TCO + TCI <= 256, "one staging block per thread");
+    const bool live = tid < TCO + TCI;
+    const bool is_a = tid < TCO;
+    const int loc = is_a ? tid : tid - TCO;
+    const int nc = is_a ? TCO / 8 : TCI / 8;
+    const int cc = loc % nc, pg = loc / nc;
+    int ch = (is_a ? co0 : ci0) + cc * 8;
+    bool ch_ok = live && ch < (is_a ? d.Cout : d.Cin);
+    int khb = kh, kwb = kw;
+    if (tap_fold && !is_a) {                               // this channel-block slot is tap `t` of the group
+        const int t = tap * tap_fold + cc;
+        khb = t / d.KW;
+        kwb = t - khb * d.KW;
+        ch = 0;
+        ch_ok = live && t < d.KH * d.KW;
+    }
+    const int tap_h = khb * d.dil_h - d.pad_h, tap_w = kwb * d.dil_w - d.pad_w;
+    const uint16_t* const src = (is_a ? dy : x) + ch;
+    const int ld = is_a ? d.ldy : d.ldx;
+    // (n, ho, wo) of the first pixel of this thread's group in the NEXT step to be loaded: set up with one div / mod pair
+    // here, then advanced by 64 pixels per step with carries
+    int s_wo = 0, s_ho = 0, s_n = 0;
+    {
+        const int m = step0 * kBK + pg * 8;
+        const int mm = m < d.M ? m : 0;
+        s_wo = mm % d.Wo;
+        const int t = mm / d.Wo;
+        s_ho = t % d.Ho;
+        s_n = t / d.Ho;
+    }
+    const uint16_t* const zero = reinterpret_cast<const uint16_t*>(&g_zero16);
+    uint4 raw[8];
+    auto load_step = [&](int step) {                       // steps must be requested in ascending order, each once
+        const int mfirst = step * kBK + pg * 8;
+        if (is_a) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int m = mfirst + i;
-                bool ok = ch_ok && m < d.M;
-                size_t off = 0;
-                if (is_a) {
-                    off = (size_t)m * d.ldy + ch;
-                } else {
-                    const int hi = ho * d.stride - d.pad_h + khb * d.dil_h;
-                    const int wi = wo * d.stride - d.pad_w + kwb * d.dil_w;
-                    ok = ok && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
-                    off = ((size_t)(n * d.H + hi) * d.W + wi) * d.ldx + ch;
-                    if (++wo == d.Wo) { wo = 0; if (++ho == d.Ho) { ho = 0; ++n; } }
-                }
-                const uint16_t* src = is_a ? dy : x;
-                raw[r][i] = *reinterpret_cast<const uint4*>(src + (ok ? off : 0));   // zeroed in store_step
-                bits |= ok ? (1u << i) : 0u;
+                const bool ok = ch_ok && m < d.M;
+                raw[i] = *reinterpret_cast<const uint4*>(ok ? src + (size_t)(unsigned)m * (unsigned)ld : zero);
             }
-            okbits[r] = bits;
+        } else {
+            int wo = s_wo, ho = s_ho, n = s_n;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int hi = ho * d.stride + tap_h, wi = wo * d.stride + tap_w;
+                const bool ok = ch_ok && mfirst + i < d.M && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
+                const int pix = (n * d.H + hi) * d.W + wi;          // < 2^31 (checked by the launcher)
+                raw[i] = *reinterpret_cast<const uint4*>(ok ? src + (size_t)(unsigned)pix * (unsigned)ld : zero);
+                if (++wo == d.Wo) { wo = 0; if (++ho == d.Ho) { ho = 0; ++n; } }
+            }
+            s_wo += kBK;                                   // the same group, one step (64 pixels) on
+            while (s_wo >= d.Wo) {
+                s_wo -= d.Wo;
+                if (++s_ho == d.Ho) { s_ho = 0; ++s_n; }
+            }
         }
     };
+    const int img_off = is_a ? 0 : TCO * kBK * 2;           // dY image first, X image behind it
     auto store_step = [&](uint8_t* buf) {
+        if (!live) return;
+        uint4 tr[8];
+        transpose8x8(raw, tr);
+        uint8_t* img = buf + img_off;
 #pragma unroll
-        for (int r = 0; r < kRounds; ++r) {
-            bool is_a, live;
-            int cc, pg;
-            block_of(r, is_a, cc, pg, live);
-            if (!live) continue;
-            uint4 tr[8], in[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) in[i] = keep(raw[r][i], (okbits[r] >> i) & 1u);
-            transpose8x8(in, tr);
-            uint8_t* img = buf + (is_a ? 0 : TCO * kBK * 2);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(img + lds_piece(cc * 8 + c, pg)) = tr[c];
-        }
+        for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(img + lds_piece(cc * 8 + c, pg)) = tr[c];
     };
 
     f32x16 acc[TA][TB];
