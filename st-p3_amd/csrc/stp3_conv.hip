@@ -63,6 +63,7 @@ constexpr int kBK = 64;         // K per step: 8 pieces of 16 bytes per row
 // VALU instruction count (196 VALU instructions beside 8 MFMAs per K-step in the forward kernel, 332 beside 4 in the
 // weight gradient), not by the matrix cores or by memory.
 __device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // v or zero, word by word (a select on the whole uint4 makes the compiler go through scratch memory)
 __device__ __forceinline__ uint4 keep(uint4 v, bool ok) {
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
     // pointwise layers (1x1, no padding: half of the launches of a step) never leave the image: no bounds tests
     const bool pointwise = taps == 1 && d.pad_h == 0 && d.pad_w == 0;
 
-    uint4 ra[4], rb[BN / 32];
+    u32x4 ra[4], rb[BN / 32];                              // first-class vectors: HIP's uint4 (a struct) ends up in scratch here
     auto load_step = [&]() {                               // the piece of the current (tap, ci) for every row of this thread
         const bool kvalid = tap < taps;
         const int dh = kh * d.dil_h, dw = kw * d.dil_w;
@@ -151,12 +152,12 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
                 const int hi = phi[i] + dh, wi = pwi[i] + dw;
                 ok = ok && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
             }
-            ra[i] = *reinterpret_cast<const uint4*>(ok ? prow[i] + toff : zero);
+            ra[i] = *reinterpret_cast<const u32x4*>(ok ? prow[i] + toff : zero);
         }
         const int kk = tap * d.Cin + ci;
 #pragma unroll
         for (int i = 0; i < BN / 32; ++i)
-            rb[i] = *reinterpret_cast<const uint4*>((kvalid && wrow[i] != zero) ? wrow[i] + kk : zero);
+            rb[i] = *reinterpret_cast<const u32x4*>((kvalid && wrow[i] != zero) ? wrow[i] + kk : zero);
         // advance to the next step: k += 64
         ci += kBK;
         while (ci >= d.Cin && tap < taps) {
@@ -167,9 +168,9 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
     };
     auto store_step = [&](uint8_t* buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(buf + lds_piece(rr + 32 * i, j)) = ra[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(buf + lds_piece(rr + 32 * i, j)) = ra[i];
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i) *reinterpret_cast<uint4*>(buf + kBM * kBK * 2 + lds_piece(rr + 32 * i, j)) = rb[i];
+        for (int i = 0; i < BN / 32; ++i) *reinterpret_cast<u32x4*>(buf + kBM * kBK * 2 + lds_piece(rr + 32 * i, j)) = rb[i];
     };
 
     f32x16 acc[TC][TP];
