@@ -286,6 +286,7 @@ def family_rooflines(step, batch_size, steps=3):
     for _ in range(steps):
         step()
     fam = profiling.summary()
+    shapes = profiling.by_shape(top=14)
     profiling.enable(False)
     out = {'steps': steps, 'timing': 'HIP events around each C-ABI call on its launch stream, in-run'}
     conv = [fam[k] for k in ('conv_fwd_dgrad', 'conv_wgrad') if k in fam]
@@ -298,7 +299,12 @@ def family_rooflines(step, batch_size, steps=3):
                        'algorithmic_tflop_per_step': round(alg / 1e12, 3),
                        'executed_tflop_per_step': round(sum(f['work'] for f in conv) / steps / 1e12, 3),
                        'calls_per_step': sum(f['calls'] for f in conv) // steps,
-                       'split_ms': {k: round(fam[k]['ms'] / steps, 3) for k in ('conv_fwd_dgrad', 'conv_wgrad') if k in fam}}
+                       'split_ms': {k: round(fam[k]['ms'] / steps, 3) for k in ('conv_fwd_dgrad', 'conv_wgrad') if k in fam},
+                       # where the family's time goes: the most expensive launched shapes (forward and data gradient
+                       # share the entry point: a data gradient shows up as the forward shape with Cin <-> Cout)
+                       'top_shapes': [{'pass': a['family'][5:], 'shape': a['shape'], 'calls_per_step': a['calls'] // steps,
+                                       'ms_per_step': round(a['ms'] / steps, 3),
+                                       'tflops': round(a['work'] / (a['ms'] * 1e-3) / 1e12, 1)} for a in shapes]}
     for name in ('batchnorm', 'depthwise', 'squeeze_excite', 'mbconv'):
         if name not in fam:
             continue

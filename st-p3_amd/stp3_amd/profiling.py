@@ -9,7 +9,7 @@ proxy that brackets every call listed in ``WORK`` with two events; ``summary()``
 import torch
 
 ENABLED = False
-RECORDS = []          # (family, work, start_event, end_event)
+RECORDS = []          # (family, work, start_event, end_event, shape label or None)
 
 
 def _obj(arg):
@@ -24,6 +24,15 @@ def _esize(dtype_code):
 def _conv_flops(args):
     d = _obj(args[0])
     return 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.KH * d.KW * d.Cin
+
+
+def _conv_label(args):
+    d = _obj(args[0])
+    return (f'{d.KH}x{d.KW}' + (f'/{d.stride}' if d.stride != 1 else '') + (f' d{d.dil_h}' if d.dil_h != 1 else '') +
+            f' {d.Cin}->{d.Cout} @{d.Ho}x{d.Wo} x{d.N}')
+
+
+LABEL = {'stp3_conv2d_fwd': _conv_label, 'stp3_conv2d_wgrad': _conv_label}
 
 
 def _bn_bytes(tensors):
@@ -85,6 +94,7 @@ class TimedLib:
             wrapped = fn
         else:
             family, work = spec
+            label = LABEL.get(name)
 
             def wrapped(*args):
                 start = torch.cuda.Event(enable_timing=True)
@@ -92,7 +102,7 @@ class TimedLib:
                 start.record()
                 rc = fn(*args)
                 end.record()
-                RECORDS.append((family, work(args), start, end))
+                RECORDS.append((family, work(args), start, end, label(args) if label else None))
                 return rc
         self.__dict__[name] = wrapped
         return wrapped
@@ -109,9 +119,24 @@ def summary():
     """family -> {'calls', 'ms', 'work'} over everything recorded since ``enable()`` (synchronises)."""
     torch.cuda.synchronize()
     out = {}
-    for family, work, s, e in RECORDS:
+    for family, work, s, e, _ in RECORDS:
         a = out.setdefault(family, {'calls': 0, 'ms': 0.0, 'work': 0.0})
         a['calls'] += 1
         a['ms'] += s.elapsed_time(e)
         a['work'] += work
     return out
+
+
+def by_shape(top=12):
+    """The labelled calls (the convolutions) aggregated per (family, shape), the `top` most expensive first:
+    [{'family', 'shape', 'calls', 'ms', 'work'}] over everything recorded since ``enable()`` (synchronises)."""
+    torch.cuda.synchronize()
+    out = {}
+    for family, work, s, e, label in RECORDS:
+        if label is None:
+            continue
+        a = out.setdefault((family, label), {'family': family, 'shape': label, 'calls': 0, 'ms': 0.0, 'work': 0.0})
+        a['calls'] += 1
+        a['ms'] += s.elapsed_time(e)
+        a['work'] += work
+    return sorted(out.values(), key=lambda a: -a['ms'])[:top]
