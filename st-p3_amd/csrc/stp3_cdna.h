@@ -24,6 +24,17 @@ __device__ __forceinline__ void lds_dma_wait() {
     __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0) expcnt(0) lgkmcnt(0)
 }
 
+// lds_read_tr16(p): ds_read_b64_tr_b16, the gfx950 LDS transpose read.  Within every 16-lane group the 16 lanes x 4
+// halfwords named by the lanes' addresses form a [4][16] block -- lane i of the group supplies row i >> 2, columns
+// 4 * (i & 3) .. + 3, as four contiguous halfwords at its own 8-byte aligned address -- and lane i RECEIVES column i
+// (its element j = row j).  An MFMA operand whose k index runs along the SLOW dimension of a row-major LDS image is
+// read with it as it lies: no transposition in registers.  (An address off 8-byte alignment silently returns the
+// aligned address's data.)
+typedef short stp3_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ stp3_s16x4 lds_read_tr16(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) stp3_s16x4*)p);
+}
+
 // All-reduce over the 16 lanes of a DPP row with four rotations (row_ror 8, 4, 2, 1): one VALU instruction per step,
 // no LDS round trip (what __shfl_xor costs).
 template <int N>

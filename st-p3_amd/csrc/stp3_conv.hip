@@ -354,37 +354,36 @@ inline void launch_colsum(hipStream_t s, int parts, int width, float* partial, f
 // Weight gradient:  dW[co][tap][ci] = sum_m dY[m][co] * X[pixel(m) + tap][ci]
 // ------------------------------------------------------------------------------------------------
 // The contraction runs over PIXELS, the slow dimension of both NHWC operands, while an MFMA fragment wants 8
-// consecutive k per lane.  So the staging transposes: a thread loads an 8-pixel x 8-channel block (8 x 16 bytes,
-// neighbouring threads neighbouring channel blocks: coalesced), transposes it in registers (32 x v_perm_b32) and
-// writes 8 pieces "8 pixels of one channel" into the same [row][8 x 16 B] LDS image the forward kernel uses -- rows
-// are now channels, K is 64 pixels per step -- and the MFMA part is the forward kernel's: dY^T as operand A (rows =
-// output channels), X^T as operand B: an accumulator lane holds dW[co ..][ci = lane & 31], i.e. coalesced float32
-// rows of the result.  Workgroup tile TCO x TCI (64 or 128 each) of one tap; the pixels are split over gridDim.z
-// workgroups (float32 partial sums, reduced deterministically afterwards).
+// consecutive k per lane.  gfx950 has the instruction for exactly this: the staging copies 16-byte pieces (8 channels
+// of a pixel) global -> LDS as they lie, into [64 pixels][T channels] images, and the fragments are read with the LDS
+// TRANSPOSE read (ds_read_b64_tr_b16, stp3_cdna.h): two reads give a lane its 8 pixels of one channel.  dY^T is
+// operand A (rows = output channels), X^T operand B: an accumulator lane holds dW[co ..][ci = lane & 31], i.e.
+// coalesced float32 rows of the result.  Workgroup tile TCO x TCI (64 or 128 each) of one tap; the pixels are split
+// over gridDim.z workgroups (float32 partial sums, reduced deterministically afterwards).
+// (Rounds 1-2 transposed 8 x 8 blocks in registers, 32 x v_perm_b32 per thread and step, and carried (n, ho, wo) per
+// loaded piece: 332 VALU instructions beside 4 MFMAs per step, profiles/r03e_wgrad_pmc.json -- VALU-bound.  Now the
+// pixel arithmetic is done ONCE per pixel and step -- lane l of every wave owns pixel 64 * step + l: coordinates
+// advanced incrementally, bounds test, input pixel index -- and a loading thread fetches the index of its pixel from
+// that lane with one ds_bpermute.)
 // Tap folding (tap_fold > 0; layers with Cin == 8, i.e. the 3-channel stem): one channel block holds ALL input
-// channels, so the TCI / 8 channel-block slots of the X tile carry tap_fold = TCI / 8 different TAPS instead -- the
-// tile's columns are (tap, ci) pairs, contiguous in dW -- and dY, the big operand (48 channels x 1.9 M pixels for the
-// stem), is read once per tap group instead of once per tap (9 x 186 MB before).
-__device__ __forceinline__ uint32_t perm_lo(uint32_t a, uint32_t b) {   // (a.lo16, b.lo16)
-    return __builtin_amdgcn_perm(b, a, 0x05040100u);
+// channels, so the TCI / 8 piece slots of an X row carry tap_fold = TCI / 8 different TAPS instead -- the tile's
+// columns are (tap, ci) pairs, contiguous in dW -- and dY, the big operand (48 channels x 1.9 M pixels for the stem),
+// is read once per tap group instead of once per tap.  The bounds test then depends on the loading thread's tap: the
+// pixel lane hands over the un-shifted pixel index and the packed (row, column) instead.
+
+// byte offset of the 16-byte piece p of pixel row m in a [64][T] bf16 image.  The pieces of a row are permuted so that
+// the four rows x 64 bytes one half-wave touches in a transpose read fall into 64 different banks (128-byte rows: rows
+// m and m + 2 share their banks -> swap the halves of the odd row pair; 256-byte rows: all rows do -> rotate by m & 3)
+template <int T>
+__device__ __forceinline__ int wg_piece(int m, int p) {
+    const int sw = T == 64 ? ((m >> 1) & 1) << 2 : (m & 3) << 2;
+    return m * (T * 2) + ((p ^ sw) << 4);
 }
-__device__ __forceinline__ uint32_t perm_hi(uint32_t a, uint32_t b) {   // (a.hi16, b.hi16)
-    return __builtin_amdgcn_perm(b, a, 0x07060302u);
-}
-// in[p] = 8 channels of pixel p  ->  out[c] = 8 pixels of channel c
-__device__ __forceinline__ void transpose8x8(const uint4 (&in)[8], uint4 (&out)[8]) {
-    uint32_t o[8][4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {                              // pixel pair (2q, 2q+1) -> dword q of every channel
-        const uint4 a = in[2 * q], b = in[2 * q + 1];
-        o[0][q] = perm_lo(a.x, b.x); o[1][q] = perm_hi(a.x, b.x);
-        o[2][q] = perm_lo(a.y, b.y); o[3][q] = perm_hi(a.y, b.y);
-        o[4][q] = perm_lo(a.z, b.z); o[5][q] = perm_hi(a.z, b.z);
-        o[6][q] = perm_lo(a.w, b.w); o[7][q] = perm_hi(a.w, b.w);
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) out[c] = make_uint4(o[c][0], o[c][1], o[c][2], o[c][3]);
-}
+
+union FragTr {
+    stp3_s16x4 h[2];
+    bf16x8 v;
+};
 
 template <int TCO, int TCI>
 __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles_ci, int ksteps_per_block, int tap_fold,
@@ -392,7 +391,11 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
                                                            const uint16_t* __restrict__ x,
                                                            float* __restrict__ partial) {
     constexpr int TA = TCO / 64, TB = TCI / 64;            // 32-row MFMA tiles per wave (2 x 2 waves)
-    constexpr int kStage = (TCO + TCI) * kBK * 2;
+    constexpr int kImgA = kBK * TCO * 2;                   // bytes of the dY image; the X image lies behind it
+    constexpr int kStage = kBK * (TCO + TCI) * 2;
+    constexpr int PA = TCO / 8, PB = TCI / 8;              // 16-byte pieces per pixel row
+    constexpr int NA = TCO / 32, NB = TCI / 32;            // pieces per thread and step
+    constexpr int RA = 256 / PA, RB = 256 / PB;            // pixel rows between two pieces of a thread
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -409,77 +412,82 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
     const int total_steps = (d.M + kBK - 1) / kBK;
     const int step0 = split * ksteps_per_block;
     const int step1 = min(step0 + ksteps_per_block, total_steps);
+    const uint16_t* const zero = reinterpret_cast<const uint16_t*>(&g_zero16);
 
-    // ---- staging roles: 8 x 8 blocks, cc = channel block, pg = pixel group; the dY tile has TCO/8 x 8 blocks, the X tile
-    // TCI/8 x 8: TCO + TCI <= 256 blocks, one per thread, dY blocks first.  Everything that does not change from step to
-    // step is computed ONCE here -- the PMC run of round 3 showed this kernel VALU-bound (83 VALU instructions per MFMA,
-    // profiles/r03e_wgrad_pmc.json), most of them the per-step div / mod of the pixel index and 64-bit address products.
-    static_assert(TCO + TCI <= 256, "one staging block per thread");
-    const bool live = tid < TCO + TCI;
-    const bool is_a = tid < TCO;
-    const int loc = is_a ? tid : tid - TCO;
-    const int nc = is_a ? TCO / 8 : TCI / 8;
-    const int cc = loc % nc, pg = loc / nc;
-    int ch = (is_a ? co0 : ci0) + cc * 8;
-    bool ch_ok = live && ch < (is_a ? d.Cout : d.Cin);
-    int khb = kh, kwb = kw;
-    if (tap_fold && !is_a) {                               // this channel-block slot is tap `t` of the group
-        const int t = tap * tap_fold + cc;
+    // ---- loading roles (fixed for the kernel): piece pa of the dY rows ra0 + RA * i, piece pb of the X rows rb0 + RB * i.
+    // A thread whose channels lie beyond the tensor reads the zero page whatever the pixel: base = zero page, pitch = 0.
+    const int pa = tid % PA, ra0 = tid / PA;
+    const int pb = tid % PB, rb0 = tid / PB;
+    const bool a_ok = co0 + pa * 8 < d.Cout;
+    const uint16_t* const srca = a_ok ? dy + co0 + pa * 8 : zero;
+    const unsigned lda = a_ok ? (unsigned)d.ldy : 0u;
+    bool b_ok = ci0 + pb * 8 < d.Cin;
+    int chb = ci0 + pb * 8, khb = kh, kwb = kw;
+    if (tap_fold) {                                        // this piece slot is tap `t` of the group
+        const int t = tap * tap_fold + pb;
         khb = t / d.KW;
         kwb = t - khb * d.KW;
-        ch = 0;
-        ch_ok = live && t < d.KH * d.KW;
+        chb = 0;
+        b_ok = t < d.KH * d.KW;
     }
-    const int tap_h = khb * d.dil_h - d.pad_h, tap_w = kwb * d.dil_w - d.pad_w;
-    const uint16_t* const src = (is_a ? dy : x) + ch;
-    const int ld = is_a ? d.ldy : d.ldx;
-    // (n, ho, wo) of the first pixel of this thread's group in the NEXT step to be loaded: set up with one div / mod pair
-    // here, then advanced by 64 pixels per step with carries
-    int s_wo = 0, s_ho = 0, s_n = 0;
+    const uint16_t* const srcb = b_ok ? x + chb : zero;
+    const unsigned ldb = b_ok ? (unsigned)d.ldx : 0u;
+    const int fold_dh = khb * d.dil_h, fold_dw = kwb * d.dil_w;              // (fold mode) this thread's tap shift
+
+    // ---- pixel role: lane l of EVERY wave owns pixel 64 * step + l of the step being loaded.  (n, ho, wo) is set up with
+    // one div / mod pair and advanced by 64 = qa * Ho * Wo + qb * Wo + qc pixels per step with two carries
+    const int hw = d.Ho * d.Wo;
+    const int qa = kBK / hw, qr = kBK - qa * hw, qb = qr / d.Wo, qc = qr - qb * d.Wo;
+    int p_wo, p_ho, p_n;
     {
-        const int m = step0 * kBK + pg * 8;
-        const int mm = m < d.M ? m : 0;
-        s_wo = mm % d.Wo;
-        const int t = mm / d.Wo;
-        s_ho = t % d.Ho;
-        s_n = t / d.Ho;
+        const int m = step0 * kBK + lane;
+        p_wo = m % d.Wo;
+        const int t = m / d.Wo;
+        p_ho = t % d.Ho;
+        p_n = t / d.Ho;
     }
-    const uint16_t* const zero = reinterpret_cast<const uint16_t*>(&g_zero16);
-    uint4 raw[8];
+    const int tap_h = kh * d.dil_h - d.pad_h, tap_w = kw * d.dil_w - d.pad_w;
+
+    u32x4 rawa[NA], rawb[NB];
     auto load_step = [&](int step) {                       // steps must be requested in ascending order, each once
-        const int mfirst = step * kBK + pg * 8;
-        if (is_a) {
+        const int mbase = step * kBK;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = mfirst + i;
-                const bool ok = ch_ok && m < d.M;
-                raw[i] = *reinterpret_cast<const uint4*>(ok ? src + (size_t)(unsigned)m * (unsigned)ld : zero);
+        for (int i = 0; i < NA; ++i) {
+            const int m = mbase + ra0 + RA * i;
+            rawa[i] = *reinterpret_cast<const u32x4*>(m < d.M ? srca + (size_t)(unsigned)m * lda : zero);
+        }
+        const bool inside = mbase + lane < d.M;
+        if (!tap_fold) {
+            const int hi = p_ho * d.stride + tap_h, wi = p_wo * d.stride + tap_w;
+            const bool ok = inside && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
+            const int pix = ok ? (p_n * d.H + hi) * d.W + wi : -1;          // < 2^31 (checked by the launcher)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int pv = __shfl(pix, rb0 + RB * i);
+                rawb[i] = *reinterpret_cast<const u32x4*>(pv >= 0 ? srcb + (size_t)(unsigned)pv * ldb : zero);
             }
         } else {
-            int wo = s_wo, ho = s_ho, n = s_n;
+            const int hs = p_ho * d.stride - d.pad_h, ws = p_wo * d.stride - d.pad_w;
+            const int base = (p_n * d.H + hs) * d.W + ws;
+            const int pack = inside ? ((hs + 32768) << 16) | (ws + 32768) : 0;   // 0: row -32768, never inside
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int hi = ho * d.stride + tap_h, wi = wo * d.stride + tap_w;
-                const bool ok = ch_ok && mfirst + i < d.M && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
-                const int pix = (n * d.H + hi) * d.W + wi;          // < 2^31 (checked by the launcher)
-                raw[i] = *reinterpret_cast<const uint4*>(ok ? src + (size_t)(unsigned)pix * (unsigned)ld : zero);
-                if (++wo == d.Wo) { wo = 0; if (++ho == d.Ho) { ho = 0; ++n; } }
-            }
-            s_wo += kBK;                                   // the same group, one step (64 pixels) on
-            while (s_wo >= d.Wo) {
-                s_wo -= d.Wo;
-                if (++s_ho == d.Ho) { s_ho = 0; ++s_n; }
+            for (int i = 0; i < NB; ++i) {
+                const int bs = __shfl(base, rb0 + RB * i), pk = __shfl(pack, rb0 + RB * i);
+                const int hi = (int)((unsigned)pk >> 16) - 32768 + fold_dh, wi = (pk & 0xffff) - 32768 + fold_dw;
+                const bool ok = (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
+                const int pv = bs + fold_dh * d.W + fold_dw;
+                rawb[i] = *reinterpret_cast<const u32x4*>(ok ? srcb + (size_t)(unsigned)pv * ldb : zero);
             }
         }
+        p_wo += qc; p_ho += qb; p_n += qa;                 // this lane's pixel of the next step
+        if (p_wo >= d.Wo) { p_wo -= d.Wo; ++p_ho; }
+        if (p_ho >= d.Ho) { p_ho -= d.Ho; ++p_n; }
     };
-    const int img_off = is_a ? 0 : TCO * kBK * 2;           // dY image first, X image behind it
     auto store_step = [&](uint8_t* buf) {
-        if (!live) return;
-        uint4 tr[8];
-        transpose8x8(raw, tr);
-        uint8_t* img = buf + img_off;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(img + lds_piece(cc * 8 + c, pg)) = tr[c];
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(buf + wg_piece<TCO>(ra0 + RA * i, pa)) = rawa[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4*>(buf + kImgA + wg_piece<TCI>(rb0 + RB * i, pb)) = rawb[i];
     };
 
     f32x16 acc[TA][TB];
@@ -490,24 +498,45 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // ---- fragment addresses: lane l reads, of the 16-pixel sub-step ks, the pixel rows 16 ks + 8 (l >> 5) + 4 r +
+    // ((l & 15) >> 2), r = 0, 1, and of its 32-channel block the channels 16 ((l >> 4) & 1) + 4 (l & 3) .. + 3; the transpose
+    // hands it channel (l & 31) of the rows 8 (l >> 5) .. + 7: an MFMA fragment.  ks and r move the address by whole
+    // multiples of 4 rows, which the piece permutation does not see: immediates.
     const int frow = lane & 31, fk = lane >> 5;
+    const int fm = 8 * fk + ((lane & 15) >> 2), fc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    int offa[TA], offb[TB];
+#pragma unroll
+    for (int a = 0; a < TA; ++a) {
+        const int c = wa * (32 * TA) + a * 32 + fc;
+        offa[a] = wg_piece<TCO>(fm, c >> 3) + (c & 7) * 2;
+    }
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+        const int c = wb * (32 * TB) + b * 32 + fc;
+        offb[b] = kImgA + wg_piece<TCI>(fm, c >> 3) + (c & 7) * 2;
+    }
+
     if (step0 < step1) {
         load_step(step0);
         store_step(smem);
     }
     __syncthreads();
     for (int s = step0; s < step1; ++s) {
-        uint8_t* cur = smem + ((s - step0) & 1) * kStage;
+        const uint8_t* cur = smem + ((s - step0) & 1) * kStage;
         if (s + 1 < step1) load_step(s + 1);
 #pragma unroll
         for (int ks = 0; ks < kBK / 16; ++ks) {
-            Frag fa[TA], fb[TB];
+            FragTr fa[TA], fb[TB];
 #pragma unroll
-            for (int a = 0; a < TA; ++a)
-                fa[a].u = *reinterpret_cast<const uint4*>(cur + lds_piece(wa * (32 * TA) + a * 32 + frow, ks * 2 + fk));
+            for (int a = 0; a < TA; ++a) {
+                fa[a].h[0] = lds_read_tr16(cur + offa[a] + (ks * 16) * (TCO * 2));
+                fa[a].h[1] = lds_read_tr16(cur + offa[a] + (ks * 16 + 4) * (TCO * 2));
+            }
 #pragma unroll
-            for (int b = 0; b < TB; ++b)
-                fb[b].u = *reinterpret_cast<const uint4*>(cur + TCO * kBK * 2 + lds_piece(wb * (32 * TB) + b * 32 + frow, ks * 2 + fk));
+            for (int b = 0; b < TB; ++b) {
+                fb[b].h[0] = lds_read_tr16(cur + offb[b] + (ks * 16) * (TCI * 2));
+                fb[b].h[1] = lds_read_tr16(cur + offb[b] + (ks * 16 + 4) * (TCI * 2));
+            }
 #pragma unroll
             for (int a = 0; a < TA; ++a)
 #pragma unroll
@@ -703,7 +732,11 @@ int stp3_conv2d_wgrad(const stp3_conv_dims* p, const void* dy, const void* x, fl
     if (p->Cin % 8 || p->Cout % 8 || p->ldx % 8 || p->ldy % 8 || p->ldx < p->Cin || p->ldy < p->Cout) return STP3_EUNSUP;
     if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15)) return STP3_EUNSUP;
     const int64_t M = (int64_t)p->N * p->Ho * p->Wo;
-    if (M >= (1LL << 31) - 64 || (int64_t)p->N * p->H * p->W >= (1LL << 31)) return STP3_EUNSUP;
+    // 32-bit pixel indices (the pixel lanes of the last step run up to 63 pixels past the end: two images of slack), and
+    // 16-bit packed (row, column) of the tap-folded path
+    if (M >= (1LL << 31) - 64 || ((int64_t)p->N + 2) * p->H * p->W >= (1LL << 31)) return STP3_EUNSUP;
+    if ((int64_t)p->Ho * p->stride >= 32768 || (int64_t)p->Wo * p->stride >= 32768 || p->pad_h >= 32768 || p->pad_w >= 32768)
+        return STP3_EUNSUP;
     if (p->KH * p->KW > 65535) return STP3_EUNSUP;
     int tco_sz, tci_sz, tco, tci, splits, ksteps, fold, taps;
     wgrad_plan(p, &tco_sz, &tci_sz, &tco, &tci, &splits, &ksteps, &fold, &taps);

@@ -954,7 +954,8 @@ def conv2d_supported(x, weight, stride, groups=1):
     if not (x.is_cuda and x.dim() == 4 and groups == 1 and s[0] == s[1] and weight.shape[1] % 8 == 0):
         return False
     n, c, h, w = x.shape
-    return n * h * w * max(c, weight.shape[0]) < (1 << 31)
+    # (the weight gradient keeps two images of slack in its 32-bit pixel indices and packs rows / columns into 16 bits)
+    return (n + 2) * h * w * max(c, weight.shape[0]) < (1 << 31) and h < 32768 and w < 32768
 
 
 def conv2d_stats_supported(x, weight, stride, padding=0, dilation=1):

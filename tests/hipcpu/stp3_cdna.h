@@ -1,6 +1,9 @@
 // TEST INFRASTRUCTURE: CPU model of st-p3_amd/csrc/stp3_cdna.h (found first on the stand-in's include path).
 #pragma once
 #include <cstring>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 template <int J>
 inline void fmac_row_bcast(float& acc, float v, float f) {
     const float b = hipcpu::exchange<float>(v, (hipcpu::cur->lane & ~15) | J);     // row_newbcast:J
@@ -11,6 +14,23 @@ inline void lds_dma16(const float* src, float* lds_base) {
     std::memcpy(reinterpret_cast<char*>(lds_base) + 16 * hipcpu::cur->lane, src, 16);
 }
 inline void lds_dma_wait() {}
+
+// ds_read_b64_tr_b16: lane i of a 16-lane group supplies row i >> 2, columns 4 * (i & 3) .. + 3 of a [4][16] halfword
+// block at its own address and receives column i.  Misaligned addresses are an error here (the hardware returns the
+// aligned address's data without a word)
+typedef short stp3_s16x4 __attribute__((ext_vector_type(4)));
+inline stp3_s16x4 lds_read_tr16(const void* p) {
+    if (reinterpret_cast<uintptr_t>(p) & 7) { std::fprintf(stderr, "lds_read_tr16: address not 8-byte aligned\n"); std::abort(); }
+    const int lane = hipcpu::cur->lane, i = lane & 15;
+    stp3_s16x4 r;
+    for (int j = 0; j < 4; ++j) {
+        const char* q = static_cast<const char*>(hipcpu::exchange<const void*>(p, (lane & ~15) | (4 * j + (i >> 2))));
+        short v;
+        std::memcpy(&v, q + 2 * (i & 3), 2);
+        r[j] = v;
+    }
+    return r;
+}
 
 template <int N>
 inline float row_ror(float v) {
