@@ -565,6 +565,43 @@ int stp3_upsample_bilinear_fwd(const stp3_upsample_dims* dims, const void* x, vo
 int stp3_upsample_bilinear_bwd(const stp3_upsample_dims* dims, const void* dy, void* dx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Planner: trajectory-cost evaluation (csrc/stp3_plan.hip) -- the reference's Cost_Function.forward, stp3/cost.py:26-47,
+ * with its seven terms (SafetyCost :210-241, HeadwayCost :244-272, LR_divider :274-315, Comfort :318-372, Progress
+ * :374-392, Rule :183-207, Cost_Volume :166-181) in one launch.  Called by Planning.select / Planning.loss
+ * (stp3/models/planning_model.py:43-88) once for the N sampled trajectories and once for the expert trajectory (N = 1).
+ *   trajs        [B][N][T][2] float32   (lateral, forward) metres in the ego frame, UNflipped (the kernel applies the
+ *                                       reference's (-1, 1) flip, cost.py:35)
+ *   cost_volume  [B][T][H][W] float32   the decoder's cost-volume head, raw (clamped to [0, 1000] inside)
+ *   occupancy    [B][T][H][W] float32   0 / 1 (labels in training, argmax of the prediction in evaluation)
+ *   drivable     [B][H][W]    float32   drivable-area mask AFTER the reference's preprocessing (labels as they are;
+ *                                       logits: softmax, entries < 0.5 zeroed -- cost.py:196-201; host side, three operators)
+ *   lane         [B][H][W]    float32   lane-divider mask after the same preprocessing (:289-294); != 0 is a divider
+ *   target       [B][2] float32 ; target_sum [1] float32 = sum of `target` (progress drops its goal term when the sum
+ *                                       over the batch is < 0.5, :386 -- a device scalar, no host synchronisation)
+ *   footprint0 / footprint_lambda  [K0][2] / [KL][2] int32  (row, column) cells of the ego box and of the box inflated
+ *                                       by LAMBDA, as BaseCost.get_origin_points builds them (:70-83; 32 / 192 cells)
+ *   cost_fc [B][N] float32 = comfort + progress ; cost_fo [B][N][T] float32 = safety + headway + lane + volume + rule,
+ *                                       every term clamped as in :36-42
+ *   cv_cell [B][N][T] int32 / cv_scale [B][N][T] float32: (optional, both or neither) the cost-volume cell each cost
+ *                                       read and d cost_fo / d cost_volume[cell] -- what the backward needs
+ *   bwd: grad_cost_volume [B][T][H][W] float32, written completely (zeros where nothing was read); contributions of
+ *        several trajectories to one cell are added in ascending trajectory order (deterministic, no atomics).
+ * Limits: B*N*T and B*T*H*W < 2^31; backward N <= 20 480 (STP3_EUNSUP). */
+typedef struct stp3_plan_dims {
+    int32_t B, N, T, H, W, K0, KL;
+    float dx0, dx1, bx0, bx1;                     /* BEV resolution / first cell centre, (x = forward, y = side) */
+    float safety, headway, lrdivider, comfort, progress, volume, rule;   /* COST_FUNCTION factors; rule = 5 */
+    float w0, w1;                                 /* SafetyCost.w */
+    float headway_dist, lr_dist;                  /* 10 m, 1 m */
+} stp3_plan_dims;
+int stp3_traj_cost_fwd(const stp3_plan_dims* dims, const float* trajs, const float* cost_volume, const float* occupancy,
+                       const float* drivable, const float* lane, const float* target, const float* target_sum,
+                       const int32_t* footprint0, const int32_t* footprint_lambda, float* cost_fc, float* cost_fo,
+                       int32_t* cv_cell, float* cv_scale, void* stream);
+int stp3_traj_cost_bwd(const stp3_plan_dims* dims, const float* grad_cost_fo, const int32_t* cv_cell,
+                       const float* cv_scale, float* grad_cost_volume, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Stand-alone voxel summing (csrc/stp3_voxsum.hip): the operator-level twin of the reference's
  * VoxelsSumming.forward / .backward (stp3/utils/geometry.py:302-318 / :320-330) for callers that hold the
  * rank-sorted row matrix; the fused path above never builds it.

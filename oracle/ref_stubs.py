@@ -30,6 +30,38 @@ def _mod(name, **attrs):
     return m
 
 
+def polygon(r, c, shape=None):
+    """Restatement of ``skimage.draw.polygon`` (scikit-image is a dependency of the reference that is NOT installed
+    here: stp3/cost.py:7, stp3/metrics.py:12; no version pinned by the reference's environment file beyond the
+    package name).  Published algorithm (skimage/draw/_draw.pyx ``_polygon`` + skimage/_shared/geometry.pxd
+    ``point_in_polygon``): every integer (row, column) of the vertices' bounding box -- rows max(0, floor-int of
+    min r) .. ceil(max r), the same for columns -- is tested with the even-odd crossing rule; points are emitted
+    row by row, columns ascending.  Releases >= 0.19 additionally count points lying EXACTLY on an edge or vertex as
+    inside; the two variants agree whenever no integer point lies on the boundary, which holds for every footprint
+    the reference builds (non-integer box corners) and is asserted by the product's own rasteriser.
+    Anchor in the reference itself: stp3/metrics.py:313 documents 32 footprint cells for the default ego box."""
+    import numpy as np
+    r = np.asarray(r, dtype=np.float64)
+    c = np.asarray(c, dtype=np.float64)
+    minr, maxr = int(max(0, r.min())), int(np.ceil(r.max()))
+    minc, maxc = int(max(0, c.min())), int(np.ceil(c.max()))
+    if shape is not None:
+        maxr, maxc = min(shape[0] - 1, maxr), min(shape[1] - 1, maxc)
+    rr, cc = [], []
+    n = len(r)
+    for y in range(minr, maxr + 1):
+        for x in range(minc, maxc + 1):
+            inside, j = False, n - 1
+            for i in range(n):
+                if ((r[i] <= y < r[j]) or (r[j] <= y < r[i])) and x < (c[j] - c[i]) * (y - r[i]) / (r[j] - r[i]) + c[i]:
+                    inside = not inside
+                j = i
+            if inside:
+                rr.append(y)
+                cc.append(x)
+    return np.array(rr, dtype=np.intp), np.array(cc, dtype=np.intp)
+
+
 def install(efficientnet_cls=None, resnet18_fn=None):
     """Register stubs and put the reference on sys.path.  Idempotent."""
     import numpy as np
@@ -59,7 +91,7 @@ def install(efficientnet_cls=None, resnet18_fn=None):
     _mod('timm.models')
     _mod('timm.models.layers', DropPath=nn.Identity)
     _mod('skimage')
-    _mod('skimage.draw', polygon=_Dummy)
+    _mod('skimage.draw', polygon=polygon)
 
     class _Normalize:  # network.py:33 subclasses it
         def __init__(self, mean=None, std=None):

@@ -62,7 +62,7 @@ constexpr int kBK = 64;         // K per step: 8 pieces of 16 bytes per row
 // the bookkeeping of which pieces were real): the PMC passes of round 3 showed both convolution kernels bound by their
 // VALU instruction count (196 VALU instructions beside 8 MFMAs per K-step in the forward kernel, 332 beside 4 in the
 // weight gradient), not by the matrix cores or by memory.
-__device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
+__device__ __attribute__((aligned(16))) uint4 g_zero16 = {0u, 0u, 0u, 0u};
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // v or zero, word by word (a select on the whole uint4 makes the compiler go through scratch memory)
@@ -137,8 +137,11 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
     while (ci >= d.Cin) { ci -= d.Cin; ++tap; }
     int kh = tap / d.KW, kw = tap - kh * d.KW;
     const int taps = d.KH * d.KW;
-    // pointwise layers (1x1, no padding: half of the launches of a step) never leave the image: no bounds tests
-    const bool pointwise = taps == 1 && d.pad_h == 0 && d.pad_w == 0;
+    // pointwise layers (1x1, no padding: half of the launches of a step) never leave the image: no bounds tests.  (The
+    // output may be LARGER than the padding implies -- the per-phase data gradients ask for it, ops._strided_dgrad -- and
+    // then a single tap does fall off the bottom / right edge.)
+    const bool pointwise = taps == 1 && d.pad_h == 0 && d.pad_w == 0 && (d.Ho - 1) * d.stride < d.H &&
+                           (d.Wo - 1) * d.stride < d.W;
 
     u32x4 ra[4], rb[BN / 32];                              // first-class vectors: HIP's uint4 (a struct) ends up in scratch here
     auto load_step = [&]() {                               // the piece of the current (tap, ci) for every row of this thread

@@ -93,6 +93,13 @@ class CeDims(ctypes.Structure):
                 ('stride_c', ctypes.c_int64), ('stride_p', ctypes.c_int64)]
 
 
+class PlanDims(ctypes.Structure):
+    """struct stp3_plan_dims (include/stp3_hip.h)."""
+    _fields_ = ([(k, ctypes.c_int32) for k in ('B', 'N', 'T', 'H', 'W', 'K0', 'KL')] +
+                [(k, ctypes.c_float) for k in ('dx0', 'dx1', 'bx0', 'bx1', 'safety', 'headway', 'lrdivider', 'comfort',
+                                               'progress', 'volume', 'rule', 'w0', 'w1', 'headway_dist', 'lr_dist')])
+
+
 class OptimBucket(ctypes.Structure):
     """struct stp3_optim_bucket (include/stp3_hip.h)."""
     _fields_ = [('grad', ctypes.c_void_p), ('param', ctypes.c_void_p), ('exp_avg', ctypes.c_void_p),
@@ -181,6 +188,8 @@ SIGNATURES = {
     'stp3_reg_loss_fwd': (c_int, [c_int32] * 4 + [c_float, c_int32] + [c_void_p] * 5 + [c_size_t, c_void_p]),
     'stp3_reg_loss_bwd': (c_int, [c_int32] * 4 + [c_float, c_int32] + [c_void_p] * 7),
     'stp3_warp_nearest': (c_int, [c_int32] * 4 + [c_void_p] * 5),
+    'stp3_traj_cost_fwd': (c_int, [ctypes.POINTER(PlanDims)] + [c_void_p] * 14),
+    'stp3_traj_cost_bwd': (c_int, [ctypes.POINTER(PlanDims)] + [c_void_p] * 5),
     'stp3_voxels_sum_fwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     'stp3_voxels_sum_bwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
 }

@@ -58,3 +58,73 @@ class IntersectionOverUnion(nn.Module):
         if self.reduction == 'sum':
             return scores.sum()
         return scores
+
+
+class PlanningMetric(nn.Module):
+    """L2 error and collision rates of the planned trajectory per future step (``stp3/metrics.py:263-399``): ``obj_col``
+    counts steps whose trajectory POINT lies in an occupied cell, ``obj_box_col`` steps whose ego BOX (the 32 cells of
+    ``cost.BaseCost.footprint``) touches one; steps at which the expert's own box already collides with the labels are
+    not counted.  Plain buffers + ``sync()`` instead of Lightning's metric states; evaluated for the whole batch at
+    once, on the device, instead of a Python loop over samples and steps with host round trips."""
+
+    def __init__(self, cfg, n_future=4):
+        super().__init__()
+        from .cost import BaseCost
+        base = BaseCost(cfg)
+        self.dx = nn.Parameter(base.dx.detach().clone(), requires_grad=False)
+        self.bx = nn.Parameter(base.bx.detach().clone(), requires_grad=False)
+        self.bev_dimension = [int(v) for v in base.bev_dimension]
+        self.W, self.H = cfg.EGO.WIDTH, cfg.EGO.HEIGHT
+        self.n_future = n_future
+        self.register_buffer('footprint', torch.from_numpy(base.footprint(0)), persistent=False)
+        for name in ('obj_col', 'obj_box_col', 'L2'):
+            self.register_buffer(name, torch.zeros(n_future), persistent=False)
+        self.register_buffer('total', torch.tensor(0), persistent=False)
+
+    def reset(self):
+        for name in ('obj_col', 'obj_box_col', 'L2', 'total'):
+            getattr(self, name).zero_()
+
+    def box_collisions(self, trajs, segmentation):
+        """(B, T) bool: does the ego box at step t of the (flipped) trajectory (B, T, 2) touch an occupied cell."""
+        B, T, _ = trajs.shape
+        rc = self.footprint.to(trajs.device)
+        rows = (trajs[..., 1:2] / self.dx[0] + rc[:, 0]).to(torch.int32).clamp(0, self.bev_dimension[0] - 1).long()
+        cols = (trajs[..., 0:1] / self.dx[1] + rc[:, 1]).to(torch.int32).clamp(0, self.bev_dimension[1] - 1).long()
+        bi = torch.arange(B, device=trajs.device).view(B, 1, 1)
+        ti = torch.arange(T, device=trajs.device).view(1, T, 1)
+        return segmentation[bi, ti, rows, cols].bool().any(dim=-1)
+
+    @torch.no_grad()
+    def update(self, trajs, gt_trajs, segmentation):
+        """trajs, gt_trajs (B, T, 3); segmentation (B, T, H, W)."""
+        assert trajs.shape == gt_trajs.shape
+        self.L2 += torch.sqrt(((trajs[..., :2] - gt_trajs[..., :2]) ** 2).sum(dim=-1)).sum(dim=0)
+        flip = torch.tensor([-1, 1], device=trajs.device, dtype=trajs.dtype)
+        plan, expert = trajs[..., :2] * flip, gt_trajs[..., :2] * flip
+        clean = ~self.box_collisions(expert, segmentation)
+        yi = ((plan[..., 1] - self.bx[0]) / self.dx[0]).long()
+        xi = ((plan[..., 0] - self.bx[1]) / self.dx[1]).long()
+        inside = (yi >= 0) & (yi < self.bev_dimension[0]) & (xi >= 0) & (xi < self.bev_dimension[1])
+        B, T = yi.shape
+        bi = torch.arange(B, device=trajs.device).view(B, 1)
+        ti = torch.arange(T, device=trajs.device).view(1, T)
+        hit = segmentation[bi, ti, yi.clamp(0, self.bev_dimension[0] - 1), xi.clamp(0, self.bev_dimension[1] - 1)]
+        self.obj_col += (hit.long() * (inside & clean)).sum(dim=0).to(self.obj_col.dtype)
+        self.obj_box_col += (self.box_collisions(plan, segmentation) & clean).sum(dim=0).to(self.obj_box_col.dtype)
+        self.total += B
+
+    def forward(self, trajs, gt_trajs, segmentation):
+        self.update(trajs, gt_trajs, segmentation)
+
+    def sync(self, group=None):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            packed = torch.cat([self.obj_col, self.obj_box_col, self.L2, self.total.reshape(1).to(self.L2.dtype)])
+            dist.all_reduce(packed, group=group)
+            n = self.n_future
+            self.obj_col, self.obj_box_col, self.L2 = packed[:n].clone(), packed[n:2 * n].clone(), packed[2 * n:3 * n].clone()
+            self.total = packed[-1].round().to(self.total.dtype)
+
+    def compute(self):
+        return {'obj_col': self.obj_col / self.total, 'obj_box_col': self.obj_box_col / self.total, 'L2': self.L2 / self.total}

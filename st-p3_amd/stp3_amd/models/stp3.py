@@ -22,6 +22,7 @@ from .decoder import Decoder
 from .distributions import DistributionModule
 from .encoder import Encoder
 from .future_prediction import FuturePrediction
+from .planning_model import Planning
 from .temporal_model import TemporalModel, TemporalModelIdentity
 
 
@@ -63,8 +64,6 @@ class STP3(nn.Module):
         self.latent_dim = cfg.MODEL.DISTRIBUTION.LATENT_DIM
         self.spatial_extent = (cfg.LIFT.X_BOUND[1], cfg.LIFT.Y_BOUND[1])
         self.bev_size = (int(dim[0]), int(dim[1]))
-        if cfg.PLANNING.ENABLED:
-            raise NotImplementedError('the planning stage is outside the accelerated path (set PLANNING.ENABLED=False)')
         if not cfg.MODEL.ENCODER.USE_DEPTH_DISTRIBUTION:
             raise NotImplementedError('USE_DEPTH_DISTRIBUTION=False is not on the benchmarked path')
 
@@ -104,6 +103,9 @@ class STP3(nn.Module):
                           'predict_instance': cfg.INSTANCE_SEG.ENABLED,
                           'predict_future_flow': cfg.INSTANCE_FLOW.ENABLED,
                           'planning': cfg.PLANNING.ENABLED})
+        if cfg.PLANNING.ENABLED:
+            # stp3.py:104-107: trajectory costs + GRU refinement (models/planning_model.py, csrc/stp3_plan.hip)
+            self.planning = Planning(cfg, self.encoder_out_channels, 6, gru_state_size=cfg.PLANNING.GRU_STATE_SIZE)
         set_bn_momentum(self, cfg.MODEL.BN_MOMENTUM)
 
         # BEV features in channels-last memory (same logical (B,T,C,X,Y) tensor): what the NHWC convolutions of the
@@ -162,7 +164,7 @@ class STP3(nn.Module):
             feat = feat.view(b, s, n, *feat.shape[1:])
             depth = depth.view(b, s, n, *depth.shape[1:])
             return ops.lift_splat(feat, depth, self.prebuilt_plan, self.discount, self.bev_channels_last,
-                                  self._bev_dtype()), depth, None
+                                  self._bev_dtype()), depth, self._cam_front(feat)
         # geometry-only work goes to a side stream: it overlaps the image encoder below
         cur = torch.cuda.current_stream(dev)
         if self._side_stream is None:
@@ -181,7 +183,12 @@ class STP3(nn.Module):
         feat = feat.view(b, s, n, *feat.shape[1:])
         depth = depth.view(b, s, n, *depth.shape[1:])
         bev = ops.lift_splat(feat, depth, plan, self.discount, self.bev_channels_last, self._bev_dtype())
-        return bev, depth, None
+        return bev, depth, self._cam_front(feat)
+
+    def _cam_front(self, feat, cam_front_index=1):
+        """The present frame's features of the front camera, (B, C, fH, fW): what the planner's GRU starts from
+        (stp3.py:209-212 ``encoder_forward(cam_front_index=1)`` + :315 ``[:, -1]``); None without a planner."""
+        return feat[:, -1, cam_front_index] if self.cfg.PLANNING.ENABLED else None
 
     def forward(self, image, intrinsics, extrinsics, future_egomotion):
         rf = self.receptive_field

@@ -137,9 +137,31 @@ def make_instance_labels(segmentation, ignore_index=255, seed=0):
     return instance, centerness.float(), offset.float(), flow.float()
 
 
+def make_planning_inputs(batch, n_future, sample_num, seed=0):
+    """Planner inputs with the shapes of the reference's loader (stp3/datas/NuscenesData.py:589-646): the expert
+    trajectory (B, n_future + 1, 3) starting at the origin, ``sample_num`` candidate trajectories (B, N, n_future + 1,
+    3) -- one third per navigation command, constant-curvature arcs at 0.5 s steps -- a command and a target point per
+    sample."""
+    g = torch.Generator().manual_seed(seed + 32452843)
+    t = torch.arange(n_future + 1, dtype=torch.float32) * 0.5
+    third = sample_num // 3
+    speed = 2.0 + 10.0 * torch.rand(batch, sample_num, 1, generator=g)
+    turn = torch.cat([0.02 + 0.1 * torch.rand(batch, third, 1, generator=g),           # LEFT third
+                      0.02 * (torch.rand(batch, third, 1, generator=g) - 0.5),          # FORWARD third
+                      -0.02 - 0.1 * torch.rand(batch, sample_num - 2 * third, 1, generator=g)], dim=1)
+    dist = speed * t
+    heading = turn * dist
+    samples = torch.stack([-dist * torch.sin(heading * 0.5), dist * torch.cos(heading * 0.5), heading], dim=-1)
+    expert = samples[:, third + third // 2].clone() * (0.8 + 0.4 * torch.rand(batch, 1, 1, generator=g))
+    return {'command': ['FORWARD'] * batch, 'sample_trajectory': samples.float(), 'gt_trajectory': expert.float(),
+            'target_point': expert[:, -1, :2].clone().float() * 2.0}
+
+
 def make_batch(batch=1, seq=3, n_cams=6, final_dim=(224, 480), bev=(200, 200), seed=0,
-               axis_aligned=False, with_images=True, with_labels=True, gt_depth=False, instance=False):
-    """Full batch dict with the reference's keys (trainer.py:102-108)."""
+               axis_aligned=False, with_images=True, with_labels=True, gt_depth=False, instance=False,
+               planning=None):
+    """Full batch dict with the reference's keys (trainer.py:102-108).  ``planning`` = (n_future, sample_num) fills
+    the planner's inputs; without it they are the placeholders of the perception path."""
     g = torch.Generator().manual_seed(seed + 104729)
     intr, extr, ego = make_rig(batch, seq, n_cams, final_dim, seed, axis_aligned)
     out = {
@@ -151,6 +173,8 @@ def make_batch(batch=1, seq=3, n_cams=6, final_dim=(224, 480), bev=(200, 200), s
         'target_point': torch.zeros(batch, 2),
         'gt_trajectory': torch.zeros(batch, 1, 3),
     }
+    if planning is not None:
+        out.update(make_planning_inputs(batch, planning[0], planning[1], seed))
     if with_images:
         out['image'] = torch.randn(batch, seq, n_cams, 3, *final_dim, generator=g)
     if with_labels:

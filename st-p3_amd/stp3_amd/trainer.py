@@ -5,8 +5,8 @@ dependency (``stp3/trainer.py:14-462``): ``TrainingModule(hparams_dict)``, ``.mo
 the reference's checkpoints (``model.*`` incl. the learned uncertainty scalars
 ``model.<task>_weight``, trainer.py:42-97), so ``load_state_dict(ckpt['state_dict'])`` works.
 
-Perception path only: instance / flow / planning heads follow the config gates exactly as the
-reference does, but the prediction and planning stages are rejected by ``STP3``.
+Instance / flow / planning heads follow the config gates exactly as the reference does; the prediction stage
+(N_FUTURE_FRAMES > 0) and the planner (PLANNING.ENABLED) are built by ``STP3`` when the configuration asks for them.
 """
 import os
 
@@ -17,7 +17,7 @@ from .config import get_cfg
 from .geometry import (cumulative_warp_features, cumulative_warp_features_reverse, label_warp_thetas,
                        warp_with_theta)
 from .losses import DepthLoss, HDmapLoss, SegmentationLoss, SpatialRegressionLoss
-from .metrics import IntersectionOverUnion
+from .metrics import IntersectionOverUnion, PlanningMetric
 from .models.stp3 import STP3
 
 
@@ -75,6 +75,9 @@ class TrainingModule(nn.Module):
             self.losses_fn['instance_flow'] = SpatialRegressionLoss(
                 norm=1, future_discount=cfg.FUTURE_DISCOUNT, ignore_index=cfg.DATASET.IGNORE_INDEX)
             self.model.flow_weight = _scalar()
+        if cfg.PLANNING.ENABLED:
+            self.metric_planning_val = PlanningMetric(cfg, cfg.N_FUTURE_FRAMES)
+            self.model.planning_weight = _scalar()
         self.training_step_count = 0
         self._fused_terms = None
 
@@ -125,10 +128,22 @@ class TrainingModule(nn.Module):
             if cfg.INSTANCE_FLOW.ENABLED:
                 self._weighted(loss, 'flow', 'instance_flow', self.losses_fn['instance_flow'](
                     output['instance_flow'], labels['flow'], rf))
+            final_traj = None
+            if cfg.PLANNING.ENABLED:
+                # trainer.py:175-193: occupancy and hd map are LABELS in training, the camera feature is detached
+                occupancy = labels['segmentation'][:, rf:].squeeze(2).bool()
+                if 'pedestrian' in labels:
+                    occupancy = occupancy | labels['pedestrian'][:, rf:].squeeze(2).bool()
+                pl_loss, final_traj = self.model.planning(
+                    cam_front=output['cam_front'].detach(), trajs=batch['sample_trajectory'][:, :, 1:],
+                    gt_trajs=labels['gt_trajectory'][:, 1:], cost_volume=output['costvolume'][:, rf:],
+                    semantic_pred=occupancy, hd_map=labels['hdmap'], commands=batch['command'],
+                    target_points=batch['target_point'])
+                self._weighted(loss, 'planning', 'planning', pl_loss)
             if self._fused_terms is not None:
                 loss['total'] = self._fused_total(self._fused_terms)
                 self._fused_terms = None
-            output = {**output, 'selected_traj': labels['gt_trajectory']}
+            output = {**output, 'selected_traj': self._with_origin(final_traj, labels['gt_trajectory'])}
         else:
             # evaluate.py:95-98 / trainer.py:216-236: argmax over classes, present frame onwards
             seg_pred = torch.argmax(output['segmentation'].detach(), dim=2, keepdim=True)
@@ -140,8 +155,30 @@ class TrainingModule(nn.Module):
                 for i in range(len(self.hdmap_class)):
                     hd_pred = torch.argmax(output['hdmap'][:, 2 * i:2 * (i + 1)].detach(), dim=1, keepdim=True)
                     self.metric_hdmap_val[i](hd_pred, labels['hdmap'][:, i:i + 1])
-            output = {**output, 'selected_traj': labels['gt_trajectory']}
+            final_traj = None
+            if cfg.PLANNING.ENABLED:
+                # trainer.py:230-246: predicted occupancy and hd map steer the planner, the labels judge the result
+                occupancy = seg_pred.bool()
+                if cfg.SEMANTIC_SEG.PEDESTRIAN.ENABLED:
+                    occupancy = occupancy | ped_pred.bool()
+                _, final_traj = self.model.planning(
+                    cam_front=output['cam_front'].detach(), trajs=batch['sample_trajectory'][:, :, 1:],
+                    gt_trajs=labels['gt_trajectory'][:, 1:], cost_volume=output['costvolume'][:, rf:].detach(),
+                    semantic_pred=occupancy[:, rf:].squeeze(2), hd_map=output['hdmap'].detach(),
+                    commands=batch['command'], target_points=batch['target_point'])
+                truth = labels['segmentation'][:, rf:].squeeze(2).bool()
+                if 'pedestrian' in labels:
+                    truth = truth | labels['pedestrian'][:, rf:].squeeze(2).bool()
+                self.metric_planning_val(final_traj, labels['gt_trajectory'][:, 1:], truth)
+            output = {**output, 'selected_traj': self._with_origin(final_traj, labels['gt_trajectory'])}
         return output, labels, loss
+
+    @staticmethod
+    def _with_origin(final_traj, gt_trajectory):
+        """The planned trajectory with the ego origin in front (trainer.py:192-193), or the expert's without a planner."""
+        if final_traj is None:
+            return gt_trajectory
+        return torch.cat([torch.zeros_like(final_traj[:, :1]), final_traj], dim=1)
 
     def _warp_pair(self, x, ego, rf, to_long):
         """Past frames warped into the present frame, future frames warped back (trainer.py:279-290)."""

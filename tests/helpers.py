@@ -197,3 +197,52 @@ class BlockTaps:
                 self.fp[f'{n}/gout'], self.fp[f'{n}/gout_norm'] = fingerprint(out.grad)
         self.outs = {}
         return self.fp
+
+
+def planning_inputs(cfg, batch=2):
+    """Deterministic inputs of the planner fixtures (oracle/make_golden_planning.py and tests/test_planning_*.py build
+    the SAME tensors): sampled trajectories that stay on the grid and a few that leave it, a cost volume that exercises
+    both clamps, occupancy with an obstacle ahead of the ego vehicle, hd-map labels and logits with two lane dividers
+    and a drivable corridor."""
+    B, N, T = batch, cfg.PLANNING.SAMPLE_NUM, cfg.N_FUTURE_FRAMES
+    step_y = (det_tensor((B, N, T), 301).abs() * 6.0)                     # 0..6 m forward per 0.5 s
+    step_x = det_tensor((B, N, T), 302, 1.5)
+    scale = torch.where(torch.arange(N) % 11 == 10, 4.0, 1.0).view(1, N, 1)   # every 11th leaves the 100 m grid
+    y = torch.cumsum(step_y, dim=2) * scale
+    x = torch.cumsum(step_x, dim=2) * scale
+    trajs = torch.stack([x, y, det_tensor((B, N, T), 303)], dim=-1)
+    gy = torch.cumsum(det_tensor((B, T), 304).abs() * 5.0, dim=1)
+    gx = torch.cumsum(det_tensor((B, T), 305, 0.8), dim=1)
+    gt = torch.stack([gx, gy, det_tensor((B, T), 306)], dim=-1)
+    occ = det_tensor((B, T, 200, 200), 307) > 0.99
+    occ[:, :, 112:118, 96:104] = True                                     # an obstacle 6-9 m ahead
+    labels = torch.zeros(B, 2, 200, 200, dtype=torch.long)
+    labels[:, 0, :, 92] = 1
+    labels[:, 0, :, 108] = 1
+    labels[:, 0, 140, 92:109] = 1
+    labels[:, 1, :, 85:116] = 1
+    labels[1, 1, 120:, :] = 0                                             # batch element 1: the road ends 10 m ahead
+    logits = det_tensor((B, 4, 200, 200), 308, 1.0)
+    logits[:, 1, :, 92] += 3.0
+    logits[:, 1, :, 108] += 3.0
+    logits[:, 3, :, 85:116] += 3.0
+    logits[:, 2, :, :85] += 3.0
+    logits[:, 2, :, 116:] += 3.0
+    return {'trajs': trajs, 'sample_trajs': trajs, 'gt_trajs': gt, 'occupancy': occ, 'hdmap_labels': labels,
+            'hdmap_logits': logits, 'cost_volume': det_tensor((B, T, 200, 200), 309, 2.0),
+            'target': torch.tensor([[-3.0, 20.0], [0.0, 0.0]])[:B].contiguous(), 'commands': ['LEFT', 'FORWARD'][:B],
+            'cam_front': det_tensor((B, 64, 28, 60), 310), 'w_fo': det_tensor((B, N, T), 311)}
+
+
+def planning_metric_trajs(cfg, batch=2):
+    """(plan, expert) (B, T, 3) for the collision counts of PlanningMetric against ``planning_inputs``' occupancy:
+    sample 0 drives straight through the obstacle 6-9 m ahead while its expert passes 6 m to the side; sample 1's
+    expert itself touches the obstacle at the second step (that step must not be counted)."""
+    T = cfg.N_FUTURE_FRAMES
+    y = torch.arange(1, T + 1, dtype=torch.float32) * 3.6
+    plan = torch.zeros(batch, T, 3)
+    plan[:, :, 1] = y
+    plan[1, :, 0] = 0.4
+    expert = plan.clone()
+    expert[0, :, 0] = 6.0
+    return plan, expert

@@ -612,6 +612,37 @@ def losses(ops):
     return out
 
 
+def plan(ops):
+    """csrc/stp3_plan.hip through stp3_amd.cost.Cost_Function (GPU route) against the torch statements of the same module
+    (CPU route, bit-equal to the reference on the fixtures of tests/golden/planning.npz): both cost tensors and the
+    cost-volume gradient, for label and logit hd maps, with and without a target point, and for a single (expert)
+    trajectory."""
+    from stp3_amd.config import perception_cfg
+    from stp3_amd.cost import Cost_Function
+    from tests import helpers as H
+    cfg = perception_cfg(**{'N_FUTURE_FRAMES': 4, 'PLANNING.ENABLED': True, 'PLANNING.SAMPLE_NUM': 60})
+    ins = H.planning_inputs(cfg)
+    cf = Cost_Function(cfg)
+    is_cuda = torch.Tensor.is_cuda
+    out = {}
+    for form in ('labels', 'logits', 'labels_no_target', 'expert'):
+        hd = ins['hdmap_logits'] if form == 'logits' else ins['hdmap_labels']
+        lane, drv = (hd[:, 0:1], hd[:, 1:2]) if hd.shape[1] == 2 else (hd[:, 0:2], hd[:, 2:4])
+        tgt = torch.zeros_like(ins['target']) if form == 'labels_no_target' else ins['target']
+        tr = ins['gt_trajs'][:, None, :, :2] if form == 'expert' else ins['trajs'][..., :2]
+        w = ins['w_fo'][:, :tr.shape[1]]
+        res = []
+        for kernel in (True, False):
+            torch.Tensor.is_cuda = is_cuda if kernel else property(lambda self: False)
+            cv = ins['cost_volume'].clone().requires_grad_()
+            fc, fo = cf(cv, tr.clone(), ins['occupancy'], lane.clone(), drv.clone(), tgt)
+            (fo * w).sum().backward()
+            res.append((fc.detach(), fo.detach(), cv.grad))
+        torch.Tensor.is_cuda = is_cuda
+        out[form] = {k: err(a, b) for k, a, b in zip(('cost_fc', 'cost_fo', 'd_cost_volume'), res[0], res[1])}
+    return out
+
+
 def conv_bn(ops):
     """conv -> BatchNorm -> act (+ skip / drop-connect) as ONE operator (conv v2 with the statistics in its epilogue)
     against the two separate operators, and both against float32 torch on the same bf16-representable data."""
@@ -945,7 +976,7 @@ def fuzz(ops, seed=1):
 
 
 CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_frames, lift_coarse_grid, lift_tall, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
-                                 conv, dwconv, mbconv_mid, losses)}
+                                 conv, dwconv, mbconv_mid, losses, plan)}
 
 if __name__ == '__main__':
     ops_mod = setup(sys.argv[1])

@@ -28,9 +28,9 @@ import build as hipcpu_build  # noqa: E402
 
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
 ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
-           ('conv', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
+           ('conv', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
            ('lift_c64_frames', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
-ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'mbconv_mid', 'losses', 'lift_c16']
+ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'mbconv_mid', 'losses', 'plan', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)]
 MODEL = [('lift_full', {}), ('model_step_two_ranks', {}), ('model_step_f32_full_losses', {}), ('model_step_f32', {}),
          ('model_step_bf16_bn_eval', {})]        # whole training steps: minutes, STP3_SLOW_TESTS=1
@@ -146,6 +146,18 @@ def test_mbconv_middle_operator(results):
             assert max(r.values()) <= tol, (name, r)
             if name.endswith('_bf16'):                    # everything that is not stored in bf16 stays float32-accurate
                 assert max(r[k] for k in ('dgamma', 'dbeta', 'dw1', 'db1', 'dw2', 'db2', 'rmean', 'rvar')) <= 2e-5, (name, r)
+
+
+def test_planner_cost_kernels(results):
+    """csrc/stp3_plan.hip (trajectory costs in one launch, deterministic cost-volume gradient) against the torch statements
+    of stp3_amd.cost -- themselves bit-equal to the reference on these inputs (tests/test_planning_cpu.py) -- for label and
+    logit hd maps, without a target point, and for the single expert trajectory; under all three fiber orders."""
+    for env in ({}, REVERSE, RANDOM):
+        r = _get(results, 'plan', env)
+        for form, e in r.items():
+            if form == 'seconds':
+                continue
+            assert e['cost_fc'] <= 2e-5 and e['cost_fo'] <= 2e-5 and e['d_cost_volume'] <= 1e-6, (form, e)
 
 
 def test_loss_and_label_warp_kernels(results):
