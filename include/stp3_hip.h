@@ -602,6 +602,32 @@ int stp3_traj_cost_bwd(const stp3_plan_dims* dims, const float* grad_cost_fo, co
                        const float* cv_scale, float* grad_cost_volume, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Camera images: decoded bytes -> network input (csrc/stp3_image.hip).  The per-image chain of the reference's loader,
+ * stp3/datas/NuscenesData.py:236-244: resize_and_crop_image (stp3/utils/geometry.py:9-13: PIL resize BILINEAR + crop)
+ * followed by torchvision ToTensor + Normalize (:68-72), for all N images of a batch in one launch.
+ *   images   [N][H][W][3] uint8 (RGB, as PIL decodes them)
+ *   kk_h / bounds_h  [Wr][ksize_h] int32 / [Wr][2] int32: Pillow's horizontal resampling coefficients in its 22-bit fixed
+ *            point and (first source column, count) per resized column; kk_v / bounds_v the same for the rows.  Built on
+ *            the host exactly as Pillow builds them (stp3_amd.datas.pil_bilinear_coefficients); configuration-only.
+ *   out      [N][3][Ho][Wo] float32 or bf16 = ((byte / 255) - mean[c]) / std[c], byte = the resized image at
+ *            (top + r, left + x); window positions outside the resized image are PIL's zero padding.
+ *   strip_rows: the largest number of source rows the vertical taps of 8 consecutive output rows span (host: from
+ *            bounds_v; stp3_image_prep_rows_per_workgroup() returns the 8); sizes the LDS strip.
+ * The resized bytes equal PIL.Image.resize(..., BILINEAR) bit for bit (both passes, byte rounding between them). */
+typedef struct stp3_image_dims {
+    int32_t N, H, W;              /* source */
+    int32_t Wr, Hr;               /* resize_dims */
+    int32_t left, top, Wo, Ho;    /* crop window in the resized image */
+    int32_t ksize_h, ksize_v;
+    int32_t out_dtype;            /* STP3_DTYPE_F32 | STP3_DTYPE_BF16 */
+    float mean[3], std[3];
+} stp3_image_dims;
+int stp3_image_prep_rows_per_workgroup(void);
+int stp3_image_prep_lds_bytes(const stp3_image_dims* dims, int32_t strip_rows, size_t* bytes);
+int stp3_image_prep(const stp3_image_dims* dims, const uint8_t* images, const int32_t* kk_h, const int32_t* bounds_h,
+                    const int32_t* kk_v, const int32_t* bounds_v, int32_t strip_rows, void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Stand-alone voxel summing (csrc/stp3_voxsum.hip): the operator-level twin of the reference's
  * VoxelsSumming.forward / .backward (stp3/utils/geometry.py:302-318 / :320-330) for callers that hold the
  * rank-sorted row matrix; the fused path above never builds it.

@@ -4,10 +4,11 @@
 #   bench line -> kernel-trace profile with the per-dispatch listing of the last step -> 2-rank launch attempt
 out=gpurun_out/${1:-r03}; mkdir -p $out
 export STP3_PARITY_REPORT=$out/parity.json STP3_PARITY_REPORT_STEP=$out/parity_step.json TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_planning_gpu.py tests/test_conv_gpu.py tests/test_prediction_gpu.py tests/test_modules_gpu.py tests/test_fused_ops_gpu.py -m gpu -q -p no:cacheprovider > $out/pytest_new.log 2>&1
+timeout 900 python -m pytest tests/test_datas_gpu.py tests/test_planning_gpu.py tests/test_conv_gpu.py tests/test_prediction_gpu.py tests/test_modules_gpu.py tests/test_fused_ops_gpu.py -m gpu -q -p no:cacheprovider > $out/pytest_new.log 2>&1
 echo "new tests rc=$?" | tee -a $out/pytest_new.log; grep -E "passed|failed|Error|assert" $out/pytest_new.log | tail -8
 if [ "$3" == "conv" ]; then timeout 300 python scripts/time_conv.py > $out/time_conv.log 2>&1; cut -c1-175 $out/time_conv.log; fi
-if [ "$3" == "plan" ] || [ "$3" == "conv" ]; then timeout 300 python scripts/time_plan.py 4 > $out/time_plan.log 2>&1; tail -4 $out/time_plan.log; fi
+if [ "$3" == "plan" ] || [ "$3" == "conv" ]; then timeout 300 python scripts/time_plan.py 4 > $out/time_plan.log 2>&1; tail -4 $out/time_plan.log
+  timeout 300 python scripts/time_image.py 4 > $out/time_image.log 2>&1; tail -4 $out/time_image.log; fi
 if [ "$3" == "lift" ]; then
   timeout 300 python scripts/time_lift.py 4 > $out/time_lift_c3.log 2>&1; tail -8 $out/time_lift_c3.log
   timeout 600 python scripts/time_lift.py 1 stress 5 > $out/time_lift_c5_b1.log 2>&1; tail -8 $out/time_lift_c5_b1.log

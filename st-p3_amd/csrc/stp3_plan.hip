@@ -157,8 +157,9 @@ __global__ __launch_bounds__(256) void traj_cost_kernel(PlanDims d, const float*
 }
 
 // d cost_volume[b, t, cell] = sum over the trajectories n that read the cell of g[b, n, t] * scale[b, n, t], in ascending n.
-// One workgroup per (t, b) plane: the plane's cells and weighted gradients sit in LDS, every trajectory scans the list,
-// the first reader of a cell adds up all of them and writes the cell.
+// The (t, b) plane's N (cell, weighted gradient) pairs sit in LDS; one THREAD per trajectory scans the list (all lanes read
+// the same entry: an LDS broadcast), and the first reader of a cell adds up all of them and writes the cell.  The plane
+// was zero-filled by the launcher; gridDim.z workgroups share the trajectories of a plane.
 __global__ __launch_bounds__(256) void traj_cost_bwd_kernel(PlanDims d, const float* __restrict__ g_fo,
                                                             const int* __restrict__ cv_cell,
                                                             const float* __restrict__ cv_scale,
@@ -167,26 +168,22 @@ __global__ __launch_bounds__(256) void traj_cost_bwd_kernel(PlanDims d, const fl
     int* cells = reinterpret_cast<int*>(smem);
     float* g = reinterpret_cast<float*>(smem) + d.N;
     const int t = blockIdx.x, b = blockIdx.y;
-    const int plane = d.H * d.W;
-    float* out = d_cost_volume + ((size_t)b * d.T + t) * plane;
-    for (int i = threadIdx.x; i < plane; i += 256) out[i] = 0.f;
+    float* out = d_cost_volume + ((size_t)b * d.T + t) * d.H * d.W;
     for (int n = threadIdx.x; n < d.N; n += 256) {
         const size_t i = ((size_t)b * d.N + n) * d.T + t;
         cells[n] = cv_cell[i];
         g[n] = g_fo[i] * cv_scale[i];
     }
     __syncthreads();
-    for (int n = threadIdx.x; n < d.N; n += 256) {
-        const int c = cells[n];
-        bool first = true;
-        for (int m = 0; m < n; ++m)
-            if (cells[m] == c) { first = false; break; }
-        if (!first) continue;
-        float s = g[n];
-        for (int m = n + 1; m < d.N; ++m)
-            if (cells[m] == c) s += g[m];
-        out[c] = s;
-    }
+    const int n = blockIdx.z * 256 + threadIdx.x;
+    if (n >= d.N) return;
+    const int c = cells[n];
+    for (int m = 0; m < n; ++m)
+        if (cells[m] == c) return;                         // an earlier trajectory owns this cell
+    float s = g[n];
+    for (int m = n + 1; m < d.N; ++m)
+        if (cells[m] == c) s += g[m];
+    out[c] = s;
 }
 
 bool valid(const stp3_plan_dims* p) {
@@ -232,12 +229,14 @@ int stp3_traj_cost_bwd(const stp3_plan_dims* p, const float* grad_cost_fo, const
                        float* grad_cost_volume, void* stream) {
     if (!valid(p) || !grad_cost_fo || !cv_cell || !cv_scale || !grad_cost_volume) return STP3_EINVAL;
     const size_t lds = (size_t)p->N * 8;
-    if (lds > 160 * 1024 || p->B > 65535) return STP3_EUNSUP;           // 20 480 trajectories per sample
+    if (lds > 160 * 1024 || p->B > 65535 || p->N > 65535 * 256) return STP3_EUNSUP;   // 20 480 trajectories per sample
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_cost_bwd_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return -(int)e;
-    hipLaunchKernelGGL(traj_cost_bwd_kernel, dim3(p->T, p->B), dim3(256), lds, (hipStream_t)stream, convert(p),
-                       grad_cost_fo, cv_cell, cv_scale, grad_cost_volume);
+    e = hipMemsetAsync(grad_cost_volume, 0, (size_t)p->B * p->T * p->H * p->W * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return -(int)e;
+    hipLaunchKernelGGL(traj_cost_bwd_kernel, dim3(p->T, p->B, (p->N + 255) / 256), dim3(256), lds, (hipStream_t)stream,
+                       convert(p), grad_cost_fo, cv_cell, cv_scale, grad_cost_volume);
     return status();
 }
 

@@ -100,6 +100,12 @@ class PlanDims(ctypes.Structure):
                                                'progress', 'volume', 'rule', 'w0', 'w1', 'headway_dist', 'lr_dist')])
 
 
+class ImageDims(ctypes.Structure):
+    """struct stp3_image_dims (include/stp3_hip.h)."""
+    _fields_ = ([(k, ctypes.c_int32) for k in ('N', 'H', 'W', 'Wr', 'Hr', 'left', 'top', 'Wo', 'Ho', 'ksize_h', 'ksize_v',
+                                               'out_dtype')] + [('mean', ctypes.c_float * 3), ('std', ctypes.c_float * 3)])
+
+
 class OptimBucket(ctypes.Structure):
     """struct stp3_optim_bucket (include/stp3_hip.h)."""
     _fields_ = [('grad', ctypes.c_void_p), ('param', ctypes.c_void_p), ('exp_avg', ctypes.c_void_p),
@@ -190,6 +196,9 @@ SIGNATURES = {
     'stp3_warp_nearest': (c_int, [c_int32] * 4 + [c_void_p] * 5),
     'stp3_traj_cost_fwd': (c_int, [ctypes.POINTER(PlanDims)] + [c_void_p] * 14),
     'stp3_traj_cost_bwd': (c_int, [ctypes.POINTER(PlanDims)] + [c_void_p] * 5),
+    'stp3_image_prep_rows_per_workgroup': (c_int, []),
+    'stp3_image_prep_lds_bytes': (c_int, [ctypes.POINTER(ImageDims), c_int32, ctypes.POINTER(c_size_t)]),
+    'stp3_image_prep': (c_int, [ctypes.POINTER(ImageDims)] + [c_void_p] * 5 + [c_int32, c_void_p, c_void_p]),
     'stp3_voxels_sum_fwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     'stp3_voxels_sum_bwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
 }

@@ -246,3 +246,17 @@ def planning_metric_trajs(cfg, batch=2):
     expert = plan.clone()
     expert[0, :, 0] = 6.0
     return plan, expert
+
+
+def image_bytes(shape, seed):
+    """Deterministic pseudo-random uint8 image batch with some low-frequency structure (exact integer arithmetic)."""
+    n = 1
+    for s in shape:
+        n *= s
+    idx = torch.arange(n, dtype=torch.int64)
+    noise = ((idx * 1103515245 + seed * 12345 + 7) % 2147483648) >> 16
+    *_, h, w, c = shape
+    y = (idx // (w * c)) % h
+    x = (idx // c) % w
+    v = (noise % 97 + (x * 3 + y * 5 + (idx % c) * 40) % 160) % 256
+    return v.to(torch.uint8).view(shape).numpy()

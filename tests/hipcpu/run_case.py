@@ -643,6 +643,29 @@ def plan(ops):
     return out
 
 
+def image_prep(ops):
+    """csrc/stp3_image.hip through stp3_amd.datas.ImagePreprocessor (GPU route) against the torch statements of the same
+    module (CPU route; byte-exact with Pillow, tests/test_datas_cpu.py): float32 and bf16 output, a crop inside the
+    resized image and one that is padded with zeros, up- and down-scaling, a source row length that is not a multiple of
+    16 bytes."""
+    from stp3_amd.datas import ImagePreprocessor
+    from tests import helpers as H
+    is_cuda = torch.Tensor.is_cuda
+    out = {}
+    cases = {'down': ((3, 90, 160, 3), (48, 27), (2, 5, 46, 25)), 'padded': ((3, 90, 160, 3), (48, 27), (-3, 5, 51, 30)),
+             'up_odd': ((2, 37, 53, 3), (70, 50), (3, 2, 64, 45)), 'mixed': ((1, 64, 21, 3), (40, 20), (0, 0, 40, 20))}
+    for name, (shape, resize_dims, crop) in cases.items():
+        images = torch.from_numpy(H.image_bytes(shape, 420 + len(name)))
+        prep = ImagePreprocessor(resize_dims=resize_dims, crop=crop, source_hw=shape[1:3])
+        torch.Tensor.is_cuda = is_cuda
+        y32, y16 = prep(images), prep(images, out_dtype=torch.bfloat16)
+        torch.Tensor.is_cuda = property(lambda self: False)
+        ref = prep(images)
+        torch.Tensor.is_cuda = is_cuda
+        out[name] = {'f32_mismatches': int((y32 != ref).sum()), 'bf16_mismatches': int((y16 != ref.to(torch.bfloat16)).sum())}
+    return out
+
+
 def conv_bn(ops):
     """conv -> BatchNorm -> act (+ skip / drop-connect) as ONE operator (conv v2 with the statistics in its epilogue)
     against the two separate operators, and both against float32 torch on the same bf16-representable data."""
@@ -976,7 +999,7 @@ def fuzz(ops, seed=1):
 
 
 CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_frames, lift_coarse_grid, lift_tall, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
-                                 conv, dwconv, mbconv_mid, losses, plan)}
+                                 conv, dwconv, mbconv_mid, losses, plan, image_prep)}
 
 if __name__ == '__main__':
     ops_mod = setup(sys.argv[1])

@@ -28,9 +28,9 @@ import build as hipcpu_build  # noqa: E402
 
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
 ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
-           ('conv', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
+           ('conv', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
            ('lift_c64_frames', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
-ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'mbconv_mid', 'losses', 'plan', 'lift_c16']
+ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)]
 MODEL = [('lift_full', {}), ('model_step_two_ranks', {}), ('model_step_f32_full_losses', {}), ('model_step_f32', {}),
          ('model_step_bf16_bn_eval', {})]        # whole training steps: minutes, STP3_SLOW_TESTS=1
@@ -158,6 +158,16 @@ def test_planner_cost_kernels(results):
             if form == 'seconds':
                 continue
             assert e['cost_fc'] <= 2e-5 and e['cost_fo'] <= 2e-5 and e['d_cost_volume'] <= 1e-6, (form, e)
+
+
+def test_image_preprocessing_kernel(results):
+    """csrc/stp3_image.hip (Pillow's two-pass bilinear resize in its fixed point + crop + ToTensor + Normalize) against the
+    torch statements of stp3_amd.datas -- byte-exact with Pillow itself (tests/test_datas_cpu.py): not one differing
+    element, float32 and bf16, under all three fiber orders."""
+    for env in ({}, REVERSE, RANDOM):
+        for name, r in _get(results, 'image_prep', env).items():
+            if name != 'seconds':
+                assert r == {'f32_mismatches': 0, 'bf16_mismatches': 0}, (name, r)
 
 
 def test_loss_and_label_warp_kernels(results):
