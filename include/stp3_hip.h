@@ -611,8 +611,8 @@ int stp3_traj_cost_bwd(const stp3_plan_dims* dims, const float* grad_cost_fo, co
  *            the host exactly as Pillow builds them (stp3_amd.datas.pil_bilinear_coefficients); configuration-only.
  *   out      [N][3][Ho][Wo] float32 or bf16 = ((byte / 255) - mean[c]) / std[c], byte = the resized image at
  *            (top + r, left + x); window positions outside the resized image are PIL's zero padding.
- *   strip_rows: the largest number of source rows the vertical taps of 8 consecutive output rows span (host: from
- *            bounds_v; stp3_image_prep_rows_per_workgroup() returns the 8); sizes the LDS strip.
+ *   strip_rows: the largest number of source rows the vertical taps of the output rows of one workgroup span (host:
+ *            from bounds_v; stp3_image_prep_rows_per_workgroup() returns how many rows that is); sizes the LDS strip.
  * The resized bytes equal PIL.Image.resize(..., BILINEAR) bit for bit (both passes, byte rounding between them). */
 typedef struct stp3_image_dims {
     int32_t N, H, W;              /* source */

@@ -21,7 +21,9 @@
 namespace {
 
 constexpr int kPrecision = 22;          // Pillow: PRECISION_BITS = 32 - 8 - 2
-constexpr int kRows = 8;                // output rows per workgroup
+constexpr int kRows = 4;                // output rows per workgroup
+constexpr int kChunk = 4;               // source rows staged per iteration
+constexpr int kPre = 5;                 // 16-byte pieces per thread of the chunk in flight (4 x 4 800 bytes: 1 200 pieces)
 
 struct ImageDims {
     int N, H, W, Wr, Hr, left, top, Wo, Ho, ksize_h, ksize_v, out_bf16, strip_rows;
@@ -37,8 +39,13 @@ __global__ __launch_bounds__(256) void image_prep_kernel(ImageDims d, const uint
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int row_bytes = d.W * 3;
     const int row_pitch = (row_bytes + 15) & ~15;
-    uint8_t* rowbuf = smem;                                // one input row
-    uint8_t* strip = smem + row_pitch;                     // [strip_rows][Wo * 3] horizontally resampled bytes
+    uint8_t* rowbuf = smem;                                // kChunk input rows
+    uint8_t* strip = smem + kChunk * row_pitch;            // [strip_rows][Wo * 3] horizontally resampled bytes
+    // the horizontal coefficients of the window's columns, [Wo][ksize_h] + (first source column, count): read once per
+    // workgroup -- fetched per tap from global memory they made the kernel bound by its vector-memory issue rate
+    const int kstride = d.ksize_h <= 9 ? 12 : d.ksize_h;    // <= 9 taps: rows padded to 48 bytes for 16-byte reads
+    int* ck = reinterpret_cast<int*>(strip + ((d.strip_rows * d.Wo * 3 + 15) & ~15));
+    int* cb = ck + d.Wo * kstride;
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * kRows, n = blockIdx.y;
     const int rows = min(kRows, d.Ho - r0);
@@ -54,32 +61,85 @@ __global__ __launch_bounds__(256) void image_prep_kernel(ImageDims d, const uint
     const uint8_t* img = images + (size_t)n * d.H * row_bytes;
     const int strip_pitch = d.Wo * 3;
     const bool vec = (row_bytes & 15) == 0 && ((uintptr_t)img & 15) == 0;
-    for (int y = y0; y < y1; ++y) {
-        const uint8_t* src = img + (size_t)y * row_bytes;
-        if (vec) {
-            for (int i = tid; i < row_bytes / 16; i += 256)
-                reinterpret_cast<uint4*>(rowbuf)[i] = reinterpret_cast<const uint4*>(src)[i];
+    // kChunk source rows at a time: the 16-byte pieces of the NEXT chunk are in flight (registers) while the horizontal
+    // pass of the current one runs from LDS -- one row per iteration was latency-bound (0.08 of the HBM rate)
+    const int pieces = row_pitch / 16;                     // per row
+    uint4 pre[kPre];
+    auto fetch = [&](int yc) {                             // pieces tid, tid + 256, ... of the chunk starting at row yc
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {
+            const int i = tid + 256 * j;
+            const int rr = i / pieces, pp = i - rr * pieces;
+            pre[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (rr < kChunk && yc + rr < y1) pre[j] = reinterpret_cast<const uint4*>(img + (size_t)(yc + rr) * row_bytes)[pp];
+        }
+    };
+    const bool staged = vec && kChunk * pieces <= 256 * kPre;
+    if (staged && y0 < y1) fetch(y0);
+    for (int i = tid; i < d.Wo; i += 256) {
+        const int xr = d.left + i;
+        const bool in = xr >= 0 && xr < d.Wr;
+        cb[2 * i] = in ? bounds_h[2 * xr] : 0;
+        cb[2 * i + 1] = in ? bounds_h[2 * xr + 1] : 0;     // outside the resized image: no taps, the byte stays 0
+        for (int t = 0; t < kstride; ++t) ck[i * kstride + t] = (in && t < d.ksize_h) ? kk_h[xr * d.ksize_h + t] : 0;
+    }
+    for (int yc = y0; yc < y1; yc += kChunk) {
+        const int nrows = min(kChunk, y1 - yc);
+        if (staged) {
+#pragma unroll
+            for (int j = 0; j < kPre; ++j) {
+                const int i = tid + 256 * j;
+                if (i < kChunk * pieces) reinterpret_cast<uint4*>(rowbuf)[i] = pre[j];
+            }
+            if (yc + kChunk < y1) fetch(yc + kChunk);
         } else {
-            for (int i = tid; i < row_bytes; i += 256) rowbuf[i] = src[i];
+            for (int rr = 0; rr < nrows; ++rr)
+                for (int i = tid; i < row_bytes; i += 256) rowbuf[rr * row_pitch + i] = img[(size_t)(yc + rr) * row_bytes + i];
         }
         __syncthreads();
-        uint8_t* dst = strip + (y - y0) * strip_pitch;
-        for (int i = tid; i < strip_pitch; i += 256) {
-            const int x = i / 3, c = i - 3 * x;
-            const int xr = d.left + x;
-            int v = 0;
-            if (xr >= 0 && xr < d.Wr) {
-                const int lo = bounds_h[2 * xr], cnt = bounds_h[2 * xr + 1];
-                const int* k = kk_h + xr * d.ksize_h;
-                int ss = 1 << (kPrecision - 1);
-                for (int t = 0; t < cnt; ++t) ss += (int)rowbuf[(lo + t) * 3 + c] * k[t];
-                v = clip8(ss);
+        for (int i = tid; i < nrows * d.Wo; i += 256) {     // one thread per (row, column): the three channels share the taps
+            const int rr = i / d.Wo, x = i - rr * d.Wo;
+            const int lo = cb[2 * x], cnt = cb[2 * x + 1];
+            const int* k = ck + x * kstride;
+            int s0 = 1 << (kPrecision - 1), s1 = s0, s2 = s0;
+            if (kstride == 12) {
+                // up to nine taps = 27 consecutive bytes: EIGHT dword reads, realigned to the first byte with funnel shifts,
+                // instead of 27 byte reads (the kernel was bound by its LDS instruction count); the coefficients as three
+                // 16-byte reads.  Taps beyond `cnt` have coefficient 0; their bytes lie inside the staging buffer.
+                const int addr = rr * row_pitch + lo * 3;
+                const int sh = (addr & 3) * 8;
+                const uint32_t* wp = reinterpret_cast<const uint32_t*>(rowbuf + (addr & ~3));
+                uint32_t w[8], v[7];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[j] = wp[j];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) v[j] = (uint32_t)(((((uint64_t)w[j + 1]) << 32) | w[j]) >> sh);
+                const uint4 ka = reinterpret_cast<const uint4*>(k)[0], kb = reinterpret_cast<const uint4*>(k)[1];
+                const int kc = k[8];
+                const int kw[9] = {(int)ka.x, (int)ka.y, (int)ka.z, (int)ka.w, (int)kb.x, (int)kb.y, (int)kb.z, (int)kb.w, kc};
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int b0 = 3 * t, b1 = 3 * t + 1, b2 = 3 * t + 2;
+                    s0 += (int)((v[b0 >> 2] >> (8 * (b0 & 3))) & 0xffu) * kw[t];
+                    s1 += (int)((v[b1 >> 2] >> (8 * (b1 & 3))) & 0xffu) * kw[t];
+                    s2 += (int)((v[b2 >> 2] >> (8 * (b2 & 3))) & 0xffu) * kw[t];
+                }
+            } else {
+                const uint8_t* src = rowbuf + rr * row_pitch + lo * 3;
+                for (int t = 0; t < cnt; ++t) {
+                    const int w = k[t];
+                    s0 += (int)src[3 * t] * w;
+                    s1 += (int)src[3 * t + 1] * w;
+                    s2 += (int)src[3 * t + 2] * w;
+                }
             }
-            dst[i] = (uint8_t)v;
+            uint8_t* dst = strip + (yc - y0 + rr) * strip_pitch + 3 * x;
+            dst[0] = cnt ? (uint8_t)clip8(s0) : 0;
+            dst[1] = cnt ? (uint8_t)clip8(s1) : 0;
+            dst[2] = cnt ? (uint8_t)clip8(s2) : 0;
         }
         __syncthreads();
     }
-    if (y0 >= y1) __syncthreads();
     // vertical pass + ToTensor + Normalize; planar output, x fastest
     const int per_plane = rows * d.Wo;
     for (int i = tid; i < 3 * per_plane; i += 256) {
@@ -110,7 +170,8 @@ extern "C" {
 
 int stp3_image_prep_lds_bytes(const stp3_image_dims* p, int32_t strip_rows, size_t* bytes) {
     if (!p || !bytes || strip_rows < 0) return STP3_EINVAL;
-    *bytes = (size_t)((p->W * 3 + 15) & ~15) + (size_t)strip_rows * p->Wo * 3;
+    *bytes = (size_t)4 * ((p->W * 3 + 15) & ~15) + (((size_t)strip_rows * p->Wo * 3 + 15) & ~(size_t)15) +     // 4 = kChunk
+             (size_t)p->Wo * ((p->ksize_h <= 9 ? 12 : p->ksize_h) + 2) * sizeof(int32_t);
     return STP3_OK;
 }
 
@@ -124,7 +185,7 @@ int stp3_image_prep(const stp3_image_dims* p, const uint8_t* images, const int32
     if (p->N > 65535 || (int64_t)p->N * p->H * p->W * 3 >= (1LL << 40)) return STP3_EUNSUP;
     size_t lds = 0;
     stp3_image_prep_lds_bytes(p, strip_rows, &lds);
-    if (lds > 160 * 1024) return STP3_EUNSUP;              // (a 1600 x 900 source at scale 0.3: 57 KB)
+    if (lds > 160 * 1024) return STP3_EUNSUP;              // (a 1600 x 900 source at scale 0.3: 78 KB)
     ImageDims d;
     d.N = p->N; d.H = p->H; d.W = p->W; d.Wr = p->Wr; d.Hr = p->Hr; d.left = p->left; d.top = p->top; d.Wo = p->Wo;
     d.Ho = p->Ho; d.ksize_h = p->ksize_h; d.ksize_v = p->ksize_v; d.out_bf16 = p->out_dtype == STP3_DTYPE_BF16;

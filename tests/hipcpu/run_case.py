@@ -646,14 +646,15 @@ def plan(ops):
 def image_prep(ops):
     """csrc/stp3_image.hip through stp3_amd.datas.ImagePreprocessor (GPU route) against the torch statements of the same
     module (CPU route; byte-exact with Pillow, tests/test_datas_cpu.py): float32 and bf16 output, a crop inside the
-    resized image and one that is padded with zeros, up- and down-scaling, a source row length that is not a multiple of
-    16 bytes."""
+    resized image and one that is padded with zeros, up- and down-scaling (<= 9 taps: the dword path; 11 taps: the generic
+    one), a source row length that is not a multiple of 16 bytes."""
     from stp3_amd.datas import ImagePreprocessor
     from tests import helpers as H
     is_cuda = torch.Tensor.is_cuda
     out = {}
     cases = {'down': ((3, 90, 160, 3), (48, 27), (2, 5, 46, 25)), 'padded': ((3, 90, 160, 3), (48, 27), (-3, 5, 51, 30)),
-             'up_odd': ((2, 37, 53, 3), (70, 50), (3, 2, 64, 45)), 'mixed': ((1, 64, 21, 3), (40, 20), (0, 0, 40, 20))}
+             'up_odd': ((2, 37, 53, 3), (70, 50), (3, 2, 64, 45)), 'mixed': ((1, 64, 21, 3), (40, 20), (0, 0, 40, 20)),
+             'down5_generic_taps': ((1, 50, 200, 3), (40, 10), (1, 0, 39, 10))}
     for name, (shape, resize_dims, crop) in cases.items():
         images = torch.from_numpy(H.image_bytes(shape, 420 + len(name)))
         prep = ImagePreprocessor(resize_dims=resize_dims, crop=crop, source_hw=shape[1:3])
