@@ -15,7 +15,8 @@ import torch.nn as nn
 
 from .. import ops
 from ..utils import hp
-from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, conv1x1_on_vector, conv2d, conv_module, plane_mean, run_fused
+from .fused import (ACT_NONE, ACT_RELU, RES_AFTER_ACT, _sync_world, bn_act, bn_act_group, conv1x1_on_vector, conv2d,
+                    conv_bn_act_member, conv_module, plane_mean, run_fused)
 
 
 def _conv_bn_relu(in_ch, out_ch, k, padding=0, dilation=1):
@@ -75,20 +76,22 @@ class ASPPConv(nn.Sequential):
                          nn.BatchNorm2d(out_channels), nn.ReLU())
         self.dilation = dilation
 
-    def forward(self, x):
-        conv, bn, act = self[0], self[1], self[2]
+    def conv_only(self, x):
+        """The convolution of the branch, with the taps that can never be in range dropped (exact)."""
+        conv = self[0]
         h, w = x.shape[-2:]
         d = self.dilation
         wgt = conv.weight
         if d >= h and d >= w:                       # only the centre tap can ever be in range
-            y = conv2d(x, wgt[:, :, 1:2, 1:2])
-        elif d >= h:                                # centre row only: 1x3
-            y = conv2d(x, wgt[:, :, 1:2, :], padding=(0, d), dilation=(1, d))
-        elif d >= w:                                # centre column only: 3x1
-            y = conv2d(x, wgt[:, :, :, 1:2], padding=(d, 0), dilation=(d, 1))
-        else:
-            y = conv_module(conv, x)
-        return bn_act(bn, y, ACT_RELU)
+            return conv2d(x, wgt[:, :, 1:2, 1:2])
+        if d >= h:                                  # centre row only: 1x3
+            return conv2d(x, wgt[:, :, 1:2, :], padding=(0, d), dilation=(1, d))
+        if d >= w:                                  # centre column only: 3x1
+            return conv2d(x, wgt[:, :, :, 1:2], padding=(d, 0), dilation=(d, 1))
+        return conv_module(conv, x)
+
+    def forward(self, x):
+        return bn_act(self[1], self.conv_only(x), ACT_RELU)
 
 
 class ASPPPooling(nn.Sequential):
@@ -98,13 +101,16 @@ class ASPPPooling(nn.Sequential):
         super().__init__(nn.AdaptiveAvgPool2d(1), nn.Conv2d(in_channels, out_channels, 1, bias=False),
                          nn.BatchNorm2d(out_channels), nn.ReLU())
 
+    def conv_only(self, x):
+        pool, conv, _, _ = self
+        # the global average through fused.plane_mean: same value as AdaptiveAvgPool2d(1), gradient in the layout of x
+        pooled = plane_mean(x).to(x.dtype)[:, :, None, None] if x.is_cuda else pool(x)
+        return conv_module(conv, pooled)            # 1x1 map: a GEMM
+
     def forward(self, x):
         """Returns the (N, C, 1, 1) pooled descriptor; bilinear upsampling of a 1x1 map is a
         broadcast, which ``ASPP`` folds into its projection."""
-        pool, conv, bn, _ = self
-        # the global average through fused.plane_mean: same value as AdaptiveAvgPool2d(1), gradient in the layout of x
-        pooled = plane_mean(x).to(x.dtype)[:, :, None, None] if x.is_cuda else pool(x)
-        return bn_act(bn, conv_module(conv, pooled), ACT_RELU)   # 1x1 map: GEMM + the fused BatchNorm on N vectors
+        return bn_act(self[2], self.conv_only(x), ACT_RELU)   # the fused BatchNorm on N vectors
 
 
 class ASPP(nn.Module):
@@ -119,9 +125,16 @@ class ASPP(nn.Module):
                                      nn.BatchNorm2d(out_channels), nn.ReLU(), nn.Dropout(0.5))
 
     def forward(self, x):
-        branches = [run_fused(self.convs[0], x)] + [conv(x) for conv in self.convs[1:-1]]
+        if _sync_world(self.convs[0][1]) > 1:
+            # N > 1 ranks: the five branches are siblings -- their BatchNorm statistics travel in ONE exchange per pass
+            members = [conv_bn_act_member(x, self.convs[0][0], self.convs[0][1], ACT_RELU)]
+            members += [dict(bn=conv[1], x=conv.conv_only(x), act=ACT_RELU) for conv in self.convs[1:-1]]
+            members.append(dict(bn=self.convs[-1][2], x=self.convs[-1].conv_only(x), act=ACT_RELU))
+            *branches, pooled = bn_act_group(members)
+        else:
+            branches = [run_fused(self.convs[0], x)] + [conv(x) for conv in self.convs[1:-1]]
+            pooled = self.convs[-1](x)                               # (N, C, 1, 1)
         spatial = torch.cat(branches, dim=1)
-        pooled = self.convs[-1](x)                                   # (N, C, 1, 1)
         proj, bn, act, drop = self.project
         n_sp = spatial.shape[1]
         y = conv2d(spatial, proj.weight[:, :n_sp])

@@ -42,12 +42,9 @@ def _act(act, y):
     return y
 
 
-def bn_act_reference(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=None):
-    """Plain-torch statement of ``bn_act`` (any device, any rank count; differentiable)."""
-    c = bn.num_features
-    if x.shape[1] != c:                             # zero-padded channel lanes (see ``bn_act``)
-        y = bn_act_reference(bn, x[:, :c], act, None if res is None else res[:, :c], res_mode, sbias, oscale)
-        return F.pad(y, [0, 0] * (x.dim() - 2) + [0, x.shape[1] - c])
+def _bn_act_reference_steps(bn, x, act, res, res_mode, sbias, oscale):
+    """The plain-torch statement as a generator: yields the packed local [sum | sum of squares] when the statistics are
+    shared between replicas and is sent back their (differentiable) sum over the replicas."""
     shape = [1, -1] + [1] * (x.dim() - 2)
     lead = [x.shape[0], -1] + [1] * (x.dim() - 2)
     if sbias is not None:
@@ -59,8 +56,7 @@ def bn_act_reference(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=Non
         count = float(xf.numel() // xf.shape[1])
         s, q = xf.sum(dims), (xf * xf).sum(dims)
         if _sync_world(bn) > 1:
-            import torch.distributed.nn.functional as dfn
-            packed = dfn.all_reduce(torch.cat([s, q]))
+            packed = yield torch.cat([s, q])
             s, q = packed[:s.numel()], packed[s.numel():]
             count *= dist.get_world_size()
         mean = s / count
@@ -90,6 +86,41 @@ def bn_act_reference(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=Non
     return y
 
 
+def _reference_member(bn, x, act, res, res_mode, sbias, oscale):
+    """(generator, finish) of one statement-route member; zero-padded channel lanes are cut off / put back around it."""
+    c = bn.num_features
+    lanes = x.shape[1]
+    if lanes != c:                                  # zero-padded channel lanes (see ``bn_act``)
+        x, res = x[:, :c], None if res is None else res[:, :c]
+    gen = _bn_act_reference_steps(bn, x, act, res, res_mode, sbias, oscale)
+    return gen, (lambda y: y if lanes == c else F.pad(y, [0, 0] * (y.dim() - 2) + [0, lanes - c]))
+
+
+def _drive_reference(members):
+    """Run statement-route members with ONE (autograd-aware) all-reduce for all that ask for an exchange."""
+    import torch.distributed.nn.functional as dfn
+    waiting, outs = [], [None] * len(members)
+    for i, (gen, finish) in enumerate(members):
+        try:
+            waiting.append((i, gen, finish, next(gen)))
+        except StopIteration as done:
+            outs[i] = finish(done.value)
+    if waiting:
+        packed = dfn.all_reduce(torch.cat([w[3] for w in waiting]) if len(waiting) > 1 else waiting[0][3])
+        for (i, gen, finish, buf), part in zip(waiting, packed.split([w[3].numel() for w in waiting])):
+            try:
+                gen.send(part)
+                raise RuntimeError('a second exchange in one BatchNorm statement')
+            except StopIteration as done:
+                outs[i] = finish(done.value)
+    return outs
+
+
+def bn_act_reference(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=None):
+    """Plain-torch statement of ``bn_act`` (any device, any rank count; differentiable)."""
+    return _drive_reference([_reference_member(bn, x, act, res, res_mode, sbias, oscale)])[0]
+
+
 flush_batch_counters = ops.flush_batch_counters          # re-export (parallel.FlatAdam, tests)
 
 
@@ -113,20 +144,87 @@ def bn_act(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=
         b, c, t = x.shape[:3]
         y = bn_act(bn, x.permute(0, 2, 1, 3, 4).reshape(b * t, c, 1, 1), act)
         return y.view(b, t, c, 1, 1).permute(0, 2, 1, 3, 4)
-    if not (x.is_cuda and x.dim() == 4) or x.dtype == torch.float64:
+    args = _kernel_args(bn, x, act, res, res_mode, sbias, oscale)
+    if args is None:
         # CPU tensors, and float64 on any device: the library has float32 / bf16 kernels only; a float64 evaluation (the
         # noise-free truth of the parity tests) takes the torch statement
         return bn_act_reference(bn, x, act, res, res_mode, sbias, oscale)
+    x, weight, bias, res, sbias, oscale, rmean, rvar, training, momentum, eps, act, res_mode, group, channels = args
+    return ops.bn_act(x, weight, bias, rmean, rvar, training, momentum, eps, act=act, res=res, res_mode=res_mode, sbias=sbias,
+                      oscale=oscale, group=group, channels=channels)
+
+
+def _kernel_args(bn, x, act, res, res_mode, sbias, oscale):
+    """Positional arguments of ``ops._BnAct`` for this layer, or None when the tensor takes the statement route."""
+    if not (x.is_cuda and x.dim() == 4) or x.dtype == torch.float64:
+        return None
     if torch.is_autocast_enabled() and x.dtype == torch.float32:
         x = x.to(torch.get_autocast_dtype('cuda'))
     training = bn.training or not bn.track_running_stats
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         ops.bump_batch_counter(bn)
     group = None if _sync_world(bn) > 1 else False
-    return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
-                      bn.running_var if bn.track_running_stats else None, training, bn.momentum, bn.eps,
-                      act=act, res=res, res_mode=res_mode, sbias=sbias, oscale=oscale, group=group,
-                      channels=bn.num_features if x.shape[1] != bn.num_features else None)
+    if res is None:
+        res_mode = RES_NONE
+    return (x, bn.weight, bn.bias, res, sbias, oscale, bn.running_mean if bn.track_running_stats else None,
+            bn.running_var if bn.track_running_stats else None, bool(training),
+            float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps), int(act), int(res_mode), group,
+            bn.num_features if x.shape[1] != bn.num_features else None)
+
+
+def bn_act_group(items):
+    """``bn_act`` for SIBLING layers -- parallel branches whose inputs do not depend on each other's outputs: with
+    cross-replica statistics (N > 1 ranks) their exchanges travel together, one all-reduce forward and one backward for
+    the whole group (``ops_fused._ExchangeGroup``; the statement route batches the same way).  ``items``: dicts with the
+    keyword arguments of ``bn_act`` (bn, x, act, res, res_mode, sbias, oscale); a member may also be a
+    ('conv_bn_act', args) pair prepared by ``conv_bn_act_member``.  Single-process runs take the ordinary operators."""
+    def norm(it):
+        return (it['bn'], it['x'], it.get('act', ACT_NONE), it.get('res'), it.get('res_mode', RES_NONE) if it.get('res') is not None
+                else RES_NONE, it.get('sbias'), it.get('oscale'))
+    first = items[0]
+    bn0 = first['bn'] if isinstance(first, dict) else first[2]
+    if _sync_world(bn0) <= 1:
+        return [_run_member(it) for it in items]
+    if all(isinstance(it, dict) and _takes_statement(it['x']) for it in items):
+        return _drive_reference([_reference_member(*norm(it)) for it in items])
+    from .. import ops_fused
+    members = []
+    for it in items:
+        if isinstance(it, dict):
+            args = _kernel_args(*norm(it))
+            if args is None:
+                raise ops._lib.Stp3HipError('bn_act_group: members on the kernels and on the statement route cannot share an exchange')
+            members.append(('bn_act', args))
+        else:
+            members.append((it[0], it[1]))
+    return ops_fused.exchange_group(members)
+
+
+def _takes_statement(x):
+    return not (x.is_cuda and x.dim() == 4) or x.dtype == torch.float64
+
+
+def _run_member(it):
+    if isinstance(it, dict):
+        return bn_act(it['bn'], it['x'], it.get('act', ACT_NONE), it.get('res'), it.get('res_mode', RES_NONE), it.get('sbias'),
+                      it.get('oscale'))
+    from .. import ops_fused
+    return ops_fused._ConvBnAct.apply(*it[1])
+
+
+def conv_bn_act_member(x, conv, bn, act):
+    """A conv -> BatchNorm -> activation layer as a member of ``bn_act_group``: the fused operator when the layer
+    qualifies (``_fusable_conv_bn``), otherwise the convolution now and its BatchNorm as the member."""
+    if _fusable_conv_bn(conv, bn, x):
+        from .. import ops_fused
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            ops.bump_batch_counter(bn)
+        group = None if _sync_world(bn) > 1 else False
+        return ('conv_bn_act', (x, conv.weight, conv.bias, bn.weight, bn.bias, None, bn.running_mean, bn.running_var,
+                                float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps), int(act),
+                                int(RES_NONE), ops._pair(conv.stride)[0], ops._pair(conv.padding), ops._pair(conv.dilation),
+                                group, None), bn)
+    return dict(bn=bn, x=conv_module(conv, x), act=act)
 
 
 # Dense convolutions.  Every bf16 (autocast) convolution on the GPU -- forward, data gradient and weight gradient, all

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..utils import hp
-from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, conv1x1_on_vector, conv2d, plane_mean
+from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, bn_act_group, conv1x1_on_vector, conv2d, plane_mean
 
 
 def _pad8(c):
@@ -208,8 +208,9 @@ class TemporalBlock(nn.Module):
             self.projection = None
 
     @staticmethod
-    def _pointwise(seq, x2, relu=True, extra2=None, lanes=None):
-        """conv_1x1x1_norm_activated (or projection) on the frame-folded tensor: a 1x1 2-D convolution.
+    def _pointwise_member(seq, x2, relu=True, extra2=None, lanes=None):
+        """conv_1x1x1_norm_activated (or projection) on the frame-folded tensor: a 1x1 2-D convolution, returned as the
+        arguments of its BatchNorm (``fused.bn_act`` / ``bn_act_group``).
         ``extra2`` (B*T, E): input channels that are constant over the plane -- their part of the 1x1 convolution is
         a per-frame bias, W[:, C:] @ extra, added inside the fused BatchNorm (exact; no concatenated tensor).
         ``lanes``: output channel lanes (>= the layer's channels; the extra ones come out zero, see ``_pad_out``)."""
@@ -218,10 +219,13 @@ class TemporalBlock(nn.Module):
         c = x2.shape[1]
         w_x = wgt if extra2 is None else wgt[:, :c]
         y = _conv2d_padded_channels(x2, w_x if lanes is None else _pad_out(w_x, lanes))
-        if extra2 is None:
-            return _bn_act_2d(norm, y, relu)
-        sbias = hp(extra2).to(hp(wgt).dtype) @ hp(wgt[:, c:, 0, 0]).t()
-        return _bn_act_2d(norm, y, relu, sbias=sbias)
+        sbias = None if extra2 is None else hp(extra2).to(hp(wgt).dtype) @ hp(wgt[:, c:, 0, 0]).t()
+        return dict(bn=norm, x=y, act=ACT_RELU if relu else ACT_NONE, sbias=sbias)
+
+    @staticmethod
+    def _pointwise(seq, x2, relu=True, extra2=None, lanes=None):
+        m = TemporalBlock._pointwise_member(seq, x2, relu, extra2, lanes)
+        return _bn_act_2d(m['bn'], m['x'], relu, sbias=m['sbias'])
 
     def forward(self, x, extra=None):
         """x (B, C, T, H, W) -> (B, C', T, H, W).  Everything runs frame-folded as 2-D ops on
@@ -241,11 +245,15 @@ class TemporalBlock(nn.Module):
                 x2 = x2.to(torch.get_autocast_dtype('cuda'))
         # the half_channels-wide paths run in lanes of 8 channels on the GPU (see ``_pad_out``)
         lanes = _pad8(self.half_channels) if x2.is_cuda else self.half_channels
-        outs = []
-        for path in self.convolution_paths[:-1]:
-            y = self._pointwise(path[0], x2, extra2=extra2, lanes=lanes)
-            outs.append(path[1].forward_folded(y, b, t))
-        outs.append(self._pointwise(self.convolution_paths[-1], x2, extra2=extra2, lanes=lanes))
+        # the pointwise convolutions at the head of the block (two paths, the third path, the skip projection) are
+        # siblings: one BatchNorm statistics exchange for all of them when the statistics are shared between ranks
+        heads = [self._pointwise_member(path[0], x2, extra2=extra2, lanes=lanes) for path in self.convolution_paths[:-1]]
+        heads.append(self._pointwise_member(self.convolution_paths[-1], x2, extra2=extra2, lanes=lanes))
+        if self.projection is not None:
+            heads.append(self._pointwise_member(self.projection, x2, relu=False, extra2=extra2))
+        heads = bn_act_group(heads)
+        outs = [path[1].forward_folded(y, b, t) for path, y in zip(self.convolution_paths[:-1], heads)]
+        outs.append(heads[len(self.convolution_paths) - 1])
         paths = torch.cat(outs, dim=1)
         agg = self.aggregation[0]
         wgt = agg.conv.weight[:, :, 0]                                   # (Cout, Cin_total, 1, 1)
@@ -269,7 +277,7 @@ class TemporalBlock(nn.Module):
                     y = y + contrib
                 off += cp
         assert self.projection is not None or extra is None
-        skip = x2 if self.projection is None else self._pointwise(self.projection, x2, relu=False, extra2=extra2)
+        skip = x2 if self.projection is None else heads[-1]
         out = _bn_act_2d(agg.norm, y, res=skip, sbias=sbias)
         return out.view(b, t, -1, h, w).permute(0, 2, 1, 3, 4)
 

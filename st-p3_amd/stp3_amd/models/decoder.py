@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from ..layers.convolutions import UpsamplingAdd
-from ..layers.fused import ACT_RELU, bn_act, conv_module, run_fused
+from ..layers.fused import ACT_RELU, _sync_world, bn_act, bn_act_group, conv_bn_act_member, conv_module, run_fused
 from .resnet import resnet18
 
 
@@ -90,12 +90,30 @@ class Decoder(nn.Module):
             return None if t is None else t.view(b, s, *t.shape[1:])
 
         present = _SelectFrame.apply(x, b, s, self.n_present - 1)      # decoder.py:122
+        heads = [('segmentation', self.segmentation_head, x)]
+        if self.predict_pedestrian:
+            heads.append(('pedestrian', self.pedestrian_head, x))
+        if self.perceive_hdmap:
+            heads.append(('hdmap', self.hdmap_head, present))
+        if self.predict_instance:
+            heads += [('instance_center', self.instance_center_head, x), ('instance_offset', self.instance_offset_head, x)]
+        if self.predict_future_flow:
+            heads.append(('instance_flow', self.instance_future_head, x))
+        if self.planning:
+            heads.append(('costvolume', self.costvolume_head, x))
+        if _sync_world(self.segmentation_head[1]) > 1:
+            # N > 1 ranks: the heads are siblings -- the statistics of their first BatchNorms travel in ONE exchange per
+            # pass; the 1x1 output convolutions (and the sigmoid of the centerness head) follow per head
+            mids = bn_act_group([conv_bn_act_member(inp, head[0], head[1], ACT_RELU) for _, head, inp in heads])
+            out = {name: run_fused(list(head)[3:], mid) for (name, head, _), mid in zip(heads, mids)}
+        else:
+            out = {name: run_fused(head, inp) for name, head, inp in heads}
         return {
-            'segmentation': per_frame(run_fused(self.segmentation_head, x)),
-            'pedestrian': per_frame(run_fused(self.pedestrian_head, x) if self.predict_pedestrian else None),
-            'hdmap': run_fused(self.hdmap_head, present) if self.perceive_hdmap else None,
-            'instance_center': per_frame(run_fused(self.instance_center_head, x) if self.predict_instance else None),
-            'instance_offset': per_frame(run_fused(self.instance_offset_head, x) if self.predict_instance else None),
-            'instance_flow': per_frame(run_fused(self.instance_future_head, x) if self.predict_future_flow else None),
-            'costvolume': per_frame(run_fused(self.costvolume_head, x).squeeze(1) if self.planning else None),
+            'segmentation': per_frame(out['segmentation']),
+            'pedestrian': per_frame(out.get('pedestrian')),
+            'hdmap': out.get('hdmap'),
+            'instance_center': per_frame(out.get('instance_center')),
+            'instance_offset': per_frame(out.get('instance_offset')),
+            'instance_flow': per_frame(out.get('instance_flow')),
+            'costvolume': per_frame(out['costvolume'].squeeze(1) if self.planning else None),
         }

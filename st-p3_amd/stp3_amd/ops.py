@@ -610,12 +610,61 @@ def _f32(t):
     return t.detach().float().contiguous()
 
 
+def drive_exchange(gen, group):
+    """Run an operator written as a generator that YIELDS the buffer it needs summed over the replicas (cross-replica
+    BatchNorm statistics; at most one exchange per pass) and resumes once it is: here with one all-reduce of its own."""
+    try:
+        buf = next(gen)
+        while True:
+            torch.distributed.all_reduce(buf, group=group)
+            buf = gen.send(None)
+    except StopIteration as done:
+        return done.value
+
+
+def drive_exchange_group(gens, group):
+    """The same for SIBLING operators (parallel branches reading one tensor: the exchange of one does not depend on the
+    result of another): all of them run up to their exchange point, ONE all-reduce carries every buffer, all resume."""
+    waiting, results = [], [None] * len(gens)
+    for i, gen in enumerate(gens):
+        try:
+            waiting.append((i, gen, next(gen)))
+        except StopIteration as done:
+            results[i] = done.value
+    if waiting:
+        if len(waiting) == 1:
+            torch.distributed.all_reduce(waiting[0][2], group=group)
+        else:
+            packed = torch.cat([buf.reshape(-1) for _, _, buf in waiting])
+            torch.distributed.all_reduce(packed, group=group)
+            for (_, _, buf), part in zip(waiting, packed.split([b.numel() for _, _, b in waiting])):
+                buf.copy_(part.view(buf.shape))
+        for i, gen, _ in waiting:
+            try:
+                gen.send(None)
+                raise RuntimeError('an operator asked for a second exchange in one pass')
+            except StopIteration as done:
+                results[i] = done.value
+    return results
+
+
 class _BnAct(torch.autograd.Function):
     """y = act(BN(x + sbias) [+ res]) * oscale [+ res] on (N, C, H, W) tensors, channels-last memory."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, res, sbias, oscale, running_mean, running_var, training, momentum, eps,
                 act, res_mode, group, channels=None):
+        return drive_exchange(_BnAct.forward_steps(ctx, x, weight, bias, res, sbias, oscale, running_mean, running_var,
+                                                   training, momentum, eps, act, res_mode, group, channels), group)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return drive_exchange(_BnAct.backward_steps(ctx, dy), ctx.group)
+
+    @staticmethod
+    def forward_steps(ctx, x, weight, bias, res, sbias, oscale, running_mean, running_var, training, momentum, eps,
+                      act, res_mode, group, channels=None):
+        """``forward`` as a generator: yields the [2C] statistics buffer when it has to be summed over the replicas."""
         _need_gpu(x)
         if x.dtype == torch.bfloat16:
             dt = _lib.DTYPE_BF16
@@ -664,9 +713,9 @@ class _BnAct(torch.autograd.Function):
             else:
                 check(lib.stp3_bn_stats(ctypes.byref(dims), x.data_ptr(), _opt_ptr(sb), ws.data_ptr(), ws_bytes, base,
                                         stream), 'stp3_bn_stats')
-                # cross-replica statistics (train.py:47 sync_batchnorm): one small all-reduce per layer;
-                # every rank holds the same number of elements (the batch is sharded evenly)
-                torch.distributed.all_reduce(stat[:2 * c], group=group)
+                # cross-replica statistics (train.py:47 sync_batchnorm): one small all-reduce per layer -- or one for
+                # several sibling layers (drive_exchange_group); every rank holds the same number of elements
+                yield stat[:2 * c]
                 count = float(n * h * w) * world
                 check(lib.stp3_bn_apply_fwd(ctypes.byref(dims), x.data_ptr(), _opt_ptr(sb), _opt_ptr(res), _opt_ptr(osc),
                                             base, count, _opt_ptr(gamma), _opt_ptr(beta), eps, momentum,
@@ -687,7 +736,7 @@ class _BnAct(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward_steps(ctx, dy):
         x, res, sb, osc, gamma, beta, stat = ctx.saved_tensors
         dims = ctx.dims
         n, rows, c = dims.N, dims.rows, dims.C
@@ -735,7 +784,7 @@ class _BnAct(torch.autograd.Function):
             gsums = lsums
             if ctx.training and ctx.world > 1:
                 gsums = lsums.clone()
-                torch.distributed.all_reduce(gsums, group=ctx.group)
+                yield gsums
             if dres is not None and dims.ldr != cx:
                 # the reduce pass read `res` with its own stride; the apply pass writes dres densely and reads res
                 # with the same stride

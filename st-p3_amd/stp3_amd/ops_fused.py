@@ -42,6 +42,18 @@ class _ConvBnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, cbias, gamma, beta, res, running_mean, running_var, momentum, eps, act, res_mode,
                 stride, pad, dil, group, oscale=None):
+        return ops.drive_exchange(_ConvBnAct.forward_steps(ctx, x, weight, cbias, gamma, beta, res, running_mean,
+                                                           running_var, momentum, eps, act, res_mode, stride, pad, dil,
+                                                           group, oscale), group)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.drive_exchange(_ConvBnAct.backward_steps(ctx, dy), ctx.cfg[3])
+
+    @staticmethod
+    def forward_steps(ctx, x, weight, cbias, gamma, beta, res, running_mean, running_var, momentum, eps, act, res_mode,
+                      stride, pad, dil, group, oscale=None):
+        """``forward`` as a generator (ops.drive_exchange): yields the [2C] statistics when they need the other replicas."""
         ops._need_gpu(x, weight)
         if x.dtype != torch.bfloat16:
             x = x.to(torch.bfloat16)
@@ -57,7 +69,7 @@ class _ConvBnAct(torch.autograd.Function):
         if group is not False and torch.distributed.is_available() and torch.distributed.is_initialized():
             world = torch.distributed.get_world_size(group)
         if world > 1:
-            torch.distributed.all_reduce(stat[:2 * cout], group=group)
+            yield stat[:2 * cout]
             count *= world
         ldr = cout
         if res is not None:
@@ -81,7 +93,7 @@ class _ConvBnAct(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward_steps(ctx, dy):
         x, wb, yc, res, g32, b32, stat, osc = ctx.saved_tensors
         ops.check_weight_stamp(ctx.weight_ref, ctx.weight_stamp, 'conv_bn_act backward')
         dims, count, world, group, stride, pad, dil, has_cbias = ctx.cfg
@@ -112,7 +124,7 @@ class _ConvBnAct(torch.autograd.Function):
         gsums = lsums
         if world > 1:
             gsums = lsums.clone()
-            torch.distributed.all_reduce(gsums, group=group)
+            yield gsums
         check(lib.stp3_bn_apply_bwd(ctypes.byref(dims), dy.data_ptr(), yc.data_ptr(), None, ops._opt_ptr(res), ops._opt_ptr(osc), mean_p,
                                     invstd_p, ops._opt_ptr(g32), ops._opt_ptr(b32), gsums.data_ptr(), count,
                                     dconv.data_ptr(), ops._opt_ptr(dres), stream), 'stp3_bn_apply_bwd')
@@ -161,6 +173,71 @@ def conv_bn_act(x, weight, cbias, bn, act=ops.ACT_NONE, res=None, res_mode=ops.R
                             bn.running_var if bn.track_running_stats else None,
                             float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps), int(act), int(res_mode),
                             s[0], ops._pair(padding), ops._pair(dilation), group, oscale)
+
+
+class _SubContext:
+    """What one member operator of an ``_ExchangeGroup`` sees in place of the autograd context."""
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = needs_input_grad
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+_MEMBER_OPS = {'bn_act': ops._BnAct, 'conv_bn_act': _ConvBnAct}
+
+
+class _ExchangeGroup(torch.autograd.Function):
+    """SIBLING BatchNorm operators -- parallel branches that read the same tensor: the five ASPP branches, the four
+    pointwise convolutions at the head of a temporal block, the decoder heads -- as ONE autograd node, so that their
+    cross-replica statistics travel in one all-reduce per pass instead of one per layer (forward [2C] sums, backward
+    [3C] sums; 46 of the 248 exchanges of a step at N > 1).  The members are the ordinary operators run as generators
+    (``forward_steps`` / ``backward_steps``): same kernels, same arithmetic, same order per member."""
+
+    @staticmethod
+    def forward(ctx, specs, group, *flat):
+        subs, gens, off = [], [], 0
+        for kind, n_args in specs:
+            sub = _SubContext(ctx.needs_input_grad[2 + off:2 + off + n_args])
+            gens.append(_MEMBER_OPS[kind].forward_steps(sub, *flat[off:off + n_args]))
+            subs.append(sub)
+            off += n_args
+        outs = ops.drive_exchange_group(gens, group)
+        saved, index = [], []
+        for sub in subs:
+            index.append((len(saved), len(sub.saved_tensors)))
+            saved.extend(sub.saved_tensors)
+            sub.saved_tensors = ()
+        ctx.save_for_backward(*saved)
+        ctx.members = (subs, index, specs, group)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        subs, index, specs, group = ctx.members
+        saved = ctx.saved_tensors
+        gens = []
+        for sub, (first, count), (kind, _), dy in zip(subs, index, specs, dys):
+            if dy is None:
+                raise RuntimeError('an output of a BatchNorm exchange group received no gradient')
+            sub.saved_tensors = saved[first:first + count]
+            gens.append(_MEMBER_OPS[kind].backward_steps(sub, dy))
+        grads = ops.drive_exchange_group(gens, group)
+        flat = []
+        for (kind, n_args), g in zip(specs, grads):
+            assert len(g) == n_args, (kind, len(g), n_args)
+            flat.extend(g)
+        return (None, None) + tuple(flat)
+
+
+def exchange_group(members, group=None):
+    """``members``: [('bn_act' | 'conv_bn_act', positional arguments of that operator's autograd function)] ->
+    their outputs, computed with one statistics exchange per pass for all of them."""
+    specs = tuple((kind, len(args)) for kind, args in members)
+    flat = [a for _, args in members for a in args]
+    return list(_ExchangeGroup.apply(specs, group, *flat))
 
 
 # ----------------------------------------------------------------------------------------------

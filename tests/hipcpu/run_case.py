@@ -884,6 +884,76 @@ def model_step_two_ranks(ops):
             'loss_one_process': loss, 'grad_rel_l2': rel_l2(out[0][1]), 'grad_rel_l2_per_rank_statistics': rel_l2(ctl[0][1])}
 
 
+def _group_worker(rank, lib_path, port, out):
+    """One rank of ``bn_group_two_ranks``: three sibling layers of one input -- a fused conv -> BatchNorm -> ReLU (bf16,
+    statistics from the convolution epilogue), a BatchNorm + ReLU with a per-sample bias on zero-padded 40-lane rows, a
+    plain BatchNorm on float32 -- first as three operators (three exchanges per pass), then as ONE exchange group."""
+    import torch.distributed as dist
+    import torch.nn as nn
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2')
+    dist.init_process_group('gloo', rank=rank, world_size=2)
+    setup(lib_path)
+    from stp3_amd.layers import fused
+    torch.manual_seed(5)
+    cl = torch.channels_last
+    conv = nn.Conv2d(16, 24, 3, padding=1, bias=False)
+    bns = [nn.BatchNorm2d(24), nn.BatchNorm2d(35), nn.BatchNorm2d(8)]
+    for bn in bns:
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.2)
+    torch.manual_seed(100 + rank)                      # every rank its own shard
+    x0 = torch.randn(2, 16, 6, 7).to(torch.bfloat16).contiguous(memory_format=cl)
+    y1 = torch.zeros(2, 40, 6, 7).contiguous(memory_format=cl)
+    y1[:, :35] = torch.randn(2, 35, 6, 7)
+    y2 = torch.randn(2, 8, 6, 7).contiguous(memory_format=cl)
+    sb = torch.randn(2, 35) * 0.3
+    gys = [torch.randn(2, 24, 6, 7).to(torch.bfloat16).contiguous(memory_format=cl), torch.randn(2, 40, 6, 7).contiguous(memory_format=cl),
+           torch.randn(2, 8, 6, 7).contiguous(memory_format=cl)]
+    calls = {'n': 0}
+    real = dist.all_reduce
+
+    def counting(*a, **k):
+        calls['n'] += 1
+        return real(*a, **k)
+    dist.all_reduce = counting
+    results = []
+    import copy
+    for grouped in (False, True):
+        cv, b0, b1, b2 = copy.deepcopy(conv), *[copy.deepcopy(b) for b in bns]
+        x, a1, a2, s1 = (t.clone().requires_grad_() for t in (x0, y1, y2, sb))
+        calls['n'] = 0
+        with torch.autocast('cpu', dtype=torch.bfloat16, enabled=False):
+            members = [fused.conv_bn_act_member(x, cv, b0, fused.ACT_RELU), dict(bn=b1, x=a1, act=fused.ACT_RELU, sbias=s1),
+                       dict(bn=b2, x=a2)]
+            assert not isinstance(members[0], dict), 'the convolution member must take the fused operator'
+            outs = fused.bn_act_group(members) if grouped else [fused._run_member(m) for m in members]
+        fwd_calls = calls['n']
+        torch.autograd.backward(outs, gys)
+        grads = [x.grad, cv.weight.grad, b0.weight.grad, b0.bias.grad, a1.grad, s1.grad, b1.weight.grad, b1.bias.grad, a2.grad,
+                 b2.weight.grad, b2.bias.grad, b0.running_var, b1.running_mean, b2.running_var]
+        results.append((fwd_calls, calls['n'] - fwd_calls, [o.detach().float() for o in outs], [g.detach().float().clone() for g in grads]))
+    dist.all_reduce = real
+    (f0, b0c, o0, g0), (f1, b1c, o1, g1) = results
+    out[rank] = {'exchanges_separate': (f0, b0c), 'exchanges_grouped': (f1, b1c),
+                 'outputs_equal': all(torch.equal(a, b) for a, b in zip(o0, o1)),
+                 'grads_equal': all(torch.equal(a, b) for a, b in zip(g0, g1))}
+    dist.destroy_process_group()
+
+
+def bn_group_two_ranks(ops):
+    """ops_fused._ExchangeGroup on two gloo ranks: the same bits as the separate operators, one exchange per pass."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    res = mgr.dict()
+    mp.spawn(_group_worker, args=(sys.argv[1], port, res), nprocs=2, join=True)
+    return {f'rank{k}': v for k, v in res.items()}
+
+
 def model_step_f32(ops):            # float32: BatchNorm / depthwise / voxel-pool kernels (dense convolutions stay on torch)
     return _model_step(ops, autocast=False)
 
@@ -1000,7 +1070,7 @@ def fuzz(ops, seed=1):
 
 
 CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_frames, lift_coarse_grid, lift_tall, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
-                                 conv, dwconv, mbconv_mid, losses, plan, image_prep)}
+                                 conv, dwconv, mbconv_mid, losses, plan, image_prep, bn_group_two_ranks)}
 
 if __name__ == '__main__':
     ops_mod = setup(sys.argv[1])

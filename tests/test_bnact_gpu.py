@@ -273,3 +273,68 @@ def test_upsampling_reads_a_concatenation_gradient_in_place():
     xr = x0.float().requires_grad_()
     F.interpolate(xr, scale_factor=2, mode='bilinear', align_corners=False).backward(gc[:, 8:].float())
     torch.testing.assert_close(xk.grad.float(), xr.grad.to(torch.bfloat16).float(), rtol=8e-3, atol=8e-3)
+
+
+def _group_worker(rank, world, port, out):
+    """Three sibling layers of one shard -- fused conv -> BatchNorm -> ReLU (bf16), BatchNorm + ReLU with a per-sample bias
+    on 40-lane rows, a float32 BatchNorm -- as separate operators and as ONE exchange group; all-reduces counted."""
+    import copy
+    import torch.distributed as dist
+    import torch.nn as nn
+    from stp3_amd.layers import fused
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    cl = torch.channels_last
+    torch.manual_seed(5)
+    conv = nn.Conv2d(16, 24, 3, padding=1, bias=False).cuda()
+    bns = [nn.BatchNorm2d(24).cuda(), nn.BatchNorm2d(35).cuda(), nn.BatchNorm2d(8).cuda()]
+    torch.manual_seed(100 + rank)
+    x0 = torch.randn(2, 16, 20, 24).to(torch.bfloat16).cuda().contiguous(memory_format=cl)
+    y1 = torch.zeros(2, 40, 20, 24).cuda().contiguous(memory_format=cl)
+    y1[:, :35] = torch.randn(2, 35, 20, 24).cuda()
+    y2 = torch.randn(2, 8, 20, 24).cuda().contiguous(memory_format=cl)
+    sb = (torch.randn(2, 35) * 0.3).cuda()
+    gys = [torch.randn(2, 24, 20, 24).to(torch.bfloat16).cuda().contiguous(memory_format=cl),
+           torch.randn(2, 40, 20, 24).cuda().contiguous(memory_format=cl), torch.randn(2, 8, 20, 24).cuda().contiguous(memory_format=cl)]
+    calls = {'n': 0}
+    real = dist.all_reduce
+
+    def counting(*a, **k):
+        calls['n'] += 1
+        return real(*a, **k)
+    dist.all_reduce = counting
+    results = []
+    for grouped in (False, True):
+        cv, b0, b1, b2 = copy.deepcopy(conv), *[copy.deepcopy(b) for b in bns]
+        x, a1, a2, s1 = (t.clone().requires_grad_() for t in (x0, y1, y2, sb))
+        calls['n'] = 0
+        members = [fused.conv_bn_act_member(x, cv, b0, fused.ACT_RELU), dict(bn=b1, x=a1, act=fused.ACT_RELU, sbias=s1),
+                   dict(bn=b2, x=a2)]
+        assert not isinstance(members[0], dict)
+        outs = fused.bn_act_group(members) if grouped else [fused._run_member(m) for m in members]
+        fwd = calls['n']
+        torch.autograd.backward(outs, gys)
+        grads = [x.grad, cv.weight.grad, b0.weight.grad, b0.bias.grad, a1.grad, s1.grad, b1.weight.grad, b1.bias.grad, a2.grad,
+                 b2.weight.grad, b2.bias.grad, b0.running_var, b1.running_mean, b2.running_var]
+        results.append((fwd, calls['n'] - fwd, [o.detach().float().cpu() for o in outs], [g.detach().float().cpu() for g in grads]))
+    dist.all_reduce = real
+    (f0, b0c, o0, g0), (f1, b1c, o1, g1) = results
+    out[rank] = {'separate': (f0, b0c), 'grouped': (f1, b1c), 'outputs_equal': all(torch.equal(a, b) for a, b in zip(o0, o1)),
+                 'grads_equal': all(torch.equal(a, b) for a, b in zip(g0, g1))}
+    dist.destroy_process_group()
+
+
+def test_sibling_layers_share_one_exchange_two_ranks_one_gpu():
+    """ops_fused._ExchangeGroup on the MI355X (two gloo ranks on cuda:0): the same bits as the separate operators, one
+    all-reduce per pass instead of three."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    mgr = ctx.Manager()
+    out = mgr.dict()
+    mp.spawn(_group_worker, args=(2, port, out), nprocs=2, join=True)
+    for rank in (0, 1):
+        assert out[rank] == {'separate': (3, 3), 'grouped': (1, 1), 'outputs_equal': True, 'grads_equal': True}, out[rank]

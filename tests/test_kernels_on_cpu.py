@@ -28,7 +28,7 @@ import build as hipcpu_build  # noqa: E402
 
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
 ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
-           ('conv', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
+           ('conv', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
            ('lift_c64_frames', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
 ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)]
@@ -158,6 +158,17 @@ def test_planner_cost_kernels(results):
             if form == 'seconds':
                 continue
             assert e['cost_fc'] <= 2e-5 and e['cost_fo'] <= 2e-5 and e['d_cost_volume'] <= 1e-6, (form, e)
+
+
+def test_sibling_batchnorms_share_their_exchange(results):
+    """ops_fused._ExchangeGroup on two gloo ranks over the kernels: a fused conv -> BatchNorm -> ReLU, a BatchNorm with a
+    per-sample bias on zero-padded lanes and a plain float32 BatchNorm as ONE autograd node -- bit-equal outputs, input,
+    parameter and per-sample-bias gradients and running statistics to the three separate operators, with one all-reduce
+    per pass instead of three (the five ASPP branches, the pointwise heads of a temporal block, the decoder heads)."""
+    r = _get(results, 'bn_group_two_ranks')
+    for rank in ('rank0', 'rank1'):
+        assert r[rank] == {'exchanges_separate': [3, 3], 'exchanges_grouped': [1, 1], 'outputs_equal': True,
+                           'grads_equal': True}, r[rank]
 
 
 def test_image_preprocessing_kernel(results):

@@ -262,11 +262,29 @@ def _step_worker(rank, world, port, out, local_stats, fast_host=False):
         trainer._BATCHED_LABEL_WARP = True
     buckets = GradientBuckets(module.model, gather=fast_host)
     batch = {k: v[rank:rank + 1] for k, v in _small_batch(2).items()}
+    # count the BatchNorm statistics exchanges of the forward pass (the statement route's autograd-aware all-reduce;
+    # its backward issues one more each) and the train-mode BatchNorm layers that ran
+    import torch.distributed.nn.functional as dfn
+    counts = {'exchanges': 0, 'layers': 0}
+    real_all_reduce = dfn.all_reduce
+
+    def counting_all_reduce(*a, **k):
+        counts['exchanges'] += 1
+        return real_all_reduce(*a, **k)
+    dfn.all_reduce = counting_all_reduce
+    from stp3_amd.layers import fused
+    real_steps = fused._bn_act_reference_steps
+
+    def counting_steps(bn, *a, **k):
+        counts['layers'] += int(bn.training)
+        return real_steps(bn, *a, **k)
+    fused._bn_act_reference_steps = counting_steps
     buckets.zero_grad()
     loss = module.training_step(batch)
+    dfn.all_reduce, fused._bn_act_reference_steps = real_all_reduce, real_steps
     loss.backward()
     buckets.finish()
-    out[rank] = (float(loss.detach()), torch.cat([f.clone() for f, _ in buckets.buckets]))
+    out[rank] = (float(loss.detach()), torch.cat([f.clone() for f, _ in buckets.buckets]), dict(counts))
     dist.destroy_process_group()
 
 
@@ -285,6 +303,13 @@ def test_full_step_two_ranks_equal_one_process_on_the_concatenated_batch():
 
     out = two_ranks(False)
     torch.testing.assert_close(out[0][1], out[1][1], rtol=0, atol=0)        # identical averaged gradients on both ranks
+    # sibling layers share their statistics exchange: 5 ASPP branches x 3 heads -> 3, the pointwise convolutions at the
+    # head of the two temporal blocks 4 + 3 -> 2, the three decoder heads of this configuration -> 1: 19 fewer
+    # exchanges than BatchNorm layers in the forward pass (and as many fewer in the backward pass); with all six heads of
+    # BASELINE configs[2] it is 23 each way, 46 of 248 per step
+    counts = out[0][2]
+    print('BatchNorm layers / forward exchanges per step:', counts)
+    assert counts == out[1][2] and counts['layers'] - counts['exchanges'] == 19, counts
     fast = two_ranks(False, fast_host=True)        # gradient gather + batched label warp: the same bits, rank by rank
     for r in (0, 1):
         assert fast[r][0] == out[r][0] and torch.equal(fast[r][1], out[r][1])
