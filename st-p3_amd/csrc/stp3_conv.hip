@@ -390,7 +390,7 @@ union FragTr {
 
 template <int TCO, int TCI>
 __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles_ci, int ksteps_per_block, int tap_fold,
-                                                           const uint16_t* __restrict__ dy,
+                                                           int xcd_chunks, const uint16_t* __restrict__ dy,
                                                            const uint16_t* __restrict__ x,
                                                            float* __restrict__ partial) {
     constexpr int TA = TCO / 64, TB = TCI / 64;            // 32-row MFMA tiles per wave (2 x 2 waves)
@@ -404,12 +404,21 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave >> 1, wb = wave & 1;               // co half / ci half of the tile
-    // (launch order as dispatched: tile, tap, split.  The XCD-contiguous order of the forward kernel was measured SLOWER
-    // here -- 3x3 64 -> 64 at 200x200x12: 205 -> 258 us, profiles/r03c_conv_timings.txt -- the nine taps of a pixel
-    // split then hit the same dY lines of one L2 at the same time)
-    const int tco = blockIdx.x / tiles_ci, tci = blockIdx.x - tco * tiles_ci;
-    const int tap = blockIdx.y;
-    const int split = blockIdx.z;
+    // Workgroup order.  As dispatched (tile, tap, split) the nine taps of a pixel split land on nine different XCDs and each
+    // pulls its own copy of the dY / X rows through its own L2 (PMC: 7 % hit rate, 4.3x the operands fetched).  With
+    // `xcd_chunks` (set by the launcher) XCD x runs a contiguous chunk of that order instead -- the taps of a split share
+    // one L2: 3x3 64 -> 64 @200x200x12 173 -> 108 us, 3x3 d12 64 -> 128 246 -> 157 us (profiles/r03r_*).  (On the round-2
+    // kernel, which was bound by its instruction count, the same order was SLOWER; it also is for 49 taps.)
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (xcd_chunks) {
+        const int lin = xcd_order(bx + (int)gridDim.x * (by + (int)gridDim.y * bz), (int)(gridDim.x * gridDim.y * gridDim.z));
+        bx = lin % (int)gridDim.x;
+        by = (lin / (int)gridDim.x) % (int)gridDim.y;
+        bz = lin / (int)(gridDim.x * gridDim.y);
+    }
+    const int tco = bx / tiles_ci, tci = bx - tco * tiles_ci;
+    const int tap = by;
+    const int split = bz;
     const int kh = tap / d.KW, kw = tap - kh * d.KW;
     const int co0 = tco * TCO, ci0 = tci * TCI;
     const int total_steps = (d.M + kBK - 1) / kBK;
@@ -610,8 +619,10 @@ int wgrad_launch(const ConvDims& d, int tco, int tci, int taps, int splits, int 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_kernel<TCO, TCI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return -(int)e;
+    // XCD-contiguous workgroup order when the grid is a 32-bit count and the layer has at most a 3x3's worth of taps
+    const int xcd = taps <= 9 && (int64_t)tco * tci * taps * splits < (1LL << 31);
     hipLaunchKernelGGL((conv2d_wgrad_kernel<TCO, TCI>), dim3(tco * tci, taps, splits), dim3(256), lds, s, d, tci, ksteps,
-                       fold, (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace);
+                       fold, xcd, (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace);
     return STP3_OK;
 }
 
