@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(DwDims d, const T*
 // pixel lanes are summed through LDS in a fixed order).  Stage 2 sums the partials over bx.
 // No atomics: deterministic.
 template <typename T, int K, int S>
-__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwDims d, const T* __restrict__ x,
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwDims d, int nbx, const T* __restrict__ x,
                                                                 const T* __restrict__ dy,
                                                                 float* __restrict__ partial) {
     constexpr int VN = Vec<T>::N;
@@ -191,8 +191,13 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwDims d, const 
     const int CVB = min(CV, 256);                    // channel vectors handled by this block column
     const int PL = 256 / CVB;                        // pixel lanes
     const int cvb = threadIdx.x % CVB, pl = threadIdx.x / CVB;
-    const int cv = blockIdx.y * CVB + cvb;
-    const int kh = blockIdx.z;
+    // 1-D launch, kernel row fastest, XCD-contiguous: the K workgroups that walk the SAME pixels for the K kernel rows sit
+    // next to each other on one XCD, so dy (read by all K) and the input rows (each needed by K (output row, kernel row)
+    // pairs) come out of that XCD's L2 instead of being fetched K times from HBM
+    const int v = xcd_order(blockIdx.x, gridDim.x);
+    const int kh = v % K;
+    const int bxi = (v / K) % nbx, byi = v / (K * nbx);
+    const int cv = byi * CVB + cvb;
     const bool live = pl < PL && cv < CV;
     const int c0 = cv * VN;
     float acc[K][VN];
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwDims d, const 
     const int wgroups = (d.Wo + TW - 1) / TW;
     const int ngroups = d.N * d.Ho * wgroups;        // < 2^31 (checked by the launcher)
     if (live) {
-        for (int p = blockIdx.x * PL + pl; p < ngroups; p += gridDim.x * PL) {
+        for (int p = bxi * PL + pl; p < ngroups; p += nbx * PL) {
             const int wg = p % wgroups;
             const int r = p / wgroups;
             const int ho = r % d.Ho;
@@ -246,11 +251,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwDims d, const 
     __syncthreads();
     for (int i = threadIdx.x; i < K * rowlen; i += 256) {
         const int t = i / rowlen, cc = i % rowlen;
-        const int c = blockIdx.y * rowlen + cc;
+        const int c = byi * rowlen + cc;
         if (c >= d.C) continue;
         float s = 0.f;
         for (int q = 0; q < PL; ++q) s += red[(q * K + t) * rowlen + cc];
-        partial[((int64_t)blockIdx.x * KK + kh * K + t) * d.C + c] = s;
+        partial[((int64_t)bxi * KK + kh * K + t) * d.C + c] = s;
     }
 }
 
@@ -483,7 +488,7 @@ int launch_bwd_weight(const DwDims& d, const void* x, const void* dy, float* dw,
     const int bx = (int)(want < kWgradBlocks ? want : kWgradBlocks);
     const int by = (CV + CVB - 1) / CVB;
     const size_t lds = (size_t)PL * K * CVB * VN * sizeof(float);
-    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, S>), dim3(bx, by, K), dim3(256), lds, s, d, (const T*)x,
+    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, S>), dim3(bx * by * K), dim3(256), lds, s, d, bx, (const T*)x,
                        (const T*)dy, ws);
     const int n = K * K * d.C;
     hipLaunchKernelGGL(dwconv_reduce_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, s, bx, n, ws, dw);
