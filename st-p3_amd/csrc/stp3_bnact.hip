@@ -39,6 +39,9 @@ __device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float((uint
 
 template <typename T, int VEC> struct Io;
 template <> struct Io<float, 4> {
+    typedef float4 Raw;                              // what a load leaves in registers until the row is worked on
+    static __device__ Raw load_raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ void unpack(const Raw& v, float* f) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
     static __device__ void load(const float* p, float* f) {
         const float4 v = *reinterpret_cast<const float4*>(p);
         f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
@@ -48,10 +51,23 @@ template <> struct Io<float, 4> {
     }
 };
 template <> struct Io<float, 1> {
+    typedef float Raw;
+    static __device__ Raw load_raw(const float* p) { return p[0]; }
+    static __device__ void unpack(const Raw& v, float* f) { f[0] = v; }
     static __device__ void load(const float* p, float* f) { f[0] = p[0]; }
     static __device__ void store(float* p, const float* f) { p[0] = f[0]; }
 };
 template <> struct Io<uint16_t, 8> {
+    typedef uint4 Raw;                               // 8 bf16 stay packed (4 registers, not 8) while the loads are in flight
+    static __device__ Raw load_raw(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+    static __device__ void unpack(const Raw& v, float* f) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
     static __device__ void load(const uint16_t* p, float* f) {
         const uint4 v = *reinterpret_cast<const uint4*>(p);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -69,6 +85,9 @@ template <> struct Io<uint16_t, 8> {
     }
 };
 template <> struct Io<uint16_t, 1> {
+    typedef uint16_t Raw;
+    static __device__ Raw load_raw(const uint16_t* p) { return p[0]; }
+    static __device__ void unpack(const Raw& v, float* f) { f[0] = bf2f(v); }
     static __device__ void load(const uint16_t* p, float* f) { f[0] = bf2f(p[0]); }
     static __device__ void store(uint16_t* p, const float* f) { p[0] = (uint16_t)pack_bf16(f[0], 0.f); }
 };
@@ -340,31 +359,35 @@ __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(
     const int step = gridDim.x * m.RL;
     dispatch_act_res(d.act, d.res_mode, [&](auto act_c, auto res_c) {
         constexpr int ACT = decltype(act_c)::value, RESM = decltype(res_c)::value;
+        typedef typename Io<T, VEC>::Raw Raw;
         for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += kUnroll * step) {
-            float v[kUnroll][VEC], rv[kUnroll][VEC];
+            Raw xr[kUnroll], rr[kUnroll];                  // loads stay packed while they are in flight
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
                 if (r + u * step < d.rows) {
-                    Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
-                    mask_tail<VEC, TAIL>(m, v[u]);
-                    if (RESM != STP3_RES_NONE) {
-                        Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
-                        mask_tail<VEC, TAIL>(m, rv[u]);
-                    }
+                    xr[u] = Io<T, VEC>::load_raw(xs + (size_t)(r + u * step) * d.ldx);
+                    if (RESM != STP3_RES_NONE) rr[u] = Io<T, VEC>::load_raw(rs + (size_t)(r + u * step) * d.ldr);
                 }
             }
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
                 if (r + u * step < d.rows) {
+                    float v[VEC], rv[VEC];
+                    Io<T, VEC>::unpack(xr[u], v);
+                    mask_tail<VEC, TAIL>(m, v);
+                    if (RESM != STP3_RES_NONE) {
+                        Io<T, VEC>::unpack(rr[u], rv);
+                        mask_tail<VEC, TAIL>(m, rv);
+                    }
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
-                        float t = fmaf(v[u][j], scale[j], shift[j]);
-                        if (RESM == STP3_RES_BEFORE_ACT) t += rv[u][j];
+                        float t = fmaf(v[j], scale[j], shift[j]);
+                        if (RESM == STP3_RES_BEFORE_ACT) t += rv[j];
                         t = act_fwd_c<ACT>(t) * os;
-                        if (RESM == STP3_RES_AFTER_ACT) t += rv[u][j];
-                        v[u][j] = t;
+                        if (RESM == STP3_RES_AFTER_ACT) t += rv[j];
+                        v[j] = t;
                     }
-                    Io<T, VEC>::store(ys + (size_t)(r + u * step) * d.ldy, v[u]);
+                    Io<T, VEC>::store(ys + (size_t)(r + u * step) * d.ldy, v);
                 }
             }
         }
@@ -387,52 +410,60 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
     for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.f;
     if (m.live) {
         const int c0 = m.cv * VEC;
-        float mu[VEC], is[VEC], ga[VEC], be[VEC];
+        // xhat = ((x + sb) - mean) * invstd; the pre-activation as the apply pass (and the forward) form it: s x + t
+        float mu[VEC], is[VEC], cs[VEC], ct[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const int c = c0 + j;
             const bool ok = c < d.C;
             const float sb = (ok && d.has_sbias) ? sbias[(size_t)n * d.C + c] : 0.f;
-            mu[j] = ok ? mean_[c] - sb : 0.f;         // xhat = ((x + sb) - mean) * invstd
+            mu[j] = ok ? mean_[c] - sb : 0.f;
             is[j] = ok ? invstd_[c] : 0.f;
-            ga[j] = ok ? (gamma ? gamma[c] : 1.f) : 0.f;
-            be[j] = ok ? (beta ? beta[c] : 0.f) : 0.f;
+            const float ga = ok ? (gamma ? gamma[c] : 1.f) : 0.f;
+            const float be = ok ? (beta ? beta[c] : 0.f) : 0.f;
+            cs[j] = ga * is[j];
+            ct[j] = be - mu[j] * cs[j];
         }
         const float os = d.has_oscale ? oscale[n] : 1.f;
         const T* xs = x + (size_t)n * d.rows * d.ldx + c0;
         const T* gs = dy + (size_t)n * d.rows * d.ldy + c0;
         const T* rs = d.res_mode == STP3_RES_BEFORE_ACT ? res + (size_t)n * d.rows * d.ldr + c0 : nullptr;
         const int step = gridDim.x * m.RL;
-        constexpr int U = 2;
+        constexpr int U = 3;                               // rows in flight per thread, loads kept packed until used
+        typedef typename Io<T, VEC>::Raw Raw;
         // (the residual only matters when it is added in front of the activation)
         dispatch_act_res(d.act, rs ? STP3_RES_BEFORE_ACT : STP3_RES_NONE, [&](auto act_c, auto res_c) {
             constexpr int ACT = decltype(act_c)::value;
             constexpr bool PRE_RES = decltype(res_c)::value == STP3_RES_BEFORE_ACT;
             for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += U * step) {
-                float v[U][VEC], g[U][VEC], rv[U][VEC];
+                Raw xr[U], gr[U], rr[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (r + u * step < d.rows) {
-                        Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
-                        Io<T, VEC>::load(gs + (size_t)(r + u * step) * d.ldy, g[u]);
-                        mask_tail<VEC, TAIL>(m, v[u]);
-                        mask_tail<VEC, TAIL>(m, g[u]);
-                        if (PRE_RES) {
-                            Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
-                            mask_tail<VEC, TAIL>(m, rv[u]);
-                        }
+                        xr[u] = Io<T, VEC>::load_raw(xs + (size_t)(r + u * step) * d.ldx);
+                        gr[u] = Io<T, VEC>::load_raw(gs + (size_t)(r + u * step) * d.ldy);
+                        if (PRE_RES) rr[u] = Io<T, VEC>::load_raw(rs + (size_t)(r + u * step) * d.ldr);
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (r + u * step < d.rows) {
+                        float v[VEC], g[VEC], rv[VEC];
+                        Io<T, VEC>::unpack(xr[u], v);
+                        Io<T, VEC>::unpack(gr[u], g);
+                        mask_tail<VEC, TAIL>(m, v);
+                        mask_tail<VEC, TAIL>(m, g);
+                        if (PRE_RES) {
+                            Io<T, VEC>::unpack(rr[u], rv);
+                            mask_tail<VEC, TAIL>(m, rv);
+                        }
 #pragma unroll
                         for (int j = 0; j < VEC; ++j) {
-                            const float xh = (v[u][j] - mu[j]) * is[j];
-                            float gg = g[u][j] * os;
+                            const float xh = (v[j] - mu[j]) * is[j];
+                            float gg = g[j] * os;
                             if (ACT != STP3_ACT_NONE) {
-                                float pre = fmaf(xh, ga[j], be[j]);
-                                if (PRE_RES) pre += rv[u][j];
+                                float pre = fmaf(v[j], cs[j], ct[j]);
+                                if (PRE_RES) pre += rv[j];
                                 gg *= act_grad_c<ACT>(pre);
                             }
                             acc[0][j] += gg;
@@ -459,18 +490,26 @@ __global__ __launch_bounds__(kThreads) void bn_apply_bwd_kernel(
     if (!m.live) return;
     const int n = blockIdx.y;
     const int c0 = m.cv * VEC;
-    float mu[VEC], is[VEC], ga[VEC], be[VEC], k0[VEC], k1[VEC];
+    // FOUR constants per channel instead of (mean, invstd, gamma, beta, k0, k1): the pre-activation is the forward's
+    // pre = s x + t (s = gamma invstd, t = beta - mean s) and dx = gamma invstd (g - k0 - xhat k1) = s g + a2 x + a3 with
+    // a2 = -s invstd k1, a3 = -s k0 - a2 mean.  The kernel held 166 registers (3 waves per SIMD, 2.4 resident on average:
+    // profiles/r03w) and a streaming kernel lives on the bytes it keeps in flight.
+    float cs[VEC], ct[VEC], a2[VEC], a3[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const int c = c0 + j;
         const bool ok = c < d.C;
         const float sb = (ok && d.has_sbias) ? sbias[(size_t)n * d.C + c] : 0.f;
-        mu[j] = ok ? mean_[c] - sb : 0.f;
-        is[j] = ok ? invstd_[c] : 0.f;
-        ga[j] = ok ? (gamma ? gamma[c] : 1.f) : 0.f;
-        be[j] = ok ? (beta ? beta[c] : 0.f) : 0.f;
-        k0[j] = (TRAIN && ok) ? gsums[c] * inv_count : 0.f;
-        k1[j] = (TRAIN && ok) ? gsums[d.C + c] * inv_count : 0.f;
+        const float mu = ok ? mean_[c] - sb : 0.f;
+        const float is = ok ? invstd_[c] : 0.f;
+        const float ga = ok ? (gamma ? gamma[c] : 1.f) : 0.f;
+        const float be = ok ? (beta ? beta[c] : 0.f) : 0.f;
+        const float k0 = (TRAIN && ok) ? gsums[c] * inv_count : 0.f;
+        const float k1 = (TRAIN && ok) ? gsums[d.C + c] * inv_count : 0.f;
+        cs[j] = ga * is;
+        ct[j] = be - mu * cs[j];
+        a2[j] = -(cs[j] * is) * k1;
+        a3[j] = -cs[j] * k0 - a2[j] * mu;
     }
     const float os = d.has_oscale ? oscale[n] : 1.f;
     const T* xs = x + (size_t)n * d.rows * d.ldx + c0;
@@ -480,42 +519,46 @@ __global__ __launch_bounds__(kThreads) void bn_apply_bwd_kernel(
     T* dxs = dx + (size_t)n * d.rows * d.ldx + c0;
     T* drs = (pre_res && dres) ? dres + (size_t)n * d.rows * d.ldr + c0 : nullptr;
     const int step = gridDim.x * m.RL;
-    constexpr int U = 2;
+    constexpr int U = 4;                                   // rows in flight per thread: their loads stay PACKED until used
+    typedef typename Io<T, VEC>::Raw Raw;
     dispatch_act_res(d.act, rs ? STP3_RES_BEFORE_ACT : STP3_RES_NONE, [&](auto act_c, auto res_c) {
         constexpr int ACT = decltype(act_c)::value;
         constexpr bool PRE_RES = decltype(res_c)::value == STP3_RES_BEFORE_ACT;
         for (int r = blockIdx.x * m.RL + m.rl; r < d.rows; r += U * step) {
-            float v[U][VEC], g[U][VEC], rv[U][VEC];
+            Raw xr[U], gr[U], rr[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (r + u * step < d.rows) {
-                    Io<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
-                    Io<T, VEC>::load(gs + (size_t)(r + u * step) * d.ldy, g[u]);
-                    mask_tail<VEC, TAIL>(m, v[u]);
-                    mask_tail<VEC, TAIL>(m, g[u]);
-                    if (PRE_RES) {
-                        Io<T, VEC>::load(rs + (size_t)(r + u * step) * d.ldr, rv[u]);
-                        mask_tail<VEC, TAIL>(m, rv[u]);
-                    }
+                    xr[u] = Io<T, VEC>::load_raw(xs + (size_t)(r + u * step) * d.ldx);
+                    gr[u] = Io<T, VEC>::load_raw(gs + (size_t)(r + u * step) * d.ldy);
+                    if (PRE_RES) rr[u] = Io<T, VEC>::load_raw(rs + (size_t)(r + u * step) * d.ldr);
                 }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (r + u * step < d.rows) {
+                    float v[VEC], g[VEC], rv[VEC];
+                    Io<T, VEC>::unpack(xr[u], v);
+                    Io<T, VEC>::unpack(gr[u], g);
+                    mask_tail<VEC, TAIL>(m, v);
+                    mask_tail<VEC, TAIL>(m, g);
+                    if (PRE_RES) {
+                        Io<T, VEC>::unpack(rr[u], rv);
+                        mask_tail<VEC, TAIL>(m, rv);
+                    }
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
-                        const float xh = (v[u][j] - mu[j]) * is[j];
-                        float gg = g[u][j] * os;
+                        float gg = g[j] * os;
                         if (ACT != STP3_ACT_NONE) {
-                            float pre = fmaf(xh, ga[j], be[j]);
-                            if (PRE_RES) pre += rv[u][j];
+                            float pre = fmaf(v[j], cs[j], ct[j]);
+                            if (PRE_RES) pre += rv[j];
                             gg *= act_grad_c<ACT>(pre);
                         }
-                        g[u][j] = gg;                                  // gradient w.r.t. the pre-activation
-                        v[u][j] = ga[j] * is[j] * (gg - k0[j] - xh * k1[j]);
+                        g[j] = gg;                                     // gradient w.r.t. the pre-activation
+                        v[j] = fmaf(cs[j], gg, fmaf(a2[j], v[j], a3[j]));
                     }
-                    Io<T, VEC>::store(dxs + (size_t)(r + u * step) * d.ldx, v[u]);
-                    if (drs) Io<T, VEC>::store(drs + (size_t)(r + u * step) * d.ldr, g[u]);
+                    Io<T, VEC>::store(dxs + (size_t)(r + u * step) * d.ldx, v);
+                    if (drs) Io<T, VEC>::store(drs + (size_t)(r + u * step) * d.ldr, g);
                 }
             }
         }

@@ -38,6 +38,9 @@ struct MbDims {
 
 template <typename T, int VEC> struct Io3;
 template <> struct Io3<float, 4> {
+    typedef float4 Raw;                              // a load as it sits in registers until its row is worked on
+    static __device__ Raw load_raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ void unpack(const Raw& v, float* f) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
     static __device__ void load(const float* p, float* f) {
         const float4 v = *reinterpret_cast<const float4*>(p);
         f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
@@ -45,6 +48,16 @@ template <> struct Io3<float, 4> {
     static __device__ void store(float* p, const float* f) { *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]); }
 };
 template <> struct Io3<uint16_t, 8> {
+    typedef uint4 Raw;                               // 8 bf16 packed: 4 registers instead of 8 while in flight
+    static __device__ Raw load_raw(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+    static __device__ void unpack(const Raw& v, float* f) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
     static __device__ void load(const uint16_t* p, float* f) {
         const uint4 v = *reinterpret_cast<const uint4*>(p);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -335,26 +348,33 @@ __global__ __launch_bounds__(kT) void mbconv_bwd_apply_kernel(MbDims d, const T*
     const T* gs = da + (size_t)n * d.rows * d.ldg + cv * VEC;
     T* os = dx + (size_t)n * d.rows * d.ldg + cv * VEC;
     const int step = gridDim.x * RL;
-    for (int r = blockIdx.x * RL + rl; r < d.rows; r += 2 * step) {
-        float v[2][VEC], g[2][VEC];
+    // four rows in flight per thread, their loads PACKED until the row is worked on (see csrc/stp3_bnact.hip: a streaming
+    // kernel lives on the bytes it keeps in flight; unpacked, two rows at 144 registers left 3 waves per SIMD)
+    constexpr int U = 4;
+    typedef typename Io3<T, VEC>::Raw Raw;
+    for (int r = blockIdx.x * RL + rl; r < d.rows; r += U * step) {
+        Raw xr[U], gr[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (r + u * step < d.rows) {
-                Io3<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
-                Io3<T, VEC>::load(gs + (size_t)(r + u * step) * d.ldg, g[u]);
+                xr[u] = Io3<T, VEC>::load_raw(xs + (size_t)(r + u * step) * d.ldx);
+                gr[u] = Io3<T, VEC>::load_raw(gs + (size_t)(r + u * step) * d.ldg);
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (r + u * step < d.rows) {
+                float v[VEC], g[VEC];
+                Io3<T, VEC>::unpack(xr[u], v);
+                Io3<T, VEC>::unpack(gr[u], g);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     float val, der;
-                    act_both<ACT>(fmaf(v[u][j], sc[j], sh[j]), val, der);
-                    const float gg = fmaf(g[u][j], ga[j], dp[j]) * der;
-                    g[u][j] = fmaf(sc[j], gg, -fmaf(e1[j], v[u][j], e0[j]));
+                    act_both<ACT>(fmaf(v[j], sc[j], sh[j]), val, der);
+                    const float gg = fmaf(g[j], ga[j], dp[j]) * der;
+                    g[j] = fmaf(sc[j], gg, -fmaf(e1[j], v[j], e0[j]));
                 }
-                Io3<T, VEC>::store(os + (size_t)(r + u * step) * d.ldg, g[u]);
+                Io3<T, VEC>::store(os + (size_t)(r + u * step) * d.ldg, g);
             }
         }
     }
@@ -380,17 +400,21 @@ __global__ __launch_bounds__(kT) void mbconv_scale_act_kernel(MbDims d, const T*
     const T* xs = x + (size_t)n * d.rows * d.ldx + cv * VEC;
     T* ys = y + (size_t)n * d.rows * d.ldg + cv * VEC;
     const int step = gridDim.x * RL;
-    for (int r = blockIdx.x * RL + rl; r < d.rows; r += 4 * step) {
-        float v[4][VEC];
+    constexpr int U = 6;                                   // rows in flight per thread, packed until used
+    typedef typename Io3<T, VEC>::Raw Raw;
+    for (int r = blockIdx.x * RL + rl; r < d.rows; r += U * step) {
+        Raw xr[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (r + u * step < d.rows) Io3<T, VEC>::load(xs + (size_t)(r + u * step) * d.ldx, v[u]);
+        for (int u = 0; u < U; ++u)
+            if (r + u * step < d.rows) xr[u] = Io3<T, VEC>::load_raw(xs + (size_t)(r + u * step) * d.ldx);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (r + u * step < d.rows) {
+                float v[VEC];
+                Io3<T, VEC>::unpack(xr[u], v);
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) v[u][j] = act_fwd<ACT>(fmaf(v[u][j], sc[j], sh[j])) * ga[j];
-                Io3<T, VEC>::store(ys + (size_t)(r + u * step) * d.ldg, v[u]);
+                for (int j = 0; j < VEC; ++j) v[j] = act_fwd<ACT>(fmaf(v[j], sc[j], sh[j])) * ga[j];
+                Io3<T, VEC>::store(ys + (size_t)(r + u * step) * d.ldg, v);
             }
         }
     }
