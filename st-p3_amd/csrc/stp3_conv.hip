@@ -665,7 +665,8 @@ int stp3_conv2d_fwd(const stp3_conv_dims* p, const void* x, const void* w, const
     if (((uintptr_t)y & (p->out_dtype == STP3_DTYPE_F32 ? 3 : 1))) return STP3_EUNSUP;
     if (sums && p->out_dtype != STP3_DTYPE_BF16) return STP3_EUNSUP;
     const int64_t M = (int64_t)p->N * p->Ho * p->Wo;
-    if (M >= (1LL << 31) || (int64_t)p->N * p->H * p->W * p->ldx >= (1LL << 31)) return STP3_EUNSUP;   // 32-bit offsets
+    // 32-bit PIXEL indices (input and output); element offsets are 64-bit pointer arithmetic since the round-3 staging
+    if (M >= (1LL << 31) || (int64_t)p->N * p->H * p->W >= (1LL << 31)) return STP3_EUNSUP;
     ConvDims d;
     d.N = p->N; d.H = p->H; d.W = p->W; d.Cin = p->Cin; d.Ho = p->Ho; d.Wo = p->Wo; d.Cout = p->Cout;
     d.KH = p->KH; d.KW = p->KW; d.stride = p->stride; d.pad_h = p->pad_h; d.pad_w = p->pad_w;

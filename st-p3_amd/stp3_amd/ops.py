@@ -996,15 +996,15 @@ _CONV_MAX_STAT_TILES = 65536          # stp3_conv2d_fwd: row tiles of 128 pixels
 
 
 def conv2d_supported(x, weight, stride, groups=1):
-    """What stp3_conv2d_fwd takes: GPU, dense (groups == 1), square stride, input channels a multiple of 8, and an
-    input small enough for the kernel's 32-bit element offsets (N*H*W*ld < 2^31; the output has at most as many
-    pixels for stride >= 1 up to the padding, checked again by the library)."""
+    """What stp3_conv2d_fwd / _wgrad take: GPU, dense (groups == 1), square stride, input channels a multiple of 8, and
+    fewer than 2^31 PIXELS (the kernels index pixels with 32 bits -- the weight gradient keeps two images of slack and
+    packs rows / columns into 16 bits -- and address elements with 64-bit pointer arithmetic: the 4.6 G-element expanded
+    tensors of BASELINE configs[4] at three samples per GPU stay on the kernels)."""
     s = _pair(stride)
     if not (x.is_cuda and x.dim() == 4 and groups == 1 and s[0] == s[1] and weight.shape[1] % 8 == 0):
         return False
     n, c, h, w = x.shape
-    # (the weight gradient keeps two images of slack in its 32-bit pixel indices and packs rows / columns into 16 bits)
-    return (n + 2) * h * w * max(c, weight.shape[0]) < (1 << 31) and h < 32768 and w < 32768
+    return (n + 2) * h * w < (1 << 31) and h < 32768 and w < 32768
 
 
 def conv2d_stats_supported(x, weight, stride, padding=0, dilation=1):

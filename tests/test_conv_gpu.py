@@ -96,3 +96,38 @@ def test_conv2d_rejects_what_it_cannot_do():
         ops.conv2d(x, w, None, 1, 1, 1)
     with pytest.raises(Exception):
         ops.conv2d(x.cpu(), w.cpu(), None, 1, 1, 1)               # no CPU fallback
+
+
+def test_conv2d_on_tensors_beyond_2g_elements():
+    """The kernels index PIXELS with 32 bits and address elements with 64-bit pointer arithmetic: a 2.3 G-element input
+    (3 x 80 x 3072 x 3072, 4.5 GB of bf16 -- the expanded tensors of BASELINE configs[4] are of that order) through the
+    forward, the data gradient and the weight gradient, checked on the crops where the offsets are largest and, for the
+    weight gradient, against torch on the whole tensor."""
+    from stp3_amd import ops
+    n, cin, h, w, cout = 3, 80, 3072, 3072, 16
+    assert n * cin * h * w > 2 ** 31
+    g = torch.Generator(device='cuda').manual_seed(7)
+    x = torch.randn(n, cin, h, w, device='cuda', dtype=torch.bfloat16, generator=g).contiguous(memory_format=torch.channels_last)
+    wgt = (torch.randn(cout, cin, 3, 3, device='cuda', generator=g) * 0.1).to(torch.bfloat16).float().requires_grad_(True)
+    xa = x.detach().requires_grad_(True)
+    assert ops.conv2d_supported(xa, wgt, 1)
+    y = ops.conv2d(xa, wgt, None, 1, 1, 1, out_dtype=torch.bfloat16)
+    gy = torch.randn(y.shape, device='cuda', dtype=torch.bfloat16, generator=g).contiguous(memory_format=torch.channels_last)
+    y.backward(gy)
+    for (i, r0, c0) in ((n - 1, h - 64, w - 64), (n - 1, 0, w - 64), (0, 0, 0), (1, 1500, 1500)):
+        crop = x[i:i + 1, :, max(r0 - 1, 0):r0 + 65, max(c0 - 1, 0):c0 + 65].float()
+        ref = F.conv2d(crop, wgt.detach(), None, 1, 1)
+        dr, dc = (1 if r0 > 0 else 0), (1 if c0 > 0 else 0)
+        inner = ref[:, :, dr:dr + 62, dc:dc + 62]                    # away from the crop's own zero padding
+        got = y[i:i + 1, :, r0 + (0 if r0 else 0):r0 + 62, c0:c0 + 62].float()
+        torch.testing.assert_close(got, inner, rtol=1e-2, atol=2e-2)
+        # data gradient: correlation of dy with the flipped kernel, same crop logic
+        gcrop = gy[i:i + 1, :, max(r0 - 1, 0):r0 + 65, max(c0 - 1, 0):c0 + 65].float()
+        dref = F.conv_transpose2d(gcrop, wgt.detach(), None, 1, 1)[:, :, dr:dr + 62, dc:dc + 62]
+        torch.testing.assert_close(xa.grad[i:i + 1, :, r0:r0 + 62, c0:c0 + 62].float(), dref, rtol=1e-2, atol=2e-2)
+    # weight gradient against torch's own over the whole tensor (float32 accumulation over 28 M pixels of bf16 products)
+    dw_ref = torch.zeros_like(wgt)
+    for i in range(n):                                               # one image at a time: keeps the reference within 2^31 too
+        dw_ref += torch.nn.grad.conv2d_weight(x[i:i + 1].float(), wgt.shape, gy[i:i + 1].float(), 1, 1)
+    scale = dw_ref.abs().max()
+    assert (wgt.grad - dw_ref).abs().max() <= 2e-2 * scale, ((wgt.grad - dw_ref).abs().max(), scale)
