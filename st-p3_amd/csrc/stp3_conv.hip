@@ -143,11 +143,8 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
     const bool pointwise = taps == 1 && d.pad_h == 0 && d.pad_w == 0 && (d.Ho - 1) * d.stride < d.H &&
                            (d.Wo - 1) * d.stride < d.W;
 
-    // TWO register sets (first-class vectors: HIP's uint4, a struct, ends up in scratch here): the loads of K-step s + 2
-    // are issued while step s is multiplied, so every load has two steps of MFMA time to land.  Both kernels are bound by
-    // their LDS footprint (3 / 2 workgroups per CU), so the second set costs no occupancy.
-    u32x4 ra0[4], rb0[BN / 32], ra1[4], rb1[BN / 32];
-    auto load_step = [&](u32x4 (&ra)[4], u32x4 (&rb)[BN / 32]) {   // the piece of the current (tap, ci) for every row of this thread
+    u32x4 ra[4], rb[BN / 32];                              // first-class vectors: HIP's uint4 (a struct) ends up in scratch here
+    auto load_step = [&]() {                               // the piece of the current (tap, ci) for every row of this thread
         const bool kvalid = tap < taps;
         const int dh = kh * d.dil_h, dw = kw * d.dil_w;
         const int toff = (dh * d.W + dw) * d.ldx + ci;
@@ -172,7 +169,7 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
             if (++kw == d.KW) { kw = 0; ++kh; }
         }
     };
-    auto store_step = [&](uint8_t* buf, const u32x4 (&ra)[4], const u32x4 (&rb)[BN / 32]) {
+    auto store_step = [&](uint8_t* buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(buf + lds_piece(rr + 32 * i, j)) = ra[i];
 #pragma unroll
@@ -188,8 +185,13 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int steps = (d.Ktot + kBK - 1) / kBK;
+    load_step();
+    store_step(smem);
+    __syncthreads();
     const int frow = lane & 31, fk = lane >> 5;            // fragment row / which 8-k half of a 16-k MFMA step
-    auto multiply = [&](const uint8_t* cur) {
+    for (int s = 0; s < steps; ++s) {
+        uint8_t* cur = smem + (s & 1) * kStage;
+        if (s + 1 < steps) load_step();
 #pragma unroll
         for (int ks = 0; ks < kBK / 16; ++ks) {
             Frag fa[TC], fb[TP];
@@ -205,22 +207,7 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
                 for (int b = 0; b < TP; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a].v, fb[b].v, acc[a][b], 0, 0, 0);
         }
-    };
-    // steps are loaded strictly in order: 0 (set 0, stored at once), 1 (set 0), 2 (set 1), then alternately
-    load_step(ra0, rb0);
-    store_step(smem, ra0, rb0);
-    if (steps > 1) load_step(ra0, rb0);
-    if (steps > 2) load_step(ra1, rb1);
-    __syncthreads();
-    for (int s = 0; s < steps; s += 2) {
-        multiply(smem);                                                     // step s; set 0 holds s + 1, set 1 holds s + 2
-        if (s + 1 < steps) store_step(smem + kStage, ra0, rb0);
-        if (s + 3 < steps) load_step(ra0, rb0);
-        __syncthreads();
-        if (s + 1 >= steps) break;
-        multiply(smem + kStage);                                            // step s + 1; set 1 holds s + 2, set 0 holds s + 3
-        if (s + 2 < steps) store_step(smem, ra1, rb1);
-        if (s + 4 < steps) load_step(ra1, rb1);
+        if (s + 1 < steps) store_step(smem + ((s + 1) & 1) * kStage);
         __syncthreads();
     }
 
