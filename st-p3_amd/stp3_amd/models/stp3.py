@@ -11,8 +11,8 @@ voxel-pool / discounted-accumulate kernel), so the 1.5 GB lifted tensor and the 
 syncs of the reference never exist.
 
 The prediction stage (``N_FUTURE_FRAMES > 0``: ``present_distribution``, ``future_prediction``, stp3.py:69-87, 157-176)
-is wired in as in the reference; the planner (``PLANNING.ENABLED``) raises
-``NotImplementedError``.
+and the planner (``PLANNING.ENABLED``: ``planning``, stp3.py:104-107) are wired in as in
+the reference; ``forward`` then also returns the present frame's front-camera features (``cam_front``) for the planner.
 """
 import torch
 import torch.nn as nn
