@@ -140,6 +140,27 @@ class PyramidSpatioTemporalPooling(nn.Module):
                 ('conv_bn_relu', conv_1x1x1_norm_activated(in_channels, reduction_channels))])))
         self.features = nn.ModuleList(feats)
 
+    def whole_plane_members(self, x, extra=None, folded=None):
+        """The whole-plane pooling branches (the reference's only setting) as members of a ``fused.bn_act_group`` plus the
+        function that turns each member's output into ``forward``'s (B, C', T, 1, 1) -- or None when a branch pools
+        smaller windows (then ``forward`` is the way).  Their BatchNorms are siblings of the pointwise convolutions at the
+        head of the temporal block: one statistics exchange for all of them."""
+        b, c, t, h, w = x.shape
+        if folded is None or any((ph, pw) != (h, w) for _, ph, pw in self.pool_sizes):
+            return None
+        members, finish = [], []
+        for f in self.features:
+            sp = plane_mean(folded).view(b, t, c).permute(0, 2, 1)[..., None, None]
+            if extra is not None:
+                sp = torch.cat([sp, hp(extra).view(b, -1, t, 1, 1)], dim=1)
+            pooled = torch.cat([sp[:, :, :1], 0.5 * (sp[:, :, 1:] + sp[:, :, :-1]), sp[:, :, -1:]], dim=2)
+            cbr = f.conv_bn_relu
+            y = conv1x1_on_vector(pooled.to(x.dtype), cbr.conv.weight)                       # (B, C', T + 1, 1, 1)
+            co = y.shape[1]
+            members.append(dict(bn=cbr.norm, x=y.permute(0, 2, 1, 3, 4).reshape(b * (t + 1), co, 1, 1), act=ACT_RELU))
+            finish.append(lambda o, co=co: o.view(b, t + 1, co, 1, 1).permute(0, 2, 1, 3, 4)[:, :, :-1])
+        return members, finish
+
     def forward(self, x, extra=None, folded=None):
         """``extra`` (B, E, T): channels that are constant over each frame's plane (the ego-motion planes of
         stp3.py:145-152) -- their window mean is the value itself, so they join after the spatial mean.
@@ -251,7 +272,13 @@ class TemporalBlock(nn.Module):
         heads.append(self._pointwise_member(self.convolution_paths[-1], x2, extra2=extra2, lanes=lanes))
         if self.projection is not None:
             heads.append(self._pointwise_member(self.projection, x2, relu=False, extra2=extra2))
+        n_pointwise = len(heads)
+        pooled_group = self.pyramid_pooling.whole_plane_members(x, extra, folded=x2) if self.use_pyramid_pooling else None
+        if pooled_group is not None:
+            heads += pooled_group[0]
         heads = bn_act_group(heads)
+        pooled_outs = None if pooled_group is None else [fin(o) for fin, o in zip(pooled_group[1], heads[n_pointwise:])]
+        heads = heads[:n_pointwise]
         outs = [path[1].forward_folded(y, b, t) for path, y in zip(self.convolution_paths[:-1], heads)]
         outs.append(heads[len(self.convolution_paths) - 1])
         paths = torch.cat(outs, dim=1)
@@ -261,7 +288,7 @@ class TemporalBlock(nn.Module):
         sbias = None
         if self.use_pyramid_pooling:
             off = self._paths_channels
-            for pooled in self.pyramid_pooling(x, extra, folded=x2):     # (B, C', T, h', w')
+            for pooled in (pooled_outs if pooled_outs is not None else self.pyramid_pooling(x, extra, folded=x2)):   # (B, C', T, h', w')
                 cp = pooled.shape[1]
                 p2 = pooled.permute(0, 2, 1, 3, 4).reshape(b * t, cp, *pooled.shape[-2:])
                 contrib = (conv1x1_on_vector(p2.to(y.dtype), wgt[:, off:off + cp].to(y.dtype))

@@ -9,7 +9,7 @@ normal fan_out, last BN gamma of every block zero).  PARITY UNPINNED against the
 """
 import torch.nn as nn
 
-from ..layers.fused import ACT_NONE, ACT_RELU, RES_BEFORE_ACT, bn_act, conv_module
+from ..layers.fused import ACT_NONE, ACT_RELU, RES_BEFORE_ACT, bn_act, bn_act_group, conv_module
 
 
 class BasicBlock(nn.Module):
@@ -26,8 +26,14 @@ class BasicBlock(nn.Module):
                                             nn.BatchNorm2d(out_ch))
 
     def forward(self, x):
-        skip = x if self.downsample is None else bn_act(self.downsample[1], conv_module(self.downsample[0], x), ACT_NONE)
-        y = bn_act(self.bn1, conv_module(self.conv1, x), ACT_RELU)
+        if self.downsample is None:
+            skip = x
+            y = bn_act(self.bn1, conv_module(self.conv1, x), ACT_RELU)
+        else:
+            # the down-sampling skip and the first convolution read the same tensor: sibling BatchNorms, one statistics
+            # exchange for both when the statistics are shared between ranks (fused.bn_act_group)
+            skip, y = bn_act_group([dict(bn=self.downsample[1], x=conv_module(self.downsample[0], x), act=ACT_NONE),
+                                    dict(bn=self.bn1, x=conv_module(self.conv1, x), act=ACT_RELU)])
         return bn_act(self.bn2, conv_module(self.conv2, y), ACT_RELU, res=skip, res_mode=RES_BEFORE_ACT)
 
 

@@ -190,10 +190,11 @@ _MEMBER_OPS = {'bn_act': ops._BnAct, 'conv_bn_act': _ConvBnAct}
 
 
 class _ExchangeGroup(torch.autograd.Function):
-    """SIBLING BatchNorm operators -- parallel branches that read the same tensor: the five ASPP branches, the four
-    pointwise convolutions at the head of a temporal block, the decoder heads -- as ONE autograd node, so that their
+    """SIBLING BatchNorm operators -- parallel branches that read the same tensor: the five ASPP branches, the
+    pointwise convolutions and the pooled descriptor at the head of a temporal block, the decoder heads, a ResNet block's
+    down-sampling skip and first convolution -- as ONE autograd node, so that their
     cross-replica statistics travel in one all-reduce per pass instead of one per layer (forward [2C] sums, backward
-    [3C] sums; 44 of the 258 exchanges of a BASELINE configs[2] step at N > 1).  The members are the ordinary operators run as generators
+    [3C] sums; 52 of the 258 exchanges of a BASELINE configs[2] step at N > 1).  The members are the ordinary operators run as generators
     (``forward_steps`` / ``backward_steps``): same kernels, same arithmetic, same order per member."""
 
     @staticmethod
