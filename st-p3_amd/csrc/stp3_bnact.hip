@@ -493,7 +493,7 @@ __global__ __launch_bounds__(kThreads) void bn_apply_bwd_kernel(
     // FOUR constants per channel instead of (mean, invstd, gamma, beta, k0, k1): the pre-activation is the forward's
     // pre = s x + t (s = gamma invstd, t = beta - mean s) and dx = gamma invstd (g - k0 - xhat k1) = s g + a2 x + a3 with
     // a2 = -s invstd k1, a3 = -s k0 - a2 mean.  The kernel held 166 registers (3 waves per SIMD, 2.4 resident on average:
-    // profiles/r03w) and a streaming kernel lives on the bytes it keeps in flight.
+    // profiles/r03w_bn_pmc.txt) and a streaming kernel lives on the bytes it keeps in flight.
     float cs[VEC], ct[VEC], a2[VEC], a3[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
     // Workgroup order.  As dispatched (tile, tap, split) the nine taps of a pixel split land on nine different XCDs and each
     // pulls its own copy of the dY / X rows through its own L2 (PMC: 7 % hit rate, 4.3x the operands fetched).  With
     // `xcd_chunks` (set by the launcher) XCD x runs a contiguous chunk of that order instead -- the taps of a split share
-    // one L2: 3x3 64 -> 64 @200x200x12 173 -> 108 us, 3x3 d12 64 -> 128 246 -> 157 us (profiles/r03r_*).  (On the round-2
+    // one L2: 3x3 64 -> 64 @200x200x12 173 -> 108 us, 3x3 d12 64 -> 128 246 -> 157 us (profiles/r03r_time_conv_wgrad_xcd.txt).  (On the round-2
     // kernel, which was bound by its instruction count, the same order was SLOWER; it also is for 49 taps.)
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (xcd_chunks) {
