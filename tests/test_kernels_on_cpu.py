@@ -29,7 +29,7 @@ import build as hipcpu_build  # noqa: E402
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
 ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
            ('conv', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
-           ('lift_c64_frames', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
+           ('lift_c64_frames', {}), ('lift_c64_rows56', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
 ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)]
 MODEL = [('lift_full', {}), ('model_step_two_ranks', {}), ('model_step_f32_full_losses', {}), ('model_step_f32', {}),
@@ -218,6 +218,12 @@ def test_voxel_pool_32_rows(results):
 
 def test_voxel_pool_many_runs_per_voxel(results):
     _check_lift(_get(results, 'lift_c64_many_runs'))
+
+
+def test_voxel_pool_tall_columns_at_64_channels(results):
+    """56 rows per column at C = 64: beyond the 32 rows of the matrix-core kernels, so the general column / backward kernels
+    at the channel count of the model."""
+    _check_lift(_get(results, 'lift_c64_rows56'))
 
 
 def test_voxel_pool_matrix_core_kernels_over_frames(results):
