@@ -1,0 +1,101 @@
+"""TEST INFRASTRUCTURE (build container only) -- the segmentation-IoU fixture of BASELINE configs[1]: B = 4, T = 3, the whole
+reference ``STP3.forward`` (stp3/models/stp3.py:132-184) in eval mode on the CPU, float32, name-derived weights.
+
+    python oracle/make_golden_iou.py        -> tests/golden/iou_b4.npz
+
+With the plain deterministic fill every BEV pixel comes out "vehicle" (MANIFEST: tp 1472 / fp 38327 / fn 0 at B = 1): an
+arg-max that never flips cannot fail an IoU criterion.  Here the bias of the class-1 output of the segmentation and the
+pedestrian head (decoder.py:42-66: the last 1x1 convolution of the head) is shifted by a constant so that 10 % / 5 % of
+the pixels are predicted positive -- the decision boundary then runs through the bulk of the logit-difference
+distribution, thousands of pixels lie within a bf16 rounding of it, and every one that flips moves tp / fp / fn.  The
+shifts are stored and applied to the product's heads by the test (same parameter, same value).
+
+Two label sets per head (evaluate.py:95-98 / metrics.py:37-65 protocol: arg-max over the class dimension, per-class
+tp / fp / fn, IoU = tp / (tp + fp + fn) of class 1; present frame = index receptive_field - 1, and all frames):
+  * ``synthetic``: the random blob labels of stp3_amd.synthetic (IoU ~ 0.02: the labels know nothing of the prediction);
+  * ``pseudo``:    the reference's own prediction with the blob pixels flipped (IoU ~ 0.75): every flipped arg-max changes
+                   the score, the sensitive case.
+Stored: shifts, strided samples of the logits, the reference's prediction maps as bit masks, both label sets (bit masks),
+tp / fp / fn for each (head, label set, frame range).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'st-p3_amd'))
+
+from oracle import ref_stubs  # noqa: E402
+from stp3_amd import synthetic  # noqa: E402
+from stp3_amd.config import perception_cfg  # noqa: E402
+from stp3_amd.models.efficientnet import EfficientNet as OurEfficientNet  # noqa: E402
+from stp3_amd.models.resnet import resnet18 as our_resnet18  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+BATCH, SEED = 4, 7
+HEADS = {'segmentation': ('segmentation_head', 0.10), 'pedestrian': ('pedestrian_head', 0.05)}
+
+
+def counts(pred, tgt):
+    """metrics.py:37-65 for class 1 of a two-class map: tp, fp, fn."""
+    return np.array([int(((pred == 1) & (tgt == 1)).sum()), int(((pred == 1) & (tgt == 0)).sum()),
+                     int(((pred == 0) & (tgt == 1)).sum())], dtype=np.int64)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count() or 8)
+    ref_stubs.install(efficientnet_cls=OurEfficientNet, resnet18_fn=our_resnet18)
+    from stp3.models.stp3 import STP3
+    cfg = perception_cfg()
+    ref = H.fill_deterministic(STP3(cfg)).eval()
+    batch = synthetic.make_batch(batch=BATCH, seq=3, seed=SEED)
+    out = {}
+    with torch.no_grad():
+        o = ref(batch['image'], batch['intrinsics'], batch['extrinsics'], batch['future_egomotion'])
+        for key, (attr, frac) in HEADS.items():
+            diff = (o[key][:, :, 1] - o[key][:, :, 0]).flatten()
+            shift = np.float32(-torch.quantile(diff.double(), 1.0 - frac).item())
+            last = getattr(ref.decoder, attr)[-1]
+            assert last.bias is not None and last.bias.shape == (2,)
+            last.bias[1] += float(shift)
+            out[f'shift/{key}'] = np.array([shift], dtype=np.float32)
+        o = ref(batch['image'], batch['intrinsics'], batch['extrinsics'], batch['future_egomotion'])
+    present = ref.receptive_field - 1
+    summary = {}
+    for key in HEADS:
+        logits = o[key]
+        pred = logits.argmax(dim=2)                                       # (B, T, 200, 200)
+        blobs = batch[key][:, :, 0]
+        pseudo = pred ^ blobs
+        out[f'logits/{key}'] = H.sample(logits, 4096).numpy()
+        margin = (logits[:, :, 1] - logits[:, :, 0]).abs()
+        out[f'pred/{key}'] = np.packbits(pred.numpy().astype(bool).reshape(BATCH * 3, -1), axis=1)
+        out[f'pseudo/{key}'] = np.packbits(pseudo.numpy().astype(bool).reshape(BATCH * 3, -1), axis=1)
+        for lname, tgt in (('synthetic', blobs), ('pseudo', pseudo)):
+            for fname, sl in (('present', slice(present, None)), ('all', slice(None))):
+                c = counts(pred[:, sl].numpy(), tgt[:, sl].numpy())
+                out[f'counts/{key}/{lname}/{fname}'] = c
+                summary[f'{key}/{lname}/{fname}'] = {'tp_fp_fn': c.tolist(), 'iou': c[0] / max(1, c.sum())}
+        summary[f'{key}/positive_fraction'] = float(pred.float().mean())
+        summary[f'{key}/pixels_within_1e-2_of_the_boundary'] = int((margin < 1e-2).sum())
+        summary[f'{key}/pixels_within_1e-3_of_the_boundary'] = int((margin < 1e-3).sum())
+        summary[f'{key}/logit_difference_std'] = float((logits[:, :, 1] - logits[:, :, 0]).std())
+    np.savez_compressed(os.path.join(GOLDEN, 'iou_b4.npz'), **out)
+    man_path = os.path.join(GOLDEN, 'MANIFEST.json')
+    man = json.load(open(man_path))
+    man['iou_b4'] = {'file': 'iou_b4.npz', 'generator': 'oracle/make_golden_iou.py', 'batch': BATCH, 'seed': SEED,
+                     'what': 'reference STP3.forward, eval mode, float32 CPU, B=4 T=3; class-1 bias of the segmentation / '
+                             'pedestrian heads shifted so that 10 % / 5 % of the pixels are positive',
+                     'summary': summary}
+    json.dump(man, open(man_path, 'w'), indent=1, sort_keys=True)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == '__main__':
+    main()

@@ -93,6 +93,20 @@ def to_float64(ref):
     return lambda: setattr(ref_stp3, 'VoxelsSumming', RefVS)
 
 
+def topk_ratios(over):
+    """The top-k ratios in the order the reference's losses sort (trainer.py:122-150: segmentation, pedestrian, then the
+    hdmap elements)."""
+    cfg = perception_cfg(**over)
+    seg = cfg.SEMANTIC_SEG
+    out = []
+    if seg.VEHICLE.USE_TOP_K:
+        out.append(seg.VEHICLE.TOP_K_RATIO)
+    if seg.PEDESTRIAN.USE_TOP_K:
+        out.append(seg.PEDESTRIAN.TOP_K_RATIO)
+    out += [r for r, use in zip(seg.HDMAP.TOP_K_RATIO, seg.HDMAP.USE_TOP_K) if use]
+    return out
+
+
 def variant_cfg(variant):
     variant = variant.rstrip('d')
     batch, topk = int(variant[1:variant.index('k')]), variant.endswith('k1')
@@ -115,10 +129,32 @@ def run_variant(variant, TrainingModule):
     batch = synthetic.make_batch(batch=batch_size, seq=3, seed=5, gt_depth=True, instance=True)
     if f64:
         batch['image'] = batch['image'].double()
-    output, labels, loss = ref.shared_step(batch, True)
+    # the pixels the reference's top-k losses SELECT (losses.py:76-81, :108-111: a descending sort, the first k kept):
+    # recorded from its own torch.sort calls, so that a test can hand the product the very same selection
+    picked, real_sort = [], torch.sort
+
+    def recording_sort(x, *a, **kw):
+        res = real_sort(x, *a, **kw)
+        if kw.get('descending') and x.dim() in (2, 3):
+            picked.append(res[1].detach())
+        return res
+    torch.sort = recording_sort
+    try:
+        output, labels, loss = ref.shared_step(batch, True)
+    finally:
+        torch.sort = real_sort
     total = sum(loss.values())
     total.backward()
     out = dict(taps.collect())
+    for i, idx in enumerate(picked):
+        # the reference keeps idx[..., :k] with k = int(ratio * P): stored as one bit per pixel and row
+        rows = idx.reshape(-1, idx.shape[-1])
+        ratio = topk_ratios(over)[i]
+        k = int(ratio * rows.shape[1])
+        mask = torch.zeros(rows.shape, dtype=torch.bool)
+        mask.scatter_(1, rows[:, :k], True)
+        out[f'topk/{i}/mask'] = np.packbits(mask.numpy(), axis=1)
+        out[f'topk/{i}/k'] = np.array([k], dtype=np.int64)
     for k, v in loss.items():
         out[f'loss/{k}'] = np.array([v.item()], dtype=np.float64)
     out['loss_total'] = np.array([total.item()], dtype=np.float64)

@@ -32,13 +32,12 @@ def _mod(name, **attrs):
 
 def polygon(r, c, shape=None):
     """Restatement of ``skimage.draw.polygon`` (scikit-image is a dependency of the reference that is NOT installed
-    here: stp3/cost.py:7, stp3/metrics.py:12; no version pinned by the reference's environment file beyond the
-    package name).  Published algorithm (skimage/draw/_draw.pyx ``_polygon`` + skimage/_shared/geometry.pxd
+    here: stp3/cost.py:7, stp3/metrics.py:12; the reference's environment.yml pins scikit-image=0.18.1).  Published algorithm (skimage/draw/_draw.pyx ``_polygon`` + skimage/_shared/geometry.pxd
     ``point_in_polygon``): every integer (row, column) of the vertices' bounding box -- rows max(0, floor-int of
     min r) .. ceil(max r), the same for columns -- is tested with the even-odd crossing rule; points are emitted
-    row by row, columns ascending.  Releases >= 0.19 additionally count points lying EXACTLY on an edge or vertex as
-    inside; the two variants agree whenever no integer point lies on the boundary, which holds for every footprint
-    the reference builds (non-integer box corners) and is asserted by the product's own rasteriser.
+    row by row, columns ascending.  This is the rule of the pinned 0.18.1; releases >= 0.19 additionally count points
+    lying EXACTLY on an edge or vertex as inside -- the two agree whenever no integer point lies on the boundary, which
+    holds for every footprint the default configuration builds (non-integer box corners).
     Anchor in the reference itself: stp3/metrics.py:313 documents 32 footprint cells for the default ego box."""
     import numpy as np
     r = np.asarray(r, dtype=np.float64)

@@ -29,30 +29,27 @@ def gen_dx_bx(xbound, ybound, zbound):
 
 def footprint_cells(corners_rc):
     """Integer (row, column) points inside the polygon with vertices ``corners_rc`` (float64 (V, 2)), in the order
-    skimage.draw.polygon emits them (row by row, columns ascending); even-odd crossing rule evaluated in float64."""
+    skimage.draw.polygon emits them (row by row, columns ascending).  Rule: the even-odd crossing test of
+    scikit-image 0.18.1 -- the version the reference's environment.yml pins -- evaluated in float64
+    (skimage/_shared/geometry.pxd ``point_in_polygon``: an edge is crossed by the rows r0 <= y < r1, half-open, and
+    counts when the point lies strictly left of it).  A lattice point exactly ON the outline is therefore decided by
+    that same half-open test (bottom / left edges in, top / right edges out for an axis-aligned box), as in the pinned
+    release; releases from 0.19 on count every outline point as inside instead, which differs only for EGO / LIFT
+    configurations whose box edges fall on cell boundaries (the default 1.85 m x 4.084 m box never does)."""
     r, c = np.asarray(corners_rc, dtype=np.float64).T
     rows = np.arange(int(max(0.0, r.min())), int(np.ceil(r.max())) + 1)
     cols = np.arange(int(max(0.0, c.min())), int(np.ceil(c.max())) + 1)
     yy, xx = np.meshgrid(rows.astype(np.float64), cols.astype(np.float64), indexing='ij')
     inside = np.zeros(yy.shape, dtype=bool)
-    on_outline = np.zeros(yy.shape, dtype=bool)
     for i in range(len(r)):
         j = i - 1
         r0, c0, r1, c1 = r[i], c[i], r[j], c[j]
-        # distance of every lattice point to the segment: a point ON the outline is where the published variants of
-        # the rasteriser disagree
-        seg = np.array([r1 - r0, c1 - c0])
-        rel = np.stack([yy - r0, xx - c0], axis=-1)
-        tt = np.clip((rel @ seg) / max(seg @ seg, 1e-300), 0.0, 1.0)
-        on_outline |= np.hypot(rel[..., 0] - tt * seg[0], rel[..., 1] - tt * seg[1]) < 1e-9
         if r0 == r1:
             continue                                      # a horizontal edge is never crossed by the half-open row test
         spans = ((r0 <= yy) & (yy < r1)) | ((r1 <= yy) & (yy < r0))
         with np.errstate(invalid='ignore', divide='ignore'):
             at = (c1 - c0) * (yy - r0) / (r1 - r0) + c0
         inside ^= spans & (xx < at)
-    if (on_outline & ~inside).any() or (on_outline & inside).any():
-        raise ValueError('ego footprint: a BEV lattice point lies exactly on the box outline (rasteriser variants differ)')
     rr, cc = np.nonzero(inside)
     return np.stack([rows[rr], cols[cc]], axis=-1).astype(np.int64)
 
@@ -74,15 +71,17 @@ class BaseCost(nn.Module):
     def footprint(self, lambda_=0):
         """(K, 2) int64 numpy (row, column) cells of the ego box inflated by ``lambda_`` metres; the box is centred
         0.5 m ahead of the ego origin (cost.py:70-83).  Depends on the configuration only: cached."""
-        if lambda_ not in self._cells:
+        key = (lambda_, self.dx._version, self.bx._version)       # load_state_dict copies in place: the version moves
+        if key not in self._cells:
             h, w = self.H, self.W
             pts = np.array([[-h / 2. + 0.5 - lambda_, w / 2. + lambda_], [h / 2. + 0.5 + lambda_, w / 2. + lambda_],
                             [h / 2. + 0.5 + lambda_, -w / 2. - lambda_], [-h / 2. + 0.5 - lambda_, -w / 2. - lambda_]])
             bx = self.bx.detach().cpu().numpy()
             dx = self.dx.detach().cpu().numpy()
             pts = (pts - bx) / dx                            # float64 - float32 -> float64, as in the reference
-            self._cells[lambda_] = footprint_cells(pts)      # (forward -> rows, lateral -> columns) already
-        return self._cells[lambda_]
+            self._cells = {k: v for k, v in self._cells.items() if k[1:] == key[1:]}      # drop stale grids
+            self._cells[key] = footprint_cells(pts)          # (forward -> rows, lateral -> columns) already
+        return self._cells[key]
 
     def get_origin_points(self, lambda_=0):
         return torch.from_numpy(self.footprint(lambda_)).to(device=self.bx.device)
@@ -261,14 +260,18 @@ class Cost_Function(nn.Module):
         self._tables = {}
 
     def _kernel_inputs(self, device):
-        """Footprint tables on the device and the scalar fields of ``stp3_plan_dims``, cached per device."""
-        key = str(device)
+        """Footprint tables on the device and the scalar fields of ``stp3_plan_dims``, cached per device and per VALUE
+        of the parameters they are cut from (their version counters: a ``load_state_dict`` after the first forward must
+        not leave the kernel path on the old grid / weights while the torch statements read the new ones)."""
+        s = self.safetycost
+        key = (str(device), s.dx._version, s.bx._version, s.w._version)
         if key not in self._tables:
-            s = self.safetycost
+            self._tables = {k: v for k, v in self._tables.items() if k[1:] == key[1:]}
             inflate = int(s._lambda / float(s.dx[0]))
             fp0 = torch.from_numpy(s.footprint(0)).to(device=device, dtype=torch.int32).contiguous()
             fpl = torch.from_numpy(s.footprint(inflate)).to(device=device, dtype=torch.int32).contiguous()
             dx, bx, w = s.dx.detach().cpu(), s.bx.detach().cpu(), s.w.detach().cpu()
+            dx, bx, w = [float(v) for v in dx], [float(v) for v in bx], [float(v) for v in w]      # values, not views
             params = dict(dx0=dx[0], dx1=dx[1], bx0=bx[0], bx1=bx[1], safety=s.factor, headway=self.headwaycost.factor,
                           lrdivider=self.lrdividercost.factor, comfort=self.comfortcost.factor,
                           progress=self.progresscost.factor, volume=self.costvolume.factor, rule=self.rulecost.factor,

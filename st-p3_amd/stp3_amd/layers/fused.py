@@ -227,10 +227,12 @@ def conv_bn_act_member(x, conv, bn, act):
     return dict(bn=bn, x=conv_module(conv, x), act=act)
 
 
-# Dense convolutions.  Every bf16 (autocast) convolution on the GPU -- forward, data gradient and weight gradient, all
-# layer shapes of the model, the 3-channel stem included (its channels are zero-padded to 8) -- runs on the hand-written
-# MFMA implicit-GEMM kernels of stp3_conv.hip; no vendor convolution is on the benchmarked path.  Float32 tensors outside
-# autocast (the float32 parity runs) and CPU tensors take torch's convolution.
+# Dense convolutions.  Every convolution on the GPU -- forward, data gradient and weight gradient, all layer shapes of the
+# model, the 3-channel stem included (its channels are zero-padded to 8) -- runs on the hand-written MFMA implicit-GEMM
+# kernels of stp3_conv.hip: bf16 tensors and anything under autocast directly (the benchmarked path), FLOAT32 tensors
+# outside autocast (the float32 legs of the parity tests) through the three-term bf16 split of ``ops.conv2d_f32`` --
+# float32-accurate on the same kernels, so that the tight float32 / float64 parity chain pins ``conv2d_igemm_kernel`` and
+# ``conv2d_wgrad_kernel`` at the step's real shapes.  No vendor convolution on the GPU; CPU tensors and float64 take torch's.
 def _use_mfma(x, weight, stride):
     if not x.is_cuda:
         return False
@@ -239,9 +241,16 @@ def _use_mfma(x, weight, stride):
     return ops.conv2d_supported(x, weight, stride)
 
 
+def _use_mfma_f32(x, weight, stride):
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and ops.conv2d_supported(x, weight, stride))
+
+
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     if _use_mfma(x, weight, stride):
         return ops.conv2d(x, weight, bias, stride, padding, dilation)
+    if _use_mfma_f32(x, weight, stride):
+        return ops.conv2d_f32(x, weight, bias, stride, padding, dilation)
     return F.conv2d(x, weight, bias, stride, padding, dilation)
 
 

@@ -63,7 +63,7 @@ class StaticSamePadConv2d(nn.Conv2d):
             # squeeze-excite 1x1 convs on a pooled 1x1 map are plain GEMMs
             y = F.linear(x.flatten(1), self.weight.flatten(1), self.bias)
             return y.view(*y.shape, 1, 1)
-        if self.groups == 1 and x.is_cuda and self.in_channels % 8 and torch.is_autocast_enabled():
+        if self.groups == 1 and x.is_cuda and self.in_channels % 8 and (torch.is_autocast_enabled() or x.dtype == torch.float32):
             # the 3-channel stem: zero-pad the channels to 8 (together with the "same" padding, one copy) so that
             # it runs on the MFMA kernel too; the padded weight columns are zero and their gradient is dropped
             cp = (-self.in_channels) % 8
@@ -74,7 +74,8 @@ class StaticSamePadConv2d(nn.Conv2d):
                 # instead of a float32 pad, a cast and a layout change (0.6 ms per step)
                 n, c, h, w = x.shape
                 left, right, top, bottom = self._pad
-                xp = torch.empty((n, c + cp, h + top + bottom, w + left + right), dtype=torch.get_autocast_dtype('cuda'),
+                xp = torch.empty((n, c + cp, h + top + bottom, w + left + right),
+                                 dtype=torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else x.dtype,
                                  device=x.device, memory_format=torch.channels_last).zero_()
                 xp[:, :c, top:top + h, left:left + w] = x
                 x = xp

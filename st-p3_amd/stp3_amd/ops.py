@@ -454,9 +454,12 @@ def _dw_weight_taps(weight):
     ent = _DW_WEIGHT_CACHE.get(key)
     if ent is None or ent[0]() is not weight or ent[1] != stamp:
         wt = weight.detach().float().reshape(c, k * k).t().contiguous()
+        if ent is None or ent[0]() is not weight:
+            # one finalizer per parameter OBJECT, not one per optimizer step (they would pile up in
+            # weakref.finalize's registry for the whole run)
+            weakref.finalize(weight, _DW_WEIGHT_CACHE.pop, key, None)
         ent = (weakref.ref(weight), stamp, wt)
         _DW_WEIGHT_CACHE[key] = ent
-        weakref.finalize(weight, _DW_WEIGHT_CACHE.pop, key, None)
     return ent[2]
 
 
@@ -1178,7 +1181,7 @@ def _phase_taps(k, pad, stride, phase):
     return k - 1 - khs[-1], len(khs), top
 
 
-def _strided_dgrad(dy, wt, x_shape, stride, pad, cache):
+def _strided_dgrad(dy, wt, x_shape, stride, pad, cache, out_dtype=torch.bfloat16):
     """dL/dx of a stride-s convolution WITHOUT zero-stuffing dy to the input resolution: one stride-1 convolution per
     input phase (s x s of them, each over dy at ITS resolution with the taps that land on the phase), results
     interleaved into dx.  The zero-stuffed form multiplies s^2 - 1 zeros out of s^2 (decoder stem 7x7 / 2: 370 us where
@@ -1195,7 +1198,7 @@ def _strided_dgrad(dy, wt, x_shape, stride, pad, cache):
             if th is not None and tw is not None and (th[2] < 0 or tw[2] < 0):
                 return None
             plans.append((ph, pw, th, tw))
-    dx = torch.empty((n, cin, h, w), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    dx = torch.empty((n, cin, h, w), dtype=out_dtype, device=dy.device, memory_format=torch.channels_last)
     for ph, pw, th, tw in plans:
         rows, cols = (h - ph + stride - 1) // stride, (w - pw + stride - 1) // stride
         if rows <= 0 or cols <= 0:
@@ -1209,12 +1212,12 @@ def _strided_dgrad(dy, wt, x_shape, stride, pad, cache):
             sub = wt[:, :, th[0]::stride, tw[0]::stride].contiguous(memory_format=torch.channels_last)
             if cache is not None:
                 cache[key] = sub
-        part = _conv2d_launch(dy, sub, None, 1, (th[2], tw[2]), (1, 1), torch.bfloat16, out_hw=(rows, cols))
+        part = _conv2d_launch(dy, sub, None, 1, (th[2], tw[2]), (1, 1), out_dtype, out_hw=(rows, cols))
         dx[:, :, ph::stride, pw::stride] = part
     return dx
 
 
-def conv2d_data_grad(dy, wb, weight_ref, x_shape, stride, pad, dil):
+def conv2d_data_grad(dy, wb, weight_ref, x_shape, stride, pad, dil, out_dtype=torch.bfloat16):
     """dL/dx of a dense convolution on the MFMA kernel: a stride-1 convolution of dy with the taps flipped and
     Cin / Cout swapped -- per input phase for a strided layer (``_strided_dgrad``), over the zero-stuffed dy when that
     does not apply.  dy (N,Cout,Ho,Wo) bf16 channels-last; wb (Cout,Cin,KH,KW) bf16; ``weight_ref``: the parameter wb
@@ -1238,7 +1241,7 @@ def conv2d_data_grad(dy, wb, weight_ref, x_shape, stride, pad, dil):
     if stride > 1 and tuple(dil) == (1, 1):
         stuffed_flops = 2.0 * x_shape[0] * x_shape[2] * x_shape[3] * cout * cin * kh * kw
         if stuffed_flops >= 5e10:
-            dx = _strided_dgrad(dy, wt, x_shape, stride, pad, phase_cache)
+            dx = _strided_dgrad(dy, wt, x_shape, stride, pad, phase_cache, out_dtype)
     if dx is None:
         g = dy
         if stride > 1:
@@ -1249,7 +1252,7 @@ def conv2d_data_grad(dy, wb, weight_ref, x_shape, stride, pad, dil):
             uw = w + 2 * pad[1] - dil[1] * (kw - 1)
             g = torch.empty((n, cout, uh, uw), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last).zero_()
             g[:, :, ::stride, ::stride][:, :, :ho, :wo] = dy
-        dx = _conv2d_launch(g, wt, None, 1, bpad, dil, torch.bfloat16)
+        dx = _conv2d_launch(g, wt, None, 1, bpad, dil, out_dtype)
     return dx
 
 
@@ -1310,6 +1313,87 @@ class _Conv2dMfma(torch.autograd.Function):
 
 
 _CONV_APPLY = _fast_apply(_Conv2dMfma)
+
+
+# ----------------------------------------------------------------------------------------------
+# float32 convolutions on the SAME matrix-core kernels: three-term bf16 split
+# ----------------------------------------------------------------------------------------------
+def _split3(t):
+    """float32 t = hi + mid + lo exactly up to 2^-24 |t|, every term a bf16 number (8 significant bits each: the
+    subtractions are exact in float32)."""
+    t = t.float()
+    hi = t.to(torch.bfloat16)
+    r = t - hi.float()
+    mid = r.to(torch.bfloat16)
+    lo = (r - mid.float()).to(torch.bfloat16)
+    return hi, mid, lo
+
+
+# (a, b) term pairs of a product of two split operands, smallest first; the dropped ones (mid*lo, lo*mid, lo*lo) are
+# below 2^-24 of |a| |b|, i.e. below float32's own rounding of the product
+_SPLIT_PAIRS = ((1, 1), (0, 2), (2, 0), (0, 1), (1, 0), (0, 0))
+
+
+class _Conv2dSplit3(torch.autograd.Function):
+    """A FLOAT32 dense convolution -- forward, data gradient, weight gradient -- on the bf16 MFMA kernels of
+    stp3_conv.hip (``conv2d_igemm_kernel``, ``conv2d_wgrad_kernel``), float32-accurate: both operands are split into
+    three bf16 terms and the six significant term products are accumulated in float32 (the kernels' own accumulators,
+    float32 outputs).  Six launches per pass instead of one: this is not a fast path, it is how float32 tensors outside
+    autocast -- the float32 legs of the parity tests, which pin the step against the reference's float32 / float64
+    runs to 1e-5..1e-3 -- exercise the very kernels the bf16 step runs on, at the step's real shapes, instead of a
+    vendor convolution."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil):
+        _need_gpu(x, weight)
+        xs = _split3(x.detach())
+        ws = [t.contiguous(memory_format=torch.channels_last) for t in _split3(weight.detach())]
+        fb = _f32(bias)
+        y = None
+        for k, (i, j) in enumerate(_SPLIT_PAIRS):
+            last = k == len(_SPLIT_PAIRS) - 1
+            part = _conv2d_launch(xs[i], ws[j], fb if last else None, stride, pad, dil, torch.float32)
+            y = part if y is None else y.add_(part)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad, dil, bias is not None, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad, dil, has_bias, bdtype = ctx.cfg
+        cout_true, cin, kh, kw = weight.shape
+        dy = dy.float()
+        db = dy.sum(dim=(0, 2, 3)).to(bdtype) if has_bias and ctx.needs_input_grad[2] else None
+        w32 = weight.detach().float()
+        cpad = (-cout_true) % 8
+        if cpad:                                            # the 1 / 2 / 4-channel heads (see _Conv2dMfma.backward)
+            dy = torch.nn.functional.pad(dy, (0, 0, 0, 0, 0, cpad))
+            w32 = torch.nn.functional.pad(w32, (0, 0, 0, 0, 0, 0, 0, cpad))
+        cout = cout_true + cpad
+        dys = [t.contiguous(memory_format=torch.channels_last) for t in _split3(dy)]
+        dx = dw = None
+        bpad = (dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1])
+        if ctx.needs_input_grad[0]:
+            if bpad[0] < 0 or bpad[1] < 0:
+                raise _lib.Stp3HipError('conv2d (float32 route): padding larger than the kernel reach')
+            ws = [t.contiguous(memory_format=torch.channels_last) for t in _split3(w32)]
+            for i, j in _SPLIT_PAIRS:
+                part = conv2d_data_grad(dys[i], ws[j], None, x.shape, stride, pad, dil, out_dtype=torch.float32)
+                dx = part if dx is None else dx.add_(part)
+        if ctx.needs_input_grad[1]:
+            xs = _split3(x.detach())
+            for i, j in _SPLIT_PAIRS:
+                part = _conv2d_wgrad(dys[i], xs[j], (cout, cin, kh, kw), stride, pad, dil)
+                dw = part if dw is None else dw.add_(part)
+            dw = dw[:cout_true].to(weight.dtype)
+        return dx, dw, db, None, None, None
+
+
+def conv2d_f32(x, weight, bias=None, stride=1, padding=0, dilation=1):
+    """float32 in, float32 out, float32-accurate, on the MFMA kernels (``_Conv2dSplit3``)."""
+    s = _pair(stride)
+    return _Conv2dSplit3.apply(x, weight, bias, s[0], _pair(padding), _pair(dilation))
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, out_dtype=torch.bfloat16):

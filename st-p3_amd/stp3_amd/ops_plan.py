@@ -61,10 +61,12 @@ def traj_cost(cost_volume, trajs, occupancy, drivable, lane, target, fp0, fpl, p
     ``occupancy`` (B, T, H, W) any dtype (0 / 1); ``drivable`` / ``lane`` (B, H, W) preprocessed masks; ``target``
     (B, 2); ``fp0`` / ``fpl`` (K, 2) int32 footprint tables on the device; ``params``: the float fields of
     ``stp3_plan_dims``."""
-    dt = cost_volume.dtype
     cv = cost_volume.float().contiguous()
     tr = trajs[..., :2].float().contiguous()
     tgt = target.float().contiguous()
     fc, fo = _TrajCost.apply(cv, tr, occupancy.float().contiguous(), drivable.float().contiguous(),
                              lane.float().contiguous(), tgt, tgt.sum().reshape(1), fp0, fpl, params)
-    return (fc, fo) if dt == torch.float32 else (fc.to(dt), fo.to(dt))
+    # always float32, whatever the cost volume's dtype: the reference indexes a half-precision cost volume and ADDS the
+    # float32 terms (stp3/cost.py:36-47: the sum promotes to float32); rounding the costs to bf16 (spacing 0.25 .. 1 at
+    # their magnitude of 32 .. 200) would re-rank near-tied trajectories and quantise the max-margin hinge
+    return fc, fo

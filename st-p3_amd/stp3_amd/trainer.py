@@ -29,6 +29,17 @@ def _scalar():
     return nn.Parameter(torch.tensor(0.0), requires_grad=True)
 
 
+def _load_checkpoint_file(path, map_location, trust_pickle):
+    """torch.load of a checkpoint dictionary; safe (``weights_only=True``) unless the caller vouches for the file."""
+    if trust_pickle:
+        return torch.load(path, map_location=map_location, weights_only=False)
+    try:
+        return torch.load(path, map_location=map_location, weights_only=True)
+    except Exception as exc:                      # pickle.UnpicklingError of a disallowed global, mostly
+        raise RuntimeError(f'{path}: not loadable with weights_only=True ({type(exc).__name__}: {exc}); if the file is a '
+                           f'legacy Lightning checkpoint from a source you trust, pass trust_pickle=True') from exc
+
+
 class TrainingModule(nn.Module):
     def __init__(self, hparams):
         super().__init__()
@@ -274,12 +285,15 @@ class TrainingModule(nn.Module):
     # ------------------------------------------------------------------------------------------
     # checkpoint surface: what train.py:21-29 and evaluate.py:31 call on the reference's module
     @classmethod
-    def load_from_checkpoint(cls, checkpoint_path, map_location='cpu', strict=True, **overrides):
+    def load_from_checkpoint(cls, checkpoint_path, map_location='cpu', strict=True, trust_pickle=False, **overrides):
         """``TrainingModule.load_from_checkpoint(path, strict=True)`` of the Lightning surface (evaluate.py:31): the
         checkpoint is the dictionary Lightning writes -- ``hyper_parameters`` (the config as a plain dict,
         trainer.py:19) and ``state_dict`` (``model.*`` keys incl. the learned loss weights) -- and the module is
-        rebuilt from the former before the latter is loaded.  ``overrides`` replace top-level hyper-parameters."""
-        ckpt = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
+        rebuilt from the former before the latter is loaded.  ``overrides`` replace top-level hyper-parameters.
+        The file is read with ``weights_only=True`` (tensors, plain containers and scalars: what ``checkpoint()`` writes);
+        ``trust_pickle=True`` runs the full pickle machinery instead, for legacy Lightning files that carry other
+        objects -- only for files you trust, unpickling executes code."""
+        ckpt = _load_checkpoint_file(checkpoint_path, map_location, trust_pickle)
         hparams = ckpt.get('hyper_parameters', ckpt.get('hparams'))
         if hparams is None:
             raise KeyError(f'{checkpoint_path}: no "hyper_parameters" entry (not a Lightning checkpoint of TrainingModule)')
@@ -290,11 +304,11 @@ class TrainingModule(nn.Module):
         module.load_state_dict(ckpt['state_dict'], strict=strict)
         return module
 
-    def load_pretrained_weights(self, path, map_location='cpu'):
+    def load_pretrained_weights(self, path, map_location='cpu', trust_pickle=False):
         """train.py:21-29 (``PRETRAINED.LOAD_WEIGHTS``): initialise from a single-image model -- every tensor of the
         checkpoint's ``state_dict`` whose key exists here and does not belong to a decoder, non-strict.  Returns the
         keys that were loaded."""
-        weights = torch.load(path, map_location=map_location, weights_only=False)['state_dict']
+        weights = _load_checkpoint_file(path, map_location, trust_pickle)['state_dict']
         state = self.state_dict()
         weights = {k: v for k, v in weights.items() if k in state and 'decoder' not in k}
         self.load_state_dict(weights, strict=False)

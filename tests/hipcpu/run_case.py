@@ -486,6 +486,36 @@ def conv(ops):
     return out
 
 
+def conv_f32(ops):
+    """FLOAT32 operands through the three-term bf16 split (ops.conv2d_f32) on the MFMA kernels, against the same
+    convolution in FLOAT64: the route the float32 legs of the GPU parity tests take."""
+    import torch.nn.functional as F
+    out = {}
+    torch.manual_seed(12)
+    for name, (cin, cout, k, s, p, d, bias) in {'3x3': (16, 24, 3, 1, 1, 1, True), '1x1_head': (8, 2, 1, 1, 0, 1, True),
+                                                 '7x7s2': (16, 8, 7, 2, 3, 1, False), 'dil2': (8, 8, 3, 1, 2, 2, False),
+                                                 'stem': (8, 48, 3, 2, 1, 1, False), '3x3s2': (16, 16, 3, 2, 1, 1, False),
+                                                 '3x3_co96': (40, 96, 3, 1, 1, 1, False)}.items():
+        x0 = torch.randn(2, cin, 9, 12) * 3.0 + 0.5                                  # plain NCHW float32, as the parity runs hand it over
+        w0 = torch.randn(cout, cin, k, k) * 0.2
+        b0 = torch.randn(cout) if bias else None
+        x, w = x0.clone().requires_grad_(), w0.clone().requires_grad_()
+        b = b0.clone().requires_grad_() if bias else None
+        y = ops.conv2d_f32(x, w, b, s, p, d)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        xr, wr = x0.double().requires_grad_(), w0.double().requires_grad_()
+        br = b0.double().requires_grad_() if bias else None
+        yr = F.conv2d(xr, wr, br, s, p, d)
+        yr.backward(gy.double())
+        # what plain float32 arithmetic makes of the same convolution, for scale
+        y32 = F.conv2d(x0, w0, b0, s, p, d)
+        out[name] = {'y': rel(y.detach(), yr.detach()), 'dx': rel(x.grad, xr.grad), 'dw': rel(w.grad, wr.grad),
+                     'db': rel(b.grad, br.grad) if bias else 0.0, 'torch_f32_y': rel(y32, yr.detach()),
+                     'dtypes': [str(y.dtype), str(x.grad.dtype), str(w.grad.dtype)]}
+    return out
+
+
 def dwconv(ops):
     import torch.nn.functional as F
     out = {}
@@ -1076,7 +1106,7 @@ def fuzz(ops, seed=1):
 
 
 CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_frames, lift_coarse_grid, lift_tall, lift_c64_rows56, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
-                                 conv, dwconv, mbconv_mid, losses, plan, image_prep, bn_group_two_ranks)}
+                                 conv, conv_f32, dwconv, mbconv_mid, losses, plan, image_prep, bn_group_two_ranks)}
 
 if __name__ == '__main__':
     ops_mod = setup(sys.argv[1])

@@ -32,7 +32,16 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize('case', CASES)
+# the shapes bench.py's step launches (BASELINE configs[2]: B = 4, T = 3 -> 12 BEV frames of 200 x 200, 72 camera images)
+BENCH_CASES = [
+    (12, 64, 200, 200, 64, 3, 1, 1, 1, False, False),    # decoder heads / ResNet layer1 3x3 64 -> 64 @200x200x12 (the work-horse)
+    (12, 128, 200, 200, 128, 3, 1, 1, 1, False, False),  # temporal DeepLabHead 3x3 128 -> 128 (128-wide tiles)
+    (72, 24, 112, 240, 144, 1, 1, 0, 1, False, False),   # trunk expand 1x1 24 -> 144 @112x240x72 (one short K-step)
+    (12, 64, 200, 200, 64, 7, 2, 3, 1, False, False),    # decoder stem 7x7 / 2 (per-phase data gradient at this size)
+]
+
+
+@pytest.mark.parametrize('case', CASES + BENCH_CASES)
 def test_conv2d_forward_and_input_gradient(case):
     from stp3_amd import ops
     n, cin, h, w, cout, k, stride, pad, dil, use_bias, sliced = case
@@ -85,6 +94,46 @@ def test_strided_data_gradient_per_phase(case):
     assert torch.equal(got, again)
     stuffed = ops.conv2d_data_grad(gy, wb, None, tuple(x.shape), 2, (pad, pad), (1, 1))   # small layer: zero-stuffed route
     torch.testing.assert_close(got.float(), stuffed.float(), rtol=1e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize('case', [CASES[3], CASES[4], CASES[5], CASES[7], CASES[8], CASES[10]] + BENCH_CASES)
+def test_conv2d_float32_route_against_float64(case):
+    """``ops.conv2d_f32`` (float32 tensors outside autocast: three bf16 terms per operand, six term products on the MFMA
+    kernels, float32 accumulators) against the same convolution in FLOAT64 -- forward, data gradient, weight gradient,
+    relative to the largest entry: float32 accuracy.  This is the route every float32 leg of the step-level parity
+    tests takes, so those pin ``conv2d_igemm_kernel`` / ``conv2d_wgrad_kernel`` themselves.  (The float64 side of the bench
+    shapes runs on 2 of the samples for the forward / data gradient: a float64 vendor convolution is slow.)"""
+    from stp3_amd import ops
+    from stp3_amd.layers import fused
+    n, cin, h, w, cout, k, stride, pad, dil, use_bias, sliced = case
+    g = torch.Generator().manual_seed(cin * 11 + cout)
+    x = (torch.randn(n, cin, h, w, generator=g) * 2.0 + 0.3).cuda().requires_grad_(True)
+    wgt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).cuda().requires_grad_(True)
+    bias = torch.randn(cout, generator=g).cuda().requires_grad_(True) if use_bias else None
+    assert fused._use_mfma_f32(x, wgt, stride)
+    y = fused.conv2d(x, wgt, bias, stride, pad, dil)                 # the dispatch the models use
+    assert y.dtype == torch.float32
+    gy = torch.randn(y.shape, generator=g).cuda()
+    y.backward(gy)
+    m = min(n, 2)
+    xd, wd = x.detach()[:m].double().requires_grad_(True), wgt.detach().double().requires_grad_(True)
+    bd = bias.detach().double().requires_grad_(True) if use_bias else None
+    ref = F.conv2d(xd, wd, bd, stride, pad, dil)
+    ref.backward(gy[:m].double())
+
+    def close(a, b, tol):
+        assert (a.double() - b).abs().max().item() <= tol * b.abs().max().item(), ((a.double() - b).abs().max().item(), b.abs().max().item())
+    close(y[:m], ref.detach(), 2e-6)
+    close(x.grad[:m], xd.grad, 2e-6)
+    if m == n:
+        close(wgt.grad, wd.grad, 5e-6)
+        if use_bias:
+            close(bias.grad, bd.grad, 5e-6)
+    else:                                   # all n samples: the weight gradient sample by sample in float64
+        dw = torch.zeros_like(wd)
+        for i in range(n):
+            dw += torch.nn.grad.conv2d_weight(x.detach()[i:i + 1].double(), wd.shape, gy[i:i + 1].double(), stride, pad, dil)
+        close(wgt.grad, dw, 5e-6)
 
 
 def test_conv2d_rejects_what_it_cannot_do():

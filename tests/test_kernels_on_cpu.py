@@ -28,7 +28,7 @@ import build as hipcpu_build  # noqa: E402
 
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
 ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
-           ('conv', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
+           ('conv', {}), ('conv_f32', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
            ('lift_c64_frames', {}), ('lift_c64_rows56', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
 ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)]
@@ -206,6 +206,17 @@ def test_convolution_kernels(results):
         if name == 'seconds':
             continue
         assert r['y'] <= 1e-5 and r['dx'] <= 1e-5 and r['dw'] <= 1e-4, (name, r)
+
+
+def test_float32_convolutions_on_the_matrix_core_kernels(results):
+    """ops.conv2d_f32: float32 operands as three bf16 terms, six term products on the bf16 MFMA kernels with float32
+    accumulation -- against the convolution in float64: float32 accuracy (1e-6), forward and both gradients."""
+    for name, r in _get(results, 'conv_f32').items():
+        if name == 'seconds':
+            continue
+        assert r['dtypes'] == ['torch.float32'] * 3, (name, r)
+        assert r['y'] <= 2e-6 and r['dx'] <= 2e-6 and r['dw'] <= 2e-6 and r['db'] <= 2e-6, (name, r)
+        assert r['y'] <= 4 * r['torch_f32_y'] + 2e-7, (name, r)          # as good as plain float32 arithmetic
 
 
 def test_voxel_pool_golden_case(results):

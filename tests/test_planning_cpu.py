@@ -104,12 +104,48 @@ def test_footprints_match_the_reference():
     assert np.array_equal(base.footprint(2), g['footprint_lambda'])
 
 
-def test_footprint_rejects_points_on_the_outline():
-    from stp3_amd.cost import footprint_cells
-    with pytest.raises(ValueError):
-        footprint_cells(np.array([[1.0, 1.5], [4.0, 1.5], [4.0, 3.5], [1.0, 3.5]]))     # rows 1 and 4 lie on edges
+def test_footprint_with_lattice_points_on_the_outline():
+    """Box edges on cell boundaries (e.g. EGO.WIDTH = 2.0 at 0.5 m cells): decided by the half-open crossing test of the
+    scikit-image release the reference pins (0.18.1) -- first row / column edge in, last one out -- and equal to the
+    independent restatement the oracle runs the reference with; nothing raises."""
+    from oracle.ref_stubs import polygon
+    from stp3_amd.cost import BaseCost, footprint_cells
+    box = np.array([[1.0, 1.5], [4.0, 1.5], [4.0, 3.5], [1.0, 3.5]])                   # rows 1 and 4 lie on edges
+    cells = footprint_cells(box)
+    assert cells.tolist() == [[r, c] for r in (1, 2, 3) for c in (2, 3)]
+    rr, cc = polygon(box[:, 0], box[:, 1])
+    assert np.array_equal(cells, np.stack([rr, cc], axis=-1))
+    both = np.array([[1.0, 1.0], [4.0, 1.0], [4.0, 3.0], [1.0, 3.0]])                  # all four edges on lattice lines
+    rr, cc = polygon(both[:, 0], both[:, 1])
+    assert np.array_equal(footprint_cells(both), np.stack([rr, cc], axis=-1))
+    assert footprint_cells(both).tolist() == [[r, c] for r in (1, 2, 3) for c in (1, 2)]
     cells = footprint_cells(np.array([[0.5, 1.5], [4.5, 1.5], [4.5, 3.5], [0.5, 3.5]]))
     assert cells.tolist() == [[r, c] for r in (1, 2, 3, 4) for c in (2, 3)]
+    # a configuration whose ego box is 2 m x 4 m on the 0.5 m grid builds its tables (it used to raise)
+    from stp3_amd.config import perception_cfg
+    c = perception_cfg(**{**PLANNING, 'EGO.WIDTH': 2.0, 'EGO.HEIGHT': 4.0})
+    base = BaseCost(c)
+    rr, cc = polygon(*(((np.array([[-1.5, 1.0], [2.5, 1.0], [2.5, -1.0], [-1.5, -1.0]]) - base.bx.numpy()) / base.dx.numpy()).T))
+    assert np.array_equal(base.footprint(0), np.stack([rr, cc], axis=-1)) and len(rr) == 32
+
+
+def test_kernel_tables_follow_a_load_state_dict():
+    """Cost_Function caches the footprint tables / scalar parameters of the kernel path: a ``load_state_dict`` that
+    changes safetycost.w / dx / bx after the first use must rebuild them."""
+    from stp3_amd.cost import Cost_Function
+    cf = Cost_Function(cfg())
+    fp0, fpl, params = cf._kernel_inputs('cpu')
+    again = cf._kernel_inputs('cpu')
+    assert again[0] is fp0 and again[2] is params                                      # cached while nothing changes
+    sd = cf.state_dict()
+    sd['safetycost.w'] = sd['safetycost.w'] * 2.0
+    sd['safetycost.dx'] = sd['safetycost.dx'] * 2.0                                    # 1 m cells: a smaller footprint
+    sd['headwaycost.dx'] = sd['headwaycost.dx'] * 2.0
+    cf.load_state_dict(sd)
+    fp0b, fplb, paramsb = cf._kernel_inputs('cpu')
+    assert float(paramsb['w0']) == 2.0 * float(params['w0']) and float(paramsb['dx0']) == 2.0 * float(params['dx0'])
+    assert fp0b.shape[0] < fp0.shape[0] and len(cf._tables) == 1
+    assert np.array_equal(cf.safetycost.footprint(0), fp0b.numpy())
 
 
 @pytest.mark.parametrize('form', ['train', 'eval'])

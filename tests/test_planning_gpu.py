@@ -30,6 +30,23 @@ def test_planner_bf16_autocast():
     np.testing.assert_allclose(out['d_cost_volume'].numpy(), g['planner/train/d_cost_volume'], rtol=1e-5, atol=1e-5)
 
 
+def test_costs_stay_float32_for_a_bf16_cost_volume():
+    """Under bf16 autocast the cost-volume head hands over a bf16 tensor; the trajectory costs must come back in float32
+    (stp3/cost.py:36-47: a half cost volume indexed and added to float32 terms promotes) and equal the costs of the same
+    values held in float32 -- not their bf16 rounding, which would re-rank near-tied samples."""
+    from stp3_amd.cost import Cost_Function
+    c = cfg()
+    ins = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in H.planning_inputs(c).items()}
+    cf = Cost_Function(c).cuda()
+    lane, drv = split_hd(ins['hdmap_labels'])
+    cv16 = ins['cost_volume'].to(torch.bfloat16)
+    fc, fo = cf(cv16, ins['trajs'][..., :2].clone(), ins['occupancy'], lane.clone(), drv.clone(), ins['target'])
+    fc32, fo32 = cf(cv16.float(), ins['trajs'][..., :2].clone(), ins['occupancy'], lane.clone(), drv.clone(), ins['target'])
+    assert fc.dtype == torch.float32 and fo.dtype == torch.float32
+    assert torch.equal(fc, fc32) and torch.equal(fo, fo32)
+    assert not torch.equal(fo, fo.to(torch.bfloat16).float())            # the costs are not bf16 numbers
+
+
 def test_cost_kernel_full_size_against_torch_statements():
     """nuscenes/Planning.yml sizes: 1 800 samples x 6 steps x batch 4.  The kernel against the module's own torch
     statements on float64 copies of the same inputs (they take the statement route), and bit-reproducible."""
