@@ -4,11 +4,15 @@ reference ``STP3.forward`` (stp3/models/stp3.py:132-184) in eval mode on the CPU
     python oracle/make_golden_iou.py        -> tests/golden/iou_b4.npz
 
 With the plain deterministic fill every BEV pixel comes out "vehicle" (MANIFEST: tp 1472 / fp 38327 / fn 0 at B = 1): an
-arg-max that never flips cannot fail an IoU criterion.  Here the bias of the class-1 output of the segmentation and the
-pedestrian head (decoder.py:42-66: the last 1x1 convolution of the head) is shifted by a constant so that 10 % / 5 % of
-the pixels are predicted positive -- the decision boundary then runs through the bulk of the logit-difference
-distribution, thousands of pixels lie within a bf16 rounding of it, and every one that flips moves tp / fp / fn.  The
-shifts are stored and applied to the product's heads by the test (same parameter, same value).
+arg-max that never flips cannot fail an IoU criterion -- and the two rows of a head's last 1x1 convolution, filled from
+the same sequence, are nearly parallel (logit difference: std 0.09 on logits of O(1), a third of all pixels within 1e-2
+of the decision boundary: such a fixture measures its own conditioning).  ``prepare_heads`` (shared with the GPU test,
+tests/helpers.py) therefore (i) re-fills the class-1 ROW of the last convolution of the segmentation and the pedestrian
+head (decoder.py:42-66) from an independent sequence, so that the logit difference has the spread of the logits
+themselves, and (ii) orients the two classes and shifts the class-1 bias by a stored constant so that the decision
+boundary falls where the FEWEST pixels lie, with 1..30 % of them positive (the BEV cells no camera sees form one narrow
+cluster of near-ties holding 3/4 of the pixels; a boundary inside it would test tie-breaking): every pixel that flips
+moves tp / fp / fn.
 
 Two label sets per head (evaluate.py:95-98 / metrics.py:37-65 protocol: arg-max over the class dimension, per-class
 tp / fp / fn, IoU = tp / (tp + fp + fn) of class 1; present frame = index receptive_field - 1, and all frames):
@@ -57,14 +61,30 @@ def main():
     batch = synthetic.make_batch(batch=BATCH, seq=3, seed=SEED)
     out = {}
     with torch.no_grad():
+        H.prepare_heads(ref.decoder, {})                                     # independent class-1 rows, no shift yet
         o = ref(batch['image'], batch['intrinsics'], batch['extrinsics'], batch['future_egomotion'])
+        shifts, swaps = {}, {}
         for key, (attr, frac) in HEADS.items():
-            diff = (o[key][:, :, 1] - o[key][:, :, 0]).flatten()
-            shift = np.float32(-torch.quantile(diff.double(), 1.0 - frac).item())
-            last = getattr(ref.decoder, attr)[-1]
-            assert last.bias is not None and last.bias.shape == (2,)
-            last.bias[1] += float(shift)
-            out[f'shift/{key}'] = np.array([shift], dtype=np.float32)
+            diff = (o[key][:, :, 1] - o[key][:, :, 0]).flatten().double()
+            # BEV cells no camera sees carry identical features: 3/4 of the pixels sit in one narrow cluster of the logit
+            # difference, the rest in a sparse tail.  The boundary is put where FEW pixels lie -- a boundary inside the
+            # cluster would make the fixture a test of tie-breaking: over both orientations of the two classes (``swap``:
+            # the tail on the positive side) and the positive fractions 1 % .. 30 %, the one with the fewest pixels
+            # within 5e-3 of the boundary
+            best = None
+            for sw in (False, True):
+                dd = -diff if sw else diff
+                for q in np.arange(0.01, 0.30, 0.0025):
+                    thr = torch.quantile(dd, 1.0 - float(q)).item()
+                    near = int(((dd - thr).abs() < 5e-3).sum())
+                    if best is None or near < best[0]:
+                        best = (near, thr, float(q), sw)
+            print(key, 'swap', best[3], 'positive fraction', best[2], 'pixels within 5e-3:', best[0], 'diff std', float(diff.std()),
+                  'histogram', torch.histc(diff.float(), bins=20).int().tolist(), float(diff.min()), float(diff.max()))
+            shifts[key], swaps[key] = float(np.float32(-best[1])), bool(best[3])
+            out[f'shift/{key}'] = np.array([shifts[key]], dtype=np.float32)
+            out[f'swap/{key}'] = np.array([int(swaps[key])], dtype=np.int64)
+        H.prepare_heads(ref.decoder, shifts, swaps)                          # same rows again (idempotent), swap, shifts
         o = ref(batch['image'], batch['intrinsics'], batch['extrinsics'], batch['future_egomotion'])
     present = ref.receptive_field - 1
     summary = {}

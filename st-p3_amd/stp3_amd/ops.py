@@ -613,6 +613,18 @@ def _f32(t):
     return t.detach().float().contiguous()
 
 
+_EXCHANGES = {'batchnorm': 0}
+
+
+def exchange_counts(reset=False):
+    """How many cross-replica statistics all-reduces the BatchNorm operators have issued (bench.py's N > 1 line)."""
+    out = dict(_EXCHANGES)
+    if reset:
+        for k in _EXCHANGES:
+            _EXCHANGES[k] = 0
+    return out
+
+
 def drive_exchange(gen, group):
     """Run an operator written as a generator that YIELDS the buffer it needs summed over the replicas (cross-replica
     BatchNorm statistics; at most one exchange per pass) and resumes once it is: here with one all-reduce of its own."""
@@ -620,6 +632,7 @@ def drive_exchange(gen, group):
         buf = next(gen)
         while True:
             torch.distributed.all_reduce(buf, group=group)
+            _EXCHANGES['batchnorm'] += 1
             buf = gen.send(None)
     except StopIteration as done:
         return done.value
@@ -635,6 +648,7 @@ def drive_exchange_group(gens, group):
         except StopIteration as done:
             results[i] = done.value
     if waiting:
+        _EXCHANGES['batchnorm'] += 1
         if len(waiting) == 1:
             torch.distributed.all_reduce(waiting[0][2], group=group)
         else:

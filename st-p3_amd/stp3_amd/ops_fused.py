@@ -420,6 +420,7 @@ class _DwBnSe(torch.autograd.Function):
             world = torch.distributed.get_world_size(group)
         if world > 1:
             torch.distributed.all_reduce(stat[:2 * c], group=group)
+            ops._EXCHANGES['batchnorm'] += 1
             count *= world
         g32, b32 = ops._f32(gamma), ops._f32(beta)
         coef = stat[2 * c:]
@@ -477,6 +478,7 @@ class _DwBnSe(torch.autograd.Function):
         if world > 1:
             gsums = lsums.clone()
             torch.distributed.all_reduce(gsums, group=group)
+            ops._EXCHANGES['batchnorm'] += 1
         de2 = torch.empty_like(e2)
         check(lib.stp3_mbconv_bwd_apply(ctypes.byref(sd), c, da.data_ptr(), e2.data_ptr(), coef.data_ptr(), ops.ACT_SWISH,
                                         gate.data_ptr(), dpooled.data_ptr(), gsums.data_ptr(), count, de2.data_ptr(), stream),

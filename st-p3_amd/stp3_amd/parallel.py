@@ -71,6 +71,7 @@ class GradientBuckets:
 
     def __init__(self, module, bucket_bytes=8 << 20, process_group=None, average=True, gather=None):
         self.gather = True if gather is None else bool(gather)
+        self.reductions_launched = 0                     # gradient-bucket all-reduces issued so far (bench.py's N > 1 line)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
@@ -169,6 +170,7 @@ class GradientBuckets:
         if self.world > 1:
             flat = self.buckets[i][0]
             self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.reductions_launched += 1
 
     def _on_grad(self, p):
         i = self._bucket_of[p]

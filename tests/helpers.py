@@ -80,6 +80,34 @@ def fill_deterministic(module, seed=0):
     return module
 
 
+IOU_HEADS = {'segmentation': 'segmentation_head', 'pedestrian': 'pedestrian_head'}
+
+
+def prepare_heads(decoder, shifts, swap=None):
+    """The IoU fixture's treatment of a deterministically filled decoder (oracle/make_golden_iou.py, applied identically
+    to the reference's decoder there and to the product's in tests/test_iou_gpu.py): the class-1 row of the last 1x1
+    convolution of the segmentation / pedestrian head is re-filled from an independent sequence (the plain fill makes the
+    two rows nearly parallel: no contrast between the classes), the two rows (weights and biases) are exchanged where
+    ``swap[head]`` says so (the logit difference changes sign: the sparse tail of its distribution becomes the positive
+    class) and the class-1 bias is shifted by ``shifts[head]``."""
+    import math
+    with torch.no_grad():
+        for key, attr in IOU_HEADS.items():
+            last = getattr(decoder, attr)[-1]
+            w = last.weight                                              # (2, C, 1, 1)
+            n = w[1].numel()
+            idx = torch.arange(n, dtype=torch.int64)
+            u = ((idx * 22695477 + 977 * (len(key) + 1) + 1) % 2147483648).double() / 2147483648.0
+            u = (u * 11.0 + (idx % 7).double() / 7.0) % 1.0
+            w[1].copy_(((u - 0.5) * 2.0 * math.sqrt(3.0 / n)).view(w[1].shape).to(w.dtype))
+            if swap and swap.get(key):
+                w.copy_(w.flip(0))
+                last.bias.copy_(last.bias.flip(0))
+            if key in shifts:
+                last.bias[1] += float(shifts[key])
+    return decoder
+
+
 def det_tensor(shape, seed, scale=1.0):
     """Deterministic pseudo-random tensor in [-scale, scale) (exact integer arithmetic)."""
     n = 1
