@@ -17,6 +17,7 @@ from .. import ops
 from ..utils import hp
 from .fused import (ACT_NONE, ACT_RELU, RES_AFTER_ACT, _sync_world, bn_act, bn_act_group, conv1x1_on_vector, conv2d,
                     conv_bn_act_member, conv_module, plane_mean, run_fused)
+from .fused import _emu as fused_emu
 
 
 def _conv_bn_relu(in_ch, out_ch, k, padding=0, dilation=1):
@@ -36,7 +37,7 @@ def _upsample(module, x, dtype):
             and isinstance(scale, (int, float))):
         xin = x.to(dtype) if x.dtype != dtype and torch.is_autocast_enabled() else x
         if ops.upsample_bilinear_supported(xin, scale):
-            return ops.upsample_bilinear(xin, scale)
+            return fused_emu(ops.upsample_bilinear(xin, scale))
     y = module(x)
     return y.to(dtype) if y.dtype != dtype and torch.is_autocast_enabled() else y
 

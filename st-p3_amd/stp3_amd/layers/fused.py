@@ -26,6 +26,27 @@ ACT_NONE, ACT_RELU, ACT_SWISH = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_SWISH
 RES_NONE, RES_BEFORE_ACT, RES_AFTER_ACT = ops.RES_NONE, ops.RES_BEFORE_ACT, ops.RES_AFTER_ACT
 
 
+# Test instrument (tests/test_train_parity_gpu.py, never set by the product): float32 tensors on the float32 kernels with
+# every operator RESULT (and every gradient that flows back through it) rounded to bf16 -- an emulation of where the bf16
+# path rounds, through an independent set of kernels.  A bf16 run that agrees with this emulation differs from the float32
+# run by rounding, not by an indexing / padding-lane / accumulation defect (those would be O(1) and in ONE of the two).
+EMULATE_BF16 = False
+
+
+class _RoundBf16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def _emu(x):
+    return _RoundBf16.apply(x) if (EMULATE_BF16 and torch.is_tensor(x) and x.dtype == torch.float32) else x
+
+
 def _sync_world(bn):
     if not (bn.training and dist.is_available() and dist.is_initialized()):
         return 1
@@ -150,8 +171,8 @@ def bn_act(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=
         # noise-free truth of the parity tests) takes the torch statement
         return bn_act_reference(bn, x, act, res, res_mode, sbias, oscale)
     x, weight, bias, res, sbias, oscale, rmean, rvar, training, momentum, eps, act, res_mode, group, channels = args
-    return ops.bn_act(x, weight, bias, rmean, rvar, training, momentum, eps, act=act, res=res, res_mode=res_mode, sbias=sbias,
-                      oscale=oscale, group=group, channels=channels)
+    return _emu(ops.bn_act(x, weight, bias, rmean, rvar, training, momentum, eps, act=act, res=res, res_mode=res_mode, sbias=sbias,
+                           oscale=oscale, group=group, channels=channels))
 
 
 def _kernel_args(bn, x, act, res, res_mode, sbias, oscale):
@@ -250,6 +271,8 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     if _use_mfma(x, weight, stride):
         return ops.conv2d(x, weight, bias, stride, padding, dilation)
     if _use_mfma_f32(x, weight, stride):
+        if EMULATE_BF16:                      # bf16 operands (weights rounded like the shadows), float32 accumulation, bf16 result
+            return _emu(ops.conv2d_f32(x, _emu(weight), bias, stride, padding, dilation))
         return ops.conv2d_f32(x, weight, bias, stride, padding, dilation)
     return F.conv2d(x, weight, bias, stride, padding, dilation)
 

@@ -11,10 +11,11 @@ sets: the synthetic random blobs (``north_star``: IoU within 1e-3 of the referen
 own prediction with the blob pixels flipped (IoU ~ 0.8; it moves with EVERY pixel whose arg-max differs from the
 reference's -- an agreement measure, far more sensitive than the criterion).
 
-Bounds: float32 -- both label sets within 1e-3, and at most 1 pixel in 2 000 with another arg-max than the reference
-(measured: see profiles/r04_iou.json); bf16 -- the synthetic-label IoU within 1e-3 (the criterion); the pseudo-label IoU
-within 5e-2 and the disagreement below 1 %, i.e. what rounding every activation of a 60-layer network to 8 bits does to
-pixels within ~1 % of the decision boundary (the reference under its own AMP would move as much).
+Bounds (measured: profiles/r04a_iou.json): float32 -- both label sets within 1e-3 (measured 1e-8: not one of the 480 000
+arg-maxes differs from the reference's; bound 24 pixels); bf16 -- the synthetic-label IoU within 1e-3 (the criterion;
+measured 1.4e-5), the pseudo-label IoU within 2e-2 (measured 8.6e-4 .. 6.6e-3) and at most 1 pixel in 1 000 with another
+arg-max (measured 4e-5 / 1.6e-4): what rounding every activation of a 60-layer network to 8 bits does to the pixels next
+to the decision boundary (the reference under its own AMP would move as much).
 """
 import json
 import os
@@ -80,5 +81,5 @@ def test_segmentation_iou_b4(mode):
     for key in H.IOU_HEADS:
         for fname in ('present', 'all'):
             assert rows[f'{key}/synthetic/{fname}']['diff'] <= 1e-3, (mode, key, fname, rows)           # the criterion
-            assert rows[f'{key}/pseudo/{fname}']['diff'] <= (1e-3 if mode == 'fp32' else 5e-2), (mode, key, fname, rows)
-        assert rows[f'{key}/argmax_disagreement'] <= (5e-4 if mode == 'fp32' else 1e-2), (mode, key, rows)
+            assert rows[f'{key}/pseudo/{fname}']['diff'] <= (1e-3 if mode == 'fp32' else 2e-2), (mode, key, fname, rows)
+        assert rows[f'{key}/argmax_disagreement'] <= (5e-5 if mode == 'fp32' else 1e-3), (mode, key, rows)

@@ -14,14 +14,28 @@ decoder outputs and by 8..11 % in the temporal / encoder / trunk gradients, with
 switched OFF.  That number is the reference's own rounding noise, not a property of any implementation; it is computed
 here from the two fixtures, tap by tap and parameter group by parameter group, and it IS the tolerance:
 
-  * ``test_step_b2_within_reference_noise``: the product's float32 step is as close to the truth as the reference's float32
-    step is (<= 2 x the reference's distance, + 1e-4), for every loss entry, head output, block output, block
-    gradient and parameter-gradient group; and within 2.5 x of the reference's float32 values themselves.
+  * ``test_step_b2_within_reference_noise``: the product's float32 step is CLOSER to the truth than the reference's
+    float32 step is (<= 0.6 x the reference's distance, + 1e-4), for every loss entry, head output, block output, block
+    gradient and parameter-gradient group -- measured 0.12 .. 0.18 x (profiles/r04a_parity_step.json: gradients 0.015 /
+    0.012 / 0.010 / 0.0009 for trunk / encoder heads / temporal / decoder where the reference has 0.109 / 0.106 / 0.081 /
+    0.009); and within 1.5 x of the reference's float32 values themselves (a run that sits at the truth is one
+    reference-noise away from the reference: measured 1.03 .. 1.06 x).
   * ``b4k0`` / ``b4k1`` (the bench's batch size; ``b4k1`` IS configs[2], top-k on): float32 reference fixtures only (a
-    float64 reference step at B=4 does not fit this container): losses to 2e-4, everything else within 2 x the B=2
-    noise profile; with top-k on the temporal-model gradients additionally carry the re-selection of pixels
-    (stp3/losses.py:62-70: a 1e-6 logit difference picks other pixels) -- bounded at 0.4.
-Measured values: profiles/r03_parity_step.json.
+    float64 reference step at B=4 does not fit this container): losses to 2e-4, everything else within 3 x the B=2
+    noise profile, the gradient groups within 1.5 x; ``b4k1`` twice: on the reference's OWN selection of the k hardest
+    pixels (stored in the fixture) at the same bounds as ``b4k0`` -- measured temporal gradients 0.081 -- and with the
+    product selecting for itself, where the temporal-model gradients additionally carry the pixels the two runs rank
+    differently around the k-th largest loss (measured 0.25, bounded at 0.4: the difference between the two tests IS
+    that re-selection).
+
+Since round 4 every convolution of these float32 runs goes through the hand-written MFMA kernels (three-term bf16 split,
+ops.conv2d_f32) instead of a vendor float32 convolution.  That settled a question of round 3: the temporal gradients'
+distance from the truth had moved 0.027 -> 0.065 between two commits that changed no float32 arithmetic of the model.
+scripts/step_noise_probe.py (profiles/r04a_step_noise_probe.json) perturbs the input images by one float32 ulp and
+repeats the step: the distance moves between 0.009 and 0.038 from draw to draw (a factor of 4: the ReLU masks of ~130
+BatchNorm + ReLU layers decide it), and it is the same to four digits with the torch statements of the losses in place of
+the loss kernels (the change between those two commits).  The old numbers were two draws of that noise around the vendor
+convolution's own, larger error; with the split-precision convolutions the run sits at 0.010 .. 0.038.
 """
 import json
 import os
@@ -42,7 +56,7 @@ NO_TOPK = {'SEMANTIC_SEG.VEHICLE.USE_TOP_K': False, 'SEMANTIC_SEG.PEDESTRIAN.USE
 OUTPUTS = ('segmentation', 'pedestrian', 'hdmap', 'instance_center', 'instance_offset', 'instance_flow', 'depth_prediction')
 GROUPS = [('encoder.backbone', 'trunk'), ('encoder', 'encoder_heads'), ('temporal_model', 'temporal'),
           ('decoder', 'decoder')]
-NOISE_FACTOR_TRUTH, NOISE_FACTOR_REF, FLOOR = 2.0, 2.5, 1e-4
+NOISE_FACTOR_TRUTH, NOISE_FACTOR_REF, FLOOR = 0.6, 1.5, 1e-4
 REPORT = {}
 DEVICE = os.environ.get('STP3_PARITY_DEVICE', 'cuda')          # 'cpu': the product's plain-torch path (exploration only)
 PERTURB = None              # (seed, relative size): scripts/step_noise_probe.py perturbs the images by that much
@@ -189,7 +203,7 @@ def _check_b4(variant, temporal_bound, tag=None, own_selection=True):
 
 def test_step_b4_smooth():
     """The bench's batch size with the top-k selection off."""
-    _check_b4('b4k0', temporal_bound=2.0 * reference_noise()['grad/temporal'] + FLOOR)
+    _check_b4('b4k0', temporal_bound=NOISE_FACTOR_REF * reference_noise()['grad/temporal'] + FLOOR)
 
 
 def test_step_b4_configs2():
@@ -226,6 +240,6 @@ def test_step_b4_configs2_on_the_references_selection(monkeypatch):
         forced = torch.where(keep, labels, torch.full_like(labels, ignore_index))
         return real(logits, forced, class_weights, row_scale, 0, ignore_index) * (float(h * w) / k)
     monkeypatch.setattr(ops_loss, 'ce_topk_mean', on_the_references_pixels)
-    _check_b4('b4k1', temporal_bound=2.0 * reference_noise()['grad/temporal'] + FLOOR,
+    _check_b4('b4k1', temporal_bound=NOISE_FACTOR_REF * reference_noise()['grad/temporal'] + FLOOR,
               tag='b4k1_on_reference_selection_vs_reference_f32', own_selection=False)
     assert len(used) == 3, used

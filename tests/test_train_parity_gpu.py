@@ -235,6 +235,20 @@ def test_training_step_c3_bf16_losses():
 F32_BLOCK_TOL = dict(out=1e-4, grad=5e-3)                # float32 kernels vs the block in float64, same inputs
 BLOCK_TOL = dict(out=2e-2, dparam=2e-2, dx=2e-2)          # bf16 accuracy for a well-conditioned block
 PROBE_FACTOR = 6.0                                        # ... or this many times the block's own sensitivity
+# link 2c: the bf16 run of a block against the float32 kernels EMULATING bf16 (every operator result and every gradient
+# rounded to bf16 at the operator boundaries, layers/fused.EMULATE_BF16): two independent kernel sets rounding at the same
+# places.  Blocks built from convolutions, BatchNorm + ReLU, up-sampling and frame pairing only (everything but the MBConv
+# blocks, whose fused middle rounds INSIDE the operator).  Measured (profiles/r04b_parity.json): the 17 blocks WITHOUT a
+# BatchNorm over pooled descriptors -- ResNet blocks, up-sampling blocks, decoder heads, the encoder's second head layers --
+# agree with the emulation to <= 2e-3 (outputs), <= 2.4e-3 (parameter gradients), <= 5.1e-3 (input gradients) where they
+# differ from their float32 run by 2e-3 .. 1e-1: those distances ARE rounding.  The 5 blocks that normalise POOLED
+# descriptors over a population of B*T = 6 / 12 vectors (the two TemporalBlocks' pyramid pooling, the image-pooling branch
+# of the three DeepLabHeads: near-equal values divided by their tiny spread) are ill-conditioned: the two bf16 evaluations
+# differ from EACH OTHER by as much as either differs from float32 (0.19 vs 0.22 on the worst block) -- no implementation
+# can be pinned tighter than the probe-scaled bound of link 2b there.
+EMU_TOL = dict(out=5e-3, dparam=1e-2, dx=2e-2)
+POOLED_BLOCKS = ('temporal_model.model.0', 'temporal_model.model.1', 'temporal_model.final_conv', 'encoder.depth_layer_1',
+                 'encoder.feature_layer_1')
 
 
 def test_bf16_blocks_teacher_forced_from_the_float32_step():
@@ -308,7 +322,7 @@ def test_bf16_blocks_teacher_forced_from_the_float32_step():
         for a in args:
             if torch.is_tensor(a) and a.is_floating_point():
                 a = a.clone()
-                if mode == 'probe':
+                if mode in ('probe', 'emu'):
                     a = a.to(torch.bfloat16).float()
                 if mode == 'bf16':
                     a = a.to(torch.bfloat16)
@@ -319,9 +333,14 @@ def test_bf16_blocks_teacher_forced_from_the_float32_step():
             ins.append(a)
         kw = {k: (v.double() if (mode == 'f64' and torch.is_tensor(v) and v.is_floating_point()) else v)
               for k, v in kwargs.items()}
-        with ctx('bf16' if mode == 'bf16' else 'fp32'):
-            y = run_fused(mod, *ins) if mod in heads else mod(*ins, **kw)
-        y.backward(gout.to(torch.bfloat16).to(y.dtype) if mode == 'probe' else gout.to(y.dtype))
+        from stp3_amd.layers import fused as fused_layers
+        fused_layers.EMULATE_BF16 = mode == 'emu'
+        try:
+            with ctx('bf16' if mode == 'bf16' else 'fp32'):
+                y = run_fused(mod, *ins) if mod in heads else mod(*ins, **kw)
+            y.backward(gout.to(torch.bfloat16).to(y.dtype) if mode in ('probe', 'emu') else gout.to(y.dtype))
+        finally:
+            fused_layers.EMULATE_BF16 = False
         dxs = [a.grad.double() for a in ins if torch.is_tensor(a) and a.requires_grad and a.grad is not None]
         dps = [p.grad.double().flatten().clone() for p in mod.parameters() if p.grad is not None]
         out = (y.detach().double(), dxs, torch.cat(dps) if dps else torch.zeros(1, device=y.device, dtype=torch.float64))
@@ -333,7 +352,7 @@ def test_bf16_blocks_teacher_forced_from_the_float32_step():
     def r2(a, b):
         return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
-    worst, rows, probes, rows64 = dict(out=0.0, dparam=0.0, dx=0.0), {}, {}, {}
+    worst, rows, probes, rows64, rows_emu = dict(out=0.0, dparam=0.0, dx=0.0), {}, {}, {}, {}
     for n, (args, kwargs, gout) in sorted(work.items()):
         yt, dxt, dpt = run(blocks[n], args, kwargs, gout, 'f64')          # the block's mathematics, noise-free
         y0, dx0, dp0 = run(blocks[n], args, kwargs, gout, 'fp32')
@@ -343,6 +362,9 @@ def test_bf16_blocks_teacher_forced_from_the_float32_step():
         probes[n] = dict(out=r2(y2, y0), dparam=r2(dp2, dp0), dx=max([r2(a, b) for a, b in zip(dx2, dx0)] + [0.0]))
         rows[n] = e
         rows64[n] = dict(out=r2(y0, yt), dparam=r2(dp0, dpt), dx=max([r2(a, b) for a, b in zip(dx0, dxt)] + [0.0]))
+        if not isinstance(blocks[n], MBConvBlock) and n != 'encoder.backbone._conv_stem':
+            y3, dx3, dp3 = run(blocks[n], args, kwargs, gout, 'emu')
+            rows_emu[n] = dict(out=r2(y1, y3), dparam=r2(dp1, dp3), dx=max([r2(a, b) for a, b in zip(dx1, dx3)] + [0.0]))
         for k in worst:
             worst[k] = max(worst[k], e[k])
     record('bf16_blocks', 'worst', worst)
@@ -353,6 +375,11 @@ def test_bf16_blocks_teacher_forced_from_the_float32_step():
     record('bf16_blocks', 'probe_dx', {n: e['dx'] for n, e in probes.items()})
     for k in ('out', 'dparam', 'dx'):
         record('fp32_blocks_vs_float64', k, {n: e[k] for n, e in rows64.items()})
+        record('bf16_blocks_vs_bf16_emulation_on_f32_kernels', k, {n: e[k] for n, e in rows_emu.items()})
+    assert len(rows_emu) >= 22, len(rows_emu)
+    assert all(n in rows_emu for n in POOLED_BLOCKS)
+    over_emu = {n: e for n, e in rows_emu.items() if n not in POOLED_BLOCKS and any(e[k] > EMU_TOL[k] for k in EMU_TOL)}
+    assert not over_emu, over_emu
     # link 2a: the float32 kernel path of every block against the block's float64 evaluation on the SAME inputs
     # (teacher-forced, so the chain's conditioning plays no part): outputs <= 1e-4, gradients <= 5e-3
     over64 = {n: e for n, e in rows64.items() if e['out'] > F32_BLOCK_TOL['out'] or e['dparam'] > F32_BLOCK_TOL['grad']
