@@ -310,6 +310,20 @@ int stp3_bn_bwd_train(const stp3_bn_dims* dims, const void* dy, const void* x, c
                       const float* gamma, const float* beta, void* workspace, size_t workspace_bytes,
                       float* sum_buf, void* dx, void* dres, void* stream);
 
+/* stp3_bn_dsbias -- gradient of the per-sample bias (the spatially constant branches folded into a BatchNorm: the ASPP
+ * image-pooling branch, stp3/layers/convolutions.py:242-270, the pyramid pooling and the ego-motion planes of the
+ * temporal blocks, stp3/layers/temporal.py:380-489, stp3/models/stp3.py:145-152) from the sums of stp3_bn_bwd_reduce:
+ *   dsbias[n][c] = gamma[c] invstd[c] (S0[n][c] - rows gsums[0][c] / count - S2[n][c] gsums[1][c] / count)
+ *   gsums NULL (evaluation mode, running statistics are constants): gamma invstd S0[n][c].
+ *   sample_sums [N][3][C], gsums [3][C] (possibly summed over ranks, count = elements over all ranks), dsbias [N][C].
+ * stp3_sum_n -- y = src[0] + ... + src[n-1], n <= 8 dense tensors of numel elements (f32 / bf16) in ONE pass, float32
+ *   accumulation in input order, one rounding: the gradients of a tensor with several consumers (the reference's
+ *   autograd adds them pairwise: stp3/layers/convolutions.py:256-266 ASPP branches, stp3/models/decoder.py:112-126
+ *   heads, stp3/layers/temporal.py:470-489 temporal-block paths).  src: HOST array of n device pointers. */
+int stp3_bn_dsbias(int32_t N, int32_t C, int32_t rows, const float* sample_sums, const float* gsums, double count,
+                   const float* gamma, const float* invstd, float* dsbias, void* stream);
+int stp3_sum_n(int32_t n, int64_t numel, int32_t dtype, const void* const* src, void* y, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Dense 2-D convolution, bf16 MFMA implicit GEMM, NHWC (csrc/stp3_conv.hip).
  * Replaces the nn.Conv2d (and frame-folded nn.Conv3d) contractions of stp3/layers/convolutions.py:183-280,

@@ -23,8 +23,22 @@ fi
 if has conv; then timeout 300 python scripts/time_conv.py > $out/time_conv.log 2>&1; cut -c1-175 $out/time_conv.log; fi
 if has plan; then timeout 300 python scripts/time_plan.py 4 > $out/time_plan.log 2>&1; tail -4 $out/time_plan.log; fi
 if has lift; then timeout 300 python scripts/time_lift.py 4 > $out/time_lift_c3.log 2>&1; tail -8 $out/time_lift_c3.log; fi
-if has bench; then
-  timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -3 $out/bench.err; cut -c1-1500 $out/bench.json
+if has perftests; then
+  timeout 1200 python -m pytest tests/test_fused_ops_gpu.py tests/test_bnact_gpu.py tests/test_modules_gpu.py tests/test_train_parity_gpu.py tests/test_step_parity_gpu.py -m gpu -q -x -p no:cacheprovider > $out/pytest_perf.log 2>&1
+  echo "perf-change tests rc=$?"; tail -4 $out/pytest_perf.log | cut -c1-300
+fi
+if has quickbench; then
+  timeout 600 python bench.py --no-cpu-baseline > $out/bench_quick.json 2> $out/bench_quick.err; tail -3 $out/bench_quick.err
+  python - <<PY
+import json
+b=json.load(open('$out/bench_quick.json'))
+print('ms_per_step', b['ms_per_step'], 'samples/s', b['value'], 'lift frac', b['roofline']['frac'])
+for k,v in b['roofline_families'].items():
+    if isinstance(v,dict): print(' ', k, v.get('ms_per_step'), v.get('frac'), v.get('calls_per_step'))
+PY
+fi
+if has bench || has profile; then
+  if has bench; then timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -3 $out/bench.err; cut -c1-1500 $out/bench.json; fi
   STEPS=4
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r04 -o bench -- python bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-roofline > $out/prof.log 2>&1
   grep '^{' $out/prof.log | tail -1 > $out/bench_profiled.json

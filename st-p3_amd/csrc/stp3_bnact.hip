@@ -565,6 +565,67 @@ __global__ __launch_bounds__(kThreads) void bn_apply_bwd_kernel(
     });
 }
 
+// ---- gradient of the per-sample bias from the backward sums (a handful of values: one launch instead of six torch
+//      operators per layer): dsbias[n][c] = gamma invstd (S0[n] - rows k0 - S2[n] k1), k = gsums / count; evaluation mode
+//      (running statistics are constants): gamma invstd S0[n] -------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void bn_dsbias_kernel(int N, int C, float rows, const float* __restrict__ sample_sums,
+                                                             const float* __restrict__ gsums, float inv_count,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ invstd, float* __restrict__ out) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    const float* s = sample_sums + (size_t)n * 3 * C;
+    const float gi = (gamma ? gamma[c] : 1.f) * invstd[c];
+    float v = s[c];
+    if (gsums) {
+        const float k0 = gsums[c] * inv_count, k1 = gsums[C + c] * inv_count;
+        v = (v - rows * k0) - s[2 * C + c] * k1;
+    }
+    out[i] = gi * v;
+}
+
+// ---- y = x_0 + x_1 + ... + x_{n-1} (n <= 8 dense tensors of one layout): the gradients arriving at a tensor that feeds
+//      several consumers, added in ONE pass with float32 accumulation (input order) and a single rounding -- instead of
+//      n - 1 pairwise additions that each read two tensors, write one and round ----------------------------------------
+struct SumPtrs {
+    const void* p[8];
+};
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void sum_n_kernel(int n, size_t nvec, SumPtrs src, T* __restrict__ y) {
+    typedef typename Io<T, VEC>::Raw Raw;
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += 2 * stride) {
+        const bool two = i + stride < nvec;
+        Raw a[8], b[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < n) {
+                a[k] = Io<T, VEC>::load_raw((const T*)src.p[k] + i * VEC);
+                if (two) b[k] = Io<T, VEC>::load_raw((const T*)src.p[k] + (i + stride) * VEC);
+            }
+        }
+        float acc[VEC], acc2[VEC], v[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = acc2[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < n) {
+                Io<T, VEC>::unpack(a[k], v);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] += v[j];
+                if (two) {
+                    Io<T, VEC>::unpack(b[k], v);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) acc2[j] += v[j];
+                }
+            }
+        }
+        Io<T, VEC>::store(y + i * VEC, acc);
+        if (two) Io<T, VEC>::store(y + (i + stride) * VEC, acc2);
+    }
+}
+
 // ---- host side --------------------------------------------------------------------------------
 inline int status() {
     hipError_t e = hipGetLastError();
@@ -764,6 +825,42 @@ int stp3_bn_apply_bwd(const stp3_bn_dims* p, const void* dy, const void* x, cons
     return status();
 }
 
+
+int stp3_bn_dsbias(int32_t N, int32_t C, int32_t rows, const float* sample_sums, const float* gsums, double count,
+                   const float* gamma, const float* invstd, float* dsbias, void* stream) {
+    if (N <= 0 || C <= 0 || rows <= 0 || !sample_sums || !invstd || !dsbias) return STP3_EINVAL;
+    if (gsums && !(count >= 1.0)) return STP3_EINVAL;
+    if ((int64_t)N * C >= (1LL << 31)) return STP3_EUNSUP;
+    hipLaunchKernelGGL(bn_dsbias_kernel, dim3((unsigned)(((int64_t)N * C + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       (hipStream_t)stream, N, C, (float)rows, sample_sums, gsums, gsums ? (float)(1.0 / count) : 0.f, gamma,
+                       invstd, dsbias);
+    return status();
+}
+
+int stp3_sum_n(int32_t n, int64_t numel, int32_t dtype, const void* const* src, void* y, void* stream) {
+    if (n < 1 || n > 8 || numel <= 0 || !src || !y) return STP3_EINVAL;
+    if (dtype != STP3_DTYPE_F32 && dtype != STP3_DTYPE_BF16) return STP3_EUNSUP;
+    SumPtrs ptrs;
+    const int wide = dtype == STP3_DTYPE_BF16 ? 8 : 4;
+    bool vec = numel % wide == 0 && aligned16(y);
+    for (int k = 0; k < 8; ++k) {
+        ptrs.p[k] = k < n ? src[k] : nullptr;
+        if (k < n && !src[k]) return STP3_EINVAL;
+        vec = vec && (k >= n || aligned16(src[k]));
+    }
+    const size_t nvec = vec ? (size_t)(numel / wide) : (size_t)numel;
+    size_t blocks = (nvec + 2 * kThreads - 1) / (2 * kThreads);
+    if (blocks > 16384) blocks = 16384;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == STP3_DTYPE_BF16) {
+        if (vec) hipLaunchKernelGGL((sum_n_kernel<uint16_t, 8>), dim3((unsigned)blocks), dim3(kThreads), 0, s, n, nvec, ptrs, (uint16_t*)y);
+        else hipLaunchKernelGGL((sum_n_kernel<uint16_t, 1>), dim3((unsigned)blocks), dim3(kThreads), 0, s, n, nvec, ptrs, (uint16_t*)y);
+    } else {
+        if (vec) hipLaunchKernelGGL((sum_n_kernel<float, 4>), dim3((unsigned)blocks), dim3(kThreads), 0, s, n, nvec, ptrs, (float*)y);
+        else hipLaunchKernelGGL((sum_n_kernel<float, 1>), dim3((unsigned)blocks), dim3(kThreads), 0, s, n, nvec, ptrs, (float*)y);
+    }
+    return status();
+}
 
 // ---- single-process composites: the same launches as the split calls above, one host crossing each ----
 int stp3_bn_fwd_train(const stp3_bn_dims* p, const void* x, const float* sbias, const void* res, const float* oscale,

@@ -92,6 +92,11 @@ class ASPPConv(nn.Sequential):
         return conv_module(conv, x)
 
     def forward(self, x):
+        h, w = x.shape[-2:]
+        if self.dilation < h and self.dilation < w:
+            # no tap dropped: the plain conv -> BN -> ReLU chain, i.e. the operator whose convolution epilogue already
+            # produces the BatchNorm statistics (one pass over the branch output less)
+            return run_fused(self, x)
         return bn_act(self[1], self.conv_only(x), ACT_RELU)
 
 
@@ -125,17 +130,49 @@ class ASPP(nn.Module):
         self.project = nn.Sequential(nn.Conv2d(len(self.convs) * out_channels, out_channels, 1, bias=False),
                                      nn.BatchNorm2d(out_channels), nn.ReLU(), nn.Dropout(0.5))
 
+    def _branches_into_one_buffer(self, xs):
+        """The spatial branches (1x1 and the dilated 3x3s, each conv -> BN -> ReLU) with their results written straight into
+        the channel slices of ONE buffer -- the concatenation the projection reads -- instead of four tensors and a
+        ``torch.cat`` (491 MB written and read again for the temporal head of configs[2]).  None when a branch does not
+        qualify for the fused operator (dropped taps, evaluation mode, float32): then the plain route is taken."""
+        from .fused import _fusable_conv_bn, _sync_world as sync_world
+        from .. import ops_fused
+        convs = [(m[0], m[1]) for m in self.convs[:-1]]
+        h, w = xs[0].shape[-2:]
+        if not all(_fusable_conv_bn(c, bn, xs[0]) for c, bn in convs):
+            return None
+        if any(isinstance(m, ASPPConv) and not (m.dilation < h and m.dilation < w) for m in self.convs[:-1]):
+            return None
+        co = convs[0][0].out_channels
+        if co % 8 or any(c.out_channels != co for c, _ in convs):
+            return None
+        if xs[0].dtype != torch.bfloat16:
+            return None
+        n = xs[0].shape[0]
+        buf = torch.empty((n, co * len(convs), h, w), dtype=torch.bfloat16, device=xs[0].device, memory_format=torch.channels_last)
+        parts = []
+        for k, ((c, bn), xi) in enumerate(zip(convs, xs)):
+            parts.append(ops_fused.conv_bn_act(xi, c.weight, c.bias, bn, ACT_RELU, None, ops.RES_NONE, c.stride, c.padding,
+                                               c.dilation, group=False, out_slot=(buf, k * co)))
+        return ops_fused.join_slices(buf, parts)
+
     def forward(self, x):
+        # the branches read one tensor: their input gradients are added in one pass (ops.fan_out), not pairwise
+        xs = ops.fan_out(x, len(self.convs)) if x.is_cuda else [x] * len(self.convs)
+        spatial = None
         if _sync_world(self.convs[0][1]) > 1:
             # N > 1 ranks: the five branches are siblings -- their BatchNorm statistics travel in ONE exchange per pass
-            members = [conv_bn_act_member(x, self.convs[0][0], self.convs[0][1], ACT_RELU)]
-            members += [dict(bn=conv[1], x=conv.conv_only(x), act=ACT_RELU) for conv in self.convs[1:-1]]
-            members.append(dict(bn=self.convs[-1][2], x=self.convs[-1].conv_only(x), act=ACT_RELU))
+            members = [conv_bn_act_member(xs[0], self.convs[0][0], self.convs[0][1], ACT_RELU)]
+            members += [dict(bn=conv[1], x=conv.conv_only(xi), act=ACT_RELU) for conv, xi in zip(self.convs[1:-1], xs[1:-1])]
+            members.append(dict(bn=self.convs[-1][2], x=self.convs[-1].conv_only(xs[-1]), act=ACT_RELU))
             *branches, pooled = bn_act_group(members)
         else:
-            branches = [run_fused(self.convs[0], x)] + [conv(x) for conv in self.convs[1:-1]]
-            pooled = self.convs[-1](x)                               # (N, C, 1, 1)
-        spatial = torch.cat(branches, dim=1)
+            spatial = self._branches_into_one_buffer(xs)
+            if spatial is None:
+                branches = [run_fused(self.convs[0], xs[0])] + [conv(xi) for conv, xi in zip(self.convs[1:-1], xs[1:-1])]
+            pooled = self.convs[-1](xs[-1])                          # (N, C, 1, 1)
+        if spatial is None:
+            spatial = torch.cat(branches, dim=1)
         proj, bn, act, drop = self.project
         n_sp = spatial.shape[1]
         y = conv2d(spatial, proj.weight[:, :n_sp])

@@ -268,12 +268,20 @@ class TemporalBlock(nn.Module):
         lanes = _pad8(self.half_channels) if x2.is_cuda else self.half_channels
         # the pointwise convolutions at the head of the block (two paths, the third path, the skip projection) are
         # siblings: one BatchNorm statistics exchange for all of them when the statistics are shared between ranks
-        heads = [self._pointwise_member(path[0], x2, extra2=extra2, lanes=lanes) for path in self.convolution_paths[:-1]]
-        heads.append(self._pointwise_member(self.convolution_paths[-1], x2, extra2=extra2, lanes=lanes))
+        # x2 feeds the pointwise convolutions, the whole-plane pooling and (without a projection) the skip: their input
+        # gradients are added in one pass (ops.fan_out) instead of pairwise
+        n_use = len(self.convolution_paths) + 1 + int(self.use_pyramid_pooling)
+        xs = ops.fan_out(x2, n_use) if x2.is_cuda else [x2] * n_use
+        heads = [self._pointwise_member(path[0], xi, extra2=extra2, lanes=lanes)
+                 for path, xi in zip(self.convolution_paths[:-1], xs)]
+        k = len(heads)
+        heads.append(self._pointwise_member(self.convolution_paths[-1], xs[k], extra2=extra2, lanes=lanes))
         if self.projection is not None:
-            heads.append(self._pointwise_member(self.projection, x2, relu=False, extra2=extra2))
+            heads.append(self._pointwise_member(self.projection, xs[k + 1], relu=False, extra2=extra2))
+        x_skip = xs[k + 1]                                               # (only used when there is no projection)
         n_pointwise = len(heads)
-        pooled_group = self.pyramid_pooling.whole_plane_members(x, extra, folded=x2) if self.use_pyramid_pooling else None
+        x_pool = xs[k + 2] if self.use_pyramid_pooling else x2
+        pooled_group = self.pyramid_pooling.whole_plane_members(x, extra, folded=x_pool) if self.use_pyramid_pooling else None
         if pooled_group is not None:
             heads += pooled_group[0]
         heads = bn_act_group(heads)
@@ -288,7 +296,7 @@ class TemporalBlock(nn.Module):
         sbias = None
         if self.use_pyramid_pooling:
             off = self._paths_channels
-            for pooled in (pooled_outs if pooled_outs is not None else self.pyramid_pooling(x, extra, folded=x2)):   # (B, C', T, h', w')
+            for pooled in (pooled_outs if pooled_outs is not None else self.pyramid_pooling(x, extra, folded=x_pool)):   # (B, C', T, h', w')
                 cp = pooled.shape[1]
                 p2 = pooled.permute(0, 2, 1, 3, 4).reshape(b * t, cp, *pooled.shape[-2:])
                 contrib = (conv1x1_on_vector(p2.to(y.dtype), wgt[:, off:off + cp].to(y.dtype))
@@ -304,7 +312,7 @@ class TemporalBlock(nn.Module):
                     y = y + contrib
                 off += cp
         assert self.projection is not None or extra is None
-        skip = x2 if self.projection is None else heads[-1]
+        skip = x_skip if self.projection is None else heads[-1]
         out = _bn_act_2d(agg.norm, y, res=skip, sbias=sbias)
         return out.view(b, t, -1, h, w).permute(0, 2, 1, 3, 4)
 

@@ -4,6 +4,7 @@ dictionary (``None`` for disabled heads)."""
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..layers.convolutions import UpsamplingAdd
 from ..layers.fused import ACT_RELU, _sync_world, bn_act, bn_act_group, conv_bn_act_member, conv_module, run_fused
 from .resnet import resnet18
@@ -35,6 +36,14 @@ class _SelectFrame(torch.autograd.Function):
                           memory_format=torch.channels_last if g.is_cuda else torch.contiguous_format).zero_()
         out.view(b, s, *g.shape[1:])[:, idx] = g
         return out, None, None, None
+
+
+# The heads that read the SAME tensor run their first layers (3x3 convolution -> BatchNorm -> ReLU, decoder.py:42-66) as
+# ONE convolution with the output channels of all heads side by side and ONE BatchNorm over those channels, and their
+# 1x1 output convolutions as ONE convolution with a block-diagonal weight: exact (a BatchNorm is per channel, a
+# convolution per output channel), the operand is staged once instead of once per head, five data gradients and their
+# additions become one.  Training mode on the bf16 kernels; everything else takes the heads one by one.
+MERGE_HEADS = True
 
 
 class Decoder(nn.Module):
@@ -73,6 +82,75 @@ class Decoder(nn.Module):
         if self.planning:
             self.costvolume_head = _head(shared, 1)
 
+    def _merged_heads(self, heads, x, others=()):
+        """{name: output} of the heads in ``heads`` (all reading x) through the merged operators and of ``others`` (name,
+        head, input: heads on another tensor -- the hd-map head reads the present frame only) one by one, or None when the
+        configuration does not qualify (see MERGE_HEADS).  With cross-replica statistics the merged BatchNorm and the
+        first BatchNorms of ``others`` are siblings: one exchange per pass for all of them."""
+        from ..layers.fused import _fusable_conv_bn, conv2d
+        from .. import ops_fused
+        if len(heads) < 2:
+            return None
+        convs, bns, lasts = [h[0] for _, h in heads], [h[1] for _, h in heads], [h[3] for _, h in heads]
+        c = convs[0].out_channels
+        if not all(_fusable_conv_bn(cv, bn, x) and cv.out_channels == c and cv.kernel_size == (3, 3) and cv.bias is None
+                   and bn.momentum == bns[0].momentum and bn.eps == bns[0].eps and bn.affine
+                   for cv, bn in zip(convs, bns)) or c % 8:
+            return None
+        running_mean, running_var = self._packed_running_stats(bns)
+        for bn in bns:
+            if bn.num_batches_tracked is not None:
+                ops.bump_batch_counter(bn)
+        shared = _sync_world(bns[0]) > 1
+        w1 = torch.cat([cv.weight for cv in convs], dim=0)                               # (heads * C, Cin, 3, 3)
+        gamma, beta = torch.cat([bn.weight for bn in bns]), torch.cat([bn.bias for bn in bns])
+        args = (x, w1, None, gamma, beta, None, running_mean, running_var,
+                float(bns[0].momentum if bns[0].momentum is not None else 0.1), float(bns[0].eps), int(ACT_RELU),
+                int(ops.RES_NONE), 1, (1, 1), (1, 1), None if shared else False, None)
+        out = {}
+        if shared and others:
+            mids = bn_act_group([('conv_bn_act', args, bns[0])]
+                                + [conv_bn_act_member(inp, head[0], head[1], ACT_RELU) for _, head, inp in others])
+            mid = mids[0]
+            for (name, head, _), m in zip(others, mids[1:]):
+                out[name] = run_fused(list(head)[3:], m)
+        else:
+            mid = ops_fused._ConvBnAct.apply(*args)
+            for name, head, inp in others:
+                out[name] = run_fused(head, inp)
+        # second layers: head k maps its C channels of `mid` to its outputs -- a block-diagonal 1x1 convolution
+        w2 = torch.block_diag(*[m.weight.flatten(1) for m in lasts])[:, :, None, None]    # (sum of outputs, heads * C, 1, 1)
+        b2 = torch.cat([m.bias for m in lasts])
+        y = conv2d(mid, w2, b2)
+        o = 0
+        for (name, head), m in zip(heads, lasts):
+            t = y[:, o:o + m.out_channels]
+            o += m.out_channels
+            for extra in list(head)[4:]:                                 # the sigmoid of the centerness head
+                t = extra(t)
+            out[name] = t
+        return out
+
+    def _packed_running_stats(self, bns):
+        """The running statistics of the heads' BatchNorms as slices of ONE buffer each (the merged BatchNorm updates them
+        in place, all heads at once): the modules' own buffers are re-pointed into it (same values, same names, same
+        state-dict entries); re-packed whenever the modules were moved or reloaded out of it."""
+        packed = self.__dict__.get('_packed_stats')
+        c = bns[0].num_features
+        ok = packed is not None and packed[0].numel() == c * len(bns) and packed[0].device == bns[0].running_mean.device
+        if ok:
+            for k, bn in enumerate(bns):
+                ok = ok and bn.running_mean.data_ptr() == packed[0].data_ptr() + 4 * c * k \
+                    and bn.running_var.data_ptr() == packed[1].data_ptr() + 4 * c * k
+        if not ok:
+            with torch.no_grad():
+                packed = (torch.cat([bn.running_mean.float() for bn in bns]), torch.cat([bn.running_var.float() for bn in bns]))
+                for k, bn in enumerate(bns):
+                    bn.running_mean.data = packed[0][k * c:(k + 1) * c]
+                    bn.running_var.data = packed[1][k * c:(k + 1) * c]
+            self.__dict__['_packed_stats'] = packed
+        return packed
+
     def forward(self, x):
         b, s, c, h, w = x.shape
         x = x.reshape(b * s, c, h, w)
@@ -89,19 +167,28 @@ class Decoder(nn.Module):
         def per_frame(t):
             return None if t is None else t.view(b, s, *t.shape[1:])
 
-        present = _SelectFrame.apply(x, b, s, self.n_present - 1)      # decoder.py:122
-        heads = [('segmentation', self.segmentation_head, x)]
+        # every head reads x: their input gradients are added in one pass (ops.fan_out), not pairwise
+        n_heads = (1 + int(self.predict_pedestrian) + int(self.perceive_hdmap) + 2 * int(self.predict_instance)
+                   + int(self.predict_future_flow) + int(self.planning))
+        xs = iter(ops.fan_out(x, n_heads) if x.is_cuda else [x] * n_heads)
+        heads = [('segmentation', self.segmentation_head, next(xs))]
         if self.predict_pedestrian:
-            heads.append(('pedestrian', self.pedestrian_head, x))
+            heads.append(('pedestrian', self.pedestrian_head, next(xs)))
         if self.perceive_hdmap:
-            heads.append(('hdmap', self.hdmap_head, present))
+            heads.append(('hdmap', self.hdmap_head, _SelectFrame.apply(next(xs), b, s, self.n_present - 1)))   # decoder.py:122
         if self.predict_instance:
-            heads += [('instance_center', self.instance_center_head, x), ('instance_offset', self.instance_offset_head, x)]
+            heads += [('instance_center', self.instance_center_head, next(xs)),
+                      ('instance_offset', self.instance_offset_head, next(xs))]
         if self.predict_future_flow:
-            heads.append(('instance_flow', self.instance_future_head, x))
+            heads.append(('instance_flow', self.instance_future_head, next(xs)))
         if self.planning:
-            heads.append(('costvolume', self.costvolume_head, x))
-        if _sync_world(self.segmentation_head[1]) > 1:
+            heads.append(('costvolume', self.costvolume_head, next(xs)))
+        others = [(name, head, inp) for name, head, inp in heads if name == 'hdmap']
+        merged = self._merged_heads([(name, head) for name, head, inp in heads if name != 'hdmap'], x, others) if MERGE_HEADS else None
+        if merged is not None:
+            # (the handles of ops.fan_out that the merged heads did not take are simply dropped: no gradient arrives there)
+            out = merged
+        elif _sync_world(self.segmentation_head[1]) > 1:
             # N > 1 ranks: the heads are siblings -- the statistics of their first BatchNorms travel in ONE exchange per
             # pass; the 1x1 output convolutions (and the sigmoid of the centerness head) follow per head
             mids = bn_act_group([conv_bn_act_member(inp, head[0], head[1], ACT_RELU) for _, head, inp in heads])

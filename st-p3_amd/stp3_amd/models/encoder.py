@@ -47,9 +47,10 @@ class Encoder(nn.Module):
             delattr(self.backbone, name)
 
     def _drop_connect_scales(self, x, rates):
-        """Drop-connect factors floor(keep + u) / keep of every residual block, u ~ U[0,1)^N drawn block by block in
-        block order (the same generator calls as drawing inside each block), the arithmetic on all of them at once:
-        3 small launches per step instead of 3 per block."""
+        """Drop-connect factors floor(keep + u) / keep of every residual block, u ~ U[0,1)^N for all blocks drawn with ONE
+        generator call and the arithmetic on all of them at once: 3 small launches per step instead of 3 per block (17
+        generator launches when drawn block by block; the device generator's stream is no part of any contract -- the
+        reference draws on the GPU, efficientnet_pytorch utils.drop_connect)."""
         which = [i for i, b in enumerate(self.backbone._blocks)
                  if rates[i] and b.stride == 1 and b.in_ch == b.out_ch]
         if not which:
@@ -59,7 +60,7 @@ class Encoder(nn.Module):
             self._keep_cache = (key, torch.tensor([1.0 - rates[i] for i in which], dtype=torch.float32,
                                                   device=x.device)[:, None])
         keep = self._keep_cache[1]
-        u = torch.stack([torch.rand(x.shape[0], dtype=torch.float32, device=x.device) for _ in which])
+        u = torch.rand(len(which), x.shape[0], dtype=torch.float32, device=x.device)
         scale = torch.floor(keep + u) / keep
         return {i: scale[k] for k, i in enumerate(which)}
 

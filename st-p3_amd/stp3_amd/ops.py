@@ -823,14 +823,11 @@ class _BnAct(torch.autograd.Function):
             dres = dres.to(ctx.res_dtype)
         dsbias = None
         if sb is not None and ctx.needs_input_grad[4]:
-            g = gamma if gamma is not None else 1.0
-            invstd = stat[3 * c:]
-            sample = sumbuf[:sums_off].view(n, 3, c)
-            if ctx.training:
-                k = gsums / ctx.count
-                dsbias = g * invstd * (sample[:, 0] - rows * k[0] - sample[:, 2] * k[1])
-            else:
-                dsbias = g * invstd * sample[:, 0]
+            # one launch (stp3_bn_dsbias) instead of six small torch operators per layer
+            dsbias = torch.empty(n, c, dtype=torch.float32, device=dev)
+            check(lib.stp3_bn_dsbias(n, c, rows, sumbuf.data_ptr(), gsums.data_ptr() if ctx.training else None,
+                                     max(ctx.count, 1.0), _opt_ptr(gamma), stat.data_ptr() + 12 * c, dsbias.data_ptr(), stream),
+                  'stp3_bn_dsbias')
         return dx, dgamma, dbeta, dres, dsbias, None, None, None, None, None, None, None, None, None, None
 
 
@@ -848,6 +845,55 @@ def bn_act(x, weight, bias, running_mean, running_var, training, momentum, eps, 
     return _BN_APPLY(x, weight, bias, res, sbias, oscale, running_mean, running_var, bool(training),
                         float(momentum if momentum is not None else 0.1), float(eps), int(act), int(res_mode), group,
                         channels)
+
+
+class _FanOut(torch.autograd.Function):
+    """x -> n aliases of x, one per consumer.  What this changes is the BACKWARD: autograd adds the n gradients arriving at
+    a tensor pairwise (n - 1 launches, each reading two tensors, writing one and rounding to bf16); here they are added
+    in ONE pass (stp3_sum_n: float32 accumulation in consumer order, one rounding)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        first = gs[0]
+        same = all(g.shape == first.shape and g.dtype == first.dtype and g.stride() == first.stride() for g in gs)
+        if (first.is_cuda and same and first.dtype in (torch.float32, torch.bfloat16) and len(gs) <= 8
+                and _dense_layout(first)):
+            out = torch.empty_like(first)
+            arr = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+            check(_lib.lib().stp3_sum_n(len(gs), first.numel(), _lib.DTYPE_BF16 if first.dtype == torch.bfloat16 else _lib.DTYPE_F32,
+                                        arr, out.data_ptr(), _stream_handle()), 'stp3_sum_n')
+            return out, None
+        total = gs[0]
+        for g in gs[1:]:
+            total = total + g
+        return total, None
+
+
+def _dense_layout(t):
+    """Non-overlapping and dense (any permutation of a contiguous layout): element order in memory is well defined."""
+    expect = 1
+    for st, sz in sorted((st, sz) for st, sz in zip(t.stride(), t.shape) if sz > 1):
+        if st != expect:
+            return False
+        expect *= sz
+    return True
+
+
+def fan_out(x, n):
+    """n handles on x for n consumers (parallel branches reading one tensor); their gradients are added in one pass."""
+    if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
+        return [x] * max(n, 1)
+    return list(_FanOut.apply(x, n))
 
 
 class _UpsampleBilinear(torch.autograd.Function):

@@ -41,10 +41,10 @@ def conv2d_v2(x, wb, bias, stride, pad, dil, sums_ptr=None):
 class _ConvBnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, cbias, gamma, beta, res, running_mean, running_var, momentum, eps, act, res_mode,
-                stride, pad, dil, group, oscale=None):
+                stride, pad, dil, group, oscale=None, out_slot=None):
         return ops.drive_exchange(_ConvBnAct.forward_steps(ctx, x, weight, cbias, gamma, beta, res, running_mean,
                                                            running_var, momentum, eps, act, res_mode, stride, pad, dil,
-                                                           group, oscale), group)
+                                                           group, oscale, out_slot), group)
 
     @staticmethod
     def backward(ctx, dy):
@@ -52,8 +52,10 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def forward_steps(ctx, x, weight, cbias, gamma, beta, res, running_mean, running_var, momentum, eps, act, res_mode,
-                      stride, pad, dil, group, oscale=None):
-        """``forward`` as a generator (ops.drive_exchange): yields the [2C] statistics when they need the other replicas."""
+                      stride, pad, dil, group, oscale=None, out_slot=None):
+        """``forward`` as a generator (ops.drive_exchange): yields the [2C] statistics when they need the other replicas.
+        ``out_slot`` = (buffer, first channel): the result is written into that channel slice of a wider channels-last
+        tensor (a concatenation that is never copied: ``join_slices``) instead of a tensor of its own."""
         ops._need_gpu(x, weight)
         if x.dtype != torch.bfloat16:
             x = x.to(torch.bfloat16)
@@ -76,15 +78,21 @@ class _ConvBnAct(torch.autograd.Function):
             res, ldr = ops._rows_view(res if res.dtype == torch.bfloat16 else res.to(torch.bfloat16))
         else:
             res_mode = ops.RES_NONE
-        out = torch.empty_like(yc)
+        ldo = cout
+        if out_slot is None:
+            out = torch.empty_like(yc)
+        else:
+            out, ldo = slot_view(out_slot, yc)
         osc = ops._f32(oscale)
-        dims = _lib.BnDims(n, ho * wo, cout, cout, cout, ldr, _lib.DTYPE_BF16, act, res_mode, 0, int(osc is not None))
+        dims = _lib.BnDims(n, ho * wo, cout, cout, ldo, ldr, _lib.DTYPE_BF16, act, res_mode, 0, int(osc is not None))
         g32, b32 = ops._f32(gamma), ops._f32(beta)
         check(_lib.lib().stp3_bn_apply_fwd(ctypes.byref(dims), yc.data_ptr(), None, ops._opt_ptr(res), ops._opt_ptr(osc), base, count,
                                            ops._opt_ptr(g32), ops._opt_ptr(b32), eps, momentum, ops._opt_ptr(running_mean),
                                            ops._opt_ptr(running_var), base + 8 * cout, base + 12 * cout, out.data_ptr(),
                                            ops._stream_handle()), 'stp3_bn_apply_fwd')
         ctx.save_for_backward(x, wb, yc, res if res_mode == ops.RES_BEFORE_ACT else None, g32, b32, stat, osc)
+        if ldo != cout:                         # the backward passes read dy with ITS row stride (set there)
+            dims = _lib.BnDims(n, ho * wo, cout, cout, cout, ldr, _lib.DTYPE_BF16, act, res_mode, 0, int(osc is not None))
         ctx.cfg = (dims, count, world, group, stride, pad, dil, cbias is not None)
         ctx.weight_ref = weight
         ctx.weight_stamp = ops.weight_stamp(weight)
@@ -103,7 +111,15 @@ class _ConvBnAct(torch.autograd.Function):
         lib = _lib.lib()
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
-        dy = dy.contiguous(memory_format=torch.channels_last)
+        dy, ldy = ops._rows_view(dy)
+        if ldy != c:
+            if ldy % 8 == 0 and dy.data_ptr() % 16 == 0:
+                # a channel slice of a wider channels-last tensor (the gradient of a concatenation): read in place with
+                # its own row stride instead of being copied dense first
+                dims = _lib.BnDims(dims.N, dims.rows, dims.C, dims.ldx, ldy, dims.ldr, dims.dtype, dims.act, dims.res_mode, 0,
+                                   dims.has_oscale)
+            else:
+                dy = dy.contiguous(memory_format=torch.channels_last)
         ws, ws_bytes = ops._bn_workspace(n, c, dev)
         sumbuf = torch.empty((n + 1) * 3 * c, dtype=torch.float32, device=dev)
         sums_off = n * 3 * c
@@ -116,6 +132,10 @@ class _ConvBnAct(torch.autograd.Function):
                 res = res.contiguous(memory_format=torch.channels_last)
                 dims = _lib.BnDims(dims.N, dims.rows, dims.C, dims.ldx, dims.ldy, c, dims.dtype, dims.act, dims.res_mode, 0,
                                    dims.has_oscale)
+        if dims.res_mode == ops.RES_AFTER_ACT and dims.ldy != c:
+            dy = dy.contiguous(memory_format=torch.channels_last)       # dres = dy is handed back: dense
+            dims = _lib.BnDims(dims.N, dims.rows, dims.C, dims.ldx, c, dims.ldr, dims.dtype, dims.act, dims.res_mode, 0,
+                               dims.has_oscale)
         stream = ops._stream_handle()
         check(lib.stp3_bn_bwd_reduce(ctypes.byref(dims), dy.data_ptr(), yc.data_ptr(), None, ops._opt_ptr(res), ops._opt_ptr(osc), mean_p,
                                      invstd_p, ops._opt_ptr(g32), ops._opt_ptr(b32), ws.data_ptr(), ws_bytes,
@@ -160,11 +180,48 @@ class _ConvBnAct(torch.autograd.Function):
                 dw = gw.to(wdt)
             if mask[2]:
                 dcb = gb.to(cbdt)
-        return (dx, dw, dcb, dgamma, dbeta, dres) + (None,) * 11
+        return (dx, dw, dcb, dgamma, dbeta, dres) + (None,) * 12
+
+
+def slot_view(out_slot, like):
+    """(channel-slice view of the slot's buffer for a result shaped like ``like``, row stride of the buffer)."""
+    buf, c0 = out_slot
+    n, c, h, w = like.shape
+    if not (buf.is_contiguous(memory_format=torch.channels_last) and buf.shape[0] == n and tuple(buf.shape[2:]) == (h, w)
+            and buf.dtype == like.dtype and c0 % 8 == 0 and c0 + c <= buf.shape[1]):
+        raise _lib.Stp3HipError('output slot does not fit the result (shape / dtype / channels-last / 16-byte channel offset)')
+    return buf[:, c0:c0 + c], buf.shape[1]
+
+
+class _JoinSlices(torch.autograd.Function):
+    """The concatenation along the channels of results that were WRITTEN into the channel slices of one buffer
+    (``out_slot``): returns the buffer -- no copy forward; backward hands every member its channel slice of the gradient
+    (a view: the BatchNorm backward passes read it in place)."""
+
+    @staticmethod
+    def forward(ctx, holder, *parts):
+        buf = holder[0]
+        c0 = 0
+        for p in parts:
+            if p.data_ptr() != buf.data_ptr() + c0 * buf.element_size() or p.shape[1] + c0 > buf.shape[1]:
+                raise _lib.Stp3HipError('join_slices: a part does not lie in its slot')
+            c0 += p.shape[1]
+        if c0 != buf.shape[1]:
+            raise _lib.Stp3HipError('join_slices: the parts do not fill the buffer')
+        ctx.sizes = [p.shape[1] for p in parts]
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + tuple(g.split(ctx.sizes, dim=1))
+
+
+def join_slices(buf, parts):
+    return _JoinSlices.apply((buf,), *parts)
 
 
 def conv_bn_act(x, weight, cbias, bn, act=ops.ACT_NONE, res=None, res_mode=ops.RES_NONE, stride=1, padding=0, dilation=1,
-                group=None, oscale=None):
+                group=None, oscale=None, out_slot=None):
     """Training-mode conv -> BatchNorm -> activation (-> + skip) through the fused kernels (GPU, bf16)."""
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         ops.bump_batch_counter(bn)
@@ -172,7 +229,7 @@ def conv_bn_act(x, weight, cbias, bn, act=ops.ACT_NONE, res=None, res_mode=ops.R
     return _ConvBnAct.apply(x, weight, cbias, bn.weight, bn.bias, res, bn.running_mean if bn.track_running_stats else None,
                             bn.running_var if bn.track_running_stats else None,
                             float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps), int(act), int(res_mode),
-                            s[0], ops._pair(padding), ops._pair(dilation), group, oscale)
+                            s[0], ops._pair(padding), ops._pair(dilation), group, oscale, out_slot)
 
 
 class _SubContext:
@@ -228,8 +285,8 @@ class _ExchangeGroup(torch.autograd.Function):
         grads = ops.drive_exchange_group(gens, group)
         flat = []
         for (kind, n_args), g in zip(specs, grads):
-            assert len(g) == n_args, (kind, len(g), n_args)
-            flat.extend(g)
+            assert len(g) >= n_args and all(v is None for v in g[n_args:]), (kind, len(g), n_args)
+            flat.extend(g[:n_args])                      # (trailing optional arguments the member was not given)
         return (None, None) + tuple(flat)
 
 

@@ -486,6 +486,33 @@ def conv(ops):
     return out
 
 
+def fan_out(ops):
+    """ops.fan_out: the n gradients of a tensor with n consumers added in one pass (stp3_sum_n) -- against the sum in
+    float64; bf16 (float32 accumulation, one rounding: at least as close as the pairwise bf16 additions of autograd) and
+    float32, vector and scalar paths, odd sizes."""
+    out = {}
+    torch.manual_seed(21)
+    for name, (shape, dt, n) in {'bf16_5': ((3, 24, 5, 7), torch.bfloat16, 5), 'f32_3': ((2, 8, 6, 6), torch.float32, 3),
+                                 'bf16_odd_6': ((1, 3, 5, 7), torch.bfloat16, 6), 'f32_8': ((2, 5, 3, 3), torch.float32, 8),
+                                 'bf16_cl_4': ((2, 16, 4, 6), torch.bfloat16, 4)}.items():
+        x = torch.randn(*shape).to(dt)
+        if 'cl' in name:
+            x = x.contiguous(memory_format=torch.channels_last)
+        x.requires_grad_()
+        ws = [torch.randn(*shape).to(dt) for _ in range(n)]
+        if 'cl' in name:
+            ws = [w.contiguous(memory_format=torch.channels_last) for w in ws]
+        handles = ops.fan_out(x, n)
+        sum((h * w).sum() for h, w in zip(handles, ws)).backward()
+        exact = sum(w.double() for w in ws)
+        pair = ws[0].clone()
+        for w in ws[1:]:
+            pair = pair + w                                            # what autograd does: pairwise, rounding every time
+        out[name] = {'err': rel(x.grad.double(), exact), 'pairwise_err': rel(pair.double(), exact),
+                     'layout': list(x.grad.stride()) == list(x.stride()), 'dtype': str(x.grad.dtype)}
+    return out
+
+
 def conv_f32(ops):
     """FLOAT32 operands through the three-term bf16 split (ops.conv2d_f32) on the MFMA kernels, against the same
     convolution in FLOAT64: the route the float32 legs of the GPU parity tests take."""
@@ -700,6 +727,93 @@ def image_prep(ops):
         ref = prep(images)
         torch.Tensor.is_cuda = is_cuda
         out[name] = {'f32_mismatches': int((y32 != ref).sum()), 'bf16_mismatches': int((y16 != ref.to(torch.bfloat16)).sum())}
+    return out
+
+
+def aspp_join(ops):
+    """ASPP (stp3/layers/convolutions.py:217-270) in training mode on bf16 activations: the spatial branches write their
+    results into the channel slices of ONE buffer (ops_fused.join_slices: no concatenation copy), the dilated branches run
+    through the fused conv -> BatchNorm operator, the branches' input gradients are added in one pass (ops.fan_out) --
+    against the module's own torch statements in float32 on the same bf16-representable data (CPU route)."""
+    import torch.nn as nn
+    from stp3_amd.layers.convolutions import ASPP
+    from stp3_amd import ops_fused
+    is_cuda = torch.Tensor.is_cuda
+    out = {}
+    torch.manual_seed(31)
+    for name, (cin, co, rates, hw) in {'all_fused': (16, 16, (1, 2, 3), (9, 10)), 'one_sliced': (16, 8, (2, 3, 12), (9, 10))}.items():
+        m = ASPP(cin, rates, co).train()
+        m.project[3].p = 0.0
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(p.to(torch.bfloat16).float())
+        x0 = torch.randn(2, cin, *hw).to(torch.bfloat16)
+        gy = None
+        res, joined = [], []
+        real_join = ops_fused.join_slices
+        ops_fused.join_slices = lambda buf, parts: (joined.append(len(parts)), real_join(buf, parts))[1]
+        for kernel in (True, False):
+            torch.Tensor.is_cuda = is_cuda if kernel else property(lambda self: False)
+            m.zero_grad()
+            x = (x0.clone().contiguous(memory_format=torch.channels_last) if kernel else x0.float()).requires_grad_()
+            with torch.autocast('cpu', dtype=torch.bfloat16, enabled=kernel):
+                y = m(x)
+            if gy is None:
+                gy = torch.randn(y.shape).to(torch.bfloat16)
+            y.backward(gy.to(y.dtype))
+            res.append((y.detach().float(), x.grad.float(), torch.cat([p.grad.flatten() for p in m.parameters()])))
+        torch.Tensor.is_cuda = is_cuda
+        ops_fused.join_slices = real_join
+        out[name] = {'y': rel(res[0][0], res[1][0]), 'dx': rel(res[0][1], res[1][1]), 'dparam': rel(res[0][2], res[1][2]),
+                     'joined': joined}
+    return out
+
+
+def decoder_heads(ops):
+    """Decoder (stp3/models/decoder.py:8-140) in training mode on bf16 activations with the heads that read the same
+    tensor MERGED (one 3x3 convolution + one BatchNorm over all heads' channels, one block-diagonal 1x1 convolution)
+    against the same kernels run head by head: same outputs, gradients, running statistics and batch counters."""
+    from stp3_amd.models import decoder as D
+    from stp3_amd.layers import fused
+    gate = {'perceive_hdmap': True, 'predict_pedestrian': True, 'predict_instance': True, 'predict_future_flow': True,
+            'planning': False}
+    torch.manual_seed(41)
+    # the stand-in's way of switching the GPU autocast on (as the whole-step cases do)
+    torch.is_autocast_enabled = lambda *a: True
+    torch.get_autocast_gpu_dtype = lambda: torch.bfloat16
+    torch.get_autocast_dtype = lambda *a: torch.bfloat16
+    m = D.Decoder(16, 2, 3, 2, gate).train()
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    x0 = torch.randn(1, 3, 16, 16, 16)
+    res, gouts = [], None
+    for merge in (True, False):
+        D.MERGE_HEADS = merge
+        m.load_state_dict(state)
+        m.zero_grad()
+        x = x0.clone().requires_grad_()
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            o = m(x)
+        keys = [k for k, v in o.items() if v is not None]
+        if gouts is None:
+            gouts = {k: torch.randn(o[k].shape) for k in keys}
+        sum((o[k].float() * gouts[k]).sum() for k in keys).backward()
+        fused.flush_batch_counters()
+        heads = {n: p.grad.clone() for n, p in m.named_parameters() if '_head' in n}
+        rest = {n: p.grad.clone() for n, p in m.named_parameters() if '_head' not in n}
+        stats = {n: b.clone() for n, b in m.named_buffers() if '_head' in n}
+        res.append((torch.cat([o[k].float().flatten() for k in keys]), x.grad.clone(), heads, rest, stats))
+    D.MERGE_HEADS = True
+    a, b = res
+    out = {'y': rel(a[0], b[0]), 'dx': rel(a[1], b[1]),
+           'head_grads': max(rel(a[2][n], b[2][n]) for n in a[2]),
+           # (relative L2 over all of them: biases in front of a BatchNorm have noise-level gradients of their own)
+           'other_grads': float((torch.cat([(a[3][n] - b[3][n]).flatten() for n in a[3]]).norm()
+                                 / torch.cat([b[3][n].flatten() for n in a[3]]).norm())),
+           'running_stats': max(rel(a[4][n].double(), b[4][n].double()) for n in a[4]), 'n_head_params': len(a[2]),
+           'aliased': bool(m.segmentation_head[1].running_mean.data_ptr() + 4 * 16 == m.pedestrian_head[1].running_mean.data_ptr())}
+    # the state dict still holds one entry per head with the right values
+    sd = m.state_dict()
+    out['state_dict_ok'] = bool(all(k in sd for k in state) and sd['pedestrian_head.1.running_mean'].shape == (16,))
     return out
 
 
@@ -1106,7 +1220,7 @@ def fuzz(ops, seed=1):
 
 
 CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_frames, lift_coarse_grid, lift_tall, lift_c64_rows56, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
-                                 conv, conv_f32, dwconv, mbconv_mid, losses, plan, image_prep, bn_group_two_ranks)}
+                                 conv, conv_f32, fan_out, aspp_join, decoder_heads, dwconv, mbconv_mid, losses, plan, image_prep, bn_group_two_ranks)}
 
 if __name__ == '__main__':
     ops_mod = setup(sys.argv[1])

@@ -28,7 +28,7 @@ import build as hipcpu_build  # noqa: E402
 
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
 ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
-           ('conv', {}), ('conv_f32', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
+           ('conv', {}), ('conv_f32', {}), ('fan_out', {}), ('aspp_join', {}), ('decoder_heads', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
            ('lift_c64_frames', {}), ('lift_c64_rows56', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
 ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)]
@@ -206,6 +206,38 @@ def test_convolution_kernels(results):
         if name == 'seconds':
             continue
         assert r['y'] <= 1e-5 and r['dx'] <= 1e-5 and r['dw'] <= 1e-4, (name, r)
+
+
+def test_fan_out_adds_the_gradients_in_one_pass(results):
+    for name, r in _get(results, 'fan_out').items():
+        if name == 'seconds':
+            continue
+        tol = 4e-3 if 'bf16' in name else 2e-7                  # one bf16 rounding of the exact sum / float32 accumulation
+        assert r['err'] <= tol and r['err'] <= r['pairwise_err'] + 1e-12 and r['layout'], (name, r)
+
+
+def test_aspp_branches_write_into_one_buffer(results):
+    """ASPP with every branch on the fused conv -> BatchNorm operator: the four spatial branches land in the channel
+    slices of one buffer (join_slices, no torch.cat); a branch with dropped taps keeps the plain route.  Against the
+    module's float32 statements; the population of the pooled branch's BatchNorm is 2 vectors here, hence the loose
+    gradient bounds."""
+    r = _get(results, 'aspp_join')
+    assert r['all_fused']['joined'] == [4] and r['one_sliced']['joined'] == []
+    for name in ('all_fused', 'one_sliced'):
+        assert r[name]['y'] <= 2e-2 and r[name]['dx'] <= 0.3 and r[name]['dparam'] <= 0.15, (name, r[name])
+    assert r['all_fused']['dx'] <= 0.1 and r['all_fused']['dparam'] <= 0.06, r['all_fused']
+
+
+def test_merged_decoder_heads_equal_the_heads_one_by_one(results):
+    """models/decoder.MERGE_HEADS: one 3x3 convolution + one BatchNorm for the first layers of the five heads that read
+    the same tensor, one block-diagonal 1x1 convolution for their output layers -- against the same kernels head by head:
+    outputs to a bf16 rounding of the 1x1 sums, parameter gradients of the heads to float32 summation order, the input
+    gradient to the one rounding that the single data gradient saves, running statistics equal and still one state-dict
+    entry per head (the buffers are slices of one packed buffer now)."""
+    r = _get(results, 'decoder_heads')
+    assert r['aliased'] and r['state_dict_ok'] and r['n_head_params'] == 30, r
+    assert r['y'] <= 2e-3 and r['head_grads'] <= 1e-3 and r['running_stats'] <= 1e-6, r
+    assert r['dx'] <= 2e-2 and r['other_grads'] <= 2e-2, r
 
 
 def test_float32_convolutions_on_the_matrix_core_kernels(results):
