@@ -430,6 +430,19 @@ def main():
     _log(f'timed steps done: {elapsed / args.steps * 1e3:.2f} ms/step')
     assert DRYRUN or torch.isfinite(loss).item(), 'loss is not finite'
 
+    # How long does the HOST need to enqueue one step?  With the GPU drained first, the call returns as soon as the last
+    # kernel is queued (nothing in the step reads a value back), so its duration is the host's own work per step: Python,
+    # autograd, ctypes crossings, torch dispatch.  Where it reaches ms_per_step the step is host-bound and a faster
+    # kernel buys nothing.  Five steps after the timed region; `value` is untouched.
+    host_ms = []
+    for _ in range(5):
+        _sync()
+        h0 = time.perf_counter()
+        step()
+        host_ms.append((time.perf_counter() - h0) * 1e3)
+    _sync()
+    host_ms = sorted(host_ms)[len(host_ms) // 2]
+
     fam = None
     if not args.no_roofline and not DRYRUN:
         fam = family_rooflines(step, args.batch)             # every rank: the steps contain the collectives
@@ -450,6 +463,7 @@ def main():
             # N > 1: every rank's own clock over the same K steps (value uses the slowest), and the collectives one step
             # issues on this rank: BatchNorm statistics exchanges (forward [2C] + backward [3C] sums; sibling layers
             # share one) and gradient-bucket all-reduces
+            'host_enqueue_ms_per_step': round(host_ms, 3),
             'per_rank_ms_per_step': per_rank_ms,
             'collectives_per_step': {'batchnorm_statistics_all_reduces': exchanges['batchnorm'] // max(args.steps, 1),
                                      'gradient_bucket_all_reduces': buckets.reductions_launched // max(args.steps + max(args.warmup, 1), 1)

@@ -657,6 +657,40 @@ int stp3_voxels_sum_fwd(const float* x, const int32_t* seg_off, int32_t n_segmen
 int stp3_voxels_sum_bwd(const float* grad_out, const int32_t* seg_off, int32_t n_segments, int32_t channels,
                         float* grad_x, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * BEV labels of the data loader (csrc/stp3_labels.hip).
+ *
+ * stp3_fill_polygons -- cv2.fillPoly of integer polygons, in order, a later one overwriting an earlier one: what
+ *   stp3/datas/NuscenesData.py:303-338 (get_birds_eye_view_label: instance / segmentation / pedestrian maps from the
+ *   annotation boxes) and :520-564 (road polygons of voxelize_hd_map) call.  OpenCV is a third-party dependency that is
+ *   not vendored under the reference: restated from its published algorithm (8-connected Bresenham outline drawn left to
+ *   right + scanlines between pairs of active edges, ceil(left) .. floor(right), 16.16 fixed-point edge positions with the
+ *   slope truncated), PARITY UNPINNED; cross-checked against an edge-walking restatement and against Pillow.
+ *   polys [n_poly] in paint order: `map` = which of the n_maps [H][W] float32 images, nv <= 8 vertices xy = (column, row)
+ *   as cv2 takes them, `value` painted.  The maps are painted over what they hold (zero them for fresh labels).
+ * stp3_instance_labels -- stp3/utils/instance.py:12-77 convert_instance_mask_to_center_and_offset_label:
+ *   instance [T][H][W] int64 ids (0 = background, 1..K instances); warped [T][H][W] float32 = frame t's instance map warped
+ *   into frame t-1 (warp_features(..., mode='nearest'), frame 0 unused) or NULL (no displacement labels);
+ *   center [T][1][H][W] = max over the frame's instances of exp(-((xc - x)^2 + (yc - y)^2) / sigma^2), (xc, yc) = rounded
+ *   mean pixel of the instance; offset [T][2][H][W] = (xc - x, yc - y) on the instance's pixels, ignore_index elsewhere;
+ *   flow [T][2][H][W] = (rounded mean pixel of the instance's WARPED next-frame mask) - (xc, yc) on the instance's
+ *   pixels when the instance is in the next frame too and its warped mask is not empty, ignore_index elsewhere.
+ *   workspace: stp3_instance_labels_workspace_bytes(T, K) (integer moments; zeroed by the call).  Deterministic.
+ */
+typedef struct stp3_poly {
+    int32_t map, nv;
+    float value;
+    int32_t reserved;
+    int32_t xy[16];
+} stp3_poly;
+
+int stp3_fill_polygons(const stp3_poly* polys, int32_t n_poly, int32_t n_maps, int32_t H, int32_t W, float* maps,
+                       void* stream);
+int stp3_instance_labels_workspace_bytes(int32_t T, int32_t K, size_t* bytes);
+int stp3_instance_labels(int32_t T, int32_t H, int32_t W, int32_t K, float ignore_index, float sigma,
+                         const int64_t* instance, const float* warped, void* workspace, size_t workspace_bytes,
+                         float* center, float* offset, float* flow, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

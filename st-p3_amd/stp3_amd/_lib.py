@@ -106,6 +106,12 @@ class ImageDims(ctypes.Structure):
                                                'out_dtype')] + [('mean', ctypes.c_float * 3), ('std', ctypes.c_float * 3)])
 
 
+class Poly(ctypes.Structure):
+    """struct stp3_poly (include/stp3_hip.h)."""
+    _fields_ = [('map', ctypes.c_int32), ('nv', ctypes.c_int32), ('value', ctypes.c_float), ('reserved', ctypes.c_int32),
+                ('xy', ctypes.c_int32 * 16)]
+
+
 class OptimBucket(ctypes.Structure):
     """struct stp3_optim_bucket (include/stp3_hip.h)."""
     _fields_ = [('grad', ctypes.c_void_p), ('param', ctypes.c_void_p), ('exp_avg', ctypes.c_void_p),
@@ -201,6 +207,10 @@ SIGNATURES = {
     'stp3_image_prep_rows_per_workgroup': (c_int, []),
     'stp3_image_prep_lds_bytes': (c_int, [ctypes.POINTER(ImageDims), c_int32, ctypes.POINTER(c_size_t)]),
     'stp3_image_prep': (c_int, [ctypes.POINTER(ImageDims)] + [c_void_p] * 5 + [c_int32, c_void_p, c_void_p]),
+    'stp3_fill_polygons': (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    'stp3_instance_labels_workspace_bytes': (c_int, [c_int32, c_int32, ctypes.POINTER(c_size_t)]),
+    'stp3_instance_labels': (c_int, [c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                     c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_voxels_sum_fwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     'stp3_voxels_sum_bwd': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
 }

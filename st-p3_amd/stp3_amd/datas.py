@@ -176,3 +176,258 @@ class ImagePreprocessor:
         _lib.check(lib.stp3_image_prep(ctypes.byref(d), ops._ptr(flat), ops._ptr(kk_h), ops._ptr(b_h), ops._ptr(kk_v),
                                        ops._ptr(b_v), strip, ops._ptr(out), ops._stream()), 'stp3_image_prep')
         return out.view(*lead, 3, d.Ho, d.Wo)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BEV labels: what NuscenesData.get_birds_eye_view_label / get_label / __getitem__ do AFTER
+# the nuScenes devkit has answered (annotation boxes, ego poses): box polygons -> label maps, instance ids -> centerness /
+# offset / displacement labels, frames -> one sample dictionary.
+# ----------------------------------------------------------------------------------------------------------------------
+MAX_POLY_VERTICES = 8
+
+
+def box_polygons(bottom_corners_xy, bev_start_position, bev_resolution):
+    """``_get_poly_region_in_image`` (NuscenesData.py:340-353) after the devkit's ``Box``: the (n, 4, 2) ego-frame bottom
+    corners of the annotation boxes -> integer polygon vertices as cv2.fillPoly takes them, (n, 4, 2) int32 with
+    [..., 0] the BEV column and [..., 1] the BEV row (the reference rounds to cells, then swaps the two coordinates)."""
+    pts = np.asarray(bottom_corners_xy, dtype=np.float64)
+    start = np.asarray(bev_start_position, dtype=np.float64)[:2]
+    res = np.asarray(bev_resolution, dtype=np.float64)[:2]
+    cells = np.round((pts - start + res / 2.0) / res).astype(np.int32)
+    return cells[..., [1, 0]]
+
+
+def fill_polygons_reference(polys, values, map_index, n_maps, hw):
+    """cv2.fillPoly, restated (edge walking; the statement CPU tensors take and the tests compare the kernel with):
+    see csrc/stp3_labels.hip for the algorithm and its provenance.  polys: sequence of (nv, 2) integer (column, row)
+    vertex arrays in paint order -> (n_maps, H, W) float32."""
+    h, w = hw
+    maps = np.zeros((n_maps, h, w), dtype=np.float32)
+    for poly, value, mi in zip(polys, values, map_index):
+        poly = np.asarray(poly, dtype=np.int64)
+        img = maps[mi]
+        nv = len(poly)
+        edges = []
+        for v in range(nv):
+            (ax, ay), (bx, by) = poly[v - 1], poly[v]
+            _bresenham(img, int(ax), int(ay), int(bx), int(by), value)
+            if ay == by:
+                continue
+            y0, y1, x0 = (ay, by, ax) if ay < by else (by, ay, bx)
+            num = int(bx - ax) << 16
+            den = int(by - ay)
+            slope = abs(num) // abs(den) * (1 if (num < 0) == (den < 0) else -1)        # C integer division: toward zero
+            edges.append((int(y0), int(y1), int(x0) << 16, slope))
+        if not edges:
+            continue
+        for y in range(max(min(e[0] for e in edges), 0), min(max(e[1] for e in edges), h)):
+            xs = sorted(x0 + slope * (y - y0) for y0, y1, x0, slope in edges if y0 <= y < y1)
+            for left, right in zip(xs[0::2], xs[1::2]):
+                x1, x2 = (left + 65535) >> 16, right >> 16
+                if x1 < w and x2 >= 0:
+                    img[y, max(x1, 0):min(x2, w - 1) + 1] = value
+    return torch.from_numpy(maps)
+
+
+def _bresenham(img, x0, y0, x1, y1, value):
+    """OpenCV's LineIterator, 8-connected, walked left to right (drawing.cpp ``Line``), clipped to the image."""
+    h, w = img.shape
+    if x0 > x1:
+        x0, y0, x1, y1 = x1, y1, x0, y0
+    dx, dy = x1 - x0, y1 - y0
+    sy = -1 if dy < 0 else 1
+    ady = abs(dy)
+    steep = ady > dx
+    big, small = (ady, dx) if steep else (dx, ady)
+    err = big - 2 * small
+    x, y = x0, y0
+    for _ in range(big + 1):
+        if 0 <= x < w and 0 <= y < h:
+            img[y, x] = value
+        diag = err < 0
+        err += -2 * small + (2 * big if diag else 0)
+        if steep:
+            y += sy
+            x += 1 if diag else 0
+        else:
+            x += 1
+            y += sy if diag else 0
+
+
+def fill_polygons(polys, values, map_index, n_maps, hw, device=None):
+    """cv2.fillPoly of integer polygons into ``n_maps`` zero-initialised (H, W) float32 maps, in order (a later polygon
+    overwrites an earlier one); ``polys``: sequence of (nv <= 8, 2) integer (column, row) arrays, ``values`` / ``map_index``
+    per polygon.  On a GPU ``device``: one launch of stp3_fill_polygons; otherwise the restatement above."""
+    device = torch.device(device) if device is not None else torch.device('cpu')
+    if not torch.empty(0, device=device).is_cuda:
+        return fill_polygons_reference(polys, values, map_index, n_maps, hw)
+    h, w = hw
+    arr = (_lib.Poly * max(len(polys), 1))()
+    for rec, poly, value, mi in zip(arr, polys, values, map_index):
+        poly = np.asarray(poly, dtype=np.int64)
+        if not 1 <= len(poly) <= MAX_POLY_VERTICES:
+            raise _lib.Stp3HipError(f'fill_polygons: {len(poly)} vertices (1 .. {MAX_POLY_VERTICES} supported)')
+        rec.map, rec.nv, rec.value = int(mi), len(poly), float(value)
+        for k, (px, py) in enumerate(poly):
+            rec.xy[2 * k], rec.xy[2 * k + 1] = int(px), int(py)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    maps = torch.zeros(n_maps, h, w, dtype=torch.float32, device=device)
+    _lib.check(_lib.lib().stp3_fill_polygons(ops._ptr(table), len(polys), n_maps, h, w, ops._ptr(maps), ops._stream()),
+               'stp3_fill_polygons')
+    return maps
+
+
+def bev_labels_from_boxes(bottom_corners_xy, categories, instance_ids, bev_start_position, bev_resolution, bev_dimension,
+                          device=None):
+    """``get_birds_eye_view_label`` (NuscenesData.py:303-338) for one frame, after the devkit: boxes (n, 4, 2) ego-frame
+    bottom corners in annotation order, ``categories`` 'vehicle' / 'human' / anything else (skipped), ``instance_ids`` the
+    ids the reference's ``instance_map`` assigns -> (segmentation, instance, pedestrian) int64 maps (H, W).  Vehicles paint
+    their id into the instance map (later boxes overwrite earlier ones) and 1 into the segmentation, pedestrians 1 into
+    the pedestrian map."""
+    h, w = int(bev_dimension[0]), int(bev_dimension[1])
+    polys = box_polygons(bottom_corners_xy, bev_start_position, bev_resolution) if len(categories) else []
+    plist, values, index = [], [], []
+    for poly, cat, iid in zip(polys, categories, instance_ids):
+        if 'vehicle' in cat:
+            plist += [poly, poly]
+            values += [float(iid), 1.0]
+            index += [1, 0]
+        elif 'human' in cat:
+            plist.append(poly)
+            values.append(1.0)
+            index.append(2)
+    maps = fill_polygons(plist, values, index, 3, (h, w), device).long()
+    return maps[0], maps[1], maps[2]
+
+
+def instance_labels_reference(instance, future_egomotion, num_instances, ignore_index=255, subtract_egomotion=True,
+                              sigma=3, spatial_extent=None):
+    """``convert_instance_mask_to_center_and_offset_label`` (stp3/utils/instance.py:12-77) with whole-tensor torch
+    operators (CPU tensors; the same arithmetic as the kernel: integer moments, float32 mean, round half to even)."""
+    from .geometry import mat2pose_vec, pose_vec2mat, warp_features
+    t_, h, w = instance.shape
+    dev = instance.device
+    center = torch.zeros(t_, 1, h, w, device=dev)
+    offset = ignore_index * torch.ones(t_, 2, h, w, device=dev)
+    flow = ignore_index * torch.ones(t_, 2, h, w, device=dev)
+    if num_instances == 0:
+        return center, offset, flow
+    warped = _warp_instances(instance, future_egomotion, subtract_egomotion, spatial_extent)
+    ids = torch.arange(1, num_instances + 1, device=dev).view(1, -1, 1, 1)
+    rows = torch.arange(h, dtype=torch.float32, device=dev).view(1, 1, h, 1)
+    cols = torch.arange(w, dtype=torch.float32, device=dev).view(1, 1, 1, w)
+
+    def moments(maps):                                  # (T, K): count, rounded mean row, rounded mean column
+        m = (maps.unsqueeze(1) == ids).float()
+        cnt = m.sum(dim=(2, 3))
+        safe = cnt.clamp_min(1.0)
+        return cnt, torch.round((m * rows).sum(dim=(2, 3)) / safe), torch.round((m * cols).sum(dim=(2, 3)) / safe)
+    cnt, xc, yc = moments(instance)
+    wcnt, wxc, wyc = moments(warped)
+    present = cnt > 0
+    ox = xc.view(t_, -1, 1, 1) - rows                   # (T, K, H, W)
+    oy = yc.view(t_, -1, 1, 1) - cols
+    g = torch.exp(-(ox ** 2 + oy ** 2) / sigma ** 2)
+    center[:, 0] = torch.where(present.view(t_, -1, 1, 1), g, torch.zeros(())).amax(dim=1)
+    own = (instance.unsqueeze(1) == ids)                # (T, K, H, W): at most one id per pixel
+    sel = own.float()
+    has = own.any(dim=1)
+    offset[:, 0] = torch.where(has, (sel * ox).sum(1), offset[:, 0])
+    offset[:, 1] = torch.where(has, (sel * oy).sum(1), offset[:, 1])
+    if t_ > 1:
+        ok = present[:-1] & present[1:] & (wcnt[1:] > 0)                     # (T-1, K)
+        dxy = torch.stack([wxc[1:] - xc[:-1], wyc[1:] - yc[:-1]], dim=1)     # (T-1, 2, K)
+        moving = own[:-1] & ok.view(t_ - 1, -1, 1, 1)
+        hit = moving.any(dim=1)
+        for a in range(2):
+            val = (moving.float() * dxy[:, a].view(t_ - 1, -1, 1, 1)).sum(1)
+            flow[:-1, a] = torch.where(hit, val, flow[:-1, a])
+    return center, offset, flow
+
+
+def _warp_instances(instance, future_egomotion, subtract_egomotion, spatial_extent):
+    """Frame t's instance map warped into frame t - 1 (instance.py:21-31); frame 0 is a copy that nothing reads.  The
+    reference applies the warp only when ``subtract_egomotion`` (its inverse-motion tensor does not exist otherwise)."""
+    from .geometry import mat2pose_vec, pose_vec2mat, warp_features
+    if not subtract_egomotion:
+        raise NotImplementedError('subtract_egomotion=False: the reference itself fails (future_egomotion_inv is undefined)')
+    inv = mat2pose_vec(torch.inverse(pose_vec2mat(future_egomotion.float())))
+    out = instance.float().clone()
+    if instance.shape[0] > 1:
+        out[1:] = warp_features(instance[1:].unsqueeze(1).float(), inv[:-1].to(instance.device), mode='nearest',
+                                spatial_extent=spatial_extent)[:, 0]
+    return out
+
+
+def instance_labels(instance, future_egomotion, num_instances, ignore_index=255, subtract_egomotion=True, sigma=3,
+                    spatial_extent=None):
+    """``convert_instance_mask_to_center_and_offset_label`` (stp3/utils/instance.py:12-77): instance (T, H, W) int64 ids,
+    future_egomotion (T, 6) -> centerness (T, 1, H, W), offset (T, 2, H, W), future displacement (T, 2, H, W), float32.
+    GPU tensors: the warp through stp3_warp_nearest, the labels through stp3_instance_labels (integer moments, no
+    per-instance Python loop)."""
+    if not instance.is_cuda:
+        return instance_labels_reference(instance, future_egomotion, num_instances, ignore_index, subtract_egomotion, sigma,
+                                         spatial_extent)
+    from . import ops_loss
+    from .geometry import mat2pose_vec, pose_vec2mat, warp_theta
+    t_, h, w = instance.shape
+    dev = instance.device
+    inst = instance.long().contiguous()
+    warped = None
+    if t_ > 1:
+        if not subtract_egomotion:
+            raise NotImplementedError('subtract_egomotion=False: the reference itself fails (future_egomotion_inv is undefined)')
+        inv = mat2pose_vec(torch.inverse(pose_vec2mat(future_egomotion.detach().float().cpu())))
+        theta = torch.cat([torch.zeros(1, 2, 3), warp_theta(inv[:-1], spatial_extent)], dim=0)
+        warped = ops_loss.warp_nearest(inst.float().unsqueeze(1), theta, [1] + [0] * (t_ - 1))[:, 0].contiguous()
+    lib = _lib.lib()
+    need = ctypes.c_size_t()
+    _lib.check(lib.stp3_instance_labels_workspace_bytes(t_, int(num_instances), ctypes.byref(need)),
+               'stp3_instance_labels_workspace_bytes')
+    ws = torch.empty(max(need.value, 16), dtype=torch.uint8, device=dev)
+    center = torch.empty(t_, 1, h, w, dtype=torch.float32, device=dev)
+    offset = torch.empty(t_, 2, h, w, dtype=torch.float32, device=dev)
+    flow = torch.empty(t_, 2, h, w, dtype=torch.float32, device=dev)
+    _lib.check(lib.stp3_instance_labels(t_, h, w, int(num_instances), float(ignore_index), float(sigma), ops._ptr(inst),
+                                        ops._ptr(warped) if warped is not None else None, ops._ptr(ws), need.value,
+                                        ops._ptr(center), ops._ptr(offset), ops._ptr(flow), ops._stream()),
+               'stp3_instance_labels')
+    return center, offset, flow
+
+
+SAMPLE_CAT_KEYS = ('image', 'intrinsics', 'extrinsics', 'depths', 'segmentation', 'instance', 'future_egomotion', 'hdmap',
+                   'pedestrian')
+
+
+def assemble_sample(frames, receptive_field, num_instances, planning=None, gt_depth=False, ignore_index=255,
+                    spatial_extent=None):
+    """``NuscenesData.__getitem__`` (NuscenesData.py:569-646) after the per-frame queries: ``frames`` = one dictionary per
+    time step with the tensors the reference's helpers return for it -- image (1, N, 3, H, W), intrinsics (1, N, 3, 3),
+    extrinsics (1, N, 4, 4) [, depths (1, N, H, W)] for the first ``receptive_field`` frames; segmentation / pedestrian
+    (1, 1, X, Y), instance (1, X, Y), future_egomotion (1, 6), hdmap (1, C, X, Y) and ``index`` for all -- concatenated
+    over time under the reference's keys, plus the instance-derived labels.  ``planning``: the present frame's
+    gt_trajectory / command / sample_trajectory (dict), placeholders of the reference's shapes otherwise."""
+    data = {k: [] for k in SAMPLE_CAT_KEYS}
+    data['indices'] = []
+    for i, fr in enumerate(frames):
+        if i < receptive_field:
+            for k in ('image', 'intrinsics', 'extrinsics'):
+                data[k].append(fr[k])
+            if gt_depth:
+                data['depths'].append(fr['depths'])
+        for k in ('segmentation', 'instance', 'pedestrian', 'future_egomotion', 'hdmap'):
+            data[k].append(fr[k])
+        data['indices'].append(fr.get('index', i))
+    for k in SAMPLE_CAT_KEYS:
+        if k == 'depths' and not gt_depth:
+            continue
+        data[k] = torch.cat(data[k], dim=0)
+    planning = planning or {}
+    data['gt_trajectory'] = planning.get('gt_trajectory', torch.zeros(1, 3))
+    data['command'] = planning.get('command', 'FORWARD')
+    data['sample_trajectory'] = planning.get('sample_trajectory', torch.zeros(1, 1, 3))
+    data['target_point'] = torch.tensor([0., 0.])
+    data['centerness'], data['offset'], data['flow'] = instance_labels(
+        data['instance'], data['future_egomotion'], num_instances, ignore_index=ignore_index, subtract_egomotion=True,
+        spatial_extent=spatial_extent)
+    return data

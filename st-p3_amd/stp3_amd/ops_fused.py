@@ -168,7 +168,7 @@ class _ConvBnAct(torch.autograd.Function):
         if hip_dw:
             dw = ops._conv2d_wgrad(dconv, x, (cout, cin, kh, kw), stride, pad, dil).to(wdt)
             if need_db:
-                dcb = dconv.float().sum(dim=(0, 2, 3)).to(cbdt)
+                dcb = ops.channel_sums(dconv).to(cbdt)
         mask = [need_dx and not hip_dx, need_dw and not hip_dw, need_db and not hip_dw]
         if any(mask):
             xd = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)

@@ -706,6 +706,35 @@ def plan(ops):
     return out
 
 
+def labels(ops):
+    """csrc/stp3_labels.hip through stp3_amd.datas (GPU route): polygon fill against the oracle's fixture and against the
+    CPU statement on random polygons (3 .. 8 vertices, partly outside the image, painted over each other); instance labels
+    against the REFERENCE's own function (tests/golden/labels.npz)."""
+    from stp3_amd import datas
+    from tests import helpers as H
+    is_cuda = torch.Tensor.is_cuda
+    g = H.load('labels.npz')
+    polys = list(g['poly/vertices'])
+    want = np.unpackbits(g['poly/oracle'], axis=1).reshape(40, 200, 200)
+    got = datas.fill_polygons(polys, [1.0] * 40, list(range(40)), 40, (200, 200), device='cpu').numpy()
+    rng = np.random.default_rng(5)
+    many = [rng.integers(-20, 120, (int(rng.integers(3, 9)), 2)) for _ in range(60)]
+    vals = [float(i % 7 + 1) for i in range(60)]
+    idx = [i % 5 for i in range(60)]
+    a = datas.fill_polygons(many, vals, idx, 5, (96, 104), device='cpu').numpy()
+    torch.Tensor.is_cuda = property(lambda self: False)
+    b = datas.fill_polygons(many, vals, idx, 5, (96, 104)).numpy()
+    torch.Tensor.is_cuda = is_cuda
+    inst = torch.from_numpy(g['instance/ids'].astype(np.int64))
+    ego = torch.from_numpy(g['instance/future_egomotion'])
+    center, offset, flow = datas.instance_labels(inst, ego, int(g['instance/num_instances'][0]), spatial_extent=(50.0, 50.0))
+    return {'fixture_mismatches': int((got.astype(np.uint8) != want).sum()), 'random_mismatches': int((a != b).sum()),
+            'painted': int((a != 0).sum()),
+            'offset_mismatches': int((offset != torch.from_numpy(g['instance/offset'])).sum()),
+            'flow_mismatches': int((flow != torch.from_numpy(g['instance/flow'])).sum()),
+            'center_err': err(center, g['instance/center'])}
+
+
 def image_prep(ops):
     """csrc/stp3_image.hip through stp3_amd.datas.ImagePreprocessor (GPU route) against the torch statements of the same
     module (CPU route; byte-exact with Pillow, tests/test_datas_cpu.py): float32 and bf16 output, a crop inside the
@@ -1220,7 +1249,7 @@ def fuzz(ops, seed=1):
 
 
 CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_frames, lift_coarse_grid, lift_tall, lift_c64_rows56, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
-                                 conv, conv_f32, fan_out, aspp_join, decoder_heads, dwconv, mbconv_mid, losses, plan, image_prep, bn_group_two_ranks)}
+                                 conv, conv_f32, fan_out, aspp_join, decoder_heads, dwconv, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
 
 if __name__ == '__main__':
     ops_mod = setup(sys.argv[1])

@@ -28,9 +28,9 @@ import build as hipcpu_build  # noqa: E402
 
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
 ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
-           ('conv', {}), ('conv_f32', {}), ('fan_out', {}), ('aspp_join', {}), ('decoder_heads', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
+           ('conv', {}), ('conv_f32', {}), ('fan_out', {}), ('aspp_join', {}), ('decoder_heads', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('labels', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
            ('lift_c64_frames', {}), ('lift_c64_rows56', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
-ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'lift_c16']
+ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'labels', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)]
 MODEL = [('lift_full', {}), ('model_step_two_ranks', {}), ('model_step_f32_full_losses', {}), ('model_step_f32', {}),
          ('model_step_bf16_bn_eval', {})]        # whole training steps: minutes, STP3_SLOW_TESTS=1
@@ -206,6 +206,14 @@ def test_convolution_kernels(results):
         if name == 'seconds':
             continue
         assert r['y'] <= 1e-5 and r['dx'] <= 1e-5 and r['dw'] <= 1e-4, (name, r)
+
+
+def test_label_kernels(results):
+    """stp3_fill_polygons (cv2.fillPoly restated: equal to the oracle's fixture and to the CPU statement on random 3..8-gons
+    painted over each other) and stp3_instance_labels (equal to the reference's own function)."""
+    r = _get(results, 'labels')
+    assert r['fixture_mismatches'] == 0 and r['random_mismatches'] == 0 and r['painted'] > 10000, r
+    assert r['offset_mismatches'] == 0 and r['flow_mismatches'] == 0 and r['center_err'] <= 1e-6, r
 
 
 def test_fan_out_adds_the_gradients_in_one_pass(results):
