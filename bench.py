@@ -56,7 +56,24 @@ HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0
 # BASELINE.json configs[2] = Perception.yml + these three switches (Perception.yml itself leaves them off,
 # stp3/configs/carla/Perception.yml:17-39)
 FULL_LOSSES = {'LIFT.GT_DEPTH': True, 'INSTANCE_SEG.ENABLED': True, 'INSTANCE_FLOW.ENABLED': True}
+# rows f2 / f3 of SURVEY.md section 8 (the stages either side of the perception path): the reference's own configurations
+# stp3/configs/nuscenes/Prediction.yml and Planning.yml (receptive field 3, 4 / 6 future frames, BATCHSIZE 2 per GPU)
+PREDICTION = {'N_FUTURE_FRAMES': 4, 'PROBABILISTIC.ENABLED': True, 'PROBABILISTIC.METHOD': 'GAUSSIAN',
+              'SEMANTIC_SEG.PEDESTRIAN.ENABLED': False, 'SEMANTIC_SEG.HDMAP.ENABLED': False, 'INSTANCE_SEG.ENABLED': True,
+              'INSTANCE_FLOW.ENABLED': True, 'FUTURE_DISCOUNT': 0.95, 'MODEL.BN_MOMENTUM': 0.05, 'OPTIMIZER.LR': 2e-4}
+PLANNING = {'N_FUTURE_FRAMES': 6, 'PROBABILISTIC.ENABLED': True, 'PROBABILISTIC.METHOD': 'GAUSSIAN',
+            'SEMANTIC_SEG.PEDESTRIAN.ENABLED': True, 'SEMANTIC_SEG.HDMAP.ENABLED': True, 'INSTANCE_SEG.ENABLED': False,
+            'INSTANCE_FLOW.ENABLED': False, 'PLANNING.ENABLED': True, 'PLANNING.SAMPLE_NUM': 1800, 'FUTURE_DISCOUNT': 0.95,
+            'MODEL.BN_MOMENTUM': 0.05, 'OPTIMIZER.LR': 2e-4}
+WORKLOAD_CFG = {'c3': FULL_LOSSES, 'perception': {}, 'prediction': PREDICTION, 'planning': PLANNING}
 WORKLOADS = {
+    'prediction': 'stp3/configs/nuscenes/Prediction.yml (SURVEY.md section 8 row f2): batch=4/GPU, 6-cam 224x480, T=3 + 4 '
+                  'future frames, STP3 with the Gaussian present distribution and the future-prediction stage (Dual_GRU, '
+                  'SpatialGRU, ConvNeXt blocks), segmentation + instance centerness/offset + flow losses over 7 frames, '
+                  'grad-clip 5, Adam',
+    'planning': 'stp3/configs/nuscenes/Planning.yml (SURVEY.md section 8 row f3): batch=4/GPU, 6-cam 224x480, T=3 + 6 future '
+                'frames, prediction stage + cost-volume head + planner (1 800 sampled trajectories scored in one launch, GRU '
+                'refinement), segmentation + pedestrian + hdmap + planning losses over 9 frames, grad-clip 5, Adam',
     'c3': 'BASELINE configs[2]: batch=4/GPU, 6-cam 224x480, T=3, full STP3 fwd+bwd with segmentation + pedestrian + '
           'hdmap + depth CE + instance centerness/offset + flow losses, grad-clip 5, Adam; EfficientNet-B4, D=48, '
           'C=64, BEV 200x200',
@@ -71,7 +88,7 @@ def build_module(device, sync_bn, workload='c3'):
     from stp3_amd.trainer import TrainingModule
     from stp3_amd.utils import to_channels_last
     torch.manual_seed(1234)
-    cfg = perception_cfg(**(FULL_LOSSES if workload == 'c3' else {}))
+    cfg = perception_cfg(**WORKLOAD_CFG[workload])
     module = TrainingModule(cfg.convert_to_dict())
     from stp3_amd.parallel import convert_sync_batchnorm
     module = convert_sync_batchnorm(module, enabled=sync_bn)
@@ -83,7 +100,11 @@ def build_module(device, sync_bn, workload='c3'):
 def make_device_batch(batch_size, device, seed, workload='c3'):
     from stp3_amd import synthetic
     full = workload == 'c3'
-    batch = synthetic.make_batch(batch=batch_size, seq=3, seed=seed, gt_depth=full, instance=full)
+    over = WORKLOAD_CFG[workload]
+    n_future = over.get('N_FUTURE_FRAMES', 0)
+    batch = synthetic.make_batch(batch=batch_size, seq=3 + n_future, seed=seed, gt_depth=full,
+                                 instance=full or bool(over.get('INSTANCE_SEG.ENABLED')),
+                                 planning=(n_future, over['PLANNING.SAMPLE_NUM']) if over.get('PLANNING.ENABLED') else None)
     out = {}
     for k, v in batch.items():
         if not torch.is_tensor(v):
@@ -125,7 +146,7 @@ def _cpu_baseline_worker(workload='c3'):
     cores = os.cpu_count() or 1
     torch.manual_seed(1234)
     full = workload == 'c3'
-    cfg = perception_cfg(**(FULL_LOSSES if full else {}))
+    cfg = perception_cfg(**WORKLOAD_CFG[workload])
     module = TrainingModule(cfg.convert_to_dict())
     port = CpuPortSTP3(cfg)
     port.load_state_dict(module.model.state_dict(), strict=False)
@@ -274,7 +295,7 @@ MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak of one MI355X (MI355X_MICR
 CONV_GFLOP_PER_SAMPLE_FWD = 292.4   # 2 x 146.2 GMAC (trunk, heads, temporal model, decoder), T = 3
 
 
-def family_rooflines(step, batch_size, steps=3):
+def family_rooflines(step, batch_size, steps=3, perception_flops=True):
     """Per-family rooflines of the training step, MEASURED IN THIS RUN: `steps` extra steps (after the timed region, so
     that `value` is untouched) with every C-ABI call bracketed by events on its own stream (stp3_amd/profiling.py).
       conv       : algorithmic flops of SURVEY.md section 8(d) (forward x 3 for forward + data + weight gradient) / time
@@ -292,7 +313,9 @@ def family_rooflines(step, batch_size, steps=3):
     conv = [fam[k] for k in ('conv_fwd_dgrad', 'conv_wgrad') if k in fam]
     if conv:
         ms = sum(f['ms'] for f in conv) / steps
-        alg = 3.0 * CONV_GFLOP_PER_SAMPLE_FWD * 1e9 * batch_size
+        # SURVEY.md section 8(d) states the algorithmic flops of the PERCEPTION step; the prediction / planning legs count
+        # the flops of the shapes they launch
+        alg = 3.0 * CONV_GFLOP_PER_SAMPLE_FWD * 1e9 * batch_size if perception_flops else sum(f['work'] for f in conv) / steps
         ach = alg / (ms * 1e-3) / 1e12
         out['conv'] = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                        'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'ms_per_step': round(ms, 3),
@@ -338,7 +361,9 @@ def main():
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-roofline', action='store_true', help='skip the voxel-pool micro-benchmark (profiling runs)')
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='c3',
-                    help='c3: BASELINE configs[2] (all losses incl. depth + instance + flow); perception: Perception.yml')
+                    help='c3: BASELINE configs[2] (all losses incl. depth + instance + flow); perception: Perception.yml; '
+                         'prediction / planning: the reference\'s Prediction.yml / Planning.yml (rows f2 / f3: own bench legs, '
+                         'not the headline metric)')
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         _cpu_baseline_worker(args.workload)
@@ -445,13 +470,15 @@ def main():
 
     fam = None
     if not args.no_roofline and not DRYRUN:
-        fam = family_rooflines(step, args.batch)             # every rank: the steps contain the collectives
+        fam = family_rooflines(step, args.batch, perception_flops=workload in ('c3', 'perception'))   # every rank: the steps contain the collectives
     if rank == 0:
         module.model.prebuilt_plan = None
         roof, kernel_ms = (None, {}) if args.no_roofline else lift_roofline(device, batch, module.model)
         _log('roofline microbench done')
         line = {
-            'metric': 'BEV samples/sec (6-cam x 3-frame fwd+bwd)', 'value': round(args.batch * world * args.steps / elapsed, 3),
+            'metric': 'BEV samples/sec (6-cam x 3-frame fwd+bwd)' if workload in ('c3', 'perception') else
+                      f'BEV samples/sec (6-cam x 3-frame + {WORKLOAD_CFG[workload]["N_FUTURE_FRAMES"]} future frames fwd+bwd, {workload} stage)',
+            'value': round(args.batch * world * args.steps / elapsed, 3),
             'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': max(args.warmup, 1),
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16 convs / f32 voxel pool', 'data': 'synthetic',
@@ -473,7 +500,7 @@ def main():
         if fam:
             line['roofline_conv'] = fam.get('conv')
             line['roofline_bn'] = fam.get('batchnorm')
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and workload in ('c3', 'perception'):
             try:
                 line['cpu_baseline'] = cpu_baseline(workload)
             except Exception as e:  # the baseline must never take the GPU number down with it

@@ -13,7 +13,7 @@ synthetic c3 batch, and records for each variant
     the 6 decoder heads): 512-sample fingerprints + norms of its input, its output and the gradient arriving at its
     output (forward hooks + ``retain_grad`` -- tests/helpers.BlockTaps, the same code the GPU test runs on the product).
 
-Variants: ``b<B>k<0|1>[d]`` = batch size B, top-k selection of the segmentation losses off / on
+Variants: ``[c5]b<B>k<0|1>[d]`` = (``c5``: BASELINE configs[4] geometry on a one-camera rig, see C5_GEOMETRY) batch size B, top-k selection of the segmentation losses off / on
 (SEMANTIC_SEG.*.USE_TOP_K, stp3/losses.py:43-76), ``d`` = the reference evaluated in FLOAT64.  ``b4k1`` IS configs[2],
 reference unmodified, float32.
 
@@ -107,12 +107,26 @@ def topk_ratios(over):
     return out
 
 
+# BASELINE configs[4] geometry: 896 x 1600 images (fH x fW = 112 x 200), D = 64 depth bins, 400 x 400 BEV cells of 0.25 m --
+# on a rig this container can hold in float32: ONE camera, T = 3 frames, one sample (3 images of 1.4 MP; the six-camera,
+# five-frame sample of the configuration needs > 100 GB of float32 activations on the CPU).  Every operator of the step
+# runs at the configuration's sizes: the trunk at 448 x 800 .. 56 x 100, the lift with 112-row columns and 64 bins into
+# 160 000 cells, the temporal model and the decoder on 400 x 400 maps.
+C5_GEOMETRY = {'IMAGE.FINAL_DIM': (896, 1600), 'LIFT.X_BOUND': [-50.0, 50.0, 0.25], 'LIFT.Y_BOUND': [-50.0, 50.0, 0.25],
+               'LIFT.D_BOUND': [2.0, 66.0, 1.0]}
+C5_BATCH = dict(n_cams=1, final_dim=(896, 1600), bev=(400, 400))
+
+
 def variant_cfg(variant):
     variant = variant.rstrip('d')
-    batch, topk = int(variant[1:variant.index('k')]), variant.endswith('k1')
+    c5 = variant.startswith('c5')
+    body = variant[2:] if c5 else variant
+    batch, topk = int(body[1:body.index('k')]), body.endswith('k1')
     over = dict(C3)
     if not topk:
         over.update(NO_TOPK)
+    if c5:
+        over.update(C5_GEOMETRY)
     return batch, over
 
 
@@ -126,7 +140,8 @@ def run_variant(variant, TrainingModule):
     restore = to_float64(ref) if f64 else (lambda: None)
     heads = [f'decoder.{a}' for a in H.DECODER_HEADS.values()]
     taps = H.BlockTaps(ref.model, extra=heads)
-    batch = synthetic.make_batch(batch=batch_size, seq=3, seed=5, gt_depth=True, instance=True)
+    batch = synthetic.make_batch(batch=batch_size, seq=3, seed=5, gt_depth=True, instance=True,
+                                 **(C5_BATCH if variant.startswith('c5') else {}))
     if f64:
         batch['image'] = batch['image'].double()
     # the pixels the reference's top-k losses SELECT (losses.py:76-81, :108-111: a descending sort, the first k kept):

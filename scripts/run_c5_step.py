@@ -3,7 +3,11 @@ bins, 400 x 400 BEV grid at 0.25 m, T = 5 frames, the losses of configs[2] -- on
 per-GPU batch of 4 is 720 images of 1.4 MP).  bf16 autocast, the same eager step as bench.py.  Prints ms per step and the
 peak memory.
 
-    python scripts/run_c5_step.py [batch] [steps]
+    python scripts/run_c5_step.py [batch] [steps] [recompute]
+
+``recompute`` (third argument, 1 / 0; default: on from three samples per GPU): the MBConv blocks of the trunk keep only their
+inputs and are re-run in the backward pass (Encoder.recompute_blocks) -- with it the configuration's four samples per GPU
+fit the 288 GB of one MI355X.
 """
 import os
 import sys
@@ -24,6 +28,7 @@ def main():
     from stp3_amd.utils import to_channels_last
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    recompute = bool(int(sys.argv[3])) if len(sys.argv) > 3 else B >= 3
     T = 5
     small = os.environ.get('C5_SMALL') == '1'             # T = 5 at the configs[2] image / grid size: a quick check of the path
     dim, bev, xb, db = ((224, 480), (200, 200), [-50.0, 50.0, 0.5], [2.0, 50.0, 1.0]) if small else \
@@ -35,6 +40,7 @@ def main():
     torch.manual_seed(1234)
     module = to_channels_last(convert_sync_batchnorm(TrainingModule(cfg.convert_to_dict()), enabled=False).cuda())
     module.train()
+    module.model.encoder.recompute_blocks = recompute
     batch = synthetic.make_batch(batch=B, seq=T, final_dim=dim, bev=bev, seed=0, gt_depth=True, instance=True)
     batch = {k: (v.cuda() if torch.is_tensor(v) and k not in ('intrinsics', 'extrinsics', 'future_egomotion') else v)
              for k, v in batch.items()}
@@ -59,7 +65,7 @@ def main():
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     n_img = B * T * 6
-    print(f'configs[4] geometry, B={B} per GPU, T={T}: {ms:.1f} ms per step = {B / ms * 1e3:.2f} samples/s '
+    print(f'configs[4] geometry, B={B} per GPU, T={T}, trunk recomputation {"on" if recompute else "off"}: {ms:.1f} ms per step = {B / ms * 1e3:.2f} samples/s '
           f'({n_img} images of {dim[0]}x{dim[1]} = {n_img * dim[0] * dim[1] / (72 * 224 * 480):.1f}x the pixels of a configs[2] step); '
           f'loss {float(loss):.4f}, finite {bool(torch.isfinite(loss))}; peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB')
 

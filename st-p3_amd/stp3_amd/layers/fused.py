@@ -84,10 +84,10 @@ def _bn_act_reference_steps(bn, x, act, res, res_mode, sbias, oscale):
         var = (q / count - mean * mean).clamp_min(0.0)
         if bn.training and bn.track_running_stats:
             with torch.no_grad():
-                mom = bn.momentum if bn.momentum is not None else 0.1
+                mom = ops.bn_momentum(bn)
                 bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
                 bn.running_var.mul_(1 - mom).add_(var * (count / max(count - 1.0, 1.0)), alpha=mom)
-                if bn.num_batches_tracked is not None:
+                if bn.num_batches_tracked is not None and not ops.RECOMPUTING[0]:
                     bn.num_batches_tracked.add_(1)
     else:
         mean, var = hp(bn.running_mean), hp(bn.running_var)
@@ -189,7 +189,7 @@ def _kernel_args(bn, x, act, res, res_mode, sbias, oscale):
         res_mode = RES_NONE
     return (x, bn.weight, bn.bias, res, sbias, oscale, bn.running_mean if bn.track_running_stats else None,
             bn.running_var if bn.track_running_stats else None, bool(training),
-            float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps), int(act), int(res_mode), group,
+            ops.bn_momentum(bn), float(bn.eps), int(act), int(res_mode), group,
             bn.num_features if x.shape[1] != bn.num_features else None)
 
 
@@ -242,7 +242,7 @@ def conv_bn_act_member(x, conv, bn, act):
             ops.bump_batch_counter(bn)
         group = None if _sync_world(bn) > 1 else False
         return ('conv_bn_act', (x, conv.weight, conv.bias, bn.weight, bn.bias, None, bn.running_mean, bn.running_var,
-                                float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps), int(act),
+                                ops.bn_momentum(bn), float(bn.eps), int(act),
                                 int(RES_NONE), ops._pair(conv.stride)[0], ops._pair(conv.padding), ops._pair(conv.dilation),
                                 group, None), bn)
     return dict(bn=bn, x=conv_module(conv, x), act=act)

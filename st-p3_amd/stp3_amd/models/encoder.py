@@ -7,12 +7,25 @@ import math
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..layers.convolutions import DeepLabHead, UpsamplingConcat
 from ..layers.fused import ACT_SWISH, bn_act
 from .efficientnet import EfficientNet
 
 _REDUCTION_CHANNELS = {'b4': [0, 24, 32, 56, 160, 448], 'b0': [0, 16, 24, 40, 112, 320]}
 _LAST_BLOCK = {'b4': 21, 'b0': 10}          # last trunk block kept when downsample == 8 (encoder.py:43-46)
+
+
+def _recomputed(block, x, rate, drop_scale):
+    """``block(x)`` keeping only x for the backward pass: the block's forward is run again when its gradients are needed
+    (torch.utils.checkpoint, non-reentrant: the saved tensors of the block's operators are rebuilt on demand).  The second
+    run happens under ``ops.recomputing()``: BatchNorm running statistics and batch counters are not touched again; the
+    drop-connect factors are an argument, so both runs see the same ones; the kernels are deterministic, so the rebuilt
+    activations are the ones the first run made."""
+    import contextlib
+    from torch.utils.checkpoint import checkpoint
+    return checkpoint(lambda t: block(t, drop_connect_rate=rate, drop_scale=drop_scale), x, use_reentrant=False,
+                      context_fn=lambda: (contextlib.nullcontext(), ops.recomputing()))
 
 
 class Encoder(nn.Module):
@@ -27,6 +40,9 @@ class Encoder(nn.Module):
             raise NotImplementedError(cfg.NAME)
         self.backbone = EfficientNet.from_pretrained(cfg.NAME)
         self.delete_unused_layers()
+        # recompute the MBConv blocks' activations in the backward pass instead of keeping them (``_recomputed``): off by
+        # default; what makes BASELINE configs[4]'s four samples per GPU of 896 x 1600 images fit (scripts/run_c5_step.py)
+        self.recompute_blocks = False
         self.reduction_channel = _REDUCTION_CHANNELS[self.version]
         self.upsampling_out_channel = [0, 48, 64, 128, 512]
         index = int(math.log2(self.downsample))
@@ -74,8 +90,12 @@ class Encoder(nn.Module):
         base_rate = bb._global_params.drop_connect_rate
         rates = [base_rate * float(idx) / n_blocks if base_rate else base_rate for idx in range(n_blocks)]
         scales = self._drop_connect_scales(x, rates) if (self.training and x.is_cuda) else {}
+        recompute = self.recompute_blocks and self.training and torch.is_grad_enabled()
         for idx, block in enumerate(bb._blocks):
-            y = block(x, drop_connect_rate=rates[idx], drop_scale=scales.get(idx))
+            if recompute and x.requires_grad:
+                y = _recomputed(block, x, rates[idx], scales.get(idx))
+            else:
+                y = block(x, drop_connect_rate=rates[idx], drop_scale=scales.get(idx))
             if x.size(2) > y.size(2):
                 endpoints.append(x)
             x = y

@@ -557,8 +557,33 @@ def flush_batch_counters():
             torch._foreach_add_(tensors, k)
 
 
+# Set while a block's forward is RE-run during backward (activation recomputation, models/encoder.py): the second run must
+# leave the BatchNorm running statistics and batch counters alone -- they were updated by the first.
+RECOMPUTING = [False]
+
+
+class recomputing:
+    def __enter__(self):
+        self.prev = RECOMPUTING[0]
+        RECOMPUTING[0] = True
+
+    def __exit__(self, *exc):
+        RECOMPUTING[0] = self.prev
+        return False
+
+
+def bn_momentum(bn):
+    """The momentum the kernels update the running statistics with: the module's, or 0 (running = 1 * running + 0 * batch:
+    unchanged, bit for bit) while a forward is being recomputed."""
+    if RECOMPUTING[0]:
+        return 0.0
+    return float(bn.momentum if bn.momentum is not None else 0.1)
+
+
 def bump_batch_counter(bn):
     """``bn.num_batches_tracked += 1`` for a training-mode forward of ``bn`` (immediately, or counted for the flush)."""
+    if RECOMPUTING[0]:
+        return
     if LAZY_COUNTERS and bn.momentum is not None:
         _count_later(bn)
     else:

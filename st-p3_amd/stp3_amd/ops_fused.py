@@ -228,7 +228,7 @@ def conv_bn_act(x, weight, cbias, bn, act=ops.ACT_NONE, res=None, res_mode=ops.R
     s = ops._pair(stride)
     return _ConvBnAct.apply(x, weight, cbias, bn.weight, bn.bias, res, bn.running_mean if bn.track_running_stats else None,
                             bn.running_var if bn.track_running_stats else None,
-                            float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps), int(act), int(res_mode),
+                            ops.bn_momentum(bn), float(bn.eps), int(act), int(res_mode),
                             s[0], ops._pair(padding), ops._pair(dilation), group, oscale, out_slot)
 
 
@@ -576,5 +576,5 @@ def dw_bn_se(x, dw_conv, bn, se_reduce, se_expand, group=None):
     if bn.num_batches_tracked is not None:
         ops.bump_batch_counter(bn)
     return _DwBnSe.apply(x, dw_conv.weight, int(dw_conv.stride[0]), tuple(int(p) for p in dw_conv._pad), bn.weight, bn.bias,
-                         bn.running_mean, bn.running_var, float(bn.momentum if bn.momentum is not None else 0.1),
+                         bn.running_mean, bn.running_var, ops.bn_momentum(bn),
                          float(bn.eps), se_reduce.weight, se_reduce.bias, se_expand.weight, se_expand.bias, group)

@@ -18,7 +18,7 @@ PKG = os.path.join(ROOT, 'st-p3_amd', 'stp3_amd')
 
 
 @pytest.mark.skipif(shutil.which('gcc') is None, reason='needs gcc for the recording library')
-@pytest.mark.parametrize('workload', ['c3', 'perception'])
+@pytest.mark.parametrize('workload', ['c3', 'perception', 'prediction', 'planning'])
 def test_bench_main_dry_run(tmp_path, workload):
     recorder = host_trace.build_recorder(str(tmp_path / 'libstp3hip_recorder.so'))
     env = {k: v for k, v in os.environ.items() if not k.startswith('STP3_')}
@@ -39,6 +39,7 @@ def test_bench_main_dry_run(tmp_path, workload):
     assert line['unit'] == 'samples/s' and line['higher_is_better'] is True and line['data'] == 'synthetic'
     assert 'workload' in line['config'] and 'model' not in line['config']
     assert ('depth CE' in line['config']['workload']) == (workload == 'c3')
+    assert ('future frames' in line['metric']) == (workload in ('prediction', 'planning'))
     assert line['config']['host_options'] == 'grad_gather=1 label_warp=batched lazy_bn_counter=1'   # bit-identical host options
     roof = line['roofline']
     for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
@@ -50,6 +51,8 @@ def test_bench_main_dry_run(tmp_path, workload):
     # what ships is what runs: every operator family of the C ABI shows up in the call trace of one step (the plain
     # stp3_dwconv2d_fwd / stp3_se_pool / stp3_se_scale serve the evaluation-mode forward: BatchNorm on running statistics)
     trace = open(tmp_path / 'trace.log').read()
+    if workload == 'planning':
+        assert 'stp3_traj_cost_fwd ' in trace and 'stp3_traj_cost_bwd ' in trace
     for entry in ('stp3_lift_plan_build', 'stp3_lift_splat_fwd', 'stp3_lift_splat_bwd',
                   'stp3_conv2d_fwd', 'stp3_conv2d_wgrad', 'stp3_conv2d_prep_weights', 'stp3_bn_fwd_train',
                   'stp3_dwconv2d_fwd_stats', 'stp3_bn_finalize', 'stp3_se_pool_act', 'stp3_se_mlp_fwd', 'stp3_se_mlp_bwd',

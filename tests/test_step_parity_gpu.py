@@ -68,18 +68,28 @@ def rel(a, ref):
     return ((a - r).norm() / r.norm().clamp_min(1e-30)).item()
 
 
+# BASELINE configs[4] geometry on the one-camera rig of the ``c5...`` fixtures (oracle/make_golden_step.py: C5_GEOMETRY)
+C5_GEOMETRY = {'IMAGE.FINAL_DIM': (896, 1600), 'LIFT.X_BOUND': [-50.0, 50.0, 0.25], 'LIFT.Y_BOUND': [-50.0, 50.0, 0.25],
+               'LIFT.D_BOUND': [2.0, 66.0, 1.0]}
+C5_BATCH = dict(n_cams=1, final_dim=(896, 1600), bev=(400, 400))
+
+
 def run_product_step(variant):
     from stp3_amd.trainer import TrainingModule
-    batch_size, topk = int(variant[1:variant.index('k')]), variant.endswith('k1')
+    c5 = variant.startswith('c5')
+    body = variant[2:] if c5 else variant
+    batch_size, topk = int(body[1:body.index('k')]), body.endswith('k1')
     over = dict(C3)
     if not topk:
         over.update(NO_TOPK)
+    if c5:
+        over.update(C5_GEOMETRY)
     tm = TrainingModule(perception_cfg(**over).convert_to_dict())
     H.fill_deterministic(tm.model)
     make_deterministic_train(tm)
     tm = tm.to(DEVICE)
     taps = H.BlockTaps(tm.model)
-    batch = synthetic.make_batch(batch=batch_size, seq=3, seed=5, gt_depth=True, instance=True)
+    batch = synthetic.make_batch(batch=batch_size, seq=3, seed=5, gt_depth=True, instance=True, **(C5_BATCH if c5 else {}))
     if PERTURB is not None:
         noise = torch.randn(batch['image'].shape, generator=torch.Generator().manual_seed(PERTURB[0]))
         batch['image'] = batch['image'] * (1.0 + PERTURB[1] * noise)
@@ -204,6 +214,15 @@ def _check_b4(variant, temporal_bound, tag=None, own_selection=True):
 def test_step_b4_smooth():
     """The bench's batch size with the top-k selection off."""
     _check_b4('b4k0', temporal_bound=NOISE_FACTOR_REF * reference_noise()['grad/temporal'] + FLOOR)
+
+
+def test_step_c5_geometry():
+    """BASELINE configs[4] GEOMETRY through the whole float32 step -- 896 x 1600 images, 112-row image columns, 64 depth
+    bins, 400 x 400 BEV cells of 0.25 m -- against the reference's ``shared_step`` on the same rig (one camera, T = 3, one
+    sample: what the reference's float32 run fits into this container's memory; ``step_c5b1k0.npz``), every block tapped:
+    the bounds of the B = 4 cases.  The lift runs on the general column kernels here (fH = 112 > 32), the convolutions on
+    the MFMA kernels at 448 x 800 .. 56 x 100 and 400 x 400."""
+    _check_b4('c5b1k0', temporal_bound=NOISE_FACTOR_REF * reference_noise()['grad/temporal'] + FLOOR)
 
 
 def test_step_b4_configs2():
