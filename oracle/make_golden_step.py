@@ -13,7 +13,7 @@ synthetic c3 batch, and records for each variant
     the 6 decoder heads): 512-sample fingerprints + norms of its input, its output and the gradient arriving at its
     output (forward hooks + ``retain_grad`` -- tests/helpers.BlockTaps, the same code the GPU test runs on the product).
 
-Variants: ``[c5]b<B>k<0|1>[d]`` = (``c5``: BASELINE configs[4] geometry on a one-camera rig, see C5_GEOMETRY) batch size B, top-k selection of the segmentation losses off / on
+Variants: ``[c5]b<B>k<0|1>[d|D]`` (``D``: float64, FORWARD only) = (``c5``: BASELINE configs[4] geometry on a one-camera rig, see C5_GEOMETRY) batch size B, top-k selection of the segmentation losses off / on
 (SEMANTIC_SEG.*.USE_TOP_K, stp3/losses.py:43-76), ``d`` = the reference evaluated in FLOAT64.  ``b4k1`` IS configs[2],
 reference unmodified, float32.
 
@@ -118,7 +118,7 @@ C5_BATCH = dict(n_cams=1, final_dim=(896, 1600), bev=(400, 400))
 
 
 def variant_cfg(variant):
-    variant = variant.rstrip('d')
+    variant = variant.rstrip('dD')
     c5 = variant.startswith('c5')
     body = variant[2:] if c5 else variant
     batch, topk = int(body[1:body.index('k')]), body.endswith('k1')
@@ -132,14 +132,15 @@ def variant_cfg(variant):
 
 def run_variant(variant, TrainingModule):
     batch_size, over = variant_cfg(variant)
-    f64 = variant.endswith('d')
+    forward_only = variant.endswith('D')                 # float64, forward pass only (no-grad: what fits at configs[4] sizes)
+    f64 = variant.endswith('d') or forward_only
     t0 = time.time()
     ref = TrainingModule(perception_cfg(**over).convert_to_dict())
     H.fill_deterministic(ref.model)
     make_deterministic_train(ref)
     restore = to_float64(ref) if f64 else (lambda: None)
     heads = [f'decoder.{a}' for a in H.DECODER_HEADS.values()]
-    taps = H.BlockTaps(ref.model, extra=heads)
+    taps = H.BlockTaps(ref.model, extra=heads, forward_only=forward_only)
     batch = synthetic.make_batch(batch=batch_size, seq=3, seed=5, gt_depth=True, instance=True,
                                  **(C5_BATCH if variant.startswith('c5') else {}))
     if f64:
@@ -155,11 +156,13 @@ def run_variant(variant, TrainingModule):
         return res
     torch.sort = recording_sort
     try:
-        output, labels, loss = ref.shared_step(batch, True)
+        with torch.set_grad_enabled(not forward_only):
+            output, labels, loss = ref.shared_step(batch, True)
     finally:
         torch.sort = real_sort
     total = sum(loss.values())
-    total.backward()
+    if not forward_only:
+        total.backward()
     out = dict(taps.collect())
     for i, idx in enumerate(picked):
         # the reference keeps idx[..., :k] with k = int(ratio * P): stored as one bit per pixel and row
@@ -178,7 +181,8 @@ def run_variant(variant, TrainingModule):
         out[f'out/{k}'] = H.sample(output[k], 256).numpy()
     for k in ('segmentation', 'pedestrian', 'instance', 'centerness', 'offset', 'flow', 'depths', 'hdmap'):
         out[f'label_sum/{k}'] = np.array([labels[k].double().sum().item()])
-    grad_samples(ref.model, 'p', out)
+    if not forward_only:
+        grad_samples(ref.model, 'p', out)
     restore()
     out = {k: (v.astype(np.float32) if v.dtype == np.float64 and v.size > 1 else v) for k, v in out.items()}
     np.savez_compressed(os.path.join(GOLDEN, f'step_{variant}.npz'), **out)

@@ -197,8 +197,9 @@ class BlockTaps:
     keeps the block's first tensor argument's fingerprint, the output tensor (gradient retained) and, after
     ``collect()``, the fingerprints of output and output-gradient."""
 
-    def __init__(self, model, extra=()):
+    def __init__(self, model, extra=(), forward_only=False):
         self.hooks, self.outs, self.fp = [], {}, {}
+        self.forward_only = forward_only                 # taps of a no-grad run (outputs only)
         self.names = [n for n, m in model.named_modules() if type(m).__name__ in BLOCK_CLASS_NAMES]
         self.names += list(extra)
         mods = dict(model.named_modules())
@@ -207,7 +208,11 @@ class BlockTaps:
 
     def _hook(self, name):
         def hook(mod, args, out):
-            if name in self.outs or not torch.is_tensor(out) or not out.requires_grad:
+            if name in self.outs or not torch.is_tensor(out) or not (out.requires_grad or self.forward_only):
+                return
+            if self.forward_only:
+                self.fp[f'{name}/out'], self.fp[f'{name}/out_norm'] = fingerprint(out)
+                self.outs[name] = None
                 return
             out.retain_grad()
             self.outs[name] = out
@@ -220,6 +225,8 @@ class BlockTaps:
         for h in self.hooks:
             h.remove()
         for n, out in self.outs.items():
+            if out is None:
+                continue
             self.fp[f'{n}/out'], self.fp[f'{n}/out_norm'] = fingerprint(out)
             if out.grad is not None:
                 self.fp[f'{n}/gout'], self.fp[f'{n}/gout_norm'] = fingerprint(out.grad)

@@ -216,13 +216,67 @@ def test_step_b4_smooth():
     _check_b4('b4k0', temporal_bound=NOISE_FACTOR_REF * reference_noise()['grad/temporal'] + FLOOR)
 
 
+def forward_noise(f32_name, truth_name):
+    """Distances of the reference's float32 FORWARD (losses, head outputs, block outputs) from its float64 forward."""
+    a, d = H.load(f32_name), H.load(truth_name)
+    n = {'loss_total': abs(a['loss_total'].item() - d['loss_total'].item()) / abs(d['loss_total'].item())}
+    for k in d.files:
+        if k.startswith('loss/'):
+            n[k] = abs(a[k].item() - d[k].item()) / max(abs(d[k].item()), 1e-3)
+        elif k.startswith('out/'):
+            n[k] = rel(a[k], d[k])
+        elif k.endswith('/out'):
+            n[f'tap_out/{k[:-4]}'] = rel(a[k], d[k])
+    return n
+
+
 def test_step_c5_geometry():
     """BASELINE configs[4] GEOMETRY through the whole float32 step -- 896 x 1600 images, 112-row image columns, 64 depth
-    bins, 400 x 400 BEV cells of 0.25 m -- against the reference's ``shared_step`` on the same rig (one camera, T = 3, one
-    sample: what the reference's float32 run fits into this container's memory; ``step_c5b1k0.npz``), every block tapped:
-    the bounds of the B = 4 cases.  The lift runs on the general column kernels here (fH = 112 > 32), the convolutions on
-    the MFMA kernels at 448 x 800 .. 56 x 100 and 400 x 400."""
-    _check_b4('c5b1k0', temporal_bound=NOISE_FACTOR_REF * reference_noise()['grad/temporal'] + FLOOR)
+    bins, 400 x 400 BEV cells of 0.25 m -- on the rig the reference's float32 run fits into this container's memory (one
+    camera, T = 3, one sample; oracle/make_golden_step.py: C5_GEOMETRY), every block tapped.  The lift runs on the general
+    column kernels here (fH = 112 > 32), the convolutions on the MFMA kernels at 448 x 800 .. 56 x 100 and 400 x 400.
+
+    FORWARD, against the reference's FLOAT64 forward of the same step (``step_c5b1k0D.npz``: forward only -- its float64
+    backward does not fit 62 GB): every loss entry, head output and block output within 0.3 x the distance of the
+    reference's own float32 forward from that truth (+ 1e-4) -- measured (profiles/r04h_parity_step_c5.json): the decoder
+    blocks 1e-4 .. 2e-4 where the reference's float32 run is 1e-2 .. 3e-2 off, i.e. 100 x closer.  The reference's noise
+    is large on this rig: a one-camera BEV is 5/6 empty, the BEV-stage
+    BatchNorms normalise populations of mostly identical values, the pooled-descriptor BatchNorms B * T = 3 vectors, and
+    the reference's float32 prefix-sum pooling of 1.4 M points per frame is lossy.
+    BACKWARD: there is no truth for this geometry; the gradients are recorded against the reference's float32 run (whose
+    forward already sits 1e-2 off the truth in the decoder: its ReLU masks differ) and bounded loosely -- a sign error or
+    a missing term would exceed it -- together with the product's own sensitivity to a ONE-ulp perturbation of the
+    images, which is recorded beside them."""
+    global PERTURB
+    noise = forward_noise('step_c5b1k0.npz', 'step_c5b1k0D.npz')
+    # one product run, measured against both fixtures
+    g32, g64 = H.load('step_c5b1k0.npz'), H.load('step_c5b1k0D.npz')
+    tm, output, labels, loss, total, fp = run_product_step('c5b1k0')
+    m = {'loss_total': abs(total.item() - g64['loss_total'].item()) / abs(g64['loss_total'].item())}
+    for k, v in loss.items():
+        m[f'loss/{k}'] = abs(v.item() - g64[f'loss/{k}'].item()) / max(abs(g64[f'loss/{k}'].item()), 1e-3)
+    for k in OUTPUTS:
+        m[f'out/{k}'] = rel(H.sample(output[k], 256).cpu(), g64[f'out/{k}'])
+    for key in g64.files:
+        if key.endswith('/out'):
+            m[f'tap_out/{key[:-4]}'] = rel(fp[key], g64[key])
+    got = {n: H.sample(p.grad, 256).double().cpu() for n, p in tm.model.named_parameters() if p.grad is not None}
+    grads_vs_ref = {f'grad/{k}': v for k, v in group_errors(got, g32).items()}
+    gout_vs_ref = {f'tap_gout/{k[:-5]}': rel(fp[k], g32[k]) for k in g32.files if k.endswith('/gout')}
+    del tm, output, labels, loss, total
+    PERTURB = (100, 1e-7)
+    try:
+        fp2 = run_product_step('c5b1k0')[5]
+    finally:
+        PERTURB = None
+    self_noise = {k: rel(fp2[k[9:] + '/gout'], fp[k[9:] + '/gout']) for k in gout_vs_ref}
+    report('c5b1k0_forward_vs_truth', dict(m, **{'tap_gout/none': 0.0}),
+           {'reference_forward_noise': noise, 'gradients_vs_reference_f32': grads_vs_ref, 'gout_vs_reference_f32': gout_vs_ref,
+            'gout_self_noise_one_ulp': self_noise})
+    bad = {k: (v, noise.get(k, 0.0)) for k, v in m.items() if v > 0.3 * noise.get(k, 0.0) + FLOOR}
+    assert not bad, dict(sorted(bad.items(), key=lambda kv: -kv[1][0])[:8])
+    assert max(grads_vs_ref.values()) <= 1.5, grads_vs_ref
+    assert all(torch.isfinite(torch.as_tensor(v)).all() for v in got.values())
 
 
 def test_step_b4_configs2():
