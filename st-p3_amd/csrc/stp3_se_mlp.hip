@@ -5,7 +5,6 @@
 // efficientnet_pytorch's MBConvBlock).  Written with torch operators that is ~10 launches forward and ~15 backward
 // per block, 22 blocks per step, every one of them launch-latency bound.  Here: one launch forward (a workgroup per
 // sample), two backward (per-sample chain, then the weight gradients reduced over the samples in a fixed order).
-// EXPERIMENTAL: host side selected with STP3_SE_MLP=1 on top of STP3_FUSED_SE=1.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -26,52 +25,71 @@ __device__ __forceinline__ float wave_sum_xor(float v) {
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
 
-constexpr int kRows = 5;        // rows of the small weight matrices a wave reduces together (S <= 40: two rounds)
+// Latency is what these kernels cost (the arithmetic is a few MFLOP): round 3's forward took 29 us per call -- a wave
+// reduced kRows = 5 rows of W1 at a time, two rounds of 15 dependent load batches each -- and the per-sample backward 23 us
+// with an uncoalesced walk down the columns of W2.  Now every thread owns <= kOwn channels and accumulates ITS part of all
+// S dot products at once: S * kOwn independent, coalesced loads in flight per thread, then one pass of wave reductions.
+constexpr int kOwn = 4;          // channels per thread and chunk (256 threads: chunks of 1024 channels)
+constexpr int kMaxS = 64;        // squeezed channels the register accumulators cover (EfficientNet-B4: <= 40)
 
-// forward: grid = N, LDS = (C + S) floats
+// part[s] (this thread's partial sums, s < S <= kMaxS) -> total[s] in LDS for all s; `scratch` [4][kMaxS] floats
+__device__ __forceinline__ void block_sums(const float* part, int S, float* scratch, float* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int s = 0; s < kMaxS; ++s) {
+        if (s < S) {
+            const float v = wave_sum_xor(part[s]);
+            if (lane == 0) scratch[wave * kMaxS + s] = v;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < S)
+        total[threadIdx.x] = (scratch[threadIdx.x] + scratch[kMaxS + threadIdx.x]) +
+                             (scratch[2 * kMaxS + threadIdx.x] + scratch[3 * kMaxS + threadIdx.x]);
+    __syncthreads();
+}
+
+// forward: grid = N, LDS = (5 kMaxS) floats
 __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(stp3_se_mlp_dims d, const float* __restrict__ pooled_sum,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
                                                          const float* __restrict__ w2, const float* __restrict__ b2,
                                                          float* __restrict__ z1, float* __restrict__ gate) {
-    extern __shared__ float smem[];
-    float* p = smem;            // [C] pooled mean
-    float* h = smem + d.C;      // [S] swish(z1)
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int c = tid; c < d.C; c += 256) p[c] = pooled_sum[(size_t)n * d.C + c] * d.inv_rows;
-    __syncthreads();
-    // rows s = wave, wave + 4, ... of W1, kRows at a time: the loads of kRows rows are in flight together and their
-    // wave reductions interleave (one row at a time was a chain of S / 4 dependent load -> reduce round trips: 27 us)
-    for (int s0 = wave; s0 < d.S; s0 += 4 * kRows) {
-        float acc[kRows];
+    __shared__ float scratch[4 * kMaxS];
+    extern __shared__ float h[];    // [S]: W1 p, then swish(z1)
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int sb = 0; sb < d.S; sb += kMaxS) {             // (one round for S <= 64: every EfficientNet-B4 block)
+        const int sn = min(kMaxS, d.S - sb);
+        float acc[kMaxS];
 #pragma unroll
-        for (int k = 0; k < kRows; ++k) acc[k] = 0.f;
-#pragma unroll 4
-        for (int c = lane; c < d.C; c += 64) {            // (unrolled: the loads of four iterations in flight)
-            const float pc = p[c];
+        for (int s = 0; s < kMaxS; ++s) acc[s] = 0.f;
+        for (int c0 = 0; c0 < d.C; c0 += 256 * kOwn) {
+            float pc[kOwn];
 #pragma unroll
-            for (int k = 0; k < kRows; ++k) {
-                const int s = s0 + 4 * k;
-                if (s < d.S) acc[k] = fmaf(w1[(size_t)s * d.C + c], pc, acc[k]);
+            for (int k = 0; k < kOwn; ++k) {
+                const int c = c0 + k * 256 + tid;
+                pc[k] = c < d.C ? pooled_sum[(size_t)n * d.C + c] * d.inv_rows : 0.f;
             }
-        }
 #pragma unroll
-        for (int k = 0; k < kRows; ++k) acc[k] = wave_sum_xor(acc[k]);
-        if (lane == 0) {
+            for (int s = 0; s < kMaxS; ++s) {
+                if (s < sn) {
 #pragma unroll
-            for (int k = 0; k < kRows; ++k) {
-                const int s = s0 + 4 * k;
-                if (s < d.S) {
-                    const float z = acc[k] + b1[s];
-                    z1[(size_t)n * d.S + s] = z;
-                    h[s] = z * sigmoidf_(z);
+                    for (int k = 0; k < kOwn; ++k) {
+                        const int c = c0 + k * 256 + tid;
+                        if (c < d.C) acc[s] = fmaf(w1[(size_t)(sb + s) * d.C + c], pc[k], acc[s]);
+                    }
                 }
             }
         }
+        block_sums(acc, sn, scratch, h + sb);
+    }
+    for (int s = tid; s < d.S; s += 256) {
+        const float z = h[s] + b1[s];
+        z1[(size_t)n * d.S + s] = z;
+        h[s] = z * sigmoidf_(z);
     }
     __syncthreads();
     // a thread owns channel c and walks ITS row of W2 (S consecutive floats): 16-byte loads when the row length allows
-    // (S = 8, 12, 28, 40 of EfficientNet-B4; 6 and 14 take 8-byte loads) -- lane-to-lane the rows are S * 4 bytes apart, so
-    // every load instruction touches 64 cache lines whatever its width: four times fewer of them
+    // (S = 8, 12, 28, 40 of EfficientNet-B4; 6 and 14 take 8-byte loads)
     for (int c = tid; c < d.C; c += 256) {
         float a = b2[c];
         const float* row = w2 + (size_t)c * d.S;
@@ -93,52 +111,39 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(stp3_se_mlp_dims d, con
 }
 
 // backward, per sample: dz2 = dgate * gate * (1 - gate); dh = dz2 W2; dz1 = dh * swish'(z1); dpooled = dz1 W1 / rows
-// grid = N, LDS = (C + 2 S) floats
+// grid = N
 __global__ __launch_bounds__(256) void se_mlp_bwd_sample_kernel(stp3_se_mlp_dims d, const float* __restrict__ dgate,
                                                                 const float* __restrict__ gate,
                                                                 const float* __restrict__ z1,
                                                                 const float* __restrict__ w1,
                                                                 const float* __restrict__ w2, float* __restrict__ dz2,
                                                                 float* __restrict__ dz1, float* __restrict__ dpooled) {
-    extern __shared__ float smem[];
-    float* g2 = smem;               // [C] dz2 of this sample
-    float* g1 = smem + d.C;         // [S] dz1 of this sample
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int c = tid; c < d.C; c += 256) {
-        const float g = gate[(size_t)n * d.C + c];
-        const float v = dgate[(size_t)n * d.C + c] * g * (1.0f - g);
-        g2[c] = v;
-        dz2[(size_t)n * d.C + c] = v;
+    __shared__ float scratch[4 * kMaxS];
+    extern __shared__ float g1[];   // [S]: dz2 W2, then dz1 of this sample
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int sb = 0; sb < d.S; sb += kMaxS) {
+        const int sn = min(kMaxS, d.S - sb);
+        float acc[kMaxS];
+#pragma unroll
+        for (int s = 0; s < kMaxS; ++s) acc[s] = 0.f;
+        // a thread owns channel c: its dz2 times ITS row of W2 (S contiguous floats) is its part of dh
+        for (int c = tid; c < d.C; c += 256) {
+            const float g = gate[(size_t)n * d.C + c];
+            const float v = dgate[(size_t)n * d.C + c] * g * (1.0f - g);
+            if (sb == 0) dz2[(size_t)n * d.C + c] = v;
+            const float* row = w2 + (size_t)c * d.S + sb;
+#pragma unroll
+            for (int s = 0; s < kMaxS; ++s)
+                if (s < sn) acc[s] = fmaf(v, row[s], acc[s]);
+        }
+        block_sums(acc, sn, scratch, g1 + sb);
     }
-    __syncthreads();
-    for (int s0 = wave; s0 < d.S; s0 += 4 * kRows) {            // kRows columns of W2 at a time (see the forward kernel)
-        float acc[kRows];
-#pragma unroll
-        for (int k = 0; k < kRows; ++k) acc[k] = 0.f;
-#pragma unroll 4
-        for (int c = lane; c < d.C; c += 64) {
-            const float gc = g2[c];
-#pragma unroll
-            for (int k = 0; k < kRows; ++k) {
-                const int s = s0 + 4 * k;
-                if (s < d.S) acc[k] = fmaf(gc, w2[(size_t)c * d.S + s], acc[k]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < kRows; ++k) acc[k] = wave_sum_xor(acc[k]);
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < kRows; ++k) {
-                const int s = s0 + 4 * k;
-                if (s < d.S) {
-                    const float z = z1[(size_t)n * d.S + s];
-                    const float sg = sigmoidf_(z);
-                    const float v = acc[k] * sg * (1.0f + z * (1.0f - sg));
-                    g1[s] = v;
-                    dz1[(size_t)n * d.S + s] = v;
-                }
-            }
-        }
+    for (int s = tid; s < d.S; s += 256) {
+        const float z = z1[(size_t)n * d.S + s];
+        const float sg = sigmoidf_(z);
+        const float v = g1[s] * sg * (1.0f + z * (1.0f - sg));
+        g1[s] = v;
+        dz1[(size_t)n * d.S + s] = v;
     }
     __syncthreads();
     for (int c = tid; c < d.C; c += 256) {
@@ -149,14 +154,16 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_sample_kernel(stp3_se_mlp_dims
     }
 }
 
-// backward, weights: thread = channel c, workgroup = (64 channels, 8 squeezed channels); samples added in ascending
-// order (deterministic)
+// backward, weights: workgroup = (64 channels, 8 squeezed channels) x 4 groups of samples; thread (channel, group) adds
+// its group's samples n = group, group + 4, ... in ascending order, the four groups are added in order: deterministic
 //   dw2[c][s] = sum_n dz2[n][c] swish(z1[n][s]);  db2[c] = sum_n dz2[n][c]
-//   dw1[s][c] = sum_n dz1[n][s] pooled[n][c];      db1[s] = sum_n dz1[n][s]   (workgroup (0, 0))
-// LDS = 2 * N * 8 floats (swish(z1) and dz1 of all samples for the workgroup's 8 squeezed channels).  The grid is
-// C/64 x S/8 workgroups: the first version ran C/256 workgroups (1-4 on the whole chip) for 78 us per call.
+//   dw1[s][c] = sum_n dz1[n][s] pooled[n][c];      db1[s] = sum_n dz1[n][s]   (workgroup (0, *))
+// LDS = 2 * N * 8 floats (swish(z1) and dz1 of all samples for the workgroup's 8 squeezed channels) + the group sums.
+// (Round 3: one thread per channel walked all N samples, two dependent-latency loads per sample: 17 us per call.)
 constexpr int kSChunk = 8;
-constexpr int kWgtThreads = 64;
+constexpr int kWgtChan = 64;
+constexpr int kWgtGroups = 4;
+constexpr int kWgtThreads = kWgtChan * kWgtGroups;
 
 __global__ __launch_bounds__(kWgtThreads) void se_mlp_bwd_weight_kernel(stp3_se_mlp_dims d,
                                                                         const float* __restrict__ pooled_sum,
@@ -166,9 +173,10 @@ __global__ __launch_bounds__(kWgtThreads) void se_mlp_bwd_weight_kernel(stp3_se_
                                                                         float* __restrict__ dw1, float* __restrict__ db1,
                                                                         float* __restrict__ dw2, float* __restrict__ db2) {
     extern __shared__ float smem[];
-    float* hs = smem;                         // [N][8]
-    float* g1 = smem + (size_t)d.N * kSChunk; // [N][8]
-    const int tid = threadIdx.x;
+    float* hs = smem;                                   // [N][8]
+    float* g1 = smem + (size_t)d.N * kSChunk;           // [N][8]
+    float* red = g1 + (size_t)d.N * kSChunk;            // [groups][2 * 8 + 1][64]
+    const int tid = threadIdx.x, cl = tid % kWgtChan, grp = tid / kWgtChan;
     const int s0 = blockIdx.y * kSChunk;
     for (int i = tid; i < d.N * kSChunk; i += kWgtThreads) {
         const int n = i / kSChunk, s = s0 + i % kSChunk;
@@ -182,38 +190,52 @@ __global__ __launch_bounds__(kWgtThreads) void se_mlp_bwd_weight_kernel(stp3_se_
         for (int n = 0; n < d.N; ++n) a += g1[n * kSChunk + tid];
         db1[s0 + tid] = a;
     }
-    const int c = blockIdx.x * kWgtThreads + tid;
-    if (c >= d.C) return;
+    const int c = blockIdx.x * kWgtChan + cl;
     float sb = 0.f;
     float a2[kSChunk], a1[kSChunk];
 #pragma unroll
     for (int k = 0; k < kSChunk; ++k) a2[k] = a1[k] = 0.f;
-#pragma unroll 4
-    for (int n = 0; n < d.N; ++n) {
-        const float x2 = dz2[(size_t)n * d.C + c];
-        const float pc = pooled_sum[(size_t)n * d.C + c] * d.inv_rows;
-        sb += x2;
+    if (c < d.C) {
+#pragma unroll 6
+        for (int n = grp; n < d.N; n += kWgtGroups) {
+            const float x2 = dz2[(size_t)n * d.C + c];
+            const float pc = pooled_sum[(size_t)n * d.C + c] * d.inv_rows;
+            sb += x2;
 #pragma unroll
-        for (int k = 0; k < kSChunk; ++k) {
-            a2[k] = fmaf(x2, hs[n * kSChunk + k], a2[k]);
-            a1[k] = fmaf(g1[n * kSChunk + k], pc, a1[k]);
+            for (int k = 0; k < kSChunk; ++k) {
+                a2[k] = fmaf(x2, hs[n * kSChunk + k], a2[k]);
+                a1[k] = fmaf(g1[n * kSChunk + k], pc, a1[k]);
+            }
         }
     }
+    constexpr int kVals = 2 * kSChunk + 1;
 #pragma unroll
     for (int k = 0; k < kSChunk; ++k) {
-        const int s = s0 + k;
-        if (s < d.S) {
-            dw2[(size_t)c * d.S + s] = a2[k];
-            dw1[(size_t)s * d.C + c] = a1[k];
+        red[(grp * kVals + k) * kWgtChan + cl] = a2[k];
+        red[(grp * kVals + kSChunk + k) * kWgtChan + cl] = a1[k];
+    }
+    red[(grp * kVals + 2 * kSChunk) * kWgtChan + cl] = sb;
+    __syncthreads();
+    if (grp != 0 || c >= d.C) return;
+#pragma unroll
+    for (int k = 0; k < kVals; ++k) {
+        float t = red[k * kWgtChan + cl];
+#pragma unroll
+        for (int g = 1; g < kWgtGroups; ++g) t += red[(g * kVals + k) * kWgtChan + cl];
+        if (k < kSChunk) {
+            if (s0 + k < d.S) dw2[(size_t)c * d.S + s0 + k] = t;
+        } else if (k < 2 * kSChunk) {
+            if (s0 + k - kSChunk < d.S) dw1[(size_t)(s0 + k - kSChunk) * d.C + c] = t;
+        } else if (blockIdx.y == 0) {
+            db2[c] = t;
         }
     }
-    if (blockIdx.y == 0) db2[c] = sb;
 }
 
 inline int check(const stp3_se_mlp_dims* d) {
     if (!d) return STP3_EINVAL;
     if (d->N <= 0 || d->C <= 0 || d->S <= 0) return STP3_EINVAL;
-    if ((size_t)(d->C + 2 * d->S) * 4 > 60 * 1024 || (size_t)2 * d->N * d->S * 4 > 60 * 1024) return STP3_EUNSUP;
+    if ((size_t)d->S * 4 > 32 * 1024 || (size_t)2 * d->N * kSChunk * 4 > 48 * 1024) return STP3_EUNSUP;
     return STP3_OK;
 }
 
@@ -226,8 +248,8 @@ int stp3_se_mlp_fwd(const stp3_se_mlp_dims* dims, const float* pooled_sum, const
     int rc = check(dims);
     if (rc) return rc;
     if (!pooled_sum || !w1 || !b1 || !w2 || !b2 || !z1 || !gate) return STP3_EINVAL;
-    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(dims->N), dim3(256), (size_t)(dims->C + dims->S) * 4, (hipStream_t)stream,
-                       *dims, pooled_sum, w1, b1, w2, b2, z1, gate);
+    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(dims->N), dim3(256), (size_t)dims->S * 4, (hipStream_t)stream, *dims, pooled_sum,
+                       w1, b1, w2, b2, z1, gate);
     return launch_status();
 }
 
@@ -239,11 +261,12 @@ int stp3_se_mlp_bwd(const stp3_se_mlp_dims* dims, const float* dgate, const floa
     if (!dgate || !gate || !pooled_sum || !z1 || !w1 || !w2 || !dz2 || !dz1 || !dpooled || !dw1 || !db1 || !dw2 || !db2)
         return STP3_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(se_mlp_bwd_sample_kernel, dim3(dims->N), dim3(256), (size_t)(dims->C + 2 * dims->S) * 4, s, *dims,
-                       dgate, gate, z1, w1, w2, dz2, dz1, dpooled);
-    hipLaunchKernelGGL(se_mlp_bwd_weight_kernel, dim3((dims->C + kWgtThreads - 1) / kWgtThreads, (dims->S + kSChunk - 1) / kSChunk),
-                       dim3(kWgtThreads), (size_t)2 * dims->N * kSChunk * 4, s, *dims, pooled_sum, z1, dz2, dz1, dw1, db1,
-                       dw2, db2);
+    hipLaunchKernelGGL(se_mlp_bwd_sample_kernel, dim3(dims->N), dim3(256), (size_t)dims->S * 4, s, *dims, dgate, gate, z1, w1,
+                       w2, dz2, dz1, dpooled);
+    hipLaunchKernelGGL(se_mlp_bwd_weight_kernel, dim3((dims->C + kWgtChan - 1) / kWgtChan, (dims->S + kSChunk - 1) / kSChunk),
+                       dim3(kWgtThreads),
+                       ((size_t)2 * dims->N * kSChunk + (size_t)kWgtGroups * (2 * kSChunk + 1) * kWgtChan) * 4, s, *dims,
+                       pooled_sum, z1, dz2, dz1, dw1, db1, dw2, db2);
     return launch_status();
 }
 
