@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "stp3_cdna.h"
 #include "stp3_hip.h"
 
 namespace {
@@ -32,55 +33,63 @@ __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf
 constexpr int kOwn = 4;          // channels per thread and chunk (256 threads: chunks of 1024 channels)
 constexpr int kMaxS = 64;        // squeezed channels the register accumulators cover (EfficientNet-B4: <= 40)
 
-// part[s] (this thread's partial sums, s < S <= kMaxS) -> total[s] in LDS for all s; `scratch` [4][kMaxS] floats
+// part[s] (this thread's partial sums, s < SR <= kMaxS) -> total[s] in LDS for s < S; `scratch` [4][kMaxS] floats.
+// SR (S rounded up to a multiple of 8) is a compile-time bound everywhere: a run-time `s < S` inside the unrolled loops put
+// every row's loads behind their own branch -- 40 dependent round trips, 38 us (profiles/r04i: slower than round 3's 29).
+// The 16-lane row sums are DPP rotations (one VALU instruction per step, stp3_cdna.h); the 16 rows of the workgroup meet
+// in LDS.  (Six __shfl_xor steps per value -- LDS round trips -- made this reduction the longest part of the kernel.)
+template <int SR>
 __device__ __forceinline__ void block_sums(const float* part, int S, float* scratch, float* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = wave * 4 + (lane >> 4);                 // 0 .. 15
 #pragma unroll
-    for (int s = 0; s < kMaxS; ++s) {
-        if (s < S) {
-            const float v = wave_sum_xor(part[s]);
-            if (lane == 0) scratch[wave * kMaxS + s] = v;
-        }
+    for (int s = 0; s < SR; ++s) {
+        const float v = row16_sum(part[s]);
+        if ((lane & 15) == 0) scratch[row * kMaxS + s] = v;
     }
     __syncthreads();
-    if ((int)threadIdx.x < S)
-        total[threadIdx.x] = (scratch[threadIdx.x] + scratch[kMaxS + threadIdx.x]) +
-                             (scratch[2 * kMaxS + threadIdx.x] + scratch[3 * kMaxS + threadIdx.x]);
+    if ((int)threadIdx.x < S) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += scratch[r * kMaxS + threadIdx.x];
+        total[threadIdx.x] = t;
+    }
     __syncthreads();
 }
 
-// forward: grid = N, LDS = (5 kMaxS) floats
+// forward: grid = N, dynamic LDS = S floats
+template <int SR>
 __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(stp3_se_mlp_dims d, const float* __restrict__ pooled_sum,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
                                                          const float* __restrict__ w2, const float* __restrict__ b2,
                                                          float* __restrict__ z1, float* __restrict__ gate) {
-    __shared__ float scratch[4 * kMaxS];
+    __shared__ float scratch[16 * kMaxS];
     extern __shared__ float h[];    // [S]: W1 p, then swish(z1)
     const int n = blockIdx.x, tid = threadIdx.x;
-    for (int sb = 0; sb < d.S; sb += kMaxS) {             // (one round for S <= 64: every EfficientNet-B4 block)
-        const int sn = min(kMaxS, d.S - sb);
-        float acc[kMaxS];
+    for (int sb = 0; sb < d.S; sb += SR) {                // (one round for S <= 64: every EfficientNet-B4 block)
+        const int sn = min(SR, d.S - sb);
+        float acc[SR];
 #pragma unroll
-        for (int s = 0; s < kMaxS; ++s) acc[s] = 0.f;
+        for (int s = 0; s < SR; ++s) acc[s] = 0.f;
         for (int c0 = 0; c0 < d.C; c0 += 256 * kOwn) {
             float pc[kOwn];
+            int cc[kOwn];
 #pragma unroll
             for (int k = 0; k < kOwn; ++k) {
                 const int c = c0 + k * 256 + tid;
+                cc[k] = min(c, d.C - 1);                       // beyond C: a valid address, times zero
                 pc[k] = c < d.C ? pooled_sum[(size_t)n * d.C + c] * d.inv_rows : 0.f;
             }
 #pragma unroll
-            for (int s = 0; s < kMaxS; ++s) {
-                if (s < sn) {
+            for (int s = 0; s < SR; ++s) {
+                // beyond S: a valid row, result unused.  32-bit element offsets (scalar row offset + the lane's channel):
+                // one scalar register per row instead of a 64-bit row pointer (40 of those spilled scalar registers)
+                const unsigned roff = (unsigned)(min(sb + s, d.S - 1) * d.C);
 #pragma unroll
-                    for (int k = 0; k < kOwn; ++k) {
-                        const int c = c0 + k * 256 + tid;
-                        if (c < d.C) acc[s] = fmaf(w1[(size_t)(sb + s) * d.C + c], pc[k], acc[s]);
-                    }
-                }
+                for (int k = 0; k < kOwn; ++k) acc[s] = fmaf(w1[roff + (unsigned)cc[k]], pc[k], acc[s]);
             }
         }
-        block_sums(acc, sn, scratch, h + sb);
+        block_sums<SR>(acc, sn, scratch, h + sb);
     }
     for (int s = tid; s < d.S; s += 256) {
         const float z = h[s] + b1[s];
@@ -111,32 +120,35 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(stp3_se_mlp_dims d, con
 }
 
 // backward, per sample: dz2 = dgate * gate * (1 - gate); dh = dz2 W2; dz1 = dh * swish'(z1); dpooled = dz1 W1 / rows
-// grid = N
+// grid = N, dynamic LDS = S floats
+template <int SR>
 __global__ __launch_bounds__(256) void se_mlp_bwd_sample_kernel(stp3_se_mlp_dims d, const float* __restrict__ dgate,
                                                                 const float* __restrict__ gate,
                                                                 const float* __restrict__ z1,
                                                                 const float* __restrict__ w1,
                                                                 const float* __restrict__ w2, float* __restrict__ dz2,
                                                                 float* __restrict__ dz1, float* __restrict__ dpooled) {
-    __shared__ float scratch[4 * kMaxS];
+    __shared__ float scratch[16 * kMaxS];
     extern __shared__ float g1[];   // [S]: dz2 W2, then dz1 of this sample
     const int n = blockIdx.x, tid = threadIdx.x;
-    for (int sb = 0; sb < d.S; sb += kMaxS) {
-        const int sn = min(kMaxS, d.S - sb);
-        float acc[kMaxS];
+    for (int sb = 0; sb < d.S; sb += SR) {
+        const int sn = min(SR, d.S - sb);
+        float acc[SR];
 #pragma unroll
-        for (int s = 0; s < kMaxS; ++s) acc[s] = 0.f;
+        for (int s = 0; s < SR; ++s) acc[s] = 0.f;
         // a thread owns channel c: its dz2 times ITS row of W2 (S contiguous floats) is its part of dh
         for (int c = tid; c < d.C; c += 256) {
             const float g = gate[(size_t)n * d.C + c];
             const float v = dgate[(size_t)n * d.C + c] * g * (1.0f - g);
             if (sb == 0) dz2[(size_t)n * d.C + c] = v;
-            const float* row = w2 + (size_t)c * d.S + sb;
+            const unsigned coff = (unsigned)(c * d.S);
+            // (c >> 30 is zero; it keeps the clamp a per-lane value: as a uniform one it took a scalar register per row and
+            // the 40-row instantiations spilled scalar registers)
+            const unsigned smax = (unsigned)(d.S - 1) + (unsigned)(c >> 30);
 #pragma unroll
-            for (int s = 0; s < kMaxS; ++s)
-                if (s < sn) acc[s] = fmaf(v, row[s], acc[s]);
+            for (int s = 0; s < SR; ++s) acc[s] = fmaf(v, w2[coff + min((unsigned)(sb + s), smax)], acc[s]);    // beyond S: unused
         }
-        block_sums(acc, sn, scratch, g1 + sb);
+        block_sums<SR>(acc, sn, scratch, g1 + sb);
     }
     for (int s = tid; s < d.S; s += 256) {
         const float z = z1[(size_t)n * d.S + s];
@@ -236,6 +248,7 @@ inline int check(const stp3_se_mlp_dims* d) {
     if (!d) return STP3_EINVAL;
     if (d->N <= 0 || d->C <= 0 || d->S <= 0) return STP3_EINVAL;
     if ((size_t)d->S * 4 > 32 * 1024 || (size_t)2 * d->N * kSChunk * 4 > 48 * 1024) return STP3_EUNSUP;
+    if ((int64_t)d->S * d->C >= (1LL << 31)) return STP3_EUNSUP;       // 32-bit element offsets into the weight matrices
     return STP3_OK;
 }
 
@@ -248,8 +261,19 @@ int stp3_se_mlp_fwd(const stp3_se_mlp_dims* dims, const float* pooled_sum, const
     int rc = check(dims);
     if (rc) return rc;
     if (!pooled_sum || !w1 || !b1 || !w2 || !b2 || !z1 || !gate) return STP3_EINVAL;
-    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(dims->N), dim3(256), (size_t)dims->S * 4, (hipStream_t)stream, *dims, pooled_sum,
-                       w1, b1, w2, b2, z1, gate);
+    const size_t lds = (size_t)dims->S * 4;
+    hipStream_t s = (hipStream_t)stream;
+#define STP3_SE_FWD(SR) hipLaunchKernelGGL(se_mlp_fwd_kernel<SR>, dim3(dims->N), dim3(256), lds, s, *dims, pooled_sum, w1, b1, w2, b2, z1, gate)
+    switch ((dims->S + 7) / 8) {
+        case 1: STP3_SE_FWD(8); break;
+        case 2: STP3_SE_FWD(16); break;
+        case 3: STP3_SE_FWD(24); break;
+        case 4: STP3_SE_FWD(32); break;
+        case 5: STP3_SE_FWD(40); break;
+        case 6: STP3_SE_FWD(48); break;
+        default: STP3_SE_FWD(64); break;
+    }
+#undef STP3_SE_FWD
     return launch_status();
 }
 
@@ -261,8 +285,18 @@ int stp3_se_mlp_bwd(const stp3_se_mlp_dims* dims, const float* dgate, const floa
     if (!dgate || !gate || !pooled_sum || !z1 || !w1 || !w2 || !dz2 || !dz1 || !dpooled || !dw1 || !db1 || !dw2 || !db2)
         return STP3_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(se_mlp_bwd_sample_kernel, dim3(dims->N), dim3(256), (size_t)dims->S * 4, s, *dims, dgate, gate, z1, w1,
-                       w2, dz2, dz1, dpooled);
+    const size_t lds = (size_t)dims->S * 4;
+#define STP3_SE_BWD(SR) hipLaunchKernelGGL(se_mlp_bwd_sample_kernel<SR>, dim3(dims->N), dim3(256), lds, s, *dims, dgate, gate, z1, w1, w2, dz2, dz1, dpooled)
+    switch ((dims->S + 7) / 8) {
+        case 1: STP3_SE_BWD(8); break;
+        case 2: STP3_SE_BWD(16); break;
+        case 3: STP3_SE_BWD(24); break;
+        case 4: STP3_SE_BWD(32); break;
+        case 5: STP3_SE_BWD(40); break;
+        case 6: STP3_SE_BWD(48); break;
+        default: STP3_SE_BWD(64); break;
+    }
+#undef STP3_SE_BWD
     hipLaunchKernelGGL(se_mlp_bwd_weight_kernel, dim3((dims->C + kWgtChan - 1) / kWgtChan, (dims->S + kSChunk - 1) / kSChunk),
                        dim3(kWgtThreads),
                        ((size_t)2 * dims->N * kSChunk + (size_t)kWgtGroups * (2 * kSChunk + 1) * kWgtChan) * 4, s, *dims,

@@ -31,7 +31,8 @@ def test_kernel_register_lds_and_scratch_budgets():
     for name, budget in (('lift_column_mma_kernel', 128), ('void lift_column_kernel<12>', 96), ('void lift_gather_kernel<float>', 64), ('void lift_gather_kernel<unsigned short>', 64),
                          ('lift_bwd_kernel', 168), ('plan_columns_kernel', 64), ('plan_fill_kernel', 64),
                          ('prep_weights_kernel', 128), ('optim_sumsq_kernel', 128), ('optim_prepare_kernel', 128),
-                         ('optim_adam_kernel', 128), ('se_mlp_fwd_kernel', 128), ('se_mlp_bwd_sample_kernel', 128),
+                         ('optim_adam_kernel', 128), ('void se_mlp_fwd_kernel<40>', 128), ('void se_mlp_bwd_sample_kernel<40>', 128),
+                         ('void se_mlp_fwd_kernel<8>', 128), ('void se_mlp_bwd_sample_kernel<16>', 128),
                          ('se_mlp_bwd_weight_kernel', 128), ('voxels_sum_fwd_kernel', 128),
                          ('voxels_sum_bwd_kernel', 128), ('void dwconv_fwd_stats_kernel<unsigned short, 3, 1>', 168),
                          ('void dwconv_fwd_stats_kernel<unsigned short, 5, 1>', 256),
