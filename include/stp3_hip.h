@@ -357,6 +357,30 @@ int stp3_conv2d_fwd_workspace(const stp3_conv_dims* dims, size_t* bytes);
 int stp3_conv2d_fwd(const stp3_conv_dims* dims, const void* x, const void* w, const float* bias, void* y,
                     float* sums, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Convolution -> BatchNorm -> activation with the convolution output NEVER in memory (csrc/stp3_conv.hip, epilogue
+ * modes): for layers whose convolution is cheap next to the tensor it produces -- the 1x1 expand convolutions of the
+ * EfficientNet MBConv blocks driven by stp3/models/encoder.py:57-97 (24..160 -> 144..960 channels: the expanded tensor is
+ * 6x the block input) -- the forward runs the convolution twice and the BatchNorm backward recomputes the output tiles
+ * from the input instead of reading a stored copy:
+ *   stp3_conv2d_fwd_stats     sums [2][Cout] = per-channel sum / sum of squares of the bf16-ROUNDED outputs; nothing stored
+ *   stp3_conv2d_fwd_bnact     y = act(scale * e0 + shift), e0 = the rounded convolution output, coef = [scale | shift |
+ *                             mean | invstd][Cout] as stp3_bn_finalize writes them
+ *   stp3_conv2d_bn_bwd_reduce sums [2][Cout] = sum g, sum g * xhat with g = dz * act'(scale * e0 + shift),
+ *                             xhat = (e0 - mean) * invstd; dz [M][ldz] bf16 = the gradient at the activation output
+ *   stp3_conv2d_bn_bwd_apply  dy = scale * (g - gsums[0] / count - xhat * gsums[1] / count): the gradient at the convolution
+ *                             output (what stp3_bn_apply_bwd writes), gsums possibly summed over ranks
+ * dims / x / w as stp3_conv2d_fwd (bf16, no bias, out_dtype bf16; Cout, ldy, ldz multiples of 8); workspace:
+ * stp3_conv2d_fwd_workspace.  Same values as the stored route: every mode rounds the accumulators to bf16 first. */
+int stp3_conv2d_fwd_stats(const stp3_conv_dims* dims, const void* x, const void* w, float* sums, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int stp3_conv2d_fwd_bnact(const stp3_conv_dims* dims, const void* x, const void* w, const float* coef, int32_t act, void* y,
+                          void* stream);
+int stp3_conv2d_bn_bwd_reduce(const stp3_conv_dims* dims, const void* x, const void* w, const void* dz, int32_t ldz,
+                              const float* coef, int32_t act, float* sums, void* workspace, size_t workspace_bytes,
+                              void* stream);
+int stp3_conv2d_bn_bwd_apply(const stp3_conv_dims* dims, const void* x, const void* w, const void* dz, int32_t ldz,
+                             const float* coef, int32_t act, const float* gsums, double count, void* dy, void* stream);
+
 /* stp3_conv2d_wgrad -- dw[co][kh][kw][ci] = sum_{n,ho,wo} dy[n][ho][wo][co] * x[n][ho*stride-pad_h+kh*dil_h][..][ci]
  * (the weight gradient autograd derives for the convolutions above), float32 output in the weight's own
  * [Cout][KH][KW][Cin] layout.  dy [N][Ho][Wo][ldy >= Cout] and x [N][H][W][ldx >= Cin] are bf16; the pixel

@@ -84,11 +84,43 @@ __device__ __forceinline__ int xcd_order(int bid, int nwg) {
 // byte offset of piece j of row r in a [rows][8 x 16 B] LDS image
 __device__ __forceinline__ int lds_piece(int r, int j) { return (r * 8 + (j ^ ((r >> 1) & 7))) * 16; }
 
-template <int BN>
+// Epilogue modes.  The expand convolution of an MBConv block (1x1, 24..160 -> 144..960 channels) is so cheap next to the
+// expanded tensor E0 it produces that E0 is never stored: the forward runs the convolution twice (STATS: the BatchNorm
+// statistics of the rounded outputs, nothing written; BNACT: the same tiles again, act(scale * e0 + shift) written), and
+// the BatchNorm backward recomputes the tiles it needs from the 6x smaller block input (BWD_REDUCE: the two sums of the
+// BatchNorm backward against the incoming gradient dz; BWD_APPLY: the gradient at the convolution output).  Every mode
+// rounds the accumulators to bf16 first: the values are those the stored tensor held.
+enum { kModePlain = 0, kModeStats = 1, kModeBnAct = 2, kModeBwdReduce = 3, kModeBwdApply = 4 };
+
+struct EpiArgs {
+    const float* coef;          // [scale | shift | mean | invstd][Cout] (stp3_bn_finalize)
+    const uint16_t* dz;         // gradient at the activation output, [M][ldz] bf16 (BWD_*)
+    const float* gsums;         // [2][Cout]: sum g, sum g * xhat over all replicas (BWD_APPLY)
+    float inv_count;
+    int ldz, act;
+};
+
+template <int ACT>
+__device__ __forceinline__ float epi_act(float v) {
+    if (ACT == STP3_ACT_RELU) return fmaxf(v, 0.f);
+    if (ACT == STP3_ACT_SWISH) return v * fast_sigmoid(v);
+    return v;
+}
+template <int ACT>
+__device__ __forceinline__ float epi_act_grad(float pre) {
+    if (ACT == STP3_ACT_RELU) return pre > 0.f ? 1.f : 0.f;
+    if (ACT == STP3_ACT_SWISH) {
+        const float sg = fast_sigmoid(pre);
+        return sg * (1.f + pre * (1.f - sg));
+    }
+    return 1.f;
+}
+
+template <int BN, int MODE = kModePlain, int ACT = STP3_ACT_NONE>
 __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles_co, const uint16_t* __restrict__ x,
                                                            const uint16_t* __restrict__ w,
                                                            const float* __restrict__ bias, void* __restrict__ y,
-                                                           float* __restrict__ stat_partial) {
+                                                           float* __restrict__ stat_partial, EpiArgs ep = EpiArgs()) {
     constexpr int TP = BN == 128 ? 2 : 1;                 // 32-pixel MFMA tiles per wave
     constexpr int TC = 2;                                 // 32-channel MFMA tiles per wave
     constexpr int kStage = (kBM + BN) * kBK * 2;          // bytes of one staging buffer (pixel image + weight image)
@@ -271,22 +303,110 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
             }
     __syncthreads();
     uint16_t* yo = reinterpret_cast<uint16_t*>(y);
-    for (int e = tid; e < kBM * (BN / 8); e += 256) {       // 16-byte pieces: 8 channels
-        const int p = e / (BN / 8), c = (e - p * (BN / 8)) * 8;
-        const int m = m0 + p, co = co0 + c;
-        if (m >= d.M || co >= d.Cout) continue;
-        const uint4 v = *reinterpret_cast<const uint4*>(tile + p * ldt + c);
-        uint16_t* dst = yo + (size_t)m * d.ldy + co;
-        if (co + 7 < d.Cout && (d.ldy & 7) == 0) {
-            *reinterpret_cast<uint4*>(dst) = v;
-        } else {
-            const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+    if (MODE == kModePlain) {
+        for (int e = tid; e < kBM * (BN / 8); e += 256) {       // 16-byte pieces: 8 channels
+            const int p = e / (BN / 8), c = (e - p * (BN / 8)) * 8;
+            const int m = m0 + p, co = co0 + c;
+            if (m >= d.M || co >= d.Cout) continue;
+            const uint4 v = *reinterpret_cast<const uint4*>(tile + p * ldt + c);
+            uint16_t* dst = yo + (size_t)m * d.ldy + co;
+            if (co + 7 < d.Cout && (d.ldy & 7) == 0) {
+                *reinterpret_cast<uint4*>(dst) = v;
+            } else {
+                const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-                if (co + r < d.Cout) dst[r] = (uint16_t)(wds[r >> 1] >> (16 * (r & 1)));
+                for (int r = 0; r < 8; ++r)
+                    if (co + r < d.Cout) dst[r] = (uint16_t)(wds[r >> 1] >> (16 * (r & 1)));
+            }
         }
     }
-    if (stat_partial) {
+    if (MODE == kModeBnAct || MODE == kModeBwdApply) {
+        // a thread's pieces all hold the same 8 channels (256 threads are a multiple of the BN / 8 pieces of a pixel):
+        // the per-channel constants live in registers.  Cout, ldy (and ldz) are multiples of 8 here (checked by the host).
+        const int c = (tid % (BN / 8)) * 8, co = co0 + c;
+        if (co < d.Cout) {
+            float cs[8], ct[8], a2[8], a3[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                cs[r] = ep.coef[co + r];
+                ct[r] = ep.coef[d.Cout + co + r];
+                if (MODE == kModeBwdApply) {
+                    const float mu = ep.coef[2 * d.Cout + co + r], is = ep.coef[3 * d.Cout + co + r];
+                    const float k0 = ep.gsums[co + r] * ep.inv_count, k1 = ep.gsums[d.Cout + co + r] * ep.inv_count;
+                    a2[r] = -(cs[r] * is) * k1;                      // the constants of bn_apply_bwd_kernel (stp3_bnact.hip)
+                    a3[r] = -cs[r] * k0 - a2[r] * mu;
+                }
+            }
+            for (int p = tid / (BN / 8); p < kBM; p += 256 / (BN / 8)) {
+                const int m = m0 + p;
+                if (m >= d.M) break;
+                const uint4 v = *reinterpret_cast<const uint4*>(tile + p * ldt + c);
+                const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+                float e0[8], out[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e0[2 * r] = __uint_as_float(wds[r] << 16);
+                    e0[2 * r + 1] = __uint_as_float(wds[r] & 0xffff0000u);
+                }
+                if (MODE == kModeBnAct) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) out[r] = epi_act<ACT>(fmaf(e0[r], cs[r], ct[r]));
+                } else {
+                    const uint4 g = *reinterpret_cast<const uint4*>(ep.dz + (size_t)m * ep.ldz + co);
+                    const uint32_t gds[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const float dzv = __uint_as_float((r & 1) ? (gds[r >> 1] & 0xffff0000u) : (gds[r >> 1] << 16));
+                        const float gg = dzv * epi_act_grad<ACT>(fmaf(e0[r], cs[r], ct[r]));
+                        out[r] = fmaf(cs[r], gg, fmaf(a2[r], e0[r], a3[r]));
+                    }
+                }
+                *reinterpret_cast<uint4*>(yo + (size_t)m * d.ldy + co) =
+                    make_uint4(pack_bf16(out[0], out[1]), pack_bf16(out[2], out[3]), pack_bf16(out[4], out[5]),
+                               pack_bf16(out[6], out[7]));
+            }
+        }
+    }
+    if (MODE == kModeBwdReduce) {
+        // the gradient tile dz[128][BN] goes through LDS too (16-byte loads), behind the output tile; then thread
+        // (channel, pixel part) adds its pixels: sum g and sum g * xhat, one partial row per workgroup
+        uint16_t* gt = tile + kBM * ldt;
+        for (int e = tid; e < kBM * (BN / 8); e += 256) {
+            const int p = e / (BN / 8), c = (e - p * (BN / 8)) * 8;
+            const int m = m0 + p, co = co0 + c;
+            uint4 g = make_uint4(0u, 0u, 0u, 0u);
+            if (m < d.M && co < d.Cout) g = *reinterpret_cast<const uint4*>(ep.dz + (size_t)m * ep.ldz + co);
+            *reinterpret_cast<uint4*>(gt + p * ldt + c) = g;
+        }
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem + 2 * kBM * ldt * 2);
+        const int c = tid % BN, part = tid / BN;
+        constexpr int kParts = 256 / BN, kRows = kBM / kParts;
+        float s1 = 0.f, s2 = 0.f;
+        if (co0 + c < d.Cout) {
+            const float cs = ep.coef[co0 + c], ct = ep.coef[d.Cout + co0 + c];
+            const float mu = ep.coef[2 * d.Cout + co0 + c], is = ep.coef[3 * d.Cout + co0 + c];
+            for (int p = part * kRows; p < (part + 1) * kRows; ++p) {
+                if (m0 + p < d.M) {
+                    const float e0 = bf2f(tile[p * ldt + c]);
+                    const float gg = bf2f(gt[p * ldt + c]) * epi_act_grad<ACT>(fmaf(e0, cs, ct));
+                    s1 += gg;
+                    s2 = fmaf(gg, (e0 - mu) * is, s2);
+                }
+            }
+        }
+        red[(part * 2) * BN + c] = s1;
+        red[(part * 2 + 1) * BN + c] = s2;
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int k = tid / BN, cc = tid - k * BN;
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < kParts; ++q) t += red[(q * 2 + k) * BN + cc];
+            if (co0 + cc < d.Cout) stat_partial[((size_t)tile_m * 2 + k) * d.Cout + co0 + cc] = t;
+        }
+    }
+    if ((MODE == kModePlain || MODE == kModeStats) && stat_partial) {
         // BatchNorm statistics of the rounded outputs: thread (channel c, pixel half) adds 64 pixels; rows beyond M
         // hold the bias only and are skipped
         float* red = reinterpret_cast<float*>(smem + kBM * ldt * 2);        // behind the tile: 2 * 2 * BN floats
@@ -639,9 +759,34 @@ int stp3_conv2d_fwd_workspace(const stp3_conv_dims* p, size_t* bytes) {
     return STP3_OK;
 }
 
-int stp3_conv2d_fwd(const stp3_conv_dims* p, const void* x, const void* w, const float* bias, void* y, float* sums,
-                    void* workspace, size_t workspace_bytes, void* stream) {
-    if (!p || !x || !w || !y) return STP3_EINVAL;
+}  // extern "C"
+
+namespace {
+
+template <int BN, int MODE, int ACT>
+int igemm_launch_one(const ConvDims& d, dim3 grid, size_t lds, int tiles_co, const void* x, const void* w, const float* bias,
+                     void* y, float* partial, const EpiArgs& ep, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_igemm_kernel<BN, MODE, ACT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return -(int)e;
+    hipLaunchKernelGGL((conv2d_igemm_kernel<BN, MODE, ACT>), grid, dim3(256), lds, s, d, tiles_co, (const uint16_t*)x,
+                       (const uint16_t*)w, bias, y, partial, ep);
+    return STP3_OK;
+}
+
+template <int BN, int MODE>
+int igemm_launch_act(int act, const ConvDims& d, dim3 grid, size_t lds, int tiles_co, const void* x, const void* w,
+                     const float* bias, void* y, float* partial, const EpiArgs& ep, hipStream_t s) {
+    if (MODE == kModePlain || MODE == kModeStats || act == STP3_ACT_NONE)
+        return igemm_launch_one<BN, MODE, STP3_ACT_NONE>(d, grid, lds, tiles_co, x, w, bias, y, partial, ep, s);
+    if (act == STP3_ACT_RELU) return igemm_launch_one<BN, MODE, STP3_ACT_RELU>(d, grid, lds, tiles_co, x, w, bias, y, partial, ep, s);
+    return igemm_launch_one<BN, MODE, STP3_ACT_SWISH>(d, grid, lds, tiles_co, x, w, bias, y, partial, ep, s);
+}
+
+// the forward kernel in one of its epilogue modes (see kMode*): shared argument checks, tile choice and launch
+int igemm_run(const stp3_conv_dims* p, const void* x, const void* w, const float* bias, void* y, float* sums, void* workspace,
+              size_t workspace_bytes, void* stream, int mode, int act, EpiArgs ep) {
+    if (!p || !x || !w || (mode != kModeStats && mode != kModeBwdReduce && !y)) return STP3_EINVAL;
     if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->Cin <= 0 || p->Cout <= 0 || p->Ho <= 0 || p->Wo <= 0 || p->KH <= 0 ||
         p->KW <= 0 || p->stride <= 0 || p->dil_h <= 0 || p->dil_w <= 0 || p->pad_h < 0 || p->pad_w < 0)
         return STP3_EINVAL;
@@ -649,8 +794,16 @@ int stp3_conv2d_fwd(const stp3_conv_dims* p, const void* x, const void* w, const
     if (p->Cin % 8 || p->ldx % 8 || p->ldx < p->Cin || p->ldy < p->Cout) return STP3_EUNSUP;   // 16-byte k pieces
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return STP3_EUNSUP;
     if (p->out_dtype != STP3_DTYPE_BF16 && p->out_dtype != STP3_DTYPE_F32) return STP3_EUNSUP;
-    if (((uintptr_t)y & (p->out_dtype == STP3_DTYPE_F32 ? 3 : 1))) return STP3_EUNSUP;
-    if (sums && p->out_dtype != STP3_DTYPE_BF16) return STP3_EUNSUP;
+    if (y && ((uintptr_t)y & (p->out_dtype == STP3_DTYPE_F32 ? 3 : 1))) return STP3_EUNSUP;
+    if ((sums || mode != kModePlain) && p->out_dtype != STP3_DTYPE_BF16) return STP3_EUNSUP;
+    if (mode != kModePlain) {
+        // the fused-BatchNorm modes: whole 16-byte channel pieces on every side, no convolution bias
+        if (p->has_bias || p->Cout % 8 || p->ldy % 8 || (y && ((uintptr_t)y & 15))) return STP3_EUNSUP;
+        if (mode >= kModeBnAct && !ep.coef) return STP3_EINVAL;
+        if (mode >= kModeBwdReduce && (!ep.dz || ep.ldz % 8 || ep.ldz < p->Cout || ((uintptr_t)ep.dz & 15))) return STP3_EUNSUP;
+        if (mode == kModeBwdApply && !ep.gsums) return STP3_EINVAL;
+        if ((mode == kModeStats || mode == kModeBwdReduce) && !sums) return STP3_EINVAL;
+    }
     const int64_t M = (int64_t)p->N * p->Ho * p->Wo;
     // 32-bit PIXEL indices (input and output); element offsets are 64-bit pointer arithmetic since the round-3 staging
     if (M >= (1LL << 31) || (int64_t)p->N * p->H * p->W >= (1LL << 31)) return STP3_EUNSUP;
@@ -660,8 +813,6 @@ int stp3_conv2d_fwd(const stp3_conv_dims* p, const void* x, const void* w, const
     d.dil_h = p->dil_h; d.dil_w = p->dil_w; d.ldx = p->ldx; d.ldy = p->ldy;
     d.out_f32 = p->out_dtype == STP3_DTYPE_F32; d.has_bias = p->has_bias;
     d.M = (int)M; d.kchunks = (p->Cin + 31) / 32; d.Ktot = p->KH * p->KW * p->Cin;
-    // vector stores need 16-byte aligned rows; otherwise the scalar tail path of the epilogue is taken per piece
-    if (((uintptr_t)y & 15)) d.ldy |= 0;                     // (alignment is re-checked per piece through ldy below)
     const unsigned gx = (unsigned)((M + kBM - 1) / kBM);
     hipStream_t s = (hipStream_t)stream;
     float* partial = nullptr;
@@ -670,32 +821,74 @@ int stp3_conv2d_fwd(const stp3_conv_dims* p, const void* x, const void* w, const
         if (!workspace || workspace_bytes < ((size_t)gx + (gx + 255) / 256) * 2 * p->Cout * sizeof(float)) return STP3_ENOSPACE;
         partial = (float*)workspace;
     }
-    if (((uintptr_t)y & 15)) return STP3_EUNSUP;
+    if (y && ((uintptr_t)y & 15)) return STP3_EUNSUP;
     // 128 x 128 tiles for the contraction-heavy layers; 128 x 64 tiles when there are few output channels or so little K
     // (<= 2 steps: the pointwise layers of the trunk, bound by activation traffic) that what counts is many light
     // workgroups per CU; one staging buffer suffices for a single K step
     const int steps = (d.Ktot + kBK - 1) / kBK;
     const bool wide = p->Cout > 64 && steps > 2;
     const int bn = wide ? 128 : 64;
-    const size_t lds = igemm_lds(bn, steps, d.out_f32 != 0);
+    size_t lds = igemm_lds(bn, steps, d.out_f32 != 0);
+    if (mode == kModeBwdReduce) {                             // output tile + gradient tile + the reduction scratch
+        const size_t need = (size_t)2 * kBM * (bn + 8) * 2 + 512 * sizeof(float);
+        if (need > lds) lds = need;
+    }
     const int tiles_co = (p->Cout + bn - 1) / bn;
     if ((int64_t)gx * tiles_co >= (1LL << 31)) return STP3_EUNSUP;
     const dim3 grid(gx * (unsigned)tiles_co);                // 1-D: the kernel derives (pixel tile, channel tile) itself
-    if (wide) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_igemm_kernel<128>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -(int)e;
-        hipLaunchKernelGGL(conv2d_igemm_kernel<128>, grid, dim3(256), lds, s, d, tiles_co, (const uint16_t*)x, (const uint16_t*)w,
-                           bias, y, partial);
-    } else {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_igemm_kernel<64>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -(int)e;
-        hipLaunchKernelGGL(conv2d_igemm_kernel<64>, grid, dim3(256), lds, s, d, tiles_co, (const uint16_t*)x, (const uint16_t*)w,
-                           bias, y, partial);
+    int rc;
+#define STP3_IGEMM_MODE(MODE)                                                                                                \
+    rc = wide ? igemm_launch_act<128, MODE>(act, d, grid, lds, tiles_co, x, w, bias, y, partial, ep, s)                       \
+              : igemm_launch_act<64, MODE>(act, d, grid, lds, tiles_co, x, w, bias, y, partial, ep, s)
+    switch (mode) {
+        case kModePlain: STP3_IGEMM_MODE(kModePlain); break;
+        case kModeStats: STP3_IGEMM_MODE(kModeStats); break;
+        case kModeBnAct: STP3_IGEMM_MODE(kModeBnAct); break;
+        case kModeBwdReduce: STP3_IGEMM_MODE(kModeBwdReduce); break;
+        default: STP3_IGEMM_MODE(kModeBwdApply); break;
     }
+#undef STP3_IGEMM_MODE
+    if (rc) return rc;
     if (sums) launch_colsum(s, (int)gx, 2 * p->Cout, partial, sums);
     return status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int stp3_conv2d_fwd(const stp3_conv_dims* p, const void* x, const void* w, const float* bias, void* y, float* sums,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    return igemm_run(p, x, w, bias, y, sums, workspace, workspace_bytes, stream, kModePlain, STP3_ACT_NONE, EpiArgs());
+}
+
+// ---- convolution -> BatchNorm -> activation WITHOUT the convolution output in memory (see kMode*) -------------------
+int stp3_conv2d_fwd_stats(const stp3_conv_dims* p, const void* x, const void* w, float* sums, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    return igemm_run(p, x, w, nullptr, nullptr, sums, workspace, workspace_bytes, stream, kModeStats, STP3_ACT_NONE, EpiArgs());
+}
+
+int stp3_conv2d_fwd_bnact(const stp3_conv_dims* p, const void* x, const void* w, const float* coef, int32_t act, void* y,
+                          void* stream) {
+    EpiArgs ep = EpiArgs();
+    ep.coef = coef;
+    return igemm_run(p, x, w, nullptr, y, nullptr, nullptr, 0, stream, kModeBnAct, act, ep);
+}
+
+int stp3_conv2d_bn_bwd_reduce(const stp3_conv_dims* p, const void* x, const void* w, const void* dz, int32_t ldz,
+                              const float* coef, int32_t act, float* sums, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+    EpiArgs ep = EpiArgs();
+    ep.coef = coef; ep.dz = (const uint16_t*)dz; ep.ldz = ldz;
+    return igemm_run(p, x, w, nullptr, nullptr, sums, workspace, workspace_bytes, stream, kModeBwdReduce, act, ep);
+}
+
+int stp3_conv2d_bn_bwd_apply(const stp3_conv_dims* p, const void* x, const void* w, const void* dz, int32_t ldz,
+                             const float* coef, int32_t act, const float* gsums, double count, void* dy, void* stream) {
+    if (!(count >= 1.0)) return STP3_EINVAL;
+    EpiArgs ep = EpiArgs();
+    ep.coef = coef; ep.dz = (const uint16_t*)dz; ep.ldz = ldz; ep.gsums = gsums; ep.inv_count = (float)(1.0 / count);
+    return igemm_run(p, x, w, nullptr, dy, nullptr, nullptr, 0, stream, kModeBwdApply, act, ep);
 }
 
 

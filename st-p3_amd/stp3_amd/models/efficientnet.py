@@ -87,6 +87,10 @@ class StaticSamePadConv2d(nn.Conv2d):
         return F.conv2d(x, self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
 
 
+# expand convolution -> BN0 -> swish through ops_fused._PointwiseBnAct (the convolution output is recomputed, never stored)
+EXPAND_WITHOUT_E0 = True
+
+
 class Swish(nn.Module):
     def forward(self, x):
         return F.silu(x)
@@ -124,7 +128,10 @@ class MBConvBlock(nn.Module):
             from .. import ops_fused
             group = None if _fused._sync_world(self._bn1) > 1 else False
         if self.expand != 1:
-            if fuse:
+            if fuse and EXPAND_WITHOUT_E0 and ops_fused.pointwise_bn_act_supported(x, self._expand_conv, self._bn0):
+                # the expanded pre-activation tensor (6x the block input) is never stored: statistics pass + recomputation
+                x = ops_fused.pointwise_bn_act(x, self._expand_conv, self._bn0, ACT_SWISH, group=group)
+            elif fuse:
                 x = ops_fused.conv_bn_act(x, self._expand_conv.weight, None, self._bn0, ACT_SWISH, group=group)
             else:
                 x = bn_act(self._bn0, self._expand_conv(x), ACT_SWISH)

@@ -183,6 +183,123 @@ class _ConvBnAct(torch.autograd.Function):
         return (dx, dw, dcb, dgamma, dbeta, dres) + (None,) * 12
 
 
+class _PointwiseBnAct(torch.autograd.Function):
+    """1x1 convolution -> BatchNorm -> activation WITHOUT the convolution output in memory: for the expand convolutions
+    of the MBConv blocks (24..160 -> 144..960 channels), whose output is 6x their input.  Forward: the convolution runs
+    twice (stp3_conv2d_fwd_stats: BatchNorm statistics only; stp3_conv2d_fwd_bnact: the same tiles again, act(BN(.))
+    written) -- the expanded pre-activation tensor E0 is neither written nor read back.  Backward: the two passes of the
+    BatchNorm backward recompute the E0 tiles they need from the block input (stp3_conv2d_bn_bwd_reduce / _bwd_apply) and
+    read only the incoming gradient.  Passes over an expanded tensor: 1 forward and 3 backward where ``_ConvBnAct`` makes 3
+    and 5 (the data and weight gradient of the convolution follow unchanged); E0 is not kept for the backward pass at all.
+    Same values: every kernel rounds the accumulators to bf16 before it uses them, as the stored tensor was."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, momentum, eps, act, group):
+        return ops.drive_exchange(_PointwiseBnAct.forward_steps(ctx, x, weight, gamma, beta, running_mean, running_var,
+                                                                momentum, eps, act, group), group)
+
+    @staticmethod
+    def backward(ctx, dz):
+        return ops.drive_exchange(_PointwiseBnAct.backward_steps(ctx, dz), ctx.cfg[3])
+
+    @staticmethod
+    def forward_steps(ctx, x, weight, gamma, beta, running_mean, running_var, momentum, eps, act, group):
+        ops._need_gpu(x, weight)
+        if x.dtype != torch.bfloat16:
+            x = x.to(torch.bfloat16)
+        wb, _ = ops._bf16_weights(weight)
+        cout, cin = wb.shape[:2]
+        n, _, h, w = x.shape
+        x, ldx = ops._rows_view(x)
+        dev = x.device
+        lib = _lib.lib()
+        dims = _lib.ConvDims(n, h, w, cin, h, w, cout, 1, 1, 1, 0, 0, 1, 1, ldx, cout, _lib.DTYPE_BF16, 0)
+        need = ctypes.c_size_t()
+        check(lib.stp3_conv2d_fwd_workspace(ctypes.byref(dims), ctypes.byref(need)), 'stp3_conv2d_fwd_workspace')
+        ws = _workspace(need.value, dev)
+        stat = torch.empty(6 * cout, dtype=torch.float32, device=dev)       # sum | sum of squares | scale | shift | mean | invstd
+        stream = ops._stream_handle()
+        check(lib.stp3_conv2d_fwd_stats(ctypes.byref(dims), x.data_ptr(), wb.data_ptr(), stat.data_ptr(), ws.data_ptr(),
+                                        need.value, stream), 'stp3_conv2d_fwd_stats')
+        count = float(n * h * w)
+        world = 1
+        if group is not False and torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size(group)
+        if world > 1:
+            yield stat[:2 * cout]
+            count *= world
+        g32, b32 = ops._f32(gamma), ops._f32(beta)
+        coef = stat[2 * cout:]
+        check(lib.stp3_bn_finalize(stat.data_ptr(), cout, count, ops._opt_ptr(g32), ops._opt_ptr(b32), eps, momentum,
+                                   ops._opt_ptr(running_mean), ops._opt_ptr(running_var), coef.data_ptr(), stream),
+              'stp3_bn_finalize')
+        y = torch.empty((n, cout, h, w), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+        check(lib.stp3_conv2d_fwd_bnact(ctypes.byref(dims), x.data_ptr(), wb.data_ptr(), coef.data_ptr(), int(act), y.data_ptr(),
+                                        stream), 'stp3_conv2d_fwd_bnact')
+        ctx.save_for_backward(x, wb, coef)
+        ctx.cfg = (dims, count, world, group, int(act), need.value)
+        ctx.weight_ref = weight
+        ctx.weight_stamp = ops.weight_stamp(weight)
+        ctx.dtypes = (weight.dtype, None if gamma is None else gamma.dtype, None if beta is None else beta.dtype)
+        return y
+
+    @staticmethod
+    def backward_steps(ctx, dz):
+        x, wb, coef = ctx.saved_tensors
+        ops.check_weight_stamp(ctx.weight_ref, ctx.weight_stamp, 'pointwise_bn_act backward')
+        dims, count, world, group, act, ws_bytes = ctx.cfg
+        wdt, gdt, bdt = ctx.dtypes
+        cout, cin = wb.shape[:2]
+        dev = x.device
+        lib = _lib.lib()
+        if dz.dtype != torch.bfloat16:
+            dz = dz.to(torch.bfloat16)
+        dz, ldz = ops._rows_view(dz)
+        if ldz % 8 or dz.data_ptr() % 16:
+            dz, ldz = dz.contiguous(memory_format=torch.channels_last), cout
+        ws = _workspace(ws_bytes, dev)
+        stream = ops._stream_handle()
+        lsums = torch.empty(2, cout, dtype=torch.float32, device=dev)        # sum g (dbeta) | sum g * xhat (dgamma)
+        check(lib.stp3_conv2d_bn_bwd_reduce(ctypes.byref(dims), x.data_ptr(), wb.data_ptr(), dz.data_ptr(), ldz, coef.data_ptr(),
+                                            act, lsums.data_ptr(), ws.data_ptr(), ws_bytes, stream), 'stp3_conv2d_bn_bwd_reduce')
+        gsums = lsums
+        if world > 1:
+            gsums = lsums.clone()
+            yield gsums
+        dconv = torch.empty((dims.N, cout, dims.H, dims.W), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+        check(lib.stp3_conv2d_bn_bwd_apply(ctypes.byref(dims), x.data_ptr(), wb.data_ptr(), dz.data_ptr(), ldz, coef.data_ptr(),
+                                           act, gsums.data_ptr(), count, dconv.data_ptr(), stream), 'stp3_conv2d_bn_bwd_apply')
+        dgamma = lsums[1].to(gdt) if gdt is not None and ctx.needs_input_grad[2] else None
+        dbeta = lsums[0].to(bdt) if bdt is not None and ctx.needs_input_grad[3] else None
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_data_grad(dconv, wb, ctx.weight_ref, x.shape, 1, (0, 0), (1, 1))
+        if ctx.needs_input_grad[1]:
+            dw = ops._conv2d_wgrad(dconv, x, (cout, cin, 1, 1), 1, (0, 0), (1, 1)).to(wdt)
+        return (dx, dw, dgamma, dbeta) + (None,) * 6
+
+
+def pointwise_bn_act_supported(x, conv, bn):
+    """``_PointwiseBnAct``: training-mode BatchNorm with running statistics behind a bias-free 1x1 / stride-1 convolution
+    of bf16 GPU activations, channel counts in whole 16-byte pieces, within the statistics epilogue's tile bound."""
+    if not (x.is_cuda and x.dim() == 4 and bn.training and bn.track_running_stats and conv.bias is None):
+        return False
+    if tuple(conv.kernel_size) != (1, 1) or tuple(conv.stride) != (1, 1) or conv.groups != 1:
+        return False
+    cout, cin = conv.weight.shape[:2]
+    n, _, h, w = x.shape
+    return cin % 8 == 0 and cout % 8 == 0 and (n * h * w + 127) // 128 <= ops._CONV_MAX_STAT_TILES and \
+        ops.conv2d_supported(x, conv.weight, 1)
+
+
+def pointwise_bn_act(x, conv, bn, act, group=None):
+    """act(bn(conv(x))) for a 1x1 convolution through ``_PointwiseBnAct`` (see there)."""
+    if bn.num_batches_tracked is not None:
+        ops.bump_batch_counter(bn)
+    return _PointwiseBnAct.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, ops.bn_momentum(bn),
+                                 float(bn.eps), int(act), group)
+
+
 def slot_view(out_slot, like):
     """(channel-slice view of the slot's buffer for a result shaped like ``like``, row stride of the buffer)."""
     buf, c0 = out_slot

@@ -798,6 +798,43 @@ def aspp_join(ops):
     return out
 
 
+def pointwise_bn(ops):
+    """ops_fused._PointwiseBnAct (1x1 convolution -> BatchNorm -> activation, the convolution output recomputed instead of
+    stored: stp3_conv2d_fwd_stats / _fwd_bnact / _bn_bwd_reduce / _bn_bwd_apply) against ops_fused._ConvBnAct (the stored
+    route, same kernels otherwise): outputs, all gradients and the running statistics -- the two routes round at the same
+    places, so they agree to float32 summation order."""
+    import torch.nn as nn
+    from stp3_amd import ops_fused
+    out = {}
+    torch.manual_seed(51)
+    for name, (n, cin, cout, h, w, act) in {'swish_24_144': (3, 24, 144, 9, 11, ops.ACT_SWISH), 'relu_160_960': (2, 160, 136, 5, 7, ops.ACT_RELU),
+                                            'none_8_48': (2, 8, 48, 13, 10, ops.ACT_NONE), 'swish_ragged': (1, 32, 192, 11, 13, ops.ACT_SWISH)}.items():
+        conv = nn.Conv2d(cin, cout, 1, bias=False)
+        res = []
+        x0 = torch.randn(n, cin, h, w).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        gy = torch.randn(n, cout, h, w).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        state = None
+        for recompute in (True, False):
+            bn = nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01).train()
+            if state is None:
+                with torch.no_grad():
+                    bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+                state = {k: v.clone() for k, v in bn.state_dict().items()}
+            bn.load_state_dict(state)
+            conv.zero_grad()
+            x = x0.clone().requires_grad_()
+            assert ops_fused.pointwise_bn_act_supported(x, conv, bn)
+            if recompute:
+                y = ops_fused.pointwise_bn_act(x, conv, bn, act, group=False)
+            else:
+                y = ops_fused.conv_bn_act(x, conv.weight, None, bn, act, group=False)
+            y.backward(gy)
+            res.append([y.detach().float(), x.grad.float(), conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                        bn.running_mean.clone(), bn.running_var.clone()])
+        out[name] = {k: rel(a, b) for k, a, b in zip(('y', 'dx', 'dw', 'dgamma', 'dbeta', 'rmean', 'rvar'), res[0], res[1])}
+    return out
+
+
 def decoder_heads(ops):
     """Decoder (stp3/models/decoder.py:8-140) in training mode on bf16 activations with the heads that read the same
     tensor MERGED (one 3x3 convolution + one BatchNorm over all heads' channels, one block-diagonal 1x1 convolution)
@@ -1249,7 +1286,7 @@ def fuzz(ops, seed=1):
 
 
 CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_frames, lift_coarse_grid, lift_tall, lift_c64_rows56, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
-                                 conv, conv_f32, fan_out, aspp_join, decoder_heads, dwconv, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
+                                 conv, conv_f32, fan_out, aspp_join, pointwise_bn, decoder_heads, dwconv, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
 
 if __name__ == '__main__':
     ops_mod = setup(sys.argv[1])

@@ -345,3 +345,47 @@ def test_mbconv_middle_operator_matches_torch_float32(case, dtype):
         err = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
         tol = 1e-4 if dtype == torch.float32 else (2e-2 if name in stored else 2e-3)
         assert err <= tol, (name, err)
+
+
+@pytest.mark.parametrize('shape', [(72, 24, 144, 112, 240), (72, 160, 960, 14, 30), (8, 32, 192, 56, 120), (3, 56, 336, 27, 61)])
+def test_pointwise_conv_bn_act_without_the_convolution_output(shape):
+    """ops_fused._PointwiseBnAct (the MBConv expand convolution -> BN0 -> swish with the expanded pre-activation tensor
+    recomputed instead of stored) at the trunk's real shapes against the stored route ops_fused._ConvBnAct: same kernels,
+    same rounding places -- outputs, input gradients and running statistics bit-equal, parameter gradients to float32
+    summation order; and both within bf16 accuracy of float32 torch on the same operands."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from stp3_amd import ops, ops_fused
+    n, cin, cout, h, w = shape
+    g = torch.Generator().manual_seed(cin + cout)
+    conv = nn.Conv2d(cin, cout, 1, bias=False).cuda()
+    x0 = torch.randn(n, cin, h, w, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, cout, h, w, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = []
+    for recompute in (True, False):
+        bn = nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01).cuda().train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, cout))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, cout))
+        conv.zero_grad()
+        x = x0.clone().requires_grad_()
+        assert ops_fused.pointwise_bn_act_supported(x, conv, bn)
+        y = (ops_fused.pointwise_bn_act(x, conv, bn, ops.ACT_SWISH, group=False) if recompute
+             else ops_fused.conv_bn_act(x, conv.weight, None, bn, ops.ACT_SWISH, group=False))
+        y.backward(gy)
+        ops.flush_batch_counters()
+        res.append((y.detach(), x.grad.clone(), conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                    bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[5], b[5]) and torch.equal(a[6], b[6])
+    assert int(a[7]) == 1
+    for i in (2, 3, 4):
+        assert (a[i] - b[i]).abs().max() <= 2e-5 * b[i].abs().max() + 1e-7, i
+    if n * h * w <= 200000:                                        # float32 torch on the same operands (the small shapes)
+        xr = x0.float().requires_grad_()
+        wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_()
+        e0 = F.conv2d(xr, wr).to(torch.bfloat16).float()
+        mean, var = e0.mean((0, 2, 3)), e0.var((0, 2, 3), unbiased=False)
+        ref = F.silu((e0 - mean[None, :, None, None]) * torch.rsqrt(var + 1e-3)[None, :, None, None]
+                     * torch.linspace(0.5, 1.5, cout).cuda()[None, :, None, None] + torch.linspace(-0.3, 0.3, cout).cuda()[None, :, None, None])
+        torch.testing.assert_close(a[0].float(), ref, rtol=2e-2, atol=2e-2)

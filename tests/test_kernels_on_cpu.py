@@ -28,9 +28,9 @@ import build as hipcpu_build  # noqa: E402
 
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
 ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
-           ('conv', {}), ('conv_f32', {}), ('fan_out', {}), ('aspp_join', {}), ('decoder_heads', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('labels', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
+           ('conv', {}), ('conv_f32', {}), ('fan_out', {}), ('aspp_join', {}), ('pointwise_bn', {}), ('decoder_heads', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('labels', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
            ('lift_c64_frames', {}), ('lift_c64_rows56', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
-ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'labels', 'lift_c16']
+ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'pointwise_bn', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'labels', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)]
 MODEL = [('lift_full', {}), ('model_step_two_ranks', {}), ('model_step_f32_full_losses', {}), ('model_step_f32', {}),
          ('model_step_bf16_bn_eval', {})]        # whole training steps: minutes, STP3_SLOW_TESTS=1
@@ -234,6 +234,16 @@ def test_aspp_branches_write_into_one_buffer(results):
     for name in ('all_fused', 'one_sliced'):
         assert r[name]['y'] <= 2e-2 and r[name]['dx'] <= 0.3 and r[name]['dparam'] <= 0.15, (name, r[name])
     assert r['all_fused']['dx'] <= 0.1 and r['all_fused']['dparam'] <= 0.06, r['all_fused']
+
+
+def test_pointwise_conv_batchnorm_without_the_convolution_output(results):
+    """ops_fused._PointwiseBnAct against the stored route (ops_fused._ConvBnAct): outputs, input gradients and running
+    statistics bit-equal (both round the accumulators to bf16 at the same place), parameter gradients to summation order."""
+    for name, r in _get(results, 'pointwise_bn').items():
+        if name == 'seconds':
+            continue
+        assert r['y'] == 0.0 and r['dx'] == 0.0 and r['rmean'] == 0.0 and r['rvar'] == 0.0, (name, r)
+        assert r['dw'] <= 5e-6 and r['dgamma'] <= 5e-6 and r['dbeta'] <= 5e-6, (name, r)
 
 
 def test_merged_decoder_heads_equal_the_heads_one_by_one(results):
