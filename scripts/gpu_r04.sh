@@ -3,7 +3,7 @@
 #   what: parity  the new / changed parity tests first (fail fast), the noise probe of the whole step
 #         suite   the whole GPU suite
 #         bench   bench line (default flags) + kernel-trace profile with the per-dispatch listing of the last step
-#         conv | lift | plan   micro-benchmarks
+#         conv | pointwise | lift | plan   micro-benchmarks
 out=gpurun_out/${1:-r04}; mkdir -p $out; shift
 export STP3_PARITY_REPORT=$out/parity.json STP3_PARITY_REPORT_STEP=$out/parity_step.json STP3_IOU_REPORT=$out/iou.json TMPDIR=/tmp
 has() { for w in "$@"; do for a in "${WHAT[@]}"; do [ "$a" == "$w" ] && return 0; done; done; return 1; }
@@ -21,6 +21,7 @@ if has suite; then
   tail -8 $out/pytest.log
 fi
 if has conv; then timeout 300 python scripts/time_conv.py > $out/time_conv.log 2>&1; cut -c1-175 $out/time_conv.log; fi
+if has pointwise; then timeout 300 python scripts/time_pointwise.py > $out/time_pointwise.log 2>&1; cut -c1-260 $out/time_pointwise.log; fi
 if has plan; then timeout 300 python scripts/time_plan.py 4 > $out/time_plan.log 2>&1; tail -4 $out/time_plan.log; fi
 if has lift; then timeout 300 python scripts/time_lift.py 4 > $out/time_lift_c3.log 2>&1; tail -8 $out/time_lift_c3.log; fi
 if has perftests; then

@@ -433,6 +433,198 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pointwise (1x1, stride 1) convolutions with a SHORT contraction (Cin <= 160): the expand convolutions of the MBConv blocks
+// and the data gradients of their project convolutions -- 24..160 channels in, 6x as many out, activations of 40..560 MB.
+// The tiled kernel above spends its time per WORKGROUP on them (one K-step of matrix work between an address prologue, two
+// LDS round trips and three barriers: 24 -> 144 @112x240x72 ran at 2.8 TB/s of its own traffic, profiles/r04l_*): these
+// layers are streaming kernels with a small matrix product inside, and are written as one:
+//   * persistent workgroups; the weight tile (<= 128 x 160 bf16) is put into LDS ONCE per workgroup;
+//   * a WAVE owns 32 pixels at a time: its operand fragments (16 bytes of a pixel row per lane and 16-k step) come straight
+//     from global memory into registers -- no staging, no workgroup barrier in the loop -- with the next tile's in flight;
+//   * the 32 x NT*32 result goes through a wave-private LDS tile (transposition to 16-byte channel pieces) and leaves in the
+//     epilogue MODE of the tiled kernel (plain + statistics, statistics only, BatchNorm + activation, the two BatchNorm
+//     backward passes); a lane keeps the same 8 channels in every tile, so their constants and partial sums live in
+//     registers; ONE partial row per workgroup (not per pixel tile) reaches the column sums.
+template <int NT, int KMAX, int MODE>
+__global__ __launch_bounds__(256) void pointwise_kernel(ConvDims d, int ksteps, int tiles_co, const uint16_t* __restrict__ x,
+                                                        const uint16_t* __restrict__ w, uint16_t* __restrict__ y,
+                                                        float* __restrict__ stat_partial, EpiArgs ep) {
+    constexpr int CT = NT * 32;                            // channels per workgroup
+    constexpr int PP = CT / 8;                             // 16-byte pieces per pixel row of the tile
+    constexpr int RPI = 64 / PP;                           // pixel rows a wave's piece pass covers per iteration
+    constexpr int LDT = CT + 8;                            // row stride of the transposition tile (elements)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // channel tile fastest in an XCD's contiguous chunk: the workgroups that read the same pixels share an L2
+    const int v_order = xcd_order(blockIdx.x, gridDim.x);
+    const int group = v_order / tiles_co, ngroups = gridDim.x / tiles_co;
+    const int co0 = (v_order - group * tiles_co) * CT;
+    const int K16 = ksteps * 16;
+    const int ldw = K16 + 8;                               // row stride of the weight image (elements)
+    uint16_t* wimg = reinterpret_cast<uint16_t*>(smem);    // [CT][ldw]
+    uint16_t* tile = wimg + CT * ldw + wave * (32 * LDT);  // this wave's [32][LDT]
+    float* red = reinterpret_cast<float*>(wimg + CT * ldw);                    // [4 waves][64 lanes][16], over the tiles
+    // ---- weight image: rows = output channels, zero beyond Cout / Cin
+    for (int e = tid; e < CT * (K16 / 8); e += 256) {
+        const int r = e / (K16 / 8), k0 = (e - r * (K16 / 8)) * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (co0 + r < d.Cout && k0 < d.Cin) v = *reinterpret_cast<const u32x4*>(w + (size_t)(co0 + r) * d.Cin + k0);
+        *reinterpret_cast<u32x4*>(wimg + r * ldw + k0) = v;
+    }
+    __syncthreads();
+    const int px = lane & 31, half = lane >> 5;
+    const int cp = lane % PP, prow = lane / PP;
+    const int cch = co0 + cp * 8;                          // this lane's 8 channels in the piece passes
+    const bool ch_ok = cch < d.Cout;                       // (Cout % 8 == 0: all eight or none)
+    float cs[8], ct[8], a2[8], a3[8], mu[8], is[8], s1[8], s2[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        cs[r] = ct[r] = a2[r] = a3[r] = mu[r] = is[r] = 0.f;
+        s1[r] = s2[r] = 0.f;
+        if (MODE >= kModeBnAct && ch_ok) {
+            cs[r] = ep.coef[cch + r];
+            ct[r] = ep.coef[d.Cout + cch + r];
+            mu[r] = ep.coef[2 * d.Cout + cch + r];
+            is[r] = ep.coef[3 * d.Cout + cch + r];
+            if (MODE == kModeBwdApply) {
+                const float k0 = ep.gsums[cch + r] * ep.inv_count, k1 = ep.gsums[d.Cout + cch + r] * ep.inv_count;
+                a2[r] = -(cs[r] * is[r]) * k1;
+                a3[r] = -cs[r] * k0 - a2[r] * mu[r];
+            }
+        }
+    }
+    const uint16_t* const zero = reinterpret_cast<const uint16_t*>(&g_zero16);
+    constexpr int kMaxSteps = KMAX;
+    u32x4 cur[kMaxSteps], nxt[kMaxSteps];
+    const int ntiles = (d.M + 31) / 32;
+    const int stride_t = ngroups * 4;
+    auto load_tile = [&](int t, u32x4 (&f)[kMaxSteps]) {
+        const int m = t * 32 + px;
+        const uint16_t* row = (t < ntiles && m < d.M) ? x + (size_t)m * d.ldx : nullptr;
+#pragma unroll
+        for (int ks = 0; ks < kMaxSteps; ++ks) {
+            if (ks < ksteps) {
+                const int k0 = ks * 16 + half * 8;
+                f[ks] = *reinterpret_cast<const u32x4*>((row && k0 < d.Cin) ? row + k0 : zero);
+            }
+        }
+    };
+    int t = group * 4 + wave;
+    load_tile(t, cur);
+    for (; t < ntiles; t += stride_t) {
+        load_tile(t + stride_t, nxt);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < kMaxSteps; ++ks) {
+            if (ks < ksteps) {
+                Frag fb;
+                fb.u = make_uint4(cur[ks][0], cur[ks][1], cur[ks][2], cur[ks][3]);
+#pragma unroll
+                for (int a = 0; a < NT; ++a) {
+                    Frag fa;
+                    fa.u = *reinterpret_cast<const uint4*>(wimg + (a * 32 + px) * ldw + ks * 16 + half * 8);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[a], 0, 0, 0);
+                }
+            }
+        }
+        // D[row = channel 8*(r>>2) + 4*half + (r&3)][col = pixel px] -> the wave's tile [pixel][channel], rounded to bf16
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint2*>(tile + px * LDT + a * 32 + 8 * q + 4 * half) =
+                    make_uint2(pack_bf16(acc[a][4 * q], acc[a][4 * q + 1]), pack_bf16(acc[a][4 * q + 2], acc[a][4 * q + 3]));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- piece passes: this lane's 8 channels of pixel rows prow, prow + RPI, ...
+        const int mbase = t * 32;
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) {
+            const int p = prow + i * RPI;
+            const int m = mbase + p;
+            if (m < d.M && ch_ok) {
+                const uint4 v = *reinterpret_cast<const uint4*>(tile + p * LDT + cp * 8);
+                if (MODE == kModePlain) *reinterpret_cast<uint4*>(y + (size_t)m * d.ldy + cch) = v;
+                if (MODE != kModePlain || stat_partial) {
+                    const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+                    float e0[8], out[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        e0[2 * r] = __uint_as_float(wds[r] << 16);
+                        e0[2 * r + 1] = __uint_as_float(wds[r] & 0xffff0000u);
+                    }
+                    if (MODE == kModePlain || MODE == kModeStats) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            s1[r] += e0[r];
+                            s2[r] = fmaf(e0[r], e0[r], s2[r]);
+                        }
+                    } else if (MODE == kModeBnAct) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const float pre = fmaf(e0[r], cs[r], ct[r]);
+                            out[r] = ep.act == STP3_ACT_SWISH ? pre * fast_sigmoid(pre) : (ep.act == STP3_ACT_RELU ? fmaxf(pre, 0.f) : pre);
+                        }
+                    } else {
+                        const uint4 g = *reinterpret_cast<const uint4*>(ep.dz + (size_t)m * ep.ldz + cch);
+                        const uint32_t gds[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const float dzv = __uint_as_float((r & 1) ? (gds[r >> 1] & 0xffff0000u) : (gds[r >> 1] << 16));
+                            const float pre = fmaf(e0[r], cs[r], ct[r]);
+                            float der = 1.f;
+                            if (ep.act == STP3_ACT_SWISH) {
+                                const float sg = fast_sigmoid(pre);
+                                der = sg * (1.f + pre * (1.f - sg));
+                            } else if (ep.act == STP3_ACT_RELU) {
+                                der = pre > 0.f ? 1.f : 0.f;
+                            }
+                            const float gg = dzv * der;
+                            if (MODE == kModeBwdReduce) {
+                                s1[r] += gg;
+                                s2[r] = fmaf(gg, (e0[r] - mu[r]) * is[r], s2[r]);
+                            } else {
+                                out[r] = fmaf(cs[r], gg, fmaf(a2[r], e0[r], a3[r]));
+                            }
+                        }
+                    }
+                    if (MODE == kModeBnAct || MODE == kModeBwdApply)
+                        *reinterpret_cast<uint4*>(y + (size_t)m * d.ldy + cch) =
+                            make_uint4(pack_bf16(out[0], out[1]), pack_bf16(out[2], out[3]), pack_bf16(out[4], out[5]),
+                                       pack_bf16(out[6], out[7]));
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                   // the tile is rewritten by the next iteration
+#pragma unroll
+        for (int ks = 0; ks < kMaxSteps; ++ks) cur[ks] = nxt[ks];
+    }
+    // ---- one partial row per workgroup: the lanes' sums meet in LDS, added in a fixed order (wave, pixel-row group)
+    if (stat_partial && (MODE == kModePlain || MODE == kModeStats || MODE == kModeBwdReduce)) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            red[(wave * 64 + lane) * 16 + r] = s1[r];
+            red[(wave * 64 + lane) * 16 + 8 + r] = s2[r];
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * CT; e += 256) {
+            const int k = e / CT, c = e - k * CT;          // which sum, which channel of the tile
+            const int pc = c >> 3, r = c & 7;
+            float tot = 0.f;
+            for (int wv = 0; wv < 4; ++wv)
+                for (int g = 0; g < RPI; ++g) tot += red[(wv * 64 + g * PP + pc) * 16 + k * 8 + r];
+            if (co0 + c < d.Cout) stat_partial[((size_t)group * 2 + k) * d.Cout + co0 + c] = tot;
+        }
+    }
+}
+
 // Column sums of a [parts][width] float32 matrix, deterministic, in two coalesced levels: workgroup (x, y) adds rows
 // [256 y, 256 y + 256) of columns [64 x, 64 x + 64) (4 row lanes x 64 columns, double accumulation) into
 // out[y][...]; a second launch with the level-1 result as input finishes (parts <= 256: one level).
@@ -783,6 +975,78 @@ int igemm_launch_act(int act, const ConvDims& d, dim3 grid, size_t lds, int tile
     return igemm_launch_one<BN, MODE, STP3_ACT_SWISH>(d, grid, lds, tiles_co, x, w, bias, y, partial, ep, s);
 }
 
+template <int NT, int KMAX, int MODE>
+int pointwise_launch_one(const ConvDims& d, int ksteps, int tiles_co, unsigned nwg, size_t lds, const void* x, const void* w,
+                         void* y, float* partial, const EpiArgs& ep, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pointwise_kernel<NT, KMAX, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return -(int)e;
+    hipLaunchKernelGGL((pointwise_kernel<NT, KMAX, MODE>), dim3(nwg), dim3(256), lds, s, d, ksteps, tiles_co,
+                       (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, partial, ep);
+    return STP3_OK;
+}
+
+template <int NT, int KMAX>
+int pointwise_launch_mode(int mode, const ConvDims& d, int ksteps, int tiles_co, unsigned nwg, size_t lds, const void* x,
+                          const void* w, void* y, float* partial, const EpiArgs& ep, hipStream_t s) {
+    switch (mode) {
+        case kModePlain: return pointwise_launch_one<NT, KMAX, kModePlain>(d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
+        case kModeStats: return pointwise_launch_one<NT, KMAX, kModeStats>(d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
+        case kModeBnAct: return pointwise_launch_one<NT, KMAX, kModeBnAct>(d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
+        case kModeBwdReduce:
+            return pointwise_launch_one<NT, KMAX, kModeBwdReduce>(d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
+        default: return pointwise_launch_one<NT, KMAX, kModeBwdApply>(d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
+    }
+}
+
+// the streaming kernel for short-contraction pointwise layers (see pointwise_kernel).  STP3_POINTWISE in the environment:
+// 0 keeps every layer on the tiled kernel (A/B measurements), 2 sends every qualifying layer here whatever its pixel count
+// (the small cases of the tests)
+int pointwise_setting() {
+    static const int v = [] {
+        const char* e = getenv("STP3_POINTWISE");
+        return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
+    }();
+    return v;
+}
+
+constexpr int kPointwiseMaxCin = 128;
+constexpr int kPointwiseMinPixels = 16384;
+
+bool pointwise_applies(const stp3_conv_dims* p, const void* y, int64_t M) {
+    return pointwise_setting() != 0 && p->KH == 1 && p->KW == 1 && p->stride == 1 && p->pad_h == 0 && p->pad_w == 0 &&
+           p->H == p->Ho && p->W == p->Wo && p->Cin <= kPointwiseMaxCin && p->Cout >= 64 && !p->has_bias &&
+           p->out_dtype == STP3_DTYPE_BF16 && p->Cout % 8 == 0 && p->ldy % 8 == 0 && !((uintptr_t)y & 15) &&
+           (M >= kPointwiseMinPixels || pointwise_setting() == 2);
+}
+
+int pointwise_run(const ConvDims& d, const void* x, const void* w, void* y, float* sums, float* partial, unsigned gx,
+                  hipStream_t s, int mode, const EpiArgs& ep) {
+    const int ksteps = (d.Cin + 15) / 16;
+    // 64 or 128 channels per workgroup: whichever pads Cout less (the wider tile on a tie: fewer passes over x)
+    const int pad64 = (d.Cout + 63) / 64 * 64, pad128 = (d.Cout + 127) / 128 * 128;
+    const int nt = pad128 <= pad64 ? 4 : 2, ct = nt * 32;
+    const int tiles_co = (d.Cout + ct - 1) / ct;
+    // weight image + four wave tiles (the reduction scratch lies over the tiles)
+    const size_t lds = (size_t)ct * (ksteps * 16 + 8) * 2 + (size_t)4 * 32 * (ct + 8) * 2;
+    // persistent: about two workgroups per CU, never more pixel groups than 128-pixel blocks (the partial-sum rows)
+    unsigned groups = (512 + tiles_co - 1) / tiles_co;
+    if (groups > gx) groups = gx;
+    if (groups < 1) groups = 1;
+    const unsigned nwg = groups * (unsigned)tiles_co;
+    int rc;
+#define STP3_PW(NT, KMAX) rc = pointwise_launch_mode<NT, KMAX>(mode, d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s)
+    if (nt == 4) {
+        if (ksteps <= 2) STP3_PW(4, 2); else if (ksteps <= 4) STP3_PW(4, 4); else STP3_PW(4, 8);
+    } else {
+        if (ksteps <= 2) STP3_PW(2, 2); else if (ksteps <= 4) STP3_PW(2, 4); else STP3_PW(2, 8);
+    }
+#undef STP3_PW
+    if (rc) return rc;
+    if (sums) launch_colsum(s, (int)groups, 2 * d.Cout, partial, sums);
+    return status();
+}
+
 // the forward kernel in one of its epilogue modes (see kMode*): shared argument checks, tile choice and launch
 int igemm_run(const stp3_conv_dims* p, const void* x, const void* w, const float* bias, void* y, float* sums, void* workspace,
               size_t workspace_bytes, void* stream, int mode, int act, EpiArgs ep) {
@@ -822,6 +1086,10 @@ int igemm_run(const stp3_conv_dims* p, const void* x, const void* w, const float
         partial = (float*)workspace;
     }
     if (y && ((uintptr_t)y & 15)) return STP3_EUNSUP;
+    if (pointwise_applies(p, y, M)) {
+        ep.act = act;
+        return pointwise_run(d, x, w, y, sums, partial, gx, s, mode, ep);
+    }
     // 128 x 128 tiles for the contraction-heavy layers; 128 x 64 tiles when there are few output channels or so little K
     // (<= 2 steps: the pointwise layers of the trunk, bound by activation traffic) that what counts is many light
     // workgroups per CU; one staging buffer suffices for a single K step

