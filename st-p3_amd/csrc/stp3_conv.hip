@@ -434,56 +434,55 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pointwise (1x1, stride 1) convolutions with a SHORT contraction (Cin <= 160): the expand convolutions of the MBConv blocks
-// and the data gradients of their project convolutions -- 24..160 channels in, 6x as many out, activations of 40..560 MB.
+// Pointwise (1x1, stride 1) convolutions with a SHORT contraction (Cin <= 128): the expand convolutions of the MBConv blocks
+// and the data gradients of their project convolutions -- 24..112 channels in, 6x as many out, activations of 40..560 MB.
 // The tiled kernel above spends its time per WORKGROUP on them (one K-step of matrix work between an address prologue, two
-// LDS round trips and three barriers: 24 -> 144 @112x240x72 ran at 2.8 TB/s of its own traffic, profiles/r04l_*): these
-// layers are streaming kernels with a small matrix product inside, and are written as one:
-//   * persistent workgroups; the weight tile (<= 128 x 160 bf16) is put into LDS ONCE per workgroup;
-//   * a WAVE owns 32 pixels at a time: its operand fragments (16 bytes of a pixel row per lane and 16-k step) come straight
-//     from global memory into registers -- no staging, no workgroup barrier in the loop -- with the next tile's in flight;
-//   * the 32 x NT*32 result goes through a wave-private LDS tile (transposition to 16-byte channel pieces) and leaves in the
-//     epilogue MODE of the tiled kernel (plain + statistics, statistics only, BatchNorm + activation, the two BatchNorm
-//     backward passes); a lane keeps the same 8 channels in every tile, so their constants and partial sums live in
-//     registers; ONE partial row per workgroup (not per pixel tile) reaches the column sums.
-template <int NT, int KMAX, int MODE>
-__global__ __launch_bounds__(256) void pointwise_kernel(ConvDims d, int ksteps, int tiles_co, const uint16_t* __restrict__ x,
-                                                        const uint16_t* __restrict__ w, uint16_t* __restrict__ y,
-                                                        float* __restrict__ stat_partial, EpiArgs ep) {
-    constexpr int CT = NT * 32;                            // channels per workgroup
-    constexpr int PP = CT / 8;                             // 16-byte pieces per pixel row of the tile
-    constexpr int RPI = 64 / PP;                           // pixel rows a wave's piece pass covers per iteration
-    constexpr int LDT = CT + 8;                            // row stride of the transposition tile (elements)
+// LDS round trips and three barriers: 24 -> 144 @112x240x72 ran at 2.5 TB/s of its own traffic): these layers are
+// streaming kernels with a small matrix product inside, and are written as such -- persistent waves, operand fragments
+// straight from global memory into registers (the next tile's in flight), no workgroup barrier in the loop, ONE partial row
+// of statistics per workgroup / pixel group -- in two forms, chosen by what the STORES need:
+//
+// pointwise_rows_kernel (Cout = 144 / 192, Cin <= 32: the two layers whose outputs -- 532 and 177 MiB at B = 4 -- do not fit
+// the 256 MB infinity cache).  scripts/probe_stores.hip: a 532-MiB tensor of 288-byte pixel rows is written at 5.6 TB/s when
+// every wave writes WHOLE pixel rows, at 3.1 TB/s when it writes the 128 bytes of a 64-channel block (what a channel-tiled
+// kernel does: the rest of each 128-byte line arrives from another wave, later) and at 2.1 TB/s in 32-byte pieces.  So a
+// wave computes ALL output channels of its 32 pixels (5 / 6 MFMA tiles, the weight image in LDS once per workgroup), turns
+// the accumulators into pixel rows through a wave-private LDS tile and stores them as one contiguous 9 / 12 KB run; a lane
+// keeps the same 8 channels in every pass (64 / PP whole rows per store instruction), so their BatchNorm constants and
+// partial sums live in registers.
+template <int PP, int MODE>
+__global__ __launch_bounds__(256, 2) void pointwise_rows_kernel(ConvDims d, int ksteps, const uint16_t* __restrict__ x,
+                                                             const uint16_t* __restrict__ w, uint16_t* __restrict__ y,
+                                                             float* __restrict__ stat_partial, EpiArgs ep) {
+    constexpr int NT = (PP + 3) / 4;                       // 32-channel MFMA tiles
+    constexpr int RPI = 64 / PP;                           // whole pixel rows per store instruction
+    constexpr int NIT = (32 + RPI - 1) / RPI;              // store instructions per 32-pixel tile
+    constexpr int LDT = NT * 32 + 8;                       // row stride of the transposition tile (elements)
+    constexpr int LDW = 40;                                // row stride of the weight image: 2 k-steps + 8
+    constexpr int KMAX = 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // channel tile fastest in an XCD's contiguous chunk: the workgroups that read the same pixels share an L2
-    const int v_order = xcd_order(blockIdx.x, gridDim.x);
-    const int group = v_order / tiles_co, ngroups = gridDim.x / tiles_co;
-    const int co0 = (v_order - group * tiles_co) * CT;
-    const int K16 = ksteps * 16;
-    const int ldw = K16 + 8;                               // row stride of the weight image (elements)
-    uint16_t* wimg = reinterpret_cast<uint16_t*>(smem);    // [CT][ldw]
-    uint16_t* tile = wimg + CT * ldw + wave * (32 * LDT);  // this wave's [32][LDT]
-    float* red = reinterpret_cast<float*>(wimg + CT * ldw);                    // [4 waves][64 lanes][16], over the tiles
-    // ---- weight image: rows = output channels, zero beyond Cout / Cin
-    for (int e = tid; e < CT * (K16 / 8); e += 256) {
-        const int r = e / (K16 / 8), k0 = (e - r * (K16 / 8)) * 8;
+    uint16_t* wimg = reinterpret_cast<uint16_t*>(smem);    // [NT * 32][LDW]
+    uint16_t* tile = wimg + NT * 32 * LDW + wave * (32 * LDT);
+    float* red = reinterpret_cast<float*>(wimg + NT * 32 * LDW);   // [4 waves][64 lanes][16], over the tiles at the end
+    for (int e = tid; e < NT * 32 * 4; e += 256) {
+        const int r = e >> 2, k0 = (e & 3) * 8;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (co0 + r < d.Cout && k0 < d.Cin) v = *reinterpret_cast<const u32x4*>(w + (size_t)(co0 + r) * d.Cin + k0);
-        *reinterpret_cast<u32x4*>(wimg + r * ldw + k0) = v;
+        if (r < d.Cout && k0 < d.Cin) v = *reinterpret_cast<const u32x4*>(w + (size_t)r * d.Cin + k0);
+        *reinterpret_cast<u32x4*>(wimg + r * LDW + k0) = v;
     }
     __syncthreads();
     const int px = lane & 31, half = lane >> 5;
     const int cp = lane % PP, prow = lane / PP;
-    const int cch = co0 + cp * 8;                          // this lane's 8 channels in the piece passes
-    const bool ch_ok = cch < d.Cout;                       // (Cout % 8 == 0: all eight or none)
+    const bool lane_ok = prow < RPI;
+    const int cch = cp * 8;                                // this lane's 8 channels in the store passes
     float cs[8], ct[8], a2[8], a3[8], mu[8], is[8], s1[8], s2[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         cs[r] = ct[r] = a2[r] = a3[r] = mu[r] = is[r] = 0.f;
         s1[r] = s2[r] = 0.f;
-        if (MODE >= kModeBnAct && ch_ok) {
+        if (MODE >= kModeBnAct) {
             cs[r] = ep.coef[cch + r];
             ct[r] = ep.coef[d.Cout + cch + r];
             mu[r] = ep.coef[2 * d.Cout + cch + r];
@@ -496,39 +495,37 @@ __global__ __launch_bounds__(256) void pointwise_kernel(ConvDims d, int ksteps, 
         }
     }
     const uint16_t* const zero = reinterpret_cast<const uint16_t*>(&g_zero16);
-    constexpr int kMaxSteps = KMAX;
-    u32x4 cur[kMaxSteps], nxt[kMaxSteps];
+    u32x4 cur[KMAX], nxt[KMAX];
     const int ntiles = (d.M + 31) / 32;
-    const int stride_t = ngroups * 4;
-    auto load_tile = [&](int t, u32x4 (&f)[kMaxSteps]) {
+    const int stride_t = gridDim.x * 4;
+    auto load_tile = [&](int t, u32x4 (&f)[KMAX]) {
         const int m = t * 32 + px;
         const uint16_t* row = (t < ntiles && m < d.M) ? x + (size_t)m * d.ldx : nullptr;
 #pragma unroll
-        for (int ks = 0; ks < kMaxSteps; ++ks) {
-            if (ks < ksteps) {
-                const int k0 = ks * 16 + half * 8;
-                f[ks] = *reinterpret_cast<const u32x4*>((row && k0 < d.Cin) ? row + k0 : zero);
-            }
+        for (int ks = 0; ks < KMAX; ++ks) {
+            const int k0 = ks * 16 + half * 8;
+            f[ks] = *reinterpret_cast<const u32x4*>((row && ks < ksteps && k0 < d.Cin) ? row + k0 : zero);
         }
     };
-    int t = group * 4 + wave;
+    int t = blockIdx.x * 4 + wave;
     load_tile(t, cur);
     for (; t < ntiles; t += stride_t) {
         load_tile(t + stride_t, nxt);
+        const int mbase = t * 32;
         f32x16 acc[NT];
 #pragma unroll
         for (int a = 0; a < NT; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < kMaxSteps; ++ks) {
+        for (int ks = 0; ks < KMAX; ++ks) {
             if (ks < ksteps) {
                 Frag fb;
                 fb.u = make_uint4(cur[ks][0], cur[ks][1], cur[ks][2], cur[ks][3]);
 #pragma unroll
                 for (int a = 0; a < NT; ++a) {
                     Frag fa;
-                    fa.u = *reinterpret_cast<const uint4*>(wimg + (a * 32 + px) * ldw + ks * 16 + half * 8);
+                    fa.u = *reinterpret_cast<const uint4*>(wimg + (a * 32 + px) * LDW + ks * 16 + half * 8);
                     acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, acc[a], 0, 0, 0);
                 }
             }
@@ -542,14 +539,13 @@ __global__ __launch_bounds__(256) void pointwise_kernel(ConvDims d, int ksteps, 
                     make_uint2(pack_bf16(acc[a][4 * q], acc[a][4 * q + 1]), pack_bf16(acc[a][4 * q + 2], acc[a][4 * q + 3]));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- piece passes: this lane's 8 channels of pixel rows prow, prow + RPI, ...
-        const int mbase = t * 32;
+        // ---- store passes: RPI whole pixel rows per instruction, this lane's 8 channels of row prow + i * RPI
 #pragma unroll
-        for (int i = 0; i < 32 / RPI; ++i) {
+        for (int i = 0; i < NIT; ++i) {
             const int p = prow + i * RPI;
             const int m = mbase + p;
-            if (m < d.M && ch_ok) {
-                const uint4 v = *reinterpret_cast<const uint4*>(tile + p * LDT + cp * 8);
+            if (lane_ok && p < 32 && m < d.M) {
+                const uint4 v = *reinterpret_cast<const uint4*>(tile + p * LDT + cch);
                 if (MODE == kModePlain) *reinterpret_cast<uint4*>(y + (size_t)m * d.ldy + cch) = v;
                 if (MODE != kModePlain || stat_partial) {
                     const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
@@ -603,7 +599,7 @@ __global__ __launch_bounds__(256) void pointwise_kernel(ConvDims d, int ksteps, 
         }
         __builtin_amdgcn_wave_barrier();                   // the tile is rewritten by the next iteration
 #pragma unroll
-        for (int ks = 0; ks < kMaxSteps; ++ks) cur[ks] = nxt[ks];
+        for (int ks = 0; ks < KMAX; ++ks) cur[ks] = nxt[ks];
     }
     // ---- one partial row per workgroup: the lanes' sums meet in LDS, added in a fixed order (wave, pixel-row group)
     if (stat_partial && (MODE == kModePlain || MODE == kModeStats || MODE == kModeBwdReduce)) {
@@ -614,14 +610,193 @@ __global__ __launch_bounds__(256) void pointwise_kernel(ConvDims d, int ksteps, 
             red[(wave * 64 + lane) * 16 + 8 + r] = s2[r];
         }
         __syncthreads();
-        for (int e = tid; e < 2 * CT; e += 256) {
-            const int k = e / CT, c = e - k * CT;          // which sum, which channel of the tile
+        for (int e = tid; e < 2 * PP * 8; e += 256) {
+            const int k = e / (PP * 8), c = e - k * (PP * 8);   // which sum, which channel
             const int pc = c >> 3, r = c & 7;
             float tot = 0.f;
             for (int wv = 0; wv < 4; ++wv)
                 for (int g = 0; g < RPI; ++g) tot += red[(wv * 64 + g * PP + pc) * 16 + k * 8 + r];
-            if (co0 + c < d.Cout) stat_partial[((size_t)group * 2 + k) * d.Cout + co0 + c] = tot;
+            stat_partial[((size_t)blockIdx.x * 2 + k) * d.Cout + c] = tot;
         }
+    }
+}
+
+// pointwise_direct_kernel (every other qualifying layer: outputs that stay in the infinity cache, where the store pattern
+// costs little) has no LDS transposition: the order of the weight rows in the A operand is free, so the 32 output
+// channels of an MFMA tile are permuted such that the 16 accumulators of a lane ARE two 16-byte channel pieces of its pixel:
+//     MFMA row 8q + 4h + j (q = 0..3, h = lane >> 5, j = 0..3)  <->  channel 16 (q >> 1) + 8 h + 4 (q & 1) + j
+//     => acc[8s .. 8s + 7] of lane (pixel, h) = channels 16 s + 8 h .. + 7            (s = 0, 1)
+// A WAVE owns one 32-channel block for the whole kernel -- its weight fragments, per-channel constants and partial sums live
+// in registers -- and walks over 32-pixel tiles: operand fragments straight from global memory (next tile in flight), 1..8
+// MFMAs, the epilogue on the accumulators, two 16-byte stores per lane (the lanes l and l + 32 of a pixel write adjacent
+// pieces; the L2 merges a line's pieces from the waves of neighbouring channel blocks, which run on the same XCD).  No LDS,
+// no barrier in the loop, >= 4 waves per SIMD for the thin layers.
+template <int KMAX, int MODE>
+__global__ __launch_bounds__(256) void pointwise_direct_kernel(ConvDims d, int ksteps, int cblocks, int ngroups,
+                                                               const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                               uint16_t* __restrict__ y, float* __restrict__ stat_partial,
+                                                               EpiArgs ep) {
+    constexpr bool kSums = MODE == kModePlain || MODE == kModeStats || MODE == kModeBwdReduce;
+    __shared__ float red[kSums ? 4 * 64 * 33 : 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = xcd_order(blockIdx.x, gridDim.x) * 4 + wave;      // consecutive slots share an XCD (and its L2)
+    const int group = slot / cblocks, cb = slot - group * cblocks;
+    const bool live = group < ngroups;
+    const int px = lane & 31, h = lane >> 5;
+    const uint16_t* const zero = reinterpret_cast<const uint16_t*>(&g_zero16);
+    // ---- weight fragments: MFMA row px holds channel cb * 32 + perm(px)
+    Frag wf[KMAX];
+    {
+        const int q = px >> 3, hh = (px >> 2) & 1, j = px & 3;
+        const int co = cb * 32 + 16 * (q >> 1) + 8 * hh + 4 * (q & 1) + j;
+#pragma unroll
+        for (int ks = 0; ks < KMAX; ++ks) {
+            const int k0 = ks * 16 + h * 8;
+            wf[ks].u = *reinterpret_cast<const uint4*>((live && ks < ksteps && co < d.Cout && k0 < d.Cin) ? w + (size_t)co * d.Cin + k0 : zero);
+        }
+    }
+    // ---- this lane's two channel pieces and their constants
+    int ch[2];
+    bool ok[2];
+    float cs[2][8], ct[2][8], mu[2][8], is[2][8], a2[2][8], a3[2][8], s1[2][8], s2[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        ch[s] = cb * 32 + 16 * s + 8 * h;
+        ok[s] = live && ch[s] < d.Cout;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            cs[s][r] = ct[s][r] = mu[s][r] = is[s][r] = a2[s][r] = a3[s][r] = 0.f;
+            s1[s][r] = s2[s][r] = 0.f;
+            if (MODE >= kModeBnAct && ok[s]) {
+                const int c = ch[s] + r;
+                cs[s][r] = ep.coef[c];
+                ct[s][r] = ep.coef[d.Cout + c];
+                mu[s][r] = ep.coef[2 * d.Cout + c];
+                is[s][r] = ep.coef[3 * d.Cout + c];
+                if (MODE == kModeBwdApply) {
+                    const float k0 = ep.gsums[c] * ep.inv_count, k1 = ep.gsums[d.Cout + c] * ep.inv_count;
+                    a2[s][r] = -(cs[s][r] * is[s][r]) * k1;
+                    a3[s][r] = -cs[s][r] * k0 - a2[s][r] * mu[s][r];
+                }
+            }
+        }
+    }
+    const int ntiles = (d.M + 31) / 32;
+    u32x4 cur[KMAX], nxt[KMAX];
+    auto load_tile = [&](int t, u32x4 (&f)[KMAX]) {
+        const int m = t * 32 + px;
+        const uint16_t* row = (live && t < ntiles && m < d.M) ? x + (size_t)m * d.ldx : nullptr;
+#pragma unroll
+        for (int ks = 0; ks < KMAX; ++ks) {
+            if (ks < ksteps) {
+                const int k0 = ks * 16 + h * 8;
+                f[ks] = *reinterpret_cast<const u32x4*>((row && k0 < d.Cin) ? row + k0 : zero);
+            }
+        }
+    };
+    int t = live ? group : ntiles;
+    load_tile(t, cur);
+    for (; t < ntiles; t += ngroups) {
+        load_tile(t + ngroups, nxt);
+        const int m = t * 32 + px;
+        const bool row_ok = m < d.M;
+        uint4 g[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+        if (MODE >= kModeBwdReduce) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                if (row_ok && ok[s]) g[s] = *reinterpret_cast<const uint4*>(ep.dz + (size_t)m * ep.ldz + ch[s]);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KMAX; ++ks) {
+            if (ks < ksteps) {
+                Frag fb;
+                fb.u = make_uint4(cur[ks][0], cur[ks][1], cur[ks][2], cur[ks][3]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks].v, fb.v, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            // the rounded outputs (what the stored tensor holds) and their float32 values
+            const uint32_t wds[4] = {pack_bf16(acc[8 * s], acc[8 * s + 1]), pack_bf16(acc[8 * s + 2], acc[8 * s + 3]),
+                                     pack_bf16(acc[8 * s + 4], acc[8 * s + 5]), pack_bf16(acc[8 * s + 6], acc[8 * s + 7])};
+            float e0[8], out[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e0[2 * r] = __uint_as_float(wds[r] << 16);
+                e0[2 * r + 1] = __uint_as_float(wds[r] & 0xffff0000u);
+            }
+            if (!(row_ok && ok[s])) continue;
+            if (MODE == kModePlain) {
+                *reinterpret_cast<uint4*>(y + (size_t)m * d.ldy + ch[s]) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+                if (!stat_partial) continue;
+            }
+            if (MODE == kModePlain || MODE == kModeStats) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    s1[s][r] += e0[r];
+                    s2[s][r] = fmaf(e0[r], e0[r], s2[s][r]);
+                }
+            } else if (MODE == kModeBnAct) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float pre = fmaf(e0[r], cs[s][r], ct[s][r]);
+                    out[r] = ep.act == STP3_ACT_SWISH ? pre * fast_sigmoid(pre) : (ep.act == STP3_ACT_RELU ? fmaxf(pre, 0.f) : pre);
+                }
+            } else {
+                const uint32_t gds[4] = {g[s].x, g[s].y, g[s].z, g[s].w};
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float dzv = __uint_as_float((r & 1) ? (gds[r >> 1] & 0xffff0000u) : (gds[r >> 1] << 16));
+                    const float pre = fmaf(e0[r], cs[s][r], ct[s][r]);
+                    float der = 1.f;
+                    if (ep.act == STP3_ACT_SWISH) {
+                        const float sg = fast_sigmoid(pre);
+                        der = sg * (1.f + pre * (1.f - sg));
+                    } else if (ep.act == STP3_ACT_RELU) {
+                        der = pre > 0.f ? 1.f : 0.f;
+                    }
+                    const float gg = dzv * der;
+                    if (MODE == kModeBwdReduce) {
+                        s1[s][r] += gg;
+                        s2[s][r] = fmaf(gg, (e0[r] - mu[s][r]) * is[s][r], s2[s][r]);
+                    } else {
+                        out[r] = fmaf(cs[s][r], gg, fmaf(a2[s][r], e0[r], a3[s][r]));
+                    }
+                }
+            }
+            if (MODE == kModeBnAct || MODE == kModeBwdApply)
+                *reinterpret_cast<uint4*>(y + (size_t)m * d.ldy + ch[s]) =
+                    make_uint4(pack_bf16(out[0], out[1]), pack_bf16(out[2], out[3]), pack_bf16(out[4], out[5]),
+                               pack_bf16(out[6], out[7]));
+        }
+#pragma unroll
+        for (int ks = 0; ks < KMAX; ++ks) cur[ks] = nxt[ks];
+    }
+    // ---- the lanes of a half-wave hold partial sums of the same 16 channels: added over the 32 pixels lanes through LDS,
+    // in lane order; one partial row per pixel group
+    if (kSums) {
+        if (!stat_partial) return;                                      // (uniform: a plain convolution without statistics)
+        float* mine = red + (wave * 64 + lane) * 33;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                mine[s * 8 + r] = s1[s][r];
+                mine[16 + s * 8 + r] = s2[s][r];
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // lane (h, idx): idx = k * 16 + s * 8 + r  ->  channel cb * 32 + 16 s + 8 h + r of sum k
+        const int idx = lane & 31;
+        float tot = 0.f;
+        for (int p = 0; p < 32; ++p) tot += red[(wave * 64 + h * 32 + p) * 33 + idx];
+        const int k = idx >> 4, sp = (idx >> 3) & 1, r = idx & 7;
+        const int c = cb * 32 + 16 * sp + 8 * h + r;
+        if (live && c < d.Cout) stat_partial[((size_t)group * 2 + k) * d.Cout + c] = tot;
     }
 }
 
@@ -975,31 +1150,51 @@ int igemm_launch_act(int act, const ConvDims& d, dim3 grid, size_t lds, int tile
     return igemm_launch_one<BN, MODE, STP3_ACT_SWISH>(d, grid, lds, tiles_co, x, w, bias, y, partial, ep, s);
 }
 
-template <int NT, int KMAX, int MODE>
-int pointwise_launch_one(const ConvDims& d, int ksteps, int tiles_co, unsigned nwg, size_t lds, const void* x, const void* w,
-                         void* y, float* partial, const EpiArgs& ep, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pointwise_kernel<NT, KMAX, MODE>),
+template <int PP, int MODE>
+int pointwise_rows_launch_one(const ConvDims& d, int ksteps, unsigned nwg, size_t lds, const void* x, const void* w, void* y,
+                              float* partial, const EpiArgs& ep, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pointwise_rows_kernel<PP, MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return -(int)e;
-    hipLaunchKernelGGL((pointwise_kernel<NT, KMAX, MODE>), dim3(nwg), dim3(256), lds, s, d, ksteps, tiles_co,
+    hipLaunchKernelGGL((pointwise_rows_kernel<PP, MODE>), dim3(nwg), dim3(256), lds, s, d, ksteps, (const uint16_t*)x,
+                       (const uint16_t*)w, (uint16_t*)y, partial, ep);
+    return STP3_OK;
+}
+
+template <int PP>
+int pointwise_rows_launch_mode(int mode, const ConvDims& d, int ksteps, unsigned nwg, size_t lds, const void* x, const void* w,
+                               void* y, float* partial, const EpiArgs& ep, hipStream_t s) {
+    switch (mode) {
+        case kModePlain: return pointwise_rows_launch_one<PP, kModePlain>(d, ksteps, nwg, lds, x, w, y, partial, ep, s);
+        case kModeStats: return pointwise_rows_launch_one<PP, kModeStats>(d, ksteps, nwg, lds, x, w, y, partial, ep, s);
+        case kModeBnAct: return pointwise_rows_launch_one<PP, kModeBnAct>(d, ksteps, nwg, lds, x, w, y, partial, ep, s);
+        case kModeBwdReduce: return pointwise_rows_launch_one<PP, kModeBwdReduce>(d, ksteps, nwg, lds, x, w, y, partial, ep, s);
+        default: return pointwise_rows_launch_one<PP, kModeBwdApply>(d, ksteps, nwg, lds, x, w, y, partial, ep, s);
+    }
+}
+
+template <int KMAX, int MODE>
+int pointwise_direct_launch_one(const ConvDims& d, int ksteps, int cblocks, int ngroups, unsigned nwg, const void* x, const void* w,
+                                void* y, float* partial, const EpiArgs& ep, hipStream_t s) {
+    hipLaunchKernelGGL((pointwise_direct_kernel<KMAX, MODE>), dim3(nwg), dim3(256), 0, s, d, ksteps, cblocks, ngroups,
                        (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, partial, ep);
     return STP3_OK;
 }
 
-template <int NT, int KMAX>
-int pointwise_launch_mode(int mode, const ConvDims& d, int ksteps, int tiles_co, unsigned nwg, size_t lds, const void* x,
-                          const void* w, void* y, float* partial, const EpiArgs& ep, hipStream_t s) {
+template <int KMAX>
+int pointwise_direct_launch_mode(int mode, const ConvDims& d, int ksteps, int cblocks, int ngroups, unsigned nwg, const void* x,
+                                 const void* w, void* y, float* partial, const EpiArgs& ep, hipStream_t s) {
     switch (mode) {
-        case kModePlain: return pointwise_launch_one<NT, KMAX, kModePlain>(d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
-        case kModeStats: return pointwise_launch_one<NT, KMAX, kModeStats>(d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
-        case kModeBnAct: return pointwise_launch_one<NT, KMAX, kModeBnAct>(d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
+        case kModePlain: return pointwise_direct_launch_one<KMAX, kModePlain>(d, ksteps, cblocks, ngroups, nwg, x, w, y, partial, ep, s);
+        case kModeStats: return pointwise_direct_launch_one<KMAX, kModeStats>(d, ksteps, cblocks, ngroups, nwg, x, w, y, partial, ep, s);
+        case kModeBnAct: return pointwise_direct_launch_one<KMAX, kModeBnAct>(d, ksteps, cblocks, ngroups, nwg, x, w, y, partial, ep, s);
         case kModeBwdReduce:
-            return pointwise_launch_one<NT, KMAX, kModeBwdReduce>(d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
-        default: return pointwise_launch_one<NT, KMAX, kModeBwdApply>(d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
+            return pointwise_direct_launch_one<KMAX, kModeBwdReduce>(d, ksteps, cblocks, ngroups, nwg, x, w, y, partial, ep, s);
+        default: return pointwise_direct_launch_one<KMAX, kModeBwdApply>(d, ksteps, cblocks, ngroups, nwg, x, w, y, partial, ep, s);
     }
 }
 
-// the streaming kernel for short-contraction pointwise layers (see pointwise_kernel).  STP3_POINTWISE in the environment:
+// the streaming kernels for short-contraction pointwise layers (see pointwise_rows_kernel).  STP3_POINTWISE in the environment:
 // 0 keeps every layer on the tiled kernel (A/B measurements), 2 sends every qualifying layer here whatever its pixel count
 // (the small cases of the tests)
 int pointwise_setting() {
@@ -1023,27 +1218,34 @@ bool pointwise_applies(const stp3_conv_dims* p, const void* y, int64_t M) {
 int pointwise_run(const ConvDims& d, const void* x, const void* w, void* y, float* sums, float* partial, unsigned gx,
                   hipStream_t s, int mode, const EpiArgs& ep) {
     const int ksteps = (d.Cin + 15) / 16;
-    // 64 or 128 channels per workgroup: whichever pads Cout less (the wider tile on a tie: fewer passes over x)
-    const int pad64 = (d.Cout + 63) / 64 * 64, pad128 = (d.Cout + 127) / 128 * 128;
-    const int nt = pad128 <= pad64 ? 4 : 2, ct = nt * 32;
-    const int tiles_co = (d.Cout + ct - 1) / ct;
-    // weight image + four wave tiles (the reduction scratch lies over the tiles)
-    const size_t lds = (size_t)ct * (ksteps * 16 + 8) * 2 + (size_t)4 * 32 * (ct + 8) * 2;
-    // persistent: about two workgroups per CU, never more pixel groups than 128-pixel blocks (the partial-sum rows)
-    unsigned groups = (512 + tiles_co - 1) / tiles_co;
-    if (groups > gx) groups = gx;
-    if (groups < 1) groups = 1;
-    const unsigned nwg = groups * (unsigned)tiles_co;
-    int rc;
-#define STP3_PW(NT, KMAX) rc = pointwise_launch_mode<NT, KMAX>(mode, d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s)
-    if (nt == 4) {
-        if (ksteps <= 2) STP3_PW(4, 2); else if (ksteps <= 4) STP3_PW(4, 4); else STP3_PW(4, 8);
+    int rc, parts;
+    if ((d.Cout == 144 || d.Cout == 192) && ksteps <= 2 && d.ldy == d.Cout && (mode < kModeBwdReduce || ep.ldz == d.Cout)) {
+        // whole pixel rows per wave; persistent, as many workgroups per CU as their LDS (weight image + four wave tiles) allows
+        const int nt = (d.Cout + 31) / 32;
+        const size_t lds = (size_t)nt * 32 * 40 * 2 + (size_t)4 * 32 * (nt * 32 + 8) * 2;
+        unsigned per_cu = (unsigned)((160 * 1024) / lds);
+        if (per_cu > 3) per_cu = 3;
+        unsigned nwg = 256 * per_cu;
+        if (nwg > gx) nwg = gx;
+        parts = (int)nwg;
+        rc = d.Cout == 144 ? pointwise_rows_launch_mode<18>(mode, d, ksteps, nwg, lds, x, w, y, partial, ep, s)
+                           : pointwise_rows_launch_mode<24>(mode, d, ksteps, nwg, lds, x, w, y, partial, ep, s);
     } else {
-        if (ksteps <= 2) STP3_PW(2, 2); else if (ksteps <= 4) STP3_PW(2, 4); else STP3_PW(2, 8);
+        // a wave per (pixel group, 32-channel block); 16 waves per CU
+        const int cblocks = (d.Cout + 31) / 32;
+        const int ntiles = (d.M + 31) / 32;
+        int ngroups = 4096 / cblocks;
+        if (ngroups > (int)gx) ngroups = (int)gx;
+        if (ngroups > ntiles) ngroups = ntiles;
+        if (ngroups < 1) ngroups = 1;
+        parts = ngroups;
+        const unsigned nwg = (unsigned)(((int64_t)ngroups * cblocks + 3) / 4);
+        if (ksteps <= 2) rc = pointwise_direct_launch_mode<2>(mode, d, ksteps, cblocks, ngroups, nwg, x, w, y, partial, ep, s);
+        else if (ksteps <= 4) rc = pointwise_direct_launch_mode<4>(mode, d, ksteps, cblocks, ngroups, nwg, x, w, y, partial, ep, s);
+        else rc = pointwise_direct_launch_mode<8>(mode, d, ksteps, cblocks, ngroups, nwg, x, w, y, partial, ep, s);
     }
-#undef STP3_PW
     if (rc) return rc;
-    if (sums) launch_colsum(s, (int)groups, 2 * d.Cout, partial, sums);
+    if (sums) launch_colsum(s, parts, 2 * d.Cout, partial, sums);
     return status();
 }
 
