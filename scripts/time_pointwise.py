@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'st-p3_amd'))
 
 SHAPES = [  # N, Cin, H, W, Cout
     (72, 24, 112, 240, 144), (72, 32, 56, 120, 192), (72, 56, 28, 60, 336), (72, 112, 14, 30, 672),
-    (72, 32, 112, 240, 24 * 6), (12, 64, 200, 200, 64),
+    (72, 32, 112, 240, 24 * 6), (12, 64, 200, 200, 64), (12, 128, 200, 200, 512), (12, 64, 200, 200, 128),
 ]
 
 
@@ -69,6 +69,7 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'child':
         child()
     else:
+        names = {'0': 'tiled kernel', '1': 'streaming kernels'}
         for setting in ('0', '1'):
-            print(f'--- STP3_POINTWISE={setting} ({"tiled kernel" if setting == "0" else "streaming kernel"})', flush=True)
+            print(f'--- STP3_POINTWISE={setting} ({names[setting]})', flush=True)
             subprocess.run([sys.executable, os.path.abspath(__file__), 'child'], env=dict(os.environ, STP3_POINTWISE=setting), check=False)

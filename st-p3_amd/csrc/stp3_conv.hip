@@ -450,33 +450,37 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
 // the accumulators into pixel rows through a wave-private LDS tile and stores them as one contiguous 9 / 12 KB run; a lane
 // keeps the same 8 channels in every pass (64 / PP whole rows per store instruction), so their BatchNorm constants and
 // partial sums live in registers.
-template <int PP, int MODE>
-__global__ __launch_bounds__(256, 2) void pointwise_rows_kernel(ConvDims d, int ksteps, const uint16_t* __restrict__ x,
+template <int PP, int KMAX, int MODE>
+__global__ __launch_bounds__(256, 2) void pointwise_rows_kernel(ConvDims d, int ksteps, int tiles_co, const uint16_t* __restrict__ x,
                                                              const uint16_t* __restrict__ w, uint16_t* __restrict__ y,
                                                              float* __restrict__ stat_partial, EpiArgs ep) {
     constexpr int NT = (PP + 3) / 4;                       // 32-channel MFMA tiles
     constexpr int RPI = 64 / PP;                           // whole pixel rows per store instruction
     constexpr int NIT = (32 + RPI - 1) / RPI;              // store instructions per 32-pixel tile
     constexpr int LDT = NT * 32 + 8;                       // row stride of the transposition tile (elements)
-    constexpr int LDW = 40;                                // row stride of the weight image: 2 k-steps + 8
-    constexpr int KMAX = 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // a workgroup = (pixel group, channel tile of PP * 8 channels): ONE tile for the 144 / 192-channel layers (whole rows);
+    // several for Cout = k * 64 / k * 128 (whole 128-byte lines); tile fastest within an XCD's contiguous chunk of the order
+    const int v_order = xcd_order(blockIdx.x, gridDim.x);
+    const int group = v_order / tiles_co, ngroups = gridDim.x / tiles_co;
+    const int co0 = (v_order - group * tiles_co) * (PP * 8);
+    const int LDW = ksteps * 16 + 8;                       // row stride of the weight image (elements)
     uint16_t* wimg = reinterpret_cast<uint16_t*>(smem);    // [NT * 32][LDW]
     uint16_t* tile = wimg + NT * 32 * LDW + wave * (32 * LDT);
     float* red = reinterpret_cast<float*>(wimg + NT * 32 * LDW);   // [4 waves][64 lanes][16], over the tiles at the end
-    for (int e = tid; e < NT * 32 * 4; e += 256) {
-        const int r = e >> 2, k0 = (e & 3) * 8;
+    for (int e = tid; e < NT * 32 * ksteps * 2; e += 256) {
+        const int r = e / (ksteps * 2), k0 = (e - r * (ksteps * 2)) * 8;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (r < d.Cout && k0 < d.Cin) v = *reinterpret_cast<const u32x4*>(w + (size_t)r * d.Cin + k0);
+        if (r < PP * 8 && k0 < d.Cin) v = *reinterpret_cast<const u32x4*>(w + (size_t)(co0 + r) * d.Cin + k0);
         *reinterpret_cast<u32x4*>(wimg + r * LDW + k0) = v;
     }
     __syncthreads();
     const int px = lane & 31, half = lane >> 5;
     const int cp = lane % PP, prow = lane / PP;
     const bool lane_ok = prow < RPI;
-    const int cch = cp * 8;                                // this lane's 8 channels in the store passes
+    const int cl = cp * 8, cch = co0 + cl;                 // this lane's 8 channels in the store passes: in the tile, in the tensor
     float cs[8], ct[8], a2[8], a3[8], mu[8], is[8], s1[8], s2[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -497,17 +501,17 @@ __global__ __launch_bounds__(256, 2) void pointwise_rows_kernel(ConvDims d, int 
     const uint16_t* const zero = reinterpret_cast<const uint16_t*>(&g_zero16);
     u32x4 cur[KMAX], nxt[KMAX];
     const int ntiles = (d.M + 31) / 32;
-    const int stride_t = gridDim.x * 4;
+    const int stride_t = ngroups * 4;
     auto load_tile = [&](int t, u32x4 (&f)[KMAX]) {
         const int m = t * 32 + px;
         const uint16_t* row = (t < ntiles && m < d.M) ? x + (size_t)m * d.ldx : nullptr;
 #pragma unroll
         for (int ks = 0; ks < KMAX; ++ks) {
             const int k0 = ks * 16 + half * 8;
-            f[ks] = *reinterpret_cast<const u32x4*>((row && ks < ksteps && k0 < d.Cin) ? row + k0 : zero);
+            if (ks < ksteps) f[ks] = *reinterpret_cast<const u32x4*>((row && k0 < d.Cin) ? row + k0 : zero);
         }
     };
-    int t = blockIdx.x * 4 + wave;
+    int t = group * 4 + wave;
     load_tile(t, cur);
     for (; t < ntiles; t += stride_t) {
         load_tile(t + stride_t, nxt);
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_rows_kernel(ConvDims d, int 
             const int p = prow + i * RPI;
             const int m = mbase + p;
             if (lane_ok && p < 32 && m < d.M) {
-                const uint4 v = *reinterpret_cast<const uint4*>(tile + p * LDT + cch);
+                const uint4 v = *reinterpret_cast<const uint4*>(tile + p * LDT + cl);
                 if (MODE == kModePlain) *reinterpret_cast<uint4*>(y + (size_t)m * d.ldy + cch) = v;
                 if (MODE != kModePlain || stat_partial) {
                     const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
@@ -611,12 +615,12 @@ __global__ __launch_bounds__(256, 2) void pointwise_rows_kernel(ConvDims d, int 
         }
         __syncthreads();
         for (int e = tid; e < 2 * PP * 8; e += 256) {
-            const int k = e / (PP * 8), c = e - k * (PP * 8);   // which sum, which channel
+            const int k = e / (PP * 8), c = e - k * (PP * 8);   // which sum, which channel of the tile
             const int pc = c >> 3, r = c & 7;
             float tot = 0.f;
             for (int wv = 0; wv < 4; ++wv)
                 for (int g = 0; g < RPI; ++g) tot += red[(wv * 64 + g * PP + pc) * 16 + k * 8 + r];
-            stat_partial[((size_t)blockIdx.x * 2 + k) * d.Cout + c] = tot;
+            stat_partial[((size_t)group * 2 + k) * d.Cout + co0 + c] = tot;
         }
     }
 }
@@ -1150,26 +1154,27 @@ int igemm_launch_act(int act, const ConvDims& d, dim3 grid, size_t lds, int tile
     return igemm_launch_one<BN, MODE, STP3_ACT_SWISH>(d, grid, lds, tiles_co, x, w, bias, y, partial, ep, s);
 }
 
-template <int PP, int MODE>
-int pointwise_rows_launch_one(const ConvDims& d, int ksteps, unsigned nwg, size_t lds, const void* x, const void* w, void* y,
-                              float* partial, const EpiArgs& ep, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pointwise_rows_kernel<PP, MODE>),
+template <int PP, int KMAX, int MODE>
+int pointwise_rows_launch_one(const ConvDims& d, int ksteps, int tiles_co, unsigned nwg, size_t lds, const void* x, const void* w,
+                              void* y, float* partial, const EpiArgs& ep, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pointwise_rows_kernel<PP, KMAX, MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return -(int)e;
-    hipLaunchKernelGGL((pointwise_rows_kernel<PP, MODE>), dim3(nwg), dim3(256), lds, s, d, ksteps, (const uint16_t*)x,
-                       (const uint16_t*)w, (uint16_t*)y, partial, ep);
+    hipLaunchKernelGGL((pointwise_rows_kernel<PP, KMAX, MODE>), dim3(nwg), dim3(256), lds, s, d, ksteps, tiles_co,
+                       (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, partial, ep);
     return STP3_OK;
 }
 
-template <int PP>
-int pointwise_rows_launch_mode(int mode, const ConvDims& d, int ksteps, unsigned nwg, size_t lds, const void* x, const void* w,
-                               void* y, float* partial, const EpiArgs& ep, hipStream_t s) {
+template <int PP, int KMAX>
+int pointwise_rows_launch_mode(int mode, const ConvDims& d, int ksteps, int tiles_co, unsigned nwg, size_t lds, const void* x,
+                               const void* w, void* y, float* partial, const EpiArgs& ep, hipStream_t s) {
     switch (mode) {
-        case kModePlain: return pointwise_rows_launch_one<PP, kModePlain>(d, ksteps, nwg, lds, x, w, y, partial, ep, s);
-        case kModeStats: return pointwise_rows_launch_one<PP, kModeStats>(d, ksteps, nwg, lds, x, w, y, partial, ep, s);
-        case kModeBnAct: return pointwise_rows_launch_one<PP, kModeBnAct>(d, ksteps, nwg, lds, x, w, y, partial, ep, s);
-        case kModeBwdReduce: return pointwise_rows_launch_one<PP, kModeBwdReduce>(d, ksteps, nwg, lds, x, w, y, partial, ep, s);
-        default: return pointwise_rows_launch_one<PP, kModeBwdApply>(d, ksteps, nwg, lds, x, w, y, partial, ep, s);
+        case kModePlain: return pointwise_rows_launch_one<PP, KMAX, kModePlain>(d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
+        case kModeStats: return pointwise_rows_launch_one<PP, KMAX, kModeStats>(d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
+        case kModeBnAct: return pointwise_rows_launch_one<PP, KMAX, kModeBnAct>(d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
+        case kModeBwdReduce:
+            return pointwise_rows_launch_one<PP, KMAX, kModeBwdReduce>(d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
+        default: return pointwise_rows_launch_one<PP, KMAX, kModeBwdApply>(d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
     }
 }
 
@@ -1219,17 +1224,28 @@ int pointwise_run(const ConvDims& d, const void* x, const void* w, void* y, floa
                   hipStream_t s, int mode, const EpiArgs& ep) {
     const int ksteps = (d.Cin + 15) / 16;
     int rc, parts;
-    if ((d.Cout == 144 || d.Cout == 192) && ksteps <= 2 && d.ldy == d.Cout && (mode < kModeBwdReduce || ep.ldz == d.Cout)) {
-        // whole pixel rows per wave; persistent, as many workgroups per CU as their LDS (weight image + four wave tiles) allows
-        const int nt = (d.Cout + 31) / 32;
-        const size_t lds = (size_t)nt * 32 * 40 * 2 + (size_t)4 * 32 * (nt * 32 + 8) * 2;
+    // the kernel of whole pixel rows / whole lines: the 144- and 192-channel layers of the trunk (one channel tile) and every
+    // layer of k * 64 channels (tiles of 128 or 64 channels = whole 128-byte lines; e.g. the 128 -> 512 data gradient of the
+    // temporal model's ASPP projection, 491 MB: 314 us in 32-byte pieces, 246 us on the tiled kernel, 143 us here; and the
+    // in-cache 64 -> 128 @200x200x12: 46 / 36 / 31 us)
+    const bool rows_small = (d.Cout == 144 || d.Cout == 192) && ksteps <= 2;
+    const bool rows_lines = d.Cout % 64 == 0;
+    if ((rows_small || rows_lines) && d.ldy % 8 == 0 && (mode < kModeBwdReduce || ep.ldz % 8 == 0)) {
+        const int pp = rows_small ? d.Cout / 8 : (d.Cout % 128 == 0 ? 16 : 8), nt = (pp + 3) / 4;
+        const int tiles_co = d.Cout / (pp * 8);
+        const size_t lds = (size_t)nt * 32 * (ksteps * 16 + 8) * 2 + (size_t)4 * 32 * (nt * 32 + 8) * 2;
+        // persistent: as many workgroups per CU as their LDS (weight image + four wave tiles) allows, at most 3
         unsigned per_cu = (unsigned)((160 * 1024) / lds);
         if (per_cu > 3) per_cu = 3;
-        unsigned nwg = 256 * per_cu;
-        if (nwg > gx) nwg = gx;
-        parts = (int)nwg;
-        rc = d.Cout == 144 ? pointwise_rows_launch_mode<18>(mode, d, ksteps, nwg, lds, x, w, y, partial, ep, s)
-                           : pointwise_rows_launch_mode<24>(mode, d, ksteps, nwg, lds, x, w, y, partial, ep, s);
+        unsigned groups = (256 * per_cu + tiles_co - 1) / tiles_co;
+        if (groups > gx) groups = gx;
+        parts = (int)groups;
+        const unsigned nwg = groups * (unsigned)tiles_co;
+        if (pp == 18) rc = pointwise_rows_launch_mode<18, 2>(mode, d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
+        else if (pp == 24) rc = pointwise_rows_launch_mode<24, 2>(mode, d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
+        else if (pp == 8) rc = pointwise_rows_launch_mode<8, 8>(mode, d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
+        else if (ksteps <= 4) rc = pointwise_rows_launch_mode<16, 4>(mode, d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
+        else rc = pointwise_rows_launch_mode<16, 8>(mode, d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
     } else {
         // a wave per (pixel group, 32-channel block); 16 waves per CU
         const int cblocks = (d.Cout + 31) / 32;

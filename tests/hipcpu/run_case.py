@@ -850,7 +850,9 @@ def pointwise_stream(ops):
     cl = torch.channels_last
     for name, (n, cin, cout, h, w, act) in {'24_144': (3, 24, 144, 9, 11, ops.ACT_SWISH), '32_192': (1, 32, 192, 11, 13, ops.ACT_SWISH),
                                             '56_336': (2, 56, 336, 5, 9, ops.ACT_RELU), '112_672': (1, 112, 672, 6, 7, ops.ACT_SWISH),
-                                            '128_64': (2, 128, 64, 7, 5, ops.ACT_NONE), '8_72': (5, 8, 72, 16, 17, ops.ACT_SWISH)}.items():
+                                            '128_64': (2, 128, 64, 7, 5, ops.ACT_NONE), '8_72': (5, 8, 72, 16, 17, ops.ACT_SWISH),
+                                            # whole-line tiles of 128 channels (the kernel of the outputs beyond the infinity cache)
+                                            '72_256': (2, 72, 256, 7, 9, ops.ACT_SWISH), '40_128': (1, 40, 128, 9, 5, ops.ACT_RELU)}.items():
         g = torch.Generator().manual_seed(11)
         x0 = torch.randn(n, cin, h, w, generator=g).to(torch.bfloat16).contiguous(memory_format=cl)
         gy = torch.randn(n, cout, h, w, generator=g).to(torch.bfloat16).contiguous(memory_format=cl)
@@ -881,7 +883,6 @@ def pointwise_stream(ops):
         dxr = F.conv2d(xg.float(), wg)
         out[name] = {'stored_vs_torch': max(rel(a, b) for a, b in zip(res[0], res[2])),
                      'recompute_vs_stored': max(rel(a, b) for a, b in zip(res[1], res[0])),
-                     'each': [rel(a, b) for a, b in zip(res[1], res[0])],
                      'plain_vs_torch': rel(dx.float(), dxr)}
     return out
 

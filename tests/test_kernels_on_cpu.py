@@ -247,7 +247,8 @@ def test_pointwise_conv_batchnorm_without_the_convolution_output(results):
 
 
 def test_streaming_pointwise_kernel_in_all_modes(results):
-    """pointwise_kernel (stp3_conv.hip: short-contraction 1x1 layers as a streaming kernel) forced onto small ragged cases:
+    """pointwise_rows_kernel / pointwise_direct_kernel (stp3_conv.hip: short-contraction 1x1 layers as streaming kernels -- whole
+    pixel rows or whole 128-byte lines per wave through a wave-private LDS tile, or no LDS at all) forced onto small ragged cases:
     the stored route and the plain convolution against float32 torch, the recomputing route against the stored one
     (dx may differ by single bf16 roundings: the float32 sums of the BatchNorm backward are added in another order).  The
     same cases on the tiled kernel (STP3_POINTWISE=0) give the same distances from torch; also under reversed and random
@@ -257,7 +258,7 @@ def test_streaming_pointwise_kernel_in_all_modes(results):
             if name == 'seconds':
                 continue
             # (relu: a pre-activation that bf16 rounds across zero flips one gradient -- on either kernel)
-            assert r['stored_vs_torch'] <= (0.1 if name == '56_336' else 6e-3), (env, name, r)
+            assert r['stored_vs_torch'] <= (0.1 if name in ('56_336', '40_128') else 6e-3), (env, name, r)
             assert r['recompute_vs_stored'] <= 5e-3 and r['plain_vs_torch'] <= 5e-3, (env, name, r)
     a, b = _get(results, 'pointwise_stream'), _get(results, 'pointwise_stream', {'STP3_POINTWISE': '0'})
     for name in a:
