@@ -22,6 +22,9 @@ SHAPES = [
     ('decoder layer2 3x3 128->128 @50x50', 12, 128, 50, 50, 128, 3, 1, 1, 1),
     ('encoder upconcat 3x3 216->64 @28x60', 72, 216, 28, 60, 64, 3, 1, 1, 1),
     ('trunk stem 3x3/2 8->48 @224x480', 72, 8, 225, 481, 48, 3, 2, 0, 1),
+    ('decoder heads merged 3x3 64->320 @200x200', 12, 64, 200, 200, 320, 3, 1, 1, 1),
+    ('decoder heads merged dgrad 3x3 320->64 @200x200', 12, 320, 200, 200, 64, 3, 1, 1, 1),
+    ('temporal ASPP merged? 3x3 64->192', 12, 64, 200, 200, 192, 3, 1, 1, 1),
     ('trunk expand 1x1 24->144 @112x240', 72, 24, 112, 240, 144, 1, 1, 0, 1),
     ('trunk project 1x1 144->32 @56x120', 72, 144, 56, 120, 32, 1, 1, 0, 1),
     ('trunk expand 1x1 32->192 @56x120', 72, 32, 56, 120, 192, 1, 1, 0, 1),

@@ -130,7 +130,8 @@ class MBConvBlock(nn.Module):
             from .. import ops_fused
             group = None if _fused._sync_world(self._bn1) > 1 else False
         if self.expand != 1:
-            if fuse and EXPAND_WITHOUT_E0 and ops_fused.pointwise_bn_act_supported(x, self._expand_conv, self._bn0):
+            if fuse and EXPAND_WITHOUT_E0 and ops_fused.pointwise_bn_act_supported(x, self._expand_conv, self._bn0) \
+                    and ops_fused.pointwise_bn_act_pays(x, self._expand_conv):
                 # the expanded pre-activation tensor (6x the block input) is never stored: statistics pass + recomputation
                 x = ops_fused.pointwise_bn_act(x, self._expand_conv, self._bn0, ACT_SWISH, group=group)
             elif fuse:

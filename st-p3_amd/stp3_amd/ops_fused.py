@@ -292,6 +292,15 @@ def pointwise_bn_act_supported(x, conv, bn):
         ops.conv2d_supported(x, conv.weight, 1)
 
 
+def pointwise_bn_act_pays(x, conv):
+    """Whether the recomputing route is the faster one: where the library runs the four passes on its streaming kernels
+    (stp3_conv.hip: pointwise_rows_kernel / pointwise_direct_kernel -- contraction <= 128, >= 16384 pixels).  On the tiled
+    kernel a recomputing pass costs as much as a storing one (160 -> 960 @14x30x72: BatchNorm-backward passes of 75 + 51 us
+    against ~20 + 25 us on the stored 58-MB tensor)."""
+    n, cin, h, w = x.shape
+    return cin <= 128 and conv.weight.shape[0] >= 64 and n * h * w >= 16384
+
+
 def pointwise_bn_act(x, conv, bn, act, group=None):
     """act(bn(conv(x))) for a 1x1 convolution through ``_PointwiseBnAct`` (see there)."""
     if bn.num_batches_tracked is not None:
