@@ -175,10 +175,12 @@ class ASPP(nn.Module):
             spatial = torch.cat(branches, dim=1)
         proj, bn, act, drop = self.project
         n_sp = spatial.shape[1]
-        y = conv2d(spatial, proj.weight[:, :n_sp])
+        # (split, not two slices: one concatenation in backward instead of two zero-fills, two copies and an addition)
+        w_sp, w_pool = proj.weight.split([n_sp, proj.weight.shape[1] - n_sp], dim=1)
+        y = conv2d(spatial, w_sp)
         # the pooled branch is a constant plane per sample: its projection is a per-sample bias, folded
         # into the fused BatchNorm instead of a broadcast add over the whole map
-        sbias = hp(conv1x1_on_vector(pooled.to(y.dtype), proj.weight[:, n_sp:]).flatten(1))
+        sbias = hp(conv1x1_on_vector(pooled.to(y.dtype), w_pool).flatten(1))
         return drop(bn_act(bn, y, ACT_RELU, sbias=sbias))
 
 

@@ -97,7 +97,9 @@ class CausalConv3d(nn.Module):
         kt = w.shape[2]
         assert self.conv.bias is None and self.conv.dilation == (1, 1, 1) and kt in (1, 2)
         lanes_in = x2.shape[1]
-        taps = [_pad_in(w[:, :, k], 1, lanes_in) for k in range(kt)]
+        # (unbind / squeeze, not w[:, :, k]: the backward of k selects is k zero-fills, k copies and k - 1 additions; that of
+        # an unbind one stack, that of a squeeze nothing)
+        taps = [_pad_in(wk, 1, lanes_in) for wk in (w.unbind(2) if kt > 1 else (w.squeeze(2),))]
         if kt == 2:
             if ops.causal_pair_supported(x2):
                 x2 = ops.causal_pair(x2, frames)
@@ -236,11 +238,12 @@ class TemporalBlock(nn.Module):
         a per-frame bias, W[:, C:] @ extra, added inside the fused BatchNorm (exact; no concatenated tensor).
         ``lanes``: output channel lanes (>= the layer's channels; the extra ones come out zero, see ``_pad_out``)."""
         conv, norm = seq[0], seq[1]
-        wgt = conv.weight[:, :, 0]
+        wgt = conv.weight.squeeze(2)                                     # (1x1x1 kernel: a view, nothing to add up in backward)
         c = x2.shape[1]
-        w_x = wgt if extra2 is None else wgt[:, :c]
+        # (split, not two slices: one concatenation in backward instead of two zero-fills, two copies and an addition)
+        w_x, w_extra = (wgt, None) if extra2 is None else wgt.split([c, wgt.shape[1] - c], dim=1)
         y = _conv2d_padded_channels(x2, w_x if lanes is None else _pad_out(w_x, lanes))
-        sbias = None if extra2 is None else hp(extra2).to(hp(wgt).dtype) @ hp(wgt[:, c:, 0, 0]).t()
+        sbias = None if extra2 is None else hp(extra2).to(hp(wgt).dtype) @ hp(w_extra.flatten(1)).t()
         return dict(bn=norm, x=y, act=ACT_RELU if relu else ACT_NONE, sbias=sbias)
 
     @staticmethod
@@ -291,16 +294,19 @@ class TemporalBlock(nn.Module):
         outs.append(heads[len(self.convolution_paths) - 1])
         paths = torch.cat(outs, dim=1)
         agg = self.aggregation[0]
-        wgt = agg.conv.weight[:, :, 0]                                   # (Cout, Cin_total, 1, 1)
-        y = _conv2d_padded_channels(paths, _pad_in(wgt[:, :self._paths_channels], len(outs), lanes))
+        wgt = agg.conv.weight.squeeze(2)                                 # (Cout, Cin_total, 1, 1)
+        # the paths' columns and one run of columns per pooled tensor: ONE split (its backward is one concatenation)
+        pooled_list = [] if not self.use_pyramid_pooling else \
+            list(pooled_outs if pooled_outs is not None else self.pyramid_pooling(x, extra, folded=x_pool))   # (B, C', T, h', w')
+        w_parts = wgt.split([self._paths_channels] + [pl.shape[1] for pl in pooled_list], dim=1) if pooled_list else (wgt,)
+        y = _conv2d_padded_channels(paths, _pad_in(w_parts[0], len(outs), lanes))
         sbias = None
         if self.use_pyramid_pooling:
-            off = self._paths_channels
-            for pooled in (pooled_outs if pooled_outs is not None else self.pyramid_pooling(x, extra, folded=x_pool)):   # (B, C', T, h', w')
+            for pooled, w_p in zip(pooled_list, w_parts[1:]):
                 cp = pooled.shape[1]
                 p2 = pooled.permute(0, 2, 1, 3, 4).reshape(b * t, cp, *pooled.shape[-2:])
-                contrib = (conv1x1_on_vector(p2.to(y.dtype), wgt[:, off:off + cp].to(y.dtype))
-                           if p2.shape[-2:] == (1, 1) else F.conv2d(p2.to(y.dtype), wgt[:, off:off + cp].to(y.dtype)))
+                contrib = (conv1x1_on_vector(p2.to(y.dtype), w_p.to(y.dtype))
+                           if p2.shape[-2:] == (1, 1) else F.conv2d(p2.to(y.dtype), w_p.to(y.dtype)))
                 if contrib.shape[-2:] == (1, 1):
                     # whole-plane pooling (the reference's only setting): a constant plane per frame, i.e. a
                     # per-sample bias of the aggregation -- folded into the fused BatchNorm
@@ -310,7 +316,6 @@ class TemporalBlock(nn.Module):
                     if contrib.shape[-2:] != (h, w):
                         contrib = F.interpolate(contrib, (h, w), mode='bilinear', align_corners=False)
                     y = y + contrib
-                off += cp
         assert self.projection is not None or extra is None
         skip = x_skip if self.projection is None else heads[-1]
         out = _bn_act_2d(agg.norm, y, res=skip, sbias=sbias)
@@ -335,7 +340,7 @@ def _gru_cell(x, state, conv_update, conv_reset, conv_state_tilde, bias_init):
     b = torch.cat([conv_update.bias, conv_reset.bias], dim=0)
     from .fused import conv2d
     gates = torch.sigmoid(hp(conv2d(xs, w, b, 1, conv_update.padding, 1)) + bias_init)
-    update, reset = gates[:, :hidden], gates[:, hidden:]
+    update, reset = gates.split(hidden, dim=1)
     state_f = hp(state)
     tilde = hp(_conv(conv_state_tilde, torch.cat([x, ((1.0 - reset) * state_f).to(x.dtype)], dim=1)))
     return ((1.0 - update) * state_f + update * tilde).to(state.dtype)
