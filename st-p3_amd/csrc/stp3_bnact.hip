@@ -644,7 +644,13 @@ struct Launch {
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-inline int plan(const stp3_bn_dims* p, Launch* L, std::initializer_list<const void*> vec_ptrs) {
+// `per_cu`: workgroups of the kernel about to be launched that one CU keeps resident (its register allocation: bn_stats 64-72
+// registers -> 7, bn_apply_fwd 78-92 -> 5, bn_bwd_reduce 120-122 -> 4, bn_apply_bwd 126-132 -> 3; pinned by
+// tests/test_kernel_resources_cpu.py).  The grid is AT MOST one resident round of the chip's 256 CUs (four rounds in the
+// full-occupancy geometry): these are streaming kernels whose blocks all take equally long, so a handful of blocks beyond a
+// round runs alone behind it -- 12-sample maps got 86 * 12 = 1032 blocks for 1024 resident places (bn_bwd_reduce 80 -> 60 us at
+// 12 x 128 x 200 x 200, the step 42.4 -> 41.4 ms with the rounding alone).
+inline int plan(const stp3_bn_dims* p, Launch* L, std::initializer_list<const void*> vec_ptrs, int per_cu) {
     if (!p) return STP3_EINVAL;
     if (p->N <= 0 || p->rows <= 0 || p->C <= 0 || p->ldx < p->C || p->ldy < p->C) return STP3_EINVAL;
     if (p->dtype != STP3_DTYPE_F32 && p->dtype != STP3_DTYPE_BF16) return STP3_EUNSUP;
@@ -678,9 +684,10 @@ inline int plan(const stp3_bn_dims* p, Launch* L, std::initializer_list<const vo
         while (RL * 2 * CVB <= kThreads) RL *= 2;
     }
     const int ctiles = (CV + CVB - 1) / CVB;
-    // ~1024 blocks in total (4096 with the experimental geometry), at least 8 rows per row lane
-    const int target = L->full ? 4096 : 1024;
-    int bx = (target + p->N * ctiles - 1) / (p->N * ctiles);
+    // at most one resident round (four in the full-occupancy geometry), at least 8 rows per row lane
+    const int target = 256 * per_cu * (L->full ? 4 : 1);
+    static const bool round_up = getenv("STP3_GRID_CEIL") != nullptr;       // (experiment: the grids of rounds 2-3, ~1024 / 4096 blocks rounded up)
+    int bx = round_up ? ((L->full ? 4096 : 1024) + p->N * ctiles - 1) / (p->N * ctiles) : target / (p->N * ctiles);
     const int max_bx = (p->rows + RL * 8 - 1) / (RL * 8);
     if (bx > max_bx) bx = max_bx;
     if (bx < 1) bx = 1;
@@ -734,7 +741,7 @@ int stp3_bn_workspace_bytes(const stp3_bn_dims* p, size_t* bytes) {
 int stp3_bn_stats(const stp3_bn_dims* p, const void* x, const float* sbias, void* workspace, size_t workspace_bytes,
                   float* sums, void* stream) {
     Launch L;
-    int rc = plan(p, &L, {x});
+    int rc = plan(p, &L, {x}, 7);
     if (rc) return rc;
     if (!x || !workspace || !sums || (p->has_sbias && !sbias)) return STP3_EINVAL;
     if (workspace_bytes < ws_bytes(p)) return STP3_ENOSPACE;
@@ -751,7 +758,7 @@ int stp3_bn_apply_fwd(const stp3_bn_dims* p, const void* x, const float* sbias, 
                       float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                       void* y, void* stream) {
     Launch L;
-    int rc = plan(p, &L, {x, res, y});
+    int rc = plan(p, &L, {x, res, y}, 5);
     if (rc) return rc;
     if (!x || !y || (p->has_sbias && !sbias) || (p->res_mode != STP3_RES_NONE && !res) ||
         (p->has_oscale && !oscale))
@@ -781,7 +788,7 @@ int stp3_bn_bwd_reduce(const stp3_bn_dims* p, const void* dy, const void* x, con
                        const float* beta, void* workspace, size_t workspace_bytes, float* sample_sums,
                        float* sums, void* stream) {
     Launch L;
-    int rc = plan(p, &L, {dy, x, res});
+    int rc = plan(p, &L, {dy, x, res}, 4);
     if (rc) return rc;
     if (!dy || !x || !mean || !invstd || !workspace || !sample_sums || !sums || (p->has_sbias && !sbias) ||
         (p->res_mode == STP3_RES_BEFORE_ACT && !res) || (p->has_oscale && !oscale))
@@ -805,7 +812,7 @@ int stp3_bn_apply_bwd(const stp3_bn_dims* p, const void* dy, const void* x, cons
                       const float* oscale, const float* mean, const float* invstd, const float* gamma,
                       const float* beta, const float* sums, double count, void* dx, void* dres, void* stream) {
     Launch L;
-    int rc = plan(p, &L, {dy, x, res, dx, dres});
+    int rc = plan(p, &L, {dy, x, res, dx, dres}, 3);
     if (rc) return rc;
     if (!dy || !x || !mean || !invstd || !dx || (p->has_sbias && !sbias) ||
         (p->res_mode == STP3_RES_BEFORE_ACT && !res) || (p->has_oscale && !oscale))

@@ -9,6 +9,7 @@
 // (profiles/r01_bench_steady_miopen.txt); these kernels replace it.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "stp3_cdna.h"
 #include "stp3_hip.h"
@@ -414,6 +415,17 @@ __global__ __launch_bounds__(256) void dwconv_stat_reduce_kernel(int nblocks, in
 constexpr int kStatBlocks = 2048;
 constexpr int kWgradBlocks = 512;
 
+// Workgroups of `kernel` (256 threads, `lds` bytes of dynamic LDS) that the chip's 256 CUs keep resident at once.  The
+// persistent kernels below take AT MOST one such round: their blocks walk equal strided shares of the pixels, so blocks beyond
+// a round run alone behind it (2048 blocks of dwconv_fwd_stats<3, 1> on 768 resident places were 2.67 rounds).
+template <typename Kern>
+inline int resident_blocks(Kern kernel, size_t lds) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    static const bool old_grids = getenv("STP3_GRID_CEIL") != nullptr;      // (experiment: the grids of rounds 2-3)
+    return old_grids ? (1 << 30) : per_cu * 256;
+}
+
 inline int status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? STP3_OK : -(int)e;
@@ -451,9 +463,11 @@ int launch_fwd_stats(const DwDims& d, const void* x, const float* w, void* y, fl
     if (ngroups >= (1LL << 31)) return STP3_EUNSUP;
     const int by = (CV + CVB - 1) / CVB;
     int64_t want = (ngroups + PL - 1) / PL;
-    const int cap = kStatBlocks / by > 0 ? kStatBlocks / by : 1;
-    const int bx = (int)(want < cap ? want : cap);
     const size_t lds = (size_t)PL * 2 * CVB * VN * sizeof(float);
+    int limit = resident_blocks(dwconv_fwd_stats_kernel<T, K, S>, lds);
+    if (limit > kStatBlocks) limit = kStatBlocks;
+    const int cap = limit / by > 0 ? limit / by : 1;
+    const int bx = (int)(want < cap ? want : cap);
     hipLaunchKernelGGL((dwconv_fwd_stats_kernel<T, K, S>), dim3(bx, by), dim3(256), lds, s, d, (const T*)x, w, (T*)y, ws);
     hipLaunchKernelGGL(dwconv_stat_reduce_kernel, dim3((2 * d.C + kRedCols - 1) / kRedCols), dim3(256), 0, s, bx, 2 * d.C, ws, sums);
     return status();
@@ -485,9 +499,12 @@ int launch_bwd_weight(const DwDims& d, const void* x, const void* dy, float* dw,
     const int64_t npix = (int64_t)d.N * d.Ho * ((d.Wo + 3) / 4);       // groups of 4 output pixels
     if (npix >= (1LL << 31)) return STP3_EUNSUP;
     int64_t want = (npix + PL - 1) / PL;
-    const int bx = (int)(want < kWgradBlocks ? want : kWgradBlocks);
     const int by = (CV + CVB - 1) / CVB;
     const size_t lds = (size_t)PL * K * CVB * VN * sizeof(float);
+    int cap = resident_blocks(dwconv_bwd_weight_kernel<T, K, S>, lds) / (by * K);      // (bx * by * K workgroups)
+    if (cap > kWgradBlocks) cap = kWgradBlocks;
+    if (cap < 1) cap = 1;
+    const int bx = (int)(want < cap ? want : cap);
     hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, S>), dim3(bx * by * K), dim3(256), lds, s, d, bx, (const T*)x,
                        (const T*)dy, ws);
     const int n = K * K * d.C;

@@ -21,6 +21,7 @@
 // HBM-bound streaming kernels: 16-byte channel vectors, float32 arithmetic, deterministic two-stage reductions.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <initializer_list>
 
@@ -427,7 +428,10 @@ struct MbPlan {
     dim3 grid;
 };
 
-inline int mb_plan(const stp3_se_dims* p, int ldg, MbPlan* P, std::initializer_list<const void*> ptrs) {
+// `per_cu`: resident workgroups per CU of the kernel about to be launched (se_pool_act / mbconv_scale_act 64-72 registers
+// -> 7, mbconv_bwd_reduce 120-128 -> 4, mbconv_bwd_apply 96-112 -> 4); the grid is at most `rounds` resident rounds of the
+// chip (see plan() in stp3_bnact.hip)
+inline int mb_plan(const stp3_se_dims* p, int ldg, MbPlan* P, std::initializer_list<const void*> ptrs, int per_cu, int rounds) {
     if (!p || p->N <= 0 || p->rows <= 0 || p->C <= 0 || p->ld < p->C || ldg < p->C) return STP3_EINVAL;
     if (p->dtype != STP3_DTYPE_F32 && p->dtype != STP3_DTYPE_BF16) return STP3_EUNSUP;
     P->bf16 = p->dtype == STP3_DTYPE_BF16;
@@ -441,7 +445,8 @@ inline int mb_plan(const stp3_se_dims* p, int ldg, MbPlan* P, std::initializer_l
     int RL = 1;
     while (RL * 2 * CVB <= kT) RL *= 2;
     const int ctiles = (CV + CVB - 1) / CVB;
-    int bx = (2048 + p->N * ctiles - 1) / (p->N * ctiles);
+    static const bool round_up = getenv("STP3_GRID_CEIL") != nullptr;       // (experiment: the old rounding)
+    int bx = round_up ? (2048 + p->N * ctiles - 1) / (p->N * ctiles) : (256 * per_cu * rounds) / (p->N * ctiles);
     const int max_bx = (p->rows + RL * 8 - 1) / (RL * 8);
     if (bx > max_bx) bx = max_bx;
     if (bx < 1) bx = 1;
@@ -498,7 +503,7 @@ int stp3_mbconv_workspace_bytes(const stp3_se_dims* p, size_t* bytes) {
 int stp3_se_pool_act(const stp3_se_dims* p, const void* x, const float* scale, const float* shift, int32_t act,
                      void* workspace, size_t workspace_bytes, float* out, void* stream) {
     MbPlan P;
-    int rc = mb_plan(p, p ? p->ld : 0, &P, {x});
+    int rc = mb_plan(p, p ? p->ld : 0, &P, {x}, 7, 1);
     if (rc) return rc;
     if (!x || !scale || !shift || !workspace || !out || !act_ok(act)) return STP3_EINVAL;
     if (workspace_bytes < (size_t)p->N * kMaxBx * p->C * sizeof(float)) return STP3_ENOSPACE;
@@ -513,7 +518,7 @@ int stp3_se_pool_act(const stp3_se_dims* p, const void* x, const float* scale, c
 int stp3_mbconv_scale_act(const stp3_se_dims* p, int32_t ldy, const void* x, const float* scale, const float* shift, int32_t act,
                           const float* gate, void* y, void* stream) {
     MbPlan P;
-    int rc = mb_plan(p, ldy, &P, {x, y});
+    int rc = mb_plan(p, ldy, &P, {x, y}, 7, 1);
     if (rc) return rc;
     if (!x || !scale || !shift || !y || !act_ok(act)) return STP3_EINVAL;
     MB_SWITCH(P, act, hipLaunchKernelGGL((mbconv_scale_act_kernel<T, VEC, ACT>), P.grid, dim3(kT), 0, (hipStream_t)stream, P.d,
@@ -524,7 +529,7 @@ int stp3_mbconv_scale_act(const stp3_se_dims* p, int32_t ldy, const void* x, con
 int stp3_mbconv_bwd_reduce(const stp3_se_dims* p, int32_t ldg, const void* da, const void* x, const float* coef, int32_t act,
                            void* workspace, size_t workspace_bytes, float* sums5, void* stream) {
     MbPlan P;
-    int rc = mb_plan(p, ldg, &P, {da, x});
+    int rc = mb_plan(p, ldg, &P, {da, x}, 4, 2);
     if (rc) return rc;
     if (!da || !x || !coef || !workspace || !sums5 || !act_ok(act)) return STP3_EINVAL;
     if (workspace_bytes < (size_t)p->N * kMaxBx * 5 * p->C * sizeof(float)) return STP3_ENOSPACE;
@@ -549,7 +554,7 @@ int stp3_mbconv_bwd_coef(int32_t N, int32_t C, const float* sums5, const float* 
 int stp3_mbconv_bwd_apply(const stp3_se_dims* p, int32_t ldg, const void* da, const void* x, const float* coef, int32_t act,
                           const float* gate, const float* dpooled, const float* gsums, double count, void* dx, void* stream) {
     MbPlan P;
-    int rc = mb_plan(p, ldg, &P, {da, x, dx});
+    int rc = mb_plan(p, ldg, &P, {da, x, dx}, 4, 2);
     if (rc) return rc;
     if (!da || !x || !coef || !gsums || !dx || !act_ok(act) || !(count >= 1.0)) return STP3_EINVAL;
     const float inv_count = (float)(1.0 / count);

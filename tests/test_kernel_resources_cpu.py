@@ -42,7 +42,30 @@ def test_kernel_register_lds_and_scratch_budgets():
         for k in by_name[name]:
             assert k['vgpr'] + k['agpr'] <= budget, k
     # the MFMA convolutions: accumulators in AGPRs, at least 2 workgroups of 256 threads per CU
-    for name in ('void conv2d_igemm_kernel<128>', 'void conv2d_wgrad_kernel<128, 128>'):
+    for name in ('void conv2d_igemm_kernel<128, 0, 0>', 'void conv2d_wgrad_kernel<128, 128>'):
         assert name in by_name, name
         for k in by_name[name]:
             assert k['agpr'] == 64 and k['vgpr'] + k['agpr'] <= 256, k
+    # The grids of the streaming kernels are sized to ONE resident round of the chip (256 CUs x the workgroups a CU keeps):
+    # the launchers carry these numbers as constants (plan() in stp3_bnact.hip, mb_plan() in stp3_mbconv.hip, wgrad_plan() in
+    # stp3_conv.hip) -- a kernel that grows beyond its register budget would silently get a second, nearly empty round
+    def per_cu(k):
+        regs = (k['vgpr'] + k['agpr'] + 7) // 8 * 8
+        return min(8, 512 // regs)
+    for prefix, want in (('void bn_stats_kernel<unsigned short, 8', 7), ('void bn_apply_fwd_kernel<unsigned short, 8', 5),
+                         ('void bn_bwd_reduce_kernel<unsigned short, 8', 4), ('void bn_apply_bwd_kernel<unsigned short, 8', 3),
+                         ('void se_pool_act_kernel<unsigned short, 8', 7), ('void mbconv_scale_act_kernel<unsigned short, 8', 7),
+                         ('void mbconv_bwd_reduce_kernel<unsigned short, 8', 4), ('void mbconv_bwd_apply_kernel<unsigned short, 8', 4),
+                         ('void conv2d_wgrad_kernel<128, 128>', 2), ('void conv2d_wgrad_kernel<128, 64>', 3),
+                         ('void conv2d_wgrad_kernel<64, 128>', 3), ('void conv2d_wgrad_kernel<64, 64>', 5)):
+        found = [k for n, ks in by_name.items() if n.startswith(prefix) for k in ks]
+        assert found, prefix
+        for k in found:
+            assert per_cu(k) >= want, (want, k)
+    # the streaming pointwise kernels: whole-row variant 2-3 workgroups per CU (launch bound), register-only variant 4 for the
+    # thin layers
+    for n, ks in by_name.items():
+        if n.startswith('void pointwise_rows_kernel<'):
+            assert all(k['vgpr'] + k['agpr'] <= 256 for k in ks), n
+        if n.startswith('void pointwise_direct_kernel<2, 0>') or n.startswith('void pointwise_direct_kernel<2, 1>'):
+            assert all(per_cu(k) >= 4 for k in ks), n
