@@ -1178,24 +1178,40 @@ int pointwise_rows_launch_mode(int mode, const ConvDims& d, int ksteps, int tile
     }
 }
 
+// one wave per (pixel group, 32-channel block); the grid is ONE resident round of this instantiation's workgroups (4 per CU for
+// the thin layers' forward modes, 1-3 for the register-heavier ones), never more pixel groups than 128-pixel blocks (the
+// partial-sum rows) or 32-pixel tiles
 template <int KMAX, int MODE>
-int pointwise_direct_launch_one(const ConvDims& d, int ksteps, int cblocks, int ngroups, unsigned nwg, const void* x, const void* w,
-                                void* y, float* partial, const EpiArgs& ep, hipStream_t s) {
+int pointwise_direct_launch_one(const ConvDims& d, int ksteps, unsigned gx, int* parts, const void* x, const void* w, void* y,
+                                float* partial, const EpiArgs& ep, hipStream_t s) {
+    static const int resident = [] {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pointwise_direct_kernel<KMAX, MODE>, 256, 0) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        return per_cu * 256;
+    }();
+    const int cblocks = (d.Cout + 31) / 32;
+    const int ntiles = (d.M + 31) / 32;
+    int ngroups = resident * 4 / cblocks;
+    if (ngroups > (int)gx) ngroups = (int)gx;
+    if (ngroups > ntiles) ngroups = ntiles;
+    if (ngroups < 1) ngroups = 1;
+    *parts = ngroups;
+    const unsigned nwg = (unsigned)(((int64_t)ngroups * cblocks + 3) / 4);
     hipLaunchKernelGGL((pointwise_direct_kernel<KMAX, MODE>), dim3(nwg), dim3(256), 0, s, d, ksteps, cblocks, ngroups,
                        (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, partial, ep);
     return STP3_OK;
 }
 
 template <int KMAX>
-int pointwise_direct_launch_mode(int mode, const ConvDims& d, int ksteps, int cblocks, int ngroups, unsigned nwg, const void* x,
-                                 const void* w, void* y, float* partial, const EpiArgs& ep, hipStream_t s) {
+int pointwise_direct_launch_mode(int mode, const ConvDims& d, int ksteps, unsigned gx, int* parts, const void* x, const void* w,
+                                 void* y, float* partial, const EpiArgs& ep, hipStream_t s) {
     switch (mode) {
-        case kModePlain: return pointwise_direct_launch_one<KMAX, kModePlain>(d, ksteps, cblocks, ngroups, nwg, x, w, y, partial, ep, s);
-        case kModeStats: return pointwise_direct_launch_one<KMAX, kModeStats>(d, ksteps, cblocks, ngroups, nwg, x, w, y, partial, ep, s);
-        case kModeBnAct: return pointwise_direct_launch_one<KMAX, kModeBnAct>(d, ksteps, cblocks, ngroups, nwg, x, w, y, partial, ep, s);
-        case kModeBwdReduce:
-            return pointwise_direct_launch_one<KMAX, kModeBwdReduce>(d, ksteps, cblocks, ngroups, nwg, x, w, y, partial, ep, s);
-        default: return pointwise_direct_launch_one<KMAX, kModeBwdApply>(d, ksteps, cblocks, ngroups, nwg, x, w, y, partial, ep, s);
+        case kModePlain: return pointwise_direct_launch_one<KMAX, kModePlain>(d, ksteps, gx, parts, x, w, y, partial, ep, s);
+        case kModeStats: return pointwise_direct_launch_one<KMAX, kModeStats>(d, ksteps, gx, parts, x, w, y, partial, ep, s);
+        case kModeBnAct: return pointwise_direct_launch_one<KMAX, kModeBnAct>(d, ksteps, gx, parts, x, w, y, partial, ep, s);
+        case kModeBwdReduce: return pointwise_direct_launch_one<KMAX, kModeBwdReduce>(d, ksteps, gx, parts, x, w, y, partial, ep, s);
+        default: return pointwise_direct_launch_one<KMAX, kModeBwdApply>(d, ksteps, gx, parts, x, w, y, partial, ep, s);
     }
 }
 
@@ -1247,18 +1263,9 @@ int pointwise_run(const ConvDims& d, const void* x, const void* w, void* y, floa
         else if (ksteps <= 4) rc = pointwise_rows_launch_mode<16, 4>(mode, d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
         else rc = pointwise_rows_launch_mode<16, 8>(mode, d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
     } else {
-        // a wave per (pixel group, 32-channel block); 16 waves per CU
-        const int cblocks = (d.Cout + 31) / 32;
-        const int ntiles = (d.M + 31) / 32;
-        int ngroups = 4096 / cblocks;
-        if (ngroups > (int)gx) ngroups = (int)gx;
-        if (ngroups > ntiles) ngroups = ntiles;
-        if (ngroups < 1) ngroups = 1;
-        parts = ngroups;
-        const unsigned nwg = (unsigned)(((int64_t)ngroups * cblocks + 3) / 4);
-        if (ksteps <= 2) rc = pointwise_direct_launch_mode<2>(mode, d, ksteps, cblocks, ngroups, nwg, x, w, y, partial, ep, s);
-        else if (ksteps <= 4) rc = pointwise_direct_launch_mode<4>(mode, d, ksteps, cblocks, ngroups, nwg, x, w, y, partial, ep, s);
-        else rc = pointwise_direct_launch_mode<8>(mode, d, ksteps, cblocks, ngroups, nwg, x, w, y, partial, ep, s);
+        if (ksteps <= 2) rc = pointwise_direct_launch_mode<2>(mode, d, ksteps, gx, &parts, x, w, y, partial, ep, s);
+        else if (ksteps <= 4) rc = pointwise_direct_launch_mode<4>(mode, d, ksteps, gx, &parts, x, w, y, partial, ep, s);
+        else rc = pointwise_direct_launch_mode<8>(mode, d, ksteps, gx, &parts, x, w, y, partial, ep, s);
     }
     if (rc) return rc;
     if (sums) launch_colsum(s, parts, 2 * d.Cout, partial, sums);
