@@ -1,12 +1,12 @@
-"""HIP-event timing of the short-contraction 1x1 layers of the trunk (B = 4, T = 3: 72 images) on the tiled kernel
-(STP3_POINTWISE=0) and the streaming kernel (pointwise_kernel, stp3_conv.hip), in the five epilogue modes; GB/s of the
-mode's own algorithmic traffic beside each time.
+"""HIP-event timing of the short-contraction 1x1 layers (trunk expand convolutions at B = 4, T = 3: 72 images; BEV layers)
+on the streaming kernels (pointwise_rows_kernel / pointwise_direct_kernel, stp3_conv.hip) in the five epilogue modes; GB/s
+of the mode's own algorithmic traffic beside each time.  (The same table on the tiled kernel, from the round in which the
+library still had a switch between the two: profiles/r04p_time_pointwise.txt.)
 
-    python scripts/time_pointwise.py            # both settings, one child process each
+    python scripts/time_pointwise.py
 """
 import ctypes
 import os
-import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -66,10 +66,4 @@ def child():
 
 
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'child':
-        child()
-    else:
-        names = {'0': 'tiled kernel', '1': 'streaming kernels'}
-        for setting in ('0', '1'):
-            print(f'--- STP3_POINTWISE={setting} ({names[setting]})', flush=True)
-            subprocess.run([sys.executable, os.path.abspath(__file__), 'child'], env=dict(os.environ, STP3_POINTWISE=setting), check=False)
+    child()

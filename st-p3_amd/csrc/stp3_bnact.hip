@@ -686,8 +686,7 @@ inline int plan(const stp3_bn_dims* p, Launch* L, std::initializer_list<const vo
     const int ctiles = (CV + CVB - 1) / CVB;
     // at most one resident round (four in the full-occupancy geometry), at least 8 rows per row lane
     const int target = 256 * per_cu * (L->full ? 4 : 1);
-    static const bool round_up = getenv("STP3_GRID_CEIL") != nullptr;       // (experiment: the grids of rounds 2-3, ~1024 / 4096 blocks rounded up)
-    int bx = round_up ? ((L->full ? 4096 : 1024) + p->N * ctiles - 1) / (p->N * ctiles) : target / (p->N * ctiles);
+    int bx = target / (p->N * ctiles);
     const int max_bx = (p->rows + RL * 8 - 1) / (RL * 8);
     if (bx > max_bx) bx = max_bx;
     if (bx < 1) bx = 1;

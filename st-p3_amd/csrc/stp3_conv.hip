@@ -25,7 +25,6 @@
 //     pass over the convolution output disappears), one partial row per workgroup, reduced deterministically.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include <string.h>
 
 #include "stp3_cdna.h"
@@ -1215,25 +1214,14 @@ int pointwise_direct_launch_mode(int mode, const ConvDims& d, int ksteps, unsign
     }
 }
 
-// the streaming kernels for short-contraction pointwise layers (see pointwise_rows_kernel).  STP3_POINTWISE in the environment:
-// 0 keeps every layer on the tiled kernel (A/B measurements), 2 sends every qualifying layer here whatever its pixel count
-// (the small cases of the tests)
-int pointwise_setting() {
-    static const int v = [] {
-        const char* e = getenv("STP3_POINTWISE");
-        return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
-    }();
-    return v;
-}
-
 constexpr int kPointwiseMaxCin = 128;
-constexpr int kPointwiseMinPixels = 16384;
 
-bool pointwise_applies(const stp3_conv_dims* p, const void* y, int64_t M) {
-    return pointwise_setting() != 0 && p->KH == 1 && p->KW == 1 && p->stride == 1 && p->pad_h == 0 && p->pad_w == 0 &&
-           p->H == p->Ho && p->W == p->Wo && p->Cin <= kPointwiseMaxCin && p->Cout >= 64 && !p->has_bias &&
-           p->out_dtype == STP3_DTYPE_BF16 && p->Cout % 8 == 0 && p->ldy % 8 == 0 && !((uintptr_t)y & 15) &&
-           (M >= kPointwiseMinPixels || pointwise_setting() == 2);
+// the layers the streaming kernels take (see pointwise_rows_kernel): 1x1 / stride 1 / no padding, contraction <= 128, at
+// least 64 output channels in whole 16-byte pieces, bf16 output, no bias
+bool pointwise_applies(const stp3_conv_dims* p, const void* y) {
+    return p->KH == 1 && p->KW == 1 && p->stride == 1 && p->pad_h == 0 && p->pad_w == 0 && p->H == p->Ho && p->W == p->Wo &&
+           p->Cin <= kPointwiseMaxCin && p->Cout >= 64 && !p->has_bias && p->out_dtype == STP3_DTYPE_BF16 &&
+           p->Cout % 8 == 0 && p->ldy % 8 == 0 && !((uintptr_t)y & 15);
 }
 
 int pointwise_run(const ConvDims& d, const void* x, const void* w, void* y, float* sums, float* partial, unsigned gx,
@@ -1311,7 +1299,7 @@ int igemm_run(const stp3_conv_dims* p, const void* x, const void* w, const float
         partial = (float*)workspace;
     }
     if (y && ((uintptr_t)y & 15)) return STP3_EUNSUP;
-    if (pointwise_applies(p, y, M)) {
+    if (pointwise_applies(p, y)) {
         ep.act = act;
         return pointwise_run(d, x, w, y, sums, partial, gx, s, mode, ep);
     }
@@ -1409,8 +1397,7 @@ static int wgrad_plan(const stp3_conv_dims* p, int* tco_sz, int* tci_sz, int* ti
     // the ~1024 (rounded up) of rounds 2-3 were 2.004 rounds of 512 places for a 3x3 128 -> 128 layer: a third round for 2
     // workgroups (tests/test_kernel_resources_cpu.py pins the register budgets)
     const int per_cu = (*tco_sz == 128 && *tci_sz == 128) ? 2 : (*tco_sz == 128 || *tci_sz == 128) ? 3 : 5;
-    static const bool old_grids = getenv("STP3_GRID_CEIL") != nullptr;      // (experiment: the grids of rounds 2-3)
-    int64_t want = old_grids ? (1024 + base - 1) / base : (256 * per_cu) / base;
+    int64_t want = (256 * per_cu) / base;
     const int64_t max_splits = (total_steps + 7) / 8;        // at least 8 k-steps per workgroup
     if (want > max_splits) want = max_splits;
     if (want < 1) want = 1;

@@ -422,8 +422,7 @@ template <typename Kern>
 inline int resident_blocks(Kern kernel, size_t lds) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    static const bool old_grids = getenv("STP3_GRID_CEIL") != nullptr;      // (experiment: the grids of rounds 2-3)
-    return old_grids ? (1 << 30) : per_cu * 256;
+    return per_cu * 256;
 }
 
 inline int status() {

@@ -445,8 +445,7 @@ inline int mb_plan(const stp3_se_dims* p, int ldg, MbPlan* P, std::initializer_l
     int RL = 1;
     while (RL * 2 * CVB <= kT) RL *= 2;
     const int ctiles = (CV + CVB - 1) / CVB;
-    static const bool round_up = getenv("STP3_GRID_CEIL") != nullptr;       // (experiment: the old rounding)
-    int bx = round_up ? (2048 + p->N * ctiles - 1) / (p->N * ctiles) : (256 * per_cu * rounds) / (p->N * ctiles);
+    int bx = (256 * per_cu * rounds) / (p->N * ctiles);
     const int max_bx = (p->rows + RL * 8 - 1) / (RL * 8);
     if (bx > max_bx) bx = max_bx;
     if (bx < 1) bx = 1;

@@ -17,8 +17,6 @@ convs, and applies it unchanged to the 224x480 inputs used here.
 import math
 from types import SimpleNamespace
 
-import os
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -90,7 +88,7 @@ class StaticSamePadConv2d(nn.Conv2d):
 
 
 # expand convolution -> BN0 -> swish through ops_fused._PointwiseBnAct (the convolution output is recomputed, never stored)
-EXPAND_WITHOUT_E0 = os.environ.get('STP3_EXPAND_WITHOUT_E0', '1') != '0'    # (the environment switch: A/B measurements)
+EXPAND_WITHOUT_E0 = True
 
 
 class Swish(nn.Module):

@@ -836,8 +836,8 @@ def pointwise_bn(ops):
 
 
 def pointwise_stream(ops):
-    """The streaming kernel for short-contraction 1x1 convolutions (pointwise_kernel in stp3_conv.hip; this process runs with
-    STP3_POINTWISE=2: every qualifying layer takes it whatever its pixel count) in its five modes: the stored route
+    """The streaming kernels for short-contraction 1x1 convolutions (pointwise_rows_kernel / pointwise_direct_kernel in
+    stp3_conv.hip: every 1x1 / stride-1 layer with <= 128 input and >= 64 output channels) in their five modes: the stored route
     (conv + statistics -> BatchNorm -> act, data gradient of the NEXT layer's shape) and the recomputing route against
     float32 torch on the same bf16-representable data.  Shapes: ragged pixel counts (last 32-pixel tile partial), Cin that is
     no multiple of 16 (zero k tail), both channel-tile widths with a ragged last tile."""
@@ -845,7 +845,6 @@ def pointwise_stream(ops):
     import torch.nn.functional as F
     from stp3_amd import ops_fused
     from stp3_amd.layers import fused
-    assert os.environ.get('STP3_POINTWISE') in ('0', '2')
     out = {}
     cl = torch.channels_last
     for name, (n, cin, cout, h, w, act) in {'24_144': (3, 24, 144, 9, 11, ops.ACT_SWISH), '32_192': (1, 32, 192, 11, 13, ops.ACT_SWISH),
@@ -1341,8 +1340,6 @@ CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_rank
                                  conv, conv_f32, fan_out, aspp_join, pointwise_bn, pointwise_stream, decoder_heads, dwconv, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
 
 if __name__ == '__main__':
-    if sys.argv[2] == 'pointwise_stream':
-        os.environ.setdefault('STP3_POINTWISE', '2')    # read once by the library (stp3_conv.hip: pointwise_setting); 0: the tiled kernel on the same cases
     ops_mod = setup(sys.argv[1])
     t0 = time.time()
     result = CASES[sys.argv[2]](ops_mod)
