@@ -55,7 +55,7 @@ def main():
     try:
         commit = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], text=True).strip()
     except Exception:
-        commit = None
+        commit = os.environ.get('STP3_COMMIT')              # (the GPU box has no .git: the caller passes the commit of the snapshot)
     res = {'frames_per_launch': 12, 'commit': commit, 'calibration': {'true_bytes_each_way': CAL_BYTES, 'fetch_correction': fc,
                                                                        'write_correction': wc}}
     res.update(out)
