@@ -4,7 +4,7 @@ For every kernel of interest: mean per dispatch of each counter (summed over the
 from the kernel trace of the first pass.  FETCH_SIZE / WRITE_SIZE are in KiB; the calibration stream (torch.add over
 256 MiB, known bytes) gives the correction factors for this access width on gfx950 (MI355X_MICROARCH.md section HBM:
 FETCH_SIZE reads 1/2 of a wide coalesced stream), which are applied to give hbm_read_bytes / hbm_write_bytes."""
-import glob, json, subprocess, sys
+import glob, json, os, subprocess, sys
 import pandas as pd
 
 CAL_BYTES = (64 << 20) * 4
