@@ -42,9 +42,10 @@ def test_kernel_register_lds_and_scratch_budgets():
         for k in by_name[name]:
             assert k['vgpr'] + k['agpr'] <= budget, k
     # the MFMA convolutions: accumulators in AGPRs, at least 2 workgroups of 256 threads per CU
-    for name in ('void conv2d_igemm_kernel<128, 0, 0>', 'void conv2d_wgrad_kernel<128, 128>'):
-        assert name in by_name, name
-        for k in by_name[name]:
+    for prefix in ('void conv2d_igemm_kernel<128, 0, 0>', 'void conv2d_wgrad_kernel<128, 128>'):
+        found = [k for n, ks in by_name.items() if n.startswith(prefix) for k in ks]
+        assert found, prefix
+        for k in found:
             assert k['agpr'] == 64 and k['vgpr'] + k['agpr'] <= 256, k
     # The grids of the streaming kernels are sized to ONE resident round of the chip (256 CUs x the workgroups a CU keeps):
     # the launchers carry these numbers as constants (plan() in stp3_bnact.hip, mb_plan() in stp3_mbconv.hip, wgrad_plan() in
