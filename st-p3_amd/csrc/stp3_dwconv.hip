@@ -131,47 +131,95 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwDims d, const T* __re
 }
 
 // ---- data gradient: dx[n,hi,wi,c] = sum_{kh,kw : (hi+pt-kh) = ho*S, (wi+pl-kw) = wo*S} dy[n,ho,wo,c] w[kh,kw,c]
-template <typename T, int K, int S>
-__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(DwDims d, const T* __restrict__ dy,
-                                                              const float* __restrict__ w, T* __restrict__ dx) {
+// Stride 1: the forward kernel on dy with flipped taps (launch_bwd_data).  STRIDE 2, one thread per 2 x 2 input quad.
+// With a thread per input pixel (rounds 1-3) the taps that reach a pixel depend on the parity of its row and column
+// (1, 2 or 4 of the 9 taps of a 3x3 kernel), so the lanes of a wave -- a few neighbouring pixels x all channel vectors --
+// walked through all nine tap branches under masks, each with its own gradient and weight loads (27 vector loads compiled,
+// 1.7 TB/s on the 532-MiB gradient of the first stride-2 block).  A 2 x 2 quad of input pixels (rows 2a - pt, 2a + 1 - pt)
+// sees every tap exactly once and reads the same R x R gradient pixels (R = (K + 1) / 2: rows a - R + 1 .. a): no
+// divergence, R * R gradient loads for four outputs.  Persistent threads with a fixed channel vector: a 3x3 kernel keeps its
+// 9 x 8 weights in registers (5x5: read per tap, L1-resident).
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dwconv_bwd_data_s2_kernel(DwDims d, int qrows, int qcols, const T* __restrict__ dy,
+                                                                 const float* __restrict__ w, T* __restrict__ dx) {
     constexpr int VN = Vec<T>::N;
+    constexpr int R = (K + 1) / 2;
+    constexpr bool kRegW = K == 3;
     const int CV = d.C / VN;
-    const int64_t total = (int64_t)d.N * d.H * d.W * CV;
-    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (tid >= total) return;
-    const int cv = (int)(tid % CV);
-    int64_t r = tid / CV;
-    const int wi = (int)(r % d.W);
-    r /= d.W;
-    const int hi = (int)(r % d.H);
-    const int n = (int)(r / d.H);
+    const int CVB = min(CV, 256);
+    const int QL = 256 / CVB;                         // quads per workgroup pass
+    const int cv = blockIdx.y * CVB + threadIdx.x % CVB, ql = threadIdx.x / CVB;
+    if (ql >= QL || cv >= CV) return;
     const int c0 = cv * VN;
-    float acc[VN];
+    float wr[kRegW ? K * K : 1][VN];
+    if (kRegW) {
 #pragma unroll
-    for (int j = 0; j < VN; ++j) acc[j] = 0.f;
+        for (int t = 0; t < K * K; ++t)
 #pragma unroll
-    for (int kh = 0; kh < K; ++kh) {
-        const int th = hi + d.pad_t - kh;
-        if (th < 0 || (S > 1 && (th % S) != 0)) continue;
-        const int ho = th / S;
-        if (ho >= d.Ho) continue;
+            for (int j = 0; j < VN; ++j) wr[t][j] = w[t * d.C + c0 + j];
+    }
+    const int a0 = d.pad_t >> 1, b0 = d.pad_l >> 1;   // quad row / column of input row / column 0
+    const int64_t total = (int64_t)d.N * qrows * qcols;
+    for (int64_t q = (int64_t)blockIdx.x * QL + ql; q < total; q += (int64_t)gridDim.x * QL) {
+        const int bi = (int)(q % qcols);
+        int64_t r = q / qcols;
+        const int ai = (int)(r % qrows);
+        const int n = (int)(r / qrows);
+        const int a = a0 + ai, b = b0 + bi;
+        float acc[2][2][VN];
 #pragma unroll
-        for (int kw = 0; kw < K; ++kw) {
-            const int tw = wi + d.pad_l - kw;
-            if (tw < 0 || (S > 1 && (tw % S) != 0)) continue;
-            const int wo = tw / S;
-            if (wo >= d.Wo) continue;
-            Vec<T> v;
-            v.load(dy + ((int64_t)(n * d.Ho + ho) * d.Wo + wo) * d.C + c0);
-            float g[VN];
-            v.to_float(g);
+        for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-            for (int j = 0; j < VN; ++j) acc[j] = fmaf(g[j], w[(kh * K + kw) * d.C + c0 + j], acc[j]);
+            for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+                for (int j = 0; j < VN; ++j) acc[pr][pc][j] = 0.f;
+#pragma unroll
+        for (int dr = 0; dr < R; ++dr) {
+            const int ho = a - dr;
+            if (ho < 0 || ho >= d.Ho) continue;
+#pragma unroll
+            for (int dc = 0; dc < R; ++dc) {
+                const int wo = b - dc;
+                if (wo < 0 || wo >= d.Wo) continue;
+                Vec<T> v;
+                v.load(dy + ((int64_t)(n * d.Ho + ho) * d.Wo + wo) * d.C + c0);
+                float g[VN];
+                v.to_float(g);
+                // input row 2a + pr - pt takes the taps kh = 2 dr + pr, column 2b + pc - pl the taps kw = 2 dc + pc
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int kh = 2 * dr + pr;
+                    if (kh >= K) continue;
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        const int kw = 2 * dc + pc;
+                        if (kw >= K) continue;
+                        if (kRegW) {
+#pragma unroll
+                            for (int j = 0; j < VN; ++j) acc[pr][pc][j] = fmaf(g[j], wr[kh * K + kw][j], acc[pr][pc][j]);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < VN; ++j)
+                                acc[pr][pc][j] = fmaf(g[j], w[(kh * K + kw) * d.C + c0 + j], acc[pr][pc][j]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int hi = 2 * a + pr - d.pad_t;
+            if (hi < 0 || hi >= d.H) continue;
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                const int wi = 2 * b + pc - d.pad_l;
+                if (wi < 0 || wi >= d.W) continue;
+                Vec<T> o;
+                o.from_float(acc[pr][pc]);
+                o.store(dx + ((int64_t)(n * d.H + hi) * d.W + wi) * d.C + c0);
+            }
         }
     }
-    Vec<T> o;
-    o.from_float(acc);
-    o.store(dx + ((int64_t)(n * d.H + hi) * d.W + wi) * d.C + c0);
 }
 
 // ---- weight gradient: dw[kh,kw,c] = sum_{n,ho,wo} dy[n,ho,wo,c] * x[n,ho*S+kh-pt,wo*S+kw-pl,c] ---
@@ -482,11 +530,23 @@ int launch_bwd_data(const DwDims& d, const void* dy, const float* w, void* dx, h
         hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, 1, TW, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, f,
                            (const T*)dy, w, (T*)dx);
         return status();
-    } else {
-        const int64_t total = (int64_t)d.N * d.H * d.W * (d.C / Vec<T>::N);
-        hipLaunchKernelGGL((dwconv_bwd_data_kernel<T, K, S>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d,
-                           (const T*)dy, w, (T*)dx);
+    } else if constexpr (S == 2) {
+        // quads: rows 2a - pt, 2a + 1 - pt for a = pt / 2 .. (H - 1 + pt) / 2
+        const int qrows = ((d.H - 1 + d.pad_t) >> 1) - (d.pad_t >> 1) + 1;
+        const int qcols = ((d.W - 1 + d.pad_l) >> 1) - (d.pad_l >> 1) + 1;
+        const int CV = d.C / Vec<T>::N;
+        const int CVB = CV < 256 ? CV : 256;
+        const int QL = 256 / CVB;
+        const int by = (CV + CVB - 1) / CVB;
+        const int64_t want = ((int64_t)d.N * qrows * qcols + QL - 1) / QL;
+        int cap = resident_blocks(dwconv_bwd_data_s2_kernel<T, K>, 0) / by;            // one resident round
+        if (cap < 1) cap = 1;
+        const int bx = (int)(want < cap ? want : cap);
+        hipLaunchKernelGGL((dwconv_bwd_data_s2_kernel<T, K>), dim3(bx, by), dim3(256), 0, s, d, qrows, qcols, (const T*)dy, w,
+                           (T*)dx);
         return status();
+    } else {
+        return STP3_EUNSUP;                                            // (the entry point admits strides 1 and 2 only)
     }
 }
 template <typename T, int K, int S>
