@@ -182,7 +182,10 @@ class Decoder(nn.Module):
         if self.planning:
             heads.append(('costvolume', self.costvolume_head, next(xs)))
         others = [(name, head, inp) for name, head, inp in heads if name == 'hdmap']
-        merged = self._merged_heads([(name, head) for name, head, inp in heads if name != 'hdmap'], x, others) if MERGE_HEADS else None
+        # (the merged operator reads x through ONE of the fan-out handles, so that its input gradient and the hd-map head's meet
+        # in the single-pass sum of ops.fan_out instead of a strided copy + an addition by the autograd engine)
+        x_merged = next((inp for name, _, inp in heads if name != 'hdmap'), x)
+        merged = self._merged_heads([(name, head) for name, head, inp in heads if name != 'hdmap'], x_merged, others) if MERGE_HEADS else None
         if merged is not None:
             # (the handles of ops.fan_out that the merged heads did not take are simply dropped: no gradient arrives there)
             out = merged
