@@ -22,6 +22,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=4)
     ap.add_argument('--top', type=int, default=70)
+    ap.add_argument('--by-time', action='store_true', help='sort by device time instead of launches')
+    ap.add_argument('--aten-only', action='store_true', help='torch operators only (not the custom autograd functions)')
     a = ap.parse_args()
     from stp3_amd.parallel import FlatAdam, GradientBuckets
     device = torch.device('cuda', 0)
@@ -47,6 +49,8 @@ def main():
     groups = collections.defaultdict(lambda: [0, 0.0, set()])
     for ev in prof.events():
         if not ev.kernels or ev.cpu_parent is not None and ev.cpu_parent.kernels:
+            continue
+        if a.aten_only and not ev.name.startswith('aten::'):
             continue                                     # leaf-most operator that owns the kernels only
         where = '?'
         for fr in ev.stack or []:
@@ -62,7 +66,7 @@ def main():
         g[0] += len(ev.kernels)
         g[1] += sum(k.duration for k in ev.kernels)
         g[2].add(str(ev.input_shapes)[:80])
-    rows = sorted(groups.items(), key=lambda kv: -kv[1][0])
+    rows = sorted(groups.items(), key=lambda kv: -(kv[1][1] if a.by_time else kv[1][0]))
     total = sum(v[0] for v in groups.values())
     print(f'{total} kernel launches from aten operators in one step')
     for (name, where), (n, us, shapes) in rows[:a.top]:

@@ -880,6 +880,9 @@ class _FanOut(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n):
         ctx.n = n
+        # a handle nobody consumed hands back None, not a zero tensor (which would be filled, and -- contiguous where the real
+        # gradients are channels-last -- push the whole sum onto strided pairwise additions: 5 x 73 us in the decoder)
+        ctx.set_materialize_grads(False)
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
