@@ -67,3 +67,13 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 // nothing: the results are rounded to bf16 or compared at 1e-4
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + __expf(-x)); }
+// The same for two values in a register pair: gfx950 issues float32 multiply / add / fma for TWO lanes' worth of data in one
+// instruction (v_pk_mul_f32, v_pk_add_f32, v_pk_fma_f32); the exponential and the reciprocal stay one instruction per value.
+// Bit-identical to fast_sigmoid: x * (-log2 e) [0xbfb8aa3b] -> v_exp_f32 -> + 1 -> v_rcp_f32.
+__device__ __forceinline__ stp3_f32x2 pk_fma(stp3_f32x2 a, stp3_f32x2 b, stp3_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ stp3_f32x2 pk_sigmoid(stp3_f32x2 x) {
+    const stp3_f32x2 t = x * __builtin_bit_cast(float, 0xbfb8aa3bu);
+    stp3_f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    e = e + 1.0f;
+    return stp3_f32x2{fast_rcp(e.x), fast_rcp(e.y)};
+}

@@ -432,6 +432,76 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
     }
 }
 
+// ---- the epilogue of the streaming kernels on 8 channels of one pixel, TWO values per instruction ---------------------------
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: the BatchNorm + swish passes of these kernels are co-limited by their vector
+// instructions at 2-3 waves per SIMD; the packed forms halve everything but the exponential and the reciprocal.  Same
+// operations in the same order as the scalar statements of the tiled kernel: same bits.)
+struct Chan8 {
+    stp3_f32x2 cs[4], ct[4], mu[4], is[4], a2[4], a3[4];
+};
+
+template <int MODE>
+__device__ __forceinline__ void load_chan8(Chan8& k, const EpiArgs& ep, int Cout, int c, bool ok) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            k.cs[r][h] = k.ct[r][h] = k.mu[r][h] = k.is[r][h] = k.a2[r][h] = k.a3[r][h] = 0.f;
+            if (MODE >= kModeBnAct && ok) {
+                const int cc = c + 2 * r + h;
+                k.cs[r][h] = ep.coef[cc];
+                k.ct[r][h] = ep.coef[Cout + cc];
+                k.mu[r][h] = ep.coef[2 * Cout + cc];
+                k.is[r][h] = ep.coef[3 * Cout + cc];
+                if (MODE == kModeBwdApply) {
+                    const float k0 = ep.gsums[cc] * ep.inv_count, k1 = ep.gsums[Cout + cc] * ep.inv_count;
+                    k.a2[r][h] = -(k.cs[r][h] * k.is[r][h]) * k1;
+                    k.a3[r][h] = -k.cs[r][h] * k0 - k.a2[r][h] * k.mu[r][h];
+                }
+            }
+        }
+}
+
+// wds: the 8 rounded outputs (bf16 pairs); gds: the 8 incoming gradients (BWD_* modes); s1 / s2: the running sums (PLAIN /
+// STATS: sum, sum of squares; BWD_REDUCE: sum g, sum g * xhat); ow: the 8 results as bf16 pairs (BNACT / BWD_APPLY)
+template <int MODE>
+__device__ __forceinline__ void epi8(const uint32_t (&wds)[4], const uint32_t (&gds)[4], const Chan8& k, int act,
+                                     stp3_f32x2 (&s1)[4], stp3_f32x2 (&s2)[4], uint32_t (&ow)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const stp3_f32x2 e0 = {__uint_as_float(wds[r] << 16), __uint_as_float(wds[r] & 0xffff0000u)};
+        if (MODE == kModePlain || MODE == kModeStats) {
+            s1[r] = s1[r] + e0;
+            s2[r] = pk_fma(e0, e0, s2[r]);
+        } else {
+            const stp3_f32x2 pre = pk_fma(e0, k.cs[r], k.ct[r]);
+            if (MODE == kModeBnAct) {
+                stp3_f32x2 out = pre;
+                if (act == STP3_ACT_SWISH) out = pre * pk_sigmoid(pre);
+                else if (act == STP3_ACT_RELU) out = stp3_f32x2{fmaxf(pre.x, 0.f), fmaxf(pre.y, 0.f)};
+                ow[r] = pack_bf16(out.x, out.y);
+            } else {
+                const stp3_f32x2 dz = {__uint_as_float(gds[r] << 16), __uint_as_float(gds[r] & 0xffff0000u)};
+                stp3_f32x2 der = {1.f, 1.f};
+                if (act == STP3_ACT_SWISH) {
+                    const stp3_f32x2 sg = pk_sigmoid(pre);
+                    der = sg * (1.f + pre * (1.f - sg));
+                } else if (act == STP3_ACT_RELU) {
+                    der = stp3_f32x2{pre.x > 0.f ? 1.f : 0.f, pre.y > 0.f ? 1.f : 0.f};
+                }
+                const stp3_f32x2 gg = dz * der;
+                if (MODE == kModeBwdReduce) {
+                    s1[r] = s1[r] + gg;
+                    s2[r] = pk_fma(gg, (e0 - k.mu[r]) * k.is[r], s2[r]);
+                } else {
+                    const stp3_f32x2 out = pk_fma(k.cs[r], gg, pk_fma(k.a2[r], e0, k.a3[r]));
+                    ow[r] = pack_bf16(out.x, out.y);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Pointwise (1x1, stride 1) convolutions with a SHORT contraction (Cin <= 128): the expand convolutions of the MBConv blocks
 // and the data gradients of their project convolutions -- 24..112 channels in, 6x as many out, activations of 40..560 MB.
@@ -480,23 +550,11 @@ __global__ __launch_bounds__(256, 2) void pointwise_rows_kernel(ConvDims d, int 
     const int cp = lane % PP, prow = lane / PP;
     const bool lane_ok = prow < RPI;
     const int cl = cp * 8, cch = co0 + cl;                 // this lane's 8 channels in the store passes: in the tile, in the tensor
-    float cs[8], ct[8], a2[8], a3[8], mu[8], is[8], s1[8], s2[8];
+    Chan8 kc;
+    load_chan8<MODE>(kc, ep, d.Cout, cch, true);
+    stp3_f32x2 s1[4], s2[4];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        cs[r] = ct[r] = a2[r] = a3[r] = mu[r] = is[r] = 0.f;
-        s1[r] = s2[r] = 0.f;
-        if (MODE >= kModeBnAct) {
-            cs[r] = ep.coef[cch + r];
-            ct[r] = ep.coef[d.Cout + cch + r];
-            mu[r] = ep.coef[2 * d.Cout + cch + r];
-            is[r] = ep.coef[3 * d.Cout + cch + r];
-            if (MODE == kModeBwdApply) {
-                const float k0 = ep.gsums[cch + r] * ep.inv_count, k1 = ep.gsums[d.Cout + cch + r] * ep.inv_count;
-                a2[r] = -(cs[r] * is[r]) * k1;
-                a3[r] = -cs[r] * k0 - a2[r] * mu[r];
-            }
-        }
-    }
+    for (int r = 0; r < 4; ++r) s1[r] = s2[r] = stp3_f32x2{0.f, 0.f};
     const uint16_t* const zero = reinterpret_cast<const uint16_t*>(&g_zero16);
     u32x4 cur[KMAX], nxt[KMAX];
     const int ntiles = (d.M + 31) / 32;
@@ -552,51 +610,14 @@ __global__ __launch_bounds__(256, 2) void pointwise_rows_kernel(ConvDims d, int 
                 if (MODE == kModePlain) *reinterpret_cast<uint4*>(y + (size_t)m * d.ldy + cch) = v;
                 if (MODE != kModePlain || stat_partial) {
                     const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
-                    float e0[8], out[8];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        e0[2 * r] = __uint_as_float(wds[r] << 16);
-                        e0[2 * r + 1] = __uint_as_float(wds[r] & 0xffff0000u);
-                    }
-                    if (MODE == kModePlain || MODE == kModeStats) {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            s1[r] += e0[r];
-                            s2[r] = fmaf(e0[r], e0[r], s2[r]);
-                        }
-                    } else if (MODE == kModeBnAct) {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            const float pre = fmaf(e0[r], cs[r], ct[r]);
-                            out[r] = ep.act == STP3_ACT_SWISH ? pre * fast_sigmoid(pre) : (ep.act == STP3_ACT_RELU ? fmaxf(pre, 0.f) : pre);
-                        }
-                    } else {
+                    uint32_t gds[4] = {0u, 0u, 0u, 0u}, ow[4];
+                    if (MODE >= kModeBwdReduce) {
                         const uint4 g = *reinterpret_cast<const uint4*>(ep.dz + (size_t)m * ep.ldz + cch);
-                        const uint32_t gds[4] = {g.x, g.y, g.z, g.w};
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            const float dzv = __uint_as_float((r & 1) ? (gds[r >> 1] & 0xffff0000u) : (gds[r >> 1] << 16));
-                            const float pre = fmaf(e0[r], cs[r], ct[r]);
-                            float der = 1.f;
-                            if (ep.act == STP3_ACT_SWISH) {
-                                const float sg = fast_sigmoid(pre);
-                                der = sg * (1.f + pre * (1.f - sg));
-                            } else if (ep.act == STP3_ACT_RELU) {
-                                der = pre > 0.f ? 1.f : 0.f;
-                            }
-                            const float gg = dzv * der;
-                            if (MODE == kModeBwdReduce) {
-                                s1[r] += gg;
-                                s2[r] = fmaf(gg, (e0[r] - mu[r]) * is[r], s2[r]);
-                            } else {
-                                out[r] = fmaf(cs[r], gg, fmaf(a2[r], e0[r], a3[r]));
-                            }
-                        }
+                        gds[0] = g.x; gds[1] = g.y; gds[2] = g.z; gds[3] = g.w;
                     }
+                    epi8<MODE>(wds, gds, kc, ep.act, s1, s2, ow);
                     if (MODE == kModeBnAct || MODE == kModeBwdApply)
-                        *reinterpret_cast<uint4*>(y + (size_t)m * d.ldy + cch) =
-                            make_uint4(pack_bf16(out[0], out[1]), pack_bf16(out[2], out[3]), pack_bf16(out[4], out[5]),
-                                       pack_bf16(out[6], out[7]));
+                        *reinterpret_cast<uint4*>(y + (size_t)m * d.ldy + cch) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
                 }
             }
         }
@@ -609,8 +630,8 @@ __global__ __launch_bounds__(256, 2) void pointwise_rows_kernel(ConvDims d, int 
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            red[(wave * 64 + lane) * 16 + r] = s1[r];
-            red[(wave * 64 + lane) * 16 + 8 + r] = s2[r];
+            red[(wave * 64 + lane) * 16 + r] = s1[r >> 1][r & 1];
+            red[(wave * 64 + lane) * 16 + 8 + r] = s2[r >> 1][r & 1];
         }
         __syncthreads();
         for (int e = tid; e < 2 * PP * 8; e += 256) {
@@ -662,28 +683,15 @@ __global__ __launch_bounds__(256) void pointwise_direct_kernel(ConvDims d, int k
     // ---- this lane's two channel pieces and their constants
     int ch[2];
     bool ok[2];
-    float cs[2][8], ct[2][8], mu[2][8], is[2][8], a2[2][8], a3[2][8], s1[2][8], s2[2][8];
+    Chan8 kc[2];
+    stp3_f32x2 s1[2][4], s2[2][4];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         ch[s] = cb * 32 + 16 * s + 8 * h;
         ok[s] = live && ch[s] < d.Cout;
+        load_chan8<MODE>(kc[s], ep, d.Cout, ch[s], ok[s]);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            cs[s][r] = ct[s][r] = mu[s][r] = is[s][r] = a2[s][r] = a3[s][r] = 0.f;
-            s1[s][r] = s2[s][r] = 0.f;
-            if (MODE >= kModeBnAct && ok[s]) {
-                const int c = ch[s] + r;
-                cs[s][r] = ep.coef[c];
-                ct[s][r] = ep.coef[d.Cout + c];
-                mu[s][r] = ep.coef[2 * d.Cout + c];
-                is[s][r] = ep.coef[3 * d.Cout + c];
-                if (MODE == kModeBwdApply) {
-                    const float k0 = ep.gsums[c] * ep.inv_count, k1 = ep.gsums[d.Cout + c] * ep.inv_count;
-                    a2[s][r] = -(cs[s][r] * is[s][r]) * k1;
-                    a3[s][r] = -cs[s][r] * k0 - a2[s][r] * mu[s][r];
-                }
-            }
-        }
+        for (int r = 0; r < 4; ++r) s1[s][r] = s2[s][r] = stp3_f32x2{0.f, 0.f};
     }
     const int ntiles = (d.M + 31) / 32;
     u32x4 cur[KMAX], nxt[KMAX];
@@ -726,55 +734,16 @@ __global__ __launch_bounds__(256) void pointwise_direct_kernel(ConvDims d, int k
             // the rounded outputs (what the stored tensor holds) and their float32 values
             const uint32_t wds[4] = {pack_bf16(acc[8 * s], acc[8 * s + 1]), pack_bf16(acc[8 * s + 2], acc[8 * s + 3]),
                                      pack_bf16(acc[8 * s + 4], acc[8 * s + 5]), pack_bf16(acc[8 * s + 6], acc[8 * s + 7])};
-            float e0[8], out[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                e0[2 * r] = __uint_as_float(wds[r] << 16);
-                e0[2 * r + 1] = __uint_as_float(wds[r] & 0xffff0000u);
-            }
             if (!(row_ok && ok[s])) continue;
             if (MODE == kModePlain) {
                 *reinterpret_cast<uint4*>(y + (size_t)m * d.ldy + ch[s]) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
                 if (!stat_partial) continue;
             }
-            if (MODE == kModePlain || MODE == kModeStats) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    s1[s][r] += e0[r];
-                    s2[s][r] = fmaf(e0[r], e0[r], s2[s][r]);
-                }
-            } else if (MODE == kModeBnAct) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const float pre = fmaf(e0[r], cs[s][r], ct[s][r]);
-                    out[r] = ep.act == STP3_ACT_SWISH ? pre * fast_sigmoid(pre) : (ep.act == STP3_ACT_RELU ? fmaxf(pre, 0.f) : pre);
-                }
-            } else {
-                const uint32_t gds[4] = {g[s].x, g[s].y, g[s].z, g[s].w};
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const float dzv = __uint_as_float((r & 1) ? (gds[r >> 1] & 0xffff0000u) : (gds[r >> 1] << 16));
-                    const float pre = fmaf(e0[r], cs[s][r], ct[s][r]);
-                    float der = 1.f;
-                    if (ep.act == STP3_ACT_SWISH) {
-                        const float sg = fast_sigmoid(pre);
-                        der = sg * (1.f + pre * (1.f - sg));
-                    } else if (ep.act == STP3_ACT_RELU) {
-                        der = pre > 0.f ? 1.f : 0.f;
-                    }
-                    const float gg = dzv * der;
-                    if (MODE == kModeBwdReduce) {
-                        s1[s][r] += gg;
-                        s2[s][r] = fmaf(gg, (e0[r] - mu[s][r]) * is[s][r], s2[s][r]);
-                    } else {
-                        out[r] = fmaf(cs[s][r], gg, fmaf(a2[s][r], e0[r], a3[s][r]));
-                    }
-                }
-            }
+            const uint32_t gds[4] = {g[s].x, g[s].y, g[s].z, g[s].w};
+            uint32_t ow[4];
+            epi8<MODE>(wds, gds, kc[s], ep.act, s1[s], s2[s], ow);
             if (MODE == kModeBnAct || MODE == kModeBwdApply)
-                *reinterpret_cast<uint4*>(y + (size_t)m * d.ldy + ch[s]) =
-                    make_uint4(pack_bf16(out[0], out[1]), pack_bf16(out[2], out[3]), pack_bf16(out[4], out[5]),
-                               pack_bf16(out[6], out[7]));
+                *reinterpret_cast<uint4*>(y + (size_t)m * d.ldy + ch[s]) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         }
 #pragma unroll
         for (int ks = 0; ks < KMAX; ++ks) cur[ks] = nxt[ks];
@@ -788,8 +757,8 @@ __global__ __launch_bounds__(256) void pointwise_direct_kernel(ConvDims d, int k
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                mine[s * 8 + r] = s1[s][r];
-                mine[16 + s * 8 + r] = s2[s][r];
+                mine[s * 8 + r] = s1[s][r >> 1][r & 1];
+                mine[16 + s * 8 + r] = s2[s][r >> 1][r & 1];
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -62,3 +62,6 @@ inline uint32_t pack_bf16(float lo, float hi) {
 }
 inline float fast_rcp(float x) { return 1.0f / x; }
 inline float fast_sigmoid(float x) { return 1.0f / (1.0f + std::exp(-x)); }
+typedef float stp3_f32x2 __attribute__((ext_vector_type(2)));
+inline stp3_f32x2 pk_fma(stp3_f32x2 a, stp3_f32x2 b, stp3_f32x2 c) { return stp3_f32x2{std::fma(a.x, b.x, c.x), std::fma(a.y, b.y, c.y)}; }
+inline stp3_f32x2 pk_sigmoid(stp3_f32x2 x) { return stp3_f32x2{fast_sigmoid(x.x), fast_sigmoid(x.y)}; }
