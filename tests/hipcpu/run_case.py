@@ -510,6 +510,15 @@ def fan_out(ops):
             pair = pair + w                                            # what autograd does: pairwise, rounding every time
         out[name] = {'err': rel(x.grad.double(), exact), 'pairwise_err': rel(pair.double(), exact),
                      'layout': list(x.grad.stride()) == list(x.stride()), 'dtype': str(x.grad.dtype)}
+    # handles nobody consumed (the decoder hands out one per head and its merged operator takes a single one): they come
+    # back as None, not as zero tensors -- the sum is that of the consumed ones, in one pass, in the tensor's layout
+    x = torch.randn(2, 16, 4, 6).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+    ws = [torch.randn(2, 16, 4, 6).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(2)]
+    handles = ops.fan_out(x, 7)
+    ((handles[1] * ws[0]).sum() + (handles[5] * ws[1]).sum()).backward()
+    exact = ws[0].double() + ws[1].double()
+    out['bf16_unused_handles'] = {'err': rel(x.grad.double(), exact), 'pairwise_err': rel((ws[0] + ws[1]).double(), exact),
+                                  'layout': list(x.grad.stride()) == list(x.stride()), 'dtype': str(x.grad.dtype)}
     return out
 
 
