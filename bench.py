@@ -206,7 +206,8 @@ def _cpu_baseline_worker(workload='c3'):
                       'sample': f'B=1 (1 sample = 6 cams x 3 frames) full fwd+bwd+clip+Adam step ({workload} losses), fp32, '
                                 f'1 warm-up + median of 3 at {best} of {cores} host threads (swept {counts}); lift = '
                                 f'reference algorithm (outer product, argsort, cumsum VoxelsSumming); B=1 not 4: the '
-                                f'bounded-sample rule (~30 s of CPU work)'}))
+                                f'bounded-sample rule (~30 s of CPU work); measured once at B=4 on the same host: 55.0 s per step = 0.0727 '
+                                f'samples/s, 0.59x the B=1 per-sample rate (profiles/r04_cpu_baseline_b4.json)'}))
 
 
 def cpu_baseline(workload='c3', timeout_s=300.0):
