@@ -13,7 +13,8 @@ synthetic c3 batch, and records for each variant
     the 6 decoder heads): 512-sample fingerprints + norms of its input, its output and the gradient arriving at its
     output (forward hooks + ``retain_grad`` -- tests/helpers.BlockTaps, the same code the GPU test runs on the product).
 
-Variants: ``[c5]b<B>k<0|1>[d|D]`` (``D``: float64, FORWARD only) = (``c5``: BASELINE configs[4] geometry on a one-camera rig, see C5_GEOMETRY) batch size B, top-k selection of the segmentation losses off / on
+Variants: ``[t1][c5]b<B>k<0|1>[d|D]`` (``D``: float64, FORWARD only) = (``t1``: BASELINE configs[0], one frame and the identity
+temporal model; ``c5``: BASELINE configs[4] geometry on a one-camera rig, see C5_GEOMETRY) batch size B, top-k selection of the segmentation losses off / on
 (SEMANTIC_SEG.*.USE_TOP_K, stp3/losses.py:43-76), ``d`` = the reference evaluated in FLOAT64.  ``b4k1`` IS configs[2],
 reference unmodified, float32.
 
@@ -117,8 +118,17 @@ C5_GEOMETRY = {'IMAGE.FINAL_DIM': (896, 1600), 'LIFT.X_BOUND': [-50.0, 50.0, 0.2
 C5_BATCH = dict(n_cams=1, final_dim=(896, 1600), bev=(400, 400))
 
 
+# BASELINE configs[0]: T = 1, i.e. the IDENTITY temporal model (stp3/models/stp3.py:34-35, 56-57: with a receptive field of one
+# frame the configuration must name 'identity'; TemporalModelIdentity hands the 64 + 6 ego-motion channels of the present
+# frame to the decoder) -- the path on which the 70-channel concatenation really exists.
+T1 = {'TIME_RECEPTIVE_FIELD': 1, 'MODEL.TEMPORAL_MODEL.NAME': 'identity'}
+
+
 def variant_cfg(variant):
     variant = variant.rstrip('dD')
+    t1 = variant.startswith('t1')
+    if t1:
+        variant = variant[2:]
     c5 = variant.startswith('c5')
     body = variant[2:] if c5 else variant
     batch, topk = int(body[1:body.index('k')]), body.endswith('k1')
@@ -127,6 +137,8 @@ def variant_cfg(variant):
         over.update(NO_TOPK)
     if c5:
         over.update(C5_GEOMETRY)
+    if t1:
+        over.update(T1)
     return batch, over
 
 
@@ -141,8 +153,8 @@ def run_variant(variant, TrainingModule):
     restore = to_float64(ref) if f64 else (lambda: None)
     heads = [f'decoder.{a}' for a in H.DECODER_HEADS.values()]
     taps = H.BlockTaps(ref.model, extra=heads, forward_only=forward_only)
-    batch = synthetic.make_batch(batch=batch_size, seq=3, seed=5, gt_depth=True, instance=True,
-                                 **(C5_BATCH if variant.startswith('c5') else {}))
+    batch = synthetic.make_batch(batch=batch_size, seq=1 if variant.startswith('t1') else 3, seed=5, gt_depth=True, instance=True,
+                                 **(C5_BATCH if 'c5' in variant[:4] else {}))
     if f64:
         batch['image'] = batch['image'].double()
     # the pixels the reference's top-k losses SELECT (losses.py:76-81, :108-111: a descending sort, the first k kept):

@@ -38,7 +38,7 @@ def rel(a, ref):
     return ((a - r).norm() / r.norm().clamp_min(1e-30)).item()
 
 
-def product_step_float64(batch_size=2):
+def product_step_float64(batch_size=2, extra_cfg=None, seq=3):
     """The product's TrainingModule on the CPU in float64 (geometry constants and poses stay float32: voxel ids are
     float32 arithmetic by contract), with the taps of tests/helpers.BlockTaps."""
     from oracle.cpu_model import CpuPortSTP3
@@ -46,7 +46,7 @@ def product_step_float64(batch_size=2):
     from stp3_amd.config import perception_cfg
     from stp3_amd.trainer import TrainingModule
     from tests.test_train_parity_gpu import make_deterministic_train
-    tm = TrainingModule(perception_cfg(**C3, **NO_TOPK).convert_to_dict())
+    tm = TrainingModule(perception_cfg(**C3, **NO_TOPK, **(extra_cfg or {})).convert_to_dict())
     H.fill_deterministic(tm.model)
     make_deterministic_train(tm)
     tm.model.__class__ = CpuPortSTP3
@@ -55,7 +55,7 @@ def product_step_float64(batch_size=2):
     for k, v in geo.items():
         getattr(tm.model, k).data = v
     taps = H.BlockTaps(tm.model)
-    batch = synthetic.make_batch(batch=batch_size, seq=3, seed=5, gt_depth=True, instance=True)
+    batch = synthetic.make_batch(batch=batch_size, seq=seq, seed=5, gt_depth=True, instance=True)
     batch['image'] = batch['image'].double()
     output, labels, loss = tm.shared_step(batch, True)
     for k in H.DECODER_HEADS:
@@ -72,10 +72,9 @@ def product_step_float64(batch_size=2):
     return tm, output, loss, total, fp
 
 
-@pytest.mark.skipif(os.environ.get('STP3_SLOW_TESTS') != '1', reason='float64 whole step on the CPU: ~4 min, ~25 GB (STP3_SLOW_TESTS=1)')
-def test_product_math_in_float64_equals_the_reference_in_float64():
-    g = H.load('step_b2k0d.npz')
-    tm, output, loss, total, fp = product_step_float64()
+def _compare_with_truth(fixture, min_blocks, **kw):
+    g = H.load(fixture)
+    tm, output, loss, total, fp = product_step_float64(**kw)
     errs = {'loss_total': abs(total.item() - g['loss_total'].item()) / abs(g['loss_total'].item())}
     for k, v in loss.items():
         errs[f'loss/{k}'] = abs(v.item() - g[f'loss/{k}'].item()) / max(abs(g[f'loss/{k}'].item()), 1e-3)
@@ -104,10 +103,26 @@ def test_product_math_in_float64_equals_the_reference_in_float64():
         json.dump(report, open(path, 'w'), indent=1, sort_keys=True)
     print('[step truth] loss', errs['loss_total'], 'grads', gerr, 'worst tap out', max(tap_out.values()), 'gout',
           max(tap_gout.values()))
-    assert len(blocks) >= 44
+    assert len(blocks) >= min_blocks
     # the fixture stores float32 fingerprints of float64 values: 6e-8 per element is the floor
     assert max(v for k, v in errs.items() if k.startswith('loss')) <= 1e-6, errs
     assert max(v for k, v in errs.items() if k.startswith('out/')) <= 1e-5, errs
     assert max(tap_out.values()) <= 1e-5, sorted(tap_out.items(), key=lambda kv: -kv[1])[:5]
     assert max(tap_gout.values()) <= 1e-4, sorted(tap_gout.items(), key=lambda kv: -kv[1])[:5]
     assert max(gerr.values()) <= 1e-4, gerr
+
+
+@pytest.mark.skipif(os.environ.get('STP3_SLOW_TESTS') != '1', reason='float64 whole step on the CPU: ~4 min, ~25 GB (STP3_SLOW_TESTS=1)')
+def test_product_math_in_float64_equals_the_reference_in_float64():
+    _compare_with_truth('step_b2k0d.npz', 44)
+
+
+def test_identity_temporal_model_of_configs0_in_float64():
+    """BASELINE configs[0]: ONE frame, hence the IDENTITY temporal model (stp3/models/stp3.py:34-35, 56-57;
+    stp3/models/temporal_model.py:63-71) -- the path on which the 64 + 6-channel concatenation of BEV features and
+    ego-motion planes really exists and goes straight to the decoder.  The product's whole step at T = 1 in float64 against
+    the reference's own float64 run of the same configuration (tests/golden/step_t1b2k0d.npz: 41 blocks -- no temporal
+    blocks, no temporal DeepLabHead): every loss entry, head output, block tap and parameter gradient.  Small enough for
+    the routine suite (12 images)."""
+    _compare_with_truth('step_t1b2k0d.npz', 41, extra_cfg={'TIME_RECEPTIVE_FIELD': 1, 'MODEL.TEMPORAL_MODEL.NAME': 'identity'},
+                        seq=1)
