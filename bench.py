@@ -280,6 +280,10 @@ def lift_roofline(device, batch, model, iters=30):
             'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
             'algorithmic_bytes_per_launch': alg_fwd, 'avg_launch_ms': round(fwd_ms, 4),
+            # the same with the BEV counted as it is WRITTEN (bf16: 2 bytes per element) -- both are reported, `frac` is the
+            # SURVEY.md section 8(d) definition (float32 BEV)
+            'algorithmic_bytes_as_written': alg_fwd - (d.BT * d.C * d.V * 2 if bf else 0),
+            'frac_as_written': round((alg_fwd - (d.BT * d.C * d.V * 2 if bf else 0)) / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             'launches': prof['lift_splat_fwd']['n'], 'bev_layout': 'channels_last' if cl else 'channels_first',
             'bev_dtype': 'bf16 (float32 sums rounded once on the way out; algorithmic bytes still count the float32 BEV of '
                          'SURVEY.md section 8d)' if bf else 'f32',
