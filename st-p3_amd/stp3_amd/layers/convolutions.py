@@ -180,7 +180,7 @@ class ASPP(nn.Module):
         y = conv2d(spatial, w_sp)
         # the pooled branch is a constant plane per sample: its projection is a per-sample bias, folded
         # into the fused BatchNorm instead of a broadcast add over the whole map
-        sbias = hp(conv1x1_on_vector(pooled.to(y.dtype), w_pool).flatten(1))
+        sbias = hp(conv1x1_on_vector(pooled, w_pool).flatten(1))
         return drop(bn_act(bn, y, ACT_RELU, sbias=sbias))
 
 

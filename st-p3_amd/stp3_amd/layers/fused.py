@@ -179,7 +179,9 @@ def _kernel_args(bn, x, act, res, res_mode, sbias, oscale):
     """Positional arguments of ``ops._BnAct`` for this layer, or None when the tensor takes the statement route."""
     if not (x.is_cuda and x.dim() == 4) or x.dtype == torch.float64:
         return None
-    if torch.is_autocast_enabled() and x.dtype == torch.float32:
+    if torch.is_autocast_enabled() and x.dtype == torch.float32 and x.shape[2] * x.shape[3] > 1:
+        # (1 x 1 maps -- the pooled descriptors of the ASPP / pyramid-pooling branches -- stay float32: the cast and its
+        # backward would be two launches for a few hundred numbers, and their consumers take float32)
         x = x.to(torch.get_autocast_dtype('cuda'))
     training = bn.training or not bn.track_running_stats
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
@@ -301,7 +303,21 @@ def plane_mean(x):
 
 
 def conv1x1_on_vector(x, weight, bias=None):
-    """A 1x1 convolution of a (N, C, 1, 1) map (or (N, C, T, 1, 1) with a 1x1x1 kernel) is a plain GEMM."""
+    """A 1x1 convolution of a (N, C, 1, 1) map (or (N, C, T, 1, 1) with a 1x1x1 kernel) is a plain GEMM.
+
+    Under GPU autocast it is evaluated in FLOAT32 with autocast off: these are (12, 128) x (128, 128)-sized products whose
+    time is launch latency, and autocast wrapped each of them in three cast kernels forward (operand, weight, result back to
+    float32 for the per-sample bias it becomes) and as many backward -- ~100 launches per step for ten products.  The pooled
+    descriptors arrive in float32 (``plane_mean``) and the weights are float32 parameters: nothing is cast at all."""
+    if x.is_cuda and torch.is_autocast_enabled():
+        with torch.autocast('cuda', enabled=False):
+            return _conv1x1_on_vector(x.float(), weight.float(), None if bias is None else bias.float())
+    if x.dtype != weight.dtype:
+        x = x.to(weight.dtype)
+    return _conv1x1_on_vector(x, weight, bias)
+
+
+def _conv1x1_on_vector(x, weight, bias):
     w2 = weight.flatten(1)
     if x.dim() == 5:
         n, c, t = x.shape[:3]

@@ -157,7 +157,7 @@ class PyramidSpatioTemporalPooling(nn.Module):
                 sp = torch.cat([sp, hp(extra).view(b, -1, t, 1, 1)], dim=1)
             pooled = torch.cat([sp[:, :, :1], 0.5 * (sp[:, :, 1:] + sp[:, :, :-1]), sp[:, :, -1:]], dim=2)
             cbr = f.conv_bn_relu
-            y = conv1x1_on_vector(pooled.to(x.dtype), cbr.conv.weight)                       # (B, C', T + 1, 1, 1)
+            y = conv1x1_on_vector(pooled, cbr.conv.weight)                       # (B, C', T + 1, 1, 1)
             co = y.shape[1]
             members.append(dict(bn=cbr.norm, x=y.permute(0, 2, 1, 3, 4).reshape(b * (t + 1), co, 1, 1), act=ACT_RELU))
             finish.append(lambda o, co=co: o.view(b, t + 1, co, 1, 1).permute(0, 2, 1, 3, 4)[:, :, :-1])
@@ -181,7 +181,7 @@ class PyramidSpatioTemporalPooling(nn.Module):
                     sp = torch.cat([sp, hp(extra).view(b, -1, t, 1, 1)], dim=1)
                 pooled = torch.cat([sp[:, :, :1], 0.5 * (sp[:, :, 1:] + sp[:, :, :-1]), sp[:, :, -1:]], dim=2)
                 cbr = f.conv_bn_relu
-                out.append(bn_act(cbr.norm, conv1x1_on_vector(pooled.to(x.dtype), cbr.conv.weight), ACT_RELU)[:, :, :-1])
+                out.append(bn_act(cbr.norm, conv1x1_on_vector(pooled, cbr.conv.weight), ACT_RELU)[:, :, :-1])
             elif h % ph == 0 and w % pw == 0:
                 # spatial mean over each pool window, then the causal 2-frame mean with
                 # count_include_pad=False (frame 0 averages only itself): identical to the padded
@@ -194,7 +194,7 @@ class PyramidSpatioTemporalPooling(nn.Module):
                 # only then drops it.
                 pooled = torch.cat([sp[:, :, :1], 0.5 * (sp[:, :, 1:] + sp[:, :, :-1]), sp[:, :, -1:]], dim=2)
                 cbr = f.conv_bn_relu
-                out.append(bn_act(cbr.norm, conv1x1_on_vector(pooled.to(x.dtype), cbr.conv.weight), ACT_RELU)[:, :, :-1])
+                out.append(bn_act(cbr.norm, conv1x1_on_vector(pooled, cbr.conv.weight), ACT_RELU)[:, :, :-1])
             else:
                 out.append(f(x)[:, :, :-1])
         return out
@@ -243,7 +243,8 @@ class TemporalBlock(nn.Module):
         # (split, not two slices: one concatenation in backward instead of two zero-fills, two copies and an addition)
         w_x, w_extra = (wgt, None) if extra2 is None else wgt.split([c, wgt.shape[1] - c], dim=1)
         y = _conv2d_padded_channels(x2, w_x if lanes is None else _pad_out(w_x, lanes))
-        sbias = None if extra2 is None else hp(extra2).to(hp(wgt).dtype) @ hp(w_extra.flatten(1)).t()
+        # (through conv1x1_on_vector: float32 with autocast off on the GPU -- a (B*T, 6) x (6, C') product needs no casts)
+        sbias = None if extra2 is None else conv1x1_on_vector(hp(extra2).to(hp(wgt).dtype)[:, :, None, None], w_extra).flatten(1)
         return dict(bn=norm, x=y, act=ACT_RELU if relu else ACT_NONE, sbias=sbias)
 
     @staticmethod
@@ -305,7 +306,7 @@ class TemporalBlock(nn.Module):
             for pooled, w_p in zip(pooled_list, w_parts[1:]):
                 cp = pooled.shape[1]
                 p2 = pooled.permute(0, 2, 1, 3, 4).reshape(b * t, cp, *pooled.shape[-2:])
-                contrib = (conv1x1_on_vector(p2.to(y.dtype), w_p.to(y.dtype))
+                contrib = (conv1x1_on_vector(p2, w_p)
                            if p2.shape[-2:] == (1, 1) else F.conv2d(p2.to(y.dtype), w_p.to(y.dtype)))
                 if contrib.shape[-2:] == (1, 1):
                     # whole-plane pooling (the reference's only setting): a constant plane per frame, i.e. a
