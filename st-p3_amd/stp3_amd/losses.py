@@ -103,15 +103,18 @@ class HDmapLoss(nn.Module):
 
     def forward(self, prediction, target):
         total = 0
+        # (the two logits of every map element through ONE split: its backward is one concatenation, that of a slice per
+        # element a zero-fill, a copy and an addition each)
+        pieces = prediction.split(2, dim=1)
         for i in range(target.shape[-3]):
             cur = target[:, i]
             b = cur.shape[0]
             if ops_loss.supported(prediction) and target.is_cuda:
                 k = int(self.top_k_ratio[i] * cur.shape[1] * cur.shape[2]) if self.use_top_k[i] else 0
-                total = total + ops_loss.ce_topk_mean(prediction[:, 2 * i:2 * (i + 1)], cur, self.class_weights[i], None, k,
+                total = total + ops_loss.ce_topk_mean(pieces[i], cur, self.class_weights[i], None, k,
                                                       self.ignore_index) * self.training_weights[i]
                 continue
-            loss = F.cross_entropy(hp(prediction[:, 2 * i:2 * (i + 1)]), cur, ignore_index=self.ignore_index,
+            loss = F.cross_entropy(hp(pieces[i]), cur, ignore_index=self.ignore_index,
                                    reduction='none',
                                    weight=self.class_weights[i].to(device=target.device, dtype=hp(prediction).dtype)).view(b, -1)
             if self.use_top_k[i]:
