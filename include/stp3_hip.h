@@ -227,6 +227,10 @@ int stp3_dwconv2d_bwd_data(const stp3_dwconv_dims* dims, const void* dy, const f
 int stp3_dwconv2d_bwd_weight_workspace(const stp3_dwconv_dims* dims, size_t* bytes);
 int stp3_dwconv2d_bwd_weight(const stp3_dwconv_dims* dims, const void* x, const void* dy, float* dw,
                              void* workspace, size_t workspace_bytes, void* stream);
+/* the same with dw in the layout of the nn.Conv2d parameter, [C][1][K][K] (what autograd hands to the optimizer as it is;
+ * stp3_dwconv2d_bwd_weight writes the tap-major [K*K][C] the kernels read their weights in) */
+int stp3_dwconv2d_bwd_weight_oihw(const stp3_dwconv_dims* dims, const void* x, const void* dy, float* dw,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused BatchNorm (+ per-sample bias) + activation (+ residual), channels-last, forward / backward.

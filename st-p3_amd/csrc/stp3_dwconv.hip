@@ -310,8 +310,10 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwDims d, int nb
 
 // dw[i] = sum_b partial[b][i]: 64 columns x 4 block lanes per workgroup (256-byte coalesced row segments, four loads
 // in flight per thread), fixed summation order (deterministic)
+// channels > 0: the result goes out in the PARAMETER's layout [C][K*K] (i = tap * C + c  ->  c * taps + tap) instead of the
+// tap-major [K*K][C] the kernels read their weights in: autograd then takes the tensor as the parameter's gradient as it is
 __global__ __launch_bounds__(256) void dwconv_reduce_partials_kernel(int nblocks, int n, const float* __restrict__ partial,
-                                                                     float* __restrict__ dw) {
+                                                                     float* __restrict__ dw, int channels) {
     __shared__ float red[256];
     const int il = threadIdx.x & 63, bl = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + il;
@@ -327,7 +329,10 @@ __global__ __launch_bounds__(256) void dwconv_reduce_partials_kernel(int nblocks
     }
     red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (bl == 0 && i < n) dw[i] = (red[il] + red[64 + il]) + (red[128 + il] + red[192 + il]);
+    if (bl == 0 && i < n) {
+        const int o = channels > 0 ? (i % channels) * (n / channels) + i / channels : i;
+        dw[o] = (red[il] + red[64 + il]) + (red[128 + il] + red[192 + il]);
+    }
 }
 
 
@@ -550,7 +555,7 @@ int launch_bwd_data(const DwDims& d, const void* dy, const float* w, void* dx, h
     }
 }
 template <typename T, int K, int S>
-int launch_bwd_weight(const DwDims& d, const void* x, const void* dy, float* dw, float* ws, hipStream_t s) {
+int launch_bwd_weight(const DwDims& d, const void* x, const void* dy, float* dw, float* ws, hipStream_t s, bool param_layout) {
     constexpr int VN = Vec<T>::N;
     const int CV = d.C / VN;
     const int CVB = CV < 256 ? CV : 256;
@@ -567,7 +572,7 @@ int launch_bwd_weight(const DwDims& d, const void* x, const void* dy, float* dw,
     hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, S>), dim3(bx * by * K), dim3(256), lds, s, d, bx, (const T*)x,
                        (const T*)dy, ws);
     const int n = K * K * d.C;
-    hipLaunchKernelGGL(dwconv_reduce_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, s, bx, n, ws, dw);
+    hipLaunchKernelGGL(dwconv_reduce_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, s, bx, n, ws, dw, param_layout ? d.C : 0);
     return status();
 }
 
@@ -635,7 +640,17 @@ int stp3_dwconv2d_bwd_weight(const stp3_dwconv_dims* p, const void* x, const voi
     if (rc) return rc;
     if (!x || !dy || !dw || !workspace) return STP3_EINVAL;
     if (workspace_bytes < (size_t)kWgradBlocks * p->K * p->K * p->C * sizeof(float)) return STP3_ENOSPACE;
-    DISPATCH(launch_bwd_weight, d, x, dy, dw, (float*)workspace, (hipStream_t)stream);
+    DISPATCH(launch_bwd_weight, d, x, dy, dw, (float*)workspace, (hipStream_t)stream, false);
+}
+
+int stp3_dwconv2d_bwd_weight_oihw(const stp3_dwconv_dims* p, const void* x, const void* dy, float* dw, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    DwDims d; int vec;
+    int rc = check(p, &d, &vec);
+    if (rc) return rc;
+    if (!x || !dy || !dw || !workspace) return STP3_EINVAL;
+    if (workspace_bytes < (size_t)kWgradBlocks * p->K * p->K * p->C * sizeof(float)) return STP3_ENOSPACE;
+    DISPATCH(launch_bwd_weight, d, x, dy, dw, (float*)workspace, (hipStream_t)stream, true);
 }
 
 }  // extern "C"

@@ -152,6 +152,7 @@ SIGNATURES = {
     'stp3_dwconv2d_bwd_data': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_dwconv2d_bwd_weight_workspace': (c_int, [_DW_P, ctypes.POINTER(c_size_t)]),
     'stp3_dwconv2d_bwd_weight': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'stp3_dwconv2d_bwd_weight_oihw': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'stp3_bn_workspace_bytes': (c_int, [_BN_P, ctypes.POINTER(c_size_t)]),
     'stp3_bn_stats': (c_int, [_BN_P, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     'stp3_bn_apply_fwd': (c_int, [_BN_P] + [c_void_p] * 5 + [c_double, c_void_p, c_void_p, c_float, c_float]

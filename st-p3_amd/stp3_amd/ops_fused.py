@@ -676,10 +676,12 @@ class _DwBnSe(torch.autograd.Function):
             check(lib.stp3_dwconv2d_bwd_weight_workspace(ctypes.byref(dwd), ctypes.byref(nbytes)),
                   'stp3_dwconv2d_bwd_weight_workspace')
             ws2 = _workspace(max(nbytes.value, ws_bytes), dev)
-            dwt = torch.empty_like(wt)
-            check(lib.stp3_dwconv2d_bwd_weight(ctypes.byref(dwd), x.data_ptr(), de2.data_ptr(), dwt.data_ptr(), ws2.data_ptr(),
-                                               nbytes.value, stream), 'stp3_dwconv2d_bwd_weight')
-            dwg = dwt.t().reshape(wshape).to(wdt)
+            # (in the parameter's own layout: autograd takes the tensor as the gradient as it is -- the tap-major form needed a
+            # transposing copy per layer and step)
+            dwg = torch.empty(wshape, dtype=torch.float32, device=dev)
+            check(lib.stp3_dwconv2d_bwd_weight_oihw(ctypes.byref(dwd), x.data_ptr(), de2.data_ptr(), dwg.data_ptr(), ws2.data_ptr(),
+                                                    nbytes.value, stream), 'stp3_dwconv2d_bwd_weight_oihw')
+            dwg = dwg.to(wdt)
         dgamma = lsums[1].to(gdt) if gdt is not None and ctx.needs_input_grad[4] else None
         dbeta = lsums[0].to(bdt) if bdt is not None and ctx.needs_input_grad[5] else None
         return (dx, dwg, None, None, dgamma, dbeta, None, None, None, None, dw1.view(w1s).to(w1d), db1.to(b1d),

@@ -74,6 +74,7 @@ WORK = {
     'stp3_dwconv2d_fwd_stats': ('depthwise', _dw_bytes),
     'stp3_dwconv2d_bwd_data': ('depthwise', _dw_bytes),
     'stp3_dwconv2d_bwd_weight': ('depthwise', _dw_bytes),
+    'stp3_dwconv2d_bwd_weight_oihw': ('depthwise', _dw_bytes),
     'stp3_se_pool': ('squeeze_excite', _se_pool_bytes),
     'stp3_se_scale': ('squeeze_excite', _se_bytes(2)),
     'stp3_se_pool_act': ('mbconv', _se_bytes(1)),

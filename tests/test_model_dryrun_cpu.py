@@ -56,8 +56,9 @@ def test_step_runs_and_call_mix(recorder, tmp_path):
     assert calls['stp3_bn_stats'] == 5 * STEPS, calls['stp3_bn_stats']
     # the 22 MBConv blocks: depthwise -> BN1 -> swish -> squeeze-excite as ONE operator (ops_fused.dw_bn_se) -- the
     # depthwise forward with the statistics epilogue, no separate BatchNorm / pool / scale passes
-    assert calls['stp3_dwconv2d_fwd_stats'] == calls['stp3_dwconv2d_bwd_data'] == calls['stp3_dwconv2d_bwd_weight'] \
+    assert calls['stp3_dwconv2d_fwd_stats'] == calls['stp3_dwconv2d_bwd_data'] == calls['stp3_dwconv2d_bwd_weight_oihw'] \
         == 22 * STEPS
+    assert calls['stp3_dwconv2d_bwd_weight'] == 0                   # (the weight gradient leaves in the parameter's layout)
     assert calls['stp3_dwconv2d_fwd'] == calls['stp3_se_pool'] == calls['stp3_se_scale'] == 0
     assert calls['stp3_se_mlp_fwd'] == calls['stp3_se_mlp_bwd'] == 22 * STEPS
     for fused in ('stp3_se_pool_act', 'stp3_mbconv_scale_act', 'stp3_mbconv_bwd_reduce',
