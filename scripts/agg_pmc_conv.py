@@ -1,11 +1,15 @@
-"""Per-kernel MFMA utilisation from one rocprofv3 --pmc pass over scripts/time_conv.py (see scripts/gpu_pmc_conv.sh).
+"""Counters of the convolution kernels per kernel AND launch geometry, from the rocprofv3 --pmc passes of
+scripts/gpu_pmc_conv.sh over scripts/time_conv.py + scripts/time_pointwise.py.
 
-    python scripts/agg_pmc_conv.py <dir>  -> JSON on stdout
+    python scripts/agg_pmc_conv.py <dir> [<dir> ...]  -> JSON on stdout
 
-For every kernel: mean of each collected counter per dispatch (summed over the counter's instances), the mean kernel
-duration from the kernel trace, and -- when both are present -- SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024
-SIMDs), i.e. the fraction of the chip's matrix-core issue slots that were busy (MI355X_MICROARCH.md: the counter is in
-shader cycles, summed over SIMDs)."""
+One entry per (kernel name, grid size, workgroup size): the launched SHAPE of a kernel is identified by its grid (the
+shape list of scripts/time_conv.py gives every shape its own grid).  Per entry: mean of each collected counter per
+dispatch (summed over the counter's instances), the mean kernel duration from the kernel trace, and the derived
+fractions -- SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs) = share of the chip's matrix-core issue
+slots that were busy (MI355X_MICROARCH.md: shader cycles summed over SIMDs), SQ_WAIT_ANY / SQ_WAVE_CYCLES, L2 hit rate,
+HBM bytes (FETCH_SIZE x 2 x 32 B per the gfx950 correction measured in profiles/r04_lift_pmc.json, WRITE_SIZE x 64 B... the
+raw counters are kept so that the correction can be re-applied)."""
 import glob
 import json
 import sys
@@ -16,29 +20,55 @@ CLOCK_HZ = 2.4e9
 SIMDS = 256 * 4
 
 
+def key_cols(df):
+    cols = ['Kernel_Name']
+    for c in ('Grid_Size', 'Workgroup_Size'):
+        if c in df.columns:
+            cols.append(c)
+    return cols
+
+
 def main():
-    d = sys.argv[1]
-    cc = pd.read_csv(glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0])
-    per = cc.groupby(['Dispatch_Id', 'Kernel_Name', 'Counter_Name'])['Counter_Value'].sum().reset_index()
-    tab = per.groupby(['Kernel_Name', 'Counter_Name'])['Counter_Value'].mean().unstack()
-    counts = per.groupby('Kernel_Name')['Dispatch_Id'].nunique()
-    dur = None
-    traces = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)
-    if traces:
-        kt = pd.read_csv(traces[0])
-        kt['dur_us'] = (kt['End_Timestamp'] - kt['Start_Timestamp']) / 1e3
-        dur = kt.groupby('Kernel_Name')['dur_us'].mean()
     out = {}
-    for name, row in tab.iterrows():
-        if not any(k in name for k in ('conv2d_', 'igemm', 'Cijk', 'ck::', 'dwconv')):
+    for d in sys.argv[1:]:
+        ccs = glob.glob(d + '/**/*counter_collection.csv', recursive=True)
+        if not ccs:
+            print('no counter_collection.csv under', d, file=sys.stderr)
             continue
-        ent = {'dispatches': int(counts[name]), **{k: float(v) for k, v in row.items() if v == v}}
-        if dur is not None and name in dur.index:
-            ent['avg_us'] = float(dur[name])
-            busy = ent.get('SQ_VALU_MFMA_BUSY_CYCLES')
-            if busy is not None and ent['avg_us'] > 0:
-                ent['mfma_busy_frac'] = busy / (ent['avg_us'] * 1e-6 * CLOCK_HZ * SIMDS)
-        out[name[:120]] = ent
+        cc = pd.read_csv(ccs[0])
+        keys = key_cols(cc)
+        per = cc.groupby(['Dispatch_Id'] + keys + ['Counter_Name'])['Counter_Value'].sum().reset_index()
+        tab = per.groupby(keys + ['Counter_Name'])['Counter_Value'].mean().unstack()
+        counts = per.groupby(keys)['Dispatch_Id'].nunique()
+        dur = None
+        traces = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)
+        if traces:
+            kt = pd.read_csv(traces[0])
+            kt['dur_us'] = (kt['End_Timestamp'] - kt['Start_Timestamp']) / 1e3
+            kk = [c for c in keys if c in kt.columns]
+            dur = kt.groupby(kk)['dur_us'].mean()
+        for idx, row in tab.iterrows():
+            idx = idx if isinstance(idx, tuple) else (idx,)
+            name = idx[0]
+            if not any(k in name for k in ('conv2d_', 'igemm', 'pointwise', 'Cijk', 'dwconv', 'colsum')):
+                continue
+            label = name[:110] + ''.join(f' | {c.lower()}={v}' for c, v in zip(keys[1:], idx[1:]))
+            ent = out.setdefault(label, {})
+            ent['dispatches'] = int(counts[idx if len(idx) > 1 else idx[0]])
+            ent.update({k: float(v) for k, v in row.items() if v == v})
+            if dur is not None:
+                try:
+                    ent['avg_us'] = float(dur[idx[:len(dur.index.names)] if len(dur.index.names) > 1 else idx[0]])
+                except KeyError:
+                    pass
+    for ent in out.values():
+        us = ent.get('avg_us')
+        if us and 'SQ_VALU_MFMA_BUSY_CYCLES' in ent:
+            ent['mfma_busy_frac'] = ent['SQ_VALU_MFMA_BUSY_CYCLES'] / (us * 1e-6 * CLOCK_HZ * SIMDS)
+        if ent.get('SQ_WAVE_CYCLES') and 'SQ_WAIT_ANY' in ent:
+            ent['wait_any_frac'] = ent['SQ_WAIT_ANY'] / ent['SQ_WAVE_CYCLES']
+        if ent.get('TCC_REQ_sum'):
+            ent['l2_hit_rate'] = ent.get('TCC_HIT_sum', 0.0) / ent['TCC_REQ_sum']
     json.dump(out, sys.stdout, indent=1)
 
 

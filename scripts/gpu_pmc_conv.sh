@@ -1,22 +1,28 @@
 #!/bin/bash
-# MFMA utilisation of the convolution kernels from PMC counters (north_star: "MFMA utilisation on the convs").
-#   bash scripts/gpu_pmc_conv.sh <tag>      -> gpurun_out/<tag>/conv_mfma.json, copy into profiles/
-# One SQ pass (8 slots on gfx950): matrix-core busy cycles against the kernel's busy cycles, per kernel, while
-# scripts/time_conv.py runs the model's dominant convolution shapes.  Counter names differ between ROCm drops, so the
-# script first lists what the box offers (rocprofv3 -L) and uses the MFMA / busy counters it finds.
+# Counters of the convolution kernels (north_star: "MFMA utilisation on the convs"), per kernel AND launched shape.
+#   bash scripts/gpu_pmc_conv.sh <tag>      -> gpurun_out/<tag>/conv_pmc.json, copy into profiles/
+# Separate rocprofv3 passes per counter group (SQ: 8 slots, TCC: FETCH_SIZE / WRITE_SIZE alone), --kernel-trace only
+# beside --pmc, while scripts/time_conv.py and scripts/time_pointwise.py run the model's dominant shapes.
 TAG=${1:-run}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*\|SQ_BUSY_CYCLES\|SQ_BUSY_CU_CYCLES\|SQ_WAVE_CYCLES\|SQ_INSTS_MFMA\|GRBM_GUI_ACTIVE" | sort -u > $OUT/counters_available.txt
-cat $OUT/counters_available.txt
-WANT=""
-for c in SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE; do
-  grep -qx "$c" $OUT/counters_available.txt && WANT="$WANT $c"
+pass() {  # name, counters...
+  local name=$1; shift
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_conv_${TAG}_$name -o c -- bash -c "python scripts/time_conv.py && python scripts/time_pointwise.py" > $OUT/pmc_conv_$name.log 2>&1
+}
+MF=""
+for c in SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES; do
+  grep -qx "$c" $OUT/counters_available.txt && MF="$MF $c"
 done
-echo "collecting:$WANT"
-[ -z "$WANT" ] && { echo "no MFMA counters offered by this rocprofv3"; exit 0; }
-timeout 400 rocprofv3 --kernel-trace --pmc $WANT --output-format csv -d /tmp/pmc_conv_$TAG -o c -- python scripts/time_conv.py > $OUT/pmc_conv.log 2>&1
-python scripts/agg_pmc_conv.py /tmp/pmc_conv_$TAG > $OUT/conv_mfma.json 2> $OUT/agg_pmc_conv.err
-cat $OUT/conv_mfma.json | head -60; tail -3 $OUT/agg_pmc_conv.err
-rm -rf /tmp/pmc_conv_$TAG
+echo "mfma pass:$MF"
+pass mfma $MF
+pass wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS
+pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+python scripts/agg_pmc_conv.py /tmp/pmc_conv_${TAG}_mfma /tmp/pmc_conv_${TAG}_wait /tmp/pmc_conv_${TAG}_tcc /tmp/pmc_conv_${TAG}_fetch /tmp/pmc_conv_${TAG}_write > $OUT/conv_pmc.json 2> $OUT/agg_pmc_conv.err
+head -c 3000 $OUT/conv_pmc.json; tail -3 $OUT/agg_pmc_conv.err
+grep -h "TF/s\|us" $OUT/pmc_conv_mfma.log | head -60 > $OUT/pmc_conv_shapes.txt
+rm -rf /tmp/pmc_conv_${TAG}_*

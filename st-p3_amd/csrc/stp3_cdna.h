@@ -20,6 +20,11 @@ __device__ __forceinline__ void lds_dma16(const float* src, float* lds_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
+// the same for ONE dword per lane (global_load_lds_dword): lane l's word lands at lds_base + 4 * l
+__device__ __forceinline__ void lds_dma4(const void* src, void* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
+}
 __device__ __forceinline__ void lds_dma_wait() {
     __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0) expcnt(0) lgkmcnt(0)
 }

@@ -41,7 +41,7 @@ def rel(a, b):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def case_lift(ops, cfg, batch, seq, cams, seed, golden=None):
+def case_lift(ops, cfg, batch, seq, cams, seed, golden=None, roll=0.0):
     from oracle import lift_oracle as lo
     from tests import helpers as H
     if golden is not None:
@@ -50,6 +50,10 @@ def case_lift(ops, cfg, batch, seq, cams, seed, golden=None):
         feat, logits = torch.from_numpy(g['feat']), torch.from_numpy(g['depth_logits'])
     else:
         intr, extr, ego, feat, logits = H.lift_inputs(cfg, batch, seq, cams, seed=seed)
+    if roll:                            # cameras rolled about their optical axis: the rows of an image column fan out over the grid
+        c, s_ = float(np.cos(roll)), float(np.sin(roll))
+        extr = extr.clone()
+        extr[..., :3, :3] = extr[..., :3, :3] @ torch.tensor([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]])
     frustum, res, start, dim = H.grid_params(cfg)
     grid = ops.LiftGrid(frustum, res, start, dim, 'cpu')
     b, s, n = intr.shape[:3]
@@ -90,7 +94,8 @@ def case_lift(ops, cfg, batch, seq, cams, seed, golden=None):
            'reproducible': bool(torch.equal(bev.detach(), again)), 'dfeat_err': err(f.grad, gf), 'dlogit_err': err(lg.grad, gl),
            'grad_scale': float(min(gf.abs().max(), gl.abs().max())), 'dims': [grid.D, grid.fH, grid.fW, cfg['out_channels']],
            'channels_last_equal': cl_equal, 'max_runs_per_voxel': int(plan.offsets().diff(dim=1).max()),
-           'counts_clean': bool(int(plan.counts.abs().max()) == 0)}
+           'counts_clean': bool(int(plan.counts.abs().max()) == 0),
+           'max_runs_per_column': int(plan.column_offsets().diff().max())}
     try:
         out['plan_runs'] = H.check_plan_structure(plan, vox)
         out['plan_ok'] = True
@@ -122,6 +127,13 @@ def lift_c64_many_runs(ops):        # 64 channels, ~190 runs per column: more ru
     cfg = dict(H.SMALL, out_channels=64, final_dim=(64, 16), downsample=2, d_bound=(2.0, 34.0, 1.0),
                x_bound=(-36.0, 36.0, 0.25), y_bound=(-36.0, 36.0, 0.25))
     return case_lift(ops, cfg, 1, 1, 1, 7)
+
+
+def lift_c64_ring_overflow(ops):    # 64 channels, 32 rows, 64 bins, rolled cameras: several hundred runs per column (more than the pipelined pass-1 kernel
+    from tests import helpers as H  # stages in LDS: the tail comes from memory) and chunks of three columns per workgroup on the stand-in's 8 CUs
+    cfg = dict(H.SMALL, out_channels=64, final_dim=(64, 96), downsample=2, d_bound=(2.0, 34.0, 0.5),
+               x_bound=(-36.0, 36.0, 0.25), y_bound=(-36.0, 36.0, 0.25))
+    return case_lift(ops, cfg, 1, 1, 1, 17, roll=0.9)
 
 
 def lift_full(ops):                 # the real geometry: 6 cameras x 224x480, D = 48, C = 64, BEV 200x200, T = 3 (golden digests)
@@ -1345,7 +1357,7 @@ def fuzz(ops, seed=1):
     return {'problems': [[t, str(c), n, str(e)] for t, c, n, e in bad]}
 
 
-CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_frames, lift_coarse_grid, lift_tall, lift_c64_rows56, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
+CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_ring_overflow, lift_c64_frames, lift_coarse_grid, lift_tall, lift_c64_rows56, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
                                  conv, conv_f32, fan_out, aspp_join, pointwise_bn, pointwise_stream, decoder_heads, dwconv, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
 
 if __name__ == '__main__':

@@ -13,6 +13,9 @@ inline void fmac_row_bcast(float& acc, float v, float f) {
 inline void lds_dma16(const float* src, float* lds_base) {
     std::memcpy(reinterpret_cast<char*>(lds_base) + 16 * hipcpu::cur->lane, src, 16);
 }
+inline void lds_dma4(const void* src, void* lds_base) {
+    std::memcpy(reinterpret_cast<char*>(lds_base) + 4 * hipcpu::cur->lane, src, 4);
+}
 inline void lds_dma_wait() {}
 
 // ds_read_b64_tr_b16: lane i of a 16-lane group supplies row i >> 2, columns 4 * (i & 3) .. + 3 of a [4][16] halfword

@@ -28,7 +28,7 @@ import build as hipcpu_build  # noqa: E402
 
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
 ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
-           ('conv', {}), ('conv_f32', {}), ('fan_out', {}), ('aspp_join', {}), ('pointwise_bn', {}), ('pointwise_stream', {}), ('decoder_heads', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('labels', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}),
+           ('conv', {}), ('conv_f32', {}), ('fan_out', {}), ('aspp_join', {}), ('pointwise_bn', {}), ('pointwise_stream', {}), ('decoder_heads', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('labels', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}), ('lift_c64_ring_overflow', {}),
            ('lift_c64_frames', {}), ('lift_c64_rows56', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
 ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'pointwise_bn', 'pointwise_stream', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'labels', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)]
@@ -294,6 +294,12 @@ def test_voxel_pool_32_rows(results):
 
 def test_voxel_pool_many_runs_per_voxel(results):
     _check_lift(_get(results, 'lift_c64_many_runs'))
+
+
+def test_voxel_pool_pipelined_pass1_beyond_its_staged_runs(results):
+    r = _get(results, 'lift_c64_ring_overflow')
+    assert r['max_runs_per_column'] > 256          # kRingRuns: the tail of the column's descriptors comes from memory
+    _check_lift(r)
 
 
 def test_voxel_pool_tall_columns_at_64_channels(results):
