@@ -442,6 +442,7 @@ def main():
         dist.barrier()
     _sync()
     ops_mod.exchange_counts(reset=True)
+    reductions_before = buckets.reductions_launched
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -451,6 +452,7 @@ def main():
     elapsed = time.perf_counter() - t0
     per_rank_ms = [elapsed / args.steps * 1e3]
     exchanges = ops_mod.exchange_counts()
+    bucket_reductions = buckets.reductions_launched - reductions_before      # of the timed steps only
     if world > 1:
         mine = torch.tensor([elapsed], device=device, dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
@@ -498,8 +500,7 @@ def main():
             'host_enqueue_ms_per_step': round(host_ms, 3),
             'per_rank_ms_per_step': per_rank_ms,
             'collectives_per_step': {'batchnorm_statistics_all_reduces': exchanges['batchnorm'] // max(args.steps, 1),
-                                     'gradient_bucket_all_reduces': buckets.reductions_launched // max(args.steps + max(args.warmup, 1), 1)
-                                     if world > 1 else 0},
+                                     'gradient_bucket_all_reduces': bucket_reductions // max(args.steps, 1) if world > 1 else 0},
             'roofline_families': fam,
         }
         if fam:

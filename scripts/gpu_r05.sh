@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 GPU visit.   bash scripts/gpu_r05.sh <tag> <what ...>
-#   what: lifttests  voxel-pool GPU tests          liftab    time_lift.py on the r04 library / one column per workgroup / ring
-#         liftprof   rocprofv3 kernel stats of time_lift.py      liftpmc   HBM traffic counters of the pool kernels
+#   what: lifttests  voxel-pool GPU tests          liftab    time_lift.py + rocprofv3 kernel stats, r04 library vs this tree
+#         liftpmc   HBM traffic counters of the pool kernels
 #         suite      the whole GPU suite           parity    step / train parity tests with reports
 #         quickbench bench.py without the CPU leg  bench     bench.py default flags + kernel-trace profile
 #         convpmc    MFMA / wait / LDS counters of the convolution kernels per launched shape
@@ -17,20 +17,20 @@ if has lifttests; then
 fi
 if has liftab; then
   R04=$PWD/st-p3_amd/exp/libstp3hip_r04.so
-  [ -f $R04 ] && { EXP_LIB=$R04 timeout 200 python scripts/time_lift.py 4 > $out/time_lift_r04lib.log 2>&1; echo "--- r04 library"; grep -E "plan build|bf16 BEV" $out/time_lift_r04lib.log | cut -c1-200; }
-  STP3_LIFT_RING=0 timeout 200 python scripts/time_lift.py 4 > $out/time_lift_noring.log 2>&1; echo "--- placed runs, one column per workgroup"; grep -E "plan build|bf16 BEV" $out/time_lift_noring.log | cut -c1-200
-  for pc in 3 4 5; do
-    STP3_LIFT_RING_PER_CU=$pc timeout 200 python scripts/time_lift.py 4 > $out/time_lift_ring$pc.log 2>&1; echo "--- ring, $pc workgroups per CU"; grep -E "bf16 BEV" $out/time_lift_ring$pc.log | cut -c1-200
+  for v in r04 new; do
+    [ $v == r04 ] && export EXP_LIB=$R04 || unset EXP_LIB
+    timeout 200 python scripts/time_lift.py 4 > $out/time_lift_$v.log 2>&1; echo "--- $v library"; grep -E "plan build|bf16 BEV" $out/time_lift_$v.log | cut -c1-200
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_lift_$v -o lift -- python scripts/time_lift.py 4 > $out/liftprof_$v.log 2>&1
+    find /tmp/prof_lift_$v -name '*kernel_stats.csv' -exec cp {} $out/lift_kernel_stats_$v.csv \;
+    python - <<PY
+import csv
+for r in csv.DictReader(open('$out/lift_kernel_stats_$v.csv')):
+    n = r['Name'].replace('(anonymous namespace)::', '')
+    if 'lift_' in n or 'plan_' in n: print('   %-60s calls %4s avg %9.1f ns  min %s' % (n[:60], r['Calls'], float(r['AverageNs']), r['MinNs']))
+PY
+    rm -rf /tmp/prof_lift_$v
   done
-  timeout 200 python scripts/time_lift.py 4 > $out/time_lift.log 2>&1; echo "--- default"; tail -7 $out/time_lift.log | cut -c1-200
-fi
-if has liftprof; then
-  for v in 0 1; do
-    STP3_LIFT_RING=$v timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_lift$v -o lift -- python scripts/time_lift.py 4 > $out/liftprof$v.log 2>&1
-    find /tmp/prof_lift$v -name '*kernel_stats.csv' -exec cp {} $out/lift_kernel_stats_ring$v.csv \;
-    echo "--- kernel stats, ring=$v"; grep -E "lift_|plan_" $out/lift_kernel_stats_ring$v.csv | cut -d, -f1-6 | cut -c1-160
-    rm -rf /tmp/prof_lift$v
-  done
+  unset EXP_LIB
 fi
 if has liftpmc; then bash scripts/gpu_pmc_lift.sh $(basename $out) > $out/liftpmc.log 2>&1; tail -5 $out/liftpmc.log | cut -c1-300; fi
 if has parity; then

@@ -8,6 +8,8 @@
 // MIOpen's grouped-conv path for this shape costs ~48 ms per weight-gradient call on MI355X
 // (profiles/r01_bench_steady_miopen.txt); these kernels replace it.
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <vector>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -471,11 +473,27 @@ constexpr int kWgradBlocks = 512;
 // Workgroups of `kernel` (256 threads, `lds` bytes of dynamic LDS) that the chip's 256 CUs keep resident at once.  The
 // persistent kernels below take AT MOST one such round: their blocks walk equal strided shares of the pixels, so blocks beyond
 // a round run alone behind it (2048 blocks of dwconv_fwd_stats<3, 1> on 768 resident places were 2.67 rounds).
+// The occupancy query costs a runtime call: the answer is cached per (kernel, LDS size) -- the step asks ~60 times -- and
+// the CU count is read from the device once.
 template <typename Kern>
 inline int resident_blocks(Kern kernel, size_t lds) {
+    struct Entry { const void* fn; size_t lds; int blocks; };
+    static std::mutex mu;
+    static std::vector<Entry> cache;
+    static int cus = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Entry& e : cache)
+        if (e.fn == (const void*)kernel && e.lds == lds) return e.blocks;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+    }
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    return per_cu * 256;
+    cache.push_back(Entry{(const void*)kernel, lds, per_cu * cus});
+    return per_cu * cus;
 }
 
 inline int status() {

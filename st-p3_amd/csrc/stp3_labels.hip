@@ -92,9 +92,10 @@ __global__ __launch_bounds__(256) void fill_polygons_kernel(const stp3_poly* __r
                     n_lt += xe < X ? 1 : 0;
                     n_le += xe <= X ? 1 : 0;
                 }
-                // between a pair of active edges (ceil(left) <= x <= floor(right)): an odd number of crossings strictly
-                // left of the pixel, or left of / at it
-                paint = paint || (n_lt & 1) || (n_le & 1);
+                // between a pair of the sorted active edges (ceil(left) <= x <= floor(right)): an odd number of crossings
+                // strictly left of the pixel -- or an even number and the next edge exactly AT the pixel (its partner
+                // cannot lie further left; two edges that meet at the pixel are the pair [x, x])
+                paint = paint || (n_lt & 1) || (n_le != n_lt);
                 if (paint) img[(size_t)y * W + x] = q.value;
             }
         }
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256) void instance_moments_kernel(int T, int H, int
 }
 
 __device__ __forceinline__ float mean_round(int sum, int cnt) {      // x[mask].mean().round(): float32 division, half to even
+    if (sum >= (1 << 24)) return (float)rint((double)sum / (double)cnt);   // beyond float32's exact integers
     return rintf((float)sum / (float)cnt);
 }
 
@@ -196,7 +198,10 @@ int stp3_instance_labels(int32_t T, int32_t H, int32_t W, int32_t K, float ignor
                          const int64_t* instance, const float* warped, void* workspace, size_t workspace_bytes,
                          float* center, float* offset, float* flow, void* stream) {
     if (T <= 0 || H <= 0 || W <= 0 || K < 0 || !instance || !workspace || !center || !offset || !flow) return STP3_EINVAL;
-    if ((int64_t)H * W >= (1LL << 24)) return STP3_EUNSUP;            // coordinate sums stay exact in float32 / int32
+    // an instance can cover the whole map: its coordinate sums reach H*W*max(H,W) and are accumulated in int32
+    // (mean_round divides sums below 2^24 in float32 -- exact operands, the reference's arithmetic -- and larger ones,
+    // where the reference's own float32 summation is no longer exact, in float64)
+    if ((int64_t)H * W * (H > W ? H : W) >= (1LL << 31)) return STP3_EUNSUP;
     const size_t need = (size_t)2 * T * (K + 1) * 3 * sizeof(int32_t);
     if (workspace_bytes < need) return STP3_ENOSPACE;
     hipStream_t s = (hipStream_t)stream;

@@ -789,162 +789,6 @@ __global__ __launch_bounds__(256, 6) void lift_column_mma_kernel(Dims dm, const 
     }
 }
 
-// Pass 1 as a software pipeline (the kernel the reference shapes run).  The one-column-per-workgroup form above spends
-// most of a workgroup's life waiting for its own loads (rocprof counters, profiles/r04_lift_pmc.json: 9 us per wave for
-// ~1.5 us of work): nothing in a workgroup overlaps the staging of a column with the arithmetic on it, and six resident
-// workgroups per CU are too few to hide it.  Here a workgroup owns a CHUNK of consecutive columns and has a FIFTH wave
-// that moves data and does nothing else: while the four compute waves work on column i out of one half of a two-deep LDS
-// ring, the loader has the LDS DMA of column i+1 in flight into the other half -- features, logits, and the column's run
-// descriptors and places (the compute waves issue no loads at all: their vmcnt holds stores only and is never waited
-// on).  Two workgroup barriers per column: A "column i has landed, column i-1 is done with", B "the softmax of column i is
-// complete".  Same arithmetic, same order, same bits as lift_column_mma_kernel.
-constexpr int kRingRuns = 256;      // run descriptors / places of a column staged in LDS (longer columns: the rest from memory)
-
-__global__ __launch_bounds__(320) void lift_column_ring_kernel(Dims dm, int chunk, const float* __restrict__ feat,
-                                                               const float* __restrict__ logits,
-                                                               const int32_t* __restrict__ col_off,
-                                                               const uint32_t* __restrict__ run_desc,
-                                                               const int32_t* __restrict__ run_place,
-                                                               float* __restrict__ prob_cm, float* __restrict__ slots) {
-    __shared__ __attribute__((aligned(16))) float ps_r[2][kMmaRows][64];   // logits, then probabilities (rotated rows)
-    __shared__ __attribute__((aligned(16))) float fs_r[2][kMmaRows][64];   // features
-    __shared__ __attribute__((aligned(16))) uint32_t dsc_r[2][kRingRuns];
-    __shared__ __attribute__((aligned(16))) int32_t plc_r[2][kRingRuns];
-    __shared__ int meta_r[2][2];                                           // slot of the column's first run, number of runs
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ncols = dm.BT * dm.NCOL;
-    const int c_lo = blockIdx.x * chunk, c_hi = min(c_lo + chunk, ncols);
-    const int D = dm.D, fH = dm.fH;
-    constexpr int C = 64;
-    const int rsub = lane >> 4, e0 = (lane & 15) * 4;
-    const int half = lane >> 5, l32 = lane & 31;
-
-    if (wv == 4) {
-        // ------------------------------------------------ the loader wave
-        // rows the DMA never writes must hold finite features (a = 0 multiplies them): zero both halves once
-        for (int r = fH + rsub; r < kMmaRows; r += 4) {
-            *reinterpret_cast<float4*>(&fs_r[0][r][e0]) = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&fs_r[1][r][e0]) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        auto issue = [&](int colg, int buf) {
-            const int bt = colg / dm.NCOL, col = colg - bt * dm.NCOL;
-            const int n = col / dm.fW, w = col - n * dm.fW;
-            const size_t pix0 = (size_t)bt * dm.NPIX + (size_t)n * fH * dm.fW + w;      // pixel (h = 0) of the column
-            const float* fcol = feat + pix0 * C;
-            const float* lcol = logits + pix0 * D;
-            const int slot0 = __builtin_amdgcn_readfirstlane(col_off[colg]);
-            const int nruns = __builtin_amdgcn_readfirstlane(col_off[colg + 1]) - slot0;
-#pragma unroll
-            for (int i = 0; i < kMmaRows / 4; ++i) {
-                const int r = 4 * i + rsub;
-                const int gb = (((lane & 15) - r) & 15) * 4;           // rotation of the probability rows, see prob_col
-                const unsigned rel = (unsigned)r * (unsigned)dm.fW;
-                if (r < fH && gb < D) lds_dma16(lcol + (rel * (unsigned)D + (unsigned)gb), &ps_r[buf][4 * i][0]);
-                if (r < fH) lds_dma16(fcol + (rel * (unsigned)C + (unsigned)e0), &fs_r[buf][4 * i][0]);
-            }
-#pragma unroll
-            for (int i = 0; i < kRingRuns / 64; ++i) {
-                if (64 * i + lane < nruns) {
-                    lds_dma4(run_desc + slot0 + 64 * i + lane, &dsc_r[buf][64 * i]);
-                    lds_dma4(run_place + slot0 + 64 * i + lane, &plc_r[buf][64 * i]);
-                }
-            }
-            if (lane == 0) {
-                meta_r[buf][0] = slot0;
-                meta_r[buf][1] = nruns;
-            }
-        };
-        if (c_lo < c_hi) issue(c_lo, 0);
-        int buf = 0;
-        for (int colg = c_lo; colg < c_hi; ++colg) {
-            lds_dma_wait();
-            __syncthreads();                                    // A: column colg has landed in half `buf`
-            if (colg + 1 < c_hi) issue(colg + 1, buf ^ 1);      //    the other half is free: everybody is past column colg-1
-            __syncthreads();                                    // B
-            buf ^= 1;
-        }
-        return;
-    }
-
-    // ---------------------------------------------------- the four compute waves
-    int buf = 0;
-    const int ksteps = (fH + 1) >> 1;
-    for (int colg = c_lo; colg < c_hi; ++colg, buf ^= 1) {
-        __syncthreads();                                        // A
-        float (*ps)[64] = ps_r[buf];
-        float (*fs)[64] = fs_r[buf];
-        const int slot0 = __builtin_amdgcn_readfirstlane(meta_r[buf][0]);
-        const int nruns = __builtin_amdgcn_readfirstlane(meta_r[buf][1]);
-        // ---- softmax over the bins of each pixel (its 16 lanes), in place: rows 8 wv .. 8 wv + 7
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = 8 * wv + 4 * i + rsub;
-            const int gb = (((lane & 15) - r) & 15) * 4;
-            const bool live = r < fH && gb < D;
-            float4 q = *reinterpret_cast<const float4*>(&ps[r][e0]);
-            if (!live) q = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-            const float mx = row16_max(fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
-            q.x = live ? __expf(q.x - mx) : 0.f;
-            q.y = live ? __expf(q.y - mx) : 0.f;
-            q.z = live ? __expf(q.z - mx) : 0.f;
-            q.w = live ? __expf(q.w - mx) : 0.f;
-            const float inv = 1.0f / row16_sum((q.x + q.y) + (q.z + q.w));
-            q.x = live ? q.x * inv : 0.f;
-            q.y = live ? q.y * inv : 0.f;
-            q.z = live ? q.z * inv : 0.f;
-            q.w = live ? q.w * inv : 0.f;
-            *reinterpret_cast<float4*>(&ps[r][e0]) = q;
-        }
-        __syncthreads();                                        // B
-        if (prob_cm) {
-            float* out = prob_cm + (size_t)colg * D * fH;
-            for (int d = 2 * wv + half; d < D; d += 8)
-                if (l32 < fH) out[d * fH + l32] = ps[l32][prob_col(l32, d)];
-        }
-        // ---- this wave's tiles: 32 runs each, round-robin
-        for (int r0 = 32 * wv; r0 < nruns; r0 += 128) {
-            const int idx = r0 + l32;
-            unsigned ds = 0x00000100u;                          // empty: first 1 > last 0
-            int place = 0;
-            if (idx < nruns) {
-                if (idx < kRingRuns) {
-                    ds = dsc_r[buf][idx];
-                    place = plc_r[buf][idx];
-                } else {
-                    ds = run_desc[slot0 + idx];
-                    place = run_place[slot0 + idx];
-                }
-            }
-            const int bin = (int)(ds & 255u), first = (int)((ds >> 8) & 255u), last = (int)(ds >> 16);
-            f32x16 acc0, acc1;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc0[k] = acc1[k] = 0.f;
-#pragma unroll
-            for (int s = 0; s < kMmaRows / 2; ++s) {
-                if (s < ksteps) {
-                    const int h = 2 * s + half;
-                    const float pr = ps[h][prob_col(h, bin)];
-                    const float a = ((h >= first) & (h <= last)) ? pr : 0.f;
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, fs[h][l32], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, fs[h][32 + l32], acc1, 0, 0, 0);
-                }
-            }
-            const int left = nruns - r0 - 4 * half;              // rows of this half that exist
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int row = (k & 3) + 8 * (k >> 2);
-                const int pk = __shfl(place, row + 4 * half);
-                if (row < left) {
-                    float* dst = slots + ((size_t)pk * C + l32);
-                    dst[0] = acc0[k];
-                    dst[32] = acc1[k];
-                }
-            }
-        }
-    }
-}
-
 // OUT = float: the reference's BEV type (stp3.py:230-232).  OUT = uint16_t: the same values rounded ONCE to bf16
 // (nearest even) -- what the bf16 temporal model makes of the float32 tensor in its first operator anyway: the kernel
 // then writes half the bytes and the consumer's cast pass (read 4, write 2 bytes per element) disappears.
@@ -1676,28 +1520,6 @@ int stp3_depth_softmax(const stp3_lift_dims* dims, const float* logits, float* p
     return launch_status();
 }
 
-// TEMPORARY A/B switch of the round-5 visit (STP3_LIFT_RING=0 selects the one-column-per-workgroup kernel); the loser
-// is deleted
-static bool ring_enabled() {
-    static const int on = [] { const char* e = getenv("STP3_LIFT_RING"); return e ? atoi(e) : 1; }();
-    return on != 0;
-}
-// workgroups of lift_column_ring_kernel that are resident at once (LDS: 36 KB each)
-static int ring_workgroups() {
-    static const int n = [] {
-        int per_cu = 0, dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-            return 1024;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lift_column_ring_kernel, 320, 0) != hipSuccess || per_cu < 1)
-            per_cu = 4;
-        const char* e = getenv("STP3_LIFT_RING_PER_CU");
-        if (e && atoi(e) > 0) per_cu = atoi(e);
-        return cus * per_cu;
-    }();
-    return n;
-}
-
 // forward: one slot (C floats) per run, at most one run per frustum point, then (channels-first output only) the
 // channels-last result in front of the transpose; backward: the imported gradient [BT][V][C]
 static size_t workspace_need(const Dims& dm) {
@@ -1742,12 +1564,7 @@ int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const flo
     float* out_cl = cf ? slots + (size_t)dm.BT * dm.P * dm.C : (float*)bev;
     const int ncols = dm.BT * dm.NCOL;
     const dim3 cgrid((ncols + 3) / 4);
-    if (column_mma_shape(dm) && ring_enabled()) {
-        const int resident = ring_workgroups();
-        const int chunk = (ncols + resident - 1) / resident;
-        hipLaunchKernelGGL(lift_column_ring_kernel, dim3((ncols + chunk - 1) / chunk), dim3(320), 0, s, dm, chunk, feat, logits,
-                           pv.col_off, pv.run_desc, pv.run_place, prob_cm, slots);
-    } else if (column_mma_shape(dm))
+    if (column_mma_shape(dm))
         hipLaunchKernelGGL(lift_column_mma_kernel, dim3(ncols), dim3(256), 0, s, dm, feat, logits, pv.col_off, pv.run_desc,
                            pv.run_place, prob_cm, slots);
     else if (dm.D <= 32)

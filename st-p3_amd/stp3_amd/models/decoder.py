@@ -97,6 +97,11 @@ class Decoder(nn.Module):
                    and bn.momentum == bns[0].momentum and bn.eps == bns[0].eps and bn.affine
                    for cv, bn in zip(convs, bns)) or c % 8:
             return None
+        # the merged BatchNorm updates float32 statistics in one packed buffer: a module converted to another dtype
+        # (``.half()`` / ``.bfloat16()``) keeps its own buffers and runs the heads one by one
+        if any(bn.running_mean is None or bn.running_mean.dtype != torch.float32 or bn.running_var.dtype != torch.float32
+               for bn in bns):
+            return None
         running_mean, running_var = self._packed_running_stats(bns)
         for bn in bns:
             if bn.num_batches_tracked is not None:
@@ -105,7 +110,7 @@ class Decoder(nn.Module):
         w1 = torch.cat([cv.weight for cv in convs], dim=0)                               # (heads * C, Cin, 3, 3)
         gamma, beta = torch.cat([bn.weight for bn in bns]), torch.cat([bn.bias for bn in bns])
         args = (x, w1, None, gamma, beta, None, running_mean, running_var,
-                float(bns[0].momentum if bns[0].momentum is not None else 0.1), float(bns[0].eps), int(ACT_RELU),
+                ops.bn_momentum(bns[0]), float(bns[0].eps), int(ACT_RELU),
                 int(ops.RES_NONE), 1, (1, 1), (1, 1), None if shared else False, None)
         out = {}
         if shared and others:

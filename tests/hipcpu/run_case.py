@@ -129,8 +129,8 @@ def lift_c64_many_runs(ops):        # 64 channels, ~190 runs per column: more ru
     return case_lift(ops, cfg, 1, 1, 1, 7)
 
 
-def lift_c64_ring_overflow(ops):    # 64 channels, 32 rows, 64 bins, rolled cameras: several hundred runs per column (more than the pipelined pass-1 kernel
-    from tests import helpers as H  # stages in LDS: the tail comes from memory) and chunks of three columns per workgroup on the stand-in's 8 CUs
+def lift_c64_rolled(ops):           # 64 channels, 32 rows, 64 bins, cameras rolled about their optical axis: up to ~1 800 runs per column and
+    from tests import helpers as H  # dozens of runs per voxel (tile loop of pass 1 far beyond four tiles, long contiguous places in pass 2)
     cfg = dict(H.SMALL, out_channels=64, final_dim=(64, 96), downsample=2, d_bound=(2.0, 34.0, 0.5),
                x_bound=(-36.0, 36.0, 0.25), y_bound=(-36.0, 36.0, 0.25))
     return case_lift(ops, cfg, 1, 1, 1, 17, roll=0.9)
@@ -743,13 +743,19 @@ def labels(ops):
     vals = [float(i % 7 + 1) for i in range(60)]
     idx = [i % 5 for i in range(60)]
     a = datas.fill_polygons(many, vals, idx, 5, (96, 104), device='cpu').numpy()
+    # thin, degenerate and self-touching polygons on a tiny lattice: edges meet exactly at pixel centres all the time
+    # (two sorted active edges AT one pixel are the pair [x, x] and paint it -- the closed form once missed that)
+    thin = [rng.integers(0, 14, (int(rng.integers(3, 9)), 2)) for _ in range(300)]
+    c = datas.fill_polygons(thin, [1.0] * 300, list(range(300)), 300, (16, 16), device='cpu').numpy()
     torch.Tensor.is_cuda = property(lambda self: False)
     b = datas.fill_polygons(many, vals, idx, 5, (96, 104)).numpy()
+    d = datas.fill_polygons(thin, [1.0] * 300, list(range(300)), 300, (16, 16)).numpy()
     torch.Tensor.is_cuda = is_cuda
     inst = torch.from_numpy(g['instance/ids'].astype(np.int64))
     ego = torch.from_numpy(g['instance/future_egomotion'])
     center, offset, flow = datas.instance_labels(inst, ego, int(g['instance/num_instances'][0]), spatial_extent=(50.0, 50.0))
     return {'fixture_mismatches': int((got.astype(np.uint8) != want).sum()), 'random_mismatches': int((a != b).sum()),
+            'thin_mismatches': int((c != d).sum()), 'thin_painted': int((c != 0).sum()),
             'painted': int((a != 0).sum()),
             'offset_mismatches': int((offset != torch.from_numpy(g['instance/offset'])).sum()),
             'flow_mismatches': int((flow != torch.from_numpy(g['instance/flow'])).sum()),
@@ -1357,7 +1363,7 @@ def fuzz(ops, seed=1):
     return {'problems': [[t, str(c), n, str(e)] for t, c, n, e in bad]}
 
 
-CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_ring_overflow, lift_c64_frames, lift_coarse_grid, lift_tall, lift_c64_rows56, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
+CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_rolled, lift_c64_frames, lift_coarse_grid, lift_tall, lift_c64_rows56, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
                                  conv, conv_f32, fan_out, aspp_join, pointwise_bn, pointwise_stream, decoder_heads, dwconv, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
 
 if __name__ == '__main__':

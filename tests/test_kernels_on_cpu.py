@@ -28,7 +28,7 @@ import build as hipcpu_build  # noqa: E402
 
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
 ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
-           ('conv', {}), ('conv_f32', {}), ('fan_out', {}), ('aspp_join', {}), ('pointwise_bn', {}), ('pointwise_stream', {}), ('decoder_heads', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('labels', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}), ('lift_c64_ring_overflow', {}),
+           ('conv', {}), ('conv_f32', {}), ('fan_out', {}), ('aspp_join', {}), ('pointwise_bn', {}), ('pointwise_stream', {}), ('decoder_heads', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('labels', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}), ('lift_c64_rolled', {}),
            ('lift_c64_frames', {}), ('lift_c64_rows56', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
 ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'pointwise_bn', 'pointwise_stream', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'labels', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)]
@@ -213,6 +213,7 @@ def test_label_kernels(results):
     painted over each other) and stp3_instance_labels (equal to the reference's own function)."""
     r = _get(results, 'labels')
     assert r['fixture_mismatches'] == 0 and r['random_mismatches'] == 0 and r['painted'] > 10000, r
+    assert r['thin_mismatches'] == 0 and r['thin_painted'] > 3000, r
     assert r['offset_mismatches'] == 0 and r['flow_mismatches'] == 0 and r['center_err'] <= 1e-6, r
 
 
@@ -296,9 +297,9 @@ def test_voxel_pool_many_runs_per_voxel(results):
     _check_lift(_get(results, 'lift_c64_many_runs'))
 
 
-def test_voxel_pool_pipelined_pass1_beyond_its_staged_runs(results):
-    r = _get(results, 'lift_c64_ring_overflow')
-    assert r['max_runs_per_column'] > 256          # kRingRuns: the tail of the column's descriptors comes from memory
+def test_voxel_pool_rolled_cameras_many_runs_per_column(results):
+    r = _get(results, 'lift_c64_rolled')
+    assert r['max_runs_per_column'] > 1000 and r['max_runs_per_voxel'] > 32
     _check_lift(r)
 
 

@@ -31,6 +31,11 @@ def test_polygon_fill_kernel():
     a = datas.fill_polygons(many, [1.0] * 60, list(range(60)), 60, (96, 104), device='cuda').cpu().numpy()
     b = datas.fill_polygons(many, [1.0] * 60, list(range(60)), 60, (96, 104)).numpy()
     assert np.array_equal(a, b)
+    # thin, degenerate and self-touching polygons on a tiny lattice: edges meet exactly at pixel centres all the time
+    thin = [rng.integers(0, 14, (int(rng.integers(3, 9)), 2)) for _ in range(300)]
+    c = datas.fill_polygons(thin, [1.0] * 300, list(range(300)), 300, (16, 16), device='cuda').cpu().numpy()
+    d = datas.fill_polygons(thin, [1.0] * 300, list(range(300)), 300, (16, 16)).numpy()
+    assert np.array_equal(c, d)
 
 
 def test_label_maps_from_boxes_on_the_gpu():
