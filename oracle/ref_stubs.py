@@ -8,18 +8,32 @@ arithmetic can be executed unmodified and used to pin the restatement in
 ``oracle/lift_oracle.py`` and to generate ``tests/golden`` fixtures
 (``oracle/make_golden.py``).
 
-Nothing under ``st-p3_amd/`` imports this file, and nothing that runs on the
-GPU box may: /root/reference does not exist there.
+Nothing under ``st-p3_amd/`` imports this file.  /root/reference does not exist on
+the GPU box: there the only importer is ``bench.py``'s ``cpu_baseline`` leg, which
+finds the archive ``__graft_entry__.build()`` left under ``oracle/_ref``
+(``oracle/snapshot_reference.py``; git-ignored).
 """
 import os
 import sys
 import types
 
-REFERENCE_ROOT = '/root/reference'
+REFERENCE_ROOT = os.environ.get('STP3_REFERENCE_ROOT', '/root/reference')     # (tests point it elsewhere to exercise the archive)
+SNAPSHOT_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ref')     # oracle/snapshot_reference.py
+
+
+def reference_root():
+    """Where the reference's ``stp3`` package can be imported from: the mounted tree in the build container, else the
+    verified archive ``__graft_entry__.build()`` left under oracle/_ref (what the GPU box has), else None."""
+    if os.path.isdir(os.path.join(REFERENCE_ROOT, 'stp3')):
+        return REFERENCE_ROOT
+    from oracle import snapshot_reference
+    if snapshot_reference.verify(SNAPSHOT_ROOT):
+        return snapshot_reference.archive_path(SNAPSHOT_ROOT)          # a zip archive: imported through zipimport
+    return None
 
 
 def reference_available():
-    return os.path.isdir(os.path.join(REFERENCE_ROOT, 'stp3'))
+    return reference_root() is not None
 
 
 def _mod(name, **attrs):
@@ -66,8 +80,9 @@ def install(efficientnet_cls=None, resnet18_fn=None):
     import numpy as np
     import torch.nn as nn
 
-    if not reference_available():
-        raise RuntimeError('reference tree not present (expected only in the build container)')
+    root = reference_root()
+    if root is None:
+        raise RuntimeError('reference tree not present (neither /root/reference nor a verified oracle/_ref snapshot)')
     if not hasattr(np, 'int'):
         np.int = int  # encoder.py:28,84 uses the removed alias
 
@@ -103,8 +118,8 @@ def install(efficientnet_cls=None, resnet18_fn=None):
     tv.models.resnet = _mod('torchvision.models.resnet', resnet18=resnet18_fn or _Dummy)
     _mod('efficientnet_pytorch', EfficientNet=efficientnet_cls or _Dummy)
 
-    if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
+    if root not in sys.path:
+        sys.path.insert(0, root)
 
 
 def make_reference_lifter(final_dim=(224, 480), x_bound=(-50.0, 50.0, 0.5), y_bound=(-50.0, 50.0, 0.5),
