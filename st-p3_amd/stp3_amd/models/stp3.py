@@ -65,7 +65,11 @@ class STP3(nn.Module):
         self.spatial_extent = (cfg.LIFT.X_BOUND[1], cfg.LIFT.Y_BOUND[1])
         self.bev_size = (int(dim[0]), int(dim[1]))
         if not cfg.MODEL.ENCODER.USE_DEPTH_DISTRIBUTION:
-            raise NotImplementedError('USE_DEPTH_DISTRIBUTION=False is not on the benchmarked path')
+            # the reference's encoder returns depth = None for this setting and its own encoder_forward then calls
+            # ``depth.view`` on it (stp3/models/stp3.py:217-222): the variant raises AttributeError in the reference before a
+            # BEV tensor exists, so there is no behaviour to reproduce (tests/test_oracle_golden.py pins that)
+            raise NotImplementedError('MODEL.ENCODER.USE_DEPTH_DISTRIBUTION=False is undefined in the reference '
+                                      '(stp3/models/stp3.py:222 dereferences the missing depth tensor)')
 
         self.encoder = Encoder(cfg=cfg.MODEL.ENCODER, D=self.depth_channels)
 

@@ -99,7 +99,8 @@ def test_full_forward_fp32_and_bf16_iou():
     assert abs(metric.compute()[1].item() - _iou(_iou_counts(o['segmentation'], batch))) < 1e-6
     # pose tensors may also arrive on the GPU (reference behaviour): same result
     o2 = model(img, batch['intrinsics'].cuda(), batch['extrinsics'].cuda(), batch['future_egomotion'].cuda())
-    torch.testing.assert_close(o2['segmentation'], o['segmentation'], rtol=1e-4, atol=1e-5)   # MIOpen convs are not bit-reproducible
+    # (float32 runs on the library's own split-MFMA convolutions, fixed summation orders everywhere: the same bits)
+    assert torch.equal(o2['segmentation'], o['segmentation'])
     # bf16 convolutions (the benchmarked precision), channels-last
     from stp3_amd.utils import to_channels_last
     model = to_channels_last(model)
