@@ -98,9 +98,8 @@ int stp3_voxel_index(const stp3_lift_dims* dims,
  * the same BEV cell most of the time; a RUN is a maximal set of consecutive h with one voxel
  * id >= 0.  The forward pass sums every run once (pass 1, per image column) into the run's SLOT and
  * then every voxel over its runs (pass 2); the plan numbers the runs (slot = position in the
- * enumeration frame, column, last row, depth bin) and gives every run its PLACE in the pass-1
- * output: the runs of a voxel are neighbours there, in ascending slot order, so that every voxel
- * is summed in ONE fixed order and pass 2 reads one contiguous stream per frame.
+ * enumeration frame, column, last row, depth bin) and lists them per voxel in ascending order, so
+ * that every voxel is summed in ONE fixed order.
  *
  *   stp3_lift_plan_bytes : size of the plan buffer for `dims`
  *   stp3_lift_plan_build : geometry inputs exactly as for stp3_voxel_index; writes
@@ -117,9 +116,8 @@ int stp3_voxel_index(const stp3_lift_dims* dims,
  *                                            column's first run; col_off[bt*N*fW] = first slot of frame bt; the
  *                                            last entry = total number of runs
  *                                   tmp      [B*T*P] int32      (scratch)
- *                                   run_place[B*T*P] int32      per slot: where pass 1 stores the run's vector =
- *                                            col_off[bt*N*fW] + vox_off[bt][v] + rank of the slot among the
- *                                            slots of its voxel v (ascending)
+ *                                   vox_runs [B*T*P] int32      slots of voxel v of frame bt, ascending, at
+ *                                            col_off[bt*N*fW] + vox_off[bt][v] .. + vox_off[bt][v+1]
  *                                   run_desc [B*T*P] uint32     per slot: depth bin | first row << 8 | last row << 16
  *                                   run_vox  [B*T*P] int32      per slot: the run's voxel
  *                          counts = int32 [B*T][V] scratch that must be ZERO on entry (the caller zero-fills

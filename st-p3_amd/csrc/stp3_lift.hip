@@ -148,10 +148,8 @@ __global__ __launch_bounds__(256) void voxel_index_kernel(Dims dm, const float* 
 //   col_off  [BT*NCOL+1]        exclusive scan of col_cnt over ALL frames = slot of the column's first run;
 //                               col_off[bt*NCOL] = first slot of frame bt, col_off[BT*NCOL] = total number of runs
 //   tmp      [BT*P]             per-voxel slot lists in arrival order (build scratch)
-//   run_place[BT*P]             per slot: the PLACE of the run's C-vector in the pass-1 output = col_off[bt*NCOL] +
-//                               vox_off[bt][v] + (rank of the slot among the slots of voxel v, ascending).  The runs of a
-//                               voxel are neighbours in the buffer, in ascending slot order, and the voxels follow each
-//                               other: pass 2 reads ONE contiguous stream per frame, no list to chase
+//   vox_runs [BT*P]             per-voxel slot lists, ascending: the runs of voxel v of frame bt are
+//                               vox_runs[col_off[bt*NCOL] + vox_off[bt][v] ... + vox_off[bt][v+1])
 //   run_desc [BT*P]             per slot: depth bin | first row << 8 | last row << 16 of the run
 //   run_vox  [BT*P]             per slot: the run's voxel
 // Replaces the reference's boolean mask + argsort + cumsum differencing (stp3.py:247-257, geometry.py:302-318).
@@ -167,7 +165,7 @@ struct PlanView {
     int32_t* col_cnt;
     int32_t* col_off;
     int32_t* tmp;
-    int32_t* run_place;
+    int32_t* vox_runs;
     uint32_t* run_desc;
     int32_t* run_vox;
 };
@@ -200,7 +198,7 @@ inline PlanView plan_view(const Dims& dm, void* base) {
     pv.col_cnt = (int32_t*)(p + o[2]);
     pv.col_off = (int32_t*)(p + o[3]);
     pv.tmp = (int32_t*)(p + o[4]);
-    pv.run_place = (int32_t*)(p + o[5]);
+    pv.vox_runs = (int32_t*)(p + o[5]);
     pv.run_desc = (uint32_t*)(p + o[6]);
     pv.run_vox = (int32_t*)(p + o[7]);
     return pv;
@@ -390,13 +388,12 @@ __global__ __launch_bounds__(256) void plan_fill_kernel(Dims dm, const int32_t* 
     }
 }
 
-// (5) the atomics in (4) hand out the positions in arrival order; this ranks every voxel's list (slots ascending = ONE
-//     canonical summation order: bit-reproducible results, no floating-point atomics anywhere) and tells every run
-//     its PLACE: first place of the frame + first place of the voxel + rank.  Lane = voxel for the usual short lists
-//     (rank sort: a handful of entries); a list longer than 32 is ranked by the whole wave.
+// (5) the atomics in (4) hand out the places in arrival order; this makes every voxel's list ascending -- ONE canonical
+//     summation order (bit-reproducible results, no floating-point atomics anywhere).  Lane = voxel for the usual short
+//     lists (rank sort: a handful of entries); a list longer than 32 is ranked by the whole wave.
 __global__ __launch_bounds__(256) void plan_sort_kernel(Dims dm, const int32_t* __restrict__ vox_off,
                                                         const int32_t* __restrict__ col_off,
-                                                        const int32_t* __restrict__ tmp, int32_t* __restrict__ run_place) {
+                                                        const int32_t* __restrict__ tmp, int32_t* __restrict__ vox_runs) {
     const int bt = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int v = blockIdx.x * 256 + threadIdx.x;
@@ -408,12 +405,13 @@ __global__ __launch_bounds__(256) void plan_sort_kernel(Dims dm, const int32_t* 
         n = off[v + 1] - beg;
     }
     const int32_t* src = tmp + (size_t)frame0;
+    int32_t* dst = vox_runs + (size_t)frame0;
     if (n <= 32) {
         for (int i = 0; i < n; ++i) {
             const int e = src[beg + i];
             int rank = 0;
             for (int j = 0; j < n; ++j) rank += src[beg + j] < e ? 1 : 0;       // slots are distinct
-            run_place[e] = frame0 + beg + rank;
+            dst[beg + rank] = e;
         }
     }
     unsigned long long big = __ballot(n > 32);
@@ -425,7 +423,7 @@ __global__ __launch_bounds__(256) void plan_sort_kernel(Dims dm, const int32_t* 
             const int e = src[bb + i];
             int rank = 0;
             for (int j = 0; j < nn; ++j) rank += src[bb + j] < e ? 1 : 0;
-            run_place[e] = frame0 + bb + rank;
+            dst[bb + rank] = e;
         }
     }
 }
@@ -509,34 +507,16 @@ __device__ __forceinline__ void fma_group(float (&acc)[64], const float (&pv)[4]
     fmac_row_bcast<(4 * GRP + 3) & 15>(acc[4 * GRP + 3], pv[GRP >> 2], f);
 }
 
-// where the runs of a column go: run k of the column (in the order the walk meets the run ends = slot order) is
-// stored at its PLACE (run_place, see the plan).  Lane i of `win` holds the place of run (cnt & ~63) + i: a run end reads
-// its place with one v_readlane, the window is reloaded (one coalesced load) every 64 runs.
-struct RunOut {
-    float* slots;
-    const int32_t* places;      // run_place + first slot of the column (wave-uniform)
-    int nruns, cnt, win;
-    __device__ __forceinline__ void open(float* s, const int32_t* pl, int n, int lane) {
-        slots = s; places = pl; nruns = n; cnt = 0;
-        win = lane < n ? pl[lane] : 0;
-    }
-    __device__ __forceinline__ void emit(float v, int lane_c, int lane, int C) {
-        const int place = __builtin_amdgcn_readlane(win, cnt & 63);
-        if (lane_c >= 0) slots[(size_t)place * C + lane_c] = v;
-        ++cnt;
-        if ((cnt & 63) == 0) win = cnt + lane < nruns ? places[cnt + lane] : 0;
-    }
-};
-
 // the runs of bins 4g .. 4g+3 that end at this row (nib: their 4 mask bits, wave-uniform): store and clear
 template <int GRP>
-__device__ __forceinline__ void emit_group(float (&acc)[64], unsigned nib, int lane_c, int lane, RunOut& ro, int C) {
+__device__ __forceinline__ void emit_group(float (&acc)[64], unsigned nib, int lane_c, float*& sp, int C) {
     if (nib == 0u) return;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if ((nib >> k) & 1u) {
-            ro.emit(acc[4 * GRP + k], lane_c, lane, C);
+            if (lane_c >= 0) sp[lane_c] = acc[4 * GRP + k];         // sp: wave-uniform, the run's slot
             acc[4 * GRP + k] = 0.f;
+            sp += C;
         }
     }
 }
@@ -544,16 +524,16 @@ __device__ __forceinline__ void emit_group(float (&acc)[64], unsigned nib, int l
 template <int G, int GRP>
 struct ColumnRow {
     static __device__ __forceinline__ void run(float (&acc)[64], const float (&pv)[4], float f, unsigned lo, unsigned hi,
-                                               int lane_c, int lane, RunOut& ro, int C) {
+                                               int lane_c, float*& sp, int C) {
         fma_group<GRP>(acc, pv, f);
-        emit_group<GRP>(acc, ((GRP < 8 ? lo : hi) >> ((4 * GRP) & 31)) & 15u, lane_c, lane, ro, C);
-        ColumnRow<G, GRP + 1>::run(acc, pv, f, lo, hi, lane_c, lane, ro, C);
+        emit_group<GRP>(acc, ((GRP < 8 ? lo : hi) >> ((4 * GRP) & 31)) & 15u, lane_c, sp, C);
+        ColumnRow<G, GRP + 1>::run(acc, pv, f, lo, hi, lane_c, sp, C);
     }
 };
 template <int G>
 struct ColumnRow<G, G> {
-    static __device__ __forceinline__ void run(float (&)[64], const float (&)[4], float, unsigned, unsigned, int, int,
-                                               RunOut&, int) {}
+    static __device__ __forceinline__ void run(float (&)[64], const float (&)[4], float, unsigned, unsigned, int, float*&,
+                                               int) {}
 };
 
 template <int G>   // depth bins in groups of 4: D <= 4 G
@@ -561,7 +541,6 @@ __global__ __launch_bounds__(256, G <= 12 ? 5 : 4) void lift_column_kernel(Dims 
                                                           const float* __restrict__ logits,
                                                           const Mask2* __restrict__ masks,
                                                           const int32_t* __restrict__ col_off,
-                                                          const int32_t* __restrict__ run_place,
                                                           float* __restrict__ prob_cm, float* __restrict__ slots) {
     __shared__ __attribute__((aligned(16))) float prob_s[4][kColRows][64];
     __shared__ __attribute__((aligned(16))) float feat_s[4][kColRows][64];
@@ -579,9 +558,7 @@ __global__ __launch_bounds__(256, G <= 12 ? 5 : 4) void lift_column_kernel(Dims 
     const float* fcol = feat + pix0 * C;        // wave-uniform bases; the per-lane parts fit 32 bits (pool_limits)
     const float* lcol = logits + pix0 * D;
     const bool chan = lane < C;
-    const int slot0 = __builtin_amdgcn_readfirstlane(col_off[colg]);                // slot of the column's first run
-    RunOut ro;
-    ro.open(slots, run_place + slot0, __builtin_amdgcn_readfirstlane(col_off[colg + 1]) - slot0, lane);
+    float* sp = slots + (size_t)__builtin_amdgcn_readfirstlane(col_off[colg]) * C;   // slot of the next run that ends
     const int lane_c = chan ? lane : -1;
     float acc[64];
 #pragma unroll
@@ -663,7 +640,7 @@ __global__ __launch_bounds__(256, G <= 12 ? 5 : 4) void lift_column_kernel(Dims 
             float pv[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) pv[k] = (4 * k < G) ? ps[i][prob_col(i, 16 * k + (lane & 15))] : 0.f;
-            ColumnRow<G, 0>::run(acc, pv, f, lo, hi, lane_c, lane, ro, C);
+            ColumnRow<G, 0>::run(acc, pv, f, lo, hi, lane_c, sp, C);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -687,7 +664,6 @@ __global__ __launch_bounds__(256, 6) void lift_column_mma_kernel(Dims dm, const 
                                                                 const float* __restrict__ logits,
                                                                 const int32_t* __restrict__ col_off,
                                                                 const uint32_t* __restrict__ run_desc,
-                                                                const int32_t* __restrict__ run_place,
                                                                 float* __restrict__ prob_cm,
                                                                 float* __restrict__ slots) {
     __shared__ __attribute__((aligned(16))) float ps[kMmaRows][64];       // logits, then probabilities (rotated rows)
@@ -720,7 +696,6 @@ __global__ __launch_bounds__(256, 6) void lift_column_mma_kernel(Dims dm, const 
     const int nruns = __builtin_amdgcn_readfirstlane(col_off[colg + 1]) - slot0;
     // descriptor of this wave's first tile (issued with the other loads: a load behind stores waits for them)
     unsigned ds = (32 * wv + l32 < nruns) ? run_desc[slot0 + 32 * wv + l32] : 0x00000100u;   // empty: first 1 > last 0
-    int pl = (32 * wv + l32 < nruns) ? run_place[slot0 + 32 * wv + l32] : 0;                 // where run l32 of the tile goes
     lds_dma_wait();
     __builtin_amdgcn_wave_barrier();
     // ---- softmax over the bins of each pixel (its 16 lanes), in place
@@ -755,11 +730,7 @@ __global__ __launch_bounds__(256, 6) void lift_column_mma_kernel(Dims dm, const 
     const int ksteps = (fH + 1) >> 1;
     for (int r0 = 32 * wv; r0 < nruns; r0 += 128) {
         const int bin = (int)(ds & 255u), first = (int)((ds >> 8) & 255u), last = (int)(ds >> 16);
-        const int place = pl;
-        if (r0 + 128 < nruns) {
-            ds = (r0 + 128 + l32 < nruns) ? run_desc[slot0 + r0 + 128 + l32] : 0x00000100u;
-            pl = (r0 + 128 + l32 < nruns) ? run_place[slot0 + r0 + 128 + l32] : 0;
-        }
+        if (r0 + 128 < nruns) ds = (r0 + 128 + l32 < nruns) ? run_desc[slot0 + r0 + 128 + l32] : 0x00000100u;
         f32x16 acc0, acc1;
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc0[k] = acc1[k] = 0.f;
@@ -773,17 +744,15 @@ __global__ __launch_bounds__(256, 6) void lift_column_mma_kernel(Dims dm, const 
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, fs[h][32 + l32], acc1, 0, 0, 0);
             }
         }
-        // D[row = (k & 3) + 8 (k >> 2) + 4 half][col = l32]: register k of the lower / upper half-wave is a 128-byte
-        // piece of run `row`, stored at the run's PLACE
+        // D[row = (k & 3) + 8 (k >> 2) + 4 half][col = l32]: two 128-byte pieces of two slots per store
+        float* tile = slots + (size_t)(slot0 + r0) * C + (4 * half * C + l32);
         const int left = nruns - r0 - 4 * half;              // rows of this half that exist
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int row = (k & 3) + 8 * (k >> 2);
-            const int pk = __shfl(place, row + 4 * half);    // every lane takes part: ds_bpermute reads live lanes only
             if (row < left) {
-                float* dst = slots + ((size_t)pk * C + l32);
-                dst[0] = acc0[k];
-                dst[32] = acc1[k];
+                tile[row * C] = acc0[k];
+                tile[row * C + 32] = acc1[k];
             }
         }
     }
@@ -795,51 +764,50 @@ __global__ __launch_bounds__(256, 6) void lift_column_mma_kernel(Dims dm, const 
 template <typename OUT, int TM>    // TM: frames handled by the prefetching form (T <= TM), 0: any T, frame by frame
 __global__ __launch_bounds__(256) void lift_gather_kernel(Dims dm, const float* __restrict__ slots,
                                                           const int32_t* __restrict__ vox_off,
-                                                          const int32_t* __restrict__ col_off, float discount,
+                                                          const int32_t* __restrict__ col_off,
+                                                          const int32_t* __restrict__ vox_runs, float discount,
                                                           OUT* __restrict__ bev_cl) {
     const int b = blockIdx.y;
     const int v = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int c4 = (threadIdx.x & 15) * 4;
     if (v >= dm.V || c4 >= dm.C) return;
-    // Pass 1 left every run at its PLACE: the runs of voxel v of frame bt are the rows  first place of the frame +
-    // vox_off[bt][v] .. + vox_off[bt][v+1]  of `slots`, in ascending slot order, and the 16 voxels of this workgroup
-    // follow each other -- the kernel reads one contiguous stream per frame.  Two dependent loads per thread (offsets,
-    // rows); the offsets of ALL frames are fetched first, then the first two rows of every frame (most voxels hold
-    // 0-2 runs per frame).  The summation order (slots ascending, frames ascending) is the plan's canonical one.
+    // The chain  offsets -> list entry -> slot row  is three dependent loads per frame; walked frame by frame that
+    // was 3 T memory latencies per thread and the kernel sat at 3.5 TB/s with SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.92.  The
+    // frames are independent up to the final recurrence, so the offsets of ALL frames are fetched first, then the first
+    // list entry of every frame, then the first slot row of every frame (most voxels hold 0-2 runs per frame): three
+    // latencies in total.  The summation order (slots ascending, frames ascending) is unchanged: same bits.
     float4 st = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (TM > 0) {
-        int beg[TM > 0 ? TM : 1], end[TM > 0 ? TM : 1];
+        constexpr int TA = TM > 0 ? TM : 1;
+        int beg[TA], end[TA], first[TA];
+        const int32_t* lists[TA];
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             beg[t] = end[t] = 0;
             if (t < dm.T) {
                 const int bt = b * dm.T + t;
                 const int32_t* off = vox_off + (size_t)bt * (dm.V + 1) + v;
-                const int frame0 = col_off[bt * dm.NCOL];
-                beg[t] = frame0 + off[0];
-                end[t] = frame0 + off[1];
+                beg[t] = off[0];
+                end[t] = off[1];
+                lists[t] = vox_runs + (size_t)col_off[bt * dm.NCOL];
             }
         }
-        float4 q0[TM > 0 ? TM : 1], q1[TM > 0 ? TM : 1];
 #pragma unroll
-        for (int t = 0; t < TM; ++t) {
-            const float* row = slots + (size_t)beg[t] * dm.C + c4;
-            q0[t] = beg[t] < end[t] ? *reinterpret_cast<const float4*>(row) : zero;
-            q1[t] = beg[t] + 1 < end[t] ? *reinterpret_cast<const float4*>(row + dm.C) : zero;
-        }
+        for (int t = 0; t < TM; ++t) first[t] = (t < dm.T && beg[t] < end[t]) ? lists[t][beg[t]] : -1;
+        float4 q0[TA];
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+            q0[t] = first[t] >= 0 ? *reinterpret_cast<const float4*>(slots + (size_t)first[t] * dm.C + c4)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             if (t < dm.T) {
-                float4 pool = zero;
-                if (beg[t] < end[t]) {
+                float4 pool = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (first[t] >= 0) {
                     pool.x += q0[t].x; pool.y += q0[t].y; pool.z += q0[t].z; pool.w += q0[t].w;
-                    if (beg[t] + 1 < end[t]) {
-                        pool.x += q1[t].x; pool.y += q1[t].y; pool.z += q1[t].z; pool.w += q1[t].w;
-                        for (int i = beg[t] + 2; i < end[t]; ++i) {
-                            const float4 q = *reinterpret_cast<const float4*>(slots + (size_t)i * dm.C + c4);
-                            pool.x += q.x; pool.y += q.y; pool.z += q.z; pool.w += q.w;
-                        }
+                    for (int i = beg[t] + 1; i < end[t]; ++i) {
+                        const float4 q = *reinterpret_cast<const float4*>(slots + (size_t)lists[t][i] * dm.C + c4);
+                        pool.x += q.x; pool.y += q.y; pool.z += q.z; pool.w += q.w;
                     }
                 }
                 st.x = st.x * discount + pool.x;              // stp3.py:296
@@ -859,11 +827,11 @@ __global__ __launch_bounds__(256) void lift_gather_kernel(Dims dm, const float* 
     for (int t = 0; t < dm.T; ++t) {
         const int bt = b * dm.T + t;
         const int32_t* off = vox_off + (size_t)bt * (dm.V + 1) + v;
-        const int frame0 = col_off[bt * dm.NCOL];
-        const int beg = frame0 + off[0], end = frame0 + off[1];
-        float4 pool = zero;
+        const int beg = off[0], end = off[1];
+        const int32_t* list = vox_runs + (size_t)col_off[bt * dm.NCOL];
+        float4 pool = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = beg; i < end; ++i) {
-            const float4 q = *reinterpret_cast<const float4*>(slots + (size_t)i * dm.C + c4);
+            const float4 q = *reinterpret_cast<const float4*>(slots + (size_t)list[i] * dm.C + c4);
             pool.x += q.x; pool.y += q.y; pool.z += q.z; pool.w += q.w;
         }
         st.x = st.x * discount + pool.x;              // stp3.py:296
@@ -1496,7 +1464,7 @@ int stp3_lift_plan_build(const stp3_lift_dims* dims, const float* cam_m, const f
     hipLaunchKernelGGL(plan_fill_kernel, cgrid, dim3(256), 0, s, dm, vox_cm, pv.masks, pv.col_off, pv.vox_off, counts, pv.tmp,
                        pv.run_desc, pv.run_vox);
     hipLaunchKernelGGL(plan_sort_kernel, dim3((dm.V + 255) / 256, dm.BT), dim3(256), 0, s, dm, pv.vox_off, pv.col_off, pv.tmp,
-                       pv.run_place);
+                       pv.vox_runs);
     return launch_status();
 }
 
@@ -1566,26 +1534,26 @@ int stp3_lift_splat_fwd(const stp3_lift_dims* dims, const float* feat, const flo
     const dim3 cgrid((ncols + 3) / 4);
     if (column_mma_shape(dm))
         hipLaunchKernelGGL(lift_column_mma_kernel, dim3(ncols), dim3(256), 0, s, dm, feat, logits, pv.col_off, pv.run_desc,
-                           pv.run_place, prob_cm, slots);
+                           prob_cm, slots);
     else if (dm.D <= 32)
-        hipLaunchKernelGGL(lift_column_kernel<8>, cgrid, dim3(256), 0, s, dm, feat, logits, pv.masks, pv.col_off, pv.run_place,
-                           prob_cm, slots);
+        hipLaunchKernelGGL(lift_column_kernel<8>, cgrid, dim3(256), 0, s, dm, feat, logits, pv.masks, pv.col_off, prob_cm, slots);
     else if (dm.D <= 48)
-        hipLaunchKernelGGL(lift_column_kernel<12>, cgrid, dim3(256), 0, s, dm, feat, logits, pv.masks, pv.col_off, pv.run_place,
-                           prob_cm, slots);
+        hipLaunchKernelGGL(lift_column_kernel<12>, cgrid, dim3(256), 0, s, dm, feat, logits, pv.masks, pv.col_off, prob_cm, slots);
     else
-        hipLaunchKernelGGL(lift_column_kernel<16>, cgrid, dim3(256), 0, s, dm, feat, logits, pv.masks, pv.col_off, pv.run_place,
-                           prob_cm, slots);
+        hipLaunchKernelGGL(lift_column_kernel<16>, cgrid, dim3(256), 0, s, dm, feat, logits, pv.masks, pv.col_off, prob_cm, slots);
+    // the prefetching form keeps the offsets, first list entries and first slot rows of all frames in registers:
+    // instantiated per frame count (T = 3: 8 waves per SIMD where the 8-frame form left 5)
     const dim3 ggrid((dm.V + 15) / 16, dm.B);
-#define STP3_GATHER(OUT, TM, ptr) \
-    hipLaunchKernelGGL((lift_gather_kernel<OUT, TM>), ggrid, dim3(256), 0, s, dm, slots, pv.vox_off, pv.col_off, discount, ptr)
+#define STP3_GATHER(OUT, TM, ptr)                                                                                     \
+    hipLaunchKernelGGL((lift_gather_kernel<OUT, TM>), ggrid, dim3(256), 0, s, dm, slots, pv.vox_off, pv.col_off,      \
+                       pv.vox_runs, discount, ptr)
     if (out_bf16) {
         if (dm.T <= 3) STP3_GATHER(uint16_t, 3, (uint16_t*)bev);
-        else if (dm.T <= 6) STP3_GATHER(uint16_t, 6, (uint16_t*)bev);
+        else if (dm.T <= 8) STP3_GATHER(uint16_t, 8, (uint16_t*)bev);
         else STP3_GATHER(uint16_t, 0, (uint16_t*)bev);
     } else {
         if (dm.T <= 3) STP3_GATHER(float, 3, out_cl);
-        else if (dm.T <= 6) STP3_GATHER(float, 6, out_cl);
+        else if (dm.T <= 8) STP3_GATHER(float, 8, out_cl);
         else STP3_GATHER(float, 0, out_cl);
     }
 #undef STP3_GATHER

@@ -16,7 +16,7 @@ import torch.nn as nn
 from .. import ops
 from ..utils import hp
 from .fused import (ACT_NONE, ACT_RELU, RES_AFTER_ACT, _sync_world, bn_act, bn_act_group, conv1x1_on_vector, conv2d,
-                    conv_bn_act_member, conv_module, plane_mean, run_fused)
+                    conv_bn_act_member, conv_module, plane_mean, pooled_bias, run_fused)
 from .fused import _emu as fused_emu
 
 
@@ -180,7 +180,7 @@ class ASPP(nn.Module):
         y = conv2d(spatial, w_sp)
         # the pooled branch is a constant plane per sample: its projection is a per-sample bias, folded
         # into the fused BatchNorm instead of a broadcast add over the whole map
-        sbias = hp(conv1x1_on_vector(pooled, w_pool).flatten(1))
+        sbias = pooled_bias(hp(conv1x1_on_vector(pooled, w_pool).flatten(1)))
         return drop(bn_act(bn, y, ACT_RELU, sbias=sbias))
 
 

@@ -43,6 +43,24 @@ class _RoundBf16(torch.autograd.Function):
         return g.to(torch.bfloat16).to(g.dtype)
 
 
+# Test instrumentation (tests/test_train_parity_gpu.py, link 2d): the per-sample bias that a pooled-descriptor branch (ASPP
+# image pooling, pyramid pooling) contributes to the fused BatchNorm behind it can be recorded in one run and replayed --
+# as a constant -- in others: the spatial path of such a block is then compared between two evaluations WITHOUT the
+# ill-conditioned BatchNorm over a dozen pooled vectors in the loop.  None in normal operation.
+POOLED_BIAS_TAP = None          # None | ('record', list) | ('replay', iterator)
+
+
+def pooled_bias(t):
+    tap = POOLED_BIAS_TAP
+    if tap is None or t is None:
+        return t
+    mode, store = tap
+    if mode == 'record':
+        store.append(t.detach().clone())
+        return t
+    return next(store).to(device=t.device, dtype=t.dtype)
+
+
 def _emu(x):
     return _RoundBf16.apply(x) if (EMULATE_BF16 and torch.is_tensor(x) and x.dtype == torch.float32) else x
 

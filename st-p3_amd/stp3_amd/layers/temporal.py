@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..utils import hp
-from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, bn_act_group, conv1x1_on_vector, conv2d, plane_mean
+from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, bn_act_group, conv1x1_on_vector, conv2d, plane_mean, pooled_bias
 
 
 def _pad8(c):
@@ -319,7 +319,7 @@ class TemporalBlock(nn.Module):
                     y = y + contrib
         assert self.projection is not None or extra is None
         skip = x_skip if self.projection is None else heads[-1]
-        out = _bn_act_2d(agg.norm, y, res=skip, sbias=sbias)
+        out = _bn_act_2d(agg.norm, y, res=skip, sbias=pooled_bias(sbias))
         return out.view(b, t, -1, h, w).permute(0, 2, 1, 3, 4)
 
 

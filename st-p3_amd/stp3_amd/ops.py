@@ -222,7 +222,7 @@ class LiftPlan:
         return self.vox_cm.view(d.B, d.T, d.N, d.fW, d.D, d.fH).permute(0, 1, 2, 4, 5, 3)
 
     def _sections(self):
-        """Byte offsets of the plan's sections (include/stp3_hip.h: vox_off, masks, col_cnt, col_off, tmp, run_place,
+        """Byte offsets of the plan's sections (include/stp3_hip.h: vox_off, masks, col_cnt, col_off, tmp, vox_runs,
         run_desc, run_vox)."""
         d = self.dims
         a = self._align256
@@ -262,10 +262,9 @@ class LiftPlan:
         o = self._sections()[7]
         return self.plan[o:o + d.BT * d.P * 4].view(torch.int32)
 
-    def run_places(self):
-        """[BT*P] int32 view, one word per slot: the PLACE of the run's vector in the pass-1 output.  Voxel v of frame
-        bt owns the places ``[column_offsets()[bt*N*fW] + offsets()[bt, v], ... + offsets()[bt, v+1])``; its runs sit
-        there in ascending slot order."""
+    def run_lists(self):
+        """[BT*P] int32 view: the per-voxel slot lists; voxel v of frame bt owns
+        ``[column_offsets()[bt*N*fW] + offsets()[bt, v], ... + offsets()[bt, v+1])``, ascending."""
         d = self.dims
         o = self._sections()[5]
         return self.plan[o:o + d.BT * d.P * 4].view(torch.int32)

@@ -130,9 +130,8 @@ def check_plan_structure(plan, vox):
     """The pooling plan against the voxel ids it was built from (include/stp3_hip.h, plan sections).
     ``vox``: (BT, N, D, fH, fW) ids in the reference's order.  A RUN is a maximal stretch of consecutive rows of an
     image column and depth bin with one id >= 0; its SLOT is its position in the enumeration frame, column, LAST row,
-    depth bin; its PLACE (where pass 1 leaves its vector) is first place of the frame + first place of its voxel + its
-    rank among the voxel's runs in ascending slot order.  Checks the row masks, the column scan, the per-voxel scan
-    and the places of all runs.  Returns the total number of runs."""
+    depth bin.  Checks the row masks, the column scan, the per-voxel scan and that every voxel lists exactly the slots
+    of its runs in ascending order.  Returns the total number of runs."""
     d = plan.dims
     vox = np.asarray(vox).reshape(d.BT, d.N, d.D, d.fH, d.fW)
     nxt = np.concatenate([vox[:, :, :, 1:], np.full_like(vox[:, :, :, :1], -1)], axis=3)
@@ -163,7 +162,7 @@ def check_plan_structure(plan, vox):
     assert np.array_equal(plan.run_descriptors().cpu().numpy()[:len(want_desc)], want_desc), 'run descriptors'
     assert np.array_equal(plan.run_voxels().cpu().numpy()[:len(want_desc)], vox_c[bt_i, col_i, h_i, d_i]), 'run voxels'
     off = plan.offsets().cpu().numpy()
-    places = plan.run_places().cpu().numpy()
+    lists = plan.run_lists().cpu().numpy()
     for bt in range(d.BT):
         e = ends_c[bt].reshape(-1)
         ids = vox_c[bt].reshape(-1)[e]
@@ -172,7 +171,7 @@ def check_plan_structure(plan, vox):
         frame0 = col_off[bt * d.N * d.fW]
         assert off[bt][-1] == col_off[(bt + 1) * d.N * d.fW] - frame0
         by_voxel = np.lexsort((slots, ids))                        # voxel ascending, then slot ascending
-        assert np.array_equal(places[slots[by_voxel]], frame0 + np.arange(len(slots))), f'run places of frame {bt}'
+        assert np.array_equal(lists[frame0:frame0 + len(slots)], slots[by_voxel]), f'run lists of frame {bt}'
     assert int(plan.counts.abs().max()) == 0, 'count scratch not left clean'
     return int(col_off[-1])
 

@@ -243,10 +243,18 @@ PROBE_FACTOR = 6.0                                        # ... or this many tim
 # agree with the emulation to <= 2e-3 (outputs), <= 2.4e-3 (parameter gradients), <= 5.1e-3 (input gradients) where they
 # differ from their float32 run by 2e-3 .. 1e-1: those distances ARE rounding.  The 5 blocks that normalise POOLED
 # descriptors over a population of B*T = 6 / 12 vectors (the two TemporalBlocks' pyramid pooling, the image-pooling branch
-# of the three DeepLabHeads: near-equal values divided by their tiny spread) are ill-conditioned: the two bf16 evaluations
-# differ from EACH OTHER by as much as either differs from float32 (0.19 vs 0.22 on the worst block) -- no implementation
-# can be pinned tighter than the probe-scaled bound of link 2b there.
+# of the three DeepLabHeads: near-equal values divided by their tiny spread) are ill-conditioned THERE and only there: with
+# the pooled branch in the loop the two bf16 evaluations differ from EACH OTHER by as much as either differs from float32
+# (0.19 vs 0.22 on the worst block, profiles/r04end_parity.json).
+# link 2d (round 5): those five blocks hold 67 of the model's 146 GMAC, so they are pinned in two pieces instead of being
+# exempted.  (i) The per-sample bias their pooled branch contributes to the fused BatchNorm behind it (a float32 quantity in
+# the product on every path) is TEACHER-FORCED: recorded from the block's float32 run and replayed as a constant in the
+# bf16 run and in the bf16 emulation alike (layers/fused.POOLED_BIAS_TAP) -- everything else of the block, i.e. its
+# convolutions, BatchNorms, lane padding, dead-tap drop and causal pairing, must then meet EMU_TOL like any other block.
+# (ii) The pooled branch itself is pinned where it is computed, in float32: its bias in the float32 run against the
+# block's float64 evaluation (DESCRIPTOR_TOL), and -- in link 2a, unchanged -- the whole block incl. that branch.
 EMU_TOL = dict(out=5e-3, dparam=1e-2, dx=2e-2)
+DESCRIPTOR_TOL = 1e-3
 POOLED_BLOCKS = ('temporal_model.model.0', 'temporal_model.model.1', 'temporal_model.final_conv', 'encoder.depth_layer_1',
                  'encoder.feature_layer_1')
 
@@ -314,7 +322,7 @@ def test_bf16_blocks_teacher_forced_from_the_float32_step():
 
     heads = {getattr(dec, a) for a in head_of.values()}
 
-    def run(mod, args, kwargs, gout, mode):
+    def run(mod, args, kwargs, gout, mode, tap=None):
         mod.zero_grad(set_to_none=True)
         if mode == 'f64':
             mod.double()                       # float64 tensors take the torch statements everywhere (layers/fused.bn_act)
@@ -335,12 +343,14 @@ def test_bf16_blocks_teacher_forced_from_the_float32_step():
               for k, v in kwargs.items()}
         from stp3_amd.layers import fused as fused_layers
         fused_layers.EMULATE_BF16 = mode == 'emu'
+        fused_layers.POOLED_BIAS_TAP = tap
         try:
             with ctx('bf16' if mode == 'bf16' else 'fp32'):
                 y = run_fused(mod, *ins) if mod in heads else mod(*ins, **kw)
             y.backward(gout.to(torch.bfloat16).to(y.dtype) if mode in ('probe', 'emu') else gout.to(y.dtype))
         finally:
             fused_layers.EMULATE_BF16 = False
+            fused_layers.POOLED_BIAS_TAP = None
         dxs = [a.grad.double() for a in ins if torch.is_tensor(a) and a.requires_grad and a.grad is not None]
         dps = [p.grad.double().flatten().clone() for p in mod.parameters() if p.grad is not None]
         out = (y.detach().double(), dxs, torch.cat(dps) if dps else torch.zeros(1, device=y.device, dtype=torch.float64))
@@ -353,9 +363,20 @@ def test_bf16_blocks_teacher_forced_from_the_float32_step():
         return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
     worst, rows, probes, rows64, rows_emu = dict(out=0.0, dparam=0.0, dx=0.0), {}, {}, {}, {}
+    rows_forced, descriptor = {}, {}
     for n, (args, kwargs, gout) in sorted(work.items()):
-        yt, dxt, dpt = run(blocks[n], args, kwargs, gout, 'f64')          # the block's mathematics, noise-free
-        y0, dx0, dp0 = run(blocks[n], args, kwargs, gout, 'fp32')
+        bias64, bias32 = [], []
+        yt, dxt, dpt = run(blocks[n], args, kwargs, gout, 'f64', tap=('record', bias64))   # the block's mathematics, noise-free
+        y0, dx0, dp0 = run(blocks[n], args, kwargs, gout, 'fp32', tap=('record', bias32))
+        if n in POOLED_BLOCKS:
+            # link 2d: (ii) the pooled branch's bias, float32 kernels vs float64; (i) the rest of the block with that bias forced
+            assert len(bias32) == len(bias64) >= 1, (n, len(bias32), len(bias64))
+            descriptor[n] = max(r2(a, b) for a, b in zip(bias32, bias64))
+            yb, dxb, dpb = run(blocks[n], args, kwargs, gout, 'bf16', tap=('replay', iter([t.float() for t in bias32])))
+            ye, dxe, dpe = run(blocks[n], args, kwargs, gout, 'emu', tap=('replay', iter([t.float() for t in bias32])))
+            rows_forced[n] = dict(out=r2(yb, ye), dparam=r2(dpb, dpe), dx=max([r2(a, b) for a, b in zip(dxb, dxe)] + [0.0]))
+        else:
+            assert not bias32 and not bias64, n
         y1, dx1, dp1 = run(blocks[n], args, kwargs, gout, 'bf16')
         y2, dx2, dp2 = run(blocks[n], args, kwargs, gout, 'probe')
         e = dict(out=r2(y1, y0), dparam=r2(dp1, dp0), dx=max([r2(a, b) for a, b in zip(dx1, dx0)] + [0.0]))
@@ -376,10 +397,17 @@ def test_bf16_blocks_teacher_forced_from_the_float32_step():
     for k in ('out', 'dparam', 'dx'):
         record('fp32_blocks_vs_float64', k, {n: e[k] for n, e in rows64.items()})
         record('bf16_blocks_vs_bf16_emulation_on_f32_kernels', k, {n: e[k] for n, e in rows_emu.items()})
+    for k in ('out', 'dparam', 'dx'):
+        record('pooled_blocks_bias_forced_bf16_vs_bf16_emulation', k, {n: e[k] for n, e in rows_forced.items()})
+    record('pooled_blocks', 'descriptor_bias_f32_vs_f64', descriptor)
     assert len(rows_emu) >= 22, len(rows_emu)
-    assert all(n in rows_emu for n in POOLED_BLOCKS)
-    over_emu = {n: e for n, e in rows_emu.items() if n not in POOLED_BLOCKS and any(e[k] > EMU_TOL[k] for k in EMU_TOL)}
+    assert set(rows_forced) == set(POOLED_BLOCKS) == set(descriptor)
+    # every block meets the emulation bound: the pooled blocks with their pooled-descriptor bias teacher-forced (link 2d),
+    # the others as they are
+    pinned = {**{n: e for n, e in rows_emu.items() if n not in POOLED_BLOCKS}, **rows_forced}
+    over_emu = {n: e for n, e in pinned.items() if any(e[k] > EMU_TOL[k] for k in EMU_TOL)}
     assert not over_emu, over_emu
+    assert max(descriptor.values()) <= DESCRIPTOR_TOL, descriptor
     # link 2a: the float32 kernel path of every block against the block's float64 evaluation on the SAME inputs
     # (teacher-forced, so the chain's conditioning plays no part): outputs <= 1e-4, gradients <= 5e-3
     over64 = {n: e for n, e in rows64.items() if e['out'] > F32_BLOCK_TOL['out'] or e['dparam'] > F32_BLOCK_TOL['grad']
