@@ -29,6 +29,15 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _ws_key(device):
+    """Key of a scratch buffer: one per device AND stream -- operators of independent branches are queued on different HIP
+    streams (the encoder's two heads, the weight gradients beside the data gradients) and must not share scratch."""
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return device
+    return (device, torch.cuda.current_stream().cuda_stream)
+
+
 def _stream_handle():
     return torch.cuda.current_stream().cuda_stream
 
@@ -289,10 +298,10 @@ def lift_workspace(dims, device):
     before the transpose pass."""
     nbytes = ctypes.c_size_t()
     check(_lib.lib().stp3_lift_workspace_bytes(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_lift_workspace_bytes')
-    key = torch.device(device)
+    key = _ws_key(device)
     ws = _WORKSPACE.get(key)
     if ws is None or ws.numel() < nbytes.value:
-        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=key)
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=torch.device(device))
         _WORKSPACE[key] = ws
     return ws, nbytes.value
 
@@ -603,10 +612,11 @@ _BN_MAX_ROW_BLOCKS = 128          # STP3_BN_MAX_ROW_BLOCKS
 def _bn_workspace(n, c, device):
     """Scratch of the two-stage reductions: N * 128 * 3 * C floats at most (one buffer per device, grown on demand)."""
     need = n * _BN_MAX_ROW_BLOCKS * 3 * c * 4
-    ws = _BN_WORKSPACE.get(device)
+    key = _ws_key(device)
+    ws = _BN_WORKSPACE.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 8 << 20), dtype=torch.uint8, device=device)
-        _BN_WORKSPACE[device] = ws
+        _BN_WORKSPACE[key] = ws
     return ws, need
 
 
@@ -1046,10 +1056,10 @@ def _conv2d_launch(x, wb, bias, stride, pad, dil, out_dtype, sums_ptr=None, out_
     if sums_ptr is not None:
         nbytes = ctypes.c_size_t()
         check(lib.stp3_conv2d_fwd_workspace(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_conv2d_fwd_workspace')
-        key = torch.device(x.device)
+        key = _ws_key(x.device)
         ws = _CONV_STAT_WS.get(key)
         if ws is None or ws.numel() < nbytes.value:
-            ws = torch.empty(max(nbytes.value, 8 << 20), dtype=torch.uint8, device=key)
+            ws = torch.empty(max(nbytes.value, 8 << 20), dtype=torch.uint8, device=x.device)
             _CONV_STAT_WS[key] = ws
         ws_ptr, ws_bytes = ws.data_ptr(), nbytes.value
     check(lib.stp3_conv2d_fwd(ctypes.byref(dims), _ptr(x), _ptr(wb), _opt_ptr(bias), _ptr(y), sums_ptr, ws_ptr, ws_bytes,
@@ -1072,10 +1082,10 @@ def _conv2d_wgrad(dy, x, wshape, stride, pad, dil):
     lib = _lib.lib()
     nbytes = ctypes.c_size_t()
     check(lib.stp3_conv2d_wgrad_workspace(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_conv2d_wgrad_workspace')
-    key = torch.device(x.device)
+    key = _ws_key(x.device)
     ws = _CONV_WORKSPACE.get(key)
     if ws is None or ws.numel() < nbytes.value:
-        ws = torch.empty(max(nbytes.value, 64 << 20), dtype=torch.uint8, device=key)
+        ws = torch.empty(max(nbytes.value, 64 << 20), dtype=torch.uint8, device=x.device)
         _CONV_WORKSPACE[key] = ws
     dw = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     check(lib.stp3_conv2d_wgrad(ctypes.byref(dims), _ptr(dy), _ptr(x), _ptr(dw), _ptr(ws), ctypes.c_size_t(nbytes.value),

@@ -25,10 +25,11 @@ _SE_MLP = True
 
 
 def _workspace(nbytes, device):
-    ws = _WS.get(device)
+    key = ops._ws_key(device)                 # per device and stream (ops._ws_key)
+    ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 32 << 20), dtype=torch.uint8, device=device)
-        _WS[device] = ws
+        _WS[key] = ws
     return ws
 
 
