@@ -56,13 +56,14 @@ fi
 if has bench || has profile; then
   if has bench; then timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -3 $out/bench.err; cut -c1-1500 $out/bench.json; fi
   STEPS=4
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r05 -o bench -- python bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-roofline > $out/prof.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r05 -o bench -- python scripts/bench_ab.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-roofline > $out/prof.log 2>&1
   grep '^{' $out/prof.log | tail -1 > $out/bench_profiled.json
   KT=$(find /tmp/prof_r05 -name '*kernel_trace.csv' | head -1)
   MS=$(python -c "import json;print(json.load(open('$out/bench_profiled.json'))['ms_per_step'])" 2>/dev/null || echo 60)
   if [ -n "$KT" ]; then
     python scripts/agg_trace.py $KT $(python -c "print($MS*($STEPS-1))") 90 > $out/steady_kernels.txt 2>&1
     python scripts/trace_last_step.py $KT $MS > $out/step_trace.txt 2>&1
+    python scripts/trace_overlap.py $KT $(python -c "print($MS*($STEPS-1))") > $out/trace_overlap.txt 2>&1; cat $out/trace_overlap.txt
   fi
   find /tmp/prof_r05 -name '*kernel_stats.csv' -exec cp {} $out/kernel_stats.csv \;
   rm -rf /tmp/prof_r05

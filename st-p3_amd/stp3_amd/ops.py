@@ -1070,8 +1070,58 @@ def _conv2d_launch(x, wb, bias, stride, pad, dil, out_dtype, sums_ptr=None, out_
 _CONV_WORKSPACE = {}
 
 
-def _conv2d_wgrad(dy, x, wshape, stride, pad, dil):
-    """dw (Cout,Cin,KH,KW) float32, channels-last memory, through stp3_conv2d_wgrad (bf16 operands)."""
+# Weight gradients beside the data gradients.  In backward the data gradient of a layer is on the critical path (the next
+# layer's backward waits for it); its weight gradient is not -- nothing reads dW before the optimizer.  ``_conv2d_wgrad``
+# therefore queues the weight-gradient kernels (MFMA-bound, a resident round of workgroups) on a second HIP stream, where
+# they share the chip with the main stream's BatchNorm passes (HBM-bound) and small-map layers (under-occupied) instead of
+# taking turns with them.  Per call: the side stream waits for what the main stream has queued so far (dy is complete
+# there), both operands are recorded on the side stream for the allocator, the launch goes to the side stream with its own
+# scratch.  The main stream joins at the end of the backward pass (an autograd engine callback queued by the first
+# deferred gradient of the pass) and wherever ``join_side_work`` is called (the gradient buckets call it before they
+# touch a gradient).  Same kernels, same arithmetic: same bits.
+SIDE_WGRAD = True
+_SIDE_QUEUES = {}
+
+
+class _SideQueue:
+    def __init__(self, device):
+        self.device = device
+        self.stream = torch.cuda.Stream(device=device)
+        self.handle = ctypes.c_void_p(self.stream.cuda_stream)
+        self.workspace = None
+        self.pending = False
+
+    def scratch(self, nbytes):
+        if self.workspace is None or self.workspace.numel() < nbytes:
+            self.workspace = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=self.device)
+        return self.workspace
+
+    def join(self):
+        if self.pending:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            self.pending = False
+
+
+def _side_queue(device):
+    q = _SIDE_QUEUES.get(device)
+    if q is None:
+        q = _SIDE_QUEUES[device] = _SideQueue(device)
+    return q
+
+
+def join_side_work():
+    """The current stream waits for every weight gradient queued on a side stream (no-op when there is none)."""
+    for q in _SIDE_QUEUES.values():
+        q.join()
+
+
+def _conv2d_wgrad(dy, x, wshape, stride, pad, dil, leaf=None):
+    """dw (Cout,Cin,KH,KW) float32, channels-last memory, through stp3_conv2d_wgrad (bf16 operands).
+    ``leaf``: the tensor the operator received as its weight.  When that is a LEAF parameter without a gradient yet, in
+    float32 and in the layout of dw, autograd's AccumulateGrad keeps dw as the parameter's ``.grad`` without launching
+    anything -- no main-stream kernel reads dw before the backward pass ends, and the gradient may be computed on the side
+    stream.  (A derived weight -- a slice, a concatenation, zero-padded lanes -- hands dw to further autograd operators on
+    the main stream: those stay on the main stream.)"""
     cout, cin, kh, kw = wshape
     n, _, h, w = x.shape
     x, ldx = _rows_view(x)
@@ -1082,15 +1132,38 @@ def _conv2d_wgrad(dy, x, wshape, stride, pad, dil):
     lib = _lib.lib()
     nbytes = ctypes.c_size_t()
     check(lib.stp3_conv2d_wgrad_workspace(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_conv2d_wgrad_workspace')
+    dw = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if (SIDE_WGRAD and leaf is not None and x.is_cuda and leaf.is_leaf and leaf.grad is None and leaf.dtype == torch.float32
+            and tuple(leaf.shape) == tuple(dw.shape) and leaf.stride() == dw.stride() and _in_backward()):
+        q = _side_queue(x.device)
+        cur = torch.cuda.current_stream(x.device)
+        if not q.pending:
+            q.pending = True
+            torch.autograd.Variable._execution_engine.queue_callback(q.join)     # joined when this backward pass ends
+        q.stream.wait_stream(cur)
+        dy.record_stream(q.stream)
+        x.record_stream(q.stream)
+        dw.record_stream(q.stream)
+        ws = q.scratch(nbytes.value)
+        check(lib.stp3_conv2d_wgrad(ctypes.byref(dims), _ptr(dy), _ptr(x), _ptr(dw), _ptr(ws), ctypes.c_size_t(nbytes.value),
+                                    q.handle), 'stp3_conv2d_wgrad')
+        return dw
     key = _ws_key(x.device)
     ws = _CONV_WORKSPACE.get(key)
     if ws is None or ws.numel() < nbytes.value:
         ws = torch.empty(max(nbytes.value, 64 << 20), dtype=torch.uint8, device=x.device)
         _CONV_WORKSPACE[key] = ws
-    dw = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     check(lib.stp3_conv2d_wgrad(ctypes.byref(dims), _ptr(dy), _ptr(x), _ptr(dw), _ptr(ws), ctypes.c_size_t(nbytes.value),
                                 _stream()), 'stp3_conv2d_wgrad')
     return dw
+
+
+def _in_backward():
+    """True while the autograd engine is running a backward pass on this thread (only then can a callback be queued)."""
+    try:
+        return torch._C._current_graph_task_id() != -1
+    except AttributeError:
+        return False
 
 
 _CONV_MAX_STAT_TILES = 65536          # stp3_conv2d_fwd: row tiles of 128 pixels the statistics epilogue can reduce
@@ -1415,7 +1488,7 @@ class _Conv2dMfma(torch.autograd.Function):
         need_dw = ctx.needs_input_grad[1]
         hip_dw = need_dw and cin % 8 == 0
         if hip_dw:
-            dw = _conv2d_wgrad(dy, x, (cout, cin, kh, kw), stride, pad, dil)[:cout_true].to(wdtype)
+            dw = _conv2d_wgrad(dy, x, (cout, cin, kh, kw), stride, pad, dil, leaf=None if cpad else ctx.weight_ref)[:cout_true].to(wdtype)
         mask = [need_dx and not hip_dx, need_dw and not hip_dw, False]
         if any(mask):
             # not reached by the model (every layer satisfies the kernels' constraints); kept so that an odd

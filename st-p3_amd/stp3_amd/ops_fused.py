@@ -167,7 +167,7 @@ class _ConvBnAct(torch.autograd.Function):
         need_db = has_cbias and ctx.needs_input_grad[2]
         hip_dw = need_dw and cin % 8 == 0 and cout % 8 == 0
         if hip_dw:
-            dw = ops._conv2d_wgrad(dconv, x, (cout, cin, kh, kw), stride, pad, dil).to(wdt)
+            dw = ops._conv2d_wgrad(dconv, x, (cout, cin, kh, kw), stride, pad, dil, leaf=ctx.weight_ref).to(wdt)
             if need_db:
                 dcb = ops.channel_sums(dconv).to(cbdt)
         mask = [need_dx and not hip_dx, need_dw and not hip_dw, need_db and not hip_dw]
@@ -276,7 +276,7 @@ class _PointwiseBnAct(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_data_grad(dconv, wb, ctx.weight_ref, x.shape, 1, (0, 0), (1, 1))
         if ctx.needs_input_grad[1]:
-            dw = ops._conv2d_wgrad(dconv, x, (cout, cin, 1, 1), 1, (0, 0), (1, 1)).to(wdt)
+            dw = ops._conv2d_wgrad(dconv, x, (cout, cin, 1, 1), 1, (0, 0), (1, 1), leaf=ctx.weight_ref).to(wdt)
         return (dx, dw, dgamma, dbeta) + (None,) * 6
 
 
