@@ -14,8 +14,9 @@ branches), the configuration the round-1 profiles under profiles/ were taken wit
 weak scaling: every rank gets its own B=4 (global batch 4N), gradients are all-reduced over RCCL
 and BatchNorm statistics are synchronised (the reference's DDP + sync_batchnorm recipe).
 
-The step is launched eagerly (hipGraph capture of the whole step was tried in round 1: replays on ROCm 7.2 were
-slower than the eager launch and numerically unreliable).
+On one GPU the step is captured ONCE into a hipGraph and replayed (stp3_amd/graph.py; `--launch eager` launches every kernel
+from Python instead: ~1 900 dispatches and 31-39 ms of host time per step); with more than one rank the step contains RCCL
+collectives and runs eagerly.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      the voxel-pool forward (stp3_lift_splat_fwd = its two kernels): algorithmic bytes per
@@ -413,6 +414,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-roofline', action='store_true', help='skip the voxel-pool micro-benchmark (profiling runs)')
+    ap.add_argument('--launch', choices=('graph', 'eager'), default='graph',
+                    help='graph (one GPU only): the whole step captured once into a hipGraph and replayed (stp3_amd/graph.py); '
+                         'eager: every kernel launched from Python.  More than one rank always runs eager (RCCL collectives)')
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='c3',
                     help='c3: BASELINE configs[2] (all losses incl. depth + instance + flow); perception: Perception.yml; '
                          'prediction / planning: the reference\'s Prediction.yml / Planning.yml (rows f2 / f3: own bench legs, '
@@ -479,6 +483,14 @@ def main():
 
     mode = 'eager'
     step = eager_step
+    if args.launch == 'graph' and world == 1 and not DRYRUN:
+        # ONE configuration here too: a capture that fails takes the bench down with it (no silent fall-back to eager)
+        from stp3_amd.graph import GraphedTrainStep
+        runner = GraphedTrainStep(module, buckets, opt, cfg.GRAD_NORM_CLIP, batch, warmup=2, log=_log)
+        mode = 'hipgraph'
+
+        def step():
+            return runner()
 
     _log(f'mode {mode}: warm-up')
     for _ in range(max(args.warmup - 1, 0)):                 # one warm-up step ran in setup
@@ -525,7 +537,8 @@ def main():
 
     fam = None
     if not args.no_roofline and not DRYRUN:
-        fam = family_rooflines(step, args.batch, perception_flops=workload in ('c3', 'perception'))   # every rank: the steps contain the collectives
+        # (per-call events need the calls: the family rooflines time the EAGER form of the same step)
+        fam = family_rooflines(eager_step, args.batch, perception_flops=workload in ('c3', 'perception'))   # every rank: the steps contain the collectives
     if rank == 0:
         module.model.prebuilt_plan = None
         roof, kernel_ms = (None, {}) if args.no_roofline else lift_roofline(device, batch, module.model)

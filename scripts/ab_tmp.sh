@@ -1,14 +1,13 @@
-mkdir -p gpurun_out/r05f
-run() { # tag AB
-  AB="$2" timeout 300 python scripts/bench_ab.py --no-cpu-baseline --no-roofline --steps 60 > gpurun_out/r05f/$1.json 2> gpurun_out/r05f/$1.err
+mkdir -p gpurun_out/r05g
+timeout 600 python -m pytest tests/test_graph_step_gpu.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -25 | cut -c1-400
+run() { # tag args
+  tag=$1; shift
+  timeout 400 python bench.py --no-cpu-baseline --no-roofline --steps 60 "$@" > gpurun_out/r05g/$tag.json 2> gpurun_out/r05g/$tag.err
+  echo "rc=$?"; tail -2 gpurun_out/r05g/$tag.err | cut -c1-300
   python -c "
-import json; b=json.load(open('gpurun_out/r05f/$1.json')); print('$1', 'ms', b['ms_per_step'], 'host', b['host_enqueue_ms_per_step'])"
+import json; b=json.load(open('gpurun_out/r05g/$tag.json')); print('$tag', b['config']['launch'], 'ms', b['ms_per_step'], 'host', b['host_enqueue_ms_per_step'])"
 }
-for rep in 1 2 3; do
-  run base.$rep "stp3_amd.models.encoder.PARALLEL_HEADS=0,stp3_amd.ops.SIDE_WGRAD=0"
-  run heads.$rep "stp3_amd.models.encoder.PARALLEL_HEADS=1,stp3_amd.ops.SIDE_WGRAD=0"
-  run wgrad.$rep "stp3_amd.models.encoder.PARALLEL_HEADS=0,stp3_amd.ops.SIDE_WGRAD=1"
-  run both.$rep "stp3_amd.models.encoder.PARALLEL_HEADS=1,stp3_amd.ops.SIDE_WGRAD=1"
+for rep in 1 2; do
+  run eager.$rep --launch eager
+  run graph.$rep --launch graph
 done
-timeout 900 python -m pytest tests/test_train_parity_gpu.py tests/test_step_parity_gpu.py tests/test_recompute_gpu.py tests/test_conv_gpu.py tests/test_fused_ops_gpu.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -4 | cut -c1-300
-AB="stp3_amd.models.encoder.PARALLEL_HEADS=1,stp3_amd.ops.SIDE_WGRAD=1" bash scripts/gpu_r05.sh r05f profile 2>&1 | tail -50 | cut -c1-200

@@ -553,6 +553,28 @@ def _count_later(bn):
         ent[1] += 1
 
 
+def pending_batch_counters():
+    """The ``num_batches_tracked`` buffers that currently hold un-flushed increments (what one step counted)."""
+    return [t for t, _ in _PENDING_COUNTS.values()]
+
+
+def discard_pending_batch_counters():
+    """Forget the increments counted since the last flush: a step that was CAPTURED into a hipGraph counted its BatchNorm
+    layers on the host while none of its kernels ran."""
+    _PENDING_COUNTS.clear()
+
+
+def count_batches_again(buffers):
+    """One more training-mode forward for every buffer in ``buffers``: a replayed hipGraph of the step runs the BatchNorm
+    kernels without passing through ``bump_batch_counter`` (stp3_amd/graph.py)."""
+    for t in buffers:
+        ent = _PENDING_COUNTS.get(id(t))
+        if ent is None or ent[0] is not t:
+            _PENDING_COUNTS[id(t)] = [t, 1]
+        else:
+            ent[1] += 1
+
+
 def flush_batch_counters():
     """Apply the increments counted since the last flush (no-op when there are none)."""
     if not _PENDING_COUNTS:

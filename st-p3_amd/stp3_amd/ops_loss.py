@@ -162,7 +162,10 @@ def warp_nearest(x, theta, identity=None):
     th = theta.to(device=x.device, dtype=torch.float32).reshape(f, 6).contiguous()
     ident = None
     if identity is not None:
-        ident = torch.as_tensor(list(identity), dtype=torch.int32).to(x.device, non_blocking=True)
+        if torch.is_tensor(identity):
+            ident = identity.to(device=x.device, dtype=torch.int32).contiguous()        # (already there: no copy)
+        else:
+            ident = torch.as_tensor(list(identity), dtype=torch.int32).to(x.device, non_blocking=True)
     y = torch.empty_like(x)
     check(_lib.lib().stp3_warp_nearest(f, c, h, w, x.data_ptr(), th.data_ptr(), ops._opt_ptr(ident), y.data_ptr(),
                                        ops._stream_handle()), 'stp3_warp_nearest')

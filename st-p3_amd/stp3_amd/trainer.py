@@ -223,24 +223,16 @@ class TrainingModule(nn.Module):
         if cfg.INSTANCE_FLOW.ENABLED:
             items.append(('flow', batch['flow'], False))
         stacked = torch.cat([x.float() for _, x, _ in items], dim=2)                  # (B,S,sum C,H,W)
-        thetas = label_warp_thetas(batch['future_egomotion'].detach().float().cpu(), rf, self.spatial_extent)
-        if stacked.is_cuda:
-            # all frames and all label channels in ONE launch (stp3_warp_nearest): frames without a theta are copied
+        prepared = batch.get('_prepared')
+        if prepared is not None:
+            # the warp matrices of this batch already sit in device memory (``prepare_batch``): no host work, no upload --
+            # what a captured step needs (stp3_amd/graph.py), and the same launch as below
             from . import ops_loss
             b_, s_ = stacked.shape[:2]
-            eye = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
-            th = torch.stack([thetas[t].float().cpu() if t in thetas else eye.expand(b_, 2, 3) for t in range(s_)], dim=1)
-            ident = [0 if t in thetas else 1 for _ in range(b_) for t in range(s_)]
-            warped = ops_loss.warp_nearest(stacked.reshape(b_ * s_, *stacked.shape[2:]), th.reshape(b_ * s_, 2, 3),
-                                           ident).view(stacked.shape)
+            warped = ops_loss.warp_nearest(stacked.reshape(b_ * s_, *stacked.shape[2:]), prepared['warp_theta'],
+                                           prepared['warp_ident']).view(stacked.shape)
         else:
-            frames = []
-            for t in range(stacked.shape[1]):
-                frame = stacked[:, t]
-                if t in thetas:
-                    frame = warp_with_theta(frame, thetas[t].to(dev), mode='nearest')
-                frames.append(frame)
-            warped = torch.stack(frames, dim=1)
+            warped = self._warp_labels(stacked, batch['future_egomotion'], rf, dev)
         c0 = 0
         for name, x, to_long in items:
             part = warped[:, :, c0:c0 + x.shape[2]]
@@ -249,6 +241,53 @@ class TrainingModule(nn.Module):
         if 'instance' in labels:
             labels['instance'] = labels['instance'][:, :, 0]
         return labels
+
+    def _label_warp_matrices(self, future_egomotion, b_, s_, rf):
+        """(theta (B*S, 2, 3) float32, identity flags (B*S) int32), on the host: the matrices of ``label_warp_thetas`` frame
+        by frame, identity (flag 1: the frame is copied) where a frame is not warped."""
+        thetas = label_warp_thetas(future_egomotion.detach().float().cpu(), rf, self.spatial_extent)
+        eye = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+        th = torch.stack([thetas[t].float().cpu() if t in thetas else eye.expand(b_, 2, 3) for t in range(s_)], dim=1)
+        ident = torch.tensor([0 if t in thetas else 1 for _ in range(b_) for t in range(s_)], dtype=torch.int32)
+        return th.reshape(b_ * s_, 2, 3).contiguous(), ident
+
+    def _warp_labels(self, stacked, future_egomotion, rf, dev):
+        b_, s_ = stacked.shape[:2]
+        if stacked.is_cuda:
+            # all frames and all label channels in ONE launch (stp3_warp_nearest): frames without a theta are copied
+            from . import ops_loss
+            th, ident = self._label_warp_matrices(future_egomotion, b_, s_, rf)
+            return ops_loss.warp_nearest(stacked.reshape(b_ * s_, *stacked.shape[2:]), th, ident).view(stacked.shape)
+        thetas = label_warp_thetas(future_egomotion.detach().float().cpu(), rf, self.spatial_extent)
+        frames = []
+        for t in range(stacked.shape[1]):
+            frame = stacked[:, t]
+            if t in thetas:
+                frame = warp_with_theta(frame, thetas[t].to(dev), mode='nearest')
+            frames.append(frame)
+        return torch.stack(frames, dim=1)
+
+    def prepare_batch(self, batch, device, out=None):
+        """Everything of a training step that depends on the batch's POSES and is computed on the host, done ahead of the
+        step and left in device memory: the label-warp matrices (``_label_warp_matrices``), the ego-motion vectors the
+        temporal model reads, and the voxel-pool plan (``STP3.prepare_plan``).  With ``batch['_prepared']`` set to the
+        result, ``training_step`` touches no host data and uploads nothing -- the step can be captured into a hipGraph and
+        replayed (stp3_amd/graph.py).  ``out``: a previous result whose device buffers are overwritten in place."""
+        rf = self.model.receptive_field
+        b_, s_ = batch['segmentation'].shape[:2]
+        th, ident = self._label_warp_matrices(batch['future_egomotion'], b_, s_, rf)
+        ego = batch['future_egomotion'].detach().float().cpu()
+        if out is None:
+            out = {'warp_theta': th.to(device), 'warp_ident': ident.to(device), 'ego': ego.to(device), 'plan': None}
+        else:
+            out['warp_theta'].copy_(th, non_blocking=True)
+            out['warp_ident'].copy_(ident, non_blocking=True)
+            out['ego'].copy_(ego, non_blocking=True)
+            out['_host'] = (th, ident, ego)              # the staging sources stay alive until the next call
+        out['plan'] = self.model.prepare_plan(batch['intrinsics'], batch['extrinsics'], batch['future_egomotion'], device,
+                                              out=out['plan'])
+        self.model.prebuilt_plan = None          # (the caller decides which forward uses it: ``STP3.prebuilt_plan``)
+        return out
 
     def prepare_future_labels(self, batch):
         if _BATCHED_LABEL_WARP:
