@@ -466,7 +466,9 @@ def main():
             loss.backward()
             buckets.finish()
             opt.clip_and_step(cfg.GRAD_NORM_CLIP)                # gradient clip + Adam (trainer.py:456-462, train.py:48)
-            return loss
+            # (detached: a loss that keeps its graph alive keeps the parameters' AccumulateGrad nodes -- and the stream they
+            # were created under -- alive with it, which a later capture on another stream trips over)
+            return loss.detach()
 
         options = (f"grad_gather={int(gather)} label_warp={'batched' if _trainer._BATCHED_LABEL_WARP else 'per_label'} "
                    f"lazy_bn_counter={int(_ops.LAZY_COUNTERS)}")

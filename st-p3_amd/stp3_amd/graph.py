@@ -38,6 +38,12 @@ class GraphedTrainStep:
         self.poses = (batch['intrinsics'], batch['extrinsics'])
         self.prepared = module.prepare_batch(batch, dev)
         self.loss = None
+        # Autograd keeps a parameter's AccumulateGrad node -- and the stream that was current when it was made -- alive for
+        # as long as any graph that reaches the parameter is alive (e.g. an un-detached loss of an earlier eager step): such
+        # a node would run on ITS stream, outside the capture.  Drop what the collector can drop before the warm-up builds
+        # fresh nodes under the capture stream.
+        import gc
+        gc.collect()
         self.stream = torch.cuda.Stream(device=dev)            # warm-up AND capture: scratch buffers are per stream
         cur = torch.cuda.current_stream(dev)
         self.stream.wait_stream(cur)
