@@ -1102,6 +1102,11 @@ _CONV_WORKSPACE = {}
 # deferred gradient of the pass) and wherever ``join_side_work`` is called (the gradient buckets call it before they
 # touch a gradient).  Same kernels, same arithmetic: same bits.
 SIDE_WGRAD = True
+# Side streams at all?  The eager step gains about a millisecond from them (measured, profiles/r05h_*); a CAPTURED step loses
+# two: hipGraph turns every cross-stream edge into a barrier packet between hardware queues, and replays of the
+# single-stream capture run the ~1 900 kernels back to back with 99 % of the wall time inside kernels.  stp3_amd/graph.py
+# clears this flag around its warm-up and capture.
+SIDE_STREAMS = True
 _SIDE_QUEUES = {}
 
 
@@ -1155,7 +1160,7 @@ def _conv2d_wgrad(dy, x, wshape, stride, pad, dil, leaf=None):
     nbytes = ctypes.c_size_t()
     check(lib.stp3_conv2d_wgrad_workspace(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_conv2d_wgrad_workspace')
     dw = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    if (SIDE_WGRAD and leaf is not None and x.is_cuda and leaf.is_leaf and leaf.grad is None and leaf.dtype == torch.float32
+    if (SIDE_WGRAD and SIDE_STREAMS and leaf is not None and x.is_cuda and leaf.is_leaf and leaf.grad is None and leaf.dtype == torch.float32
             and tuple(leaf.shape) == tuple(dw.shape) and leaf.stride() == dw.stride() and _in_backward()):
         q = _side_queue(x.device)
         cur = torch.cuda.current_stream(x.device)
