@@ -311,7 +311,7 @@ def lift_roofline(device, batch, model, iters=30):
     fwd_ms = prof['lift_splat_fwd']['avg_ms']
     ach = alg_fwd / (fwd_ms * 1e-3) / 1e9
     traffic, traffic_source = None, None
-    pmc_path = next((q for q in (os.path.join(ROOT, 'profiles', f) for f in ('r04_lift_pmc.json', 'r03_lift_pmc.json', 'r02_lift_pmc.json'))
+    pmc_path = next((q for q in (os.path.join(ROOT, 'profiles', f) for f in ('r05_lift_pmc.json', 'r04_lift_pmc.json', 'r03_lift_pmc.json', 'r02_lift_pmc.json'))
                      if os.path.exists(q)), '')
     if os.path.exists(pmc_path):
         try:

@@ -21,11 +21,7 @@ SIMDS = 256 * 4
 
 
 def key_cols(df):
-    cols = ['Kernel_Name']
-    for c in ('Grid_Size', 'Workgroup_Size'):
-        if c in df.columns:
-            cols.append(c)
-    return cols
+    return ['Kernel_Name'] + [c for c in df.columns if c.startswith('Grid_Size') or c.startswith('Workgroup_Size')]
 
 
 def main():
@@ -37,6 +33,7 @@ def main():
             continue
         cc = pd.read_csv(ccs[0])
         keys = key_cols(cc)
+        cc[keys[1:]] = cc[keys[1:]].fillna(-1)
         per = cc.groupby(['Dispatch_Id'] + keys + ['Counter_Name'])['Counter_Value'].sum().reset_index()
         tab = per.groupby(keys + ['Counter_Name'])['Counter_Value'].mean().unstack()
         counts = per.groupby(keys)['Dispatch_Id'].nunique()
@@ -46,19 +43,21 @@ def main():
             kt = pd.read_csv(traces[0])
             kt['dur_us'] = (kt['End_Timestamp'] - kt['Start_Timestamp']) / 1e3
             kk = [c for c in keys if c in kt.columns]
+            kt[kk[1:]] = kt[kk[1:]].fillna(-1)
             dur = kt.groupby(kk)['dur_us'].mean()
         for idx, row in tab.iterrows():
             idx = idx if isinstance(idx, tuple) else (idx,)
             name = idx[0]
-            if not any(k in name for k in ('conv2d_', 'igemm', 'pointwise', 'Cijk', 'dwconv', 'colsum')):
+            if not any(k in str(name) for k in ('conv2d_', 'igemm', 'pointwise', 'Cijk', 'dwconv', 'colsum')):
                 continue
-            label = name[:110] + ''.join(f' | {c.lower()}={v}' for c, v in zip(keys[1:], idx[1:]))
+            label = str(name)[:110] + ''.join(f' | {c.lower()}={v}' for c, v in zip(keys[1:], idx[1:]))
             ent = out.setdefault(label, {})
             ent['dispatches'] = int(counts[idx if len(idx) > 1 else idx[0]])
             ent.update({k: float(v) for k, v in row.items() if v == v})
             if dur is not None:
+                want = tuple(v for c, v in zip(keys, idx) if c in dur.index.names)
                 try:
-                    ent['avg_us'] = float(dur[idx[:len(dur.index.names)] if len(dur.index.names) > 1 else idx[0]])
+                    ent['avg_us'] = float(dur[want if len(want) > 1 else want[0]])
                 except KeyError:
                     pass
     for ent in out.values():
