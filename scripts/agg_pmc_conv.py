@@ -27,20 +27,25 @@ def key_cols(df):
 def main():
     out = {}
     for d in sys.argv[1:]:
-        ccs = glob.glob(d + '/**/*counter_collection.csv', recursive=True)
+        ccs = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True))
         if not ccs:
             print('no counter_collection.csv under', d, file=sys.stderr)
             continue
-        cc = pd.read_csv(ccs[0])
+        parts = []
+        for i, f in enumerate(ccs):                       # one file per profiled process: keep their dispatch ids apart
+            part = pd.read_csv(f)
+            part['Dispatch_Id'] = part['Dispatch_Id'] + i * 10_000_000
+            parts.append(part)
+        cc = pd.concat(parts, ignore_index=True)
         keys = key_cols(cc)
         cc[keys[1:]] = cc[keys[1:]].fillna(-1)
         per = cc.groupby(['Dispatch_Id'] + keys + ['Counter_Name'])['Counter_Value'].sum().reset_index()
         tab = per.groupby(keys + ['Counter_Name'])['Counter_Value'].mean().unstack()
         counts = per.groupby(keys)['Dispatch_Id'].nunique()
         dur = None
-        traces = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)
+        traces = sorted(glob.glob(d + '/**/*kernel_trace.csv', recursive=True))
         if traces:
-            kt = pd.read_csv(traces[0])
+            kt = pd.concat([pd.read_csv(f) for f in traces], ignore_index=True)
             kt['dur_us'] = (kt['End_Timestamp'] - kt['Start_Timestamp']) / 1e3
             kk = [c for c in keys if c in kt.columns]
             kt[kk[1:]] = kt[kk[1:]].fillna(-1)

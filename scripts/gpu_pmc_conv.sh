@@ -10,7 +10,9 @@ export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*\|SQ_BUSY_CYCLES\|SQ_BUSY_CU_CYCLES\|SQ_WAVE_CYCLES\|SQ_INSTS_MFMA\|GRBM_GUI_ACTIVE" | sort -u > $OUT/counters_available.txt
 pass() {  # name, counters...
   local name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_conv_${TAG}_$name -o c -- bash -c "python scripts/time_conv.py && python scripts/time_pointwise.py" > $OUT/pmc_conv_$name.log 2>&1
+  # (one rocprofv3 run per script: two processes under one run overwrite each other's output files)
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_conv_${TAG}_$name/conv -o c -- python scripts/time_conv.py > $OUT/pmc_conv_$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_conv_${TAG}_$name/pw -o c -- python scripts/time_pointwise.py >> $OUT/pmc_conv_$name.log 2>&1
 }
 MF=""
 for c in SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES; do

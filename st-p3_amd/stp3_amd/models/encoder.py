@@ -112,7 +112,7 @@ class Encoder(nn.Module):
     def get_features_depth(self, x):
         endpoints = self.trunk(x)
         deep, skip = endpoints[self._index], endpoints[self._index - 1]   # reduction_{index+1}, reduction_{index}
-        if self.use_depth_distribution and deep.is_cuda and PARALLEL_HEADS and ops.SIDE_STREAMS:
+        if self.use_depth_distribution and deep.is_cuda and PARALLEL_HEADS and ops.side_streams():
             return self._heads_on_two_streams(deep, skip)
         feature = self.feature_layer_2(self.feature_layer_1(deep), skip)
         depth = None

@@ -1110,6 +1110,17 @@ SIDE_STREAMS = True
 _SIDE_QUEUES = {}
 
 
+def side_streams():
+    """Whether independent branches of a step may be queued on side streams here: the switch above, and ONE process -- with
+    more than one rank the step carries RCCL exchanges (cross-replica BatchNorm statistics inside the branches, gradient
+    buckets behind the weight gradients) whose interplay with side streams has never run on hardware (no multi-GPU node
+    was available to any round); the N > 1 step therefore stays on the single stream its tests cover."""
+    if not SIDE_STREAMS:
+        return False
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
 class _SideQueue:
     def __init__(self, device):
         self.device = device
@@ -1160,7 +1171,7 @@ def _conv2d_wgrad(dy, x, wshape, stride, pad, dil, leaf=None):
     nbytes = ctypes.c_size_t()
     check(lib.stp3_conv2d_wgrad_workspace(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_conv2d_wgrad_workspace')
     dw = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    if (SIDE_WGRAD and SIDE_STREAMS and leaf is not None and x.is_cuda and leaf.is_leaf and leaf.grad is None and leaf.dtype == torch.float32
+    if (SIDE_WGRAD and leaf is not None and x.is_cuda and side_streams() and leaf.is_leaf and leaf.grad is None and leaf.dtype == torch.float32
             and tuple(leaf.shape) == tuple(dw.shape) and leaf.stride() == dw.stride() and _in_backward()):
         q = _side_queue(x.device)
         cur = torch.cuda.current_stream(x.device)
