@@ -31,25 +31,30 @@ def main():
         if not ccs:
             print('no counter_collection.csv under', d, file=sys.stderr)
             continue
-        parts = []
+        import os
+        parts, durs = [], []
         for i, f in enumerate(ccs):                       # one file per profiled process: keep their dispatch ids apart
             part = pd.read_csv(f)
             part['Dispatch_Id'] = part['Dispatch_Id'] + i * 10_000_000
             parts.append(part)
+            tr = f.replace('counter_collection', 'kernel_trace')
+            if os.path.exists(tr):                        # the duration of EVERY dispatch, joined on its id (the trace has no grid columns)
+                t = pd.read_csv(tr)
+                if 'Dispatch_Id' in t.columns:
+                    t = t.assign(Dispatch_Id=t['Dispatch_Id'] + i * 10_000_000, dur_us=(t['End_Timestamp'] - t['Start_Timestamp']) / 1e3)
+                    durs.append(t[['Dispatch_Id', 'dur_us']])
         cc = pd.concat(parts, ignore_index=True)
+        by_dispatch = pd.concat(durs, ignore_index=True).set_index('Dispatch_Id')['dur_us'] if durs else None
         keys = key_cols(cc)
         cc[keys[1:]] = cc[keys[1:]].fillna(-1)
         per = cc.groupby(['Dispatch_Id'] + keys + ['Counter_Name'])['Counter_Value'].sum().reset_index()
         tab = per.groupby(keys + ['Counter_Name'])['Counter_Value'].mean().unstack()
         counts = per.groupby(keys)['Dispatch_Id'].nunique()
         dur = None
-        traces = sorted(glob.glob(d + '/**/*kernel_trace.csv', recursive=True))
-        if traces:
-            kt = pd.concat([pd.read_csv(f) for f in traces], ignore_index=True)
-            kt['dur_us'] = (kt['End_Timestamp'] - kt['Start_Timestamp']) / 1e3
-            kk = [c for c in keys if c in kt.columns]
-            kt[kk[1:]] = kt[kk[1:]].fillna(-1)
-            dur = kt.groupby(kk)['dur_us'].mean()
+        if by_dispatch is not None:
+            one = per.drop_duplicates('Dispatch_Id').copy()
+            one['dur_us'] = one['Dispatch_Id'].map(by_dispatch)
+            dur = one.groupby(keys)['dur_us'].mean()
         for idx, row in tab.iterrows():
             idx = idx if isinstance(idx, tuple) else (idx,)
             name = idx[0]
@@ -60,9 +65,8 @@ def main():
             ent['dispatches'] = int(counts[idx if len(idx) > 1 else idx[0]])
             ent.update({k: float(v) for k, v in row.items() if v == v})
             if dur is not None:
-                want = tuple(v for c, v in zip(keys, idx) if c in dur.index.names)
                 try:
-                    ent['avg_us'] = float(dur[want if len(want) > 1 else want[0]])
+                    ent.setdefault('avg_us', float(dur[idx if len(idx) > 1 else idx[0]]))   # (of the FIRST pass: the MFMA counters')
                 except KeyError:
                     pass
     for ent in out.values():

@@ -28,7 +28,7 @@ def test_kernel_register_lds_and_scratch_budgets():
         assert k['vgpr_spills'] == 0, k                                  # no vector register spills anywhere
         assert k['scratch'] == 0 and k['sgpr_spills'] == 0, k               # no scratch memory, no spills of any kind
     # the memory-bound kernels keep at least 3 waves per SIMD resident (<= 168 registers); the voxel pool's fit 4 and 3
-    for name, budget in (('lift_column_mma_kernel', 128), ('void lift_column_kernel<12>', 96), ('void lift_gather_kernel<float>', 64), ('void lift_gather_kernel<unsigned short>', 64),
+    for name, budget in (('lift_column_mma_kernel', 128), ('void lift_column_kernel<12>', 96), ('void lift_gather_kernel<float, 3>', 64), ('void lift_gather_kernel<unsigned short, 3>', 64), ('void lift_gather_kernel<unsigned short, 8>', 64),
                          ('lift_bwd_kernel', 168), ('plan_columns_kernel', 64), ('plan_fill_kernel', 64),
                          ('prep_weights_kernel', 128), ('optim_sumsq_kernel', 128), ('optim_prepare_kernel', 128),
                          ('optim_adam_kernel', 128), ('void se_mlp_fwd_kernel<40>', 128), ('void se_mlp_bwd_sample_kernel<40>', 128),
