@@ -1,26 +1,17 @@
-mkdir -p gpurun_out/r05h
-run() { # tag AB args
-  tag=$1; ab=$2; shift; shift
-  AB="$ab" timeout 400 python scripts/bench_ab.py --no-cpu-baseline --no-roofline --steps 100 "$@" > gpurun_out/r05h/$tag.json 2> gpurun_out/r05h/$tag.err
-  python -c "
-import json; b=json.load(open('gpurun_out/r05h/$tag.json')); print('$tag', b['config']['launch'], 'ms', b['ms_per_step'], 'host', b['host_enqueue_ms_per_step'])"
-}
-OFF="stp3_amd.models.encoder.PARALLEL_HEADS=0,stp3_amd.ops.SIDE_WGRAD=0"
-ON="stp3_amd.models.encoder.PARALLEL_HEADS=1,stp3_amd.ops.SIDE_WGRAD=1"
+mkdir -p gpurun_out/r05o
+PREV=$PWD/st-p3_amd/exp/libstp3hip_prev.so
 for rep in 1 2; do
-  run eager_off.$rep "$OFF" --launch eager
-  run eager_on.$rep "$ON" --launch eager
-  run graph_off.$rep "$OFF" --launch graph
-  run graph_on.$rep "$ON" --launch graph
+  EXP_LIB=$PREV timeout 300 python scripts/time_conv.py > gpurun_out/r05o/time_conv_prev.$rep.log 2>&1
+  timeout 300 python scripts/time_conv.py > gpurun_out/r05o/time_conv_dma.$rep.log 2>&1
 done
-export TMPDIR=/tmp
-for v in off on; do
-  [ $v == off ] && AB="$OFF" || AB="$ON"
-  AB="$AB" timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_g$v -o g -- python scripts/bench_ab.py --steps 4 --warmup 3 --no-cpu-baseline --no-roofline --launch graph > gpurun_out/r05h/prof_$v.log 2>&1
-  KT=$(find /tmp/prof_g$v -name '*kernel_trace.csv' | head -1)
-  MS=$(grep '^{' gpurun_out/r05h/prof_$v.log | tail -1 | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
-  echo "graph $v under profiler: ms_per_step $MS"
-  python scripts/trace_overlap.py $KT $(python -c "print($MS*3)")
-  python scripts/agg_trace.py $KT $(python -c "print($MS*3)") 12 | cut -c1-150
-  rm -rf /tmp/prof_g$v
+paste -d'|' <(cut -c1-44,46-62,150-175 gpurun_out/r05o/time_conv_prev.1.log) <(cut -c46-62,150-175 gpurun_out/r05o/time_conv_dma.1.log) <(cut -c46-62,150-175 gpurun_out/r05o/time_conv_prev.2.log) <(cut -c46-62,150-175 gpurun_out/r05o/time_conv_dma.2.log) | grep -v amdgpu
+timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_fused_ops_gpu.py tests/test_train_parity_gpu.py tests/test_graph_step_gpu.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -3 | cut -c1-200
+for rep in 1 2; do
+  for v in prev new; do
+    [ $v == prev ] && export EXP_LIB=$PREV || unset EXP_LIB
+    timeout 400 python scripts/bench_ab.py --no-cpu-baseline --steps 100 > gpurun_out/r05o/bench_$v.$rep.json 2> gpurun_out/r05o/bench_$v.$rep.err
+    python -c "
+import json; b=json.load(open('gpurun_out/r05o/bench_$v.$rep.json')); f=b['roofline_families']; print('$v $rep', b['config']['launch'], 'ms', b['ms_per_step'], 'conv', f['conv']['ms_per_step'], f['conv']['split_ms'], 'frac', f['conv']['frac'])"
+  done
 done
+unset EXP_LIB
