@@ -16,6 +16,19 @@ from ..cost import Cost_Function
 from ..layers.convolutions import Bottleneck
 
 
+_AXIS_WEIGHT = {}
+
+
+def _axis_weight(device, dtype):
+    """The (10, 1) weights of the refinement loss (planning_model.py:146-149), uploaded once per device: a constant built
+    inside the step is a host-to-device copy per step -- and not capturable into a hipGraph."""
+    key = (str(device), dtype)
+    t = _AXIS_WEIGHT.get(key)
+    if t is None:
+        t = _AXIS_WEIGHT[key] = torch.tensor([10., 1.], device=device, dtype=dtype)
+    return t
+
+
 class Planning(nn.Module):
     def __init__(self, cfg, feature_channel, gru_input_size=6, gru_state_size=256):
         super().__init__()
@@ -97,7 +110,7 @@ class Planning(nn.Module):
         refined = torch.stack(refined, dim=1)
         refined = torch.cat([refined, torch.zeros_like(refined[..., :1])], dim=-1)
         if self.training:
-            axis_weight = torch.tensor([10., 1.], device=refined.device, dtype=refined.dtype)
+            axis_weight = _axis_weight(refined.device, refined.dtype)
             loss = loss * 0.5 + (F.smooth_l1_loss(refined[..., :2], gt_trajs[..., :2].to(refined.dtype), reduction='none') *
                                  axis_weight).mean()
         return loss, refined
