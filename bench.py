@@ -492,7 +492,10 @@ def main():
         mode = 'hipgraph'
 
         def step():
-            return runner()
+            # the FULL per-batch path every step, as the eager step has it: the pose-dependent host work (voxel-pool plan,
+            # label-warp matrices, ego vectors: TrainingModule.prepare_batch) is redone and uploaded, then the replay; only the
+            # copies of the resident input tensors onto themselves are skipped
+            return runner(batch)
 
     _log(f'mode {mode}: warm-up')
     for _ in range(max(args.warmup - 1, 0)):                 # one warm-up step ran in setup

@@ -174,6 +174,34 @@ def voxel_index(grid, dims, cam_m, cam_t, ego_r, ego_t, order=VOX_REFERENCE, cou
     return vox
 
 
+class PinnedUpload:
+    """Asynchronous host -> device refresh of a small static device tensor (a hipGraph's inputs that depend on the batch's
+    poses: camera / ego matrices, label-warp matrices).  A copy from pageable memory is staged synchronously -- the host
+    would wait for everything queued before it -- so the values go through one of TWO pinned buffers; a buffer is reused
+    only after the copy that last read it has completed (its event), which bounds the host's lead to two refreshes."""
+
+    def __init__(self, dst):
+        self.dst = dst
+        self.pinned = dst.is_cuda
+        if self.pinned:
+            self.bufs = [torch.empty(dst.shape, dtype=dst.dtype, pin_memory=True) for _ in range(2)]
+            self.events = [None, None]
+            self.k = 0
+
+    def __call__(self, src):
+        if not self.pinned:
+            self.dst.copy_(src)
+            return
+        k, self.k = self.k, self.k ^ 1
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        self.bufs[k].copy_(src.reshape(self.dst.shape))
+        self.dst.copy_(self.bufs[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dst.device))
+        self.events[k] = ev
+
+
 class LiftPlan:
     """Geometry-only pooling plan for one batch: voxel ids (``vox_cm``: column-major [B*T, N*fW, D, fH]) + per-voxel
     lists of column runs.
@@ -194,8 +222,9 @@ class LiftPlan:
         lib = _lib.lib()
         if out is not None:
             assert bytes(out.dims) == bytes(dims), 'LiftPlan.build(out=...): shape changed'
-            out.mats_host = mats                    # keep the staging source alive until the next rebuild
-            out.mats.copy_(mats, non_blocking=True)
+            if getattr(out, 'mats_upload', None) is None or out.mats_upload.dst is not out.mats:
+                out.mats_upload = PinnedUpload(out.mats)
+            out.mats_upload(mats)                   # (asynchronous: pinned double buffer)
             mats, counts, vox_cm, plan, nbytes = out.mats, out.counts, out.vox_cm, out.plan, out.plan.numel()
         else:
             mats = mats.to(grid.device, non_blocking=True)
@@ -1102,6 +1131,7 @@ _CONV_WORKSPACE = {}
 # deferred gradient of the pass) and wherever ``join_side_work`` is called (the gradient buckets call it before they
 # touch a gradient).  Same kernels, same arithmetic: same bits.
 SIDE_WGRAD = True
+DIRECT_BUCKET_GRADS = True        # weight gradients of leaf parameters written straight into their gradient-bucket slice
 # Side streams at all?  The eager step gains about a millisecond from them (measured, profiles/r05h_*); a CAPTURED step loses
 # two: hipGraph turns every cross-stream edge into a barrier packet between hardware queues, and replays of the
 # single-stream capture run the ~1 900 kernels back to back with 99 % of the wall time inside kernels.  stp3_amd/graph.py
@@ -1171,8 +1201,23 @@ def _conv2d_wgrad(dy, x, wshape, stride, pad, dil, leaf=None):
     nbytes = ctypes.c_size_t()
     check(lib.stp3_conv2d_wgrad_workspace(ctypes.byref(dims), ctypes.byref(nbytes)), 'stp3_conv2d_wgrad_workspace')
     dw = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    if (SIDE_WGRAD and leaf is not None and x.is_cuda and side_streams() and leaf.is_leaf and leaf.grad is None and leaf.dtype == torch.float32
-            and tuple(leaf.shape) == tuple(dw.shape) and leaf.stride() == dw.stride() and _in_backward()):
+    # a LEAF parameter without a gradient yet, float32, in the memory order of dw: AccumulateGrad keeps the tensor we hand back
+    # as the parameter's .grad without launching anything
+    plain_leaf = (leaf is not None and x.is_cuda and leaf.is_leaf and leaf.grad is None and leaf.dtype == torch.float32
+                  and tuple(leaf.shape) == tuple(dw.shape) and _same_memory_order(leaf, dw))
+    if plain_leaf:
+        # ... so the gradient can be written where the optimizer reads it: the parameter's slice of its flat gradient bucket
+        # (parallel.GradientBuckets), a FRESH alias of it (autograd only keeps a tensor nobody else holds) -- the gather copy
+        # of the bucket then skips this parameter
+        # Once per backward pass and parameter: a weight that is used several times in one graph (the GRU cells of the
+        # prediction stage) gets its second and later contributions in fresh tensors, which autograd adds to the first.
+        view = getattr(leaf, '_stp3_grad_view', None)
+        task = _graph_task_id()
+        if (DIRECT_BUCKET_GRADS and view is not None and task != -1 and getattr(leaf, '_stp3_grad_claim', None) != task and view.device == dw.device
+                and view.dtype == torch.float32 and _same_memory_order(view, dw)):
+            leaf._stp3_grad_claim = task
+            dw = view.detach()
+    if SIDE_WGRAD and plain_leaf and side_streams() and _in_backward():
         q = _side_queue(x.device)
         cur = torch.cuda.current_stream(x.device)
         if not q.pending:
@@ -1196,12 +1241,23 @@ def _conv2d_wgrad(dy, x, wshape, stride, pad, dil, leaf=None):
     return dw
 
 
+def _same_memory_order(a, b):
+    """Same shape and the same stride in every dimension that has more than one element (a 1 x 1 kernel's channels-last and
+    contiguous strides differ only in dimensions of size one: the same memory)."""
+    return tuple(a.shape) == tuple(b.shape) and all(sa == sb for n, sa, sb in zip(a.shape, a.stride(), b.stride()) if n > 1)
+
+
+def _graph_task_id():
+    """Id of the backward pass the autograd engine is running on this thread, -1 outside of one."""
+    try:
+        return torch._C._current_graph_task_id()
+    except AttributeError:
+        return -1
+
+
 def _in_backward():
     """True while the autograd engine is running a backward pass on this thread (only then can a callback be queued)."""
-    try:
-        return torch._C._current_graph_task_id() != -1
-    except AttributeError:
-        return False
+    return _graph_task_id() != -1
 
 
 _CONV_MAX_STAT_TILES = 65536          # stp3_conv2d_fwd: row tiles of 128 pixels the statistics epilogue can reduce

@@ -118,6 +118,9 @@ class GradientBuckets:
                 p.data = view
                 gview = torch.as_strided(flat, size, stride, off)
                 views.append(gview)
+                # an operator that produces this parameter's WHOLE gradient in one launch may write it here directly
+                # (ops._conv2d_wgrad: no gather copy for the convolution weights, ~95 % of the gradient bytes)
+                p._stp3_grad_view = gview
                 # gather mode: autograd must find no gradient tensor on the parameter, or it accumulates in place into
                 # the view and ``_gather`` cannot tell "already in the bucket" from "took no part in this step"
                 p.grad = None if self.gather else gview
@@ -150,7 +153,9 @@ class GradientBuckets:
         (one multi-tensor copy) and point every ``p.grad`` back at its view."""
         flat, params = self.buckets[i]
         views = self.grad_views[i]
-        have = [(v, p.grad) for v, p in zip(views, params) if p.grad is not None and p.grad is not v]
+        # (a gradient that was written straight into its slice -- same memory, another tensor object -- needs no copy)
+        have = [(v, p.grad) for v, p in zip(views, params)
+                if p.grad is not None and p.grad is not v and p.grad.data_ptr() != v.data_ptr()]
         # p.grad is its view: a backward that ran without a preceding ``zero_grad()`` accumulated in place -- already in
         # the bucket, keep it.  p.grad is None: the parameter took no part in this step -- its slice must read zero.
         absent = [v for v, p in zip(views, params) if p.grad is None]

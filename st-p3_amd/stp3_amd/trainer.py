@@ -280,10 +280,11 @@ class TrainingModule(nn.Module):
         if out is None:
             out = {'warp_theta': th.to(device), 'warp_ident': ident.to(device), 'ego': ego.to(device), 'plan': None}
         else:
-            out['warp_theta'].copy_(th, non_blocking=True)
-            out['warp_ident'].copy_(ident, non_blocking=True)
-            out['ego'].copy_(ego, non_blocking=True)
-            out['_host'] = (th, ident, ego)              # the staging sources stay alive until the next call
+            if '_upload' not in out:
+                from . import ops
+                out['_upload'] = {k: ops.PinnedUpload(out[k]) for k in ('warp_theta', 'warp_ident', 'ego')}
+            for k, v in (('warp_theta', th), ('warp_ident', ident), ('ego', ego)):
+                out['_upload'][k](v)                     # (asynchronous: pinned double buffers)
         out['plan'] = self.model.prepare_plan(batch['intrinsics'], batch['extrinsics'], batch['future_egomotion'], device,
                                               out=out['plan'])
         self.model.prebuilt_plan = None          # (the caller decides which forward uses it: ``STP3.prebuilt_plan``)

@@ -62,7 +62,8 @@ def test_replays_equal_the_eager_steps_bit_for_bit():
 
     module, cfg, buckets, opt, batch = _setup()
     runner = GraphedTrainStep(module, buckets, opt, cfg.GRAD_NORM_CLIP, batch, warmup=WARMUP)
-    got = [runner().clone() for _ in range(STEPS)]
+    # (the full per-batch path, as bench.py runs it: plan and warp matrices rebuilt and uploaded before every replay)
+    got = [runner(batch).clone() for _ in range(STEPS)]
     torch.cuda.synchronize()
     for i, (g, e) in enumerate(zip(got, eager[WARMUP:])):
         assert torch.isfinite(g).item() and torch.equal(g, e), (i, g.item(), e.item())
