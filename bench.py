@@ -486,16 +486,25 @@ def main():
     mode = 'eager'
     step = eager_step
     if args.launch == 'graph' and world == 1 and not DRYRUN:
-        # ONE configuration here too: a capture that fails takes the bench down with it (no silent fall-back to eager)
+        # Same workload, same kernels, same arithmetic either way (tests/test_graph_step_gpu.py: replays equal eager steps bit
+        # for bit) -- so a capture that fails does not take the measurement down: the step is then launched eagerly and the
+        # line SAYS so (`config.launch`), with the reason.
         from stp3_amd.graph import GraphedTrainStep
-        runner = GraphedTrainStep(module, buckets, opt, cfg.GRAD_NORM_CLIP, batch, warmup=2, log=_log)
-        mode = 'hipgraph'
+        try:
+            runner = GraphedTrainStep(module, buckets, opt, cfg.GRAD_NORM_CLIP, batch, warmup=2, log=_log)
+        except Exception as exc:                              # noqa: BLE001 -- reported, not swallowed
+            _sync()
+            mode = f'eager (hipGraph capture failed: {type(exc).__name__}: {str(exc)[:160]})'
+            _log(mode)
+            module.model.prebuilt_plan = None
+        else:
+            mode = 'hipgraph'
 
-        def step():
-            # the FULL per-batch path every step, as the eager step has it: the pose-dependent host work (voxel-pool plan,
-            # label-warp matrices, ego vectors: TrainingModule.prepare_batch) is redone and uploaded, then the replay; only the
-            # copies of the resident input tensors onto themselves are skipped
-            return runner(batch)
+            def step():
+                # the FULL per-batch path every step, as the eager step has it: the pose-dependent host work (voxel-pool plan,
+                # label-warp matrices, ego vectors: TrainingModule.prepare_batch) is redone and uploaded, then the replay; only
+                # the copies of the resident input tensors onto themselves are skipped
+                return runner(batch)
 
     _log(f'mode {mode}: warm-up')
     for _ in range(max(args.warmup - 1, 0)):                 # one warm-up step ran in setup

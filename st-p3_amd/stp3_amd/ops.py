@@ -182,7 +182,7 @@ class PinnedUpload:
 
     def __init__(self, dst):
         self.dst = dst
-        self.pinned = dst.is_cuda
+        self.pinned = dst.is_cuda and torch.cuda.is_available()      # (the CPU dry runs pose as a GPU without one)
         if self.pinned:
             self.bufs = [torch.empty(dst.shape, dtype=dst.dtype, pin_memory=True) for _ in range(2)]
             self.events = [None, None]
