@@ -1145,7 +1145,7 @@ def side_streams():
     more than one rank the step carries RCCL exchanges (cross-replica BatchNorm statistics inside the branches, gradient
     buckets behind the weight gradients) whose interplay with side streams has never run on hardware (no multi-GPU node
     was available to any round); the N > 1 step therefore stays on the single stream its tests cover."""
-    if not SIDE_STREAMS:
+    if not SIDE_STREAMS or not torch.cuda.is_available():       # (the CPU stand-in runs pose as a GPU without one)
         return False
     import torch.distributed as dist
     return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
@@ -1183,6 +1183,27 @@ def join_side_work():
         q.join()
 
 
+def note_weight_use(weight):
+    """Forward side of the side-stream rule below: count how many operators of the graphs under construction read this
+    weight.  A weight that is used more than once (the GRU cells of the prediction stage) gets its gradient contributions
+    ADDED by the autograd engine on the main stream as they arrive -- a contribution still being computed on the side stream
+    would be read too early; only single-use weights are deferred.  (The count falls back as the backward passes consume the
+    uses; a graph that is dropped without a backward leaves it high, which only switches the deferral off for that weight.)"""
+    if isinstance(weight, torch.nn.Parameter) and weight.requires_grad and torch.is_grad_enabled():
+        weight._stp3_uses = getattr(weight, '_stp3_uses', 0) + 1
+    return weight
+
+
+def _weight_used_once(leaf):
+    """Backward side: True when this is the only use of ``leaf`` in flight; consumes one use either way."""
+    uses = getattr(leaf, '_stp3_uses', 0)
+    pending = getattr(leaf, '_stp3_pending', 0) or uses          # uses still to be consumed by backward calls
+    leaf._stp3_pending = max(pending - 1, 0)
+    if leaf._stp3_pending == 0:
+        leaf._stp3_uses = 0
+    return uses == 1
+
+
 def _conv2d_wgrad(dy, x, wshape, stride, pad, dil, leaf=None):
     """dw (Cout,Cin,KH,KW) float32, channels-last memory, through stp3_conv2d_wgrad (bf16 operands).
     ``leaf``: the tensor the operator received as its weight.  When that is a LEAF parameter without a gradient yet, in
@@ -1217,7 +1238,8 @@ def _conv2d_wgrad(dy, x, wshape, stride, pad, dil, leaf=None):
                 and view.dtype == torch.float32 and _same_memory_order(view, dw)):
             leaf._stp3_grad_claim = task
             dw = view.detach()
-    if SIDE_WGRAD and plain_leaf and side_streams() and _in_backward():
+    once = leaf is not None and isinstance(leaf, torch.nn.Parameter) and _weight_used_once(leaf)
+    if SIDE_WGRAD and plain_leaf and once and side_streams() and _in_backward():
         q = _side_queue(x.device)
         cur = torch.cuda.current_stream(x.device)
         if not q.pending:
@@ -1550,7 +1572,7 @@ class _Conv2dMfma(torch.autograd.Function):
         wb, _ = _bf16_weights(weight)
         fb = _f32(bias)
         y = _conv2d_launch(x, wb, fb, stride, pad, dil, out_dtype)
-        ctx.weight_ref = weight
+        ctx.weight_ref = note_weight_use(weight)
         ctx.weight_stamp = weight_stamp(weight)
         ctx.save_for_backward(x, wb)
         ctx.cfg = (stride, pad, dil, bias is not None, weight.dtype, None if bias is None else bias.dtype)
