@@ -1,5 +1,5 @@
 """A/B of host-side switches inside one GPU session: bench.py with module-level flags overridden from AB, e.g.
-    AB="stp3_amd.models.encoder.PARALLEL_HEADS=0" python scripts/bench_ab.py --no-cpu-baseline
+    AB="stp3_amd.ops.DIRECT_BUCKET_GRADS=0" python scripts/bench_ab.py --no-cpu-baseline
 (and EXP_LIB=<path> for another build of the library).  Prints bench.py's line; not used by anything else."""
 import importlib
 import os

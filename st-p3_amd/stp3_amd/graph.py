@@ -4,10 +4,11 @@ A step of BASELINE configs[2] is ~1 900 kernel launches of 5-100 us; launched ea
 31-39 ms against 39-40 ms of GPU time: the host is the wall the kernels run into.  Every shape in the
 step is static, no operator reads a value back, every scratch buffer is owned by an operator -- so forward, backward,
 gradient gather, clipping, Adam and the refresh of the bf16 weight shadows are captured ONCE and replayed per batch.  The
-captured step is a single stream: the side streams of the eager step (the encoder's two heads, the weight gradients of leaf
-parameters: models/encoder.py, ops._conv2d_wgrad) are switched off for the capture -- hipGraph turns every cross-stream edge
-into a barrier between hardware queues, and a replay of the multi-stream capture measured 2.4 ms SLOWER than the single-stream
-one (41.0 vs 38.5 ms, profiles/r05h_*), whose replays run the ~1 900 kernels back to back (99 % of the wall time in kernels).
+captured step is a single stream (with a prepared plan the forward forks no side stream): a multi-stream form of the step --
+the encoder's two heads on two streams, the weight gradients of leaf parameters beside the data gradients -- was built and
+measured this round: about a millisecond faster launched eagerly, 2.4 ms SLOWER captured (hipGraph turns every cross-stream
+edge into a barrier between hardware queues: 41.0 vs 38.5 ms, profiles/r05h_*), and it is deleted: replays of the single-stream
+capture run the ~1 900 kernels back to back (99 % of the wall time in kernels).
 
 Per batch the host does what depends on the batch and nothing else (``TrainingModule.prepare_batch``): copies the batch into
 the graph's static input buffers (skipped for tensors that already are those buffers), rebuilds the geometry-only voxel-pool
@@ -78,18 +79,14 @@ class GraphedTrainStep:
         self.buckets.zero_grad()
         model = self.module.model
         model.prebuilt_plan = self.prepared['plan']            # forward pools with the prepared plan (no host work) ...
-        streams, ops.SIDE_STREAMS = ops.SIDE_STREAMS, False    # ONE stream: cross-stream edges cost a replay more than
-        try:                                                   # the overlap returns (ops.SIDE_STREAMS)
-            try:
-                with torch.autocast('cuda', dtype=self.autocast_dtype):
-                    loss = self.module.training_step(self._graph_batch())
-            finally:
-                model.prebuilt_plan = None                     # ... and only this step does
-            loss.backward()
-            self.buckets.finish()
-            self.optimizer.clip_and_step(self.grad_clip)
+        try:
+            with torch.autocast('cuda', dtype=self.autocast_dtype):
+                loss = self.module.training_step(self._graph_batch())
         finally:
-            ops.SIDE_STREAMS = streams
+            model.prebuilt_plan = None                         # ... and only this step does
+        loss.backward()
+        self.buckets.finish()
+        self.optimizer.clip_and_step(self.grad_clip)
         return loss.detach()
 
     def __call__(self, batch=None):

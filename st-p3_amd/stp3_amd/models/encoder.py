@@ -28,14 +28,9 @@ def _recomputed(block, x, rate, drop_scale):
                       context_fn=lambda: (contextlib.nullcontext(), ops.recomputing()))
 
 
-# the two heads of the encoder on two HIP streams (``Encoder._heads_on_two_streams``)
-PARALLEL_HEADS = True
-
-
 class Encoder(nn.Module):
     def __init__(self, cfg, D):
         super().__init__()
-        self._head_stream = None
         self.D = D
         self.C = cfg.OUT_CHANNELS
         self.use_depth_distribution = cfg.USE_DEPTH_DISTRIBUTION
@@ -112,33 +107,10 @@ class Encoder(nn.Module):
     def get_features_depth(self, x):
         endpoints = self.trunk(x)
         deep, skip = endpoints[self._index], endpoints[self._index - 1]   # reduction_{index+1}, reduction_{index}
-        if self.use_depth_distribution and deep.is_cuda and PARALLEL_HEADS and ops.side_streams():
-            return self._heads_on_two_streams(deep, skip)
         feature = self.feature_layer_2(self.feature_layer_1(deep), skip)
         depth = None
         if self.use_depth_distribution:
             depth = self.depth_layer_2(self.depth_layer_1(deep), skip)
-        return feature, depth
-
-    def _heads_on_two_streams(self, deep, skip):
-        """The feature head and the depth head are two independent chains of a dozen small-map layers each (72 images of
-        14 x 30 / 28 x 60 pixels: 236 .. 945 workgroups per convolution, BatchNorm passes of a few microseconds) on the same
-        two inputs: queued on two HIP streams they share the chip instead of taking turns on a half-empty one.  Autograd
-        runs a node's backward on the stream of its forward, so the backward passes overlap the same way.  Same kernels,
-        same arithmetic per head: same bits as the sequential form."""
-        cur = torch.cuda.current_stream(deep.device)
-        if self._head_stream is None or self._head_stream[0] != deep.device:
-            self._head_stream = (deep.device, torch.cuda.Stream(device=deep.device))
-        side = self._head_stream[1]
-        side.wait_stream(cur)                                  # the trunk's endpoints are complete there
-        feature = self.feature_layer_2(self.feature_layer_1(deep), skip)        # (program order as in the sequential form:
-        with torch.cuda.stream(side):                                            #  the dropout generator is consumed alike)
-            depth = self.depth_layer_2(self.depth_layer_1(deep), skip)
-        cur.wait_stream(side)
-        # allocator bookkeeping: the inputs are read on the side stream, the depth logits are consumed on the main one
-        deep.record_stream(side)
-        skip.record_stream(side)
-        depth.record_stream(cur)
         return feature, depth
 
     def forward(self, x):

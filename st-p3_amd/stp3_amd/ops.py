@@ -1121,96 +1121,16 @@ def _conv2d_launch(x, wb, bias, stride, pad, dil, out_dtype, sums_ptr=None, out_
 _CONV_WORKSPACE = {}
 
 
-# Weight gradients beside the data gradients.  In backward the data gradient of a layer is on the critical path (the next
-# layer's backward waits for it); its weight gradient is not -- nothing reads dW before the optimizer.  ``_conv2d_wgrad``
-# therefore queues the weight-gradient kernels (MFMA-bound, a resident round of workgroups) on a second HIP stream, where
-# they share the chip with the main stream's BatchNorm passes (HBM-bound) and small-map layers (under-occupied) instead of
-# taking turns with them.  Per call: the side stream waits for what the main stream has queued so far (dy is complete
-# there), both operands are recorded on the side stream for the allocator, the launch goes to the side stream with its own
-# scratch.  The main stream joins at the end of the backward pass (an autograd engine callback queued by the first
-# deferred gradient of the pass) and wherever ``join_side_work`` is called (the gradient buckets call it before they
-# touch a gradient).  Same kernels, same arithmetic: same bits.
-SIDE_WGRAD = True
-DIRECT_BUCKET_GRADS = True        # weight gradients of leaf parameters written straight into their gradient-bucket slice
-# Side streams at all?  The eager step gains about a millisecond from them (measured, profiles/r05h_*); a CAPTURED step loses
-# two: hipGraph turns every cross-stream edge into a barrier packet between hardware queues, and replays of the
-# single-stream capture run the ~1 900 kernels back to back with 99 % of the wall time inside kernels.  stp3_amd/graph.py
-# clears this flag around its warm-up and capture.
-SIDE_STREAMS = True
-_SIDE_QUEUES = {}
-
-
-def side_streams():
-    """Whether independent branches of a step may be queued on side streams here: the switch above, and ONE process -- with
-    more than one rank the step carries RCCL exchanges (cross-replica BatchNorm statistics inside the branches, gradient
-    buckets behind the weight gradients) whose interplay with side streams has never run on hardware (no multi-GPU node
-    was available to any round); the N > 1 step therefore stays on the single stream its tests cover."""
-    if not SIDE_STREAMS or not torch.cuda.is_available():       # (the CPU stand-in runs pose as a GPU without one)
-        return False
-    import torch.distributed as dist
-    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-
-
-class _SideQueue:
-    def __init__(self, device):
-        self.device = device
-        self.stream = torch.cuda.Stream(device=device)
-        self.handle = ctypes.c_void_p(self.stream.cuda_stream)
-        self.workspace = None
-        self.pending = False
-
-    def scratch(self, nbytes):
-        if self.workspace is None or self.workspace.numel() < nbytes:
-            self.workspace = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=self.device)
-        return self.workspace
-
-    def join(self):
-        if self.pending:
-            torch.cuda.current_stream(self.device).wait_stream(self.stream)
-            self.pending = False
-
-
-def _side_queue(device):
-    q = _SIDE_QUEUES.get(device)
-    if q is None:
-        q = _SIDE_QUEUES[device] = _SideQueue(device)
-    return q
-
-
-def join_side_work():
-    """The current stream waits for every weight gradient queued on a side stream (no-op when there is none)."""
-    for q in _SIDE_QUEUES.values():
-        q.join()
-
-
-def note_weight_use(weight):
-    """Forward side of the side-stream rule below: count how many operators of the graphs under construction read this
-    weight.  A weight that is used more than once (the GRU cells of the prediction stage) gets its gradient contributions
-    ADDED by the autograd engine on the main stream as they arrive -- a contribution still being computed on the side stream
-    would be read too early; only single-use weights are deferred.  (The count falls back as the backward passes consume the
-    uses; a graph that is dropped without a backward leaves it high, which only switches the deferral off for that weight.)"""
-    if isinstance(weight, torch.nn.Parameter) and weight.requires_grad and torch.is_grad_enabled():
-        weight._stp3_uses = getattr(weight, '_stp3_uses', 0) + 1
-    return weight
-
-
-def _weight_used_once(leaf):
-    """Backward side: True when this is the only use of ``leaf`` in flight; consumes one use either way."""
-    uses = getattr(leaf, '_stp3_uses', 0)
-    pending = getattr(leaf, '_stp3_pending', 0) or uses          # uses still to be consumed by backward calls
-    leaf._stp3_pending = max(pending - 1, 0)
-    if leaf._stp3_pending == 0:
-        leaf._stp3_uses = 0
-    return uses == 1
+# Weight gradients of LEAF parameters are written straight into the parameter's slice of its flat gradient bucket
+# (parallel.GradientBuckets), see ``_conv2d_wgrad``.
+DIRECT_BUCKET_GRADS = True
 
 
 def _conv2d_wgrad(dy, x, wshape, stride, pad, dil, leaf=None):
     """dw (Cout,Cin,KH,KW) float32, channels-last memory, through stp3_conv2d_wgrad (bf16 operands).
     ``leaf``: the tensor the operator received as its weight.  When that is a LEAF parameter without a gradient yet, in
-    float32 and in the layout of dw, autograd's AccumulateGrad keeps dw as the parameter's ``.grad`` without launching
-    anything -- no main-stream kernel reads dw before the backward pass ends, and the gradient may be computed on the side
-    stream.  (A derived weight -- a slice, a concatenation, zero-padded lanes -- hands dw to further autograd operators on
-    the main stream: those stay on the main stream.)"""
+    float32 and in the memory order of dw, autograd's AccumulateGrad keeps the tensor handed back as the parameter's ``.grad``
+    without launching anything -- so it can be written where the optimizer reads it (below)."""
     cout, cin, kh, kw = wshape
     n, _, h, w = x.shape
     x, ldx = _rows_view(x)
@@ -1238,21 +1158,6 @@ def _conv2d_wgrad(dy, x, wshape, stride, pad, dil, leaf=None):
                 and view.dtype == torch.float32 and _same_memory_order(view, dw)):
             leaf._stp3_grad_claim = task
             dw = view.detach()
-    once = leaf is not None and isinstance(leaf, torch.nn.Parameter) and _weight_used_once(leaf)
-    if SIDE_WGRAD and plain_leaf and once and side_streams() and _in_backward():
-        q = _side_queue(x.device)
-        cur = torch.cuda.current_stream(x.device)
-        if not q.pending:
-            q.pending = True
-            torch.autograd.Variable._execution_engine.queue_callback(q.join)     # joined when this backward pass ends
-        q.stream.wait_stream(cur)
-        dy.record_stream(q.stream)
-        x.record_stream(q.stream)
-        dw.record_stream(q.stream)
-        ws = q.scratch(nbytes.value)
-        check(lib.stp3_conv2d_wgrad(ctypes.byref(dims), _ptr(dy), _ptr(x), _ptr(dw), _ptr(ws), ctypes.c_size_t(nbytes.value),
-                                    q.handle), 'stp3_conv2d_wgrad')
-        return dw
     key = _ws_key(x.device)
     ws = _CONV_WORKSPACE.get(key)
     if ws is None or ws.numel() < nbytes.value:
@@ -1275,11 +1180,6 @@ def _graph_task_id():
         return torch._C._current_graph_task_id()
     except AttributeError:
         return -1
-
-
-def _in_backward():
-    """True while the autograd engine is running a backward pass on this thread (only then can a callback be queued)."""
-    return _graph_task_id() != -1
 
 
 _CONV_MAX_STAT_TILES = 65536          # stp3_conv2d_fwd: row tiles of 128 pixels the statistics epilogue can reduce
@@ -1572,7 +1472,7 @@ class _Conv2dMfma(torch.autograd.Function):
         wb, _ = _bf16_weights(weight)
         fb = _f32(bias)
         y = _conv2d_launch(x, wb, fb, stride, pad, dil, out_dtype)
-        ctx.weight_ref = note_weight_use(weight)
+        ctx.weight_ref = weight
         ctx.weight_stamp = weight_stamp(weight)
         ctx.save_for_backward(x, wb)
         ctx.cfg = (stride, pad, dil, bias is not None, weight.dtype, None if bias is None else bias.dtype)

@@ -170,9 +170,6 @@ class GradientBuckets:
 
     def _launch(self, i):
         self._launched[i] = True
-        if self.flat_params[i].is_cuda:
-            from . import ops
-            ops.join_side_work()                 # weight gradients queued on the side stream (ops._conv2d_wgrad) are complete
         if self.gather:
             self._gather(i)
         if self.world > 1:
