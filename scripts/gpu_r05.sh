@@ -5,7 +5,7 @@
 #         suite      the whole GPU suite           parity    step / train parity tests with reports
 #         quickbench bench.py without the CPU leg  bench     bench.py default flags + kernel-trace profile
 #         convpmc    MFMA / wait / LDS counters of the convolution kernels per launched shape
-#         graph      whole-step capture probe
+#         steppmc    counters of every kernel of the (eager) step, per kernel name
 out=gpurun_out/${1:-r05}; mkdir -p $out; shift
 export STP3_PARITY_REPORT=$out/parity.json STP3_PARITY_REPORT_STEP=$out/parity_step.json STP3_IOU_REPORT=$out/iou.json TMPDIR=/tmp
 has() { for w in "$@"; do for a in "${WHAT[@]}"; do [ "$a" == "$w" ] && return 0; done; done; return 1; }
@@ -42,7 +42,7 @@ if has suite; then
   tail -8 $out/pytest.log | cut -c1-300
 fi
 if has convpmc; then bash scripts/gpu_pmc_conv.sh $(basename $out) > $out/convpmc.log 2>&1; tail -3 $out/convpmc.log | cut -c1-300; fi
-if has graph; then timeout 400 python scripts/graph_probe.py > $out/graph_probe.log 2>&1; echo "graph probe rc=$?"; tail -12 $out/graph_probe.log | cut -c1-300; fi
+if has steppmc; then bash scripts/gpu_pmc_step.sh $(basename $out) 2>&1 | tail -50 | cut -c1-160; fi
 if has quickbench; then
   timeout 600 python bench.py --no-cpu-baseline > $out/bench_quick.json 2> $out/bench_quick.err; tail -3 $out/bench_quick.err
   python - <<PY
