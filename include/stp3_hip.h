@@ -212,6 +212,9 @@ int stp3_lift_splat_bwd(const stp3_lift_dims* dims, const void* grad_bev, int be
  *   w  [K*K][C] float32 (tap-major), dw same layout, float32
  *   K in {3,5}, stride in {1,2}; pad_top / pad_left = leading zero padding (the trailing padding is
  *   implied by Ho, Wo: "static same" padding is asymmetric on stride-2 layers)
+ *   K = 7 at stride 1: the 7x7 depthwise layer of the ConvNeXt blocks of the prediction stage
+ *   (stp3/layers/convolutions.py:309-345 `Block.dwconv`, nn.Conv2d(dim, dim, 7, padding=3, groups=dim) WITH a bias:
+ *   stp3_dwconv2d_fwd_bias adds bias[C] float32 (NULL: none); its gradient is the per-channel sum of dy)
  * bwd_weight is deterministic (two-stage reduction through `workspace`, no atomics).
  */
 typedef struct stp3_dwconv_dims {
@@ -223,6 +226,8 @@ typedef struct stp3_dwconv_dims {
 } stp3_dwconv_dims;
 
 int stp3_dwconv2d_fwd(const stp3_dwconv_dims* dims, const void* x, const float* w, void* y, void* stream);
+int stp3_dwconv2d_fwd_bias(const stp3_dwconv_dims* dims, const void* x, const float* w, const float* bias, void* y,
+                           void* stream);
 int stp3_dwconv2d_bwd_data(const stp3_dwconv_dims* dims, const void* dy, const float* w, void* dx, void* stream);
 int stp3_dwconv2d_bwd_weight_workspace(const stp3_dwconv_dims* dims, size_t* bytes);
 int stp3_dwconv2d_bwd_weight(const stp3_dwconv_dims* dims, const void* x, const void* dy, float* dw,

@@ -56,7 +56,7 @@ fi
 if has bench || has profile; then
   if has bench; then timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -3 $out/bench.err; cut -c1-1500 $out/bench.json; fi
   STEPS=4
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r05 -o bench -- python scripts/bench_ab.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-roofline > $out/prof.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r05 -o bench -- python scripts/bench_ab.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-roofline ${BENCH_ARGS:-} > $out/prof.log 2>&1
   grep '^{' $out/prof.log | tail -1 > $out/bench_profiled.json
   KT=$(find /tmp/prof_r05 -name '*kernel_trace.csv' | head -1)
   MS=$(python -c "import json;print(json.load(open('$out/bench_profiled.json'))['ms_per_step'])" 2>/dev/null || echo 60)

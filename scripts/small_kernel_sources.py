@@ -23,14 +23,15 @@ def main():
     ap.add_argument('--batch', type=int, default=4)
     ap.add_argument('--top', type=int, default=70)
     ap.add_argument('--by-time', action='store_true', help='sort by device time instead of launches')
+    ap.add_argument('--workload', default='c3', choices=sorted(bench.WORKLOADS))
     ap.add_argument('--aten-only', action='store_true', help='torch operators only (not the custom autograd functions)')
     a = ap.parse_args()
     from stp3_amd.parallel import FlatAdam, GradientBuckets
     device = torch.device('cuda', 0)
-    module, cfg = bench.build_module(device, sync_bn=True)
+    module, cfg = bench.build_module(device, sync_bn=True, workload=a.workload)
     buckets = GradientBuckets(module.model, gather=True)
     opt = FlatAdam(buckets, lr=cfg.OPTIMIZER.LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY)
-    batch = bench.make_device_batch(a.batch, device, seed=100)
+    batch = bench.make_device_batch(a.batch, device, seed=100, workload=a.workload)
 
     def step():
         buckets.zero_grad()

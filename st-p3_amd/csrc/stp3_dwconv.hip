@@ -73,7 +73,8 @@ __device__ __forceinline__ int xcd_order(int bid, int nwg) {
 // (TW outputs per thread share one input span per kernel row; the tap-major weights are read once per row).
 template <typename T, int K, int S, int TW, bool FLIP>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwDims d, const T* __restrict__ x,
-                                                         const float* __restrict__ w, T* __restrict__ y) {
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         T* __restrict__ y) {
     constexpr int VN = Vec<T>::N;
     const int CV = d.C / VN;
     const int wgroups = (d.Wo + TW - 1) / TW;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwDims d, const T* __re
 #pragma unroll
     for (int i = 0; i < TW; ++i)
 #pragma unroll
-        for (int j = 0; j < VN; ++j) acc[i][j] = 0.f;
+        for (int j = 0; j < VN; ++j) acc[i][j] = bias ? bias[c0 + j] : 0.f;     // (the ConvNeXt blocks' 7x7 layers have one)
     constexpr int SPAN = (TW - 1) * S + K;
     const int wi0 = wo0 * S - d.pad_l;
 #pragma unroll
@@ -504,7 +505,9 @@ inline int status() {
 inline int check(const stp3_dwconv_dims* p, DwDims* d, int* vec) {
     if (!p) return STP3_EINVAL;
     if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->C <= 0 || p->Ho <= 0 || p->Wo <= 0) return STP3_EINVAL;
-    if (!((p->K == 3 || p->K == 5) && (p->stride == 1 || p->stride == 2))) return STP3_EUNSUP;
+    // 3x3 / 5x5 at strides 1 and 2 (EfficientNet trunk), 7x7 at stride 1 (ConvNeXt blocks of the prediction stage)
+    if (!(((p->K == 3 || p->K == 5) && (p->stride == 1 || p->stride == 2)) || (p->K == 7 && p->stride == 1)))
+        return STP3_EUNSUP;
     if (p->dtype != STP3_DTYPE_F32 && p->dtype != STP3_DTYPE_BF16) return STP3_EUNSUP;
     *vec = p->dtype == STP3_DTYPE_BF16 ? 8 : 4;
     if (p->C % *vec) return STP3_EUNSUP;
@@ -515,12 +518,12 @@ inline int check(const stp3_dwconv_dims* p, DwDims* d, int* vec) {
 }
 
 template <typename T, int K, int S>
-int launch_fwd(const DwDims& d, const void* x, const float* w, void* y, hipStream_t s) {
+int launch_fwd(const DwDims& d, const void* x, const float* w, const float* bias, void* y, hipStream_t s) {
     constexpr int TW = 4;
     const int CV = d.C / Vec<T>::N;
     const int64_t total = (int64_t)d.N * d.Ho * ((d.Wo + TW - 1) / TW) * CV;
     hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, S, TW, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d,
-                       (const T*)x, w, (T*)y);
+                       (const T*)x, w, bias, (T*)y);
     return status();
 }
 template <typename T, int K, int S>
@@ -551,7 +554,7 @@ int launch_bwd_data(const DwDims& d, const void* dy, const float* w, void* dx, h
         f.pad_t = K - 1 - d.pad_t; f.pad_l = K - 1 - d.pad_l;
         const int64_t n = (int64_t)f.N * f.Ho * ((f.Wo + TW - 1) / TW) * (f.C / Vec<T>::N);
         hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, 1, TW, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, f,
-                           (const T*)dy, w, (T*)dx);
+                           (const T*)dy, w, (const float*)nullptr, (T*)dx);
         return status();
     } else if constexpr (S == 2) {
         // quads: rows 2a - pt, 2a + 1 - pt for a = pt / 2 .. (H - 1 + pt) / 2
@@ -600,6 +603,7 @@ int launch_bwd_weight(const DwDims& d, const void* x, const void* dy, float* dw,
         if (p->K == 3 && p->stride == 1) return bf ? FN<uint16_t, 3, 1>(__VA_ARGS__) : FN<float, 3, 1>(__VA_ARGS__); \
         if (p->K == 3 && p->stride == 2) return bf ? FN<uint16_t, 3, 2>(__VA_ARGS__) : FN<float, 3, 2>(__VA_ARGS__); \
         if (p->K == 5 && p->stride == 1) return bf ? FN<uint16_t, 5, 1>(__VA_ARGS__) : FN<float, 5, 1>(__VA_ARGS__); \
+        if (p->K == 7) return bf ? FN<uint16_t, 7, 1>(__VA_ARGS__) : FN<float, 7, 1>(__VA_ARGS__);                   \
         return bf ? FN<uint16_t, 5, 2>(__VA_ARGS__) : FN<float, 5, 2>(__VA_ARGS__);                       \
     } while (0)
 
@@ -612,7 +616,16 @@ int stp3_dwconv2d_fwd(const stp3_dwconv_dims* p, const void* x, const float* w, 
     int rc = check(p, &d, &vec);
     if (rc) return rc;
     if (!x || !w || !y) return STP3_EINVAL;
-    DISPATCH(launch_fwd, d, x, w, y, (hipStream_t)stream);
+    DISPATCH(launch_fwd, d, x, w, (const float*)nullptr, y, (hipStream_t)stream);
+}
+
+int stp3_dwconv2d_fwd_bias(const stp3_dwconv_dims* p, const void* x, const float* w, const float* bias, void* y,
+                           void* stream) {
+    DwDims d; int vec;
+    int rc = check(p, &d, &vec);
+    if (rc) return rc;
+    if (!x || !w || !y) return STP3_EINVAL;
+    DISPATCH(launch_fwd, d, x, w, bias, y, (hipStream_t)stream);
 }
 
 int stp3_dwconv2d_fwd_stats_workspace(const stp3_dwconv_dims* p, size_t* bytes) {

@@ -149,6 +149,7 @@ SIGNATURES = {
     'stp3_lift_splat_bwd': (c_int, [_DIMS_P, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_float, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     'stp3_dwconv2d_fwd': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'stp3_dwconv2d_fwd_bias': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_dwconv2d_bwd_data': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_dwconv2d_bwd_weight_workspace': (c_int, [_DW_P, ctypes.POINTER(c_size_t)]),
     'stp3_dwconv2d_bwd_weight': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -502,11 +502,11 @@ def _dw_weight_taps(weight):
 
 
 class _DepthwiseConv2d(torch.autograd.Function):
-    """x (N,C,H,W) channels-last memory, weight (C,1,K,K) -> y (N,C,Ho,Wo) channels-last memory.
+    """x (N,C,H,W) channels-last memory, weight (C,1,K,K) [, bias (C)] -> y (N,C,Ho,Wo) channels-last memory.
     pad = (left, right, top, bottom) explicit zero padding ("static same": may be asymmetric)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, pad):
+    def forward(ctx, x, weight, stride, pad, bias=None):
         _need_gpu(x, weight)
         c, _, k, _ = weight.shape
         left, right, top, bottom = pad
@@ -517,12 +517,18 @@ class _DepthwiseConv2d(torch.autograd.Function):
         wt = _dw_weight_taps(weight)                                            # [K*K][C] float32
         y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         dims = _dw_dims(x, k, stride, top, left, ho, wo)
-        check(_lib.lib().stp3_dwconv2d_fwd(ctypes.byref(dims), _ptr(x), _ptr(wt), _ptr(y), _stream()),
-              'stp3_dwconv2d_fwd')
+        if bias is None:
+            check(_lib.lib().stp3_dwconv2d_fwd(ctypes.byref(dims), _ptr(x), _ptr(wt), _ptr(y), _stream()),
+                  'stp3_dwconv2d_fwd')
+        else:
+            bf = bias.detach().float().contiguous()
+            check(_lib.lib().stp3_dwconv2d_fwd_bias(ctypes.byref(dims), _ptr(x), _ptr(wt), _ptr(bf), _ptr(y), _stream()),
+                  'stp3_dwconv2d_fwd_bias')
         ctx.save_for_backward(x, wt)
         ctx.dims = dims
         ctx.wshape = weight.shape
         ctx.wdtype = weight.dtype
+        ctx.bdtype = None if bias is None else bias.dtype
         return y
 
     @staticmethod
@@ -547,18 +553,33 @@ class _DepthwiseConv2d(torch.autograd.Function):
             check(lib.stp3_dwconv2d_bwd_weight(ctypes.byref(dims), _ptr(x), _ptr(dy), _ptr(dwt), _ptr(ws),
                                                ctypes.c_size_t(nbytes.value), _stream()), 'stp3_dwconv2d_bwd_weight')
             dw = dwt.t().reshape(ctx.wshape).to(ctx.wdtype)
-        return dx, dw, None, None
+        db = None
+        if ctx.bdtype is not None and ctx.needs_input_grad[4]:
+            db = channel_sums(dy).to(ctx.bdtype)
+        return dx, dw, None, None, db
 
 
 _DW_APPLY = _fast_apply(_DepthwiseConv2d)
 
 
-def depthwise_conv2d(x, weight, stride=1, pad=(0, 0, 0, 0)):
+def depthwise_conv2d(x, weight, stride=1, pad=(0, 0, 0, 0), bias=None):
     """Depthwise conv (groups == channels) through the HIP kernels.  Under autocast the activations
-    run in the autocast dtype (bf16); the weights are consumed in float32 either way."""
+    run in the autocast dtype (bf16); the weights (and the bias) are consumed in float32 either way."""
     if torch.is_autocast_enabled():
         x = x.to(torch.get_autocast_dtype('cuda'))
-    return _DW_APPLY(x, weight, int(stride), tuple(int(p) for p in pad))
+    if bias is None:
+        return _DW_APPLY(x, weight, int(stride), tuple(int(p) for p in pad))
+    return _DW_APPLY(x, weight, int(stride), tuple(int(p) for p in pad), bias)
+
+
+def depthwise_supported(x, weight, stride):
+    """What stp3_dwconv2d_* take: 3x3 / 5x5 at strides 1 and 2, 7x7 at stride 1; channels a multiple of the 16-byte vector."""
+    k, s = weight.shape[-1], _pair(stride)
+    if not (x.is_cuda and x.dim() == 4 and weight.shape[1] == 1 and weight.shape[-2] == k and s[0] == s[1]):
+        return False
+    if not ((k in (3, 5) and s[0] in (1, 2)) or (k == 7 and s[0] == 1)):
+        return False
+    return x.shape[1] % 8 == 0
 
 
 # ``num_batches_tracked`` -- one int64 increment KERNEL per BatchNorm layer and step in the reference -- is counted on

@@ -568,18 +568,25 @@ def dwconv(ops):
     import torch.nn.functional as F
     out = {}
     torch.manual_seed(3)
-    for name, (k, s, pad) in {'k3s1': (3, 1, (1, 1, 1, 1)), 'k5s2': (5, 2, (1, 2, 1, 2)), 'k3s2': (3, 2, (0, 1, 0, 1))}.items():
+    cases = {'k3s1': (3, 1, (1, 1, 1, 1), False), 'k5s2': (5, 2, (1, 2, 1, 2), False), 'k3s2': (3, 2, (0, 1, 0, 1), False),
+             'k7s1_bias': (7, 1, (3, 3, 3, 3), True)}                  # the ConvNeXt blocks' 7x7 layer (has a bias)
+    for name, (k, s, pad, bias) in cases.items():
         c = 24
         x0 = torch.randn(2, c, 9, 12).contiguous(memory_format=torch.channels_last)
         w0 = torch.randn(c, 1, k, k) * 0.3
+        b0 = torch.randn(c) * 0.5 if bias else None
         x, w = x0.clone().requires_grad_(), w0.clone().requires_grad_()
-        y = ops.depthwise_conv2d(x, w, s, pad)
+        b = b0.clone().requires_grad_() if bias else None
+        y = ops.depthwise_conv2d(x, w, s, pad, bias=b)
         gy = torch.randn_like(y)
         y.backward(gy)
         xr, wr = x0.clone().requires_grad_(), w0.clone().requires_grad_()
-        yr = F.conv2d(F.pad(xr, pad), wr, None, s, 0, 1, c)
+        br = b0.clone().requires_grad_() if bias else None
+        yr = F.conv2d(F.pad(xr, pad), wr, br, s, 0, 1, c)
         yr.backward(gy)
         out[name] = {'y': rel(y.detach(), yr.detach()), 'dx': rel(x.grad, xr.grad), 'dw': rel(w.grad, wr.grad)}
+        if bias:
+            out[name]['db'] = rel(b.grad, br.grad)
     return out
 
 

@@ -22,6 +22,8 @@ CASES = [
     (2, 960, 14, 30, 5, 1, (2, 2, 2, 2)),
     (1, 8, 5, 7, 3, 2, (0, 1, 0, 1)),           # tiny / ragged
     (1, 16, 1, 1, 5, 1, (2, 2, 2, 2)),          # 1x1 map: only the centre tap is ever in range
+    (3, 64, 50, 47, 7, 1, (3, 3, 3, 3)),        # the 7x7 layer of the prediction stage's ConvNeXt blocks
+    (1, 8, 3, 4, 7, 1, (3, 3, 3, 3)),           # ... on a map smaller than the kernel
 ]
 
 
@@ -63,6 +65,32 @@ def test_depthwise_conv_matches_torch_cpu(case, dtype):
     torch.testing.assert_close(y.float().cpu(), y_ref, **tol)
     torch.testing.assert_close(xg.grad.float().cpu(), dx_ref, **tol)
     torch.testing.assert_close(wg.grad.float().cpu(), dw_ref, **wtol)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_depthwise_7x7_with_bias_matches_torch_cpu(dtype):
+    """stp3_dwconv2d_fwd_bias: nn.Conv2d(dim, dim, 7, padding=3, groups=dim) of stp3/layers/convolutions.py:318 -- output,
+    input gradient, weight gradient and the bias gradient (per-channel sum of dy)."""
+    from stp3_amd import ops
+    n, c, h, w_ = 2, 64, 40, 36
+    x = H.det_tensor((n, c, h, w_), 11)
+    wt, b = H.det_tensor((c, 1, 7, 7), 12, 0.3), H.det_tensor((c,), 13, 0.5)
+    dy = H.det_tensor((n, c, h, w_), 14)
+    if dtype == torch.bfloat16:
+        x, dy = x.bfloat16().float(), dy.bfloat16().float()
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, 1, 3, 1, c)
+    yr.backward(dy)
+    xg = x.to(dtype).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wg, bg = wt.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = ops.depthwise_conv2d(xg, wg, 1, (3, 3, 3, 3), bias=bg)
+    y.backward(dy.to(dtype).cuda())
+    tol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    wtol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=1e-3, atol=1e-3 * (n * h * w_) ** 0.5)
+    torch.testing.assert_close(y.float().cpu(), yr.detach(), **tol)
+    torch.testing.assert_close(xg.grad.float().cpu(), xr.grad, **tol)
+    torch.testing.assert_close(wg.grad.float().cpu(), wr.grad, **wtol)
+    torch.testing.assert_close(bg.grad.float().cpu(), br.grad, **wtol)
 
 
 def test_weight_gradient_is_bit_reproducible():

@@ -205,7 +205,7 @@ def test_convolution_kernels(results):
     for name, r in _get(results, 'dwconv').items():
         if name == 'seconds':
             continue
-        assert r['y'] <= 1e-5 and r['dx'] <= 1e-5 and r['dw'] <= 1e-4, (name, r)
+        assert r['y'] <= 1e-5 and r['dx'] <= 1e-5 and r['dw'] <= 1e-4 and r.get('db', 0.0) <= 1e-4, (name, r)
 
 
 def test_label_kernels(results):

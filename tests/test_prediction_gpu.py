@@ -15,7 +15,7 @@ def test_prediction_layers_float32(name):
     assert errs['out'] <= 5e-4 and max(errs.values()) <= 5e-3, errs
 
 
-@pytest.mark.parametrize('name', ['bottleneck_ds', 'bottleblock', 'spatial_gru', 'dual_gru', 'future_prediction'])
+@pytest.mark.parametrize('name', ['bottleneck_ds', 'block', 'bottleblock', 'spatial_gru', 'dual_gru', 'future_prediction'])
 def test_prediction_layers_bf16(name):
     errs = run_case(name, device='cuda', autocast=True)
     # the whole FuturePrediction is a 7-step recurrent chain behind which sit BatchNorm + ReLU stages: its INPUT gradients
