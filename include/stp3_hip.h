@@ -238,6 +238,34 @@ int stp3_dwconv2d_bwd_weight_oihw(const stp3_dwconv_dims* dims, const void* x, c
                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * LayerNorm over the channels of every pixel (+ GELU), channels-last rows -- the prediction stage (SURVEY.md section 8 row
+ * f2).  Replaces `LayerNorm` of stp3/layers/convolutions.py:283-307 (F.layer_norm over C in its channels_last form, the
+ * hand-written mean / variance over dim 1 in its channels_first form: the same normalisation) and the nn.GELU() that
+ * follows it in `Bottleblock` (:347-380); `Block` (:309-345) uses it without the activation.
+ *   x, dx [rows][ldx >= C], y / dy [rows][ldy >= C]   dtype STP3_DTYPE_F32 / _BF16, float32 arithmetic, one rounding
+ *   y = act((x - mean_c) / sqrt(var_c + eps) * gamma + beta), biased variance; gamma / beta [C] float32 (NULL: 1 / 0)
+ *   act = STP3_ACT_NONE or STP3_ACT_GELU (defined with the other activations below; exact: 0.5 v (1 + erf(v / sqrt 2)))
+ *   C / (16 bytes of elements) must be a power of two <= 64, ld multiples of it, 16-byte aligned pointers (STP3_EUNSUP
+ *   otherwise: the caller keeps torch's operator)
+ * bwd recomputes the row statistics from x; dgamma / dbeta [C] float32 (either may be NULL) through a two-stage
+ * deterministic reduction in `workspace` (stp3_layernorm_bwd_workspace bytes).
+ */
+typedef struct stp3_layernorm_dims {
+    int64_t rows;                /* pixels: N * H * W                         */
+    int32_t C, ldx, ldy;         /* channels, row strides (elements)          */
+    int32_t dtype;               /* STP3_DTYPE_*                              */
+    int32_t act;                 /* STP3_ACT_NONE | STP3_ACT_GELU             */
+    float eps;
+} stp3_layernorm_dims;
+
+int stp3_layernorm_fwd(const stp3_layernorm_dims* dims, const void* x, const float* gamma, const float* beta, void* y,
+                       void* stream);
+int stp3_layernorm_bwd_workspace(const stp3_layernorm_dims* dims, size_t* bytes);
+int stp3_layernorm_bwd(const stp3_layernorm_dims* dims, const void* dy, const void* x, const float* gamma,
+                       const float* beta, void* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused BatchNorm (+ per-sample bias) + activation (+ residual), channels-last, forward / backward.
  * Replaces the nn.BatchNorm2d/3d -> ReLU / swish (-> "+ skip") chains of
  * stp3/layers/convolutions.py:183-280, stp3/layers/temporal.py:252-273,315-325,426-489,
@@ -272,6 +300,7 @@ int stp3_dwconv2d_bwd_weight_oihw(const stp3_dwconv_dims* dims, const void* x, c
 #define STP3_ACT_NONE  0
 #define STP3_ACT_RELU  1
 #define STP3_ACT_SWISH 2
+#define STP3_ACT_GELU  3   /* stp3_layernorm_* only */
 #define STP3_RES_NONE       0
 #define STP3_RES_BEFORE_ACT 1
 #define STP3_RES_AFTER_ACT  2

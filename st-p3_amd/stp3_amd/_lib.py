@@ -46,6 +46,12 @@ class DwConvDims(ctypes.Structure):
                                               'dtype')]
 
 
+class LayerNormDims(ctypes.Structure):
+    """struct stp3_layernorm_dims (include/stp3_hip.h)."""
+    _fields_ = [('rows', ctypes.c_int64), ('C', ctypes.c_int32), ('ldx', ctypes.c_int32), ('ldy', ctypes.c_int32),
+                ('dtype', ctypes.c_int32), ('act', ctypes.c_int32), ('eps', ctypes.c_float)]
+
+
 class BnDims(ctypes.Structure):
     """struct stp3_bn_dims (include/stp3_hip.h)."""
     _fields_ = [(k, ctypes.c_int32) for k in ('N', 'rows', 'C', 'ldx', 'ldy', 'ldr', 'dtype', 'act', 'res_mode',
@@ -128,12 +134,14 @@ BEV_CHANNELS_LAST = 1
 BEV_CHANNELS_LAST_BF16 = 2
 
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
+ACT_GELU = 3                  # stp3_layernorm_* only
 RES_NONE, RES_BEFORE_ACT, RES_AFTER_ACT = 0, 1, 2
 
 _DIMS_P = ctypes.POINTER(LiftDims)
 _BN_P = ctypes.POINTER(BnDims)
 c_double = ctypes.c_double
 _DW_P = ctypes.POINTER(DwConvDims)
+_LN_P = ctypes.POINTER(LayerNormDims)
 
 # name -> (restype, argtypes); mirrors include/stp3_hip.h one to one
 SIGNATURES = {
@@ -148,6 +156,9 @@ SIGNATURES = {
     'stp3_lift_bwd_needs_prob': (c_int, [_DIMS_P, ctypes.POINTER(c_int)]),
     'stp3_lift_splat_bwd': (c_int, [_DIMS_P, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_float, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    'stp3_layernorm_fwd': (c_int, [_LN_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'stp3_layernorm_bwd_workspace': (c_int, [_LN_P, ctypes.POINTER(c_size_t)]),
+    'stp3_layernorm_bwd': (c_int, [_LN_P] + [c_void_p] * 8 + [c_size_t, c_void_p]),
     'stp3_dwconv2d_fwd': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_dwconv2d_fwd_bias': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_dwconv2d_bwd_data': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -13,7 +13,7 @@ Exact work reductions relative to a literal translation (no approximation):
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, ops_pred
 from ..utils import hp
 from .fused import (ACT_NONE, ACT_RELU, RES_AFTER_ACT, _sync_world, bn_act, bn_act_group, conv1x1_on_vector, conv2d,
                     conv_bn_act_member, conv_module, plane_mean, pooled_bias, run_fused)
@@ -265,10 +265,16 @@ class LayerNorm(nn.Module):
     def forward(self, x):
         if self.data_format == 'channels_last':
             return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
-        # channels_first: the same normalisation over dim 1 -- evaluated on the (N,H,W,C) VIEW, which for the
-        # channels-last tensors of this code base is contiguous memory: one fused layer_norm instead of five passes
-        y = F.layer_norm(x.permute(0, 2, 3, 1), self.normalized_shape, self.weight, self.bias, self.eps)
-        return y.permute(0, 3, 1, 2)
+        return self.channels_first(x)
+
+    def channels_first(self, x, act=ops_pred.ACT_NONE):
+        """The normalisation over dim 1 of (N,C,H,W) [+ GELU]: on the GPU one pass of stp3_layernorm_fwd over the
+        channels-last rows; otherwise F.layer_norm on the (N,H,W,C) VIEW, which for the channels-last tensors of this code
+        base is contiguous memory (one fused layer_norm instead of the reference's five passes)."""
+        if ops_pred.layer_norm_supported(x, self.normalized_shape[0]):
+            return ops_pred.layer_norm_channels(x, self.weight, self.bias, self.eps, act)
+        y = F.layer_norm(x.permute(0, 2, 3, 1), self.normalized_shape, self.weight, self.bias, self.eps).permute(0, 3, 1, 2)
+        return F.gelu(y) if act == ops_pred.ACT_GELU else y
 
 
 class Block(nn.Module):
@@ -300,7 +306,7 @@ class Block(nn.Module):
         if on_kernels and (y.dtype == torch.bfloat16 or torch.is_autocast_enabled()):
             # the two Linear layers act on the channels of every pixel: 1x1 convolutions of the channels-last tensor, on
             # the streaming MFMA kernels (hipBLASLt picks a 26 TFLOP/s kernel for the 1 120 000 x 64 x 256 product)
-            z = self.norm(y.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+            z = self.norm.channels_first(y)
             h = self.act(conv2d(z, self.pwconv1.weight[:, :, None, None], self.pwconv1.bias))
             o = conv2d(h, self.pwconv2.weight[:, :, None, None], self.pwconv2.bias)
             if self.gamma is None:
@@ -331,5 +337,14 @@ class Bottleblock(nn.Module):
             nn.Conv2d(in_channels, out_channels, kernel_size=1, bias=False), nn.GELU())
 
     def forward(self, x):
-        y = run_fused(self.layers, x)
+        y, mods, i = x, list(self.layers), 0
+        while i < len(mods):                         # conv -> LayerNorm -> GELU three times: the last two as one pass
+            m = mods[i]
+            if isinstance(m, LayerNorm) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.GELU) \
+                    and m.data_format == 'channels_first':
+                y = m.channels_first(y, ops_pred.ACT_GELU)
+                i += 2
+                continue
+            y = conv_module(m, y) if type(m) is nn.Conv2d else m(y)
+            i += 1
         return y + (x if self.projection is None else run_fused(self.projection, x))

@@ -1370,8 +1370,39 @@ def fuzz(ops, seed=1):
     return {'problems': [[t, str(c), n, str(e)] for t, c, n, e in bad]}
 
 
+def layernorm(ops):
+    """stp3_layernorm_fwd / _bwd (stp3/layers/convolutions.py:283-307 LayerNorm over the channels, + the GELU behind it in
+    Bottleblock) against float64 torch autograd: float32 and bf16 rows, 32 / 64 / 24-of-a-slice channels, with and without
+    the activation; outputs, input gradient, gamma / beta gradients."""
+    import torch.nn.functional as F
+    from stp3_amd import ops_pred
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    cl = torch.channels_last
+    for name, (c, dtype, act, sliced) in {'c64_f32': (64, torch.float32, False, False), 'c32_f32_gelu': (32, torch.float32, True, False),
+                                          'c64_bf16': (64, torch.bfloat16, False, False), 'c32_bf16_gelu': (32, torch.bfloat16, True, False),
+                                          'c64_bf16_gelu_slice': (64, torch.bfloat16, True, True)}.items():
+        n, h, w = 2, 7, 9
+        full = (torch.randn(n, c + (16 if sliced else 0), h, w, generator=g) * 1.5 + 0.3).to(dtype).contiguous(memory_format=cl)
+        x0 = full[:, 8:8 + c] if sliced else full                       # a channel slice: row stride > C
+        w0, b0 = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+        assert ops_pred.layer_norm_supported(x0, c)
+        x, wt, b = x0.clone().requires_grad_() if not sliced else x0.detach().requires_grad_(), w0.clone().requires_grad_(), b0.clone().requires_grad_()
+        y = ops_pred.layer_norm_channels(x, wt, b, 1e-6, ops_pred.ACT_GELU if act else ops_pred.ACT_NONE)
+        gy = torch.randn(y.shape, generator=g).to(dtype)
+        y.backward(gy)
+        xr, wr, br = x0.detach().double().requires_grad_(), w0.double().requires_grad_(), b0.double().requires_grad_()
+        yr = F.layer_norm(xr.permute(0, 2, 3, 1), (c,), wr, br, 1e-6).permute(0, 3, 1, 2)
+        if act:
+            yr = F.gelu(yr)
+        yr.backward(gy.double())
+        out[name] = {'y': rel(y.detach().float(), yr.detach()), 'dx': rel(x.grad.float(), xr.grad), 'dw': rel(wt.grad, wr.grad),
+                     'db': rel(b.grad, br.grad), 'dtype': str(y.dtype), 'cl': bool(y.is_contiguous(memory_format=cl))}
+    return out
+
+
 CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_rolled, lift_c64_frames, lift_coarse_grid, lift_tall, lift_c64_rows56, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
-                                 conv, conv_f32, fan_out, aspp_join, pointwise_bn, pointwise_stream, decoder_heads, dwconv, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
+                                 conv, conv_f32, fan_out, aspp_join, pointwise_bn, pointwise_stream, decoder_heads, dwconv, layernorm, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
 
 if __name__ == '__main__':
     ops_mod = setup(sys.argv[1])

@@ -27,10 +27,10 @@ sys.path.insert(0, HIPCPU)
 import build as hipcpu_build  # noqa: E402
 
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
-ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
+ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('layernorm', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
            ('conv', {}), ('conv_f32', {}), ('fan_out', {}), ('aspp_join', {}), ('pointwise_bn', {}), ('pointwise_stream', {}), ('decoder_heads', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('labels', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}), ('lift_c64_rolled', {}),
            ('lift_c64_frames', {}), ('lift_c64_rows56', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
-ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'conv', 'conv_bn', 'pointwise_bn', 'pointwise_stream', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'labels', 'lift_c16']
+ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'layernorm', 'bn_act', 'conv', 'conv_bn', 'pointwise_bn', 'pointwise_stream', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'labels', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)]
 MODEL = [('lift_full', {}), ('model_step_two_ranks', {}), ('model_step_f32_full_losses', {}), ('model_step_f32', {}),
          ('model_step_bf16_bn_eval', {})]        # whole training steps: minutes, STP3_SLOW_TESTS=1
@@ -208,6 +208,18 @@ def test_convolution_kernels(results):
         assert r['y'] <= 1e-5 and r['dx'] <= 1e-5 and r['dw'] <= 1e-4 and r.get('db', 0.0) <= 1e-4, (name, r)
 
 
+def test_layernorm_over_channels(results):
+    """stp3_layernorm_fwd / _bwd (stp3/layers/convolutions.py:283-307, + the GELU of Bottleblock :347-380) against float64
+    autograd: float32 rows to rounding, bf16 rows to bf16 rounding of the result, parameter gradients (float32
+    accumulation, two-stage reduction) to 1e-5; a channel slice as input keeps its row stride."""
+    for name, r in _get(results, 'layernorm').items():
+        if name == 'seconds':
+            continue
+        tol = 4e-3 if 'bf16' in name else 1e-6
+        assert r['y'] <= tol and r['dx'] <= tol and r['dw'] <= 1e-5 and r['db'] <= 1e-5 and r['cl'], (name, r)
+        assert r['dtype'] == ('torch.bfloat16' if 'bf16' in name else 'torch.float32'), (name, r)
+
+
 def test_label_kernels(results):
     """stp3_fill_polygons (cv2.fillPoly restated: equal to the oracle's fixture and to the CPU statement on random 3..8-gons
     painted over each other) and stp3_instance_labels (equal to the reference's own function)."""
@@ -375,7 +387,7 @@ def test_no_out_of_bounds_access_under_address_sanitizer(tmp_path):
                              capture_output=True, text=True, timeout=3000)
         return case, extra, out
 
-    jobs = [(c, {}) for c in ('voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'bn_act', 'bn_act_padded', 'causal_pair', 'upsample', 'conv', 'conv_bn', 'lift_c16',
+    jobs = [(c, {}) for c in ('voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'layernorm', 'bn_act', 'bn_act_padded', 'causal_pair', 'upsample', 'conv', 'conv_bn', 'lift_c16',
                               'lift_c16_rows32', 'lift_c64_many_runs', 'lift_c64_frames', 'lift_coarse_grid', 'lift_small', 'lift_tall')]
     with ThreadPoolExecutor(max_workers=4) as pool:
         done = list(pool.map(lambda j: run(*j), jobs))
