@@ -238,6 +238,36 @@ int stp3_dwconv2d_bwd_weight_oihw(const stp3_dwconv_dims* dims, const void* x, c
                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Element-wise half of the convolutional GRU cells of the prediction stage.  Replaces, around
+ * the three convolutions of `SpatialGRU.gru_cell` (stp3/layers/temporal.py:42-56) and `Dual_GRU.gru_cell_1 / _2`
+ * (:118-145):  update, reset = sigmoid(conv([x, state]) + bias_init);  tilde = conv([x, (1 - reset) * state]);
+ * out = (1 - update) * state + update * tilde  -- and the gradients autograd derives from them.
+ *   rows = N * H * W pixels, channels-last.  xs, xs2, dxs2, acc [rows][Cx + C] = [x | state];
+ *   gates, dgates [rows][2C] = [update | reset] PRE-activations (the two gate convolutions run as one with 2C outputs);
+ *   tilde, dtilde, out [rows][C];  dout [rows][ld_dout >= C].  dtype STP3_DTYPE_F32 / _BF16 (float32 arithmetic, one
+ *   rounding per result); Cx, C multiples of 16 bytes of elements, 16-byte aligned pointers (STP3_EUNSUP otherwise).
+ *   reset_cat_fwd : xs2 = [x | (1 - r) state]                       (the operand of the tilde convolution)
+ *   output_fwd    : out = (1 - u) state + u tilde
+ *   output_bwd    : dtilde = dout u;  dgates[:, :C] = dout (tilde - state) u (1 - u)
+ *   reset_cat_bwd : acc = [dxs2_x | dout (1 - u) + dxs2_state (1 - r)];  dgates[:, C:] = -dxs2_state state r (1 - r)
+ *                   (the caller adds the data gradient of the gate convolution to acc: d[x | state])
+ */
+typedef struct stp3_gru_dims {
+    int64_t rows;
+    int32_t Cx, C;               /* channels of x and of the state              */
+    int32_t dtype;               /* STP3_DTYPE_*                                */
+    float bias_init;             /* gru_bias_init of the reference (default 0)  */
+} stp3_gru_dims;
+
+int stp3_gru_reset_cat_fwd(const stp3_gru_dims* dims, const void* xs, const void* gates, void* xs2, void* stream);
+int stp3_gru_output_fwd(const stp3_gru_dims* dims, const void* gates, const void* xs, const void* tilde, void* out,
+                        void* stream);
+int stp3_gru_output_bwd(const stp3_gru_dims* dims, const void* dout, int32_t ld_dout, const void* gates, const void* xs,
+                        const void* tilde, void* dtilde, void* dgates, void* stream);
+int stp3_gru_reset_cat_bwd(const stp3_gru_dims* dims, const void* dout, int32_t ld_dout, const void* gates, const void* xs,
+                           const void* dxs2, void* acc, void* dgates, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * LayerNorm over the channels of every pixel (+ GELU), channels-last rows -- the prediction stage (SURVEY.md section 8 row
  * f2).  Replaces `LayerNorm` of stp3/layers/convolutions.py:283-307 (F.layer_norm over C in its channels_last form, the
  * hand-written mean / variance over dim 1 in its channels_first form: the same normalisation) and the nn.GELU() that

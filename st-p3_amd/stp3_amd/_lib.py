@@ -52,6 +52,12 @@ class LayerNormDims(ctypes.Structure):
                 ('dtype', ctypes.c_int32), ('act', ctypes.c_int32), ('eps', ctypes.c_float)]
 
 
+class GruDims(ctypes.Structure):
+    """struct stp3_gru_dims (include/stp3_hip.h)."""
+    _fields_ = [('rows', ctypes.c_int64), ('Cx', ctypes.c_int32), ('C', ctypes.c_int32), ('dtype', ctypes.c_int32),
+                ('bias_init', ctypes.c_float)]
+
+
 class BnDims(ctypes.Structure):
     """struct stp3_bn_dims (include/stp3_hip.h)."""
     _fields_ = [(k, ctypes.c_int32) for k in ('N', 'rows', 'C', 'ldx', 'ldy', 'ldr', 'dtype', 'act', 'res_mode',
@@ -142,6 +148,7 @@ _BN_P = ctypes.POINTER(BnDims)
 c_double = ctypes.c_double
 _DW_P = ctypes.POINTER(DwConvDims)
 _LN_P = ctypes.POINTER(LayerNormDims)
+_GRU_P = ctypes.POINTER(GruDims)
 
 # name -> (restype, argtypes); mirrors include/stp3_hip.h one to one
 SIGNATURES = {
@@ -156,6 +163,10 @@ SIGNATURES = {
     'stp3_lift_bwd_needs_prob': (c_int, [_DIMS_P, ctypes.POINTER(c_int)]),
     'stp3_lift_splat_bwd': (c_int, [_DIMS_P, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_float, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    'stp3_gru_reset_cat_fwd': (c_int, [_GRU_P, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'stp3_gru_output_fwd': (c_int, [_GRU_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'stp3_gru_output_bwd': (c_int, [_GRU_P, c_void_p, ctypes.c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'stp3_gru_reset_cat_bwd': (c_int, [_GRU_P, c_void_p, ctypes.c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_layernorm_fwd': (c_int, [_LN_P, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_layernorm_bwd_workspace': (c_int, [_LN_P, ctypes.POINTER(c_size_t)]),
     'stp3_layernorm_bwd': (c_int, [_LN_P] + [c_void_p] * 8 + [c_size_t, c_void_p]),

@@ -335,6 +335,11 @@ def _gru_cell(x, state, conv_update, conv_reset, conv_state_tilde, bias_init):
     """One convolutional GRU step (temporal.py:42-56): the update and reset gates read the same [x, state] operand, so
     their two 3x3 convolutions run as ONE convolution with the output channels concatenated (exact: the operand tile
     is staged once instead of twice)."""
+    from .. import ops_pred
+    if ops_pred.gru_cell_supported(x, state, conv_update, conv_reset, conv_state_tilde):
+        # bf16 on the GPU: the three convolutions and the gate arithmetic as one operator (two element-wise launches forward,
+        # two backward, instead of a dozen and two dozen torch ones: stp3_gru_*); the state stays bf16 along the recurrence
+        return ops_pred.gru_cell(x, state, conv_update, conv_reset, conv_state_tilde, bias_init)
     xs = torch.cat([x, state], dim=1)
     hidden = conv_update.out_channels
     w = torch.cat([conv_update.weight, conv_reset.weight], dim=0)

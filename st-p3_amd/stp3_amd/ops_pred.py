@@ -92,3 +92,133 @@ def layer_norm_channels(x, weight, bias, eps, act=ACT_NONE):
     if torch.is_autocast_enabled() and x.dtype != torch.get_autocast_dtype('cuda'):
         x = x.to(torch.get_autocast_dtype('cuda'))
     return _LN_APPLY(x, weight, bias, float(eps), int(act))
+
+
+# ----------------------------------------------------------------------------------------------
+# Convolutional GRU cell: stp3/layers/temporal.py:42-56 (SpatialGRU.gru_cell), :118-145 (Dual_GRU.gru_cell_1 / _2)
+# ----------------------------------------------------------------------------------------------
+_GATE_WEIGHTS = {}        # (id(update weight), id(reset weight)) -> [stamp, merged bf16 weight, merged float32 bias]
+
+
+def _merged_gate_weights(conv_update, conv_reset):
+    """The update and the reset gate read the same [x, state] operand: their two 3x3 convolutions run as ONE with the output
+    channels concatenated (exact).  The merged bf16 weight is cut from the two parameters' bf16 shadows once per optimizer
+    step (all time steps of a GRU share it), not once per cell."""
+    wu, wr = conv_update.weight, conv_reset.weight
+    key = (id(wu), id(wr))
+    stamp = (ops.weight_stamp(wu), ops.weight_stamp(wr), wu.data_ptr(), wr.data_ptr())
+    ent = _GATE_WEIGHTS.get(key)
+    if ent is None or ent[0] != stamp:
+        wb = torch.cat([ops._bf16_weights(wu)[0], ops._bf16_weights(wr)[0]], dim=0).contiguous(memory_format=torch.channels_last)
+        bias = torch.cat([conv_update.bias.detach().float(), conv_reset.bias.detach().float()])
+        ent = [stamp, wb, bias]
+        _GATE_WEIGHTS[key] = ent
+    return ent[1], ent[2]
+
+
+def gru_cell_supported(x, state, conv_update, conv_reset, conv_state_tilde):
+    """bf16 (or autocast) GPU tensors, 3x3 / stride 1 / padding 1 gate convolutions with a bias, channel counts multiples of 8."""
+    if not (x.is_cuda and x.dim() == 4 and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled())):
+        return False
+    for conv in (conv_update, conv_reset, conv_state_tilde):
+        if not (tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
+                and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.bias is not None
+                and conv.weight.dtype == torch.float32):
+            return False
+    c, cx = state.shape[1], x.shape[1]
+    return (cx % 8 == 0 and c % 8 == 0 and conv_update.in_channels == cx + c and conv_update.out_channels == c
+            and conv_reset.out_channels == c and conv_state_tilde.out_channels == c
+            and ops.conv2d_supported(x, conv_update.weight, 1))
+
+
+def _gru_dims(xs, cx, c, bias_init):
+    n, _, h, w = xs.shape
+    return _lib.GruDims(n * h * w, cx, c, _lib.DTYPE_BF16, float(bias_init))
+
+
+class _GruCell(torch.autograd.Function):
+    """x (N,Cx,H,W), state (N,C,H,W) bf16 -> new state (N,C,H,W) bf16; all convolutions and the gate arithmetic inside, the
+    cell's only saved tensors are [x | state], the gate pre-activations, [x | (1 - r) state] and the proposal (bf16)."""
+
+    @staticmethod
+    def forward(ctx, x, state, wu, bu, wr, br, wt, bt, mods, bias_init):
+        conv_update, conv_reset, conv_tilde = mods
+        ops._need_gpu(x, state)
+        n, cx, h, w = x.shape
+        c = state.shape[1]
+        cl = torch.channels_last
+        xs = torch.empty((n, cx + c, h, w), dtype=torch.bfloat16, device=x.device, memory_format=cl)
+        torch.cat([x, state], dim=1, out=xs)
+        wg_b, bg = _merged_gate_weights(conv_update, conv_reset)
+        gates = ops._conv2d_launch(xs, wg_b, bg, 1, (1, 1), (1, 1), torch.bfloat16)
+        dims = _gru_dims(xs, cx, c, bias_init)
+        lib = _lib.lib()
+        xs2 = torch.empty_like(xs, memory_format=cl)
+        check(lib.stp3_gru_reset_cat_fwd(ctypes.byref(dims), ops._ptr(xs), ops._ptr(gates), ops._ptr(xs2), ops._stream()),
+              'stp3_gru_reset_cat_fwd')
+        wt_b = ops._bf16_weights(wt)[0]
+        tilde = ops._conv2d_launch(xs2, wt_b, ops._f32(bt), 1, (1, 1), (1, 1), torch.bfloat16)
+        out = torch.empty((n, c, h, w), dtype=torch.bfloat16, device=x.device, memory_format=cl)
+        check(lib.stp3_gru_output_fwd(ctypes.byref(dims), ops._ptr(gates), ops._ptr(xs), ops._ptr(tilde), ops._ptr(out),
+                                      ops._stream()), 'stp3_gru_output_fwd')
+        ctx.save_for_backward(xs, gates, xs2, tilde, wg_b, wt_b)
+        ctx.params = (wu, wr, wt)
+        ctx.stamps = tuple(ops.weight_stamp(p) for p in (wu, wr, wt))
+        ctx.conf = (cx, c, float(bias_init), bu.dtype, br.dtype, bt.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xs, gates, xs2, tilde, wg_b, wt_b = ctx.saved_tensors
+        wu, wr, wt = ctx.params
+        for p, st in zip(ctx.params, ctx.stamps):
+            ops.check_weight_stamp(p, st, 'GRU cell backward')
+        cx, c, bias_init, bu_dt, br_dt, bt_dt = ctx.conf
+        cl = torch.channels_last
+        n, _, h, w = xs.shape
+        if dout.dtype != torch.bfloat16:
+            dout = dout.to(torch.bfloat16)
+        dout, ld = ops._rows_view(dout)
+        dims = _gru_dims(xs, cx, c, bias_init)
+        lib = _lib.lib()
+        dtilde = torch.empty((n, c, h, w), dtype=torch.bfloat16, device=xs.device, memory_format=cl)
+        dgates = torch.empty((n, 2 * c, h, w), dtype=torch.bfloat16, device=xs.device, memory_format=cl)
+        check(lib.stp3_gru_output_bwd(ctypes.byref(dims), ops._ptr(dout), ld, ops._ptr(gates), ops._ptr(xs), ops._ptr(tilde),
+                                      ops._ptr(dtilde), ops._ptr(dgates), ops._stream()), 'stp3_gru_output_bwd')
+        pad, dil = (1, 1), (1, 1)
+        need = ctx.needs_input_grad
+        dwt = ops._conv2d_wgrad(dtilde, xs2, tuple(wt_b.shape), 1, pad, dil, leaf=wt) if need[6] else None
+        dbt = ops.channel_sums(dtilde).to(bt_dt) if need[7] else None
+        dxs2 = ops.conv2d_data_grad(dtilde, wt_b, wt, xs2.shape, 1, pad, dil)
+        acc = torch.empty_like(xs, memory_format=cl)
+        check(lib.stp3_gru_reset_cat_bwd(ctypes.byref(dims), ops._ptr(dout), ld, ops._ptr(gates), ops._ptr(xs),
+                                         ops._ptr(dxs2), ops._ptr(acc), ops._ptr(dgates), ops._stream()),
+              'stp3_gru_reset_cat_bwd')
+        dwu = dwr = dbu = dbr = None
+        if need[2] or need[4]:
+            dwg = ops._conv2d_wgrad(dgates, xs, tuple(wg_b.shape), 1, pad, dil)
+            dwu, dwr = dwg[:c], dwg[c:]
+        if need[3] or need[5]:
+            dbg = ops.channel_sums(dgates)
+            dbu, dbr = dbg[:c].to(bu_dt), dbg[c:].to(br_dt)
+        dx = dstate = None
+        if need[0] or need[1]:
+            dxs = ops.conv2d_data_grad(dgates, wg_b, None, xs.shape, 1, pad, dil)
+            total = torch.empty_like(xs, memory_format=cl)
+            arr = (ctypes.c_void_p * 2)(acc.data_ptr(), dxs.data_ptr())
+            check(lib.stp3_sum_n(2, total.numel(), _lib.DTYPE_BF16, arr, total.data_ptr(), ops._stream_handle()), 'stp3_sum_n')
+            dx, dstate = total[:, :cx], total[:, cx:]
+        return dx, dstate, dwu, dbu, dwr, dbr, dwt, dbt, None, None
+
+
+_GRU_APPLY = ops._fast_apply(_GruCell)
+
+
+def gru_cell(x, state, conv_update, conv_reset, conv_state_tilde, bias_init=0.0):
+    """One convolutional GRU step on the kernels (``gru_cell_supported``): bf16 tensors in, bf16 state out."""
+    bf = torch.bfloat16
+    x = x if x.dtype == bf else x.to(bf)
+    state = state if state.dtype == bf else state.to(bf)
+    return _GRU_APPLY(x, state, conv_update.weight, conv_update.bias, conv_reset.weight, conv_reset.bias,
+                      conv_state_tilde.weight, conv_state_tilde.bias, (conv_update, conv_reset, conv_state_tilde),
+                      float(bias_init))

@@ -1401,8 +1401,47 @@ def layernorm(ops):
     return out
 
 
+def gru_cell(ops):
+    """ops_pred.gru_cell (the three convolutions on stp3_conv.hip + stp3_gru_* around them) against float32 torch autograd of
+    the reference's cell (stp3/layers/temporal.py:42-56) on the same bf16-representable tensors and weights: new state, input /
+    state gradients, every weight and bias gradient; Cx = 32 and 64, with a gate bias offset."""
+    import torch.nn as nn
+    from stp3_amd import ops_pred
+    out = {}
+    cl = torch.channels_last
+    for name, (cx, c, b0) in {'cx32_c64': (32, 64, 0.0), 'cx64_c64_b0': (64, 64, 0.5)}.items():
+        g = torch.Generator().manual_seed(7)
+        n, h, w = 2, 6, 9
+        convs = [nn.Conv2d(cx + c, c, 3, padding=1) for _ in range(3)]
+        with torch.no_grad():
+            for m in convs:
+                m.weight.copy_((torch.randn(m.weight.shape, generator=g) * 0.05).to(torch.bfloat16).float())
+                m.bias.copy_(torch.randn(c, generator=g) * 0.2)
+        x0 = torch.randn(n, cx, h, w, generator=g).to(torch.bfloat16).contiguous(memory_format=cl)
+        s0 = torch.randn(n, c, h, w, generator=g).to(torch.bfloat16).contiguous(memory_format=cl)
+        x, st = x0.clone().requires_grad_(), s0.clone().requires_grad_()
+        assert ops_pred.gru_cell_supported(x, st, *convs)
+        y = ops_pred.gru_cell(x, st, *convs, b0)
+        gy = torch.randn(y.shape, generator=g).to(torch.bfloat16)
+        y.backward(gy)
+        got = [p.grad.clone() for m in convs for p in (m.weight, m.bias)]
+        for m in convs:
+            m.weight.grad = m.bias.grad = None
+        xr, sr = x0.float().requires_grad_(), s0.float().requires_grad_()
+        xs = torch.cat([xr, sr], 1)
+        u = torch.sigmoid(convs[0](xs) + b0)
+        r = torch.sigmoid(convs[1](xs) + b0)
+        tl = convs[2](torch.cat([xr, (1.0 - r) * sr], 1))
+        yr = (1.0 - u) * sr + u * tl
+        yr.backward(gy.float())
+        want = [p.grad for m in convs for p in (m.weight, m.bias)]
+        out[name] = {'y': rel(y.detach().float(), yr.detach()), 'dx': rel(x.grad.float(), xr.grad), 'dstate': rel(st.grad.float(), sr.grad),
+                     'dparam': max(rel(a, b) for a, b in zip(got, want)), 'dtype': str(y.dtype)}
+    return out
+
+
 CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_rolled, lift_c64_frames, lift_coarse_grid, lift_tall, lift_c64_rows56, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
-                                 conv, conv_f32, fan_out, aspp_join, pointwise_bn, pointwise_stream, decoder_heads, dwconv, layernorm, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
+                                 conv, conv_f32, fan_out, aspp_join, pointwise_bn, pointwise_stream, decoder_heads, dwconv, layernorm, gru_cell, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
 
 if __name__ == '__main__':
     ops_mod = setup(sys.argv[1])

@@ -27,10 +27,10 @@ sys.path.insert(0, HIPCPU)
 import build as hipcpu_build  # noqa: E402
 
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
-ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('layernorm', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
+ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('layernorm', {}), ('gru_cell', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
            ('conv', {}), ('conv_f32', {}), ('fan_out', {}), ('aspp_join', {}), ('pointwise_bn', {}), ('pointwise_stream', {}), ('decoder_heads', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('labels', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}), ('lift_c64_rolled', {}),
            ('lift_c64_frames', {}), ('lift_c64_rows56', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
-ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'layernorm', 'bn_act', 'conv', 'conv_bn', 'pointwise_bn', 'pointwise_stream', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'labels', 'lift_c16']
+ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'layernorm', 'gru_cell', 'bn_act', 'conv', 'conv_bn', 'pointwise_bn', 'pointwise_stream', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'labels', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)]
 MODEL = [('lift_full', {}), ('model_step_two_ranks', {}), ('model_step_f32_full_losses', {}), ('model_step_f32', {}),
          ('model_step_bf16_bn_eval', {})]        # whole training steps: minutes, STP3_SLOW_TESTS=1
@@ -218,6 +218,16 @@ def test_layernorm_over_channels(results):
         tol = 4e-3 if 'bf16' in name else 1e-6
         assert r['y'] <= tol and r['dx'] <= tol and r['dw'] <= 1e-5 and r['db'] <= 1e-5 and r['cl'], (name, r)
         assert r['dtype'] == ('torch.bfloat16' if 'bf16' in name else 'torch.float32'), (name, r)
+
+
+def test_gru_cell(results):
+    """ops_pred.gru_cell -- the reference's convolutional GRU step (stp3/layers/temporal.py:42-56, :118-145) as one operator:
+    merged gate convolution, stp3_gru_reset_cat / _output kernels forward and backward -- against float32 autograd of the
+    cell as the reference writes it, on bf16-representable data: everything within bf16 rounding of the stored tensors."""
+    for name, r in _get(results, 'gru_cell').items():
+        if name == 'seconds':
+            continue
+        assert max(r['y'], r['dx'], r['dstate'], r['dparam']) <= 1e-2 and r['dtype'] == 'torch.bfloat16', (name, r)
 
 
 def test_label_kernels(results):
