@@ -331,6 +331,87 @@ def _conv(m, x):
     return conv_module(m, x)
 
 
+# Sequences of the prediction stage as FRAME-MAJOR channels-last memory.  The reference keeps (B,S,C,H,W) tensors and takes
+# frames with x[:, t] / builds them with torch.stack(..., dim=1) (temporal.py:34-40, :98-117; future_prediction.py:33-45).  In
+# that memory order a frame is neither a dense channels-last tensor (the kernels' layout: a copy per frame and use) nor is its
+# gradient (SelectBackward: a zero fill, a copy and an addition per frame).  Here a sequence is stored [S][B][H][W][C] and
+# presented as the (B,S,C,H,W) permutation of it: every frame x[:, t] is a dense channels-last (B,C,H,W) view, the whole
+# sequence is ONE channels-last batch of S*B frames (frames_as_batch: a view), and the two autograd functions below keep the
+# gradients in the same order.  Values and the (B,S,...) indexing are the reference's; only strides differ.
+class _StackFrames(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *frames):
+        buf = torch.stack([f.permute(0, 2, 3, 1) for f in frames], dim=0)          # [S][B][H][W][C], one launch
+        return buf.permute(1, 0, 4, 2, 3)
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g[:, t] for t in range(g.shape[1]))
+
+
+class _UnbindFrames(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        ctx.meta = (x.shape, x.dtype, x.device)
+        return tuple(x[:, t] for t in range(x.shape[1]))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        shape, dtype, device = ctx.meta
+        b, s, c, h, w = shape
+        if all(g is None for g in grads):
+            return None
+        if all(g is not None for g in grads):
+            buf = torch.stack([g.permute(0, 2, 3, 1) for g in grads], dim=0)       # one launch
+        else:
+            buf = torch.empty((s, b, h, w, c), dtype=dtype, device=device)
+            for t, g in enumerate(grads):
+                if g is None:
+                    buf[t].zero_()
+                else:
+                    buf[t].copy_(g.permute(0, 2, 3, 1))
+        return buf.permute(1, 0, 4, 2, 3)
+
+
+def stack_frames(frames):
+    """list of S (B,C,H,W) tensors -> (B,S,C,H,W) in frame-major channels-last memory (see above)."""
+    return _StackFrames.apply(*frames)
+
+
+def unbind_frames(x):
+    """(B,S,C,H,W) -> its S frames; the gradient comes back frame-major."""
+    return _UnbindFrames.apply(x)
+
+
+def frames_as_batch(x):
+    """(B,S,C,H,W) -> (a (S*B,C,H,W) channels-last batch, restore): per-frame modules (convolutions, BatchNorm over all
+    frames, LayerNorm) do not care about the order of the frames in the batch, so a frame-major sequence goes in as the VIEW
+    it already is -- frame-major batch order -- and ``restore`` turns the result back into a (B,S,C',H',W') sequence.
+    Anything else is flattened like the reference does (``x.view(b * s, c, h, w)``)."""
+    b, s, c, h, w = x.shape
+    fm = x.permute(1, 0, 3, 4, 2)
+    if s > 1 and fm.is_contiguous():
+        def restore(y):
+            y = y.permute(0, 2, 3, 1)
+            if not y.is_contiguous():
+                y = y.contiguous()
+            return y.view(s, b, *y.shape[1:]).permute(1, 0, 4, 2, 3)
+        return fm.reshape(s * b, h, w, c).permute(0, 3, 1, 2), restore
+    return x.reshape(b * s, c, h, w), lambda y: y.view(b, s, *y.shape[1:])
+
+
+def batch_major(x):
+    """A frame-major sequence as (B,S,C,H,W) with [B][S][H][W][C] memory: what ``x.view(b * s, c, h, w)`` of the consumers
+    behind the prediction stage (the decoder) flattens without a copy into a channels-last batch.  One transposing copy."""
+    b, s, c, h, w = x.shape
+    if s == 1 or not x.permute(1, 0, 3, 4, 2).is_contiguous():
+        return x
+    out = torch.empty((b, s, h, w, c), dtype=x.dtype, device=x.device)
+    out.copy_(x.permute(0, 1, 3, 4, 2))
+    return out.permute(0, 1, 4, 2, 3)
+
+
 def _gru_cell(x, state, conv_update, conv_reset, conv_state_tilde, bias_init):
     """One convolutional GRU step (temporal.py:42-56): the update and reset gates read the same [x, state] operand, so
     their two 3x3 convolutions run as ONE convolution with the output channels concatenated (exact: the operand tile
@@ -368,10 +449,10 @@ class SpatialGRU(nn.Module):
         b, steps, c, h, w = x.shape
         rnn_state = x.new_zeros(b, self.hidden_size, h, w) if state is None else state
         out = []
-        for t in range(steps):
-            rnn_state = self.gru_cell(x[:, t], rnn_state)
+        for frame in unbind_frames(x):
+            rnn_state = self.gru_cell(frame, rnn_state)
             out.append(_conv(self.conv_decoder, rnn_state))
-        return torch.stack(out, dim=1)
+        return stack_frames(out)
 
     def gru_cell(self, x, state):
         return _gru_cell(x, state.to(x.dtype), self.conv_update, self.conv_reset, self.conv_state_tilde, self.gru_bias_init)
@@ -403,10 +484,11 @@ class Dual_GRU(nn.Module):
         b, s, c, hh, ww = x.shape
         assert c == self.input_size, f'feature sizes must match, got input {c} for layer with size {self.input_size}'
         n_present = state.shape[1]
-        h = state[:, 0]
+        past = unbind_frames(state)
+        h = past[0]
         for t in range(n_present - 1):                       # warm-up on the past frames
-            h = self.gru_cell_2(state[:, t], h)
-        rnn_state1 = rnn_state2 = state[:, -1]
+            h = self.gru_cell_2(past[t], h)
+        rnn_state1 = rnn_state2 = past[-1]
         x = x[:, 0]
         pred = []
         for _ in range(self.n_future):
@@ -420,7 +502,7 @@ class Dual_GRU(nn.Module):
             pred.append(cur)
             if self.mixture:
                 rnn_state1 = rnn_state2 = cur
-        return torch.stack(pred, dim=1)
+        return stack_frames(pred)
 
     def gru_cell_1(self, x, state):
         return _gru_cell(x.to(state.dtype), state, self.conv_update_1, self.conv_reset_1, self.conv_state_tilde_1,

@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from ..layers.convolutions import Block, DeepLabHead
-from ..layers.temporal import Dual_GRU, SpatialGRU
+from ..layers.temporal import Dual_GRU, SpatialGRU, batch_major, frames_as_batch, stack_frames, unbind_frames
 
 
 class FuturePrediction(nn.Module):
@@ -25,14 +25,16 @@ class FuturePrediction(nn.Module):
         self.res_blocks = nn.ModuleList(res)
 
     def forward(self, x, state):
-        """x (B,1,latent,H,W): the latent sample; state (B,n_present,C,H,W) -> (B,n_present+n_future,C,H,W)."""
+        """x (B,1,latent,H,W): the latent sample; state (B,n_present,C,H,W) -> (B,n_present+n_future,C,H,W).
+        Sequences are kept frame-major between the recurrent and the per-frame stages (layers/temporal.py ``stack_frames``)."""
         x = self.dual_grus(x, state)
-        b, n_future, c, h, w = x.shape
-        x = self.res_blocks1(x.reshape(b * n_future, c, h, w)).view(b, n_future, c, h, w)
-        x = torch.cat([state.to(x.dtype), x], dim=1)
-        hidden = x[:, 0]
+        x4, restore = frames_as_batch(x)
+        x = restore(self.res_blocks1(x4))
+        frames = list(unbind_frames(state.to(x.dtype))) + list(unbind_frames(x))
+        x = stack_frames(frames)
+        hidden = frames[0]
         for gru, res in zip(self.spatial_grus, self.res_blocks):
             x = gru(x, hidden)
-            b, s, c, h, w = x.shape
-            x = res(x.reshape(b * s, c, h, w)).view(b, s, c, h, w)
-        return x
+            x4, restore = frames_as_batch(x)
+            x = restore(res(x4))
+        return batch_major(x)
