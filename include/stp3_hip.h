@@ -275,7 +275,7 @@ int stp3_gru_reset_cat_bwd(const stp3_gru_dims* dims, const void* dout, int32_t 
  *   x, dx [rows][ldx >= C], y / dy [rows][ldy >= C]   dtype STP3_DTYPE_F32 / _BF16, float32 arithmetic, one rounding
  *   y = act((x - mean_c) / sqrt(var_c + eps) * gamma + beta), biased variance; gamma / beta [C] float32 (NULL: 1 / 0)
  *   act = STP3_ACT_NONE or STP3_ACT_GELU (defined with the other activations below; exact: 0.5 v (1 + erf(v / sqrt 2)))
- *   C / (16 bytes of elements) must be a power of two <= 64, ld multiples of it, 16-byte aligned pointers (STP3_EUNSUP
+ *   C / (16 bytes of elements) must be a power of two in 4 .. 64, ld multiples of the vector, 16-byte aligned pointers (STP3_EUNSUP
  *   otherwise: the caller keeps torch's operator)
  * bwd recomputes the row statistics from x; dgamma / dbeta [C] float32 (either may be NULL) through a two-stage
  * deterministic reduction in `workspace` (stp3_layernorm_bwd_workspace bytes).

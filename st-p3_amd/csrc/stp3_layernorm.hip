@@ -9,7 +9,7 @@
 //
 // A row (pixel) is C contiguous channels; L = C / VEC lanes of a wavefront hold it (16 bytes each) and reduce with
 // xor-shuffles, so a 64-channel bf16 row is 8 lanes and a wavefront normalises 8 pixels per step.  C / VEC must be a power
-// of two <= 64 (C = 32 .. 512 in bf16): the prediction stage has 32 and 64.
+// of two in 4 .. 64 (C = 32 .. 512 in bf16, 16 .. 256 in float32): the prediction stage has 32 and 64.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -228,7 +228,7 @@ inline int check(const stp3_layernorm_dims* p, LnDims* d) {
     const int vec = p->dtype == STP3_DTYPE_BF16 ? 8 : 4;
     if (p->C % vec || p->ldx % vec || p->ldy % vec) return 0;
     const int L = p->C / vec;
-    if (L < 1 || L > 64 || (L & (L - 1))) return 0;
+    if (L < 4 || L > 64 || (L & (L - 1))) return 0;
     d->rows = p->rows; d->C = p->C; d->ldx = p->ldx; d->ldy = p->ldy; d->act = p->act; d->eps = p->eps;
     return L;
 }
@@ -236,8 +236,6 @@ inline int check(const stp3_layernorm_dims* p, LnDims* d) {
 // run CALL with `LL` (lanes per row) and `GELU` bound as compile-time constants
 #define LN_LANES_G(L, G, ...)                                                      \
     switch (L) {                                                                   \
-        case 1:  { constexpr int LL = 1;  constexpr bool GELU = G; __VA_ARGS__; break; }  \
-        case 2:  { constexpr int LL = 2;  constexpr bool GELU = G; __VA_ARGS__; break; }  \
         case 4:  { constexpr int LL = 4;  constexpr bool GELU = G; __VA_ARGS__; break; }  \
         case 8:  { constexpr int LL = 8;  constexpr bool GELU = G; __VA_ARGS__; break; }  \
         case 16: { constexpr int LL = 16; constexpr bool GELU = G; __VA_ARGS__; break; }  \

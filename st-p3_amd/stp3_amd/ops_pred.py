@@ -2,6 +2,7 @@
 pixel (+ GELU) -- ``stp3/layers/convolutions.py:283-307`` and the ``nn.GELU()`` behind it in ``Bottleblock`` (:347-380).
 GPU only; the layers keep torch's operators for shapes the kernels do not take (``layer_norm_supported``)."""
 import ctypes
+import weakref
 
 import torch
 
@@ -23,11 +24,11 @@ def _workspace(nbytes, device):
 
 def layer_norm_supported(x, channels):
     """What stp3_layernorm_* take: a 4-D (N,C,H,W) GPU tensor in bf16 / float32 whose channel count is 16 bytes of elements
-    times a power of two <= 64 (the prediction stage: 32 and 64 channels)."""
+    times a power of two in 4 .. 64 (the prediction stage: 32 and 64 channels)."""
     if not (x.is_cuda and x.dim() == 4 and x.shape[1] == channels and x.dtype in (torch.bfloat16, torch.float32)):
         return False
     lanes, rem = divmod(channels, 8 if x.dtype == torch.bfloat16 else 4)
-    return rem == 0 and 1 <= lanes <= 64 and lanes & (lanes - 1) == 0
+    return rem == 0 and 4 <= lanes <= 64 and lanes & (lanes - 1) == 0
 
 
 def _dims(x, ldx, ldy, act, eps):
@@ -106,12 +107,16 @@ def _merged_gate_weights(conv_update, conv_reset):
     step (all time steps of a GRU share it), not once per cell."""
     wu, wr = conv_update.weight, conv_reset.weight
     key = (id(wu), id(wr))
-    stamp = (ops.weight_stamp(wu), ops.weight_stamp(wr), wu.data_ptr(), wr.data_ptr())
+    stamp = (ops.weight_stamp(wu), ops.weight_stamp(wr), wu.data_ptr(), wr.data_ptr(),
+             conv_update.bias._version, conv_reset.bias._version)
     ent = _GATE_WEIGHTS.get(key)
-    if ent is None or ent[0] != stamp:
+    # (id() values are recycled: an entry only counts while it still points at THESE live parameters)
+    if ent is None or ent[0] != stamp or ent[3]() is not wu or ent[4]() is not wr:
         wb = torch.cat([ops._bf16_weights(wu)[0], ops._bf16_weights(wr)[0]], dim=0).contiguous(memory_format=torch.channels_last)
         bias = torch.cat([conv_update.bias.detach().float(), conv_reset.bias.detach().float()])
-        ent = [stamp, wb, bias]
+        if ent is None or ent[3]() is not wu:
+            weakref.finalize(wu, _GATE_WEIGHTS.pop, key, None)
+        ent = [stamp, wb, bias, weakref.ref(wu), weakref.ref(wr)]
         _GATE_WEIGHTS[key] = ent
     return ent[1], ent[2]
 
