@@ -26,7 +26,7 @@ import json; b=json.load(open('$out/bench_planning.json')); print('planning ms/s
       [ -n "$KT" ] && python scripts/agg_trace.py $KT $(python -c "print($MS*($STEPS-1))") 60 > $out/steady_kernels.txt 2>&1
       rm -rf /tmp/prof_pred; head -45 $out/steady_kernels.txt | cut -c1-170 ;;
     sources)
-      timeout 360 python scripts/small_kernel_sources.py --workload prediction --by-time --top 70 > $out/sources_prediction.txt 2> $out/sources.err
-      cut -c1-230 $out/sources_prediction.txt | head -50 ;;
+      timeout 360 python scripts/small_kernel_sources.py --workload ${WL:-prediction} --by-time --top 70 > $out/sources_${WL:-prediction}.txt 2> $out/sources.err
+      cut -c1-230 $out/sources_${WL:-prediction}.txt | head -50 ;;
   esac
 done

@@ -83,3 +83,35 @@ def test_prediction_config_state_dict_matches_reference():
     assert not missing and not extra, (missing[:5], extra[:5])
     assert not [k for k in want if want[k] != got[k]]
     assert len(want) > 1000
+
+
+def test_frame_major_sequences_are_the_reference_sequences():
+    """layers/temporal.py keeps (B,S,C,H,W) sequences as [S][B][H][W][C] memory between the recurrent and the per-frame stages
+    of the prediction stage.  Values, indexing and gradients must be those of the reference's ``x[:, t]`` / ``torch.stack(...,
+    dim=1)`` / ``x.view(b * s, c, h, w)`` (stp3/layers/temporal.py:34-40, stp3/models/future_prediction.py:33-45); only the
+    strides differ: every frame is a dense channels-last tensor and the whole sequence a channels-last batch (a view)."""
+    from stp3_amd.layers.temporal import batch_major, frames_as_batch, stack_frames, unbind_frames
+    g = torch.Generator().manual_seed(5)
+    b, s, c, h, w = 2, 3, 8, 4, 5
+    frames = [torch.randn(b, c, h, w, generator=g).contiguous(memory_format=torch.channels_last).requires_grad_(True) for _ in range(s)]
+    ref_frames = [f.detach().clone().requires_grad_(True) for f in frames]
+    x, xr = stack_frames(frames), torch.stack(ref_frames, dim=1)
+    assert x.shape == xr.shape and torch.equal(x, xr)
+    assert all(f.is_contiguous(memory_format=torch.channels_last) and torch.equal(f, r)
+               for f, r in zip(unbind_frames(x), xr.unbind(1)))
+    x4, restore = frames_as_batch(x)
+    assert x4.is_contiguous(memory_format=torch.channels_last) and x4.data_ptr() == x.data_ptr()      # a view, no copy
+    # a per-frame function of the batch (frame order inside the batch is free), then back to (B,S,...)
+    wgt = torch.randn(6, c, 1, 1, generator=g)
+    y = restore(torch.nn.functional.conv2d(x4, wgt))
+    yr = torch.nn.functional.conv2d(xr.reshape(b * s, c, h, w), wgt).reshape(b, s, 6, h, w)
+    assert torch.allclose(y, yr, atol=1e-6)
+    z = batch_major(y)
+    assert torch.equal(z, y) and z.reshape(b * s, 6, h, w).is_contiguous(memory_format=torch.channels_last)
+    # gradients: through the frame-major functions and through the reference's indexing
+    probe = torch.randn(y.shape, generator=g)
+    first = unbind_frames(x)[0]
+    ((z * probe).sum() + (first * 0.5).sum()).backward()
+    ((yr * probe).sum() + (xr[:, 0] * 0.5).sum()).backward()
+    for f, r in zip(frames, ref_frames):
+        assert torch.allclose(f.grad, r.grad, atol=1e-6)
