@@ -116,9 +116,20 @@ def _merged_gate_weights(conv_update, conv_reset):
         bias = torch.cat([conv_update.bias.detach().float(), conv_reset.bias.detach().float()])
         if ent is None or ent[3]() is not wu:
             weakref.finalize(wu, _GATE_WEIGHTS.pop, key, None)
-        ent = [stamp, wb, bias, weakref.ref(wu), weakref.ref(wr)]
+        ent = [stamp, wb, bias, weakref.ref(wu), weakref.ref(wr), None]
         _GATE_WEIGHTS[key] = ent
     return ent[1], ent[2]
+
+
+def _merged_gate_weights_flipped(wu, wr, wb):
+    """The merged gate weight with its taps flipped and its channel dimensions swapped (what the data gradient convolves dy
+    with), once per optimizer step like the merged weight itself; cut on the spot when the cache has moved on."""
+    ent = _GATE_WEIGHTS.get((id(wu), id(wr)))
+    if ent is None or ent[1] is not wb:
+        return wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+    if ent[5] is None:
+        ent[5] = wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+    return ent[5]
 
 
 def gru_cell_supported(x, state, conv_update, conv_reset, conv_state_tilde):
@@ -208,7 +219,8 @@ class _GruCell(torch.autograd.Function):
             dbu, dbr = dbg[:c].to(bu_dt), dbg[c:].to(br_dt)
         dx = dstate = None
         if need[0] or need[1]:
-            dxs = ops.conv2d_data_grad(dgates, wg_b, None, xs.shape, 1, pad, dil)
+            # stride 1, padding 1: the data gradient is the 3x3 convolution of dgates with the flipped, channel-swapped weight
+            dxs = ops._conv2d_launch(dgates, _merged_gate_weights_flipped(wu, wr, wg_b), None, 1, pad, dil, torch.bfloat16)
             total = torch.empty_like(xs, memory_format=cl)
             arr = (ctypes.c_void_p * 2)(acc.data_ptr(), dxs.data_ptr())
             check(lib.stp3_sum_n(2, total.numel(), _lib.DTYPE_BF16, arr, total.data_ptr(), ops._stream_handle()), 'stp3_sum_n')
