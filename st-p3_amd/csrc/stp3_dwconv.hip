@@ -57,6 +57,20 @@ template <> struct Vec<uint16_t> {
     }
 };
 
+// Addressing.  The kernels below are instruction-bound on the 5x5 / 7x7 layers (25 / 49 multiply-adds per output against 2 + 2
+// bytes; profiles/r05x_step_pmc.json: 8-11 VALU lane-instructions per byte), and with 64-bit element offsets a third of those
+// instructions was address arithmetic: a quarter-rate v_mad_u64_u32 per 16-byte load, 64-bit divisions in every thread's
+// prologue.  `Off` is the type of a BYTE offset from the (uniform) tensor base: uint32_t whenever every tensor of the call is
+// smaller than 4 GiB -- the loads then take the scalar-base + 32-bit-offset form --, uint64_t otherwise.
+template <typename T, typename Off>
+__device__ __forceinline__ const T* at(const T* base, Off byte_off) {
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <typename T, typename Off>
+__device__ __forceinline__ T* at(T* base, Off byte_off) {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
+}
+
 // XCD-aware workgroup order (see stp3_conv.hip): the dispatcher places workgroup b on XCD b % 8, each XCD has its own L2, and
 // neighbouring workgroups read overlapping input rows (every input row serves K output rows).  v = xcd_order(b, n): XCD x
 // runs the x-th contiguous chunk of the launch order, so the K - 1 halo rows are L2 hits instead of K separate fills.
@@ -71,22 +85,22 @@ __device__ __forceinline__ int xcd_order(int bid, int nwg) {
 // FLIP: the taps are read in reverse order -- the data gradient of a stride-1 depthwise convolution IS a depthwise
 // convolution of dy with the flipped kernel (padding K - 1 - p), so it shares this kernel and its register reuse
 // (TW outputs per thread share one input span per kernel row; the tap-major weights are read once per row).
-template <typename T, int K, int S, int TW, bool FLIP>
+template <typename T, int K, int S, int TW, bool FLIP, typename Off>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwDims d, const T* __restrict__ x,
                                                          const float* __restrict__ w, const float* __restrict__ bias,
                                                          T* __restrict__ y) {
     constexpr int VN = Vec<T>::N;
     const int CV = d.C / VN;
     const int wgroups = (d.Wo + TW - 1) / TW;
-    const int64_t total = (int64_t)d.N * d.Ho * wgroups * CV;
-    const int64_t tid = (int64_t)xcd_order(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    const Off total = (Off)d.N * d.Ho * wgroups * CV;
+    const Off tid = (Off)xcd_order(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (tid >= total) return;
-    const int cv = (int)(tid % CV);
-    int64_t r = tid / CV;
-    const int wg = (int)(r % wgroups);
-    r /= wgroups;
-    const int ho = (int)(r % d.Ho);
-    const int n = (int)(r / d.Ho);
+    const int cv = (int)(tid % (Off)CV);
+    Off r = tid / (Off)CV;
+    const int wg = (int)(r % (Off)wgroups);
+    r /= (Off)wgroups;
+    const int ho = (int)(r % (Off)d.Ho);
+    const int n = (int)(r / (Off)d.Ho);
     const int c0 = cv * VN;
     const int wo0 = wg * TW;
     float acc[TW][VN];
@@ -96,23 +110,27 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwDims d, const T* __re
         for (int j = 0; j < VN; ++j) acc[i][j] = bias ? bias[c0 + j] : 0.f;     // (the ConvNeXt blocks' 7x7 layers have one)
     constexpr int SPAN = (TW - 1) * S + K;
     const int wi0 = wo0 * S - d.pad_l;
+    const Off pix = (Off)d.C * sizeof(T);                     // bytes from one pixel to the next
+    const Off wtap = (Off)d.C * sizeof(float);                // bytes from one tap's weight row to the next
+    const Off wc0 = (Off)c0 * sizeof(float);
 #pragma unroll
     for (int kh = 0; kh < K; ++kh) {
         const int hi = ho * S + kh - d.pad_t;
         if (hi < 0 || hi >= d.H) continue;
         float wk[K][VN];
 #pragma unroll
-        for (int kw = 0; kw < K; ++kw)
+        for (int kw = 0; kw < K; ++kw) {
+            const float* wp = at(w, (Off)(FLIP ? (K - 1 - kh) * K + (K - 1 - kw) : kh * K + kw) * wtap + wc0);
 #pragma unroll
-            for (int j = 0; j < VN; ++j)
-                wk[kw][j] = w[(FLIP ? (K - 1 - kh) * K + (K - 1 - kw) : kh * K + kw) * d.C + c0 + j];
-        const T* xrow = x + ((int64_t)(n * d.H + hi) * d.W) * d.C + c0;
+            for (int j = 0; j < VN; ++j) wk[kw][j] = wp[j];
+        }
+        const Off xrow = ((Off)(n * d.H + hi) * d.W) * pix + (Off)c0 * sizeof(T);
         float xin[SPAN][VN];
 #pragma unroll
         for (int i = 0; i < SPAN; ++i) {
             const int wi = wi0 + i;
             Vec<T> v;
-            if (wi >= 0 && wi < d.W) v.load(xrow + (int64_t)wi * d.C); else v.zero();
+            if (wi >= 0 && wi < d.W) v.load(at(x, xrow + (Off)wi * pix)); else v.zero();
             v.to_float(xin[i]);
         }
 #pragma unroll
@@ -122,13 +140,13 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwDims d, const T* __re
 #pragma unroll
                 for (int j = 0; j < VN; ++j) acc[o][j] = fmaf(xin[o * S + kw][j], wk[kw][j], acc[o][j]);
     }
-    T* yrow = y + ((int64_t)(n * d.Ho + ho) * d.Wo) * d.C + c0;
+    const Off yrow = ((Off)(n * d.Ho + ho) * d.Wo) * pix + (Off)c0 * sizeof(T);
 #pragma unroll
     for (int o = 0; o < TW; ++o) {
         if (wo0 + o < d.Wo) {
             Vec<T> v;
             v.from_float(acc[o]);
-            v.store(yrow + (int64_t)(wo0 + o) * d.C);
+            v.store(at(y, yrow + (Off)(wo0 + o) * pix));
         }
     }
 }
@@ -230,7 +248,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_s2_kernel(DwDims d, int q
 // into partial[bx][kh*K + kw][C] (threads = channel vectors x pixel lanes, coalesced along C; the
 // pixel lanes are summed through LDS in a fixed order).  Stage 2 sums the partials over bx.
 // No atomics: deterministic.
-template <typename T, int K, int S>
+template <typename T, int K, int S, typename Off>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwDims d, int nbx, const T* __restrict__ x,
                                                                 const T* __restrict__ dy,
                                                                 float* __restrict__ partial) {
@@ -268,21 +286,22 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(DwDims d, int nb
             const int hi = ho * S + kh - d.pad_t;
             if (hi < 0 || hi >= d.H) continue;
             const int wo0 = wg * TW;
-            const T* grow = dy + ((size_t)(n * d.Ho + ho) * d.Wo + wo0) * d.C + c0;
-            const T* xrow = x + ((size_t)(n * d.H + hi) * d.W) * d.C + c0;
+            const Off pix = (Off)d.C * sizeof(T);
+            const Off grow = ((Off)(n * d.Ho + ho) * d.Wo + wo0) * pix + (Off)c0 * sizeof(T);
+            const Off xrow = ((Off)(n * d.H + hi) * d.W) * pix + (Off)c0 * sizeof(T);
             const int wi0 = wo0 * S - d.pad_l;
             float g[TW][VN], xin[SPAN][VN];
 #pragma unroll
             for (int o = 0; o < TW; ++o) {
                 Vec<T> v;
-                if (wo0 + o < d.Wo) v.load(grow + (size_t)o * d.C); else v.zero();
+                if (wo0 + o < d.Wo) v.load(at(dy, grow + (Off)o * pix)); else v.zero();
                 v.to_float(g[o]);
             }
 #pragma unroll
             for (int i = 0; i < SPAN; ++i) {
                 const int wi = wi0 + i;
                 Vec<T> v;
-                if (wi >= 0 && wi < d.W) v.load(xrow + (size_t)wi * d.C); else v.zero();
+                if (wi >= 0 && wi < d.W) v.load(at(x, xrow + (Off)wi * pix)); else v.zero();
                 v.to_float(xin[i]);
             }
 #pragma unroll
@@ -344,7 +363,7 @@ __global__ __launch_bounds__(256) void dwconv_reduce_partials_kernel(int nblocks
 // walks the output pixels grid-stride, so that a thread keeps ONE channel vector and can carry that vector's sum and
 // sum of squares (of the ROUNDED outputs: what a statistics pass over y would read) in registers; one partial row
 // [2][C] per workgroup, reduced deterministically by dwconv_stat_reduce_kernel.  Saves the stp3_bn_stats pass over y.
-template <typename T, int K, int S>
+template <typename T, int K, int S, typename Off>
 __global__ __launch_bounds__(256) void dwconv_fwd_stats_kernel(DwDims d, const T* __restrict__ x, const float* __restrict__ w,
                                                                T* __restrict__ y, float* __restrict__ partial) {
     constexpr int VN = Vec<T>::N;
@@ -377,22 +396,26 @@ __global__ __launch_bounds__(256) void dwconv_fwd_stats_kernel(DwDims d, const T
 #pragma unroll
                 for (int j = 0; j < VN; ++j) acc[i][j] = 0.f;
             const int wi0 = wo0 * S - d.pad_l;
+            const Off pix = (Off)d.C * sizeof(T);
+            const Off wtap = (Off)d.C * sizeof(float), wc0 = (Off)c0 * sizeof(float);
 #pragma unroll
             for (int kh = 0; kh < K; ++kh) {
                 const int hi = ho * S + kh - d.pad_t;
                 if (hi < 0 || hi >= d.H) continue;
                 float wk[K][VN];
 #pragma unroll
-                for (int kw = 0; kw < K; ++kw)
+                for (int kw = 0; kw < K; ++kw) {
+                    const float* wp = at(w, (Off)(kh * K + kw) * wtap + wc0);
 #pragma unroll
-                    for (int j = 0; j < VN; ++j) wk[kw][j] = w[(kh * K + kw) * d.C + c0 + j];
-                const T* xrow = x + ((int64_t)(n * d.H + hi) * d.W) * d.C + c0;
+                    for (int j = 0; j < VN; ++j) wk[kw][j] = wp[j];
+                }
+                const Off xrow = ((Off)(n * d.H + hi) * d.W) * pix + (Off)c0 * sizeof(T);
                 float xin[SPAN][VN];
 #pragma unroll
                 for (int i = 0; i < SPAN; ++i) {
                     const int wi = wi0 + i;
                     Vec<T> v;
-                    if (wi >= 0 && wi < d.W) v.load(xrow + (int64_t)wi * d.C); else v.zero();
+                    if (wi >= 0 && wi < d.W) v.load(at(x, xrow + (Off)wi * pix)); else v.zero();
                     v.to_float(xin[i]);
                 }
 #pragma unroll
@@ -402,13 +425,13 @@ __global__ __launch_bounds__(256) void dwconv_fwd_stats_kernel(DwDims d, const T
 #pragma unroll
                         for (int j = 0; j < VN; ++j) acc[o][j] = fmaf(xin[o * S + kw][j], wk[kw][j], acc[o][j]);
             }
-            T* yrow = y + ((int64_t)(n * d.Ho + ho) * d.Wo) * d.C + c0;
+            const Off yrow = ((Off)(n * d.Ho + ho) * d.Wo) * pix + (Off)c0 * sizeof(T);
 #pragma unroll
             for (int o = 0; o < TW; ++o) {
                 if (wo0 + o < d.Wo) {
                     Vec<T> v;
                     v.from_float(acc[o]);
-                    v.store(yrow + (int64_t)(wo0 + o) * d.C);
+                    v.store(at(y, yrow + (Off)(wo0 + o) * pix));
                     float rv[VN];
                     v.to_float(rv);                         // the stored (rounded) values
 #pragma unroll
@@ -517,13 +540,26 @@ inline int check(const stp3_dwconv_dims* p, DwDims* d, int* vec) {
     return STP3_OK;
 }
 
+// every tensor of the call (input, output, tap-major weights) below 4 GiB, with a pixel row of slack for the offsets of
+// padded columns that are formed but never dereferenced: byte offsets fit 32 bits
+template <typename T>
+inline bool small_tensors(const DwDims& d) {
+    const uint64_t lim = (1ull << 32) - (uint64_t)(d.W + d.Wo + 16) * d.C * sizeof(float);
+    return (uint64_t)d.N * d.H * d.W * d.C * sizeof(T) < lim && (uint64_t)d.N * d.Ho * d.Wo * d.C * sizeof(T) < lim &&
+           (uint64_t)64 * d.C * sizeof(float) < lim;
+}
+
 template <typename T, int K, int S>
 int launch_fwd(const DwDims& d, const void* x, const float* w, const float* bias, void* y, hipStream_t s) {
     constexpr int TW = 4;
     const int CV = d.C / Vec<T>::N;
     const int64_t total = (int64_t)d.N * d.Ho * ((d.Wo + TW - 1) / TW) * CV;
-    hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, S, TW, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d,
-                       (const T*)x, w, bias, (T*)y);
+    if (small_tensors<T>(d))
+        hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, S, TW, false, uint32_t>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           s, d, (const T*)x, w, bias, (T*)y);
+    else
+        hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, S, TW, false, uint64_t>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           s, d, (const T*)x, w, bias, (T*)y);
     return status();
 }
 template <typename T, int K, int S>
@@ -537,11 +573,16 @@ int launch_fwd_stats(const DwDims& d, const void* x, const float* w, void* y, fl
     const int by = (CV + CVB - 1) / CVB;
     int64_t want = (ngroups + PL - 1) / PL;
     const size_t lds = (size_t)PL * 2 * CVB * VN * sizeof(float);
-    int limit = resident_blocks(dwconv_fwd_stats_kernel<T, K, S>, lds);
+    const bool small = small_tensors<T>(d);
+    int limit = small ? resident_blocks(dwconv_fwd_stats_kernel<T, K, S, uint32_t>, lds)
+                      : resident_blocks(dwconv_fwd_stats_kernel<T, K, S, uint64_t>, lds);
     if (limit > kStatBlocks) limit = kStatBlocks;
     const int cap = limit / by > 0 ? limit / by : 1;
     const int bx = (int)(want < cap ? want : cap);
-    hipLaunchKernelGGL((dwconv_fwd_stats_kernel<T, K, S>), dim3(bx, by), dim3(256), lds, s, d, (const T*)x, w, (T*)y, ws);
+    if (small)
+        hipLaunchKernelGGL((dwconv_fwd_stats_kernel<T, K, S, uint32_t>), dim3(bx, by), dim3(256), lds, s, d, (const T*)x, w, (T*)y, ws);
+    else
+        hipLaunchKernelGGL((dwconv_fwd_stats_kernel<T, K, S, uint64_t>), dim3(bx, by), dim3(256), lds, s, d, (const T*)x, w, (T*)y, ws);
     hipLaunchKernelGGL(dwconv_stat_reduce_kernel, dim3((2 * d.C + kRedCols - 1) / kRedCols), dim3(256), 0, s, bx, 2 * d.C, ws, sums);
     return status();
 }
@@ -553,8 +594,12 @@ int launch_bwd_data(const DwDims& d, const void* dy, const float* w, void* dx, h
         f.H = d.Ho; f.W = d.Wo; f.Ho = d.H; f.Wo = d.W;
         f.pad_t = K - 1 - d.pad_t; f.pad_l = K - 1 - d.pad_l;
         const int64_t n = (int64_t)f.N * f.Ho * ((f.Wo + TW - 1) / TW) * (f.C / Vec<T>::N);
-        hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, 1, TW, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, f,
-                           (const T*)dy, w, (const float*)nullptr, (T*)dx);
+        if (small_tensors<T>(f))
+            hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, 1, TW, true, uint32_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                               f, (const T*)dy, w, (const float*)nullptr, (T*)dx);
+        else
+            hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, 1, TW, true, uint64_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                               f, (const T*)dy, w, (const float*)nullptr, (T*)dx);
         return status();
     } else if constexpr (S == 2) {
         // quads: rows 2a - pt, 2a + 1 - pt for a = pt / 2 .. (H - 1 + pt) / 2
@@ -586,12 +631,18 @@ int launch_bwd_weight(const DwDims& d, const void* x, const void* dy, float* dw,
     int64_t want = (npix + PL - 1) / PL;
     const int by = (CV + CVB - 1) / CVB;
     const size_t lds = (size_t)PL * K * CVB * VN * sizeof(float);
-    int cap = resident_blocks(dwconv_bwd_weight_kernel<T, K, S>, lds) / (by * K);      // (bx * by * K workgroups)
+    const bool small = small_tensors<T>(d);
+    int cap = (small ? resident_blocks(dwconv_bwd_weight_kernel<T, K, S, uint32_t>, lds)
+                     : resident_blocks(dwconv_bwd_weight_kernel<T, K, S, uint64_t>, lds)) / (by * K);      // (bx * by * K workgroups)
     if (cap > kWgradBlocks) cap = kWgradBlocks;
     if (cap < 1) cap = 1;
     const int bx = (int)(want < cap ? want : cap);
-    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, S>), dim3(bx * by * K), dim3(256), lds, s, d, bx, (const T*)x,
-                       (const T*)dy, ws);
+    if (small)
+        hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, S, uint32_t>), dim3(bx * by * K), dim3(256), lds, s, d, bx, (const T*)x,
+                           (const T*)dy, ws);
+    else
+        hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, S, uint64_t>), dim3(bx * by * K), dim3(256), lds, s, d, bx, (const T*)x,
+                           (const T*)dy, ws);
     const int n = K * K * d.C;
     hipLaunchKernelGGL(dwconv_reduce_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, s, bx, n, ws, dw, param_layout ? d.C : 0);
     return status();
