@@ -34,8 +34,8 @@ def test_kernel_register_lds_and_scratch_budgets():
                          ('optim_adam_kernel', 128), ('void se_mlp_fwd_kernel<40>', 128), ('void se_mlp_bwd_sample_kernel<40>', 128),
                          ('void se_mlp_fwd_kernel<8>', 128), ('void se_mlp_bwd_sample_kernel<16>', 128),
                          ('se_mlp_bwd_weight_kernel', 128), ('voxels_sum_fwd_kernel', 128),
-                         ('voxels_sum_bwd_kernel', 128), ('void dwconv_fwd_stats_kernel<unsigned short, 3, 1>', 168),
-                         ('void dwconv_fwd_stats_kernel<unsigned short, 5, 1>', 256),
+                         ('voxels_sum_bwd_kernel', 128), ('void dwconv_fwd_stats_kernel<unsigned short, 3, 1, unsigned int>', 168),
+                         ('void dwconv_fwd_stats_kernel<unsigned short, 5, 1, unsigned int>', 256),
                          ('void mbconv_bwd_reduce_kernel<unsigned short, 8, 2>', 128),
                          ('void mbconv_bwd_apply_kernel<unsigned short, 8, 2>', 168), ('topk_select_kernel', 64)):
         assert name in by_name, name
