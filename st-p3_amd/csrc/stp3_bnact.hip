@@ -165,43 +165,45 @@ __device__ __forceinline__ void dispatch_act_res(int act, int res_mode, F&& f) {
 
 // In-block tree reduction over the row lanes of K values per thread, then one partial row per block:
 // partial[((n * gridDim.x + bx) * K + k) * C + c]
+// All K sums go through the tree TOGETHER (red holds K planes): one barrier per level instead of K -- the same additions in
+// the same order as one tree per sum (bit-identical), a third of the barriers behind every bn_bwd_reduce launch.
 template <int VEC, int K, bool FULL>
 __device__ __forceinline__ void block_reduce_store(const BnDims& d, const Map& m, float (*acc)[VEC], float* red,
                                                    float* __restrict__ partial) {
     const int cvb = threadIdx.x % m.CVB;
     const int width = m.CVB * VEC;
+    constexpr int plane = kThreads * VEC;
+    __syncthreads();
+    if (m.rl < m.RL) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        __syncthreads();
-        if (m.rl < m.RL) {
+        for (int k = 0; k < K; ++k)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) red[m.rl * width + cvb * VEC + j] = m.live ? acc[k][j] : 0.f;
+            for (int j = 0; j < VEC; ++j) red[k * plane + m.rl * width + cvb * VEC + j] = m.live ? acc[k][j] : 0.f;
+    }
+    __syncthreads();
+    int first = m.RL >> 1;
+    if (FULL) {                                               // RL need not be a power of two
+        int p2 = 1;
+        while (p2 < m.RL) p2 <<= 1;
+        first = p2 >> 1;
+    }
+    for (int s = first; s > 0; s >>= 1) {
+        if (m.rl < s && m.rl + s < m.RL) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    red[k * plane + m.rl * width + cvb * VEC + j] += red[k * plane + (m.rl + s) * width + cvb * VEC + j];
         }
         __syncthreads();
-        if (FULL) {                                           // RL need not be a power of two
-            int p2 = 1;
-            while (p2 < m.RL) p2 <<= 1;
-            for (int s = p2 >> 1; s > 0; s >>= 1) {
-                if (m.rl < s && m.rl + s < m.RL) {
+    }
+    if (m.rl == 0 && m.cv < m.CV) {
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) red[m.rl * width + cvb * VEC + j] += red[(m.rl + s) * width + cvb * VEC + j];
-                }
-                __syncthreads();
-            }
-        } else {
-            for (int s = m.RL >> 1; s > 0; s >>= 1) {
-                if (m.rl < s) {
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) red[m.rl * width + cvb * VEC + j] += red[(m.rl + s) * width + cvb * VEC + j];
-                }
-                __syncthreads();
-            }
-        }
-        if (m.rl == 0 && m.cv < m.CV) {
+        for (int k = 0; k < K; ++k) {
             float* out = partial + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * K + k) * d.C + m.cv * VEC;
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
-                if (m.cv * VEC + j < d.C) out[j] = red[cvb * VEC + j];
+                if (m.cv * VEC + j < d.C) out[j] = red[k * plane + cvb * VEC + j];
         }
     }
 }
@@ -211,7 +213,7 @@ template <typename T, int VEC, bool FULL, bool TAIL>
 __global__ __launch_bounds__(kThreads) void bn_stats_kernel(BnDims d, const T* __restrict__ x,
                                                             const float* __restrict__ sbias,
                                                             float* __restrict__ partial) {
-    __shared__ float red[kThreads * VEC];
+    __shared__ float red[2 * kThreads * VEC];
     const Map m = make_map<VEC, FULL>(d);
     const int n = blockIdx.y;
     float acc[2][VEC];
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
     const T* __restrict__ res, const float* __restrict__ oscale, const float* __restrict__ mean_,
     const float* __restrict__ invstd_, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ partial) {
-    __shared__ float red[kThreads * VEC];
+    __shared__ float red[3 * kThreads * VEC];
     const Map m = make_map<VEC, FULL>(d);
     const int n = blockIdx.y;
     float acc[3][VEC];
