@@ -198,7 +198,11 @@ def _cpu_baseline_worker(workload='c3'):
         opt.step()
         return time.time() - t0
 
-    batch = synthetic.make_batch(batch=1, seq=3, seed=0, gt_depth=full, instance=full)
+    over = WORKLOAD_CFG[workload]
+    n_future = over.get('N_FUTURE_FRAMES', 0)                       # rows f2 / f3: the future frames and their labels too
+    batch_kw = dict(seq=3 + n_future, seed=0, gt_depth=full, instance=full or bool(over.get('INSTANCE_SEG.ENABLED')),
+                    planning=(n_future, over['PLANNING.SAMPLE_NUM']) if over.get('PLANNING.ENABLED') else None)
+    batch = synthetic.make_batch(batch=1, **batch_kw)
     counts = sorted({min(c, cores) for c in CPU_BASELINE_THREADS})
     torch.set_num_threads(counts[0])
     train_step(batch)                                                # warm-up (allocator, oneDNN primitives)
@@ -242,7 +246,7 @@ def _cpu_baseline_worker(workload='c3'):
     # the batch the GPU line is quoted on: one step, no warm-up of its own (~1 minute of CPU work)
     b4 = None
     if os.environ.get('STP3_CPU_BASELINE_B4', '1') != '0':
-        batch4 = synthetic.make_batch(batch=4, seq=3, seed=0, gt_depth=full, instance=full)
+        batch4 = synthetic.make_batch(batch=4, **batch_kw)
         b4 = train_step(batch4)
     what = ('the reference\'s TrainingModule.shared_step on its own modules (stp3/models, layers, losses, utils/geometry; '
             'third-party EfficientNet-B4 / ResNet-18 restated), train() mode' if kind == 'reference' else
@@ -254,7 +258,7 @@ def _cpu_baseline_worker(workload='c3'):
                       'step_s_median_of_3': round(median, 2),
                       'b4_step_s': None if b4 is None else round(b4, 2),
                       'b4_samples_per_s': None if b4 is None else round(4.0 / b4, 4),
-                      'sample': f'{what}; B=1 (1 sample = 6 cams x 3 frames) full fwd+bwd+clip+Adam step ({workload} losses), fp32, '
+                      'sample': f'{what}; B=1 (1 sample = 6 cams x 3 frames{f" + {n_future} future frames" if n_future else ""}) full fwd+bwd+clip+Adam step ({workload} losses), fp32, '
                                 f'1 warm-up + median of 3 at {best} of {cores} host threads (swept {counts}) = value; '
                                 f'b4_step_s = ONE step at the bench batch (B=4) at {best} threads'}))
 

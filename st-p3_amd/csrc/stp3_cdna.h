@@ -82,3 +82,23 @@ __device__ __forceinline__ stp3_f32x2 pk_sigmoid(stp3_f32x2 x) {
     e = e + 1.0f;
     return stp3_f32x2{fast_rcp(e.x), fast_rcp(e.y)};
 }
+
+// ---- raw buffer loads -----------------------------------------------------------------------------------------------
+// A buffer resource (V#) over [base, base + bytes): loads through it take a SCALAR base and a 32-bit byte offset per lane
+// (no 64-bit address arithmetic in vector registers) and return ZERO for any offset at or beyond `bytes` -- the hardware's
+// range check.  A staging loop marks a padding tap / a row beyond the matrix with the offset kBufOob instead of selecting
+// between two 64-bit addresses.  Requires bytes < 2^31 (so that kBufOob is out of range and offset + 16 cannot wrap).
+typedef unsigned stp3_u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t stp3_buffer;
+constexpr uint32_t kBufOob = 0x80000000u;
+__device__ __forceinline__ stp3_buffer make_buffer(const void* base, uint32_t bytes) {
+    // base and size are uniform (kernel arguments); saying so keeps the resource in scalar registers -- otherwise every load is
+    // wrapped in a readfirstlane loop over the lanes' (identical) resources
+    const uint64_t a = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0,
+                                             (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ stp3_u32x4 buffer_load16(stp3_buffer rsrc, uint32_t byte_offset) {
+    return __builtin_bit_cast(stp3_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_offset, 0, 0));
+}

@@ -62,7 +62,7 @@ constexpr int kBK = 64;         // K per step: 8 pieces of 16 bytes per row
 // VALU instruction count (196 VALU instructions beside 8 MFMAs per K-step in the forward kernel, 332 beside 4 in the
 // weight gradient), not by the matrix cores or by memory.
 __device__ __attribute__((aligned(16))) uint4 g_zero16 = {0u, 0u, 0u, 0u};
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef stp3_u32x4 u32x4;
 
 // v or zero, word by word (a select on the whole uint4 makes the compiler go through scratch memory)
 __device__ __forceinline__ uint4 keep(uint4 v, bool ok) {
@@ -115,7 +115,12 @@ __device__ __forceinline__ float epi_act_grad(float pre) {
     return 1.f;
 }
 
-template <int BN, int MODE = kModePlain, int ACT = STP3_ACT_NONE>
+// BUF (the launcher sets it whenever the input and the weight tensor are each smaller than 2 GiB): the staging loads go through
+// buffer resources -- a scalar base, one 32-bit byte offset per load, and the hardware's range check returning zeros for the
+// offset kBufOob of a padding tap / a row beyond the matrix -- instead of selecting between a 64-bit address and the address of
+// g_zero16 (which the compiler turned into exec-mask branches: 284 instructions per K step beside 16 MFMAs, 103 of them VALU
+// and 115 SALU, `s_getpc` of g_zero16 ten times per step).
+template <int BN, int MODE = kModePlain, int ACT = STP3_ACT_NONE, bool BUF = false>
 __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles_co, const uint16_t* __restrict__ x,
                                                            const uint16_t* __restrict__ w,
                                                            const float* __restrict__ bias, void* __restrict__ y,
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
     const int j = tid & 7, rr = tid >> 3;
     const uint16_t* const zero = reinterpret_cast<const uint16_t*>(&g_zero16);
     const uint16_t* prow[4];                              // pixel rows: address of (hi0, wi0, channel 0), or `zero`
+    uint32_t poff[4];                                     // BUF: the same as a byte offset from x (mod 2^32), kBufOob = no row
     int phi[4], pwi[4];                                   // ... and hi0, wi0
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -150,19 +156,24 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
             const int n = t / d.Ho;
             phi[i] = ho * d.stride - d.pad_h;
             pwi[i] = wo * d.stride - d.pad_w;
-            prow[i] = x + (ptrdiff_t)((n * d.H + phi[i]) * d.W + pwi[i]) * d.ldx;
+            if (BUF) poff[i] = (uint32_t)(((n * d.H + phi[i]) * d.W + pwi[i]) * d.ldx) * 2u;
+            else prow[i] = x + (ptrdiff_t)((n * d.H + phi[i]) * d.W + pwi[i]) * d.ldx;
         } else {
             phi[i] = -(1 << 28);                           // never inside the image
             pwi[i] = 0;
-            prow[i] = zero;
+            if (BUF) poff[i] = kBufOob; else prow[i] = zero;
         }
     }
     const uint16_t* wrow[BN / 32];                        // weight rows: address of (co, k = 0), or `zero`
+    uint32_t woff[BN / 32];                               // BUF: byte offset from w, kBufOob = no row
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i) {
         const int co = co0 + rr + 32 * i;
-        wrow[i] = co < d.Cout ? w + (size_t)co * d.Ktot : zero;
+        if (BUF) woff[i] = co < d.Cout ? (uint32_t)(co * d.Ktot) * 2u : kBufOob;
+        else wrow[i] = co < d.Cout ? w + (size_t)co * d.Ktot : zero;
     }
+    const stp3_buffer xbuf = make_buffer(x, BUF ? (uint32_t)((size_t)d.N * d.H * d.W * d.ldx * 2) : 0u);
+    const stp3_buffer wbuf = make_buffer(w, BUF ? (uint32_t)((size_t)d.Cout * d.Ktot * 2) : 0u);
     // position of this thread's piece in K: k = step * 64 + j * 8 = tap * Cin + ci
     int tap = 0, ci = j * 8;
     while (ci >= d.Cin) { ci -= d.Cin; ++tap; }
@@ -181,17 +192,30 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
         const int toff = (dh * d.W + dw) * d.ldx + ci;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            bool ok = kvalid && prow[i] != zero;
-            if (!pointwise) {
-                const int hi = phi[i] + dh, wi = pwi[i] + dw;
-                ok = ok && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
+            if (BUF) {
+                // branch-free: the conditions are combined with `&` (every one is cheap and safe to evaluate), the offset of a
+                // tap outside the image becomes kBufOob and the load returns zeros
+                bool ok = kvalid & (poff[i] != kBufOob);
+                if (!pointwise) {
+                    const int hi = phi[i] + dh, wi = pwi[i] + dw;
+                    ok = ok & ((unsigned)hi < (unsigned)d.H) & ((unsigned)wi < (unsigned)d.W);
+                }
+                ra[i] = buffer_load16(xbuf, ok ? poff[i] + (uint32_t)toff * 2u : kBufOob);
+            } else {
+                bool ok = kvalid && prow[i] != zero;
+                if (!pointwise) {
+                    const int hi = phi[i] + dh, wi = pwi[i] + dw;
+                    ok = ok && (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
+                }
+                ra[i] = *reinterpret_cast<const u32x4*>(ok ? prow[i] + toff : zero);
             }
-            ra[i] = *reinterpret_cast<const u32x4*>(ok ? prow[i] + toff : zero);
         }
         const int kk = tap * d.Cin + ci;
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i)
-            rb[i] = *reinterpret_cast<const u32x4*>((kvalid && wrow[i] != zero) ? wrow[i] + kk : zero);
+        for (int i = 0; i < BN / 32; ++i) {
+            if (BUF) rb[i] = buffer_load16(wbuf, (kvalid & (woff[i] != kBufOob)) ? woff[i] + (uint32_t)kk * 2u : kBufOob);
+            else rb[i] = *reinterpret_cast<const u32x4*>((kvalid && wrow[i] != zero) ? wrow[i] + kk : zero);
+        }
         // advance to the next step: k += 64
         ci += kBK;
         while (ci >= d.Cin && tap < taps) {
@@ -847,7 +871,8 @@ union FragTr {
     bf16x8 v;
 };
 
-template <int TCO, int TCI>
+// BUF: the staging loads through buffer resources (see conv2d_igemm_kernel): both operands smaller than 2 GiB
+template <int TCO, int TCI, bool BUF = false>
 __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles_ci, int ksteps_per_block, int tap_fold,
                                                            int xcd_chunks, const uint16_t* __restrict__ dy,
                                                            const uint16_t* __restrict__ x,
@@ -903,6 +928,10 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
     }
     const uint16_t* const srcb = b_ok ? x + chb : zero;
     const unsigned ldb = b_ok ? (unsigned)d.ldx : 0u;
+    const stp3_buffer abuf = make_buffer(dy, BUF ? (uint32_t)((size_t)d.M * d.ldy * 2) : 0u);
+    const stp3_buffer bbuf = make_buffer(x, BUF ? (uint32_t)((size_t)d.N * d.H * d.W * d.ldx * 2) : 0u);
+    const uint32_t cola = (uint32_t)(co0 + pa * 8) * 2u, colb = (uint32_t)chb * 2u;     // BUF: byte offset of the piece in a row
+    const uint32_t pitcha = (uint32_t)d.ldy * 2u, pitchb = (uint32_t)d.ldx * 2u;
     const int fold_dh = khb * d.dil_h, fold_dw = kwb * d.dil_w;              // (fold mode) this thread's tap shift
 
     // ---- pixel role: lane l of EVERY wave owns pixel 64 * step + l of the step being loaded.  (n, ho, wo) is set up with
@@ -925,7 +954,8 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int m = mbase + ra0 + RA * i;
-            rawa[i] = *reinterpret_cast<const u32x4*>(m < d.M ? srca + (size_t)(unsigned)m * lda : zero);
+            if (BUF) rawa[i] = buffer_load16(abuf, (a_ok & (m < d.M)) ? (uint32_t)m * pitcha + cola : kBufOob);
+            else rawa[i] = *reinterpret_cast<const u32x4*>(m < d.M ? srca + (size_t)(unsigned)m * lda : zero);
         }
         const bool inside = mbase + lane < d.M;
         if (!tap_fold) {
@@ -935,7 +965,8 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int pv = __shfl(pix, rb0 + RB * i);
-                rawb[i] = *reinterpret_cast<const u32x4*>(pv >= 0 ? srcb + (size_t)(unsigned)pv * ldb : zero);
+                if (BUF) rawb[i] = buffer_load16(bbuf, (b_ok & (pv >= 0)) ? (uint32_t)pv * pitchb + colb : kBufOob);
+                else rawb[i] = *reinterpret_cast<const u32x4*>(pv >= 0 ? srcb + (size_t)(unsigned)pv * ldb : zero);
             }
         } else {
             const int hs = p_ho * d.stride - d.pad_h, ws = p_wo * d.stride - d.pad_w;
@@ -947,7 +978,8 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_kernel(ConvDims d, int tiles
                 const int hi = (int)((unsigned)pk >> 16) - 32768 + fold_dh, wi = (pk & 0xffff) - 32768 + fold_dw;
                 const bool ok = (unsigned)hi < (unsigned)d.H && (unsigned)wi < (unsigned)d.W;
                 const int pv = bs + fold_dh * d.W + fold_dw;
-                rawb[i] = *reinterpret_cast<const u32x4*>(ok ? srcb + (size_t)(unsigned)pv * ldb : zero);
+                if (BUF) rawb[i] = buffer_load16(bbuf, (b_ok & ok) ? (uint32_t)pv * pitchb + colb : kBufOob);
+                else rawb[i] = *reinterpret_cast<const u32x4*>(ok ? srcb + (size_t)(unsigned)pv * ldb : zero);
             }
         }
         p_wo += qc; p_ho += qb; p_n += qa;                 // this lane's pixel of the next step
@@ -1075,11 +1107,20 @@ template <int TCO, int TCI>
 int wgrad_launch(const ConvDims& d, int tco, int tci, int taps, int splits, int ksteps, int fold, const void* dy,
                  const void* x, void* workspace, hipStream_t s) {
     const size_t lds = (size_t)2 * (TCO + TCI) * kBK * 2;
+    // XCD-contiguous workgroup order when the grid is a 32-bit count and the layer has at most a 3x3's worth of taps
+    const int xcd = taps <= 9 && (int64_t)tco * tci * taps * splits < (1LL << 31);
+    const bool buf = (size_t)d.M * d.ldy * 2 < (1ull << 31) && (size_t)d.N * d.H * d.W * d.ldx * 2 < (1ull << 31);
+    if (buf) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_kernel<TCO, TCI, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+        hipLaunchKernelGGL((conv2d_wgrad_kernel<TCO, TCI, true>), dim3(tco * tci, taps, splits), dim3(256), lds, s, d, tci,
+                           ksteps, fold, xcd, (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace);
+        return STP3_OK;
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_kernel<TCO, TCI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return -(int)e;
-    // XCD-contiguous workgroup order when the grid is a 32-bit count and the layer has at most a 3x3's worth of taps
-    const int xcd = taps <= 9 && (int64_t)tco * tci * taps * splits < (1LL << 31);
     hipLaunchKernelGGL((conv2d_wgrad_kernel<TCO, TCI>), dim3(tco * tci, taps, splits), dim3(256), lds, s, d, tci, ksteps,
                        fold, xcd, (const uint16_t*)dy, (const uint16_t*)x, (float*)workspace);
     return STP3_OK;
@@ -1105,6 +1146,17 @@ namespace {
 template <int BN, int MODE, int ACT>
 int igemm_launch_one(const ConvDims& d, dim3 grid, size_t lds, int tiles_co, const void* x, const void* w, const float* bias,
                      void* y, float* partial, const EpiArgs& ep, hipStream_t s) {
+    // input and weights each below 2 GiB: buffer-addressed staging (see the kernel); the stress geometry's 4.6 G-element
+    // tensors keep the 64-bit addresses
+    const bool buf = (size_t)d.N * d.H * d.W * d.ldx * 2 < (1ull << 31) && (size_t)d.Cout * d.Ktot * 2 < (1ull << 31);
+    if (buf) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_igemm_kernel<BN, MODE, ACT, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+        hipLaunchKernelGGL((conv2d_igemm_kernel<BN, MODE, ACT, true>), grid, dim3(256), lds, s, d, tiles_co, (const uint16_t*)x,
+                           (const uint16_t*)w, bias, y, partial, ep);
+        return STP3_OK;
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_igemm_kernel<BN, MODE, ACT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return -(int)e;

@@ -68,3 +68,14 @@ inline float fast_sigmoid(float x) { return 1.0f / (1.0f + std::exp(-x)); }
 typedef float stp3_f32x2 __attribute__((ext_vector_type(2)));
 inline stp3_f32x2 pk_fma(stp3_f32x2 a, stp3_f32x2 b, stp3_f32x2 c) { return stp3_f32x2{std::fma(a.x, b.x, c.x), std::fma(a.y, b.y, c.y)}; }
 inline stp3_f32x2 pk_sigmoid(stp3_f32x2 x) { return stp3_f32x2{fast_sigmoid(x.x), fast_sigmoid(x.y)}; }
+
+// ---- raw buffer loads (model): zero beyond the resource's range, like the hardware's check ------------------------------
+typedef unsigned stp3_u32x4 __attribute__((ext_vector_type(4)));
+struct stp3_buffer { const char* base; uint32_t bytes; };
+constexpr uint32_t kBufOob = 0x80000000u;
+inline stp3_buffer make_buffer(const void* base, uint32_t bytes) { return stp3_buffer{static_cast<const char*>(base), bytes}; }
+inline stp3_u32x4 buffer_load16(stp3_buffer rsrc, uint32_t byte_offset) {
+    stp3_u32x4 v = {0u, 0u, 0u, 0u};
+    if ((uint64_t)byte_offset + 16 <= rsrc.bytes) memcpy(&v, rsrc.base + byte_offset, 16);
+    return v;
+}

@@ -42,7 +42,7 @@ def test_kernel_register_lds_and_scratch_budgets():
         for k in by_name[name]:
             assert k['vgpr'] + k['agpr'] <= budget, k
     # the MFMA convolutions: accumulators in AGPRs, at least 2 workgroups of 256 threads per CU
-    for prefix in ('void conv2d_igemm_kernel<128, 0, 0>', 'void conv2d_wgrad_kernel<128, 128>'):
+    for prefix in ('void conv2d_igemm_kernel<128, 0, 0, ', 'void conv2d_wgrad_kernel<128, 128, '):
         found = [k for n, ks in by_name.items() if n.startswith(prefix) for k in ks]
         assert found, prefix
         for k in found:
@@ -57,8 +57,8 @@ def test_kernel_register_lds_and_scratch_budgets():
                          ('void bn_bwd_reduce_kernel<unsigned short, 8', 4), ('void bn_apply_bwd_kernel<unsigned short, 8', 3),
                          ('void se_pool_act_kernel<unsigned short, 8', 7), ('void mbconv_scale_act_kernel<unsigned short, 8', 7),
                          ('void mbconv_bwd_reduce_kernel<unsigned short, 8', 4), ('void mbconv_bwd_apply_kernel<unsigned short, 8', 4),
-                         ('void conv2d_wgrad_kernel<128, 128>', 2), ('void conv2d_wgrad_kernel<128, 64>', 3),
-                         ('void conv2d_wgrad_kernel<64, 128>', 3), ('void conv2d_wgrad_kernel<64, 64>', 5)):
+                         ('void conv2d_wgrad_kernel<128, 128, ', 2), ('void conv2d_wgrad_kernel<128, 64, ', 3),
+                         ('void conv2d_wgrad_kernel<64, 128, ', 3), ('void conv2d_wgrad_kernel<64, 64, ', 5)):
         found = [k for n, ks in by_name.items() if n.startswith(prefix) for k in ks]
         assert found, prefix
         for k in found:
