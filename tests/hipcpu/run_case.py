@@ -1271,6 +1271,10 @@ def model_step_bf16_bn_eval(ops):   # the same with BatchNorm on its running sta
     return _model_step(ops, autocast=True, bn_eval=True)
 
 
+def model_step_f32_bn_eval(ops):    # float32 with BatchNorm on its running statistics: a smooth function, kernels to round-off
+    return _model_step(ops, autocast=False, bn_eval=True)
+
+
 def fuzz(ops, seed=1):
     """Random shapes / modes of the depthwise, BatchNorm and dense convolution operators against torch in float32."""
     import random
@@ -1440,7 +1444,7 @@ def gru_cell(ops):
     return out
 
 
-CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_rolled, lift_c64_frames, lift_coarse_grid, lift_tall, lift_c64_rows56, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
+CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_f32_bn_eval, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_rolled, lift_c64_frames, lift_coarse_grid, lift_tall, lift_c64_rows56, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
                                  conv, conv_f32, fan_out, aspp_join, pointwise_bn, pointwise_stream, decoder_heads, dwconv, layernorm, gru_cell, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
 
 if __name__ == '__main__':

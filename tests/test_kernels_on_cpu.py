@@ -33,7 +33,7 @@ ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_bloc
 ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'layernorm', 'gru_cell', 'bn_act', 'conv', 'conv_bn', 'pointwise_bn', 'pointwise_stream', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'labels', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)]
 MODEL = [('lift_full', {}), ('model_step_two_ranks', {}), ('model_step_f32_full_losses', {}), ('model_step_f32', {}),
-         ('model_step_bf16_bn_eval', {})]        # whole training steps: minutes, STP3_SLOW_TESTS=1
+         ('model_step_f32_bn_eval', {}), ('model_step_bf16_bn_eval', {})]        # whole training steps: minutes, STP3_SLOW_TESTS=1
 
 pytestmark = pytest.mark.skipif(not os.path.exists(hipcpu_build.CLANG) or shutil.which('gcc') is None,
                                 reason='needs the clang++ that ships with ROCm')
@@ -354,7 +354,14 @@ def test_whole_step_float32_matches_the_cpu_port(results):
     amplification of this tiny configuration (tests/test_parallel_cpu.py measures 7e-3 for a mere sample swap)."""
     r = _get(results, 'model_step_f32')
     assert not r['params_without_grad']
-    assert abs(r['loss'] - r['ref_loss']) <= 1e-5 * abs(r['ref_loss']) and r['grad_rel_l2'] <= 2e-2
+    # Train-mode BatchNorm over the 4 x 6 maps of this configuration amplifies round-off chaotically: the figure moves with
+    # any change of a summation order anywhere in the step (1.0e-2 at the end of round 4, 3.8e-2 at the end of round 5 with
+    # kernels that are bit-identical or exact elsewhere) -- it bounds gross errors only.  What pins the kernels is the same
+    # step with BatchNorm on its running statistics, a smooth function: loss equal to the last digit, gradient 6e-6.
+    assert abs(r['loss'] - r['ref_loss']) <= 1e-5 * abs(r['ref_loss']) and r['grad_rel_l2'] <= 8e-2
+    e = _get(results, 'model_step_f32_bn_eval')
+    assert not e['params_without_grad']
+    assert abs(e['loss'] - e['ref_loss']) <= 1e-6 * abs(e['ref_loss']) and e['grad_rel_l2'] <= 1e-4
 
 
 def test_whole_step_bf16_matches_the_cpu_port(results):
