@@ -53,6 +53,10 @@ def test_bench_main_dry_run(tmp_path, workload):
     trace = open(tmp_path / 'trace.log').read()
     if workload == 'planning':
         assert 'stp3_traj_cost_fwd ' in trace and 'stp3_traj_cost_bwd ' in trace
+    if workload in ('prediction', 'planning'):                # the prediction stage's own operators
+        for entry in ('stp3_dwconv2d_fwd_bias', 'stp3_layernorm_fwd', 'stp3_layernorm_bwd', 'stp3_gru_reset_cat_fwd',
+                      'stp3_gru_output_fwd', 'stp3_gru_output_bwd', 'stp3_gru_reset_cat_bwd'):
+            assert entry + ' ' in trace, entry
     for entry in ('stp3_lift_plan_build', 'stp3_lift_splat_fwd', 'stp3_lift_splat_bwd',
                   'stp3_conv2d_fwd', 'stp3_conv2d_wgrad', 'stp3_conv2d_prep_weights', 'stp3_bn_fwd_train',
                   'stp3_dwconv2d_fwd_stats', 'stp3_bn_finalize', 'stp3_se_pool_act', 'stp3_se_mlp_fwd', 'stp3_se_mlp_bwd',
