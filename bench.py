@@ -367,7 +367,9 @@ def family_rooflines(step, batch_size, steps=3, perception_flops=True):
     fam = profiling.summary()
     shapes = profiling.by_shape(top=14)
     profiling.enable(False)
-    out = {'steps': steps, 'timing': 'HIP events around each C-ABI call on its launch stream, in-run'}
+    out = {'steps': steps, 'launch': 'eager',
+           'timing': 'HIP events around each C-ABI call on its launch stream, in-run, on the EAGER form of the step (the headline '
+                     'value replays the same kernels from a hipGraph: per-call events need the calls)'}
     conv = [fam[k] for k in ('conv_fwd_dgrad', 'conv_wgrad') if k in fam]
     if conv:
         ms = sum(f['ms'] for f in conv) / steps

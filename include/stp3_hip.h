@@ -459,6 +459,26 @@ int stp3_conv2d_wgrad_workspace(const stp3_conv_dims* dims, size_t* bytes);
 int stp3_conv2d_wgrad(const stp3_conv_dims* dims, const void* dy, const void* x, float* dw, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* The same weight gradient in two halves, for callers that can wait for it (the gradient of a LEAF parameter is read by
+ * nobody before the optimizer -- torch.autograd's AccumulateGrad only keeps the tensor; reference: the `loss.backward()` /
+ * `optimizer.step()` pair PyTorch-Lightning drives for stp3/trainer.py:101-172).
+ * stp3_conv2d_wgrad_partials runs the split contraction only: partials[split][Cout][KH][KW][Cin] float32 into caller memory of
+ * stp3_conv2d_wgrad_workspace(dims) bytes that must stay untouched until the reduction; *splits receives the split count.
+ * stp3_conv2d_wgrad_reduce_batch sums the partials of n such layers in ONE launch per STP3_WGRAD_BATCH_MAX jobs (`jobs` is a
+ * HOST array, it travels as the kernel argument): dw[i] = sum_k partials[k][i], the additions in the order of
+ * stp3_conv2d_wgrad (bit-identical results). */
+#define STP3_WGRAD_BATCH_MAX 96
+typedef struct stp3_wgrad_job {
+    const void* partials;   /* device: [splits][numel] float32 */
+    float* dw;              /* device: [numel] float32 */
+    int64_t numel;          /* Cout * KH * KW * Cin, < 2^32 */
+    int32_t splits;
+    int32_t reserved;
+} stp3_wgrad_job;
+int stp3_conv2d_wgrad_partials(const stp3_conv_dims* dims, const void* dy, const void* x, void* partials,
+                               size_t partials_bytes, int32_t* splits, void* stream);
+int stp3_conv2d_wgrad_reduce_batch(int32_t n, const stp3_wgrad_job* jobs, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Squeeze-and-excitation data passes (csrc/stp3_se.hip).
  * Replace the pooling, the gate multiply and the elementwise / reduction passes of their backward inside the

@@ -1091,6 +1091,50 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(int splits, si
     if (kl == 0 && i < n) dw[i] = (red[il] + red[64 + il]) + (red[128 + il] + red[192 + il]);
 }
 
+// The split-K sums of MANY layers in one launch.  Nothing reads the weight gradient of a leaf parameter before the optimizer,
+// so the ~100 per-layer reduction launches of a training step (4-7 us each, pure launch floor) are deferred: every layer's
+// main kernel leaves its partials in its own slice of an arena, and at the end of the backward pass ONE launch sums them
+// all -- job j owns the workgroups [first[j], first[j + 1]), the same 64 columns x 4 split lanes, the same order of
+// additions as conv2d_wgrad_reduce_kernel (bit-identical).  The job table travels as the kernel argument (no upload).
+constexpr int kWgradBatch = STP3_WGRAD_BATCH_MAX;
+struct WgradJobs {
+    const float* partial[kWgradBatch];
+    float* dw[kWgradBatch];
+    unsigned n[kWgradBatch];
+    int splits[kWgradBatch];
+    int first[kWgradBatch + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void conv2d_wgrad_reduce_batch_kernel(WgradJobs jobs) {
+    __shared__ float red[256];
+    // which job: binary search of the workgroup index in first[] (uniform over the workgroup: scalar code)
+    int lo = 0, hi = jobs.count;
+    const int b = blockIdx.x;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (jobs.first[mid] <= b) lo = mid; else hi = mid;
+    }
+    const float* __restrict__ partial = jobs.partial[lo];
+    float* __restrict__ dw = jobs.dw[lo];
+    const size_t n = jobs.n[lo];
+    const int splits = jobs.splits[lo];
+    const int il = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const size_t i = (size_t)(b - jobs.first[lo]) * 64 + il;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int k = kl;
+        for (; k + 12 < splits; k += 16) {
+            const float a = partial[(size_t)k * n + i], bb = partial[(size_t)(k + 4) * n + i];
+            const float c = partial[(size_t)(k + 8) * n + i], d = partial[(size_t)(k + 12) * n + i];
+            s0 += a; s1 += bb; s2 += c; s3 += d;
+        }
+        for (; k < splits; k += 4) s0 += partial[(size_t)k * n + i];
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (kl == 0 && i < n) dw[i] = (red[il] + red[64 + il]) + (red[128 + il] + red[192 + il]);
+}
+
 inline int status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? STP3_OK : -(int)e;
@@ -1437,9 +1481,10 @@ int stp3_conv2d_wgrad_workspace(const stp3_conv_dims* p, size_t* bytes) {
     return STP3_OK;
 }
 
-int stp3_conv2d_wgrad(const stp3_conv_dims* p, const void* dy, const void* x, float* dw, void* workspace,
-                      size_t workspace_bytes, void* stream) {
-    if (!p || !dy || !x || !dw || !workspace) return STP3_EINVAL;
+// the main kernel of the weight gradient: partial[split][Cout][KH][KW][Cin] into `workspace`; *splits_out = the splits
+static int wgrad_partials(const stp3_conv_dims* p, const void* dy, const void* x, void* workspace, size_t workspace_bytes,
+                          int* splits_out, hipStream_t s) {
+    if (!p || !dy || !x || !workspace) return STP3_EINVAL;
     if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->Cin <= 0 || p->Cout <= 0 || p->Ho <= 0 || p->Wo <= 0 || p->KH <= 0 ||
         p->KW <= 0 || p->stride <= 0 || p->dil_h <= 0 || p->dil_w <= 0 || p->pad_h < 0 || p->pad_w < 0)
         return STP3_EINVAL;
@@ -1462,15 +1507,63 @@ int stp3_conv2d_wgrad(const stp3_conv_dims* p, const void* dy, const void* x, fl
     d.KH = p->KH; d.KW = p->KW; d.stride = p->stride; d.pad_h = p->pad_h; d.pad_w = p->pad_w;
     d.dil_h = p->dil_h; d.dil_w = p->dil_w; d.ldx = p->ldx; d.ldy = p->ldy;
     d.out_f32 = 1; d.has_bias = 0; d.M = (int)M; d.kchunks = 0; d.Ktot = p->KH * p->KW * p->Cin;
-    hipStream_t s = (hipStream_t)stream;
     int rc;
     if (tco_sz == 128 && tci_sz == 128) rc = wgrad_launch<128, 128>(d, tco, tci, taps, splits, ksteps, fold, dy, x, workspace, s);
     else if (tco_sz == 128) rc = wgrad_launch<128, 64>(d, tco, tci, taps, splits, ksteps, fold, dy, x, workspace, s);
     else if (tci_sz == 128) rc = wgrad_launch<64, 128>(d, tco, tci, taps, splits, ksteps, fold, dy, x, workspace, s);
     else rc = wgrad_launch<64, 64>(d, tco, tci, taps, splits, ksteps, fold, dy, x, workspace, s);
     if (rc) return rc;
+    *splits_out = splits;
+    return status();
+}
+
+int stp3_conv2d_wgrad(const stp3_conv_dims* p, const void* dy, const void* x, float* dw, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    if (!dw) return STP3_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int splits = 0;
+    int rc = wgrad_partials(p, dy, x, workspace, workspace_bytes, &splits, s);
+    if (rc) return rc;
+    const size_t wsize = (size_t)p->Cout * p->KH * p->KW * p->Cin;
     hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((wsize + 63) / 64)), dim3(256), 0, s, splits, wsize,
                        (const float*)workspace, dw);
+    return status();
+}
+
+int stp3_conv2d_wgrad_partials(const stp3_conv_dims* p, const void* dy, const void* x, void* partials, size_t partials_bytes,
+                               int32_t* splits, void* stream) {
+    if (!splits) return STP3_EINVAL;
+    int n = 0;
+    int rc = wgrad_partials(p, dy, x, partials, partials_bytes, &n, (hipStream_t)stream);
+    if (rc) return rc;
+    *splits = n;
+    return STP3_OK;
+}
+
+int stp3_conv2d_wgrad_reduce_batch(int32_t n, const stp3_wgrad_job* jobs, void* stream) {
+    if (n < 0 || (n > 0 && !jobs)) return STP3_EINVAL;
+    for (int j = 0; j < n; ++j)
+        if (!jobs[j].partials || !jobs[j].dw || jobs[j].splits <= 0 || jobs[j].numel <= 0 || jobs[j].numel >= (1LL << 32))
+            return STP3_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    for (int j0 = 0; j0 < n; j0 += kWgradBatch) {
+        WgradJobs t;
+        t.count = n - j0 < kWgradBatch ? n - j0 : kWgradBatch;
+        int64_t blocks = 0;
+        for (int j = 0; j < t.count; ++j) {
+            const stp3_wgrad_job& q = jobs[j0 + j];
+            t.partial[j] = (const float*)q.partials;
+            t.dw[j] = q.dw;
+            t.n[j] = (unsigned)q.numel;
+            t.splits[j] = q.splits;
+            t.first[j] = (int)blocks;
+            blocks += (q.numel + 63) / 64;
+            if (blocks >= (1LL << 31)) return STP3_EUNSUP;
+        }
+        for (int j = t.count; j <= kWgradBatch; ++j) t.first[j] = (int)blocks;
+        for (int j = t.count; j < kWgradBatch; ++j) { t.partial[j] = nullptr; t.dw[j] = nullptr; t.n[j] = 0; t.splits[j] = 0; }
+        hipLaunchKernelGGL(conv2d_wgrad_reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t);
+    }
     return status();
 }
 

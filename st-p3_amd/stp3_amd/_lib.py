@@ -46,6 +46,12 @@ class DwConvDims(ctypes.Structure):
                                               'dtype')]
 
 
+class WgradJob(ctypes.Structure):
+    """struct stp3_wgrad_job (include/stp3_hip.h)."""
+    _fields_ = [('partials', ctypes.c_void_p), ('dw', ctypes.c_void_p), ('numel', ctypes.c_int64), ('splits', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
+
+
 class LayerNormDims(ctypes.Structure):
     """struct stp3_layernorm_dims (include/stp3_hip.h)."""
     _fields_ = [('rows', ctypes.c_int64), ('C', ctypes.c_int32), ('ldx', ctypes.c_int32), ('ldy', ctypes.c_int32),
@@ -200,6 +206,9 @@ SIGNATURES = {
     'stp3_se_scale': (c_int, [ctypes.POINTER(SeDims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_conv2d_wgrad_workspace': (c_int, [ctypes.POINTER(ConvDims), ctypes.POINTER(c_size_t)]),
     'stp3_conv2d_wgrad': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'stp3_conv2d_wgrad_partials': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_size_t,
+                                           ctypes.POINTER(c_int32), c_void_p]),
+    'stp3_conv2d_wgrad_reduce_batch': (c_int, [c_int32, ctypes.POINTER(WgradJob), c_void_p]),
     'stp3_conv2d_prep_weights': (c_int, [c_void_p, c_int32, ctypes.c_int64, c_void_p]),
     'stp3_se_mlp_fwd': (c_int, [c_void_p] * 9),
     'stp3_se_mlp_bwd': (c_int, [c_void_p] * 15),

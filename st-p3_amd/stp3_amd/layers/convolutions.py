@@ -296,7 +296,10 @@ class Block(nn.Module):
 
     def forward(self, x):
         dw = self.dwconv
-        on_kernels = x.is_cuda and ops.depthwise_supported(x, dw.weight, 1)
+        # (the kernel route is the module's own layer only: 7x7, stride 1, `same` padding, one group per channel)
+        on_kernels = (x.is_cuda and tuple(dw.kernel_size) == (7, 7) and tuple(dw.stride) == (1, 1) and tuple(dw.padding) == (3, 3)
+                      and tuple(dw.dilation) == (1, 1) and dw.groups == x.shape[1] == dw.out_channels
+                      and ops.depthwise_supported(x, dw.weight, 1))
         if on_kernels:
             # the 7x7 depthwise layer on stp3_dwconv2d_* (torch hands it to a naive MIOpen kernel: 1.8 ms forward and
             # 4.3 ms backward per call at 28 x 64 x 200 x 200); channels-last memory, so the (N,H,W,C) view below is free

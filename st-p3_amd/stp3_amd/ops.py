@@ -579,6 +579,13 @@ def depthwise_supported(x, weight, stride):
         return False
     if not ((k in (3, 5) and s[0] in (1, 2)) or (k == 7 and s[0] == 1)):
         return False
+    # the kernels compute in bf16 / float32: float32 tensors under a bf16 autocast are cast by the operator, anything else
+    # (float64 truth runs, fp16) keeps torch's convolution
+    if not (x.dtype in (torch.bfloat16, torch.float32) or
+            (torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16)):
+        return False
+    if torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') != torch.bfloat16:
+        return False
     return x.shape[1] % 8 == 0
 
 
@@ -1165,6 +1172,7 @@ def _conv2d_wgrad(dy, x, wshape, stride, pad, dil, leaf=None):
     dw = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     # a LEAF parameter without a gradient yet, float32, in the memory order of dw: AccumulateGrad keeps the tensor we hand back
     # as the parameter's .grad without launching anything
+    direct = False
     plain_leaf = (leaf is not None and x.is_cuda and leaf.is_leaf and leaf.grad is None and leaf.dtype == torch.float32
                   and tuple(leaf.shape) == tuple(dw.shape) and _same_memory_order(leaf, dw))
     if plain_leaf:
@@ -1179,7 +1187,21 @@ def _conv2d_wgrad(dy, x, wshape, stride, pad, dil, leaf=None):
                 and view.dtype == torch.float32 and _same_memory_order(view, dw)):
             leaf._stp3_grad_claim = task
             dw = view.detach()
+            direct = True
     key = _ws_key(x.device)
+    if direct and DEFER_WGRAD_REDUCE and getattr(leaf, '_stp3_uses', 0) == 1 and _single_process():
+        # nobody reads this gradient before the optimizer: only the split contraction runs now, its partial sums stay in this
+        # layer's slice of the arena, and ``flush_wgrad_reductions`` (GradientBuckets.finish) sums all layers' in one launch
+        arena = _WGRAD_ARENAS.get(key)
+        if arena is None:
+            arena = _WGRAD_ARENAS[key] = _WgradArena(x.device)
+        slot = arena.take(nbytes.value)
+        if slot is not None:
+            splits = ctypes.c_int32()
+            check(lib.stp3_conv2d_wgrad_partials(ctypes.byref(dims), _ptr(dy), _ptr(x), slot, ctypes.c_size_t(nbytes.value),
+                                                 ctypes.byref(splits), _stream()), 'stp3_conv2d_wgrad_partials')
+            arena.jobs.append((slot, dw.data_ptr(), cout * cin * kh * kw, splits.value))
+            return dw
     ws = _CONV_WORKSPACE.get(key)
     if ws is None or ws.numel() < nbytes.value:
         ws = torch.empty(max(nbytes.value, 64 << 20), dtype=torch.uint8, device=x.device)
@@ -1187,6 +1209,76 @@ def _conv2d_wgrad(dy, x, wshape, stride, pad, dil, leaf=None):
     check(lib.stp3_conv2d_wgrad(ctypes.byref(dims), _ptr(dy), _ptr(x), _ptr(dw), _ptr(ws), ctypes.c_size_t(nbytes.value),
                                 _stream()), 'stp3_conv2d_wgrad')
     return dw
+
+
+# The split-K reductions of the weight gradients that go straight into their bucket slice are DEFERRED to one launch at the
+# end of the backward pass (weights applied exactly once since zero_grad -- ``note_weight_use`` --, single process only: with more ranks the bucket hooks all-reduce a bucket as soon as its last
+# gradient lands, so the gradient must be complete when the operator returns).
+DEFER_WGRAD_REDUCE = True
+_WGRAD_ARENAS = {}
+
+
+def note_weight_use(weight):
+    """Called by the forward of every operator that hands ``leaf=weight`` to ``_conv2d_wgrad``: counts the applications of a
+    weight since the last ``GradientBuckets.zero_grad``.  A weight applied more than once in one graph (the GRU cells of the
+    prediction stage, a block re-run under activation recomputation) has its contributions ADDED by the autograd engine as
+    they arrive -- the first one must be complete by then, so only single-use weights may defer their split-K sum."""
+    if weight is not None:
+        weight._stp3_uses = getattr(weight, '_stp3_uses', 0) + 1
+    return weight
+
+
+def _single_process():
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
+class _WgradArena:
+    """Partial sums of the deferred weight gradients of one backward pass: a bump allocator over one device buffer.  A pass that
+    needs more than the buffer holds takes the immediate path for the layers that do not fit and the buffer grows BETWEEN
+    passes (never while partials are live); the same sequence of layers gets the same addresses in every pass, which is what
+    a captured step needs."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+        self.retired = []              # outgrown buffers stay allocated: a captured step may still name their addresses
+        self.used = 0
+        self.wanted = 0
+        self.jobs = []
+
+    def take(self, nbytes):
+        nbytes = (nbytes + 255) // 256 * 256
+        self.wanted += nbytes
+        if self.used + nbytes > self.buf.numel():
+            return None
+        ptr = self.buf.data_ptr() + self.used
+        self.used += nbytes
+        return ptr
+
+    def flush(self):
+        if self.jobs:
+            arr = (_lib.WgradJob * len(self.jobs))()
+            for rec, (partials, dw, numel, splits) in zip(arr, self.jobs):
+                rec.partials, rec.dw, rec.numel, rec.splits = partials, dw, numel, splits
+            check(_lib.lib().stp3_conv2d_wgrad_reduce_batch(len(self.jobs), arr, _stream()), 'stp3_conv2d_wgrad_reduce_batch')
+        grow = self.wanted > self.buf.numel() and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
+        self.jobs, self.used, wanted, self.wanted = [], 0, self.wanted, 0
+        if grow:
+            self.retired.append(self.buf)
+            self.buf = torch.empty(wanted + (wanted >> 3), dtype=torch.uint8, device=self.device)
+
+
+def flush_wgrad_reductions():
+    """Sum the deferred weight-gradient partials of the backward pass that just ran (one launch per device).  Called by
+    ``GradientBuckets.finish``; a no-op when nothing is pending."""
+    for arena in _WGRAD_ARENAS.values():
+        if arena.jobs or arena.wanted:
+            arena.flush()
+
+
+def pending_wgrad_reductions():
+    return sum(len(a.jobs) for a in _WGRAD_ARENAS.values())
 
 
 def _same_memory_order(a, b):
@@ -1493,7 +1585,7 @@ class _Conv2dMfma(torch.autograd.Function):
         wb, _ = _bf16_weights(weight)
         fb = _f32(bias)
         y = _conv2d_launch(x, wb, fb, stride, pad, dil, out_dtype)
-        ctx.weight_ref = weight
+        ctx.weight_ref = note_weight_use(weight)
         ctx.weight_stamp = weight_stamp(weight)
         ctx.save_for_backward(x, wb)
         ctx.cfg = (stride, pad, dil, bias is not None, weight.dtype, None if bias is None else bias.dtype)

@@ -95,7 +95,7 @@ class _ConvBnAct(torch.autograd.Function):
         if ldo != cout:                         # the backward passes read dy with ITS row stride (set there)
             dims = _lib.BnDims(n, ho * wo, cout, cout, cout, ldr, _lib.DTYPE_BF16, act, res_mode, 0, int(osc is not None))
         ctx.cfg = (dims, count, world, group, stride, pad, dil, cbias is not None)
-        ctx.weight_ref = weight
+        ctx.weight_ref = ops.note_weight_use(weight)
         ctx.weight_stamp = ops.weight_stamp(weight)
         ctx.dtypes = (weight.dtype, None if cbias is None else cbias.dtype, None if gamma is None else gamma.dtype,
                       None if beta is None else beta.dtype, None if res is None else res.dtype)
@@ -239,7 +239,7 @@ class _PointwiseBnAct(torch.autograd.Function):
                                         stream), 'stp3_conv2d_fwd_bnact')
         ctx.save_for_backward(x, wb, coef)
         ctx.cfg = (dims, count, world, group, int(act), need.value)
-        ctx.weight_ref = weight
+        ctx.weight_ref = ops.note_weight_use(weight)
         ctx.weight_stamp = ops.weight_stamp(weight)
         ctx.dtypes = (weight.dtype, None if gamma is None else gamma.dtype, None if beta is None else beta.dtype)
         return y

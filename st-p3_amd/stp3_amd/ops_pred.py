@@ -27,8 +27,22 @@ def layer_norm_supported(x, channels):
     times a power of two in 4 .. 64 (the prediction stage: 32 and 64 channels)."""
     if not (x.is_cuda and x.dim() == 4 and x.shape[1] == channels and x.dtype in (torch.bfloat16, torch.float32)):
         return False
-    lanes, rem = divmod(channels, 8 if x.dtype == torch.bfloat16 else 4)
-    return rem == 0 and 4 <= lanes <= 64 and lanes & (lanes - 1) == 0
+    per = 8 if x.dtype == torch.bfloat16 else 4
+    lanes, rem = divmod(channels, per)
+    if not (rem == 0 and 4 <= lanes <= 64 and lanes & (lanes - 1) == 0):
+        return False
+    # rows as the kernel will see them (ops._rows_view keeps a channel slice of a channels-last tensor in place, anything it
+    # cannot use becomes a fresh dense copy): 16-byte aligned, row stride a multiple of the vector width -- otherwise
+    # stp3_layernorm_* answer STP3_EUNSUP and the caller keeps torch's operator
+    n, c, h, w = x.shape
+    if x.is_contiguous(memory_format=torch.channels_last):
+        return x.data_ptr() % 16 == 0
+    sn, sc, sh, sw = x.stride()
+    if c > 1 and sc != 1:
+        return True
+    ld = sw if w > 1 else (sh if h > 1 else (sn if n > 1 else c))
+    in_place = ld >= c and (w == 1 or sw == ld) and (h == 1 or sh == w * ld) and (n == 1 or sn == h * w * ld)
+    return not in_place or (ld % per == 0 and x.data_ptr() % 16 == 0)
 
 
 def _dims(x, ldx, ldy, act, eps):
@@ -134,7 +148,8 @@ def _merged_gate_weights_flipped(wu, wr, wb):
 
 def gru_cell_supported(x, state, conv_update, conv_reset, conv_state_tilde):
     """bf16 (or autocast) GPU tensors, 3x3 / stride 1 / padding 1 gate convolutions with a bias, channel counts multiples of 8."""
-    if not (x.is_cuda and x.dim() == 4 and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled())):
+    bf16_autocast = torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
+    if not (x.is_cuda and x.dim() == 4 and (bf16_autocast or (x.dtype == torch.bfloat16 and not torch.is_autocast_enabled()))):
         return False
     for conv in (conv_update, conv_reset, conv_state_tilde):
         if not (tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
@@ -232,10 +247,13 @@ _GRU_APPLY = ops._fast_apply(_GruCell)
 
 
 def gru_cell(x, state, conv_update, conv_reset, conv_state_tilde, bias_init=0.0):
-    """One convolutional GRU step on the kernels (``gru_cell_supported``): bf16 tensors in, bf16 state out."""
+    """One convolutional GRU step on the kernels (``gru_cell_supported``): computed in bf16, the new state in ``state``'s type."""
     bf = torch.bfloat16
+    state_dtype = state.dtype
     x = x if x.dtype == bf else x.to(bf)
     state = state if state.dtype == bf else state.to(bf)
-    return _GRU_APPLY(x, state, conv_update.weight, conv_update.bias, conv_reset.weight, conv_reset.bias,
-                      conv_state_tilde.weight, conv_state_tilde.bias, (conv_update, conv_reset, conv_state_tilde),
-                      float(bias_init))
+    new_state = _GRU_APPLY(x, state, conv_update.weight, conv_update.bias, conv_reset.weight, conv_reset.bias,
+                           conv_state_tilde.weight, conv_state_tilde.bias, (conv_update, conv_reset, conv_state_tilde),
+                           float(bias_init))
+    # the state leaves in the type it came in (what the torch statement of the cell, layers/temporal._gru_cell, returns)
+    return new_state if state_dtype == bf else new_state.to(state_dtype)

@@ -136,6 +136,11 @@ class GradientBuckets:
                 dist.broadcast(t.data, src=0, group=self.group)
 
     def zero_grad(self):
+        if self.buckets[0][0].is_cuda:
+            from . import ops
+            ops.flush_wgrad_reductions()     # (a backward pass nobody finished: its partial sums must not outlive it)
+        for p in self.params:
+            p._stp3_uses = 0                 # applications of the weight in the coming pass (ops.note_weight_use)
         if self.gather:
             for p in self.params:
                 p.grad = None
@@ -190,6 +195,9 @@ class GradientBuckets:
         if self._finished:
             return
         self._finished = True
+        if self.buckets[0][0].is_cuda:
+            from . import ops
+            ops.flush_wgrad_reductions()     # the deferred split-K sums of the weight gradients: one launch for all layers
         for i in range(len(self.buckets)):
             if not self._launched[i] and (self.gather or self.world > 1):
                 self._launch(i)

@@ -498,6 +498,55 @@ def conv(ops):
     return out
 
 
+def wgrad_defer(ops):
+    """Weight gradients written into their bucket slice, their split-K sums deferred to ONE launch per backward pass
+    (ops.DEFER_WGRAD_REDUCE; stp3_conv2d_wgrad_partials + stp3_conv2d_wgrad_reduce_batch): the flat buckets against the plain
+    route (fresh tensors, reduced at once, gathered), bit for bit.  One weight is applied three times (must NOT defer), one
+    has padded output channels (takes the gather route), and a second pass meets the state the first one left."""
+    import torch.nn as nn
+    from stp3_amd.parallel import GradientBuckets
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Conv2d(16, 32, 3, padding=1, bias=True)
+            self.shared = nn.Conv2d(32, 32, 3, padding=1, bias=False)
+            self.odd = nn.Conv2d(32, 35, 1, bias=False)
+            self.tail = nn.Conv2d(32, 72, 1, bias=False)
+
+        def forward(self, x):
+            h = ops.conv2d(x, self.a.weight, self.a.bias, 1, 1, 1)
+            for _ in range(3):
+                h = torch.relu(ops.conv2d(h, self.shared.weight, None, 1, 1, 1))
+            return ops.conv2d(h, self.odd.weight, None, 1, 0, 1).float().square().mean() + \
+                ops.conv2d(h, self.tail.weight, None, 1, 0, 1).float().square().mean()
+
+    def run(direct, defer):
+        ops.DIRECT_BUCKET_GRADS, ops.DEFER_WGRAD_REDUCE = direct, defer
+        torch.manual_seed(3)
+        model = Net().to(memory_format=torch.channels_last)         # the layout of dw: what the product's models hold
+        buckets = GradientBuckets(model, bucket_bytes=32 << 10)
+        x = torch.randn(2, 16, 9, 20, generator=torch.Generator().manual_seed(9)).to(torch.bfloat16)
+        x = x.contiguous(memory_format=torch.channels_last)
+        flats, pending = [], []
+        for _ in range(2):
+            buckets.zero_grad()
+            model(x).backward()
+            pending.append(ops.pending_wgrad_reductions())
+            buckets.finish()
+            flats.append(torch.cat([f.clone() for f, _ in buckets.buckets]))
+        return flats, pending
+
+    keep = ops.DIRECT_BUCKET_GRADS, ops.DEFER_WGRAD_REDUCE
+    plain, p0 = run(False, False)
+    direct, p1 = run(True, False)
+    deferred, p2 = run(True, True)
+    ops.DIRECT_BUCKET_GRADS, ops.DEFER_WGRAD_REDUCE = keep
+    return {'direct_equal': all(torch.equal(a, b) for a, b in zip(plain, direct)),
+            'deferred_equal': all(torch.equal(a, b) for a, b in zip(plain, deferred)),
+            'nonzero': float(plain[0].abs().max()) > 0, 'pending': [p0, p1, p2], 'left_over': ops.pending_wgrad_reductions()}
+
+
 def fan_out(ops):
     """ops.fan_out: the n gradients of a tensor with n consumers added in one pass (stp3_sum_n) -- against the sum in
     float64; bf16 (float32 accumulation, one rounding: at least as close as the pairwise bf16 additions of autograd) and
@@ -1445,7 +1494,7 @@ def gru_cell(ops):
 
 
 CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_f32_bn_eval, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_rolled, lift_c64_frames, lift_coarse_grid, lift_tall, lift_c64_rows56, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
-                                 conv, conv_f32, fan_out, aspp_join, pointwise_bn, pointwise_stream, decoder_heads, dwconv, layernorm, gru_cell, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
+                                 conv, conv_f32, wgrad_defer, fan_out, aspp_join, pointwise_bn, pointwise_stream, decoder_heads, dwconv, layernorm, gru_cell, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
 
 if __name__ == '__main__':
     ops_mod = setup(sys.argv[1])

@@ -77,7 +77,12 @@ def test_step_runs_and_call_mix(recorder, tmp_path):
     assert calls['stp3_reg_loss_fwd'] == calls['stp3_reg_loss_bwd'] == 3 * STEPS
     assert calls['stp3_warp_nearest'] == STEPS
     # dense convolutions: forward + data gradient launches, one weight-gradient launch per convolution layer
-    assert calls['stp3_conv2d_fwd'] > 200 * STEPS and calls['stp3_conv2d_wgrad'] > 100 * STEPS
+    # (the split-K sum of a leaf weight's gradient is deferred: stp3_conv2d_wgrad_partials per layer, ONE
+    # stp3_conv2d_wgrad_reduce_batch per step; derived weights -- merged heads, folded temporal kernels -- reduce at once)
+    wgrads = calls['stp3_conv2d_wgrad'] + calls['stp3_conv2d_wgrad_partials']
+    assert calls['stp3_conv2d_fwd'] > 200 * STEPS and wgrads > 100 * STEPS
+    # (the first step meets an arena that is too small for all of them: those layers reduce at once, the arena grows after it)
+    assert calls['stp3_conv2d_wgrad_partials'] > 70 and calls['stp3_conv2d_wgrad_reduce_batch'] == STEPS, calls
     # weight shadows: once per newly met layer during the first step, then once per optimizer step -- never per use
     n_layers = calls['stp3_conv2d_prep_weights'] - STEPS
-    assert 0 < n_layers <= calls['stp3_conv2d_wgrad'] // STEPS + 1, (n_layers, calls['stp3_conv2d_wgrad'])
+    assert 0 < n_layers <= wgrads // STEPS + 1, (n_layers, wgrads)
