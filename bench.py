@@ -14,9 +14,9 @@ branches), the configuration the round-1 profiles under profiles/ were taken wit
 weak scaling: every rank gets its own B=4 (global batch 4N), gradients are all-reduced over RCCL
 and BatchNorm statistics are synchronised (the reference's DDP + sync_batchnorm recipe).
 
-On one GPU the step is captured ONCE into a hipGraph and replayed (stp3_amd/graph.py; `--launch eager` launches every kernel
-from Python instead: ~1 900 dispatches and 31-39 ms of host time per step); with more than one rank the step contains RCCL
-collectives and runs eagerly.
+The step is captured ONCE into a hipGraph and replayed (stp3_amd/graph.py; `--launch eager` launches every kernel
+from Python instead: ~1 800 dispatches and 31-39 ms of host time per step); with more than one rank the RCCL collectives of
+the step (BatchNorm statistics exchanges, gradient buckets) are captured with it.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      the voxel-pool forward (stp3_lift_splat_fwd = its two kernels): algorithmic bytes per
@@ -421,8 +421,8 @@ def main():
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-roofline', action='store_true', help='skip the voxel-pool micro-benchmark (profiling runs)')
     ap.add_argument('--launch', choices=('graph', 'eager'), default='graph',
-                    help='graph (one GPU only): the whole step captured once into a hipGraph and replayed (stp3_amd/graph.py); '
-                         'eager: every kernel launched from Python.  More than one rank always runs eager (RCCL collectives)')
+                    help='graph: the whole step -- with its RCCL collectives when there is more than one rank -- captured once into '
+                         'a hipGraph and replayed (stp3_amd/graph.py); eager: every kernel launched from Python')
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='c3',
                     help='c3: BASELINE configs[2] (all losses incl. depth + instance + flow); perception: Perception.yml; '
                          'prediction / planning: the reference\'s Prediction.yml / Planning.yml (rows f2 / f3: own bench legs, '
@@ -491,7 +491,7 @@ def main():
 
     mode = 'eager'
     step = eager_step
-    if args.launch == 'graph' and world == 1 and not DRYRUN:
+    if args.launch == 'graph' and not DRYRUN:
         # Same workload, same kernels, same arithmetic either way (tests/test_graph_step_gpu.py: replays equal eager steps bit
         # for bit) -- so a capture that fails does not take the measurement down: the step is then launched eagerly and the
         # line SAYS so (`config.launch`), with the reason.
@@ -505,7 +505,15 @@ def main():
             module.model.prebuilt_plan = None
         else:
             mode = 'hipgraph'
-
+        if world > 1:
+            # one mode for all ranks (a replaying and an eagerly launching rank would still meet in every collective -- the
+            # sequences are the same -- but the line must describe ONE measurement)
+            ok = torch.tensor([1.0 if mode == 'hipgraph' else 0.0], device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if mode == 'hipgraph' and ok.item() == 0.0:
+                mode = 'eager (hipGraph capture failed on another rank)'
+                module.model.prebuilt_plan = None
+        if mode == 'hipgraph':
             def step():
                 # the FULL per-batch path every step, as the eager step has it: the pose-dependent host work (voxel-pool plan,
                 # label-warp matrices, ego vectors: TrainingModule.prepare_batch) is redone and uploaded, then the replay; only
@@ -580,7 +588,9 @@ def main():
             # share one) and gradient-bucket all-reduces
             'host_enqueue_ms_per_step': round(host_ms, 3),
             'per_rank_ms_per_step': per_rank_ms,
-            'collectives_per_step': {'batchnorm_statistics_all_reduces': exchanges['batchnorm'] // max(args.steps, 1),
+            # (a replayed step issues the collectives it was captured with: counted at the capture)
+            'collectives_per_step': dict(runner.collectives) if mode == 'hipgraph' else
+                                    {'batchnorm_statistics_all_reduces': exchanges['batchnorm'] // max(args.steps, 1),
                                      'gradient_bucket_all_reduces': bucket_reductions // max(args.steps, 1) if world > 1 else 0},
             'roofline_families': fam,
         }

@@ -1,4 +1,4 @@
-"""The training step as ONE hipGraph (single process).
+"""The training step as ONE hipGraph.
 
 A step of BASELINE configs[2] is ~1 900 kernel launches of 5-100 us; launched eagerly the Python side of the step costs
 31-39 ms against 39-40 ms of GPU time: the host is the wall the kernels run into.  Every shape in the
@@ -17,7 +17,18 @@ five index kernels), counts the BatchNorm batch counters, replays.
 
 Semantics kept (reference: stp3/trainer.py:101-172 ``shared_step``, :456-462 Adam, train.py:48 gradient clipping): the
 captured body is ``bench.py``'s eager step, operator for operator; tests/test_graph_step_gpu.py pins the loss trajectory of
-replays against the eager step bit for bit.  With more than one rank the step contains RCCL collectives and stays eager.
+replays against the eager step bit for bit.
+
+More than one rank (train.py:43-56: DDP + sync_batchnorm): the step then contains RCCL collectives -- the BatchNorm statistics
+exchanges on the sequential chain of layers and the gradient-bucket all-reduces issued from the hooks during backward -- and
+they are captured WITH it (RCCL kernels are graph nodes like any other; ``torch.distributed`` enqueues them on its own stream
+and joins it to the capturing stream with events, which the capture records as cross-stream edges).  Nothing in the step
+changes: the same operators issue the same collectives in the same order, so a rank that replays and a rank that (after a
+failed capture) launches eagerly still meet in every collective; ``bench.py`` nevertheless makes the ranks agree on one mode.
+What the capture buys at N > 1 is what it buys at N = 1 -- the 31-39 ms of host work per step disappear -- plus the ~200
+blocking host-side collective calls of the statistics exchanges.  Exercised on hardware with ONE RCCL rank taking the N > 1 code
+path (``ops.FORCE_EXCHANGE``, tests/test_graph_exchange_gpu.py: RCCL refuses two ranks on one device); no multi-GPU node
+was available to any round, so no scaling curve has been measured.
 """
 import torch
 
@@ -56,11 +67,27 @@ class GraphedTrainStep:
                 log(f'graph: eager warm-up {i} done')
         cur.wait_stream(self.stream)
         torch.cuda.synchronize(dev)
+        if buckets.exchange:
+            # The process group's watchdog thread polls the events of the collectives the warm-up steps enqueued until it has
+            # seen them complete (one pass every 100 ms); a poll that lands inside the capture fails with
+            # hipErrorCapturedEvent and takes the process down (3 of 3 runs, profiles/r06c_graph_exchange_capture.txt).  The
+            # device is idle here, so a second is ample for the watchdog to retire everything -- and collectives recorded
+            # DURING a capture are never handed to it.
+            import time
+            time.sleep(1.0)
         ops.flush_batch_counters()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
+        # (with collectives in the step the process group's watchdog thread polls events of EARLIER work while this thread
+        # captures: `relaxed` keeps that legal -- the default mode fails the capture on any such call from any thread; ROCm 7.2
+        # does not start a `thread_local` capture at all: capture_begin trips over an inactive capture status, r06c)
+        mode = 'relaxed' if buckets.exchange else 'global'
+        exchanges0, reductions0 = ops.exchange_counts()['batchnorm'], buckets.reductions_launched
+        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode=mode):
             self.loss = self._body()
         torch.cuda.synchronize(dev)
+        # the collectives ONE replay issues (counted where they were recorded: the host does not see them again)
+        self.collectives = {'batchnorm_statistics_all_reduces': ops.exchange_counts()['batchnorm'] - exchanges0,
+                            'gradient_bucket_all_reduces': buckets.reductions_launched - reductions0}
         # capturing records the kernels, it does not run them: take back what the host counted during the capture pass
         self.counted = ops.pending_batch_counters()            # the BatchNorm layers one step runs in training mode
         ops.discard_pending_batch_counters()

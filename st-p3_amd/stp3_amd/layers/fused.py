@@ -70,7 +70,8 @@ def _sync_world(bn):
         return 1
     if getattr(bn, 'stp3_local_stats', False):
         return 1
-    return dist.get_world_size()
+    world = dist.get_world_size()
+    return 2 if (world == 1 and ops.FORCE_EXCHANGE) else world      # (callers ask "> 1": do the layers exchange?)
 
 
 def _act(act, y):

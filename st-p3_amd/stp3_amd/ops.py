@@ -730,6 +730,23 @@ def _f32(t):
 _EXCHANGES = {'batchnorm': 0}
 
 
+# Tests only: take the cross-replica code path -- split statistics / apply passes with an all-reduce between them, gradient
+# buckets reduced from their hooks -- in a process group of ONE rank.  RCCL refuses two ranks on one device
+# (scripts/probe_nccl_one_gpu.py), so this is how the captured N > 1 step (stp3_amd/graph.py) is exercised on RCCL on the
+# one-GPU boxes the tests run on: every collective is issued (and captured), it just has nobody to talk to.
+FORCE_EXCHANGE = False
+
+
+def replicas(group):
+    """(replicas that share their BatchNorm statistics / gradients, whether exchanges are issued) for process group ``group``
+    (None: the default group; False: this layer keeps local statistics)."""
+    dist = torch.distributed
+    if group is False or not (dist.is_available() and dist.is_initialized()):
+        return 1, False
+    world = dist.get_world_size(group)
+    return world, world > 1 or FORCE_EXCHANGE
+
+
 def exchange_counts(reset=False):
     """How many cross-replica statistics all-reduces the BatchNorm operators have issued (bench.py's N > 1 line)."""
     out = dict(_EXCHANGES)
@@ -827,15 +844,14 @@ class _BnAct(torch.autograd.Function):
         gamma, beta = _f32(weight), _f32(bias)
         sb, osc = _f32(sbias), _f32(oscale)
         stream = _stream_handle()
-        world = 1
+        world, exchange = 1, False
         stat = None
         if training:
             ws, ws_bytes = _bn_workspace(n, c, dev)
             stat = torch.empty(4 * c, dtype=torch.float32, device=dev)       # sum | sum of squares | mean | invstd
             base = stat.data_ptr()
-            if group is not False and torch.distributed.is_available() and torch.distributed.is_initialized():
-                world = torch.distributed.get_world_size(group)
-            if world == 1:
+            world, exchange = replicas(group)
+            if not exchange:
                 check(lib.stp3_bn_fwd_train(ctypes.byref(dims), x.data_ptr(), _opt_ptr(sb), _opt_ptr(res), _opt_ptr(osc),
                                             _opt_ptr(gamma), _opt_ptr(beta), eps, momentum, _opt_ptr(running_mean),
                                             _opt_ptr(running_var), base, ws.data_ptr(), ws_bytes, y.data_ptr(), stream),
@@ -860,7 +876,7 @@ class _BnAct(torch.autograd.Function):
                                         None, 0.0, _opt_ptr(gamma), _opt_ptr(beta), eps, 0.0, running_mean.data_ptr(),
                                         running_var.data_ptr(), None, None, y.data_ptr(), stream), 'stp3_bn_apply_fwd')
         ctx.save_for_backward(x, res if res_mode == RES_BEFORE_ACT else None, sb, osc, gamma, beta, stat)
-        ctx.dims, ctx.training, ctx.count, ctx.world, ctx.group = dims, training, count, world, group
+        ctx.dims, ctx.training, ctx.count, ctx.exchange, ctx.group = dims, training, count, exchange, group
         ctx.res_dtype = None if res is None else res.dtype
         ctx.has_affine = (weight is not None, bias is not None)
         ctx.in_dtypes = (None if weight is None else weight.dtype, None if bias is None else bias.dtype)
@@ -898,7 +914,7 @@ class _BnAct(torch.autograd.Function):
         bdims = dims
         if dims.res_mode == RES_BEFORE_ACT and ctx.needs_input_grad[3]:
             dres = torch.empty((n, cx) + tuple(x.shape[2:]), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
-        simple = ctx.training and ctx.world == 1 and (dres is None or dims.ldr == cx)
+        simple = ctx.training and not ctx.exchange and (dres is None or dims.ldr == cx)
         if simple:
             check(lib.stp3_bn_bwd_train(ctypes.byref(dims), dy.data_ptr(), x.data_ptr(), _opt_ptr(sb), _opt_ptr(res),
                                         _opt_ptr(osc), mean_p, invstd_p, _opt_ptr(gamma), _opt_ptr(beta), ws.data_ptr(),
@@ -913,7 +929,7 @@ class _BnAct(torch.autograd.Function):
                   'stp3_bn_bwd_reduce')
             lsums = sumbuf[sums_off:].view(3, c)
             gsums = lsums
-            if ctx.training and ctx.world > 1:
+            if ctx.training and ctx.exchange:
                 gsums = lsums.clone()
                 yield gsums
             if dres is not None and dims.ldr != cx:
@@ -1229,8 +1245,7 @@ def note_weight_use(weight):
 
 
 def _single_process():
-    import torch.distributed as dist
-    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+    return not replicas(None)[1]
 
 
 class _WgradArena:

@@ -68,10 +68,8 @@ class _ConvBnAct(torch.autograd.Function):
         yc = conv2d_v2(x, wb, ops._f32(cbias), stride, pad, dil, sums_ptr=base)
         n, _, ho, wo = yc.shape
         count = float(n * ho * wo)
-        world = 1
-        if group is not False and torch.distributed.is_available() and torch.distributed.is_initialized():
-            world = torch.distributed.get_world_size(group)
-        if world > 1:
+        world, exchange = ops.replicas(group)
+        if exchange:
             yield stat[:2 * cout]
             count *= world
         ldr = cout
@@ -94,7 +92,7 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.save_for_backward(x, wb, yc, res if res_mode == ops.RES_BEFORE_ACT else None, g32, b32, stat, osc)
         if ldo != cout:                         # the backward passes read dy with ITS row stride (set there)
             dims = _lib.BnDims(n, ho * wo, cout, cout, cout, ldr, _lib.DTYPE_BF16, act, res_mode, 0, int(osc is not None))
-        ctx.cfg = (dims, count, world, group, stride, pad, dil, cbias is not None)
+        ctx.cfg = (dims, count, exchange, group, stride, pad, dil, cbias is not None)
         ctx.weight_ref = ops.note_weight_use(weight)
         ctx.weight_stamp = ops.weight_stamp(weight)
         ctx.dtypes = (weight.dtype, None if cbias is None else cbias.dtype, None if gamma is None else gamma.dtype,
@@ -105,7 +103,7 @@ class _ConvBnAct(torch.autograd.Function):
     def backward_steps(ctx, dy):
         x, wb, yc, res, g32, b32, stat, osc = ctx.saved_tensors
         ops.check_weight_stamp(ctx.weight_ref, ctx.weight_stamp, 'conv_bn_act backward')
-        dims, count, world, group, stride, pad, dil, has_cbias = ctx.cfg
+        dims, count, exchange, group, stride, pad, dil, has_cbias = ctx.cfg
         wdt, cbdt, gdt, bdt, rdt = ctx.dtypes
         n, rows, c = dims.N, dims.rows, dims.C
         dev = x.device
@@ -143,7 +141,7 @@ class _ConvBnAct(torch.autograd.Function):
                                      sumbuf.data_ptr(), sumbuf.data_ptr() + 4 * sums_off, stream), 'stp3_bn_bwd_reduce')
         lsums = sumbuf[sums_off:].view(3, c)
         gsums = lsums
-        if world > 1:
+        if exchange:
             gsums = lsums.clone()
             yield gsums
         check(lib.stp3_bn_apply_bwd(ctypes.byref(dims), dy.data_ptr(), yc.data_ptr(), None, ops._opt_ptr(res), ops._opt_ptr(osc), mean_p,
@@ -223,10 +221,8 @@ class _PointwiseBnAct(torch.autograd.Function):
         check(lib.stp3_conv2d_fwd_stats(ctypes.byref(dims), x.data_ptr(), wb.data_ptr(), stat.data_ptr(), ws.data_ptr(),
                                         need.value, stream), 'stp3_conv2d_fwd_stats')
         count = float(n * h * w)
-        world = 1
-        if group is not False and torch.distributed.is_available() and torch.distributed.is_initialized():
-            world = torch.distributed.get_world_size(group)
-        if world > 1:
+        world, exchange = ops.replicas(group)
+        if exchange:
             yield stat[:2 * cout]
             count *= world
         g32, b32 = ops._f32(gamma), ops._f32(beta)
@@ -238,7 +234,7 @@ class _PointwiseBnAct(torch.autograd.Function):
         check(lib.stp3_conv2d_fwd_bnact(ctypes.byref(dims), x.data_ptr(), wb.data_ptr(), coef.data_ptr(), int(act), y.data_ptr(),
                                         stream), 'stp3_conv2d_fwd_bnact')
         ctx.save_for_backward(x, wb, coef)
-        ctx.cfg = (dims, count, world, group, int(act), need.value)
+        ctx.cfg = (dims, count, exchange, group, int(act), need.value)
         ctx.weight_ref = ops.note_weight_use(weight)
         ctx.weight_stamp = ops.weight_stamp(weight)
         ctx.dtypes = (weight.dtype, None if gamma is None else gamma.dtype, None if beta is None else beta.dtype)
@@ -248,7 +244,7 @@ class _PointwiseBnAct(torch.autograd.Function):
     def backward_steps(ctx, dz):
         x, wb, coef = ctx.saved_tensors
         ops.check_weight_stamp(ctx.weight_ref, ctx.weight_stamp, 'pointwise_bn_act backward')
-        dims, count, world, group, act, ws_bytes = ctx.cfg
+        dims, count, exchange, group, act, ws_bytes = ctx.cfg
         wdt, gdt, bdt = ctx.dtypes
         cout, cin = wb.shape[:2]
         dev = x.device
@@ -264,7 +260,7 @@ class _PointwiseBnAct(torch.autograd.Function):
         check(lib.stp3_conv2d_bn_bwd_reduce(ctypes.byref(dims), x.data_ptr(), wb.data_ptr(), dz.data_ptr(), ldz, coef.data_ptr(),
                                             act, lsums.data_ptr(), ws.data_ptr(), ws_bytes, stream), 'stp3_conv2d_bn_bwd_reduce')
         gsums = lsums
-        if world > 1:
+        if exchange:
             gsums = lsums.clone()
             yield gsums
         dconv = torch.empty((dims.N, cout, dims.H, dims.W), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
@@ -599,10 +595,8 @@ class _DwBnSe(torch.autograd.Function):
         check(lib.stp3_dwconv2d_fwd_stats(ctypes.byref(dwd), x.data_ptr(), wt.data_ptr(), e2.data_ptr(), stat.data_ptr(),
                                           ws.data_ptr(), ws_bytes, stream), 'stp3_dwconv2d_fwd_stats')
         count = float(n * ho * wo)
-        world = 1
-        if group is not False and torch.distributed.is_available() and torch.distributed.is_initialized():
-            world = torch.distributed.get_world_size(group)
-        if world > 1:
+        world, exchange = ops.replicas(group)
+        if exchange:
             torch.distributed.all_reduce(stat[:2 * c], group=group)
             ops._EXCHANGES['batchnorm'] += 1
             count *= world
@@ -626,7 +620,7 @@ class _DwBnSe(torch.autograd.Function):
         check(lib.stp3_mbconv_scale_act(ctypes.byref(sd), c, e2.data_ptr(), scale_p, shift_p, ops.ACT_SWISH, gate.data_ptr(),
                                         a.data_ptr(), stream), 'stp3_mbconv_scale_act')
         ctx.save_for_backward(x, wt, e2, coef, gate, pooled_sum, z1, w1f, w2f)
-        ctx.cfg = (dwd, sd, md, count, world, group, ws_bytes)
+        ctx.cfg = (dwd, sd, md, count, exchange, group, ws_bytes)
         ctx.meta = (dw_weight.shape, dw_weight.dtype, None if gamma is None else gamma.dtype,
                     None if beta is None else beta.dtype, w1.shape, w2.shape, w1.dtype, b1.dtype, w2.dtype, b2.dtype)
         return a
@@ -634,7 +628,7 @@ class _DwBnSe(torch.autograd.Function):
     @staticmethod
     def backward(ctx, da):
         x, wt, e2, coef, gate, pooled_sum, z1, w1f, w2f = ctx.saved_tensors
-        dwd, sd, md, count, world, group, ws_bytes = ctx.cfg
+        dwd, sd, md, count, exchange, group, ws_bytes = ctx.cfg
         wshape, wdt, gdt, bdt, w1s, w2s, w1d, b1d, w2d, b2d = ctx.meta
         lib = _lib.lib()
         dev = x.device
@@ -659,7 +653,7 @@ class _DwBnSe(torch.autograd.Function):
         check(lib.stp3_mbconv_bwd_coef(n, c, sums5.data_ptr(), gate.data_ptr(), dpooled.data_ptr(), lsums.data_ptr(), stream),
               'stp3_mbconv_bwd_coef')
         gsums = lsums
-        if world > 1:
+        if exchange:
             gsums = lsums.clone()
             torch.distributed.all_reduce(gsums, group=group)
             ops._EXCHANGES['batchnorm'] += 1

@@ -74,6 +74,9 @@ class GradientBuckets:
         self.reductions_launched = 0                     # gradient-bucket all-reduces issued so far (bench.py's N > 1 line)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        from . import ops
+        # buckets reduced from their hooks: more than one rank (or the one-rank exercise of that path, ops.FORCE_EXCHANGE)
+        self.exchange = self.world > 1 or (dist.is_initialized() and ops.FORCE_EXCHANGE)
         self.average = average
         params = [p for p in module.parameters() if p.requires_grad]
         self.params = params[::-1]                       # backward order
@@ -96,7 +99,7 @@ class GradientBuckets:
         self._finished = False
         self._works = []
         self._hooks = []
-        if self.world > 1:
+        if self.exchange:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.broadcast_parameters(module)
@@ -177,7 +180,7 @@ class GradientBuckets:
         self._launched[i] = True
         if self.gather:
             self._gather(i)
-        if self.world > 1:
+        if self.exchange:
             flat = self.buckets[i][0]
             self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.reductions_launched += 1
@@ -199,9 +202,9 @@ class GradientBuckets:
             from . import ops
             ops.flush_wgrad_reductions()     # the deferred split-K sums of the weight gradients: one launch for all layers
         for i in range(len(self.buckets)):
-            if not self._launched[i] and (self.gather or self.world > 1):
+            if not self._launched[i] and (self.gather or self.exchange):
                 self._launch(i)
-        if self.world == 1:
+        if not self.exchange:
             return
         for w in self._works:
             w.wait()
