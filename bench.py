@@ -423,6 +423,10 @@ def main():
     ap.add_argument('--launch', choices=('graph', 'eager'), default='graph',
                     help='graph: the whole step -- with its RCCL collectives when there is more than one rank -- captured once into '
                          'a hipGraph and replayed (stp3_amd/graph.py); eager: every kernel launched from Python')
+    ap.add_argument('--force-exchange', action='store_true',
+                    help='diagnostic, one GPU: run the N > 1 form of the step (BatchNorm statistics exchanges, bucket all-reduces '
+                         'from the hooks) in a process group of ONE RCCL rank -- what a rank of a multi-GPU job executes, minus '
+                         'the wire; reported in config.parallelism')
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='c3',
                     help='c3: BASELINE configs[2] (all losses incl. depth + instance + flow); perception: Perception.yml; '
                          'prediction / planning: the reference\'s Prediction.yml / Planning.yml (rows f2 / f3: own bench legs, '
@@ -446,6 +450,16 @@ def main():
     from stp3_amd.parallel import FlatAdam, GradientBuckets, init_distributed
     rank, world, local = init_distributed()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if args.force_exchange:
+        assert world == 1 and not DRYRUN, '--force-exchange is the one-GPU exercise of the N > 1 code path'
+        import socket
+        from stp3_amd import ops as _ops_fx
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(sock.getsockname()[1]))
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', rank=0, world_size=1)
+        _ops_fx.FORCE_EXCHANGE = True
     device = torch.device('cpu') if DRYRUN else torch.device('cuda', local)
     if not DRYRUN:
         torch.cuda.set_device(device)
@@ -579,7 +593,9 @@ def main():
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16 convs / f32 voxel pool', 'data': 'synthetic',
             'config': {'workload': WORKLOADS[workload].replace('batch=4/GPU', f'batch={args.batch}/GPU'),
-                       'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'launch': mode,
+                       'global_batch': args.batch * world,
+                       'parallelism': f'dp{world}' + (' (N > 1 code path forced on one RCCL rank: --force-exchange)' if args.force_exchange else ''),
+                       'launch': mode,
                        'host_options': host_options},
             'roofline': roof,
             'kernel_ms': kernel_ms,
@@ -605,6 +621,7 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.barrier()              # rank 0 may still be in its roofline micro-benchmark: leave together
+    if world > 1 or args.force_exchange:
         dist.destroy_process_group()
 
 

@@ -491,6 +491,60 @@ __global__ __launch_bounds__(256) void dwconv_stat_reduce_kernel(int nblocks, in
     if (bl == 0 && i < n) sums[i] = (float)red[il];
 }
 
+// The same sums AND what stp3_bn_finalize makes of them, in one launch (single process: nothing happens between the two).  A
+// workgroup owns 4 channels -- its 8 columns are (sum, sum of squares) of those channels, each column added in the order of
+// dwconv_stat_reduce_kernel (same bits) -- and its first four threads finish them with bn_finalize_kernel's arithmetic
+// (stp3_mbconv.hip: same bits again): coef = scale | shift | mean | invstd, running statistics updated.
+struct BnFin {
+    float inv_count, unbias, eps, momentum;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    float* coef;
+};
+__global__ __launch_bounds__(256) void dwconv_stat_reduce_finalize_kernel(int nblocks, int C, const float* __restrict__ partial,
+                                                                          float* __restrict__ sums, BnFin f) {
+    __shared__ double red[256];
+    const int il = threadIdx.x % kRedCols, bl = threadIdx.x / kRedCols;
+    const int c = blockIdx.x * (kRedCols / 2) + (il & 3), k = il >> 2;
+    const int n = 2 * C;
+    const int i = k * C + c;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (c < C) {
+        const float* src = partial + i;
+        int b = bl;
+        for (; b + 3 * kRedLanes < nblocks; b += 4 * kRedLanes) {
+            const float a = src[(int64_t)b * n], cc = src[(int64_t)(b + kRedLanes) * n];
+            const float e = src[(int64_t)(b + 2 * kRedLanes) * n], g = src[(int64_t)(b + 3 * kRedLanes) * n];
+            s0 += (double)a; s1 += (double)cc; s2 += (double)e; s3 += (double)g;
+        }
+        for (; b < nblocks; b += kRedLanes) s0 += (double)src[(int64_t)b * n];
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    for (int st = kRedLanes / 2; st > 0; st >>= 1) {
+        if (bl < st) red[threadIdx.x] += red[threadIdx.x + st * kRedCols];
+        __syncthreads();
+    }
+    if (bl == 0 && c < C) sums[i] = (float)red[il];
+    if (threadIdx.x < 4 && c < C) {                       // il = channel slot, k = 0: both columns of the channel are in red[]
+        const float sum = (float)red[il], sq = (float)red[4 + il];
+        const float mean = sum * f.inv_count;
+        const float var = fmaxf(sq * f.inv_count - mean * mean, 0.f);
+        const float invstd = 1.0f / sqrtf(var + f.eps);
+        const float scale = (f.gamma ? f.gamma[c] : 1.f) * invstd;
+        f.coef[c] = scale;
+        f.coef[C + c] = (f.beta ? f.beta[c] : 0.f) - mean * scale;
+        f.coef[2 * C + c] = mean;
+        f.coef[3 * C + c] = invstd;
+        if (f.running_mean) {
+            f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * mean;
+            f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * var * f.unbias;
+        }
+    }
+}
+
 constexpr int kStatBlocks = 2048;
 constexpr int kWgradBlocks = 512;
 
@@ -563,7 +617,8 @@ int launch_fwd(const DwDims& d, const void* x, const float* w, const float* bias
     return status();
 }
 template <typename T, int K, int S>
-int launch_fwd_stats(const DwDims& d, const void* x, const float* w, void* y, float* sums, float* ws, hipStream_t s) {
+int launch_fwd_stats(const DwDims& d, const void* x, const float* w, void* y, float* sums, float* ws, hipStream_t s,
+                     const BnFin* fin = nullptr) {
     constexpr int VN = Vec<T>::N;
     const int CV = d.C / VN;
     const int CVB = CV < 256 ? CV : 256;
@@ -583,7 +638,11 @@ int launch_fwd_stats(const DwDims& d, const void* x, const float* w, void* y, fl
         hipLaunchKernelGGL((dwconv_fwd_stats_kernel<T, K, S, uint32_t>), dim3(bx, by), dim3(256), lds, s, d, (const T*)x, w, (T*)y, ws);
     else
         hipLaunchKernelGGL((dwconv_fwd_stats_kernel<T, K, S, uint64_t>), dim3(bx, by), dim3(256), lds, s, d, (const T*)x, w, (T*)y, ws);
-    hipLaunchKernelGGL(dwconv_stat_reduce_kernel, dim3((2 * d.C + kRedCols - 1) / kRedCols), dim3(256), 0, s, bx, 2 * d.C, ws, sums);
+    if (fin)
+        hipLaunchKernelGGL(dwconv_stat_reduce_finalize_kernel, dim3((d.C + kRedCols / 2 - 1) / (kRedCols / 2)), dim3(256), 0, s, bx,
+                           d.C, ws, sums, *fin);
+    else
+        hipLaunchKernelGGL(dwconv_stat_reduce_kernel, dim3((2 * d.C + kRedCols - 1) / kRedCols), dim3(256), 0, s, bx, 2 * d.C, ws, sums);
     return status();
 }
 template <typename T, int K, int S>
@@ -696,6 +755,23 @@ int stp3_dwconv2d_fwd_stats(const stp3_dwconv_dims* p, const void* x, const floa
     if (!x || !w || !y || !sums || !workspace) return STP3_EINVAL;
     if (workspace_bytes < (size_t)kStatBlocks * 2 * p->C * sizeof(float)) return STP3_ENOSPACE;
     DISPATCH(launch_fwd_stats, d, x, w, y, sums, (float*)workspace, (hipStream_t)stream);
+}
+
+int stp3_dwconv2d_fwd_stats_bn(const stp3_dwconv_dims* p, const void* x, const float* w, void* y, float* sums, double count,
+                               const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                               float* running_var, float* coef, void* workspace, size_t workspace_bytes, void* stream) {
+    DwDims d; int vec;
+    int rc = check(p, &d, &vec);
+    if (rc) return rc;
+    if (!x || !w || !y || !sums || !coef || !workspace || !(count >= 1.0)) return STP3_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return STP3_EINVAL;
+    if (workspace_bytes < (size_t)kStatBlocks * 2 * p->C * sizeof(float)) return STP3_ENOSPACE;
+    BnFin fin;
+    fin.inv_count = (float)(1.0 / count);
+    fin.unbias = count > 1.0 ? (float)(count / (count - 1.0)) : 1.f;
+    fin.eps = eps; fin.momentum = momentum; fin.gamma = gamma; fin.beta = beta;
+    fin.running_mean = running_mean; fin.running_var = running_var; fin.coef = coef;
+    DISPATCH(launch_fwd_stats, d, x, w, y, sums, (float*)workspace, (hipStream_t)stream, &fin);
 }
 
 int stp3_dwconv2d_bwd_data(const stp3_dwconv_dims* p, const void* dy, const float* w, void* dx, void* stream) {

@@ -164,7 +164,7 @@ def bn_act_reference(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=Non
 flush_batch_counters = ops.flush_batch_counters          # re-export (parallel.FlatAdam, tests)
 
 
-def bn_act(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=None):
+def bn_act(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=None, out_slot=None):
     """y = act(bn(x + sbias) [+ res if BEFORE_ACT]) * oscale [+ res if AFTER_ACT].
 
     ``bn``: the nn.BatchNorm2d / nn.BatchNorm3d / nn.SyncBatchNorm module (its forward is not called);
@@ -184,17 +184,24 @@ def bn_act(bn, x, act=ACT_NONE, res=None, res_mode=RES_NONE, sbias=None, oscale=
         b, c, t = x.shape[:3]
         y = bn_act(bn, x.permute(0, 2, 1, 3, 4).reshape(b * t, c, 1, 1), act)
         return y.view(b, t, c, 1, 1).permute(0, 2, 1, 3, 4)
-    args = _kernel_args(bn, x, act, res, res_mode, sbias, oscale)
+    args = _kernel_args(bn, x, act, res, res_mode, sbias, oscale, out_slot)
     if args is None:
         # CPU tensors, and float64 on any device: the library has float32 / bf16 kernels only; a float64 evaluation (the
         # noise-free truth of the parity tests) takes the torch statement
+        assert out_slot is None, 'an output slot needs the kernel route (see slot_ok)'
         return bn_act_reference(bn, x, act, res, res_mode, sbias, oscale)
-    x, weight, bias, res, sbias, oscale, rmean, rvar, training, momentum, eps, act, res_mode, group, channels = args
+    x, weight, bias, res, sbias, oscale, rmean, rvar, training, momentum, eps, act, res_mode, group, channels, out_slot = args
     return _emu(ops.bn_act(x, weight, bias, rmean, rvar, training, momentum, eps, act=act, res=res, res_mode=res_mode, sbias=sbias,
-                           oscale=oscale, group=group, channels=channels))
+                           oscale=oscale, group=group, channels=channels, out_slot=out_slot))
 
 
-def _kernel_args(bn, x, act, res, res_mode, sbias, oscale):
+def slot_ok(x):
+    """May a ``bn_act`` of ``x`` write into an output slot?  Only where the kernel route runs and returns its own tensor: a bf16
+    4-D GPU tensor (float32 under EMULATE_BF16 comes back rounded -- a new tensor -- and CPU / float64 take the statement)."""
+    return x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16
+
+
+def _kernel_args(bn, x, act, res, res_mode, sbias, oscale, out_slot=None):
     """Positional arguments of ``ops._BnAct`` for this layer, or None when the tensor takes the statement route."""
     if not (x.is_cuda and x.dim() == 4) or x.dtype == torch.float64:
         return None
@@ -211,7 +218,7 @@ def _kernel_args(bn, x, act, res, res_mode, sbias, oscale):
     return (x, bn.weight, bn.bias, res, sbias, oscale, bn.running_mean if bn.track_running_stats else None,
             bn.running_var if bn.track_running_stats else None, bool(training),
             ops.bn_momentum(bn), float(bn.eps), int(act), int(res_mode), group,
-            bn.num_features if x.shape[1] != bn.num_features else None)
+            bn.num_features if x.shape[1] != bn.num_features else None, out_slot)
 
 
 def bn_act_group(items):
@@ -222,13 +229,13 @@ def bn_act_group(items):
     ('conv_bn_act', args) pair prepared by ``conv_bn_act_member``.  Single-process runs take the ordinary operators."""
     def norm(it):
         return (it['bn'], it['x'], it.get('act', ACT_NONE), it.get('res'), it.get('res_mode', RES_NONE) if it.get('res') is not None
-                else RES_NONE, it.get('sbias'), it.get('oscale'))
+                else RES_NONE, it.get('sbias'), it.get('oscale'), it.get('out_slot'))
     first = items[0]
     bn0 = first['bn'] if isinstance(first, dict) else first[2]
     if _sync_world(bn0) <= 1:
         return [_run_member(it) for it in items]
     if all(isinstance(it, dict) and _takes_statement(it['x']) for it in items):
-        return _drive_reference([_reference_member(*norm(it)) for it in items])
+        return _drive_reference([_reference_member(*norm(it)[:7]) for it in items])
     from .. import ops_fused
     members = []
     for it in items:
@@ -249,7 +256,7 @@ def _takes_statement(x):
 def _run_member(it):
     if isinstance(it, dict):
         return bn_act(it['bn'], it['x'], it.get('act', ACT_NONE), it.get('res'), it.get('res_mode', RES_NONE), it.get('sbias'),
-                      it.get('oscale'))
+                      it.get('oscale'), it.get('out_slot'))
     from .. import ops_fused
     return ops_fused._ConvBnAct.apply(*it[1])
 

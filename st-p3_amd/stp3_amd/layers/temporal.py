@@ -16,7 +16,8 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..utils import hp
-from .fused import ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, bn_act_group, conv1x1_on_vector, conv2d, plane_mean, pooled_bias
+from .fused import (ACT_NONE, ACT_RELU, RES_AFTER_ACT, bn_act, bn_act_group, conv1x1_on_vector, conv2d, plane_mean, pooled_bias,
+                    slot_ok)
 
 
 def _pad8(c):
@@ -60,10 +61,10 @@ def _conv2d_padded_channels(x, weight, padding=0):
     return y[:, :co] if cop != co else y
 
 
-def _bn_act_2d(norm, x, relu=True, res=None, sbias=None):
+def _bn_act_2d(norm, x, relu=True, res=None, sbias=None, out_slot=None):
     """BatchNorm3d over (B,C,T,H,W) == batch norm over (B*T,C,H,W): apply the 3-D module's statistics
     and affine parameters to the frame-folded 4-D tensor (fused with the ReLU / skip add)."""
-    return bn_act(norm, x, ACT_RELU if relu else ACT_NONE, res=res, res_mode=RES_AFTER_ACT, sbias=sbias)
+    return bn_act(norm, x, ACT_RELU if relu else ACT_NONE, res=res, res_mode=RES_AFTER_ACT, sbias=sbias, out_slot=out_slot)
 
 
 class CausalConv3d(nn.Module):
@@ -88,7 +89,7 @@ class CausalConv3d(nn.Module):
         x = F.conv3d(x, self.conv.weight, self.conv.bias, 1, self._hw_pad, self.conv.dilation)
         return self.activation(self.norm(x))
 
-    def forward_folded(self, x2, batch, frames):
+    def forward_folded(self, x2, batch, frames, out_slot=None):
         """Same layer on the frame-folded tensor x2 (B*T, C, H, W).  A causal (2,3,3) convolution is
         y[t] = W[:, :, 0] * x[t-1] + W[:, :, 1] * x[t] with x[-1] = 0, i.e. ONE 2-D 3x3 convolution over
         the channel pairing [x[t-1], x[t]] (one kernel pass: ``ops.causal_pair``); a (1,3,3) convolution is a per-frame
@@ -114,7 +115,7 @@ class CausalConv3d(nn.Module):
         if x2.is_cuda:
             w2 = _pad_out(w2, _pad8(w2.shape[0]))
         y = _conv2d_padded_channels(x2, w2, padding=self._hw_pad[1:])
-        return _bn_act_2d(self.norm, y)
+        return _bn_act_2d(self.norm, y, out_slot=out_slot)
 
 
 def conv_1x1x1_norm_activated(in_channels, out_channels):
@@ -280,6 +281,14 @@ class TemporalBlock(nn.Module):
                  for path, xi in zip(self.convolution_paths[:-1], xs)]
         k = len(heads)
         heads.append(self._pointwise_member(self.convolution_paths[-1], xs[k], extra2=extra2, lanes=lanes))
+        # The three path outputs are WRITTEN into the channel slices of one buffer (the aggregation's operand) instead of being
+        # concatenated: two concatenations of 3 x (12, 40 | 32, 200, 200) per step, 98 + 76 us (profiles/r05last_step_trace.txt)
+        joined = None
+        if slot_ok(heads[k]['x']) and heads[k]['x'].shape[1] == lanes:
+            from .. import ops_fused
+            joined = torch.empty((b * t, (k + 1) * lanes, h, w), dtype=heads[k]['x'].dtype, device=x2.device,
+                                 memory_format=torch.channels_last)
+            heads[k]['out_slot'] = (joined, k * lanes)
         if self.projection is not None:
             heads.append(self._pointwise_member(self.projection, xs[k + 1], relu=False, extra2=extra2))
         x_skip = xs[k + 1]                                               # (only used when there is no projection)
@@ -291,9 +300,10 @@ class TemporalBlock(nn.Module):
         heads = bn_act_group(heads)
         pooled_outs = None if pooled_group is None else [fin(o) for fin, o in zip(pooled_group[1], heads[n_pointwise:])]
         heads = heads[:n_pointwise]
-        outs = [path[1].forward_folded(y, b, t) for path, y in zip(self.convolution_paths[:-1], heads)]
+        outs = [path[1].forward_folded(y, b, t, out_slot=None if joined is None else (joined, i * lanes))
+                for i, (path, y) in enumerate(zip(self.convolution_paths[:-1], heads))]
         outs.append(heads[len(self.convolution_paths) - 1])
-        paths = torch.cat(outs, dim=1)
+        paths = torch.cat(outs, dim=1) if joined is None else ops_fused.join_slices(joined, outs)
         agg = self.aggregation[0]
         wgt = agg.conv.weight.squeeze(2)                                 # (Cout, Cin_total, 1, 1)
         # the paths' columns and one run of columns per pooled tensor: ONE split (its backward is one concatenation)

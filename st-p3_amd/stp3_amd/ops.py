@@ -801,9 +801,9 @@ class _BnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, res, sbias, oscale, running_mean, running_var, training, momentum, eps,
-                act, res_mode, group, channels=None):
+                act, res_mode, group, channels=None, out_slot=None):
         return drive_exchange(_BnAct.forward_steps(ctx, x, weight, bias, res, sbias, oscale, running_mean, running_var,
-                                                   training, momentum, eps, act, res_mode, group, channels), group)
+                                                   training, momentum, eps, act, res_mode, group, channels, out_slot), group)
 
     @staticmethod
     def backward(ctx, dy):
@@ -811,8 +811,10 @@ class _BnAct(torch.autograd.Function):
 
     @staticmethod
     def forward_steps(ctx, x, weight, bias, res, sbias, oscale, running_mean, running_var, training, momentum, eps,
-                      act, res_mode, group, channels=None):
-        """``forward`` as a generator: yields the [2C] statistics buffer when it has to be summed over the replicas."""
+                      act, res_mode, group, channels=None, out_slot=None):
+        """``forward`` as a generator: yields the [2C] statistics buffer when it has to be summed over the replicas.
+        ``out_slot`` = (buffer, first channel): the result is written into that channel slice of a wider channels-last
+        buffer (``ops_fused.join_slices`` then IS the concatenation of the layers that filled it: no copy)."""
         _need_gpu(x)
         if x.dtype == torch.bfloat16:
             dt = _lib.DTYPE_BF16
@@ -838,8 +840,11 @@ class _BnAct(torch.autograd.Function):
             res, ldr = _rows_view(res if res.dtype == x.dtype else res.to(x.dtype))
         else:
             res_mode = RES_NONE
-        y = torch.empty((n, cx, h, w), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
-        dims = _lib.BnDims(n, h * w, c, ldx, cx, ldr, dt, act, res_mode, sbias is not None, oscale is not None, cpad)
+        if out_slot is None:
+            y, ldy = torch.empty((n, cx, h, w), dtype=x.dtype, device=dev, memory_format=torch.channels_last), cx
+        else:
+            y, ldy = slot_view(out_slot, x)
+        dims = _lib.BnDims(n, h * w, c, ldx, ldy, ldr, dt, act, res_mode, sbias is not None, oscale is not None, cpad)
         lib = _lib.lib()
         gamma, beta = _f32(weight), _f32(bias)
         sb, osc = _f32(sbias), _f32(oscale)
@@ -958,14 +963,24 @@ class _BnAct(torch.autograd.Function):
             check(lib.stp3_bn_dsbias(n, c, rows, sumbuf.data_ptr(), gsums.data_ptr() if ctx.training else None,
                                      max(ctx.count, 1.0), _opt_ptr(gamma), stat.data_ptr() + 12 * c, dsbias.data_ptr(), stream),
                   'stp3_bn_dsbias')
-        return dx, dgamma, dbeta, dres, dsbias, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, dsbias, None, None, None, None, None, None, None, None, None, None, None
 
 
 _BN_APPLY = _fast_apply(_BnAct)
 
 
+def slot_view(out_slot, like):
+    """(channel-slice view of the slot's buffer for a result shaped like ``like``, row stride of the buffer)."""
+    buf, c0 = out_slot
+    n, c, h, w = like.shape
+    if not (buf.is_contiguous(memory_format=torch.channels_last) and buf.shape[0] == n and tuple(buf.shape[2:]) == (h, w)
+            and buf.dtype == like.dtype and c0 % 8 == 0 and c0 + c <= buf.shape[1]):
+        raise _lib.Stp3HipError('output slot does not fit the result (shape / dtype / channels-last / 16-byte channel offset)')
+    return buf[:, c0:c0 + c], buf.shape[1]
+
+
 def bn_act(x, weight, bias, running_mean, running_var, training, momentum, eps, act=ACT_NONE, res=None,
-           res_mode=RES_NONE, sbias=None, oscale=None, group=None, channels=None):
+           res_mode=RES_NONE, sbias=None, oscale=None, group=None, channels=None, out_slot=None):
     """Fused BatchNorm + activation (+ residual) through the HIP kernels (GPU tensors only).
     ``group=False`` disables the cross-replica statistics even when torch.distributed is initialised.
     ``channels``: the BatchNorm's channel count when x (and res) carry rows zero-padded to a multiple of 8 lanes
@@ -974,7 +989,7 @@ def bn_act(x, weight, bias, running_mean, running_var, training, momentum, eps, 
         res_mode = RES_NONE
     return _BN_APPLY(x, weight, bias, res, sbias, oscale, running_mean, running_var, bool(training),
                         float(momentum if momentum is not None else 0.1), float(eps), int(act), int(res_mode), group,
-                        channels)
+                        channels, out_slot)
 
 
 class _FanOut(torch.autograd.Function):

@@ -32,7 +32,7 @@ def _conv_label(args):
             f' {d.Cin}->{d.Cout} @{d.Ho}x{d.Wo} x{d.N}')
 
 
-LABEL = {'stp3_conv2d_fwd': _conv_label, 'stp3_conv2d_wgrad': _conv_label}
+LABEL = {'stp3_conv2d_fwd': _conv_label, 'stp3_conv2d_wgrad': _conv_label, 'stp3_conv2d_wgrad_partials': _conv_label}
 
 
 def _bn_bytes(tensors):
@@ -64,6 +64,8 @@ def _se_pool_bytes(args):
 WORK = {
     'stp3_conv2d_fwd': ('conv_fwd_dgrad', _conv_flops),
     'stp3_conv2d_wgrad': ('conv_wgrad', _conv_flops),
+    'stp3_conv2d_wgrad_partials': ('conv_wgrad', _conv_flops),              # (the split contraction: all of the layer's flops)
+    'stp3_conv2d_wgrad_reduce_batch': ('conv_wgrad', lambda args: 0.0),     # (their deferred sums, one launch per pass: time only)
     'stp3_bn_stats': ('batchnorm', _bn_bytes(1)),
     'stp3_bn_apply_fwd': ('batchnorm', _bn_bytes(2)),
     'stp3_bn_fwd_train': ('batchnorm', _bn_bytes(2)),          # statistics + apply over the same x: x is compulsory once
@@ -72,14 +74,17 @@ WORK = {
     'stp3_bn_bwd_train': ('batchnorm', _bn_bytes(3)),
     'stp3_dwconv2d_fwd': ('depthwise', _dw_bytes),
     'stp3_dwconv2d_fwd_stats': ('depthwise', _dw_bytes),
+    'stp3_dwconv2d_fwd_stats_bn': ('depthwise', _dw_bytes),
     'stp3_dwconv2d_bwd_data': ('depthwise', _dw_bytes),
     'stp3_dwconv2d_bwd_weight': ('depthwise', _dw_bytes),
     'stp3_dwconv2d_bwd_weight_oihw': ('depthwise', _dw_bytes),
     'stp3_se_pool': ('squeeze_excite', _se_pool_bytes),
     'stp3_se_scale': ('squeeze_excite', _se_bytes(2)),
     'stp3_se_pool_act': ('mbconv', _se_bytes(1)),
+    'stp3_se_pool_act_parts': ('mbconv', _se_bytes(1)),
     'stp3_mbconv_scale_act': ('mbconv', _se_bytes(2)),
     'stp3_mbconv_bwd_reduce': ('mbconv', _se_bytes(2)),
+    'stp3_mbconv_bwd_reduce_parts': ('mbconv', _se_bytes(2)),
     'stp3_mbconv_bwd_apply': ('mbconv', _se_bytes(3)),
 }
 

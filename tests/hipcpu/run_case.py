@@ -658,7 +658,10 @@ def mbconv_mid(ops):
             x0 = torch.randn(n, c, h, w, generator=g).to(dtype).contiguous(memory_format=cl)
             s = max(1, c // 4)
             res = []
-            for mode in ('fused', 'torch'):
+            for mode in ('fused', 'unmerged', 'torch'):
+                # 'unmerged': the stand-alone reductions between the passes (what more than one rank runs) -- the merged form
+                # must give the same BITS (ops_fused.MERGE_SMALL_REDUCTIONS)
+                ops_fused.MERGE_SMALL_REDUCTIONS = mode != 'unmerged'
                 dw = StaticSamePadConv2d(c, c, k, img, stride=stride, groups=c)
                 bn = nn.BatchNorm2d(c, momentum=0.01, eps=1e-3)
                 r1, r2 = StaticSamePadConv2d(c, s, 1, 1, bias=True), StaticSamePadConv2d(s, c, 1, 1, bias=True)
@@ -668,7 +671,7 @@ def mbconv_mid(ops):
                     bn.weight.copy_(torch.rand(c, generator=gp) + 0.5); bn.bias.copy_(torch.randn(c, generator=gp) * 0.2)
                     r1.weight.copy_(torch.randn(r1.weight.shape, generator=gp) * 0.3); r1.bias.copy_(torch.randn(s, generator=gp) * 0.2)
                     r2.weight.copy_(torch.randn(r2.weight.shape, generator=gp) * 0.3); r2.bias.copy_(torch.randn(c, generator=gp) * 0.2)
-                if mode == 'fused':
+                if mode != 'torch':
                     x = x0.clone().requires_grad_()
                     assert ops_fused.dw_bn_se_supported(x, dw, bn)
                     y = ops_fused.dw_bn_se(x, dw, bn, r1, r2, group=False)
@@ -683,11 +686,13 @@ def mbconv_mid(ops):
                     y = sact * gate[:, :, None, None]
                 if mode == 'fused':
                     gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(dtype).contiguous(memory_format=cl)
-                y.backward(gy if mode == 'fused' else gy.float())
+                y.backward(gy if mode != 'torch' else gy.float())
                 res.append([y.detach().float(), x.grad.float(), dw.weight.grad, bn.weight.grad, bn.bias.grad, r1.weight.grad,
                             r1.bias.grad, r2.weight.grad, r2.bias.grad, bn.running_mean.clone(), bn.running_var.clone()])
+            ops_fused.MERGE_SMALL_REDUCTIONS = True
             names = ['y', 'dx', 'ddw', 'dgamma', 'dbeta', 'dw1', 'db1', 'dw2', 'db2', 'rmean', 'rvar']
-            out[f'{name}_{tag}'] = {k_: rel(a, b) for k_, a, b in zip(names, *res)}
+            out[f'{name}_{tag}'] = {k_: rel(a, b) for k_, a, b in zip(names, res[0], res[2])}
+            out[f'{name}_{tag}']['merged_differs'] = float(sum(0 if torch.equal(a, b) else 1 for a, b in zip(res[0], res[1])))
     return out
 
 

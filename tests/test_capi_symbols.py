@@ -34,3 +34,17 @@ def test_argument_validation_without_gpu():
     assert lib.stp3_lift_plan_bytes(ctypes.byref(ok), ctypes.byref(nbytes)) == 0
     assert nbytes.value >= 12 * (40001 + 483840) * 4
     assert lib.stp3_lift_plan_bytes(None, ctypes.byref(nbytes)) == -10001
+
+
+def test_family_rooflines_count_every_variant_of_an_entry_point():
+    """bench.py's per-family rooflines (stp3_amd/profiling.py) time the C-ABI calls listed in ``WORK``: a variant of a listed
+    entry (``*_parts``, ``*_partials``, ``*_bn``, ``*_reduce_batch``: the same kernels with a reduction moved) that is missing
+    there silently drops its time from the family -- the family would look faster than it is."""
+    from stp3_amd import profiling
+    listed = set(profiling.WORK)
+    for name in _declared():
+        for suffix in ('_parts', '_partials', '_bn', '_reduce_batch', '_oihw'):
+            if name.endswith(suffix) and name[:-len(suffix)] in listed:
+                assert name in listed, name
+    assert {'stp3_conv2d_wgrad_partials', 'stp3_conv2d_wgrad_reduce_batch', 'stp3_dwconv2d_fwd_stats_bn',
+            'stp3_se_pool_act_parts', 'stp3_mbconv_bwd_reduce_parts'} <= listed

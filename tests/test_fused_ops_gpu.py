@@ -391,3 +391,34 @@ def test_pointwise_conv_bn_act_without_the_convolution_output(shape):
         ref = F.silu((e0 - mean[None, :, None, None]) * torch.rsqrt(var + 1e-3)[None, :, None, None]
                      * torch.linspace(0.5, 1.5, cout).cuda()[None, :, None, None] + torch.linspace(-0.3, 0.3, cout).cuda()[None, :, None, None])
         torch.testing.assert_close(a[0].float(), ref, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize('channels,out_channels,pyramid', [(70, 64, True), (64, 64, True), (64, 64, False)])
+def test_temporal_block_paths_written_into_one_buffer_bit_equal(monkeypatch, channels, out_channels, pyramid):
+    """TemporalBlock (stp3/layers/temporal.py:426-489): its three paths write their BatchNorm outputs into the channel
+    slices of the aggregation's operand (``out_slot`` of ``ops.bn_act`` + ``ops_fused.join_slices``) instead of being
+    concatenated -- against the same block with the concatenation: outputs, input gradient and every parameter gradient
+    bit for bit (same kernels on the same values; only where the rows land differs)."""
+    from stp3_amd.layers import fused, temporal
+    from stp3_amd.utils import to_channels_last
+
+    def run(slots):
+        monkeypatch.setattr(temporal, 'slot_ok', fused.slot_ok if slots else (lambda x: False))
+        torch.manual_seed(4)
+        extra_ch = channels - 64
+        blk = to_channels_last(temporal.TemporalBlock(channels, out_channels, use_pyramid_pooling=pyramid,
+                                                      pool_sizes=[(2, 40, 48)] if pyramid else None).cuda())
+        blk.train()
+        g = torch.Generator().manual_seed(8)
+        x = torch.randn(2, 64, 3, 40, 48, generator=g).cuda().requires_grad_()
+        extra = torch.randn(2, extra_ch, 3, generator=g).cuda() if extra_ch else None
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = blk(x, extra) if extra is not None else blk(x)
+        gy = torch.randn(y.shape, generator=g).cuda().to(y.dtype)
+        y.backward(gy)
+        return [y.detach(), x.grad] + [p.grad for p in blk.parameters()]
+
+    cat, slot = run(False), run(True)
+    assert len(cat) == len(slot) and float(cat[0].float().abs().max()) > 0
+    for i, (a, b) in enumerate(zip(cat, slot)):
+        assert a is not None and b is not None and torch.equal(a, b), i

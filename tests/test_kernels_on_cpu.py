@@ -144,7 +144,8 @@ def test_mbconv_middle_operator(results):
             if name == 'seconds':
                 continue
             tol = 2e-5 if name.endswith('_f32') else 2e-2
-            assert max(r.values()) <= tol, (name, r)
+            # (merged_differs: tensors that differ between the merged small reductions and the stand-alone ones: none, bitwise)
+            assert max(r.values()) <= tol and r['merged_differs'] == 0, (name, r)
             if name.endswith('_bf16'):                    # everything that is not stored in bf16 stays float32-accurate
                 assert max(r[k] for k in ('dgamma', 'dbeta', 'dw1', 'db1', 'dw2', 'db2', 'rmean', 'rvar')) <= 2e-5, (name, r)
 

@@ -56,21 +56,25 @@ def test_step_runs_and_call_mix(recorder, tmp_path):
     assert calls['stp3_bn_stats'] == 5 * STEPS, calls['stp3_bn_stats']
     # the 22 MBConv blocks: depthwise -> BN1 -> swish -> squeeze-excite as ONE operator (ops_fused.dw_bn_se) -- the
     # depthwise forward with the statistics epilogue, no separate BatchNorm / pool / scale passes
-    assert calls['stp3_dwconv2d_fwd_stats'] == calls['stp3_dwconv2d_bwd_data'] == calls['stp3_dwconv2d_bwd_weight_oihw'] \
+    # (single process: the entry points whose small reductions are done by their consumers -- *_bn / *_parts, ops_fused.
+    # MERGE_SMALL_REDUCTIONS -- instead of the stand-alone ones)
+    assert calls['stp3_dwconv2d_fwd_stats_bn'] == calls['stp3_dwconv2d_bwd_data'] == calls['stp3_dwconv2d_bwd_weight_oihw'] \
         == 22 * STEPS
+    assert calls['stp3_dwconv2d_fwd_stats'] == 0
     assert calls['stp3_dwconv2d_bwd_weight'] == 0                   # (the weight gradient leaves in the parameter's layout)
     assert calls['stp3_dwconv2d_fwd'] == calls['stp3_se_pool'] == calls['stp3_se_scale'] == 0
-    assert calls['stp3_se_mlp_fwd'] == calls['stp3_se_mlp_bwd'] == 22 * STEPS
-    for fused in ('stp3_se_pool_act', 'stp3_mbconv_scale_act', 'stp3_mbconv_bwd_reduce',
+    assert calls['stp3_se_mlp_fwd_parts'] == calls['stp3_se_mlp_bwd_parts'] == 22 * STEPS
+    assert calls['stp3_se_mlp_fwd'] == calls['stp3_se_mlp_bwd'] == calls['stp3_se_pool_act'] == calls['stp3_mbconv_bwd_reduce'] == 0
+    for fused in ('stp3_se_pool_act_parts', 'stp3_mbconv_scale_act', 'stp3_mbconv_bwd_reduce_parts',
                   'stp3_mbconv_bwd_coef', 'stp3_mbconv_bwd_apply'):
         assert calls[fused] == 22 * STEPS, (fused, calls[fused])
     # expand convolution -> BN0 -> swish WITHOUT the expanded pre-activation tensor (ops_fused._PointwiseBnAct) in the
     # blocks where the streaming kernels run it (contraction <= 128 channels, >= 16384 pixels): four passes per block,
-    # each its own entry point, and one more stp3_bn_finalize than the 22 of the depthwise stages
+    # each its own entry point, and one stp3_bn_finalize each (the depthwise stages finish theirs inside stp3_dwconv2d_fwd_stats_bn)
     recomputed = calls['stp3_conv2d_fwd_stats']
     assert recomputed >= STEPS and recomputed % STEPS == 0, recomputed
     assert calls['stp3_conv2d_fwd_bnact'] == calls['stp3_conv2d_bn_bwd_reduce'] == calls['stp3_conv2d_bn_bwd_apply'] == recomputed
-    assert calls['stp3_bn_finalize'] == 22 * STEPS + recomputed, calls['stp3_bn_finalize']
+    assert calls['stp3_bn_finalize'] == recomputed, calls['stp3_bn_finalize']
     # losses and label warp on the kernels: 5 cross-entropy calls (segmentation, pedestrian, 2 HD-map elements, depth),
     # 3 regression losses, one warp launch per step
     assert calls['stp3_ce_topk_fwd'] == calls['stp3_ce_topk_bwd'] == 5 * STEPS
