@@ -566,29 +566,13 @@ int stp3_mbconv_bwd_apply(const stp3_se_dims* dims, int32_t ldg, const void* da,
                           int32_t act, const float* gate, const float* dpooled, const float* gsums, double count,
                           void* dx, void* stream);
 
-/* The same chain with three launches less per block and direction when nothing happens between the passes (one process: no
- * statistics exchange) -- the partial sums a streaming pass leaves per row block are added by the kernel that consumes them,
- * in the order of the stand-alone reductions (bit-identical results):
- *   stp3_dwconv2d_fwd_stats_bn   : stp3_dwconv2d_fwd_stats + stp3_bn_finalize (coef [4][C], running statistics) -- the final
- *                                  reduction finishes its own channels;
- *   stp3_se_pool_act_parts       : stp3_se_pool_act without the sum over the row blocks: partial [N][*parts][C] in `workspace`;
- *   stp3_se_mlp_fwd_parts        : stp3_se_mlp_fwd reading those partial rows; WRITES pooled_sum [N][C] (the backward's input);
- *   stp3_mbconv_bwd_reduce_parts : stp3_mbconv_bwd_reduce without the sum: partial [N][*parts][5][C] in `workspace`;
- *   stp3_se_mlp_bwd_parts        : stp3_se_mlp_bwd reading them; WRITES sums5 [5][N][C] (dgate = sums5[0]) for
- *                                  stp3_mbconv_bwd_coef.
- * `workspace` must stay untouched between a *_parts producer and its consumer (they are adjacent launches on one stream). */
+/* stp3_dwconv2d_fwd_stats_bn -- stp3_dwconv2d_fwd_stats + stp3_bn_finalize in the launches of the former (one process: nothing
+ * happens between the statistics and their use, so the final reduction finishes its own channels -- coef [4][C] = scale |
+ * shift | mean | invstd, running statistics updated; the additions keep the order of the stand-alone reduction and the
+ * constants stp3_bn_finalize's arithmetic: bit-identical).  count = elements per channel. */
 int stp3_dwconv2d_fwd_stats_bn(const stp3_dwconv_dims* dims, const void* x, const float* w, void* y, float* sums, double count,
                                const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                                float* running_var, float* coef, void* workspace, size_t workspace_bytes, void* stream);
-int stp3_se_pool_act_parts(const stp3_se_dims* dims, const void* x, const float* scale, const float* shift, int32_t act,
-                           void* workspace, size_t workspace_bytes, int32_t* parts, void* stream);
-int stp3_se_mlp_fwd_parts(const stp3_se_mlp_dims* dims, const float* pooled_part, int32_t parts, const float* w1, const float* b1,
-                          const float* w2, const float* b2, float* pooled_sum, float* z1, float* gate, void* stream);
-int stp3_mbconv_bwd_reduce_parts(const stp3_se_dims* dims, int32_t ldg, const void* da, const void* x, const float* coef,
-                                 int32_t act, void* workspace, size_t workspace_bytes, int32_t* parts, void* stream);
-int stp3_se_mlp_bwd_parts(const stp3_se_mlp_dims* dims, const float* sums_part, int32_t parts, const float* gate,
-                          const float* pooled_sum, const float* z1, const float* w1, const float* w2, float* sums5, float* dz2,
-                          float* dz1, float* dpooled, float* dw1, float* db1, float* dw2, float* db2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training losses of the perception path and the label warp (csrc/stp3_loss.hip).

@@ -514,22 +514,6 @@ int stp3_se_pool_act(const stp3_se_dims* p, const void* x, const float* scale, c
     return mb_status();
 }
 
-// the same pass WITHOUT the sum over the row blocks: partial [N][*parts][C] stays in `workspace` for a consumer that adds the
-// rows itself (stp3_se_mlp_fwd_parts: one launch less on the chain depthwise -> gate -> scale)
-int stp3_se_pool_act_parts(const stp3_se_dims* p, const void* x, const float* scale, const float* shift, int32_t act,
-                           void* workspace, size_t workspace_bytes, int32_t* parts, void* stream) {
-    MbPlan P;
-    int rc = mb_plan(p, p ? p->ld : 0, &P, {x}, 7, 1);
-    if (rc) return rc;
-    if (!x || !scale || !shift || !workspace || !parts || !act_ok(act)) return STP3_EINVAL;
-    if (workspace_bytes < (size_t)p->N * kMaxBx * p->C * sizeof(float)) return STP3_ENOSPACE;
-    float* partial = (float*)workspace;
-    MB_SWITCH(P, act, hipLaunchKernelGGL((se_pool_act_kernel<T, VEC, ACT>), P.grid, dim3(kT), 0, (hipStream_t)stream, P.d,
-                                         (const T*)x, scale, shift, partial));
-    *parts = (int32_t)P.grid.x;
-    return mb_status();
-}
-
 int stp3_mbconv_scale_act(const stp3_se_dims* p, int32_t ldy, const void* x, const float* scale, const float* shift, int32_t act,
                           const float* gate, void* y, void* stream) {
     MbPlan P;
@@ -555,21 +539,6 @@ int stp3_mbconv_bwd_reduce(const stp3_se_dims* p, int32_t ldg, const void* da, c
     // partial [N][bx][5][C] -> sums5 [5][N][C]
     hipLaunchKernelGGL(mb_reduce_kernel, dim3((5 * p->C + 63) / 64, p->N), dim3(kT), 0, s, (int)P.grid.x, 5 * p->C, 5, partial,
                        sums5);
-    return mb_status();
-}
-
-// ... WITHOUT the sum over the row blocks: partial [N][*parts][5][C] stays in `workspace` (stp3_se_mlp_bwd_parts adds the rows)
-int stp3_mbconv_bwd_reduce_parts(const stp3_se_dims* p, int32_t ldg, const void* da, const void* x, const float* coef, int32_t act,
-                                 void* workspace, size_t workspace_bytes, int32_t* parts, void* stream) {
-    MbPlan P;
-    int rc = mb_plan(p, ldg, &P, {da, x}, 4, 2);
-    if (rc) return rc;
-    if (!da || !x || !coef || !workspace || !parts || !act_ok(act)) return STP3_EINVAL;
-    if (workspace_bytes < (size_t)p->N * kMaxBx * 5 * p->C * sizeof(float)) return STP3_ENOSPACE;
-    float* partial = (float*)workspace;
-    MB_SWITCH(P, act, hipLaunchKernelGGL((mbconv_bwd_reduce_kernel<T, VEC, ACT>), P.grid, dim3(kT), 0, (hipStream_t)stream, P.d,
-                                         (const T*)da, (const T*)x, coef, partial));
-    *parts = (int32_t)P.grid.x;
     return mb_status();
 }
 

@@ -57,33 +57,9 @@ __device__ __forceinline__ void block_sums(const float* part, int S, float* scra
     __syncthreads();
 }
 
-// The sum over the `parts` partial rows a streaming pass left behind for one (sample, channel): what mb_reduce_kernel
-// (stp3_mbconv.hip) computes -- four part lanes p = l, l + 4, ... with two alternating double accumulators each, then
-// (l0 + l1) + (l2 + l3) -- in ONE thread, the additions in the same order (bit-identical): the consumers below add the rows
-// themselves instead of waiting for a launch that does nothing else.  src: the column of (sample, quantity, channel), `stride`
-// floats between rows.
-__device__ __forceinline__ float sum_parts(const float* __restrict__ src, int parts, size_t stride) {
-    double lane[4];
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-        double s0 = 0.0, s1 = 0.0;
-        int q = l;
-        for (; q + 4 < parts; q += 8) {
-            s0 += (double)src[(size_t)q * stride];
-            s1 += (double)src[(size_t)(q + 4) * stride];
-        }
-        for (; q < parts; q += 4) s0 += (double)src[(size_t)q * stride];
-        lane[l] = s0 + s1;
-    }
-    return (float)((lane[0] + lane[1]) + (lane[2] + lane[3]));
-}
-
 // forward: grid = N, dynamic LDS = S floats
-// parts > 0: `pooled_part` [N][parts][C] holds the squeeze as partial sums (stp3_se_pool_act_parts); the kernel adds them and
-// WRITES pooled_sum [N][C] (the backward reads it); parts == 0: pooled_sum is the input
 template <int SR>
-__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(stp3_se_mlp_dims d, float* __restrict__ pooled_sum,
-                                                         const float* __restrict__ pooled_part, int parts,
+__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(stp3_se_mlp_dims d, const float* __restrict__ pooled_sum,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
                                                          const float* __restrict__ w2, const float* __restrict__ b2,
                                                          float* __restrict__ z1, float* __restrict__ gate) {
@@ -102,20 +78,7 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(stp3_se_mlp_dims d, flo
             for (int k = 0; k < kOwn; ++k) {
                 const int c = c0 + k * 256 + tid;
                 cc[k] = min(c, d.C - 1);                       // beyond C: a valid address, times zero
-                float ps = 0.f;
-                if (c < d.C) {
-                    if (parts > 0) {
-                        if (sb == 0) {
-                            ps = sum_parts(pooled_part + (size_t)n * parts * d.C + c, parts, (size_t)d.C);
-                            pooled_sum[(size_t)n * d.C + c] = ps;
-                        } else {
-                            ps = pooled_sum[(size_t)n * d.C + c];      // (a second round of squeezed channels: this thread's own write)
-                        }
-                    } else {
-                        ps = pooled_sum[(size_t)n * d.C + c];
-                    }
-                }
-                pc[k] = ps * d.inv_rows;
+                pc[k] = c < d.C ? pooled_sum[(size_t)n * d.C + c] * d.inv_rows : 0.f;
             }
 #pragma unroll
             for (int s = 0; s < SR; ++s) {
@@ -159,10 +122,7 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(stp3_se_mlp_dims d, flo
 // backward, per sample: dz2 = dgate * gate * (1 - gate); dh = dz2 W2; dz1 = dh * swish'(z1); dpooled = dz1 W1 / rows
 // grid = N, dynamic LDS = S floats
 template <int SR>
-// parts > 0: `sums_part` [N][parts][5][C] holds the five sums of stp3_mbconv_bwd_reduce_parts as partial rows; the kernel adds
-// them, WRITES sums5 [5][N][C] (dgate = sums5[0]; stp3_mbconv_bwd_coef reads the rest) and uses its row of sums5[0]
-__global__ __launch_bounds__(256) void se_mlp_bwd_sample_kernel(stp3_se_mlp_dims d, float* __restrict__ dgate,
-                                                                const float* __restrict__ sums_part, int parts,
+__global__ __launch_bounds__(256) void se_mlp_bwd_sample_kernel(stp3_se_mlp_dims d, const float* __restrict__ dgate,
                                                                 const float* __restrict__ gate,
                                                                 const float* __restrict__ z1,
                                                                 const float* __restrict__ w1,
@@ -179,12 +139,6 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_sample_kernel(stp3_se_mlp_dims
         // a thread owns channel c: its dz2 times ITS row of W2 (S contiguous floats) is its part of dh
         for (int c = tid; c < d.C; c += 256) {
             const float g = gate[(size_t)n * d.C + c];
-            if (parts > 0 && sb == 0) {
-                const float* col = sums_part + (size_t)n * parts * 5 * d.C + c;
-                const size_t q = (size_t)d.N * d.C;
-#pragma unroll
-                for (int k = 0; k < 5; ++k) dgate[k * q + (size_t)n * d.C + c] = sum_parts(col + (size_t)k * d.C, parts, (size_t)5 * d.C);
-            }
             const float v = dgate[(size_t)n * d.C + c] * g * (1.0f - g);
             if (sb == 0) dz2[(size_t)n * d.C + c] = v;
             const unsigned coff = (unsigned)(c * d.S);
@@ -302,14 +256,14 @@ inline int check(const stp3_se_mlp_dims* d) {
 
 extern "C" {
 
-static int se_mlp_fwd_run(const stp3_se_mlp_dims* dims, float* pooled_sum, const float* pooled_part, int parts, const float* w1,
-                          const float* b1, const float* w2, const float* b2, float* z1, float* gate, void* stream) {
+int stp3_se_mlp_fwd(const stp3_se_mlp_dims* dims, const float* pooled_sum, const float* w1, const float* b1,
+                    const float* w2, const float* b2, float* z1, float* gate, void* stream) {
     int rc = check(dims);
     if (rc) return rc;
-    if (!pooled_sum || !w1 || !b1 || !w2 || !b2 || !z1 || !gate || parts < 0 || (parts > 0 && !pooled_part)) return STP3_EINVAL;
+    if (!pooled_sum || !w1 || !b1 || !w2 || !b2 || !z1 || !gate) return STP3_EINVAL;
     const size_t lds = (size_t)dims->S * 4;
     hipStream_t s = (hipStream_t)stream;
-#define STP3_SE_FWD(SR) hipLaunchKernelGGL(se_mlp_fwd_kernel<SR>, dim3(dims->N), dim3(256), lds, s, *dims, pooled_sum, pooled_part, parts, w1, b1, w2, b2, z1, gate)
+#define STP3_SE_FWD(SR) hipLaunchKernelGGL(se_mlp_fwd_kernel<SR>, dim3(dims->N), dim3(256), lds, s, *dims, pooled_sum, w1, b1, w2, b2, z1, gate)
     switch ((dims->S + 7) / 8) {
         case 1: STP3_SE_FWD(8); break;
         case 2: STP3_SE_FWD(16); break;
@@ -323,28 +277,16 @@ static int se_mlp_fwd_run(const stp3_se_mlp_dims* dims, float* pooled_sum, const
     return launch_status();
 }
 
-int stp3_se_mlp_fwd(const stp3_se_mlp_dims* dims, const float* pooled_sum, const float* w1, const float* b1,
-                    const float* w2, const float* b2, float* z1, float* gate, void* stream) {
-    return se_mlp_fwd_run(dims, const_cast<float*>(pooled_sum), nullptr, 0, w1, b1, w2, b2, z1, gate, stream);
-}
-
-int stp3_se_mlp_fwd_parts(const stp3_se_mlp_dims* dims, const float* pooled_part, int32_t parts, const float* w1, const float* b1,
-                          const float* w2, const float* b2, float* pooled_sum, float* z1, float* gate, void* stream) {
-    if (parts <= 0) return STP3_EINVAL;
-    return se_mlp_fwd_run(dims, pooled_sum, pooled_part, parts, w1, b1, w2, b2, z1, gate, stream);
-}
-
-static int se_mlp_bwd_run(const stp3_se_mlp_dims* dims, float* dgate, const float* sums_part, int parts, const float* gate,
-                          const float* pooled_sum, const float* z1, const float* w1, const float* w2, float* dz2, float* dz1,
-                          float* dpooled, float* dw1, float* db1, float* dw2, float* db2, void* stream) {
+int stp3_se_mlp_bwd(const stp3_se_mlp_dims* dims, const float* dgate, const float* gate, const float* pooled_sum,
+                    const float* z1, const float* w1, const float* w2, float* dz2, float* dz1, float* dpooled,
+                    float* dw1, float* db1, float* dw2, float* db2, void* stream) {
     int rc = check(dims);
     if (rc) return rc;
-    if (!dgate || !gate || !pooled_sum || !z1 || !w1 || !w2 || !dz2 || !dz1 || !dpooled || !dw1 || !db1 || !dw2 || !db2 ||
-        parts < 0 || (parts > 0 && !sums_part))
+    if (!dgate || !gate || !pooled_sum || !z1 || !w1 || !w2 || !dz2 || !dz1 || !dpooled || !dw1 || !db1 || !dw2 || !db2)
         return STP3_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)dims->S * 4;
-#define STP3_SE_BWD(SR) hipLaunchKernelGGL(se_mlp_bwd_sample_kernel<SR>, dim3(dims->N), dim3(256), lds, s, *dims, dgate, sums_part, parts, gate, z1, w1, w2, dz2, dz1, dpooled)
+#define STP3_SE_BWD(SR) hipLaunchKernelGGL(se_mlp_bwd_sample_kernel<SR>, dim3(dims->N), dim3(256), lds, s, *dims, dgate, gate, z1, w1, w2, dz2, dz1, dpooled)
     switch ((dims->S + 7) / 8) {
         case 1: STP3_SE_BWD(8); break;
         case 2: STP3_SE_BWD(16); break;
@@ -360,21 +302,6 @@ static int se_mlp_bwd_run(const stp3_se_mlp_dims* dims, float* dgate, const floa
                        ((size_t)2 * dims->N * kSChunk + (size_t)kWgtGroups * (2 * kSChunk + 1) * kWgtChan) * 4, s, *dims,
                        pooled_sum, z1, dz2, dz1, dw1, db1, dw2, db2);
     return launch_status();
-}
-
-int stp3_se_mlp_bwd(const stp3_se_mlp_dims* dims, const float* dgate, const float* gate, const float* pooled_sum,
-                    const float* z1, const float* w1, const float* w2, float* dz2, float* dz1, float* dpooled,
-                    float* dw1, float* db1, float* dw2, float* db2, void* stream) {
-    return se_mlp_bwd_run(dims, const_cast<float*>(dgate), nullptr, 0, gate, pooled_sum, z1, w1, w2, dz2, dz1, dpooled, dw1, db1,
-                          dw2, db2, stream);
-}
-
-int stp3_se_mlp_bwd_parts(const stp3_se_mlp_dims* dims, const float* sums_part, int32_t parts, const float* gate,
-                          const float* pooled_sum, const float* z1, const float* w1, const float* w2, float* sums5, float* dz2,
-                          float* dz1, float* dpooled, float* dw1, float* db1, float* dw2, float* db2, void* stream) {
-    if (parts <= 0) return STP3_EINVAL;
-    return se_mlp_bwd_run(dims, sums5, sums_part, parts, gate, pooled_sum, z1, w1, w2, dz2, dz1, dpooled, dw1, db1, dw2, db2,
-                          stream);
 }
 
 }  // extern "C"

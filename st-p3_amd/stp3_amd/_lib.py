@@ -235,12 +235,6 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_double, c_void_p, c_void_p]),
     'stp3_dwconv2d_fwd_stats_bn': (c_int, [_DW_P, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_float,
                                            c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    'stp3_se_pool_act_parts': (c_int, [ctypes.POINTER(SeDims), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t,
-                                       ctypes.POINTER(c_int32), c_void_p]),
-    'stp3_se_mlp_fwd_parts': (c_int, [c_void_p, c_void_p, c_int32] + [c_void_p] * 8),
-    'stp3_mbconv_bwd_reduce_parts': (c_int, [ctypes.POINTER(SeDims), c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
-                                             c_size_t, ctypes.POINTER(c_int32), c_void_p]),
-    'stp3_se_mlp_bwd_parts': (c_int, [c_void_p, c_void_p, c_int32] + [c_void_p] * 14),
     'stp3_ce_topk_workspace_bytes': (c_int, [ctypes.POINTER(CeDims), ctypes.POINTER(c_size_t)]),
     'stp3_ce_topk_fwd': (c_int, [ctypes.POINTER(CeDims)] + [c_void_p] * 6 + [c_double, c_int32, c_void_p, c_void_p, c_size_t,
                                                                            c_void_p]),

@@ -549,9 +549,10 @@ def se_block(x, se_reduce, se_expand):
 # ----------------------------------------------------------------------------------------------
 # MBConv middle: depthwise conv -> BatchNorm -> swish -> squeeze-excite, as ONE operator
 # ----------------------------------------------------------------------------------------------
-# The reductions over the per-row-block partial sums of the MBConv middle are done by the kernels that consume them (and the
-# BatchNorm-1 constants by the reduction that produces their sums): three launches less per block forward and one less
-# backward -- 66 + 22 per step -- with bit-identical results (the additions keep the order of the stand-alone reductions).
+# The BatchNorm-1 constants of the MBConv middle are made by the reduction that produces their sums
+# (stp3_dwconv2d_fwd_stats_bn: one launch less per block, bit-identical).  The same idea one step further -- the gate kernels
+# adding the squeeze's / the backward sums' partial rows themselves instead of waiting for mb_reduce_kernel -- was built and
+# measured and LOSES 0.65 ms per step: those consumers are one workgroup per sample (profiles/r06e_ab_consumer_side_reductions.txt).
 MERGE_SMALL_REDUCTIONS = True
 
 
@@ -617,20 +618,11 @@ class _DwBnSe(torch.autograd.Function):
         md = _lib.SeMlpDims(n, c, w1f.shape[0], 1.0 / float(ho * wo))
         z1 = torch.empty(n, md.S, dtype=torch.float32, device=dev)
         gate = torch.empty(n, c, dtype=torch.float32, device=dev)
-        if MERGE_SMALL_REDUCTIONS:
-            # the squeeze leaves its per-row-block sums in the scratch buffer and the gate kernel adds them (one launch less)
-            parts = ctypes.c_int32()
-            check(lib.stp3_se_pool_act_parts(ctypes.byref(sd), e2.data_ptr(), scale_p, shift_p, ops.ACT_SWISH, ws.data_ptr(), ws_bytes,
-                                             ctypes.byref(parts), stream), 'stp3_se_pool_act_parts')
-            check(lib.stp3_se_mlp_fwd_parts(ctypes.byref(md), ws.data_ptr(), parts.value, w1f.data_ptr(), ops._f32(b1).data_ptr(),
-                                            w2f.data_ptr(), ops._f32(b2).data_ptr(), pooled_sum.data_ptr(), z1.data_ptr(),
-                                            gate.data_ptr(), stream), 'stp3_se_mlp_fwd_parts')
-        else:
-            check(lib.stp3_se_pool_act(ctypes.byref(sd), e2.data_ptr(), scale_p, shift_p, ops.ACT_SWISH, ws.data_ptr(), ws_bytes,
-                                       pooled_sum.data_ptr(), stream), 'stp3_se_pool_act')
-            check(lib.stp3_se_mlp_fwd(ctypes.byref(md), pooled_sum.data_ptr(), w1f.data_ptr(), ops._f32(b1).data_ptr(),
-                                      w2f.data_ptr(), ops._f32(b2).data_ptr(), z1.data_ptr(), gate.data_ptr(), stream),
-                  'stp3_se_mlp_fwd')
+        check(lib.stp3_se_pool_act(ctypes.byref(sd), e2.data_ptr(), scale_p, shift_p, ops.ACT_SWISH, ws.data_ptr(), ws_bytes,
+                                   pooled_sum.data_ptr(), stream), 'stp3_se_pool_act')
+        check(lib.stp3_se_mlp_fwd(ctypes.byref(md), pooled_sum.data_ptr(), w1f.data_ptr(), ops._f32(b1).data_ptr(),
+                                  w2f.data_ptr(), ops._f32(b2).data_ptr(), z1.data_ptr(), gate.data_ptr(), stream),
+              'stp3_se_mlp_fwd')
         a = torch.empty_like(e2)
         check(lib.stp3_mbconv_scale_act(ctypes.byref(sd), c, e2.data_ptr(), scale_p, shift_p, ops.ACT_SWISH, gate.data_ptr(),
                                         a.data_ptr(), stream), 'stp3_mbconv_scale_act')
@@ -659,21 +651,11 @@ class _DwBnSe(torch.autograd.Function):
         dpooled = torch.empty(n, c, **f32)
         dw1, db1 = torch.empty(md.S, c, **f32), torch.empty(md.S, **f32)
         dw2, db2 = torch.empty(c, md.S, **f32), torch.empty(c, **f32)
-        if MERGE_SMALL_REDUCTIONS:
-            # the five sums stay per row block in the scratch buffer; the per-sample kernel of the gate's backward adds them
-            parts = ctypes.c_int32()
-            check(lib.stp3_mbconv_bwd_reduce_parts(ctypes.byref(sd), c, da.data_ptr(), e2.data_ptr(), coef.data_ptr(), ops.ACT_SWISH,
-                                                   ws.data_ptr(), ws_bytes, ctypes.byref(parts), stream), 'stp3_mbconv_bwd_reduce_parts')
-            check(lib.stp3_se_mlp_bwd_parts(ctypes.byref(md), ws.data_ptr(), parts.value, gate.data_ptr(), pooled_sum.data_ptr(),
-                                            z1.data_ptr(), w1f.data_ptr(), w2f.data_ptr(), sums5.data_ptr(), dz2.data_ptr(),
-                                            dz1.data_ptr(), dpooled.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
-                                            db2.data_ptr(), stream), 'stp3_se_mlp_bwd_parts')
-        else:
-            check(lib.stp3_mbconv_bwd_reduce(ctypes.byref(sd), c, da.data_ptr(), e2.data_ptr(), coef.data_ptr(), ops.ACT_SWISH,
-                                             ws.data_ptr(), ws_bytes, sums5.data_ptr(), stream), 'stp3_mbconv_bwd_reduce')
-            check(lib.stp3_se_mlp_bwd(ctypes.byref(md), sums5.data_ptr(), gate.data_ptr(), pooled_sum.data_ptr(), z1.data_ptr(),
-                                      w1f.data_ptr(), w2f.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), dpooled.data_ptr(),
-                                      dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), stream), 'stp3_se_mlp_bwd')
+        check(lib.stp3_mbconv_bwd_reduce(ctypes.byref(sd), c, da.data_ptr(), e2.data_ptr(), coef.data_ptr(), ops.ACT_SWISH,
+                                         ws.data_ptr(), ws_bytes, sums5.data_ptr(), stream), 'stp3_mbconv_bwd_reduce')
+        check(lib.stp3_se_mlp_bwd(ctypes.byref(md), sums5.data_ptr(), gate.data_ptr(), pooled_sum.data_ptr(), z1.data_ptr(),
+                                  w1f.data_ptr(), w2f.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), dpooled.data_ptr(),
+                                  dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), stream), 'stp3_se_mlp_bwd')
         lsums = torch.empty(2, c, **f32)                                  # sum g (dbeta) | sum g * xhat (dgamma), this rank
         check(lib.stp3_mbconv_bwd_coef(n, c, sums5.data_ptr(), gate.data_ptr(), dpooled.data_ptr(), lsums.data_ptr(), stream),
               'stp3_mbconv_bwd_coef')

@@ -81,10 +81,8 @@ WORK = {
     'stp3_se_pool': ('squeeze_excite', _se_pool_bytes),
     'stp3_se_scale': ('squeeze_excite', _se_bytes(2)),
     'stp3_se_pool_act': ('mbconv', _se_bytes(1)),
-    'stp3_se_pool_act_parts': ('mbconv', _se_bytes(1)),
     'stp3_mbconv_scale_act': ('mbconv', _se_bytes(2)),
     'stp3_mbconv_bwd_reduce': ('mbconv', _se_bytes(2)),
-    'stp3_mbconv_bwd_reduce_parts': ('mbconv', _se_bytes(2)),
     'stp3_mbconv_bwd_apply': ('mbconv', _se_bytes(3)),
 }
 

@@ -56,16 +56,14 @@ def test_step_runs_and_call_mix(recorder, tmp_path):
     assert calls['stp3_bn_stats'] == 5 * STEPS, calls['stp3_bn_stats']
     # the 22 MBConv blocks: depthwise -> BN1 -> swish -> squeeze-excite as ONE operator (ops_fused.dw_bn_se) -- the
     # depthwise forward with the statistics epilogue, no separate BatchNorm / pool / scale passes
-    # (single process: the entry points whose small reductions are done by their consumers -- *_bn / *_parts, ops_fused.
-    # MERGE_SMALL_REDUCTIONS -- instead of the stand-alone ones)
+    # (single process: the BatchNorm-1 constants come out of the statistics reduction itself, stp3_dwconv2d_fwd_stats_bn)
     assert calls['stp3_dwconv2d_fwd_stats_bn'] == calls['stp3_dwconv2d_bwd_data'] == calls['stp3_dwconv2d_bwd_weight_oihw'] \
         == 22 * STEPS
     assert calls['stp3_dwconv2d_fwd_stats'] == 0
     assert calls['stp3_dwconv2d_bwd_weight'] == 0                   # (the weight gradient leaves in the parameter's layout)
     assert calls['stp3_dwconv2d_fwd'] == calls['stp3_se_pool'] == calls['stp3_se_scale'] == 0
-    assert calls['stp3_se_mlp_fwd_parts'] == calls['stp3_se_mlp_bwd_parts'] == 22 * STEPS
-    assert calls['stp3_se_mlp_fwd'] == calls['stp3_se_mlp_bwd'] == calls['stp3_se_pool_act'] == calls['stp3_mbconv_bwd_reduce'] == 0
-    for fused in ('stp3_se_pool_act_parts', 'stp3_mbconv_scale_act', 'stp3_mbconv_bwd_reduce_parts',
+    assert calls['stp3_se_mlp_fwd'] == calls['stp3_se_mlp_bwd'] == 22 * STEPS
+    for fused in ('stp3_se_pool_act', 'stp3_mbconv_scale_act', 'stp3_mbconv_bwd_reduce',
                   'stp3_mbconv_bwd_coef', 'stp3_mbconv_bwd_apply'):
         assert calls[fused] == 22 * STEPS, (fused, calls[fused])
     # expand convolution -> BN0 -> swish WITHOUT the expanded pre-activation tensor (ops_fused._PointwiseBnAct) in the
