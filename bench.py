@@ -19,6 +19,9 @@ from Python instead: ~1 800 dispatches and 31-39 ms of host time per step); with
 the step (BatchNorm statistics exchanges, gradient buckets) are captured with it.
 
 Prints ONE JSON line (rank 0).  Extra objects:
+  other_workloads  (default flags on one GPU only) the reference's Prediction.yml / Planning.yml steps -- rows f2 / f3 of
+                SURVEY.md section 8 -- each measured by a child run of this file: rate, ms per step, in-run family rooflines
+                (`python bench.py --workload prediction` prints the full line of such a leg, with the reference's CPU step)
   roofline      the voxel-pool forward (stp3_lift_splat_fwd = its two kernels): algorithmic bytes per
                 launch / HIP-event time of launches on the stream they run on (measured live in this
                 process on the bench shape, right after the timed steps), against the 8 TB/s HBM3E peak;
@@ -204,6 +207,9 @@ def _cpu_baseline_worker(workload='c3'):
                     planning=(n_future, over['PLANNING.SAMPLE_NUM']) if over.get('PLANNING.ENABLED') else None)
     batch = synthetic.make_batch(batch=1, **batch_kw)
     counts = sorted({min(c, cores) for c in CPU_BASELINE_THREADS})
+    quick = os.environ.get('STP3_CPU_BASELINE_QUICK') == '1'       # the prediction / planning legs: one thread count, no B=4 step
+    if quick:
+        counts = counts[:1]
     torch.set_num_threads(counts[0])
     train_step(batch)                                                # warm-up (allocator, oneDNN primitives)
     sweep = {}
@@ -245,7 +251,7 @@ def _cpu_baseline_worker(workload='c3'):
             model.encoder = enc
     # the batch the GPU line is quoted on: one step, no warm-up of its own (~1 minute of CPU work)
     b4 = None
-    if os.environ.get('STP3_CPU_BASELINE_B4', '1') != '0':
+    if os.environ.get('STP3_CPU_BASELINE_B4', '1') != '0' and not quick:
         batch4 = synthetic.make_batch(batch=4, **batch_kw)
         b4 = train_step(batch4)
     what = ('the reference\'s TrainingModule.shared_step on its own modules (stp3/models, layers, losses, utils/geometry; '
@@ -263,16 +269,40 @@ def _cpu_baseline_worker(workload='c3'):
                                 f'b4_step_s = ONE step at the bench batch (B=4) at {best} threads'}))
 
 
-def cpu_baseline(workload='c3', timeout_s=480.0):
+def cpu_baseline(workload='c3', timeout_s=480.0, quick=False):
     """Runs the worker in a child process (own thread pool, hard time limit) and returns its JSON object."""
     import subprocess
+    env = {**os.environ, 'HIP_VISIBLE_DEVICES': ''}
+    if quick:
+        env['STP3_CPU_BASELINE_QUICK'] = '1'
     out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--workload', workload],
-                         capture_output=True,
-                         text=True, timeout=timeout_s, env={**os.environ, 'HIP_VISIBLE_DEVICES': ''})
+                         capture_output=True, text=True, timeout=timeout_s, env=env)
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
     if not lines:
         raise RuntimeError(f'cpu baseline worker failed: {out.stderr[-500:]}')
     return json.loads(lines[-1])
+
+
+def other_workload(workload, steps=10, warmup=3, timeout_s=300.0):
+    """One of the widened configurations (rows f2 / f3 of SURVEY.md section 8) through a child run of this file: the captured
+    step's rate, its in-run family rooflines and host time -- the GPU side only (`bench.py --workload <w>` alone adds the
+    reference's CPU step)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--workload', workload, '--steps', str(steps), '--warmup', str(warmup),
+           '--no-cpu-baseline', '--no-other-workloads']
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+        if not lines:
+            return {'error': out.stderr[-300:]}
+        d = json.loads(lines[-1])
+        fam = d.get('roofline_families') or {}
+        return {'metric': d['metric'], 'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'],
+                'warmup': d['warmup'], 'config': d['config'], 'host_enqueue_ms_per_step': d.get('host_enqueue_ms_per_step'),
+                'roofline_families': {k: ({kk: vv for kk, vv in v.items() if kk != 'top_shapes'} if isinstance(v, dict) else v)
+                                      for k, v in fam.items()}}
+    except Exception as e:  # noqa: BLE001 -- reported in the entry
+        return {'error': repr(e)}
 
 
 def lift_roofline(device, batch, model, iters=30):
@@ -315,7 +345,7 @@ def lift_roofline(device, batch, model, iters=30):
     fwd_ms = prof['lift_splat_fwd']['avg_ms']
     ach = alg_fwd / (fwd_ms * 1e-3) / 1e9
     traffic, traffic_source = None, None
-    pmc_path = next((q for q in (os.path.join(ROOT, 'profiles', f) for f in ('r05_lift_pmc.json', 'r04_lift_pmc.json', 'r03_lift_pmc.json', 'r02_lift_pmc.json'))
+    pmc_path = next((q for q in (os.path.join(ROOT, 'profiles', f) for f in ('r06_lift_pmc.json', 'r05_lift_pmc.json', 'r04_lift_pmc.json', 'r03_lift_pmc.json', 'r02_lift_pmc.json'))
                      if os.path.exists(q)), '')
     if os.path.exists(pmc_path):
         try:
@@ -342,6 +372,8 @@ def lift_roofline(device, batch, model, iters=30):
                          'SURVEY.md section 8d)' if bf else 'f32',
             'counted_from': 'depth logits (the softmax is part of the timed call)',
             'plan_build_ms': round(prof['plan_build']['avg_ms'], 4),
+            # poses -> BEV: the geometry-only plan (rebuilt for every batch) counted into the forward's time
+            'frac_with_plan': round(alg_fwd / ((fwd_ms + prof['plan_build']['avg_ms']) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             'backward': {'algorithmic_bytes_per_launch': alg_bwd,
                          'avg_launch_ms': round(prof['lift_splat_bwd']['avg_ms'], 4),
                          'achieved': round(alg_bwd / (prof['lift_splat_bwd']['avg_ms'] * 1e-3) / 1e9, 1),
@@ -423,6 +455,8 @@ def main():
     ap.add_argument('--launch', choices=('graph', 'eager'), default='graph',
                     help='graph: the whole step -- with its RCCL collectives when there is more than one rank -- captured once into '
                          'a hipGraph and replayed (stp3_amd/graph.py); eager: every kernel launched from Python')
+    ap.add_argument('--no-other-workloads', action='store_true',
+                    help='skip the prediction / planning legs the default run appends to the line (`other_workloads`)')
     ap.add_argument('--force-exchange', action='store_true',
                     help='diagnostic, one GPU: run the N > 1 form of the step (BatchNorm statistics exchanges, bucket all-reduces '
                          'from the hooks) in a process group of ONE RCCL rank -- what a rank of a multi-GPU job executes, minus '
@@ -613,11 +647,17 @@ def main():
         if fam:
             line['roofline_conv'] = fam.get('conv')
             line['roofline_bn'] = fam.get('batchnorm')
-        if world == 1 and not args.no_cpu_baseline and workload in ('c3', 'perception'):
+        if world == 1 and not args.no_cpu_baseline:
             try:
-                line['cpu_baseline'] = cpu_baseline(workload)
+                # (the prediction / planning legs: B=1 at one thread count, median of 3 -- their reference step is 2-3x longer)
+                line['cpu_baseline'] = cpu_baseline(workload, quick=workload not in ('c3', 'perception'))
             except Exception as e:  # the baseline must never take the GPU number down with it
                 line['cpu_baseline'] = {'error': repr(e)}
+        if (world == 1 and workload == 'c3' and not args.no_other_workloads and not args.no_roofline and not args.no_cpu_baseline
+                and not args.force_exchange and not DRYRUN):
+            # the reference's Prediction.yml / Planning.yml steps, each measured by a child run of
+            # this file (its own process: own model, own graph; a failure stays in its entry) -- the headline above is untouched
+            line['other_workloads'] = {w: other_workload(w) for w in ('prediction', 'planning')}
         print(json.dumps(line))
     if world > 1:
         dist.barrier()              # rank 0 may still be in its roofline micro-benchmark: leave together
