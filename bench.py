@@ -641,7 +641,7 @@ def main():
             # (a replayed step issues the collectives it was captured with: counted at the capture)
             'collectives_per_step': dict(runner.collectives) if mode == 'hipgraph' else
                                     {'batchnorm_statistics_all_reduces': exchanges['batchnorm'] // max(args.steps, 1),
-                                     'gradient_bucket_all_reduces': bucket_reductions // max(args.steps, 1) if world > 1 else 0},
+                                     'gradient_bucket_all_reduces': bucket_reductions // max(args.steps, 1) if buckets.exchange else 0},
             'roofline_families': fam,
         }
         if fam:
