@@ -385,6 +385,16 @@ MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak of one MI355X (MI355X_MICR
 CONV_GFLOP_PER_SAMPLE_FWD = 292.4   # 2 x 146.2 GMAC (trunk, heads, temporal model, decoder), T = 3
 
 
+def _shape_entry(a, steps):
+    sec = a['ms'] * 1e-3
+    tflops, tbs = a['work'] / sec / 1e12, a['bytes'] / sec / 1e12
+    hbm_bound = a['bytes'] > 0 and a['work'] / a['bytes'] < MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    return {'pass': a['family'][5:], 'shape': a['shape'], 'calls_per_step': a['calls'] // steps,
+            'ms_per_step': round(a['ms'] / steps, 3), 'tflops': round(tflops, 1), 'compulsory_tb_per_s': round(tbs, 2),
+            'bound': 'hbm' if hbm_bound else 'mfma',
+            'frac_of_its_bound': round(tbs / (HBM_PEAK_GBS / 1e3) if hbm_bound else tflops / MFMA_PEAK_TFLOPS, 3)}
+
+
 def family_rooflines(step, batch_size, steps=3, perception_flops=True):
     """Per-family rooflines of the training step, MEASURED IN THIS RUN: `steps` extra steps (after the timed region, so
     that `value` is untouched) with every C-ABI call bracketed by events on its own stream (stp3_amd/profiling.py).
@@ -417,9 +427,9 @@ def family_rooflines(step, batch_size, steps=3, perception_flops=True):
                        'split_ms': {k: round(fam[k]['ms'] / steps, 3) for k in ('conv_fwd_dgrad', 'conv_wgrad') if k in fam},
                        # where the family's time goes: the most expensive launched shapes (forward and data gradient
                        # share the entry point: a data gradient shows up as the forward shape with Cin <-> Cout)
-                       'top_shapes': [{'pass': a['family'][5:], 'shape': a['shape'], 'calls_per_step': a['calls'] // steps,
-                                       'ms_per_step': round(a['ms'] / steps, 3),
-                                       'tflops': round(a['work'] / (a['ms'] * 1e-3) / 1e12, 1)} for a in shapes]}
+                       # ... each against ITS roof: a shape whose flops per compulsory byte are below the part's ridge
+                       # (2.5 PF / 8 TB/s = 312) is a streaming kernel with a matrix product inside and is priced in TB/s
+                       'top_shapes': [_shape_entry(a, steps) for a in shapes]}
     for name in ('batchnorm', 'depthwise', 'squeeze_excite', 'mbconv'):
         if name not in fam:
             continue

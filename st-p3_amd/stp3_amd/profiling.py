@@ -9,7 +9,7 @@ proxy that brackets every call listed in ``WORK`` with two events; ``summary()``
 import torch
 
 ENABLED = False
-RECORDS = []          # (family, work, start_event, end_event, shape label or None)
+RECORDS = []          # (family, work, start_event, end_event, shape label or None, compulsory bytes or None)
 
 
 def _obj(arg):
@@ -24,6 +24,19 @@ def _esize(dtype_code):
 def _conv_flops(args):
     d = _obj(args[0])
     return 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.KH * d.KW * d.Cin
+
+
+def _conv_bytes(args):
+    """Compulsory bytes of one convolution call: input, output (bf16 / float32) and weights once."""
+    d = _obj(args[0])
+    return (2.0 * d.N * d.H * d.W * d.Cin + float(_esize(1 if d.out_dtype == 1 else 0)) * d.N * d.Ho * d.Wo * d.Cout
+            + 2.0 * d.Cout * d.KH * d.KW * d.Cin)
+
+
+def _wgrad_bytes(args):
+    """... of one weight-gradient call: both bf16 operands and the float32 result once."""
+    d = _obj(args[0])
+    return 2.0 * d.N * d.H * d.W * d.Cin + 2.0 * d.N * d.Ho * d.Wo * d.Cout + 4.0 * d.Cout * d.KH * d.KW * d.Cin
 
 
 def _conv_label(args):
@@ -106,7 +119,8 @@ class TimedLib:
                 start.record()
                 rc = fn(*args)
                 end.record()
-                RECORDS.append((family, work(args), start, end, label(args) if label else None))
+                RECORDS.append((family, work(args), start, end, label(args) if label else None,
+                                (_wgrad_bytes if 'wgrad' in name else _conv_bytes)(args) if label else None))
                 return rc
         self.__dict__[name] = wrapped
         return wrapped
@@ -123,7 +137,7 @@ def summary():
     """family -> {'calls', 'ms', 'work'} over everything recorded since ``enable()`` (synchronises)."""
     torch.cuda.synchronize()
     out = {}
-    for family, work, s, e, _ in RECORDS:
+    for family, work, s, e, _, _ in RECORDS:
         a = out.setdefault(family, {'calls': 0, 'ms': 0.0, 'work': 0.0})
         a['calls'] += 1
         a['ms'] += s.elapsed_time(e)
@@ -136,11 +150,12 @@ def by_shape(top=12):
     [{'family', 'shape', 'calls', 'ms', 'work'}] over everything recorded since ``enable()`` (synchronises)."""
     torch.cuda.synchronize()
     out = {}
-    for family, work, s, e, label in RECORDS:
+    for family, work, s, e, label, nbytes in RECORDS:
         if label is None:
             continue
-        a = out.setdefault((family, label), {'family': family, 'shape': label, 'calls': 0, 'ms': 0.0, 'work': 0.0})
+        a = out.setdefault((family, label), {'family': family, 'shape': label, 'calls': 0, 'ms': 0.0, 'work': 0.0, 'bytes': 0.0})
         a['calls'] += 1
         a['ms'] += s.elapsed_time(e)
         a['work'] += work
+        a['bytes'] += nbytes or 0.0
     return sorted(out.values(), key=lambda a: -a['ms'])[:top]
