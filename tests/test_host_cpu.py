@@ -243,3 +243,24 @@ def test_strided_data_gradient_phase_plan(monkeypatch):
         checked += 1
         torch.testing.assert_close(got.double(), want, rtol=2e-2, atol=2e-2 * float(want.abs().max()))
     assert checked >= 8
+
+
+def test_bench_prices_a_shape_against_its_own_roof():
+    """bench.py's ``top_shapes``: a convolution whose flops per compulsory byte are below the part's ridge (2.5 PF / 8 TB/s)
+    is priced in TB/s of its compulsory bytes (input + output + weights once; the weight gradient: both operands + the float32
+    result), anything above it in TFLOP/s against the bf16 MFMA peak."""
+    import ctypes
+    import bench
+    from stp3_amd import _lib, profiling
+    thin = _lib.ConvDims(72, 56, 120, 32, 56, 120, 192, 1, 1, 1, 0, 0, 1, 1, 32, 192, _lib.DTYPE_BF16, 0)       # 1x1 32 -> 192
+    fat = _lib.ConvDims(12, 200, 200, 128, 200, 200, 128, 3, 3, 1, 1, 1, 1, 1, 128, 128, _lib.DTYPE_BF16, 0)    # 3x3 128 -> 128
+    px = 72 * 56 * 120
+    assert profiling._conv_bytes([ctypes.byref(thin)]) == 2.0 * px * (32 + 192) + 2.0 * 32 * 192
+    assert profiling._wgrad_bytes([ctypes.byref(thin)]) == 2.0 * px * (32 + 192) + 4.0 * 32 * 192
+    for dims, want in ((thin, 'hbm'), (fat, 'mfma')):
+        a = {'family': 'conv_fwd_dgrad', 'shape': 's', 'calls': 3, 'ms': 0.3, 'work': 3 * profiling._conv_flops([ctypes.byref(dims)]),
+             'bytes': 3 * profiling._conv_bytes([ctypes.byref(dims)])}
+        e = bench._shape_entry(a, 3)
+        assert e['bound'] == want and e['calls_per_step'] == 1 and abs(e['ms_per_step'] - 0.1) < 1e-9
+        roof = e['compulsory_tb_per_s'] / 8.0 if want == 'hbm' else e['tflops'] / 2500.0
+        assert abs(e['frac_of_its_bound'] - roof) < 2e-3
