@@ -391,6 +391,12 @@ int stp3_bn_bwd_train(const stp3_bn_dims* dims, const void* dy, const void* x, c
 int stp3_bn_dsbias(int32_t N, int32_t C, int32_t rows, const float* sample_sums, const float* gsums, double count,
                    const float* gamma, const float* invstd, float* dsbias, void* stream);
 int stp3_sum_n(int32_t n, int64_t numel, int32_t dtype, const void* const* src, void* y, void* stream);
+/* stp3_sum_n_plane -- stp3_sum_n plus one addend that is constant over the plane of every (sample, channel): the gradient of a
+ *   whole-plane mean (the ASPP image pooling of stp3/layers/convolutions.py:229-240, the pyramid pooling of
+ *   stp3/layers/temporal.py:380-424), which torch materialises as a full tensor before adding it.  The dense tensors are
+ *   channels-last [N][H*W][C] (per_sample = H*W*C elements per sample); plane [N][C] in the tensors' type; added last. */
+int stp3_sum_n_plane(int32_t n, int64_t numel, int32_t dtype, const void* const* src, const void* plane, int64_t per_sample,
+                     int32_t C, void* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense 2-D convolution, bf16 MFMA implicit GEMM, NHWC (csrc/stp3_conv.hip).

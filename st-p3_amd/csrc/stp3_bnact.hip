@@ -593,8 +593,12 @@ __global__ __launch_bounds__(kThreads) void bn_dsbias_kernel(int N, int C, float
 struct SumPtrs {
     const void* p[8];
 };
+// plane (nullable): one more addend that is CONSTANT over the plane of every (sample, channel) -- the gradient of a whole-plane
+// mean, [N][C] in the tensors' type -- for channels-last tensors [N][H*W][C]: vector i belongs to sample i / vps and to the
+// channel vector i % cvs (vps = H*W*C / VEC vectors per sample, cvs = C / VEC).  Added last, in float32, before the one rounding.
 template <typename T, int VEC>
-__global__ __launch_bounds__(kThreads) void sum_n_kernel(int n, size_t nvec, SumPtrs src, T* __restrict__ y) {
+__global__ __launch_bounds__(kThreads) void sum_n_kernel(int n, size_t nvec, SumPtrs src, T* __restrict__ y,
+                                                         const T* __restrict__ plane, unsigned vps, unsigned cvs) {
     typedef typename Io<T, VEC>::Raw Raw;
     const size_t stride = (size_t)gridDim.x * kThreads;
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += 2 * stride) {
@@ -621,6 +625,17 @@ __global__ __launch_bounds__(kThreads) void sum_n_kernel(int n, size_t nvec, Sum
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) acc2[j] += v[j];
                 }
+            }
+        }
+        if (plane) {
+            Io<T, VEC>::load(plane + ((size_t)(i / vps) * cvs + i % cvs) * VEC, v);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] += v[j];
+            if (two) {
+                const size_t i2 = i + stride;
+                Io<T, VEC>::load(plane + ((size_t)(i2 / vps) * cvs + i2 % cvs) * VEC, v);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc2[j] += v[j];
             }
         }
         Io<T, VEC>::store(y + i * VEC, acc);
@@ -845,12 +860,14 @@ int stp3_bn_dsbias(int32_t N, int32_t C, int32_t rows, const float* sample_sums,
     return status();
 }
 
-int stp3_sum_n(int32_t n, int64_t numel, int32_t dtype, const void* const* src, void* y, void* stream) {
+static int sum_n_run(int32_t n, int64_t numel, int32_t dtype, const void* const* src, const void* plane, int64_t per_sample,
+                     int32_t C, void* y, void* stream) {
     if (n < 1 || n > 8 || numel <= 0 || !src || !y) return STP3_EINVAL;
     if (dtype != STP3_DTYPE_F32 && dtype != STP3_DTYPE_BF16) return STP3_EUNSUP;
+    if (plane && (C <= 0 || per_sample <= 0 || per_sample % C || numel % per_sample || per_sample >= (1LL << 32))) return STP3_EINVAL;
     SumPtrs ptrs;
     const int wide = dtype == STP3_DTYPE_BF16 ? 8 : 4;
-    bool vec = numel % wide == 0 && aligned16(y);
+    bool vec = numel % wide == 0 && aligned16(y) && (!plane || (C % wide == 0 && aligned16(plane)));
     for (int k = 0; k < 8; ++k) {
         ptrs.p[k] = k < n ? src[k] : nullptr;
         if (k < n && !src[k]) return STP3_EINVAL;
@@ -860,14 +877,26 @@ int stp3_sum_n(int32_t n, int64_t numel, int32_t dtype, const void* const* src, 
     size_t blocks = (nvec + 2 * kThreads - 1) / (2 * kThreads);
     if (blocks > 16384) blocks = 16384;
     hipStream_t s = (hipStream_t)stream;
+    const int w = vec ? wide : 1;
+    const unsigned vps = plane ? (unsigned)(per_sample / w) : 1u, cvs = plane ? (unsigned)(C / w) : 1u;
     if (dtype == STP3_DTYPE_BF16) {
-        if (vec) hipLaunchKernelGGL((sum_n_kernel<uint16_t, 8>), dim3((unsigned)blocks), dim3(kThreads), 0, s, n, nvec, ptrs, (uint16_t*)y);
-        else hipLaunchKernelGGL((sum_n_kernel<uint16_t, 1>), dim3((unsigned)blocks), dim3(kThreads), 0, s, n, nvec, ptrs, (uint16_t*)y);
+        if (vec) hipLaunchKernelGGL((sum_n_kernel<uint16_t, 8>), dim3((unsigned)blocks), dim3(kThreads), 0, s, n, nvec, ptrs, (uint16_t*)y, (const uint16_t*)plane, vps, cvs);
+        else hipLaunchKernelGGL((sum_n_kernel<uint16_t, 1>), dim3((unsigned)blocks), dim3(kThreads), 0, s, n, nvec, ptrs, (uint16_t*)y, (const uint16_t*)plane, vps, cvs);
     } else {
-        if (vec) hipLaunchKernelGGL((sum_n_kernel<float, 4>), dim3((unsigned)blocks), dim3(kThreads), 0, s, n, nvec, ptrs, (float*)y);
-        else hipLaunchKernelGGL((sum_n_kernel<float, 1>), dim3((unsigned)blocks), dim3(kThreads), 0, s, n, nvec, ptrs, (float*)y);
+        if (vec) hipLaunchKernelGGL((sum_n_kernel<float, 4>), dim3((unsigned)blocks), dim3(kThreads), 0, s, n, nvec, ptrs, (float*)y, (const float*)plane, vps, cvs);
+        else hipLaunchKernelGGL((sum_n_kernel<float, 1>), dim3((unsigned)blocks), dim3(kThreads), 0, s, n, nvec, ptrs, (float*)y, (const float*)plane, vps, cvs);
     }
     return status();
+}
+
+int stp3_sum_n(int32_t n, int64_t numel, int32_t dtype, const void* const* src, void* y, void* stream) {
+    return sum_n_run(n, numel, dtype, src, nullptr, 0, 0, y, stream);
+}
+
+int stp3_sum_n_plane(int32_t n, int64_t numel, int32_t dtype, const void* const* src, const void* plane, int64_t per_sample,
+                     int32_t C, void* y, void* stream) {
+    if (!plane) return STP3_EINVAL;
+    return sum_n_run(n, numel, dtype, src, plane, per_sample, C, y, stream);
 }
 
 // ---- single-process composites: the same launches as the split calls above, one host crossing each ----

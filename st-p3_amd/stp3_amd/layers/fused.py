@@ -320,6 +320,10 @@ class _PlaneMean(torch.autograd.Function):
     def backward(ctx, g):
         (n, c, h, w), dtype, cl = ctx.meta
         g = (g * (1.0 / (h * w))).to(dtype).view(n, c, 1, 1).expand(n, c, h, w)
+        if g.is_cuda and cl and dtype in (torch.bfloat16, torch.float32):
+            # the broadcast stays a stride-0 VIEW: the single-pass sum of the input's gradients (ops.fan_out) adds it as a
+            # per-(sample, channel) term; any other consumer sees an ordinary (expanded) tensor
+            return g
         return g.contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format)
 
 

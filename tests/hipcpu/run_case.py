@@ -580,6 +580,19 @@ def fan_out(ops):
     exact = ws[0].double() + ws[1].double()
     out['bf16_unused_handles'] = {'err': rel(x.grad.double(), exact), 'pairwise_err': rel((ws[0] + ws[1]).double(), exact),
                                   'layout': list(x.grad.stride()) == list(x.stride()), 'dtype': str(x.grad.dtype)}
+    # one consumer is a whole-plane mean (layers/fused.plane_mean): its gradient is constant over every (sample, channel) plane
+    # and joins the single-pass sum as a broadcast addend (stp3_sum_n_plane) instead of a materialised tensor
+    from stp3_amd.layers import fused
+    for name, dt in (('bf16_plane', torch.bfloat16), ('f32_plane', torch.float32)):
+        x = torch.randn(3, 16, 5, 7).to(dt).contiguous(memory_format=torch.channels_last).requires_grad_()
+        ws = [torch.randn(3, 16, 5, 7).to(dt).contiguous(memory_format=torch.channels_last) for _ in range(2)]
+        pw = torch.randn(3, 16)
+        handles = ops.fan_out(x, 3)
+        ((handles[0] * ws[0]).sum() + (fused.plane_mean(handles[1]) * pw).sum() + (handles[2] * ws[1]).sum()).backward()
+        plane = (pw / 35.0).to(dt).double()[:, :, None, None].expand(3, 16, 5, 7)
+        exact = ws[0].double() + ws[1].double() + plane
+        out[name] = {'err': rel(x.grad.double(), exact), 'pairwise_err': rel(((ws[0] + ws[1]) + plane.to(dt)).double(), exact),
+                     'layout': list(x.grad.stride()) == list(x.stride()), 'dtype': str(x.grad.dtype)}
     return out
 
 
