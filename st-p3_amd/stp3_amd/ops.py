@@ -1074,13 +1074,17 @@ class _UpsampleBilinear(torch.autograd.Function):
     """Bilinear up-sampling by an integer factor, align_corners=False (stp3_upsample_bilinear_fwd / _bwd)."""
 
     @staticmethod
-    def forward(ctx, x, scale):
+    def forward(ctx, x, scale, out_slot=None):
         _need_gpu(x)
         n, c, h, w = x.shape
         x, ldx = _rows_view(x)
         dt = _lib.DTYPE_BF16 if x.dtype == torch.bfloat16 else _lib.DTYPE_F32
-        y = torch.empty((n, c, h * scale, w * scale), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        dims = _lib.UpsampleDims(n, h, w, c, scale, ldx, c, dt)
+        if out_slot is None:
+            y, ldy = torch.empty((n, c, h * scale, w * scale), dtype=x.dtype, device=x.device, memory_format=torch.channels_last), c
+        else:
+            # written straight into its channel slice of a concatenation's buffer (ops_fused.join_slices)
+            y, ldy = slot_view(out_slot, torch.empty((n, c, h * scale, w * scale), dtype=x.dtype, device='meta'))
+        dims = _lib.UpsampleDims(n, h, w, c, scale, ldx, ldy, dt)
         check(_lib.lib().stp3_upsample_bilinear_fwd(ctypes.byref(dims), x.data_ptr(), y.data_ptr(), _stream_handle()),
               'stp3_upsample_bilinear_fwd')
         ctx.shape = (n, c, h, w, scale, dt)
@@ -1099,7 +1103,7 @@ class _UpsampleBilinear(torch.autograd.Function):
         dims = _lib.UpsampleDims(n, h, w, c, scale, c, ldy, dt)
         check(_lib.lib().stp3_upsample_bilinear_bwd(ctypes.byref(dims), dy.data_ptr(), dx.data_ptr(), _stream_handle()),
               'stp3_upsample_bilinear_bwd')
-        return dx, None
+        return dx, None, None
 
 
 def upsample_bilinear_supported(x, scale):
@@ -1110,11 +1114,11 @@ def upsample_bilinear_supported(x, scale):
     return float(scale) == int(scale) and 1 <= int(scale) <= 4 and x.shape[1] % per == 0
 
 
-def upsample_bilinear(x, scale):
+def upsample_bilinear(x, scale, out_slot=None):
     """F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=False) for channels-last GPU tensors, in the
     tensor's own dtype (float32 arithmetic, one rounding); a channel slice of a concatenation's gradient is read in
     place by the backward."""
-    return _UpsampleBilinear.apply(x, int(scale))
+    return _UpsampleBilinear.apply(x, int(scale), out_slot)
 
 
 class _CausalPair(torch.autograd.Function):

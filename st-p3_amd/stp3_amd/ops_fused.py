@@ -332,6 +332,25 @@ class _JoinSlices(torch.autograd.Function):
         return (None,) + tuple(g.split(ctx.sizes, dim=1))
 
 
+class _CopyIntoSlot(torch.autograd.Function):
+    """A tensor that some other operator produced, copied into its channel slice of a concatenation's buffer (the members
+    that CAN write their slice directly do: ``out_slot``); the gradient of the slice goes back as it is."""
+
+    @staticmethod
+    def forward(ctx, x, holder, c0):
+        view, _ = slot_view((holder[0], c0), x)
+        view.copy_(x)
+        return view
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None
+
+
+def copy_into_slot(x, out_slot):
+    return _CopyIntoSlot.apply(x, (out_slot[0],), out_slot[1])
+
+
 def join_slices(buf, parts):
     return _JoinSlices.apply((buf,), *parts)
 

@@ -592,7 +592,9 @@ def fan_out(ops):
         plane = (pw / 35.0).to(dt).double()[:, :, None, None].expand(3, 16, 5, 7)
         exact = ws[0].double() + ws[1].double() + plane
         out[name] = {'err': rel(x.grad.double(), exact), 'pairwise_err': rel(((ws[0] + ws[1]) + plane.to(dt)).double(), exact),
-                     'layout': list(x.grad.stride()) == list(x.stride()), 'dtype': str(x.grad.dtype)}
+                     'layout': list(x.grad.stride()) == list(x.stride()), 'dtype': str(x.grad.dtype),
+                     # the forward: the whole-plane mean itself (stp3_se_pool) against the float64 mean of the same values
+                     'mean_err': rel(fused.plane_mean(x.detach()).double(), x.detach().double().mean((2, 3)))}
     return out
 
 

@@ -422,3 +422,30 @@ def test_temporal_block_paths_written_into_one_buffer_bit_equal(monkeypatch, cha
     assert len(cat) == len(slot) and float(cat[0].float().abs().max()) > 0
     for i, (a, b) in enumerate(zip(cat, slot)):
         assert a is not None and b is not None and torch.equal(a, b), i
+
+
+def test_upsampling_concat_written_into_one_buffer_bit_equal(monkeypatch):
+    """UpsamplingConcat (stp3/layers/convolutions.py:183-205): the up-sampling kernel writes into its channel slice of the
+    3x3 convolution's operand and the skip is copied into the other, instead of ``torch.cat`` of the two -- against the
+    concatenating form: output, both input gradients and every parameter gradient bit for bit."""
+    from stp3_amd.layers import convolutions, fused
+    from stp3_amd.utils import to_channels_last
+
+    def run(slots):
+        monkeypatch.setattr(fused, 'slot_ok', (lambda x: x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16) if slots
+                            else (lambda x: False))
+        torch.manual_seed(6)
+        mod = to_channels_last(convolutions.UpsamplingConcat(160 + 56, 64).cuda())
+        mod.train()
+        g = torch.Generator().manual_seed(2)
+        lo = torch.randn(3, 160, 14, 30, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+        skip = torch.randn(3, 56, 28, 60, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = mod(lo, skip)
+        y.backward(torch.randn(y.shape, generator=g).cuda().to(y.dtype))
+        return [y.detach(), lo.grad, skip.grad] + [p.grad for p in mod.parameters()]
+
+    cat, slot = run(False), run(True)
+    assert len(cat) == len(slot) and float(cat[0].float().abs().max()) > 0
+    for i, (a, b) in enumerate(zip(cat, slot)):
+        assert a is not None and b is not None and torch.equal(a, b), i
