@@ -61,7 +61,10 @@ def test_step_runs_and_call_mix(recorder, tmp_path):
         == 22 * STEPS
     assert calls['stp3_dwconv2d_fwd_stats'] == 0
     assert calls['stp3_dwconv2d_bwd_weight'] == 0                   # (the weight gradient leaves in the parameter's layout)
-    assert calls['stp3_dwconv2d_fwd'] == calls['stp3_se_pool'] == calls['stp3_se_scale'] == 0
+    assert calls['stp3_dwconv2d_fwd'] == calls['stp3_se_scale'] == 0
+    # (stp3_se_pool: the five whole-plane means of a step -- pyramid pooling of the two temporal blocks, image pooling of the
+    # three ASPP heads -- layers/fused.plane_mean; the squeeze of the MBConv blocks is stp3_se_pool_act)
+    assert calls['stp3_se_pool'] == 5 * STEPS, calls['stp3_se_pool']
     assert calls['stp3_se_mlp_fwd'] == calls['stp3_se_mlp_bwd'] == 22 * STEPS
     for fused in ('stp3_se_pool_act', 'stp3_mbconv_scale_act', 'stp3_mbconv_bwd_reduce',
                   'stp3_mbconv_bwd_coef', 'stp3_mbconv_bwd_apply'):
