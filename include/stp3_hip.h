@@ -398,6 +398,15 @@ int stp3_sum_n(int32_t n, int64_t numel, int32_t dtype, const void* const* src, 
 int stp3_sum_n_plane(int32_t n, int64_t numel, int32_t dtype, const void* const* src, const void* plane, int64_t per_sample,
                      int32_t C, void* y, void* stream);
 
+/* stp3_linear_fwd / _bwd -- y [M][N] = x [M][K] w[N][K]^T + b[N] (b may be NULL), float32, for the pooled descriptors of the BEV
+ *   networks: 1x1 convolutions of maps that are constant over the plane (ASPP image pooling, stp3/layers/convolutions.py:229-240;
+ *   pyramid pooling, stp3/layers/temporal.py:380-424; the ego-motion planes, stp3/models/stp3.py:145-152) are products of a few
+ *   rows whose time is launch latency -- one launch forward, ONE backward for dx [M][K], dw [N][K] and db [N] (each may be NULL:
+ *   not needed).  Deterministic: every sum is split over 16 lanes in a fixed way and finished by a fixed tree. */
+int stp3_linear_fwd(int32_t M, int32_t K, int32_t N, const float* x, const float* w, const float* b, float* y, void* stream);
+int stp3_linear_bwd(int32_t M, int32_t K, int32_t N, const float* dy, const float* x, const float* w, float* dx, float* dw,
+                    float* db, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Dense 2-D convolution, bf16 MFMA implicit GEMM, NHWC (csrc/stp3_conv.hip).
  * Replaces the nn.Conv2d (and frame-folded nn.Conv3d) contractions of stp3/layers/convolutions.py:183-280,

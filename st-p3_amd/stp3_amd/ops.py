@@ -1070,6 +1070,47 @@ def fan_out(x, n):
     return list(_FanOut.apply(x, n))
 
 
+class _SmallLinear(torch.autograd.Function):
+    """y = x W^T + b for a handful of rows, float32 (stp3_linear_fwd / _bwd): one launch each way."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _need_gpu(x, w)
+        x, w = x.contiguous(), w.contiguous()
+        m, k = x.shape
+        n = w.shape[0]
+        y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+        check(_lib.lib().stp3_linear_fwd(m, k, n, x.data_ptr(), w.data_ptr(), _opt_ptr(b), y.data_ptr(), _stream_handle()),
+              'stp3_linear_fwd')
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        m, k = x.shape
+        n = w.shape[0]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        db = torch.empty(n, dtype=torch.float32, device=x.device) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        check(_lib.lib().stp3_linear_bwd(m, k, n, dy.data_ptr(), x.data_ptr(), w.data_ptr(), _opt_ptr(dx), _opt_ptr(dw), _opt_ptr(db),
+                                         _stream_handle()), 'stp3_linear_bwd')
+        return dx, dw, db
+
+
+def small_linear_supported(x, w, b=None):
+    """float32 GPU matrices, few enough multiply-adds that the product is launch latency (the pooled descriptors: <= 72 rows)."""
+    return (x.is_cuda and x.dim() == 2 and w.dim() == 2 and x.dtype == w.dtype == torch.float32 and x.shape[1] == w.shape[1]
+            and (b is None or (b.dtype == torch.float32 and b.dim() == 1 and b.is_contiguous()))
+            and x.shape[0] * x.shape[1] * w.shape[0] <= (1 << 22))
+
+
+def small_linear(x, w, b=None):
+    return _SmallLinear.apply(x, w, b)
+
+
 class _UpsampleBilinear(torch.autograd.Function):
     """Bilinear up-sampling by an integer factor, align_corners=False (stp3_upsample_bilinear_fwd / _bwd)."""
 

@@ -547,6 +547,28 @@ def wgrad_defer(ops):
             'nonzero': float(plain[0].abs().max()) > 0, 'pending': [p0, p1, p2], 'left_over': ops.pending_wgrad_reductions()}
 
 
+def small_linear(ops):
+    """stp3_linear_fwd / _bwd (the pooled descriptors' 1x1 convolutions as one launch each way) against float64 torch: output,
+    input / weight / bias gradients; with and without a bias, row counts that are not multiples of the 16-lane split."""
+    import torch.nn.functional as F
+    out = {}
+    torch.manual_seed(0)
+    for name, (m, k, n, bias) in {'m12_k64_n128_b': (12, 64, 128, True), 'm16_k70_n23': (16, 70, 23, False),
+                                  'm72_k160_n64_b': (72, 160, 64, True), 'm3_k6_n35': (3, 6, 35, False)}.items():
+        x, w = torch.randn(m, k, requires_grad=True), torch.randn(n, k, requires_grad=True)
+        b = torch.randn(n, requires_grad=True) if bias else None
+        assert ops.small_linear_supported(x, w, b)
+        y = ops.small_linear(x, w, b)
+        gy = torch.randn(m, n)
+        y.backward(gy)
+        xr, wr = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
+        br = b.detach().double().requires_grad_() if bias else None
+        F.linear(xr, wr, br).backward(gy.double())
+        out[name] = {'y': rel(y.detach(), F.linear(xr, wr, br).detach()), 'dx': rel(x.grad, xr.grad), 'dw': rel(w.grad, wr.grad),
+                     'db': rel(b.grad, br.grad) if bias else 0.0}
+    return out
+
+
 def fan_out(ops):
     """ops.fan_out: the n gradients of a tensor with n consumers added in one pass (stp3_sum_n) -- against the sum in
     float64; bf16 (float32 accumulation, one rounding: at least as close as the pairwise bf16 additions of autograd) and
@@ -1514,7 +1536,7 @@ def gru_cell(ops):
 
 
 CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_f32_bn_eval, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_rolled, lift_c64_frames, lift_coarse_grid, lift_tall, lift_c64_rows56, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
-                                 conv, conv_f32, wgrad_defer, fan_out, aspp_join, pointwise_bn, pointwise_stream, decoder_heads, dwconv, layernorm, gru_cell, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
+                                 conv, conv_f32, wgrad_defer, small_linear, fan_out, aspp_join, pointwise_bn, pointwise_stream, decoder_heads, dwconv, layernorm, gru_cell, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
 
 if __name__ == '__main__':
     ops_mod = setup(sys.argv[1])

@@ -64,7 +64,8 @@ def test_bench_main_dry_run(tmp_path, workload):
                   'stp3_se_mlp_bwd', 'stp3_mbconv_scale_act', 'stp3_mbconv_bwd_reduce', 'stp3_mbconv_bwd_coef',
                   'stp3_mbconv_bwd_apply',
                   'stp3_dwconv2d_bwd_data', 'stp3_dwconv2d_bwd_weight_oihw', 'stp3_optim_clip_adam',
-                  'stp3_ce_topk_fwd', 'stp3_ce_topk_bwd', 'stp3_warp_nearest',
+                  'stp3_ce_topk_fwd', 'stp3_ce_topk_bwd', 'stp3_warp_nearest', 'stp3_linear_fwd', 'stp3_linear_bwd',
+                  'stp3_sum_n_plane', 'stp3_se_pool',
                   'stp3_causal_pair_fwd', 'stp3_causal_pair_bwd', 'stp3_upsample_bilinear_fwd', 'stp3_upsample_bilinear_bwd'):
         assert entry + ' ' in trace, entry
     if workload == 'c3':                                      # the instance / flow regression losses exist in c3 only

@@ -449,3 +449,24 @@ def test_upsampling_concat_written_into_one_buffer_bit_equal(monkeypatch):
     assert len(cat) == len(slot) and float(cat[0].float().abs().max()) > 0
     for i, (a, b) in enumerate(zip(cat, slot)):
         assert a is not None and b is not None and torch.equal(a, b), i
+
+
+@pytest.mark.parametrize('m,k,n,bias', [(12, 64, 128, True), (16, 70, 23, False), (72, 160, 64, True), (12, 6, 35, False)])
+def test_small_linear_matches_torch(m, k, n, bias):
+    """stp3_linear_fwd / _bwd -- the 1x1 convolutions of the pooled descriptors (stp3/layers/convolutions.py:229-240,
+    stp3/layers/temporal.py:380-424) as one launch each way -- against float64 torch, rtol 1e-5 (float32 sums of <= 160 terms)."""
+    from stp3_amd import ops
+    g = torch.Generator().manual_seed(m + k)
+    x = torch.randn(m, k, generator=g).cuda().requires_grad_()
+    w = torch.randn(n, k, generator=g).cuda().requires_grad_()
+    b = torch.randn(n, generator=g).cuda().requires_grad_() if bias else None
+    assert ops.small_linear_supported(x, w, b)
+    y = ops.small_linear(x, w, b)
+    gy = torch.randn(m, n, generator=g).cuda()
+    y.backward(gy)
+    xr, wr = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
+    br = b.detach().double().requires_grad_() if bias else None
+    yr = F.linear(xr, wr, br)
+    yr.backward(gy.double())
+    for got, want in ((y, yr), (x.grad, xr.grad), (w.grad, wr.grad)) + (((b.grad, br.grad),) if bias else ()):
+        torch.testing.assert_close(got.detach().double(), want.detach(), rtol=1e-5, atol=1e-5)

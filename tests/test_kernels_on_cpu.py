@@ -28,7 +28,7 @@ import build as hipcpu_build  # noqa: E402
 
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
 ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('layernorm', {}), ('gru_cell', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
-           ('conv', {}), ('conv_f32', {}), ('wgrad_defer', {}), ('fan_out', {}), ('aspp_join', {}), ('pointwise_bn', {}), ('pointwise_stream', {}), ('decoder_heads', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('labels', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}), ('lift_c64_rolled', {}),
+           ('conv', {}), ('conv_f32', {}), ('wgrad_defer', {}), ('small_linear', {}), ('fan_out', {}), ('aspp_join', {}), ('pointwise_bn', {}), ('pointwise_stream', {}), ('decoder_heads', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('labels', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}), ('lift_c64_rolled', {}),
            ('lift_c64_frames', {}), ('lift_c64_rows56', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
 ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'layernorm', 'gru_cell', 'bn_act', 'conv', 'conv_bn', 'pointwise_bn', 'pointwise_stream', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'labels', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)]
@@ -215,6 +215,12 @@ def test_deferred_weight_gradient_sums_are_bit_equal(results):
     assert r['nonzero'] and r['direct_equal'] and r['deferred_equal'] and r['left_over'] == 0, r
     # plain / direct: nothing pending after backward; deferred: the two single-use weights, in both passes
     assert r['pending'] == [[0, 0], [0, 0], [2, 2]], r
+
+
+def test_small_linear_kernels(results):
+    for name, r in _get(results, 'small_linear').items():
+        if name != 'seconds':
+            assert max(r.values()) <= 1e-6, (name, r)
 
 
 def test_layernorm_over_channels(results):
