@@ -464,6 +464,15 @@ int stp3_conv2d_bn_bwd_reduce(const stp3_conv_dims* dims, const void* x, const v
 int stp3_conv2d_bn_bwd_apply(const stp3_conv_dims* dims, const void* x, const void* w, const void* dz, int32_t ldz,
                              const float* coef, int32_t act, const float* gsums, double count, void* dy, void* stream);
 
+/* stp3_conv2d_fwd_add -- stp3_conv2d_fwd (bf16 output, no statistics) with y = bf16(bf16(conv + bias) + add): the DATA GRADIENT
+ * of a block's first convolution written together with the gradient of the block's skip connection (`add` = the gradient at
+ * the block output, [N][Ho][Wo][ldadd >= Cout] bf16) -- what torch.autograd does with one more pass over both tensors when a
+ * tensor has two consumers (the identity skips of the MBConv blocks, stp3/models/encoder.py:57-97, and of the decoder's
+ * ResNet blocks, stp3/models/decoder.py:22-30).  Same bits as the separate addition (it adds the rounded convolution result).
+ * Requires Cout % 8 == 0, ldy % 8 == 0, ldadd % 8 == 0 and 16-byte aligned y / add. */
+int stp3_conv2d_fwd_add(const stp3_conv_dims* dims, const void* x, const void* w, const float* bias, const void* add,
+                        int32_t ldadd, void* y, void* stream);
+
 /* stp3_conv2d_wgrad -- dw[co][kh][kw][ci] = sum_{n,ho,wo} dy[n][ho][wo][co] * x[n][ho*stride-pad_h+kh*dil_h][..][ci]
  * (the weight gradient autograd derives for the convolutions above), float32 output in the weight's own
  * [Cout][KH][KW][Cin] layout.  dy [N][Ho][Wo][ldy >= Cout] and x [N][H][W][ldx >= Cin] are bf16; the pixel

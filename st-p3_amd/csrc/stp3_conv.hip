@@ -92,6 +92,8 @@ __device__ __forceinline__ int lds_piece(int r, int j) { return (r * 8 + (j ^ ((
 enum { kModePlain = 0, kModeStats = 1, kModeBnAct = 2, kModeBwdReduce = 3, kModeBwdApply = 4 };
 
 struct EpiArgs {
+    const uint16_t* add;        // PLAIN mode, bf16 output: y = bf16(bf16(conv + bias) + add[m][co]) -- the gradient of a skip
+    int ldadd;                  // connection added where the data gradient is written ([M][ldadd] bf16, 16-byte pieces)
     const float* coef;          // [scale | shift | mean | invstd][Cout] (stp3_bn_finalize)
     const uint16_t* dz;         // gradient at the activation output, [M][ldz] bf16 (BWD_*)
     const float* gsums;         // [2][Cout]: sum g, sum g * xhat over all replicas (BWD_APPLY)
@@ -331,9 +333,19 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvDims d, int tiles
             const int p = e / (BN / 8), c = (e - p * (BN / 8)) * 8;
             const int m = m0 + p, co = co0 + c;
             if (m >= d.M || co >= d.Cout) continue;
-            const uint4 v = *reinterpret_cast<const uint4*>(tile + p * ldt + c);
+            uint4 v = *reinterpret_cast<const uint4*>(tile + p * ldt + c);
             uint16_t* dst = yo + (size_t)m * d.ldy + co;
             if (co + 7 < d.Cout && (d.ldy & 7) == 0) {
+                if (ep.add) {                                  // (the host passes `add` only for whole 16-byte pieces)
+                    const uint4 a = *reinterpret_cast<const uint4*>(ep.add + (size_t)m * ep.ldadd + co);
+                    const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, aw[4] = {a.x, a.y, a.z, a.w};
+                    uint32_t ow[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ow[r] = pack_bf16(__uint_as_float(vw[r] << 16) + __uint_as_float(aw[r] << 16),
+                                          __uint_as_float(vw[r] & 0xffff0000u) + __uint_as_float(aw[r] & 0xffff0000u));
+                    v = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                }
                 *reinterpret_cast<uint4*>(dst) = v;
             } else {
                 const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
@@ -1364,7 +1376,12 @@ int igemm_run(const stp3_conv_dims* p, const void* x, const void* w, const float
         partial = (float*)workspace;
     }
     if (y && ((uintptr_t)y & 15)) return STP3_EUNSUP;
-    if (pointwise_applies(p, y)) {
+    if (ep.add) {
+        // the skip-gradient addend: plain mode, bf16 output, whole 16-byte channel pieces on both sides
+        if (mode != kModePlain || d.out_f32 || p->Cout % 8 || p->ldy % 8 || ep.ldadd % 8 || ep.ldadd < p->Cout ||
+            ((uintptr_t)ep.add & 15) || ((uintptr_t)y & 15))
+            return STP3_EUNSUP;
+    } else if (pointwise_applies(p, y)) {
         ep.act = act;
         return pointwise_run(d, x, w, y, sums, partial, gx, s, mode, ep);
     }
@@ -1406,6 +1423,15 @@ extern "C" {
 int stp3_conv2d_fwd(const stp3_conv_dims* p, const void* x, const void* w, const float* bias, void* y, float* sums,
                     void* workspace, size_t workspace_bytes, void* stream) {
     return igemm_run(p, x, w, bias, y, sums, workspace, workspace_bytes, stream, kModePlain, STP3_ACT_NONE, EpiArgs());
+}
+
+int stp3_conv2d_fwd_add(const stp3_conv_dims* p, const void* x, const void* w, const float* bias, const void* add, int32_t ldadd,
+                        void* y, void* stream) {
+    if (!add) return STP3_EINVAL;
+    EpiArgs ep = EpiArgs();
+    ep.add = (const uint16_t*)add;
+    ep.ldadd = ldadd;
+    return igemm_run(p, x, w, bias, y, nullptr, nullptr, 0, stream, kModePlain, STP3_ACT_NONE, ep);
 }
 
 // ---- convolution -> BatchNorm -> activation WITHOUT the convolution output in memory (see kMode*) -------------------

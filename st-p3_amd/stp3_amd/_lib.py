@@ -198,6 +198,7 @@ SIGNATURES = {
     'stp3_sum_n_plane': (c_int, [c_int32, ctypes.c_int64, c_int32, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_void_p, c_void_p]),
     'stp3_conv2d_fwd_workspace': (c_int, [ctypes.POINTER(ConvDims), ctypes.POINTER(c_size_t)]),
     'stp3_conv2d_fwd': (c_int, [ctypes.POINTER(ConvDims)] + [c_void_p] * 6 + [c_size_t, c_void_p]),
+    'stp3_conv2d_fwd_add': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     'stp3_conv2d_fwd_stats': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'stp3_conv2d_fwd_bnact': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     'stp3_conv2d_bn_bwd_reduce': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32,

@@ -89,6 +89,8 @@ class StaticSamePadConv2d(nn.Conv2d):
 
 # expand convolution -> BN0 -> swish through ops_fused._PointwiseBnAct (the convolution output is recomputed, never stored)
 EXPAND_WITHOUT_E0 = True
+# the gradient of a block's identity skip added by the expand convolution's data-gradient kernel (ops.SkipCarrier)
+SKIP_GRADIENT_IN_DGRAD = True
 
 
 class Swish(nn.Module):
@@ -124,16 +126,25 @@ class MBConvBlock(nn.Module):
                 and self.in_ch % 8 == 0 and (self.in_ch * self.expand) % 8 == 0
                 # the statistics epilogue of the convolution kernel reduces at most 65 536 row tiles of 128 pixels
                 and (x.shape[0] * x.shape[2] * x.shape[3] + 127) // 128 <= ops._CONV_MAX_STAT_TILES)
+        carrier = None
         if fuse:
             from .. import ops_fused
             group = None if _fused._sync_world(self._bn1) > 1 else False
+            # the identity skip's gradient travels from the project BatchNorm (which adds the skip) to the expand convolution
+            # (which consumes the block input) and joins its data gradient in the kernel that writes it, instead of being
+            # added by the autograd engine in a pass of its own (bf16 blocks with an expand layer and an input gradient)
+            if (SKIP_GRADIENT_IN_DGRAD and self.expand != 1 and self.stride == 1 and self.in_ch == self.out_ch
+                    and x.requires_grad and torch.is_grad_enabled() and x.dtype == torch.bfloat16
+                    and x.is_contiguous(memory_format=torch.channels_last)):
+                carrier = ops.SkipCarrier()
         if self.expand != 1:
             if fuse and EXPAND_WITHOUT_E0 and ops_fused.pointwise_bn_act_supported(x, self._expand_conv, self._bn0) \
                     and ops_fused.pointwise_bn_act_pays(x, self._expand_conv):
                 # the expanded pre-activation tensor (6x the block input) is never stored: statistics pass + recomputation
-                x = ops_fused.pointwise_bn_act(x, self._expand_conv, self._bn0, ACT_SWISH, group=group)
+                x = ops_fused.pointwise_bn_act(x, self._expand_conv, self._bn0, ACT_SWISH, group=group, skip_carrier=carrier)
             elif fuse:
-                x = ops_fused.conv_bn_act(x, self._expand_conv.weight, None, self._bn0, ACT_SWISH, group=group)
+                x = ops_fused.conv_bn_act(x, self._expand_conv.weight, None, self._bn0, ACT_SWISH, group=group,
+                                          skip_carrier=carrier)
             else:
                 x = bn_act(self._bn0, self._expand_conv(x), ACT_SWISH)
         from .. import ops_fused
@@ -160,7 +171,8 @@ class MBConvBlock(nn.Module):
             oscale = torch.floor(keep + torch.rand(x.shape[0], dtype=torch.float32, device=x.device)) / keep
         if fuse:
             return ops_fused.conv_bn_act(x, self._project_conv.weight, None, self._bn2, ACT_NONE, inputs if skip else None,
-                                         RES_AFTER_ACT if skip else _fused.RES_NONE, group=group, oscale=oscale)
+                                         RES_AFTER_ACT if skip else _fused.RES_NONE, group=group, oscale=oscale,
+                                         res_carrier=carrier if skip else None)
         x = self._project_conv(x)
         if skip:
             return bn_act(self._bn2, x, ACT_NONE, res=inputs, res_mode=RES_AFTER_ACT, oscale=oscale)

@@ -1217,7 +1217,23 @@ def _conv_out(size, k, stride, pad, dil):
 _CONV_STAT_WS = {}
 
 
-def _conv2d_launch(x, wb, bias, stride, pad, dil, out_dtype, sums_ptr=None, out_hw=None):
+class SkipCarrier:
+    """The gradient of a block's identity skip, handed from the operator that adds the skip (the BatchNorm at the block's end:
+    its backward runs first and stores the gradient here instead of returning it) to the operator that consumes the block
+    input (the block's first convolution: its data-gradient kernel adds it in its epilogue, stp3_conv2d_fwd_add).  Replaces the
+    pass torch.autograd makes over both tensors when a tensor has two consumers.  One carrier per block and forward pass; both
+    operators must belong to the same backward pass (they do: one feeds the other)."""
+    __slots__ = ('grad',)
+
+    def __init__(self):
+        self.grad = None
+
+    def take(self):
+        g, self.grad = self.grad, None
+        return g
+
+
+def _conv2d_launch(x, wb, bias, stride, pad, dil, out_dtype, sums_ptr=None, out_hw=None, add=None):
     """x (N,Cin,H,W) bf16 with channels-last memory (row stride ld >= Cin); wb (Cout,Cin,KH,KW) bf16 channels-last.
     ``sums_ptr``: device address of a float32 [2][Cout] buffer that receives the BatchNorm statistics of y (bf16 y).
     ``out_hw``: output size when it is not the one ``pad`` implies on both sides (``pad`` is the top / left padding;
@@ -1243,6 +1259,18 @@ def _conv2d_launch(x, wb, bias, stride, pad, dil, out_dtype, sums_ptr=None, out_
             ws = torch.empty(max(nbytes.value, 8 << 20), dtype=torch.uint8, device=x.device)
             _CONV_STAT_WS[key] = ws
         ws_ptr, ws_bytes = ws.data_ptr(), nbytes.value
+    if add is not None:
+        # y = conv + add in the kernel's epilogue (the skip's gradient joins the data gradient where it is written)
+        assert sums_ptr is None
+        add, ldadd = _rows_view(add)
+        if (out_dtype == torch.bfloat16 and add.dtype == torch.bfloat16 and tuple(add.shape) == tuple(y.shape) and cout % 8 == 0
+                and ldadd % 8 == 0 and add.data_ptr() % 16 == 0):
+            check(lib.stp3_conv2d_fwd_add(ctypes.byref(dims), _ptr(x), _ptr(wb), _opt_ptr(bias), _ptr(add), ldadd, _ptr(y),
+                                          _stream()), 'stp3_conv2d_fwd_add')
+            return y
+        check(lib.stp3_conv2d_fwd(ctypes.byref(dims), _ptr(x), _ptr(wb), _opt_ptr(bias), _ptr(y), None, None, 0, _stream()),
+              'stp3_conv2d_fwd')
+        return y + add.to(y.dtype)
     check(lib.stp3_conv2d_fwd(ctypes.byref(dims), _ptr(x), _ptr(wb), _opt_ptr(bias), _ptr(y), sums_ptr, ws_ptr, ws_bytes,
                               _stream()), 'stp3_conv2d_fwd')
     return y
@@ -1618,7 +1646,7 @@ def _strided_dgrad(dy, wt, x_shape, stride, pad, cache, out_dtype=torch.bfloat16
     return dx
 
 
-def conv2d_data_grad(dy, wb, weight_ref, x_shape, stride, pad, dil, out_dtype=torch.bfloat16):
+def conv2d_data_grad(dy, wb, weight_ref, x_shape, stride, pad, dil, out_dtype=torch.bfloat16, add=None):
     """dL/dx of a dense convolution on the MFMA kernel: a stride-1 convolution of dy with the taps flipped and
     Cin / Cout swapped -- per input phase for a strided layer (``_strided_dgrad``), over the zero-stuffed dy when that
     does not apply.  dy (N,Cout,Ho,Wo) bf16 channels-last; wb (Cout,Cin,KH,KW) bf16; ``weight_ref``: the parameter wb
@@ -1653,8 +1681,8 @@ def conv2d_data_grad(dy, wb, weight_ref, x_shape, stride, pad, dil, out_dtype=to
             uw = w + 2 * pad[1] - dil[1] * (kw - 1)
             g = torch.empty((n, cout, uh, uw), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last).zero_()
             g[:, :, ::stride, ::stride][:, :, :ho, :wo] = dy
-        dx = _conv2d_launch(g, wt, None, 1, bpad, dil, out_dtype)
-    return dx
+        return _conv2d_launch(g, wt, None, 1, bpad, dil, out_dtype, add=add)
+    return dx if add is None else dx + add.to(dx.dtype)
 
 
 def channel_sums(t):

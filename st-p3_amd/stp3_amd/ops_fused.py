@@ -42,10 +42,10 @@ def conv2d_v2(x, wb, bias, stride, pad, dil, sums_ptr=None):
 class _ConvBnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, cbias, gamma, beta, res, running_mean, running_var, momentum, eps, act, res_mode,
-                stride, pad, dil, group, oscale=None, out_slot=None):
+                stride, pad, dil, group, oscale=None, out_slot=None, res_carrier=None, skip_carrier=None):
         return ops.drive_exchange(_ConvBnAct.forward_steps(ctx, x, weight, cbias, gamma, beta, res, running_mean,
                                                            running_var, momentum, eps, act, res_mode, stride, pad, dil,
-                                                           group, oscale, out_slot), group)
+                                                           group, oscale, out_slot, res_carrier, skip_carrier), group)
 
     @staticmethod
     def backward(ctx, dy):
@@ -53,8 +53,11 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def forward_steps(ctx, x, weight, cbias, gamma, beta, res, running_mean, running_var, momentum, eps, act, res_mode,
-                      stride, pad, dil, group, oscale=None, out_slot=None):
-        """``forward`` as a generator (ops.drive_exchange): yields the [2C] statistics when they need the other replicas.
+                      stride, pad, dil, group, oscale=None, out_slot=None, res_carrier=None, skip_carrier=None):
+        """``res_carrier`` / ``skip_carrier`` (ops.SkipCarrier): this operator ADDS a block's skip (res, RES_AFTER_ACT) and hands
+        the skip's gradient to the carrier instead of returning it / this operator CONSUMES the block input and adds the
+        carrier's gradient to its data gradient in the kernel that writes it.
+        ``forward`` as a generator (ops.drive_exchange): yields the [2C] statistics when they need the other replicas.
         ``out_slot`` = (buffer, first channel): the result is written into that channel slice of a wider channels-last
         tensor (a concatenation that is never copied: ``join_slices``) instead of a tensor of its own."""
         ops._need_gpu(x, weight)
@@ -93,6 +96,7 @@ class _ConvBnAct(torch.autograd.Function):
         if ldo != cout:                         # the backward passes read dy with ITS row stride (set there)
             dims = _lib.BnDims(n, ho * wo, cout, cout, cout, ldr, _lib.DTYPE_BF16, act, res_mode, 0, int(osc is not None))
         ctx.cfg = (dims, count, exchange, group, stride, pad, dil, cbias is not None)
+        ctx.carriers = (res_carrier if (res is not None and res_mode == ops.RES_AFTER_ACT) else None, skip_carrier)
         ctx.weight_ref = ops.note_weight_use(weight)
         ctx.weight_stamp = ops.weight_stamp(weight)
         ctx.dtypes = (weight.dtype, None if cbias is None else cbias.dtype, None if gamma is None else gamma.dtype,
@@ -105,6 +109,7 @@ class _ConvBnAct(torch.autograd.Function):
         ops.check_weight_stamp(ctx.weight_ref, ctx.weight_stamp, 'conv_bn_act backward')
         dims, count, exchange, group, stride, pad, dil, has_cbias = ctx.cfg
         wdt, cbdt, gdt, bdt, rdt = ctx.dtypes
+        res_carrier, skip_carrier = ctx.carriers
         n, rows, c = dims.N, dims.rows, dims.C
         dev = x.device
         lib = _lib.lib()
@@ -153,6 +158,9 @@ class _ConvBnAct(torch.autograd.Function):
             dres = dy
         if dres is not None and rdt is not None and dres.dtype != rdt:
             dres = dres.to(rdt)
+        if res_carrier is not None and dres is not None:
+            res_carrier.grad, dres = dres, None          # (the block's first operator adds it to its data gradient)
+        skip_grad = None if skip_carrier is None else skip_carrier.take()
         # ---- convolution backward (same routes as ops._Conv2dMfma.backward) ------------------------------------
         cout, cin, kh, kw = wb.shape
         dx = dw = dcb = None
@@ -160,7 +168,8 @@ class _ConvBnAct(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         hip_dx = need_dx and cout % 8 == 0 and bpad[0] >= 0 and bpad[1] >= 0
         if hip_dx:
-            dx = ops.conv2d_data_grad(dconv, wb, ctx.weight_ref, x.shape, stride, pad, dil)
+            dx = ops.conv2d_data_grad(dconv, wb, ctx.weight_ref, x.shape, stride, pad, dil, add=skip_grad)
+            skip_grad = None
         need_dw = ctx.needs_input_grad[1]
         need_db = has_cbias and ctx.needs_input_grad[2]
         hip_dw = need_dw and cin % 8 == 0 and cout % 8 == 0
@@ -179,7 +188,9 @@ class _ConvBnAct(torch.autograd.Function):
                 dw = gw.to(wdt)
             if mask[2]:
                 dcb = gb.to(cbdt)
-        return (dx, dw, dcb, dgamma, dbeta, dres) + (None,) * 12
+        if skip_grad is not None:
+            dx = skip_grad if dx is None else dx + skip_grad.to(dx.dtype)
+        return (dx, dw, dcb, dgamma, dbeta, dres) + (None,) * 14
 
 
 class _PointwiseBnAct(torch.autograd.Function):
@@ -193,17 +204,18 @@ class _PointwiseBnAct(torch.autograd.Function):
     Same values: every kernel rounds the accumulators to bf16 before it uses them, as the stored tensor was."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, momentum, eps, act, group):
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, momentum, eps, act, group, skip_carrier=None):
         return ops.drive_exchange(_PointwiseBnAct.forward_steps(ctx, x, weight, gamma, beta, running_mean, running_var,
-                                                                momentum, eps, act, group), group)
+                                                                momentum, eps, act, group, skip_carrier), group)
 
     @staticmethod
     def backward(ctx, dz):
         return ops.drive_exchange(_PointwiseBnAct.backward_steps(ctx, dz), ctx.cfg[3])
 
     @staticmethod
-    def forward_steps(ctx, x, weight, gamma, beta, running_mean, running_var, momentum, eps, act, group):
+    def forward_steps(ctx, x, weight, gamma, beta, running_mean, running_var, momentum, eps, act, group, skip_carrier=None):
         ops._need_gpu(x, weight)
+        ctx.skip_carrier = skip_carrier           # (ops.SkipCarrier: the block's skip gradient joins the data gradient)
         if x.dtype != torch.bfloat16:
             x = x.to(torch.bfloat16)
         wb, _ = ops._bf16_weights(weight)
@@ -269,11 +281,14 @@ class _PointwiseBnAct(torch.autograd.Function):
         dgamma = lsums[1].to(gdt) if gdt is not None and ctx.needs_input_grad[2] else None
         dbeta = lsums[0].to(bdt) if bdt is not None and ctx.needs_input_grad[3] else None
         dx = dw = None
+        skip_grad = None if ctx.skip_carrier is None else ctx.skip_carrier.take()
         if ctx.needs_input_grad[0]:
-            dx = ops.conv2d_data_grad(dconv, wb, ctx.weight_ref, x.shape, 1, (0, 0), (1, 1))
+            dx = ops.conv2d_data_grad(dconv, wb, ctx.weight_ref, x.shape, 1, (0, 0), (1, 1), add=skip_grad)
+        elif skip_grad is not None:
+            dx = skip_grad
         if ctx.needs_input_grad[1]:
             dw = ops._conv2d_wgrad(dconv, x, (cout, cin, 1, 1), 1, (0, 0), (1, 1), leaf=ctx.weight_ref).to(wdt)
-        return (dx, dw, dgamma, dbeta) + (None,) * 6
+        return (dx, dw, dgamma, dbeta) + (None,) * 7
 
 
 def pointwise_bn_act_supported(x, conv, bn):
@@ -298,12 +313,12 @@ def pointwise_bn_act_pays(x, conv):
     return cin <= 128 and conv.weight.shape[0] >= 64 and n * h * w >= 16384
 
 
-def pointwise_bn_act(x, conv, bn, act, group=None):
+def pointwise_bn_act(x, conv, bn, act, group=None, skip_carrier=None):
     """act(bn(conv(x))) for a 1x1 convolution through ``_PointwiseBnAct`` (see there)."""
     if bn.num_batches_tracked is not None:
         ops.bump_batch_counter(bn)
     return _PointwiseBnAct.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, ops.bn_momentum(bn),
-                                 float(bn.eps), int(act), group)
+                                 float(bn.eps), int(act), group, skip_carrier)
 
 
 slot_view = ops.slot_view
@@ -356,7 +371,7 @@ def join_slices(buf, parts):
 
 
 def conv_bn_act(x, weight, cbias, bn, act=ops.ACT_NONE, res=None, res_mode=ops.RES_NONE, stride=1, padding=0, dilation=1,
-                group=None, oscale=None, out_slot=None):
+                group=None, oscale=None, out_slot=None, res_carrier=None, skip_carrier=None):
     """Training-mode conv -> BatchNorm -> activation (-> + skip) through the fused kernels (GPU, bf16)."""
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         ops.bump_batch_counter(bn)
@@ -364,7 +379,7 @@ def conv_bn_act(x, weight, cbias, bn, act=ops.ACT_NONE, res=None, res_mode=ops.R
     return _ConvBnAct.apply(x, weight, cbias, bn.weight, bn.bias, res, bn.running_mean if bn.track_running_stats else None,
                             bn.running_var if bn.track_running_stats else None,
                             ops.bn_momentum(bn), float(bn.eps), int(act), int(res_mode),
-                            s[0], ops._pair(padding), ops._pair(dilation), group, oscale, out_slot)
+                            s[0], ops._pair(padding), ops._pair(dilation), group, oscale, out_slot, res_carrier, skip_carrier)
 
 
 class _SubContext:

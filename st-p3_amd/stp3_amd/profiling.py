@@ -45,7 +45,7 @@ def _conv_label(args):
             f' {d.Cin}->{d.Cout} @{d.Ho}x{d.Wo} x{d.N}')
 
 
-LABEL = {'stp3_conv2d_fwd': _conv_label, 'stp3_conv2d_wgrad': _conv_label, 'stp3_conv2d_wgrad_partials': _conv_label}
+LABEL = {'stp3_conv2d_fwd': _conv_label, 'stp3_conv2d_fwd_add': _conv_label, 'stp3_conv2d_wgrad': _conv_label, 'stp3_conv2d_wgrad_partials': _conv_label}
 
 
 def _bn_bytes(tensors):
@@ -76,6 +76,7 @@ def _se_pool_bytes(args):
 # C-ABI entry -> (family, algorithmic work of one call); flops for 'conv*', bytes for everything else
 WORK = {
     'stp3_conv2d_fwd': ('conv_fwd_dgrad', _conv_flops),
+    'stp3_conv2d_fwd_add': ('conv_fwd_dgrad', _conv_flops),                 # (a data gradient + the skip's gradient)
     'stp3_conv2d_wgrad': ('conv_wgrad', _conv_flops),
     'stp3_conv2d_wgrad_partials': ('conv_wgrad', _conv_flops),              # (the split contraction: all of the layer's flops)
     'stp3_conv2d_wgrad_reduce_batch': ('conv_wgrad', lambda args: 0.0),     # (their deferred sums, one launch per pass: time only)

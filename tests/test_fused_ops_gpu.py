@@ -470,3 +470,36 @@ def test_small_linear_matches_torch(m, k, n, bias):
     yr.backward(gy.double())
     for got, want in ((y, yr), (x.grad, xr.grad), (w.grad, wr.grad)) + (((b.grad, br.grad),) if bias else ()):
         torch.testing.assert_close(got.detach().double(), want.detach(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('shape', [(4, 32, 64, 64), (3, 112, 14, 30)])
+def test_skip_gradient_added_in_the_data_gradient_kernel_bit_equal(monkeypatch, shape):
+    """An MBConv block with an identity skip (stp3/models/encoder.py:57-97 drives efficientnet_pytorch's MBConvBlock): the
+    skip's gradient travels from the project BatchNorm to the expand convolution through an ``ops.SkipCarrier`` and is added
+    in the epilogue of the data-gradient kernel (stp3_conv2d_fwd_add) instead of by the autograd engine -- output, input
+    gradient and every parameter gradient bit for bit against the engine's own addition; both expand routes (the recomputing
+    streaming one for the big map, the stored one for the small map)."""
+    from stp3_amd import _lib
+    from stp3_amd.models import efficientnet as E
+    from stp3_amd.utils import to_channels_last
+    n, c, h, w = shape
+
+    def run(on):
+        monkeypatch.setattr(E, 'SKIP_GRADIENT_IN_DGRAD', on)
+        torch.manual_seed(0)
+        blk = to_channels_last(E.MBConvBlock(c, c, 3, 1, 6, 64).cuda())
+        blk.train()
+        g = torch.Generator().manual_seed(1)
+        x0 = torch.randn(n, c, h, w, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+        calls = []
+        real = _lib.lib().stp3_conv2d_fwd_add
+        monkeypatch.setattr(_lib.lib(), 'stp3_conv2d_fwd_add', lambda *a: (calls.append(1), real(*a))[1], raising=False)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = blk(x0 * 1.0, drop_connect_rate=0.0)
+        y.backward(torch.randn(y.shape, generator=g).cuda().to(y.dtype))
+        return [y.detach(), x0.grad] + [p.grad for p in blk.parameters()], len(calls)
+
+    (plain, n_plain), (fused, n_fused) = run(False), run(True)
+    assert n_plain == 0 and n_fused == 1
+    for i, (a, b) in enumerate(zip(plain, fused)):
+        assert a is not None and b is not None and torch.equal(a, b), i

@@ -85,7 +85,10 @@ def test_step_runs_and_call_mix(recorder, tmp_path):
     # (the split-K sum of a leaf weight's gradient is deferred: stp3_conv2d_wgrad_partials per layer, ONE
     # stp3_conv2d_wgrad_reduce_batch per step; derived weights -- merged heads, folded temporal kernels -- reduce at once)
     wgrads = calls['stp3_conv2d_wgrad'] + calls['stp3_conv2d_wgrad_partials']
-    assert calls['stp3_conv2d_fwd'] > 200 * STEPS and wgrads > 100 * STEPS
+    # (stp3_conv2d_fwd_add: the data gradient of the expand convolution of the 16 MBConv blocks with an identity skip and an
+    # expand layer, written together with the skip's gradient -- ops.SkipCarrier)
+    assert calls['stp3_conv2d_fwd_add'] == 16 * STEPS, calls['stp3_conv2d_fwd_add']
+    assert calls['stp3_conv2d_fwd'] + calls['stp3_conv2d_fwd_add'] > 200 * STEPS and wgrads > 100 * STEPS
     # (the first step meets an arena that is too small for all of them: those layers reduce at once, the arena grows after it)
     assert calls['stp3_conv2d_wgrad_partials'] > 70 and calls['stp3_conv2d_wgrad_reduce_batch'] == STEPS, calls
     # weight shadows: once per newly met layer during the first step, then once per optimizer step -- never per use
