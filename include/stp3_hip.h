@@ -590,7 +590,8 @@ int stp3_mbconv_bwd_apply(const stp3_se_dims* dims, int32_t ldg, const void* da,
                           int32_t act, const float* gate, const float* dpooled, const float* gsums, double count,
                           void* dx, void* stream);
 
-/* stp3_dwconv2d_fwd_stats_bn -- stp3_dwconv2d_fwd_stats + stp3_bn_finalize in the launches of the former (one process: nothing
+/* stp3_dwconv2d_fwd_stats_bn -- (depthwise convolution -> BatchNorm-1 of an MBConv block, stp3/models/encoder.py:57-97)
+ * stp3_dwconv2d_fwd_stats + stp3_bn_finalize in the launches of the former (one process: nothing
  * happens between the statistics and their use, so the final reduction finishes its own channels -- coef [4][C] = scale |
  * shift | mean | invstd, running statistics updated; the additions keep the order of the stand-alone reduction and the
  * constants stp3_bn_finalize's arithmetic: bit-identical).  count = elements per channel. */
