@@ -124,6 +124,29 @@ def conv_1x1x1_norm_activated(in_channels, out_channels):
                                       ('activation', nn.ReLU(inplace=True))]))
 
 
+class Bottleneck3D(nn.Module):
+    """1x1x1 down-projection -> causal (kt, 3, 3) convolution -> 1x1x1 up-projection, plus the (projected) skip
+    (temporal.py:328-375).  Only built for ``MODEL.TEMPORAL_MODEL.INBETWEEN_LAYERS > 0``, which no shipped configuration sets:
+    the layers run as the plain torch modules they are (off the benchmarked path; parameter names as in the reference)."""
+
+    def __init__(self, in_channels, out_channels=None, kernel_size=(2, 3, 3), dilation=(1, 1, 1)):
+        super().__init__()
+        half = in_channels // 2
+        out_channels = out_channels or in_channels
+        self.layers = nn.Sequential(OrderedDict([
+            ('conv_down_project', conv_1x1x1_norm_activated(in_channels, half)),
+            ('conv', CausalConv3d(half, half, kernel_size=kernel_size, dilation=dilation, bias=False)),
+            ('conv_up_project', conv_1x1x1_norm_activated(half, out_channels))]))
+        self.projection = None
+        if out_channels != in_channels:
+            self.projection = nn.Sequential(nn.Conv3d(in_channels, out_channels, kernel_size=1, bias=False),
+                                            nn.BatchNorm3d(out_channels))
+
+    def forward(self, x):
+        skip = x if self.projection is None else self.projection(x)
+        return self.layers(x) + skip
+
+
 class PyramidSpatioTemporalPooling(nn.Module):
     """Causal (2-frame) average over time and the full pool window, 1x1x1 conv + BN + ReLU.
 

@@ -4,15 +4,13 @@ frame.  Mirrors ``stp3/models/temporal_model.py`` (TemporalModel :7-60, Temporal
 import torch.nn as nn
 
 from ..layers.convolutions import DeepLabHead
-from ..layers.temporal import TemporalBlock
+from ..layers.temporal import Bottleneck3D, TemporalBlock
 
 
 class TemporalModel(nn.Module):
     def __init__(self, in_channels, receptive_field, input_shape, start_out_channels=64, extra_in_channels=0,
                  n_spatial_layers_between_temporal_layers=0, use_pyramid_pooling=True):
         super().__init__()
-        if n_spatial_layers_between_temporal_layers:
-            raise NotImplementedError('INBETWEEN_LAYERS > 0 (Bottleneck3D) is off the benchmarked path')
         self.receptive_field = receptive_field
         h, w = input_shape
         blocks = []
@@ -20,6 +18,9 @@ class TemporalModel(nn.Module):
         for _ in range(receptive_field - 1):
             blocks.append(TemporalBlock(block_in, block_out, use_pyramid_pooling=bool(use_pyramid_pooling),
                                         pool_sizes=[(2, h, w)] if use_pyramid_pooling else None))
+            # INBETWEEN_LAYERS spatial bottlenecks behind every temporal block (temporal_model.py:33-37; 0 in every shipped config)
+            blocks.extend(Bottleneck3D(block_out, block_out, kernel_size=(1, 3, 3))
+                          for _ in range(n_spatial_layers_between_temporal_layers))
             block_in = block_out
             block_out += extra_in_channels
         self.out_channels = block_in
@@ -31,6 +32,8 @@ class TemporalModel(nn.Module):
         constants (the six ego-motion planes of stp3.py:145-152) -- folded into the first block, never materialised."""
         x = x.permute(0, 2, 1, 3, 4)                        # (B, C, T, X, Y)
         for i, blk in enumerate(self.model):
+            if x.is_cuda and isinstance(blk, Bottleneck3D):
+                x = x.contiguous()                           # (plain torch modules: their own layout)
             x = blk(x, extra.permute(0, 2, 1)) if (i == 0 and extra is not None) else blk(x)
         x = x.permute(0, 2, 1, 3, 4)
         b, s, c, h, w = x.shape

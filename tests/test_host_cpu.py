@@ -264,3 +264,18 @@ def test_bench_prices_a_shape_against_its_own_roof():
         assert e['bound'] == want and e['calls_per_step'] == 1 and abs(e['ms_per_step'] - 0.1) < 1e-9
         roof = e['compulsory_tb_per_s'] / 8.0 if want == 'hbm' else e['tflops'] / 2500.0
         assert abs(e['frac_of_its_bound'] - roof) < 2e-3
+
+
+@torch.no_grad()
+def test_temporal_model_with_spatial_bottlenecks_matches_the_reference():
+    """``INBETWEEN_LAYERS > 0`` (stp3/layers/temporal.py:328-375 Bottleneck3D behind every temporal block; no shipped
+    configuration sets it): the reference's own TemporalModel (oracle/make_golden_inbetween.py) against the product's, same
+    name-derived weights, same input -- and the same state-dict keys."""
+    from oracle.make_golden_inbetween import ARGS, INPUT
+    from stp3_amd.models.temporal_model import TemporalModel
+    g = H.load('temporal_inbetween.npz')
+    m = prep(TemporalModel(**ARGS))
+    assert sorted(m.state_dict().keys()) == list(g['keys'])
+    y = m(H.det_tensor(*INPUT))
+    assert tuple(y.shape) == tuple(g['shape'])
+    torch.testing.assert_close(H.sample(y).float(), torch.from_numpy(g['y']), rtol=2e-3, atol=2e-4)
