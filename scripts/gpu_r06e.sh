@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 6, visit e: same-box A/B of the round-5 tree (.ab_r05, commit 93f4b96) against HEAD, then a kernel trace of HEAD
+# (.ab_r05 is git-ignored scratch that travels with gpurun:  mkdir .ab_r05 && git archive 93f4b96 | tar -x -C .ab_r05 &&
+#  make -C .ab_r05/st-p3_amd/csrc -j8 && cp -r oracle/_ref .ab_r05/oracle/)
 out=gpurun_out/r06e; mkdir -p $out
 export TMPDIR=/tmp
 for i in 1 2; do
