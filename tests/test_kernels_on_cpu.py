@@ -371,10 +371,11 @@ def test_whole_step_float32_matches_the_cpu_port(results):
     r = _get(results, 'model_step_f32')
     assert not r['params_without_grad']
     # Train-mode BatchNorm over the 4 x 6 maps of this configuration amplifies round-off chaotically: the figure moves with
-    # any change of a summation order anywhere in the step (1.0e-2 at the end of round 4, 3.8e-2 at the end of round 5 with
-    # kernels that are bit-identical or exact elsewhere) -- it bounds gross errors only.  What pins the kernels is the same
-    # step with BatchNorm on its running statistics, a smooth function: loss equal to the last digit, gradient 6e-6.
-    assert abs(r['loss'] - r['ref_loss']) <= 1e-5 * abs(r['ref_loss']) and r['grad_rel_l2'] <= 8e-2
+    # any change of a summation order anywhere in the step (1.0e-2 at the end of round 4, 3.8e-2 at the end of round 5, 3.6e-3
+    # at the end of round 6 -- with kernels that are bit-identical or exact elsewhere each time) -- it bounds gross errors only
+    # (4e-2 again since round 6; the round-5 bound was 8e-2).  What pins the kernels is the same step with BatchNorm on its
+    # running statistics, a smooth function: loss equal to the last digit, gradient 6e-6.
+    assert abs(r['loss'] - r['ref_loss']) <= 1e-5 * abs(r['ref_loss']) and r['grad_rel_l2'] <= 4e-2
     e = _get(results, 'model_step_f32_bn_eval')
     assert not e['params_without_grad']
     assert abs(e['loss'] - e['ref_loss']) <= 1e-6 * abs(e['ref_loss']) and e['grad_rel_l2'] <= 1e-4
