@@ -463,6 +463,15 @@ int stp3_conv2d_bn_bwd_reduce(const stp3_conv_dims* dims, const void* x, const v
                               void* stream);
 int stp3_conv2d_bn_bwd_apply(const stp3_conv_dims* dims, const void* x, const void* w, const void* dz, int32_t ldz,
                              const float* coef, int32_t act, const float* gsums, double count, void* dy, void* stream);
+/* stp3_conv2d_bn_bwd_apply_dx -- stp3_conv2d_bn_bwd_apply that ALSO writes the data gradient of the 1x1 convolution,
+ * dx[m][ci] = sum_co dy[m][co] w[co][ci] (+ add[m][ci]: the gradient of the block's identity skip, may be NULL), [M][lddx] bf16:
+ * the kernel holds the dy tile of its 32 pixels in LDS when it stores it, so the second matrix product reads it there instead
+ * of a separate data-gradient convolution reading the 6x larger dy back from memory (the expand convolutions of the MBConv
+ * blocks, stp3/models/encoder.py:57-97: 144 / 192 output channels, <= 32 input channels -- the whole-row streaming kernel;
+ * anything else: STP3_EUNSUP, the caller keeps the two calls).  dy is still written (the weight gradient reads it). */
+int stp3_conv2d_bn_bwd_apply_dx(const stp3_conv_dims* dims, const void* x, const void* w, const void* dz, int32_t ldz,
+                                const float* coef, int32_t act, const float* gsums, double count, void* dy, void* dx,
+                                int32_t lddx, const void* add, int32_t ldadd, void* stream);
 
 /* stp3_conv2d_fwd_add -- stp3_conv2d_fwd (bf16 output, no statistics) with y = bf16(bf16(conv + bias) + add): the DATA GRADIENT
  * of a block's first convolution written together with the gradient of the block's skip connection (`add` = the gradient at

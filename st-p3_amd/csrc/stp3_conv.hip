@@ -94,6 +94,8 @@ enum { kModePlain = 0, kModeStats = 1, kModeBnAct = 2, kModeBwdReduce = 3, kMode
 struct EpiArgs {
     const uint16_t* add;        // PLAIN mode, bf16 output: y = bf16(bf16(conv + bias) + add[m][co]) -- the gradient of a skip
     int ldadd;                  // connection added where the data gradient is written ([M][ldadd] bf16, 16-byte pieces)
+    uint16_t* dx;               // BWD_APPLY of the whole-row streaming kernel: ALSO the data gradient of the 1x1 convolution,
+    int lddx;                   // dx[m][ci] = sum_co dy[m][co] w[co][ci] (+ add[m][ci]), [M][lddx] bf16, from the tile in LDS
     const float* coef;          // [scale | shift | mean | invstd][Cout] (stp3_bn_finalize)
     const uint16_t* dz;         // gradient at the activation output, [M][ldz] bf16 (BWD_*)
     const float* gsums;         // [2][Cout]: sum g, sum g * xhat over all replicas (BWD_APPLY)
@@ -575,6 +577,16 @@ __global__ __launch_bounds__(256, 2) void pointwise_rows_kernel(ConvDims d, int 
     uint16_t* wimg = reinterpret_cast<uint16_t*>(smem);    // [NT * 32][LDW]
     uint16_t* tile = wimg + NT * 32 * LDW + wave * (32 * LDT);
     float* red = reinterpret_cast<float*>(wimg + NT * 32 * LDW);   // [4 waves][64 lanes][16], over the tiles at the end
+    // BWD_APPLY with ep.dx: the TRANSPOSED weight image [32 input channels][LDT] behind the four wave tiles -- the second
+    // matrix product of the pass, dx^T[ci][pixel] = sum_co w[co][ci] dy[pixel][co], reads dy from the wave's tile
+    uint16_t* wtimg = wimg + NT * 32 * LDW + 4 * (32 * LDT);
+    const bool with_dx = MODE == kModeBwdApply && ep.dx != nullptr;
+    if (with_dx) {
+        for (int e = tid; e < 32 * NT * 32; e += 256) {
+            const int k = e / (NT * 32), c = e - k * (NT * 32);
+            wtimg[k * LDT + c] = (c < PP * 8 && k < d.Cin) ? w[(size_t)(co0 + c) * d.Cin + k] : (uint16_t)0;
+        }
+    }
     for (int e = tid; e < NT * 32 * ksteps * 2; e += 256) {
         const int r = e / (ksteps * 2), k0 = (e - r * (ksteps * 2)) * 8;
         u32x4 v = {0u, 0u, 0u, 0u};
@@ -654,6 +666,41 @@ __global__ __launch_bounds__(256, 2) void pointwise_rows_kernel(ConvDims d, int 
                     epi8<MODE>(wds, gds, kc, ep.act, s1, s2, ow);
                     if (MODE == kModeBnAct || MODE == kModeBwdApply)
                         *reinterpret_cast<uint4*>(y + (size_t)m * d.ldy + cch) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                    if (with_dx)                            // dy replaces the recomputed output in the wave's tile
+                        *reinterpret_cast<uint4*>(tile + p * LDT + cl) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                }
+            }
+        }
+        if (with_dx) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            f32x16 dxa;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dxa[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NT * 2; ++ks) {
+                Frag fa, fb;
+                fa.u = *reinterpret_cast<const uint4*>(wtimg + px * LDT + ks * 16 + half * 8);
+                fb.u = *reinterpret_cast<const uint4*>(tile + px * LDT + ks * 16 + half * 8);
+                dxa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, dxa, 0, 0, 0);
+            }
+            // D[row = input channel 8 q + 4 half + j][col = pixel px]: four 8-byte pieces of the pixel's dx row per lane
+            const int m = mbase + px;
+            if (m < d.M) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ci = 8 * q + 4 * half;
+                    if (ci < d.Cin) {
+                        uint32_t lo = pack_bf16(dxa[4 * q], dxa[4 * q + 1]), hi = pack_bf16(dxa[4 * q + 2], dxa[4 * q + 3]);
+                        if (ep.add) {                      // + the gradient of the block's skip (added to the ROUNDED product)
+                            const uint2 a = *reinterpret_cast<const uint2*>(ep.add + (size_t)m * ep.ldadd + ci);
+                            lo = pack_bf16(__uint_as_float(lo << 16) + __uint_as_float(a.x << 16),
+                                           __uint_as_float(lo & 0xffff0000u) + __uint_as_float(a.x & 0xffff0000u));
+                            hi = pack_bf16(__uint_as_float(hi << 16) + __uint_as_float(a.y << 16),
+                                           __uint_as_float(hi & 0xffff0000u) + __uint_as_float(a.y & 0xffff0000u));
+                        }
+                        *reinterpret_cast<uint2*>(ep.dx + (size_t)m * ep.lddx + ci) = make_uint2(lo, hi);
+                    }
                 }
             }
         }
@@ -1314,7 +1361,9 @@ int pointwise_run(const ConvDims& d, const void* x, const void* w, void* y, floa
     if ((rows_small || rows_lines) && d.ldy % 8 == 0 && (mode < kModeBwdReduce || ep.ldz % 8 == 0)) {
         const int pp = rows_small ? d.Cout / 8 : (d.Cout % 128 == 0 ? 16 : 8), nt = (pp + 3) / 4;
         const int tiles_co = d.Cout / (pp * 8);
-        const size_t lds = (size_t)nt * 32 * (ksteps * 16 + 8) * 2 + (size_t)4 * 32 * (nt * 32 + 8) * 2;
+        if (ep.dx && !(rows_small && mode == kModeBwdApply && d.Cin <= 32)) return STP3_EUNSUP;
+        const size_t lds = (size_t)nt * 32 * (ksteps * 16 + 8) * 2 + (size_t)4 * 32 * (nt * 32 + 8) * 2 +
+                           (ep.dx ? (size_t)32 * (nt * 32 + 8) * 2 : 0);
         // persistent: as many workgroups per CU as their LDS (weight image + four wave tiles) allows, at most 3
         unsigned per_cu = (unsigned)((160 * 1024) / lds);
         if (per_cu > 3) per_cu = 3;
@@ -1328,6 +1377,7 @@ int pointwise_run(const ConvDims& d, const void* x, const void* w, void* y, floa
         else if (ksteps <= 4) rc = pointwise_rows_launch_mode<16, 4>(mode, d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
         else rc = pointwise_rows_launch_mode<16, 8>(mode, d, ksteps, tiles_co, nwg, lds, x, w, y, partial, ep, s);
     } else {
+        if (ep.dx) return STP3_EUNSUP;
         if (ksteps <= 2) rc = pointwise_direct_launch_mode<2>(mode, d, ksteps, gx, &parts, x, w, y, partial, ep, s);
         else if (ksteps <= 4) rc = pointwise_direct_launch_mode<4>(mode, d, ksteps, gx, &parts, x, w, y, partial, ep, s);
         else rc = pointwise_direct_launch_mode<8>(mode, d, ksteps, gx, &parts, x, w, y, partial, ep, s);
@@ -1376,6 +1426,14 @@ int igemm_run(const stp3_conv_dims* p, const void* x, const void* w, const float
         partial = (float*)workspace;
     }
     if (y && ((uintptr_t)y & 15)) return STP3_EUNSUP;
+    if (ep.dx) {
+        // BWD_APPLY + data gradient: the whole-row streaming kernel only (stp3_conv2d_bn_bwd_apply_dx)
+        if (!pointwise_applies(p, y) || ep.lddx % 4 || ep.lddx < p->Cin || ((uintptr_t)ep.dx & 7) ||
+            (ep.add && (ep.ldadd % 4 || ep.ldadd < p->Cin || ((uintptr_t)ep.add & 7))))
+            return STP3_EUNSUP;
+        ep.act = act;
+        return pointwise_run(d, x, w, y, sums, partial, gx, s, mode, ep);
+    }
     if (ep.add) {
         // the skip-gradient addend: plain mode, bf16 output, whole 16-byte channel pieces on both sides
         if (mode != kModePlain || d.out_f32 || p->Cout % 8 || p->ldy % 8 || ep.ldadd % 8 || ep.ldadd < p->Cout ||
@@ -1460,6 +1518,16 @@ int stp3_conv2d_bn_bwd_apply(const stp3_conv_dims* p, const void* x, const void*
     if (!(count >= 1.0)) return STP3_EINVAL;
     EpiArgs ep = EpiArgs();
     ep.coef = coef; ep.dz = (const uint16_t*)dz; ep.ldz = ldz; ep.gsums = gsums; ep.inv_count = (float)(1.0 / count);
+    return igemm_run(p, x, w, nullptr, dy, nullptr, nullptr, 0, stream, kModeBwdApply, act, ep);
+}
+
+int stp3_conv2d_bn_bwd_apply_dx(const stp3_conv_dims* p, const void* x, const void* w, const void* dz, int32_t ldz,
+                                const float* coef, int32_t act, const float* gsums, double count, void* dy, void* dx,
+                                int32_t lddx, const void* add, int32_t ldadd, void* stream) {
+    if (!(count >= 1.0) || !dx) return STP3_EINVAL;
+    EpiArgs ep = EpiArgs();
+    ep.coef = coef; ep.dz = (const uint16_t*)dz; ep.ldz = ldz; ep.gsums = gsums; ep.inv_count = (float)(1.0 / count);
+    ep.dx = (uint16_t*)dx; ep.lddx = lddx; ep.add = (const uint16_t*)add; ep.ldadd = ldadd;
     return igemm_run(p, x, w, nullptr, dy, nullptr, nullptr, 0, stream, kModeBwdApply, act, ep);
 }
 

@@ -208,6 +208,8 @@ SIGNATURES = {
     'stp3_se_workspace_bytes': (c_int, [ctypes.POINTER(SeDims), ctypes.POINTER(c_size_t)]),
     'stp3_se_pool': (c_int, [ctypes.POINTER(SeDims), c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     'stp3_se_scale': (c_int, [ctypes.POINTER(SeDims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'stp3_conv2d_bn_bwd_apply_dx': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
+                                            ctypes.c_double, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p]),
     'stp3_conv2d_wgrad_workspace': (c_int, [ctypes.POINTER(ConvDims), ctypes.POINTER(c_size_t)]),
     'stp3_conv2d_wgrad': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'stp3_conv2d_wgrad_partials': (c_int, [ctypes.POINTER(ConvDims), c_void_p, c_void_p, c_void_p, c_size_t,

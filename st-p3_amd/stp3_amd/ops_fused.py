@@ -193,6 +193,10 @@ class _ConvBnAct(torch.autograd.Function):
         return (dx, dw, dcb, dgamma, dbeta, dres) + (None,) * 14
 
 
+# the expand convolution's data gradient computed inside the BatchNorm-backward apply pass (stp3_conv2d_bn_bwd_apply_dx)
+EXPAND_DGRAD_IN_APPLY = True
+
+
 class _PointwiseBnAct(torch.autograd.Function):
     """1x1 convolution -> BatchNorm -> activation WITHOUT the convolution output in memory: for the expand convolutions
     of the MBConv blocks (24..160 -> 144..960 channels), whose output is 6x their input.  Forward: the convolution runs
@@ -276,15 +280,33 @@ class _PointwiseBnAct(torch.autograd.Function):
             gsums = lsums.clone()
             yield gsums
         dconv = torch.empty((dims.N, cout, dims.H, dims.W), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
-        check(lib.stp3_conv2d_bn_bwd_apply(ctypes.byref(dims), x.data_ptr(), wb.data_ptr(), dz.data_ptr(), ldz, coef.data_ptr(),
-                                           act, gsums.data_ptr(), count, dconv.data_ptr(), stream), 'stp3_conv2d_bn_bwd_apply')
-        dgamma = lsums[1].to(gdt) if gdt is not None and ctx.needs_input_grad[2] else None
-        dbeta = lsums[0].to(bdt) if bdt is not None and ctx.needs_input_grad[3] else None
         dx = dw = None
         skip_grad = None if ctx.skip_carrier is None else ctx.skip_carrier.take()
-        if ctx.needs_input_grad[0]:
+        applied = False
+        if ctx.needs_input_grad[0] and EXPAND_DGRAD_IN_APPLY and cout in (144, 192) and cin <= 32:
+            # the data gradient out of the same pass: the kernel holds the gradient tile in LDS when it stores it (whole-row
+            # streaming kernel only: 144 / 192 channels from <= 32 -- the launcher's own test, repeated here so that no buffer
+            # is made for nothing; a shape it still turns down answers STP3_EUNSUP and takes the two calls)
+            dx = torch.empty((dims.N, cin, dims.H, dims.W), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+            add, ldadd = (None, 0)
+            if skip_grad is not None:
+                add, ldadd = ops._rows_view(skip_grad if skip_grad.dtype == torch.bfloat16 else skip_grad.to(torch.bfloat16))
+            rc = lib.stp3_conv2d_bn_bwd_apply_dx(ctypes.byref(dims), x.data_ptr(), wb.data_ptr(), dz.data_ptr(), ldz, coef.data_ptr(),
+                                                 act, gsums.data_ptr(), count, dconv.data_ptr(), dx.data_ptr(), cin,
+                                                 ops._opt_ptr(add), ldadd, stream)
+            if rc == -10002:                                  # STP3_EUNSUP: not a shape of that kernel
+                dx = None
+            else:
+                check(rc, 'stp3_conv2d_bn_bwd_apply_dx')
+                applied, skip_grad = True, None
+        if not applied:
+            check(lib.stp3_conv2d_bn_bwd_apply(ctypes.byref(dims), x.data_ptr(), wb.data_ptr(), dz.data_ptr(), ldz, coef.data_ptr(),
+                                               act, gsums.data_ptr(), count, dconv.data_ptr(), stream), 'stp3_conv2d_bn_bwd_apply')
+        dgamma = lsums[1].to(gdt) if gdt is not None and ctx.needs_input_grad[2] else None
+        dbeta = lsums[0].to(bdt) if bdt is not None and ctx.needs_input_grad[3] else None
+        if ctx.needs_input_grad[0] and dx is None:
             dx = ops.conv2d_data_grad(dconv, wb, ctx.weight_ref, x.shape, 1, (0, 0), (1, 1), add=skip_grad)
-        elif skip_grad is not None:
+        elif dx is None and skip_grad is not None:
             dx = skip_grad
         if ctx.needs_input_grad[1]:
             dw = ops._conv2d_wgrad(dconv, x, (cout, cin, 1, 1), 1, (0, 0), (1, 1), leaf=ctx.weight_ref).to(wdt)

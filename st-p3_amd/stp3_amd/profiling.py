@@ -77,6 +77,9 @@ def _se_pool_bytes(args):
 WORK = {
     'stp3_conv2d_fwd': ('conv_fwd_dgrad', _conv_flops),
     'stp3_conv2d_fwd_add': ('conv_fwd_dgrad', _conv_flops),                 # (a data gradient + the skip's gradient)
+    # (the expand convolution's data gradient inside the BatchNorm-backward apply pass of the recomputing route: counted with
+    # the data gradient's flops and the WHOLE pass's time -- pessimistic for the family, never flattering)
+    'stp3_conv2d_bn_bwd_apply_dx': ('conv_fwd_dgrad', _conv_flops),
     'stp3_conv2d_wgrad': ('conv_wgrad', _conv_flops),
     'stp3_conv2d_wgrad_partials': ('conv_wgrad', _conv_flops),              # (the split contraction: all of the layer's flops)
     'stp3_conv2d_wgrad_reduce_batch': ('conv_wgrad', lambda args: 0.0),     # (their deferred sums, one launch per pass: time only)

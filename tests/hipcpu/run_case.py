@@ -957,6 +957,34 @@ def pointwise_bn(ops):
             res.append([y.detach().float(), x.grad.float(), conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
                         bn.running_mean.clone(), bn.running_var.clone()])
         out[name] = {k: rel(a, b) for k, a, b in zip(('y', 'dx', 'dw', 'dgamma', 'dbeta', 'rmean', 'rvar'), res[0], res[1])}
+    # the data gradient out of the apply pass (stp3_conv2d_bn_bwd_apply_dx) against the separate data-gradient convolution,
+    # without and with a skip gradient handed over by a carrier (ops.SkipCarrier); ragged pixel counts, both widths
+    from stp3_amd import _lib
+    lib = _lib.lib()
+    for name, (n, cin, cout, h, w) in {'dx_24_144': (3, 24, 144, 9, 11), 'dx_32_192': (1, 32, 192, 11, 13), 'dx_8_192': (2, 8, 192, 5, 7)}.items():
+        conv = nn.Conv2d(cin, cout, 1, bias=False)
+        bn = nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01).train()
+        x0 = torch.randn(n, cin, h, w).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        gy = torch.randn(n, cout, h, w).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        skip = torch.randn(n, cin, h, w).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        worst, ran = 0.0, []
+        for with_skip in (False, True):
+            got = []
+            for on in (False, True):
+                ops_fused.EXPAND_DGRAD_IN_APPLY = on
+                conv.zero_grad(); bn.zero_grad()
+                carrier = None
+                if with_skip:
+                    carrier = ops.SkipCarrier()
+                    carrier.grad = skip.clone()
+                x = x0.clone().requires_grad_()
+                y = ops_fused.pointwise_bn_act(x, conv, bn, ops.ACT_SWISH, group=False, skip_carrier=carrier)
+                y.backward(gy)
+                got.append([x.grad.float(), conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()])
+                ran.append(carrier is None or carrier.grad is None)
+            worst = max(worst, max(rel(a, b) for a, b in zip(got[1], got[0])))
+        ops_fused.EXPAND_DGRAD_IN_APPLY = True
+        out[name] = {'one_vs_two_kernels': worst, 'carrier_emptied': all(ran)}
     return out
 
 

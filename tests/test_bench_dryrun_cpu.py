@@ -58,7 +58,7 @@ def test_bench_main_dry_run(tmp_path, workload):
                       'stp3_gru_output_fwd', 'stp3_gru_output_bwd', 'stp3_gru_reset_cat_bwd'):
             assert entry + ' ' in trace, entry
     for entry in ('stp3_lift_plan_build', 'stp3_lift_splat_fwd', 'stp3_lift_splat_bwd',
-                  'stp3_conv2d_fwd', 'stp3_conv2d_fwd_add', 'stp3_conv2d_wgrad', 'stp3_conv2d_wgrad_partials',
+                  'stp3_conv2d_fwd', 'stp3_conv2d_fwd_add', 'stp3_conv2d_bn_bwd_apply_dx', 'stp3_conv2d_wgrad', 'stp3_conv2d_wgrad_partials',
                   'stp3_conv2d_wgrad_reduce_batch',
                   'stp3_conv2d_prep_weights', 'stp3_bn_fwd_train',
                   'stp3_dwconv2d_fwd_stats_bn', 'stp3_bn_finalize', 'stp3_se_pool_act', 'stp3_se_mlp_fwd',

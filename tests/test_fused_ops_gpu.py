@@ -492,14 +492,44 @@ def test_skip_gradient_added_in_the_data_gradient_kernel_bit_equal(monkeypatch, 
         g = torch.Generator().manual_seed(1)
         x0 = torch.randn(n, c, h, w, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
         calls = []
-        real = _lib.lib().stp3_conv2d_fwd_add
-        monkeypatch.setattr(_lib.lib(), 'stp3_conv2d_fwd_add', lambda *a: (calls.append(1), real(*a))[1], raising=False)
+        # (the skip gradient is added by stp3_conv2d_fwd_add -- the data-gradient convolution -- or, where the expand layer's
+        # BatchNorm-backward apply pass computes the data gradient itself, by stp3_conv2d_bn_bwd_apply_dx)
+        for entry in ('stp3_conv2d_fwd_add', 'stp3_conv2d_bn_bwd_apply_dx'):
+            real = getattr(_lib.lib(), entry)
+            monkeypatch.setattr(_lib.lib(), entry, (lambda real: lambda *a: (calls.append(a[-3 if real.__name__.endswith('_dx') else 4]), real(*a))[1])(real),
+                                raising=False)
         with torch.autocast('cuda', dtype=torch.bfloat16):
             y = blk(x0 * 1.0, drop_connect_rate=0.0)
         y.backward(torch.randn(y.shape, generator=g).cuda().to(y.dtype))
-        return [y.detach(), x0.grad] + [p.grad for p in blk.parameters()], len(calls)
+        return [y.detach(), x0.grad] + [p.grad for p in blk.parameters()], sum(1 for add in calls if add)
 
     (plain, n_plain), (fused, n_fused) = run(False), run(True)
-    assert n_plain == 0 and n_fused == 1
+    assert n_plain == 0 and n_fused == 1                     # (calls that were handed a skip gradient)
     for i, (a, b) in enumerate(zip(plain, fused)):
         assert a is not None and b is not None and torch.equal(a, b), i
+
+
+@pytest.mark.parametrize('cin,cout', [(24, 144), (32, 192)])
+def test_expand_data_gradient_inside_the_apply_pass(monkeypatch, cin, cout):
+    """stp3_conv2d_bn_bwd_apply_dx: the expand convolution's data gradient computed by the BatchNorm-backward apply pass of the
+    recomputing route (from the gradient tile it holds in LDS) against the separate data-gradient convolution: every gradient
+    of ``ops_fused.pointwise_bn_act`` (MBConv expand layer, stp3/models/encoder.py:57-97) within bf16 rounding of one another
+    (rtol 1e-2; the two sum the same bf16 products in float32)."""
+    from stp3_amd import ops_fused
+    conv = nn.Conv2d(cin, cout, 1, bias=False).cuda().to(memory_format=torch.channels_last)
+    bn = nn.BatchNorm2d(cout, momentum=0.01, eps=1e-3).cuda()
+
+    def run(on):
+        monkeypatch.setattr(ops_fused, 'EXPAND_DGRAD_IN_APPLY', on)
+        conv.weight.grad = bn.weight.grad = bn.bias.grad = None
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(4, cin, 72, 80, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+        assert ops_fused.pointwise_bn_act_supported(x, conv, bn) and ops_fused.pointwise_bn_act_pays(x, conv)
+        y = ops_fused.pointwise_bn_act(x, conv, bn, 2, group=False)
+        y.backward(torch.randn(y.shape, generator=g).cuda().to(y.dtype))
+        return [y.detach().float(), x.grad.float(), conv.weight.grad.float(), bn.weight.grad.float(), bn.bias.grad.float()]
+
+    two, one = run(False), run(True)
+    assert torch.equal(two[0], one[0]) and torch.equal(two[2], one[2]) and torch.equal(two[3], one[3])
+    torch.testing.assert_close(one[1], two[1], rtol=1e-2, atol=1e-2 * float(two[1].abs().max()))
+    print('dx bit-equal:', bool(torch.equal(one[1], two[1])))

@@ -281,6 +281,11 @@ def test_pointwise_conv_batchnorm_without_the_convolution_output(results):
     for name, r in _get(results, 'pointwise_bn').items():
         if name == 'seconds':
             continue
+        if name.startswith('dx_'):
+            # stp3_conv2d_bn_bwd_apply_dx (the data gradient out of the apply pass, skip gradient added) against the apply
+            # pass + data-gradient convolution: the same bf16 products summed in float32 in another order, rounded once
+            assert r['carrier_emptied'] and r['one_vs_two_kernels'] <= 4e-3, (name, r)
+            continue
         assert r['y'] == 0.0 and r['dx'] == 0.0 and r['rmean'] == 0.0 and r['rvar'] == 0.0, (name, r)
         assert r['dw'] <= 5e-6 and r['dgamma'] <= 5e-6 and r['dbeta'] <= 5e-6, (name, r)
 
