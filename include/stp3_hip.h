@@ -671,9 +671,23 @@ typedef struct stp3_wprep_entry {
     int64_t stride_co, stride_ci, stride_kh, stride_kw;
     int64_t first_block;
     int32_t cout, cin, kh, kw;
+    /* a PIECE of an assembled weight: the block lands at channel offsets (co_off, ci_off) of destinations with dst_cout x
+     * dst_cin channels (fwd [dst_cout][KH][KW][dst_cin], flip [dst_cin][KH][KW][dst_cout]); dst_cout == 0: the entry is the
+     * whole weight (dst = cout x cin, offsets 0).  Elements no piece covers are not written. */
+    int32_t dst_cout, dst_cin, co_off, ci_off;
+    int32_t fwd_f32;       /* 1: fwd receives float32 (the tap-major [KH*KW][C] weights of stp3_dwconv2d_*: cout = 1, cin = C) */
+    int32_t reserved;
 } stp3_wprep_entry;
 
 int stp3_conv2d_prep_weights(const stp3_wprep_entry* table, int32_t n_entries, int64_t total_blocks, void* stream);
+
+/* The way back: the float32 gradient of an assembled weight ([dst_cout][KH][KW][dst_cin], what stp3_conv2d_wgrad writes) cut
+ * into its pieces, each stored into its parameter's gradient -- same table layout, with ``src`` = the (writable) destination
+ * inside the parameter's gradient, read through the entry's strides, and ``fwd`` = the assembled gradient.  One launch for
+ * every assembled weight of a backward pass.  Replaces the backward of the reference's weight plumbing (torch autograd of
+ * the slices / pads / concatenations around stp3/layers/temporal.py:8-37 CausalConv3d, stp3/layers/convolutions.py ASPP.project,
+ * stp3/models/decoder.py:96-140 heads): slice_backward, constant_pad_nd, cat and add kernels per layer. */
+int stp3_conv2d_scatter_weight_grads(const stp3_wprep_entry* table, int32_t n_entries, int64_t total_blocks, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Gradient-norm clipping + Adam on flat fp32 buckets in three launches (csrc/stp3_optim.hip).  Replaces, for the flat buckets of stp3_amd/parallel.py, the reference's

@@ -86,7 +86,9 @@ class WprepEntry(ctypes.Structure):
     _fields_ = [('src', ctypes.c_void_p), ('fwd', ctypes.c_void_p), ('flip', ctypes.c_void_p),
                 ('stride_co', ctypes.c_int64), ('stride_ci', ctypes.c_int64), ('stride_kh', ctypes.c_int64),
                 ('stride_kw', ctypes.c_int64), ('first_block', ctypes.c_int64),
-                ('cout', ctypes.c_int32), ('cin', ctypes.c_int32), ('kh', ctypes.c_int32), ('kw', ctypes.c_int32)]
+                ('cout', ctypes.c_int32), ('cin', ctypes.c_int32), ('kh', ctypes.c_int32), ('kw', ctypes.c_int32),
+                ('dst_cout', ctypes.c_int32), ('dst_cin', ctypes.c_int32), ('co_off', ctypes.c_int32),
+                ('ci_off', ctypes.c_int32), ('fwd_f32', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 class SeMlpDims(ctypes.Structure):
@@ -216,6 +218,7 @@ SIGNATURES = {
                                            ctypes.POINTER(c_int32), c_void_p]),
     'stp3_conv2d_wgrad_reduce_batch': (c_int, [c_int32, ctypes.POINTER(WgradJob), c_void_p]),
     'stp3_conv2d_prep_weights': (c_int, [c_void_p, c_int32, ctypes.c_int64, c_void_p]),
+    'stp3_conv2d_scatter_weight_grads': (c_int, [c_void_p, c_int32, ctypes.c_int64, c_void_p]),
     'stp3_se_mlp_fwd': (c_int, [c_void_p] * 9),
     'stp3_se_mlp_bwd': (c_int, [c_void_p] * 15),
     'stp3_optim_workspace_bytes': (c_int, [ctypes.c_int64, ctypes.POINTER(c_size_t)]),

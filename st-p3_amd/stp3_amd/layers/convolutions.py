@@ -106,13 +106,21 @@ class ASPPConv(nn.Sequential):
         h, w = x.shape[-2:]
         d = self.dilation
         wgt = conv.weight
+        rows, cols = (slice(1, 2) if d >= h else slice(None)), (slice(1, 2) if d >= w else slice(None))
+        if d < h and d < w:
+            return conv_module(conv, x)
+        if wgt.shape[0] % 8 == 0 and x.shape[1] % 8 == 0 and ops.assembled_weight_supported(x, (wgt,)):
+            # the taps that remain as a weight of their own, cut from the parameter by the launch that refreshes every bf16
+            # shadow (ops.assembled_weight: no slice / cast / re-layout per step, and the gradient goes back the same way)
+            kept = wgt.detach()[:, :, rows, cols]
+            sub = ops.assembled_weight((id(conv), 'kept taps'), tuple(kept.shape), [ops.weight_piece(wgt, kept)])
+        else:
+            sub = wgt[:, :, rows, cols]
         if d >= h and d >= w:                       # only the centre tap can ever be in range
-            return conv2d(x, wgt[:, :, 1:2, 1:2])
+            return conv2d(x, sub)
         if d >= h:                                  # centre row only: 1x3
-            return conv2d(x, wgt[:, :, 1:2, :], padding=(0, d), dilation=(1, d))
-        if d >= w:                                  # centre column only: 3x1
-            return conv2d(x, wgt[:, :, :, 1:2], padding=(d, 0), dilation=(d, 1))
-        return conv_module(conv, x)
+            return conv2d(x, sub, padding=(0, d), dilation=(1, d))
+        return conv2d(x, sub, padding=(d, 0), dilation=(d, 1))          # centre column only: 3x1
 
     def forward(self, x):
         h, w = x.shape[-2:]
@@ -199,7 +207,14 @@ class ASPP(nn.Module):
         proj, bn, act, drop = self.project
         n_sp = spatial.shape[1]
         # (split, not two slices: one concatenation in backward instead of two zero-fills, two copies and an addition)
-        w_sp, w_pool = proj.weight.split([n_sp, proj.weight.shape[1] - n_sp], dim=1)
+        if n_sp % 8 == 0 and proj.weight.shape[0] % 8 == 0 and ops.assembled_weight_supported(spatial, (proj.weight,)):
+            # the columns of the spatial branches as a weight of their own (ops.assembled_weight); the pooled branch's columns
+            # go another way (below), so the parameter's gradient is put together by autograd
+            w_pool = proj.weight[:, n_sp:]
+            w_sp = ops.assembled_weight((id(proj), 'spatial'), (proj.weight.shape[0], n_sp, 1, 1),
+                                        [ops.weight_piece(proj.weight, proj.weight.detach()[:, :n_sp])], direct=False)
+        else:
+            w_sp, w_pool = proj.weight.split([n_sp, proj.weight.shape[1] - n_sp], dim=1)
         y = conv2d(spatial, w_sp)
         # the pooled branch is a constant plane per sample: its projection is a per-sample bias, folded
         # into the fused BatchNorm instead of a broadcast add over the whole map

@@ -61,6 +61,17 @@ def _conv2d_padded_channels(x, weight, padding=0):
     return y[:, :co] if cop != co else y
 
 
+def _conv2d_pieces(x, key, out_channels, kernel, pieces, padding=0, direct=True):
+    """conv2d of x with the weight ASSEMBLED from ``pieces`` (``ops.weight_piece``: views of parameters at channel offsets of a
+    zero weight with ``out_channels`` outputs -- padded to a multiple of 8 -- and x's channels as inputs): what
+    ``_conv2d_padded_channels(x, <the same weight built with pad / cat>)`` computes, without a torch operator for the weight
+    or its gradient (``ops.assembled_weight``).  Callers check ``ops.assembled_weight_supported`` and x.shape[1] % 8 == 0."""
+    cop = _pad8(out_channels)
+    w = ops.assembled_weight(key, (cop, x.shape[1], kernel[0], kernel[1]), pieces, direct=direct)
+    y = conv2d(x, w, None, 1, padding)
+    return y[:, :out_channels] if cop != out_channels else y
+
+
 def _bn_act_2d(norm, x, relu=True, res=None, sbias=None, out_slot=None):
     """BatchNorm3d over (B,C,T,H,W) == batch norm over (B*T,C,H,W): apply the 3-D module's statistics
     and affine parameters to the frame-folded 4-D tensor (fused with the ReLU / skip add)."""
@@ -98,6 +109,15 @@ class CausalConv3d(nn.Module):
         kt = w.shape[2]
         assert self.conv.bias is None and self.conv.dilation == (1, 1, 1) and kt in (1, 2)
         lanes_in = x2.shape[1]
+        if lanes_in % 8 == 0 and ops.assembled_weight_supported(x2, (w,)) and (kt == 1 or ops.causal_pair_supported(x2)):
+            # the taps side by side, each in its own run of ``lanes_in`` input lanes, output lanes padded to 8: pieces of one
+            # assembled weight (no unbind / pad / cat, and none of their backward)
+            taps = w.detach().unbind(2)
+            pieces = [ops.weight_piece(w, taps[k], 0, k * lanes_in) for k in range(kt)]
+            if kt == 2:
+                x2 = ops.causal_pair(x2, frames)
+            y = _conv2d_pieces(x2, (id(self), 'folded'), _pad8(w.shape[0]), w.shape[3:], pieces, padding=self._hw_pad[1:])
+            return _bn_act_2d(self.norm, y, out_slot=out_slot)
         # (unbind / squeeze, not w[:, :, k]: the backward of k selects is k zero-fills, k copies and k - 1 additions; that of
         # an unbind one stack, that of a squeeze nothing)
         taps = [_pad_in(wk, 1, lanes_in) for wk in (w.unbind(2) if kt > 1 else (w.squeeze(2),))]
@@ -264,9 +284,17 @@ class TemporalBlock(nn.Module):
         conv, norm = seq[0], seq[1]
         wgt = conv.weight.squeeze(2)                                     # (1x1x1 kernel: a view, nothing to add up in backward)
         c = x2.shape[1]
-        # (split, not two slices: one concatenation in backward instead of two zero-fills, two copies and an addition)
-        w_x, w_extra = (wgt, None) if extra2 is None else wgt.split([c, wgt.shape[1] - c], dim=1)
-        y = _conv2d_padded_channels(x2, w_x if lanes is None else _pad_out(w_x, lanes))
+        if c % 8 == 0 and ops.assembled_weight_supported(x2, (conv.weight,)):
+            # the columns that multiply x2, output lanes padded: one piece of an assembled weight.  With ``extra2`` the
+            # parameter's other columns take their own way to the loss (below): its gradient is put together by autograd.
+            piece = ops.weight_piece(conv.weight, conv.weight.detach().squeeze(2)[:, :c])
+            y = _conv2d_pieces(x2, (id(conv), 'x'), wgt.shape[0] if lanes is None else lanes, (1, 1), [piece],
+                               direct=extra2 is None)
+            w_extra = None if extra2 is None else wgt[:, c:]
+        else:
+            # (split, not two slices: one concatenation in backward instead of two zero-fills, two copies and an addition)
+            w_x, w_extra = (wgt, None) if extra2 is None else wgt.split([c, wgt.shape[1] - c], dim=1)
+            y = _conv2d_padded_channels(x2, w_x if lanes is None else _pad_out(w_x, lanes))
         # (through conv1x1_on_vector: float32 with autocast off on the GPU -- a (B*T, 6) x (6, C') product needs no casts)
         sbias = None if extra2 is None else conv1x1_on_vector(hp(extra2).to(hp(wgt).dtype)[:, :, None, None], w_extra).flatten(1)
         return dict(bn=norm, x=y, act=ACT_RELU if relu else ACT_NONE, sbias=sbias)
@@ -333,7 +361,14 @@ class TemporalBlock(nn.Module):
         pooled_list = [] if not self.use_pyramid_pooling else \
             list(pooled_outs if pooled_outs is not None else self.pyramid_pooling(x, extra, folded=x_pool))   # (B, C', T, h', w')
         w_parts = wgt.split([self._paths_channels] + [pl.shape[1] for pl in pooled_list], dim=1) if pooled_list else (wgt,)
-        y = _conv2d_padded_channels(paths, _pad_in(w_parts[0], len(outs), lanes))
+        if lanes % 8 == 0 and paths.shape[1] == len(outs) * lanes and ops.assembled_weight_supported(paths, (agg.conv.weight,)):
+            # one run of columns per path, each at the start of its run of ``lanes`` input lanes: pieces of an assembled weight
+            g = self._paths_channels // len(outs)
+            flat = agg.conv.weight.detach().squeeze(2)
+            pieces = [ops.weight_piece(agg.conv.weight, flat[:, i * g:(i + 1) * g], 0, i * lanes) for i in range(len(outs))]
+            y = _conv2d_pieces(paths, (id(agg.conv), 'paths'), wgt.shape[0], (1, 1), pieces, direct=not pooled_list)
+        else:
+            y = _conv2d_padded_channels(paths, _pad_in(w_parts[0], len(outs), lanes))
         sbias = None
         if self.use_pyramid_pooling:
             for pooled, w_p in zip(pooled_list, w_parts[1:]):

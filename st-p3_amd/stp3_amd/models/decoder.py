@@ -107,7 +107,15 @@ class Decoder(nn.Module):
             if bn.num_batches_tracked is not None:
                 ops.bump_batch_counter(bn)
         shared = _sync_world(bns[0]) > 1
-        w1 = torch.cat([cv.weight for cv in convs], dim=0)                               # (heads * C, Cin, 3, 3)
+        assembled = ops.assembled_weight_supported(x, [cv.weight for cv in convs] + [m.weight for m in lasts]) and \
+            all(m.bias is not None for m in lasts)
+        if assembled:
+            # the heads' kernels one below the other: pieces of ONE weight (ops.assembled_weight: no concatenation per step,
+            # and the gradient of the whole is cut into the heads' gradients by the launch that serves every such weight)
+            w1 = ops.assembled_weight((id(self), 'heads 3x3'), (len(convs) * c, convs[0].weight.shape[1], 3, 3),
+                                      [ops.weight_piece(cv.weight, cv.weight.detach(), k * c, 0) for k, cv in enumerate(convs)])
+        else:
+            w1 = torch.cat([cv.weight for cv in convs], dim=0)                           # (heads * C, Cin, 3, 3)
         gamma, beta = torch.cat([bn.weight for bn in bns]), torch.cat([bn.bias for bn in bns])
         args = (x, w1, None, gamma, beta, None, running_mean, running_var,
                 ops.bn_momentum(bns[0]), float(bns[0].eps), int(ACT_RELU),
@@ -124,9 +132,21 @@ class Decoder(nn.Module):
             for name, head, inp in others:
                 out[name] = run_fused(head, inp)
         # second layers: head k maps its C channels of `mid` to its outputs -- a block-diagonal 1x1 convolution
-        w2 = torch.block_diag(*[m.weight.flatten(1) for m in lasts])[:, :, None, None]    # (sum of outputs, heads * C, 1, 1)
-        b2 = torch.cat([m.bias for m in lasts])
-        y = conv2d(mid, w2, b2)
+        n_out = sum(m.out_channels for m in lasts)
+        if assembled:
+            # (output channels padded to 8 lanes: both gradients of the layer then run without padded copies of dy and the weight)
+            lanes_out = (n_out + 7) // 8 * 8
+            pieces, co = [], 0
+            for k, m in enumerate(lasts):
+                pieces.append(ops.weight_piece(m.weight, m.weight.detach(), co, k * c))
+                co += m.out_channels
+            w2 = ops.assembled_weight((id(self), 'heads 1x1'), (lanes_out, len(lasts) * c, 1, 1), pieces)
+            b2 = torch.cat([m.bias for m in lasts] + ([m.bias.new_zeros(lanes_out - n_out)] if lanes_out != n_out else []))
+            y = conv2d(mid, w2, b2)[:, :n_out]
+        else:
+            w2 = torch.block_diag(*[m.weight.flatten(1) for m in lasts])[:, :, None, None]    # (sum of outputs, heads * C, 1, 1)
+            b2 = torch.cat([m.bias for m in lasts])
+            y = conv2d(mid, w2, b2)
         # (one split: its backward writes the heads' gradients into ONE tensor, instead of a zero-fill, a copy and an addition per head)
         for (name, head), t in zip(heads, y.split([m.out_channels for m in lasts], dim=1)):
             for extra in list(head)[4:]:                                 # the sigmoid of the centerness head

@@ -79,7 +79,13 @@ class StaticSamePadConv2d(nn.Conv2d):
                                  device=x.device, memory_format=torch.channels_last).zero_()
                 xp[:, :c, top:top + h, left:left + w] = x
                 x = xp
-            return conv2d(x, F.pad(self.weight, (0, 0, 0, 0, 0, cp)), self.bias, self.stride, 0, self.dilation)
+            if self.out_channels % 8 == 0 and ops.assembled_weight_supported(x, (self.weight,)):
+                # (the weight with its zero columns: an assembled weight -- no pad per step, no slice of its gradient)
+                wp = ops.assembled_weight((id(self), 'padded'), (self.out_channels, self.in_channels + cp, *self.kernel_size),
+                                          [ops.weight_piece(self.weight, self.weight.detach())])
+            else:
+                wp = F.pad(self.weight, (0, 0, 0, 0, 0, cp))
+            return conv2d(x, wp, self.bias, self.stride, 0, self.dilation)
         if any(self._pad):
             x = F.pad(x, self._pad)
         if self.groups == 1:

@@ -487,6 +487,11 @@ def _dw_weight_taps(weight):
     c, _, k, _ = weight.shape
     if not (isinstance(weight, torch.nn.Parameter) and weight.is_leaf):
         return weight.detach().float().reshape(c, k * k).t().contiguous()
+    if ASSEMBLED_WEIGHTS and weight.is_cuda and weight.dtype == torch.float32:
+        # with the convolution weights' shadows: rewritten by the one launch of stp3_conv2d_prep_weights after an optimizer step
+        tab = _shadows(weight.device)
+        ent = tab.lookup(weight) or tab.register_taps(weight)
+        return ent['taps']
     key = id(weight)
     stamp = (weight._version, _WEIGHT_EPOCH[0], weight.data_ptr(), tuple(weight.shape))
     ent = _DW_WEIGHT_CACHE.get(key)
@@ -1318,6 +1323,13 @@ def _conv2d_wgrad(dy, x, wshape, stride, pad, dil, leaf=None):
             leaf._stp3_grad_claim = task
             dw = view.detach()
             direct = True
+    asm = getattr(leaf, '_stp3_assembled', None) if leaf is not None else None
+    if (asm is not None and ASSEMBLED_WEIGHTS and DIRECT_BUCKET_GRADS and x.is_cuda and leaf._stp3_assembled_direct
+            and _assembled_claim(asm, dw)):
+        # the stand-in of an assembled weight: the gradient of the whole goes to the entry's buffer, and one launch per backward
+        # pass (``_WeightShadows.scatter``) cuts every such buffer into the parameters' bucket slices
+        dw = asm['dw'].detach()
+        direct = True
     key = _ws_key(x.device)
     if direct and DEFER_WGRAD_REDUCE and getattr(leaf, '_stp3_uses', 0) == 1 and _single_process():
         # nobody reads this gradient before the optimizer: only the split contraction runs now, its partial sums stay in this
@@ -1404,10 +1416,21 @@ def flush_wgrad_reductions():
     for arena in _WGRAD_ARENAS.values():
         if arena.jobs or arena.wanted:
             arena.flush()
+    for tab in _SHADOW_TABLES.values():             # (after the sums: the assembled weights' gradients are among them)
+        if tab.pending_scatter:
+            ents, tab.pending_scatter = tab.pending_scatter, []
+            tab.scatter(ents)
 
 
 def pending_wgrad_reductions():
-    return sum(len(a.jobs) for a in _WGRAD_ARENAS.values())
+    return sum(len(a.jobs) for a in _WGRAD_ARENAS.values()) + sum(len(t.pending_scatter) for t in _SHADOW_TABLES.values())
+
+
+def reset_weight_uses():
+    """``GradientBuckets.zero_grad``: a new pass -- no assembled weight has been applied in it yet."""
+    for tab in _SHADOW_TABLES.values():
+        for e in tab.assembled.values():
+            e['uses'] = 0
 
 
 def _same_memory_order(a, b):
@@ -1470,6 +1493,10 @@ class _WeightShadows:
     def __init__(self, device):
         self.device = torch.device(device)
         self.entries = {}            # id(parameter) -> entry
+        self.assembled = {}          # key -> entry of a weight assembled from parameter views (``assembled_weight``)
+        self.scatter_tables = {}     # set of assembled weights -> device table of their gradient scatter
+        self.pending_scatter = []    # assembled weights whose gradient waits for the end of the backward pass
+        self.rows = 0
         self.order = []
         self.table = None            # stp3_wprep_entry[n] in device memory
         self.total_blocks = 0
@@ -1489,33 +1516,87 @@ class _WeightShadows:
                'wb': torch.empty((cout, cin, kh, kw), **opts),         # memory [Cout][KH][KW][Cin]
                'wt': torch.empty((cin, cout, kh, kw), **opts)}         # memory [Cin][KH][KW][Cout], taps flipped
         self.entries[id(weight)] = ent
-        self.order = [e for e in self.order if e['ref']() is not None and e is not ent] + [ent]
+        self.order = [e for e in self.order if _shadow_alive(e) and e is not ent] + [ent]
         self._build_table()
         self.refresh()
         return ent
 
-    def _build_table(self):
-        arr = (_lib.WprepEntry * len(self.order))()
-        block = 0
-        for rec, e in zip(arr, self.order):
+    def register_taps(self, weight):
+        """A depthwise (C,1,K,K) parameter: its tap-major float32 copy [K*K][C] (what stp3_dwconv2d_* read) joins the table."""
+        c, _, k, _ = weight.shape
+        ent = {'ref': weakref.ref(weight), 'ptr': weight.data_ptr(), 'version': weight._version, 'kind': 'taps',
+               'taps': torch.empty((k * k, c), dtype=torch.float32, device=weight.device)}
+        self.entries[id(weight)] = ent
+        self.order = [e for e in self.order if _shadow_alive(e) and e is not ent] + [ent]
+        self._build_table()
+        self.refresh()
+        return ent
+
+    def register_assembled(self, key, shape, pieces):
+        """A weight ASSEMBLED from views of parameters (``assembled_weight``): shadows of the whole, one table row per piece."""
+        cout, cin, kh, kw = shape
+        dev = self.device
+        opts = dict(dtype=torch.bfloat16, device=dev)
+        ent = {'kind': 'assembled', 'key': key, 'shape': tuple(shape), 'pieces': pieces, 'uses': 0, 'claim': None,
+               'signature': _pieces_signature(shape, pieces),
+               # (zeroed ONCE: the lanes between the pieces are never written)
+               'wb': torch.zeros((cout, cin, kh, kw), **opts).contiguous(memory_format=torch.channels_last),
+               'wt': torch.zeros((cin, cout, kh, kw), **opts).contiguous(memory_format=torch.channels_last),
+               # the float32 gradient of the whole, [Cout][KH][KW][Cin]: stp3_conv2d_wgrad writes it, one launch per backward pass
+               # cuts it into the parameters' gradients
+               'dw': torch.zeros((cout, cin, kh, kw), dtype=torch.float32, device=dev).contiguous(memory_format=torch.channels_last),
+               # what the operators receive as "the weight": shape and dtype only -- every kernel reads the shadows; NaN so
+               # that anything that did read it shows
+               'token': torch.full((1,), float('nan'), dtype=torch.float32, device=dev).expand(cout, cin, kh, kw),
+               'scatter_table': None}
+        self.assembled[key] = ent
+        self.order = [e for e in self.order if _shadow_alive(e) and e is not ent] + [ent]
+        self._build_table()
+        self.refresh()
+        return ent
+
+    def _rows(self, e):
+        kind = e.get('kind', 'leaf')
+        if kind == 'leaf':
             w = e['ref']()
-            cout, cin, kh, kw = w.shape
-            rec.src, rec.fwd, rec.flip = w.data_ptr(), e['wb'].data_ptr(), e['wt'].data_ptr()
-            rec.stride_co, rec.stride_ci, rec.stride_kh, rec.stride_kw = w.stride()
+            return [dict(src=w.data_ptr(), fwd=e['wb'].data_ptr(), flip=e['wt'].data_ptr(), strides=w.stride(), dims=tuple(w.shape))]
+        if kind == 'taps':
+            w = e['ref']()
+            c, _, k, _ = w.shape
+            return [dict(src=w.data_ptr(), fwd=e['taps'].data_ptr(), flip=0, strides=(0, w.stride(0), w.stride(2), w.stride(3)),
+                         dims=(1, c, k, k), fwd_f32=1)]
+        cout, cin = e['shape'][:2]
+        return [dict(src=pc['param']().data_ptr() + 4 * pc['offset'], fwd=e['wb'].data_ptr(), flip=e['wt'].data_ptr(),
+                     strides=pc['strides'], dims=pc['dims'], dst=(cout, cin, pc['co_off'], pc['ci_off'])) for pc in e['pieces']]
+
+    @staticmethod
+    def _fill_table(rows):
+        arr = (_lib.WprepEntry * len(rows))()
+        block = 0
+        for rec, r in zip(arr, rows):
+            rec.src, rec.fwd, rec.flip = r['src'], r['fwd'], r['flip']
+            rec.stride_co, rec.stride_ci, rec.stride_kh, rec.stride_kw = r['strides']
             rec.first_block = block
-            rec.cout, rec.cin, rec.kh, rec.kw = cout, cin, kh, kw
-            block += (w.numel() + 255) // 256
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            rec.cout, rec.cin, rec.kh, rec.kw = r['dims']
+            rec.dst_cout, rec.dst_cin, rec.co_off, rec.ci_off = r.get('dst', (0, 0, 0, 0))
+            rec.fwd_f32 = r.get('fwd_f32', 0)
+            block += (r['dims'][0] * r['dims'][1] * r['dims'][2] * r['dims'][3] + 255) // 256
+        return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8), block
+
+    def _build_table(self):
+        rows = [r for e in self.order for r in self._rows(e)]
+        host, self.total_blocks = self._fill_table(rows)
         self.table = host.to(self.device)
-        self.total_blocks = block
+        self.rows = len(rows)
 
     def refresh(self):
         """Rewrite every shadow from its fp32 master: one launch."""
         if not self.order:
             return
-        if any(e['ref']() is None or e['ref']().data_ptr() != e['ptr'] for e in self.order):
-            self.order = [e for e in self.order if e['ref']() is not None and e['ref']().data_ptr() == e['ptr']]
-            self.entries = {id(e['ref']()): e for e in self.order}
+        if not all(_shadow_alive(e) for e in self.order):
+            self.order = [e for e in self.order if _shadow_alive(e)]
+            self.entries = {id(e['ref']()): e for e in self.order if 'ref' in e}
+            self.assembled = {e['key']: e for e in self.order if e.get('kind') == 'assembled'}
             if not self.order:
                 return
             self._build_table()
@@ -1523,11 +1604,53 @@ class _WeightShadows:
         # the launch goes to the device that owns the pointers in the table (CPU tensors: the kernels-on-CPU test build)
         guard = torch.cuda.device(self.device) if self.device.type == 'cuda' else contextlib.nullcontext()
         with guard:
-            check(_lib.lib().stp3_conv2d_prep_weights(_ptr(self.table), len(self.order), self.total_blocks, _stream()),
+            check(_lib.lib().stp3_conv2d_prep_weights(_ptr(self.table), self.rows, self.total_blocks, _stream()),
                   'stp3_conv2d_prep_weights')
         for e in self.order:
-            e['version'] = e['ref']()._version
+            if 'ref' in e:
+                e['version'] = e['ref']()._version
+            else:
+                e['versions'] = tuple(pc['param']()._version for pc in e['pieces'])
             e.pop('phases', None)                  # sub-kernels cut from the flipped shadow (_strided_dgrad)
+
+    # -- the gradients of the assembled weights: back to their parameters ---------------------------------------------------
+    def scatter_rows(self, e):
+        """Table rows that cut ``e['dw']`` into the parameters' gradient slices (``_stp3_grad_view``: same strides as the
+        parameter, parallel.GradientBuckets)."""
+        cout, cin = e['shape'][:2]
+        return [dict(src=pc['param']()._stp3_grad_view.data_ptr() + 4 * pc['offset'], fwd=e['dw'].data_ptr(), flip=0,
+                     strides=pc['strides'], dims=pc['dims'], dst=(cout, cin, pc['co_off'], pc['ci_off'])) for pc in e['pieces']]
+
+    def scatter(self, ents):
+        """One launch: the gradients of the assembled weights ``ents`` into their parameters' bucket slices.  The table of a
+        set of weights is uploaded once and kept (the same set comes back every step; a captured step replays the launch)."""
+        if not ents:
+            return
+        key = tuple(id(e) for e in ents) + tuple(pc['param']()._stp3_grad_view.data_ptr() for e in ents for pc in e['pieces'])
+        tab = self.scatter_tables.get(key)
+        if tab is None:
+            rows = [r for e in ents for r in self.scatter_rows(e)]
+            host, blocks = self._fill_table(rows)
+            if len(self.scatter_tables) > 64:
+                self.scatter_tables.clear()
+            tab = self.scatter_tables[key] = (host.to(self.device), len(rows), blocks, list(ents))
+        import contextlib
+        guard = torch.cuda.device(self.device) if self.device.type == 'cuda' else contextlib.nullcontext()
+        with guard:
+            check(_lib.lib().stp3_conv2d_scatter_weight_grads(_ptr(tab[0]), tab[1], tab[2], _stream()),
+                  'stp3_conv2d_scatter_weight_grads')
+
+
+def _shadow_alive(e):
+    if 'ref' in e:
+        w = e['ref']()
+        return w is not None and w.data_ptr() == e['ptr']
+    return all(pc['param']() is not None and pc['param']().data_ptr() == pc['ptr'] for pc in e['pieces'])
+
+
+def _pieces_signature(shape, pieces):
+    return (tuple(shape),) + tuple((id(pc['param']()), pc['ptr'], pc['offset'], tuple(pc['strides']), tuple(pc['dims']),
+                                    pc['co_off'], pc['ci_off']) for pc in pieces)
 
 
 _SHADOW_TABLES = {}                                # device -> _WeightShadows
@@ -1566,6 +1689,9 @@ def invalidate_weight_cache():
 
 
 def _bf16_weights(weight, need_flipped=False):
+    asm = getattr(weight, '_stp3_assembled', None)
+    if asm is not None:                          # (``assembled_weight``: the stand-in tensor of a weight made of parameter views)
+        return asm['wb'], asm['wt']
     if isinstance(weight, torch.nn.Parameter) and weight.requires_grad \
             and weight.dtype == torch.float32 and weight.is_cuda:
         tab = _shadows(weight.device)
@@ -1591,6 +1717,123 @@ def _bf16_weights(weight, need_flipped=False):
     if need_flipped and ent[3] is None:
         ent[3] = ent[2].flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
     return ent[2], ent[3]
+
+
+# Weights the model ASSEMBLES from parameters -- zero-padded channel lanes, the taps of a causal 3-D kernel side by side, the
+# heads of the decoder merged into one convolution, a projection split in two -- as shadows that stp3_conv2d_prep_weights writes
+# piece by piece with all the others, and whose gradient one launch per backward pass cuts back into the parameters' bucket
+# slices (``assembled_weight``).  Off: the call sites build the weight with torch (pad / cat / slice and their backward).
+ASSEMBLED_WEIGHTS = True
+
+
+def weight_piece(param, view, co_off=0, ci_off=0):
+    """One piece of an assembled weight: ``view`` -- a 4-D (co, ci, kh, kw) view of the leaf parameter ``param`` (any strides:
+    ``param.detach().unbind(2)[k]``, a channel split, the centre tap) -- placed at channel offsets (co_off, ci_off)."""
+    assert view.dim() == 4 and view.dtype == torch.float32 and param.dtype == torch.float32
+    off = (view.data_ptr() - param.data_ptr()) // 4
+    return {'param': weakref.ref(param), 'ptr': param.data_ptr(), 'offset': off, 'strides': tuple(view.stride()),
+            'dims': tuple(view.shape), 'co_off': int(co_off), 'ci_off': int(ci_off)}
+
+
+def assembled_weight_supported(x, params):
+    """The assembled route serves the bf16 kernels only (nothing holds the weight's float32 values): bf16 GPU activations (or
+    autocast, which makes them so) and float32 leaf parameters on the same device."""
+    return (ASSEMBLED_WEIGHTS and x.is_cuda and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled())
+            and all(isinstance(p, torch.nn.Parameter) and p.is_leaf and p.dtype == torch.float32 and p.device == x.device
+                    for p in params))
+
+
+def assembled_weight(key, shape, pieces, direct=True):
+    """The stand-in tensor of the (Cout, Cin, KH, KW) weight made of ``pieces`` (``weight_piece``), zero elsewhere: hand it to
+    ``conv2d`` / ``ops_fused.conv_bn_act`` as the weight.  Its bf16 shadows exist from the first call on and are rewritten with
+    every other weight's after an optimizer step; its gradient reaches the parameters of the pieces (through autograd: the
+    stand-in is the output of ``_AssembledWeight``).  ``key``: what identifies the weight among the model's (a module and a
+    name); the pieces may change between calls (another lane count): the entry is rebuilt then.
+    ``direct=False``: a parameter of the pieces ALSO reaches the loss some other way (the columns of a projection that
+    multiply a pooled vector): its gradient contributions must meet in autograd, so this one is handed over as a tensor."""
+    params = []
+    for pc in pieces:
+        p = pc['param']()
+        if not any(p is q for q in params):
+            params.append(p)
+    tab = _shadows(params[0].device)
+    ent = tab.assembled.get(key)
+    if ent is not None and (ent['signature'] != _pieces_signature(shape, pieces) or not _shadow_alive(ent)):
+        tab.order = [e for e in tab.order if e is not ent]
+        ent = None
+    if ent is None:
+        ent = tab.register_assembled(key, shape, pieces)
+    elif ent['versions'] != tuple(pc['param']()._version for pc in ent['pieces']):
+        tab.refresh()                              # a parameter was updated in place behind our back (a torch optimizer)
+    ent['uses'] += 1
+    token = _AssembledWeight.apply(ent, *params)
+    token._stp3_assembled = ent
+    token._stp3_assembled_direct = bool(direct)
+    return token
+
+
+def _assembled_claim(ent, dw):
+    """May the weight gradient of this backward pass go to the entry's buffer and from there to the bucket slices?  Yes for a
+    weight applied once since ``zero_grad`` whose parameters all take a direct gradient (see ``_conv2d_wgrad``: gather-mode
+    buckets, no gradient on the parameter yet, not claimed by another operator of this pass)."""
+    task = _graph_task_id()
+    if task == -1 or ent['uses'] != 1 or ent['claim'] == task or tuple(dw.shape) != ent['shape']:
+        return False
+    params = {id(pc['param']()): pc['param']() for pc in ent['pieces']}
+    for p in params.values():
+        view = getattr(p, '_stp3_grad_view', None)
+        if (view is None or p.grad is not None or not p.requires_grad or getattr(p, '_stp3_grad_claim', None) == task
+                or view.dtype != torch.float32 or view.device != dw.device or not _same_memory_order(view, p)):
+            return False
+    for p in params.values():
+        p._stp3_grad_claim = task
+    ent['claim'] = task
+    return True
+
+
+class _AssembledWeight(torch.autograd.Function):
+    """parameters -> the stand-in tensor of the weight assembled from their views.  Forward launches nothing (the shadows are
+    current).  Backward receives the gradient of the whole weight: when ``_conv2d_wgrad`` wrote it into the entry's buffer, the
+    parameters get fresh aliases of their bucket slices (autograd keeps them as ``.grad`` without a launch) and the entry
+    joins the pass's scatter launch (``flush_wgrad_reductions``; at once when the buckets are exchanged between ranks: the
+    bucket hooks may send a bucket as soon as its last gradient has landed); otherwise each parameter's gradient is cut out
+    with torch."""
+
+    @staticmethod
+    def forward(ctx, ent, *params):
+        ctx.ent = ent
+        ctx.params = params
+        return ent['token'].detach()
+
+    @staticmethod
+    def backward(ctx, dw):
+        ent, params = ctx.ent, ctx.params
+        direct = ent['claim'] == _graph_task_id() and dw.data_ptr() == ent['dw'].data_ptr()
+        grads = []
+        if direct:
+            tab = _shadows(ent['dw'].device)
+            for p in params:
+                covered = sum(pc['dims'][0] * pc['dims'][1] * pc['dims'][2] * pc['dims'][3] for pc in ent['pieces'] if pc['param']() is p)
+                if covered < p.numel():
+                    p._stp3_grad_view.zero_()      # (a dropped tap, an unused slice: its gradient is zero)
+                grads.append(p._stp3_grad_view.detach())
+            if _single_process():
+                tab.pending_scatter.append(ent)
+            else:
+                tab.scatter([ent])
+            return (None,) + tuple(grads)
+        for p, need in zip(params, ctx.needs_input_grad[1:]):
+            if not need:
+                grads.append(None)
+                continue
+            g = torch.zeros_like(p)
+            for pc in ent['pieces']:
+                if pc['param']() is p:
+                    co, ci = pc['dims'][:2]
+                    g.as_strided(pc['dims'], pc['strides'], pc['offset']).copy_(
+                        dw[pc['co_off']:pc['co_off'] + co, pc['ci_off']:pc['ci_off'] + ci])
+            grads.append(g)
+        return (None,) + tuple(grads)
 
 
 def _evict_weight(key, ent):
@@ -1654,7 +1897,11 @@ def conv2d_data_grad(dy, wb, weight_ref, x_shape, stride, pad, dil, out_dtype=to
     cout, cin, kh, kw = wb.shape
     bpad = (dil[0] * (kh - 1) - pad[0], dil[1] * (kw - 1) - pad[1])
     phase_cache = None
-    if weight_ref is not None and weight_ref.is_leaf and weight_ref.requires_grad:
+    asm = getattr(weight_ref, '_stp3_assembled', None) if weight_ref is not None else None
+    if asm is not None:
+        wt = asm['wt']
+        phase_cache = asm.setdefault('phases', {})
+    elif weight_ref is not None and weight_ref.is_leaf and weight_ref.requires_grad:
         wt = _bf16_weights(weight_ref, need_flipped=True)[1]
         ent = _shadows(weight_ref.device).lookup(weight_ref) if isinstance(weight_ref, torch.nn.Parameter) else None
         if ent is not None and ent['wt'] is wt:

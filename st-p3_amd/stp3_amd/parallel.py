@@ -144,6 +144,8 @@ class GradientBuckets:
             ops.flush_wgrad_reductions()     # (a backward pass nobody finished: its partial sums must not outlive it)
         for p in self.params:
             p._stp3_uses = 0                 # applications of the weight in the coming pass (ops.note_weight_use)
+        if self.buckets[0][0].is_cuda:
+            ops.reset_weight_uses()
         if self.gather:
             for p in self.params:
                 p.grad = None

@@ -547,6 +547,86 @@ def wgrad_defer(ops):
             'nonzero': float(plain[0].abs().max()) > 0, 'pending': [p0, p1, p2], 'left_over': ops.pending_wgrad_reductions()}
 
 
+def assembled_weights(ops):
+    """ops.ASSEMBLED_WEIGHTS: the weights the model puts together from parameters (padded channel lanes and causal taps of the
+    temporal block, the heads of the decoder merged, ASPP's kept taps and split projection, the padded stem) as shadows written
+    by stp3_conv2d_prep_weights and gradients cut back by stp3_conv2d_scatter_weight_grads -- against the same modules building
+    those weights with torch (pad / cat / block_diag / slice and their backward).  Same kernels, same bf16 operands: outputs and
+    flat gradient buckets must agree to the rounding of one bf16 sum; two passes with an optimizer-like update in between (the
+    shadows must follow the parameters), then the entries' use counters and pending lists must be clean."""
+    import torch.nn as nn
+    from stp3_amd.layers import temporal as T, convolutions as C, fused
+    from stp3_amd.models import decoder as D, efficientnet as E
+    from stp3_amd.parallel import GradientBuckets
+    torch.is_autocast_enabled = lambda *a: True
+    torch.get_autocast_gpu_dtype = lambda: torch.bfloat16
+    torch.get_autocast_dtype = lambda *a: torch.bfloat16
+    gate = {'perceive_hdmap': False, 'predict_pedestrian': True, 'predict_instance': True, 'predict_future_flow': False, 'planning': False}
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.stem = E.StaticSamePadConv2d(3, 16, 3, image_size=32, stride=2)
+            self.first = T.TemporalBlock(22, 16, use_pyramid_pooling=True, pool_sizes=[(2, 16, 24)])   # 16 planes + 6 constants
+            self.second = T.TemporalBlock(16, 16)
+            self.aspp = C.ASPP(16, [2, 18, 40], 16)          # 16 x 24 map: all taps, centre row only, centre tap only
+            self.decoder = D.Decoder(16, 2, 2, 2, gate)
+
+        def forward(self, img, extra):
+            b, t = extra.shape[0], extra.shape[2]
+            f = self.stem(img)                                                   # (b*t, 16, 16, 24)
+            x = f.view(b, t, *f.shape[1:]).permute(0, 2, 1, 3, 4)
+            x = self.second(self.first(x, extra))
+            y = x.permute(0, 2, 1, 3, 4).reshape(b * t, *x.shape[1:2], *x.shape[3:])
+            y = self.aspp(y.contiguous(memory_format=torch.channels_last))
+            out = self.decoder(y.view(b, t, *y.shape[1:]))
+            return sum(v.float().square().mean() for v in out.values() if v is not None) + f.float().mean()
+
+    def run(on):
+        ops.ASSEMBLED_WEIGHTS = on
+        torch.manual_seed(5)
+        from stp3_amd.utils import to_channels_last
+        model = to_channels_last(Net()).train()
+        for m in model.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0
+        buckets = GradientBuckets(model, bucket_bytes=64 << 10)
+        g = torch.Generator().manual_seed(2)
+        img = torch.randn(4, 3, 32, 48, generator=g)
+        extra = torch.randn(2, 6, 2, generator=g)
+        losses, flats, pending, calls = [], [], [], []
+        for it in range(2):
+            buckets.zero_grad()
+            with torch.autocast('cpu', dtype=torch.bfloat16):
+                loss = model(img, extra)
+            loss.backward()
+            pending.append(ops.pending_wgrad_reductions())
+            buckets.finish()
+            fused.flush_batch_counters()
+            losses.append(float(loss))
+            flats.append(torch.cat([f.clone() for f, _ in buckets.buckets]))
+            with torch.no_grad():                                                # "optimizer": through the flat buffers
+                for fp in buckets.flat_params:
+                    fp.mul_(0.97)
+            ops.invalidate_weight_cache()
+        n_asm = sum(len(t.assembled) for t in ops._SHADOW_TABLES.values())
+        return losses, flats, pending, n_asm
+
+    keep = ops.ASSEMBLED_WEIGHTS
+    plain = run(False)
+    for t in ops._SHADOW_TABLES.values():
+        assert not t.assembled
+    asm = run(True)
+    ops.ASSEMBLED_WEIGHTS = keep
+    scale = [float(f.abs().max()) for f in plain[1]]
+    return {'loss': max(abs(a - b) / abs(b) for a, b in zip(asm[0], plain[0])),
+            'grads': max(float((a - b).abs().max()) / s for a, b, s in zip(asm[1], plain[1], scale)),
+            'grads_l2': max(float((a - b).norm() / b.norm()) for a, b in zip(asm[1], plain[1])),
+            'nonzero': min(scale) > 0, 'assembled': asm[3], 'pending_before_finish': asm[2],
+            'left_over': ops.pending_wgrad_reductions(),
+            'uses_reset': all(e['uses'] <= 1 for t in ops._SHADOW_TABLES.values() for e in t.assembled.values())}
+
+
 def small_linear(ops):
     """stp3_linear_fwd / _bwd (the pooled descriptors' 1x1 convolutions as one launch each way) against float64 torch: output,
     input / weight / bias gradients; with and without a bias, row counts that are not multiples of the 16-lane split."""
@@ -1564,7 +1644,7 @@ def gru_cell(ops):
 
 
 CASES = {f.__name__: f for f in (model_step_f32_full_losses, model_step_two_ranks, lift_full, fuzz, model_step_f32, model_step_f32_bn_eval, model_step_bf16, model_step_bf16_bn_eval, conv_bn, lift_small, lift_c16, lift_c16_rows32, lift_c64_many_runs, lift_c64_rolled, lift_c64_frames, lift_coarse_grid, lift_tall, lift_c64_rows56, voxsum, wprep, optim, se_block, bn_act, bn_act_padded, causal_pair, upsample,
-                                 conv, conv_f32, wgrad_defer, small_linear, fan_out, aspp_join, pointwise_bn, pointwise_stream, decoder_heads, dwconv, layernorm, gru_cell, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
+                                 conv, conv_f32, wgrad_defer, assembled_weights, small_linear, fan_out, aspp_join, pointwise_bn, pointwise_stream, decoder_heads, dwconv, layernorm, gru_cell, mbconv_mid, losses, plan, image_prep, labels, bn_group_two_ranks)}
 
 if __name__ == '__main__':
     ops_mod = setup(sys.argv[1])

@@ -533,3 +533,86 @@ def test_expand_data_gradient_inside_the_apply_pass(monkeypatch, cin, cout):
     assert torch.equal(two[0], one[0]) and torch.equal(two[2], one[2]) and torch.equal(two[3], one[3])
     torch.testing.assert_close(one[1], two[1], rtol=1e-2, atol=1e-2 * float(two[1].abs().max()))
     print('dx bit-equal:', bool(torch.equal(one[1], two[1])))
+
+
+def test_assembled_weights_equal_the_torch_built_ones(monkeypatch):
+    """ops.ASSEMBLED_WEIGHTS: weights the model puts together from parameters (padded lanes and causal taps of the temporal
+    block, stp3/layers/temporal.py:8-37 / stp3/models/temporal_model.py; ASPP's kept taps and split projection,
+    stp3/layers/convolutions.py; the merged decoder heads, stp3/models/decoder.py:96-140) as shadows written piece by piece by
+    stp3_conv2d_prep_weights, their gradients cut back into the bucket slices by ONE stp3_conv2d_scatter_weight_grads per
+    backward pass -- against the same modules building the weights with torch.  Same kernels on the same bf16 operands: the
+    loss and the flat gradient buckets are bit-equal, over two passes with a parameter update in between."""
+    from stp3_amd import _lib, ops
+    from stp3_amd.layers import temporal as T, convolutions as C, fused
+    from stp3_amd.models import decoder as D
+    from stp3_amd.parallel import GradientBuckets
+    from stp3_amd.utils import to_channels_last
+    gate = {'perceive_hdmap': False, 'predict_pedestrian': True, 'predict_instance': True, 'predict_future_flow': False, 'planning': False}
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.first = T.TemporalBlock(70, 64, use_pyramid_pooling=True, pool_sizes=[(2, 32, 48)])   # 64 planes + 6 constants
+            self.second = T.TemporalBlock(64, 64)
+            self.aspp = C.ASPP(64, [2, 36, 60], 32)            # 32 x 48 map: all taps, centre row only, centre tap only
+            self.decoder = D.Decoder(32, 2, 2, 2, gate)
+
+        def forward(self, x, extra):
+            b, _, t = extra.shape
+            x = self.second(self.first(x, extra))
+            y = x.permute(0, 2, 1, 3, 4).reshape(b * t, x.shape[1], *x.shape[3:]).contiguous(memory_format=torch.channels_last)
+            out = self.decoder(self.aspp(y).view(b, t, -1, *y.shape[2:]))
+            return sum(v.float().square().mean() for v in out.values() if v is not None)
+
+    lib = _lib.lib()
+    counts = {}
+
+    class Counting:
+        def __getattr__(self, name):
+            fn = getattr(lib, name)
+            if name != 'stp3_conv2d_scatter_weight_grads':
+                return fn
+
+            def wrapped(*a):
+                counts[name] = counts.get(name, 0) + 1
+                return fn(*a)
+            return wrapped
+
+    monkeypatch.setattr(_lib, 'lib', lambda: Counting())
+
+    def run(on):
+        monkeypatch.setattr(ops, 'ASSEMBLED_WEIGHTS', on)
+        torch.manual_seed(5)
+        model = to_channels_last(Net()).cuda().train()
+        for m in model.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0
+        buckets = GradientBuckets(model)
+        g = torch.Generator().manual_seed(2)
+        x = torch.randn(2, 64, 2, 32, 48, generator=g).cuda()
+        extra = torch.randn(2, 6, 2, generator=g).cuda()
+        losses, flats = [], []
+        for _ in range(2):
+            buckets.zero_grad()
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                loss = model(x, extra)
+            loss.backward()
+            buckets.finish()
+            fused.flush_batch_counters()
+            losses.append(float(loss.detach()))
+            flats.append(torch.cat([f.clone() for f, _ in buckets.buckets]))
+            with torch.no_grad():
+                for fp in buckets.flat_params:
+                    fp.mul_(0.97)
+            ops.invalidate_weight_cache()
+        return losses, flats
+
+    plain = run(False)
+    assert not counts
+    asm = run(True)
+    assert counts == {'stp3_conv2d_scatter_weight_grads': 2}            # one launch per backward pass
+    assert sum(len(t.assembled) for t in ops._SHADOW_TABLES.values()) >= 12
+    assert asm[0] == plain[0], (asm[0], plain[0])
+    for a, b in zip(asm[1], plain[1]):
+        assert float(b.abs().max()) > 0
+        assert torch.equal(a, b), float((a - b).abs().max() / b.abs().max())

@@ -28,7 +28,7 @@ import build as hipcpu_build  # noqa: E402
 
 REVERSE, RANDOM = {'HIPCPU_ORDER': 'reverse'}, {'HIPCPU_ORDER': 'random'}     # fiber scheduling orders (missing barriers)
 ROUTINE = [('fuzz', {}), ('voxsum', {}), ('wprep', {}), ('optim', {}), ('se_block', {}), ('dwconv', {}), ('layernorm', {}), ('gru_cell', {}), ('bn_act', {}), ('bn_act_padded', {}), ('causal_pair', {}), ('upsample', {}),
-           ('conv', {}), ('conv_f32', {}), ('wgrad_defer', {}), ('small_linear', {}), ('fan_out', {}), ('aspp_join', {}), ('pointwise_bn', {}), ('pointwise_stream', {}), ('decoder_heads', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('labels', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}), ('lift_c64_rolled', {}),
+           ('conv', {}), ('conv_f32', {}), ('wgrad_defer', {}), ('assembled_weights', {}), ('small_linear', {}), ('fan_out', {}), ('aspp_join', {}), ('pointwise_bn', {}), ('pointwise_stream', {}), ('decoder_heads', {}), ('conv_bn', {}), ('mbconv_mid', {}), ('losses', {}), ('plan', {}), ('image_prep', {}), ('labels', {}), ('bn_group_two_ranks', {}), ('lift_c16', {}), ('lift_c16_rows32', {}), ('lift_c64_many_runs', {}), ('lift_c64_rolled', {}),
            ('lift_c64_frames', {}), ('lift_c64_rows56', {}), ('lift_coarse_grid', {}), ('lift_small', {}), ('lift_tall', {})]
 ORDER_CASES = ['voxsum', 'wprep', 'optim', 'se_block', 'dwconv', 'layernorm', 'gru_cell', 'bn_act', 'conv', 'conv_bn', 'pointwise_bn', 'pointwise_stream', 'mbconv_mid', 'losses', 'plan', 'image_prep', 'labels', 'lift_c16']
 ROUTINE += [(c, o) for c in ORDER_CASES for o in (REVERSE, RANDOM)]
@@ -288,6 +288,18 @@ def test_pointwise_conv_batchnorm_without_the_convolution_output(results):
             continue
         assert r['y'] == 0.0 and r['dx'] == 0.0 and r['rmean'] == 0.0 and r['rvar'] == 0.0, (name, r)
         assert r['dw'] <= 5e-6 and r['dgamma'] <= 5e-6 and r['dbeta'] <= 5e-6, (name, r)
+
+
+def test_assembled_weights_equal_the_torch_built_ones(results):
+    """ops.ASSEMBLED_WEIGHTS (stp3_conv2d_prep_weights writing the pieces of padded / merged / split weights,
+    stp3_conv2d_scatter_weight_grads cutting their gradients back into the parameters' bucket slices) against the same modules
+    building those weights with torch: temporal blocks (with and without constant planes and pyramid pooling), ASPP with kept
+    taps, merged decoder heads, the padded stem -- the same kernels on the same bf16 operands, so loss and flat gradient
+    buckets agree to float32 summation order over two passes with a parameter update in between."""
+    r = _get(results, 'assembled_weights')
+    assert r['nonzero'] and r['assembled'] >= 15 and r['left_over'] == 0 and r['uses_reset'], r
+    assert all(p > 0 for p in r['pending_before_finish']), r           # (single process: the scatter waits for finish())
+    assert r['loss'] <= 1e-6 and r['grads'] <= 1e-5 and r['grads_l2'] <= 1e-6, r
 
 
 def test_streaming_pointwise_kernel_in_all_modes(results):

@@ -97,5 +97,10 @@ def test_step_runs_and_call_mix(recorder, tmp_path):
     # (the first step meets an arena that is too small for all of them: those layers reduce at once, the arena grows after it)
     assert calls['stp3_conv2d_wgrad_partials'] > 70 and calls['stp3_conv2d_wgrad_reduce_batch'] == STEPS, calls
     # weight shadows: once per newly met layer during the first step, then once per optimizer step -- never per use
+    # (the depthwise layers' tap-major float32 copies and the weights ASSEMBLED from parameter views -- padded lanes, causal taps
+    # side by side, merged heads, split projections: ops.assembled_weight -- are rows of the same table)
     n_layers = calls['stp3_conv2d_prep_weights'] - STEPS
-    assert 0 < n_layers <= wgrads // STEPS + 1, (n_layers, wgrads)
+    n_depthwise = calls['stp3_dwconv2d_fwd_stats_bn'] // STEPS
+    assert 0 < n_layers <= wgrads // STEPS + 1 + n_depthwise, (n_layers, wgrads, n_depthwise)
+    # ... and the gradients of the assembled weights go back to their parameters in ONE launch per backward pass
+    assert calls['stp3_conv2d_scatter_weight_grads'] == STEPS, calls['stp3_conv2d_scatter_weight_grads']
