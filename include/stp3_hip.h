@@ -402,10 +402,14 @@ int stp3_sum_n_plane(int32_t n, int64_t numel, int32_t dtype, const void* const*
  *   networks: 1x1 convolutions of maps that are constant over the plane (ASPP image pooling, stp3/layers/convolutions.py:229-240;
  *   pyramid pooling, stp3/layers/temporal.py:380-424; the ego-motion planes, stp3/models/stp3.py:145-152) are products of a few
  *   rows whose time is launch latency -- one launch forward, ONE backward for dx [M][K], dw [N][K] and db [N] (each may be NULL:
- *   not needed).  Deterministic: every sum is split over 16 lanes in a fixed way and finished by a fixed tree. */
-int stp3_linear_fwd(int32_t M, int32_t K, int32_t N, const float* x, const float* w, const float* b, float* y, void* stream);
-int stp3_linear_bwd(int32_t M, int32_t K, int32_t N, const float* dy, const float* x, const float* w, float* dx, float* dw,
-                    float* db, void* stream);
+ *   not needed).  Deterministic: every sum is split over 16 lanes in a fixed way and finished by a fixed tree.
+ *   ldw / lddw: row strides (in floats, >= K) of w and dw -- the weight may be a run of COLUMNS of a wider parameter (the columns
+ *   of ASPP's projection that multiply the pooled vector, of a temporal block's 1x1x1 kernel that multiply the ego-motion
+ *   planes), read in place, and its gradient written straight into the same columns of the parameter's gradient. */
+int stp3_linear_fwd(int32_t M, int32_t K, int32_t N, const float* x, const float* w, int32_t ldw, const float* b, float* y,
+                    void* stream);
+int stp3_linear_bwd(int32_t M, int32_t K, int32_t N, const float* dy, const float* x, const float* w, int32_t ldw, float* dx,
+                    float* dw, int32_t lddw, float* db, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense 2-D convolution, bf16 MFMA implicit GEMM, NHWC (csrc/stp3_conv.hip).

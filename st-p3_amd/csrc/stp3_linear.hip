@@ -19,7 +19,7 @@ constexpr int kLanes = 16;                  // lanes that share one output eleme
 
 // forward: element e = m * N + n
 __global__ __launch_bounds__(kT) void linear_fwd_kernel(int M, int K, int N, const float* __restrict__ x,
-                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        const float* __restrict__ w, int ldw, const float* __restrict__ b,
                                                         float* __restrict__ y) {
     const int lane = threadIdx.x & (kLanes - 1);
     const long e = ((long)blockIdx.x * kT + threadIdx.x) / kLanes;
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(kT) void linear_fwd_kernel(int M, int K, int N, con
     const long ec = ok ? e : 0;                                   // (all 16 lanes of a row run the tree: clamp, do not exit)
     const int m = (int)(ec / N), n = (int)(ec - (long)m * N);
     const float* xr = x + (size_t)m * K;
-    const float* wr = w + (size_t)n * K;
+    const float* wr = w + (size_t)n * ldw;
     float acc = 0.f;
     for (int k = lane; k < K; k += kLanes) acc = fmaf(xr[k], wr[k], acc);
     acc = row16_sum(acc);
@@ -37,8 +37,9 @@ __global__ __launch_bounds__(kT) void linear_fwd_kernel(int M, int K, int N, con
 // backward: elements [0, M*K) = dx, [M*K, M*K + N*K) = dw, then N of db; absent outputs (null) take no elements
 //   dx[m][k] = sum_n dy[m][n] w[n][k];   dw[n][k] = sum_m dy[m][n] x[m][k];   db[n] = sum_m dy[m][n]
 __global__ __launch_bounds__(kT) void linear_bwd_kernel(int M, int K, int N, const float* __restrict__ dy,
-                                                        const float* __restrict__ x, const float* __restrict__ w,
-                                                        float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db) {
+                                                        const float* __restrict__ x, const float* __restrict__ w, int ldw,
+                                                        float* __restrict__ dx, float* __restrict__ dw, int lddw,
+                                                        float* __restrict__ db) {
     const int lane = threadIdx.x & (kLanes - 1);
     const long n_dx = dx ? (long)M * K : 0, n_dw = dw ? (long)N * K : 0, n_db = db ? N : 0;
     const long e = ((long)blockIdx.x * kT + threadIdx.x) / kLanes;
@@ -48,13 +49,13 @@ __global__ __launch_bounds__(kT) void linear_bwd_kernel(int M, int K, int N, con
     if (ok) {
         if (e < n_dx) {
             const int m = (int)(e / K), k = (int)(e - (long)m * K);
-            for (int n = lane; n < N; n += kLanes) acc = fmaf(dy[(size_t)m * N + n], w[(size_t)n * K + k], acc);
+            for (int n = lane; n < N; n += kLanes) acc = fmaf(dy[(size_t)m * N + n], w[(size_t)n * ldw + k], acc);
             out = dx + e;
         } else if (e < n_dx + n_dw) {
             const long q = e - n_dx;
             const int n = (int)(q / K), k = (int)(q - (long)n * K);
             for (int m = lane; m < M; m += kLanes) acc = fmaf(dy[(size_t)m * N + n], x[(size_t)m * K + k], acc);
-            out = dw + q;
+            out = dw + (size_t)n * lddw + k;
         } else {
             const int n = (int)(e - n_dx - n_dw);
             for (int m = lane; m < M; m += kLanes) acc += dy[(size_t)m * N + n];
@@ -74,23 +75,24 @@ inline int status() {
 
 extern "C" {
 
-int stp3_linear_fwd(int32_t M, int32_t K, int32_t N, const float* x, const float* w, const float* b, float* y, void* stream) {
-    if (M <= 0 || K <= 0 || N <= 0 || !x || !w || !y) return STP3_EINVAL;
+int stp3_linear_fwd(int32_t M, int32_t K, int32_t N, const float* x, const float* w, int32_t ldw, const float* b, float* y,
+                    void* stream) {
+    if (M <= 0 || K <= 0 || N <= 0 || !x || !w || !y || ldw < K) return STP3_EINVAL;
     const int64_t elems = (int64_t)M * N;
     if (elems * kLanes >= (1LL << 31) * (int64_t)kT) return STP3_EUNSUP;
     const unsigned blocks = (unsigned)((elems * kLanes + kT - 1) / kT);
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3(blocks), dim3(kT), 0, (hipStream_t)stream, (int)M, (int)K, (int)N, x, w, b, y);
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3(blocks), dim3(kT), 0, (hipStream_t)stream, (int)M, (int)K, (int)N, x, w, (int)ldw, b, y);
     return status();
 }
 
-int stp3_linear_bwd(int32_t M, int32_t K, int32_t N, const float* dy, const float* x, const float* w, float* dx, float* dw,
-                    float* db, void* stream) {
-    if (M <= 0 || K <= 0 || N <= 0 || !dy || (dx && !w) || (dw && !x)) return STP3_EINVAL;
+int stp3_linear_bwd(int32_t M, int32_t K, int32_t N, const float* dy, const float* x, const float* w, int32_t ldw, float* dx,
+                    float* dw, int32_t lddw, float* db, void* stream) {
+    if (M <= 0 || K <= 0 || N <= 0 || !dy || (dx && (!w || ldw < K)) || (dw && (!x || lddw < K))) return STP3_EINVAL;
     const int64_t elems = (dx ? (int64_t)M * K : 0) + (dw ? (int64_t)N * K : 0) + (db ? N : 0);
     if (elems == 0) return STP3_OK;
     if (elems * kLanes >= (1LL << 31) * (int64_t)kT) return STP3_EUNSUP;
     const unsigned blocks = (unsigned)((elems * kLanes + kT - 1) / kT);
-    hipLaunchKernelGGL(linear_bwd_kernel, dim3(blocks), dim3(kT), 0, (hipStream_t)stream, (int)M, (int)K, (int)N, dy, x, w, dx, dw, db);
+    hipLaunchKernelGGL(linear_bwd_kernel, dim3(blocks), dim3(kT), 0, (hipStream_t)stream, (int)M, (int)K, (int)N, dy, x, w, (int)ldw, dx, dw, (int)lddw, db);
     return status();
 }
 

@@ -195,8 +195,9 @@ SIGNATURES = {
     'stp3_bn_bwd_train': (c_int, [_BN_P] + [c_void_p] * 10 + [c_size_t] + [c_void_p] * 4),
     'stp3_bn_dsbias': (c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     'stp3_sum_n': (c_int, [c_int32, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
-    'stp3_linear_fwd': (c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'stp3_linear_bwd': (c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'stp3_linear_fwd': (c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    'stp3_linear_bwd': (c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
+                                c_void_p]),
     'stp3_sum_n_plane': (c_int, [c_int32, ctypes.c_int64, c_int32, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_void_p, c_void_p]),
     'stp3_conv2d_fwd_workspace': (c_int, [ctypes.POINTER(ConvDims), ctypes.POINTER(c_size_t)]),
     'stp3_conv2d_fwd': (c_int, [ctypes.POINTER(ConvDims)] + [c_void_p] * 6 + [c_size_t, c_void_p]),

@@ -209,10 +209,10 @@ class ASPP(nn.Module):
         # (split, not two slices: one concatenation in backward instead of two zero-fills, two copies and an addition)
         if n_sp % 8 == 0 and proj.weight.shape[0] % 8 == 0 and ops.assembled_weight_supported(spatial, (proj.weight,)):
             # the columns of the spatial branches as a weight of their own (ops.assembled_weight); the pooled branch's columns
-            # go another way (below), so the parameter's gradient is put together by autograd
-            w_pool = proj.weight[:, n_sp:]
+            # go another way (below) and write their part of the parameter's gradient themselves (ops.weight_columns)
             w_sp = ops.assembled_weight((id(proj), 'spatial'), (proj.weight.shape[0], n_sp, 1, 1),
-                                        [ops.weight_piece(proj.weight, proj.weight.detach()[:, :n_sp])], direct=False)
+                                        [ops.weight_piece(proj.weight, proj.weight.detach()[:, :n_sp])], direct='shared')
+            w_pool = ops.weight_columns(w_sp, proj.weight, n_sp, proj.weight.shape[1])
         else:
             w_sp, w_pool = proj.weight.split([n_sp, proj.weight.shape[1] - n_sp], dim=1)
         y = conv2d(spatial, w_sp)

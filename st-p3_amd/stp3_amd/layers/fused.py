@@ -328,7 +328,12 @@ class _PlaneMean(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (n, c, h, w), dtype, cl = ctx.meta
-        g = (g * (1.0 / (h * w))).to(dtype).view(n, c, 1, 1).expand(n, c, h, w)
+        if g.is_cuda and g.dtype == torch.float32 and dtype == torch.bfloat16:
+            # (scale and round in ONE launch: float32 product, one rounding -- what the two operators below give)
+            g = torch.mul(g, 1.0 / (h * w), out=torch.empty(g.shape, dtype=dtype, device=g.device))
+        else:
+            g = (g * (1.0 / (h * w))).to(dtype)
+        g = g.view(n, c, 1, 1).expand(n, c, h, w)
         if g.is_cuda and cl and dtype in (torch.bfloat16, torch.float32):
             # the broadcast stays a stride-0 VIEW: the single-pass sum of the input's gradients (ops.fan_out) adds it as a
             # per-(sample, channel) term; any other consumer sees an ordinary (expanded) tensor

@@ -61,13 +61,15 @@ def _conv2d_padded_channels(x, weight, padding=0):
     return y[:, :co] if cop != co else y
 
 
-def _conv2d_pieces(x, key, out_channels, kernel, pieces, padding=0, direct=True):
+def _conv2d_pieces(x, key, out_channels, kernel, pieces, padding=0, direct=True, token_out=None):
     """conv2d of x with the weight ASSEMBLED from ``pieces`` (``ops.weight_piece``: views of parameters at channel offsets of a
     zero weight with ``out_channels`` outputs -- padded to a multiple of 8 -- and x's channels as inputs): what
     ``_conv2d_padded_channels(x, <the same weight built with pad / cat>)`` computes, without a torch operator for the weight
     or its gradient (``ops.assembled_weight``).  Callers check ``ops.assembled_weight_supported`` and x.shape[1] % 8 == 0."""
     cop = _pad8(out_channels)
     w = ops.assembled_weight(key, (cop, x.shape[1], kernel[0], kernel[1]), pieces, direct=direct)
+    if token_out is not None:
+        token_out.append(w)                        # (for ``ops.weight_columns``: the parameter's other columns)
     y = conv2d(x, w, None, 1, padding)
     return y[:, :out_channels] if cop != out_channels else y
 
@@ -288,9 +290,10 @@ class TemporalBlock(nn.Module):
             # the columns that multiply x2, output lanes padded: one piece of an assembled weight.  With ``extra2`` the
             # parameter's other columns take their own way to the loss (below): its gradient is put together by autograd.
             piece = ops.weight_piece(conv.weight, conv.weight.detach().squeeze(2)[:, :c])
+            token = []
             y = _conv2d_pieces(x2, (id(conv), 'x'), wgt.shape[0] if lanes is None else lanes, (1, 1), [piece],
-                               direct=extra2 is None)
-            w_extra = None if extra2 is None else wgt[:, c:]
+                               direct=True if extra2 is None else 'shared', token_out=token)
+            w_extra = None if extra2 is None else ops.weight_columns(token[0], conv.weight, c, wgt.shape[1])
         else:
             # (split, not two slices: one concatenation in backward instead of two zero-fills, two copies and an addition)
             w_x, w_extra = (wgt, None) if extra2 is None else wgt.split([c, wgt.shape[1] - c], dim=1)
@@ -360,14 +363,21 @@ class TemporalBlock(nn.Module):
         # the paths' columns and one run of columns per pooled tensor: ONE split (its backward is one concatenation)
         pooled_list = [] if not self.use_pyramid_pooling else \
             list(pooled_outs if pooled_outs is not None else self.pyramid_pooling(x, extra, folded=x_pool))   # (B, C', T, h', w')
-        w_parts = wgt.split([self._paths_channels] + [pl.shape[1] for pl in pooled_list], dim=1) if pooled_list else (wgt,)
         if lanes % 8 == 0 and paths.shape[1] == len(outs) * lanes and ops.assembled_weight_supported(paths, (agg.conv.weight,)):
-            # one run of columns per path, each at the start of its run of ``lanes`` input lanes: pieces of an assembled weight
+            # one run of columns per path, each at the start of its run of ``lanes`` input lanes: pieces of an assembled weight;
+            # the pooled tensors' columns go their own way (below) and write their part of the gradient themselves
             g = self._paths_channels // len(outs)
             flat = agg.conv.weight.detach().squeeze(2)
             pieces = [ops.weight_piece(agg.conv.weight, flat[:, i * g:(i + 1) * g], 0, i * lanes) for i in range(len(outs))]
-            y = _conv2d_pieces(paths, (id(agg.conv), 'paths'), wgt.shape[0], (1, 1), pieces, direct=not pooled_list)
+            token = []
+            y = _conv2d_pieces(paths, (id(agg.conv), 'paths'), wgt.shape[0], (1, 1), pieces,
+                               direct='shared' if pooled_list else True, token_out=token)
+            w_parts, c0 = [None], self._paths_channels
+            for pl in pooled_list:
+                w_parts.append(ops.weight_columns(token[0], agg.conv.weight, c0, c0 + pl.shape[1]))
+                c0 += pl.shape[1]
         else:
+            w_parts = wgt.split([self._paths_channels] + [pl.shape[1] for pl in pooled_list], dim=1) if pooled_list else (wgt,)
             y = _conv2d_padded_channels(paths, _pad_in(w_parts[0], len(outs), lanes))
         sbias = None
         if self.use_pyramid_pooling:

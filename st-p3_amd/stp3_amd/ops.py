@@ -1075,17 +1075,31 @@ def fan_out(x, n):
     return list(_FanOut.apply(x, n))
 
 
+def _rows_f32(w):
+    """A float32 matrix as (tensor, row stride) for the kernels: rows of unit stride, any row stride (the columns of a wider
+    parameter, read in place); anything else is copied."""
+    if w.stride(1) != 1 or w.stride(0) < w.shape[1]:
+        w = w.contiguous()
+    return w, w.stride(0)
+
+
+_COLUMN_DESTS = {}        # (address, rows, columns) of a ``weight_columns`` tensor -> (entry, parameter, c0, c1)
+
+
 class _SmallLinear(torch.autograd.Function):
-    """y = x W^T + b for a handful of rows, float32 (stp3_linear_fwd / _bwd): one launch each way."""
+    """y = x W^T + b for a handful of rows, float32 (stp3_linear_fwd / _bwd): one launch each way.  W may be a run of columns
+    of a wider parameter (``weight_columns``): it is read in place, and its gradient is written straight into the same columns
+    of the parameter's bucket slice when the parameter takes direct gradients (``_direct_ok``)."""
 
     @staticmethod
     def forward(ctx, x, w, b):
         _need_gpu(x, w)
-        x, w = x.contiguous(), w.contiguous()
+        x = x.contiguous()
+        w, ldw = _rows_f32(w)
         m, k = x.shape
         n = w.shape[0]
         y = torch.empty((m, n), dtype=torch.float32, device=x.device)
-        check(_lib.lib().stp3_linear_fwd(m, k, n, x.data_ptr(), w.data_ptr(), _opt_ptr(b), y.data_ptr(), _stream_handle()),
+        check(_lib.lib().stp3_linear_fwd(m, k, n, x.data_ptr(), w.data_ptr(), ldw, _opt_ptr(b), y.data_ptr(), _stream_handle()),
               'stp3_linear_fwd')
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
@@ -1098,10 +1112,17 @@ class _SmallLinear(torch.autograd.Function):
         n = w.shape[0]
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dest = _COLUMN_DESTS.get((w.data_ptr(), n, k))
+            if dest is not None and dest[1]() is not None and _direct_ok(dest[0], _graph_task_id(), dy.device, True):
+                view = dest[1]()._stp3_grad_view        # the columns of the parameter's bucket slice
+                dw = view.as_strided((n, k), (view.stride(0), view.stride(1)), view.storage_offset() + dest[2] * view.stride(1))
+            else:
+                dw = torch.empty((n, k), dtype=torch.float32, device=x.device)
         db = torch.empty(n, dtype=torch.float32, device=x.device) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        check(_lib.lib().stp3_linear_bwd(m, k, n, dy.data_ptr(), x.data_ptr(), w.data_ptr(), _opt_ptr(dx), _opt_ptr(dw), _opt_ptr(db),
-                                         _stream_handle()), 'stp3_linear_bwd')
+        check(_lib.lib().stp3_linear_bwd(m, k, n, dy.data_ptr(), x.data_ptr(), w.data_ptr(), w.stride(0), _opt_ptr(dx), _opt_ptr(dw),
+                                         0 if dw is None else dw.stride(0), _opt_ptr(db), _stream_handle()), 'stp3_linear_bwd')
         return dx, dw, db
 
 
@@ -1325,7 +1346,7 @@ def _conv2d_wgrad(dy, x, wshape, stride, pad, dil, leaf=None):
             direct = True
     asm = getattr(leaf, '_stp3_assembled', None) if leaf is not None else None
     if (asm is not None and ASSEMBLED_WEIGHTS and DIRECT_BUCKET_GRADS and x.is_cuda and leaf._stp3_assembled_direct
-            and _assembled_claim(asm, dw)):
+            and _assembled_claim(asm, dw, leaf._stp3_assembled_direct == 'shared')):
         # the stand-in of an assembled weight: the gradient of the whole goes to the entry's buffer, and one launch per backward
         # pass (``_WeightShadows.scatter``) cuts every such buffer into the parameters' bucket slices
         dw = asm['dw'].detach()
@@ -1431,6 +1452,7 @@ def reset_weight_uses():
     for tab in _SHADOW_TABLES.values():
         for e in tab.assembled.values():
             e['uses'] = 0
+            e['columns'] = []
 
 
 def _same_memory_order(a, b):
@@ -1537,7 +1559,7 @@ class _WeightShadows:
         cout, cin, kh, kw = shape
         dev = self.device
         opts = dict(dtype=torch.bfloat16, device=dev)
-        ent = {'kind': 'assembled', 'key': key, 'shape': tuple(shape), 'pieces': pieces, 'uses': 0, 'claim': None,
+        ent = {'kind': 'assembled', 'key': key, 'shape': tuple(shape), 'pieces': pieces, 'uses': 0, 'claim': None, 'columns': [],
                'signature': _pieces_signature(shape, pieces),
                # (zeroed ONCE: the lanes between the pieces are never written)
                'wb': torch.zeros((cout, cin, kh, kw), **opts).contiguous(memory_format=torch.channels_last),
@@ -1749,8 +1771,10 @@ def assembled_weight(key, shape, pieces, direct=True):
     every other weight's after an optimizer step; its gradient reaches the parameters of the pieces (through autograd: the
     stand-in is the output of ``_AssembledWeight``).  ``key``: what identifies the weight among the model's (a module and a
     name); the pieces may change between calls (another lane count): the entry is rebuilt then.
-    ``direct=False``: a parameter of the pieces ALSO reaches the loss some other way (the columns of a projection that
-    multiply a pooled vector): its gradient contributions must meet in autograd, so this one is handed over as a tensor."""
+    ``direct=False``: a parameter of the pieces ALSO reaches the loss some other way: its gradient contributions must meet in
+    autograd, so this one is handed over as a tensor.  ``direct='shared'``: that other way is ``weight_columns`` (the columns
+    of a projection that multiply a pooled vector) and the two together cover the parameter: both write their part of the
+    bucket slice, one of them hands autograd the alias."""
     params = []
     for pc in pieces:
         p = pc['param']()
@@ -1766,29 +1790,108 @@ def assembled_weight(key, shape, pieces, direct=True):
     elif ent['versions'] != tuple(pc['param']()._version for pc in ent['pieces']):
         tab.refresh()                              # a parameter was updated in place behind our back (a torch optimizer)
     ent['uses'] += 1
-    token = _AssembledWeight.apply(ent, *params)
+    token = _AssembledWeight.apply(ent, direct == 'shared', *params)
     token._stp3_assembled = ent
-    token._stp3_assembled_direct = bool(direct)
+    token._stp3_assembled_direct = direct
     return token
 
 
-def _assembled_claim(ent, dw):
+def _direct_grad_ready(p, device):
+    """A leaf parameter whose gradient an operator may write straight into its bucket slice (gather-mode buckets: see
+    ``_conv2d_wgrad``)."""
+    view = getattr(p, '_stp3_grad_view', None)
+    return (view is not None and p.grad is None and p.requires_grad and view.dtype == torch.float32 and view.device == device
+            and _same_memory_order(view, p))
+
+
+def _entry_params(ent):
+    return list({id(pc['param']()): pc['param']() for pc in ent['pieces']}.values())
+
+
+def _direct_ok(ent, task, device, shared):
+    """The ONE predicate every operator that writes a part of the gradients of an assembled weight's parameters evaluates
+    (``_conv2d_wgrad`` for the weight itself, ``_WeightColumns`` for the columns that go their own way): all of them take the
+    direct route or none does.  It only reads state that does not change between their backward calls."""
+    if not (ASSEMBLED_WEIGHTS and DIRECT_BUCKET_GRADS) or task == -1 or ent['uses'] != 1:
+        return False
+    ranges = sorted(ent['columns'])
+    if any(a[1] > b[0] for a, b in zip(ranges, ranges[1:])) or (ranges and not shared):
+        return False                               # (the same columns used twice: their gradients must be added)
+    for p in _entry_params(ent):
+        if not _direct_grad_ready(p, device):
+            return False
+        if getattr(p, '_stp3_grad_claim', None) == task and not (shared and getattr(p, '_stp3_grad_shared', None) == id(ent)):
+            return False                           # (claimed by an operator that is not part of this weight)
+    return True
+
+
+def _claim_params(ent, task, shared):
+    """Mark the parameters as written directly in this pass; returns the ones nobody had claimed (their AccumulateGrad gets
+    the alias of the bucket slice from the caller)."""
+    first = set()
+    for p in _entry_params(ent):
+        if getattr(p, '_stp3_grad_claim', None) != task:
+            first.add(id(p))
+        p._stp3_grad_claim = task
+        p._stp3_grad_shared = id(ent) if shared else None
+    return first
+
+
+def _assembled_claim(ent, dw, shared):
     """May the weight gradient of this backward pass go to the entry's buffer and from there to the bucket slices?  Yes for a
     weight applied once since ``zero_grad`` whose parameters all take a direct gradient (see ``_conv2d_wgrad``: gather-mode
-    buckets, no gradient on the parameter yet, not claimed by another operator of this pass)."""
+    buckets, no gradient on the parameter yet) and are not claimed by another operator of this pass -- except, for a
+    ``shared`` weight, by the operator that writes the parameter's OTHER columns (``weight_columns``)."""
     task = _graph_task_id()
-    if task == -1 or ent['uses'] != 1 or ent['claim'] == task or tuple(dw.shape) != ent['shape']:
+    if ent['claim'] == task or tuple(dw.shape) != ent['shape'] or not _direct_ok(ent, task, dw.device, shared):
         return False
-    params = {id(pc['param']()): pc['param']() for pc in ent['pieces']}
-    for p in params.values():
-        view = getattr(p, '_stp3_grad_view', None)
-        if (view is None or p.grad is not None or not p.requires_grad or getattr(p, '_stp3_grad_claim', None) == task
-                or view.dtype != torch.float32 or view.device != dw.device or not _same_memory_order(view, p)):
-            return False
-    for p in params.values():
-        p._stp3_grad_claim = task
+    ent['mine'] = _claim_params(ent, task, shared)
     ent['claim'] = task
     return True
+
+
+class _WeightColumns(torch.autograd.Function):
+    """Columns [c0, c1) of a 1x1 kernel parameter as a (Cout, c1 - c0, 1, 1) tensor (the values themselves: an alias) for the
+    operators that read float32 weights (``small_linear``), when the parameter's OTHER columns are a piece of an assembled
+    weight (``assembled_weight(..., direct='shared')``): backward stores the columns' gradient into the parameter's bucket
+    slice and hands autograd an alias of the slice -- or nothing when the assembled weight already did."""
+
+    @staticmethod
+    def forward(ctx, param, ent, c0, c1):
+        ctx.param, ctx.ent, ctx.cols = param, ent, (c0, c1)
+        base = param.detach()
+        return base.as_strided((base.shape[0], c1 - c0, 1, 1), (base.stride(0), base.stride(1), 1, 1),
+                               base.storage_offset() + c0 * base.stride(1))
+
+    @staticmethod
+    def backward(ctx, g):
+        p, ent, (c0, c1) = ctx.param, ctx.ent, ctx.cols
+        task = _graph_task_id()
+        if _direct_ok(ent, task, g.device, True):
+            view = p._stp3_grad_view
+            cols = view.as_strided((p.shape[0], c1 - c0, 1, 1), (view.stride(0), view.stride(1), 1, 1),
+                                   view.storage_offset() + c0 * view.stride(1))
+            if g.data_ptr() != cols.data_ptr():     # (``_SmallLinear`` writes its weight gradient there itself)
+                cols.copy_(g)
+            # (when the weight's own gradient comes later, ``_assembled_claim`` finds the parameter claimed for this weight and
+            # hands out no second alias)
+            first = _claim_params(ent, task, True)
+            return (view.detach() if id(p) in first else None), None, None, None
+        full = torch.zeros_like(p)
+        full.as_strided((p.shape[0], c1 - c0, 1, 1), (full.stride(0), full.stride(1), 1, 1), c0 * full.stride(1)).copy_(g)
+        return full, None, None, None
+
+
+def weight_columns(token, param, c0, c1):
+    """Columns [c0, c1) of ``param`` for a float32 operator; ``token``: the stand-in of the assembled weight that holds the
+    parameter's other columns (``assembled_weight(..., direct='shared')``).  See ``_WeightColumns``."""
+    ent = token._stp3_assembled
+    ent['columns'].append((int(c0), int(c1)))
+    cols = _WeightColumns.apply(param, ent, int(c0), int(c1))
+    if len(_COLUMN_DESTS) > 256:
+        _COLUMN_DESTS.clear()
+    _COLUMN_DESTS[(cols.data_ptr(), cols.shape[0], cols.shape[1])] = (ent, weakref.ref(param), int(c0), int(c1))
+    return cols
 
 
 class _AssembledWeight(torch.autograd.Function):
@@ -1800,8 +1903,9 @@ class _AssembledWeight(torch.autograd.Function):
     with torch."""
 
     @staticmethod
-    def forward(ctx, ent, *params):
+    def forward(ctx, ent, shared, *params):
         ctx.ent = ent
+        ctx.shared = shared
         ctx.params = params
         return ent['token'].detach()
 
@@ -1814,15 +1918,20 @@ class _AssembledWeight(torch.autograd.Function):
             tab = _shadows(ent['dw'].device)
             for p in params:
                 covered = sum(pc['dims'][0] * pc['dims'][1] * pc['dims'][2] * pc['dims'][3] for pc in ent['pieces'] if pc['param']() is p)
-                if covered < p.numel():
-                    p._stp3_grad_view.zero_()      # (a dropped tap, an unused slice: its gradient is zero)
-                grads.append(p._stp3_grad_view.detach())
+                if covered < p.numel() and not ctx.shared and ent.get('zeroed') != (id(p), p._stp3_grad_view.data_ptr()):
+                    # a dropped tap, an unused slice: its gradient is zero.  ONCE per bucket slice: nothing writes those
+                    # elements afterwards but scalings (clipping, the mean over ranks, the optimizer's write-back of the clipped
+                    # gradient) and the passes that take the other route, which store zeros there themselves
+                    p._stp3_grad_view.zero_()
+                    ent['zeroed'] = (id(p), p._stp3_grad_view.data_ptr())
+                # (a shared parameter whose other columns were written first: their operator handed over the alias)
+                grads.append(p._stp3_grad_view.detach() if id(p) in ent['mine'] else None)
             if _single_process():
                 tab.pending_scatter.append(ent)
             else:
                 tab.scatter([ent])
-            return (None,) + tuple(grads)
-        for p, need in zip(params, ctx.needs_input_grad[1:]):
+            return (None, None) + tuple(grads)
+        for p, need in zip(params, ctx.needs_input_grad[2:]):
             if not need:
                 grads.append(None)
                 continue
@@ -1833,7 +1942,7 @@ class _AssembledWeight(torch.autograd.Function):
                     g.as_strided(pc['dims'], pc['strides'], pc['offset']).copy_(
                         dw[pc['co_off']:pc['co_off'] + co, pc['ci_off']:pc['ci_off'] + ci])
             grads.append(g)
-        return (None,) + tuple(grads)
+        return (None, None) + tuple(grads)
 
 
 def _evict_weight(key, ent):

@@ -646,6 +646,15 @@ def small_linear(ops):
         F.linear(xr, wr, br).backward(gy.double())
         out[name] = {'y': rel(y.detach(), F.linear(xr, wr, br).detach()), 'dx': rel(x.grad, xr.grad), 'dw': rel(w.grad, wr.grad),
                      'db': rel(b.grad, br.grad) if bias else 0.0}
+    # the weight as a run of COLUMNS of a wider matrix, read in place (row stride 70)
+    x, wide = torch.randn(12, 6, requires_grad=True), torch.randn(35, 70, requires_grad=True)
+    y = ops.small_linear(x, wide[:, 64:], None)
+    gy = torch.randn(12, 35)
+    y.backward(gy)
+    xr, wr = x.detach().double().requires_grad_(), wide.detach().double().requires_grad_()
+    F.linear(xr, wr[:, 64:]).backward(gy.double())
+    out['columns_of_a_wider_matrix'] = {'y': rel(y.detach(), F.linear(xr, wr[:, 64:]).detach()), 'dx': rel(x.grad, xr.grad),
+                                        'dw': rel(wide.grad, wr.grad), 'db': 0.0}
     return out
 
 
