@@ -166,6 +166,181 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_sample_kernel(stp3_se_mlp_dims
     }
 }
 
+// ---- the same two kernels with their loads issued in explicit batches (S a multiple of 4, S <= SR <= kMaxS) --------------------
+// What the kernels above cost is dependent round trips to L2 / the memory-side cache, and how many loads the compiler keeps in
+// flight decides their number: the 32-row instantiation of the forward kernel came out fully batched (220 VGPRs, 10 us), the
+// 40-row one rolled up (70 VGPRs, 28 us -- profiles/r06s_step_trace.txt), and the loops over a thread's channels (W2 rows in the
+// forward pass, W1 columns in the backward pass) were sequential: 4 x 5 round trips of 8 loads.  Here every phase loads a fixed
+// batch for ALL of the thread's channels, then multiplies: rows beyond S repeat a valid address and meet a zero (an activation
+// vector zero-padded in LDS) or an accumulator nobody reads.  Same sums in the same order as above: bit-equal results.
+template <int SR>
+__global__ __launch_bounds__(256) void se_mlp_fwd_batched_kernel(stp3_se_mlp_dims d, const float* __restrict__ pooled_sum,
+                                                                 const float* __restrict__ w1, const float* __restrict__ b1,
+                                                                 const float* __restrict__ w2, const float* __restrict__ b2,
+                                                                 float* __restrict__ z1, float* __restrict__ gate) {
+    __shared__ float scratch[16 * kMaxS];
+    __shared__ float h[kMaxS];      // W1 p, then swish(z1), zero beyond S
+    const int n = blockIdx.x, tid = threadIdx.x;
+    float acc[SR];
+#pragma unroll
+    for (int s = 0; s < SR; ++s) acc[s] = 0.f;
+    for (int c0 = 0; c0 < d.C; c0 += 256 * kOwn) {
+        float pc[kOwn];
+        unsigned cc[kOwn];
+#pragma unroll
+        for (int k = 0; k < kOwn; ++k) {
+            const int c = c0 + k * 256 + tid;
+            cc[k] = (unsigned)min(c, d.C - 1);                 // beyond C: a valid address, times zero
+            pc[k] = c < d.C ? pooled_sum[(size_t)n * d.C + c] * d.inv_rows : 0.f;
+        }
+#pragma unroll
+        for (int s0 = 0; s0 < SR; s0 += 8) {
+            float wv[8][kOwn];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned roff = (unsigned)(min(s0 + j, d.S - 1) * d.C);
+#pragma unroll
+                for (int k = 0; k < kOwn; ++k) wv[j][k] = w1[roff + cc[k]];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int k = 0; k < kOwn; ++k) acc[s0 + j] = fmaf(wv[j][k], pc[k], acc[s0 + j]);
+        }
+    }
+    block_sums<SR>(acc, d.S, scratch, h);
+    if (tid < kMaxS) {
+        float v = 0.f;
+        if (tid < d.S) {
+            const float z = h[tid] + b1[tid];
+            z1[(size_t)n * d.S + tid] = z;
+            v = z * sigmoidf_(z);
+        }
+        h[tid] = v;
+    }
+    __syncthreads();
+    // a thread owns <= kOwn channels per chunk and walks THEIR rows of W2 (S consecutive floats) together, 16 bytes at a time
+    for (int c0 = 0; c0 < d.C; c0 += 256 * kOwn) {
+        float a[kOwn];
+        unsigned roff[kOwn];
+#pragma unroll
+        for (int k = 0; k < kOwn; ++k) {
+            const int c = min(c0 + k * 256 + tid, d.C - 1);
+            a[k] = b2[c];
+            roff[k] = (unsigned)(c * d.S);
+        }
+#pragma unroll
+        for (int s0 = 0; s0 < SR; s0 += 8) {
+            float4 wv[2][kOwn];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned so = (unsigned)min(s0 + 4 * q, d.S - 4);
+#pragma unroll
+                for (int k = 0; k < kOwn; ++k) wv[q][k] = *reinterpret_cast<const float4*>(w2 + roff[k] + so);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float h0 = h[s0 + 4 * q], h1 = h[s0 + 4 * q + 1], h2 = h[s0 + 4 * q + 2], h3 = h[s0 + 4 * q + 3];
+#pragma unroll
+                for (int k = 0; k < kOwn; ++k) {
+                    a[k] = fmaf(wv[q][k].x, h0, a[k]); a[k] = fmaf(wv[q][k].y, h1, a[k]);
+                    a[k] = fmaf(wv[q][k].z, h2, a[k]); a[k] = fmaf(wv[q][k].w, h3, a[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kOwn; ++k) {
+            const int c = c0 + k * 256 + tid;
+            if (c < d.C) gate[(size_t)n * d.C + c] = sigmoidf_(a[k]);
+        }
+    }
+}
+
+template <int SR>
+__global__ __launch_bounds__(256) void se_mlp_bwd_sample_batched_kernel(stp3_se_mlp_dims d, const float* __restrict__ dgate,
+                                                                        const float* __restrict__ gate,
+                                                                        const float* __restrict__ z1,
+                                                                        const float* __restrict__ w1,
+                                                                        const float* __restrict__ w2, float* __restrict__ dz2,
+                                                                        float* __restrict__ dz1, float* __restrict__ dpooled) {
+    __shared__ float scratch[16 * kMaxS];
+    __shared__ float g1[kMaxS];     // dz2 W2, then dz1 of this sample, zero beyond S
+    const int n = blockIdx.x, tid = threadIdx.x;
+    float acc[SR];
+#pragma unroll
+    for (int s = 0; s < SR; ++s) acc[s] = 0.f;
+    // a thread owns channel c: its dz2 times ITS row of W2 (S contiguous floats) is its part of dh; two channels' rows per batch
+    for (int c0 = 0; c0 < d.C; c0 += 256 * 2) {
+        float v[2];
+        unsigned roff[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c = c0 + k * 256 + tid;
+            const int cc = min(c, d.C - 1);
+            const float g = gate[(size_t)n * d.C + cc];
+            v[k] = c < d.C ? dgate[(size_t)n * d.C + cc] * g * (1.0f - g) : 0.f;
+            if (c < d.C) dz2[(size_t)n * d.C + c] = v[k];
+            roff[k] = (unsigned)(cc * d.S);
+        }
+        float4 wv[SR / 4][2];
+#pragma unroll
+        for (int q = 0; q < SR / 4; ++q) {
+            const unsigned so = (unsigned)min(4 * q, d.S - 4);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) wv[q][k] = *reinterpret_cast<const float4*>(w2 + roff[k] + so);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int q = 0; q < SR / 4; ++q) {                         // (rows beyond S: accumulators nobody reads)
+                acc[4 * q] = fmaf(v[k], wv[q][k].x, acc[4 * q]);         acc[4 * q + 1] = fmaf(v[k], wv[q][k].y, acc[4 * q + 1]);
+                acc[4 * q + 2] = fmaf(v[k], wv[q][k].z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(v[k], wv[q][k].w, acc[4 * q + 3]);
+            }
+    }
+    block_sums<SR>(acc, d.S, scratch, g1);
+    if (tid < kMaxS) {
+        float v = 0.f;
+        if (tid < d.S) {
+            const float z = z1[(size_t)n * d.S + tid];
+            const float sg = sigmoidf_(z);
+            v = g1[tid] * sg * (1.0f + z * (1.0f - sg));
+            dz1[(size_t)n * d.S + tid] = v;
+        }
+        g1[tid] = v;
+    }
+    __syncthreads();
+    for (int c0 = 0; c0 < d.C; c0 += 256 * kOwn) {
+        float a[kOwn];
+        unsigned cc[kOwn];
+#pragma unroll
+        for (int k = 0; k < kOwn; ++k) {
+            a[k] = 0.f;
+            cc[k] = (unsigned)min(c0 + k * 256 + tid, d.C - 1);
+        }
+#pragma unroll
+        for (int s0 = 0; s0 < SR; s0 += 8) {
+            float wv[8][kOwn];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned roff = (unsigned)(min(s0 + j, d.S - 1) * d.C);
+#pragma unroll
+                for (int k = 0; k < kOwn; ++k) wv[j][k] = w1[roff + cc[k]];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float gv = g1[s0 + j];
+#pragma unroll
+                for (int k = 0; k < kOwn; ++k) a[k] = fmaf(gv, wv[j][k], a[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kOwn; ++k) {
+            const int c = c0 + k * 256 + tid;
+            if (c < d.C) dpooled[(size_t)n * d.C + c] = a[k] * d.inv_rows;
+        }
+    }
+}
+
 // backward, weights: workgroup = (64 channels, 8 squeezed channels) x 4 groups of samples; thread (channel, group) adds
 // its group's samples n = group, group + 4, ... in ascending order, the four groups are added in order: deterministic
 //   dw2[c][s] = sum_n dz2[n][c] swish(z1[n][s]);  db2[c] = sum_n dz2[n][c]
@@ -252,6 +427,12 @@ inline int check(const stp3_se_mlp_dims* d) {
     return STP3_OK;
 }
 
+// the batched kernels: whole 16-byte pieces of the W2 rows (S a multiple of 4, the matrix 16-byte aligned), S within the
+// register accumulators
+inline bool batched(const stp3_se_mlp_dims* d, const float* w2) {
+    return d->S % 4 == 0 && d->S <= kMaxS && ((uintptr_t)w2 & 15) == 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -263,6 +444,20 @@ int stp3_se_mlp_fwd(const stp3_se_mlp_dims* dims, const float* pooled_sum, const
     if (!pooled_sum || !w1 || !b1 || !w2 || !b2 || !z1 || !gate) return STP3_EINVAL;
     const size_t lds = (size_t)dims->S * 4;
     hipStream_t s = (hipStream_t)stream;
+    if (batched(dims, w2)) {
+#define STP3_SE_FWDB(SR) hipLaunchKernelGGL(se_mlp_fwd_batched_kernel<SR>, dim3(dims->N), dim3(256), 0, s, *dims, pooled_sum, w1, b1, w2, b2, z1, gate)
+        switch ((dims->S + 7) / 8) {
+            case 1: STP3_SE_FWDB(8); break;
+            case 2: STP3_SE_FWDB(16); break;
+            case 3: STP3_SE_FWDB(24); break;
+            case 4: STP3_SE_FWDB(32); break;
+            case 5: STP3_SE_FWDB(40); break;
+            case 6: STP3_SE_FWDB(48); break;
+            default: STP3_SE_FWDB(64); break;
+        }
+#undef STP3_SE_FWDB
+        return launch_status();
+    }
 #define STP3_SE_FWD(SR) hipLaunchKernelGGL(se_mlp_fwd_kernel<SR>, dim3(dims->N), dim3(256), lds, s, *dims, pooled_sum, w1, b1, w2, b2, z1, gate)
     switch ((dims->S + 7) / 8) {
         case 1: STP3_SE_FWD(8); break;
@@ -286,17 +481,31 @@ int stp3_se_mlp_bwd(const stp3_se_mlp_dims* dims, const float* dgate, const floa
         return STP3_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)dims->S * 4;
+    if (batched(dims, w2)) {
+#define STP3_SE_BWDB(SR) hipLaunchKernelGGL(se_mlp_bwd_sample_batched_kernel<SR>, dim3(dims->N), dim3(256), 0, s, *dims, dgate, gate, z1, w1, w2, dz2, dz1, dpooled)
+        switch ((dims->S + 7) / 8) {
+            case 1: STP3_SE_BWDB(8); break;
+            case 2: STP3_SE_BWDB(16); break;
+            case 3: STP3_SE_BWDB(24); break;
+            case 4: STP3_SE_BWDB(32); break;
+            case 5: STP3_SE_BWDB(40); break;
+            case 6: STP3_SE_BWDB(48); break;
+            default: STP3_SE_BWDB(64); break;
+        }
+#undef STP3_SE_BWDB
+    } else {
 #define STP3_SE_BWD(SR) hipLaunchKernelGGL(se_mlp_bwd_sample_kernel<SR>, dim3(dims->N), dim3(256), lds, s, *dims, dgate, gate, z1, w1, w2, dz2, dz1, dpooled)
-    switch ((dims->S + 7) / 8) {
-        case 1: STP3_SE_BWD(8); break;
-        case 2: STP3_SE_BWD(16); break;
-        case 3: STP3_SE_BWD(24); break;
-        case 4: STP3_SE_BWD(32); break;
-        case 5: STP3_SE_BWD(40); break;
-        case 6: STP3_SE_BWD(48); break;
-        default: STP3_SE_BWD(64); break;
-    }
+        switch ((dims->S + 7) / 8) {
+            case 1: STP3_SE_BWD(8); break;
+            case 2: STP3_SE_BWD(16); break;
+            case 3: STP3_SE_BWD(24); break;
+            case 4: STP3_SE_BWD(32); break;
+            case 5: STP3_SE_BWD(40); break;
+            case 6: STP3_SE_BWD(48); break;
+            default: STP3_SE_BWD(64); break;
+        }
 #undef STP3_SE_BWD
+    }
     hipLaunchKernelGGL(se_mlp_bwd_weight_kernel, dim3((dims->C + kWgtChan - 1) / kWgtChan, (dims->S + kSChunk - 1) / kSChunk),
                        dim3(kWgtThreads),
                        ((size_t)2 * dims->N * kSChunk + (size_t)kWgtGroups * (2 * kSChunk + 1) * kWgtChan) * 4, s, *dims,

@@ -280,7 +280,9 @@ def se_block(ops):
         ops_fused._SE_MLP = mlp
         torch.manual_seed(0)
         worst = 0.0
-        for n, c, s, hh, ww in [(5, 48, 12, 6, 7), (3, 200, 9, 4, 4), (2, 16, 4, 1, 3)]:
+        # (S a multiple of 4: the batched gate kernels; 9 and 14: the general ones; 1100 channels: two chunks per thread, ragged)
+        for n, c, s, hh, ww in [(5, 48, 12, 6, 7), (3, 200, 9, 4, 4), (2, 16, 4, 1, 3), (3, 960, 40, 2, 3), (2, 672, 28, 3, 2),
+                                (2, 1100, 8, 2, 2), (2, 336, 14, 2, 2), (2, 1048, 64, 1, 2)]:
             x = torch.randn(n, c, hh, ww).contiguous(memory_format=torch.channels_last).requires_grad_()
             params = [(torch.randn(s, c, 1, 1) * 0.3).requires_grad_(), torch.randn(s).requires_grad_(),
                       (torch.randn(c, s, 1, 1) * 0.3).requires_grad_(), torch.randn(c).requires_grad_()]

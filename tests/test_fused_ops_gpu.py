@@ -211,7 +211,10 @@ def test_se_mlp_kernels_match_the_torch_operator_mlp(monkeypatch, dtype):
     same block with the MLP written in torch operators (float32 in both), forward and all five gradients."""
     from stp3_amd import ops_fused
     torch.manual_seed(0)
-    for n, c, s, hh, ww in [(72, 144, 6, 14, 30), (12, 960, 40, 7, 15), (3, 48, 12, 5, 9)]:
+    # (S a multiple of 4: the batched kernels -- 960 / 40 and 672 / 28 are the trunk's slow ones; 6 and 14: the general kernels;
+    # 1100 channels: two chunks per thread, the second ragged)
+    for n, c, s, hh, ww in [(72, 144, 6, 14, 30), (72, 960, 40, 7, 15), (72, 672, 28, 7, 15), (3, 48, 12, 5, 9), (5, 336, 14, 7, 9),
+                            (4, 1100, 8, 3, 5)]:
         x0 = torch.randn(n, c, hh, ww, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
         params0 = [torch.randn(s, c, 1, 1, device='cuda') * 0.1, torch.randn(s, device='cuda') * 0.1,
                    torch.randn(c, s, 1, 1, device='cuda') * 0.1, torch.randn(c, device='cuda') * 0.1]
