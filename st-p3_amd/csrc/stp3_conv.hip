@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(int splits, si
 // The split-K sums of MANY layers in one launch.  Nothing reads the weight gradient of a leaf parameter before the optimizer,
 // so the ~100 per-layer reduction launches of a training step (4-7 us each, pure launch floor) are deferred: every layer's
 // main kernel leaves its partials in its own slice of an arena, and at the end of the backward pass ONE launch sums them
-// all -- job j owns the workgroups [first[j], first[j + 1]), the same 64 columns x 4 split lanes, the same order of
+// all -- job j owns the workgroups [first[j], first[j + 1]), the same four split lanes per column, the same order of
 // additions as conv2d_wgrad_reduce_kernel (bit-identical).  The job table travels as the kernel argument (no upload).
 constexpr int kWgradBatch = STP3_WGRAD_BATCH_MAX;
 struct WgradJobs {
@@ -1164,8 +1164,12 @@ struct WgradJobs {
     int first[kWgradBatch + 1];
     int count;
 };
+// A workgroup owns 256 columns: thread (column group cg, split lane kl) adds the split slices kl, kl + 4, ... of ITS four
+// consecutive columns, 16 bytes per load (the first version read 4 bytes per lane: 1 TB/s on what is a plain stream -- 140 us
+// per launch, two launches per step).  Per column the additions are the ones listed above, in the same order.
+constexpr int kWgradBatchCols = 256;
 __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_batch_kernel(WgradJobs jobs) {
-    __shared__ float red[256];
+    __shared__ float4 red[256];
     // which job: binary search of the workgroup index in first[] (uniform over the workgroup: scalar code)
     int lo = 0, hi = jobs.count;
     const int b = blockIdx.x;
@@ -1177,21 +1181,49 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_batch_kernel(WgradJob
     float* __restrict__ dw = jobs.dw[lo];
     const size_t n = jobs.n[lo];
     const int splits = jobs.splits[lo];
-    const int il = threadIdx.x & 63, kl = threadIdx.x >> 6;
-    const size_t i = (size_t)(b - jobs.first[lo]) * 64 + il;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (i < n) {
+    const int cg = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const size_t i = (size_t)(b - jobs.first[lo]) * kWgradBatchCols + 4 * (size_t)cg;
+    float4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    auto add = [](float4& a, const float4& v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+    if (i + 3 < n && (n & 3) == 0 && ((uintptr_t)partial & 15) == 0) {
         int k = kl;
         for (; k + 12 < splits; k += 16) {
-            const float a = partial[(size_t)k * n + i], bb = partial[(size_t)(k + 4) * n + i];
-            const float c = partial[(size_t)(k + 8) * n + i], d = partial[(size_t)(k + 12) * n + i];
-            s0 += a; s1 += bb; s2 += c; s3 += d;
+            const float4 a = *reinterpret_cast<const float4*>(partial + (size_t)k * n + i);
+            const float4 bb = *reinterpret_cast<const float4*>(partial + (size_t)(k + 4) * n + i);
+            const float4 c = *reinterpret_cast<const float4*>(partial + (size_t)(k + 8) * n + i);
+            const float4 d = *reinterpret_cast<const float4*>(partial + (size_t)(k + 12) * n + i);
+            add(s0, a); add(s1, bb); add(s2, c); add(s3, d);
         }
-        for (; k < splits; k += 4) s0 += partial[(size_t)k * n + i];
+        for (; k < splits; k += 4) add(s0, *reinterpret_cast<const float4*>(partial + (size_t)k * n + i));
+    } else if (i < n) {
+        // a ragged end or an odd size: the same sums element by element
+        float* s0e = &s0.x; float* s1e = &s1.x; float* s2e = &s2.x; float* s3e = &s3.x;
+        for (int e = 0; e < 4 && i + e < n; ++e) {
+            int k = kl;
+            for (; k + 12 < splits; k += 16) {
+                s0e[e] += partial[(size_t)k * n + i + e];       s1e[e] += partial[(size_t)(k + 4) * n + i + e];
+                s2e[e] += partial[(size_t)(k + 8) * n + i + e]; s3e[e] += partial[(size_t)(k + 12) * n + i + e];
+            }
+            for (; k < splits; k += 4) s0e[e] += partial[(size_t)k * n + i + e];
+        }
     }
-    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    float4 t;
+    t.x = (s0.x + s1.x) + (s2.x + s3.x); t.y = (s0.y + s1.y) + (s2.y + s3.y);
+    t.z = (s0.z + s1.z) + (s2.z + s3.z); t.w = (s0.w + s1.w) + (s2.w + s3.w);
+    red[threadIdx.x] = t;
     __syncthreads();
-    if (kl == 0 && i < n) dw[i] = (red[il] + red[64 + il]) + (red[128 + il] + red[192 + il]);
+    if (kl == 0 && i < n) {
+        const float4 a = red[cg], bb = red[64 + cg], c = red[128 + cg], d = red[192 + cg];
+        float4 o;
+        o.x = (a.x + bb.x) + (c.x + d.x); o.y = (a.y + bb.y) + (c.y + d.y);
+        o.z = (a.z + bb.z) + (c.z + d.z); o.w = (a.w + bb.w) + (c.w + d.w);
+        if (i + 3 < n && ((uintptr_t)(dw + i) & 15) == 0) {
+            *reinterpret_cast<float4*>(dw + i) = o;
+        } else {
+            const float* oe = &o.x;
+            for (int e = 0; e < 4 && i + e < n; ++e) dw[i + e] = oe[e];
+        }
+    }
 }
 
 inline int status() {
@@ -1651,7 +1683,7 @@ int stp3_conv2d_wgrad_reduce_batch(int32_t n, const stp3_wgrad_job* jobs, void* 
             t.n[j] = (unsigned)q.numel;
             t.splits[j] = q.splits;
             t.first[j] = (int)blocks;
-            blocks += (q.numel + 63) / 64;
+            blocks += (q.numel + kWgradBatchCols - 1) / kWgradBatchCols;
             if (blocks >= (1LL << 31)) return STP3_EUNSUP;
         }
         for (int j = t.count; j <= kWgradBatch; ++j) t.first[j] = (int)blocks;

@@ -72,11 +72,19 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 // rowsum = sum of the k largest = sum_{l > tau} l + (k - #{l > tau}) * tau, and the share of every tie at tau in the
 // gradient, (k - #{l > tau}) / #{l == tau}.  k >= P: no selection, rowsum = sum of the row.
 // sel[row] = {tau, tie_share};  grid = rows, kSelT threads.
+// Six rows of 40 000 losses are six workgroups: what the kernel costs is its own serial chain.  Round 6 took three links out of
+// it (52 -> ~15 us per call, five calls per step): the row is read ONCE into registers (kSelOwn values per thread: rows up to
+// 40 960 pixels -- the 200 x 200 BEV; longer rows re-read it per pass as before), the bin that holds the need-th largest is
+// found by one wave (four bins per lane, a suffix scan over the lanes) instead of one thread walking 256 LDS words four times,
+// and the two closing block sums share their tree.
+constexpr int kSelOwn = 40;
+template <bool CACHED>
 __global__ __launch_bounds__(kSelT) void topk_select_kernel(int P, int k, const float* __restrict__ loss, float* __restrict__ sel,
                                                             double* __restrict__ rowsum) {
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_need;
     __shared__ double red[kSelT];
+    __shared__ double red2[kSelT];
     const int row = blockIdx.x;
     const float* l = loss + (size_t)row * P;
     if (k >= P || k <= 0) {
@@ -90,6 +98,16 @@ __global__ __launch_bounds__(kSelT) void topk_select_kernel(int P, int k, const 
         }
         return;
     }
+    // this thread's elements: i = threadIdx.x + j * kSelT
+    const int own = CACHED ? kSelOwn : (P + kSelT - 1) / kSelT;
+    float v[kSelOwn];
+    if (CACHED) {
+#pragma unroll
+        for (int j = 0; j < kSelOwn; ++j) {
+            const int i = threadIdx.x + j * kSelT;
+            v[j] = i < P ? l[i] : -1.f;                 // (beyond the row: skipped by index in the passes; -1 is neither > nor == tau)
+        }
+    }
     unsigned prefix = 0, need = (unsigned)k;            // bits fixed so far; how many of the largest are still to be found
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
@@ -100,25 +118,52 @@ __global__ __launch_bounds__(kSelT) void topk_select_kernel(int P, int k, const 
         // plain atomic per element serialises 40 000 increments on one or two LDS words (64 us per call measured); a thread
         // counts its consecutive equal digits and issues one atomic per run
         unsigned cur = 0xffffffffu, cnt = 0;
-        for (int i = threadIdx.x; i < P; i += kSelT) {
-            const unsigned u = __float_as_uint(l[i]);
-            if ((u & mask_hi) != prefix) continue;
+        auto take = [&](unsigned u) {
+            if ((u & mask_hi) != prefix) return;
             const unsigned b = (u >> shift) & 255u;
-            if (b == cur) { ++cnt; continue; }
+            if (b == cur) { ++cnt; return; }
             if (cnt) atomicAdd(&hist[cur], cnt);                                         // integer counts: order-free
             cur = b;
             cnt = 1;
+        };
+        if (CACHED) {
+#pragma unroll
+            for (int j = 0; j < kSelOwn; ++j)
+                if ((int)threadIdx.x + j * kSelT < P) take(__float_as_uint(v[j]));
+        } else {
+            for (int j = 0; j < own; ++j) {
+                const int i = threadIdx.x + j * kSelT;
+                if (i < P) take(__float_as_uint(l[i]));
+            }
         }
         if (cnt) atomicAdd(&hist[cur], cnt);
         __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned n = need, b = 255;
-            for (;; --b) {                               // from the top bin down to the one that holds the need-th largest
-                if (hist[b] >= n || b == 0) break;
-                n -= hist[b];
+        // the bin that holds the need-th largest, from the top: the highest b with sum_{b' >= b} hist[b'] >= need (bin 0 when
+        // even that sum falls short), and how many of ITS elements are still needed
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const unsigned tot = h0 + h1 + h2 + h3;
+            unsigned suf = tot;                           // counts of this lane's bins and every higher lane's
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = __shfl(suf, min(lane + off, 63), 64);
+                if (lane + off < 64) suf += o;
             }
-            s_prefix = prefix | (b << shift);
-            s_need = n;
+            const unsigned above = suf - tot;
+            const bool mine = (above < need && need <= suf) || (lane == 0 && suf < need);
+            if (mine) {
+                unsigned n = need - above, b = 4 * lane + 3;
+                if (h3 < n) {
+                    n -= h3; --b;
+                    if (h2 < n) {
+                        n -= h2; --b;
+                        if (h1 < n) { n -= h1; --b; }
+                    }
+                }
+                s_prefix = prefix | (b << shift);
+                s_need = n;
+            }
         }
         __syncthreads();
         prefix = s_prefix;
@@ -127,15 +172,33 @@ __global__ __launch_bounds__(kSelT) void topk_select_kernel(int P, int k, const 
     const float tau = __uint_as_float(prefix);           // `need` of the elements equal to tau belong to the top k
     double s = 0.0;
     unsigned ties = 0;
-    for (int i = threadIdx.x; i < P; i += kSelT) {
-        const float v = l[i];
-        if (v > tau) s += (double)v;
-        ties += v == tau ? 1u : 0u;
+    if (CACHED) {
+#pragma unroll
+        for (int j = 0; j < kSelOwn; ++j) {
+            if (v[j] > tau) s += (double)v[j];
+            ties += v[j] == tau ? 1u : 0u;
+        }
+    } else {
+        for (int i = threadIdx.x; i < P; i += kSelT) {
+            const float x = l[i];
+            if (x > tau) s += (double)x;
+            ties += x == tau ? 1u : 0u;
+        }
     }
-    s = block_sum(s, red);
-    const double tcount = block_sum((double)ties, red);
+    // both block sums through one tree (fixed order)
+    red[threadIdx.x] = s;
+    red2[threadIdx.x] = (double)ties;
+    __syncthreads();
+    for (int st = kSelT >> 1; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            red[threadIdx.x] += red[threadIdx.x + st];
+            red2[threadIdx.x] += red2[threadIdx.x + st];
+        }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        rowsum[row] = s + (double)need * (double)tau;
+        const double tcount = red2[0];
+        rowsum[row] = red[0] + (double)need * (double)tau;
         sel[2 * row] = tau;
         sel[2 * row + 1] = tcount > 0.0 ? (float)((double)need / tcount) : 0.f;
     }
@@ -314,8 +377,12 @@ int stp3_ce_topk_fwd(const stp3_ce_dims* p, const void* logits, const int64_t* l
     const long long n = (long long)d.rows * d.P;
     hipLaunchKernelGGL(ce_pixel_kernel, dim3((unsigned)((n + kT - 1) / kT)), dim3(kT), 0, s, d, logits, labels, class_weights,
                        row_scale, loss_px);
-    hipLaunchKernelGGL(topk_select_kernel, dim3(d.rows), dim3(kSelT), 0, s, d.P, d.k, (const float*)loss_px, sel,
-                       (double*)workspace);
+    if ((long long)d.P <= (long long)kSelOwn * kSelT)
+        hipLaunchKernelGGL(topk_select_kernel<true>, dim3(d.rows), dim3(kSelT), 0, s, d.P, d.k, (const float*)loss_px, sel,
+                           (double*)workspace);
+    else
+        hipLaunchKernelGGL(topk_select_kernel<false>, dim3(d.rows), dim3(kSelT), 0, s, d.P, d.k, (const float*)loss_px, sel,
+                           (double*)workspace);
     hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, s, d.rows, (const double*)workspace, out_scale, (int)accumulate,
                        out);
     return status();

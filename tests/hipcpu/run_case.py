@@ -861,6 +861,11 @@ def losses(ops):
     predq = (torch.randint(-2, 3, (b * s_, 2, h, w), generator=g).float() * 0.5).view(b, s_, 2, h, w)
     r = both(lambda: L.SegmentationLoss(torch.Tensor([1.0, 2.0]), use_top_k=True, top_k_ratio=0.25), predq, seg, 3)
     out['seg_topk_ties'] = {'value': r['value']}
+    # rows at and beyond what the selection kernel keeps in registers (40 960 losses): 200 x 200 (the BEV) and 210 x 200
+    for tag, (hh, ww) in (('bev_row', (200, 200)), ('long_row', (210, 200))):
+        segl = (torch.rand(1, 1, 1, hh, ww, generator=g) < 0.2).long()
+        predl = torch.randn(1, 1, 2, hh, ww, generator=g) * 2
+        out[f'seg_topk_{tag}'] = both(lambda: L.SegmentationLoss(torch.Tensor([1.0, 2.0]), use_top_k=True, top_k_ratio=0.25), predl, segl, 1)
     hd = (torch.rand(b, 2, h, w, generator=g) < 0.3).long()
     predh = torch.randn(b, 4, h, w, generator=g).contiguous(memory_format=torch.channels_last)
     out['hdmap'] = both(lambda: L.HDmapLoss(torch.Tensor([[1.0, 5.0], [1.0, 1.0]]), [1, 2], [True, False], [0.25, 0.25]), predh, hd)
