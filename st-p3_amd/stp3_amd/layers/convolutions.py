@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from .. import ops, ops_pred
 from ..utils import hp
-from .fused import (ACT_NONE, ACT_RELU, RES_AFTER_ACT, _sync_world, bn_act, bn_act_group, conv1x1_on_vector, conv2d,
+from .fused import (ACT_NONE, ACT_RELU, RES_AFTER_ACT, _sync_world, bn_act, bn_act_group, conv1x1_on_vector, conv2d, conv_bn_act_layer,
                     conv_bn_act_member, conv_module, plane_mean, pooled_bias, run_fused)
 from .fused import _emu as fused_emu
 
@@ -89,7 +89,7 @@ class UpsamplingAdd(nn.Module):
 
     def forward(self, x, x_skip):
         up, conv, bn = self.upsample_layer
-        return bn_act(bn, conv_module(conv, _upsample(up, x, x.dtype)), ACT_NONE, res=x_skip, res_mode=RES_AFTER_ACT)
+        return conv_bn_act_layer(_upsample(up, x, x.dtype), conv, bn, ACT_NONE, res=x_skip, res_mode=RES_AFTER_ACT)
 
 
 class ASPPConv(nn.Sequential):

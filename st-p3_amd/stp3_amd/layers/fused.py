@@ -397,6 +397,22 @@ def _fusable_conv_bn(conv, bn, x):
             and ops.conv2d_stats_supported(x, conv.weight, conv.stride, conv.padding, conv.dilation))
 
 
+# conv -> BatchNorm (-> activation, + skip) layers written out in a module's forward (the ResNet blocks of the decoder, its stem
+# and its upsample-add stages) through the operator whose convolution epilogue produces the statistics, like ``run_fused`` does for
+# Sequentials.  Off: the convolution, then the BatchNorm with its own statistics pass over the convolution output.
+FUSE_WRITTEN_OUT_LAYERS = True
+
+
+def conv_bn_act_layer(x, conv, bn, act, res=None, res_mode=RES_NONE):
+    """act(bn(conv(x))) (+ res: ``res_mode``) -- ``ops_fused.conv_bn_act`` where the layer qualifies (``_fusable_conv_bn``)."""
+    if FUSE_WRITTEN_OUT_LAYERS and _fusable_conv_bn(conv, bn, x):
+        from .. import ops_fused
+        group = None if _sync_world(bn) > 1 else False
+        return ops_fused.conv_bn_act(x, conv.weight, conv.bias, bn, act, res, res_mode if res is not None else RES_NONE,
+                                     conv.stride, conv.padding, conv.dilation, group=group)
+    return bn_act(bn, conv_module(conv, x), act, res=res, res_mode=res_mode)
+
+
 def run_fused(seq, x):
     """Run an ``nn.Sequential`` with every ``BatchNorm -> ReLU`` pair (or lone BatchNorm) fused."""
     mods = list(seq)

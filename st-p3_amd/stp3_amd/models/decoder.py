@@ -6,7 +6,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..layers.convolutions import UpsamplingAdd
-from ..layers.fused import ACT_RELU, _sync_world, bn_act, bn_act_group, conv_bn_act_member, conv_module, run_fused
+from ..layers.fused import ACT_RELU, _sync_world, bn_act, bn_act_group, conv_bn_act_layer, conv_bn_act_member, conv_module, run_fused
 from .resnet import resnet18
 
 
@@ -178,7 +178,7 @@ class Decoder(nn.Module):
         b, s, c, h, w = x.shape
         x = x.reshape(b * s, c, h, w)
         skip1 = x
-        x = self.layer1(bn_act(self.bn1, conv_module(self.first_conv, x), ACT_RELU))  # 1/2
+        x = self.layer1(conv_bn_act_layer(x, self.first_conv, self.bn1, ACT_RELU))  # 1/2
         skip2 = x
         x = self.layer2(x)                                            # 1/4
         skip3 = x

@@ -9,7 +9,8 @@ normal fan_out, last BN gamma of every block zero).  PARITY UNPINNED against the
 """
 import torch.nn as nn
 
-from ..layers.fused import ACT_NONE, ACT_RELU, RES_BEFORE_ACT, bn_act, bn_act_group, conv_module
+from ..layers import fused
+from ..layers.fused import ACT_NONE, ACT_RELU, RES_BEFORE_ACT, bn_act_group, conv_bn_act_layer, conv_bn_act_member, conv_module
 
 
 class BasicBlock(nn.Module):
@@ -26,15 +27,20 @@ class BasicBlock(nn.Module):
                                             nn.BatchNorm2d(out_ch))
 
     def forward(self, x):
+        # every conv -> BatchNorm pair through the operator whose convolution epilogue produces the statistics
+        # (fused.conv_bn_act_layer / conv_bn_act_member): no statistics pass over the convolution outputs
         if self.downsample is None:
             skip = x
-            y = bn_act(self.bn1, conv_module(self.conv1, x), ACT_RELU)
-        else:
+            y = conv_bn_act_layer(x, self.conv1, self.bn1, ACT_RELU)
+        elif fused.FUSE_WRITTEN_OUT_LAYERS:
             # the down-sampling skip and the first convolution read the same tensor: sibling BatchNorms, one statistics
             # exchange for both when the statistics are shared between ranks (fused.bn_act_group)
+            skip, y = bn_act_group([conv_bn_act_member(x, self.downsample[0], self.downsample[1], ACT_NONE),
+                                    conv_bn_act_member(x, self.conv1, self.bn1, ACT_RELU)])
+        else:
             skip, y = bn_act_group([dict(bn=self.downsample[1], x=conv_module(self.downsample[0], x), act=ACT_NONE),
                                     dict(bn=self.bn1, x=conv_module(self.conv1, x), act=ACT_RELU)])
-        return bn_act(self.bn2, conv_module(self.conv2, y), ACT_RELU, res=skip, res_mode=RES_BEFORE_ACT)
+        return conv_bn_act_layer(y, self.conv2, self.bn2, ACT_RELU, res=skip, res_mode=RES_BEFORE_ACT)
 
 
 class ResNet18Stages(nn.Module):

@@ -49,8 +49,9 @@ def test_step_runs_and_call_mix(recorder, tmp_path):
         assert calls[per_step] == STEPS, (per_step, calls[per_step])
     # one BatchNorm forward/backward pair per BatchNorm layer: the composite entry points, or -- where the convolution
     # in front produces the statistics in its epilogue -- apply-only forward and reduce + apply backward
-    assert calls['stp3_bn_fwd_train'] == calls['stp3_bn_bwd_train'] > 40 * STEPS
-    assert calls['stp3_bn_apply_fwd'] == calls['stp3_bn_bwd_reduce'] == calls['stp3_bn_apply_bwd'] > 50 * STEPS
+    # (the composite ones that remain: the temporal blocks -- padded lanes, per-sample biases -- and BatchNorms on vectors)
+    assert calls['stp3_bn_fwd_train'] == calls['stp3_bn_bwd_train'] > 20 * STEPS
+    assert calls['stp3_bn_apply_fwd'] == calls['stp3_bn_bwd_reduce'] == calls['stp3_bn_apply_bwd'] > 70 * STEPS
     # single process: the BatchNorm passes are never split; what remains are the bias gradients of the biased convolutions
     # on the bf16 kernels (ops.channel_sums: column sums of dy through the statistics kernel), five per step
     assert calls['stp3_bn_stats'] == 5 * STEPS, calls['stp3_bn_stats']
