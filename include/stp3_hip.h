@@ -544,7 +544,7 @@ int stp3_se_scale(const stp3_se_dims* dims, const void* x, const float* gate, co
  *   bwd : dgate [N][C] = sum_hw dy * x (stp3_se_pool with dy)  ->  dpooled [N][C] (gradient at pooled_sum... of the
  *         MEAN, already scaled by inv_rows, i.e. what stp3_se_scale adds per pixel), dw1 [S][C], db1 [S], dw2 [C][S],
  *         db2 [C]; dz2 [N][C] and dz1 [N][S] are caller-provided scratch.  Samples are reduced in ascending order.
- * Limits: (C + 2 S) and 2 N S floats must fit in 60 KB of LDS, else STP3_EUNSUP. */
+ * Limits: S <= 8192; the weight-gradient kernel keeps 16 N + 8704 floats in LDS (N <= 480 samples per call); S * C < 2^31; else STP3_EUNSUP. */
 typedef struct stp3_se_mlp_dims {
     int32_t N, C, S;
     float inv_rows;

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kSelT) void topk_select_kernel(int P, int k, const 
 #pragma unroll
         for (int j = 0; j < kSelOwn; ++j) {
             const int i = threadIdx.x + j * kSelT;
-            v[j] = i < P ? l[i] : -1.f;                 // (beyond the row: skipped by index in the passes; -1 is neither > nor == tau)
+            v[j] = i < P ? l[i] : -1.f;                 // (beyond the row: its sign bit keeps it out of every pass; neither > nor == tau)
         }
     }
     unsigned prefix = 0, need = (unsigned)k;            // bits fixed so far; how many of the largest are still to be found
@@ -113,7 +113,8 @@ __global__ __launch_bounds__(kSelT) void topk_select_kernel(int P, int k, const 
         const int shift = 24 - 8 * pass;
         if (threadIdx.x < 256) hist[threadIdx.x] = 0;
         __syncthreads();
-        const unsigned mask_hi = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+        // (pass 0 only asks for a clear sign bit: losses are >= +0; the -1 that pads a thread's registers beyond the row is not one)
+        const unsigned mask_hi = pass == 0 ? 0x80000000u : (0xffffffffu << (shift + 8));
         // run-length aggregation in registers: the losses of a row share their leading bytes (one or two exponents), so a
         // plain atomic per element serialises 40 000 increments on one or two LDS words (64 us per call measured); a thread
         // counts its consecutive equal digits and issues one atomic per run
@@ -128,8 +129,7 @@ __global__ __launch_bounds__(kSelT) void topk_select_kernel(int P, int k, const 
         };
         if (CACHED) {
 #pragma unroll
-            for (int j = 0; j < kSelOwn; ++j)
-                if ((int)threadIdx.x + j * kSelT < P) take(__float_as_uint(v[j]));
+            for (int j = 0; j < kSelOwn; ++j) take(__float_as_uint(v[j]));
         } else {
             for (int j = 0; j < own; ++j) {
                 const int i = threadIdx.x + j * kSelT;

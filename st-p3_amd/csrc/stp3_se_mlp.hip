@@ -341,15 +341,15 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_sample_batched_kernel(stp3_se_
     }
 }
 
-// backward, weights: workgroup = (64 channels, 8 squeezed channels) x 4 groups of samples; thread (channel, group) adds
-// its group's samples n = group, group + 4, ... in ascending order, the four groups are added in order: deterministic
+// backward, weights: workgroup = (64 channels, 8 squeezed channels) x 8 groups of samples; thread (channel, group) adds
+// its group's samples n = group, group + 8, ... in ascending order, the eight groups are added in order: deterministic
 //   dw2[c][s] = sum_n dz2[n][c] swish(z1[n][s]);  db2[c] = sum_n dz2[n][c]
 //   dw1[s][c] = sum_n dz1[n][s] pooled[n][c];      db1[s] = sum_n dz1[n][s]   (workgroup (0, *))
 // LDS = 2 * N * 8 floats (swish(z1) and dz1 of all samples for the workgroup's 8 squeezed channels) + the group sums.
 // (Round 3: one thread per channel walked all N samples, two dependent-latency loads per sample: 17 us per call.)
 constexpr int kSChunk = 8;
 constexpr int kWgtChan = 64;
-constexpr int kWgtGroups = 4;
+constexpr int kWgtGroups = 8;
 constexpr int kWgtThreads = kWgtChan * kWgtGroups;
 
 __global__ __launch_bounds__(kWgtThreads) void se_mlp_bwd_weight_kernel(stp3_se_mlp_dims d,
@@ -422,7 +422,10 @@ __global__ __launch_bounds__(kWgtThreads) void se_mlp_bwd_weight_kernel(stp3_se_
 inline int check(const stp3_se_mlp_dims* d) {
     if (!d) return STP3_EINVAL;
     if (d->N <= 0 || d->C <= 0 || d->S <= 0) return STP3_EINVAL;
-    if ((size_t)d->S * 4 > 32 * 1024 || (size_t)2 * d->N * kSChunk * 4 > 48 * 1024) return STP3_EUNSUP;
+    // (the weight-gradient kernel's LDS: the samples' 8-channel slices + the group sums, within the 64 KB a launch may ask for)
+    if ((size_t)d->S * 4 > 32 * 1024 ||
+        ((size_t)2 * d->N * kSChunk + (size_t)kWgtGroups * (2 * kSChunk + 1) * kWgtChan) * 4 > 64 * 1024)
+        return STP3_EUNSUP;
     if ((int64_t)d->S * d->C >= (1LL << 31)) return STP3_EUNSUP;       // 32-bit element offsets into the weight matrices
     return STP3_OK;
 }

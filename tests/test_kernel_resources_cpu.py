@@ -37,7 +37,11 @@ def test_kernel_register_lds_and_scratch_budgets():
                          ('voxels_sum_bwd_kernel', 128), ('void dwconv_fwd_stats_kernel<unsigned short, 3, 1, unsigned int>', 168),
                          ('void dwconv_fwd_stats_kernel<unsigned short, 5, 1, unsigned int>', 256),
                          ('void mbconv_bwd_reduce_kernel<unsigned short, 8, 2>', 128),
-                         ('void mbconv_bwd_apply_kernel<unsigned short, 8, 2>', 168), ('topk_select_kernel', 64)):
+                         ('void mbconv_bwd_apply_kernel<unsigned short, 8, 2>', 168),
+                         # (1024 threads per workgroup: at most 128 registers; the row's 40 losses per thread live in them)
+                         ('void topk_select_kernel<true>', 128), ('void topk_select_kernel<false>', 64),
+                         # the batched gate kernels: every phase's loads in flight at once, one workgroup of 4 waves per sample
+                         ('void se_mlp_fwd_batched_kernel<40>', 256), ('void se_mlp_bwd_sample_batched_kernel<40>', 256)):
         assert name in by_name, name
         for k in by_name[name]:
             assert k['vgpr'] + k['agpr'] <= budget, k
