@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 6, visit u (experiment): the weight-gradient kernels' split count against the partial-sum traffic it causes
+# (an EXPERIMENT build: wgrad_plan() of stp3_conv.hip read STP3_WGRAD_MIN_KSTEPS / STP3_WGRAD_ROUND_PCT for this visit; the
+# switches are not in the tree -- the result, profiles/r06u_wgrad_split_policy.txt, kept the policy as it was)
 out=gpurun_out/r06u; mkdir -p $out
 for cfg in "8 100" "4 100" "6 100" "4 100" "8 100"; do
   set -- $cfg
