@@ -25,6 +25,7 @@
 //     pass over the convolution output disappears), one partial row per workgroup, reduced deterministically.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "stp3_cdna.h"
@@ -1479,7 +1480,10 @@ int igemm_run(const stp3_conv_dims* p, const void* x, const void* w, const float
     // (<= 2 steps: the pointwise layers of the trunk, bound by activation traffic) that what counts is many light
     // workgroups per CU; one staging buffer suffices for a single K step
     const int steps = (d.Ktot + kBK - 1) / kBK;
-    const bool wide = p->Cout > 64 && steps > 2;
+    // ... and the narrow tile too when the wide tiling would leave the chip under-filled (fewer than two workgroups per CU: the
+    // 25 x 25 and 50 x 50 stages of the decoder, the 14 x 30 maps of the trunk -- 118 / 235 / 237 workgroups of the wide tile):
+    // twice the workgroups hide each other's latency (round 6: -0.15 ms per step, profiles/r06y_igemm_narrow_tile.txt)
+    const bool wide = p->Cout > 64 && steps > 2 && (int64_t)gx * ((p->Cout + 127) / 128) >= 512;
     const int bn = wide ? 128 : 64;
     size_t lds = igemm_lds(bn, steps, d.out_f32 != 0);
     if (mode == kModeBwdReduce) {                             // output tile + gradient tile + the reduction scratch

@@ -472,9 +472,12 @@ def conv(ops):
                                                  # layer (128 x 64 and 64 x 128 tiles), several ci / co tiles
                                                  '3x3_co96': (40, 96, 3, 1, 1, 1, False), '3x3_ci96': (96, 40, 3, 1, 1, 1, False),
                                                  '3x3_d2_co136': (72, 136, 3, 1, 2, 2, False),
-                                                 '3x3_wide': (16, 24, 3, 1, 1, 1, False), '3x3s2_wide': (8, 16, 3, 2, 1, 1, False)}.items():
+                                                 '3x3_wide': (16, 24, 3, 1, 1, 1, False), '3x3s2_wide': (8, 16, 3, 2, 1, 1, False),
+                                                 # enough pixels that the forward / data-gradient kernel takes its 128 x 128 tile (the
+                                                 # launcher keeps the 128 x 64 tile below 512 workgroups): two channel tiles, the second ragged
+                                                 '3x3_tile128': (24, 136, 3, 1, 1, 1, False)}.items():
         # '*_wide': rows longer than one 64-pixel weight-gradient step (the incremental pixel coordinates carry rarely)
-        shape = (1, cin, 5, 150) if name.endswith('_wide') else (2, cin, 9, 12)
+        shape = (1, cin, 5, 150) if name.endswith('_wide') else (1, cin, 128, 256) if name.endswith('_tile128') else (2, cin, 9, 12)
         x0 = torch.randn(*shape).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         w0 = (torch.randn(cout, cin, k, k) * 0.2).to(torch.bfloat16).float()       # bf16-representable weights
         b0 = torch.randn(cout) if bias else None
