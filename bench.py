@@ -453,6 +453,22 @@ _T0 = time.perf_counter()
 ENTRY = [os.path.abspath(__file__)]          # what the self-launcher starts per rank (tests substitute their wrapper)
 
 
+def _claim_stdout():
+    """The process's standard output belongs to the ONE JSON line.  Libraries write there too -- RCCL prints a version banner to
+    C stdout from its own thread when a communicator comes up, and with a file or a pipe behind fd 1 it landed in the MIDDLE of
+    the line (profiles/r06z: the N > 1 code path on one rank).  So: fd 1 is pointed at stderr for everybody else, and the
+    line goes to the saved descriptor in one write."""
+    sys.stdout.flush()
+    fd = os.dup(1)
+    os.dup2(2, 1)
+    return fd
+
+
+def _emit(fd, obj):
+    sys.stdout.flush()
+    os.write(fd, (json.dumps(obj) + '\n').encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -491,6 +507,7 @@ def main():
                '--master-addr', '127.0.0.1', '--master-port', str(port)] + ENTRY + sys.argv[1:]
         sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')))
 
+    out_fd = _claim_stdout()         # (a rank process from here on: not the launcher above, not the CPU-baseline worker)
     from stp3_amd.parallel import FlatAdam, GradientBuckets, init_distributed
     rank, world, local = init_distributed()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
@@ -668,7 +685,7 @@ def main():
             # the reference's Prediction.yml / Planning.yml steps, each measured by a child run of
             # this file (its own process: own model, own graph; a failure stays in its entry) -- the headline above is untouched
             line['other_workloads'] = {w: other_workload(w) for w in ('prediction', 'planning')}
-        print(json.dumps(line))
+        _emit(out_fd, line)
     if world > 1:
         dist.barrier()              # rank 0 may still be in its roofline micro-benchmark: leave together
     if world > 1 or args.force_exchange:

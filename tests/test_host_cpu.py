@@ -279,3 +279,27 @@ def test_temporal_model_with_spatial_bottlenecks_matches_the_reference():
     y = m(H.det_tensor(*INPUT))
     assert tuple(y.shape) == tuple(g['shape'])
     torch.testing.assert_close(H.sample(y).float(), torch.from_numpy(g['y']), rtol=2e-3, atol=2e-4)
+
+
+def test_bench_line_owns_standard_output():
+    import os
+    """bench.py: libraries print to C stdout from their own threads (RCCL's version banner when a communicator comes up landed in
+    the middle of the JSON line of a run on the N > 1 code path).  ``_claim_stdout`` points fd 1 at stderr for everybody else
+    and ``_emit`` writes the line to the saved descriptor in one write: whatever else is written to fd 1 -- through Python or
+    past it -- ends up on stderr, and standard output is exactly the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); import bench\n"
+            "fd = bench._claim_stdout()\n"
+            "os.write(1, b'RCCL version : banner past Python\\n')\n"
+            "print('a log line through Python')\n"
+            "bench._emit(fd, {'metric': 'm', 'value': 1.5, 'config': {'workload': 'x' * 5000}})\n"
+            "os.write(1, b'another banner at exit\\n')\n") % root
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, STP3_HOST_DRYRUN='1'))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and json.loads(lines[0])['value'] == 1.5 and len(json.loads(lines[0])['config']['workload']) == 5000
+    assert 'banner past Python' in out.stderr and 'a log line through Python' in out.stderr and 'another banner' in out.stderr
